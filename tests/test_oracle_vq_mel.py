@@ -1,0 +1,81 @@
+"""Oracle VQ / mel restatements against the fixtures generated from the imported reference."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import mel_ref, vq_ref
+
+K, D = 1024, 192
+
+
+def _sample(t, n):
+    f = t.detach().reshape(-1)
+    return f[::max(1, f.numel() // n)].numpy()
+
+
+def vq_case(g, name):
+    seed, N, s = g[name + ":seed_N_scale"]
+    rng = np.random.default_rng(int(seed))
+    x = torch.from_numpy(rng.standard_normal((int(N), D), dtype=np.float32) * np.float32(s))
+    e = torch.from_numpy(rng.standard_normal((K, D), dtype=np.float32))
+    return x, e, g[name + ":idx"]
+
+
+def test_vq_indices_bit_exact(golden_dir):
+    g = np.load(os.path.join(golden_dir, "vq.npz"))
+    for name in ("n1024_s1", "n1024_s01", "n1024_s10", "n4096_s1"):
+        x, e, idx = vq_case(g, name)
+        got = vq_ref.quantize(x, e).numpy()
+        assert np.array_equal(got, idx), name
+        assert int(vq_ref.near_tie_audit(x, e, torch.from_numpy(idx)).sum()) == 0, name
+
+
+def test_vq_ties_lowest_index(golden_dir):
+    g = np.load(os.path.join(golden_dir, "vq.npz"))
+    rng = np.random.default_rng(int(g["ties:seed"]))
+    e = rng.standard_normal((K, D), dtype=np.float32)
+    e[512:] = e[:512]
+    x = e[rng.integers(0, 512, 256)] + rng.standard_normal((256, D), dtype=np.float32) * np.float32(0.01)
+    got = vq_ref.quantize(torch.from_numpy(x), torch.from_numpy(e)).numpy()
+    assert np.array_equal(got, g["ties:idx"]) and got.max() < 512
+
+
+def test_vq_train_forward_and_ema(golden_dir):
+    g = np.load(os.path.join(golden_dir, "vq.npz"))
+    rng = np.random.default_rng(int(g["train:seed"]))
+    e = torch.from_numpy(rng.standard_normal((K, D), dtype=np.float32))
+    x = torch.from_numpy(rng.standard_normal((4, D, 128), dtype=np.float32)).requires_grad_(True)
+    buf = {"embed": e.clone(), "embed_avg": e * 4.0, "cluster_size": torch.full((K,), 4.0)}
+    q, codes, commit, ql = vq_ref.rvq_forward(x, buf, training=True)
+    (q.sum() * 0.5 + commit).backward()
+    assert np.array_equal(codes.numpy(), g["train:codes"])
+    np.testing.assert_allclose(q.detach().numpy(), g["train:quantized"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(commit.item(), g["train:commit"], rtol=1e-6)
+    np.testing.assert_allclose(x.grad.numpy(), g["train:dx"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(buf["cluster_size"].numpy(), g["train:cluster_size"], rtol=1e-6)
+    np.testing.assert_allclose(_sample(buf["embed_avg"], 8192), g["train:embed_avg_sample"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(_sample(buf["embed"], 8192), g["train:embed_sample"], rtol=1e-5, atol=1e-6)
+
+
+def test_mel_set_a(golden_dir):
+    g = np.load(os.path.join(golden_dir, "mel.npz"))
+    y = torch.from_numpy(g["A:wav"])
+    spec = mel_ref.spectrogram(y, 2048, 640, 2048)
+    np.testing.assert_allclose(spec.numpy(), g["A:spec"], rtol=1e-5, atol=1e-6)
+    mel = mel_ref.spec_to_mel(spec, 2048, 128, 32000, 0, None)
+    np.testing.assert_allclose(mel.numpy(), g["A:mel"], rtol=1e-5, atol=1e-5)
+    yseg = torch.from_numpy(g["A:wav"][:, :20480].copy()).requires_grad_(True)
+    m = mel_ref.mel_spectrogram(yseg, 2048, 128, 32000, 640, 2048, 0, None)
+    loss = torch.nn.functional.l1_loss(m, torch.from_numpy(g["A:seg_target"])) * 45
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g["A:seg_loss"], rtol=1e-6)
+    np.testing.assert_allclose(yseg.grad.numpy(), g["A:seg_grad"], rtol=1e-4, atol=1e-6)
+
+
+def test_mel_set_b(golden_dir):
+    g = np.load(os.path.join(golden_dir, "mel.npz"))
+    y = torch.from_numpy(g["B:wav"])
+    np.testing.assert_allclose(mel_ref.spectrogram(y, 1024, 256, 1024).numpy(), g["B:spec"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(mel_ref.mel_spectrogram(y, 1024, 80, 22050, 256, 1024, 0, 8000).numpy(), g["B:mel"],
+                               rtol=1e-5, atol=1e-5)

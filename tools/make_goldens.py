@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING THE REFERENCE (/root/reference).
+
+Runs only in the build container (the reference is not present on the GPU box); the fixtures it
+writes are data (inputs as seeds / small arrays, expected outputs) and are committed.  Re-run with
+    python tools/make_goldens.py            # all
+    python tools/make_goldens.py gpt vq mel # subsets
+Inputs and parameters that are too big to store are regenerated deterministically on both sides with
+`oracle.gpt_ref.det_fill` / numpy `default_rng(seed)` (seeds are stored in the fixture).
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+import ref_import  # noqa: E402
+
+librosa_mel_stub = ref_import.install()
+import torch  # noqa: E402
+
+from oracle import gpt_ref  # noqa: E402  (only for det_fill / synthetic inputs -- not for expected outputs)
+from oracle import mel_ref  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(8)
+
+TINY_GPT = {"model_dim": 64, "max_mel_tokens": 64, "max_text_tokens": 32, "heads": 2,
+            "use_mel_codes_as_input": True, "layers": 2, "number_text_tokens": 256,
+            "number_mel_codes": 1026, "start_mel_token": 1024, "stop_mel_token": 1025,
+            "start_text_token": 255, "train_solo_embeddings": False}
+
+
+def sample(t, n=4096):
+    f = t.detach().reshape(-1)
+    stride = max(1, f.numel() // n)
+    return f[::stride].numpy().copy()
+
+
+def ref_gpt(cfg):
+    import ttts.gpt.model as gm
+    m = gm.UnifiedVoice(**cfg)
+    sd = gpt_ref.det_state_dict(cfg)
+    missing = m.load_state_dict(sd, strict=True)
+    return m, sd
+
+
+def tiny_inputs():
+    g = torch.Generator().manual_seed(7)
+    text = torch.randint(1, 255, (2, 12), generator=g, dtype=torch.int64)
+    mel = torch.randint(0, 1024, (2, 24), generator=g, dtype=torch.int64)
+    text_lengths = torch.tensor([12, 9])
+    wav_lengths = torch.tensor([24 * 1024, 17 * 1024 + 5])  # second sample: padding rewritten to STOP
+    text[1, 9:] = 0
+    mel[1, 17:] = 0
+    return text, text_lengths, mel, wav_lengths
+
+
+def gen_gpt():
+    import ttts.gpt.model as gm
+    import ttts.vqvae.vq2 as vq2
+    # ---- G0 surface -------------------------------------------------------------------------------
+    cfg = json.load(open("/root/reference/ttts/gpt/config.json"))["gpt"]
+    m = gm.UnifiedVoice(**cfg)
+    surface = {"gpt": [[k, list(v.shape), str(v.dtype)] for k, v in m.state_dict().items()]}
+    vcfg = json.load(open("/root/reference/ttts/vqvae/config.json"))
+    g = vq2.SynthesizerTrn(vcfg["data"]["filter_length"] // 2 + 1,
+                           vcfg["train"]["segment_size"] // vcfg["data"]["hop_length"], **vcfg["vqvae"])
+    d = vq2.MultiPeriodDiscriminator()
+    surface["vqvae_g"] = [[k, list(v.shape), str(v.dtype)] for k, v in g.state_dict().items()]
+    surface["vqvae_d"] = [[k, list(v.shape), str(v.dtype)] for k, v in d.state_dict().items()]
+    surface["gpt_config"] = cfg
+    surface["vqvae_config"] = vcfg
+    json.dump(surface, open(os.path.join(OUT, "surface.json"), "w"))
+    print("G0 surface:", len(surface["gpt"]), len(surface["vqvae_g"]), len(surface["vqvae_d"]))
+
+    # ---- G1 tiny (eval: dropouts off), unequal lengths --------------------------------------------
+    m, sd = ref_gpt(TINY_GPT)
+    m.eval()
+    text, tl, mel, wl = tiny_inputs()
+    lt, lm, logits = m(text.clone(), tl, mel.clone(), wl)
+    loss = lt * 0.01 + lm
+    loss.backward()
+    grads = {k: p.grad for k, p in m.named_parameters()}
+    gn = float(torch.sqrt(sum((gr.double() ** 2).sum() for gr in grads.values())))
+    out = {"text": text.numpy(), "text_lengths": tl.numpy(), "mel": mel.numpy(), "wav_lengths": wl.numpy(),
+           "loss_text": lt.detach().numpy(), "loss_mel": lm.detach().numpy(),
+           "mel_logits": logits.detach().numpy(), "grad_norm": np.float64(gn),
+           "cfg_json": np.array(json.dumps(TINY_GPT))}
+    for k, gr in grads.items():
+        out["grad:" + k] = sample(gr)
+    np.savez_compressed(os.path.join(OUT, "gpt_tiny.npz"), **out)
+    print("G1 tiny: loss_text %.6f loss_mel %.6f gradnorm %.6f" % (float(lt), float(lm), gn))
+
+    # ---- G9 three optimizer steps on the tiny model (eval-mode forward; AdamW + LambdaLR + clip) ----
+    m, sd = ref_gpt(TINY_GPT)
+    m.eval()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, betas=(0.9, 0.96), weight_decay=0.01)
+
+    def warmup(step):  # ttts/gpt/train.py:36-40
+        return float(step / 500) if step < 500 else 1
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=warmup)
+    rec = {"cfg_json": np.array(json.dumps(TINY_GPT))}
+    norms, losses = [], []
+    for s in range(5):
+        lt, lm, _ = m(text.clone(), tl, mel.clone(), wl)
+        loss = lt * 0.01 + lm
+        loss.backward()
+        tn = torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        opt.step()
+        opt.zero_grad()
+        sched.step()
+        norms.append(float(tn))
+        losses.append(float(loss))
+    rec["grad_norms"] = np.array(norms, np.float64)
+    rec["losses"] = np.array(losses, np.float64)
+    for k, p in m.named_parameters():
+        rec["param:" + k] = sample(p, 1024)
+        rec["delta:" + k] = sample(p.detach().double() - sd[k].double(), 1024).astype(np.float64)
+        st = opt.state[p]
+        rec["m:" + k] = sample(st["exp_avg"], 1024)
+        rec["v:" + k] = sample(st["exp_avg_sq"], 1024)
+    np.savez_compressed(os.path.join(OUT, "gpt_step.npz"), **rec)
+    print("G9 step: norms", norms, "losses", losses)
+
+    # ---- G1b full config, B=1 and the BASELINE shape (128 text + 1024 audio tokens) -----------------
+    m, sd = ref_gpt(cfg)
+    m.eval()
+    text, tl, mel, wl = gpt_ref.synthetic_batch(B=1, seed=1234, cfg=cfg)
+    lt, lm, logits = m(text.clone(), tl, mel.clone(), wl)
+    (lt * 0.01 + lm).backward()
+    grads = {k: p.grad for k, p in m.named_parameters()}
+    gn = float(torch.sqrt(sum((gr.double() ** 2).sum() for gr in grads.values())))
+    out = {"seed": np.int64(1234), "loss_text": lt.detach().numpy(), "loss_mel": lm.detach().numpy(),
+           "logits_slice": logits.detach()[0, ::64, ::64].numpy(), "grad_norm": np.float64(gn)}
+    for k in ["mel_head.weight", "gpt.h.0.attn.c_attn.weight", "gpt.h.5.mlp.c_fc.weight", "text_embedding.weight",
+              "mel_pos_embedding.emb.weight", "gpt.h.3.ln_1.weight", "final_norm.bias"]:
+        out["grad:" + k] = sample(grads[k], 2048)
+    np.savez_compressed(os.path.join(OUT, "gpt_full_b1.npz"), **out)
+    print("G1b full: loss_text %.6f loss_mel %.6f gradnorm %.6f" % (float(lt), float(lm), gn))
+
+
+def gen_vq():
+    import ttts.vqvae.core_vq as cv
+    from ttts.vqvae.quantize import ResidualVectorQuantizer
+    rec = {}
+    K, D = 1024, 192
+    cb = cv.EuclideanCodebook(dim=D, codebook_size=K, kmeans_init=True, kmeans_iters=50, threshold_ema_dead_code=2)
+    cb.inited.fill_(1)
+    # (a) random data at three scales, N = 1024 and the BASELINE N = 4096
+    cases = [("n1024_s1", 1024, 1.0, 11), ("n1024_s01", 1024, 0.1, 12), ("n1024_s10", 1024, 10.0, 13),
+             ("n4096_s1", 4096, 1.0, 14)]
+    for name, N, s, seed in cases:
+        rng = np.random.default_rng(seed)
+        x = torch.from_numpy(rng.standard_normal((N, D), dtype=np.float32) * np.float32(s))
+        e = torch.from_numpy(rng.standard_normal((K, D), dtype=np.float32))
+        cb.embed.copy_(e)
+        idx = cb.quantize(x)
+        rec[name + ":seed_N_scale"] = np.array([seed, N, s], np.float64)
+        rec[name + ":idx"] = idx.numpy().astype(np.int64)
+    # (b) exact ties: duplicated codebook rows -> lowest index wins (torch.max on ties)
+    rng = np.random.default_rng(21)
+    e = rng.standard_normal((K, D), dtype=np.float32)
+    e[512:] = e[:512]  # every code appears twice
+    x = e[rng.integers(0, 512, 256)] + rng.standard_normal((256, D), dtype=np.float32) * np.float32(0.01)
+    cb.embed.copy_(torch.from_numpy(e))
+    rec["ties:idx"] = cb.quantize(torch.from_numpy(x)).numpy().astype(np.int64)
+    rec["ties:seed"] = np.int64(21)
+    assert int(rec["ties:idx"].max()) < 512
+    # (c) train-mode VectorQuantization.forward through the RVQ wrapper (n_q=1), buffers pre-initialised
+    rvq = ResidualVectorQuantizer(dimension=D, n_q=1, bins=K)
+    rvq.train()
+    code = rvq.vq.layers[0]._codebook
+    rng = np.random.default_rng(31)
+    e = rng.standard_normal((K, D), dtype=np.float32)
+    x = rng.standard_normal((4, D, 128), dtype=np.float32)
+    code.inited.fill_(1)
+    code.embed.copy_(torch.from_numpy(e))
+    code.embed_avg.copy_(torch.from_numpy(e) * 4.0)
+    code.cluster_size.fill_(4.0)
+    xt = torch.from_numpy(x).requires_grad_(True)
+    q, codes, commit, qlist = rvq(xt, layers=[0])
+    (q.sum() * 0.5 + commit).backward()
+    rec["train:seed"] = np.int64(31)
+    rec["train:quantized"] = q.detach().numpy()
+    rec["train:codes"] = codes.numpy().astype(np.int64)
+    rec["train:commit"] = commit.detach().numpy()
+    rec["train:dx"] = xt.grad.numpy()
+    rec["train:cluster_size"] = code.cluster_size.numpy().copy()
+    rec["train:embed_avg_sample"] = sample(code.embed_avg, 8192)
+    rec["train:embed_sample"] = sample(code.embed, 8192)
+    np.savez_compressed(os.path.join(OUT, "vq.npz"), **rec)
+    print("G3 vq:", {k: v.shape for k, v in rec.items() if k.endswith("idx")}, "commit", float(commit))
+
+
+def gen_mel():
+    import ttts.utils.data_utils as du
+    rec = {}
+    # mel-basis provenance check: our Slaney restatement vs the transformers implementation behind the stub
+    for (sr, n_fft, n_mels, fmin, fmax) in [(32000, 2048, 128, 0, None), (22050, 1024, 80, 0, 8000)]:
+        a = librosa_mel_stub(sr=sr, n_fft=n_fft, n_mels=n_mels, fmin=fmin, fmax=fmax)
+        b = mel_ref.slaney_mel_basis(sr, n_fft, n_mels, fmin, fmax)
+        err = np.abs(a - b).max()
+        print("mel basis %d/%d/%d max|diff| = %.3e (max %.3e)" % (sr, n_fft, n_mels, err, np.abs(a).max()))
+        assert err < 1e-6 * max(1.0, np.abs(a).max()) + 1e-7
+    rng = np.random.default_rng(41)
+    # set A: the vqvae config (32 kHz, 2048/640/2048, 128 mels, fmin 0, fmax null)  vqvae/config.json:53-64
+    t = np.arange(32000) / 32000.0
+    wav = np.stack([0.4 * np.sin(2 * np.pi * 220 * t) + 0.2 * np.sin(2 * np.pi * 3300 * t + 1.0),
+                    0.3 * np.sin(2 * np.pi * 700 * t * (1 + 0.2 * t))]).astype(np.float32)
+    wav = np.clip(wav + 0.05 * rng.standard_normal(wav.shape, dtype=np.float32), -1, 1)
+    y = torch.from_numpy(wav)
+    spec = du.spectrogram_torch(y, 2048, 640, 2048, center=False)
+    mel = du.spec_to_mel_torch(spec, 2048, 128, 32000, 0, None)
+    rec["A:wav"] = wav
+    rec["A:spec"] = spec.numpy()
+    rec["A:mel"] = mel.numpy()
+    # differentiable path on a segment (train.py:362-371,394): d/dy  mean|mel(y) - target| * 45
+    yseg = torch.from_numpy(wav[:, :20480].copy()).requires_grad_(True)
+    target = torch.from_numpy(rng.standard_normal((2, 128, 32), dtype=np.float32))
+    yh_mel = du.mel_spectrogram_torch(yseg, 2048, 128, 32000, 640, 2048, 0, None)
+    loss = torch.nn.functional.l1_loss(yh_mel, target) * 45
+    loss.backward()
+    rec["A:seg_target"] = target.numpy()
+    rec["A:seg_mel"] = yh_mel.detach().numpy()
+    rec["A:seg_loss"] = loss.detach().numpy()
+    rec["A:seg_grad"] = yseg.grad.numpy()
+    # set B: 22.05 kHz, 1024/256/1024, 80 mels, fmax 8000 (utils/utils.py:388-389 style front-end)
+    mel_basis_cache = du.mel_basis
+    mel_basis_cache.clear()
+    wavb = np.clip(0.5 * rng.standard_normal((2, 22050), dtype=np.float32), -1, 1)
+    yb = torch.from_numpy(wavb)
+    specb = du.spectrogram_torch(yb, 1024, 256, 1024, center=False)
+    melb = du.mel_spectrogram_torch(yb, 1024, 80, 22050, 256, 1024, 0, 8000)
+    rec["B:wav"] = wavb
+    rec["B:spec"] = specb.numpy()
+    rec["B:mel"] = melb.numpy()
+    np.savez_compressed(os.path.join(OUT, "mel.npz"), **rec)
+    print("G4 mel:", spec.shape, mel.shape, specb.shape, melb.shape, "seg loss", float(loss))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["gpt", "vq", "mel"]
+    with torch.no_grad() if False else torch.enable_grad():
+        if "gpt" in which:
+            gen_gpt()
+        if "vq" in which:
+            gen_vq()
+        if "mel" in which:
+            gen_mel()
+    print("fixtures:", {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT))})
