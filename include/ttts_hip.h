@@ -1,0 +1,219 @@
+/*
+ * ttts_hip.h -- C ABI of libttts_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * training hot path of adelacvg/ttts (GPT train step, VQ codebook, mel/STFT).
+ *
+ * The reference (/root/reference) is 100 % Python and has NO plugin / operator / FFI layer
+ * (SURVEY.md F1, section 8b2): each entry point below replaces a *PyTorch op sequence* of the
+ * reference, cited per function as `file:line` relative to /root/reference (or to the installed
+ * `transformers` GPT-2 implementation the reference instantiates, ttts/gpt/model.py:245-265).
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions (all entry points):
+ *  - plain C: raw DEVICE pointers (tensor.data_ptr()), explicit sizes/strides in ELEMENTS, scalars by value;
+ *    no torch / C++ types cross the boundary.
+ *  - the CALLER owns all memory (inputs, outputs, workspaces; sizes from the *_workspace_bytes helpers);
+ *    the library never allocates or frees device memory and keeps no mutable global state besides a
+ *    thread-local error string and the option table of ttts_set_option().
+ *  - launches are asynchronous on `stream` (a hipStream_t passed as void*; NULL = the default stream);
+ *    no internal synchronisation; every kernel is hipGraph-capturable (no host reads of device data).
+ *  - return value: TTTS_OK (0) or a negative error code; ttts_last_error() gives the message.
+ *  - "bf16" = bfloat16 stored as uint16 bit patterns; "f32" = IEEE float; indices are int64 unless noted.
+ *  - gradient outputs documented as "+=" ACCUMULATE into their buffer (zero it at the start of a step).
+ */
+#ifndef TTTS_HIP_H
+#define TTTS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TTTS_OK 0
+#define TTTS_EINVAL (-1)       /* bad shape / alignment / null pointer */
+#define TTTS_EHIP (-2)         /* a HIP runtime call or kernel launch failed */
+#define TTTS_EUNSUPPORTED (-3) /* valid request this build has no kernel for */
+
+#define TTTS_ABI_VERSION 1
+
+/* ---- library ------------------------------------------------------------------------------------ */
+int ttts_abi_version(void);
+const char* ttts_last_error(void);
+/* Device query: writes {gfx arch number (950), CU count, wavefront size, LDS bytes/CU}. */
+int ttts_device_info(int32_t out[4]);
+
+/* ---- GEMM (bf16 operands, fp32 MFMA accumulation) ------------------------------------------------
+ * Replaces: HF Conv1D addmm (transformers/pytorch_utils.py Conv1D.forward) at
+ * modeling_gpt2.py:103-107,229-243, nn.Linear heads at ttts/gpt/model.py:348-349,432-438, and their
+ * autograd backward (dX = dY W^T, dW = X^T dY, db = colsum dY) under autocast(bf16).
+ */
+enum {
+  TTTS_EPI_STORE_BF16 = 0,      /* C = bf16(acc + bias)                                              */
+  TTTS_EPI_GELU_BF16 = 1,       /* aux = bf16(acc + bias) (pre-activation), C = bf16(gelu_new(aux)) */
+  TTTS_EPI_RESID_ADD_F32 = 2,   /* resid[m][n] += float(bf16(acc + bias))   (fp32 residual stream)  */
+  TTTS_EPI_DGELU_BF16 = 3,      /* C = bf16(acc * gelu_new'(aux[m][n]))      (aux = saved pre-act)   */
+  TTTS_EPI_STORE_F32 = 4        /* Cf = acc + bias (fp32 output)                                     */
+};
+/* C[M,N] = epilogue(A[M,K] . B[N,K]^T): both operands K-contiguous ("NT").  lda/ldb/ldc in elements,
+ * K % 8 == 0, lda % 8 == 0, ldb % 8 == 0, ldc % 4 == 0, 16-byte aligned bases.
+ * bias: f32[N] or NULL.  C: bf16 (or f32 for STORE_F32 / RESID_ADD_F32).  aux: bf16 [M, ldc] or NULL. */
+int ttts_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                      const float* bias, void* aux, int32_t M, int32_t N, int32_t K, int32_t epilogue,
+                      void* stream);
+/* Same, plus: resid_in (RESID_ADD_F32 only): C = resid_in + dropout(bf16(acc + bias)) out of place (NULL: C += ...);
+ * dropout_p/seed: residual dropout (GPT-2 resid_pdrop, modeling_gpt2.py:223,241) on element index m*N + n. */
+int ttts_gemm_nt_bf16_ex(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                         const float* bias, void* aux, int32_t M, int32_t N, int32_t K, int32_t epilogue,
+                         const float* resid_in, float dropout_p, uint64_t seed, void* stream);
+/* C[Mo,No] += At[Kr,Mo]^T . Bt[Kr,No]  (fp32 atomic accumulation, split over Kr): the weight-gradient
+ * GEMM; both operands are row-major with the REDUCTION dimension as rows ("TN").
+ * Mo % 8 == 0 or ldat-padded, ldat % 8 == 0, ldbt % 8 == 0. */
+int ttts_gemm_tn_bf16_accum_f32(const void* At, int64_t ldat, const void* Bt, int64_t ldbt, float* C,
+                                int64_t ldc, int32_t Mo, int32_t No, int32_t Kr, void* stream);
+/* out[n] += sum_m X[m][n]   (bias gradients; X bf16 [M, ldx]) */
+int ttts_colsum_bf16_accum_f32(const void* X, int64_t ldx, float* out, int32_t M, int32_t N, void* stream);
+/* Batched fp32 -> bf16 cast (+ optional transposed copy) of parameter matrices.
+ * desc: DEVICE array of n_desc ttts_cast_desc; total_tiles = sum over descriptors of their 32x32 tiles
+ * (ttts_cast_desc_tiles()).  Produces the bf16 "shadow" weights both GEMM operand layouts need. */
+typedef struct {
+  const float* src; /* [rows, cols] fp32 row-major                 */
+  void* dst;        /* [rows, cols] bf16 or NULL                    */
+  void* dst_t;      /* [cols, rows] bf16 (transposed copy) or NULL  */
+  int32_t rows, cols;
+  int32_t tile_begin; /* exclusive prefix sum of tiles of earlier descriptors */
+  int32_t ldt;        /* leading dimension of dst_t in elements (0 = rows) */
+} ttts_cast_desc;
+int32_t ttts_cast_desc_tiles(int32_t rows, int32_t cols);
+int ttts_cast_bf16_batched(const ttts_cast_desc* desc, int32_t n_desc, int32_t total_tiles, void* stream);
+
+/* ---- causal self-attention (flash-style, bf16 I/O, fp32 softmax) -----------------------------------
+ * Replaces: GPT2Attention core, modeling_gpt2.py:53-72 (eager) / sdpa, reached from ttts/gpt/model.py:422.
+ * q/k/v/o element address = base + b*stride_b + s*stride_s + h*head_dim + d  (so a packed [B,S,3*H*dh]
+ * c_attn output is consumed in place: q=base, k=base+H*dh, v=base+2*H*dh, stride_s = 3*H*dh).
+ * lse: f32 [B,H,S] = log(sum exp(scaled scores)).  head_dim in {32, 64, 128}.  scale = dh^-0.5.
+ * dropout_p in [0,1): keep-mask from a counter hash of (seed, b, h, q, k), quantised to 1/65536;
+ * the same (seed) must be given to the backward. */
+int ttts_attn_causal_fwd_bf16(const void* q, const void* k, const void* v, void* o, float* lse,
+                              int32_t B, int32_t H, int32_t S, int32_t head_dim,
+                              int64_t qkv_stride_b, int64_t qkv_stride_s, int64_t o_stride_b, int64_t o_stride_s,
+                              float scale, float dropout_p, uint64_t seed, void* stream);
+/* delta: f32 workspace [B,H,S] (ttts_attn_bwd_workspace_bytes).  dq/dk/dv use the qkv strides (a packed
+ * [B,S,3*H*dh] gradient buffer is written in place); do/o use the o strides. */
+int64_t ttts_attn_bwd_workspace_bytes(int32_t B, int32_t H, int32_t S);
+int ttts_attn_causal_bwd_bf16(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                              const float* lse, void* dq, void* dk, void* dv, void* workspace,
+                              int32_t B, int32_t H, int32_t S, int32_t head_dim,
+                              int64_t qkv_stride_b, int64_t qkv_stride_s, int64_t o_stride_b, int64_t o_stride_s,
+                              float scale, float dropout_p, uint64_t seed, void* stream);
+/* Debug/test aid: materialise the attention-dropout keep mask (uint8 [B,H,S,S], 1 = keep). */
+int ttts_attn_dropout_mask_u8(uint8_t* mask, int32_t B, int32_t H, int32_t S, float dropout_p, uint64_t seed,
+                              void* stream);
+
+/* ---- LayerNorm (fp32 statistics) -----------------------------------------------------------------
+ * Replaces: nn.LayerNorm in GPT2Block (modeling_gpt2.py:254,256), ln_f, final_norm (ttts/gpt/model.py:347,427).
+ * x f32 [M,D]; y bf16 or f32 [M,D] (y_is_bf16); mean/rstd f32 [M] saved for backward.
+ * split_S/split_T > 0: output row of input row (b*split_S + t) is the "text|mel split layout"
+ *   t < split_T ? b*split_T + t : B*split_T + b*(split_S-split_T) + (t-split_T)      (B = M / split_S)
+ * which makes the rows each head GEMM consumes contiguous (ttts/gpt/model.py:432-437 slices). */
+int ttts_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int32_t y_is_bf16,
+                       float* mean, float* rstd, int32_t M, int32_t D, float eps,
+                       int32_t split_S, int32_t split_T, void* stream);
+/* dx = [dx_in +] LN'(dy); dgamma += sum dy*xhat; dbeta += sum dy.   dy bf16 or f32 (same row remap as fwd).
+ * dx_in may be NULL (then dx = LN'(dy)) or alias dx.  dx_bf16: optional bf16 copy of dx (or NULL).
+ * workspace: ttts_layernorm_bwd_workspace_bytes(M, D). */
+int64_t ttts_layernorm_bwd_workspace_bytes(int32_t M, int32_t D);
+int ttts_layernorm_bwd(const void* dy, int32_t dy_is_bf16, const float* x, const float* gamma,
+                       const float* mean, const float* rstd, const float* dx_in, float* dx, void* dx_bf16,
+                       float* dgamma, float* dbeta, void* workspace, int32_t M, int32_t D,
+                       int32_t split_S, int32_t split_T, void* stream);
+/* Same, with the bf16 copy dx_bf16 = bf16(dropout_mask(seed, element row*D + d) * dx / (1 - p)): the gradient that
+ * enters the residual-dropout site consuming it (the mask ttts_gemm_nt_bf16_ex applied in the forward). */
+int ttts_layernorm_bwd_ex(const void* dy, int32_t dy_is_bf16, const float* x, const float* gamma,
+                          const float* mean, const float* rstd, const float* dx_in, float* dx, void* dx_bf16,
+                          float* dgamma, float* dbeta, void* workspace, int32_t M, int32_t D,
+                          int32_t split_S, int32_t split_T, float bf16_dropout_p, uint64_t bf16_dropout_seed,
+                          void* stream);
+
+/* ---- embeddings ----------------------------------------------------------------------------------
+ * Replaces: ttts/gpt/model.py:488,494-495,418 -- token + learned-position embedding sums of the text
+ * and mel streams concatenated to x f32 [B, Tt+Tm, D].  dropout_p: GPT2Model.drop (embd_pdrop). */
+int ttts_gpt_embed_fwd(const int64_t* text_inp, const int64_t* mel_inp, const float* text_emb,
+                       const float* text_pos, const float* mel_emb, const float* mel_pos, float* x,
+                       int32_t B, int32_t Tt, int32_t Tm, int32_t D, int32_t n_text, int32_t n_mel,
+                       float dropout_p, uint64_t seed, void* stream);
+int ttts_gpt_embed_bwd(const int64_t* text_inp, const int64_t* mel_inp, const float* dx, float* d_text_emb,
+                       float* d_text_pos, float* d_mel_emb, float* d_mel_pos,
+                       int32_t B, int32_t Tt, int32_t Tm, int32_t D, float dropout_p, uint64_t seed, void* stream);
+
+/* ---- cross-entropy -------------------------------------------------------------------------------
+ * Replaces: F.cross_entropy(logits.permute, targets) mean reduction, ttts/gpt/model.py:508-509.
+ * logits bf16 [R, ldl] (C valid classes per row), targets int64 [R].
+ * fwd: row_loss f32 [R] = lse - logit[target]; row_lse f32 [R]; loss_mean (f32 scalar) = mean(row_loss).
+ * bwd: dlogits bf16 [R, ldl] = (softmax - onehot) * grad_scale * (*grad_scale_dev if non-NULL) / R. */
+int ttts_ce_fwd_bf16(const void* logits, int64_t ldl, const int64_t* targets, float* row_loss, float* row_lse,
+                     float* loss_mean, int32_t R, int32_t C, void* stream);
+int ttts_ce_bwd_bf16(const void* logits, int64_t ldl, const int64_t* targets, const float* row_lse,
+                     void* dlogits, float grad_scale, const float* grad_scale_dev, int32_t R, int32_t C,
+                     void* stream);
+
+/* ---- optimizer -----------------------------------------------------------------------------------
+ * Replaces: get_grad_norm (ttts/gpt/train.py:22-31, 84 .item() syncs), accelerator.clip_grad_norm_(1.0)
+ * (:115), torch.optim.AdamW (:56,118), LambdaLR(warmup) (:36-40,57,120) -- on ONE flat fp32 arena.
+ *
+ * state: f32[8] device buffer {step, lr, bias_corr1, bias_corr2_sqrt, grad_norm, clip_coef, -, -}.
+ * ttts_adamw_schedule: step += 1 (step counts optimizer steps taken, starts at 0), lr = base_lr *
+ *   (warmup_steps > 0 ? min(1, (step-1)/warmup_steps) : 1)  [LambdaLR value used by THIS step],
+ *   bias corrections in double precision.  Device-side so the whole step stays graph-capturable. */
+int ttts_adamw_schedule(float* state, float base_lr, float beta1, float beta2, int32_t warmup_steps, void* stream);
+/* grad_norm = ||g||_2, clip_coef = min(1, max_norm / (norm + 1e-6)) (max_norm <= 0: coef = 1) -> state[4..5].
+ * workspace: ttts_gradnorm_workspace_bytes(n). */
+int64_t ttts_gradnorm_workspace_bytes(int64_t n);
+int ttts_gradnorm_f32(const float* g, int64_t n, float max_norm, float* state, void* workspace, void* stream);
+/* AdamW on n elements (n % 4 == 0, 16-byte aligned), torch single-tensor formula order; the gradient is
+ * scaled by state[5] (clip_coef); zero_grad != 0 writes g = 0 after use; shadow: optional bf16 [n] copy of
+ * the updated parameters (same layout). */
+int ttts_adamw_f32(float* p, float* g, float* m, float* v, void* shadow_bf16, int64_t n, const float* state,
+                   float beta1, float beta2, float eps, float weight_decay, int32_t zero_grad, void* stream);
+
+/* ---- VQ codebook ---------------------------------------------------------------------------------
+ * Replaces: EuclideanCodebook.quantize / dequantize (ttts/vqvae/core_vq.py:174-189), the straight-through
+ * + commitment MSE of VectorQuantization.forward (:303-322) and the EMA update (:212-228).
+ * x f32 [N,D] row-major, codebook f32 [K,D]; idx int64 [N]; xq f32 [N,D] = codebook[idx].
+ * Distances are evaluated in IEEE fp32 exactly as the reference's expression
+ *   -((|x|^2 - 2*dot) + |e|^2), dot = k-ordered fmaf chain; first maximum wins (ties -> lowest index).
+ * workspace: ttts_vq_workspace_bytes(N, K) (code norms + per-row scratch). */
+int64_t ttts_vq_workspace_bytes(int32_t N, int32_t K);
+int ttts_vq_nearest_f32(const float* x, const float* codebook, int64_t* idx, float* xq, float* best_dist,
+                        void* workspace, int32_t N, int32_t K, int32_t D, void* stream);
+/* loss (f32 scalar) = mean((xq - x)^2) computed as mse(x + (xq - x), x) like the reference (:311-317);
+ * dx f32 [N,D] += grad_scale * 2 (x - q)/(N*D)  (gradient of the commitment term w.r.t. x). */
+int ttts_vq_commit_f32(const float* x, const float* xq, float* loss, float* dx, float grad_scale,
+                       int32_t N, int32_t D, void* workspace, void* stream);
+/* EMA update: cluster_size, embed_avg, embed updated in place from (x, idx) -- scatter-add, no one-hot.
+ * workspace: ttts_vq_ema_workspace_bytes(K, D). */
+int64_t ttts_vq_ema_workspace_bytes(int32_t K, int32_t D);
+int ttts_vq_ema_update_f32(const float* x, const int64_t* idx, float* cluster_size, float* embed_avg,
+                           float* embed, void* workspace, int32_t N, int32_t K, int32_t D, float decay,
+                           float epsilon, void* stream);
+
+/* ---- mel / STFT front-end --------------------------------------------------------------------------
+ * Replaces: spectrogram_torch (ttts/utils/data_utils.py:52-87): reflect-pad (n_fft-hop)/2, hann window,
+ * onesided STFT (center=False), sqrt(re^2 + im^2 + 1e-6).   wav f32 [B,T]; spec f32 [B, n_fft/2+1, frames],
+ * frames = (T + 2*pad - n_fft)/hop + 1.  n_fft = win_size in {1024, 2048}.
+ * twiddle: f32 [n_fft] device table (cos, sin interleaved pairs for k < n_fft/2) from ttts_stft_twiddle_host. */
+int ttts_stft_twiddle_host(float* host_out, int32_t n_fft);
+int ttts_stft_mag_fwd_f32(const float* wav, const float* window, const float* twiddle, float* spec,
+                          int32_t B, int32_t T, int32_t n_fft, int32_t hop, void* stream);
+/* spec_to_mel_torch (:90-103): mel f32 [B, n_mels, frames] = log(clamp(basis[n_mels, n_bins] @ spec, 1e-5)). */
+int ttts_mel_log_fwd_f32(const float* spec, const float* basis, float* mel, int32_t B, int32_t n_bins,
+                         int32_t n_mels, int32_t frames, void* stream);
+
+/* ---- probes (tests only): dump hardware fragment layouts the kernels rely on ------------------------ */
+/* out_c f32 [64 lanes][16 regs]: raw accumulators of one 32x32x16 bf16 MFMA with D[i][j] = (i+1) + 64*(j+1);
+ * out_tr i32 [64 lanes][8]: the uint16 LDS element indices two ds_read_b64_tr_b16 return for the kernels' address map. */
+int ttts_probe_mfma_layout(float* out_c, int32_t* out_tr, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TTTS_HIP_H */

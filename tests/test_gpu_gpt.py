@@ -1,0 +1,189 @@
+"""-m gpu: the assembled GPT train step (ttts_amd.gpt: UnifiedVoice / GptEngine / Trainer) against the oracle and
+the reference-generated fixtures.  Stated tolerance for the bf16 path (north_star "stated fp tolerance"):
+  losses within 1e-2 relative of the fp32 reference; every parameter-gradient tensor within 5e-2 relative L2
+  (cosine > 0.998) of the fp32 reference and within 2e-2 of the oracle run with the same bf16 rounding points."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def cosine(a, b):
+    return float(torch.nn.functional.cosine_similarity(a.double().cpu().flatten(), b.double().cpu().flatten(), dim=0))
+
+
+def _sample(t, n=4096):
+    f = t.detach().reshape(-1)
+    return f[::max(1, f.numel() // n)].float().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def gpt():
+    assert torch.cuda.is_available()
+    import ttts_amd.gpt as g
+    return g
+
+
+def _oracle_grads(cfg, sd, batch, bf16, device):
+    from oracle import gpt_ref
+    leaves = {k: v.to(device).clone().requires_grad_(True) for k, v in sd.items()}
+    b = [t.to(device) for t in batch]
+    lt, lm, logits = gpt_ref.unified_voice_forward(leaves, cfg, *b, bf16=bf16)
+    (lt * 0.01 + lm).backward()
+    return lt.item(), lm.item(), logits.detach(), {k: v.grad for k, v in leaves.items()}
+
+
+def test_tiny_matches_reference_fixture(gpt, golden_dir):
+    from oracle import gpt_ref
+    g = np.load(os.path.join(golden_dir, "gpt_tiny.npz"))
+    cfg = json.loads(str(g["cfg_json"]))
+    sd = gpt_ref.det_state_dict(cfg)
+    model = gpt.UnifiedVoice(**cfg, device="cuda:0", dropout_p=0.0)
+    model.load_state_dict(sd)
+    assert list(model.state_dict().keys()) == [k for k, _ in gpt_ref.state_dict_spec(cfg)]
+    batch = [torch.from_numpy(g[k]) for k in ("text", "text_lengths", "mel", "wav_lengths")]
+    mel_before = batch[2].clone()
+    lt, lm, logits = model(batch[0].cuda(), batch[1], batch[2].cuda(), batch[3])
+    assert torch.equal(batch[2], mel_before)
+    (lt * 0.01 + lm).backward()
+    np.testing.assert_allclose(lt.item(), g["loss_text"], rtol=1e-2)
+    np.testing.assert_allclose(lm.item(), g["loss_mel"], rtol=1e-2)
+    assert logits.shape == tuple(g["mel_logits"].shape)
+    assert rel_err(logits.float(), torch.from_numpy(g["mel_logits"])) < 3e-2
+    eng = model.engine
+    # vs the fp32 reference fixture (sampled gradients) and vs the oracle with bf16 rounding points (full tensors)
+    _, _, _, og = _oracle_grads(cfg, sd, batch, True, "cpu")
+    worst = {}
+    for k, p in model.named_parameters():
+        assert p.grad is not None and p.grad.data_ptr() == eng.view(eng.grads, k).data_ptr()
+        ref = torch.from_numpy(g["grad:" + k])
+        got = torch.from_numpy(_sample(p.grad))
+        if float(ref.norm()) > 1e-6:
+            assert rel_err(got, ref) < 5e-2 and cosine(got, ref) > 0.998, (k, rel_err(got, ref))
+        e = rel_err(p.grad, og[k]) if float(og[k].norm()) > 1e-6 else 0.0
+        worst[k] = e
+        assert e < 2e-2, (k, e)
+    os.makedirs(os.path.join(ROOT, "gpurun_out", "diag"), exist_ok=True)
+    json.dump(worst, open(os.path.join(ROOT, "gpurun_out", "diag", "tiny_grad_err.json"), "w"), indent=1)
+
+
+def test_full_config_b1_fixture(gpt, golden_dir):
+    from oracle import gpt_ref
+    g = np.load(os.path.join(golden_dir, "gpt_full_b1.npz"))
+    sd = gpt_ref.det_state_dict(None)
+    model = gpt.UnifiedVoice(**gpt_ref.GPT_CONFIG, device="cuda:0", dropout_p=0.0)
+    model.load_state_dict(sd)
+    batch = gpt_ref.synthetic_batch(B=1, seed=int(g["seed"]))
+    lt, lm, logits = model(batch[0].cuda(), batch[1], batch[2].cuda(), batch[3])
+    (lt * 0.01 + lm).backward()
+    np.testing.assert_allclose(lt.item(), g["loss_text"], rtol=1e-2)
+    np.testing.assert_allclose(lm.item(), g["loss_mel"], rtol=1e-2)
+    assert rel_err(logits[0, ::64, ::64].float(), torch.from_numpy(g["logits_slice"])) < 3e-2
+    eng = model.engine
+    gn = float(eng.grads.double().norm())
+    np.testing.assert_allclose(gn, g["grad_norm"], rtol=3e-2)
+    for key in g.files:
+        if key.startswith("grad:"):
+            ref = torch.from_numpy(g[key])
+            got = torch.from_numpy(_sample(eng.view(eng.grads, key[5:]), 2048))
+            assert rel_err(got, ref) < 6e-2 and cosine(got, ref) > 0.998, (key, rel_err(got, ref))
+
+
+def test_train_steps_match_bf16_oracle_full_shape(gpt):
+    """BASELINE config #2 (B=8, 128 text + 1024 audio tokens): three optimizer steps vs the oracle run on the GPU
+    with bf16 rounding points; also the hipGraph replay must reproduce the eager launch sequence exactly."""
+    from oracle import gpt_ref
+    sd = gpt_ref.det_state_dict(None)
+    dev = torch.device("cuda:0")
+    batch = gpt_ref.synthetic_batch(B=8, seed=1234)
+    ref_sd = {k: v.to(dev).clone() for k, v in sd.items()}
+    opt = gpt_ref.new_opt_state(ref_sd)
+    ref_losses = []
+    # warm-up makes lr = 0 at step 0: run with lr scaled so the parameters really move
+    for s in range(3):
+        out = gpt_ref.gpt_train_step(ref_sd, opt, [t.to(dev) for t in batch], None, {"lr": 1e-2}, bf16=True)
+        ref_losses.append((out["loss_text"], out["loss_mel"], out["grad_norm"]))
+    results = {}
+    for capture in (False, True):
+        eng = gpt.GptEngine(gpt_ref.GPT_CONFIG, dev, dropout_p=0.0)
+        eng.load_state_dict(sd)
+        toks = gpt.prepare_tokens(eng.c, *batch)
+        got = []
+        for s in range(3):
+            eng.train_step(toks, 0.01, 1.0, capture=capture, lr=1e-2)
+            lt, lm = eng.losses()
+            got.append((lt, lm, float(eng.opt_state[4])))
+        results[capture] = (got, eng.params.clone())
+        for (lt, lm, gn), (rt, rm, rn) in zip(got, ref_losses):
+            np.testing.assert_allclose(lt, rt, rtol=5e-3)
+            np.testing.assert_allclose(lm, rm, rtol=5e-3)
+            np.testing.assert_allclose(gn, rn, rtol=3e-2)
+        delta = eng.view(eng.params, "gpt.h.3.mlp.c_fc.weight").cpu() - sd["gpt.h.3.mlp.c_fc.weight"]
+        rdelta = ref_sd["gpt.h.3.mlp.c_fc.weight"].cpu() - sd["gpt.h.3.mlp.c_fc.weight"]
+        assert cosine(delta, rdelta) > 0.98
+    # graph replay == eager, up to the fp32 atomics' summation order in the weight-gradient GEMMs
+    assert rel_err(results[True][1], results[False][1]) < 1e-5
+    os.makedirs(os.path.join(ROOT, "gpurun_out", "diag"), exist_ok=True)
+    json.dump({"ref": ref_losses, "eager": results[False][0], "graph": results[True][0]},
+              open(os.path.join(ROOT, "gpurun_out", "diag", "train_steps.json"), "w"), indent=1)
+
+
+def test_ragged_batch_and_dropout_training(gpt):
+    """Unequal lengths (clip + STOP padding) and dropout-on training: finite, and the loss goes down."""
+    from oracle import gpt_ref
+    cfg = dict(gpt_ref.GPT_CONFIG)
+    cfg["layers"] = 2
+    model = gpt.UnifiedVoice(**cfg, device="cuda:0", dropout_p=0.1, seed=5)
+    opt = gpt.FusedAdamW(model, lr=3e-3, warmup_steps=0)
+    g = torch.Generator().manual_seed(0)
+    text = torch.randint(1, 255, (4, 40), generator=g); mel = torch.randint(0, 1024, (4, 300), generator=g)
+    tl = torch.tensor([40, 33, 12, 25]); wl = torch.tensor([300, 257, 100, 299]) * 1024 + 7
+    losses = []
+    for _ in range(12):
+        lt, lm, _ = model(text.cuda(), tl, mel.cuda(), wl)
+        (lt * 0.01 + lm).backward()
+        opt.step()
+        losses.append(lm.item())
+    assert all(np.isfinite(losses)), losses
+    assert losses[-1] < losses[0] - 0.5, losses
+    # eval-mode forward equals the oracle on the same (trained) weights
+    model.eval()
+    with torch.no_grad():
+        lt, lm, _ = model(text.cuda(), tl, mel.cuda(), wl)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    rt, rm, _ = gpt_ref.unified_voice_forward(sd, cfg, text, tl, mel, wl)
+    np.testing.assert_allclose(lm.item(), rm.item(), rtol=1e-2)
+    np.testing.assert_allclose(lt.item(), rt.item(), rtol=1e-2)
+
+
+def test_trainer_entry_point(gpt, tmp_path):
+    """ttts_amd.gpt.train.Trainer: config surface, checkpoint dict layout {'step','model'}, save/load round trip."""
+    from ttts_amd.gpt.train import Trainer
+    cfg = json.load(open(os.path.join(ROOT, "ttts_amd", "gpt", "config.json")))
+    cfg["gpt"].update({"layers": 2, "model_dim": 128, "heads": 2})
+    cfg["train"].update({"train_steps": 3, "val_freq": 1, "save_freq": 2, "logs_folder": str(tmp_path / "logs")})
+    cfg["dataloader"]["batch_size"] = 2
+    p = tmp_path / "cfg.json"
+    p.write_text(json.dumps(cfg))
+    tr = Trainer(str(p))
+    tr.train()
+    ckpts = sorted(tr.logs_folder.glob("model-*.pt"))
+    assert ckpts, list(tr.logs_folder.iterdir())
+    data = torch.load(ckpts[-1], map_location="cpu")
+    assert set(data.keys()) == {"step", "model"} and len(data["model"]) == 12 * 2 + 12
+    tr2 = Trainer(str(p))
+    tr2.load(str(ckpts[-1]))
+    assert data["step"] == 2 and torch.equal(tr2.gpt.engine.params.cpu(), tr.gpt.engine.params.cpu())
+    log = [json.loads(l) for l in open(tr.logs_folder / "train_log.jsonl")]
+    assert len(log) == 3 and all(np.isfinite(r["loss"]) for r in log)

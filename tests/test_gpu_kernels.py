@@ -1,0 +1,400 @@
+"""-m gpu: every HIP kernel, called through the C ABI (ttts_amd.ops -> libttts_hip.so), against the oracle
+(torch fp32 restatements / the plain-C VQ oracle / the reference-generated golden fixtures).
+Tolerances are written where they are used; integer outputs (VQ indices) are compared bit-exactly."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DIAG = os.path.join(ROOT, "gpurun_out", "diag")
+
+
+def _diag(name, text):
+    os.makedirs(DIAG, exist_ok=True)
+    with open(os.path.join(DIAG, name), "w") as f:
+        f.write(text)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    from ttts_amd import ops as o
+    return o
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel_err(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def acc_row(r, h):
+    return (r & 3) + 8 * (r >> 2) + 4 * h
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def test_probe_hardware_layouts(ops):
+    """The two hardware facts every MFMA kernel here relies on: the 32x32x16 bf16 fragment / accumulator layout
+    and what ds_read_b64_tr_b16 returns for our address map."""
+    info = ops.device_info()
+    assert info["arch"] == 950 and info["wave"] == 64, info
+    c, tr = ops.probe_layout(dev())
+    c, tr = c.cpu().numpy(), tr.cpu().numpy()
+    _diag("probe.txt", "acc:\n%s\ntr:\n%s\n" % (np.array2string(c, threshold=10**6), np.array2string(tr, threshold=10**6)))
+    for lane in range(64):
+        h = lane >> 5
+        for r in range(16):
+            v = int(round(float(c[lane, r])))
+            i, j = (v % 64) - 1, v // 64 - 1
+            assert (i, j) == (acc_row(r, h), lane & 31), ("mfma layout", lane, r, v)
+        for j in range(8):
+            row, col = tr[lane, j] // 64, tr[lane, j] % 64
+            assert col == (lane & 31) and row == 8 * h + j, ("tr layout", lane, j, int(tr[lane, j]))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 200, 128), (1040, 257, 512), (128, 128, 64), (9248, 1536, 512), (777, 512, 2048)])
+def test_gemm_nt_epilogues(ops, M, N, K):
+    from ttts_amd.lib import EPI_DGELU_BF16, EPI_GELU_BF16, EPI_RESID_ADD_F32, EPI_STORE_BF16, EPI_STORE_F32
+    from oracle.gpt_ref import gelu_new
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N)
+    a = _bf(torch.randn(M, K, generator=g)).to(dev())
+    b = _bf(torch.randn(N, K, generator=g) * 0.1).to(dev())
+    bias = torch.randn(N, generator=g).to(dev())
+    ref = a.float() @ b.float().t() + bias.to(torch.bfloat16).float()
+    ldc = (N + 7) // 8 * 8
+    c = torch.zeros(M, ldc, dtype=torch.bfloat16, device=dev())
+    ops.gemm_nt(a, b, c, bias, n=N, epilogue=EPI_STORE_BF16)
+    assert rel_err(c[:, :N].float(), ref) < 4e-3          # bf16 output rounding (2^-9) dominates
+    assert float(c[:, N:].abs().max()) == 0.0 if ldc > N else True
+    # fp32 store: tight check of the MFMA accumulation itself
+    cf = torch.zeros(M, ldc, dtype=torch.float32, device=dev())
+    ops.gemm_nt(a, b, cf, None, n=N, epilogue=EPI_STORE_F32)
+    assert rel_err(cf[:, :N], a.float() @ b.float().t()) < 2e-6
+    # gelu: pre-activation + activation
+    pre = torch.zeros(M, ldc, dtype=torch.bfloat16, device=dev())
+    act = torch.zeros(M, ldc, dtype=torch.bfloat16, device=dev())
+    ops.gemm_nt(a, b, act, bias, aux=pre, n=N, epilogue=EPI_GELU_BF16)
+    assert torch.equal(pre[:, :N], c[:, :N])
+    assert rel_err(act[:, :N].float(), gelu_new(pre[:, :N].float())) < 4e-3
+    # residual add, out of place and in place
+    if N % 4 == 0:
+        r_in = torch.randn(M, N, generator=g).to(dev())
+        out = torch.empty_like(r_in)
+        ops.gemm_nt(a, b, out, bias, n=N, epilogue=EPI_RESID_ADD_F32, resid_in=r_in)
+        assert rel_err(out, r_in + c[:, :N].float()) < 1e-6
+        r2 = r_in.clone()
+        ops.gemm_nt(a, b, r2, bias, n=N, epilogue=EPI_RESID_ADD_F32)
+        assert torch.equal(r2, out)
+        # dgelu
+        dg = torch.zeros(M, ldc, dtype=torch.bfloat16, device=dev())
+        ops.gemm_nt(a, b, dg, None, aux=pre, n=N, epilogue=EPI_DGELU_BF16)
+        x = pre[:, :N].float().requires_grad_(True)
+        gelu_new(x).sum().backward()
+        assert rel_err(dg[:, :N].float(), (a.float() @ b.float().t()) * x.grad) < 5e-3
+
+
+@pytest.mark.parametrize("Kr,Mo,No", [(1000, 257, 512), (9248, 512, 1536), (333, 128, 128), (2080, 2048, 512), (8208, 1026, 512)])
+def test_gemm_tn_accumulates(ops, Kr, Mo, No):
+    g = torch.Generator(device="cpu").manual_seed(Kr + Mo)
+    lda = (Mo + 7) // 8 * 8
+    at = torch.zeros(Kr, lda, dtype=torch.bfloat16)
+    at[:, :Mo] = _bf(torch.randn(Kr, Mo, generator=g))
+    bt = _bf(torch.randn(Kr, No, generator=g) * 0.1)
+    at, bt = at.to(dev()), bt.to(dev())
+    c0 = torch.randn(Mo, No, generator=g).to(dev())
+    c = c0.clone()
+    ops.gemm_tn_accum(at, bt, c, mo=Mo)
+    ref = c0.double() + at[:, :Mo].double().t() @ bt.double()
+    assert rel_err(c, ref) < 3e-6   # fp32 accumulation, split-K atomics
+
+
+def test_colsum_and_cast(ops):
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = _bf(torch.randn(999, 264, generator=g)).to(dev())
+    out = torch.ones(257, device=dev())
+    ops.colsum_accum(x, out, n=257)
+    assert rel_err(out, 1 + x[:, :257].float().sum(0)) < 1e-5
+    w1 = torch.randn(512, 1536, generator=g).to(dev())
+    w2 = torch.randn(257, 512, generator=g).to(dev())
+    d1 = torch.zeros(512, 1536, dtype=torch.bfloat16, device=dev())
+    t1 = torch.zeros(1536, 512, dtype=torch.bfloat16, device=dev())
+    t2 = torch.zeros(512, 264, dtype=torch.bfloat16, device=dev())
+    plan = ops.CastPlan([(w1, d1, t1), (w2, None, t2[:, :257])], dev())
+    plan.run()
+    assert torch.equal(d1, w1.to(torch.bfloat16)) and torch.equal(t1, w1.t().to(torch.bfloat16))
+    assert torch.equal(t2[:, :257], w2.t().to(torch.bfloat16)) and float(t2[:, 257:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,D,split", [(520, 512, (0, 0)), (9248, 512, (1156, 130)), (76, 64, (38, 14)), (64, 1024, (0, 0))])
+def test_layernorm_fwd_bwd(ops, M, D, split):
+    g = torch.Generator(device="cpu").manual_seed(M)
+    x = (torch.randn(M, D, generator=g) * 2 + 0.3).to(dev())
+    gamma = (1 + 0.1 * torch.randn(D, generator=g)).to(dev())
+    beta = (0.1 * torch.randn(D, generator=g)).to(dev())
+    S, T = split
+    perm = torch.arange(M)
+    if S:
+        B = M // S
+        rows = torch.arange(M)
+        b, t = rows // S, rows % S
+        perm = torch.where(t < T, b * T + t, B * T + b * (S - T) + (t - T))
+    perm = perm.to(dev())
+    for out_dtype in (torch.float32, torch.bfloat16):
+        y = torch.empty(M, D, dtype=out_dtype, device=dev())
+        mean = torch.empty(M, device=dev()); rstd = torch.empty(M, device=dev())
+        ops.layernorm_fwd(x, gamma, beta, y, mean, rstd, split=split)
+        ref = torch.nn.functional.layer_norm(x, (D,), gamma, beta, 1e-5)
+        tol = 2e-6 if out_dtype == torch.float32 else 4e-3
+        assert rel_err(y[perm].float(), ref) < tol
+    # backward (dy bf16 in the split layout, residual add, bf16 copy)
+    dy_nat = torch.randn(M, D, generator=g).to(dev())
+    dy = torch.empty(M, D, dtype=torch.bfloat16, device=dev())
+    dy[perm] = dy_nat.to(torch.bfloat16)
+    dx_in = torch.randn(M, D, generator=g).to(dev())
+    dx = torch.empty(M, D, device=dev()); dxb = torch.empty(M, D, dtype=torch.bfloat16, device=dev())
+    dg = torch.ones(D, device=dev()); db = torch.ones(D, device=dev())
+    ws = ops.layernorm_bwd_workspace(M, D, dev())
+    ops.layernorm_bwd(dy, x, gamma, mean, rstd, dx_in, dx, dxb, dg, db, ws, split=split)
+    xr = x.clone().requires_grad_(True); gr = gamma.clone().requires_grad_(True); br = beta.clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-5).backward(dy_nat.to(torch.bfloat16).float())
+    assert rel_err(dx, dx_in + xr.grad) < 5e-6
+    assert rel_err(dxb.float(), dx) < 4e-3
+    assert rel_err(dg, 1 + gr.grad) < 1e-5 and rel_err(db, 1 + br.grad) < 1e-5
+
+
+def test_embed_fwd_bwd(ops):
+    g = torch.Generator(device="cpu").manual_seed(9)
+    B, Tt, Tm, D = 3, 14, 26, 64
+    te, tp = torch.randn(257, D, generator=g), torch.randn(34, D, generator=g)
+    me, mp = torch.randn(1026, D, generator=g), torch.randn(66, D, generator=g)
+    ti = torch.randint(0, 257, (B, Tt), generator=g); mi = torch.randint(0, 1026, (B, Tm), generator=g)
+    x = torch.empty(B, Tt + Tm, D, device=dev())
+    args = [t.to(dev()) for t in (ti, mi, te, tp, me, mp)]
+    ops.embed_fwd(*args, x)
+    ref = torch.cat([te[ti] + tp[:Tt], me[mi] + mp[:Tm]], 1)
+    assert torch.equal(x.cpu(), ref)
+    dx = torch.randn(B, Tt + Tm, D, generator=g)
+    gte, gtp, gme, gmp = [torch.zeros_like(t).to(dev()) for t in (te, tp, me, mp)]
+    ops.embed_bwd(args[0], args[1], dx.to(dev()), gte, gtp, gme, gmp)
+    r = [t.clone().requires_grad_(True) for t in (te, tp, me, mp)]
+    torch.cat([r[0][ti] + r[1][:Tt], r[2][mi] + r[3][:Tm]], 1).backward(dx)
+    for got, want in zip((gte, gtp, gme, gmp), r):
+        assert rel_err(got.cpu(), want.grad) < 1e-6
+
+
+@pytest.mark.parametrize("R,C", [(1040, 257), (8208, 1026), (52, 1026)])
+def test_cross_entropy(ops, R, C):
+    g = torch.Generator(device="cpu").manual_seed(R)
+    ld = (C + 7) // 8 * 8
+    logits = torch.zeros(R, ld, dtype=torch.bfloat16)
+    logits[:, :C] = _bf(torch.randn(R, C, generator=g) * 3)
+    tgt = torch.randint(0, C, (R,), generator=g)
+    logits, tgt = logits.to(dev()), tgt.to(dev())
+    rl = torch.empty(R, device=dev()); lse = torch.empty(R, device=dev()); mean = torch.empty(1, device=dev())
+    ops.ce_fwd(logits, tgt, rl, lse, mean, C)
+    x = logits[:, :C].float().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(x, tgt)
+    np.testing.assert_allclose(mean.item(), ref.item(), rtol=2e-6)
+    (ref * 0.37).backward()
+    dl = torch.full((R, ld), 7.0, dtype=torch.bfloat16, device=dev())
+    scale_dev = torch.tensor(0.5, device=dev())
+    ops.ce_bwd(logits, tgt, lse, dl, C, 0.74, scale_dev)
+    assert rel_err(dl[:, :C].float(), x.grad) < 4e-3
+    assert float(dl[:, C:].abs().max()) == 0.0 if ld > C else True
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def _attn_ref(qkv, B, S, H, dh, mask=None, p=0.0):
+    D = H * dh
+    q, k, v = [t.view(B, S, H, dh).transpose(1, 2) for t in qkv.float().split(D, dim=-1)]
+    att = (q @ k.transpose(-1, -2)) * dh ** -0.5
+    causal = torch.ones(S, S, dtype=torch.bool, device=qkv.device).tril()
+    att = att.masked_fill(~causal, float("-inf"))
+    lse = torch.logsumexp(att, -1)
+    pr = torch.softmax(att, -1)
+    if mask is not None:
+        pr = pr * mask.float() / (1.0 - p)
+    o = pr.to(torch.bfloat16).float() @ v
+    return o.transpose(1, 2).reshape(B, S, D), lse
+
+
+@pytest.mark.parametrize("B,S,H,dh", [(2, 1156, 8, 64), (2, 38, 2, 32), (1, 130, 2, 64), (1, 257, 1, 128), (3, 64, 4, 64)])
+def test_attention_fwd_bwd(ops, B, S, H, dh):
+    D = H * dh
+    g = torch.Generator(device="cpu").manual_seed(S)
+    qkv = _bf(torch.randn(B, S, 3 * D, generator=g)).to(dev())
+    o = torch.zeros(B, S, D, dtype=torch.bfloat16, device=dev())
+    lse = torch.zeros(B, H, S, device=dev())
+    q2 = qkv.view(B * S, 3 * D)
+    ops.attn_fwd(q2, q2[:, D:], q2[:, 2 * D:], o, lse, B, H, S, dh, (S * 3 * D, 3 * D), (S * D, D), dh ** -0.5)
+    leaf = qkv.float().requires_grad_(True)
+    ref_o, ref_lse = _attn_ref(leaf, B, S, H, dh)
+    assert rel_err(lse, ref_lse) < 1e-5
+    assert rel_err(o.float(), ref_o) < 6e-3          # bf16 P and bf16 output rounding
+    do = _bf(torch.randn(B, S, D, generator=g)).to(dev())
+    ref_o.backward(do.float())
+    dqkv = torch.zeros(B * S, 3 * D, dtype=torch.bfloat16, device=dev())
+    ws = torch.empty(B * H * S, device=dev())
+    ops.attn_bwd(q2, q2[:, D:], q2[:, 2 * D:], o, do, lse, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], ws, B, H, S, dh,
+                 (S * 3 * D, 3 * D), (S * D, D), dh ** -0.5)
+    got = dqkv.view(B, S, 3 * D).float()
+    for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+        e = rel_err(got[..., sl], leaf.grad[..., sl])
+        assert e < 1.5e-2, (name, e)
+
+
+def test_attention_dropout_matches_mask(ops):
+    B, S, H, dh, p, seed = 1, 200, 2, 64, 0.1, 1234567
+    D = H * dh
+    g = torch.Generator(device="cpu").manual_seed(1)
+    qkv = _bf(torch.randn(B, S, 3 * D, generator=g)).to(dev())
+    mask = ops.attn_dropout_mask(B, H, S, p, seed, dev())
+    keep = mask.float().mean().item()
+    assert abs(keep - 0.9) < 0.01, keep
+    o = torch.zeros(B, S, D, dtype=torch.bfloat16, device=dev()); lse = torch.zeros(B, H, S, device=dev())
+    q2 = qkv.view(B * S, 3 * D)
+    ops.attn_fwd(q2, q2[:, D:], q2[:, 2 * D:], o, lse, B, H, S, dh, (S * 3 * D, 3 * D), (S * D, D), dh ** -0.5, p, seed)
+    leaf = qkv.float().requires_grad_(True)
+    p_eff = round(p * 65536) / 65536.0
+    ref_o, _ = _attn_ref(leaf, B, S, H, dh, mask=mask, p=p_eff)
+    assert rel_err(o.float(), ref_o) < 8e-3
+    do = _bf(torch.randn(B, S, D, generator=g)).to(dev())
+    ref_o.backward(do.float())
+    dqkv = torch.zeros(B * S, 3 * D, dtype=torch.bfloat16, device=dev()); ws = torch.empty(B * H * S, device=dev())
+    ops.attn_bwd(q2, q2[:, D:], q2[:, 2 * D:], o, do, lse, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], ws, B, H, S, dh,
+                 (S * 3 * D, 3 * D), (S * D, D), dh ** -0.5, p, seed)
+    assert rel_err(dqkv.view(B, S, 3 * D).float(), leaf.grad) < 2e-2
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def test_adamw_and_gradnorm(ops):
+    n = 100_000
+    g = torch.Generator(device="cpu").manual_seed(3)
+    p0 = torch.randn(n, generator=g); gr = torch.randn(n, generator=g) * 0.01
+    ref_p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref_p], lr=1e-4, betas=(0.9, 0.96), weight_decay=0.01)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda s: float(s / 500) if s < 500 else 1)
+    p = p0.clone().to(dev()); m = torch.zeros(n, device=dev()); v = torch.zeros(n, device=dev())
+    shadow = torch.zeros(n, dtype=torch.bfloat16, device=dev())
+    state = torch.zeros(8, device=dev()); ws = ops.gradnorm_workspace(n, dev())
+    for step in range(4):
+        gstep = gr * (step + 1)
+        ref_p.grad = gstep.clone()
+        tn = torch.nn.utils.clip_grad_norm_([ref_p], 1.0)
+        opt.step(); sched.step()
+        gd = gstep.clone().to(dev())
+        ops.adamw_schedule(state, 1e-4, 0.9, 0.96, 500)
+        ops.gradnorm(gd, 1.0, state, ws)
+        ops.adamw(p, gd, m, v, shadow, state, 0.9, 0.96, 1e-8, 0.01, zero_grad=True)
+        np.testing.assert_allclose(state[4].item(), float(tn), rtol=1e-5)
+        assert float(gd.abs().max()) == 0.0
+    assert rel_err(p.cpu() - p0, ref_p.detach() - p0) < 1e-3     # update deltas
+    assert rel_err(m.cpu(), opt.state[ref_p]["exp_avg"]) < 1e-5
+    assert rel_err(v.cpu(), opt.state[ref_p]["exp_avg_sq"]) < 1e-5
+    assert torch.equal(shadow, p.to(torch.bfloat16))
+    assert state[0].item() == 4.0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def _vq_c_oracle():
+    so = os.path.join(ROOT, "oracle", "_build", "libvq_ref.so")
+    lib = ctypes.CDLL(so)
+    lib.vq_nearest_ref.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_int64] * 3 + [ctypes.c_void_p] * 2
+    return lib
+
+
+def test_vq_nearest_bit_exact(ops, golden_dir):
+    from oracle import vq_ref
+    g = np.load(os.path.join(golden_dir, "vq.npz"))
+    lib = _vq_c_oracle()
+    K, D = 1024, 192
+    report = []
+    for name in ("n1024_s1", "n1024_s01", "n1024_s10", "n4096_s1"):
+        seed, N, s = g[name + ":seed_N_scale"]
+        rng = np.random.default_rng(int(seed))
+        x = rng.standard_normal((int(N), D), dtype=np.float32) * np.float32(s)
+        e = rng.standard_normal((K, D), dtype=np.float32)
+        idx, xq, dist = ops.vq_nearest(torch.from_numpy(x).to(dev()), torch.from_numpy(e).to(dev()), True, True)
+        idx, xq, dist = idx.cpu().numpy(), xq.cpu().numpy(), dist.cpu().numpy()
+        assert np.array_equal(idx, g[name + ":idx"]), name            # reference-generated indices: bit exact
+        ci = np.empty(int(N), np.int64); cd = np.empty(int(N), np.float32)
+        lib.vq_nearest_ref(x.ctypes.data, e.ctypes.data, int(N), K, D, ci.ctypes.data, cd.ctypes.data)
+        assert np.array_equal(idx, ci) and np.array_equal(dist, cd), name   # C oracle: indices AND distances bit exact
+        assert np.array_equal(xq, e[idx])
+        report.append((name, int(vq_ref.near_tie_audit(torch.from_numpy(x), torch.from_numpy(e), None).sum())))
+    _diag("vq_near_ties.txt", json.dumps(report))
+    # exact ties -> lowest index
+    rng = np.random.default_rng(int(g["ties:seed"]))
+    e = rng.standard_normal((K, D), dtype=np.float32)
+    e[512:] = e[:512]
+    x = e[rng.integers(0, 512, 256)] + rng.standard_normal((256, D), dtype=np.float32) * np.float32(0.01)
+    idx, _, _ = ops.vq_nearest(torch.from_numpy(x).to(dev()), torch.from_numpy(e).to(dev()))
+    assert np.array_equal(idx.cpu().numpy(), g["ties:idx"])
+    # ragged sizes: N not a multiple of 32, K not a multiple of 128, small D
+    rng = np.random.default_rng(99)
+    x = rng.standard_normal((77, 64), dtype=np.float32); e = rng.standard_normal((300, 64), dtype=np.float32)
+    idx, _, dist = ops.vq_nearest(torch.from_numpy(x).to(dev()), torch.from_numpy(e).to(dev()), True, True)
+    ci = np.empty(77, np.int64); cd = np.empty(77, np.float32)
+    lib.vq_nearest_ref(x.ctypes.data, e.ctypes.data, 77, 300, 64, ci.ctypes.data, cd.ctypes.data)
+    assert np.array_equal(idx.cpu().numpy(), ci) and np.array_equal(dist.cpu().numpy(), cd)
+
+
+def test_vq_commit_and_ema(ops, golden_dir):
+    from oracle import vq_ref
+    g = np.load(os.path.join(golden_dir, "vq.npz"))
+    K, D = 1024, 192
+    rng = np.random.default_rng(int(g["train:seed"]))
+    e = torch.from_numpy(rng.standard_normal((K, D), dtype=np.float32))
+    x = torch.from_numpy(rng.standard_normal((4, D, 128), dtype=np.float32))
+    flat = x.transpose(1, 2).reshape(-1, D).contiguous().to(dev())
+    idx, xq, _ = ops.vq_nearest(flat, e.to(dev()))
+    assert np.array_equal(idx.view(1, 4, 128).cpu().numpy(), g["train:codes"])
+    dx = torch.zeros_like(flat)
+    loss = ops.vq_commit(flat, xq, dx, 1.0)
+    np.testing.assert_allclose(loss.item(), g["train:commit"], rtol=1e-5)
+    # golden dx = 0.5 (straight-through of q.sum()*0.5) + commitment gradient
+    want = torch.from_numpy(g["train:dx"]).transpose(1, 2).reshape(-1, D) - 0.5
+    assert rel_err(dx.cpu(), want) < 1e-5
+    cs = torch.full((K,), 4.0, device=dev()); avg = (e * 4.0).to(dev()); emb = e.clone().to(dev())
+    ops.vq_ema_update(flat, idx, cs, avg, emb, 0.99, 1e-5)
+    np.testing.assert_allclose(cs.cpu().numpy(), g["train:cluster_size"], rtol=1e-6)
+    samp = lambda t: t.reshape(-1)[::max(1, t.numel() // 8192)].cpu().numpy()  # noqa: E731
+    np.testing.assert_allclose(samp(avg), g["train:embed_avg_sample"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(samp(emb), g["train:embed_sample"], rtol=1e-5, atol=1e-6)
+
+
+def test_stft_and_mel(ops, golden_dir):
+    from oracle import mel_ref
+    g = np.load(os.path.join(golden_dir, "mel.npz"))
+    for tag, n_fft, hop, n_mels, sr, fmax in (("A", 2048, 640, 128, 32000, None), ("B", 1024, 256, 80, 22050, 8000)):
+        wav = torch.from_numpy(g[tag + ":wav"]).to(dev())
+        win = torch.hann_window(n_fft).to(dev())
+        spec = ops.stft_mag(wav, win, n_fft, hop)
+        ref = torch.from_numpy(g[tag + ":spec"])
+        assert spec.shape == ref.shape
+        # fp32 FFT vs the reference's (pocketfft) result: 1e-4 of the spectrum's scale
+        assert float((spec.cpu() - ref).abs().max()) < 1e-4 * float(ref.abs().max())
+        basis = torch.from_numpy(mel_ref.slaney_mel_basis(sr, n_fft, n_mels, 0, fmax)).to(dev())
+        mel = ops.mel_log(spec, basis)
+        np.testing.assert_allclose(mel.cpu().numpy(), g[tag + ":mel"], rtol=2e-3, atol=2e-3)
+    # BASELINE shape: 32 clips x 163 840 samples -> (32, 1025, 256), vs the oracle (torch.stft) on the GPU box
+    gen = torch.Generator(device="cpu").manual_seed(8)
+    wav = (torch.rand(4, 163840, generator=gen) - 0.5)
+    spec = ops.stft_mag(wav.to(dev()), torch.hann_window(2048).to(dev()), 2048, 640)
+    ref = mel_ref.spectrogram(wav, 2048, 640, 2048)
+    assert spec.shape == (4, 1025, 256)
+    assert float((spec.cpu() - ref).abs().max()) < 1e-4 * float(ref.abs().max())

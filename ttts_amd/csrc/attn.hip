@@ -1,0 +1,569 @@
+// Causal self-attention forward / backward for gfx950 (flash-style: the S x S score matrix never reaches HBM).
+// Replaces GPT2Attention's core (transformers modeling_gpt2.py:53-72) as reached from ttts/gpt/model.py:422.
+//
+// MFMA: v_mfma_f32_32x32x16_bf16.  All three kernels keep the softmax statistics lane-local by choosing which
+// operand is "transposed":
+//   forward / dQ kernels ("S^T form"): S^T = K.Q^T puts ONE QUERY PER LANE (column) and 16 keys of each 32-key
+//     block in that lane's accumulator registers, so row max / row sum are in-register reductions plus one
+//     lane<->lane+32 exchange, and the exponentiated registers ARE the B operand of the next MFMA
+//     (O^T = V^T.P^T, dQ^T = K^T.dS^T) -- P never touches LDS.  The A operand of that MFMA (V^T / K^T) is fetched
+//     from the row-major [key][dh] LDS tile with the hardware transpose read ds_read_b64_tr_b16.
+//   dK/dV kernel ("S form"): S = Q.K^T puts ONE KEY PER LANE, so dV^T = dO^T.P and dK^T = Q^T.dS again consume
+//     the accumulator registers directly as B operands; the per-query lse / delta come from a small LDS array.
+// Work split: 4 waves x 32 rows (queries resp. keys) per workgroup, 64-row tiles of the other sequence axis
+// staged global -> registers -> LDS (double buffered, next tile's loads in flight under the MFMAs).
+// Causality: tiles strictly above the diagonal are never loaded; workgroups are launched heaviest-first.
+#include <algorithm>
+
+#include "common.hpp"
+
+namespace ttts {
+
+struct AttnParams {
+  const bf16 *q, *k, *v;
+  const bf16 *o, *d_o;
+  bf16 *out, *dq, *dk, *dv;
+  float* lse;
+  const float* lse_in;
+  float* delta;
+  int B, H, S;
+  int64_t sb, ss;    // q/k/v (and dq/dk/dv) strides: batch, sequence
+  int64_t osb, oss;  // o / dO strides
+  float scale, c;    // softmax scale, scale * log2(e)
+  uint32_t thr;      // dropout threshold on 16 random bits (0 = no dropout)
+  float inv_keep;
+  uint32_t seed_lo, seed_hi;
+};
+
+constexpr float NEG_BIG = -1.0e30f;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+template <int DH> struct AttnCfg {
+  static constexpr int KSTR = DH + 8;                      // natural (ds_read_b128) tiles, elements
+  static constexpr int VSTR = (DH == 32) ? 32 : DH + 32;   // transposed-read-only tiles
+  static constexpr int KS = DH / 16;                       // MFMA k-steps across the head dim
+  static constexpr int NB = DH / 32;                       // 32-wide output blocks across the head dim
+  static constexpr int CPT = DH / 32;                      // 16-byte chunks per thread for a 64 x DH tile
+  static constexpr int CPR = DH / 8;                       // 16-byte chunks per row
+};
+
+// keep-mask bit for attention element e = ((b*H + h)*S + query)*S + key
+__device__ __forceinline__ bool drop_keep(uint32_t e, uint32_t thr, uint32_t slo, uint32_t shi) {
+  const uint32_t r = hash32(e >> 1, slo, shi);
+  return ((e & 1u) ? (r >> 16) : (r & 0xFFFFu)) >= thr;
+}
+
+// load / store a 64 x DH bf16 tile (rows row0.. of a [*, stride] matrix, zero beyond nrows)
+template <int DH>
+__device__ __forceinline__ void tile_load(bf16x8 (&r)[AttnCfg<DH>::CPT], const bf16* base, int64_t stride, int row0,
+                                          int nrows, int tid) {
+#pragma unroll
+  for (int i = 0; i < AttnCfg<DH>::CPT; ++i) {
+    const int c = tid + i * 256, row = c / AttnCfg<DH>::CPR, dc = (c % AttnCfg<DH>::CPR) * 8;
+    r[i] = (row0 + row < nrows) ? *reinterpret_cast<const bf16x8*>(base + (int64_t)(row0 + row) * stride + dc) : zero8();
+  }
+}
+template <int DH, int STR>
+__device__ __forceinline__ void tile_store(const bf16x8 (&r)[AttnCfg<DH>::CPT], bf16* lds, int tid) {
+#pragma unroll
+  for (int i = 0; i < AttnCfg<DH>::CPT; ++i) {
+    const int c = tid + i * 256, row = c / AttnCfg<DH>::CPR, dc = (c % AttnCfg<DH>::CPR) * 8;
+    *reinterpret_cast<bf16x8*>(lds + row * STR + dc) = r[i];
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------
+// forward
+// -------------------------------------------------------------------------------------------------------
+template <int DH, bool DROPOUT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+  using C = AttnCfg<DH>;
+  __shared__ __attribute__((aligned(16))) bf16 Ks[2][64 * C::KSTR];
+  __shared__ __attribute__((aligned(16))) bf16 Vs[2][64 * C::VSTR];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5, g = lane >> 4, ip = lane & 15;
+  const int nqb = (p.S + 127) / 128;
+  const int qb = nqb - 1 - (int)(blockIdx.x % nqb);  // heaviest (latest) query blocks first
+  const int bh = blockIdx.x / nqb, h = bh % p.H, b = bh / p.H;
+  const int q_base = qb * 128 + wave * 32;
+  const int query = q_base + (lane & 31);
+  const bf16* qp = p.q + (int64_t)b * p.sb + h * DH;
+  const bf16* kp = p.k + (int64_t)b * p.sb + h * DH;
+  const bf16* vp = p.v + (int64_t)b * p.sb + h * DH;
+
+  bf16x8 qf[C::KS];
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks)
+    qf[ks] = query < p.S ? *reinterpret_cast<const bf16x8*>(qp + (int64_t)query * p.ss + ks * 16 + hh * 8) : zero8();
+
+  f32x16 ot[C::NB];
+#pragma unroll
+  for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[nb][r] = 0.f;
+  float m = NEG_BIG, l = 0.f;
+
+  const int kv_end = min(p.S, qb * 128 + 128);
+  const int nt = (kv_end + 63) / 64;
+  bf16x8 rk[C::CPT], rv[C::CPT];
+  tile_load<DH>(rk, kp, p.ss, 0, p.S, tid);
+  tile_load<DH>(rv, vp, p.ss, 0, p.S, tid);
+  tile_store<DH, C::KSTR>(rk, Ks[0], tid);
+  tile_store<DH, C::VSTR>(rv, Vs[0], tid);
+  __syncthreads();
+  const int k_nat = (lane & 31) * C::KSTR + hh * 8;
+  const int v_tr = (4 * hh + (ip >> 2)) * C::VSTR + 16 * (g & 1) + 4 * (ip & 3);
+  const uint32_t e_row = (uint32_t)(((int64_t)(b * p.H + h) * p.S + query) * p.S);
+
+  for (int jt = 0; jt < nt; ++jt) {
+    const int buf = jt & 1, kv0 = jt * 64;
+    if (jt + 1 < nt) {
+      tile_load<DH>(rk, kp, p.ss, kv0 + 64, p.S, tid);
+      tile_load<DH>(rv, vp, p.ss, kv0 + 64, p.S, tid);
+    }
+    if (kv0 <= q_base + 31) {  // wave-uniform: at least one (query, key) pair of this wave is unmasked
+      f32x16 s[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[buf][k_nat + kb * 32 * C::KSTR + ks * 16]);
+          s[kb] = mfma32(kf, qf[ks], s[kb]);
+        }
+      }
+      if (kv0 + 63 > q_base || kv0 + 63 >= p.S) {  // diagonal / ragged tile: mask
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kv0 + kb * 32 + acc_row(r, hh);
+            if (key > query || key >= p.S) s[kb][r] = NEG_BIG;
+          }
+      }
+      float mx = NEG_BIG;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m - m_new) * p.c);
+      m = m_new;
+      const float m2 = m_new * p.c;
+      l *= alpha;
+#pragma unroll
+      for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[nb][r] *= alpha;
+      bf16x8 pf[2][2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][r], p.c, -m2));
+          l += pv;
+          if (DROPOUT) {
+            const int key = kv0 + kb * 32 + acc_row(r, hh);
+            pv = drop_keep(e_row + (uint32_t)key, p.thr, p.seed_lo, p.seed_hi) ? pv * p.inv_keep : 0.f;
+          }
+          pf[kb][r >> 3][r & 7] = (bf16)pv;
+        }
+#pragma unroll
+      for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int cs = 0; cs < 2; ++cs) {
+            const bf16* vt = &Vs[buf][v_tr + (kb * 32 + 16 * cs) * C::VSTR + nb * 32];
+            const bf16x8 vf = cat4(lds_tr_b64(vt), lds_tr_b64(vt + 8 * C::VSTR));
+            ot[nb] = mfma32(vf, pf[kb][cs], ot[nb]);
+          }
+    }
+    if (jt + 1 < nt) {
+      tile_store<DH, C::KSTR>(rk, Ks[buf ^ 1], tid);
+      tile_store<DH, C::VSTR>(rv, Vs[buf ^ 1], tid);
+    }
+    __syncthreads();
+  }
+  l += __shfl_xor(l, 32, 64);
+  if (query < p.S) {
+    const float inv = 1.0f / l;
+    bf16* op = p.out + (int64_t)b * p.osb + (int64_t)query * p.oss + h * DH;
+#pragma unroll
+    for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16)(ot[nb][4 * qd + e] * inv);
+        *reinterpret_cast<bf16x4*>(op + nb * 32 + 8 * qd + 4 * hh) = o;
+      }
+    if (hh == 0) p.lse[(int64_t)(b * p.H + h) * p.S + query] = (m * p.c + __log2f(l)) * LN2;
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------
+// backward: delta = rowsum(dO * O)
+// -------------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (b, s, h)
+  const int64_t total = (int64_t)p.B * p.S * p.H;
+  if (i >= total) return;
+  const int h = (int)(i % p.H);
+  const int s = (int)((i / p.H) % p.S);
+  const int b = (int)(i / ((int64_t)p.H * p.S));
+  const bf16* o = p.o + (int64_t)b * p.osb + (int64_t)s * p.oss + h * DH;
+  const bf16* d = p.d_o + (int64_t)b * p.osb + (int64_t)s * p.oss + h * DH;
+  float acc = 0.f;
+#pragma unroll
+  for (int c = 0; c < DH / 8; ++c) {
+    const bf16x8 ov = *reinterpret_cast<const bf16x8*>(o + c * 8);
+    const bf16x8 dv = *reinterpret_cast<const bf16x8*>(d + c * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += (float)ov[j] * (float)dv[j];
+  }
+  p.delta[(int64_t)(b * p.H + h) * p.S + s] = acc;
+}
+
+// -------------------------------------------------------------------------------------------------------
+// backward: dQ (S^T form, one query per lane; loops over key tiles up to the diagonal)
+// -------------------------------------------------------------------------------------------------------
+template <int DH, bool DROPOUT>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
+  using C = AttnCfg<DH>;
+  __shared__ __attribute__((aligned(16))) bf16 Ks[2][64 * C::KSTR];
+  __shared__ __attribute__((aligned(16))) bf16 Vs[2][64 * C::KSTR];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5, g = lane >> 4, ip = lane & 15;
+  const int nqb = (p.S + 127) / 128;
+  const int qb = nqb - 1 - (int)(blockIdx.x % nqb);
+  const int bh = blockIdx.x / nqb, h = bh % p.H, b = bh / p.H;
+  const int q_base = qb * 128 + wave * 32;
+  const int query = q_base + (lane & 31);
+  const bf16* qp = p.q + (int64_t)b * p.sb + h * DH;
+  const bf16* kp = p.k + (int64_t)b * p.sb + h * DH;
+  const bf16* vp = p.v + (int64_t)b * p.sb + h * DH;
+  const bf16* dop = p.d_o + (int64_t)b * p.osb + h * DH;
+
+  bf16x8 qf[C::KS], dof[C::KS];
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks) {
+    qf[ks] = query < p.S ? *reinterpret_cast<const bf16x8*>(qp + (int64_t)query * p.ss + ks * 16 + hh * 8) : zero8();
+    dof[ks] = query < p.S ? *reinterpret_cast<const bf16x8*>(dop + (int64_t)query * p.oss + ks * 16 + hh * 8) : zero8();
+  }
+  const int64_t stat = (int64_t)(b * p.H + h) * p.S + query;
+  const float lse2 = query < p.S ? p.lse_in[stat] * LOG2E : 0.f;
+  const float delta = query < p.S ? p.delta[stat] : 0.f;
+
+  f32x16 dqt[C::NB];
+#pragma unroll
+  for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dqt[nb][r] = 0.f;
+
+  const int kv_end = min(p.S, qb * 128 + 128);
+  const int nt = (kv_end + 63) / 64;
+  bf16x8 rk[C::CPT], rv[C::CPT];
+  tile_load<DH>(rk, kp, p.ss, 0, p.S, tid);
+  tile_load<DH>(rv, vp, p.ss, 0, p.S, tid);
+  tile_store<DH, C::KSTR>(rk, Ks[0], tid);
+  tile_store<DH, C::KSTR>(rv, Vs[0], tid);
+  __syncthreads();
+  const int k_nat = (lane & 31) * C::KSTR + hh * 8;
+  const int k_tr = (4 * hh + (ip >> 2)) * C::KSTR + 16 * (g & 1) + 4 * (ip & 3);
+  const uint32_t e_row = (uint32_t)(((int64_t)(b * p.H + h) * p.S + query) * p.S);
+
+  for (int jt = 0; jt < nt; ++jt) {
+    const int buf = jt & 1, kv0 = jt * 64;
+    if (jt + 1 < nt) {
+      tile_load<DH>(rk, kp, p.ss, kv0 + 64, p.S, tid);
+      tile_load<DH>(rv, vp, p.ss, kv0 + 64, p.S, tid);
+    }
+    if (kv0 <= q_base + 31) {
+      bf16x8 dsf[2][2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[buf][k_nat + kb * 32 * C::KSTR + ks * 16]);
+          const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vs[buf][k_nat + kb * 32 * C::KSTR + ks * 16]);
+          s = mfma32(kf, qf[ks], s);
+          dp = mfma32(vf, dof[ks], dp);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kv0 + kb * 32 + acc_row(r, hh);
+          float pv = (key > query || key >= p.S) ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[r], p.c, -lse2));
+          float dpv = dp[r];
+          if (DROPOUT) dpv = drop_keep(e_row + (uint32_t)key, p.thr, p.seed_lo, p.seed_hi) ? dpv * p.inv_keep : 0.f;
+          dsf[kb][r >> 3][r & 7] = (bf16)(pv * (dpv - delta));
+        }
+      }
+#pragma unroll
+      for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int cs = 0; cs < 2; ++cs) {
+            const bf16* kt = &Ks[buf][k_tr + (kb * 32 + 16 * cs) * C::KSTR + nb * 32];
+            const bf16x8 kf = cat4(lds_tr_b64(kt), lds_tr_b64(kt + 8 * C::KSTR));
+            dqt[nb] = mfma32(kf, dsf[kb][cs], dqt[nb]);
+          }
+    }
+    if (jt + 1 < nt) {
+      tile_store<DH, C::KSTR>(rk, Ks[buf ^ 1], tid);
+      tile_store<DH, C::KSTR>(rv, Vs[buf ^ 1], tid);
+    }
+    __syncthreads();
+  }
+  if (query < p.S) {
+    bf16* dq = p.dq + (int64_t)b * p.sb + (int64_t)query * p.ss + h * DH;
+#pragma unroll
+    for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16)(dqt[nb][4 * qd + e] * p.scale);
+        *reinterpret_cast<bf16x4*>(dq + nb * 32 + 8 * qd + 4 * hh) = o;
+      }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------
+// backward: dK, dV (S form, one key per lane; loops over query tiles from the diagonal down)
+// -------------------------------------------------------------------------------------------------------
+template <int DH, bool DROPOUT>
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
+  using C = AttnCfg<DH>;
+  __shared__ __attribute__((aligned(16))) bf16 Qs[2][64 * C::KSTR];
+  __shared__ __attribute__((aligned(16))) bf16 Ds[2][64 * C::KSTR];
+  __shared__ __attribute__((aligned(16))) float Ls[2][64];
+  __shared__ __attribute__((aligned(16))) float Dl[2][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5, g = lane >> 4, ip = lane & 15;
+  const int nkb = (p.S + 127) / 128;
+  const int kblk = (int)(blockIdx.x % nkb);  // earliest key blocks see the most queries: they come first
+  const int bh = blockIdx.x / nkb, h = bh % p.H, b = bh / p.H;
+  const int k_base = kblk * 128 + wave * 32;
+  const int key = k_base + (lane & 31);
+  const bf16* qp = p.q + (int64_t)b * p.sb + h * DH;
+  const bf16* kp = p.k + (int64_t)b * p.sb + h * DH;
+  const bf16* vp = p.v + (int64_t)b * p.sb + h * DH;
+  const bf16* dop = p.d_o + (int64_t)b * p.osb + h * DH;
+  const float* lsep = p.lse_in + (int64_t)(b * p.H + h) * p.S;
+  const float* delp = p.delta + (int64_t)(b * p.H + h) * p.S;
+
+  bf16x8 kf[C::KS], vf[C::KS];
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks) {
+    kf[ks] = key < p.S ? *reinterpret_cast<const bf16x8*>(kp + (int64_t)key * p.ss + ks * 16 + hh * 8) : zero8();
+    vf[ks] = key < p.S ? *reinterpret_cast<const bf16x8*>(vp + (int64_t)key * p.ss + ks * 16 + hh * 8) : zero8();
+  }
+  f32x16 dkt[C::NB], dvt[C::NB];
+#pragma unroll
+  for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dkt[nb][r] = 0.f; dvt[nb][r] = 0.f; }
+
+  const int qt0 = (kblk * 128) / 64;
+  const int nqt = (p.S + 63) / 64;
+  bf16x8 rq[C::CPT], rd[C::CPT];
+  float rl = 0.f, rdl = 0.f;
+  auto load_stats = [&](int q0) {
+    if (tid < 64) rl = (q0 + tid < p.S) ? lsep[q0 + tid] * LOG2E : 0.f;
+    else if (tid < 128) rdl = (q0 + tid - 64 < p.S) ? delp[q0 + tid - 64] : 0.f;
+  };
+  auto store_stats = [&](int buf) {
+    if (tid < 64) Ls[buf][tid] = rl;
+    else if (tid < 128) Dl[buf][tid - 64] = rdl;
+  };
+  tile_load<DH>(rq, qp, p.ss, qt0 * 64, p.S, tid);
+  tile_load<DH>(rd, dop, p.oss, qt0 * 64, p.S, tid);
+  load_stats(qt0 * 64);
+  tile_store<DH, C::KSTR>(rq, Qs[0], tid);
+  tile_store<DH, C::KSTR>(rd, Ds[0], tid);
+  store_stats(0);
+  __syncthreads();
+  const int q_nat = (lane & 31) * C::KSTR + hh * 8;
+  const int q_tr = (4 * hh + (ip >> 2)) * C::KSTR + 16 * (g & 1) + 4 * (ip & 3);
+  const uint32_t e_bh = (uint32_t)((int64_t)(b * p.H + h) * p.S);
+
+  for (int qt = qt0; qt < nqt; ++qt) {
+    const int buf = (qt - qt0) & 1, q0 = qt * 64;
+    if (qt + 1 < nqt) {
+      tile_load<DH>(rq, qp, p.ss, q0 + 64, p.S, tid);
+      tile_load<DH>(rd, dop, p.oss, q0 + 64, p.S, tid);
+      load_stats(q0 + 64);
+    }
+    if (q0 + 63 >= k_base) {  // wave-uniform: some query of this tile can see some key of this wave
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+          const bf16x8 qa = *reinterpret_cast<const bf16x8*>(&Qs[buf][q_nat + qs * 32 * C::KSTR + ks * 16]);
+          const bf16x8 da = *reinterpret_cast<const bf16x8*>(&Ds[buf][q_nat + qs * 32 * C::KSTR + ks * 16]);
+          s = mfma32(qa, kf[ks], s);
+          dp = mfma32(da, vf[ks], dp);
+        }
+        bf16x8 pf[2], dsf[2];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(&Ls[buf][qs * 32 + 8 * qd + 4 * hh]);
+          const f32x4 d4 = *reinterpret_cast<const f32x4*>(&Dl[buf][qs * 32 + 8 * qd + 4 * hh]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * qd + e;
+            const int query = q0 + qs * 32 + 8 * qd + 4 * hh + e;
+            float pv = (key > query || query >= p.S) ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[r], p.c, -l4[e]));
+            float dpv = dp[r];
+            float pd = pv;
+            if (DROPOUT) {
+              const bool keep = drop_keep((e_bh + (uint32_t)query) * (uint32_t)p.S + (uint32_t)key, p.thr, p.seed_lo, p.seed_hi);
+              dpv = keep ? dpv * p.inv_keep : 0.f;
+              pd = keep ? pv * p.inv_keep : 0.f;
+            }
+            pf[r >> 3][r & 7] = (bf16)pd;
+            dsf[r >> 3][r & 7] = (bf16)(pv * (dpv - d4[e]));
+          }
+        }
+#pragma unroll
+        for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+          for (int cs = 0; cs < 2; ++cs) {
+            const bf16* dt = &Ds[buf][q_tr + (qs * 32 + 16 * cs) * C::KSTR + nb * 32];
+            const bf16* qt_ = &Qs[buf][q_tr + (qs * 32 + 16 * cs) * C::KSTR + nb * 32];
+            const bf16x8 dof = cat4(lds_tr_b64(dt), lds_tr_b64(dt + 8 * C::KSTR));
+            const bf16x8 qf = cat4(lds_tr_b64(qt_), lds_tr_b64(qt_ + 8 * C::KSTR));
+            dvt[nb] = mfma32(dof, pf[cs], dvt[nb]);
+            dkt[nb] = mfma32(qf, dsf[cs], dkt[nb]);
+          }
+      }
+    }
+    if (qt + 1 < nqt) {
+      tile_store<DH, C::KSTR>(rq, Qs[buf ^ 1], tid);
+      tile_store<DH, C::KSTR>(rd, Ds[buf ^ 1], tid);
+      store_stats(buf ^ 1);
+    }
+    __syncthreads();
+  }
+  if (key < p.S) {
+    bf16* dk = p.dk + (int64_t)b * p.sb + (int64_t)key * p.ss + h * DH;
+    bf16* dv = p.dv + (int64_t)b * p.sb + (int64_t)key * p.ss + h * DH;
+#pragma unroll
+    for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        bf16x4 ok, ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          ok[e] = (bf16)(dkt[nb][4 * qd + e] * p.scale);
+          ov[e] = (bf16)dvt[nb][4 * qd + e];
+        }
+        *reinterpret_cast<bf16x4*>(dk + nb * 32 + 8 * qd + 4 * hh) = ok;
+        *reinterpret_cast<bf16x4*>(dv + nb * 32 + 8 * qd + 4 * hh) = ov;
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_dropout_mask_kernel(uint8_t* mask, int64_t total, uint32_t thr,
+                                                                uint32_t slo, uint32_t shi) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
+    mask[i] = thr == 0 ? 1 : (drop_keep((uint32_t)i, thr, slo, shi) ? 1 : 0);
+}
+
+static int fill_params(AttnParams& p, int B, int H, int S, int head_dim, int64_t sb, int64_t ss, int64_t osb,
+                       int64_t oss, float scale, float dropout_p, uint64_t seed) {
+  TTTS_REQUIRE(B > 0 && H > 0 && S > 0, "attn: bad shape B=%d H=%d S=%d", B, H, S);
+  TTTS_REQUIRE(head_dim == 32 || head_dim == 64 || head_dim == 128, "attn: head_dim %d not in {32,64,128}", head_dim);
+  TTTS_REQUIRE(ss % 8 == 0 && sb % 8 == 0 && oss % 8 == 0 && osb % 8 == 0, "attn: strides must be multiples of 8 elements");
+  TTTS_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "attn: dropout_p out of range");
+  TTTS_REQUIRE((int64_t)B * H * S * S < (int64_t)1 << 32 || dropout_p == 0.f, "attn: dropout index space exceeds 2^32");
+  p.B = B; p.H = H; p.S = S;
+  p.sb = sb; p.ss = ss; p.osb = osb; p.oss = oss;
+  p.scale = scale;
+  p.c = scale * LOG2E;
+  p.thr = dropout_threshold(dropout_p);
+  p.inv_keep = p.thr ? 65536.0f / (65536.0f - (float)p.thr) : 1.0f;
+  p.seed_lo = (uint32_t)seed;
+  p.seed_hi = (uint32_t)(seed >> 32);
+  return TTTS_OK;
+}
+
+}  // namespace ttts
+
+using namespace ttts;
+
+extern "C" int ttts_attn_causal_fwd_bf16(const void* q, const void* k, const void* v, void* o, float* lse, int32_t B,
+                                         int32_t H, int32_t S, int32_t head_dim, int64_t qkv_stride_b,
+                                         int64_t qkv_stride_s, int64_t o_stride_b, int64_t o_stride_s, float scale,
+                                         float dropout_p, uint64_t seed, void* stream) {
+  TTTS_REQUIRE(q && k && v && o && lse, "attn_fwd: null pointer");
+  TTTS_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(o), "attn_fwd: 16-byte alignment required");
+  AttnParams p{};
+  int rc = fill_params(p, B, H, S, head_dim, qkv_stride_b, qkv_stride_s, o_stride_b, o_stride_s, scale, dropout_p, seed);
+  if (rc) return rc;
+  p.q = (const bf16*)q; p.k = (const bf16*)k; p.v = (const bf16*)v; p.out = (bf16*)o; p.lse = lse;
+  const int grid = ((S + 127) / 128) * H * B;
+  hipStream_t s = as_stream(stream);
+#define FWD(DH)                                                        \
+  if (p.thr) attn_fwd_kernel<DH, true><<<grid, 256, 0, s>>>(p);        \
+  else attn_fwd_kernel<DH, false><<<grid, 256, 0, s>>>(p);
+  if (head_dim == 32) { FWD(32) } else if (head_dim == 64) { FWD(64) } else { FWD(128) }
+#undef FWD
+  return check_launch("attn_fwd");
+}
+
+extern "C" int64_t ttts_attn_bwd_workspace_bytes(int32_t B, int32_t H, int32_t S) {
+  return (int64_t)B * H * S * (int64_t)sizeof(float);
+}
+
+extern "C" int ttts_attn_causal_bwd_bf16(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                                         const float* lse, void* dq, void* dk, void* dv, void* workspace, int32_t B,
+                                         int32_t H, int32_t S, int32_t head_dim, int64_t qkv_stride_b,
+                                         int64_t qkv_stride_s, int64_t o_stride_b, int64_t o_stride_s, float scale,
+                                         float dropout_p, uint64_t seed, void* stream) {
+  TTTS_REQUIRE(q && k && v && o && d_o && lse && dq && dk && dv && workspace, "attn_bwd: null pointer");
+  TTTS_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(o) && aligned16(d_o) && aligned16(dq) &&
+               aligned16(dk) && aligned16(dv), "attn_bwd: 16-byte alignment required");
+  AttnParams p{};
+  int rc = fill_params(p, B, H, S, head_dim, qkv_stride_b, qkv_stride_s, o_stride_b, o_stride_s, scale, dropout_p, seed);
+  if (rc) return rc;
+  p.q = (const bf16*)q; p.k = (const bf16*)k; p.v = (const bf16*)v; p.o = (const bf16*)o; p.d_o = (const bf16*)d_o;
+  p.lse_in = lse; p.dq = (bf16*)dq; p.dk = (bf16*)dk; p.dv = (bf16*)dv; p.delta = (float*)workspace;
+  hipStream_t s = as_stream(stream);
+  const int grid = ((S + 127) / 128) * H * B;
+  const int dgrid = (int)cdiv((int64_t)B * S * H, 256);
+#define BWD(DH)                                                             \
+  attn_delta_kernel<DH><<<dgrid, 256, 0, s>>>(p);                          \
+  if (p.thr) {                                                              \
+    attn_bwd_dkdv_kernel<DH, true><<<grid, 256, 0, s>>>(p);                 \
+    attn_bwd_dq_kernel<DH, true><<<grid, 256, 0, s>>>(p);                   \
+  } else {                                                                  \
+    attn_bwd_dkdv_kernel<DH, false><<<grid, 256, 0, s>>>(p);                \
+    attn_bwd_dq_kernel<DH, false><<<grid, 256, 0, s>>>(p);                  \
+  }
+  if (head_dim == 32) { BWD(32) } else if (head_dim == 64) { BWD(64) } else { BWD(128) }
+#undef BWD
+  return check_launch("attn_bwd");
+}
+
+extern "C" int ttts_attn_dropout_mask_u8(uint8_t* mask, int32_t B, int32_t H, int32_t S, float dropout_p, uint64_t seed,
+                                         void* stream) {
+  TTTS_REQUIRE(mask && B > 0 && H > 0 && S > 0 && dropout_p >= 0.f && dropout_p < 1.f, "dropout_mask: bad arguments");
+  const int64_t total = (int64_t)B * H * S * S;
+  TTTS_REQUIRE(total < (int64_t)1 << 32, "dropout_mask: index space exceeds 2^32");
+  attn_dropout_mask_kernel<<<(int)std::min<int64_t>(cdiv(total, 256), 8192), 256, 0, as_stream(stream)>>>(
+      mask, total, dropout_threshold(dropout_p), (uint32_t)seed, (uint32_t)(seed >> 32));
+  return check_launch("dropout_mask");
+}

@@ -1,0 +1,120 @@
+// Shared host/device helpers for libttts_hip.so (gfx950 only -- no CUDA / multi-backend paths).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/ttts_hip.h"
+
+namespace ttts {
+
+// ---- error plumbing (thread-local message, no exceptions across the ABI) ---------------------------
+char* error_buffer();
+inline int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(error_buffer(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(TTTS_EHIP, "%s: %s", what, hipGetErrorString(e));
+  return TTTS_OK;
+}
+#define TTTS_REQUIRE(cond, ...) \
+  do {                          \
+    if (!(cond)) return ::ttts::fail(TTTS_EINVAL, __VA_ARGS__); \
+  } while (0)
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- device types ----------------------------------------------------------------------------------
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+constexpr int WAVE = 64;  // CDNA wavefront
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// v_mfma_f32_32x32x16_bf16: D[32x32] += A[32x16] * B[16x32].
+//   A operand: lane l holds A[row = l & 31][k = 8*(l >> 5) + 0..7]
+//   B operand: lane l holds B[k = 8*(l >> 5) + 0..7][col = l & 31]
+//   C/D:       lane l, reg r holds D[row = (r & 3) + 8*(r >> 2) + 4*(l >> 5)][col = l & 31]
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// row index inside a 32x32 accumulator tile held by (reg r, lane-half h = lane >> 5)
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ds_read_b64_tr_b16: within each 16-lane group the 16 lanes x 4 bf16 they address are transposed:
+// result lane i (0..15), element j = the element (i & 3) of the 8-byte chunk addressed by lane 4*j + (i >> 2).
+// With lane i' addressing &tile[k0 + (i' >> 2)][c0 + 4*(i' & 3)] every lane i receives column c0 + i of the
+// 4(k) x 16(c) block: elements tile[k0 + 0..3][c0 + i].
+__device__ __forceinline__ bf16x4 lds_tr_b64(const bf16* p) {
+  s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+  return __builtin_bit_cast(bf16x4, t);
+}
+__device__ __forceinline__ bf16x8 cat4(bf16x4 a, bf16x4 b) {
+  bf16x8 r;
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
+  r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+  return r;
+}
+__device__ __forceinline__ bf16x8 zero8() {
+  bf16x8 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r[i] = (bf16)0.0f;
+  return r;
+}
+
+// counter hash -> 32 random bits (dropout masks; deterministic in (seed, index), same in fwd and bwd)
+__device__ __forceinline__ uint32_t hash32(uint32_t x, uint32_t seed_lo, uint32_t seed_hi) {
+  x ^= seed_lo;
+  x *= 0x9E3779B1u;
+  x ^= x >> 16;
+  x += seed_hi;
+  x *= 0x85EBCA6Bu;
+  x ^= x >> 13;
+  x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  return x;
+}
+// dropout threshold on 16 random bits: keep iff r16 >= thr, thr = round(p * 65536)
+__host__ __device__ inline uint32_t dropout_threshold(float p) {
+  float t = p * 65536.0f + 0.5f;
+  return t <= 0.f ? 0u : (t >= 65535.f ? 65535u : (uint32_t)t);
+}
+
+__device__ __forceinline__ float gelu_new_f(float x) {
+  const float k0 = 0.7978845608028654f;  // sqrt(2/pi)
+  float u = k0 * (x + 0.044715f * x * x * x);
+  return 0.5f * x * (1.0f + tanhf(u));
+}
+__device__ __forceinline__ float gelu_new_grad_f(float x) {
+  const float k0 = 0.7978845608028654f;
+  float x2 = x * x;
+  float u = k0 * (x + 0.044715f * x * x2);
+  float t = tanhf(u);
+  float du = k0 * (1.0f + 3.0f * 0.044715f * x2);
+  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
+}
+
+}  // namespace ttts

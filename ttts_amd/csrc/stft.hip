@@ -1,0 +1,181 @@
+// Mel / STFT front-end (ttts/utils/data_utils.py:52-103): HBM-bound, so a real FFT in LDS (not a DFT-as-GEMM).
+//  stft_mag: workgroup = 16 consecutive frames of one clip.  Per frame: reflect-padded, hann-windowed samples are
+//  packed as an n_fft/2-point complex sequence, transformed by a radix-2 Stockham autosort FFT ping-ponging between
+//  two LDS buffers (one butterfly per thread and pass for n_fft = 1024, two for 2048), unpacked to the n_fft/2+1
+//  one-sided real spectrum, and sqrt(re^2 + im^2 + 1e-6) is parked in an LDS [bin][16 frames] tile so that HBM
+//  writes are 64-byte runs along the frame axis of spec[b][bin][frame].
+//  Twiddles come from a host-computed (double precision) table: fp32 sincos on device would cost ~1e-6 accuracy.
+#include <math.h>
+
+#include <algorithm>
+
+#include "common.hpp"
+
+namespace ttts {
+
+constexpr int STFT_FR = 16;  // frames per workgroup
+
+__global__ __launch_bounds__(256) void stft_mag_kernel(const float* __restrict__ wav, const float* __restrict__ window,
+                                                       const float2* __restrict__ tw, float* __restrict__ spec, int T,
+                                                       int n_fft, int hop, int frames, int log2L) {
+  extern __shared__ __attribute__((aligned(16))) float stft_smem[];
+  const int L = n_fft >> 1;  // complex FFT length
+  float2* buf0 = reinterpret_cast<float2*>(stft_smem);
+  float2* buf1 = buf0 + L;
+  float* outs = reinterpret_cast<float*>(buf1 + L);  // [L + 1][STFT_FR + 1]
+  const int tid = threadIdx.x;
+  const int fblocks = (frames + STFT_FR - 1) / STFT_FR;
+  const int b = blockIdx.x / fblocks;
+  const int f0 = (blockIdx.x % fblocks) * STFT_FR;
+  const int pad = (n_fft - hop) / 2;
+  const float* w = wav + (int64_t)b * T;
+
+  for (int ff = 0; ff < STFT_FR; ++ff) {
+    const int frame = f0 + ff;
+    if (frame >= frames) break;  // block-uniform
+    // 1. windowed, reflect-padded frame packed as z[n] = x[2n] + i x[2n+1]
+    for (int n = tid; n < L; n += 256) {
+      float v[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        int i = frame * hop + 2 * n + e - pad;
+        if (i < 0) i = -i;
+        if (i >= T) i = 2 * (T - 1) - i;
+        v[e] = w[i] * window[2 * n + e];
+      }
+      buf0[n] = make_float2(v[0], v[1]);
+    }
+    __syncthreads();
+    // 2. radix-2 Stockham passes: Ns = 1, 2, ..., L/2
+    float2* src = buf0;
+    float2* dst = buf1;
+    for (int ps = 0; ps < log2L; ++ps) {
+      const int Ns = 1 << ps;
+      for (int j = tid; j < (L >> 1); j += 256) {
+        const int k = j & (Ns - 1);
+        const float2 a = src[j];
+        const float2 bb = src[j + (L >> 1)];
+        const float2 t = tw[k * (n_fft >> (ps + 1))];  // exp(-2 pi i k / (2 Ns))
+        const float2 bt = make_float2(bb.x * t.x - bb.y * t.y, bb.x * t.y + bb.y * t.x);
+        const int j0 = (j << 1) - k;
+        dst[j0] = make_float2(a.x + bt.x, a.y + bt.y);
+        dst[j0 + Ns] = make_float2(a.x - bt.x, a.y - bt.y);
+      }
+      __syncthreads();
+      float2* tmp = src; src = dst; dst = tmp;
+    }
+    // 3. unpack the real spectrum: X[k] = E + w_k O, E = (Z[k] + conj Z[L-k])/2, O = -i (Z[k] - conj Z[L-k])/2
+    for (int k = tid; k <= L; k += 256) {
+      float re, im;
+      if (k == 0 || k == L) {
+        const float2 z0 = src[0];
+        re = (k == 0) ? z0.x + z0.y : z0.x - z0.y;
+        im = 0.f;
+      } else {
+        const float2 zk = src[k];
+        const float2 zc = src[L - k];
+        const float er = 0.5f * (zk.x + zc.x), ei = 0.5f * (zk.y - zc.y);
+        const float orr = 0.5f * (zk.y + zc.y), oi = -0.5f * (zk.x - zc.x);
+        const float2 t = tw[k];
+        re = er + (orr * t.x - oi * t.y);
+        im = ei + (orr * t.y + oi * t.x);
+      }
+      outs[k * (STFT_FR + 1) + ff] = sqrtf(re * re + im * im + 1e-6f);
+    }
+    __syncthreads();
+  }
+  const int nf = min(STFT_FR, frames - f0);
+  for (int i = tid; i < (L + 1) * STFT_FR; i += 256) {
+    const int k = i / STFT_FR, ff = i % STFT_FR;
+    if (ff < nf) spec[((int64_t)b * (L + 1) + k) * frames + f0 + ff] = outs[k * (STFT_FR + 1) + ff];
+  }
+}
+
+// mel[b][m][f] = log(max(sum_k basis[m][k] spec[b][k][f], 1e-5)); tile 32 mels x 64 frames, k chunks of 32
+__global__ __launch_bounds__(256) void mel_log_kernel(const float* __restrict__ spec, const float* __restrict__ basis,
+                                                      float* __restrict__ mel, int n_bins, int n_mels, int frames) {
+  __shared__ float As[32][33];
+  __shared__ float Bs[32][64];
+  const int tid = threadIdx.x, tm = tid >> 6, tf = tid & 63;
+  const int ftiles = (frames + 63) / 64, mtiles = (n_mels + 31) / 32;
+  const int b = blockIdx.x / (ftiles * mtiles);
+  const int rem = blockIdx.x % (ftiles * mtiles);
+  const int m0 = (rem / ftiles) * 32, f0 = (rem % ftiles) * 64;
+  const float* sp = spec + (int64_t)b * n_bins * frames;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < n_bins; k0 += 32) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * 256, m = e >> 5, k = e & 31;
+      As[m][k] = (m0 + m < n_mels && k0 + k < n_bins) ? basis[(int64_t)(m0 + m) * n_bins + k0 + k] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = tid + i * 256, k = e >> 6, f = e & 63;
+      Bs[k][f] = (k0 + k < n_bins && f0 + f < frames) ? sp[(int64_t)(k0 + k) * frames + f0 + f] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+      const float bv = Bs[k][tf];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = fmaf(As[tm * 8 + i][k], bv, acc[i]);
+    }
+    __syncthreads();
+  }
+  if (f0 + tf < frames) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + tm * 8 + i;
+      if (m < n_mels) mel[((int64_t)b * n_mels + m) * frames + f0 + tf] = logf(fmaxf(acc[i], 1e-5f));
+    }
+  }
+}
+
+}  // namespace ttts
+
+using namespace ttts;
+
+extern "C" int ttts_stft_twiddle_host(float* host_out, int32_t n_fft) {
+  TTTS_REQUIRE(host_out && n_fft >= 4 && (n_fft & (n_fft - 1)) == 0, "stft_twiddle: n_fft must be a power of two");
+  for (int k = 0; k < n_fft / 2; ++k) {
+    const double a = -2.0 * M_PI * (double)k / (double)n_fft;
+    host_out[2 * k] = (float)cos(a);
+    host_out[2 * k + 1] = (float)sin(a);
+  }
+  return TTTS_OK;
+}
+
+extern "C" int ttts_stft_mag_fwd_f32(const float* wav, const float* window, const float* twiddle, float* spec,
+                                     int32_t B, int32_t T, int32_t n_fft, int32_t hop, void* stream) {
+  TTTS_REQUIRE(wav && window && twiddle && spec, "stft: null pointer");
+  TTTS_REQUIRE(n_fft >= 64 && n_fft <= 4096 && (n_fft & (n_fft - 1)) == 0, "stft: n_fft must be a power of two in [64, 4096]");
+  TTTS_REQUIRE(hop > 0 && hop <= n_fft && B > 0, "stft: bad hop / batch");
+  const int pad = (n_fft - hop) / 2;
+  TTTS_REQUIRE(T > pad, "stft: reflect padding needs T > (n_fft - hop)/2");
+  TTTS_REQUIRE(T + 2 * pad >= n_fft, "stft: clip shorter than one frame");
+  const int frames = (T + 2 * pad - n_fft) / hop + 1;
+  const int L = n_fft / 2;
+  int log2L = 0;
+  while ((1 << log2L) < L) ++log2L;
+  const size_t smem = (size_t)2 * L * sizeof(float2) + (size_t)(L + 1) * (STFT_FR + 1) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stft_mag_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return fail(TTTS_EHIP, "stft: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  const int grid = B * (int)cdiv(frames, STFT_FR);
+  stft_mag_kernel<<<grid, 256, smem, as_stream(stream)>>>(wav, window, reinterpret_cast<const float2*>(twiddle), spec, T,
+                                                          n_fft, hop, frames, log2L);
+  return check_launch("stft_mag_fwd");
+}
+
+extern "C" int ttts_mel_log_fwd_f32(const float* spec, const float* basis, float* mel, int32_t B, int32_t n_bins,
+                                    int32_t n_mels, int32_t frames, void* stream) {
+  TTTS_REQUIRE(spec && basis && mel && B > 0 && n_bins > 0 && n_mels > 0 && frames > 0, "mel_log: bad arguments");
+  const int grid = B * (int)cdiv(frames, 64) * (int)cdiv(n_mels, 32);
+  mel_log_kernel<<<grid, 256, 0, as_stream(stream)>>>(spec, basis, mel, n_bins, n_mels, frames);
+  return check_launch("mel_log_fwd");
+}

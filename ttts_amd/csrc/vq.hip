@@ -1,0 +1,267 @@
+// VQ codebook kernels (ttts/vqvae/core_vq.py:174-230, 303-322): exact-fp32 nearest code, commitment loss,
+// EMA codebook update by scatter-add (the reference's 4096 x 1024 one-hot matrix is never materialised).
+//
+// Nearest code: distances must be IEEE fp32 in the reference's expression order
+//     dist = -((|x|^2 - 2*dot) + |e|^2),  argmax, ties -> lowest index          (core_vq.py:176-181)
+// so the contraction runs on the f32-input MFMA v_mfma_f32_32x32x2_f32, which is bit-for-bit a k-ordered
+// fmaf chain (no reduced-precision path exists on gfx950).  The MFMA is issued with the CODEBOOK as the A
+// operand so that each lane owns one x-row (column) and 16 codes per 32-code tile in its accumulator
+// registers: the running arg-max is an in-register scan in increasing code order.
+#include <algorithm>
+
+#include "common.hpp"
+
+namespace ttts {
+
+constexpr int VQ_ROWS = 32;    // x rows per workgroup
+constexpr int VQ_CODES = 128;  // codes staged per iteration (4 waves x 32)
+
+// |e|^2 per code: sequential fmaf chain in k order (defines the reference value used by every row)
+__global__ __launch_bounds__(256) void vq_code_norm_kernel(const float* __restrict__ e, float* __restrict__ e2, int K,
+                                                           int D) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  float s = 0.f;
+  for (int d = 0; d < D; ++d) s = fmaf(e[(int64_t)k * D + d], e[(int64_t)k * D + d], s);
+  e2[k] = s;
+}
+
+__global__ __launch_bounds__(256) void vq_nearest_kernel(const float* __restrict__ x, const float* __restrict__ cb,
+                                                         const float* __restrict__ e2, int64_t* __restrict__ idx,
+                                                         float* __restrict__ xq, float* __restrict__ best_dist, int N,
+                                                         int K, int D) {
+  extern __shared__ __attribute__((aligned(16))) float vq_smem[];
+  const int LD = D + 1;  // +1 float pad: lanes (rows) hit distinct banks at a fixed k
+  float* xs = vq_smem;                       // [VQ_ROWS][LD]
+  float* es = xs + VQ_ROWS * LD;             // [VQ_CODES][LD]
+  float* red_d = es + VQ_CODES * LD;         // [4][VQ_ROWS]
+  int* red_i = reinterpret_cast<int*>(red_d + 4 * VQ_ROWS);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+  const int r0 = blockIdx.x * VQ_ROWS;
+  for (int i = tid; i < VQ_ROWS * D; i += 256) {
+    const int r = i / D, d = i % D;
+    xs[r * LD + d] = (r0 + r < N) ? x[(int64_t)(r0 + r) * D + d] : 0.f;
+  }
+  __syncthreads();
+  const float* xrow = xs + (lane & 31) * LD;
+  float x2 = 0.f;
+  for (int d = 0; d < D; ++d) x2 = fmaf(xrow[d], xrow[d], x2);
+  float best = -INFINITY;
+  int best_i = 0;
+  for (int c0 = 0; c0 < K; c0 += VQ_CODES) {
+    __syncthreads();
+    for (int i = tid; i < VQ_CODES * D; i += 256) {
+      const int c = i / D, d = i % D;
+      es[c * LD + d] = (c0 + c < K) ? cb[(int64_t)(c0 + c) * D + d] : 0.f;
+    }
+    __syncthreads();
+    const int cw = c0 + wave * 32;  // this wave's 32 codes
+    if (cw < K) {
+      const float* erow = es + (wave * 32 + (lane & 31)) * LD;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      for (int d = 0; d < D; d += 2) {
+        // A[i = code][k = hh], B[k = hh][j = x row]: D[code][row] += e[code][d+hh] * x[row][d+hh]
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(erow[d + hh], xrow[d + hh], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int code = cw + acc_row(r, hh);
+        if (code < K) {
+          const float dist = -((x2 - 2.0f * acc[r]) + e2[code]);
+          if (dist > best) { best = dist; best_i = code; }
+        }
+      }
+    }
+  }
+  // merge the two lane halves, then the four waves (ties -> lowest index)
+  {
+    const float od = __shfl_xor(best, 32, 64);
+    const int oi = __shfl_xor(best_i, 32, 64);
+    if (od > best || (od == best && oi < best_i)) { best = od; best_i = oi; }
+  }
+  if (lane < 32) {
+    red_d[wave * VQ_ROWS + lane] = best;
+    red_i[wave * VQ_ROWS + lane] = best_i;
+  }
+  __syncthreads();
+  if (tid < VQ_ROWS) {
+    float bd = red_d[tid];
+    int bi = red_i[tid];
+    for (int w = 1; w < 4; ++w) {
+      const float od = red_d[w * VQ_ROWS + tid];
+      const int oi = red_i[w * VQ_ROWS + tid];
+      if (od > bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+    }
+    red_i[tid] = bi;
+    if (r0 + tid < N) {
+      idx[r0 + tid] = (int64_t)bi;
+      if (best_dist) best_dist[r0 + tid] = bd;
+    }
+  }
+  __syncthreads();
+  if (xq) {
+    for (int i = tid; i < VQ_ROWS * D; i += 256) {
+      const int r = i / D, d = i % D;
+      if (r0 + r < N) xq[(int64_t)(r0 + r) * D + d] = cb[(int64_t)red_i[r] * D + d];
+    }
+  }
+}
+
+// commitment: t = x + (xq - x); loss = mean((t - x)^2); dx += gs * 2 (x - t) / n
+__global__ __launch_bounds__(256) void vq_commit_kernel(const float* __restrict__ x, const float* __restrict__ xq,
+                                                        float* __restrict__ dx, float gscale, int64_t n,
+                                                        double* __restrict__ partial) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float xv = x[i];
+    const float t = xv + (xq[i] - xv);
+    const float df = t - xv;
+    s += df * df;
+    if (dx) dx[i] += gscale * 2.0f * (xv - t) / (float)n;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = ((double)sh[0] + sh[1]) + ((double)sh[2] + sh[3]);
+}
+__global__ __launch_bounds__(256) void vq_commit_final_kernel(const double* __restrict__ partial, int nblk, int64_t n,
+                                                              float* __restrict__ loss) {
+  __shared__ double sh[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += 256) s += partial[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *loss = (float)(((sh[0] + sh[1]) + (sh[2] + sh[3])) / (double)n);
+}
+
+// EMA update ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vq_ema_scatter_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx,
+                                                             float* __restrict__ counts, float* __restrict__ sums,
+                                                             int N, int D) {
+  const int D4 = D >> 2;
+  const int64_t total = (int64_t)N * D4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int n = (int)(i / D4), d4 = (int)(i % D4);
+    const int64_t k = idx[n];
+    const float4 v = reinterpret_cast<const float4*>(x + (int64_t)n * D)[d4];
+    float* dst = sums + k * D + d4 * 4;
+    atomicAdd(dst + 0, v.x);
+    atomicAdd(dst + 1, v.y);
+    atomicAdd(dst + 2, v.z);
+    atomicAdd(dst + 3, v.w);
+    if (d4 == 0) atomicAdd(counts + k, 1.0f);
+  }
+}
+// single block: cluster_size EMA + Laplace-smoothed sizes -> smoothed[K] (workspace)
+__global__ __launch_bounds__(1024) void vq_ema_sizes_kernel(float* __restrict__ cluster_size,
+                                                            const float* __restrict__ counts,
+                                                            float* __restrict__ smoothed, int K, float decay,
+                                                            float eps) {
+  __shared__ double sh[16];
+  __shared__ float total_s;
+  double s = 0.0;
+  for (int k = threadIdx.x; k < K; k += 1024) {
+    const float cs = cluster_size[k] * decay + counts[k] * (1.0f - decay);
+    cluster_size[k] = cs;
+    s += (double)cs;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < 16; ++i) t += sh[i];
+    total_s = (float)t;
+  }
+  __syncthreads();
+  const float tot = total_s;
+  for (int k = threadIdx.x; k < K; k += 1024)
+    smoothed[k] = (cluster_size[k] + eps) / (tot + (float)K * eps) * tot;
+}
+__global__ __launch_bounds__(256) void vq_ema_embed_kernel(float* __restrict__ embed_avg, float* __restrict__ embed,
+                                                           const float* __restrict__ sums,
+                                                           const float* __restrict__ smoothed, int K, int D,
+                                                           float decay) {
+  const int64_t total = (int64_t)K * D;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int k = (int)(i / D);
+    const float a = embed_avg[i] * decay + sums[i] * (1.0f - decay);
+    embed_avg[i] = a;
+    embed[i] = a / smoothed[k];
+  }
+}
+
+}  // namespace ttts
+
+using namespace ttts;
+
+extern "C" int64_t ttts_vq_workspace_bytes(int32_t N, int32_t K) {
+  (void)N;
+  return (int64_t)K * (int64_t)sizeof(float) + 1024 * (int64_t)sizeof(double);
+}
+
+extern "C" int ttts_vq_nearest_f32(const float* x, const float* codebook, int64_t* idx, float* xq, float* best_dist,
+                                   void* workspace, int32_t N, int32_t K, int32_t D, void* stream) {
+  TTTS_REQUIRE(x && codebook && idx && workspace, "vq_nearest: null pointer");
+  TTTS_REQUIRE(N > 0 && K > 0 && D > 0 && D % 2 == 0 && D <= 256, "vq_nearest: need even D <= 256 (D=%d)", D);
+  hipStream_t s = as_stream(stream);
+  float* e2 = reinterpret_cast<float*>(workspace);
+  vq_code_norm_kernel<<<(int)cdiv(K, 256), 256, 0, s>>>(codebook, e2, K, D);
+  int rc = check_launch("vq_code_norm");
+  if (rc) return rc;
+  const size_t smem = ((size_t)(VQ_ROWS + VQ_CODES) * (D + 1) + 8 * VQ_ROWS) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(vq_nearest_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return fail(TTTS_EHIP, "vq_nearest: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  vq_nearest_kernel<<<(int)cdiv(N, VQ_ROWS), 256, smem, s>>>(x, codebook, e2, idx, xq, best_dist, N, K, D);
+  return check_launch("vq_nearest");
+}
+
+extern "C" int ttts_vq_commit_f32(const float* x, const float* xq, float* loss, float* dx, float grad_scale, int32_t N,
+                                  int32_t D, void* workspace, void* stream) {
+  TTTS_REQUIRE(x && xq && loss && workspace && N > 0 && D > 0, "vq_commit: bad arguments");
+  const int64_t n = (int64_t)N * D;
+  const int nblk = (int)std::min<int64_t>(1024, cdiv(n, 256));
+  double* partial = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + 0);
+  hipStream_t s = as_stream(stream);
+  vq_commit_kernel<<<nblk, 256, 0, s>>>(x, xq, dx, grad_scale, n, partial);
+  int rc = check_launch("vq_commit");
+  if (rc) return rc;
+  vq_commit_final_kernel<<<1, 256, 0, s>>>(partial, nblk, n, loss);
+  return check_launch("vq_commit_final");
+}
+
+extern "C" int64_t ttts_vq_ema_workspace_bytes(int32_t K, int32_t D) {
+  return ((int64_t)K * D + 2 * (int64_t)K) * (int64_t)sizeof(float);
+}
+
+extern "C" int ttts_vq_ema_update_f32(const float* x, const int64_t* idx, float* cluster_size, float* embed_avg,
+                                      float* embed, void* workspace, int32_t N, int32_t K, int32_t D, float decay,
+                                      float epsilon, void* stream) {
+  TTTS_REQUIRE(x && idx && cluster_size && embed_avg && embed && workspace, "vq_ema: null pointer");
+  TTTS_REQUIRE(N > 0 && K > 0 && D > 0 && D % 4 == 0, "vq_ema: need D %% 4 == 0");
+  hipStream_t s = as_stream(stream);
+  float* sums = reinterpret_cast<float*>(workspace);
+  float* counts = sums + (int64_t)K * D;
+  float* smoothed = counts + K;
+  hipError_t e = hipMemsetAsync(workspace, 0, ((size_t)K * D + K) * sizeof(float), s);
+  if (e != hipSuccess) return fail(TTTS_EHIP, "vq_ema: memset: %s", hipGetErrorString(e));
+  vq_ema_scatter_kernel<<<(int)std::min<int64_t>(2048, cdiv((int64_t)N * (D / 4), 256)), 256, 0, s>>>(x, idx, counts, sums, N, D);
+  int rc = check_launch("vq_ema_scatter");
+  if (rc) return rc;
+  vq_ema_sizes_kernel<<<1, 1024, 0, s>>>(cluster_size, counts, smoothed, K, decay, epsilon);
+  rc = check_launch("vq_ema_sizes");
+  if (rc) return rc;
+  vq_ema_embed_kernel<<<(int)std::min<int64_t>(2048, cdiv((int64_t)K * D, 256)), 256, 0, s>>>(embed_avg, embed, sums, smoothed, K, D, decay);
+  return check_launch("vq_ema_embed");
+}

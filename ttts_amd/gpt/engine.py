@@ -1,0 +1,363 @@
+"""GPT train-step engine: the MI355X-native restatement of the reference's hot loop body
+
+    loss_text, loss_mel, mel_logits = UnifiedVoice(...)(text, text_lengths, mel, wav_lengths)    ttts/gpt/model.py:453-510
+    loss.backward(); clip_grad_norm_(1.0); AdamW.step(); LambdaLR.step()                          ttts/gpt/train.py:104-120
+
+as a fixed sequence of hand-written HIP kernels (C ABI, `ttts_amd.ops`) over memory laid out once for the GPU:
+
+* ONE flat fp32 arena each for parameters, gradients and the two Adam moments (state-dict tensors are views into
+  it, so the 84 `.item()` grad-norm syncs / 84 optimizer launches of the reference collapse to 3 launches);
+* a flat bf16 "shadow" of the parameters written by the AdamW kernel, plus transposed bf16 copies of the GEMM
+  weights, so that every forward / dX GEMM reads both operands K-contiguously;
+* an fp32 residual stream with one saved copy per LayerNorm input (no gradient checkpointing: 288 GB of HBM make the
+  reference's recompute-to-save-memory trade unnecessary; results are identical);
+* text and mel rows of the final hidden state in a split layout so each head GEMM sees contiguous rows.
+
+The whole step is free of host reads of device data, hence capturable in one hipGraph (`capture=True`).
+"""
+import math
+
+import torch
+
+from .. import ops
+from ..lib import EPI_DGELU_BF16, EPI_GELU_BF16, EPI_RESID_ADD_F32, EPI_STORE_BF16, TttsError
+
+DEFAULTS = dict(layers=8, model_dim=512, heads=8, max_text_tokens=120, max_mel_tokens=250,
+                max_conditioning_inputs=1, mel_length_compression=1024, number_text_tokens=256,
+                start_text_token=None, number_mel_codes=8194, start_mel_token=8192, stop_mel_token=8193,
+                train_solo_embeddings=False, use_mel_codes_as_input=True, checkpointing=True, types=1)
+
+
+def resolve_config(cfg):
+    """UnifiedVoice constructor arguments with the reference's defaults (ttts/gpt/model.py:293-297,316-318)."""
+    c = dict(DEFAULTS)
+    c.update(cfg or {})
+    if c["start_text_token"] is None:
+        c["start_text_token"] = c["number_text_tokens"] * c["types"]
+    c["stop_text_token"] = 0
+    if not c["use_mel_codes_as_input"] or c["train_solo_embeddings"]:
+        raise NotImplementedError("ttts_amd covers the live training path: use_mel_codes_as_input=True, "
+                                  "train_solo_embeddings=False (ttts/gpt/config.json:20,28)")
+    if c["model_dim"] % c["heads"] or c["model_dim"] // c["heads"] not in (32, 64, 128):
+        raise NotImplementedError("head_dim must be 32, 64 or 128")
+    return c
+
+
+def param_spec(c):
+    """(key, shape) in the reference's state-dict order (tests/golden/surface.json pins it)."""
+    d, L = c["model_dim"], c["layers"]
+    nt = c["number_text_tokens"] * c["types"] + 1
+    spec = [("text_embedding.weight", (nt, d)), ("mel_embedding.weight", (c["number_mel_codes"], d))]
+    for i in range(L):
+        p = "gpt.h.%d." % i
+        spec += [(p + "ln_1.weight", (d,)), (p + "ln_1.bias", (d,)),
+                 (p + "attn.c_attn.weight", (d, 3 * d)), (p + "attn.c_attn.bias", (3 * d,)),
+                 (p + "attn.c_proj.weight", (d, d)), (p + "attn.c_proj.bias", (d,)),
+                 (p + "ln_2.weight", (d,)), (p + "ln_2.bias", (d,)),
+                 (p + "mlp.c_fc.weight", (d, 4 * d)), (p + "mlp.c_fc.bias", (4 * d,)),
+                 (p + "mlp.c_proj.weight", (4 * d, d)), (p + "mlp.c_proj.bias", (d,))]
+    spec += [("gpt.ln_f.weight", (d,)), ("gpt.ln_f.bias", (d,)),
+             ("mel_pos_embedding.emb.weight", (c["max_mel_tokens"] + 2, d)),
+             ("text_pos_embedding.emb.weight", (c["max_text_tokens"] + 2, d)),
+             ("final_norm.weight", (d,)), ("final_norm.bias", (d,)),
+             ("text_head.weight", (nt, d)), ("text_head.bias", (nt,)),
+             ("mel_head.weight", (c["number_mel_codes"], d)), ("mel_head.bias", (c["number_mel_codes"],))]
+    return spec
+
+
+def _up(x, m):
+    return (x + m - 1) // m * m
+
+
+class GptEngine:
+    """Owns the arenas and activation buffers of one model replica on one GPU."""
+
+    def __init__(self, cfg, device, dropout_p=0.1, seed=0):
+        if not torch.cuda.is_available():
+            raise TttsError("ttts_amd needs a ROCm GPU: there is no CPU path (the oracle lives in oracle/, for tests)")
+        self.c = resolve_config(cfg)
+        self.device = torch.device(device)
+        self.dropout_p = float(dropout_p)   # HF GPT2Config default embd/attn/resid_pdrop = 0.1
+        self.training = True
+        self.seed = int(seed)
+        self.step_count = 0                 # host mirror of the device step counter (seeds dropout streams)
+        self.spec = param_spec(self.c)
+        self.shapes = dict(self.spec)
+        self.offsets = {}
+        off = 0
+        for k, shp in self.spec:
+            self.offsets[k] = off
+            off += _up(math.prod(shp), 8)   # 8-element granule: fp32 float4 and bf16 16-byte alignment
+        self.n_arena = off
+        dev = self.device
+        self.params = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.shadow = torch.zeros(off, dtype=torch.bfloat16, device=dev)
+        self.opt_state = torch.zeros(8, dtype=torch.float32, device=dev)
+        self.gn_ws = ops.gradnorm_workspace(off, dev)
+        d = self.c["model_dim"]
+        self.nt = self.c["number_text_tokens"] * self.c["types"] + 1
+        self.nm = self.c["number_mel_codes"]
+        self.ld_t, self.ld_m = _up(self.nt, 8), _up(self.nm, 8)
+        # transposed bf16 shadows: forward B operands of the Conv1D layers, dX B operands of the heads
+        self.wT = {}
+        entries = []
+        for i in range(self.c["layers"]):
+            for nm in ("attn.c_attn", "attn.c_proj", "mlp.c_fc", "mlp.c_proj"):
+                k = "gpt.h.%d.%s.weight" % (i, nm)
+                src = self.view(self.params, k)
+                t = torch.zeros(src.shape[1], src.shape[0], dtype=torch.bfloat16, device=dev)
+                self.wT[k] = t
+                entries.append((src, None, t))
+        for k, ld in (("text_head.weight", self.ld_t), ("mel_head.weight", self.ld_m)):
+            src = self.view(self.params, k)
+            t = torch.zeros(d, ld, dtype=torch.bfloat16, device=dev)   # [in, out padded]; pad columns stay zero
+            self.wT[k] = t
+            entries.append((src, None, t[:, :src.shape[0]]))
+        self.cast_plan = ops.CastPlan(entries, dev)
+        self._bufs_key = None
+        self._graph = None
+        self._graph_key = None
+
+    # ---- parameter plumbing -------------------------------------------------------------------------------
+    def view(self, arena, key):
+        shp = self.shapes[key]
+        o = self.offsets[key]
+        return arena[o:o + math.prod(shp)].view(shp)
+
+    def w(self, key):
+        """bf16 shadow of a parameter in its stored layout."""
+        return self.view(self.shadow, key)
+
+    def refresh_shadows(self):
+        """After parameters were written from outside (init / load_state_dict)."""
+        self.shadow.copy_(self.params)
+        self.cast_plan.run()
+
+    def load_state_dict(self, sd):
+        missing = [k for k, _ in self.spec if k not in sd]
+        if missing:
+            raise KeyError("missing keys: %s" % missing[:4])
+        with torch.no_grad():
+            for k, shp in self.spec:
+                if tuple(sd[k].shape) != tuple(shp):
+                    raise ValueError("shape mismatch for %s: %s vs %s" % (k, tuple(sd[k].shape), shp))
+                self.view(self.params, k).copy_(sd[k].to(device=self.device, dtype=torch.float32))
+        self.refresh_shadows()
+
+    def state_dict(self):
+        return {k: self.view(self.params, k).detach().clone() for k, _ in self.spec}
+
+    # ---- buffers ----------------------------------------------------------------------------------------------
+    def _ensure_buffers(self, B, Tt, Tm):
+        key = (B, Tt, Tm)
+        if self._bufs_key == key:
+            return
+        c, dev = self.c, self.device
+        D, L, H = c["model_dim"], c["layers"], c["heads"]
+        S = Tt + Tm
+        M = B * S
+        f32, bf = torch.float32, torch.bfloat16
+        e = lambda *s, dt=bf: torch.empty(*s, dtype=dt, device=dev)  # noqa: E731
+        b = {}
+        b["xs"] = [e(M, D, dt=f32) for _ in range(2 * L + 1)]
+        b["ln1"] = [e(M, D) for _ in range(L)]
+        b["ln2"] = [e(M, D) for _ in range(L)]
+        b["stats"] = [[e(M, dt=f32) for _ in range(4)] for _ in range(L)]   # mean1, rstd1, mean2, rstd2
+        b["qkv"] = [e(M, 3 * D) for _ in range(L)]
+        b["att"] = [e(M, D) for _ in range(L)]
+        b["lse"] = [e(B * H * S, dt=f32) for _ in range(L)]
+        b["fc_pre"] = [e(M, 4 * D) for _ in range(L)]
+        b["fc_act"] = [e(M, 4 * D) for _ in range(L)]
+        b["lnf"] = e(M, D, dt=f32)
+        b["fstats"] = [e(M, dt=f32) for _ in range(4)]
+        b["enc"] = e(M, D)                                   # split layout: text rows, then mel rows
+        b["logits_t"] = torch.zeros(B * Tt, self.ld_t, dtype=bf, device=dev)
+        b["logits_m"] = torch.zeros(B * Tm, self.ld_m, dtype=bf, device=dev)
+        b["rows_t"] = [e(B * Tt, dt=f32) for _ in range(2)]  # row_loss, row_lse
+        b["rows_m"] = [e(B * Tm, dt=f32) for _ in range(2)]
+        b["losses"] = torch.zeros(2, dtype=f32, device=dev)  # loss_text, loss_mel
+        # backward temporaries
+        b["dlog_t"] = torch.zeros(B * Tt, self.ld_t, dtype=bf, device=dev)
+        b["dlog_m"] = torch.zeros(B * Tm, self.ld_m, dtype=bf, device=dev)
+        b["d_enc"] = e(M, D)
+        b["d_tmp"] = e(M, D, dt=f32)
+        b["dres"] = e(M, D, dt=f32)
+        b["dres_bf"] = e(M, D)
+        b["d_fc"] = e(M, 4 * D)
+        b["d_ln"] = e(M, D)
+        b["d_att"] = e(M, D)
+        b["dqkv"] = e(M, 3 * D)
+        b["delta"] = e(B * H * S, dt=f32)
+        b["ln_ws"] = ops.layernorm_bwd_workspace(M, D, dev)
+        # static token buffers (graph replay reads them)
+        i64 = torch.int64
+        b["text_inp"] = torch.zeros(B, Tt, dtype=i64, device=dev)
+        b["text_tar"] = torch.zeros(B * Tt, dtype=i64, device=dev)
+        b["mel_inp"] = torch.zeros(B, Tm, dtype=i64, device=dev)
+        b["mel_tar"] = torch.zeros(B * Tm, dtype=i64, device=dev)
+        self.b = b
+        self._bufs_key = key
+        self._graph = None
+
+    def set_tokens(self, text_inp, text_tar, mel_inp, mel_tar):
+        B, Tt = text_inp.shape
+        Tm = mel_inp.shape[1]
+        if Tt > self.c["max_text_tokens"] + 2 or Tm > self.c["max_mel_tokens"] + 2:
+            raise ValueError("sequence exceeds the learned position tables (text %d, mel %d)" % (Tt, Tm))
+        self._ensure_buffers(B, Tt, Tm)
+        b = self.b
+        b["text_inp"].copy_(text_inp, non_blocking=True)
+        b["text_tar"].copy_(text_tar.reshape(-1), non_blocking=True)
+        b["mel_inp"].copy_(mel_inp, non_blocking=True)
+        b["mel_tar"].copy_(mel_tar.reshape(-1), non_blocking=True)
+
+    # ---- dropout seeds: one stream per (step, site) ------------------------------------------------------------
+    def _p(self):
+        return self.dropout_p if self.training else 0.0
+
+    def _seed(self, site):
+        return (self.seed * 0x9E3779B97F4A7C15 + self.step_count * 0x100000001B3 + site * 0x632BE59BD9B4E019) & (2 ** 64 - 1)
+
+    # ---- forward ---------------------------------------------------------------------------------------------
+    def forward(self):
+        """Runs on the tokens last given to set_tokens(); fills b['losses'], b['logits_*']."""
+        c, b = self.c, self.b
+        B, Tt, Tm = self._bufs_key
+        D, L, H = c["model_dim"], c["layers"], c["heads"]
+        S, dh = Tt + Tm, D // H
+        p = self._p()
+        P = lambda k: self.view(self.params, k)  # noqa: E731
+        ops.embed_fwd(b["text_inp"], b["mel_inp"], P("text_embedding.weight"), P("text_pos_embedding.emb.weight"),
+                      P("mel_embedding.weight"), P("mel_pos_embedding.emb.weight"), b["xs"][0], p, self._seed(1))
+        for i in range(L):
+            pre = "gpt.h.%d." % i
+            x0, x1, x2 = b["xs"][2 * i], b["xs"][2 * i + 1], b["xs"][2 * i + 2]
+            st = b["stats"][i]
+            ops.layernorm_fwd(x0, P(pre + "ln_1.weight"), P(pre + "ln_1.bias"), b["ln1"][i], st[0], st[1])
+            ops.gemm_nt(b["ln1"][i], self.wT[pre + "attn.c_attn.weight"], b["qkv"][i], P(pre + "attn.c_attn.bias"))
+            qkv = b["qkv"][i]
+            ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], b["att"][i], b["lse"][i], B, H, S, dh, (S * 3 * D, 3 * D),
+                         (S * D, D), dh ** -0.5, p, self._seed(16 * i + 2))
+            ops.gemm_nt(b["att"][i], self.wT[pre + "attn.c_proj.weight"], x1, P(pre + "attn.c_proj.bias"),
+                        epilogue=EPI_RESID_ADD_F32, resid_in=x0, dropout_p=p, seed=self._seed(16 * i + 3))
+            ops.layernorm_fwd(x1, P(pre + "ln_2.weight"), P(pre + "ln_2.bias"), b["ln2"][i], st[2], st[3])
+            ops.gemm_nt(b["ln2"][i], self.wT[pre + "mlp.c_fc.weight"], b["fc_act"][i], P(pre + "mlp.c_fc.bias"),
+                        aux=b["fc_pre"][i], epilogue=EPI_GELU_BF16)
+            ops.gemm_nt(b["fc_act"][i], self.wT[pre + "mlp.c_proj.weight"], x2, P(pre + "mlp.c_proj.bias"),
+                        epilogue=EPI_RESID_ADD_F32, resid_in=x1, dropout_p=p, seed=self._seed(16 * i + 4))
+        fs = b["fstats"]
+        ops.layernorm_fwd(b["xs"][2 * L], P("gpt.ln_f.weight"), P("gpt.ln_f.bias"), b["lnf"], fs[0], fs[1])
+        ops.layernorm_fwd(b["lnf"], P("final_norm.weight"), P("final_norm.bias"), b["enc"], fs[2], fs[3],
+                          split=(S, Tt))
+        enc_t, enc_m = b["enc"][:B * Tt], b["enc"][B * Tt:]
+        ops.gemm_nt(enc_t, self.w("text_head.weight"), b["logits_t"], P("text_head.bias"), n=self.nt)
+        ops.gemm_nt(enc_m, self.w("mel_head.weight"), b["logits_m"], P("mel_head.bias"), n=self.nm)
+        ops.ce_fwd(b["logits_t"], b["text_tar"], b["rows_t"][0], b["rows_t"][1], b["losses"][0:1], self.nt)
+        ops.ce_fwd(b["logits_m"], b["mel_tar"], b["rows_m"][0], b["rows_m"][1], b["losses"][1:2], self.nm)
+
+    # ---- backward ----------------------------------------------------------------------------------------------
+    def backward(self, w_text=0.01, w_mel=1.0, g_text_dev=None, g_mel_dev=None):
+        """Accumulates d(w_text*loss_text + w_mel*loss_mel) into self.grads (optionally scaled by device scalars)."""
+        c, b = self.c, self.b
+        B, Tt, Tm = self._bufs_key
+        D, L, H = c["model_dim"], c["layers"], c["heads"]
+        S, dh = Tt + Tm, D // H
+        p = self._p()
+        P = lambda k: self.view(self.params, k)  # noqa: E731
+        G = lambda k: self.view(self.grads, k)   # noqa: E731
+        ops.ce_bwd(b["logits_t"], b["text_tar"], b["rows_t"][1], b["dlog_t"], self.nt, w_text, g_text_dev)
+        ops.ce_bwd(b["logits_m"], b["mel_tar"], b["rows_m"][1], b["dlog_m"], self.nm, w_mel, g_mel_dev)
+        enc_t, enc_m = b["enc"][:B * Tt], b["enc"][B * Tt:]
+        ops.gemm_tn_accum(b["dlog_t"], enc_t, G("text_head.weight"), mo=self.nt)
+        ops.gemm_tn_accum(b["dlog_m"], enc_m, G("mel_head.weight"), mo=self.nm)
+        ops.colsum_accum(b["dlog_t"], G("text_head.bias"), n=self.nt)
+        ops.colsum_accum(b["dlog_m"], G("mel_head.bias"), n=self.nm)
+        ops.gemm_nt(b["dlog_t"], self.wT["text_head.weight"], b["d_enc"][:B * Tt])
+        ops.gemm_nt(b["dlog_m"], self.wT["mel_head.weight"], b["d_enc"][B * Tt:])
+        fs = b["fstats"]
+        ops.layernorm_bwd(b["d_enc"], b["lnf"], P("final_norm.weight"), fs[2], fs[3], None, b["d_tmp"], None,
+                          G("final_norm.weight"), G("final_norm.bias"), b["ln_ws"], split=(S, Tt))
+        ops.layernorm_bwd(b["d_tmp"], b["xs"][2 * L], P("gpt.ln_f.weight"), fs[0], fs[1], None, b["dres"], b["dres_bf"],
+                          G("gpt.ln_f.weight"), G("gpt.ln_f.bias"), b["ln_ws"], dropout_p=p,
+                          seed=self._seed(16 * (L - 1) + 4))
+        for i in reversed(range(L)):
+            pre = "gpt.h.%d." % i
+            st = b["stats"][i]
+            x0, x1 = b["xs"][2 * i], b["xs"][2 * i + 1]
+            dy = b["dres_bf"]                                  # gradient entering mlp.c_proj (resid dropout applied)
+            ops.gemm_tn_accum(b["fc_act"][i], dy, G(pre + "mlp.c_proj.weight"))
+            ops.colsum_accum(dy, G(pre + "mlp.c_proj.bias"))
+            ops.gemm_nt(dy, self.w(pre + "mlp.c_proj.weight"), b["d_fc"], aux=b["fc_pre"][i], epilogue=EPI_DGELU_BF16)
+            ops.gemm_tn_accum(b["ln2"][i], b["d_fc"], G(pre + "mlp.c_fc.weight"))
+            ops.colsum_accum(b["d_fc"], G(pre + "mlp.c_fc.bias"))
+            ops.gemm_nt(b["d_fc"], self.w(pre + "mlp.c_fc.weight"), b["d_ln"])
+            ops.layernorm_bwd(b["d_ln"], x1, P(pre + "ln_2.weight"), st[2], st[3], b["dres"], b["dres"], b["dres_bf"],
+                              G(pre + "ln_2.weight"), G(pre + "ln_2.bias"), b["ln_ws"], dropout_p=p,
+                              seed=self._seed(16 * i + 3))
+            dy = b["dres_bf"]                                  # gradient entering attn.c_proj
+            ops.gemm_tn_accum(b["att"][i], dy, G(pre + "attn.c_proj.weight"))
+            ops.colsum_accum(dy, G(pre + "attn.c_proj.bias"))
+            ops.gemm_nt(dy, self.w(pre + "attn.c_proj.weight"), b["d_att"])
+            qkv, dqkv = b["qkv"][i], b["dqkv"]
+            ops.attn_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], b["att"][i], b["d_att"], b["lse"][i], dqkv, dqkv[:, D:],
+                         dqkv[:, 2 * D:], b["delta"], B, H, S, dh, (S * 3 * D, 3 * D), (S * D, D), dh ** -0.5, p,
+                         self._seed(16 * i + 2))
+            ops.gemm_tn_accum(b["ln1"][i], dqkv, G(pre + "attn.c_attn.weight"))
+            ops.colsum_accum(dqkv, G(pre + "attn.c_attn.bias"))
+            ops.gemm_nt(dqkv, self.w(pre + "attn.c_attn.weight"), b["d_ln"])
+            ops.layernorm_bwd(b["d_ln"], x0, P(pre + "ln_1.weight"), st[0], st[1], b["dres"], b["dres"],
+                              b["dres_bf"] if i > 0 else None, G(pre + "ln_1.weight"), G(pre + "ln_1.bias"),
+                              b["ln_ws"], dropout_p=p if i > 0 else 0.0, seed=self._seed(16 * (i - 1) + 4))
+        ops.embed_bwd(b["text_inp"], b["mel_inp"], b["dres"], G("text_embedding.weight"),
+                      G("text_pos_embedding.emb.weight"), G("mel_embedding.weight"), G("mel_pos_embedding.emb.weight"),
+                      p, self._seed(1))
+
+    # ---- optimizer ---------------------------------------------------------------------------------------------
+    def optimizer_step(self, lr=1e-4, betas=(0.9, 0.96), eps=1e-8, weight_decay=0.01, max_norm=1.0, warmup_steps=500):
+        """get_grad_norm + clip_grad_norm_(1.0) + AdamW.step + zero_grad + LambdaLR(warmup).step
+        (ttts/gpt/train.py:114-120) in four launches; refreshes the bf16 shadows."""
+        ops.adamw_schedule(self.opt_state, lr, betas[0], betas[1], warmup_steps)
+        ops.gradnorm(self.grads, max_norm, self.opt_state, self.gn_ws)
+        ops.adamw(self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.shadow, self.opt_state, betas[0],
+                  betas[1], eps, weight_decay, zero_grad=True)
+        self.cast_plan.run()
+
+    def zero_grad(self):
+        self.grads.zero_()
+
+    # ---- whole step (optionally replayed from one hipGraph) ---------------------------------------------------
+    def train_step(self, tokens, w_text=0.01, w_mel=1.0, capture=False, **opt):
+        """tokens = (text_inp, text_tar, mel_inp, mel_tar) int64 tensors (see model.prepare_tokens).
+        Returns nothing: losses stay on the device in self.b['losses'] (no host sync in the hot loop)."""
+        self.set_tokens(*tokens)
+        if capture and self._p() > 0.0:
+            raise TttsError("graph capture freezes the dropout seeds; capture only with dropout_p = 0 / eval()")
+        if not capture:
+            self.forward()
+            self.backward(w_text, w_mel)
+            self.optimizer_step(**opt)
+        else:
+            key = (self._bufs_key, w_text, w_mel, tuple(sorted(opt.items())))
+            if self._graph is None or self._graph_key != key:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self.forward()
+                    self.backward(w_text, w_mel)
+                    self.optimizer_step(**opt)
+                self._graph, self._graph_key = g, key
+            self._graph.replay()   # capture only records; every step (the first included) is a replay
+        self.step_count += 1
+
+    def losses(self):
+        """(loss_text, loss_mel) as Python floats -- host sync; call it off the hot path."""
+        t = self.b["losses"].tolist()
+        return t[0], t[1]
+
+    def mel_logits(self):
+        """bf16 (B, classes, positions) view, the reference's permuted layout (model.py:441)."""
+        B, Tt, Tm = self._bufs_key
+        return self.b["logits_m"][:, :self.nm].view(B, Tm, self.nm).permute(0, 2, 1)

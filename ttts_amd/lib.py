@@ -1,0 +1,134 @@
+"""ctypes binding of libttts_hip.so (C ABI: include/ttts_hip.h) and the in-tree build recipe.
+
+The library is built IN-TREE (`ttts_amd/libttts_hip.so`, git-ignored, shipped to the GPU box with the snapshot) by
+`build()`: one `hipcc --offload-arch=gfx950 -c` per kernel file, then a shared link.  `get()` loads it and FAILS
+LOUDLY if it is missing -- there is no fallback path.
+"""
+import ctypes
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+BUILD = os.path.join(CSRC, "build")
+SO_PATH = os.path.join(HERE, "libttts_hip.so")
+SOURCES = ["lib.hip", "elementwise.hip", "gemm.hip", "attn.hip", "vq.hip", "stft.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-Wall", "-Wno-unused-variable"]
+
+TTTS_OK = 0
+EPI_STORE_BF16, EPI_GELU_BF16, EPI_RESID_ADD_F32, EPI_DGELU_BF16, EPI_STORE_F32 = range(5)
+
+
+class TttsError(RuntimeError):
+    pass
+
+
+def _needs_rebuild(obj, deps):
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 and link ttts_amd/libttts_hip.so (cross-compiles without a GPU)."""
+    os.makedirs(BUILD, exist_ok=True)
+    headers = [os.path.join(CSRC, "common.hpp"), os.path.join(os.path.dirname(HERE), "include", "ttts_hip.h")]
+    jobs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(BUILD, src.replace(".hip", ".o"))
+        if force or _needs_rebuild(o, [s] + headers):
+            jobs.append([HIPCC] + FLAGS + ["-c", s, "-o", o])
+
+    def run(cmd):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise TttsError("hipcc failed: %s\n%s" % (" ".join(cmd), r.stderr[-4000:]))
+        if verbose and r.stderr.strip():
+            print(r.stderr, file=sys.stderr)
+
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        list(ex.map(run, jobs))
+    objs = [os.path.join(BUILD, s.replace(".hip", ".o")) for s in SOURCES]
+    if force or jobs or _needs_rebuild(SO_PATH, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO_PATH] + objs)
+    return SO_PATH
+
+
+_c = ctypes
+_P, _I32, _I64, _U64, _F = _c.c_void_p, _c.c_int32, _c.c_int64, _c.c_uint64, _c.c_float
+
+
+class CastDesc(ctypes.Structure):
+    _fields_ = [("src", _P), ("dst", _P), ("dst_t", _P), ("rows", _I32), ("cols", _I32), ("tile_begin", _I32),
+                ("ldt", _I32)]
+
+
+# name -> (restype, argtypes); every symbol include/ttts_hip.h declares
+SIGNATURES = {
+    "ttts_abi_version": (_I32, []),
+    "ttts_last_error": (_c.c_char_p, []),
+    "ttts_device_info": (_I32, [_P]),
+    "ttts_gemm_nt_bf16": (_I32, [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "ttts_gemm_nt_bf16_ex": (_I32, [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I32, _I32, _I32, _I32, _P, _F, _U64, _P]),
+    "ttts_gemm_tn_bf16_accum_f32": (_I32, [_P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P]),
+    "ttts_colsum_bf16_accum_f32": (_I32, [_P, _I64, _P, _I32, _I32, _P]),
+    "ttts_cast_desc_tiles": (_I32, [_I32, _I32]),
+    "ttts_cast_bf16_batched": (_I32, [_P, _I32, _I32, _P]),
+    "ttts_attn_causal_fwd_bf16": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _F, _F,
+                                         _U64, _P]),
+    "ttts_attn_bwd_workspace_bytes": (_I64, [_I32, _I32, _I32]),
+    "ttts_attn_causal_bwd_bf16": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I64, _I64,
+                                         _I64, _I64, _F, _F, _U64, _P]),
+    "ttts_attn_dropout_mask_u8": (_I32, [_P, _I32, _I32, _I32, _F, _U64, _P]),
+    "ttts_layernorm_fwd": (_I32, [_P, _P, _P, _P, _I32, _P, _P, _I32, _I32, _F, _I32, _I32, _P]),
+    "ttts_layernorm_bwd_workspace_bytes": (_I64, [_I32, _I32]),
+    "ttts_layernorm_bwd": (_I32, [_P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "ttts_layernorm_bwd_ex": (_I32, [_P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _U64,
+                                     _P]),
+    "ttts_gpt_embed_fwd": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _F, _U64, _P]),
+    "ttts_gpt_embed_bwd": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _U64, _P]),
+    "ttts_ce_fwd_bf16": (_I32, [_P, _I64, _P, _P, _P, _P, _I32, _I32, _P]),
+    "ttts_ce_bwd_bf16": (_I32, [_P, _I64, _P, _P, _P, _F, _P, _I32, _I32, _P]),
+    "ttts_adamw_schedule": (_I32, [_P, _F, _F, _F, _I32, _P]),
+    "ttts_gradnorm_workspace_bytes": (_I64, [_I64]),
+    "ttts_gradnorm_f32": (_I32, [_P, _I64, _F, _P, _P, _P]),
+    "ttts_adamw_f32": (_I32, [_P, _P, _P, _P, _P, _I64, _P, _F, _F, _F, _F, _I32, _P]),
+    "ttts_vq_workspace_bytes": (_I64, [_I32, _I32]),
+    "ttts_vq_nearest_f32": (_I32, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P]),
+    "ttts_vq_commit_f32": (_I32, [_P, _P, _P, _P, _F, _I32, _I32, _P, _P]),
+    "ttts_vq_ema_workspace_bytes": (_I64, [_I32, _I32]),
+    "ttts_vq_ema_update_f32": (_I32, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _F, _F, _P]),
+    "ttts_stft_twiddle_host": (_I32, [_P, _I32]),
+    "ttts_stft_mag_fwd_f32": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "ttts_mel_log_fwd_f32": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "ttts_probe_mfma_layout": (_I32, [_P, _P, _P]),
+}
+
+_lib = None
+
+
+def get():
+    """Load libttts_hip.so (once).  Raises TttsError if it has not been built -- no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise TttsError("libttts_hip.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`"
+                            % SO_PATH)
+        lib = ctypes.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is missing
+            fn.restype, fn.argtypes = res, args
+        if lib.ttts_abi_version() != 1:
+            raise TttsError("libttts_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != TTTS_OK:
+        raise TttsError("%s failed (%d): %s" % (what or "ttts call", rc, get().ttts_last_error().decode()))

@@ -1,0 +1,283 @@
+"""Tensor-level wrappers over the C ABI (include/ttts_hip.h).  PyTorch is plumbing only: device memory,
+the current HIP stream and (elsewhere) torch.distributed.  Every function requires tensors on a ROCm device and
+raises `TttsError` on any failure -- there is no eager / CPU fallback.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import lib as _l
+from .lib import (EPI_DGELU_BF16, EPI_GELU_BF16, EPI_RESID_ADD_F32, EPI_STORE_BF16, EPI_STORE_F32, TttsError, check)
+
+__all__ = ["gemm_nt", "gemm_tn_accum", "colsum_accum", "attn_fwd", "attn_bwd", "layernorm_fwd", "layernorm_bwd",
+           "embed_fwd", "embed_bwd", "ce_fwd", "ce_bwd", "gradnorm", "adamw", "adamw_schedule", "vq_nearest",
+           "vq_commit", "vq_ema_update", "stft_mag", "mel_log", "CastPlan", "probe_layout", "device_info"]
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _req(t, dtype, name):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise TttsError("%s must live on the GPU (no CPU fallback in ttts_amd)" % name)
+    if t.dtype != dtype:
+        raise TttsError("%s must be %s, got %s" % (name, dtype, t.dtype))
+
+
+def device_info():
+    out = (ctypes.c_int32 * 4)()
+    check(_l.get().ttts_device_info(out), "device_info")
+    return {"arch": out[0], "cus": out[1], "wave": out[2], "lds_per_cu": out[3]}
+
+
+def _ld(t):
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise TttsError("expected a 2-D row-major (inner-contiguous) tensor, got strides %s" % (t.stride(),))
+    return t.stride(0)
+
+
+def gemm_nt(a, b, c, bias=None, aux=None, epilogue=EPI_STORE_BF16, n=None, k=None, resid_in=None, dropout_p=0.0,
+            seed=0):
+    """c[M,N] = epi(a[M,K] @ b[N,K]^T).  a/b bf16 row-major views; c bf16 or f32 (per epilogue)."""
+    _req(resid_in, torch.float32, "resid_in")
+    _req(a, torch.bfloat16, "a"); _req(b, torch.bfloat16, "b"); _req(bias, torch.float32, "bias")
+    _req(aux, torch.bfloat16, "aux")
+    M = a.shape[0]
+    K = a.shape[1] if k is None else k
+    N = b.shape[0] if n is None else n
+    want = torch.float32 if epilogue in (EPI_RESID_ADD_F32, EPI_STORE_F32) else torch.bfloat16
+    _req(c, want, "c")
+    if resid_in is not None and (resid_in.shape != c.shape or resid_in.stride() != c.stride()):
+        raise TttsError("resid_in must have the layout of c")
+    check(_l.get().ttts_gemm_nt_bf16_ex(_p(a), _ld(a), _p(b), _ld(b), _p(c), _ld(c), _p(bias), _p(aux), M, N, K,
+                                        epilogue, _p(resid_in), dropout_p, seed, _stream()), "gemm_nt")
+    return c
+
+
+def gemm_tn_accum(at, bt, c, mo=None, no=None):
+    """c[Mo,No] += at[Kr,Mo]^T @ bt[Kr,No]  (fp32 accumulate)."""
+    _req(at, torch.bfloat16, "at"); _req(bt, torch.bfloat16, "bt"); _req(c, torch.float32, "c")
+    Kr = at.shape[0]
+    Mo = at.shape[1] if mo is None else mo
+    No = bt.shape[1] if no is None else no
+    check(_l.get().ttts_gemm_tn_bf16_accum_f32(_p(at), _ld(at), _p(bt), _ld(bt), _p(c), _ld(c), Mo, No, Kr, _stream()),
+          "gemm_tn")
+    return c
+
+
+def colsum_accum(x, out, n=None):
+    _req(x, torch.bfloat16, "x"); _req(out, torch.float32, "out")
+    check(_l.get().ttts_colsum_bf16_accum_f32(_p(x), _ld(x), _p(out), x.shape[0], x.shape[1] if n is None else n,
+                                              _stream()), "colsum")
+    return out
+
+
+def attn_fwd(q, k, v, o, lse, B, H, S, dh, qkv_strides, o_strides, scale, dropout_p=0.0, seed=0):
+    for t, nm in ((q, "q"), (k, "k"), (v, "v"), (o, "o")):
+        _req(t, torch.bfloat16, nm)
+    _req(lse, torch.float32, "lse")
+    check(_l.get().ttts_attn_causal_fwd_bf16(_p(q), _p(k), _p(v), _p(o), _p(lse), B, H, S, dh, qkv_strides[0],
+                                             qkv_strides[1], o_strides[0], o_strides[1], scale, dropout_p, seed,
+                                             _stream()), "attn_fwd")
+
+
+def attn_bwd(q, k, v, o, d_o, lse, dq, dk, dv, workspace, B, H, S, dh, qkv_strides, o_strides, scale, dropout_p=0.0,
+             seed=0):
+    for t, nm in ((q, "q"), (k, "k"), (v, "v"), (o, "o"), (d_o, "d_o"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
+        _req(t, torch.bfloat16, nm)
+    _req(lse, torch.float32, "lse")
+    if workspace.numel() * workspace.element_size() < _l.get().ttts_attn_bwd_workspace_bytes(B, H, S):
+        raise TttsError("attn_bwd workspace too small")
+    check(_l.get().ttts_attn_causal_bwd_bf16(_p(q), _p(k), _p(v), _p(o), _p(d_o), _p(lse), _p(dq), _p(dk), _p(dv),
+                                             _p(workspace), B, H, S, dh, qkv_strides[0], qkv_strides[1], o_strides[0],
+                                             o_strides[1], scale, dropout_p, seed, _stream()), "attn_bwd")
+
+
+def attn_dropout_mask(B, H, S, p, seed, device):
+    m = torch.empty(B, H, S, S, dtype=torch.uint8, device=device)
+    check(_l.get().ttts_attn_dropout_mask_u8(_p(m), B, H, S, p, seed, _stream()), "dropout_mask")
+    return m
+
+
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps=1e-5, split=(0, 0)):
+    _req(x, torch.float32, "x"); _req(gamma, torch.float32, "gamma"); _req(beta, torch.float32, "beta")
+    M, D = x.shape
+    check(_l.get().ttts_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), int(y.dtype == torch.bfloat16), _p(mean),
+                                      _p(rstd), M, D, eps, split[0], split[1], _stream()), "layernorm_fwd")
+    return y
+
+
+def layernorm_bwd_workspace(M, D, device):
+    return torch.empty(_l.get().ttts_layernorm_bwd_workspace_bytes(M, D) // 4, dtype=torch.float32, device=device)
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx_in, dx, dx_bf16, dgamma, dbeta, workspace, split=(0, 0), dropout_p=0.0,
+                  seed=0):
+    _req(x, torch.float32, "x"); _req(dx, torch.float32, "dx"); _req(dx_bf16, torch.bfloat16, "dx_bf16")
+    M, D = x.shape
+    check(_l.get().ttts_layernorm_bwd_ex(_p(dy), int(dy.dtype == torch.bfloat16), _p(x), _p(gamma), _p(mean), _p(rstd),
+                                         _p(dx_in), _p(dx), _p(dx_bf16), _p(dgamma), _p(dbeta), _p(workspace), M, D,
+                                         split[0], split[1], dropout_p, seed, _stream()), "layernorm_bwd")
+
+
+def embed_fwd(text_inp, mel_inp, text_emb, text_pos, mel_emb, mel_pos, x, dropout_p=0.0, seed=0):
+    _req(text_inp, torch.int64, "text_inp"); _req(mel_inp, torch.int64, "mel_inp"); _req(x, torch.float32, "x")
+    B, Tt = text_inp.shape
+    Tm = mel_inp.shape[1]
+    D = x.shape[-1]
+    check(_l.get().ttts_gpt_embed_fwd(_p(text_inp), _p(mel_inp), _p(text_emb), _p(text_pos), _p(mel_emb), _p(mel_pos),
+                                      _p(x), B, Tt, Tm, D, text_emb.shape[0], mel_emb.shape[0], dropout_p, seed,
+                                      _stream()), "embed_fwd")
+    return x
+
+
+def embed_bwd(text_inp, mel_inp, dx, d_text_emb, d_text_pos, d_mel_emb, d_mel_pos, dropout_p=0.0, seed=0):
+    B, Tt = text_inp.shape
+    Tm = mel_inp.shape[1]
+    D = dx.shape[-1]
+    check(_l.get().ttts_gpt_embed_bwd(_p(text_inp), _p(mel_inp), _p(dx), _p(d_text_emb), _p(d_text_pos), _p(d_mel_emb),
+                                      _p(d_mel_pos), B, Tt, Tm, D, dropout_p, seed, _stream()), "embed_bwd")
+
+
+def ce_fwd(logits, targets, row_loss, row_lse, loss_mean, C):
+    _req(logits, torch.bfloat16, "logits"); _req(targets, torch.int64, "targets")
+    check(_l.get().ttts_ce_fwd_bf16(_p(logits), _ld(logits), _p(targets), _p(row_loss), _p(row_lse), _p(loss_mean),
+                                    logits.shape[0], C, _stream()), "ce_fwd")
+
+
+def ce_bwd(logits, targets, row_lse, dlogits, C, grad_scale=1.0, grad_scale_dev=None):
+    _req(dlogits, torch.bfloat16, "dlogits")
+    check(_l.get().ttts_ce_bwd_bf16(_p(logits), _ld(logits), _p(targets), _p(row_lse), _p(dlogits), grad_scale,
+                                    _p(grad_scale_dev), logits.shape[0], C, _stream()), "ce_bwd")
+
+
+def adamw_schedule(state, base_lr, beta1, beta2, warmup_steps):
+    _req(state, torch.float32, "state")
+    check(_l.get().ttts_adamw_schedule(_p(state), base_lr, beta1, beta2, warmup_steps, _stream()), "adamw_schedule")
+
+
+def gradnorm_workspace(n, device):
+    return torch.empty(_l.get().ttts_gradnorm_workspace_bytes(n) // 8, dtype=torch.float64, device=device)
+
+
+def gradnorm(g, max_norm, state, workspace):
+    _req(g, torch.float32, "g")
+    check(_l.get().ttts_gradnorm_f32(_p(g), g.numel(), max_norm, _p(state), _p(workspace), _stream()), "gradnorm")
+
+
+def adamw(p, g, m, v, shadow, state, beta1, beta2, eps, wd, zero_grad=True):
+    for t, nm in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _req(t, torch.float32, nm)
+    _req(shadow, torch.bfloat16, "shadow")
+    check(_l.get().ttts_adamw_f32(_p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), _p(state), beta1, beta2, eps, wd,
+                                  int(zero_grad), _stream()), "adamw")
+
+
+class CastPlan:
+    """Device-resident descriptor table for the batched fp32 -> bf16 (+ transposed) shadow-weight cast."""
+
+    def __init__(self, entries, device):
+        """entries: list of (src f32 [r,c], dst bf16 [r,c] or None, dst_t bf16 [c,r(+pad)] or None)."""
+        arr = (_l.CastDesc * len(entries))()
+        tiles = 0
+        for i, (src, dst, dst_t) in enumerate(entries):
+            r, c = src.shape
+            _req(src, torch.float32, "cast src")
+            if dst_t is not None and (dst_t.shape[0] != c or dst_t.stride(0) < r or dst_t.stride(1) != 1):
+                raise TttsError("transposed shadow must be a row-major [cols, >= rows] view")
+            arr[i].src, arr[i].dst, arr[i].dst_t = src.data_ptr(), (dst.data_ptr() if dst is not None else None), \
+                (dst_t.data_ptr() if dst_t is not None else None)
+            arr[i].rows, arr[i].cols, arr[i].tile_begin = r, c, tiles
+            arr[i].ldt = dst_t.stride(0) if dst_t is not None else 0
+            tiles += _l.get().ttts_cast_desc_tiles(r, c)
+        raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+        self.table = torch.from_numpy(raw).to(device)
+        self.n, self.tiles = len(entries), tiles
+        self._keep = entries
+
+    def run(self):
+        check(_l.get().ttts_cast_bf16_batched(_p(self.table), self.n, self.tiles, _stream()), "cast_batched")
+
+
+def vq_nearest(x, codebook, want_xq=True, want_dist=False):
+    """x f32 [N,D], codebook f32 [K,D] -> (idx int64 [N], xq f32 [N,D] | None, dist f32 [N] | None)."""
+    _req(x, torch.float32, "x"); _req(codebook, torch.float32, "codebook")
+    x = x.contiguous(); codebook = codebook.contiguous()
+    N, D = x.shape
+    K = codebook.shape[0]
+    idx = torch.empty(N, dtype=torch.int64, device=x.device)
+    xq = torch.empty_like(x) if want_xq else None
+    dist = torch.empty(N, dtype=torch.float32, device=x.device) if want_dist else None
+    ws = torch.empty(_l.get().ttts_vq_workspace_bytes(N, K), dtype=torch.uint8, device=x.device)
+    check(_l.get().ttts_vq_nearest_f32(_p(x), _p(codebook), _p(idx), _p(xq), _p(dist), _p(ws), N, K, D, _stream()),
+          "vq_nearest")
+    return idx, xq, dist
+
+
+def vq_commit(x, xq, dx=None, grad_scale=1.0):
+    x = x.contiguous(); xq = xq.contiguous()
+    N, D = x.shape
+    loss = torch.empty((), dtype=torch.float32, device=x.device)
+    ws = torch.empty(_l.get().ttts_vq_workspace_bytes(N, 1), dtype=torch.uint8, device=x.device)
+    check(_l.get().ttts_vq_commit_f32(_p(x), _p(xq), _p(loss), _p(dx), grad_scale, N, D, _p(ws), _stream()),
+          "vq_commit")
+    return loss
+
+
+def vq_ema_update(x, idx, cluster_size, embed_avg, embed, decay=0.99, epsilon=1e-5):
+    x = x.contiguous()
+    N, D = x.shape
+    K = embed.shape[0]
+    ws = torch.empty(_l.get().ttts_vq_ema_workspace_bytes(K, D), dtype=torch.uint8, device=x.device)
+    check(_l.get().ttts_vq_ema_update_f32(_p(x), _p(idx), _p(cluster_size), _p(embed_avg), _p(embed), _p(ws), N, K, D,
+                                          decay, epsilon, _stream()), "vq_ema_update")
+
+
+_twiddle_cache = {}
+
+
+def stft_twiddle(n_fft, device):
+    key = (n_fft, str(device))
+    if key not in _twiddle_cache:
+        host = np.empty(n_fft, dtype=np.float32)
+        check(_l.get().ttts_stft_twiddle_host(host.ctypes.data_as(ctypes.c_void_p), n_fft), "stft_twiddle")
+        _twiddle_cache[key] = torch.from_numpy(host).to(device)
+    return _twiddle_cache[key]
+
+
+def stft_mag(wav, window, n_fft, hop):
+    """wav f32 [B,T] -> spec f32 [B, n_fft/2+1, frames] (reflect pad, hann, |.| with 1e-6 floor)."""
+    _req(wav, torch.float32, "wav"); _req(window, torch.float32, "window")
+    wav = wav.contiguous()
+    B, T = wav.shape
+    pad = (n_fft - hop) // 2
+    frames = (T + 2 * pad - n_fft) // hop + 1
+    spec = torch.empty(B, n_fft // 2 + 1, frames, dtype=torch.float32, device=wav.device)
+    check(_l.get().ttts_stft_mag_fwd_f32(_p(wav), _p(window), _p(stft_twiddle(n_fft, wav.device)), _p(spec), B, T,
+                                         n_fft, hop, _stream()), "stft_mag")
+    return spec
+
+
+def mel_log(spec, basis):
+    _req(spec, torch.float32, "spec"); _req(basis, torch.float32, "basis")
+    spec = spec.contiguous(); basis = basis.contiguous()
+    B, n_bins, frames = spec.shape
+    n_mels = basis.shape[0]
+    mel = torch.empty(B, n_mels, frames, dtype=torch.float32, device=spec.device)
+    check(_l.get().ttts_mel_log_fwd_f32(_p(spec), _p(basis), _p(mel), B, n_bins, n_mels, frames, _stream()), "mel_log")
+    return mel
+
+
+def probe_layout(device):
+    c = torch.empty(64, 16, dtype=torch.float32, device=device)
+    tr = torch.empty(64, 8, dtype=torch.int32, device=device)
+    check(_l.get().ttts_probe_mfma_layout(_p(c), _p(tr), _stream()), "probe")
+    return c, tr
