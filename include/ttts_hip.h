@@ -65,11 +65,13 @@ int ttts_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, vo
 int ttts_gemm_nt_bf16_ex(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                          const float* bias, void* aux, int32_t M, int32_t N, int32_t K, int32_t epilogue,
                          const float* resid_in, float dropout_p, uint64_t seed, void* stream);
-/* C[Mo,No] += At[Kr,Mo]^T . Bt[Kr,No]  (fp32 atomic accumulation, split over Kr): the weight-gradient
- * GEMM; both operands are row-major with the REDUCTION dimension as rows ("TN").
+/* C[Mo,No] += At[Kr,Mo]^T . Bt[Kr,No]: the weight-gradient GEMM.  The reduction is split over workgroups into fp32
+ * slabs in `workspace` (ttts_gemm_tn_workspace_bytes; may be 0 -> NULL) that a second kernel sums in a fixed order
+ * (deterministic; no atomics); both operands are row-major with the REDUCTION dimension as rows ("TN").
  * Mo % 8 == 0 or ldat-padded, ldat % 8 == 0, ldbt % 8 == 0. */
+int64_t ttts_gemm_tn_workspace_bytes(int32_t Mo, int32_t No, int32_t Kr);
 int ttts_gemm_tn_bf16_accum_f32(const void* At, int64_t ldat, const void* Bt, int64_t ldbt, float* C,
-                                int64_t ldc, int32_t Mo, int32_t No, int32_t Kr, void* stream);
+                                int64_t ldc, int32_t Mo, int32_t No, int32_t Kr, void* workspace, void* stream);
 /* out[n] += sum_m X[m][n]   (bias gradients; X bf16 [M, ldx]) */
 int ttts_colsum_bf16_accum_f32(const void* X, int64_t ldx, float* out, int32_t M, int32_t N, void* stream);
 /* Batched fp32 -> bf16 cast (+ optional transposed copy) of parameter matrices.
@@ -127,10 +129,11 @@ int ttts_layernorm_bwd(const void* dy, int32_t dy_is_bf16, const float* x, const
                        float* dgamma, float* dbeta, void* workspace, int32_t M, int32_t D,
                        int32_t split_S, int32_t split_T, void* stream);
 /* Same, with the bf16 copy dx_bf16 = bf16(dropout_mask(seed, element row*D + d) * dx / (1 - p)): the gradient that
- * enters the residual-dropout site consuming it (the mask ttts_gemm_nt_bf16_ex applied in the forward). */
+ * enters the residual-dropout site consuming it (the mask ttts_gemm_nt_bf16_ex applied in the forward), and
+ * dcolsum[d] += sum_rows dx_bf16[row][d] (the bias gradient of the projection that consumes dx_bf16; may be NULL). */
 int ttts_layernorm_bwd_ex(const void* dy, int32_t dy_is_bf16, const float* x, const float* gamma,
                           const float* mean, const float* rstd, const float* dx_in, float* dx, void* dx_bf16,
-                          float* dgamma, float* dbeta, void* workspace, int32_t M, int32_t D,
+                          float* dgamma, float* dbeta, float* dcolsum, void* workspace, int32_t M, int32_t D,
                           int32_t split_S, int32_t split_T, float bf16_dropout_p, uint64_t bf16_dropout_seed,
                           void* stream);
 
@@ -212,6 +215,8 @@ int ttts_mel_log_fwd_f32(const float* spec, const float* basis, float* mel, int3
 /* out_c f32 [64 lanes][16 regs]: raw accumulators of one 32x32x16 bf16 MFMA with D[i][j] = (i+1) + 64*(j+1);
  * out_tr i32 [64 lanes][8]: the uint16 LDS element indices two ds_read_b64_tr_b16 return for the kernels' address map. */
 int ttts_probe_mfma_layout(float* out_c, int32_t* out_tr, void* stream);
+/* Timing ablations for tools/kernel_bench.py (0 = normal operation; results are WRONG when non-zero). */
+int ttts_debug_set_flags(int32_t flags);
 
 #ifdef __cplusplus
 }

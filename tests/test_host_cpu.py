@@ -47,7 +47,9 @@ def test_argument_validation_without_gpu(lib):
     assert l.ttts_attn_causal_fwd_bf16(p, p, p, p, p, 1, 1, 16, 48, 16, 16, 16, 16, 1.0, 0.0, 0, None) == -1
     assert b"head_dim" in l.ttts_last_error()
     assert l.ttts_vq_nearest_f32(p, p, p, None, None, p, 8, 8, 7, None) == -1                # odd D
-    assert l.ttts_layernorm_bwd_workspace_bytes(9248, 512) == 289 * 2 * 512 * 4
+    assert l.ttts_layernorm_bwd_workspace_bytes(9248, 512) == 289 * 3 * 512 * 4
+    assert l.ttts_gemm_tn_workspace_bytes(512, 1536, 9248) == 8 * 512 * 1536 * 4   # 48 tiles -> 8 slabs
+    assert l.ttts_gemm_tn_workspace_bytes(128, 128, 200) == 0                       # single split: no workspace
     assert l.ttts_cast_desc_tiles(257, 512) == 9 * 16
     tw = np.empty(2048, np.float32)
     assert l.ttts_stft_twiddle_host(tw.ctypes.data_as(ctypes.c_void_p), 2048) == 0
@@ -142,8 +144,8 @@ def test_dropout_threshold_and_hash_reference():
     """The dropout keep rule documented in DESIGN.md: 16 random bits per element from hash32(e >> 1)."""
     def hash32(x, lo, hi):
         m = 0xFFFFFFFF
-        x ^= lo; x = (x * 0x9E3779B1) & m; x ^= x >> 16; x = (x + hi) & m; x = (x * 0x85EBCA6B) & m
-        x ^= x >> 13; x = (x * 0xC2B2AE35) & m; x ^= x >> 16
+        x = ((x ^ lo) + hi) & m
+        x ^= x >> 16; x = (x * 0x7FEB352D) & m; x ^= x >> 15; x = (x * 0x846CA68B) & m; x ^= x >> 16
         return x
     thr = int(0.1 * 65536 + 0.5)
     e = np.arange(200000)
@@ -173,7 +175,7 @@ assert torch.allclose(grads, want, atol=1e-6)
 assert abs(dp.max_over_ranks(float(rank)) - 1.0) < 1e-12
 assert shard_indices(7, rank, world) == list(range(7))[rank::2]
 dp.barrier()
-sys.stdout.write("rank%d-ok\n" % rank)
+sys.stdout.write("rank" + str(rank) + "-ok\n")
 """
 
 

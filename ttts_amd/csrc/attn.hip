@@ -27,6 +27,7 @@ struct AttnParams {
   const float* lse_in;
   float* delta;
   int B, H, S;
+  int Sp;            // S rounded up to 4: row pitch of the dropout-mask index space
   int64_t sb, ss;    // q/k/v (and dq/dk/dv) strides: batch, sequence
   int64_t osb, oss;  // o / dO strides
   float scale, c;    // softmax scale, scale * log2(e)
@@ -48,10 +49,18 @@ template <int DH> struct AttnCfg {
   static constexpr int CPR = DH / 8;                       // 16-byte chunks per row
 };
 
-// keep-mask bit for attention element e = ((b*H + h)*S + query)*S + key
+// keep-mask bit for attention element e = ((b*H + h)*S + query)*Sp + key: 16 random bits, two elements per hash
 __device__ __forceinline__ bool drop_keep(uint32_t e, uint32_t thr, uint32_t slo, uint32_t shi) {
   const uint32_t r = hash32(e >> 1, slo, shi);
   return ((e & 1u) ? (r >> 16) : (r & 0xFFFFu)) >= thr;
+}
+// the same for four consecutive elements e0 .. e0+3 (e0 % 4 == 0): two hashes
+__device__ __forceinline__ void drop_keep4(uint32_t e0, uint32_t thr, uint32_t slo, uint32_t shi, bool (&k)[4]) {
+  const uint32_t r0 = hash32(e0 >> 1, slo, shi), r1 = hash32((e0 >> 1) + 1, slo, shi);
+  k[0] = (r0 & 0xFFFFu) >= thr;
+  k[1] = (r0 >> 16) >= thr;
+  k[2] = (r1 & 0xFFFFu) >= thr;
+  k[3] = (r1 >> 16) >= thr;
 }
 
 // load / store a 64 x DH bf16 tile (rows row0.. of a [*, stride] matrix, zero beyond nrows)
@@ -114,7 +123,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   __syncthreads();
   const int k_nat = (lane & 31) * C::KSTR + hh * 8;
   const int v_tr = (4 * hh + (ip >> 2)) * C::VSTR + 16 * (g & 1) + 4 * (ip & 3);
-  const uint32_t e_row = (uint32_t)(((int64_t)(b * p.H + h) * p.S + query) * p.S);
+  const uint32_t e_row = (uint32_t)(((int64_t)(b * p.H + h) * p.S + query) * p.Sp);
 
   for (int jt = 0; jt < nt; ++jt) {
     const int buf = jt & 1, kv0 = jt * 64;
@@ -162,14 +171,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][r], p.c, -m2));
-          l += pv;
-          if (DROPOUT) {
-            const int key = kv0 + kb * 32 + acc_row(r, hh);
-            pv = drop_keep(e_row + (uint32_t)key, p.thr, p.seed_lo, p.seed_hi) ? pv * p.inv_keep : 0.f;
+        for (int qd = 0; qd < 4; ++qd) {
+          bool keep[4] = {true, true, true, true};
+          if (DROPOUT) drop_keep4(e_row + (uint32_t)(kv0 + kb * 32 + 8 * qd + 4 * hh), p.thr, p.seed_lo, p.seed_hi, keep);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * qd + e;
+            float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][r], p.c, -m2));
+            l += pv;
+            if (DROPOUT) pv = keep[e] ? pv * p.inv_keep : 0.f;
+            pf[kb][r >> 3][r & 7] = (bf16)pv;
           }
-          pf[kb][r >> 3][r & 7] = (bf16)pv;
         }
 #pragma unroll
       for (int nb = 0; nb < C::NB; ++nb)
@@ -275,7 +287,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   __syncthreads();
   const int k_nat = (lane & 31) * C::KSTR + hh * 8;
   const int k_tr = (4 * hh + (ip >> 2)) * C::KSTR + 16 * (g & 1) + 4 * (ip & 3);
-  const uint32_t e_row = (uint32_t)(((int64_t)(b * p.H + h) * p.S + query) * p.S);
+  const uint32_t e_row = (uint32_t)(((int64_t)(b * p.H + h) * p.S + query) * p.Sp);
 
   for (int jt = 0; jt < nt; ++jt) {
     const int buf = jt & 1, kv0 = jt * 64;
@@ -298,12 +310,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
           dp = mfma32(vf, dof[ks], dp);
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kv0 + kb * 32 + acc_row(r, hh);
-          float pv = (key > query || key >= p.S) ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[r], p.c, -lse2));
-          float dpv = dp[r];
-          if (DROPOUT) dpv = drop_keep(e_row + (uint32_t)key, p.thr, p.seed_lo, p.seed_hi) ? dpv * p.inv_keep : 0.f;
-          dsf[kb][r >> 3][r & 7] = (bf16)(pv * (dpv - delta));
+        for (int qd = 0; qd < 4; ++qd) {
+          bool keep[4] = {true, true, true, true};
+          if (DROPOUT) drop_keep4(e_row + (uint32_t)(kv0 + kb * 32 + 8 * qd + 4 * hh), p.thr, p.seed_lo, p.seed_hi, keep);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * qd + e;
+            const int key = kv0 + kb * 32 + 8 * qd + 4 * hh + e;
+            const float pv = (key > query || key >= p.S) ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[r], p.c, -lse2));
+            float dpv = dp[r];
+            if (DROPOUT) dpv = keep[e] ? dpv * p.inv_keep : 0.f;
+            dsf[kb][r >> 3][r & 7] = (bf16)(pv * (dpv - delta));
+          }
         }
       }
 #pragma unroll
@@ -429,7 +447,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
             float dpv = dp[r];
             float pd = pv;
             if (DROPOUT) {
-              const bool keep = drop_keep((e_bh + (uint32_t)query) * (uint32_t)p.S + (uint32_t)key, p.thr, p.seed_lo, p.seed_hi);
+              const bool keep = drop_keep((e_bh + (uint32_t)query) * (uint32_t)p.Sp + (uint32_t)key, p.thr, p.seed_lo, p.seed_hi);
               dpv = keep ? dpv * p.inv_keep : 0.f;
               pd = keep ? pv * p.inv_keep : 0.f;
             }
@@ -476,10 +494,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
   }
 }
 
-__global__ __launch_bounds__(256) void attn_dropout_mask_kernel(uint8_t* mask, int64_t total, uint32_t thr,
-                                                                uint32_t slo, uint32_t shi) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
-    mask[i] = thr == 0 ? 1 : (drop_keep((uint32_t)i, thr, slo, shi) ? 1 : 0);
+__global__ __launch_bounds__(256) void attn_dropout_mask_kernel(uint8_t* mask, int64_t total, int S, int Sp,
+                                                                uint32_t thr, uint32_t slo, uint32_t shi) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / S;  // (b*H + h)*S + query
+    const int key = (int)(i % S);
+    mask[i] = thr == 0 ? 1 : (drop_keep((uint32_t)(row * Sp + key), thr, slo, shi) ? 1 : 0);
+  }
 }
 
 static int fill_params(AttnParams& p, int B, int H, int S, int head_dim, int64_t sb, int64_t ss, int64_t osb,
@@ -488,7 +509,8 @@ static int fill_params(AttnParams& p, int B, int H, int S, int head_dim, int64_t
   TTTS_REQUIRE(head_dim == 32 || head_dim == 64 || head_dim == 128, "attn: head_dim %d not in {32,64,128}", head_dim);
   TTTS_REQUIRE(ss % 8 == 0 && sb % 8 == 0 && oss % 8 == 0 && osb % 8 == 0, "attn: strides must be multiples of 8 elements");
   TTTS_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "attn: dropout_p out of range");
-  TTTS_REQUIRE((int64_t)B * H * S * S < (int64_t)1 << 32 || dropout_p == 0.f, "attn: dropout index space exceeds 2^32");
+  p.Sp = (S + 3) & ~3;
+  TTTS_REQUIRE((int64_t)B * H * S * p.Sp < (int64_t)1 << 32 || dropout_p == 0.f, "attn: dropout index space exceeds 2^32");
   p.B = B; p.H = H; p.S = S;
   p.sb = sb; p.ss = ss; p.osb = osb; p.oss = oss;
   p.scale = scale;
@@ -562,8 +584,9 @@ extern "C" int ttts_attn_dropout_mask_u8(uint8_t* mask, int32_t B, int32_t H, in
                                          void* stream) {
   TTTS_REQUIRE(mask && B > 0 && H > 0 && S > 0 && dropout_p >= 0.f && dropout_p < 1.f, "dropout_mask: bad arguments");
   const int64_t total = (int64_t)B * H * S * S;
-  TTTS_REQUIRE(total < (int64_t)1 << 32, "dropout_mask: index space exceeds 2^32");
+  const int Sp = (S + 3) & ~3;
+  TTTS_REQUIRE((int64_t)B * H * S * Sp < (int64_t)1 << 32, "dropout_mask: index space exceeds 2^32");
   attn_dropout_mask_kernel<<<(int)std::min<int64_t>(cdiv(total, 256), 8192), 256, 0, as_stream(stream)>>>(
-      mask, total, dropout_threshold(dropout_p), (uint32_t)seed, (uint32_t)(seed >> 32));
+      mask, total, S, Sp, dropout_threshold(dropout_p), (uint32_t)seed, (uint32_t)(seed >> 32));
   return check_launch("dropout_mask");
 }

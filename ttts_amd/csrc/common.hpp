@@ -85,15 +85,14 @@ __device__ __forceinline__ bf16x8 zero8() {
   return r;
 }
 
-// counter hash -> 32 random bits (dropout masks; deterministic in (seed, index), same in fwd and bwd)
+// counter hash -> 32 random bits (dropout masks; deterministic in (seed, index), identical in forward and backward).
+// "lowbias32" finaliser (2 multiplies, 3 xor-shifts) over index ^ seed_lo, offset by seed_hi.
 __device__ __forceinline__ uint32_t hash32(uint32_t x, uint32_t seed_lo, uint32_t seed_hi) {
-  x ^= seed_lo;
-  x *= 0x9E3779B1u;
+  x = (x ^ seed_lo) + seed_hi;
   x ^= x >> 16;
-  x += seed_hi;
-  x *= 0x85EBCA6Bu;
-  x ^= x >> 13;
-  x *= 0xC2B2AE35u;
+  x *= 0x7FEB352Du;
+  x ^= x >> 15;
+  x *= 0x846CA68Bu;
   x ^= x >> 16;
   return x;
 }
@@ -103,17 +102,23 @@ __host__ __device__ inline uint32_t dropout_threshold(float p) {
   return t <= 0.f ? 0u : (t >= 65535.f ? 65535u : (uint32_t)t);
 }
 
+// tanh via one v_exp_f32 and one reciprocal: tanh(u) = 1 - 2 / (1 + e^(2u)); saturates correctly at +-inf.
+// (tanhf() costs ~40 instructions per element and made the GELU epilogues as long as the GEMM main loop.)
+__device__ __forceinline__ float fast_tanh(float u) {
+  const float e = __builtin_amdgcn_exp2f(u * 2.885390081777927f);  // e^(2u) = 2^(2u log2 e)
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
+}
 __device__ __forceinline__ float gelu_new_f(float x) {
   const float k0 = 0.7978845608028654f;  // sqrt(2/pi)
-  float u = k0 * (x + 0.044715f * x * x * x);
-  return 0.5f * x * (1.0f + tanhf(u));
+  const float u = k0 * (x + 0.044715f * x * x * x);
+  return 0.5f * x * (1.0f + fast_tanh(u));
 }
 __device__ __forceinline__ float gelu_new_grad_f(float x) {
   const float k0 = 0.7978845608028654f;
-  float x2 = x * x;
-  float u = k0 * (x + 0.044715f * x * x2);
-  float t = tanhf(u);
-  float du = k0 * (1.0f + 3.0f * 0.044715f * x2);
+  const float x2 = x * x;
+  const float u = k0 * (x + 0.044715f * x * x2);
+  const float t = fast_tanh(u);
+  const float du = k0 * (1.0f + 3.0f * 0.044715f * x2);
   return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
 }
 

@@ -169,15 +169,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      bf16* __restrict__ dx_bf16, float* __restrict__ partial, int M,
                                                      int D, int split_S, int split_T, uint32_t thr, float inv_keep,
                                                      uint32_t seed_lo, uint32_t seed_hi) {
-  extern __shared__ __attribute__((aligned(16))) float ln_smem[];  // [4 waves][2][D]
+  extern __shared__ __attribute__((aligned(16))) float ln_smem[];  // [4 waves][3][D]
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int nB = split_S > 0 ? M / split_S : 0;
-  float4 dg[VPL], db[VPL], gm[VPL];
+  float4 dg[VPL], db[VPL], gm[VPL], dc[VPL];  // dc: column sums of the bf16 copy (bias gradient of its consumer)
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
     dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    dc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int d = (lane + i * 64) * 4;
     gm[i] = d < D ? *reinterpret_cast<const float4*>(gamma + d) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
@@ -240,34 +241,47 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
           bf16x4 ob;
           ob[0] = (bf16)o.x; ob[1] = (bf16)o.y; ob[2] = (bf16)o.z; ob[3] = (bf16)o.w;
           *reinterpret_cast<bf16x4*>(dx_bf16 + row * D + d) = ob;
+          dc[i].x += (float)ob[0]; dc[i].y += (float)ob[1]; dc[i].z += (float)ob[2]; dc[i].w += (float)ob[3];
         }
       }
     }
   }
-  // cross-wave reduction of the per-lane dgamma/dbeta partials, then one partial row per block
-  float* sg = ln_smem + (size_t)wave * 2 * D;
+  // cross-wave reduction of the per-lane column partials, then one partial row per block: [dgamma | dbeta | dcolsum]
+  float* sg = ln_smem + (size_t)wave * 3 * D;
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
     const int d = (lane + i * 64) * 4;
     if (d < D) {
       *reinterpret_cast<float4*>(sg + d) = dg[i];
       *reinterpret_cast<float4*>(sg + D + d) = db[i];
+      *reinterpret_cast<float4*>(sg + 2 * D + d) = dc[i];
     }
   }
   __syncthreads();
-  for (int j = threadIdx.x; j < 2 * D; j += 256) {
-    const float s = (ln_smem[j] + ln_smem[2 * D + j]) + (ln_smem[4 * D + j] + ln_smem[6 * D + j]);
-    partial[(size_t)blockIdx.x * 2 * D + j] = s;
+  for (int j = threadIdx.x; j < 3 * D; j += 256) {
+    const float s = (ln_smem[j] + ln_smem[3 * D + j]) + (ln_smem[6 * D + j] + ln_smem[9 * D + j]);
+    partial[(size_t)blockIdx.x * 3 * D + j] = s;
   }
 }
 
+// out[j] += sum over blocks of partial[b][j]: 64 columns per workgroup, 4 row lanes, fixed summation order
 __global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int D,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= 2 * D) return;
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ dcolsum) {
+  __shared__ float sh[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + tx;
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * 2 * D + j];
-  if (j < D) dgamma[j] += s; else dbeta[j - D] += s;
+  if (j < 3 * D)
+    for (int b = ty; b < nblk; b += 4) s += partial[(size_t)b * 3 * D + j];
+  sh[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && j < 3 * D) {
+    const float t = (sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]);
+    if (j < D) dgamma[j] += t;
+    else if (j < 2 * D) dbeta[j - D] += t;
+    else if (dcolsum) dcolsum[j - 2 * D] += t;
+  }
 }
 
 // ======================================================================================================
@@ -351,22 +365,37 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const bf16* __restrict__ lo
 // ======================================================================================================
 // bias gradients: out[n] += sum_m X[m][n]
 // ======================================================================================================
-constexpr int COLSUM_ROWS = 64;
+// workgroup = 64 columns x 256 rows: 8 column chunks (16 B) x 32 row lanes, 8 rows per thread, LDS reduction over
+// the row lanes, then one atomic per column and workgroup (M/256 atomics per column in total)
+constexpr int COLSUM_ROWS = 256;
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ X, int64_t ldx, float* __restrict__ out,
                                                      int M, int N) {
-  const int n0 = (blockIdx.x * 256 + threadIdx.x) * 8;
-  if (n0 >= N) return;
+  __shared__ float sh[32][65];
+  const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+  const int n0 = blockIdx.x * 64 + tx * 8;
   const int m0 = blockIdx.y * COLSUM_ROWS;
-  const int m1 = min(M, m0 + COLSUM_ROWS);
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int m = m0; m < m1; ++m) {
-    const bf16x8 v = *reinterpret_cast<const bf16x8*>(X + (int64_t)m * ldx + n0);
+  if (n0 < N) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+    for (int r = 0; r < COLSUM_ROWS / 32; ++r) {
+      const int m = m0 + ty + 32 * r;
+      if (m < M) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(X + (int64_t)m * ldx + n0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+      }
+    }
   }
 #pragma unroll
-  for (int j = 0; j < 8; ++j)
-    if (n0 + j < N) atomicAdd(out + n0 + j, acc[j]);
+  for (int j = 0; j < 8; ++j) sh[ty][tx * 8 + j] = acc[j];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) s += sh[r][threadIdx.x];
+    const int n = blockIdx.x * 64 + threadIdx.x;
+    if (n < N) atomicAdd(out + n, s);
+  }
 }
 
 // ======================================================================================================
@@ -545,19 +574,20 @@ extern "C" int ttts_layernorm_fwd(const float* x, const float* gamma, const floa
 }
 
 extern "C" int64_t ttts_layernorm_bwd_workspace_bytes(int32_t M, int32_t D) {
-  return (int64_t)cdiv(M, LN_BWD_ROWS) * 2 * D * (int64_t)sizeof(float);
+  return (int64_t)cdiv(M, LN_BWD_ROWS) * 3 * D * (int64_t)sizeof(float);
 }
 
 // internal entry with the dropout arguments for the bf16 copy (used by the GPT step)
-int layernorm_bwd_impl(const void* dy, int dy_is_bf16, const float* x, const float* gamma, const float* mean,
-                       const float* rstd, const float* dx_in, float* dx, void* dx_bf16, float* dgamma, float* dbeta,
-                       void* workspace, int M, int D, int split_S, int split_T, float drop_p, uint64_t seed,
-                       hipStream_t s) {
+static int layernorm_bwd_impl(const void* dy, int dy_is_bf16, const float* x, const float* gamma, const float* mean,
+                              const float* rstd, const float* dx_in, float* dx, void* dx_bf16, float* dgamma,
+                              float* dbeta, float* dcolsum, void* workspace, int M, int D, int split_S, int split_T,
+                              float drop_p, uint64_t seed, hipStream_t s) {
   TTTS_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && workspace, "layernorm_bwd: null pointer");
   TTTS_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "layernorm_bwd: need 0 < D <= 1024, D %% 4 == 0 (D=%d)", D);
   TTTS_REQUIRE(split_S <= 0 || (M % split_S == 0 && split_T >= 0 && split_T <= split_S), "layernorm_bwd: bad split");
+  TTTS_REQUIRE(!dcolsum || dx_bf16, "layernorm_bwd: dcolsum needs the bf16 copy");
   const int nblk = (int)cdiv(M, LN_BWD_ROWS);
-  const size_t smem = (size_t)4 * 2 * D * sizeof(float);
+  const size_t smem = (size_t)4 * 3 * D * sizeof(float);
   float* partial = reinterpret_cast<float*>(workspace);
   const uint32_t thr = dropout_threshold(drop_p);
   const float inv_keep = thr ? 65536.0f / (65536.0f - (float)thr) : 1.0f;
@@ -572,7 +602,7 @@ int layernorm_bwd_impl(const void* dy, int dy_is_bf16, const float* x, const flo
 #undef LN_BWD
   int rc = check_launch("layernorm_bwd");
   if (rc) return rc;
-  ln_bwd_finalize_kernel<<<(int)cdiv(2 * D, 256), 256, 0, s>>>(partial, nblk, D, dgamma, dbeta);
+  ln_bwd_finalize_kernel<<<(int)cdiv(3 * D, 64), 256, 0, s>>>(partial, nblk, D, dgamma, dbeta, dcolsum);
   return check_launch("layernorm_bwd_finalize");
 }
 
@@ -580,18 +610,18 @@ extern "C" int ttts_layernorm_bwd(const void* dy, int32_t dy_is_bf16, const floa
                                   const float* mean, const float* rstd, const float* dx_in, float* dx, void* dx_bf16,
                                   float* dgamma, float* dbeta, void* workspace, int32_t M, int32_t D, int32_t split_S,
                                   int32_t split_T, void* stream) {
-  return layernorm_bwd_impl(dy, dy_is_bf16, x, gamma, mean, rstd, dx_in, dx, dx_bf16, dgamma, dbeta, workspace, M, D,
-                            split_S, split_T, 0.f, 0, as_stream(stream));
+  return layernorm_bwd_impl(dy, dy_is_bf16, x, gamma, mean, rstd, dx_in, dx, dx_bf16, dgamma, dbeta, nullptr, workspace,
+                            M, D, split_S, split_T, 0.f, 0, as_stream(stream));
 }
 
 extern "C" int ttts_layernorm_bwd_ex(const void* dy, int32_t dy_is_bf16, const float* x, const float* gamma,
                                      const float* mean, const float* rstd, const float* dx_in, float* dx, void* dx_bf16,
-                                     float* dgamma, float* dbeta, void* workspace, int32_t M, int32_t D,
+                                     float* dgamma, float* dbeta, float* dcolsum, void* workspace, int32_t M, int32_t D,
                                      int32_t split_S, int32_t split_T, float bf16_dropout_p, uint64_t bf16_dropout_seed,
                                      void* stream) {
   TTTS_REQUIRE(bf16_dropout_p >= 0.f && bf16_dropout_p < 1.f, "layernorm_bwd: dropout_p out of range");
-  return layernorm_bwd_impl(dy, dy_is_bf16, x, gamma, mean, rstd, dx_in, dx, dx_bf16, dgamma, dbeta, workspace, M, D,
-                            split_S, split_T, bf16_dropout_p, bf16_dropout_seed, as_stream(stream));
+  return layernorm_bwd_impl(dy, dy_is_bf16, x, gamma, mean, rstd, dx_in, dx, dx_bf16, dgamma, dbeta, dcolsum, workspace,
+                            M, D, split_S, split_T, bf16_dropout_p, bf16_dropout_seed, as_stream(stream));
 }
 
 extern "C" int ttts_ce_fwd_bf16(const void* logits, int64_t ldl, const int64_t* targets, float* row_loss,
@@ -618,7 +648,7 @@ extern "C" int ttts_ce_bwd_bf16(const void* logits, int64_t ldl, const int64_t* 
 extern "C" int ttts_colsum_bf16_accum_f32(const void* X, int64_t ldx, float* out, int32_t M, int32_t N, void* stream) {
   TTTS_REQUIRE(X && out && M > 0 && N > 0, "colsum: bad arguments");
   TTTS_REQUIRE(ldx % 8 == 0 && ldx >= ((N + 7) / 8) * 8 && aligned16(X), "colsum: need ldx %% 8 == 0 and ldx >= roundup8(N)");
-  dim3 grid((unsigned)cdiv(cdiv(N, 8), 256), (unsigned)cdiv(M, COLSUM_ROWS));
+  dim3 grid((unsigned)cdiv(N, 64), (unsigned)cdiv(M, COLSUM_ROWS));
   colsum_kernel<<<grid, 256, 0, as_stream(stream)>>>((const bf16*)X, ldx, out, M, N);
   return check_launch("colsum");
 }

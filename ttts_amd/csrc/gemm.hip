@@ -3,16 +3,20 @@
 //  * gemm_nt: C[M,N] = epi(A[M,K] . B[N,K]^T)   -- forward projections and dX (both operands K-contiguous;
 //    the bf16 "shadow" weights are kept in both layouts so that no operand ever needs a transposed read).
 //  * gemm_tn: C[Mo,No] += At[Kr,Mo]^T . Bt[Kr,No] -- weight gradients; the reduction runs over ROWS of both
-//    operands, so fragments are fetched with the LDS transpose read (ds_read_b64_tr_b16) and the reduction is
-//    split across workgroups (fp32 atomics into the gradient arena).
+//    operands, so fragments are fetched with the LDS transpose read (ds_read_b64_tr_b16); the reduction is split
+//    across workgroups into fp32 slabs that a second kernel sums in a fixed order (no atomics).
 //
 // Tiling: 128x128 block tile, 4 waves (2x2), each wave a 64x64 sub-tile = 2x2 MFMA 32x32 tiles (64 fp32
-// accumulator VGPRs), K staged 64 deep through a double-buffered LDS tile; global->register->LDS staging with
-// the next tile's loads in flight under the current tile's MFMAs, ONE barrier per K-tile.
-// LDS row stride 144 B (NT) makes every ds_read_b128 16-lane service group hit 64 distinct banks;
-// 320 B (TN) does the same for the 4-row x 64-byte footprint of a transposed read.
-// The MFMA is issued "swapped" (weights as the A operand) so that every lane ends up owning 4 CONSECUTIVE
-// output columns of one row per accumulator quad: epilogues use 8-byte bf16 / 16-byte fp32 accesses.
+// accumulator VGPRs), double-buffered LDS operand tiles, ONE barrier per K-tile.
+// What the first profiles showed and this file answers (tools/kernel_bench.py ablations, MI355X):
+//  - the register-staged main loop was LDS-WRITE bound (ds_write_b128 ~ 79 B/clk/CU): the NT main loop now fills LDS
+//    with global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip, no ds_write); the DMA image is lane-linear, so the
+//    bank-conflict-free layout comes from XOR-swizzling the SOURCE chunk (chunk ^ ((row >> 1) & 7)) and applying the
+//    same involution on the ds_read_b128 side;
+//  - per-lane epilogue stores touched 32 rows x 16 B per instruction (partial cache lines, half of the kernel time):
+//    accumulators are now staged through LDS and leave as whole 256/512-byte rows, 16 bytes per lane.
+// The MFMA is issued "swapped" (weights as the A operand) so every lane owns 4 consecutive output columns per
+// accumulator quad (float4 staging writes).
 #include <algorithm>
 
 #include "common.hpp"
@@ -20,27 +24,268 @@
 namespace ttts {
 
 constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int NT_LDS_STRIDE = BK + 8;   // elements (144 B)
-constexpr int TN_LDS_STRIDE = 128 + 32; // elements (320 B)
+constexpr int NT_LDS_STRIDE = BK + 8;    // register-staged fallback: 144-byte rows
+constexpr int TN_LDS_STRIDE = 128 + 32;  // elements (320 B)
+constexpr int ST_LD = 132;               // fp32 staging row pitch (floats)
+constexpr int EPI_ACCUM_F32 = 16;        // internal: C += acc      (gemm_tn, single split)
+constexpr int EPI_SLAB_F32 = 17;         // internal: slab = acc    (gemm_tn, several splits)
 
-struct GemmNtParams {
-  const bf16* A; int64_t lda;
-  const bf16* B; int64_t ldb;
+struct GemmEpi {
   void* C; int64_t ldc;
   const float* bias;
   bf16* aux;
   const float* resid_in;  // RESID_ADD: C = resid_in + dropout(bf16(acc + bias)); NULL -> in place (C += ...)
-  int M, N, K;
+  int M, N;
   uint32_t thr; float inv_keep; uint32_t seed_lo, seed_hi;  // residual dropout (RESID_ADD only; thr = 0: off)
+  int debug;  // ablations: 16 = skip the global stores of the epilogue, 32 = skip the LDS staging
 };
 
+struct GemmNtParams {
+  const bf16* A; int64_t lda;
+  const bf16* B; int64_t ldb;
+  int K;
+  int debug;  // timing ablations (tools/kernel_bench.py): 1 = no epilogue, 2 = no global loads, 4 = no MFMA
+  GemmEpi e;
+};
+
+// ---- shared epilogue: accumulators -> fp32 LDS stage (64 rows at a time) -> coalesced global access ---------------
+// stage: >= 64 * ST_LD floats of LDS that no wave reads any more (callers end their main loop with a barrier).
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNtParams p) {
-  __shared__ __attribute__((aligned(16))) bf16 As[2][BM * NT_LDS_STRIDE];
-  __shared__ __attribute__((aligned(16))) bf16 Bs[2][BN * NT_LDS_STRIDE];
+__device__ __forceinline__ void tile_epilogue(const GemmEpi& e, f32x16 (&acc)[2][2], float* stage, int m0, int n0,
+                                              int tid) {
+  const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, h = lane >> 5;
+  const bool bf16_out = (EPI == TTTS_EPI_STORE_BF16 || EPI == TTTS_EPI_GELU_BF16 || EPI == TTTS_EPI_DGELU_BF16);
+  const bool vec_ok = bf16_out ? ((e.ldc & 7) == 0) : ((e.ldc & 3) == 0);
+  // this thread stores columns n0 + (tid & 15)*8 .. +8 of every row it touches: fetch their bias once
+  float bias8[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int n = n0 + (tid & 15) * 8 + t;
+    const float b = (e.bias && n < e.N) ? e.bias[n] : 0.f;
+    bias8[t] = (EPI == TTTS_EPI_STORE_F32) ? b : (float)(bf16)b;  // autocast rounds the bias to bf16
+  }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (wm == half && !(e.debug & 32)) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int col = wn * 64 + j * 32 + 8 * q + 4 * h;
+            const float4 v = make_float4(acc[j][i][4 * q], acc[j][i][4 * q + 1], acc[j][i][4 * q + 2], acc[j][i][4 * q + 3]);
+            *reinterpret_cast<float4*>(&stage[(i * 32 + (lane & 31)) * ST_LD + col]) = v;
+          }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int row_l = pass * 16 + (tid >> 4);
+      const int m = m0 + half * 64 + row_l;
+      const int n = n0 + (tid & 15) * 8;
+      if (m >= e.M || n >= e.N) continue;
+      float v[8];
+      {
+        const float4 a = *reinterpret_cast<const float4*>(&stage[row_l * ST_LD + (tid & 15) * 8]);
+        const float4 b = *reinterpret_cast<const float4*>(&stage[row_l * ST_LD + (tid & 15) * 8 + 4]);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] += bias8[t];
+      const int64_t off = (int64_t)m * e.ldc + n;
+      const bool full = vec_ok && (n + 8 <= e.N);
+      if ((e.debug & 16) && v[0] + v[3] != 123456.75f) continue;
+      if (EPI == TTTS_EPI_STORE_BF16) {
+        bf16* c = reinterpret_cast<bf16*>(e.C) + off;
+        if (full) {
+          bf16x8 o;
+#pragma unroll
+          for (int t = 0; t < 8; ++t) o[t] = (bf16)v[t];
+          *reinterpret_cast<bf16x8*>(c) = o;
+        } else {
+#pragma unroll
+          for (int t = 0; t < 8; ++t)
+            if (n + t < e.N) c[t] = (bf16)v[t];
+        }
+      } else if (EPI == TTTS_EPI_GELU_BF16) {
+        bf16* c = reinterpret_cast<bf16*>(e.C) + off;
+        bf16* ax = e.aux + off;
+        bf16x8 pre, act;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          pre[t] = (bf16)v[t];
+          act[t] = (bf16)gelu_new_f((float)pre[t]);
+        }
+        if (full) {
+          *reinterpret_cast<bf16x8*>(ax) = pre;
+          *reinterpret_cast<bf16x8*>(c) = act;
+        } else {
+#pragma unroll
+          for (int t = 0; t < 8; ++t)
+            if (n + t < e.N) { ax[t] = pre[t]; c[t] = act[t]; }
+        }
+      } else if (EPI == TTTS_EPI_RESID_ADD_F32) {
+        float* c = reinterpret_cast<float*>(e.C) + off;
+        const float* rin = e.resid_in ? e.resid_in + off : c;
+        float y[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) y[t] = (float)(bf16)v[t];
+        if (e.thr) {  // resid_pdrop: element index m*N + n, 16 random bits per element (two elements per hash)
+          const uint32_t lin = (uint32_t)(((int64_t)m * e.N + n) >> 1);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const uint32_t r = hash32(lin + t, e.seed_lo, e.seed_hi);
+            y[2 * t] = (r & 0xFFFFu) >= e.thr ? y[2 * t] * e.inv_keep : 0.f;
+            y[2 * t + 1] = (r >> 16) >= e.thr ? y[2 * t + 1] * e.inv_keep : 0.f;
+          }
+        }
+        if (full) {
+          const float4 r0 = *reinterpret_cast<const float4*>(rin), r1 = *reinterpret_cast<const float4*>(rin + 4);
+          *reinterpret_cast<float4*>(c) = make_float4(r0.x + y[0], r0.y + y[1], r0.z + y[2], r0.w + y[3]);
+          *reinterpret_cast<float4*>(c + 4) = make_float4(r1.x + y[4], r1.y + y[5], r1.z + y[6], r1.w + y[7]);
+        } else {
+#pragma unroll
+          for (int t = 0; t < 8; ++t)
+            if (n + t < e.N) c[t] = rin[t] + y[t];
+        }
+      } else if (EPI == TTTS_EPI_DGELU_BF16) {
+        bf16* c = reinterpret_cast<bf16*>(e.C) + off;
+        const bf16* ax = e.aux + off;
+        if (full) {
+          const bf16x8 pre = *reinterpret_cast<const bf16x8*>(ax);
+          bf16x8 o;
+#pragma unroll
+          for (int t = 0; t < 8; ++t) o[t] = (bf16)(v[t] * gelu_new_grad_f((float)pre[t]));
+          *reinterpret_cast<bf16x8*>(c) = o;
+        } else {
+#pragma unroll
+          for (int t = 0; t < 8; ++t)
+            if (n + t < e.N) c[t] = (bf16)(v[t] * gelu_new_grad_f((float)ax[t]));
+        }
+      } else {  // STORE_F32 / ACCUM_F32 / SLAB_F32
+        float* c = reinterpret_cast<float*>(e.C) + off;
+        if (full) {
+          float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
+          if (EPI == EPI_ACCUM_F32) {
+            const float4 c0 = *reinterpret_cast<const float4*>(c), c1 = *reinterpret_cast<const float4*>(c + 4);
+            o0 = make_float4(c0.x + o0.x, c0.y + o0.y, c0.z + o0.z, c0.w + o0.w);
+            o1 = make_float4(c1.x + o1.x, c1.y + o1.y, c1.z + o1.z, c1.w + o1.w);
+          }
+          *reinterpret_cast<float4*>(c) = o0;
+          *reinterpret_cast<float4*>(c + 4) = o1;
+        } else {
+#pragma unroll
+          for (int t = 0; t < 8; ++t)
+            if (n + t < e.N) c[t] = (EPI == EPI_ACCUM_F32 ? c[t] : 0.f) + v[t];
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+#define ZERO_ACC(acc)                                 \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j)       \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i)       \
+  _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+
+__device__ __forceinline__ bool debug_drop(int debug, f32x16 (&acc)[2][2], void* C) {
+  if (!(debug & 1)) return false;  // ablation: keep the accumulators live, store (almost) nothing
+  float t = 0.f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += acc[j][i][r];
+  if (t == 123456.75f) reinterpret_cast<float*>(C)[0] = t;
+  return true;
+}
+
+// ---- NT, LDS-DMA main loop (K % 64 == 0) ---------------------------------------------------------------------------
+// LDS image per operand and buffer: [128 rows][64 k] bf16, 128-byte rows, NO padding (the DMA writes lane-linearly:
+// instruction (wave w, i) covers rows w*32 + i*8 .. +8, lane l -> row += l >> 3, 16-byte slot l & 7).  Slot s of row r
+// holds the logical k-chunk s ^ ((r >> 1) & 7); ds_read_b128 of a 16-lane service group then hits 64 distinct banks.
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmNtParams p) {
+  __shared__ __attribute__((aligned(16))) bf16 smem[2 * 2 * BM * BK];  // 64 KB: [buf][A|B][128*64]; reused as stage
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_n = (p.e.N + BN - 1) / BN;
+  const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+  const int nk = p.K / BK;
+
+  // this lane's DMA source rows (clamped: rows beyond M / N are loaded from the last valid row and never stored)
+  const bf16* ga[4];
+  const bf16* gb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = wave * 32 + i * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+    ga[i] = p.A + (int64_t)min(m0 + r, p.e.M - 1) * p.lda + chunk * 8;
+    gb[i] = p.B + (int64_t)min(n0 + r, p.e.N - 1) * p.ldb + chunk * 8;
+  }
+  auto issue = [&](int kt, int buf) {
+    bf16* as = smem + (buf * 2 + 0) * BM * BK + wave * 32 * BK;
+    bf16* bs = smem + (buf * 2 + 1) * BM * BK + wave * 32 * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[i] + kt * BK),
+                                       (__attribute__((address_space(3))) void*)(as + i * 8 * BK), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb[i] + kt * BK),
+                                       (__attribute__((address_space(3))) void*)(bs + i * 8 * BK), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];  // [j: 32-col block of N][i: 32-row block of M]; D = Btile . Atile^T (rows = n, cols = m)
+  ZERO_ACC(acc)
+  issue(0, 0);
+  __syncthreads();  // (hipcc drains the LDS-DMA -- vmcnt(0) -- in front of the barrier)
+  const int hh = lane >> 5;
+  int aoff[2], boff[2], sw[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ra = wm * 64 + i * 32 + (lane & 31), rb = wn * 64 + i * 32 + (lane & 31);
+    aoff[i] = ra * BK;
+    boff[i] = rb * BK;
+    sw[0][i] = (ra >> 1) & 7;
+    sw[1][i] = (rb >> 1) & 7;
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk && !(p.debug & 2)) issue(kt + 1, buf ^ 1);
+    const bf16* as = smem + (buf * 2 + 0) * BM * BK;
+    const bf16* bs = smem + (buf * 2 + 1) * BM * BK;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8 af[2], bfr[2];
+      const int lc = ks * 2 + hh;  // logical 16-byte chunk of this lane's 8 k-values
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = *reinterpret_cast<const bf16x8*>(as + aoff[i] + ((lc ^ sw[0][i]) << 3));
+        bfr[i] = *reinterpret_cast<const bf16x8*>(bs + boff[i] + ((lc ^ sw[1][i]) << 3));
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[j][i] = mfma32(bfr[j], af[i], acc[j][i]);
+    }
+    __syncthreads();  // next tile landed (vmcnt(0)) and everyone is done reading this one
+  }
+  if (debug_drop(p.debug, acc, p.e.C)) return;
+  tile_epilogue<EPI>(p.e, acc, reinterpret_cast<float*>(smem), m0, n0, tid);
+}
+
+// ---- NT, register-staged main loop (any K % 8 == 0; zero-fills ragged K) ---------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNtParams p) {
+  __shared__ __attribute__((aligned(16))) bf16 smem[2 * 2 * BM * NT_LDS_STRIDE];  // 72 KB
+  auto As = [&](int buf) { return smem + (2 * buf) * BM * NT_LDS_STRIDE; };
+  auto Bs = [&](int buf) { return smem + (2 * buf + 1) * BM * NT_LDS_STRIDE; };
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = (p.e.N + BN - 1) / BN;
   const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
   const int nk = (p.K + BK - 1) / BK;
 
@@ -52,27 +297,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNtParams p) {
       const int c = tid + i * 256, row = c >> 3, kc = (c & 7) * 8;
       const int k = kt * BK + kc;
       const int gm = m0 + row, gn = n0 + row;
-      ra[i] = (gm < p.M && k < p.K) ? *reinterpret_cast<const bf16x8*>(p.A + (int64_t)gm * p.lda + k) : zero8();
-      rb[i] = (gn < p.N && k < p.K) ? *reinterpret_cast<const bf16x8*>(p.B + (int64_t)gn * p.ldb + k) : zero8();
+      ra[i] = (gm < p.e.M && k < p.K) ? *reinterpret_cast<const bf16x8*>(p.A + (int64_t)gm * p.lda + k) : zero8();
+      rb[i] = (gn < p.e.N && k < p.K) ? *reinterpret_cast<const bf16x8*>(p.B + (int64_t)gn * p.ldb + k) : zero8();
     }
   };
   auto store_lds = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = tid + i * 256, row = c >> 3, kc = (c & 7) * 8;
-      *reinterpret_cast<bf16x8*>(&As[buf][row * NT_LDS_STRIDE + kc]) = ra[i];
-      *reinterpret_cast<bf16x8*>(&Bs[buf][row * NT_LDS_STRIDE + kc]) = rb[i];
+      *reinterpret_cast<bf16x8*>(As(buf) + row * NT_LDS_STRIDE + kc) = ra[i];
+      *reinterpret_cast<bf16x8*>(Bs(buf) + row * NT_LDS_STRIDE + kc) = rb[i];
     }
   };
 
-  f32x16 acc[2][2];  // [j: 32-col block of N][i: 32-row block of M]; D = Btile . Atile^T (rows = n, cols = m)
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
-
+  f32x16 acc[2][2];
+  ZERO_ACC(acc)
   load_regs(0);
   store_lds(0);
   __syncthreads();
@@ -80,8 +319,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNtParams p) {
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) load_regs(kt + 1);
-    const bf16* as = &As[buf][(wm * 64 + frow) * NT_LDS_STRIDE + fk];
-    const bf16* bs = &Bs[buf][(wn * 64 + frow) * NT_LDS_STRIDE + fk];
+    const bf16* as = As(buf) + (wm * 64 + frow) * NT_LDS_STRIDE + fk;
+    const bf16* bs = Bs(buf) + (wn * 64 + frow) * NT_LDS_STRIDE + fk;
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       bf16x8 af[2], bfr[2];
@@ -98,112 +337,41 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNtParams p) {
     if (kt + 1 < nk) store_lds(buf ^ 1);
     __syncthreads();
   }
-
-  // epilogue: lane owns row m = .. + (lane & 31); accumulator quad q covers columns n = .. + 8q + 4h + 0..3
-  const int h = lane >> 5;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = m0 + wm * 64 + i * 32 + (lane & 31);
-    if (m >= p.M) continue;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = n0 + wn * 64 + j * 32 + 8 * q + 4 * h;
-        if (n >= p.N) continue;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[j][i][4 * q + e];
-        if (p.bias) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (n + e < p.N) v[e] += (EPI == TTTS_EPI_STORE_F32) ? p.bias[n + e] : (float)(bf16)p.bias[n + e];
-        }
-        const int64_t off = (int64_t)m * p.ldc + n;
-        if (EPI == TTTS_EPI_STORE_BF16) {
-          bf16x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
-          *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.C) + off) = o;
-        } else if (EPI == TTTS_EPI_GELU_BF16) {
-          bf16x4 pre, act;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            pre[e] = (bf16)v[e];
-            act[e] = (bf16)gelu_new_f((float)pre[e]);
-          }
-          *reinterpret_cast<bf16x4*>(p.aux + off) = pre;
-          *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.C) + off) = act;
-        } else if (EPI == TTTS_EPI_RESID_ADD_F32) {
-          float* c = reinterpret_cast<float*>(p.C) + off;
-          const float* rin = p.resid_in ? p.resid_in + off : c;
-          float y[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) y[e] = (float)(bf16)v[e];
-          if (p.thr) {  // resid_pdrop: element index m*N + n, 16 random bits per element (pair hash)
-            const uint32_t lin = (uint32_t)(((int64_t)m * p.N + n) >> 1);
-            const uint32_t r0 = hash32(lin, p.seed_lo, p.seed_hi), r1 = hash32(lin + 1, p.seed_lo, p.seed_hi);
-            y[0] = (r0 & 0xFFFFu) >= p.thr ? y[0] * p.inv_keep : 0.f;
-            y[1] = (r0 >> 16) >= p.thr ? y[1] * p.inv_keep : 0.f;
-            y[2] = (r1 & 0xFFFFu) >= p.thr ? y[2] * p.inv_keep : 0.f;
-            y[3] = (r1 >> 16) >= p.thr ? y[3] * p.inv_keep : 0.f;
-          }
-          if (n + 3 < p.N) {
-            const float4 r = *reinterpret_cast<const float4*>(rin);
-            *reinterpret_cast<float4*>(c) = make_float4(r.x + y[0], r.y + y[1], r.z + y[2], r.w + y[3]);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (n + e < p.N) c[e] = rin[e] + y[e];
-          }
-        } else if (EPI == TTTS_EPI_DGELU_BF16) {
-          const bf16x4 pre = *reinterpret_cast<const bf16x4*>(p.aux + off);
-          bf16x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (bf16)(v[e] * gelu_new_grad_f((float)pre[e]));
-          *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.C) + off) = o;
-        } else {  // STORE_F32
-          float* c = reinterpret_cast<float*>(p.C) + off;
-          if (n + 3 < p.N) {
-            *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (n + e < p.N) c[e] = v[e];
-          }
-        }
-      }
-    }
-  }
+  if (debug_drop(p.debug, acc, p.e.C)) return;
+  tile_epilogue<EPI>(p.e, acc, reinterpret_cast<float*>(smem), m0, n0, tid);
 }
 
 // -------------------------------------------------------------------------------------------------------
+constexpr int BK_TN = 32;  // reduction rows per LDS tile: 40 KB of LDS per workgroup -> 3 workgroups per CU
+
 struct GemmTnParams {
   const bf16* At; int64_t ldat;
   const bf16* Bt; int64_t ldbt;
   float* C; int64_t ldc;
-  int Mo, No, Kr, k_chunk;
+  float* partial;      // [splits][Mo][ldp] fp32 slabs when splits > 1
+  int64_t ldp;
+  int Mo, No, Kr, k_chunk, splits;
 };
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTnParams p) {
-  __shared__ __attribute__((aligned(16))) bf16 As[2][BK * TN_LDS_STRIDE];  // [k][m]
-  __shared__ __attribute__((aligned(16))) bf16 Bs[2][BK * TN_LDS_STRIDE];  // [k][n]
+__global__ __launch_bounds__(256, 3) void gemm_tn_kernel(GemmTnParams p) {
+  __shared__ __attribute__((aligned(16))) bf16 smem[2 * 2 * BK_TN * TN_LDS_STRIDE];  // 40 KB; reused as the stage
+  auto As = [&](int buf) { return smem + (2 * buf) * BK_TN * TN_LDS_STRIDE; };      // [k][m]
+  auto Bs = [&](int buf) { return smem + (2 * buf + 1) * BK_TN * TN_LDS_STRIDE; };  // [k][n]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int tiles_n = (p.No + BN - 1) / BN;
   const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
   const int kbeg = blockIdx.y * p.k_chunk;
   const int kend = min(p.Kr, kbeg + p.k_chunk);
-  const int nk = (kend - kbeg + BK - 1) / BK;
-  if (nk <= 0) return;
+  const int nk = (kend - kbeg + BK_TN - 1) / BK_TN;
 
-  // staging map: chunk c = tid + i*256 (i < 4): k-row = c >> 4, 16-byte chunk along m/n = c & 15
-  bf16x8 ra[4], rb[4];
+  // staging map: chunk c = tid + i*256 (i < 2): k-row = c >> 4, 16-byte chunk along m/n = c & 15
+  bf16x8 ra[2], rb[2];
   auto load_regs = [&](int kt) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 2; ++i) {
       const int c = tid + i * 256, kr = c >> 4, mc = (c & 15) * 8;
-      const int k = kbeg + kt * BK + kr;
+      const int k = kbeg + kt * BK_TN + kr;
       const bool kv = k < kend;
       ra[i] = (kv && m0 + mc < p.Mo) ? *reinterpret_cast<const bf16x8*>(p.At + (int64_t)k * p.ldat + m0 + mc) : zero8();
       rb[i] = (kv && n0 + mc < p.No) ? *reinterpret_cast<const bf16x8*>(p.Bt + (int64_t)k * p.ldbt + n0 + mc) : zero8();
@@ -211,23 +379,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTnParams p) {
   };
   auto store_lds = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 2; ++i) {
       const int c = tid + i * 256, kr = c >> 4, mc = (c & 15) * 8;
-      *reinterpret_cast<bf16x8*>(&As[buf][kr * TN_LDS_STRIDE + mc]) = ra[i];
-      *reinterpret_cast<bf16x8*>(&Bs[buf][kr * TN_LDS_STRIDE + mc]) = rb[i];
+      *reinterpret_cast<bf16x8*>(As(buf) + kr * TN_LDS_STRIDE + mc) = ra[i];
+      *reinterpret_cast<bf16x8*>(Bs(buf) + kr * TN_LDS_STRIDE + mc) = rb[i];
     }
   };
 
   f32x16 acc[2][2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
-
-  load_regs(0);
-  store_lds(0);
+  ZERO_ACC(acc)
+  if (nk > 0) {
+    load_regs(0);
+    store_lds(0);
+  }
   __syncthreads();
   // transposed-read lane map: 16-lane group g = lane >> 4 covers columns 16*(g & 1) + 0..15 of a 32-wide block and
   // k-rows 8*(g >> 1) + {0..3} (first read) / + {4..7} (second read); lane i' = lane & 15 addresses
@@ -237,10 +401,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTnParams p) {
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) load_regs(kt + 1);
-    const bf16* as = &As[buf][tr_off + wm * 64];
-    const bf16* bs = &Bs[buf][tr_off + wn * 64];
+    const bf16* as = As(buf) + tr_off + wm * 64;
+    const bf16* bs = Bs(buf) + tr_off + wn * 64;
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
+    for (int ks = 0; ks < BK_TN / 16; ++ks) {
       bf16x8 af[2], bfr[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -257,27 +421,57 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTnParams p) {
     if (kt + 1 < nk) store_lds(buf ^ 1);
     __syncthreads();
   }
-  const int h = lane >> 5;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = m0 + wm * 64 + i * 32 + (lane & 31);
-    if (m >= p.Mo) continue;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = n0 + wn * 64 + j * 32 + 8 * q + 4 * h;
-        float* c = p.C + (int64_t)m * p.ldc + n;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (n + e < p.No) atomicAdd(c + e, acc[j][i][4 * q + e]);
-      }
+  // one split: C += acc (this workgroup owns the tile); several: store the fp32 slab, gemm_tn_reduce_kernel sums the
+  // slabs in a fixed order (deterministic; device-scope fp32 atomics were ~6x slower here)
+  GemmEpi e{};
+  e.M = p.Mo;
+  e.N = p.No;
+  if (p.splits > 1) {
+    e.C = p.partial + (int64_t)blockIdx.y * p.Mo * p.ldp;
+    e.ldc = p.ldp;
+    tile_epilogue<EPI_SLAB_F32>(e, acc, reinterpret_cast<float*>(smem), m0, n0, tid);
+  } else {
+    e.C = p.C;
+    e.ldc = p.ldc;
+    tile_epilogue<EPI_ACCUM_F32>(e, acc, reinterpret_cast<float*>(smem), m0, n0, tid);
   }
+}
+
+// C[m][n] += sum_s partial[s][m][n]   (float4 per thread, slabs read in split order)
+__global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __restrict__ partial, int64_t ldp, int splits,
+                                                             float* __restrict__ C, int64_t ldc, int Mo, int No) {
+  const int n4 = (int)(ldp >> 2);
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)Mo * n4) return;
+  const int m = (int)(i / n4), n = (int)(i % n4) * 4;
+  if (n >= No) return;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int sp = 0; sp < splits; ++sp) {
+    const float4 v = *reinterpret_cast<const float4*>(partial + ((int64_t)sp * Mo + m) * ldp + n);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  float* c = C + (int64_t)m * ldc + n;
+  const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (n + e < No) c[e] += sv[e];
 }
 
 }  // namespace ttts
 
 using namespace ttts;
+
+static int g_debug_flags = 0;
+extern "C" int ttts_debug_set_flags(int32_t flags) {
+  g_debug_flags = flags;
+  return TTTS_OK;
+}
+
+template <int EPI>
+static void launch_nt(const GemmNtParams& p, int grid, hipStream_t s) {
+  if (p.K % BK == 0 && !(g_debug_flags & 8)) gemm_nt_glds_kernel<EPI><<<grid, 256, 0, s>>>(p);
+  else gemm_nt_kernel<EPI><<<grid, 256, 0, s>>>(p);
+}
 
 extern "C" int ttts_gemm_nt_bf16_ex(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                                     const float* bias, void* aux, int32_t M, int32_t N, int32_t K, int32_t epilogue,
@@ -287,20 +481,22 @@ extern "C" int ttts_gemm_nt_bf16_ex(const void* A, int64_t lda, const void* B, i
   TTTS_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K, "gemm_nt: K, lda, ldb must be multiples of 8 (K=%d lda=%lld ldb=%lld)", K, (long long)lda, (long long)ldb);
   TTTS_REQUIRE(ldc % 4 == 0 && ldc >= ((N + 3) / 4) * 4, "gemm_nt: ldc must be a multiple of 4 and >= roundup4(N)");
   TTTS_REQUIRE(aligned16(A) && aligned16(B) && aligned16(C), "gemm_nt: 16-byte aligned bases required");
-  TTTS_REQUIRE((epilogue != TTTS_EPI_GELU_BF16 && epilogue != TTTS_EPI_DGELU_BF16) || aux, "gemm_nt: epilogue needs aux");
+  TTTS_REQUIRE((epilogue != TTTS_EPI_GELU_BF16 && epilogue != TTTS_EPI_DGELU_BF16) || (aux && aligned16(aux)), "gemm_nt: epilogue needs a 16-byte aligned aux");
   TTTS_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "gemm_nt: dropout_p out of range");
-  TTTS_REQUIRE(dropout_p == 0.f || (epilogue == TTTS_EPI_RESID_ADD_F32 && N % 4 == 0), "gemm_nt: dropout only with RESID_ADD and N %% 4 == 0");
-  GemmNtParams p{(const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, bias, (bf16*)aux, resid_in, M, N, K,
-                 dropout_threshold(dropout_p), 1.0f, (uint32_t)seed, (uint32_t)(seed >> 32)};
-  if (p.thr) p.inv_keep = 65536.0f / (65536.0f - (float)p.thr);
+  TTTS_REQUIRE(dropout_p == 0.f || (epilogue == TTTS_EPI_RESID_ADD_F32 && N % 8 == 0), "gemm_nt: dropout only with RESID_ADD and N %% 8 == 0");
+  TTTS_REQUIRE(!resid_in || aligned16(resid_in), "gemm_nt: resid_in must be 16-byte aligned");
+  GemmNtParams p{(const bf16*)A, lda, (const bf16*)B, ldb, K, g_debug_flags,
+                 GemmEpi{C, ldc, bias, (bf16*)aux, resid_in, M, N, dropout_threshold(dropout_p), 1.0f, (uint32_t)seed,
+                         (uint32_t)(seed >> 32), g_debug_flags}};
+  if (p.e.thr) p.e.inv_keep = 65536.0f / (65536.0f - (float)p.e.thr);
   const int grid = (int)(cdiv(M, BM) * cdiv(N, BN));
   hipStream_t s = as_stream(stream);
   switch (epilogue) {
-    case TTTS_EPI_STORE_BF16: gemm_nt_kernel<TTTS_EPI_STORE_BF16><<<grid, 256, 0, s>>>(p); break;
-    case TTTS_EPI_GELU_BF16: gemm_nt_kernel<TTTS_EPI_GELU_BF16><<<grid, 256, 0, s>>>(p); break;
-    case TTTS_EPI_RESID_ADD_F32: gemm_nt_kernel<TTTS_EPI_RESID_ADD_F32><<<grid, 256, 0, s>>>(p); break;
-    case TTTS_EPI_DGELU_BF16: gemm_nt_kernel<TTTS_EPI_DGELU_BF16><<<grid, 256, 0, s>>>(p); break;
-    case TTTS_EPI_STORE_F32: gemm_nt_kernel<TTTS_EPI_STORE_F32><<<grid, 256, 0, s>>>(p); break;
+    case TTTS_EPI_STORE_BF16: launch_nt<TTTS_EPI_STORE_BF16>(p, grid, s); break;
+    case TTTS_EPI_GELU_BF16: launch_nt<TTTS_EPI_GELU_BF16>(p, grid, s); break;
+    case TTTS_EPI_RESID_ADD_F32: launch_nt<TTTS_EPI_RESID_ADD_F32>(p, grid, s); break;
+    case TTTS_EPI_DGELU_BF16: launch_nt<TTTS_EPI_DGELU_BF16>(p, grid, s); break;
+    case TTTS_EPI_STORE_F32: launch_nt<TTTS_EPI_STORE_F32>(p, grid, s); break;
     default: return fail(TTTS_EUNSUPPORTED, "gemm_nt: unknown epilogue %d", epilogue);
   }
   return check_launch("gemm_nt");
@@ -312,19 +508,38 @@ extern "C" int ttts_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int6
   return ttts_gemm_nt_bf16_ex(A, lda, B, ldb, C, ldc, bias, aux, M, N, K, epilogue, nullptr, 0.f, 0, stream);
 }
 
+static void tn_plan(int Mo, int No, int Kr, int& splits, int& k_chunk) {
+  const int tiles = (int)(cdiv(Mo, BM) * cdiv(No, BN));
+  // enough workgroups to fill 256 CUs (~1.5 per CU), as few slabs as possible, >= 256 reduction rows per split
+  splits = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(Kr, 256), (384 + tiles / 2) / tiles));
+  k_chunk = (int)(cdiv(cdiv(Kr, splits), BK_TN) * BK_TN);
+  splits = (int)cdiv(Kr, k_chunk);
+}
+
+extern "C" int64_t ttts_gemm_tn_workspace_bytes(int32_t Mo, int32_t No, int32_t Kr) {
+  int splits, k_chunk;
+  tn_plan(Mo, No, Kr, splits, k_chunk);
+  return splits > 1 ? (int64_t)splits * Mo * (((int64_t)No + 7) / 8 * 8) * (int64_t)sizeof(float) : 0;
+}
+
 extern "C" int ttts_gemm_tn_bf16_accum_f32(const void* At, int64_t ldat, const void* Bt, int64_t ldbt, float* C,
-                                           int64_t ldc, int32_t Mo, int32_t No, int32_t Kr, void* stream) {
+                                           int64_t ldc, int32_t Mo, int32_t No, int32_t Kr, void* workspace,
+                                           void* stream) {
   TTTS_REQUIRE(At && Bt && C, "gemm_tn: null pointer");
   TTTS_REQUIRE(Mo > 0 && No > 0 && Kr > 0, "gemm_tn: bad shape");
   TTTS_REQUIRE(ldat % 8 == 0 && ldbt % 8 == 0 && ldat >= ((Mo + 7) / 8) * 8 && ldbt >= ((No + 7) / 8) * 8,
                "gemm_tn: ldat/ldbt must be multiples of 8 and cover roundup8(Mo/No)");
-  TTTS_REQUIRE(aligned16(At) && aligned16(Bt), "gemm_tn: 16-byte aligned bases required");
+  TTTS_REQUIRE(aligned16(At) && aligned16(Bt) && aligned16(C), "gemm_tn: 16-byte aligned bases required");
+  int splits, k_chunk;
+  tn_plan(Mo, No, Kr, splits, k_chunk);
+  TTTS_REQUIRE(splits == 1 || (workspace && aligned16(workspace)), "gemm_tn: workspace (ttts_gemm_tn_workspace_bytes) required");
   const int tiles = (int)(cdiv(Mo, BM) * cdiv(No, BN));
-  // split the reduction so that ~3 workgroups per CU are in flight (256 CUs)
-  int splits = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(Kr, 2 * BK), cdiv(768, tiles)));
-  const int k_chunk = (int)(cdiv(cdiv(Kr, splits), BK) * BK);
-  splits = (int)cdiv(Kr, k_chunk);
-  GemmTnParams p{(const bf16*)At, ldat, (const bf16*)Bt, ldbt, C, ldc, Mo, No, Kr, k_chunk};
-  gemm_tn_kernel<<<dim3(tiles, splits), 256, 0, as_stream(stream)>>>(p);
-  return check_launch("gemm_tn");
+  const int64_t ldp = ((int64_t)No + 7) / 8 * 8;
+  GemmTnParams p{(const bf16*)At, ldat, (const bf16*)Bt, ldbt, C, ldc, (float*)workspace, ldp, Mo, No, Kr, k_chunk, splits};
+  hipStream_t s = as_stream(stream);
+  gemm_tn_kernel<<<dim3(tiles, splits), 256, 0, s>>>(p);
+  int rc = check_launch("gemm_tn");
+  if (rc || splits == 1) return rc;
+  gemm_tn_reduce_kernel<<<(int)cdiv((int64_t)Mo * (ldp / 4), 256), 256, 0, s>>>((const float*)workspace, ldp, splits, C, ldc, Mo, No);
+  return check_launch("gemm_tn_reduce");
 }

@@ -192,6 +192,8 @@ class GptEngine:
         b["dqkv"] = e(M, 3 * D)
         b["delta"] = e(B * H * S, dt=f32)
         b["ln_ws"] = ops.layernorm_bwd_workspace(M, D, dev)
+        tn_shapes = [(D, 3 * D, M), (D, D, M), (D, 4 * D, M), (4 * D, D, M), (self.nt, D, B * Tt), (self.nm, D, B * Tm)]
+        b["tn_ws"] = max((ops.gemm_tn_workspace(mo, no, kr, dev) for mo, no, kr in tn_shapes), key=lambda t: t.numel())
         # static token buffers (graph replay reads them)
         i64 = torch.int64
         b["text_inp"] = torch.zeros(B, Tt, dtype=i64, device=dev)
@@ -271,8 +273,8 @@ class GptEngine:
         ops.ce_bwd(b["logits_t"], b["text_tar"], b["rows_t"][1], b["dlog_t"], self.nt, w_text, g_text_dev)
         ops.ce_bwd(b["logits_m"], b["mel_tar"], b["rows_m"][1], b["dlog_m"], self.nm, w_mel, g_mel_dev)
         enc_t, enc_m = b["enc"][:B * Tt], b["enc"][B * Tt:]
-        ops.gemm_tn_accum(b["dlog_t"], enc_t, G("text_head.weight"), mo=self.nt)
-        ops.gemm_tn_accum(b["dlog_m"], enc_m, G("mel_head.weight"), mo=self.nm)
+        ops.gemm_tn_accum(b["dlog_t"], enc_t, G("text_head.weight"), mo=self.nt, workspace=b["tn_ws"])
+        ops.gemm_tn_accum(b["dlog_m"], enc_m, G("mel_head.weight"), mo=self.nm, workspace=b["tn_ws"])
         ops.colsum_accum(b["dlog_t"], G("text_head.bias"), n=self.nt)
         ops.colsum_accum(b["dlog_m"], G("mel_head.bias"), n=self.nm)
         ops.gemm_nt(b["dlog_t"], self.wT["text_head.weight"], b["d_enc"][:B * Tt])
@@ -282,35 +284,34 @@ class GptEngine:
                           G("final_norm.weight"), G("final_norm.bias"), b["ln_ws"], split=(S, Tt))
         ops.layernorm_bwd(b["d_tmp"], b["xs"][2 * L], P("gpt.ln_f.weight"), fs[0], fs[1], None, b["dres"], b["dres_bf"],
                           G("gpt.ln_f.weight"), G("gpt.ln_f.bias"), b["ln_ws"], dropout_p=p,
-                          seed=self._seed(16 * (L - 1) + 4))
+                          seed=self._seed(16 * (L - 1) + 4), dcolsum=G("gpt.h.%d.mlp.c_proj.bias" % (L - 1)))
         for i in reversed(range(L)):
             pre = "gpt.h.%d." % i
             st = b["stats"][i]
             x0, x1 = b["xs"][2 * i], b["xs"][2 * i + 1]
             dy = b["dres_bf"]                                  # gradient entering mlp.c_proj (resid dropout applied)
-            ops.gemm_tn_accum(b["fc_act"][i], dy, G(pre + "mlp.c_proj.weight"))
-            ops.colsum_accum(dy, G(pre + "mlp.c_proj.bias"))
+            ops.gemm_tn_accum(b["fc_act"][i], dy, G(pre + "mlp.c_proj.weight"), workspace=b["tn_ws"])
             ops.gemm_nt(dy, self.w(pre + "mlp.c_proj.weight"), b["d_fc"], aux=b["fc_pre"][i], epilogue=EPI_DGELU_BF16)
-            ops.gemm_tn_accum(b["ln2"][i], b["d_fc"], G(pre + "mlp.c_fc.weight"))
+            ops.gemm_tn_accum(b["ln2"][i], b["d_fc"], G(pre + "mlp.c_fc.weight"), workspace=b["tn_ws"])
             ops.colsum_accum(b["d_fc"], G(pre + "mlp.c_fc.bias"))
             ops.gemm_nt(b["d_fc"], self.w(pre + "mlp.c_fc.weight"), b["d_ln"])
             ops.layernorm_bwd(b["d_ln"], x1, P(pre + "ln_2.weight"), st[2], st[3], b["dres"], b["dres"], b["dres_bf"],
                               G(pre + "ln_2.weight"), G(pre + "ln_2.bias"), b["ln_ws"], dropout_p=p,
-                              seed=self._seed(16 * i + 3))
+                              seed=self._seed(16 * i + 3), dcolsum=G(pre + "attn.c_proj.bias"))
             dy = b["dres_bf"]                                  # gradient entering attn.c_proj
-            ops.gemm_tn_accum(b["att"][i], dy, G(pre + "attn.c_proj.weight"))
-            ops.colsum_accum(dy, G(pre + "attn.c_proj.bias"))
+            ops.gemm_tn_accum(b["att"][i], dy, G(pre + "attn.c_proj.weight"), workspace=b["tn_ws"])
             ops.gemm_nt(dy, self.w(pre + "attn.c_proj.weight"), b["d_att"])
             qkv, dqkv = b["qkv"][i], b["dqkv"]
             ops.attn_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], b["att"][i], b["d_att"], b["lse"][i], dqkv, dqkv[:, D:],
                          dqkv[:, 2 * D:], b["delta"], B, H, S, dh, (S * 3 * D, 3 * D), (S * D, D), dh ** -0.5, p,
                          self._seed(16 * i + 2))
-            ops.gemm_tn_accum(b["ln1"][i], dqkv, G(pre + "attn.c_attn.weight"))
+            ops.gemm_tn_accum(b["ln1"][i], dqkv, G(pre + "attn.c_attn.weight"), workspace=b["tn_ws"])
             ops.colsum_accum(dqkv, G(pre + "attn.c_attn.bias"))
             ops.gemm_nt(dqkv, self.w(pre + "attn.c_attn.weight"), b["d_ln"])
             ops.layernorm_bwd(b["d_ln"], x0, P(pre + "ln_1.weight"), st[0], st[1], b["dres"], b["dres"],
                               b["dres_bf"] if i > 0 else None, G(pre + "ln_1.weight"), G(pre + "ln_1.bias"),
-                              b["ln_ws"], dropout_p=p if i > 0 else 0.0, seed=self._seed(16 * (i - 1) + 4))
+                              b["ln_ws"], dropout_p=p if i > 0 else 0.0, seed=self._seed(16 * (i - 1) + 4),
+                              dcolsum=G("gpt.h.%d.mlp.c_proj.bias" % (i - 1)) if i > 0 else None)
         ops.embed_bwd(b["text_inp"], b["mel_inp"], b["dres"], G("text_embedding.weight"),
                       G("text_pos_embedding.emb.weight"), G("mel_embedding.weight"), G("mel_pos_embedding.emb.weight"),
                       p, self._seed(1))

@@ -75,7 +75,8 @@ SIGNATURES = {
     "ttts_device_info": (_I32, [_P]),
     "ttts_gemm_nt_bf16": (_I32, [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "ttts_gemm_nt_bf16_ex": (_I32, [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I32, _I32, _I32, _I32, _P, _F, _U64, _P]),
-    "ttts_gemm_tn_bf16_accum_f32": (_I32, [_P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P]),
+    "ttts_gemm_tn_workspace_bytes": (_I64, [_I32, _I32, _I32]),
+    "ttts_gemm_tn_bf16_accum_f32": (_I32, [_P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _P]),
     "ttts_colsum_bf16_accum_f32": (_I32, [_P, _I64, _P, _I32, _I32, _P]),
     "ttts_cast_desc_tiles": (_I32, [_I32, _I32]),
     "ttts_cast_bf16_batched": (_I32, [_P, _I32, _I32, _P]),
@@ -88,8 +89,8 @@ SIGNATURES = {
     "ttts_layernorm_fwd": (_I32, [_P, _P, _P, _P, _I32, _P, _P, _I32, _I32, _F, _I32, _I32, _P]),
     "ttts_layernorm_bwd_workspace_bytes": (_I64, [_I32, _I32]),
     "ttts_layernorm_bwd": (_I32, [_P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
-    "ttts_layernorm_bwd_ex": (_I32, [_P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _U64,
-                                     _P]),
+    "ttts_layernorm_bwd_ex": (_I32, [_P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F,
+                                     _U64, _P]),
     "ttts_gpt_embed_fwd": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _F, _U64, _P]),
     "ttts_gpt_embed_bwd": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _U64, _P]),
     "ttts_ce_fwd_bf16": (_I32, [_P, _I64, _P, _P, _P, _P, _I32, _I32, _P]),
@@ -107,6 +108,7 @@ SIGNATURES = {
     "ttts_stft_mag_fwd_f32": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "ttts_mel_log_fwd_f32": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "ttts_probe_mfma_layout": (_I32, [_P, _P, _P]),
+    "ttts_debug_set_flags": (_I32, [_I32]),
 }
 
 _lib = None

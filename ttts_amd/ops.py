@@ -62,14 +62,24 @@ def gemm_nt(a, b, c, bias=None, aux=None, epilogue=EPI_STORE_BF16, n=None, k=Non
     return c
 
 
-def gemm_tn_accum(at, bt, c, mo=None, no=None):
-    """c[Mo,No] += at[Kr,Mo]^T @ bt[Kr,No]  (fp32 accumulate)."""
+def gemm_tn_workspace(mo, no, kr, device):
+    n = _l.get().ttts_gemm_tn_workspace_bytes(mo, no, kr)
+    return torch.empty(max(n, 16) // 4, dtype=torch.float32, device=device)
+
+
+def gemm_tn_accum(at, bt, c, mo=None, no=None, workspace=None):
+    """c[Mo,No] += at[Kr,Mo]^T @ bt[Kr,No]  (fp32; split-K slabs in `workspace`, summed deterministically)."""
     _req(at, torch.bfloat16, "at"); _req(bt, torch.bfloat16, "bt"); _req(c, torch.float32, "c")
     Kr = at.shape[0]
     Mo = at.shape[1] if mo is None else mo
     No = bt.shape[1] if no is None else no
-    check(_l.get().ttts_gemm_tn_bf16_accum_f32(_p(at), _ld(at), _p(bt), _ld(bt), _p(c), _ld(c), Mo, No, Kr, _stream()),
-          "gemm_tn")
+    need = _l.get().ttts_gemm_tn_workspace_bytes(Mo, No, Kr)
+    if workspace is None:
+        workspace = gemm_tn_workspace(Mo, No, Kr, at.device)
+    elif workspace.numel() * workspace.element_size() < need:
+        raise TttsError("gemm_tn workspace too small (%d < %d bytes)" % (workspace.numel() * workspace.element_size(), need))
+    check(_l.get().ttts_gemm_tn_bf16_accum_f32(_p(at), _ld(at), _p(bt), _ld(bt), _p(c), _ld(c), Mo, No, Kr,
+                                               _p(workspace), _stream()), "gemm_tn")
     return c
 
 
@@ -120,12 +130,13 @@ def layernorm_bwd_workspace(M, D, device):
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx_in, dx, dx_bf16, dgamma, dbeta, workspace, split=(0, 0), dropout_p=0.0,
-                  seed=0):
+                  seed=0, dcolsum=None):
     _req(x, torch.float32, "x"); _req(dx, torch.float32, "dx"); _req(dx_bf16, torch.bfloat16, "dx_bf16")
     M, D = x.shape
     check(_l.get().ttts_layernorm_bwd_ex(_p(dy), int(dy.dtype == torch.bfloat16), _p(x), _p(gamma), _p(mean), _p(rstd),
-                                         _p(dx_in), _p(dx), _p(dx_bf16), _p(dgamma), _p(dbeta), _p(workspace), M, D,
-                                         split[0], split[1], dropout_p, seed, _stream()), "layernorm_bwd")
+                                         _p(dx_in), _p(dx), _p(dx_bf16), _p(dgamma), _p(dbeta), _p(dcolsum),
+                                         _p(workspace), M, D, split[0], split[1], dropout_p, seed, _stream()),
+          "layernorm_bwd")
 
 
 def embed_fwd(text_inp, mel_inp, text_emb, text_pos, mel_emb, mel_pos, x, dropout_p=0.0, seed=0):
