@@ -110,9 +110,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--mode", default="train", choices=["train", "graph_nodropout"],
-                    help="train: reference training mode (dropout 0.1), eager launches; graph_nodropout: dropout off, "
-                         "whole step replayed from one hipGraph (diagnostic, not the headline)")
+    ap.add_argument("--mode", default="train", choices=["train", "eager", "graph_nodropout"],
+                    help="train: reference training mode (dropout 0.1), whole step replayed from one hipGraph (N = 1) -- "
+                         "the headline; eager: same, launch by launch; graph_nodropout: dropout off (diagnostic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3)
     args = ap.parse_args()
@@ -126,7 +126,7 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     cfg = json.load(open(os.path.join(ROOT, "ttts_amd", "gpt", "config.json")))
-    dropout = 0.1 if args.mode == "train" else 0.0
+    dropout = 0.0 if args.mode == "graph_nodropout" else 0.1
     eng = GptEngine(cfg["gpt"], dev, dropout_p=dropout, seed=rank)
     # random-init weights of the named architecture (no checkpoints offline): GPT-2 init via the module surface
     from ttts_amd.gpt import UnifiedVoice  # noqa: F401  (initialisation rule lives there)
@@ -153,7 +153,7 @@ def main():
 
     def step():
         toks = prepare_tokens(eng.c, text_d, tl, mel_d, wl)   # token plumbing (lengths are host tensors: no sync)
-        if args.mode == "graph_nodropout" and world == 1:
+        if args.mode != "eager" and world == 1:
             eng.train_step(toks, w_text, w_mel, capture=True, lr=tr["lr"])
             return
         eng.set_tokens(*toks)
@@ -181,7 +181,7 @@ def main():
     roof = None
     if rank == 0:
         saved_mode = args.mode
-        args.mode = "train"
+        args.mode = "eager"
         with KernelTimer(ops) as kt:
             for _ in range(args.profile_steps):
                 step()
@@ -206,7 +206,7 @@ def main():
                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": "VALL-E GPT train step (ttts/gpt/config.json model: 6 layers, d512, 8 heads, 21.46 M "
                                       "params), batch 8 per GPU x (128 text + 1024 audio tokens) = S 1156, fwd+bwd+clip+AdamW, "
-                                      "dropout %.1f, %s" % (dropout, "eager launches" if args.mode == "train" else "hipGraph replay"),
+                                      "dropout %.1f, %s" % (dropout, "eager launches" if (args.mode == "eager" or world > 1) else "hipGraph replay"),
                           "global_batch": world * B_PER_GPU, "seq_len": TEXT_LEN + 2 + MEL_LEN + 2, "parallelism": "dp%d" % world,
                           "mode": args.mode},
                "final_loss_mel": round(lm, 4), "roofline": roof}

@@ -39,6 +39,11 @@ extern "C" {
 /* ---- library ------------------------------------------------------------------------------------ */
 int ttts_abi_version(void);
 const char* ttts_last_error(void);
+/* Process-wide dropout stream counter: `device_counter` points to a uint32 in DEVICE memory owned by the caller (or
+ * NULL to disable).  Every dropout-capable kernel adds it to its `seed` at run time; incrementing it once per step
+ * (on the stream) gives fresh masks on each replay of a captured hipGraph.  Forward and backward of one step must
+ * see the same value. */
+int ttts_set_dropout_counter(const uint32_t* device_counter);
 /* Device query: writes {gfx arch number (950), CU count, wavefront size, LDS bytes/CU}. */
 int ttts_device_info(int32_t out[4]);
 

@@ -187,3 +187,31 @@ def test_trainer_entry_point(gpt, tmp_path):
     assert data["step"] == 2 and torch.equal(tr2.gpt.engine.params.cpu(), tr.gpt.engine.params.cpu())
     log = [json.loads(l) for l in open(tr.logs_folder / "train_log.jsonl")]
     assert len(log) == 3 and all(np.isfinite(r["loss"]) for r in log)
+
+
+def test_dropout_training_under_graph_replay(gpt):
+    """Dropout masks come from (constant per-site seed + device-side stream counter): the whole step, dropout
+    included, replays from ONE hipGraph and still draws fresh masks every step."""
+    from oracle import gpt_ref
+    cfg = dict(gpt_ref.GPT_CONFIG)
+    cfg["layers"] = 2
+    dev = torch.device("cuda:0")
+    eng = gpt.GptEngine(cfg, dev, dropout_p=0.1, seed=3)
+    eng.load_state_dict(gpt_ref.det_state_dict(cfg))
+    batch = gpt_ref.synthetic_batch(B=2, text_len=32, mel_len=200, seed=5, cfg=cfg)
+    toks = gpt.prepare_tokens(eng.c, *batch)
+    c0 = int(eng.seed_ctr.item())
+    eng.set_tokens(*toks)
+    eng.forward(); a = eng.losses()
+    eng.forward(); b = eng.losses()
+    assert a == b                                   # same counter -> same masks
+    losses = []
+    for _ in range(4):
+        eng.train_step(toks, 0.01, 1.0, capture=True, lr=0.0)   # lr 0: only the masks change between replays
+        losses.append(eng.losses()[1])
+    assert int(eng.seed_ctr.item()) == c0 + 4
+    assert all(np.isfinite(losses)) and len(set(losses)) == 4, losses
+    eng.training = False
+    eng.forward()
+    lm_eval = eng.losses()[1]
+    assert abs(np.mean(losses) - lm_eval) < 0.2 * abs(lm_eval)

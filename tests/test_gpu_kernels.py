@@ -282,6 +282,19 @@ def test_attention_dropout_matches_mask(ops):
     assert rel_err(dqkv.view(B, S, 3 * D).float(), leaf.grad) < 2e-2
 
 
+def test_dropout_counter_gives_fresh_masks(ops):
+    """The device-side stream counter (graph-replay-safe dropout): same seed + same counter -> same mask,
+    counter + 1 -> a different mask with the same keep rate."""
+    ctr = ops.dropout_counter(dev())
+    m1 = ops.attn_dropout_mask(1, 2, 96, 0.1, 42, dev()).clone()
+    m2 = ops.attn_dropout_mask(1, 2, 96, 0.1, 42, dev()).clone()
+    assert torch.equal(m1, m2)
+    ctr.add_(1)
+    m3 = ops.attn_dropout_mask(1, 2, 96, 0.1, 42, dev())
+    assert not torch.equal(m1, m3) and abs(m3.float().mean().item() - 0.9) < 0.02
+    assert abs((m1 == m3).float().mean().item() - 0.82) < 0.03   # independent masks agree with prob 0.9^2 + 0.1^2
+
+
 # ---------------------------------------------------------------------------------------------------------------
 def test_adamw_and_gradnorm(ops):
     n = 100_000

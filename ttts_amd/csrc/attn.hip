@@ -34,6 +34,7 @@ struct AttnParams {
   uint32_t thr;      // dropout threshold on 16 random bits (0 = no dropout)
   float inv_keep;
   uint32_t seed_lo, seed_hi;
+  const uint32_t* ctr;  // process-wide dropout stream counter (device) or NULL
 };
 
 constexpr float NEG_BIG = -1.0e30f;
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   const int k_nat = (lane & 31) * C::KSTR + hh * 8;
   const int v_tr = (4 * hh + (ip >> 2)) * C::VSTR + 16 * (g & 1) + 4 * (ip & 3);
   const uint32_t e_row = (uint32_t)(((int64_t)(b * p.H + h) * p.S + query) * p.Sp);
+  const uint32_t shi = DROPOUT ? seed_mix(p.seed_hi, p.ctr) : 0u;
 
   for (int jt = 0; jt < nt; ++jt) {
     const int buf = jt & 1, kv0 = jt * 64;
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
           bool keep[4] = {true, true, true, true};
-          if (DROPOUT) drop_keep4(e_row + (uint32_t)(kv0 + kb * 32 + 8 * qd + 4 * hh), p.thr, p.seed_lo, p.seed_hi, keep);
+          if (DROPOUT) drop_keep4(e_row + (uint32_t)(kv0 + kb * 32 + 8 * qd + 4 * hh), p.thr, p.seed_lo, shi, keep);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int r = 4 * qd + e;
@@ -288,6 +290,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   const int k_nat = (lane & 31) * C::KSTR + hh * 8;
   const int k_tr = (4 * hh + (ip >> 2)) * C::KSTR + 16 * (g & 1) + 4 * (ip & 3);
   const uint32_t e_row = (uint32_t)(((int64_t)(b * p.H + h) * p.S + query) * p.Sp);
+  const uint32_t shi = DROPOUT ? seed_mix(p.seed_hi, p.ctr) : 0u;
 
   for (int jt = 0; jt < nt; ++jt) {
     const int buf = jt & 1, kv0 = jt * 64;
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
           bool keep[4] = {true, true, true, true};
-          if (DROPOUT) drop_keep4(e_row + (uint32_t)(kv0 + kb * 32 + 8 * qd + 4 * hh), p.thr, p.seed_lo, p.seed_hi, keep);
+          if (DROPOUT) drop_keep4(e_row + (uint32_t)(kv0 + kb * 32 + 8 * qd + 4 * hh), p.thr, p.seed_lo, shi, keep);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int r = 4 * qd + e;
@@ -413,6 +416,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
   const int q_nat = (lane & 31) * C::KSTR + hh * 8;
   const int q_tr = (4 * hh + (ip >> 2)) * C::KSTR + 16 * (g & 1) + 4 * (ip & 3);
   const uint32_t e_bh = (uint32_t)((int64_t)(b * p.H + h) * p.S);
+  const uint32_t shi = DROPOUT ? seed_mix(p.seed_hi, p.ctr) : 0u;
 
   for (int qt = qt0; qt < nqt; ++qt) {
     const int buf = (qt - qt0) & 1, q0 = qt * 64;
@@ -447,7 +451,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
             float dpv = dp[r];
             float pd = pv;
             if (DROPOUT) {
-              const bool keep = drop_keep((e_bh + (uint32_t)query) * (uint32_t)p.Sp + (uint32_t)key, p.thr, p.seed_lo, p.seed_hi);
+              const bool keep = drop_keep((e_bh + (uint32_t)query) * (uint32_t)p.Sp + (uint32_t)key, p.thr, p.seed_lo, shi);
               dpv = keep ? dpv * p.inv_keep : 0.f;
               pd = keep ? pv * p.inv_keep : 0.f;
             }
@@ -495,7 +499,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
 }
 
 __global__ __launch_bounds__(256) void attn_dropout_mask_kernel(uint8_t* mask, int64_t total, int S, int Sp,
-                                                                uint32_t thr, uint32_t slo, uint32_t shi) {
+                                                                uint32_t thr, uint32_t slo, uint32_t shi,
+                                                                const uint32_t* ctr) {
+  shi = seed_mix(shi, ctr);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t row = i / S;  // (b*H + h)*S + query
     const int key = (int)(i % S);
@@ -519,6 +525,7 @@ static int fill_params(AttnParams& p, int B, int H, int S, int head_dim, int64_t
   p.inv_keep = p.thr ? 65536.0f / (65536.0f - (float)p.thr) : 1.0f;
   p.seed_lo = (uint32_t)seed;
   p.seed_hi = (uint32_t)(seed >> 32);
+  p.ctr = dropout_counter();
   return TTTS_OK;
 }
 
@@ -587,6 +594,6 @@ extern "C" int ttts_attn_dropout_mask_u8(uint8_t* mask, int32_t B, int32_t H, in
   const int Sp = (S + 3) & ~3;
   TTTS_REQUIRE((int64_t)B * H * S * Sp < (int64_t)1 << 32, "dropout_mask: index space exceeds 2^32");
   attn_dropout_mask_kernel<<<(int)std::min<int64_t>(cdiv(total, 256), 8192), 256, 0, as_stream(stream)>>>(
-      mask, total, S, Sp, dropout_threshold(dropout_p), (uint32_t)seed, (uint32_t)(seed >> 32));
+      mask, total, S, Sp, dropout_threshold(dropout_p), (uint32_t)seed, (uint32_t)(seed >> 32), dropout_counter());
   return check_launch("dropout_mask");
 }

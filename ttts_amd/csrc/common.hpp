@@ -96,6 +96,13 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x, uint32_t seed_lo, uint32_
   x ^= x >> 16;
   return x;
 }
+// Process-wide dropout stream counter: a uint32 in DEVICE memory owned by the caller (ttts_set_dropout_counter).
+// Kernels add it to their seed at run time, so a step captured once in a hipGraph draws fresh masks on every
+// replay (kernel arguments are frozen by capture, device memory is not).  NULL = disabled.
+const uint32_t* dropout_counter();
+__device__ __forceinline__ uint32_t seed_mix(uint32_t seed_hi, const uint32_t* ctr) {
+  return ctr ? seed_hi + *ctr * 0x9E3779B1u : seed_hi;
+}
 // dropout threshold on 16 random bits: keep iff r16 >= thr, thr = round(p * 65536)
 __host__ __device__ inline uint32_t dropout_threshold(float p) {
   float t = p * 65536.0f + 0.5f;

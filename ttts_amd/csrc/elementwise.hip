@@ -16,7 +16,8 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
                                                         const float* __restrict__ mel_pos, float* __restrict__ x,
                                                         int B, int Tt, int Tm, int D, int n_text, int n_mel,
                                                         uint32_t thr, float inv_keep, uint32_t seed_lo,
-                                                        uint32_t seed_hi) {
+                                                        uint32_t seed_hi, const uint32_t* ctr) {
+  if (thr) seed_hi = seed_mix(seed_hi, ctr);
   const int S = Tt + Tm;
   const int D4 = D >> 2;
   const int64_t total = (int64_t)B * S * D4;
@@ -57,7 +58,8 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
                                                         float* __restrict__ d_text_pos, float* __restrict__ d_mel_emb,
                                                         float* __restrict__ d_mel_pos, int B, int Tt, int Tm, int D,
                                                         uint32_t thr, float inv_keep, uint32_t seed_lo,
-                                                        uint32_t seed_hi) {
+                                                        uint32_t seed_hi, const uint32_t* ctr) {
+  if (thr) seed_hi = seed_mix(seed_hi, ctr);
   const int S = Tt + Tm;
   const int D4 = D >> 2;
   const int64_t total = (int64_t)S * D4;
@@ -168,7 +170,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      const float* __restrict__ rstd, const float* dx_in, float* dx,
                                                      bf16* __restrict__ dx_bf16, float* __restrict__ partial, int M,
                                                      int D, int split_S, int split_T, uint32_t thr, float inv_keep,
-                                                     uint32_t seed_lo, uint32_t seed_hi) {
+                                                     uint32_t seed_lo, uint32_t seed_hi, const uint32_t* ctr) {
+  if (thr) seed_hi = seed_mix(seed_hi, ctr);
   extern __shared__ __attribute__((aligned(16))) float ln_smem[];  // [4 waves][3][D]
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -539,7 +542,7 @@ extern "C" int ttts_gpt_embed_fwd(const int64_t* text_inp, const int64_t* mel_in
   const float inv_keep = thr ? 65536.0f / (65536.0f - (float)thr) : 1.0f;
   embed_fwd_kernel<<<grid, 256, 0, as_stream(stream)>>>(text_inp, mel_inp, text_emb, text_pos, mel_emb, mel_pos, x, B,
                                                         Tt, Tm, D, n_text, n_mel, thr, inv_keep, (uint32_t)seed,
-                                                        (uint32_t)(seed >> 32));
+                                                        (uint32_t)(seed >> 32), dropout_counter());
   return check_launch("embed_fwd");
 }
 
@@ -553,7 +556,7 @@ extern "C" int ttts_gpt_embed_bwd(const int64_t* text_inp, const int64_t* mel_in
   const float inv_keep = thr ? 65536.0f / (65536.0f - (float)thr) : 1.0f;
   embed_bwd_kernel<<<(int)cdiv(total, 256), 256, 0, as_stream(stream)>>>(text_inp, mel_inp, dx, d_text_emb, d_text_pos,
                                                                          d_mel_emb, d_mel_pos, B, Tt, Tm, D, thr,
-                                                                         inv_keep, (uint32_t)seed, (uint32_t)(seed >> 32));
+                                                                         inv_keep, (uint32_t)seed, (uint32_t)(seed >> 32), dropout_counter());
   return check_launch("embed_bwd");
 }
 
@@ -594,10 +597,10 @@ static int layernorm_bwd_impl(const void* dy, int dy_is_bf16, const float* x, co
 #define LN_BWD(V)                                                                                                   \
   if (dy_is_bf16)                                                                                                   \
     ln_bwd_kernel<V, true><<<nblk, 256, smem, s>>>(dy, x, gamma, mean, rstd, dx_in, dx, (bf16*)dx_bf16, partial, M, D, \
-                                                   split_S, split_T, thr, inv_keep, (uint32_t)seed, (uint32_t)(seed >> 32)); \
+                                                   split_S, split_T, thr, inv_keep, (uint32_t)seed, (uint32_t)(seed >> 32), dropout_counter()); \
   else                                                                                                              \
     ln_bwd_kernel<V, false><<<nblk, 256, smem, s>>>(dy, x, gamma, mean, rstd, dx_in, dx, (bf16*)dx_bf16, partial, M, D, \
-                                                    split_S, split_T, thr, inv_keep, (uint32_t)seed, (uint32_t)(seed >> 32));
+                                                    split_S, split_T, thr, inv_keep, (uint32_t)seed, (uint32_t)(seed >> 32), dropout_counter());
   if (D <= 256) { LN_BWD(1) } else if (D <= 512) { LN_BWD(2) } else { LN_BWD(4) }
 #undef LN_BWD
   int rc = check_launch("layernorm_bwd");

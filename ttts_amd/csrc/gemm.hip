@@ -38,6 +38,7 @@ struct GemmEpi {
   int M, N;
   uint32_t thr; float inv_keep; uint32_t seed_lo, seed_hi;  // residual dropout (RESID_ADD only; thr = 0: off)
   int debug;  // ablations: 16 = skip the global stores of the epilogue, 32 = skip the LDS staging
+  const uint32_t* ctr;  // process-wide dropout stream counter (device) or NULL
 };
 
 struct GemmNtParams {
@@ -133,9 +134,10 @@ __device__ __forceinline__ void tile_epilogue(const GemmEpi& e, f32x16 (&acc)[2]
         for (int t = 0; t < 8; ++t) y[t] = (float)(bf16)v[t];
         if (e.thr) {  // resid_pdrop: element index m*N + n, 16 random bits per element (two elements per hash)
           const uint32_t lin = (uint32_t)(((int64_t)m * e.N + n) >> 1);
+          const uint32_t shi = seed_mix(e.seed_hi, e.ctr);
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            const uint32_t r = hash32(lin + t, e.seed_lo, e.seed_hi);
+            const uint32_t r = hash32(lin + t, e.seed_lo, shi);
             y[2 * t] = (r & 0xFFFFu) >= e.thr ? y[2 * t] * e.inv_keep : 0.f;
             y[2 * t + 1] = (r >> 16) >= e.thr ? y[2 * t + 1] * e.inv_keep : 0.f;
           }
@@ -487,7 +489,7 @@ extern "C" int ttts_gemm_nt_bf16_ex(const void* A, int64_t lda, const void* B, i
   TTTS_REQUIRE(!resid_in || aligned16(resid_in), "gemm_nt: resid_in must be 16-byte aligned");
   GemmNtParams p{(const bf16*)A, lda, (const bf16*)B, ldb, K, g_debug_flags,
                  GemmEpi{C, ldc, bias, (bf16*)aux, resid_in, M, N, dropout_threshold(dropout_p), 1.0f, (uint32_t)seed,
-                         (uint32_t)(seed >> 32), g_debug_flags}};
+                         (uint32_t)(seed >> 32), g_debug_flags, dropout_counter()}};
   if (p.e.thr) p.e.inv_keep = 65536.0f / (65536.0f - (float)p.e.thr);
   const int grid = (int)(cdiv(M, BM) * cdiv(N, BN));
   hipStream_t s = as_stream(stream);

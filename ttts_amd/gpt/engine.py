@@ -80,7 +80,8 @@ class GptEngine:
         self.dropout_p = float(dropout_p)   # HF GPT2Config default embd/attn/resid_pdrop = 0.1
         self.training = True
         self.seed = int(seed)
-        self.step_count = 0                 # host mirror of the device step counter (seeds dropout streams)
+        self.step_count = 0                 # optimizer steps taken (host mirror)
+        self.seed_ctr = ops.dropout_counter(self.device)   # device-side dropout stream counter (graph-replay safe)
         self.spec = param_spec(self.c)
         self.shapes = dict(self.spec)
         self.offsets = {}
@@ -221,7 +222,8 @@ class GptEngine:
         return self.dropout_p if self.training else 0.0
 
     def _seed(self, site):
-        return (self.seed * 0x9E3779B97F4A7C15 + self.step_count * 0x100000001B3 + site * 0x632BE59BD9B4E019) & (2 ** 64 - 1)
+        # per-site constant; the per-step variation comes from the device counter the kernels add at run time
+        return (self.seed * 0x9E3779B97F4A7C15 + site * 0x632BE59BD9B4E019 + 0x1234567) & (2 ** 64 - 1)
 
     # ---- forward ---------------------------------------------------------------------------------------------
     def forward(self):
@@ -325,6 +327,7 @@ class GptEngine:
         ops.adamw(self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.shadow, self.opt_state, betas[0],
                   betas[1], eps, weight_decay, zero_grad=True)
         self.cast_plan.run()
+        self.seed_ctr.add_(1)   # next step draws fresh dropout masks (also under graph replay)
 
     def zero_grad(self):
         self.grads.zero_()
@@ -334,8 +337,6 @@ class GptEngine:
         """tokens = (text_inp, text_tar, mel_inp, mel_tar) int64 tensors (see model.prepare_tokens).
         Returns nothing: losses stay on the device in self.b['losses'] (no host sync in the hot loop)."""
         self.set_tokens(*tokens)
-        if capture and self._p() > 0.0:
-            raise TttsError("graph capture freezes the dropout seeds; capture only with dropout_p = 0 / eval()")
         if not capture:
             self.forward()
             self.backward(w_text, w_mel)

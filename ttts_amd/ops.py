@@ -287,6 +287,20 @@ def mel_log(spec, basis):
     return mel
 
 
+_dropout_counters = {}
+
+
+def dropout_counter(device):
+    """The process-wide dropout stream counter (int32 [1] on `device`), registered with the library on first use and
+    never freed.  Increment it once per training step (`counter.add_(1)`, capturable) for fresh masks."""
+    key = str(torch.device(device))
+    if key not in _dropout_counters:
+        t = torch.zeros(1, dtype=torch.int32, device=device)
+        check(_l.get().ttts_set_dropout_counter(_p(t)), "set_dropout_counter")
+        _dropout_counters[key] = t
+    return _dropout_counters[key]
+
+
 def probe_layout(device):
     c = torch.empty(64, 16, dtype=torch.float32, device=device)
     tr = torch.empty(64, 8, dtype=torch.int32, device=device)
