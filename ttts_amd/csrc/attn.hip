@@ -87,7 +87,7 @@ __device__ __forceinline__ void tile_store(const bf16x8 (&r)[AttnCfg<DH>::CPT], 
 // forward
 // -------------------------------------------------------------------------------------------------------
 template <int DH, bool DROPOUT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   using C = AttnCfg<DH>;
   __shared__ __attribute__((aligned(16))) bf16 Ks[2][64 * C::KSTR];
   __shared__ __attribute__((aligned(16))) bf16 Vs[2][64 * C::VSTR];
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
 // backward: dQ (S^T form, one query per lane; loops over key tiles up to the diagonal)
 // -------------------------------------------------------------------------------------------------------
 template <int DH, bool DROPOUT>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
   using C = AttnCfg<DH>;
   __shared__ __attribute__((aligned(16))) bf16 Ks[2][64 * C::KSTR];
   __shared__ __attribute__((aligned(16))) bf16 Vs[2][64 * C::KSTR];
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 // backward: dK, dV (S form, one key per lane; loops over query tiles from the diagonal down)
 // -------------------------------------------------------------------------------------------------------
 template <int DH, bool DROPOUT>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
   using C = AttnCfg<DH>;
   __shared__ __attribute__((aligned(16))) bf16 Qs[2][64 * C::KSTR];
   __shared__ __attribute__((aligned(16))) bf16 Ds[2][64 * C::KSTR];
@@ -397,21 +397,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
   const int qt0 = (kblk * 128) / 64;
   const int nqt = (p.S + 63) / 64;
   bf16x8 rq[C::CPT], rd[C::CPT];
-  float rl = 0.f, rdl = 0.f;
-  auto load_stats = [&](int q0) {
-    if (tid < 64) rl = (q0 + tid < p.S) ? lsep[q0 + tid] * LOG2E : 0.f;
-    else if (tid < 128) rdl = (q0 + tid - 64 < p.S) ? delp[q0 + tid - 64] : 0.f;
-  };
-  auto store_stats = [&](int buf) {
-    if (tid < 64) Ls[buf][tid] = rl;
-    else if (tid < 128) Dl[buf][tid - 64] = rdl;
-  };
+  // per-tile statistics: threads 0..63 stage lse (in log2 units), threads 64..127 stage delta
+  float rstat = 0.f;
+#define LOAD_STATS(q0)                                                                   \
+  {                                                                                      \
+    const int qi = (q0) + (tid & 63);                                                    \
+    if (tid < 128) rstat = qi < p.S ? (tid < 64 ? lsep[qi] * LOG2E : delp[qi]) : 0.f;    \
+  }
+#define STORE_STATS(buf)                           \
+  {                                                \
+    if (tid < 64) Ls[buf][tid] = rstat;            \
+    else if (tid < 128) Dl[buf][tid - 64] = rstat; \
+  }
   tile_load<DH>(rq, qp, p.ss, qt0 * 64, p.S, tid);
   tile_load<DH>(rd, dop, p.oss, qt0 * 64, p.S, tid);
-  load_stats(qt0 * 64);
+  LOAD_STATS(qt0 * 64)
   tile_store<DH, C::KSTR>(rq, Qs[0], tid);
   tile_store<DH, C::KSTR>(rd, Ds[0], tid);
-  store_stats(0);
+  STORE_STATS(0)
   __syncthreads();
   const int q_nat = (lane & 31) * C::KSTR + hh * 8;
   const int q_tr = (4 * hh + (ip >> 2)) * C::KSTR + 16 * (g & 1) + 4 * (ip & 3);
@@ -423,7 +426,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
     if (qt + 1 < nqt) {
       tile_load<DH>(rq, qp, p.ss, q0 + 64, p.S, tid);
       tile_load<DH>(rd, dop, p.oss, q0 + 64, p.S, tid);
-      load_stats(q0 + 64);
+      LOAD_STATS(q0 + 64)
     }
     if (q0 + 63 >= k_base) {  // wave-uniform: some query of this tile can see some key of this wave
 #pragma unroll
@@ -475,7 +478,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
     if (qt + 1 < nqt) {
       tile_store<DH, C::KSTR>(rq, Qs[buf ^ 1], tid);
       tile_store<DH, C::KSTR>(rd, Ds[buf ^ 1], tid);
-      store_stats(buf ^ 1);
+      STORE_STATS(buf ^ 1)
     }
     __syncthreads();
   }

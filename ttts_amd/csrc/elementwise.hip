@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   }
 }
 
-constexpr int LN_BWD_ROWS = 32;  // rows per block (8 per wave)
+constexpr int LN_BWD_ROWS = 8;   // rows per block (2 per wave): 1156 workgroups at M = 9248 keep ~18 waves per CU in flight
 
 template <int VPL, bool DY_BF16>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, const float* __restrict__ x,
@@ -267,20 +267,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
   }
 }
 
-// out[j] += sum over blocks of partial[b][j]: 64 columns per workgroup, 4 row lanes, fixed summation order
-__global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int D,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                              float* __restrict__ dcolsum) {
-  __shared__ float sh[4][64];
+// out[j] += sum over blocks of partial[b][j]: 64 columns per workgroup, 16 row lanes, fixed summation order
+__global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int D,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               float* __restrict__ dcolsum) {
+  __shared__ float sh[16][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + tx;
   float s = 0.f;
-  if (j < 3 * D)
-    for (int b = ty; b < nblk; b += 4) s += partial[(size_t)b * 3 * D + j];
+  if (j < 3 * D) {
+#pragma unroll 4
+    for (int b = ty; b < nblk; b += 16) s += partial[(size_t)b * 3 * D + j];
+  }
   sh[ty][tx] = s;
   __syncthreads();
   if (ty == 0 && j < 3 * D) {
-    const float t = (sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]);
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += sh[r][tx];
     if (j < D) dgamma[j] += t;
     else if (j < 2 * D) dbeta[j - D] += t;
     else if (dcolsum) dcolsum[j - 2 * D] += t;
@@ -605,7 +609,7 @@ static int layernorm_bwd_impl(const void* dy, int dy_is_bf16, const float* x, co
 #undef LN_BWD
   int rc = check_launch("layernorm_bwd");
   if (rc) return rc;
-  ln_bwd_finalize_kernel<<<(int)cdiv(3 * D, 64), 256, 0, s>>>(partial, nblk, D, dgamma, dbeta, dcolsum);
+  ln_bwd_finalize_kernel<<<(int)cdiv(3 * D, 64), 1024, 0, s>>>(partial, nblk, D, dgamma, dbeta, dcolsum);
   return check_launch("layernorm_bwd_finalize");
 }
 
