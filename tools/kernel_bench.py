@@ -15,7 +15,13 @@ from ttts_amd.lib import EPI_DGELU_BF16, EPI_GELU_BF16, EPI_RESID_ADD_F32, EPI_S
 dev = torch.device("cuda:0")
 
 
-def timeit(fn, reps=20, rounds=3):
+REPS = int(os.environ.get('KB_REPS', '20'))
+ROUNDS = int(os.environ.get('KB_ROUNDS', '3'))
+
+
+def timeit(fn, reps=None, rounds=None):
+    reps = reps or REPS
+    rounds = rounds or ROUNDS
     best = []
     for _ in range(rounds):
         fn()
@@ -45,7 +51,7 @@ def bench_gemm():
         rin = torch.randn(M, N, device=dev) if epi == EPI_RESID_ADD_F32 else None
         fl = 2.0 * M * N * K
         row = {}
-        for flag, tag in ((0, "full"), (1, "no_epilogue"), (16, "epi_no_gstore"), (32, "epi_no_lds_stage"), (48, "epi_neither")):
+        for flag, tag in ((0, "xcd_swizzle"), (128, "linear"), (1, "xcd_no_epi"), (129, "linear_no_epi")) if os.environ.get("KB_QUICK") else ((0, "full"), (1, "no_epilogue"), (16, "epi_no_gstore"), (32, "epi_no_lds_stage"), (48, "epi_neither")):
             lib.get().ttts_debug_set_flags(flag)
             us = timeit(lambda: ops.gemm_nt(a, b, c, bias, aux=aux, epilogue=epi, resid_in=rin))
             row[tag] = "%.1f us  %.0f TF/s" % (us, fl / us / 1e6)

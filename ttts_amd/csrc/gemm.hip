@@ -187,6 +187,14 @@ __device__ __forceinline__ void tile_epilogue(const GemmEpi& e, f32x16 (&acc)[2]
   }
 }
 
+// XCD-aware tile order: the dispatcher places workgroup b on XCD b % 8 (observed, speed only).  Remap so that each XCD
+// walks a CONTIGUOUS range of tile ids: tiles that share an operand panel then hit the same (private) L2.  Bijective
+// for any grid size.
+__device__ __forceinline__ int xcd_tile(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
 #define ZERO_ACC(acc)                                 \
   _Pragma("unroll") for (int j = 0; j < 2; ++j)       \
   _Pragma("unroll") for (int i = 0; i < 2; ++i)       \
@@ -205,38 +213,48 @@ __device__ __forceinline__ bool debug_drop(int debug, f32x16 (&acc)[2][2], void*
   return true;
 }
 
-// ---- NT, LDS-DMA main loop (K % 64 == 0) ---------------------------------------------------------------------------
-// LDS image per operand and buffer: [128 rows][64 k] bf16, 128-byte rows, NO padding (the DMA writes lane-linearly:
-// instruction (wave w, i) covers rows w*32 + i*8 .. +8, lane l -> row += l >> 3, 16-byte slot l & 7).  Slot s of row r
-// holds the logical k-chunk s ^ ((r >> 1) & 7); ds_read_b128 of a 16-lane service group then hits 64 distinct banks.
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmNtParams p) {
-  __shared__ __attribute__((aligned(16))) bf16 smem[2 * 2 * BM * BK];  // 64 KB: [buf][A|B][128*64]; reused as stage
+// ---- NT, LDS-DMA main loop (K % BKT == 0) --------------------------------------------------------------------------
+// LDS image per operand and buffer: [128 rows][BKT k] bf16, NO padding (the DMA writes lane-linearly: one wave
+// instruction = 1 KB = 64*8/BKT... rows; lane l -> row += l / CPR, 16-byte slot l % CPR, CPR = BKT/8 chunks per row).
+// Slot s of row r holds the logical k-chunk s ^ f(r), f(r) = (r >> 1) & 7 for 128-byte rows (BKT = 64) and
+// (r >> 2) & 3 for 64-byte rows (BKT = 32): ds_read_b128 of a 16-lane service group then hits 64 distinct banks.
+// BKT = 64: 64 KB LDS, 2 workgroups per CU.  BKT = 32: 33.8 KB, 3 workgroups per CU -- their store phases and main
+// loops interleave instead of running in lock-step.
+template <int EPI, int BKT>
+__global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_nt_glds_kernel(GemmNtParams p) {
+  constexpr int CPR = BKT / 8;           // 16-byte chunks per row
+  constexpr int RPI = 64 / CPR;          // rows per wave instruction
+  constexpr int IPW = 128 / RPI / 4;     // instructions per wave and operand
+  constexpr int TILE = BM * BKT;
+  constexpr int SMEM = (4 * TILE * 2 > 64 * ST_LD * 4) ? 4 * TILE : 64 * ST_LD * 2;  // elements
+  __shared__ __attribute__((aligned(16))) bf16 smem[SMEM];  // [buf][A|B][128*BKT]; reused as the epilogue stage
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int tiles_n = (p.e.N + BN - 1) / BN;
-  const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
-  const int nk = p.K / BK;
+  const int tile = (p.debug & 128) ? (int)blockIdx.x : xcd_tile(blockIdx.x, gridDim.x);
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  const int nk = p.K / BKT;
+  auto fsw = [](int r) { return BKT == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
 
   // this lane's DMA source rows (clamped: rows beyond M / N are loaded from the last valid row and never stored)
-  const bf16* ga[4];
-  const bf16* gb[4];
+  const bf16* ga[IPW];
+  const bf16* gb[IPW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = wave * 32 + i * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+  for (int i = 0; i < IPW; ++i) {
+    const int r = wave * (IPW * RPI) + i * RPI + lane / CPR;
+    const int chunk = (lane % CPR) ^ fsw(r);
     ga[i] = p.A + (int64_t)min(m0 + r, p.e.M - 1) * p.lda + chunk * 8;
     gb[i] = p.B + (int64_t)min(n0 + r, p.e.N - 1) * p.ldb + chunk * 8;
   }
   auto issue = [&](int kt, int buf) {
-    bf16* as = smem + (buf * 2 + 0) * BM * BK + wave * 32 * BK;
-    bf16* bs = smem + (buf * 2 + 1) * BM * BK + wave * 32 * BK;
+    bf16* as = smem + (buf * 2 + 0) * TILE + wave * (IPW * RPI) * BKT;
+    bf16* bs = smem + (buf * 2 + 1) * TILE + wave * (IPW * RPI) * BKT;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[i] + kt * BK),
-                                       (__attribute__((address_space(3))) void*)(as + i * 8 * BK), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb[i] + kt * BK),
-                                       (__attribute__((address_space(3))) void*)(bs + i * 8 * BK), 16, 0, 0);
+    for (int i = 0; i < IPW; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[i] + kt * BKT),
+                                       (__attribute__((address_space(3))) void*)(as + i * RPI * BKT), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb[i] + kt * BKT),
+                                       (__attribute__((address_space(3))) void*)(bs + i * RPI * BKT), 16, 0, 0);
     }
   };
 
@@ -249,18 +267,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmNtParams p) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int ra = wm * 64 + i * 32 + (lane & 31), rb = wn * 64 + i * 32 + (lane & 31);
-    aoff[i] = ra * BK;
-    boff[i] = rb * BK;
-    sw[0][i] = (ra >> 1) & 7;
-    sw[1][i] = (rb >> 1) & 7;
+    aoff[i] = ra * BKT;
+    boff[i] = rb * BKT;
+    sw[0][i] = fsw(ra);
+    sw[1][i] = fsw(rb);
   }
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk && !(p.debug & 2)) issue(kt + 1, buf ^ 1);
-    const bf16* as = smem + (buf * 2 + 0) * BM * BK;
-    const bf16* bs = smem + (buf * 2 + 1) * BM * BK;
+    const bf16* as = smem + (buf * 2 + 0) * TILE;
+    const bf16* bs = smem + (buf * 2 + 1) * TILE;
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
+    for (int ks = 0; ks < BKT / 16; ++ks) {
       bf16x8 af[2], bfr[2];
       const int lc = ks * 2 + hh;  // logical 16-byte chunk of this lane's 8 k-values
 #pragma unroll
@@ -439,6 +457,100 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(GemmTnParams p) {
   }
 }
 
+// ---- TN, LDS-DMA main loop (k range a multiple of 64 rows) -----------------------------------------------------------
+// LDS image per operand and buffer: [64 k-rows][128 cols] bf16, 256-byte rows, no padding (DMA is lane-linear:
+// instruction (wave w, i) covers k-rows w*16 + i*4 .. +4, lane l -> row += l >> 4, 16-byte slot l & 15).  The four
+// 64-byte segments of row k are XOR-permuted by (k & 3): a transposed read touches 4 consecutive k-rows x one 64-byte
+// segment per half-wave, which the permutation spreads over all 64 banks.
+__global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(GemmTnParams p) {
+  __shared__ __attribute__((aligned(16))) bf16 smem[2 * 2 * 64 * 128];  // 64 KB: [buf][A|B][64*128]; reused as stage
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = (p.No + BN - 1) / BN;
+  // XCD-aware order over (split, tile): each XCD walks a contiguous range, i.e. (mostly) one reduction split with all
+  // its output tiles -- the At / Bt panels of that split are then fetched into that XCD's L2 once
+  const int lin = xcd_tile(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+  const int tile = lin % gridDim.x, split = lin / gridDim.x;
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  const int kbeg = split * p.k_chunk;
+  const int kend = min(p.Kr, kbeg + p.k_chunk);
+  const int nk = (kend - kbeg) / 64;
+
+  // DMA sources: columns beyond Mo / No are clamped to the last valid 16-byte chunk (those outputs are never stored)
+  const int ca_max = max(0, ((p.Mo - m0 + 7) >> 3) - 1), cb_max = max(0, ((p.No - n0 + 7) >> 3) - 1);
+  const bf16* ga[4];
+  const bf16* gb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = wave * 16 + i * 4 + (lane >> 4);
+    const int lc = (lane & 15) ^ ((r & 3) << 2);
+    ga[i] = p.At + (int64_t)(kbeg + r) * p.ldat + m0 + min(lc, ca_max) * 8;
+    gb[i] = p.Bt + (int64_t)(kbeg + r) * p.ldbt + n0 + min(lc, cb_max) * 8;
+  }
+  auto issue = [&](int kt, int buf) {
+    bf16* as = smem + (buf * 2 + 0) * 64 * 128 + wave * 16 * 128;
+    bf16* bs = smem + (buf * 2 + 1) * 64 * 128 + wave * 16 * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[i] + (int64_t)kt * 64 * p.ldat),
+                                       (__attribute__((address_space(3))) void*)(as + i * 4 * 128), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb[i] + (int64_t)kt * 64 * p.ldbt),
+                                       (__attribute__((address_space(3))) void*)(bs + i * 4 * 128), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+  ZERO_ACC(acc)
+  if (nk > 0) issue(0, 0);
+  __syncthreads();
+  // transposed-read lane map (see gemm_tn_kernel) on the permuted image: lane i' = lane & 15 of group g reads k-row
+  // 8*(g >> 1) + (i' >> 2) (+4), logical column block + 16*(g & 1) + 4*(i' & 3)
+  const int g = lane >> 4, ip = lane & 15;
+  const int krow = 8 * (g >> 1) + (ip >> 2);
+  const int sw = ((ip >> 2) & 3) << 2;  // (k & 3) << 2 for both reads (k-row offsets are multiples of 4)
+  int offa[2], offb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ca = wm * 64 + i * 32 + 16 * (g & 1) + 4 * (ip & 3), cb = wn * 64 + i * 32 + 16 * (g & 1) + 4 * (ip & 3);
+    offa[i] = krow * 128 + (((ca >> 3) ^ sw) << 3) + (ca & 7);
+    offb[i] = krow * 128 + (((cb >> 3) ^ sw) << 3) + (cb & 7);
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
+    const bf16* as = smem + (buf * 2 + 0) * 64 * 128;
+    const bf16* bs = smem + (buf * 2 + 1) * 64 * 128;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bf16* pa = as + ks * 16 * 128 + offa[i];
+        const bf16* pb = bs + ks * 16 * 128 + offb[i];
+        af[i] = cat4(lds_tr_b64(pa), lds_tr_b64(pa + 4 * 128));
+        bfr[i] = cat4(lds_tr_b64(pb), lds_tr_b64(pb + 4 * 128));
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[j][i] = mfma32(bfr[j], af[i], acc[j][i]);
+    }
+    __syncthreads();
+  }
+  GemmEpi e{};
+  e.M = p.Mo;
+  e.N = p.No;
+  if (p.splits > 1) {
+    e.C = p.partial + (int64_t)split * p.Mo * p.ldp;
+    e.ldc = p.ldp;
+    tile_epilogue<EPI_SLAB_F32>(e, acc, reinterpret_cast<float*>(smem), m0, n0, tid);
+  } else {
+    e.C = p.C;
+    e.ldc = p.ldc;
+    tile_epilogue<EPI_ACCUM_F32>(e, acc, reinterpret_cast<float*>(smem), m0, n0, tid);
+  }
+}
+
 // C[m][n] += sum_s partial[s][m][n]   (float4 per thread, slabs read in split order)
 __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __restrict__ partial, int64_t ldp, int splits,
                                                              float* __restrict__ C, int64_t ldc, int Mo, int No) {
@@ -471,7 +583,8 @@ extern "C" int ttts_debug_set_flags(int32_t flags) {
 
 template <int EPI>
 static void launch_nt(const GemmNtParams& p, int grid, hipStream_t s) {
-  if (p.K % BK == 0 && !(g_debug_flags & 8)) gemm_nt_glds_kernel<EPI><<<grid, 256, 0, s>>>(p);
+  if (p.K % 64 == 0 && !(g_debug_flags & (8 | 64))) gemm_nt_glds_kernel<EPI, 64><<<grid, 256, 0, s>>>(p);
+  else if (p.K % 32 == 0 && !(g_debug_flags & 8)) gemm_nt_glds_kernel<EPI, 32><<<grid, 256, 0, s>>>(p);
   else gemm_nt_kernel<EPI><<<grid, 256, 0, s>>>(p);
 }
 
@@ -512,9 +625,10 @@ extern "C" int ttts_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int6
 
 static void tn_plan(int Mo, int No, int Kr, int& splits, int& k_chunk) {
   const int tiles = (int)(cdiv(Mo, BM) * cdiv(No, BN));
-  // enough workgroups to fill 256 CUs (~1.5 per CU), as few slabs as possible, >= 256 reduction rows per split
+  // enough workgroups to fill 256 CUs (~1.5 per CU), as few slabs as possible, >= 256 reduction rows per split;
+  // k_chunk is a multiple of 64 so that the LDS-DMA kernel can take every split whole
   splits = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(Kr, 256), (384 + tiles / 2) / tiles));
-  k_chunk = (int)(cdiv(cdiv(Kr, splits), BK_TN) * BK_TN);
+  k_chunk = (int)(cdiv(cdiv(Kr, splits), 64) * 64);
   splits = (int)cdiv(Kr, k_chunk);
 }
 
@@ -537,11 +651,34 @@ extern "C" int ttts_gemm_tn_bf16_accum_f32(const void* At, int64_t ldat, const v
   TTTS_REQUIRE(splits == 1 || (workspace && aligned16(workspace)), "gemm_tn: workspace (ttts_gemm_tn_workspace_bytes) required");
   const int tiles = (int)(cdiv(Mo, BM) * cdiv(No, BN));
   const int64_t ldp = ((int64_t)No + 7) / 8 * 8;
-  GemmTnParams p{(const bf16*)At, ldat, (const bf16*)Bt, ldbt, C, ldc, (float*)workspace, ldp, Mo, No, Kr, k_chunk, splits};
   hipStream_t s = as_stream(stream);
-  gemm_tn_kernel<<<dim3(tiles, splits), 256, 0, s>>>(p);
-  int rc = check_launch("gemm_tn");
-  if (rc || splits == 1) return rc;
-  gemm_tn_reduce_kernel<<<(int)cdiv((int64_t)Mo * (ldp / 4), 256), 256, 0, s>>>((const float*)workspace, ldp, splits, C, ldc, Mo, No);
-  return check_launch("gemm_tn_reduce");
+  const int kr_main = (g_debug_flags & 8) ? 0 : Kr / 64 * 64;  // whole 64-row tiles: LDS-DMA kernel
+  if (kr_main > 0) {
+    const int sp = (int)cdiv(kr_main, k_chunk);
+    GemmTnParams p{(const bf16*)At, ldat, (const bf16*)Bt, ldbt, C, ldc, (float*)workspace, ldp, Mo, No, kr_main, k_chunk, sp};
+    gemm_tn_glds_kernel<<<dim3(tiles, sp), 256, 0, s>>>(p);
+    int rc = check_launch("gemm_tn");
+    if (rc) return rc;
+    if (sp > 1) {
+      gemm_tn_reduce_kernel<<<(int)cdiv((int64_t)Mo * (ldp / 4), 256), 256, 0, s>>>((const float*)workspace, ldp, sp, C, ldc, Mo, No);
+      rc = check_launch("gemm_tn_reduce");
+      if (rc) return rc;
+    }
+  }
+  if (kr_main < Kr) {  // ragged tail (< 64 rows, or everything in the debug path): register-staged kernel, C += directly
+    const int kt = Kr - kr_main;
+    if (kr_main > 0 || splits == 1) {
+      GemmTnParams p{(const bf16*)At + (int64_t)kr_main * ldat, ldat, (const bf16*)Bt + (int64_t)kr_main * ldbt, ldbt, C, ldc,
+                     nullptr, ldp, Mo, No, kt, kt, 1};
+      gemm_tn_kernel<<<dim3(tiles, 1), 256, 0, s>>>(p);
+      return check_launch("gemm_tn_tail");
+    }
+    GemmTnParams p{(const bf16*)At, ldat, (const bf16*)Bt, ldbt, C, ldc, (float*)workspace, ldp, Mo, No, Kr, k_chunk, splits};
+    gemm_tn_kernel<<<dim3(tiles, splits), 256, 0, s>>>(p);
+    int rc = check_launch("gemm_tn");
+    if (rc) return rc;
+    gemm_tn_reduce_kernel<<<(int)cdiv((int64_t)Mo * (ldp / 4), 256), 256, 0, s>>>((const float*)workspace, ldp, splits, C, ldc, Mo, No);
+    return check_launch("gemm_tn_reduce");
+  }
+  return TTTS_OK;
 }
