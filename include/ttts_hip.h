@@ -216,6 +216,15 @@ int ttts_stft_mag_fwd_f32(const float* wav, const float* window, const float* tw
 int ttts_mel_log_fwd_f32(const float* spec, const float* basis, float* mel, int32_t B, int32_t n_bins,
                          int32_t n_mels, int32_t frames, void* stream);
 
+/* Backward of the two functions above (mel_spectrogram_torch on the generated audio is differentiated in the VQ-VAE
+ * step, ttts/vqvae/train.py:362-371,394).  dspec f32 [B, n_bins, frames] += basis^T . (dmel / v) where the clamp passed;
+ * dwav f32 [B, T] += adjoint(STFT magnitude)(dspec) (the frame spectra are recomputed, not stored).
+ * twiddle2: f32 [2*n_fft] table from ttts_stft_twiddle_host(out, 2*n_fft). */
+int ttts_mel_log_bwd_f32(const float* dmel, const float* mel, const float* basis, float* dspec, int32_t B,
+                         int32_t n_bins, int32_t n_mels, int32_t frames, void* stream);
+int ttts_stft_mag_bwd_f32(const float* wav, const float* window, const float* twiddle2, const float* dspec,
+                          float* dwav, int32_t B, int32_t T, int32_t n_fft, int32_t hop, void* stream);
+
 /* ---- probes (tests only): dump hardware fragment layouts the kernels rely on ------------------------ */
 /* out_c f32 [64 lanes][16 regs]: raw accumulators of one 32x32x16 bf16 MFMA with D[i][j] = (i+1) + 64*(j+1);
  * out_tr i32 [64 lanes][8]: the uint16 LDS element indices two ds_read_b64_tr_b16 return for the kernels' address map. */

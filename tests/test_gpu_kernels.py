@@ -416,3 +416,31 @@ def test_stft_and_mel(ops, golden_dir):
     ref = mel_ref.spectrogram(wav, 2048, 640, 2048)
     assert spec.shape == (4, 1025, 256)
     assert float((spec.cpu() - ref).abs().max()) < 1e-4 * float(ref.abs().max())
+
+
+def test_mel_spectrogram_backward(ops, golden_dir):
+    """Differentiable mel front-end (ttts/vqvae/train.py:362-371,394): gradient of 45 * L1(mel(y), target) w.r.t. y
+    through ttts_amd.utils.data_utils (HIP forward + backward) vs the reference-generated fixture."""
+    from ttts_amd.utils import data_utils as du
+    g = np.load(os.path.join(golden_dir, "mel.npz"))
+    y = torch.from_numpy(g["A:wav"][:, :20480].copy()).to(dev()).requires_grad_(True)
+    target = torch.from_numpy(g["A:seg_target"]).to(dev())
+    mel = du.mel_spectrogram_torch(y, 2048, 128, 32000, 640, 2048, 0, None)
+    np.testing.assert_allclose(mel.detach().cpu().numpy(), g["A:seg_mel"], rtol=2e-3, atol=2e-3)
+    loss = torch.nn.functional.l1_loss(mel, target) * 45
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g["A:seg_loss"], rtol=1e-4)
+    ref = torch.from_numpy(g["A:seg_grad"])
+    assert rel_err(y.grad.cpu(), ref) < 2e-3, rel_err(y.grad.cpu(), ref)
+    # spectrogram alone, random cotangent, vs torch.stft autograd (oracle) at the second parameter set
+    from oracle import mel_ref
+    gen = torch.Generator(device="cpu").manual_seed(4)
+    yb = (torch.rand(2, 8000, generator=gen) - 0.5)
+    ct = torch.randn(2, 513, 31, generator=gen)
+    yr = yb.clone().requires_grad_(True)
+    mel_ref.spectrogram(yr, 1024, 256, 1024).backward(ct)
+    yg = yb.to(dev()).requires_grad_(True)
+    sp = du.spectrogram_torch(yg, 1024, 256, 1024)
+    assert sp.shape == (2, 513, 31)
+    sp.backward(ct.to(dev()))
+    assert rel_err(yg.grad.cpu(), yr.grad) < 1e-4

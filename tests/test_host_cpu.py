@@ -140,6 +140,40 @@ def test_stockham_fft_index_math_mirror():
         np.testing.assert_allclose(X, np.fft.rfft(x), rtol=1e-10, atol=1e-10)
 
 
+def test_stft_backward_index_math_mirror():
+    """numpy mirror of stft_mag_bwd_kernel: adjoint of the one-sided real DFT as an N-point Stockham FFT of conj(H)
+    with twiddles taken from the 2N table."""
+    for n_fft in (64, 1024):
+        rng = np.random.default_rng(n_fft + 1)
+        L = n_fft // 2
+        g = rng.standard_normal(L + 1) + 1j * rng.standard_normal(L + 1)       # G_k = dRe + i dIm
+        n = np.arange(n_fft)
+        k = np.arange(L + 1)
+        th = 2 * np.pi * np.outer(k, n) / n_fft
+        want = (g.real[:, None] * np.cos(th) - g.imag[:, None] * np.sin(th)).sum(0)
+        tw2 = np.exp(-2j * np.pi * np.arange(n_fft) / (2 * n_fft))
+        src = np.zeros(n_fft, complex)
+        src[:L + 1] = np.conj(g)
+        log2L = int(np.log2(L))
+        for ps in range(log2L + 1):
+            Ns = 1 << ps
+            dst = np.empty(n_fft, complex)
+            j = np.arange(L)
+            kk = j & (Ns - 1)
+            a, b = src[j], src[j + L] * tw2[kk * (n_fft >> ps)]
+            j0 = (j << 1) - kk
+            dst[j0], dst[j0 + Ns] = a + b, a - b
+            src = dst
+        np.testing.assert_allclose(src.real, want, rtol=1e-9, atol=1e-9)
+
+
+def test_mel_basis_matches_oracle():
+    from oracle import mel_ref
+    from ttts_amd.utils.data_utils import slaney_mel_basis
+    for args in ((32000, 2048, 128, 0, None), (22050, 1024, 80, 0, 8000)):
+        assert np.array_equal(slaney_mel_basis(*args), mel_ref.slaney_mel_basis(*args))
+
+
 def test_dropout_threshold_and_hash_reference():
     """The dropout keep rule documented in DESIGN.md: 16 random bits per element from hash32(e >> 1)."""
     def hash32(x, lo, hi):

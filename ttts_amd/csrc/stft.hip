@@ -132,6 +132,160 @@ __global__ __launch_bounds__(256) void mel_log_kernel(const float* __restrict__ 
   }
 }
 
+// ---- backward ---------------------------------------------------------------------------------------------------
+// d spec[b][k][f] = sum_m basis[m][k] * g[m][f],  g = dmel / max(v, 1e-5) where the clamp passed (v = exp(mel) >= 1e-5)
+// (torch.clamp(min) passes the gradient where x >= min; log'(v) = 1/v).  Tile: 32 bins x 64 frames, m chunks of 32.
+__global__ __launch_bounds__(256) void mel_log_bwd_kernel(const float* __restrict__ dmel, const float* __restrict__ mel,
+                                                          const float* __restrict__ basis, float* __restrict__ dspec,
+                                                          int n_bins, int n_mels, int frames) {
+  __shared__ float As[32][33];  // [bin][m]
+  __shared__ float Bs[32][64];  // [m][frame]
+  const int tid = threadIdx.x, tm = tid >> 6, tf = tid & 63;
+  const int ftiles = (frames + 63) / 64, ktiles = (n_bins + 31) / 32;
+  const int b = blockIdx.x / (ftiles * ktiles);
+  const int rem = blockIdx.x % (ftiles * ktiles);
+  const int k0 = (rem / ftiles) * 32, f0 = (rem % ftiles) * 64;
+  const float LOG_CLIP = -11.512925464970229f;  // log(1e-5)
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int m0 = 0; m0 < n_mels; m0 += 32) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * 256, m = e >> 5, k = e & 31;  // coalesced along bins
+      As[k][m] = (m0 + m < n_mels && k0 + k < n_bins) ? basis[(int64_t)(m0 + m) * n_bins + k0 + k] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = tid + i * 256, m = e >> 6, f = e & 63;
+      float g = 0.f;
+      if (m0 + m < n_mels && f0 + f < frames) {
+        const int64_t idx = ((int64_t)b * n_mels + m0 + m) * frames + f0 + f;
+        const float ml = mel[idx];
+        // forward value log(max(v, clip)): ml > log(clip) <=> v > clip; at equality torch passes the gradient too
+        g = ml >= LOG_CLIP ? dmel[idx] * __expf(-ml) : 0.f;
+      }
+      Bs[m][f] = g;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int m = 0; m < 32; ++m) {
+      const float bv = Bs[m][tf];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = fmaf(As[tm * 8 + i][m], bv, acc[i]);
+    }
+    __syncthreads();
+  }
+  if (f0 + tf < frames) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = k0 + tm * 8 + i;
+      if (k < n_bins) dspec[((int64_t)b * n_bins + k) * frames + f0 + tf] += acc[i];
+    }
+  }
+}
+
+// STFT-magnitude backward, one workgroup per frame: recompute the frame's spectrum (same packed real FFT as the forward),
+// G_k = dmag_k * (re, im) / mag, then the adjoint of the real DFT,
+//   dframe[n] = Re( sum_{k=0..N/2} G_k e^{+2 pi i k n / N} ) = Re( FFT_N(conj(H)) )[n],  H_k = G_k (k <= N/2), 0 otherwise,
+// as an N-point complex Stockham FFT, and scatter-add window[n] * dframe[n] onto the (reflect-folded) waveform gradient.
+// tw2: twiddle table for 2N (N entries exp(-2 pi i t / 2N)); exp(-2 pi i t / N) = tw2[2t].
+__global__ __launch_bounds__(256) void stft_mag_bwd_kernel(const float* __restrict__ wav, const float* __restrict__ window,
+                                                           const float2* __restrict__ tw2, const float* __restrict__ dspec,
+                                                           float* __restrict__ dwav, int T, int n_fft, int hop,
+                                                           int frames, int log2L) {
+  extern __shared__ __attribute__((aligned(16))) float stft_smem[];
+  const int N = n_fft, L = n_fft >> 1;
+  float2* buf0 = reinterpret_cast<float2*>(stft_smem);  // N complex each
+  float2* buf1 = buf0 + N;
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / frames, frame = blockIdx.x % frames;
+  const int pad = (n_fft - hop) / 2;
+  const float* w = wav + (int64_t)b * T;
+  // 1. forward: packed real FFT of the windowed frame (length L complex)
+  for (int n = tid; n < L; n += 256) {
+    float v[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      int i = frame * hop + 2 * n + e - pad;
+      if (i < 0) i = -i;
+      if (i >= T) i = 2 * (T - 1) - i;
+      v[e] = w[i] * window[2 * n + e];
+    }
+    buf0[n] = make_float2(v[0], v[1]);
+  }
+  __syncthreads();
+  float2* src = buf0;
+  float2* dst = buf1;
+  for (int ps = 0; ps < log2L; ++ps) {
+    const int Ns = 1 << ps;
+    for (int j = tid; j < (L >> 1); j += 256) {
+      const int k = j & (Ns - 1);
+      const float2 a = src[j];
+      const float2 bb = src[j + (L >> 1)];
+      const float2 t = tw2[2 * (k * (n_fft >> (ps + 1)))];
+      const float2 bt = make_float2(bb.x * t.x - bb.y * t.y, bb.x * t.y + bb.y * t.x);
+      const int j0 = (j << 1) - k;
+      dst[j0] = make_float2(a.x + bt.x, a.y + bt.y);
+      dst[j0 + Ns] = make_float2(a.x - bt.x, a.y - bt.y);
+    }
+    __syncthreads();
+    float2* tmp = src; src = dst; dst = tmp;
+  }
+  // 2. H = conj(G) into dst (length N, upper half zero)
+  const float* dsp = dspec + (int64_t)b * (L + 1) * frames + frame;
+  for (int k = tid; k < N; k += 256) {
+    float2 h = make_float2(0.f, 0.f);
+    if (k <= L) {
+      float re, im;
+      if (k == 0 || k == L) {
+        const float2 z0 = src[0];
+        re = (k == 0) ? z0.x + z0.y : z0.x - z0.y;
+        im = 0.f;
+      } else {
+        const float2 zk = src[k];
+        const float2 zc = src[L - k];
+        const float er = 0.5f * (zk.x + zc.x), ei = 0.5f * (zk.y - zc.y);
+        const float orr = 0.5f * (zk.y + zc.y), oi = -0.5f * (zk.x - zc.x);
+        const float2 t = tw2[2 * k];
+        re = er + (orr * t.x - oi * t.y);
+        im = ei + (orr * t.y + oi * t.x);
+      }
+      const float mag = sqrtf(re * re + im * im + 1e-6f);
+      const float gk = dsp[(int64_t)k * frames] / mag;
+      h = make_float2(gk * re, -gk * im);
+    }
+    dst[k] = h;
+  }
+  __syncthreads();
+  // 3. N-point complex FFT of H (dst -> ...), log2(N) = log2L + 1 passes
+  {
+    float2* s2 = dst;
+    float2* d2 = src;
+    for (int ps = 0; ps <= log2L; ++ps) {
+      const int Ns = 1 << ps;
+      for (int j = tid; j < L; j += 256) {  // N/2 butterflies
+        const int k = j & (Ns - 1);
+        const float2 a = s2[j];
+        const float2 bb = s2[j + L];
+        const float2 t = tw2[k * (n_fft >> ps)];  // exp(-2 pi i k / (2 Ns)) = tw2[k * 2N / (2 Ns)]
+        const float2 bt = make_float2(bb.x * t.x - bb.y * t.y, bb.x * t.y + bb.y * t.x);
+        const int j0 = (j << 1) - k;
+        d2[j0] = make_float2(a.x + bt.x, a.y + bt.y);
+        d2[j0 + Ns] = make_float2(a.x - bt.x, a.y - bt.y);
+      }
+      __syncthreads();
+      float2* tmp = s2; s2 = d2; d2 = tmp;
+    }
+    // 4. overlap-add onto the waveform gradient through the reflect padding
+    float* dw = dwav + (int64_t)b * T;
+    for (int n = tid; n < N; n += 256) {
+      int i = frame * hop + n - pad;
+      if (i < 0) i = -i;
+      if (i >= T) i = 2 * (T - 1) - i;
+      atomicAdd(dw + i, s2[n].x * window[n]);
+    }
+  }
+}
+
 }  // namespace ttts
 
 using namespace ttts;
@@ -178,4 +332,35 @@ extern "C" int ttts_mel_log_fwd_f32(const float* spec, const float* basis, float
   const int grid = B * (int)cdiv(frames, 64) * (int)cdiv(n_mels, 32);
   mel_log_kernel<<<grid, 256, 0, as_stream(stream)>>>(spec, basis, mel, n_bins, n_mels, frames);
   return check_launch("mel_log_fwd");
+}
+
+extern "C" int ttts_mel_log_bwd_f32(const float* dmel, const float* mel, const float* basis, float* dspec, int32_t B,
+                                    int32_t n_bins, int32_t n_mels, int32_t frames, void* stream) {
+  TTTS_REQUIRE(dmel && mel && basis && dspec && B > 0 && n_bins > 0 && n_mels > 0 && frames > 0, "mel_log_bwd: bad arguments");
+  const int grid = B * (int)cdiv(frames, 64) * (int)cdiv(n_bins, 32);
+  mel_log_bwd_kernel<<<grid, 256, 0, as_stream(stream)>>>(dmel, mel, basis, dspec, n_bins, n_mels, frames);
+  return check_launch("mel_log_bwd");
+}
+
+extern "C" int ttts_stft_mag_bwd_f32(const float* wav, const float* window, const float* twiddle2, const float* dspec,
+                                     float* dwav, int32_t B, int32_t T, int32_t n_fft, int32_t hop, void* stream) {
+  TTTS_REQUIRE(wav && window && twiddle2 && dspec && dwav, "stft_bwd: null pointer");
+  TTTS_REQUIRE(n_fft >= 64 && n_fft <= 4096 && (n_fft & (n_fft - 1)) == 0, "stft_bwd: n_fft must be a power of two in [64, 4096]");
+  TTTS_REQUIRE(hop > 0 && hop <= n_fft && B > 0, "stft_bwd: bad hop / batch");
+  const int pad = (n_fft - hop) / 2;
+  TTTS_REQUIRE(T > pad && T + 2 * pad >= n_fft, "stft_bwd: clip too short");
+  const int frames = (T + 2 * pad - n_fft) / hop + 1;
+  int log2L = 0;
+  while ((1 << log2L) < n_fft / 2) ++log2L;
+  const size_t smem = (size_t)2 * n_fft * sizeof(float2);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stft_mag_bwd_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return fail(TTTS_EHIP, "stft_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  stft_mag_bwd_kernel<<<B * frames, 256, smem, as_stream(stream)>>>(wav, window, reinterpret_cast<const float2*>(twiddle2),
+                                                                   dspec, dwav, T, n_fft, hop, frames, log2L);
+  return check_launch("stft_mag_bwd");
 }

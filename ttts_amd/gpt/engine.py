@@ -160,18 +160,21 @@ class GptEngine:
         D, L, H = c["model_dim"], c["layers"], c["heads"]
         S = Tt + Tm
         M = B * S
+        Mp = _up(M, 64)   # row padding (kept zero) of every weight-gradient GEMM operand: whole 64-row DMA tiles
+        self._Mp = Mp
         f32, bf = torch.float32, torch.bfloat16
         e = lambda *s, dt=bf: torch.empty(*s, dtype=dt, device=dev)  # noqa: E731
+        z = lambda r, c: torch.zeros(Mp, c, dtype=bf, device=dev)[:r]  # noqa: E731  ([M, c] view of a zero-padded buffer)
         b = {}
         b["xs"] = [e(M, D, dt=f32) for _ in range(2 * L + 1)]
-        b["ln1"] = [e(M, D) for _ in range(L)]
-        b["ln2"] = [e(M, D) for _ in range(L)]
+        b["ln1"] = [z(M, D) for _ in range(L)]
+        b["ln2"] = [z(M, D) for _ in range(L)]
         b["stats"] = [[e(M, dt=f32) for _ in range(4)] for _ in range(L)]   # mean1, rstd1, mean2, rstd2
         b["qkv"] = [e(M, 3 * D) for _ in range(L)]
-        b["att"] = [e(M, D) for _ in range(L)]
+        b["att"] = [z(M, D) for _ in range(L)]
         b["lse"] = [e(B * H * S, dt=f32) for _ in range(L)]
         b["fc_pre"] = [e(M, 4 * D) for _ in range(L)]
-        b["fc_act"] = [e(M, 4 * D) for _ in range(L)]
+        b["fc_act"] = [z(M, 4 * D) for _ in range(L)]
         b["lnf"] = e(M, D, dt=f32)
         b["fstats"] = [e(M, dt=f32) for _ in range(4)]
         b["enc"] = e(M, D)                                   # split layout: text rows, then mel rows
@@ -186,14 +189,14 @@ class GptEngine:
         b["d_enc"] = e(M, D)
         b["d_tmp"] = e(M, D, dt=f32)
         b["dres"] = e(M, D, dt=f32)
-        b["dres_bf"] = e(M, D)
-        b["d_fc"] = e(M, 4 * D)
+        b["dres_bf"] = z(M, D)
+        b["d_fc"] = z(M, 4 * D)
         b["d_ln"] = e(M, D)
         b["d_att"] = e(M, D)
-        b["dqkv"] = e(M, 3 * D)
+        b["dqkv"] = z(M, 3 * D)
         b["delta"] = e(B * H * S, dt=f32)
         b["ln_ws"] = ops.layernorm_bwd_workspace(M, D, dev)
-        tn_shapes = [(D, 3 * D, M), (D, D, M), (D, 4 * D, M), (4 * D, D, M), (self.nt, D, B * Tt), (self.nm, D, B * Tm)]
+        tn_shapes = [(D, 3 * D, Mp), (D, D, Mp), (D, 4 * D, Mp), (4 * D, D, Mp), (self.nt, D, B * Tt), (self.nm, D, B * Tm)]
         b["tn_ws"] = max((ops.gemm_tn_workspace(mo, no, kr, dev) for mo, no, kr in tn_shapes), key=lambda t: t.numel())
         # static token buffers (graph replay reads them)
         i64 = torch.int64
@@ -204,6 +207,10 @@ class GptEngine:
         self.b = b
         self._bufs_key = key
         self._graph = None
+
+    def _padded(self, t):
+        """The zero-row-padded [Mp, c] buffer behind an [M, c] activation view (weight-gradient GEMM operand)."""
+        return torch.as_strided(t, (self._Mp, t.shape[1]), t.stride(), t.storage_offset())
 
     def set_tokens(self, text_inp, text_tar, mel_inp, mel_tar):
         B, Tt = text_inp.shape
@@ -292,22 +299,22 @@ class GptEngine:
             st = b["stats"][i]
             x0, x1 = b["xs"][2 * i], b["xs"][2 * i + 1]
             dy = b["dres_bf"]                                  # gradient entering mlp.c_proj (resid dropout applied)
-            ops.gemm_tn_accum(b["fc_act"][i], dy, G(pre + "mlp.c_proj.weight"), workspace=b["tn_ws"])
+            ops.gemm_tn_accum(self._padded(b["fc_act"][i]), self._padded(dy), G(pre + "mlp.c_proj.weight"), workspace=b["tn_ws"])
             ops.gemm_nt(dy, self.w(pre + "mlp.c_proj.weight"), b["d_fc"], aux=b["fc_pre"][i], epilogue=EPI_DGELU_BF16)
-            ops.gemm_tn_accum(b["ln2"][i], b["d_fc"], G(pre + "mlp.c_fc.weight"), workspace=b["tn_ws"])
+            ops.gemm_tn_accum(self._padded(b["ln2"][i]), self._padded(b["d_fc"]), G(pre + "mlp.c_fc.weight"), workspace=b["tn_ws"])
             ops.colsum_accum(b["d_fc"], G(pre + "mlp.c_fc.bias"))
             ops.gemm_nt(b["d_fc"], self.w(pre + "mlp.c_fc.weight"), b["d_ln"])
             ops.layernorm_bwd(b["d_ln"], x1, P(pre + "ln_2.weight"), st[2], st[3], b["dres"], b["dres"], b["dres_bf"],
                               G(pre + "ln_2.weight"), G(pre + "ln_2.bias"), b["ln_ws"], dropout_p=p,
                               seed=self._seed(16 * i + 3), dcolsum=G(pre + "attn.c_proj.bias"))
             dy = b["dres_bf"]                                  # gradient entering attn.c_proj
-            ops.gemm_tn_accum(b["att"][i], dy, G(pre + "attn.c_proj.weight"), workspace=b["tn_ws"])
+            ops.gemm_tn_accum(self._padded(b["att"][i]), self._padded(dy), G(pre + "attn.c_proj.weight"), workspace=b["tn_ws"])
             ops.gemm_nt(dy, self.w(pre + "attn.c_proj.weight"), b["d_att"])
             qkv, dqkv = b["qkv"][i], b["dqkv"]
             ops.attn_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], b["att"][i], b["d_att"], b["lse"][i], dqkv, dqkv[:, D:],
                          dqkv[:, 2 * D:], b["delta"], B, H, S, dh, (S * 3 * D, 3 * D), (S * D, D), dh ** -0.5, p,
                          self._seed(16 * i + 2))
-            ops.gemm_tn_accum(b["ln1"][i], dqkv, G(pre + "attn.c_attn.weight"), workspace=b["tn_ws"])
+            ops.gemm_tn_accum(self._padded(b["ln1"][i]), self._padded(dqkv), G(pre + "attn.c_attn.weight"), workspace=b["tn_ws"])
             ops.colsum_accum(dqkv, G(pre + "attn.c_attn.bias"))
             ops.gemm_nt(dqkv, self.w(pre + "attn.c_attn.weight"), b["d_ln"])
             ops.layernorm_bwd(b["d_ln"], x0, P(pre + "ln_1.weight"), st[0], st[1], b["dres"], b["dres"],

@@ -108,6 +108,8 @@ SIGNATURES = {
     "ttts_stft_twiddle_host": (_I32, [_P, _I32]),
     "ttts_stft_mag_fwd_f32": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "ttts_mel_log_fwd_f32": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "ttts_mel_log_bwd_f32": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "ttts_stft_mag_bwd_f32": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "ttts_probe_mfma_layout": (_I32, [_P, _P, _P]),
     "ttts_debug_set_flags": (_I32, [_I32]),
 }

@@ -67,10 +67,12 @@ def gemm_tn_workspace(mo, no, kr, device):
     return torch.empty(max(n, 16) // 4, dtype=torch.float32, device=device)
 
 
-def gemm_tn_accum(at, bt, c, mo=None, no=None, workspace=None):
+def gemm_tn_accum(at, bt, c, mo=None, no=None, workspace=None, kr=None):
     """c[Mo,No] += at[Kr,Mo]^T @ bt[Kr,No]  (fp32; split-K slabs in `workspace`, summed deterministically)."""
     _req(at, torch.bfloat16, "at"); _req(bt, torch.bfloat16, "bt"); _req(c, torch.float32, "c")
-    Kr = at.shape[0]
+    Kr = at.shape[0] if kr is None else kr
+    if at.shape[0] < Kr or bt.shape[0] < Kr:
+        raise TttsError("gemm_tn: kr exceeds the operands' rows")
     Mo = at.shape[1] if mo is None else mo
     No = bt.shape[1] if no is None else no
     need = _l.get().ttts_gemm_tn_workspace_bytes(Mo, No, Kr)
@@ -299,6 +301,27 @@ def dropout_counter(device):
         check(_l.get().ttts_set_dropout_counter(_p(t)), "set_dropout_counter")
         _dropout_counters[key] = t
     return _dropout_counters[key]
+
+
+def stft_mag_bwd(wav, window, dspec, n_fft, hop):
+    """Gradient of stft_mag w.r.t. wav: f32 [B, T]."""
+    _req(wav, torch.float32, "wav"); _req(dspec, torch.float32, "dspec")
+    wav = wav.contiguous(); dspec = dspec.contiguous()
+    B, T = wav.shape
+    dwav = torch.zeros_like(wav)
+    check(_l.get().ttts_stft_mag_bwd_f32(_p(wav), _p(window), _p(stft_twiddle(2 * n_fft, wav.device)), _p(dspec), _p(dwav),
+                                         B, T, n_fft, hop, _stream()), "stft_mag_bwd")
+    return dwav
+
+
+def mel_log_bwd(dmel, mel, basis, n_bins):
+    _req(dmel, torch.float32, "dmel"); _req(mel, torch.float32, "mel")
+    dmel = dmel.contiguous(); mel = mel.contiguous(); basis = basis.contiguous()
+    B, n_mels, frames = mel.shape
+    dspec = torch.zeros(B, n_bins, frames, dtype=torch.float32, device=mel.device)
+    check(_l.get().ttts_mel_log_bwd_f32(_p(dmel), _p(mel), _p(basis), _p(dspec), B, n_bins, n_mels, frames, _stream()),
+          "mel_log_bwd")
+    return dspec
 
 
 def probe_layout(device):
