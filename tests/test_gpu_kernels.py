@@ -444,3 +444,42 @@ def test_mel_spectrogram_backward(ops, golden_dir):
     assert sp.shape == (2, 513, 31)
     sp.backward(ct.to(dev()))
     assert rel_err(yg.grad.cpu(), yr.grad) < 1e-4
+
+
+def test_rvq_module_surface_and_training_forward(golden_dir):
+    """ttts_amd.vqvae.ResidualVectorQuantizer: state-dict keys of the reference, train-mode forward/backward and buffer
+    updates vs the reference-generated fixture (codes bit-exact), encode/decode round trip, k-means initialisation."""
+    from ttts_amd.vqvae import ResidualVectorQuantizer
+    surf = json.load(open(os.path.join(golden_dir, "surface.json")))
+    want_keys = [k[len("quantizer."):] for k, _, _ in surf["vqvae_g"] if k.startswith("quantizer.")]
+    g = np.load(os.path.join(golden_dir, "vq.npz"))
+    K, D = 1024, 192
+    rvq = ResidualVectorQuantizer(dimension=D, n_q=1, bins=K).to(dev())
+    assert list(rvq.state_dict().keys()) == want_keys
+    rng = np.random.default_rng(int(g["train:seed"]))
+    e = torch.from_numpy(rng.standard_normal((K, D), dtype=np.float32)).to(dev())
+    x = torch.from_numpy(rng.standard_normal((4, D, 128), dtype=np.float32)).to(dev()).requires_grad_(True)
+    cb = rvq.vq.layers[0]._codebook
+    cb.inited.fill_(1); cb.embed.copy_(e); cb.embed_avg.copy_(e * 4.0); cb.cluster_size.fill_(4.0)
+    rvq.train()
+    q, codes, commit, qlist = rvq(x, layers=[0])
+    (q.sum() * 0.5 + commit).backward()
+    assert np.array_equal(codes.cpu().numpy(), g["train:codes"])
+    np.testing.assert_allclose(q.detach().cpu().numpy(), g["train:quantized"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(commit.item(), g["train:commit"], rtol=1e-5)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g["train:dx"], rtol=2e-6, atol=1e-8)
+    np.testing.assert_allclose(cb.cluster_size.cpu().numpy(), g["train:cluster_size"], rtol=1e-6)
+    samp = lambda t: t.reshape(-1)[::max(1, t.numel() // 8192)].cpu().numpy()  # noqa: E731
+    np.testing.assert_allclose(samp(cb.embed), g["train:embed_sample"], rtol=1e-5, atol=1e-6)
+    # eval: encode / decode round trip on the updated codebook
+    rvq.eval()
+    with torch.no_grad():
+        c2 = rvq.encode(x.detach())
+        xr = rvq.decode(c2)
+        q2, codes2, loss2, _ = rvq(x.detach())
+    assert torch.equal(c2, codes2) and torch.allclose(xr, q2) and float(loss2) == 0.0
+    # k-means initialisation on the first training batch
+    rvq2 = ResidualVectorQuantizer(dimension=64, n_q=2, bins=32, kmeans_iters=5).to(dev())
+    rvq2.train()
+    out = rvq2(torch.randn(2, 64, 300, device=dev()))
+    assert bool(rvq2.vq.layers[0]._codebook.inited) and out[1].shape == (2, 2, 300) and torch.isfinite(out[2])
