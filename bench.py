@@ -178,15 +178,15 @@ def main():
     assert lt == lt and lm == lm, "non-finite loss"
 
     # per-kernel HIP-event timing (same kernels, shapes and data; eager launches), right after the timed steps
+    # EVERY rank runs the instrumented steps (they contain the gradient all-reduce); only rank 0 records events.
     roof = None
+    saved_mode = args.mode
+    args.mode = "eager"
     if rank == 0:
-        saved_mode = args.mode
-        args.mode = "eager"
         with KernelTimer(ops) as kt:
             for _ in range(args.profile_steps):
                 step()
             agg = kt.summary()
-        args.mode = saved_mode
         fam, (cnt, secs, flops) = max(agg.items(), key=lambda kv: kv[1][1])
         ach = flops / secs / 1e12
         roof = {"bound": "mfma", "kernel": fam, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
@@ -195,6 +195,11 @@ def main():
                 "avg_gflop_per_launch": round(flops / cnt / 1e9, 3),
                 "all_kernels_ms_per_step": {k: round(v[1] / args.profile_steps * 1e3, 3) for k, v in sorted(agg.items())},
                 "all_kernels_tflops": {k: round(v[2] / v[1] / 1e12, 1) for k, v in sorted(agg.items())}}
+    else:
+        for _ in range(args.profile_steps):
+            step()
+    args.mode = saved_mode
+    torch.cuda.synchronize()
     if world > 1:
         dp.barrier()
 

@@ -215,3 +215,20 @@ def test_dropout_training_under_graph_replay(gpt):
     eng.forward()
     lm_eval = eng.losses()[1]
     assert abs(np.mean(losses) - lm_eval) < 0.2 * abs(lm_eval)
+
+
+def test_bench_two_ranks_sharing_the_gpu(tmp_path):
+    """bench.py's N > 1 control flow end to end on the one GPU of the test box: two ranks (gloo, both on cuda:0):
+    rendezvous, parameter broadcast, flat gradient all-reduce, barriers, max-over-ranks timing, one JSON line."""
+    import subprocess
+    import sys
+    env = dict(os.environ, TTTS_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(29400 + os.getpid() % 500),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--profile-steps", "1"], capture_output=True, text=True, env=env, timeout=240)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16 and out["value"] > 0 and out["scaling"] == "weak"

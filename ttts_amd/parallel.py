@@ -21,9 +21,12 @@ def env_rank_world():
 def init_distributed(backend=None):
     """Initialise the default process group from the torchrun environment (RANK / WORLD_SIZE / MASTER_*)."""
     rank, world, local = env_rank_world()
+    if os.environ.get("TTTS_SHARE_GPU"):   # test hook: several ranks on ONE GPU (RCCL refuses duplicate GPUs -> gloo)
+        local = 0
+        backend = backend or "gloo"
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("TTTS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
