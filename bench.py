@@ -153,8 +153,9 @@ def main():
 
     def step():
         toks = prepare_tokens(eng.c, text_d, tl, mel_d, wl)   # token plumbing (lengths are host tensors: no sync)
-        if args.mode != "eager" and world == 1:
-            eng.train_step(toks, w_text, w_mel, capture=True, lr=tr["lr"])
+        if args.mode != "eager":
+            eng.train_step(toks, w_text, w_mel, capture=True, lr=tr["lr"],
+                           exchange=(lambda: dp.allreduce_grads_(eng.grads)) if world > 1 else None)
             return
         eng.set_tokens(*toks)
         eng.forward()
@@ -211,7 +212,8 @@ def main():
                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": "VALL-E GPT train step (ttts/gpt/config.json model: 6 layers, d512, 8 heads, 21.46 M "
                                       "params), batch 8 per GPU x (128 text + 1024 audio tokens) = S 1156, fwd+bwd+clip+AdamW, "
-                                      "dropout %.1f, %s" % (dropout, "eager launches" if (args.mode == "eager" or world > 1) else "hipGraph replay"),
+                                      "dropout %.1f, %s" % (dropout, "eager launches" if args.mode == "eager" else ("hipGraph replay" if world == 1 else
+                                                                       "hipGraph replay around one RCCL all-reduce")),
                           "global_batch": world * B_PER_GPU, "seq_len": TEXT_LEN + 2 + MEL_LEN + 2, "parallelism": "dp%d" % world,
                           "mode": args.mode},
                "final_loss_mel": round(lm, 4), "roofline": roof}

@@ -340,25 +340,39 @@ class GptEngine:
         self.grads.zero_()
 
     # ---- whole step (optionally replayed from one hipGraph) ---------------------------------------------------
-    def train_step(self, tokens, w_text=0.01, w_mel=1.0, capture=False, **opt):
+    def train_step(self, tokens, w_text=0.01, w_mel=1.0, capture=False, exchange=None, **opt):
         """tokens = (text_inp, text_tar, mel_inp, mel_tar) int64 tensors (see model.prepare_tokens).
-        Returns nothing: losses stay on the device in self.b['losses'] (no host sync in the hot loop)."""
+        exchange: optional callable run between backward and the optimizer (the data-parallel gradient all-reduce).
+        capture=True replays the step from hipGraphs: one graph without `exchange`, two (forward+backward | optimizer)
+        around the collective with it.  Returns nothing: losses stay on the device (no host sync in the hot loop)."""
         self.set_tokens(*tokens)
         if not capture:
             self.forward()
             self.backward(w_text, w_mel)
+            if exchange is not None:
+                exchange()
             self.optimizer_step(**opt)
         else:
-            key = (self._bufs_key, w_text, w_mel, tuple(sorted(opt.items())))
+            key = (self._bufs_key, w_text, w_mel, tuple(sorted(opt.items())), exchange is not None)
             if self._graph is None or self._graph_key != key:
                 torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                ga = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga):
                     self.forward()
                     self.backward(w_text, w_mel)
-                    self.optimizer_step(**opt)
-                self._graph, self._graph_key = g, key
-            self._graph.replay()   # capture only records; every step (the first included) is a replay
+                    if exchange is None:
+                        self.optimizer_step(**opt)
+                gb = None
+                if exchange is not None:
+                    gb = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gb):
+                        self.optimizer_step(**opt)
+                self._graph, self._graph_key = (ga, gb), key
+            ga, gb = self._graph
+            ga.replay()   # capture only records; every step (the first included) is a replay
+            if gb is not None:
+                exchange()
+                gb.replay()
         self.step_count += 1
 
     def losses(self):

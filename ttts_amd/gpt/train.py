@@ -117,7 +117,7 @@ class Trainer(object):
             eng.set_tokens(*toks)
             eng.forward()
             eng.backward(self.text_loss_weight * scale, self.mel_loss_weight * scale)
-        self.dp.allreduce_grads_(eng.grads)
+        self.dp.allreduce_grads_(eng.grads)      # ONE flat RCCL all-reduce (no-op at world size 1)
         eng.optimizer_step(lr=self.lr, max_norm=1.0, warmup_steps=500)
         eng.step_count += 1
 
