@@ -225,6 +225,42 @@ int ttts_mel_log_bwd_f32(const float* dmel, const float* mel, const float* basis
 int ttts_stft_mag_bwd_f32(const float* wav, const float* window, const float* twiddle2, const float* dspec,
                           float* dwav, int32_t B, int32_t T, int32_t n_fft, int32_t hop, void* stream);
 
+/* ---- 1-D convolution family (fp32, (B, C, L) layout, groups = 1) ---------------------------------------------
+ * Replaces: nn.Conv1d (incl. groups) / Conv2d with (k,1) kernels / ConvTranspose1d / weight_norm + the leaky-relu, bias, residual-add and tanh around them in
+ * ResBlock1 (ttts/vqvae/modules.py:224-318), Generator (ttts/vqvae/vq2.py:341-415), PosteriorAudioEncoder (:667-745),
+ * WN (modules.py:136-221), and their autograd.  w: [Cout, Cin, K].
+ * fwd:   y = [y +] out_scale * act_out(lrelu'(gate) * (bias[co] + bbias[b][co] + conv(lrelu(x, in_slope), w)) + resid)
+ *        Lout = (Lin + 2 pad - dil (K-1) - 1)/stride + 1;  lrelu'(gate) = gate > 0 ? 1 : gate_slope (gate NULL: 1);
+ *        out_act: 0 none, 1 tanh, 2 leaky-relu(out_slope).  Cin/Cout are TOTAL channel counts; w: [Cout, Cin/groups, K].
+ * dgrad: dx = [dx +] out_scale * (lrelu'(gate) * (bias[ci] + conv^T(lrelu(dy, in_slope), w)) + resid) -- with a
+ *        ConvTranspose1d weight [Cin_t, Cout_t, K] passed as w (Cout := Cin_t, Cin := Cout_t, Lin := output length) this
+ *        IS the transposed convolution's forward (and fwd is its data gradient); stride > 1 requires dil == 1.
+ * wgrad: dw += sum_{b,l} lrelu(dy, dy_slope) * lrelu(x, x_slope) (shifted).   bias_grad: db[c] += sum_{b,l} dy.
+ * weight_norm (dim 0): w[r] = g[r] v[r] / ||v[r]||, norm[r] saved; bwd accumulates dv, dg. */
+int ttts_conv1d_fwd_f32(const float* x, const float* w, const float* bias, const float* bbias, const float* resid,
+                        const float* gate, float* y, int32_t B, int32_t Cin, int32_t Lin, int32_t Cout, int32_t Lout,
+                        int32_t K, int32_t stride, int32_t pad, int32_t dil, int32_t groups, float in_slope,
+                        float gate_slope, int32_t out_act, float out_slope, float out_scale, int32_t accumulate,
+                        void* stream);
+int ttts_conv1d_dgrad_f32(const float* dy, const float* w, const float* bias, const float* resid,
+                          const float* gate, float* dx, int32_t B, int32_t Cin, int32_t Lin, int32_t Cout,
+                          int32_t Lout, int32_t K, int32_t stride, int32_t pad, int32_t dil, int32_t groups,
+                          float in_slope, float gate_slope, float out_scale, int32_t accumulate, void* stream);
+int ttts_conv1d_wgrad_f32(const float* dy, const float* x, float* dw, int32_t B, int32_t Cin, int32_t Lin,
+                          int32_t Cout, int32_t Lout, int32_t K, int32_t stride, int32_t pad, int32_t dil,
+                          int32_t groups, float dy_slope, float x_slope, void* stream);
+int ttts_conv1d_bias_grad_f32(const float* dy, float* db, int32_t B, int32_t C, int32_t L, void* stream);
+int ttts_weight_norm_fwd_f32(const float* v, const float* g, float* w, float* norm, int32_t rows, int32_t n,
+                             void* stream);
+int ttts_weight_norm_bwd_f32(const float* dw, const float* v, const float* g, const float* norm, float* dv,
+                             float* dg, int32_t rows, int32_t n, void* stream);
+int ttts_tanh_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, void* stream);
+int ttts_lrelu_bwd_f32(const float* dy, const float* y, float* dx, float slope, int64_t n, void* stream);
+/* y = scale * (a + b + c + d), b/c/d optional (NULL): `xs / num_kernels` of Generator.forward (vq2.py:396-403) and its
+ * gradient (a = dy, scale = 1/num_kernels).  Pointers 16-byte aligned. */
+int ttts_add4_scale_f32(const float* a, const float* b, const float* c, const float* d, float scale, float* y,
+                        int64_t n, void* stream);
+
 /* ---- probes (tests only): dump hardware fragment layouts the kernels rely on ------------------------ */
 /* out_c f32 [64 lanes][16 regs]: raw accumulators of one 32x32x16 bf16 MFMA with D[i][j] = (i+1) + 64*(j+1);
  * out_tr i32 [64 lanes][8]: the uint16 LDS element indices two ds_read_b64_tr_b16 return for the kernels' address map. */

@@ -79,3 +79,22 @@ def test_mel_set_b(golden_dir):
     np.testing.assert_allclose(mel_ref.spectrogram(y, 1024, 256, 1024).numpy(), g["B:spec"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(mel_ref.mel_spectrogram(y, 1024, 80, 22050, 256, 1024, 0, 8000).numpy(), g["B:mel"],
                                rtol=1e-5, atol=1e-5)
+
+
+def test_generator_restatement(golden_dir):
+    """oracle/vqvae_ref.py (ResBlock1, Generator, both weight-norm styles) vs the reference-generated fixture."""
+    import json
+    from oracle import vqvae_ref
+    g = np.load(os.path.join(golden_dir, "vqvae_generator.npz"))
+    cfg = json.loads(str(g["cfg_json"]))
+    sd = {k[3:]: torch.from_numpy(g[k]).requires_grad_(True) for k in g.files if k.startswith("sd:")}
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    gg = torch.from_numpy(g["g"]).requires_grad_(True)
+    y = vqvae_ref.generator_forward(sd, cfg, x, gg)
+    np.testing.assert_allclose(y.detach().numpy(), g["y"], rtol=1e-5, atol=1e-6)
+    (y * torch.from_numpy(g["ct"])).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), g["dx"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(gg.grad.numpy(), g["dg"], rtol=1e-4, atol=1e-6)
+    for k in g.files:
+        if k.startswith("grad:"):
+            np.testing.assert_allclose(sd[k[5:]].grad.numpy(), g[k], rtol=1e-4, atol=1e-6, err_msg=k)

@@ -8,5 +8,6 @@ run rowwise tests/test_gpu_kernels.py -k "layernorm or embed or cross_entropy or
 run attention tests/test_gpu_kernels.py -k "attention"
 run vq_stft tests/test_gpu_kernels.py -k "vq or stft"
 run gpt tests/test_gpu_gpt.py
+run vqvae tests/test_gpu_vqvae.py
 } > gpurun_out/pytest_gpu.log 2>&1
 grep -E "^===|passed|failed|error" gpurun_out/pytest_gpu.log | tail -40

@@ -244,8 +244,44 @@ def gen_mel():
     print("G4 mel:", spec.shape, mel.shape, specb.shape, melb.shape, "seg loss", float(loss))
 
 
+TINY_GEN = {"initial_channel": 16, "resblock": "1", "resblock_kernel_sizes": [3, 7, 11],
+            "resblock_dilation_sizes": [[1, 3, 5], [1, 3, 5], [1, 3, 5]], "upsample_rates": [4, 2],
+            "upsample_initial_channel": 32, "upsample_kernel_sizes": [8, 4], "gin_channels": 8}
+
+
+def gen_vqvae():
+    """G5: tiny HiFi-GAN Generator (both weight-norm styles, ConvTranspose ups, ResBlock1 stacks): forward + grads."""
+    import ttts.vqvae.vq2 as vq2
+    torch.manual_seed(0)
+    gen = vq2.Generator(**TINY_GEN)
+    rng = np.random.default_rng(51)
+    with torch.no_grad():
+        for k, p in gen.named_parameters():
+            a = rng.standard_normal(tuple(p.shape), dtype=np.float32)
+            if k.endswith("weight_g") or k.endswith("original0"):
+                a = 0.5 + 0.1 * np.abs(a)
+            elif p.dim() > 1:
+                a = a * (0.3 / np.sqrt(p.shape[1] * p.shape[2]))
+            else:
+                a = a * 0.05
+            p.copy_(torch.from_numpy(a))
+    x = torch.from_numpy(rng.standard_normal((2, 16, 20), dtype=np.float32)).requires_grad_(True)
+    g = torch.from_numpy(rng.standard_normal((2, 8, 1), dtype=np.float32)).requires_grad_(True)
+    ct = torch.from_numpy(rng.standard_normal((2, 1, 160), dtype=np.float32))
+    y = gen(x, g)
+    (y * ct).sum().backward()
+    rec = {"cfg_json": np.array(json.dumps(TINY_GEN)), "x": x.detach().numpy(), "g": g.detach().numpy(), "ct": ct.numpy(),
+           "y": y.detach().numpy(), "dx": x.grad.numpy(), "dg": g.grad.numpy()}
+    for k, v in gen.state_dict().items():
+        rec["sd:" + k] = v.numpy()
+    for k, p in gen.named_parameters():
+        rec["grad:" + k] = p.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "vqvae_generator.npz"), **rec)
+    print("G5 generator:", y.shape, "params", sum(p.numel() for p in gen.parameters()), "keys", len(gen.state_dict()))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gpt", "vq", "mel"]
+    which = sys.argv[1:] or ["gpt", "vq", "mel", "vqvae"]
     with torch.no_grad() if False else torch.enable_grad():
         if "gpt" in which:
             gen_gpt()
@@ -253,4 +289,6 @@ if __name__ == "__main__":
             gen_vq()
         if "mel" in which:
             gen_mel()
+        if "vqvae" in which:
+            gen_vqvae()
     print("fixtures:", {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT))})

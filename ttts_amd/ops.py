@@ -289,6 +289,112 @@ def mel_log(spec, basis):
     return mel
 
 
+def conv_out_len(lin, k, stride, pad, dil):
+    return (lin + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+_OUT_ACT = {None: 0, "none": 0, "tanh": 1, "lrelu": 2}
+
+
+def conv1d_fwd(x, w, bias=None, resid=None, stride=1, pad=0, dil=1, in_slope=1.0, out_act=None, out_scale=1.0,
+               out=None, accumulate=False, bbias=None, gate=None, gate_slope=1.0, groups=1, out_slope=1.0):
+    """y = [y +] out_scale * act(lrelu'(gate) * (bias + bbias + conv1d(lrelu(x, in_slope), w)) + resid);
+    x (B,Cin,L) fp32, w (Cout,Cin/groups,K), bbias (B,Cout); out_act None | 'tanh' | 'lrelu' (slope out_slope).
+    Also the data gradient of a ConvTranspose1d (w = its weight)."""
+    for t, n in ((x, "x"), (w, "w"), (bias, "bias"), (resid, "resid"), (bbias, "bbias"), (gate, "gate")):
+        _req(t, torch.float32, n)
+    x = x.contiguous(); w = w.contiguous()
+    B, Cin, Lin = x.shape
+    Cout, _, K = w.shape
+    Lout = conv_out_len(Lin, K, stride, pad, dil)
+    y = out if out is not None else torch.empty(B, Cout, Lout, dtype=torch.float32, device=x.device)
+    c = lambda t: t.contiguous() if t is not None else None
+    check(_l.get().ttts_conv1d_fwd_f32(_p(x), _p(w), _p(c(bias)), _p(c(bbias)), _p(c(resid)), _p(c(gate)), _p(y), B, Cin, Lin,
+                                       Cout, Lout, K, stride, pad, dil, groups, in_slope, gate_slope, _OUT_ACT[out_act],
+                                       out_slope, out_scale, int(accumulate), _stream()), "conv1d_fwd")
+    return y
+
+
+def conv1d_dgrad(dy, w, lin, stride=1, pad=0, dil=1, gate=None, gate_slope=1.0, bias=None, in_slope=1.0, resid=None,
+                 out_scale=1.0, out=None, accumulate=False, groups=1):
+    """dx (B,Cin,lin) of a conv with weight w (Cout,Cin/groups,K) -- or the ConvTranspose1d forward with w = its weight
+    (then `in_slope` is the leaky-relu fused on its input and `bias` its bias)."""
+    _req(dy, torch.float32, "dy"); _req(w, torch.float32, "w")
+    dy = dy.contiguous(); w = w.contiguous()
+    B, Cout, Lout = dy.shape
+    Cin, K = w.shape[1] * groups, w.shape[2]
+    dx = out if out is not None else torch.empty(B, Cin, lin, dtype=torch.float32, device=dy.device)
+    c = lambda t: t.contiguous() if t is not None else None
+    check(_l.get().ttts_conv1d_dgrad_f32(_p(dy), _p(w), _p(c(bias)), _p(c(resid)), _p(c(gate)), _p(dx), B, Cin, lin, Cout, Lout,
+                                         K, stride, pad, dil, groups, in_slope, gate_slope, out_scale, int(accumulate),
+                                         _stream()), "conv1d_dgrad")
+    return dx
+
+
+def conv1d_wgrad(dy, x, k, stride=1, pad=0, dil=1, x_slope=1.0, dy_slope=1.0, out=None, groups=1):
+    """dw (Cout,Cin/groups,k) [+]= sum_{b,l} lrelu(dy, dy_slope) * lrelu(x, x_slope) (shifted); `out` accumulates."""
+    dy = dy.contiguous(); x = x.contiguous()
+    B, Cout, Lout = dy.shape
+    _, Cin, Lin = x.shape
+    dw = out if out is not None else torch.zeros(Cout, Cin // groups, k, dtype=torch.float32, device=dy.device)
+    check(_l.get().ttts_conv1d_wgrad_f32(_p(dy), _p(x), _p(dw), B, Cin, Lin, Cout, Lout, k, stride, pad, dil, groups, dy_slope,
+                                         x_slope, _stream()), "conv1d_wgrad")
+    return dw
+
+
+def conv1d_bias_grad(dy):
+    dy = dy.contiguous()
+    B, C, L = dy.shape
+    db = torch.zeros(C, dtype=torch.float32, device=dy.device)
+    check(_l.get().ttts_conv1d_bias_grad_f32(_p(dy), _p(db), B, C, L, _stream()), "conv1d_bias_grad")
+    return db
+
+
+def weight_norm_fwd(v, g):
+    v = v.contiguous()
+    rows, n = v.shape[0], v.numel() // v.shape[0]
+    w = torch.empty_like(v)
+    norm = torch.empty(rows, dtype=torch.float32, device=v.device)
+    check(_l.get().ttts_weight_norm_fwd_f32(_p(v), _p(g.contiguous()), _p(w), _p(norm), rows, n, _stream()), "weight_norm_fwd")
+    return w, norm
+
+
+def weight_norm_bwd(dw, v, g, norm):
+    v = v.contiguous(); dw = dw.contiguous()
+    rows, n = v.shape[0], v.numel() // v.shape[0]
+    dv = torch.zeros_like(v)
+    dg = torch.zeros_like(g).contiguous()
+    check(_l.get().ttts_weight_norm_bwd_f32(_p(dw), _p(v), _p(g.contiguous()), _p(norm), _p(dv), _p(dg), rows, n, _stream()),
+          "weight_norm_bwd")
+    return dv, dg
+
+
+def tanh_bwd(dy, y):
+    dy = dy.contiguous(); y = y.contiguous()
+    dx = torch.empty_like(dy)
+    check(_l.get().ttts_tanh_bwd_f32(_p(dy), _p(y), _p(dx), dy.numel(), _stream()), "tanh_bwd")
+    return dx
+
+
+def lrelu_bwd(dy, y, slope):
+    dy = dy.contiguous(); y = y.contiguous()
+    dx = torch.empty_like(dy)
+    check(_l.get().ttts_lrelu_bwd_f32(_p(dy), _p(y), _p(dx), slope, dy.numel(), _stream()), "lrelu_bwd")
+    return dx
+
+
+def add_scale(tensors, scale=1.0):
+    """scale * sum(tensors) for 1..4 same-shape fp32 tensors."""
+    ts = [t.contiguous() for t in tensors]
+    assert 1 <= len(ts) <= 4
+    for t in ts:
+        _req(t, torch.float32, "add_scale input")
+    y = torch.empty_like(ts[0])
+    ptrs = [_p(t) for t in ts] + [None] * (4 - len(ts))
+    check(_l.get().ttts_add4_scale_f32(*ptrs, scale, _p(y), y.numel(), _stream()), "add4_scale")
+    return y
+
+
 _dropout_counters = {}
 
 
