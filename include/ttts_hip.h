@@ -261,6 +261,27 @@ int ttts_lrelu_bwd_f32(const float* dy, const float* y, float* dx, float slope, 
 int ttts_add4_scale_f32(const float* a, const float* b, const float* c, const float* d, float scale, float* y,
                         int64_t n, void* stream);
 
+/* ---- loss reductions of the VQ-VAE-GAN step ---------------------------------------------------------------------
+ * Replaces: feature_loss / discriminator_loss / generator_loss / kl_loss (ttts/vqvae/losses.py:7-61) and
+ * F.l1_loss(y_mel, y_hat_mel) (ttts/vqvae/train.py:389).  Deterministic two-stage sums; results stay on the device.
+ * reduce_loss: out[0] = [out[0] +] scale * sum_i term(a_i, b_i); term = |a-b| (ABSDIFF), (1-a)^2, a^2.
+ * reduce_loss_bwd: d = [d +] gout[0] * scale * dterm  -- ABSDIFF: w.r.t. b; the squares: w.r.t. a; gout NULL = 1.
+ * kl_loss: tensors [B,C,T], mask [B,1,T]; out[0] = sum(kl * mask) / sum(mask), out[1] = sum(mask) (kept for bwd).
+ * workspace: ttts_loss_workspace_bytes() bytes. */
+#define TTTS_RED_ABSDIFF 0
+#define TTTS_RED_SQ_ONE_MINUS 1
+#define TTTS_RED_SQ 2
+int64_t ttts_loss_workspace_bytes(void);
+int ttts_reduce_loss_f32(const float* a, const float* b, int64_t n, int32_t mode, float scale, float* out,
+                         int32_t accumulate, void* workspace, void* stream);
+int ttts_reduce_loss_bwd_f32(const float* a, const float* b, int64_t n, int32_t mode, float scale, const float* gout,
+                             float* d, int32_t accumulate, void* stream);
+int ttts_kl_loss_fwd_f32(const float* z_p, const float* logs_q, const float* m_p, const float* logs_p,
+                         const float* mask, int32_t B, int32_t C, int32_t T, float* out, void* workspace, void* stream);
+int ttts_kl_loss_bwd_f32(const float* z_p, const float* logs_q, const float* m_p, const float* logs_p,
+                         const float* mask, const float* out, const float* gout, int32_t B, int32_t C, int32_t T,
+                         float* dz_p, float* dlogs_q, float* dm_p, float* dlogs_p, void* stream);
+
 /* ---- probes (tests only): dump hardware fragment layouts the kernels rely on ------------------------ */
 /* out_c f32 [64 lanes][16 regs]: raw accumulators of one 32x32x16 bf16 MFMA with D[i][j] = (i+1) + 64*(j+1);
  * out_tr i32 [64 lanes][8]: the uint16 LDS element indices two ds_read_b64_tr_b16 return for the kernels' address map. */

@@ -62,3 +62,97 @@ def generator_forward(sd, cfg, x, g=None, pfx=""):
     x = F.leaky_relu(x)            # default slope 0.01 (vq2.py:404)
     x = F.conv1d(x, sd[pfx + "conv_post.weight"], None, padding=3)
     return torch.tanh(x)
+
+
+# ---- discriminators (ttts/vqvae/vq2.py:418-551) and losses (ttts/vqvae/losses.py:7-61) --------------------------------
+def det_fill(name, shape):
+    """Deterministic, construction-order-independent parameter fill shared by tools/make_goldens.py, the oracle tests and
+    the GPU parity tests (so multi-million-parameter state dicts need not be stored)."""
+    import zlib
+    import numpy as np
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    a = rng.standard_normal(size=tuple(shape), dtype=np.float32)
+    if name.endswith("weight_g") or name.endswith("original0"):
+        a = np.float32(1.0) + np.float32(0.1) * np.abs(a)            # ~ ||v|| = 1.2 * sqrt(fan_in)/sqrt(fan_in) scale below
+    elif len(shape) > 1:
+        fan_in = 1
+        for d in shape[1:]:
+            fan_in *= d
+        a = a * np.float32(1.2 / fan_in ** 0.5)
+    else:
+        a = a * np.float32(0.05)
+    return torch.from_numpy(a)
+
+
+DS_SPEC = [(15, 1, 1, 7), (41, 4, 4, 20), (41, 4, 16, 20), (41, 4, 64, 20), (41, 4, 256, 20), (5, 1, 1, 2)]  # k, stride, groups, pad
+
+
+def discriminator_s(x, sd, pfx):
+    fmap = []
+    for i, (k, s, g, pd) in enumerate(DS_SPEC):
+        x = F.leaky_relu(F.conv1d(x, _weight(sd, f"{pfx}convs.{i}."), sd[f"{pfx}convs.{i}.bias"], stride=s, padding=pd, groups=g),
+                         LRELU_SLOPE)
+        fmap.append(x)
+    x = F.conv1d(x, _weight(sd, pfx + "conv_post."), sd[pfx + "conv_post.bias"], padding=1)
+    fmap.append(x)
+    return torch.flatten(x, 1, -1), fmap
+
+
+def discriminator_p(x, sd, pfx, period, kernel_size=5, stride=3):
+    fmap = []
+    b, c, t = x.shape
+    if t % period != 0:
+        n_pad = period - (t % period)
+        x = F.pad(x, (0, n_pad), "reflect")
+        t = t + n_pad
+    x = x.view(b, c, t // period, period)
+    pad = (get_padding(kernel_size, 1), 0)
+    for i in range(5):
+        x = F.leaky_relu(F.conv2d(x, _weight(sd, f"{pfx}convs.{i}."), sd[f"{pfx}convs.{i}.bias"],
+                                  stride=(stride if i < 4 else 1, 1), padding=pad), LRELU_SLOPE)
+        fmap.append(x)
+    x = F.conv2d(x, _weight(sd, pfx + "conv_post."), sd[pfx + "conv_post.bias"], padding=(1, 0))
+    fmap.append(x)
+    return torch.flatten(x, 1, -1), fmap
+
+
+PERIODS = [2, 3, 5, 7, 11]
+
+
+def mpd_forward(sd, y, y_hat):
+    outs = ([], [], [], [])
+    for i in range(6):
+        pfx = f"discriminators.{i}."
+        f = (lambda t: discriminator_s(t, sd, pfx)) if i == 0 else (lambda t: discriminator_p(t, sd, pfx, PERIODS[i - 1]))
+        r, fr = f(y)
+        g, fg = f(y_hat)
+        outs[0].append(r); outs[1].append(g); outs[2].append(fr); outs[3].append(fg)
+    return outs
+
+
+def feature_loss(fmap_r, fmap_g):
+    loss = 0
+    for dr, dg in zip(fmap_r, fmap_g):
+        for rl, gl in zip(dr, dg):
+            loss = loss + torch.mean(torch.abs(rl.detach() - gl))
+    return loss * 2
+
+
+def discriminator_loss(dr_list, dg_list):
+    loss = 0
+    for dr, dg in zip(dr_list, dg_list):
+        loss = loss + torch.mean((1 - dr) ** 2) + torch.mean(dg ** 2)
+    return loss
+
+
+def generator_loss(dg_list):
+    loss = 0
+    for dg in dg_list:
+        loss = loss + torch.mean((1 - dg) ** 2)
+    return loss
+
+
+def kl_loss(z_p, logs_q, m_p, logs_p, z_mask):
+    kl = logs_p - logs_q - 0.5
+    kl = kl + 0.5 * ((z_p - m_p) ** 2) * torch.exp(-2.0 * logs_p)
+    return torch.sum(kl * z_mask) / torch.sum(z_mask)

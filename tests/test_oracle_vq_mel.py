@@ -98,3 +98,37 @@ def test_generator_restatement(golden_dir):
     for k in g.files:
         if k.startswith("grad:"):
             np.testing.assert_allclose(sd[k[5:]].grad.numpy(), g[k], rtol=1e-4, atol=1e-6, err_msg=k)
+
+
+def _mpd_state_dict():
+    """Reference key/shape list (surface.json, G0) filled with oracle.vqvae_ref.det_fill."""
+    import json
+    from oracle import vqvae_ref
+    surf = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "surface.json")))
+    return {k: vqvae_ref.det_fill(k, s) for k, s, *_ in surf["vqvae_d"]}
+
+
+def test_discriminators_and_losses_restatement(golden_dir):
+    """oracle/vqvae_ref.py (DiscriminatorS/P, MPD, losses) vs the reference-generated fixture vqvae_disc.npz."""
+    from oracle import vqvae_ref
+    g = np.load(os.path.join(golden_dir, "vqvae_disc.npz"))
+    sd = {k: v.requires_grad_(True) for k, v in _mpd_state_dict().items()}
+    y = torch.from_numpy(g["y"]); y_hat = torch.from_numpy(g["y_hat"]).requires_grad_(True)
+    dr, dg, _, _ = vqvae_ref.mpd_forward(sd, y, y_hat.detach())
+    loss_d = vqvae_ref.discriminator_loss(dr, dg)
+    np.testing.assert_allclose(loss_d.item(), g["loss_disc"], rtol=1e-5)
+    for i in range(6):
+        np.testing.assert_allclose(dr[i].detach().numpy(), g[f"logit_r{i}"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(dg[i].detach().numpy(), g[f"logit_g{i}"], rtol=1e-4, atol=1e-5)
+    loss_d.backward()
+    np.testing.assert_allclose([v.grad.abs().sum().item() for v in sd.values()], g["d_grad_abs_sum"], rtol=2e-4)
+    dr, dg, fr, fg = vqvae_ref.mpd_forward(sd, y, y_hat)
+    lfm, lgen = vqvae_ref.feature_loss(fr, fg), vqvae_ref.generator_loss(dg)
+    np.testing.assert_allclose([lfm.item(), lgen.item()], [g["loss_fm"], g["loss_gen"]], rtol=1e-5)
+    (lfm + lgen).backward()
+    np.testing.assert_allclose(y_hat.grad.numpy(), g["dy_hat"], rtol=1e-3, atol=1e-6)
+    zs = [torch.from_numpy(a).requires_grad_(True) for a in g["kl_in"]]
+    kl = vqvae_ref.kl_loss(*zs, torch.from_numpy(g["kl_mask"]))
+    np.testing.assert_allclose(kl.item(), g["kl"], rtol=1e-6)
+    kl.backward()
+    np.testing.assert_allclose(np.stack([z.grad.numpy() for z in zs]), g["kl_grads"], rtol=1e-5, atol=1e-7)

@@ -280,8 +280,54 @@ def gen_vqvae():
     print("G5 generator:", y.shape, "params", sum(p.numel() for p in gen.parameters()), "keys", len(gen.state_dict()))
 
 
+def gen_disc():
+    """G5b/G7: the reference MultiPeriodDiscriminator + losses.py on a 2 x 4100-sample pair (4100 is not a multiple of
+    any period: exercises the reflect pad).  Weights: oracle.vqvae_ref.det_fill (not stored)."""
+    import ttts.vqvae.vq2 as vq2
+    import ttts.vqvae.losses as L
+    from oracle import vqvae_ref
+    torch.manual_seed(0)
+    mpd = vq2.MultiPeriodDiscriminator()
+    with torch.no_grad():
+        for k, p in mpd.named_parameters():
+            p.copy_(vqvae_ref.det_fill(k, p.shape))
+    rng = np.random.default_rng(77)
+    y = torch.from_numpy((rng.standard_normal((2, 1, 4100)) * 0.3).astype(np.float32))
+    y_hat = torch.from_numpy((rng.standard_normal((2, 1, 4100)) * 0.3).astype(np.float32)).requires_grad_(True)
+    rec = {"y": y.numpy(), "y_hat": y_hat.detach().numpy()}
+    # discriminator phase
+    dr, dg, _, _ = mpd(y, y_hat.detach())
+    loss_d, r_l, g_l = L.discriminator_loss(dr, dg)
+    mpd.zero_grad()
+    loss_d.backward()
+    rec["loss_disc"] = loss_d.detach().numpy(); rec["r_losses"] = np.array(r_l, np.float32); rec["g_losses"] = np.array(g_l, np.float32)
+    rec["d_grad_abs_sum"] = np.array([p.grad.abs().sum().item() for _, p in mpd.named_parameters()], np.float64)
+    rec["d_grad_sum"] = np.array([p.grad.sum().item() for _, p in mpd.named_parameters()], np.float64)
+    for i in range(6):
+        rec[f"logit_r{i}"] = dr[i].detach().numpy(); rec[f"logit_g{i}"] = dg[i].detach().numpy()
+    # generator phase
+    mpd.zero_grad()
+    dr, dg, fr, fg = mpd(y, y_hat)
+    loss_fm = L.feature_loss(fr, fg)
+    loss_gen, _ = L.generator_loss(dg)
+    (loss_fm + loss_gen).backward()
+    rec["loss_fm"] = loss_fm.detach().numpy(); rec["loss_gen"] = loss_gen.detach().numpy()
+    rec["dy_hat"] = y_hat.grad.numpy()
+    rec["fmap_abs_mean"] = np.array([[f.abs().mean().item() for f in fl] + [0.0] * (7 - len(fl)) for fl in fg], np.float64)
+    rec["fmap_shapes"] = np.array(json.dumps([[list(f.shape) for f in fl] for fl in fg]))
+    # kl loss (G7)
+    zs = [torch.from_numpy(rng.standard_normal((2, 6, 37)).astype(np.float32)).requires_grad_(True) for _ in range(4)]
+    mask = torch.ones(2, 1, 37); mask[1, :, 25:] = 0
+    kl = L.kl_loss(zs[0], zs[1], zs[2], zs[3], mask)
+    kl.backward()
+    rec["kl_in"] = np.stack([z.detach().numpy() for z in zs]); rec["kl_mask"] = mask.numpy(); rec["kl"] = kl.detach().numpy()
+    rec["kl_grads"] = np.stack([z.grad.numpy() for z in zs])
+    np.savez_compressed(os.path.join(OUT, "vqvae_disc.npz"), **rec)
+    print("G5b disc:", float(loss_d), float(loss_fm), float(loss_gen), float(kl))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gpt", "vq", "mel", "vqvae"]
+    which = sys.argv[1:] or ["gpt", "vq", "mel", "vqvae", "disc"]
     with torch.no_grad() if False else torch.enable_grad():
         if "gpt" in which:
             gen_gpt()
@@ -291,4 +337,6 @@ if __name__ == "__main__":
             gen_mel()
         if "vqvae" in which:
             gen_vqvae()
+        if "disc" in which:
+            gen_disc()
     print("fixtures:", {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT))})

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(CSRC, "build")
 SO_PATH = os.path.join(HERE, "libttts_hip.so")
-SOURCES = ["lib.hip", "elementwise.hip", "gemm.hip", "attn.hip", "vq.hip", "stft.hip", "conv.hip"]
+SOURCES = ["lib.hip", "elementwise.hip", "gemm.hip", "attn.hip", "vq.hip", "stft.hip", "conv.hip", "losses.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-Wall", "-Wno-unused-variable"]
 
@@ -122,6 +122,11 @@ SIGNATURES = {
     "ttts_weight_norm_bwd_f32": (_I32, [_P, _P, _P, _P, _P, _P, _I32, _I32, _P]),
     "ttts_tanh_bwd_f32": (_I32, [_P, _P, _P, _I64, _P]),
     "ttts_add4_scale_f32": (_I32, [_P, _P, _P, _P, _F, _P, _I64, _P]),
+    "ttts_loss_workspace_bytes": (_I64, []),
+    "ttts_reduce_loss_f32": (_I32, [_P, _P, _I64, _I32, _F, _P, _I32, _P, _P]),
+    "ttts_reduce_loss_bwd_f32": (_I32, [_P, _P, _I64, _I32, _F, _P, _P, _I32, _P]),
+    "ttts_kl_loss_fwd_f32": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P]),
+    "ttts_kl_loss_bwd_f32": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
     "ttts_probe_mfma_layout": (_I32, [_P, _P, _P]),
     "ttts_debug_set_flags": (_I32, [_I32]),
 }

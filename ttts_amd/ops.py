@@ -395,6 +395,55 @@ def add_scale(tensors, scale=1.0):
     return y
 
 
+RED_ABSDIFF, RED_SQ_ONE_MINUS, RED_SQ = 0, 1, 2
+_loss_ws = {}
+
+
+def _loss_workspace(device):
+    key = (str(device), torch.cuda.current_stream().cuda_stream)
+    if key not in _loss_ws:
+        _loss_ws[key] = torch.empty(_l.get().ttts_loss_workspace_bytes(), dtype=torch.uint8, device=device)
+    return _loss_ws[key]
+
+
+def reduce_loss(a, b, mode, scale, out=None, accumulate=False):
+    """out[0] = [out[0] +] scale * sum term(a, b) (device scalar, fp32 [1]); a, b contiguous fp32."""
+    _req(a, torch.float32, "a"); _req(b, torch.float32, "b")
+    assert a.is_contiguous() and (b is None or (b.is_contiguous() and b.numel() == a.numel()))
+    if out is None:
+        out = torch.empty(1, dtype=torch.float32, device=a.device)
+    check(_l.get().ttts_reduce_loss_f32(_p(a), _p(b), a.numel(), mode, scale, _p(out), int(accumulate),
+                                        _p(_loss_workspace(a.device)), _stream()), "reduce_loss")
+    return out
+
+
+def reduce_loss_bwd(a, b, mode, scale, gout, out=None, accumulate=False):
+    d = out if out is not None else torch.empty_like(a)
+    check(_l.get().ttts_reduce_loss_bwd_f32(_p(a), _p(b), a.numel(), mode, scale, _p(gout), _p(d), int(accumulate), _stream()),
+          "reduce_loss_bwd")
+    return d
+
+
+def kl_loss_fwd(z_p, logs_q, m_p, logs_p, mask):
+    ts = [t.contiguous() for t in (z_p, logs_q, m_p, logs_p, mask)]
+    for t in ts:
+        _req(t, torch.float32, "kl_loss input")
+    B, C, T = ts[0].shape
+    out = torch.empty(2, dtype=torch.float32, device=ts[0].device)
+    check(_l.get().ttts_kl_loss_fwd_f32(*[_p(t) for t in ts], B, C, T, _p(out), _p(_loss_workspace(out.device)), _stream()),
+          "kl_loss_fwd")
+    return out
+
+
+def kl_loss_bwd(z_p, logs_q, m_p, logs_p, mask, out, gout):
+    ts = [t.contiguous() for t in (z_p, logs_q, m_p, logs_p, mask)]
+    B, C, T = ts[0].shape
+    ds = [torch.empty_like(ts[0]) for _ in range(4)]
+    check(_l.get().ttts_kl_loss_bwd_f32(*[_p(t) for t in ts], _p(out), _p(gout), B, C, T, *[_p(d) for d in ds], _stream()),
+          "kl_loss_bwd")
+    return ds
+
+
 _dropout_counters = {}
 
 

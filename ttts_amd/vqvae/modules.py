@@ -145,7 +145,7 @@ class _ConvBase(nn.Module):
     def apply_weight_norm(self, style):
         """style 'old': torch.nn.utils.weight_norm (weight_g, weight_v); 'new': parametrizations.weight_norm."""
         w = self.weight.detach()
-        g = w.flatten(1).norm(dim=1).view(-1, 1, 1).clone()
+        g = w.flatten(1).norm(dim=1).view(-1, *([1] * (w.dim() - 1))).clone()
         del self.weight
         if style == "old":
             self.weight_g = nn.Parameter(g)
@@ -182,6 +182,22 @@ class Conv1d(_ConvBase):
     def forward(self, x, in_slope=1.0, resid=None, bbias=None, out_act=None, out_slope=LRELU_SLOPE):
         return _Conv1dFn.apply(x, self.effective_weight(), self.bias, resid, bbias, self.stride, self.padding, self.dilation,
                                float(in_slope), out_act, self.groups, float(out_slope))
+
+
+class Conv2dK1(_ConvBase):
+    """nn.Conv2d(in, out, (k, 1), (stride, 1), padding=(pad, 0)) -- the only Conv2d shape on the path (DiscriminatorP,
+    vq2.py:425-472).  Parameters keep the 4-D reference shapes ((out, in, k, 1), weight_g (out, 1, 1, 1)); the module
+    computes on (B*W, C, H) tensors, i.e. as a 1-D convolution along H with the period axis folded into the batch."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, kernel_size
+        self.stride, self.padding = stride, padding
+        self._init_params((out_channels, in_channels, kernel_size, 1), in_channels * kernel_size, out_channels, bias)
+
+    def forward(self, x, in_slope=1.0, out_act=None, out_slope=LRELU_SLOPE):
+        return _Conv1dFn.apply(x, self.effective_weight().squeeze(-1), self.bias, None, None, self.stride, self.padding, 1,
+                               float(in_slope), out_act, 1, float(out_slope))
 
 
 class ConvTranspose1d(_ConvBase):

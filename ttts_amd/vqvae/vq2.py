@@ -1,0 +1,92 @@
+"""VQ-VAE-GAN model classes on the HIP kernels, mirroring ttts/vqvae/vq2.py (constructor arguments, forward signatures,
+return structure and state-dict keys).
+
+Built so far: `Generator` (:341-415, in modules.py), `DiscriminatorP` (:418-494), `DiscriminatorS` (:497-524),
+`MultiPeriodDiscriminator` (:527-551).
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .modules import LRELU_SLOPE, Conv1d, Conv2dK1, Generator, get_padding  # noqa: F401
+
+
+def _no_spectral_norm(flag):
+    if flag:
+        raise NotImplementedError("use_spectral_norm=True is not on the training path (vqvae/config.json: false)")
+
+
+class DiscriminatorP(nn.Module):
+    """Period discriminator: the waveform folded to (T/p, p) and convolved along T/p with (5,1) kernels.  The period axis
+    is folded into the batch, so every layer is a dense 1-D convolution on contiguous rows; feature maps are handed out
+    as (B, C, H, W) views of that storage (no copies)."""
+
+    def __init__(self, period, kernel_size=5, stride=3, use_spectral_norm=False):
+        super().__init__()
+        _no_spectral_norm(use_spectral_norm)
+        self.period = period
+        chans = [1, 32, 128, 512, 1024, 1024]
+        self.convs = nn.ModuleList([
+            Conv2dK1(chans[i], chans[i + 1], kernel_size, stride if i < 4 else 1,
+                     padding=get_padding(kernel_size, 1)).apply_weight_norm("old") for i in range(5)])
+        self.conv_post = Conv2dK1(1024, 1, 3, 1, padding=1).apply_weight_norm("old")
+
+    def forward(self, x):
+        fmap = []
+        b, c, t = x.shape
+        p = self.period
+        if t % p != 0:
+            n_pad = p - (t % p)
+            x = F.pad(x, (0, n_pad), "reflect")
+            t = t + n_pad
+        x = x.view(b, t // p, p).permute(0, 2, 1).reshape(b * p, 1, t // p)        # (B*W, 1, H)
+
+        def nchw(h):
+            return h.view(b, p, h.shape[1], h.shape[2]).permute(0, 2, 3, 1)          # (B, C, H, W) view
+
+        for l in self.convs:
+            x = l(x, out_act="lrelu", out_slope=LRELU_SLOPE)
+            fmap.append(nchw(x))
+        x = self.conv_post(x)
+        fmap.append(nchw(x))
+        return torch.flatten(fmap[-1], 1, -1), fmap
+
+
+class DiscriminatorS(nn.Module):
+    def __init__(self, use_spectral_norm=False):
+        super().__init__()
+        _no_spectral_norm(use_spectral_norm)
+        spec = [(1, 16, 15, 1, 1, 7), (16, 64, 41, 4, 4, 20), (64, 256, 41, 4, 16, 20), (256, 1024, 41, 4, 64, 20),
+                (1024, 1024, 41, 4, 256, 20), (1024, 1024, 5, 1, 1, 2)]
+        self.convs = nn.ModuleList([Conv1d(ci, co, k, s, padding=pd, groups=g).apply_weight_norm("old")
+                                    for ci, co, k, s, g, pd in spec])
+        self.conv_post = Conv1d(1024, 1, 3, 1, padding=1).apply_weight_norm("old")
+
+    def forward(self, x):
+        fmap = []
+        for l in self.convs:
+            x = l(x, out_act="lrelu", out_slope=LRELU_SLOPE)
+            fmap.append(x)
+        x = self.conv_post(x)
+        fmap.append(x)
+        return torch.flatten(x, 1, -1), fmap
+
+
+class MultiPeriodDiscriminator(nn.Module):
+    def __init__(self, use_spectral_norm=False):
+        super().__init__()
+        periods = [2, 3, 5, 7, 11]
+        discs = [DiscriminatorS(use_spectral_norm=use_spectral_norm)]
+        discs = discs + [DiscriminatorP(i, use_spectral_norm=use_spectral_norm) for i in periods]
+        self.discriminators = nn.ModuleList(discs)
+
+    def forward(self, y, y_hat):
+        y_d_rs, y_d_gs, fmap_rs, fmap_gs = [], [], [], []
+        for d in self.discriminators:
+            y_d_r, fmap_r = d(y)
+            y_d_g, fmap_g = d(y_hat)
+            y_d_rs.append(y_d_r)
+            y_d_gs.append(y_d_g)
+            fmap_rs.append(fmap_r)
+            fmap_gs.append(fmap_g)
+        return y_d_rs, y_d_gs, fmap_rs, fmap_gs
