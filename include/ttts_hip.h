@@ -229,21 +229,21 @@ int ttts_stft_mag_bwd_f32(const float* wav, const float* window, const float* tw
  * Replaces: nn.Conv1d (incl. groups) / Conv2d with (k,1) kernels / ConvTranspose1d / weight_norm + the leaky-relu, bias, residual-add and tanh around them in
  * ResBlock1 (ttts/vqvae/modules.py:224-318), Generator (ttts/vqvae/vq2.py:341-415), PosteriorAudioEncoder (:667-745),
  * WN (modules.py:136-221), and their autograd.  w: [Cout, Cin, K].
- * fwd:   y = [y +] out_scale * act_out(lrelu'(gate) * (bias[co] + bbias[b][co] + conv(lrelu(x, in_slope), w)) + resid)
+ * fwd:   y = [y +] out_scale * omask[b][l] * act_out(lrelu'(gate) * (bias[co] + bbias[b][co] + conv(lrelu(x, in_slope), w)) + resid)
  *        Lout = (Lin + 2 pad - dil (K-1) - 1)/stride + 1;  lrelu'(gate) = gate > 0 ? 1 : gate_slope (gate NULL: 1);
- *        out_act: 0 none, 1 tanh, 2 leaky-relu(out_slope).  Cin/Cout are TOTAL channel counts; w: [Cout, Cin/groups, K].
- * dgrad: dx = [dx +] out_scale * (lrelu'(gate) * (bias[ci] + conv^T(lrelu(dy, in_slope), w)) + resid) -- with a
+ *        out_act: 0 none, 1 tanh, 2 leaky-relu(out_slope); omask [B, L] (sequence mask) or NULL.  Cin/Cout are TOTAL channel counts; w: [Cout, Cin/groups, K].
+ * dgrad: dx = [dx +] out_scale * omask[b][l] * (lrelu'(gate) * (bias[ci] + conv^T(lrelu(dy, in_slope), w)) + resid) -- with a
  *        ConvTranspose1d weight [Cin_t, Cout_t, K] passed as w (Cout := Cin_t, Cin := Cout_t, Lin := output length) this
  *        IS the transposed convolution's forward (and fwd is its data gradient); stride > 1 requires dil == 1.
  * wgrad: dw += sum_{b,l} lrelu(dy, dy_slope) * lrelu(x, x_slope) (shifted).   bias_grad: db[c] += sum_{b,l} dy.
  * weight_norm (dim 0): w[r] = g[r] v[r] / ||v[r]||, norm[r] saved; bwd accumulates dv, dg. */
 int ttts_conv1d_fwd_f32(const float* x, const float* w, const float* bias, const float* bbias, const float* resid,
-                        const float* gate, float* y, int32_t B, int32_t Cin, int32_t Lin, int32_t Cout, int32_t Lout,
+                        const float* gate, const float* omask, float* y, int32_t B, int32_t Cin, int32_t Lin, int32_t Cout, int32_t Lout,
                         int32_t K, int32_t stride, int32_t pad, int32_t dil, int32_t groups, float in_slope,
                         float gate_slope, int32_t out_act, float out_slope, float out_scale, int32_t accumulate,
                         void* stream);
 int ttts_conv1d_dgrad_f32(const float* dy, const float* w, const float* bias, const float* resid,
-                          const float* gate, float* dx, int32_t B, int32_t Cin, int32_t Lin, int32_t Cout,
+                          const float* gate, const float* omask, float* dx, int32_t B, int32_t Cin, int32_t Lin, int32_t Cout,
                           int32_t Lout, int32_t K, int32_t stride, int32_t pad, int32_t dil, int32_t groups,
                           float in_slope, float gate_slope, float out_scale, int32_t accumulate, void* stream);
 int ttts_conv1d_wgrad_f32(const float* dy, const float* x, float* dw, int32_t B, int32_t Cin, int32_t Lin,
@@ -260,6 +260,42 @@ int ttts_lrelu_bwd_f32(const float* dy, const float* y, float* dx, float slope, 
  * gradient (a = dy, scale = 1/num_kernels).  Pointers 16-byte aligned. */
 int ttts_add4_scale_f32(const float* a, const float* b, const float* c, const float* d, float scale, float* y,
                         int64_t n, void* stream);
+
+/* ---- elementwise / small kernels of the VQ-VAE-GAN generator stacks (fp32, (B, C, T)) ---------------------------
+ * gate: x [B,2H,T] -> y [B,H,T]; kind 0 = tanh(a) sigmoid(b) (commons.fused_add_tanh_sigmoid_multiply,
+ *       ttts/utils/commons.py:103-109; the add is the conv's bbias), kind 1 = a sigmoid(b) (GLU, modules.py Conv1dGLU).
+ * mul_mask: y = x * mask[b][t] (x_mask multiplies of vq2.py / modules.py).
+ * gauss_sample: stats [B,2C,T] = (m | logs); z = (m + eps exp(logs)) mask (vq2.py:742-744); bwd writes dstats.
+ * upsample2: F.interpolate(scale 2, nearest) (vq2.py:853-855); n = number of INPUT elements.
+ * act: relu / mish;  dropout: keep iff 16 hash bits >= round(p 65536), scaled 1/(1-p); same call on dy = backward.
+ * snake_aa: Activation1d(SnakeBeta(alpha_logscale)) -- kaiser-sinc x2 upsample, x + sin^2(x e^alpha)/(e^beta + 1e-9),
+ *       low-pass x2 downsample (alias_free_torch/act.py:8-28, resample.py, filter.py, activations.py:62-119);
+ *       filters are the modules' 12-tap buffers; bwd accumulates dalpha/dbeta [C].  8 <= T <= 3072.
+ * layernorm_ch: modules.LayerNorm (modules.py:19-31): LayerNorm over C at every (b, t); mean/rstd [B*T] saved. */
+#define TTTS_ACT_RELU 0
+#define TTTS_ACT_MISH 1
+int ttts_gate_fwd_f32(const float* x, float* y, int32_t B, int32_t H, int32_t T, int32_t kind, void* stream);
+int ttts_gate_bwd_f32(const float* dy, const float* x, float* dx, int32_t B, int32_t H, int32_t T, int32_t kind,
+                      void* stream);
+int ttts_mul_mask_f32(const float* x, const float* mask, float* y, int32_t B, int32_t C, int32_t T, void* stream);
+int ttts_gauss_sample_fwd_f32(const float* stats, const float* eps, const float* mask, float* z, int32_t B, int32_t C,
+                              int32_t T, void* stream);
+int ttts_gauss_sample_bwd_f32(const float* dz, const float* stats, const float* eps, const float* mask, float* dstats,
+                              int32_t B, int32_t C, int32_t T, int32_t accumulate, void* stream);
+int ttts_upsample2_fwd_f32(const float* x, float* y, int64_t n, void* stream);
+int ttts_upsample2_bwd_f32(const float* dy, float* dx, int64_t n, void* stream);
+int ttts_act_fwd_f32(const float* x, float* y, int64_t n, int32_t op, void* stream);
+int ttts_act_bwd_f32(const float* dy, const float* x, float* dx, int64_t n, int32_t op, void* stream);
+int ttts_dropout_f32(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
+int ttts_snake_aa_fwd_f32(const float* x, const float* alpha, const float* beta, const float* up_filter,
+                          const float* down_filter, float* y, int32_t B, int32_t C, int32_t T, void* stream);
+int ttts_snake_aa_bwd_f32(const float* dy, const float* x, const float* alpha, const float* beta,
+                          const float* up_filter, const float* down_filter, float* dx, float* dalpha, float* dbeta,
+                          int32_t B, int32_t C, int32_t T, void* stream);
+int ttts_layernorm_ch_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                              int32_t B, int32_t C, int32_t T, float eps, void* stream);
+int ttts_layernorm_ch_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                              float* dx, float* dgamma, float* dbeta, int32_t B, int32_t C, int32_t T, void* stream);
 
 /* ---- loss reductions of the VQ-VAE-GAN step ---------------------------------------------------------------------
  * Replaces: feature_loss / discriminator_loss / generator_loss / kl_loss (ttts/vqvae/losses.py:7-61) and

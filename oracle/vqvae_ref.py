@@ -156,3 +156,87 @@ def kl_loss(z_p, logs_q, m_p, logs_p, z_mask):
     kl = logs_p - logs_q - 0.5
     kl = kl + 0.5 * ((z_p - m_p) ** 2) * torch.exp(-2.0 * logs_p)
     return torch.sum(kl * z_mask) / torch.sum(z_mask)
+
+
+# ---- WN / coupling flow / anti-aliased SnakeBeta / PosteriorAudioEncoder ---------------------------------------------------
+def wn_forward(x, x_mask, sd, pfx, hidden, kernel_size, dilation_rate, n_layers, g=None):
+    """modules.WN.forward (ttts/vqvae/modules.py:187-213), p_dropout = 0."""
+    output = torch.zeros_like(x)
+    if g is not None:
+        g = F.conv1d(g, _weight(sd, pfx + "cond_layer."), sd[pfx + "cond_layer.bias"])
+    for i in range(n_layers):
+        dil = dilation_rate ** i
+        pad = int((kernel_size * dil - dil) / 2)
+        x_in = F.conv1d(x, _weight(sd, f"{pfx}in_layers.{i}."), sd[f"{pfx}in_layers.{i}.bias"], dilation=dil, padding=pad)
+        if g is not None:
+            x_in = x_in + g[:, i * 2 * hidden:(i + 1) * 2 * hidden, :]
+        acts = torch.tanh(x_in[:, :hidden]) * torch.sigmoid(x_in[:, hidden:])
+        rs = F.conv1d(acts, _weight(sd, f"{pfx}res_skip_layers.{i}."), sd[f"{pfx}res_skip_layers.{i}.bias"])
+        if i < n_layers - 1:
+            x = (x + rs[:, :hidden]) * x_mask
+            output = output + rs[:, hidden:]
+        else:
+            output = output + rs
+    return output * x_mask
+
+
+def coupling_block_forward(x, x_mask, sd, pfx, channels, hidden, kernel_size, dilation_rate, n_layers, n_flows, g=None):
+    """ResidualCouplingBlock.forward (vq2.py:245-252) with mean-only layers (modules.py:440-459) and Flip."""
+    half = channels // 2
+    for f in range(n_flows):
+        p = f"{pfx}flows.{2 * f}."
+        x0, x1 = torch.split(x, [half, half], 1)
+        h = F.conv1d(x0, sd[p + "pre.weight"], sd[p + "pre.bias"]) * x_mask
+        h = wn_forward(h, x_mask, sd, p + "enc.", hidden, kernel_size, dilation_rate, n_layers, g)
+        m = F.conv1d(h, sd[p + "post.weight"], sd[p + "post.bias"]) * x_mask
+        x = torch.cat([x0, m + x1 * x_mask], 1)
+        x = torch.flip(x, [1])
+    return x
+
+
+def kaiser_sinc_filter1d(cutoff, half_width, kernel_size):
+    """alias_free_torch/filter.py:28-56."""
+    import math
+    half = kernel_size // 2
+    A = 2.285 * (half - 1) * math.pi * 4 * half_width + 7.95
+    beta = 0.1102 * (A - 8.7) if A > 50.0 else (0.5842 * (A - 21) ** 0.4 + 0.07886 * (A - 21.0) if A >= 21.0 else 0.0)
+    window = torch.kaiser_window(kernel_size, beta=beta, periodic=False)
+    time = (torch.arange(-half, half) + 0.5) if kernel_size % 2 == 0 else torch.arange(kernel_size) - half
+    f = 2 * cutoff * window * torch.sinc(2 * cutoff * time)
+    return (f / f.sum()).view(1, 1, kernel_size)
+
+
+def snake_aa(x, alpha, beta, fup=None, fdn=None):
+    """Activation1d(SnakeBeta(alpha_logscale=True)) with ratio 2, 12 taps (alias_free_torch/act.py, resample.py;
+    activations.py:101-119)."""
+    C = x.shape[1]
+    fup = kaiser_sinc_filter1d(0.25, 0.3, 12) if fup is None else fup
+    fdn = kaiser_sinc_filter1d(0.25, 0.3, 12) if fdn is None else fdn
+    u = F.pad(x, (5, 5), mode="replicate")
+    u = 2 * F.conv_transpose1d(u, fup.expand(C, -1, -1), stride=2, groups=C)[..., 15:-15]
+    a, b = torch.exp(alpha)[None, :, None], torch.exp(beta)[None, :, None]
+    v = u + (1.0 / (b + 1e-9)) * torch.sin(u * a) ** 2
+    v = F.pad(v, (5, 6), mode="replicate")
+    return F.conv1d(v, fdn.expand(C, -1, -1), stride=2, groups=C)
+
+
+def posterior_audio_encoder_forward(sd, pfx, x, x_audio, x_mask, g, noise, out_channels=192, hidden=192):
+    """PosteriorAudioEncoder.forward (vq2.py:714-745) with the randn draw injected."""
+    ks, ss = [16, 16, 8, 2, 2], [10, 8, 2, 2, 2]
+    xa = F.conv1d(x_audio, sd[pfx + "down_pre.weight"], sd[pfx + "down_pre.bias"], padding=3)
+    for i in range(5):
+        xa = F.conv1d(xa, _weight(sd, f"{pfx}downs.{i}."), sd[f"{pfx}downs.{i}.bias"], stride=ss[i], padding=(ks[i] - 1) // 2)
+        xs = None
+        for j, k in enumerate([3, 7, 11]):
+            r = resblock1(xa, sd, f"{pfx}resblocks.{i * 3 + j}.", k, (1, 3, 5))
+            xs = r if xs is None else xs + r
+        xa = xs / 3
+    xa = snake_aa(xa, sd[pfx + "activation_post.act.alpha"], sd[pfx + "activation_post.act.beta"])
+    xa = F.conv1d(xa, sd[pfx + "conv_post.weight"], sd[pfx + "conv_post.bias"], padding=3)
+    h = F.conv1d(x, sd[pfx + "pre.weight"], sd[pfx + "pre.bias"]) * x_mask
+    h = wn_forward(h, x_mask, sd, pfx + "enc.", hidden, 5, 1, 16, g)
+    xa = xa * x_mask
+    stats = F.conv1d(torch.cat([h, xa], 1), sd[pfx + "proj.weight"], sd[pfx + "proj.bias"]) * x_mask
+    m, logs = torch.split(stats, out_channels, dim=1)
+    z = (m + noise * torch.exp(logs)) * x_mask
+    return z, m, logs

@@ -239,3 +239,112 @@ def test_l1_loss_and_layout_agnostic_feature_pairs():
     got = L.l1_loss(av, bv); got.backward()
     np.testing.assert_allclose(got.item(), want.item(), rtol=1e-6)
     _close(bv.grad, br.grad, 1e-6, 0, "dl1")
+
+
+def _load_det(module):
+    from oracle import vqvae_ref
+    sd = {}
+    for k, v in module.state_dict().items():
+        sd[k] = v if k.endswith("filter") else vqvae_ref.det_fill(k, v.shape)
+    module.load_state_dict(sd)
+    return module.to(_dev())
+
+
+def test_wn_coupling_snake_match_reference_fixture(golden_dir):
+    from ttts_amd.vqvae import modules as M
+    from ttts_amd.vqvae.vq2 import ResidualCouplingBlock
+    g = np.load(os.path.join(golden_dir, "vqvae_flow.npz"))
+    D = lambda k: torch.from_numpy(g[k]).to(_dev())
+    # WN(16, 5, dilation_rate 2, 3 layers, gin 8), ragged mask
+    wn = _load_det(M.WN(16, 5, 2, 3, gin_channels=8))
+    x = D("wn_x").requires_grad_(True); gg = D("wn_g").requires_grad_(True)
+    y = wn(x, D("wn_mask"), g=gg)
+    _close(y, torch.from_numpy(g["wn_y"]), 2e-5, 1e-6, "wn y")
+    (y * D("wn_ct")).sum().backward()
+    _close(x.grad, torch.from_numpy(g["wn_dx"]), 1e-4, 1e-6, "wn dx")
+    _close(gg.grad, torch.from_numpy(g["wn_dg"]), 1e-4, 1e-6, "wn dg")
+    for k, p in wn.named_parameters():
+        _close(p.grad, torch.from_numpy(g["wn_grad:" + k]), 2e-4, 1e-6, "wn " + k)
+    # ResidualCouplingBlock(8, 16, 5, 1, 2, n_flows 2, gin 8)
+    fl = _load_det(ResidualCouplingBlock(8, 16, 5, 1, 2, n_flows=2, gin_channels=8))
+    x = D("fl_x").requires_grad_(True); gg = D("fl_g").requires_grad_(True)
+    y = fl(x, D("wn_mask"), g=gg)
+    _close(y, torch.from_numpy(g["fl_y"]), 2e-5, 1e-6, "flow y")
+    (y * D("fl_ct")).sum().backward()
+    _close(x.grad, torch.from_numpy(g["fl_dx"]), 1e-4, 1e-6, "flow dx")
+    _close(gg.grad, torch.from_numpy(g["fl_dg"]), 1e-4, 1e-6, "flow dg")
+    for k, p in fl.named_parameters():
+        _close(p.grad, torch.from_numpy(g["fl_grad:" + k]), 2e-4, 1e-6, "flow " + k)
+    # Activation1d(SnakeBeta(6)), T = 40
+    act = M.Activation1d(M.SnakeBeta(6))
+    np.testing.assert_allclose(act.upsample.filter.numpy(), g["aa_fup"], rtol=1e-6)
+    np.testing.assert_allclose(act.downsample.lowpass.filter.numpy(), g["aa_fdn"], rtol=1e-6)
+    act = act.to(_dev())
+    with torch.no_grad():
+        act.act.alpha.copy_(D("aa_alpha")); act.act.beta.copy_(D("aa_beta"))
+    x = D("aa_x").requires_grad_(True)
+    y = act(x)
+    _close(y, torch.from_numpy(g["aa_y"]), 1e-5, 1e-6, "snake y")
+    (y * D("aa_ct")).sum().backward()
+    _close(x.grad, torch.from_numpy(g["aa_dx"]), 5e-5, 1e-6, "snake dx")
+    _close(act.act.alpha.grad, torch.from_numpy(g["aa_dalpha"]), 1e-4, 1e-6, "snake dalpha")
+    _close(act.act.beta.grad, torch.from_numpy(g["aa_dbeta"]), 1e-4, 1e-6, "snake dbeta")
+
+
+def test_posterior_audio_encoder_matches_reference_fixture(golden_dir):
+    from ttts_amd.vqvae.vq2 import PosteriorAudioEncoder
+    g = np.load(os.path.join(golden_dir, "vqvae_flow.npz"))
+    D = lambda k: torch.from_numpy(g[k]).to(_dev())
+    enc = PosteriorAudioEncoder(20, 192, 192, 5, 1, 16, gin_channels=16)
+    assert [[k, list(v.shape)] for k, v in enc.state_dict().items()] == json.loads(str(g["pe_keys"]))
+    enc = _load_det(enc)
+    spec = D("pe_spec").requires_grad_(True); wav = D("pe_wav").requires_grad_(True); gg = D("pe_g").requires_grad_(True)
+    z, m, logs = enc(spec, wav, D("pe_mask"), g=gg, noise=D("pe_noise"))
+    for a, k in ((z, "pe_z"), (m, "pe_m"), (logs, "pe_logs")):
+        _close(a, torch.from_numpy(g[k]), 1e-4, 1e-5, k)
+    ct = D("pe_ct")
+    ((z * ct).sum() + 0.1 * (m * ct).sum() + 0.1 * logs.sum()).backward()
+    _close(wav.grad, torch.from_numpy(g["pe_dwav"]), 2e-3, 0, "dwav")
+    _close(spec.grad, torch.from_numpy(g["pe_dspec"]), 2e-3, 0, "dspec")
+    _close(gg.grad, torch.from_numpy(g["pe_dg"]), 2e-3, 0, "dg")
+    names = json.loads(str(g["pe_names"]))
+    params = dict(enc.named_parameters())
+    got = np.array([params[k].grad.abs().sum().item() for k in names])
+    np.testing.assert_allclose(got, g["pe_grad_abs_sum"], rtol=2e-3)
+
+
+def test_small_vqvae_ops_vs_torch():
+    """mish / relu / GLU gate / dropout / channel LayerNorm / nearest x2 upsample against torch on the CPU."""
+    from ttts_amd import ops
+    from ttts_amd.vqvae import modules as M
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(3, 10, 77, generator=g) * 2
+    xd = x.to(_dev())
+    _close(ops.act_fwd(xd, ops.ACT_MISH), F.mish(x), 1e-6, 1e-6, "mish")
+    _close(ops.act_fwd(xd, ops.ACT_RELU), F.relu(x), 0, 0, "relu")
+    xr = x.clone().requires_grad_(True); F.mish(xr).sum().backward()
+    _close(ops.act_bwd(torch.ones_like(xd), xd, ops.ACT_MISH), xr.grad, 1e-5, 1e-6, "dmish")
+    want = x[:, :5] * torch.sigmoid(x[:, 5:])
+    _close(ops.gate_fwd(xd, ops.GATE_GLU), want, 1e-6, 1e-6, "glu")
+    xr = x.clone().requires_grad_(True); (xr[:, :5] * torch.sigmoid(xr[:, 5:])).sum().backward()
+    _close(ops.gate_bwd(torch.ones(3, 5, 77, device=_dev()), xd, ops.GATE_GLU), xr.grad, 1e-5, 1e-6, "dglu")
+    y = ops.dropout(xd, 0.25, 1234)
+    keep = (y != 0).float().mean().item()
+    assert abs(keep - 0.75) < 0.03
+    nz = y != 0
+    _close(y[nz], xd[nz] / 0.75, 1e-6, 0, "dropout scale")
+    assert torch.equal(ops.dropout(xd, 0.25, 1234), y) and not torch.equal(ops.dropout(xd, 0.25, 1235), y)
+    gam = torch.rand(10, generator=g) + 0.5; bet = torch.randn(10, generator=g)
+    xr = x.clone().requires_grad_(True); gr = gam.clone().requires_grad_(True); br = bet.clone().requires_grad_(True)
+    yr = F.layer_norm(xr.transpose(1, -1), (10,), gr, br, 1e-5).transpose(1, -1)
+    ct = torch.randn(3, 10, 77, generator=g)
+    (yr * ct).sum().backward()
+    yd, mean, rstd = ops.layernorm_ch_fwd(xd, gam.to(_dev()), bet.to(_dev()))
+    _close(yd, yr, 1e-5, 1e-6, "ln_ch")
+    dx, dg, db = ops.layernorm_ch_bwd(ct.to(_dev()), xd, gam.to(_dev()), mean, rstd)
+    _close(dx, xr.grad, 1e-4, 1e-6, "ln_ch dx"); _close(dg, gr.grad, 1e-4, 1e-6, "ln_ch dg"); _close(db, br.grad, 1e-4, 1e-6, "ln_ch db")
+    up = M.upsample_nearest2(xd.requires_grad_(True))
+    assert torch.equal(up.cpu(), F.interpolate(x, size=154, mode="nearest"))
+    (up * torch.arange(154, device=_dev())).sum().backward()
+    want = (torch.arange(77) * 4 + 1).float().expand(3, 10, 77)
+    assert torch.equal(xd.grad.cpu(), want)

@@ -132,3 +132,61 @@ def test_discriminators_and_losses_restatement(golden_dir):
     np.testing.assert_allclose(kl.item(), g["kl"], rtol=1e-6)
     kl.backward()
     np.testing.assert_allclose(np.stack([z.grad.numpy() for z in zs]), g["kl_grads"], rtol=1e-5, atol=1e-7)
+
+
+def _flow_fixture(golden_dir):
+    return np.load(os.path.join(golden_dir, "vqvae_flow.npz"))
+
+
+def _sd_from(module_cls_keys):
+    from oracle import vqvae_ref
+    return {k: vqvae_ref.det_fill(k, s).requires_grad_(True) for k, s in module_cls_keys}
+
+
+def test_wn_flow_snake_posterior_restatement(golden_dir):
+    """oracle/vqvae_ref.py (WN, coupling block, anti-aliased SnakeBeta, PosteriorAudioEncoder) vs vqvae_flow.npz."""
+    import json
+    from oracle import vqvae_ref
+    g = _flow_fixture(golden_dir)
+    T = torch.from_numpy
+    # WN
+    keys = [(k[len("wn_grad:"):], g[k].shape) for k in g.files if k.startswith("wn_grad:")]
+    sd = _sd_from(keys)
+    x = T(g["wn_x"]).requires_grad_(True); gg = T(g["wn_g"]).requires_grad_(True)
+    y = vqvae_ref.wn_forward(x, T(g["wn_mask"]), sd, "", 16, 5, 2, 3, gg)
+    np.testing.assert_allclose(y.detach().numpy(), g["wn_y"], rtol=1e-5, atol=1e-5)
+    (y * T(g["wn_ct"])).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), g["wn_dx"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(gg.grad.numpy(), g["wn_dg"], rtol=1e-4, atol=1e-4)
+    for k, _ in keys:
+        np.testing.assert_allclose(sd[k].grad.numpy(), g["wn_grad:" + k], rtol=1e-4, atol=1e-4, err_msg=k)
+    # coupling block
+    keys = [(k[len("fl_grad:"):], g[k].shape) for k in g.files if k.startswith("fl_grad:")]
+    sd = _sd_from(keys)
+    x = T(g["fl_x"]).requires_grad_(True); gg = T(g["fl_g"]).requires_grad_(True)
+    y = vqvae_ref.coupling_block_forward(x, T(g["wn_mask"]), sd, "", 8, 16, 5, 1, 2, 2, gg)
+    np.testing.assert_allclose(y.detach().numpy(), g["fl_y"], rtol=1e-5, atol=1e-5)
+    (y * T(g["fl_ct"])).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), g["fl_dx"], rtol=1e-4, atol=1e-4)
+    # snake
+    x = T(g["aa_x"]).requires_grad_(True); al = T(g["aa_alpha"]).requires_grad_(True); be = T(g["aa_beta"]).requires_grad_(True)
+    np.testing.assert_allclose(vqvae_ref.kaiser_sinc_filter1d(0.25, 0.3, 12).numpy(), g["aa_fup"], rtol=1e-6)
+    np.testing.assert_allclose(vqvae_ref.kaiser_sinc_filter1d(0.25, 0.3, 12).numpy(), g["aa_fdn"], rtol=1e-6)
+    y = vqvae_ref.snake_aa(x, al, be)
+    np.testing.assert_allclose(y.detach().numpy(), g["aa_y"], rtol=1e-5, atol=1e-6)
+    (y * T(g["aa_ct"])).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), g["aa_dx"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(al.grad.numpy(), g["aa_dalpha"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(be.grad.numpy(), g["aa_dbeta"], rtol=1e-4, atol=1e-5)
+    # posterior audio encoder
+    keys = [(k, s) for k, s in json.loads(str(g["pe_keys"])) if not k.endswith("filter")]
+    sd = _sd_from(keys)
+    spec = T(g["pe_spec"]).requires_grad_(True); wav = T(g["pe_wav"]).requires_grad_(True); gg = T(g["pe_g"]).requires_grad_(True)
+    z, m, logs = vqvae_ref.posterior_audio_encoder_forward(sd, "", spec, wav, T(g["pe_mask"]), gg, T(g["pe_noise"]))
+    for a, k in ((z, "pe_z"), (m, "pe_m"), (logs, "pe_logs")):
+        np.testing.assert_allclose(a.detach().numpy(), g[k], rtol=1e-4, atol=1e-4, err_msg=k)
+    ct = T(g["pe_ct"])
+    ((z * ct).sum() + 0.1 * (m * ct).sum() + 0.1 * logs.sum()).backward()
+    np.testing.assert_allclose(wav.grad.numpy(), g["pe_dwav"], rtol=1e-3, atol=1e-4 * np.abs(g["pe_dwav"]).max())
+    names = json.loads(str(g["pe_names"]))
+    np.testing.assert_allclose([sd[k].grad.abs().sum().item() for k in names], g["pe_grad_abs_sum"], rtol=1e-3)

@@ -326,8 +326,86 @@ def gen_disc():
     print("G5b disc:", float(loss_d), float(loss_fm), float(loss_gen), float(kl))
 
 
+def _fill_det(module, scale_hint=None):
+    from oracle import vqvae_ref
+    with torch.no_grad():
+        for k, p in module.named_parameters():
+            p.copy_(vqvae_ref.det_fill(k, p.shape))
+
+
+def _grads(module):
+    return {("grad:" + k): p.grad.numpy() for k, p in module.named_parameters() if p.grad is not None}
+
+
+def gen_flow():
+    """G5c: reference WN, ResidualCouplingBlock, Activation1d(SnakeBeta), PosteriorAudioEncoder (tiny / short inputs)."""
+    import ttts.vqvae.modules as M
+    import ttts.vqvae.vq2 as vq2
+    from ttts.vqvae import activations
+    from ttts.vqvae.alias_free_torch import Activation1d
+    rng = np.random.default_rng(99)
+    t = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32))
+    rec = {}
+    # WN (dilation_rate 2 exercises the dilated in_layers)
+    wn = M.WN(16, 5, 2, 3, gin_channels=8)
+    _fill_det(wn)
+    x = t(2, 16, 50).requires_grad_(True); g = t(2, 8, 1).requires_grad_(True)
+    mask = torch.ones(2, 1, 50); mask[1, :, 37:] = 0
+    ct = t(2, 16, 50)
+    y = wn(x, mask, g=g)
+    (y * ct).sum().backward()
+    rec.update({"wn_x": x.detach().numpy(), "wn_g": g.detach().numpy(), "wn_mask": mask.numpy(), "wn_ct": ct.numpy(),
+                "wn_y": y.detach().numpy(), "wn_dx": x.grad.numpy(), "wn_dg": g.grad.numpy()})
+    rec.update({"wn_" + k: v for k, v in _grads(wn).items()})
+    # coupling block
+    fl = vq2.ResidualCouplingBlock(8, 16, 5, 1, 2, n_flows=2, gin_channels=8)
+    _fill_det(fl)
+    x = t(2, 8, 50).requires_grad_(True); g = t(2, 8, 1).requires_grad_(True); ct = t(2, 8, 50)
+    y = fl(x, mask, g=g)
+    (y * ct).sum().backward()
+    rec.update({"fl_x": x.detach().numpy(), "fl_g": g.detach().numpy(), "fl_ct": ct.numpy(), "fl_y": y.detach().numpy(),
+                "fl_dx": x.grad.numpy(), "fl_dg": g.grad.numpy()})
+    rec.update({"fl_" + k: v for k, v in _grads(fl).items()})
+    # anti-aliased snake
+    act = Activation1d(activation=activations.SnakeBeta(6, alpha_logscale=True))
+    with torch.no_grad():
+        act.act.alpha.copy_(t(6) * 0.3); act.act.beta.copy_(t(6) * 0.3)
+    x = t(2, 6, 40).requires_grad_(True); ct = t(2, 6, 40)
+    y = act(x)
+    (y * ct).sum().backward()
+    rec.update({"aa_x": x.detach().numpy(), "aa_ct": ct.numpy(), "aa_alpha": act.act.alpha.detach().numpy(),
+                "aa_beta": act.act.beta.detach().numpy(), "aa_y": y.detach().numpy(), "aa_dx": x.grad.numpy(),
+                "aa_dalpha": act.act.alpha.grad.numpy(), "aa_dbeta": act.act.beta.grad.numpy(),
+                "aa_fup": act.upsample.filter.numpy(), "aa_fdn": act.downsample.lowpass.filter.numpy()})
+    # PosteriorAudioEncoder: spec 20 channels, T = 8 frames (wav 5120), gin 16; weights det_fill (not stored)
+    enc = vq2.PosteriorAudioEncoder(20, 192, 192, 5, 1, 16, gin_channels=16)
+    _fill_det(enc)
+    spec = t(2, 20, 8).requires_grad_(True); wav = (t(2, 1, 5120) * 0.3).requires_grad_(True); g = t(2, 16, 1).requires_grad_(True)
+    mask = torch.ones(2, 1, 8); mask[1, :, 6:] = 0
+    noise = t(2, 192, 8)
+    orig = torch.randn_like
+    torch.randn_like = lambda m_, *a, **k: noise
+    try:
+        z, m, logs = enc(spec, wav, mask, g=g)
+    finally:
+        torch.randn_like = orig
+    ctz = t(2, 192, 8)
+    ((z * ctz).sum() + 0.1 * (m * ctz).sum() + 0.1 * logs.sum()).backward()
+    names = [k for k, _ in enc.named_parameters()]
+    rec.update({"pe_spec": spec.detach().numpy(), "pe_wav": wav.detach().numpy(), "pe_g": g.detach().numpy(),
+                "pe_mask": mask.numpy(), "pe_noise": noise.numpy(), "pe_ct": ctz.numpy(), "pe_z": z.detach().numpy(),
+                "pe_m": m.detach().numpy(), "pe_logs": logs.detach().numpy(), "pe_dspec": spec.grad.numpy(),
+                "pe_dwav": wav.grad.numpy(), "pe_dg": g.grad.numpy(),
+                "pe_names": np.array(json.dumps(names)),
+                "pe_grad_abs_sum": np.array([p.grad.abs().sum().item() for _, p in enc.named_parameters()], np.float64),
+                "pe_grad_sum": np.array([p.grad.sum().item() for _, p in enc.named_parameters()], np.float64),
+                "pe_keys": np.array(json.dumps([[k, list(v.shape)] for k, v in enc.state_dict().items()]))})
+    np.savez_compressed(os.path.join(OUT, "vqvae_flow.npz"), **rec)
+    print("G5c flow/wn/aa/posterior:", float(z.abs().mean()), len(names))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gpt", "vq", "mel", "vqvae", "disc"]
+    which = sys.argv[1:] or ["gpt", "vq", "mel", "vqvae", "disc", "flow"]
     with torch.no_grad() if False else torch.enable_grad():
         if "gpt" in which:
             gen_gpt()
@@ -339,4 +417,6 @@ if __name__ == "__main__":
             gen_vqvae()
         if "disc" in which:
             gen_disc()
+        if "flow" in which:
+            gen_flow()
     print("fixtures:", {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT))})

@@ -27,6 +27,7 @@ struct ConvParams {
   const float* bias;  // per output channel of THIS kernel or NULL
   const float* bbias; // fwd: per (batch element, output channel) bias [B, Cout] or NULL (broadcast conditioning)
   const float* resid; // added to the output (same shape) or NULL
+  const float* omask; // [B, L_out]: output multiplied by omask[b][l] (sequence mask x_mask of the VITS stacks) or NULL
   const float* gate;  // output multiplied by lrelu'(gate) = (gate > 0 ? 1 : gate_slope); same shape as the output; or NULL
   float* y;           // fwd: [B, Cout, Lout]                 dgrad: dx [B, Cin, Lin]
   int B, Cin, Lin, Cout, Lout, K, stride, pad, dil;   // Cin, Cout are PER GROUP
@@ -102,6 +103,7 @@ __global__ __launch_bounds__(256) void conv1d_fwd_kernel(ConvParams p) {
       if (p.resid) v += p.resid[o];
       if (p.out_act == 1) v = tanhf(v);
       else if (p.out_act == 2) v = lrelu(v, p.out_slope);
+      if (p.omask) v *= p.omask[(int64_t)b * p.Lout + l];
       v *= p.out_scale;
       p.y[o] = p.accumulate ? p.y[o] + v : v;
     }
@@ -174,6 +176,7 @@ __global__ __launch_bounds__(256) void conv1d_dgrad_kernel(ConvParams p) {
       float v = acc[i][jj] + bv;
       if (p.gate) v *= (p.gate[o] > 0.f ? 1.f : p.gate_slope);
       if (p.resid) v += p.resid[o];
+      if (p.omask) v *= p.omask[(int64_t)b * p.Lin + j];
       v *= p.out_scale;
       p.y[o] = p.accumulate ? p.y[o] + v : v;
     }
@@ -341,7 +344,7 @@ static int conv_check(int B, int Cin, int Lin, int Cout, int Lout, int K, int st
 }
 
 extern "C" int ttts_conv1d_fwd_f32(const float* x, const float* w, const float* bias, const float* bbias,
-                                   const float* resid, const float* gate, float* y, int32_t B, int32_t Cin, int32_t Lin,
+                                   const float* resid, const float* gate, const float* omask, float* y, int32_t B, int32_t Cin, int32_t Lin,
                                    int32_t Cout, int32_t Lout, int32_t K, int32_t stride, int32_t pad, int32_t dil,
                                    int32_t groups, float in_slope, float gate_slope, int32_t out_act, float out_slope,
                                    float out_scale, int32_t accumulate, void* stream) {
@@ -355,7 +358,7 @@ extern "C" int ttts_conv1d_fwd_f32(const float* x, const float* w, const float* 
   static bool attr = false;
   rc = set_smem_attr(reinterpret_cast<const void*>(conv1d_fwd_kernel), attr);
   if (rc) return rc;
-  ConvParams p{x, w, bias, bbias, resid, gate, y, B, Cin / groups, Lin, Cout / groups, Lout, K, stride, pad, dil, groups,
+  ConvParams p{x, w, bias, bbias, resid, omask, gate, y, B, Cin / groups, Lin, Cout / groups, Lout, K, stride, pad, dil, groups,
                in_slope, gate_slope, out_act, out_slope, out_scale, accumulate};
   dim3 grid((unsigned)cdiv(Lout, CV_LT), (unsigned)cdiv(Cout / groups, CV_CT), (unsigned)(B * groups));
   conv1d_fwd_kernel<<<grid, 256, smem, as_stream(stream)>>>(p);
@@ -363,7 +366,7 @@ extern "C" int ttts_conv1d_fwd_f32(const float* x, const float* w, const float* 
 }
 
 extern "C" int ttts_conv1d_dgrad_f32(const float* dy, const float* w, const float* bias, const float* resid,
-                                     const float* gate, float* dx, int32_t B, int32_t Cin, int32_t Lin, int32_t Cout,
+                                     const float* gate, const float* omask, float* dx, int32_t B, int32_t Cin, int32_t Lin, int32_t Cout,
                                      int32_t Lout, int32_t K, int32_t stride, int32_t pad, int32_t dil, int32_t groups,
                                      float in_slope, float gate_slope, float out_scale, int32_t accumulate,
                                      void* stream) {
@@ -378,7 +381,7 @@ extern "C" int ttts_conv1d_dgrad_f32(const float* dy, const float* w, const floa
   static bool attr = false;
   int rc = set_smem_attr(reinterpret_cast<const void*>(conv1d_dgrad_kernel), attr);
   if (rc) return rc;
-  ConvParams p{dy, w, bias, nullptr, resid, gate, dx, B, Cin / groups, Lin, Cout / groups, Lout, K, stride, pad, dil, groups,
+  ConvParams p{dy, w, bias, nullptr, resid, omask, gate, dx, B, Cin / groups, Lin, Cout / groups, Lout, K, stride, pad, dil, groups,
                in_slope, gate_slope, 0, 1.f, out_scale, accumulate};
   dim3 grid((unsigned)cdiv(Lin, CV_LT), (unsigned)cdiv(Cin / groups, CV_CT), (unsigned)(B * groups));
   conv1d_dgrad_kernel<<<grid, 256, smem, as_stream(stream)>>>(p);

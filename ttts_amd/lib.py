@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(CSRC, "build")
 SO_PATH = os.path.join(HERE, "libttts_hip.so")
-SOURCES = ["lib.hip", "elementwise.hip", "gemm.hip", "attn.hip", "vq.hip", "stft.hip", "conv.hip", "losses.hip"]
+SOURCES = ["lib.hip", "elementwise.hip", "gemm.hip", "attn.hip", "vq.hip", "stft.hip", "conv.hip", "losses.hip", "vqvae_ops.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-Wall", "-Wno-unused-variable"]
 
@@ -110,9 +110,9 @@ SIGNATURES = {
     "ttts_mel_log_fwd_f32": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "ttts_mel_log_bwd_f32": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "ttts_stft_mag_bwd_f32": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
-    "ttts_conv1d_fwd_f32": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32,
+    "ttts_conv1d_fwd_f32": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32,
                                    _F, _F, _I32, _F, _F, _I32, _P]),
-    "ttts_conv1d_dgrad_f32": (_I32, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32,
+    "ttts_conv1d_dgrad_f32": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32,
                                      _F, _F, _F, _I32, _P]),
     "ttts_conv1d_wgrad_f32": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _F, _F,
                                      _P]),
@@ -122,6 +122,20 @@ SIGNATURES = {
     "ttts_weight_norm_bwd_f32": (_I32, [_P, _P, _P, _P, _P, _P, _I32, _I32, _P]),
     "ttts_tanh_bwd_f32": (_I32, [_P, _P, _P, _I64, _P]),
     "ttts_add4_scale_f32": (_I32, [_P, _P, _P, _P, _F, _P, _I64, _P]),
+    "ttts_gate_fwd_f32": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _P]),
+    "ttts_gate_bwd_f32": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "ttts_mul_mask_f32": (_I32, [_P, _P, _P, _I32, _I32, _I32, _P]),
+    "ttts_gauss_sample_fwd_f32": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _P]),
+    "ttts_gauss_sample_bwd_f32": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "ttts_upsample2_fwd_f32": (_I32, [_P, _P, _I64, _P]),
+    "ttts_upsample2_bwd_f32": (_I32, [_P, _P, _I64, _P]),
+    "ttts_act_fwd_f32": (_I32, [_P, _P, _I64, _I32, _P]),
+    "ttts_act_bwd_f32": (_I32, [_P, _P, _P, _I64, _I32, _P]),
+    "ttts_dropout_f32": (_I32, [_P, _P, _I64, _F, _U64, _P]),
+    "ttts_snake_aa_fwd_f32": (_I32, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P]),
+    "ttts_snake_aa_bwd_f32": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P]),
+    "ttts_layernorm_ch_fwd_f32": (_I32, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _F, _P]),
+    "ttts_layernorm_ch_bwd_f32": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P]),
     "ttts_loss_workspace_bytes": (_I64, []),
     "ttts_reduce_loss_f32": (_I32, [_P, _P, _I64, _I32, _F, _P, _I32, _P, _P]),
     "ttts_reduce_loss_bwd_f32": (_I32, [_P, _P, _I64, _I32, _F, _P, _P, _I32, _P]),

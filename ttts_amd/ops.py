@@ -297,7 +297,7 @@ _OUT_ACT = {None: 0, "none": 0, "tanh": 1, "lrelu": 2}
 
 
 def conv1d_fwd(x, w, bias=None, resid=None, stride=1, pad=0, dil=1, in_slope=1.0, out_act=None, out_scale=1.0,
-               out=None, accumulate=False, bbias=None, gate=None, gate_slope=1.0, groups=1, out_slope=1.0):
+               out=None, accumulate=False, bbias=None, gate=None, gate_slope=1.0, groups=1, out_slope=1.0, omask=None):
     """y = [y +] out_scale * act(lrelu'(gate) * (bias + bbias + conv1d(lrelu(x, in_slope), w)) + resid);
     x (B,Cin,L) fp32, w (Cout,Cin/groups,K), bbias (B,Cout); out_act None | 'tanh' | 'lrelu' (slope out_slope).
     Also the data gradient of a ConvTranspose1d (w = its weight)."""
@@ -309,14 +309,14 @@ def conv1d_fwd(x, w, bias=None, resid=None, stride=1, pad=0, dil=1, in_slope=1.0
     Lout = conv_out_len(Lin, K, stride, pad, dil)
     y = out if out is not None else torch.empty(B, Cout, Lout, dtype=torch.float32, device=x.device)
     c = lambda t: t.contiguous() if t is not None else None
-    check(_l.get().ttts_conv1d_fwd_f32(_p(x), _p(w), _p(c(bias)), _p(c(bbias)), _p(c(resid)), _p(c(gate)), _p(y), B, Cin, Lin,
+    check(_l.get().ttts_conv1d_fwd_f32(_p(x), _p(w), _p(c(bias)), _p(c(bbias)), _p(c(resid)), _p(c(gate)), _p(c(omask)), _p(y), B, Cin, Lin,
                                        Cout, Lout, K, stride, pad, dil, groups, in_slope, gate_slope, _OUT_ACT[out_act],
                                        out_slope, out_scale, int(accumulate), _stream()), "conv1d_fwd")
     return y
 
 
 def conv1d_dgrad(dy, w, lin, stride=1, pad=0, dil=1, gate=None, gate_slope=1.0, bias=None, in_slope=1.0, resid=None,
-                 out_scale=1.0, out=None, accumulate=False, groups=1):
+                 out_scale=1.0, out=None, accumulate=False, groups=1, omask=None):
     """dx (B,Cin,lin) of a conv with weight w (Cout,Cin/groups,K) -- or the ConvTranspose1d forward with w = its weight
     (then `in_slope` is the leaky-relu fused on its input and `bias` its bias)."""
     _req(dy, torch.float32, "dy"); _req(w, torch.float32, "w")
@@ -325,7 +325,7 @@ def conv1d_dgrad(dy, w, lin, stride=1, pad=0, dil=1, gate=None, gate_slope=1.0, 
     Cin, K = w.shape[1] * groups, w.shape[2]
     dx = out if out is not None else torch.empty(B, Cin, lin, dtype=torch.float32, device=dy.device)
     c = lambda t: t.contiguous() if t is not None else None
-    check(_l.get().ttts_conv1d_dgrad_f32(_p(dy), _p(w), _p(c(bias)), _p(c(resid)), _p(c(gate)), _p(dx), B, Cin, lin, Cout, Lout,
+    check(_l.get().ttts_conv1d_dgrad_f32(_p(dy), _p(w), _p(c(bias)), _p(c(resid)), _p(c(gate)), _p(c(omask)), _p(dx), B, Cin, lin, Cout, Lout,
                                          K, stride, pad, dil, groups, in_slope, gate_slope, out_scale, int(accumulate),
                                          _stream()), "conv1d_dgrad")
     return dx
@@ -393,6 +393,133 @@ def add_scale(tensors, scale=1.0):
     ptrs = [_p(t) for t in ts] + [None] * (4 - len(ts))
     check(_l.get().ttts_add4_scale_f32(*ptrs, scale, _p(y), y.numel(), _stream()), "add4_scale")
     return y
+
+
+GATE_TANH_SIGMOID, GATE_GLU = 0, 1
+ACT_RELU, ACT_MISH = 0, 1
+
+
+def _f32c(t, name):
+    _req(t, torch.float32, name)
+    return t.contiguous()
+
+
+def gate_fwd(x, kind=GATE_TANH_SIGMOID):
+    x = _f32c(x, "x")
+    B, C2, T = x.shape
+    y = torch.empty(B, C2 // 2, T, dtype=torch.float32, device=x.device)
+    check(_l.get().ttts_gate_fwd_f32(_p(x), _p(y), B, C2 // 2, T, kind, _stream()), "gate_fwd")
+    return y
+
+
+def gate_bwd(dy, x, kind=GATE_TANH_SIGMOID):
+    dy = _f32c(dy, "dy"); x = _f32c(x, "x")
+    B, C2, T = x.shape
+    dx = torch.empty_like(x)
+    check(_l.get().ttts_gate_bwd_f32(_p(dy), _p(x), _p(dx), B, C2 // 2, T, kind, _stream()), "gate_bwd")
+    return dx
+
+
+def mul_mask(x, mask):
+    """x (B,C,T) * mask (B,1,T) or (B,T)."""
+    x = _f32c(x, "x"); mask = _f32c(mask, "mask")
+    B, C, T = x.shape
+    assert mask.numel() == B * T
+    y = torch.empty_like(x)
+    check(_l.get().ttts_mul_mask_f32(_p(x), _p(mask), _p(y), B, C, T, _stream()), "mul_mask")
+    return y
+
+
+def gauss_sample_fwd(stats, eps, mask):
+    stats = _f32c(stats, "stats"); eps = _f32c(eps, "eps")
+    mask = _f32c(mask, "mask") if mask is not None else None
+    B, C2, T = stats.shape
+    z = torch.empty(B, C2 // 2, T, dtype=torch.float32, device=stats.device)
+    check(_l.get().ttts_gauss_sample_fwd_f32(_p(stats), _p(eps), _p(mask), _p(z), B, C2 // 2, T, _stream()), "gauss_sample_fwd")
+    return z
+
+
+def gauss_sample_bwd(dz, stats, eps, mask):
+    dz = _f32c(dz, "dz")
+    B, C2, T = stats.shape
+    dstats = torch.empty_like(stats)
+    check(_l.get().ttts_gauss_sample_bwd_f32(_p(dz), _p(stats), _p(eps), _p(mask), _p(dstats), B, C2 // 2, T, 0, _stream()),
+          "gauss_sample_bwd")
+    return dstats
+
+
+def upsample2_fwd(x):
+    x = _f32c(x, "x")
+    y = torch.empty(*x.shape[:-1], x.shape[-1] * 2, dtype=torch.float32, device=x.device)
+    check(_l.get().ttts_upsample2_fwd_f32(_p(x), _p(y), x.numel(), _stream()), "upsample2_fwd")
+    return y
+
+
+def upsample2_bwd(dy):
+    dy = _f32c(dy, "dy")
+    dx = torch.empty(*dy.shape[:-1], dy.shape[-1] // 2, dtype=torch.float32, device=dy.device)
+    check(_l.get().ttts_upsample2_bwd_f32(_p(dy), _p(dx), dx.numel(), _stream()), "upsample2_bwd")
+    return dx
+
+
+def act_fwd(x, op):
+    x = _f32c(x, "x")
+    y = torch.empty_like(x)
+    check(_l.get().ttts_act_fwd_f32(_p(x), _p(y), x.numel(), op, _stream()), "act_fwd")
+    return y
+
+
+def act_bwd(dy, x, op):
+    dy = _f32c(dy, "dy")
+    dx = torch.empty_like(x)
+    check(_l.get().ttts_act_bwd_f32(_p(dy), _p(x), _p(dx), x.numel(), op, _stream()), "act_bwd")
+    return dx
+
+
+def dropout(x, p, seed):
+    x = _f32c(x, "x")
+    y = torch.empty_like(x)
+    check(_l.get().ttts_dropout_f32(_p(x), _p(y), x.numel(), p, seed, _stream()), "dropout")
+    return y
+
+
+def snake_aa_fwd(x, alpha, beta, fup, fdn):
+    x = _f32c(x, "x")
+    B, C, T = x.shape
+    y = torch.empty_like(x)
+    check(_l.get().ttts_snake_aa_fwd_f32(_p(x), _p(_f32c(alpha, "alpha")), _p(_f32c(beta, "beta")), _p(_f32c(fup, "fup")),
+                                         _p(_f32c(fdn, "fdn")), _p(y), B, C, T, _stream()), "snake_aa_fwd")
+    return y
+
+
+def snake_aa_bwd(dy, x, alpha, beta, fup, fdn):
+    dy = _f32c(dy, "dy")
+    B, C, T = x.shape
+    dx = torch.empty_like(x)
+    da = torch.zeros_like(alpha); db = torch.zeros_like(beta)
+    check(_l.get().ttts_snake_aa_bwd_f32(_p(dy), _p(x), _p(alpha.contiguous()), _p(beta.contiguous()), _p(fup.contiguous()),
+                                         _p(fdn.contiguous()), _p(dx), _p(da), _p(db), B, C, T, _stream()), "snake_aa_bwd")
+    return dx, da, db
+
+
+def layernorm_ch_fwd(x, gamma, beta, eps=1e-5):
+    x = _f32c(x, "x")
+    B, C, T = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(B * T, dtype=torch.float32, device=x.device); rstd = torch.empty_like(mean)
+    check(_l.get().ttts_layernorm_ch_fwd_f32(_p(x), _p(_f32c(gamma, "gamma")), _p(_f32c(beta, "beta")), _p(y), _p(mean), _p(rstd),
+                                             B, C, T, eps, _stream()), "layernorm_ch_fwd")
+    return y, mean, rstd
+
+
+def layernorm_ch_bwd(dy, x, gamma, mean, rstd):
+    dy = _f32c(dy, "dy")
+    B, C, T = x.shape
+    dx = torch.empty_like(x)
+    dg = torch.zeros_like(gamma); db = torch.zeros_like(gamma)
+    check(_l.get().ttts_layernorm_ch_bwd_f32(_p(dy), _p(x), _p(gamma.contiguous()), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db),
+                                             B, C, T, _stream()), "layernorm_ch_bwd")
+    return dx, dg, db
 
 
 RED_ABSDIFF, RED_SQ_ONE_MINUS, RED_SQ = 0, 1, 2

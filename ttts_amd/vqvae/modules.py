@@ -45,19 +45,24 @@ class _Conv1dFn(torch.autograd.Function):
     """y = act(bias + bbias + conv1d(lrelu(x, in_slope), w) + resid);  out_act None | 'tanh' | 'lrelu'."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, resid, bbias, stride, pad, dil, in_slope, out_act, groups=1, out_slope=LRELU_SLOPE):
+    def forward(ctx, x, w, bias, resid, bbias, stride, pad, dil, in_slope, out_act, groups=1, out_slope=LRELU_SLOPE,
+                omask=None):
+        if omask is not None:
+            omask = omask.reshape(x.shape[0], -1).contiguous()
         y = ops.conv1d_fwd(x, w, bias, resid, stride, pad, dil, in_slope, out_act, bbias=bbias, groups=groups,
-                           out_slope=out_slope)
-        ctx.save_for_backward(x, w, y if out_act else None)
+                           out_slope=out_slope, omask=omask)
+        ctx.save_for_backward(x, w, y if out_act else None, omask)
         ctx.cfg = (stride, pad, dil, in_slope, out_act, groups, out_slope, bias is not None, resid is not None,
                    bbias is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, y = ctx.saved_tensors
+        x, w, y, omask = ctx.saved_tensors
         stride, pad, dil, in_slope, out_act, groups, out_slope, has_b, has_r, has_bb = ctx.cfg
         dy = dy.contiguous()
+        if omask is not None:
+            dy = ops.mul_mask(dy, omask)
         if out_act == "tanh":
             dy = ops.tanh_bwd(dy, y)
         elif out_act == "lrelu":
@@ -74,7 +79,7 @@ class _Conv1dFn(torch.autograd.Function):
         if has_bb and need[4]:
             B, C, L = dy.shape
             dbb = ops.conv1d_bias_grad(dy.view(1, B * C, L)).view(B, C)
-        return dx, dw, db, (dy if has_r and need[3] else None), dbb, None, None, None, None, None, None, None
+        return dx, dw, db, (dy if has_r and need[3] else None), dbb, None, None, None, None, None, None, None, None
 
 
 class _ConvTranspose1dFn(torch.autograd.Function):
@@ -170,7 +175,7 @@ class _ConvBase(nn.Module):
 class Conv1d(_ConvBase):
     """nn.Conv1d(in, out, k, stride, padding, dilation, bias) (groups = 1) on the HIP kernels.  `forward` takes the fused
     neighbours: `in_slope` (leaky-relu on the input), `resid` (added to the output), `bbias` (per-sample bias (B, C)),
-    `out_act` ('tanh' | 'lrelu' on the output)."""
+    `out_act` ('tanh' | 'lrelu' on the output), `omask` (sequence mask (B, 1, T) multiplied last)."""
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True):
         super().__init__()
@@ -179,9 +184,9 @@ class Conv1d(_ConvBase):
         self._init_params((out_channels, in_channels // groups, kernel_size), in_channels // groups * kernel_size,
                           out_channels, bias)
 
-    def forward(self, x, in_slope=1.0, resid=None, bbias=None, out_act=None, out_slope=LRELU_SLOPE):
+    def forward(self, x, in_slope=1.0, resid=None, bbias=None, out_act=None, out_slope=LRELU_SLOPE, omask=None):
         return _Conv1dFn.apply(x, self.effective_weight(), self.bias, resid, bbias, self.stride, self.padding, self.dilation,
-                               float(in_slope), out_act, self.groups, float(out_slope))
+                               float(in_slope), out_act, self.groups, float(out_slope), omask)
 
 
 class Conv2dK1(_ConvBase):
@@ -273,3 +278,265 @@ class Generator(nn.Module):
             xs = [self.resblocks[i * self.num_kernels + j](x) for j in range(self.num_kernels)]
             x = add_scale(xs, 1.0 / self.num_kernels)
         return self.conv_post(x, in_slope=0.01, out_act="tanh")   # F.leaky_relu default slope (vq2.py:404)
+
+
+# ---- small fused pieces -------------------------------------------------------------------------------------------------
+class _MulMaskFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mask):
+        ctx.save_for_backward(mask)
+        return ops.mul_mask(x, mask)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        return ops.mul_mask(dy, mask), None
+
+
+def mul_mask(x, mask):
+    """x (B, C, T) * mask (B, 1, T)."""
+    return _MulMaskFn.apply(x, mask)
+
+
+class _GaussSampleFn(torch.autograd.Function):
+    """z = (m + eps * exp(logs)) * mask with stats = (m | logs) stacked on the channel axis."""
+
+    @staticmethod
+    def forward(ctx, stats, eps, mask):
+        ctx.save_for_backward(stats, eps, mask)
+        return ops.gauss_sample_fwd(stats, eps, mask)
+
+    @staticmethod
+    def backward(ctx, dz):
+        stats, eps, mask = ctx.saved_tensors
+        return ops.gauss_sample_bwd(dz, stats, eps, mask), None, None
+
+
+class _Upsample2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return ops.upsample2_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.upsample2_bwd(dy)
+
+
+def upsample_nearest2(x):
+    """F.interpolate(x, size=2*T, mode='nearest') (vq2.py:853-855)."""
+    return _Upsample2Fn.apply(x)
+
+
+class _SnakeAAFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, alpha, beta, fup, fdn):
+        ctx.save_for_backward(x, alpha, beta, fup, fdn)
+        return ops.snake_aa_fwd(x, alpha, beta, fup, fdn)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, alpha, beta, fup, fdn = ctx.saved_tensors
+        dx, da, db = ops.snake_aa_bwd(dy, x, alpha, beta, fup, fdn)
+        return dx, da, db, None, None
+
+
+def kaiser_sinc_filter1d(cutoff, half_width, kernel_size):
+    """Windowed-sinc low-pass prototype of alias_free_torch/filter.py:28-56, shape (1, 1, kernel_size)."""
+    half = kernel_size // 2
+    delta_f = 4 * half_width
+    A = 2.285 * (half - 1) * math.pi * delta_f + 7.95
+    if A > 50.0:
+        beta = 0.1102 * (A - 8.7)
+    elif A >= 21.0:
+        beta = 0.5842 * (A - 21) ** 0.4 + 0.07886 * (A - 21.0)
+    else:
+        beta = 0.0
+    window = torch.kaiser_window(kernel_size, beta=beta, periodic=False)
+    time = (torch.arange(-half, half) + 0.5) if kernel_size % 2 == 0 else (torch.arange(kernel_size) - half)
+    filt = 2 * cutoff * window * torch.sinc(2 * cutoff * time)
+    filt = filt / filt.sum()
+    return filt.view(1, 1, kernel_size)
+
+
+class _FilterHolder(nn.Module):
+    def __init__(self, filt):
+        super().__init__()
+        self.register_buffer("filter", filt)
+
+
+class _DownSampleHolder(nn.Module):
+    def __init__(self, filt):
+        super().__init__()
+        self.lowpass = _FilterHolder(filt)
+
+
+class SnakeBeta(nn.Module):
+    """activations.SnakeBeta(in_features, alpha_logscale=True) parameters (activations.py:62-119)."""
+
+    def __init__(self, in_features, alpha_logscale=True):
+        super().__init__()
+        if not alpha_logscale:
+            raise NotImplementedError("only alpha_logscale=True is on the path (vq2.py:703)")
+        self.alpha = nn.Parameter(torch.zeros(in_features))
+        self.beta = nn.Parameter(torch.zeros(in_features))
+
+
+class Activation1d(nn.Module):
+    """alias_free_torch.Activation1d(SnakeBeta) with ratio 2 / 12-tap filters (act.py:8-28) as one fused kernel.
+    State-dict keys as in the reference: act.alpha, act.beta, upsample.filter, downsample.lowpass.filter."""
+
+    def __init__(self, activation, up_ratio=2, down_ratio=2, up_kernel_size=12, down_kernel_size=12):
+        super().__init__()
+        if (up_ratio, down_ratio, up_kernel_size, down_kernel_size) != (2, 2, 12, 12) or not isinstance(activation, SnakeBeta):
+            raise NotImplementedError("Activation1d: only SnakeBeta with ratio 2 and 12-tap filters is built")
+        self.act = activation
+        self.upsample = _FilterHolder(kaiser_sinc_filter1d(0.5 / up_ratio, 0.6 / up_ratio, up_kernel_size))
+        self.downsample = _DownSampleHolder(kaiser_sinc_filter1d(0.5 / down_ratio, 0.6 / down_ratio, down_kernel_size))
+
+    def forward(self, x):
+        return _SnakeAAFn.apply(x, self.act.alpha, self.act.beta, self.upsample.filter.view(-1),
+                                self.downsample.lowpass.filter.view(-1))
+
+
+# ---- WaveNet stack (modules.WN, ttts/vqvae/modules.py:136-221) as ONE autograd node ------------------------------------
+class _WNFn(torch.autograd.Function):
+    """params = [in_v, in_g, in_b, rs_v, rs_g, rs_b] * n_layers (old-style weight norm tensors).
+    Per layer: x_in = conv_k(x) + g_l ; acts = tanh*sigmoid ; (res | skip) = 1x1(acts) ; x = (x + res) * mask ;
+    out += skip ; finally out * mask.  The mask multiplies, the conditioning add, the residual add and the skip
+    accumulation are epilogues of the convolutions."""
+
+    @staticmethod
+    def forward(ctx, x, mask, gcond, n_layers, K, dil_rate, *params):
+        B, H, T = x.shape
+        m2 = mask.reshape(B, T).contiguous() if mask is not None else None
+        out = torch.empty_like(x)
+        saved, xi = [], x.contiguous()
+        for i in range(n_layers):
+            in_v, in_g, in_b, rs_v, rs_g, rs_b = params[6 * i:6 * i + 6]
+            dil = dil_rate ** i
+            pad = int((K * dil - dil) / 2)
+            w_in, n_in = ops.weight_norm_fwd(in_v, in_g)
+            w_rs, n_rs = ops.weight_norm_fwd(rs_v, rs_g)
+            bb = gcond[:, 2 * H * i:2 * H * (i + 1), 0].contiguous() if gcond is not None else None
+            x_in = ops.conv1d_fwd(xi, w_in, in_b, None, 1, pad, dil, bbias=bb)
+            acts = ops.gate_fwd(x_in, ops.GATE_TANH_SIGMOID)
+            if i < n_layers - 1:
+                x_next = ops.conv1d_fwd(acts, w_rs[:H], rs_b[:H], xi, omask=m2)
+                ops.conv1d_fwd(acts, w_rs[H:], rs_b[H:], omask=m2, out=out, accumulate=i > 0)
+            else:
+                x_next = None
+                ops.conv1d_fwd(acts, w_rs, rs_b, omask=m2, out=out, accumulate=i > 0)
+            saved += [xi, x_in, acts, w_in, n_in, w_rs, n_rs]
+            xi = x_next
+        ctx.save_for_backward(m2, *saved, *params)
+        ctx.cfg = (n_layers, K, dil_rate, gcond is not None, H)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        n_layers, K, dil_rate, has_g, H = ctx.cfg
+        m2 = ctx.saved_tensors[0]
+        saved = ctx.saved_tensors[1:1 + 7 * n_layers]
+        params = ctx.saved_tensors[1 + 7 * n_layers:]
+        dout = dout.contiguous()
+        B, _, T = dout.shape
+        dsk = ops.mul_mask(dout, m2) if m2 is not None else dout
+        dres = None
+        pgrads = [None] * (6 * n_layers)
+        dgs = [None] * n_layers
+        for i in reversed(range(n_layers)):
+            xi, x_in, acts, w_in, n_in, w_rs, n_rs = saved[7 * i:7 * i + 7]
+            in_v, in_g, in_b, rs_v, rs_g, rs_b = params[6 * i:6 * i + 6]
+            dil = dil_rate ** i
+            pad = int((K * dil - dil) / 2)
+            dw_rs = torch.zeros_like(w_rs)
+            if i < n_layers - 1:
+                dacts = ops.conv1d_dgrad(dres, w_rs[:H], T)
+                ops.conv1d_dgrad(dsk, w_rs[H:], T, out=dacts, accumulate=True)
+                ops.conv1d_wgrad(dres, acts, 1, out=dw_rs[:H])
+                ops.conv1d_wgrad(dsk, acts, 1, out=dw_rs[H:])
+                db_rs = torch.cat([ops.conv1d_bias_grad(dres), ops.conv1d_bias_grad(dsk)])
+            else:
+                dacts = ops.conv1d_dgrad(dsk, w_rs, T)
+                ops.conv1d_wgrad(dsk, acts, 1, out=dw_rs)
+                db_rs = ops.conv1d_bias_grad(dsk)
+            dx_in = ops.gate_bwd(dacts, x_in, ops.GATE_TANH_SIGMOID)
+            if has_g:
+                dgs[i] = ops.conv1d_bias_grad(dx_in.view(1, B * 2 * H, T)).view(B, 2 * H)
+            db_in = ops.conv1d_bias_grad(dx_in)
+            dw_in = ops.conv1d_wgrad(dx_in, xi, K, 1, pad, dil)
+            dres = ops.conv1d_dgrad(dx_in, w_in, T, 1, pad, dil, resid=dres, omask=m2 if i > 0 else None)
+            dv_in, dg_in = ops.weight_norm_bwd(dw_in, in_v, in_g, n_in)
+            dv_rs, dg_rs = ops.weight_norm_bwd(dw_rs, rs_v, rs_g, n_rs)
+            pgrads[6 * i:6 * i + 6] = [dv_in, dg_in, db_in, dv_rs, dg_rs, db_rs]
+        dg = torch.cat(dgs, dim=1).unsqueeze(-1) if has_g else None
+        return (dres, None, dg, None, None, None, *pgrads)
+
+
+class WN(nn.Module):
+    """modules.WN(hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels, p_dropout)."""
+
+    def __init__(self, hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels=0, p_dropout=0):
+        super().__init__()
+        assert kernel_size % 2 == 1
+        if p_dropout != 0:
+            raise NotImplementedError("WN dropout is 0 everywhere on the path (vq2.py:708, modules.py:425)")
+        self.hidden_channels, self.kernel_size, self.dilation_rate = hidden_channels, (kernel_size,), dilation_rate
+        self.n_layers, self.gin_channels, self.p_dropout = n_layers, gin_channels, p_dropout
+        self.in_layers = nn.ModuleList()
+        self.res_skip_layers = nn.ModuleList()
+        if gin_channels != 0:
+            self.cond_layer = Conv1d(gin_channels, 2 * hidden_channels * n_layers, 1).apply_weight_norm("old")
+        for i in range(n_layers):
+            dilation = dilation_rate ** i
+            padding = int((kernel_size * dilation - dilation) / 2)
+            self.in_layers.append(Conv1d(hidden_channels, 2 * hidden_channels, kernel_size, dilation=dilation,
+                                         padding=padding).apply_weight_norm("old"))
+            rs = 2 * hidden_channels if i < n_layers - 1 else hidden_channels
+            self.res_skip_layers.append(Conv1d(hidden_channels, rs, 1).apply_weight_norm("old"))
+
+    def forward(self, x, x_mask, g=None, **kwargs):
+        gcond = self.cond_layer(g) if g is not None else None
+        params = []
+        for a, b in zip(self.in_layers, self.res_skip_layers):
+            params += [a.weight_v, a.weight_g, a.bias, b.weight_v, b.weight_g, b.bias]
+        return _WNFn.apply(x, x_mask, gcond, self.n_layers, self.kernel_size[0], self.dilation_rate, *params)
+
+
+class Flip(nn.Module):
+    """modules.Flip (modules.py:377-385)."""
+
+    def forward(self, x, *args, reverse=False, **kwargs):
+        x = torch.flip(x, [1])
+        if not reverse:
+            return x, torch.zeros(x.size(0), dtype=x.dtype, device=x.device)
+        return x
+
+
+class ResidualCouplingLayer(nn.Module):
+    """modules.ResidualCouplingLayer (modules.py:403-459), forward direction; `mean_only=True` on the path."""
+
+    def __init__(self, channels, hidden_channels, kernel_size, dilation_rate, n_layers, p_dropout=0, gin_channels=0,
+                 mean_only=False):
+        assert channels % 2 == 0, "channels should be divisible by 2"
+        super().__init__()
+        if not mean_only:
+            raise NotImplementedError("only mean_only=True coupling layers are on the path (vq2.py:240)")
+        self.channels, self.hidden_channels, self.half_channels = channels, hidden_channels, channels // 2
+        self.mean_only = mean_only
+        self.pre = Conv1d(self.half_channels, hidden_channels, 1)
+        self.enc = WN(hidden_channels, kernel_size, dilation_rate, n_layers, p_dropout=p_dropout, gin_channels=gin_channels)
+        self.post = Conv1d(hidden_channels, self.half_channels, 1)
+        with torch.no_grad():
+            self.post.weight.zero_()
+            self.post.bias.zero_()
+
+    def forward(self, x, x_mask, g=None, reverse=False):
+        if reverse:
+            raise NotImplementedError("reverse flow (inference) is not on the training path")
+        x0, x1 = torch.split(x, [self.half_channels] * 2, 1)
+        h = self.pre(x0.contiguous(), omask=x_mask)
+        h = self.enc(h, x_mask, g=g)
+        x1 = self.post(h, resid=x1.contiguous(), omask=x_mask)      # m + x1 * mask  (logs = 0)
+        x = torch.cat([x0, x1], 1)
+        return x, torch.zeros(x.size(0), dtype=x.dtype, device=x.device)

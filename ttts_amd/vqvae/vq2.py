@@ -2,12 +2,13 @@
 return structure and state-dict keys).
 
 Built so far: `Generator` (:341-415, in modules.py), `DiscriminatorP` (:418-494), `DiscriminatorS` (:497-524),
-`MultiPeriodDiscriminator` (:527-551).
+`MultiPeriodDiscriminator` (:527-551), `ResidualCouplingBlock` (:208-252), `PosteriorAudioEncoder` (:667-745).
 """
 import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import modules
 from .modules import LRELU_SLOPE, Conv1d, Conv2dK1, Generator, get_padding  # noqa: F401
 
 
@@ -90,3 +91,69 @@ class MultiPeriodDiscriminator(nn.Module):
             fmap_rs.append(fmap_r)
             fmap_gs.append(fmap_g)
         return y_d_rs, y_d_gs, fmap_rs, fmap_gs
+
+
+class ResidualCouplingBlock(nn.Module):
+    """vq2.py:208-252: n_flows x (mean-only ResidualCouplingLayer, Flip), forward direction."""
+
+    def __init__(self, channels, hidden_channels, kernel_size, dilation_rate, n_layers, n_flows=4, gin_channels=0):
+        super().__init__()
+        self.channels, self.hidden_channels, self.kernel_size = channels, hidden_channels, kernel_size
+        self.dilation_rate, self.n_layers, self.n_flows, self.gin_channels = dilation_rate, n_layers, n_flows, gin_channels
+        self.flows = nn.ModuleList()
+        for _ in range(n_flows):
+            self.flows.append(modules.ResidualCouplingLayer(channels, hidden_channels, kernel_size, dilation_rate, n_layers,
+                                                            gin_channels=gin_channels, mean_only=True))
+            self.flows.append(modules.Flip())
+
+    def forward(self, x, x_mask, g=None, reverse=False):
+        if reverse:
+            raise NotImplementedError("reverse flow (inference) is not on the training path")
+        for flow in self.flows:
+            x, _ = flow(x, x_mask, g=g, reverse=reverse)
+        return x
+
+
+class PosteriorAudioEncoder(nn.Module):
+    """vq2.py:667-745: waveform down-conv/ResBlock1 stack (x640) + spectrogram WN stack -> (z, m, logs).
+    `noise` (optional, shape of m) replaces the internal randn draw (tests / injected noise)."""
+
+    def __init__(self, in_channels, out_channels, hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels=0):
+        super().__init__()
+        self.in_channels, self.out_channels, self.hidden_channels = in_channels, out_channels, hidden_channels
+        self.kernel_size, self.dilation_rate, self.n_layers, self.gin_channels = kernel_size, dilation_rate, n_layers, gin_channels
+        self.pre = Conv1d(in_channels, hidden_channels, 1)
+        self.down_pre = Conv1d(1, 16, 7, 1, padding=3)
+        self.resblocks = nn.ModuleList()
+        downsample_rates = [10, 8, 2, 2, 2]
+        downsample_kernel_sizes = [16, 16, 8, 2, 2]
+        ch = [16, 32, 64, 96, 128, 192]
+        self.num_kernels = 3
+        self.downs = nn.ModuleList()
+        for i, (u, k) in enumerate(zip(downsample_rates, downsample_kernel_sizes)):
+            self.downs.append(Conv1d(ch[i], ch[i + 1], k, u, padding=(k - 1) // 2).apply_weight_norm("old"))
+        for i in range(5):
+            for k, d in zip([3, 7, 11], [[1, 3, 5]] * 3):
+                self.resblocks.append(modules.ResBlock1(ch[i + 1], k, d))
+        self.activation_post = modules.Activation1d(activation=modules.SnakeBeta(ch[-1], alpha_logscale=True))
+        self.conv_post = Conv1d(ch[-1], hidden_channels, 7, 1, padding=3)
+        self.enc = modules.WN(hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels=gin_channels)
+        self.proj = Conv1d(hidden_channels * 2, out_channels * 2, 1)
+
+    def forward(self, x, x_audio, x_mask, g=None, noise=None):
+        x_audio = self.down_pre(x_audio)
+        for i in range(5):
+            x_audio = self.downs[i](x_audio)
+            xs = [self.resblocks[i * self.num_kernels + j](x_audio) for j in range(self.num_kernels)]
+            x_audio = modules.add_scale(xs, 1.0 / self.num_kernels)
+        x_audio = self.activation_post(x_audio)
+        assert x_audio.shape[-1] == x_mask.shape[-1]
+        x_audio = self.conv_post(x_audio, omask=x_mask)
+        x = self.pre(x, omask=x_mask)
+        x = self.enc(x, x_mask, g=g)
+        stats = self.proj(torch.cat([x, x_audio], dim=1), omask=x_mask)
+        m, logs = torch.split(stats, self.out_channels, dim=1)
+        if noise is None:
+            noise = torch.randn(m.shape, dtype=m.dtype, device=m.device)
+        z = modules._GaussSampleFn.apply(stats, noise, x_mask.reshape(x_mask.shape[0], -1).contiguous())
+        return z, m, logs
