@@ -297,6 +297,38 @@ int ttts_layernorm_ch_fwd_f32(const float* x, const float* gamma, const float* b
 int ttts_layernorm_ch_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                               float* dx, float* dgamma, float* dbeta, int32_t B, int32_t C, int32_t T, void* stream);
 
+/* embedding_ct: nn.Embedding + transpose(1, 2) (vq2.py:156): y[b][c][t] = table[idx[b][t]][c]; bwd accumulates dtable.
+ * masked_mean: MelStyleEncoder.temporal_avg_pool (modules.py:726-734): y[b][c] = sum_t x m / sum_t m (mask NULL: mean). */
+int ttts_embedding_ct_fwd_f32(const int64_t* idx, const float* table, float* y, int32_t B, int32_t C, int32_t T,
+                              void* stream);
+int ttts_embedding_ct_bwd_f32(const int64_t* idx, const float* dy, float* dtable, int32_t B, int32_t C, int32_t T,
+                              void* stream);
+int ttts_masked_mean_fwd_f32(const float* x, const float* mask, float* y, int32_t B, int32_t C, int32_t T, void* stream);
+int ttts_masked_mean_bwd_f32(const float* dy, const float* mask, float* dx, int32_t B, int32_t C, int32_t T, void* stream);
+
+/* ---- fp32 attention pieces of the VQ-VAE text / style encoders ------------------------------------------------------
+ * Replaces: attentions.MultiHeadAttention.attention (ttts/vqvae/attentions.py:239-289, relative window 4), the MRTE
+ * cross-attention (ttts/utils/vc_utils.py:571-627) and ScaledDotProductAttention (ttts/vqvae/modules.py:664-683).
+ * bgemm:  C[z][m][n] = alpha sum_k A[z][m][k] B[z][k][n] + beta C, every operand addressed by element strides
+ *         (s_m, s_k / s_k, s_n / s_m, s_n) and a two-level batch z = (outer, inner) with its own strides -- heads are
+ *         contiguous d_k-row blocks of (B, C, T) tensors, so no transposes are materialised.
+ * attn_softmax_fwd: in place on scores [B,H,Tq,Tk]: add the relative-key logits scale <q_i, Ek[j-i+w]> (|j-i| <= w),
+ *         fill where qmask[b][i] kmask[b][j] == 0, softmax over j.  q [B, H dk, Tq]; emb_rel_k [heads_rel, 2w+1, dk].
+ * attn_softmax_bwd: in place on dP: dS = [mask] P (dP - sum_j dP P).
+ * attn_rel (T = Tq = Tk): mode 0: X[b,h,d,i] += scale sum_r W[i][i+r] E[r+w][d];  mode 1: W[i][i+r] += scale
+ *         sum_d X[b,h,d,i] E[r+w][d];  mode 2: E[r+w][d] += scale sum_{b,h,i} W[i][i+r] X[b,h,d,i]. */
+int ttts_bgemm_f32(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int64_t a_sm,
+                   int64_t a_sk, int64_t b_sk, int64_t b_sn, int64_t c_sm, int64_t c_sn, int32_t batch_outer,
+                   int32_t batch_inner, int64_t a_so, int64_t a_si, int64_t b_so, int64_t b_si, int64_t c_so,
+                   int64_t c_si, float alpha, float beta, void* stream);
+int ttts_attn_softmax_fwd_f32(float* scores, const float* q, const float* emb_rel_k, const float* qmask,
+                              const float* kmask, int32_t B, int32_t H, int32_t Tq, int32_t Tk, int32_t dk,
+                              int32_t window, int32_t heads_rel, float scale, float fill, void* stream);
+int ttts_attn_softmax_bwd_f32(float* dP, const float* P, const float* qmask, const float* kmask, int32_t B, int32_t H,
+                              int32_t Tq, int32_t Tk, void* stream);
+int ttts_attn_rel_f32(float* W, float* X, float* E, int32_t B, int32_t H, int32_t T, int32_t dk, int32_t window,
+                      int32_t heads_rel, float scale, int32_t mode, void* stream);
+
 /* ---- loss reductions of the VQ-VAE-GAN step ---------------------------------------------------------------------
  * Replaces: feature_loss / discriminator_loss / generator_loss / kl_loss (ttts/vqvae/losses.py:7-61) and
  * F.l1_loss(y_mel, y_hat_mel) (ttts/vqvae/train.py:389).  Deterministic two-stage sums; results stay on the device.

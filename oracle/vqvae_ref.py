@@ -240,3 +240,117 @@ def posterior_audio_encoder_forward(sd, pfx, x, x_audio, x_mask, g, noise, out_c
     m, logs = torch.split(stats, out_channels, dim=1)
     z = (m + noise * torch.exp(logs)) * x_mask
     return z, m, logs
+
+
+# ---- attention stacks: attentions.Encoder / MultiHeadAttention / FFN, MRTE, TextEncoder, MelStyleEncoder ---------------------
+def _ln_ch(x, sd, pfx, eps=1e-5):
+    return F.layer_norm(x.transpose(1, -1), (x.shape[1],), sd[pfx + "gamma"], sd[pfx + "beta"], eps).transpose(1, -1)
+
+
+def mha_forward(x, c, attn_mask, sd, pfx, n_heads, window):
+    """attentions.MultiHeadAttention.forward / attention (attentions.py:231-289); dropout off.  The relative-position
+    terms are written as explicit diagonals instead of the reference's pad-and-reshape skewing (:320-356)."""
+    import math
+    q = F.conv1d(x, sd[pfx + "conv_q.weight"], sd[pfx + "conv_q.bias"])
+    k = F.conv1d(c, sd[pfx + "conv_k.weight"], sd[pfx + "conv_k.bias"])
+    v = F.conv1d(c, sd[pfx + "conv_v.weight"], sd[pfx + "conv_v.bias"])
+    b, d, t_s = k.shape
+    t_t = q.shape[2]
+    dk = d // n_heads
+    q = q.view(b, n_heads, dk, t_t).transpose(2, 3)
+    k = k.view(b, n_heads, dk, t_s).transpose(2, 3)
+    v = v.view(b, n_heads, dk, t_s).transpose(2, 3)
+    qs = q / math.sqrt(dk)
+    scores = torch.matmul(qs, k.transpose(-2, -1))
+    if window:
+        ek, ev = sd[pfx + "emb_rel_k"], sd[pfx + "emb_rel_v"]          # (1, 2w+1, dk)
+        idx = torch.arange(t_t)
+        rel = idx[None, :] - idx[:, None]                               # j - i
+        inside = (rel.abs() <= window)
+        r = (rel + window).clamp(0, 2 * window)
+        logits = torch.einsum("bhid,hrd->bhir", qs, ek.expand(n_heads, -1, -1) if ek.shape[0] == 1 else ek)
+        scores = scores + torch.gather(logits, 3, r[None, None].expand(b, n_heads, -1, -1)) * inside
+    if attn_mask is not None:
+        scores = scores.masked_fill(attn_mask == 0, -1e4)
+    p = F.softmax(scores, dim=-1)
+    out = torch.matmul(p, v)
+    if window:
+        evh = ev.expand(n_heads, -1, -1) if ev.shape[0] == 1 else ev
+        pw = torch.zeros(b, n_heads, t_t, 2 * window + 1)
+        for rr in range(2 * window + 1):
+            diag = torch.diagonal(p, offset=rr - window, dim1=2, dim2=3)        # p[i, i + rr - w]
+            lo = max(0, window - rr)
+            pw[:, :, lo:lo + diag.shape[-1], rr] = diag
+        out = out + torch.einsum("bhir,hrd->bhid", pw, evh)
+    out = out.transpose(2, 3).contiguous().view(b, d, t_t)
+    return F.conv1d(out, sd[pfx + "conv_o.weight"], sd[pfx + "conv_o.bias"])
+
+
+def ffn_forward(x, x_mask, sd, pfx, kernel_size):
+    pad = ((kernel_size - 1) // 2, kernel_size // 2)
+    x = F.conv1d(F.pad(x * x_mask, pad), sd[pfx + "conv_1.weight"], sd[pfx + "conv_1.bias"])
+    x = torch.relu(x)
+    x = F.conv1d(F.pad(x * x_mask, pad), sd[pfx + "conv_2.weight"], sd[pfx + "conv_2.bias"])
+    return x * x_mask
+
+
+def encoder_forward(x, x_mask, sd, pfx, n_heads, n_layers, kernel_size, window=4):
+    """attentions.Encoder.forward (attentions.py:66-88), dropout off."""
+    attn_mask = x_mask.unsqueeze(2) * x_mask.unsqueeze(-1)
+    x = x * x_mask
+    for i in range(n_layers):
+        y = mha_forward(x, x, attn_mask, sd, f"{pfx}attn_layers.{i}.", n_heads, window)
+        x = _ln_ch(x + y, sd, f"{pfx}norm_layers_1.{i}.")
+        y = ffn_forward(x, x_mask, sd, f"{pfx}ffn_layers.{i}.", kernel_size)
+        x = _ln_ch(x + y, sd, f"{pfx}norm_layers_2.{i}.")
+    return x * x_mask
+
+
+def seq_mask(lengths, max_len):
+    return (torch.arange(max_len)[None, :] < lengths[:, None])
+
+
+def text_encoder_forward(sd, pfx, y, y_lengths, text, text_lengths, ge, n_heads=2, n_layers=6, kernel_size=3, out_channels=192):
+    """TextEncoder.forward (vq2.py:144-164) + MRTE.forward (vq2.py:33-46), dropout off."""
+    y_mask = seq_mask(y_lengths, y.size(2)).unsqueeze(1).to(y.dtype)
+    y = encoder_forward(y * y_mask, y_mask, sd, pfx + "encoder_ssl.", n_heads, n_layers // 2, kernel_size)
+    text_mask = seq_mask(text_lengths, text.size(1)).unsqueeze(1).to(y.dtype)
+    t = F.embedding(text, sd[pfx + "text_embedding.weight"]).transpose(1, 2)
+    t = encoder_forward(t * text_mask, text_mask, sd, pfx + "encoder_text.", n_heads, n_layers, kernel_size)
+    m = pfx + "mrte."
+    attn_mask = text_mask.unsqueeze(2) * y_mask.unsqueeze(-1)
+    ssl_enc = F.conv1d(y * y_mask, sd[m + "c_pre.weight"], sd[m + "c_pre.bias"])
+    text_enc = F.conv1d(t * text_mask, sd[m + "text_pre.weight"], sd[m + "text_pre.bias"])
+    x = mha_forward(ssl_enc * y_mask, text_enc * text_mask, attn_mask, sd, m + "cross_attention.", 4, 0) + ssl_enc + ge
+    y = F.conv1d(x * y_mask, sd[m + "c_post.weight"], sd[m + "c_post.bias"])
+    y = encoder_forward(y * y_mask, y_mask, sd, pfx + "encoder2.", n_heads, n_layers // 2, kernel_size)
+    stats = F.conv1d(y, sd[pfx + "proj.weight"], sd[pfx + "proj.bias"]) * y_mask
+    m_, logs = torch.split(stats, out_channels, dim=1)
+    return y, m_, logs
+
+
+def mel_style_encoder_forward(sd, pfx, x, mask, hidden=128, n_head=2):
+    """MelStyleEncoder.forward (modules.py:736-764), eval mode; x (B, n_mel, T), mask (B, 1, T) 1 = valid."""
+    x = x.transpose(1, 2)
+    pad = (mask.int() == 0).squeeze(1)
+    lin = lambda t, k: F.linear(t, sd[pfx + k + ".weight"], sd[pfx + k + ".bias"])
+    x = F.mish(lin(x, "spectral.0.fc"))
+    x = F.mish(lin(x, "spectral.3.fc"))
+    x = x.transpose(1, 2)
+    for i in range(2):
+        h = F.conv1d(x, sd[f"{pfx}temporal.{i}.conv1.conv.weight"], sd[f"{pfx}temporal.{i}.conv1.conv.bias"], padding=2)
+        x = x + h[:, :hidden] * torch.sigmoid(h[:, hidden:])
+    x = x.transpose(1, 2)
+    x = x.masked_fill(pad.unsqueeze(-1), 0)
+    b, t, _ = x.shape
+    dk = hidden // n_head
+    split = lambda z: z.view(b, t, n_head, dk).permute(2, 0, 1, 3).reshape(-1, t, dk)
+    q, k, v = split(lin(x, "slf_attn.w_qs")), split(lin(x, "slf_attn.w_ks")), split(lin(x, "slf_attn.w_vs"))
+    attn = torch.bmm(q, k.transpose(1, 2)) / (hidden ** 0.5)
+    attn = attn.masked_fill(pad.unsqueeze(1).expand(-1, t, -1).repeat(n_head, 1, 1), -float("inf"))
+    out = torch.bmm(torch.softmax(attn, dim=2), v)
+    out = out.view(n_head, b, t, dk).permute(1, 2, 0, 3).reshape(b, t, -1)
+    x = lin(out, "slf_attn.fc") + x
+    x = lin(x, "fc.fc")
+    x = x.masked_fill(pad.unsqueeze(-1), 0).sum(dim=1) / (~pad).sum(dim=1).unsqueeze(1)
+    return x.unsqueeze(-1)

@@ -190,3 +190,29 @@ def test_wn_flow_snake_posterior_restatement(golden_dir):
     np.testing.assert_allclose(wav.grad.numpy(), g["pe_dwav"], rtol=1e-3, atol=1e-4 * np.abs(g["pe_dwav"]).max())
     names = json.loads(str(g["pe_names"]))
     np.testing.assert_allclose([sd[k].grad.abs().sum().item() for k in names], g["pe_grad_abs_sum"], rtol=1e-3)
+
+
+def test_attention_stacks_restatement(golden_dir):
+    """oracle/vqvae_ref.py (Encoder / rel-pos MHA / FFN / MRTE / TextEncoder / MelStyleEncoder) vs vqvae_attn.npz."""
+    import json
+    from oracle import vqvae_ref
+    g = np.load(os.path.join(golden_dir, "vqvae_attn.npz"))
+    T = torch.from_numpy
+    sd = _sd_from([(k, s) for k, s in json.loads(str(g["te_keys"]))])
+    y = T(g["te_y"]).requires_grad_(True); ge = T(g["te_ge"]).requires_grad_(True)
+    out, m, logs = vqvae_ref.text_encoder_forward(sd, "", y, T(g["te_ylen"]), T(g["te_text"]), T(g["te_tlen"]), ge)
+    for a, k in ((out, "te_out"), (m, "te_m"), (logs, "te_logs")):
+        np.testing.assert_allclose(a.detach().numpy(), g[k], rtol=1e-4, atol=2e-6, err_msg=k)
+    ct = T(g["te_ct"])
+    ((out * ct).sum() + (m * ct).sum() + 0.5 * logs.sum()).backward()
+    np.testing.assert_allclose(y.grad.numpy(), g["te_dy"], rtol=1e-3, atol=1e-5 * np.abs(g["te_dy"]).max())
+    np.testing.assert_allclose(ge.grad.numpy(), g["te_dge"], rtol=1e-3, atol=1e-5 * np.abs(g["te_dge"]).max())
+    names = json.loads(str(g["te_names"]))
+    got = np.array([sd[k].grad.abs().sum().item() if sd[k].grad is not None else 0.0 for k in names])
+    np.testing.assert_allclose(got, g["te_grad_abs_sum"], rtol=2e-3, atol=1e-6)
+    sd = _sd_from([(k, s) for k, s in json.loads(str(g["se_keys"]))])
+    x = T(g["se_x"]).requires_grad_(True); mask = T(g["se_mask"])
+    w = vqvae_ref.mel_style_encoder_forward(sd, "", x * mask, mask)
+    np.testing.assert_allclose(w.detach().numpy(), g["se_w"], rtol=1e-4, atol=1e-5)
+    (w * T(g["se_ct"])).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), g["se_dx"], rtol=1e-3, atol=1e-5 * np.abs(g["se_dx"]).max())

@@ -404,8 +404,48 @@ def gen_flow():
     print("G5c flow/wn/aa/posterior:", float(z.abs().mean()), len(names))
 
 
+def gen_attn():
+    """G6: reference TextEncoder (3 + 6 + 3 relative-attention layers, MRTE cross-attention) and MelStyleEncoder in eval
+    mode on short ragged inputs; weights det_fill (not stored)."""
+    import ttts.vqvae.vq2 as vq2
+    import ttts.vqvae.modules as M
+    rng = np.random.default_rng(123)
+    t = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32))
+    rec = {}
+    te = vq2.TextEncoder(192, 192, 768, 2, 6, 3, 0.1).eval()
+    _fill_det(te)
+    y = t(2, 192, 40).requires_grad_(True); ge = t(2, 512, 1).requires_grad_(True)
+    y_len = torch.tensor([40, 29]); text = torch.from_numpy(rng.integers(1, 255, (2, 12))); text_len = torch.tensor([12, 7])
+    out, m, logs = te(y, y_len, text, text_len, ge)
+    ct = t(2, 192, 40)
+    ((out * ct).sum() + (m * ct).sum() + 0.5 * logs.sum()).backward()
+    names = [k for k, _ in te.named_parameters()]
+    rec.update({"te_y": y.detach().numpy(), "te_ge": ge.detach().numpy(), "te_ylen": y_len.numpy(), "te_text": text.numpy(),
+                "te_tlen": text_len.numpy(), "te_ct": ct.numpy(), "te_out": out.detach().numpy(), "te_m": m.detach().numpy(),
+                "te_logs": logs.detach().numpy(), "te_dy": y.grad.numpy(), "te_dge": ge.grad.numpy(),
+                "te_names": np.array(json.dumps(names)),
+                "te_keys": np.array(json.dumps([[k, list(v.shape)] for k, v in te.state_dict().items()])),
+                "te_grad_abs_sum": np.array([p.grad.abs().sum().item() if p.grad is not None else 0.0 for _, p in te.named_parameters()]),
+                "te_grad_sum": np.array([p.grad.sum().item() if p.grad is not None else 0.0 for _, p in te.named_parameters()])})
+    se = M.MelStyleEncoder(40, style_vector_dim=512).eval()
+    _fill_det(se)
+    x = t(2, 40, 33).requires_grad_(True)
+    mask = torch.ones(2, 1, 33); mask[1, :, 20:] = 0
+    w = se(x * mask, mask)
+    ctw = t(2, 512, 1)
+    (w * ctw).sum().backward()
+    names = [k for k, _ in se.named_parameters()]
+    rec.update({"se_x": x.detach().numpy(), "se_mask": mask.numpy(), "se_ct": ctw.numpy(), "se_w": w.detach().numpy(),
+                "se_dx": x.grad.numpy(), "se_names": np.array(json.dumps(names)),
+                "se_keys": np.array(json.dumps([[k, list(v.shape)] for k, v in se.state_dict().items()])),
+                "se_grad_abs_sum": np.array([p.grad.abs().sum().item() for _, p in se.named_parameters()]),
+                "se_grad_sum": np.array([p.grad.sum().item() for _, p in se.named_parameters()])})
+    np.savez_compressed(os.path.join(OUT, "vqvae_attn.npz"), **rec)
+    print("G6 attn:", float(out.abs().mean()), float(w.abs().mean()))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gpt", "vq", "mel", "vqvae", "disc", "flow"]
+    which = sys.argv[1:] or ["gpt", "vq", "mel", "vqvae", "disc", "flow", "attn"]
     with torch.no_grad() if False else torch.enable_grad():
         if "gpt" in which:
             gen_gpt()
@@ -419,4 +459,6 @@ if __name__ == "__main__":
             gen_disc()
         if "flow" in which:
             gen_flow()
+        if "attn" in which:
+            gen_attn()
     print("fixtures:", {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT))})

@@ -313,6 +313,53 @@ __global__ __launch_bounds__(256) void layernorm_ch_bwd_param_kernel(const float
   if (threadIdx.x == 0) { dgamma[c] += tg; dbeta[c] += (sh[0] + sh[1]) + (sh[2] + sh[3]); }
 }
 
+// ---- token embedding straight into (B, C, T): y[b][c][t] = table[idx[b][t]][c]; bwd scatter-adds -------------------------
+__global__ __launch_bounds__(256) void embedding_ct_fwd_kernel(const int64_t* __restrict__ idx, const float* __restrict__ table,
+                                                               float* __restrict__ y, int B, int C, int T) {
+  const int64_t n = (int64_t)B * C * T;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int t = (int)(i % T), c = (int)((i / T) % C);
+    const int64_t b = i / ((int64_t)C * T);
+    y[i] = table[idx[b * T + t] * C + c];
+  }
+}
+__global__ __launch_bounds__(256) void embedding_ct_bwd_kernel(const int64_t* __restrict__ idx, const float* __restrict__ dy,
+                                                               float* __restrict__ dtable, int B, int C, int T) {
+  const int64_t n = (int64_t)B * C * T;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int t = (int)(i % T), c = (int)((i / T) % C);
+    const int64_t b = i / ((int64_t)C * T);
+    atomicAdd(dtable + idx[b * T + t] * C + c, dy[i]);
+  }
+}
+
+// ---- masked temporal mean: y[b][c] = sum_t x[b][c][t] m[b][t] / sum_t m[b][t]  (one wave per (b, c)) ------------------------
+__global__ __launch_bounds__(256) void masked_mean_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mask,
+                                                              float* __restrict__ y, int B, int C, int T) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= B * C) return;
+  const int b = row / C;
+  float s = 0.f, ms = 0.f;
+  for (int t = lane; t < T; t += 64) {
+    const float mk = mask ? mask[(int64_t)b * T + t] : 1.f;
+    s = fmaf(x[(int64_t)row * T + t], mk, s);
+    ms += mk;
+  }
+  s = wave_sum(s); ms = wave_sum(ms);
+  if (lane == 0) y[row] = s / ms;
+}
+__global__ __launch_bounds__(256) void masked_mean_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ mask,
+                                                              float* __restrict__ dx, int B, int C, int T) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= B * C) return;
+  const int b = row / C;
+  float ms = 0.f;
+  for (int t = lane; t < T; t += 64) ms += mask ? mask[(int64_t)b * T + t] : 1.f;
+  ms = wave_sum(ms);
+  const float g = dy[row] / ms;
+  for (int t = lane; t < T; t += 64) dx[(int64_t)row * T + t] = g * (mask ? mask[(int64_t)b * T + t] : 1.f);
+}
+
 static inline int grid_for(int64_t n) { return (int)std::min<int64_t>(cdiv(n, 256), 4096); }
 
 }  // namespace ttts
@@ -402,4 +449,29 @@ extern "C" int ttts_layernorm_ch_bwd_f32(const float* dy, const float* x, const 
   layernorm_ch_bwd_dx_kernel<<<(int)cdiv((int64_t)B * T, 256), 256, 0, as_stream(stream)>>>(dy, x, gamma, mean, rstd, dx, B, C, T);
   layernorm_ch_bwd_param_kernel<<<C, 256, 0, as_stream(stream)>>>(dy, x, mean, rstd, dgamma, dbeta, B, C, T);
   return check_launch("layernorm_ch_bwd");
+}
+
+extern "C" int ttts_embedding_ct_fwd_f32(const int64_t* idx, const float* table, float* y, int32_t B, int32_t C, int32_t T,
+                                         void* stream) {
+  TTTS_REQUIRE(idx && table && y && B > 0 && C > 0 && T > 0, "embedding_ct_fwd: bad arguments");
+  embedding_ct_fwd_kernel<<<grid_for((int64_t)B * C * T), 256, 0, as_stream(stream)>>>(idx, table, y, B, C, T);
+  return check_launch("embedding_ct_fwd");
+}
+extern "C" int ttts_embedding_ct_bwd_f32(const int64_t* idx, const float* dy, float* dtable, int32_t B, int32_t C, int32_t T,
+                                         void* stream) {
+  TTTS_REQUIRE(idx && dy && dtable && B > 0 && C > 0 && T > 0, "embedding_ct_bwd: bad arguments");
+  embedding_ct_bwd_kernel<<<grid_for((int64_t)B * C * T), 256, 0, as_stream(stream)>>>(idx, dy, dtable, B, C, T);
+  return check_launch("embedding_ct_bwd");
+}
+extern "C" int ttts_masked_mean_fwd_f32(const float* x, const float* mask, float* y, int32_t B, int32_t C, int32_t T,
+                                        void* stream) {
+  TTTS_REQUIRE(x && y && B > 0 && C > 0 && T > 0, "masked_mean_fwd: bad arguments");
+  masked_mean_fwd_kernel<<<(int)cdiv((int64_t)B * C, 4), 256, 0, as_stream(stream)>>>(x, mask, y, B, C, T);
+  return check_launch("masked_mean_fwd");
+}
+extern "C" int ttts_masked_mean_bwd_f32(const float* dy, const float* mask, float* dx, int32_t B, int32_t C, int32_t T,
+                                        void* stream) {
+  TTTS_REQUIRE(dy && dx && B > 0 && C > 0 && T > 0, "masked_mean_bwd: bad arguments");
+  masked_mean_bwd_kernel<<<(int)cdiv((int64_t)B * C, 4), 256, 0, as_stream(stream)>>>(dy, mask, dx, B, C, T);
+  return check_launch("masked_mean_bwd");
 }

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(CSRC, "build")
 SO_PATH = os.path.join(HERE, "libttts_hip.so")
-SOURCES = ["lib.hip", "elementwise.hip", "gemm.hip", "attn.hip", "vq.hip", "stft.hip", "conv.hip", "losses.hip", "vqvae_ops.hip"]
+SOURCES = ["lib.hip", "elementwise.hip", "gemm.hip", "attn.hip", "vq.hip", "stft.hip", "conv.hip", "losses.hip", "vqvae_ops.hip", "attn_f32.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-Wall", "-Wno-unused-variable"]
 
@@ -136,6 +136,15 @@ SIGNATURES = {
     "ttts_snake_aa_bwd_f32": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P]),
     "ttts_layernorm_ch_fwd_f32": (_I32, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _F, _P]),
     "ttts_layernorm_ch_bwd_f32": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P]),
+    "ttts_embedding_ct_fwd_f32": (_I32, [_P, _P, _P, _I32, _I32, _I32, _P]),
+    "ttts_embedding_ct_bwd_f32": (_I32, [_P, _P, _P, _I32, _I32, _I32, _P]),
+    "ttts_masked_mean_fwd_f32": (_I32, [_P, _P, _P, _I32, _I32, _I32, _P]),
+    "ttts_masked_mean_bwd_f32": (_I32, [_P, _P, _P, _I32, _I32, _I32, _P]),
+    "ttts_bgemm_f32": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _I64, _I64, _I32, _I32, _I64, _I64, _I64,
+                              _I64, _I64, _I64, _F, _F, _P]),
+    "ttts_attn_softmax_fwd_f32": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _F, _F, _P]),
+    "ttts_attn_softmax_bwd_f32": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "ttts_attn_rel_f32": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _F, _I32, _P]),
     "ttts_loss_workspace_bytes": (_I64, []),
     "ttts_reduce_loss_f32": (_I32, [_P, _P, _I64, _I32, _F, _P, _I32, _P, _P]),
     "ttts_reduce_loss_bwd_f32": (_I32, [_P, _P, _I64, _I32, _F, _P, _P, _I32, _P]),

@@ -522,6 +522,67 @@ def layernorm_ch_bwd(dy, x, gamma, mean, rstd):
     return dx, dg, db
 
 
+def embedding_ct_fwd(idx, table):
+    _req(idx, torch.int64, "idx"); table = _f32c(table, "table")
+    idx = idx.contiguous()
+    B, T = idx.shape
+    C = table.shape[1]
+    y = torch.empty(B, C, T, dtype=torch.float32, device=table.device)
+    check(_l.get().ttts_embedding_ct_fwd_f32(_p(idx), _p(table), _p(y), B, C, T, _stream()), "embedding_ct_fwd")
+    return y
+
+
+def embedding_ct_bwd(idx, dy, rows):
+    dy = _f32c(dy, "dy")
+    B, C, T = dy.shape
+    dt = torch.zeros(rows, C, dtype=torch.float32, device=dy.device)
+    check(_l.get().ttts_embedding_ct_bwd_f32(_p(idx.contiguous()), _p(dy), _p(dt), B, C, T, _stream()), "embedding_ct_bwd")
+    return dt
+
+
+def masked_mean_fwd(x, mask):
+    x = _f32c(x, "x")
+    B, C, T = x.shape
+    y = torch.empty(B, C, dtype=torch.float32, device=x.device)
+    check(_l.get().ttts_masked_mean_fwd_f32(_p(x), _p(mask), _p(y), B, C, T, _stream()), "masked_mean_fwd")
+    return y
+
+
+def masked_mean_bwd(dy, mask, T):
+    dy = _f32c(dy, "dy")
+    B, C = dy.shape
+    dx = torch.empty(B, C, T, dtype=torch.float32, device=dy.device)
+    check(_l.get().ttts_masked_mean_bwd_f32(_p(dy), _p(mask), _p(dx), B, C, T, _stream()), "masked_mean_bwd")
+    return dx
+
+
+def bgemm(A, B, C, M, N, K, a_s, b_s, c_s, outer, inner, a_b, b_b, c_b, alpha=1.0, beta=0.0):
+    """C[z][m][n] = alpha sum_k A[z][m][k] B[z][k][n] + beta C; a_s = (s_m, s_k), b_s = (s_k, s_n), c_s = (s_m, s_n),
+    *_b = (outer batch stride, inner batch stride), all in elements; tensors are only used for their base pointers."""
+    check(_l.get().ttts_bgemm_f32(_p(A), _p(B), _p(C), M, N, K, a_s[0], a_s[1], b_s[0], b_s[1], c_s[0], c_s[1], outer, inner,
+                                  a_b[0], a_b[1], b_b[0], b_b[1], c_b[0], c_b[1], alpha, beta, _stream()), "bgemm")
+    return C
+
+
+def attn_softmax_fwd(S, q, ek, qmask, kmask, dk, window, scale, fill):
+    B, H, Tq, Tk = S.shape
+    hrel = ek.shape[0] if ek is not None else 1
+    check(_l.get().ttts_attn_softmax_fwd_f32(_p(S), _p(q), _p(ek), _p(qmask), _p(kmask), B, H, Tq, Tk, dk, window, hrel, scale,
+                                             fill, _stream()), "attn_softmax_fwd")
+    return S
+
+
+def attn_softmax_bwd(dP, P, qmask, kmask):
+    B, H, Tq, Tk = P.shape
+    check(_l.get().ttts_attn_softmax_bwd_f32(_p(dP), _p(P), _p(qmask), _p(kmask), B, H, Tq, Tk, _stream()), "attn_softmax_bwd")
+    return dP
+
+
+def attn_rel(W, X, E, H, window, scale, mode):
+    B, C, T = X.shape
+    check(_l.get().ttts_attn_rel_f32(_p(W), _p(X), _p(E), B, H, T, C // H, window, E.shape[0], scale, mode, _stream()), "attn_rel")
+
+
 RED_ABSDIFF, RED_SQ_ONE_MINUS, RED_SQ = 0, 1, 2
 _loss_ws = {}
 

@@ -8,7 +8,10 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from . import modules
+from .. import ops
+from . import attentions, modules
+from .attentions import MultiHeadAttention
+from .style_encoder import MelStyleEncoder  # noqa: F401
 from .modules import LRELU_SLOPE, Conv1d, Conv2dK1, Generator, get_padding  # noqa: F401
 
 
@@ -157,3 +160,76 @@ class PosteriorAudioEncoder(nn.Module):
             noise = torch.randn(m.shape, dtype=m.dtype, device=m.device)
         z = modules._GaussSampleFn.apply(stats, noise, x_mask.reshape(x_mask.shape[0], -1).contiguous())
         return z, m, logs
+
+
+def sequence_mask(length, max_length=None):
+    """commons.sequence_mask (ttts/utils/commons.py:116-120)."""
+    if max_length is None:
+        max_length = length.max()
+    x = torch.arange(max_length, dtype=length.dtype, device=length.device)
+    return x.unsqueeze(0) < length.unsqueeze(1)
+
+
+class _EmbeddingCTFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, idx, table):
+        ctx.save_for_backward(idx)
+        ctx.rows = table.shape[0]
+        return ops.embedding_ct_fwd(idx, table)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        return None, ops.embedding_ct_bwd(idx, dy, ctx.rows)
+
+
+class MRTE(nn.Module):
+    """vq2.py:17-46: cross-attention of the audio stream (queries) over the text stream (keys / values)."""
+
+    def __init__(self, content_enc_channels=192, hidden_size=512, out_channels=192, kernel_size=5, n_heads=4, ge_layer=2):
+        super().__init__()
+        self.cross_attention = MultiHeadAttention(hidden_size, hidden_size, n_heads)
+        self.c_pre = Conv1d(content_enc_channels, hidden_size, 1)
+        self.text_pre = Conv1d(content_enc_channels, hidden_size, 1)
+        self.c_post = Conv1d(hidden_size, out_channels, 1)
+
+    def forward(self, ssl_enc, ssl_mask, text, text_mask, ge, test=None):
+        ssl_enc = self.c_pre(modules.mul_mask(ssl_enc, ssl_mask))
+        text_enc = self.text_pre(modules.mul_mask(text, text_mask))
+        # (cross_attention(..) + ssl_enc + ge) * ssl_mask: residual, broadcast style vector and mask are epilogues of the
+        # attention's output projection
+        x = self.cross_attention(modules.mul_mask(ssl_enc, ssl_mask), modules.mul_mask(text_enc, text_mask),
+                                 q_mask=ssl_mask, k_mask=text_mask, resid=ssl_enc,
+                                 bbias=ge.squeeze(-1) if ge is not None else None, omask=ssl_mask)
+        return self.c_post(x)
+
+
+class TextEncoder(nn.Module):
+    """vq2.py:90-164."""
+
+    def __init__(self, out_channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout,
+                 latent_channels=192):
+        super().__init__()
+        self.out_channels, self.hidden_channels, self.filter_channels = out_channels, hidden_channels, filter_channels
+        self.n_heads, self.n_layers, self.kernel_size, self.p_dropout = n_heads, n_layers, kernel_size, p_dropout
+        self.latent_channels = latent_channels
+        self.encoder_ssl = attentions.Encoder(hidden_channels, filter_channels, n_heads, n_layers // 2, kernel_size, p_dropout)
+        self.encoder_text = attentions.Encoder(hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout)
+        self.text_embedding = nn.Embedding(256, hidden_channels)
+        self.mrte = MRTE()
+        self.encoder2 = attentions.Encoder(hidden_channels, filter_channels, n_heads, n_layers // 2, kernel_size, p_dropout)
+        self.proj = Conv1d(hidden_channels, out_channels * 2, 1)
+
+    def forward(self, y, y_lengths, text, text_lengths, ge, test=None):
+        y_mask = torch.unsqueeze(sequence_mask(y_lengths, y.size(2)), 1).to(y.dtype)
+        y = self.encoder_ssl(y, y_mask)                 # Encoder masks its input itself (x * x_mask)
+        text_mask = torch.unsqueeze(sequence_mask(text_lengths, text.size(1)), 1).to(y.dtype)
+        if test == 1:
+            text = torch.zeros_like(text)
+        text = _EmbeddingCTFn.apply(text, self.text_embedding.weight)
+        text = self.encoder_text(text, text_mask)
+        y = self.mrte(y, y_mask, text, text_mask, ge)
+        y = self.encoder2(y, y_mask)
+        stats = self.proj(y, omask=y_mask)
+        m, logs = torch.split(stats, self.out_channels, dim=1)
+        return y, m, logs
