@@ -65,20 +65,23 @@ def generator_forward(sd, cfg, x, g=None, pfx=""):
 
 
 # ---- discriminators (ttts/vqvae/vq2.py:418-551) and losses (ttts/vqvae/losses.py:7-61) --------------------------------
-def det_fill(name, shape):
+def det_fill(name, shape, gain=1.0):
     """Deterministic, construction-order-independent parameter fill shared by tools/make_goldens.py, the oracle tests and
-    the GPU parity tests (so multi-million-parameter state dicts need not be stored)."""
+    the GPU parity tests (so multi-million-parameter state dicts need not be stored).  `gain` < 1 makes every layer
+    contractive (used for the full-model fixtures, where unit-gain residual stacks would blow up)."""
     import zlib
     import numpy as np
     rng = np.random.default_rng(zlib.crc32(name.encode()))
     a = rng.standard_normal(size=tuple(shape), dtype=np.float32)
     if name.endswith("weight_g") or name.endswith("original0"):
-        a = np.float32(1.0) + np.float32(0.1) * np.abs(a)            # ~ ||v|| = 1.2 * sqrt(fan_in)/sqrt(fan_in) scale below
+        a = np.float32(gain) * (np.float32(1.0) + np.float32(0.1) * np.abs(a))
     elif len(shape) > 1:
         fan_in = 1
         for d in shape[1:]:
             fan_in *= d
-        a = a * np.float32(1.2 / fan_in ** 0.5)
+        a = a * np.float32(gain * 1.2 / fan_in ** 0.5)
+    elif name.endswith("gamma"):
+        a = np.float32(1.0) + a * np.float32(0.05) if gain != 1.0 else a * np.float32(0.05)
     else:
         a = a * np.float32(0.05)
     return torch.from_numpy(a)

@@ -399,3 +399,87 @@ def test_attention_dropout_is_consistent_between_forward_and_backward():
     out0 = _AttnCoreFn.apply(q, k, torch.zeros_like(v), ek, ev, None, None, 2, 4, 0.25, -1e4, 0.3, 99)
     lin = (out - out0).sum().item()          # the part of out that is linear in v (rel_v term does not depend on v)
     np.testing.assert_allclose((v.grad * v.detach()).sum().item(), lin, rtol=1e-4)
+
+
+def _step_setup(golden_dir):
+    """Trainer with the fixture's deterministic weights / codebook (tools/make_goldens.py gen_step)."""
+    from oracle import vqvae_ref
+    from ttts_amd.utils.data_utils import HParams
+    from ttts_amd.vqvae.train import VqvaeTrainer, get_hparams
+    g = np.load(os.path.join(golden_dir, "vqvae_step.npz"))
+    hps = get_hparams()
+    hps.vqvae.p_dropout = 0.0
+    tr = VqvaeTrainer(hps, device=_dev())
+    with torch.no_grad():
+        for k, p in tr.net_g.named_parameters():
+            p.copy_(vqvae_ref.det_fill(k, p.shape, 0.4))
+        for k, p in tr.net_d.named_parameters():
+            p.copy_(vqvae_ref.det_fill(k, p.shape, 0.6))
+        cb = tr.net_g.quantizer.vq.layers[0]._codebook
+        cb.inited.fill_(1)
+        cb.embed.copy_(vqvae_ref.det_fill("codebook.embed", cb.embed.shape) * 2.0)
+        cb.embed_avg.copy_(cb.embed * 4.0)
+        cb.cluster_size.fill_(4.0)
+    tr.net_g.ref_enc.eval()
+    D = lambda k: torch.from_numpy(g[k]).to(_dev())
+    data = {"wav": D("wav"), "wav_lengths": D("wav_lengths"), "text": D("text"), "text_lengths": D("text_lengths")}
+    inject = {"noise_p": D("noise_p"), "noise_q": D("noise_q"), "ids_slice": D("ids_slice")}
+    return g, tr, data, inject
+
+
+def test_full_vqvae_gan_step_matches_reference_fixture(golden_dir):
+    """One complete two-phase step (spectrograms, SynthesizerTrn, mel, MPD x2, all losses, both AdamW updates, codebook
+    EMA) against the reference-generated tests/golden/vqvae_step.npz."""
+    g, tr, data, inject = _step_setup(golden_dir)
+    g_before = tr.optim_g.flat_p.clone(); d_before = tr.optim_d.flat_p.clone()
+    # forward-only check first (fresh graph), then the real step
+    h = tr.hps.data
+    from ttts_amd.utils.data_utils import spectrogram_torch
+    spec = spectrogram_torch(data["wav"], h.filter_length, h.hop_length, h.win_length)
+    cbuf = {k: v.clone() for k, v in tr.net_g.quantizer.state_dict().items()}
+    with torch.no_grad():
+        o, commit, ids, y_mask, (z, z_p, m_p, logs_p, m_q, logs_q), quantized = tr.net_g(
+            data["wav"], data["wav"], data["wav_lengths"], spec, spec, data["wav_lengths"] // h.hop_length, data["text"],
+            data["text_lengths"], **inject)
+    tr.net_g.quantizer.load_state_dict(cbuf)          # undo the EMA update of the probe forward
+    for a, k, tol in ((z, "z", 2e-4), (m_q, "m_q", 2e-4), (logs_q, "logs_q", 2e-4), (quantized, "quantized", 2e-4),
+                      (m_p, "m_p", 5e-4), (logs_p, "logs_p", 5e-4), (z_p, "z_p", 5e-4), (o, "o", 1e-3)):
+        _close(a, torch.from_numpy(g[k]), tol, 1e-6, k)
+    np.testing.assert_allclose(commit.item(), g["commit"], rtol=1e-4)
+    assert torch.equal(y_mask.cpu(), torch.from_numpy(g["y_mask"]))
+    out = tr.train_step(data, inject)
+    got = np.array([out[k].item() for k in ("loss_disc", "loss_gen", "loss_fm", "loss_mel", "kl_ssl", "loss_kl")])
+    np.testing.assert_allclose(got, g["losses"], rtol=2e-3)
+    np.testing.assert_allclose([out["grad_norm_d"].item(), out["grad_norm_g"].item()], g["grad_norms"], rtol=5e-3)
+    # parameter updates: per-tensor |delta| sums (AdamW step 1 moves every element by ~lr)
+    gd = (tr.optim_g.flat_p - g_before).abs()
+    got = np.array([gd[o_:o_ + p.numel()].sum().item() for p, o_ in zip(tr.optim_g.params, tr.optim_g.offsets)])
+    # Adam's first step moves an element by lr * g / (|g| + 1e-9): where the true gradient is zero (e.g. attention key
+    # biases) the update is decided by rounding noise on both sides -- compare the well-conditioned tensors only
+    numel = np.array([p.numel() for p in tr.optim_g.params])
+    ok = g["g_grad_abs"] / numel > 1e-6
+    assert ok.sum() > 1400
+    np.testing.assert_allclose(got[ok], g["g_delta_abs"][ok], rtol=2e-2)
+    dd = (tr.optim_d.flat_p - d_before).abs()
+    got = np.array([dd[o_:o_ + p.numel()].sum().item() for p, o_ in zip(tr.optim_d.params, tr.optim_d.offsets)])
+    np.testing.assert_allclose(got, g["d_delta_abs"], rtol=2e-2)
+    cb = tr.net_g.quantizer.vq.layers[0]._codebook
+    np.testing.assert_allclose(cb.cluster_size.cpu().numpy(), g["cb_cluster_size"], rtol=1e-5)
+    np.testing.assert_allclose(cb.embed_avg.sum(1).cpu().numpy(), g["cb_embed_avg_sum"], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(cb.embed[:8].cpu().numpy(), g["cb_embed_head"], rtol=1e-4, atol=1e-6)
+
+
+def test_vqvae_checkpoint_roundtrip(tmp_path, golden_dir):
+    from ttts_amd.vqvae.train import latest_checkpoint_path, load_checkpoint
+    g, tr, data, inject = _step_setup(golden_dir)
+    tr.hps.train.exp_dir = str(tmp_path)
+    tr.train_step(data, inject)
+    tr.save(7)
+    ck = torch.load(latest_checkpoint_path(str(tmp_path), "G_*.pth"), map_location="cpu", weights_only=False)
+    assert set(ck) == {"model", "iteration", "optimizer", "learning_rate"} and ck["iteration"] == 7
+    assert len(ck["model"]) == 1463 and set(ck["optimizer"]) == {"state", "param_groups"}
+    want_p, want_m = tr.optim_g.flat_p.clone(), tr.optim_g.exp_avg.clone()
+    tr.optim_g.flat_p.zero_(); tr.optim_g.exp_avg.zero_()
+    assert tr.load_latest() == 7
+    assert torch.equal(tr.optim_g.flat_p, want_p) and torch.equal(tr.optim_g.exp_avg, want_m)
+    assert tr.optim_g.state[0].item() == 1.0

@@ -326,11 +326,11 @@ def gen_disc():
     print("G5b disc:", float(loss_d), float(loss_fm), float(loss_gen), float(kl))
 
 
-def _fill_det(module, scale_hint=None):
+def _fill_det(module, gain=1.0):
     from oracle import vqvae_ref
     with torch.no_grad():
         for k, p in module.named_parameters():
-            p.copy_(vqvae_ref.det_fill(k, p.shape))
+            p.copy_(vqvae_ref.det_fill(k, p.shape, gain))
 
 
 def _grads(module):
@@ -444,8 +444,111 @@ def gen_attn():
     print("G6 attn:", float(out.abs().mean()), float(w.abs().mean()))
 
 
+STEP_HPS = {"filter_length": 2048, "hop_length": 640, "win_length": 2048, "n_mel_channels": 128, "sampling_rate": 32000,
+            "mel_fmin": 0.0, "mel_fmax": None, "segment_size": 20480, "c_mel": 45, "c_kl": 1.0, "learning_rate": 1e-4,
+            "betas": [0.8, 0.99], "eps": 1e-9}
+
+
+STEP_GAIN = 0.4
+
+
+def gen_step():
+    """G8: one full two-phase VQ-VAE-GAN step of the reference (train.py:313-406 restated around the imported modules):
+    SynthesizerTrn(full vqvae/config.json, p_dropout 0, ref_enc.eval()) + MultiPeriodDiscriminator on 2 clips of
+    50 / 40 frames, injected noise and segment starts, pre-initialised codebook, AdamW(1e-4, (0.8, 0.99), 1e-9)."""
+    import ttts.vqvae.vq2 as vq2
+    import ttts.vqvae.losses as L
+    import ttts.utils.commons as commons
+    import ttts.utils.data_utils as du
+    from oracle import vqvae_ref
+    h = STEP_HPS
+    cfg = json.load(open("/root/reference/ttts/vqvae/config.json"))["vqvae"]
+    cfg["p_dropout"] = 0.0
+    torch.manual_seed(0)
+    net_g = vq2.SynthesizerTrn(h["filter_length"] // 2 + 1, h["segment_size"] // h["hop_length"], **cfg)
+    net_d = vq2.MultiPeriodDiscriminator()
+    _fill_det(net_g, STEP_GAIN); _fill_det(net_d, 0.6)
+    net_g.train(); net_d.train(); net_g.ref_enc.eval()
+    cb = net_g.quantizer.vq.layers[0]._codebook
+    with torch.no_grad():
+        cb.inited.fill_(1)
+        cb.embed.copy_(vqvae_ref.det_fill("codebook.embed", cb.embed.shape) * 2.0)
+        cb.embed_avg.copy_(cb.embed * 4.0)
+        cb.cluster_size.fill_(4.0)
+    rng = np.random.default_rng(2024)
+    tt = np.arange(32000) / 32000.0
+    wav = np.stack([sum(rng.uniform(0.02, 0.2) * np.sin(2 * np.pi * rng.uniform(60, 6000) * tt + rng.uniform(0, 6.28))
+                        for _ in range(16)) for _ in range(2)]).astype(np.float32)
+    wav = np.clip(wav + 0.05 * rng.standard_normal(wav.shape).astype(np.float32), -1, 1)
+    wav[1, 25600:] = 0
+    wav = torch.from_numpy(wav)
+    wav_lengths = torch.tensor([32000, 25600])
+    text = torch.from_numpy(rng.integers(1, 255, (2, 16))); text_lengths = torch.tensor([16, 11])
+    noises = [torch.from_numpy(rng.standard_normal((2, 192, 50)).astype(np.float32)) for _ in range(2)]
+    ids = torch.tensor([3, 5])
+    calls = {"n": 0}
+
+    def fake_randn_like(t_, *a, **k):
+        calls["n"] += 1
+        return noises[calls["n"] - 1]
+
+    def fake_slice(x, x_lengths=None, segment_size=4):
+        return commons.slice_segments(x, ids, segment_size), ids
+
+    optim_g = torch.optim.AdamW(net_g.parameters(), h["learning_rate"], betas=h["betas"], eps=h["eps"])
+    optim_d = torch.optim.AdamW(net_d.parameters(), h["learning_rate"], betas=h["betas"], eps=h["eps"])
+    g_before = {k: p.detach().clone() for k, p in net_g.named_parameters()}
+    d_before = {k: p.detach().clone() for k, p in net_d.named_parameters()}
+    orig_randn_like, orig_slice = torch.randn_like, commons.rand_slice_segments
+    torch.randn_like = fake_randn_like; commons.rand_slice_segments = fake_slice
+    try:
+        spec = du.spectrogram_torch(wav, h["filter_length"], h["hop_length"], h["win_length"], center=False).squeeze(0)
+        spec_lengths = torch.LongTensor([x // h["hop_length"] for x in wav_lengths])
+        y_hat, kl_ssl, ids_slice, z_mask, (z, z_p, m_p, logs_p, m_q, logs_q), quantized = net_g(
+            wav, wav, wav_lengths, spec, spec, spec_lengths, text, text_lengths)
+    finally:
+        torch.randn_like = orig_randn_like; commons.rand_slice_segments = orig_slice
+    assert calls["n"] == 2
+    mel = du.spec_to_mel_torch(spec, h["filter_length"], h["n_mel_channels"], h["sampling_rate"], h["mel_fmin"], h["mel_fmax"])
+    y_mel = commons.slice_segments(mel, ids_slice, h["segment_size"] // h["hop_length"])
+    y_hat_mel = du.mel_spectrogram_torch(y_hat.squeeze(1), h["filter_length"], h["n_mel_channels"], h["sampling_rate"],
+                                         h["hop_length"], h["win_length"], h["mel_fmin"], h["mel_fmax"])
+    y = commons.slice_segments(wav.unsqueeze(1), ids_slice * h["hop_length"], h["segment_size"])
+    y_d_hat_r, y_d_hat_g, _, _ = net_d(y, y_hat.detach())
+    loss_disc, _, _ = L.discriminator_loss(y_d_hat_r, y_d_hat_g)
+    optim_d.zero_grad(); loss_disc.backward()
+    grad_norm_d = commons.clip_grad_value_(net_d.parameters(), None)
+    d_grad_abs = np.array([p.grad.abs().sum().item() for _, p in net_d.named_parameters()])
+    optim_d.step()
+    y_d_hat_r, y_d_hat_g, fmap_r, fmap_g = net_d(y, y_hat)
+    loss_mel = torch.nn.functional.l1_loss(y_mel, y_hat_mel) * h["c_mel"]
+    loss_kl = L.kl_loss(z_p, logs_q, m_p, logs_p, z_mask) * h["c_kl"]
+    loss_fm = L.feature_loss(fmap_r, fmap_g)
+    loss_gen, _ = L.generator_loss(y_d_hat_g)
+    loss_gen_all = loss_gen + loss_fm + loss_mel + kl_ssl * 1 + loss_kl
+    optim_g.zero_grad(); loss_gen_all.backward()
+    grad_norm_g = commons.clip_grad_value_(net_g.parameters(), None)
+    g_names = [k for k, _ in net_g.named_parameters()]
+    g_grad_abs = np.array([p.grad.abs().sum().item() if p.grad is not None else -1.0 for _, p in net_g.named_parameters()])
+    optim_g.step()
+    rec = {"wav": wav.numpy(), "wav_lengths": wav_lengths.numpy(), "text": text.numpy(), "text_lengths": text_lengths.numpy(),
+           "noise_p": noises[0].numpy(), "noise_q": noises[1].numpy(), "ids_slice": ids.numpy(),
+           "o": y_hat.detach().numpy(), "commit": kl_ssl.detach().numpy(), "quantized": quantized.detach().numpy(),
+           "z": z.detach().numpy(), "z_p": z_p.detach().numpy(), "m_p": m_p.detach().numpy(), "logs_p": logs_p.detach().numpy(),
+           "m_q": m_q.detach().numpy(), "logs_q": logs_q.detach().numpy(), "y_mask": z_mask.numpy(),
+           "losses": np.array([loss_disc.item(), loss_gen.item(), loss_fm.item(), loss_mel.item(), kl_ssl.item(), loss_kl.item()]),
+           "grad_norms": np.array([grad_norm_d, grad_norm_g]), "d_grad_abs": d_grad_abs, "g_grad_abs": g_grad_abs,
+           "g_names": np.array(json.dumps(g_names)),
+           "g_delta_abs": np.array([(p.detach() - g_before[k]).abs().sum().item() for k, p in net_g.named_parameters()]),
+           "d_delta_abs": np.array([(p.detach() - d_before[k]).abs().sum().item() for k, p in net_d.named_parameters()]),
+           "cb_cluster_size": cb.cluster_size.numpy(), "cb_embed_avg_sum": cb.embed_avg.sum(1).numpy(),
+           "cb_embed_head": cb.embed[:8].numpy(), "hps": np.array(json.dumps(h)), "cfg": np.array(json.dumps(cfg))}
+    np.savez_compressed(os.path.join(OUT, "vqvae_step.npz"), **rec)
+    print("G8 step losses:", rec["losses"], "norms", rec["grad_norms"], "unused g params:", int((g_grad_abs < 0).sum()))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gpt", "vq", "mel", "vqvae", "disc", "flow", "attn"]
+    which = sys.argv[1:] or ["gpt", "vq", "mel", "vqvae", "disc", "flow", "attn", "step"]
     with torch.no_grad() if False else torch.enable_grad():
         if "gpt" in which:
             gen_gpt()
@@ -461,4 +564,6 @@ if __name__ == "__main__":
             gen_flow()
         if "attn" in which:
             gen_attn()
+        if "step" in which:
+            gen_step()
     print("fixtures:", {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT))})

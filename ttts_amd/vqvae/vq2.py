@@ -2,7 +2,8 @@
 return structure and state-dict keys).
 
 Built so far: `Generator` (:341-415, in modules.py), `DiscriminatorP` (:418-494), `DiscriminatorS` (:497-524),
-`MultiPeriodDiscriminator` (:527-551), `ResidualCouplingBlock` (:208-252), `PosteriorAudioEncoder` (:667-745).
+`MultiPeriodDiscriminator` (:527-551), `ResidualCouplingBlock` (:208-252), `PosteriorAudioEncoder` (:667-745),
+`MRTE` (:17-46), `TextEncoder` (:90-164), `SynthesizerTrn` (:750-871, training forward).
 """
 import torch
 import torch.nn.functional as F
@@ -11,6 +12,7 @@ from torch import nn
 from .. import ops
 from . import attentions, modules
 from .attentions import MultiHeadAttention
+from .quantize import ResidualVectorQuantizer
 from .style_encoder import MelStyleEncoder  # noqa: F401
 from .modules import LRELU_SLOPE, Conv1d, Conv2dK1, Generator, get_padding  # noqa: F401
 
@@ -233,3 +235,62 @@ class TextEncoder(nn.Module):
         stats = self.proj(y, omask=y_mask)
         m, logs = torch.split(stats, self.out_channels, dim=1)
         return y, m, logs
+
+
+def slice_segments(x, ids_str, segment_size=4):
+    """commons.slice_segments (ttts/utils/commons.py:48-54) as one gather instead of a Python loop over the batch."""
+    idx = ids_str.view(-1, 1) + torch.arange(segment_size, device=x.device).view(1, -1)            # (B, seg)
+    return torch.gather(x, 2, idx.unsqueeze(1).expand(-1, x.size(1), -1))
+
+
+def rand_slice_segments(x, x_lengths=None, segment_size=4, ids_str=None):
+    """commons.rand_slice_segments (:57-66); `ids_str` injects the window starts (tests)."""
+    b, d, t = x.size()
+    if x_lengths is None:
+        x_lengths = t
+    if ids_str is None:
+        ids_str_max = x_lengths - segment_size + 1
+        ids_str = (torch.rand([b], device=x.device) * ids_str_max).to(dtype=torch.long)
+    return slice_segments(x, ids_str, segment_size), ids_str
+
+
+class SynthesizerTrn(nn.Module):
+    """Synthesizer for training (vq2.py:750-871): same constructor, `forward(wav, wav_aug, wav_lengths, y, y_aug,
+    y_lengths, text, text_lengths)` and 6-tuple return.  Extra keyword-only hooks `noise_p`, `noise_q`, `ids_slice`
+    inject the three random draws (posterior samples, segment starts) for parity tests."""
+
+    def __init__(self, spec_channels, segment_size, inter_channels, hidden_channels, filter_channels, n_heads, n_layers,
+                 kernel_size, p_dropout, resblock, resblock_kernel_sizes, resblock_dilation_sizes, upsample_rates,
+                 upsample_initial_channel, upsample_kernel_sizes, prosody_size=20, n_speakers=0, gin_channels=0,
+                 semantic_frame_rate=None, freeze_quantizer=None, **kwargs):
+        super().__init__()
+        self.spec_channels, self.inter_channels, self.hidden_channels = spec_channels, inter_channels, hidden_channels
+        self.filter_channels, self.n_heads, self.n_layers, self.kernel_size = filter_channels, n_heads, n_layers, kernel_size
+        self.p_dropout, self.resblock = p_dropout, resblock
+        self.segment_size, self.n_speakers, self.gin_channels, self.mel_size = segment_size, n_speakers, gin_channels, prosody_size
+        self.dec = Generator(inter_channels, resblock, resblock_kernel_sizes, resblock_dilation_sizes, upsample_rates,
+                             upsample_initial_channel, upsample_kernel_sizes, gin_channels=gin_channels)
+        self.enc_p = PosteriorAudioEncoder(spec_channels, inter_channels, hidden_channels, 5, 1, 16, gin_channels=gin_channels)
+        self.enc_p_2 = TextEncoder(inter_channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout)
+        self.enc_q = PosteriorAudioEncoder(spec_channels, inter_channels, hidden_channels, 5, 1, 16, gin_channels=gin_channels)
+        self.flow = ResidualCouplingBlock(inter_channels, hidden_channels, 5, 1, 4, gin_channels=gin_channels)
+        self.ref_enc = MelStyleEncoder(spec_channels, style_vector_dim=gin_channels)
+        self.quantizer = ResidualVectorQuantizer(dimension=inter_channels, n_q=1, bins=1024)
+        self.proj = Conv1d(inter_channels, inter_channels, 2, stride=2)
+        if freeze_quantizer:
+            self.enc_p.requires_grad_(False)
+
+    def forward(self, wav, wav_aug, wav_lengths, y, y_aug, y_lengths, text, text_lengths, *, noise_p=None, noise_q=None,
+                ids_slice=None):
+        y_mask = torch.unsqueeze(sequence_mask(y_lengths, y.size(2)), 1).to(y.dtype)
+        ge = self.ref_enc(modules.mul_mask(y, y_mask), y_mask)
+        x, _, _ = self.enc_p(y_aug, wav_aug.unsqueeze(1), y_mask, g=ge, noise=noise_p)
+        x = self.proj(x)
+        quantized, codes, commit_loss, quantized_list = self.quantizer(x, layers=[0])
+        quantized = modules.upsample_nearest2(quantized)
+        x, m_p, logs_p = self.enc_p_2(quantized, y_lengths, text, text_lengths, ge)
+        z, m_q, logs_q = self.enc_q(y, wav.unsqueeze(1), y_mask, g=ge, noise=noise_q)
+        z_p = self.flow(z, y_mask, g=ge)
+        z_slice, ids_slice = rand_slice_segments(z, y_lengths, self.segment_size, ids_slice)
+        o = self.dec(z_slice, g=ge)
+        return o, commit_loss, ids_slice, y_mask, (z, z_p, m_p, logs_p, m_q, logs_q), quantized
