@@ -575,7 +575,7 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __rest
 
 using namespace ttts;
 
-static int g_debug_flags = 0;
+int g_debug_flags = 0;  // shared with conv.hip (flag 256: direct conv kernels only)
 extern "C" int ttts_debug_set_flags(int32_t flags) {
   g_debug_flags = flags;
   return TTTS_OK;
