@@ -24,6 +24,10 @@ int conv1d_mfma_try(const float* x, const float* w, const float* bias, const flo
                     float out_slope, float out_scale, int accumulate, hipStream_t stream, bool* handled);
 int conv1d_wgrad_mfma_try(const float* dy, const float* x, float* dw, int B, int Cin, int Lin, int Cout, int Lout, int K,
                           int stride, int pad, int dil, float dy_slope, float x_slope, hipStream_t stream, bool* handled);
+int conv1d_dgrad_strided_mfma_try(const float* dy, const float* w, const float* bias, const float* resid,
+                                  const float* gate, const float* omask, float* dx, int B, int Cin, int Lin, int Cout,
+                                  int Lout, int K, int stride, int pad, float in_slope, float gate_slope, float out_scale,
+                                  int accumulate, hipStream_t stream, bool* handled);
 
 constexpr int CV_CT = 32;   // output-channel tile
 constexpr int CV_LT = 128;  // position tile
@@ -244,18 +248,23 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(const float* __restri
   }
 }
 
-// db[c] += sum_{b,l} dy[b][c][l]
+// db[c] += sum_{b,l} dy[b][c][l];  grid (C, splits): a block sums rows b = blockIdx.y, blockIdx.y + gridDim.y, ...
 __global__ __launch_bounds__(256) void conv1d_bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db, int B,
-                                                               int C, int L) {
+                                                               int C, int L, int lchunks) {
   __shared__ float sh[4];
   const int c = blockIdx.x;
   float s = 0.f;
-  for (int b = 0; b < B; ++b)
-    for (int l = threadIdx.x; l < L; l += 256) s += dy[((int64_t)b * C + c) * L + l];
+  // work items = (b, chunk of L); chunk length = ceil(L / lchunks)
+  const int clen = (L + lchunks - 1) / lchunks;
+  for (int it = blockIdx.y; it < B * lchunks; it += gridDim.y) {
+    const int b = it / lchunks, l0 = (it % lchunks) * clen, l1 = min(L, l0 + clen);
+    const float* row = dy + ((int64_t)b * C + c) * L;
+    for (int l = l0 + threadIdx.x; l < l1; l += 256) s += row[l];
+  }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) db[c] += (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  if (threadIdx.x == 0) atomicAdd(db + c, (sh[0] + sh[1]) + (sh[2] + sh[3]));
 }
 
 // weight norm over dim 0 (torch.nn.utils.weight_norm / parametrizations.weight_norm): w[r] = g[r] * v[r] / ||v[r]||
@@ -398,6 +407,12 @@ extern "C" int ttts_conv1d_dgrad_f32(const float* dy, const float* w, const floa
                               dil, 1, in_slope, gate_slope, 0, 1.f, out_scale, accumulate, as_stream(stream), &handled);
     if (rc2 || handled) return rc2;
   }
+  if (groups == 1 && stride > 1 && dil == 1 && !(g_debug_flags & 256)) {
+    bool handled = false;
+    int rc2 = conv1d_dgrad_strided_mfma_try(dy, w, bias, resid, gate, omask, dx, B, Cin, Lin, Cout, Lout, K, stride, pad, in_slope,
+                                            gate_slope, out_scale, accumulate, as_stream(stream), &handled);
+    if (rc2 || handled) return rc2;
+  }
   const int lt = (CV_LT - 1 + (K - 1) * dil) / stride + 2;
   const size_t smem = ((size_t)CV_CI * lt + (size_t)CV_CI * CV_CT * K) * sizeof(float);
   TTTS_REQUIRE(smem <= 160 * 1024, "conv1d_dgrad: tile does not fit LDS");
@@ -442,7 +457,9 @@ extern "C" int ttts_conv1d_wgrad_f32(const float* dy, const float* x, float* dw,
 
 extern "C" int ttts_conv1d_bias_grad_f32(const float* dy, float* db, int32_t B, int32_t C, int32_t L, void* stream) {
   TTTS_REQUIRE(dy && db && B > 0 && C > 0 && L > 0, "conv1d_bias_grad: bad arguments");
-  conv1d_bias_grad_kernel<<<C, 256, 0, as_stream(stream)>>>(dy, db, B, C, L);
+  const int lchunks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(L, 2048), 64));
+  const int splits = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)B * lchunks, cdiv(1024, C)));
+  conv1d_bias_grad_kernel<<<dim3(C, splits), 256, 0, as_stream(stream)>>>(dy, db, B, C, L, lchunks);
   return check_launch("conv1d_bias_grad");
 }
 

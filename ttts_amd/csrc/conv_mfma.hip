@@ -26,7 +26,12 @@ struct ConvMfmaParams {
   float* y;            // output [B, M, Lout]
   int B, M, N, Lin, Lout, K, stride, pad, dil;
   int transposed;      // 1: A[m][n][k] = w[n][m][K-1-k]  (stride-1 data gradient)
-  int NT;              // input channels per LDS stage (8 or 16)
+  int NT;              // input channels per LDS stage (multiple of 8)
+  // polyphase view used by strided data gradients / transposed convolutions (identity: Kmem = K, 0, 1, 1, 0, Lout)
+  int Kmem;            // taps per (m, n) pair in memory
+  int tap_off, tap_stride;   // effective tap q reads memory tap tap_off + tap_stride * q
+  int out_stride, out_off;   // local output index t writes position out_off + t * out_stride
+  int LoutTotal;       // row length of the output tensor
   float in_slope, gate_slope;
   int out_act; float out_slope, out_scale; int accumulate;
 };
@@ -55,7 +60,10 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvMfmaParams p) {
   const int in0 = j0 * p.stride - p.pad;
   for (int f = tid; f < KK; f += 256) foff[f] = (f / p.K) * lin_t + (f % p.K) * p.dil;
   if (p.transposed)
-    for (int i = tid; i < MT * p.K; i += 256) tmap[i] = (i / p.K) * wpitch + (p.K - 1 - i % p.K);
+    for (int i = tid; i < MT * p.Kmem; i += 256) {
+      const int km = i % p.Kmem - p.tap_off;          // memory tap -> effective tap q (if on this phase) -> flipped slot
+      tmap[i] = (km >= 0 && km % p.tap_stride == 0 && km / p.tap_stride < p.K) ? (i / p.Kmem) * wpitch + (p.K - 1 - km / p.tap_stride) : -1;
+    }
   f32x16 acc0, acc1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
@@ -85,11 +93,14 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvMfmaParams p) {
         for (int f = lq; f < KK; f += 256 / MT) wd[f] = f < flim ? wr[f] : 0.f;
       } else {
         // A[m][n][k] = w[n][m][K-1-k]  (w is [N][M][K] here): for one n the MT*K values w[n][m0 .. m0+MT)[:] are contiguous
-        const int cnt = min(MT, p.M - m0) * p.K;
+        const int cnt = min(MT, p.M - m0) * p.Kmem;
         for (int n = wave; n < NT; n += 4) {
           const bool nok = n0 + n < p.N;
-          const float* wr = p.w + ((int64_t)(n0 + n) * p.M + m0) * p.K;
-          for (int i = lane; i < MT * p.K; i += 64) ws[tmap[i] + n * p.K] = (nok && i < cnt) ? wr[i] : 0.f;
+          const float* wr = p.w + ((int64_t)(n0 + n) * p.M + m0) * p.Kmem;
+          for (int i = lane; i < MT * p.Kmem; i += 64) {
+            const int slot = tmap[i];
+            if (slot >= 0) ws[slot + n * p.K] = (nok && i < cnt) ? wr[i] : 0.f;
+          }
         }
       }
     }
@@ -105,14 +116,15 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvMfmaParams p) {
   // ---- epilogue
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    const int j = j0 + wl * 64 + t * 32 + col;
-    if (j >= p.Lout) continue;
-    const float om = p.omask ? p.omask[(int64_t)b * p.Lout + j] : 1.f;
+    const int jt = j0 + wl * 64 + t * 32 + col;
+    if (jt >= p.Lout) continue;
+    const int j = p.out_off + jt * p.out_stride;
+    const float om = p.omask ? p.omask[(int64_t)b * p.LoutTotal + j] : 1.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = m0 + wco * 32 + acc_row(r, hh);
       if (m >= p.M) continue;
-      const int64_t o = ((int64_t)b * p.M + m) * p.Lout + j;
+      const int64_t o = ((int64_t)b * p.M + m) * p.LoutTotal + j;
       float v = (t == 0 ? acc0[r] : acc1[r]) + (p.bias ? p.bias[m] : 0.f);
       if (p.bbias) v += p.bbias[(int64_t)b * p.M + m];
       if (p.gate) v *= (p.gate[o] > 0.f ? 1.f : p.gate_slope);
@@ -198,26 +210,22 @@ static int set_attr_once(const void* fn, bool& done) {
 
 // ---- dispatch helpers used by conv.hip ------------------------------------------------------------------------------------
 // Returns TTTS_OK and sets *handled when the MFMA path took the launch.
-int conv1d_mfma_try(const float* x, const float* w, const float* bias, const float* bbias, const float* resid,
-                    const float* gate, const float* omask, float* y, int B, int M, int N, int Lin, int Lout, int K,
-                    int stride, int pad, int dil, int transposed, float in_slope, float gate_slope, int out_act,
-                    float out_slope, float out_scale, int accumulate, hipStream_t stream, bool* handled) {
+static int conv1d_mfma_launch(ConvMfmaParams p, hipStream_t stream, bool* handled) {
   *handled = false;
-  if (N < 8 || M < 8 || K > 16) return TTTS_OK;            // thin layers / long taps stay on the direct kernels
-  const bool narrow = M <= 32;
+  const bool narrow = p.M <= 32;
   const int LT = narrow ? 256 : 128, MT = narrow ? 32 : 64;
-  const int lin_t = (LT - 1) * stride + (K - 1) * dil + 1;
+  const int K = p.K;
+  const int lin_t = (LT - 1) * p.stride + (K - 1) * p.dil + 1;
   auto smem_for = [&](int nt) {
-    return ((size_t)nt * lin_t + (size_t)MT * ((nt * K) | 1)) * sizeof(float) + ((size_t)nt * K + (size_t)MT * K) * sizeof(int);
+    return ((size_t)nt * lin_t + (size_t)MT * ((nt * K) | 1)) * sizeof(float) + ((size_t)nt * K + (size_t)MT * p.Kmem) * sizeof(int);
   };
   // aim at ~96 reduction indices per stage (amortises the barrier pair), within 48 KB so that >= 3 workgroups share a CU
   int NT = std::min(64, std::max(8, (int)cdiv(96, K) / 8 * 8));
-  while (NT > 8 && (NT > (N + 7) / 8 * 8 || smem_for(NT) > 48 * 1024)) NT -= 8;
+  while (NT > 8 && (NT > (p.N + 7) / 8 * 8 || smem_for(NT) > 48 * 1024)) NT -= 8;
   const size_t smem = smem_for(NT);
   if (smem > 96 * 1024) return TTTS_OK;
-  ConvMfmaParams p{x, w, bias, bbias, resid, omask, gate, y, B, M, N, Lin, Lout, K, stride, pad, dil, transposed, NT,
-                   in_slope, gate_slope, out_act, out_slope, out_scale, accumulate};
-  dim3 grid((unsigned)cdiv(Lout, LT), (unsigned)cdiv(M, MT), (unsigned)B);
+  p.NT = NT;
+  dim3 grid((unsigned)cdiv(p.Lout, LT), (unsigned)cdiv(p.M, MT), (unsigned)p.B);
   static bool a1 = false, a2 = false;
   if (narrow) {
     int rc = set_attr_once(reinterpret_cast<const void*>(conv1d_mfma_kernel<1>), a1);
@@ -230,6 +238,44 @@ int conv1d_mfma_try(const float* x, const float* w, const float* bias, const flo
   }
   *handled = true;
   return check_launch("conv1d_mfma");
+}
+
+// Returns TTTS_OK and sets *handled when the MFMA path took the launch.
+int conv1d_mfma_try(const float* x, const float* w, const float* bias, const float* bbias, const float* resid,
+                    const float* gate, const float* omask, float* y, int B, int M, int N, int Lin, int Lout, int K,
+                    int stride, int pad, int dil, int transposed, float in_slope, float gate_slope, int out_act,
+                    float out_slope, float out_scale, int accumulate, hipStream_t stream, bool* handled) {
+  *handled = false;
+  if (N < 8 || M < 8 || K > 16) return TTTS_OK;            // thin layers / long taps stay on the direct kernels
+  ConvMfmaParams p{x, w, bias, bbias, resid, omask, gate, y, B, M, N, Lin, Lout, K, stride, pad, dil, transposed, 0,
+                   K, 0, 1, 1, 0, Lout, in_slope, gate_slope, out_act, out_slope, out_scale, accumulate};
+  return conv1d_mfma_launch(p, stream, handled);
+}
+
+// Data gradient of a stride-s convolution (== forward of a ConvTranspose1d), dilation 1, as s stride-1 sub-convolutions:
+// output phase phi = (j + pad) mod s only sees the taps k = phi + s q, so
+//   dx[s t' + phi - pad] = sum_{co, q} w[co][ci][phi + s q] * dy[co][t' - q].
+int conv1d_dgrad_strided_mfma_try(const float* dy, const float* w, const float* bias, const float* resid,
+                                  const float* gate, const float* omask, float* dx, int B, int Cin, int Lin, int Cout,
+                                  int Lout, int K, int stride, int pad, float in_slope, float gate_slope, float out_scale,
+                                  int accumulate, hipStream_t stream, bool* handled) {
+  *handled = false;
+  if (Cout < 8 || Cin < 8 || K > 16 * stride || K < stride) return TTTS_OK;
+  for (int phi = 0; phi < stride; ++phi) {
+    const int Kp = (K - phi + stride - 1) / stride;                       // taps of this phase (>= 1 since K >= stride)
+    const int tmin = phi >= pad ? 0 : (pad - phi + stride - 1) / stride;  // first t' with a non-negative output position
+    const int off = stride * tmin + phi - pad;
+    if (off >= Lin) continue;
+    const int T = (Lin - 1 - off) / stride + 1;
+    ConvMfmaParams p{dy, w, bias, nullptr, resid, omask, gate, dx, B, Cin, Cout, Lout, T, Kp, 1, (Kp - 1) - tmin, 1, 1, 0,
+                     K, phi, stride, stride, off, Lin, in_slope, gate_slope, 0, 1.f, out_scale, accumulate};
+    bool h = false;
+    int rc = conv1d_mfma_launch(p, stream, &h);
+    if (rc) return rc;
+    if (!h) return phi == 0 ? TTTS_OK : fail(TTTS_EUNSUPPORTED, "conv1d_dgrad: polyphase tile does not fit LDS");
+  }
+  *handled = true;
+  return TTTS_OK;
 }
 
 int conv1d_wgrad_mfma_try(const float* dy, const float* x, float* dw, int B, int Cin, int Lin, int Cout, int Lout, int K,
