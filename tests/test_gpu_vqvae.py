@@ -483,3 +483,45 @@ def test_vqvae_checkpoint_roundtrip(tmp_path, golden_dir):
     assert tr.load_latest() == 7
     assert torch.equal(tr.optim_g.flat_p, want_p) and torch.equal(tr.optim_g.exp_avg, want_m)
     assert tr.optim_g.state[0].item() == 1.0
+
+
+VQ_WORKER = r"""
+import os, sys, json, torch
+sys.path.insert(0, ROOT)
+from ttts_amd.vqvae.train import SyntheticVqvaeBatches, VqvaeTrainer, get_hparams
+hps = get_hparams()
+hps.vqvae.p_dropout = 0.0
+tr = VqvaeTrainer(hps)
+assert tr.dp.enabled and tr.world == 2
+cb = tr.net_g.quantizer.vq.layers[0]._codebook
+with torch.no_grad():
+    cb.inited.fill_(1); cb.embed.normal_(0, 0.3); cb.embed_avg.copy_(cb.embed * 4); cb.cluster_size.fill_(4.0)
+loader = iter(SyntheticVqvaeBatches(1, n_samples=32000, text_len=12, seed=100 + tr.rank, device=tr.device))
+for _ in range(2):
+    out = tr.train_step(next(loader))
+torch.cuda.synchronize()
+vals = {k: float(v) for k, v in out.items()}
+assert all(v == v and abs(v) < 1e9 for v in vals.values()), vals
+# replicas must stay identical: same parameters after the all-reduced updates, same (rank-0) codebook
+chk = torch.stack([tr.optim_g.flat_p.double().sum(), tr.optim_d.flat_p.double().sum(), cb.embed.double().sum()]).cpu()
+gathered = [torch.zeros_like(chk) for _ in range(2)]
+torch.distributed.all_gather(gathered, chk)
+assert torch.equal(gathered[0][:2], gathered[1][:2]), gathered
+sys.stdout.write("rank" + str(tr.rank) + "-ok " + json.dumps(vals) + "\n")
+"""
+
+
+def test_vqvae_two_ranks_sharing_the_gpu(tmp_path):
+    """N > 1 control flow of the VQ-VAE-GAN trainer on the one GPU of the test box (gloo, both ranks on cuda:0): parameter
+    broadcast, codebook broadcast, the two flat gradient all-reduces; replicas stay bit-identical."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "vq_worker.py"
+    script.write_text("ROOT = %r\n" % root + VQ_WORKER)
+    env = dict(os.environ, TTTS_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(29900 + os.getpid() % 90), str(script)],
+                       capture_output=True, text=True, env=env, timeout=400)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "rank0-ok" in r.stdout and "rank1-ok" in r.stdout

@@ -32,6 +32,8 @@ struct ConvMfmaParams {
   int tap_off, tap_stride;   // effective tap q reads memory tap tap_off + tap_stride * q
   int out_stride, out_off;   // local output index t writes position out_off + t * out_stride
   int LoutTotal;       // row length of the output tensor
+  int SEG;             // positions per batch segment of a tile: LT (one batch element per tile) or 32 / 64 -- short rows
+                       // (DiscriminatorP's late layers: 23..127 positions) fold several batch elements into one tile
   float in_slope, gate_slope;
   int out_act; float out_slope, out_scale; int accumulate;
 };
@@ -49,14 +51,16 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvMfmaParams p) {
   const int NT = p.NT;
   const int KK = NT * p.K;                     // reduction indices per stage (even)
   const int wpitch = KK | 1;                   // odd pitch: conflict-free A-fragment reads
-  const int lin_t = (LT - 1) * p.stride + (p.K - 1) * p.dil + 1;
-  float* xs = cm_smem;                         // [NT][lin_t]
+  const int SEG = p.SEG, nseg = LT / SEG;
+  const int lin_s = (SEG - 1) * p.stride + (p.K - 1) * p.dil + 1;      // input strip of one segment
+  const int lin_t = nseg * lin_s;
+  float* xs = cm_smem;                         // [NT][nseg][lin_s]
   float* ws = xs + NT * lin_t;                 // [MT][wpitch]
   int* foff = reinterpret_cast<int*>(ws + MT * wpitch);   // [KK]: (n_local, k) -> n_local * lin_t + k * dil
   int* tmap = foff + KK;                                  // transposed loader: i = m*K + k -> m * wpitch + (K-1-k)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, col = lane & 31;
   const int wco = wave % WCO, wl = wave / WCO;
-  const int j0 = blockIdx.x * LT, m0 = blockIdx.y * MT, b = blockIdx.z;
+  const int j0 = blockIdx.x * LT, m0 = blockIdx.y * MT, b0 = blockIdx.z * nseg;   // folded tiles: gridDim.x == 1, j0 == 0
   const int in0 = j0 * p.stride - p.pad;
   for (int f = tid; f < KK; f += 256) foff[f] = (f / p.K) * lin_t + (f % p.K) * p.dil;
   if (p.transposed)
@@ -67,20 +71,25 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvMfmaParams p) {
   f32x16 acc0, acc1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-  const float* xb = p.x + (int64_t)b * p.N * p.Lin;
+  const float* xb = p.x + (int64_t)b0 * p.N * p.Lin;
   const float* arow = ws + (wco * 32 + col) * wpitch + hh;
-  const int bpos0 = (wl * 64 + col) * p.stride, bpos1 = bpos0 + 32 * p.stride;
+  // column c of the tile -> segment c / SEG (a 32-column MFMA tile never straddles segments), position c % SEG
+  const int c0 = wl * 64 + col, c1 = c0 + 32;
+  const int bpos0 = (c0 / SEG) * lin_s + (c0 % SEG) * p.stride, bpos1 = (c1 / SEG) * lin_s + (c1 % SEG) * p.stride;
   const int lrow = tid / (256 / MT), lq = tid % (256 / MT);     // weight loader: 256 / MT threads per output-channel row
   for (int n0 = 0; n0 < p.N; n0 += NT) {
     __syncthreads();
     // input strip: one wave per channel row at a time, lanes along positions (coalesced, no index arithmetic)
     for (int n = wave; n < NT; n += 4) {
       const bool nok = n0 + n < p.N;
-      const float* xr = xb + (int64_t)(n0 + n) * p.Lin;
-      float* xd = xs + n * lin_t;
-      for (int pos = lane; pos < lin_t; pos += 64) {
-        const int gi = in0 + pos;
-        xd[pos] = (nok && gi >= 0 && gi < p.Lin) ? lrelu_f(xr[gi], p.in_slope) : 0.f;
+      for (int sg = 0; sg < nseg; ++sg) {
+        const bool bok = nok && b0 + sg < p.B;
+        const float* xr = xb + ((int64_t)sg * p.N + n0 + n) * p.Lin;
+        float* xd = xs + n * lin_t + sg * lin_s;
+        for (int pos = lane; pos < lin_s; pos += 64) {
+          const int gi = in0 + pos;
+          xd[pos] = (bok && gi >= 0 && gi < p.Lin) ? lrelu_f(xr[gi], p.in_slope) : 0.f;
+        }
       }
     }
     {
@@ -116,8 +125,9 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvMfmaParams p) {
   // ---- epilogue
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    const int jt = j0 + wl * 64 + t * 32 + col;
-    if (jt >= p.Lout) continue;
+    const int ct = wl * 64 + t * 32 + col;
+    const int b = b0 + ct / SEG, jt = j0 + ct % SEG;
+    if (jt >= p.Lout || b >= p.B) continue;
     const int j = p.out_off + jt * p.out_stride;
     const float om = p.omask ? p.omask[(int64_t)b * p.LoutTotal + j] : 1.f;
 #pragma unroll
@@ -215,7 +225,9 @@ static int conv1d_mfma_launch(ConvMfmaParams p, hipStream_t stream, bool* handle
   const bool narrow = p.M <= 32;
   const int LT = narrow ? 256 : 128, MT = narrow ? 32 : 64;
   const int K = p.K;
-  const int lin_t = (LT - 1) * p.stride + (K - 1) * p.dil + 1;
+  const int SEG = (p.Lout <= 32 && p.B > 1) ? 32 : ((p.Lout <= 64 && p.B > 1) ? 64 : LT);
+  p.SEG = SEG;
+  const int lin_t = (LT / SEG) * ((SEG - 1) * p.stride + (K - 1) * p.dil + 1);
   auto smem_for = [&](int nt) {
     return ((size_t)nt * lin_t + (size_t)MT * ((nt * K) | 1)) * sizeof(float) + ((size_t)nt * K + (size_t)MT * p.Kmem) * sizeof(int);
   };
@@ -225,7 +237,7 @@ static int conv1d_mfma_launch(ConvMfmaParams p, hipStream_t stream, bool* handle
   const size_t smem = smem_for(NT);
   if (smem > 96 * 1024) return TTTS_OK;
   p.NT = NT;
-  dim3 grid((unsigned)cdiv(p.Lout, LT), (unsigned)cdiv(p.M, MT), (unsigned)p.B);
+  dim3 grid((unsigned)cdiv(p.Lout, SEG == LT ? LT : SEG), (unsigned)cdiv(p.M, MT), (unsigned)cdiv(p.B, LT / SEG));
   static bool a1 = false, a2 = false;
   if (narrow) {
     int rc = set_attr_once(reinterpret_cast<const void*>(conv1d_mfma_kernel<1>), a1);
@@ -248,7 +260,7 @@ int conv1d_mfma_try(const float* x, const float* w, const float* bias, const flo
   *handled = false;
   if (N < 8 || M < 8 || K > 16) return TTTS_OK;            // thin layers / long taps stay on the direct kernels
   ConvMfmaParams p{x, w, bias, bbias, resid, omask, gate, y, B, M, N, Lin, Lout, K, stride, pad, dil, transposed, 0,
-                   K, 0, 1, 1, 0, Lout, in_slope, gate_slope, out_act, out_slope, out_scale, accumulate};
+                   K, 0, 1, 1, 0, Lout, 0, in_slope, gate_slope, out_act, out_slope, out_scale, accumulate};
   return conv1d_mfma_launch(p, stream, handled);
 }
 
@@ -268,7 +280,7 @@ int conv1d_dgrad_strided_mfma_try(const float* dy, const float* w, const float* 
     if (off >= Lin) continue;
     const int T = (Lin - 1 - off) / stride + 1;
     ConvMfmaParams p{dy, w, bias, nullptr, resid, omask, gate, dx, B, Cin, Cout, Lout, T, Kp, 1, (Kp - 1) - tmin, 1, 1, 0,
-                     K, phi, stride, stride, off, Lin, in_slope, gate_slope, 0, 1.f, out_scale, accumulate};
+                     K, phi, stride, stride, off, Lin, 0, in_slope, gate_slope, 0, 1.f, out_scale, accumulate};
     bool h = false;
     int rc = conv1d_mfma_launch(p, stream, &h);
     if (rc) return rc;
