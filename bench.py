@@ -190,8 +190,16 @@ def main():
             agg = kt.summary()
         fam, (cnt, secs, flops) = max(agg.items(), key=lambda kv: kv[1][1])
         ach = flops / secs / 1e12
+        # HBM-side bytes per launch from the separate rocprofv3 --pmc passes (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE), see
+        # profiles/pmc_traffic.json; null when no counter run exists for this kernel family
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")))
+            traffic = pmc["traffic_bytes_per_launch"].get(fam)
+        except Exception:
+            traffic = None
         roof = {"bound": "mfma", "kernel": fam, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                 "launches_per_step": cnt // args.profile_steps, "avg_launch_us": round(secs / cnt * 1e6, 2),
                 "avg_gflop_per_launch": round(flops / cnt / 1e9, 3),
                 "all_kernels_ms_per_step": {k: round(v[1] / args.profile_steps * 1e3, 3) for k, v in sorted(agg.items())},
