@@ -94,8 +94,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, g = lane >> 4, ip = lane & 15;
   const int nqb = (p.S + 127) / 128;
-  const int qb = nqb - 1 - (int)(blockIdx.x % nqb);  // heaviest (latest) query blocks first
-  const int bh = blockIdx.x / nqb, h = bh % p.H, b = bh / p.H;
+  // global longest-first order: ALL (b, h) pairs' heaviest (latest) query blocks are dispatched first, the 2-tile blocks
+  // last, so the tail of the launch is made of short blocks (causal work per block: 2 .. 19 KV tiles)
+  const int nbh = gridDim.x / nqb;
+  const int qb = nqb - 1 - (int)(blockIdx.x / nbh);
+  const int bh = blockIdx.x % nbh, h = bh % p.H, b = bh / p.H;
   const int q_base = qb * 128 + wave * 32;
   const int query = q_base + (lane & 31);
   const bf16* qp = p.q + (int64_t)b * p.sb + h * DH;
@@ -254,8 +257,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, g = lane >> 4, ip = lane & 15;
   const int nqb = (p.S + 127) / 128;
-  const int qb = nqb - 1 - (int)(blockIdx.x % nqb);
-  const int bh = blockIdx.x / nqb, h = bh % p.H, b = bh / p.H;
+  const int nbh = gridDim.x / nqb;
+  const int qb = nqb - 1 - (int)(blockIdx.x / nbh);   // global longest-first order (see attn_fwd_kernel)
+  const int bh = blockIdx.x % nbh, h = bh % p.H, b = bh / p.H;
   const int q_base = qb * 128 + wave * 32;
   const int query = q_base + (lane & 31);
   const bf16* qp = p.q + (int64_t)b * p.sb + h * DH;
@@ -371,8 +375,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, g = lane >> 4, ip = lane & 15;
   const int nkb = (p.S + 127) / 128;
-  const int kblk = (int)(blockIdx.x % nkb);  // earliest key blocks see the most queries: they come first
-  const int bh = blockIdx.x / nkb, h = bh % p.H, b = bh / p.H;
+  const int nbh = gridDim.x / nkb;
+  const int kblk = (int)(blockIdx.x / nbh);  // earliest key blocks see the most queries: all of them come first
+  const int bh = blockIdx.x % nbh, h = bh % p.H, b = bh / p.H;
   const int k_base = kblk * 128 + wave * 32;
   const int key = k_base + (lane & 31);
   const bf16* qp = p.q + (int64_t)b * p.sb + h * DH;
@@ -446,6 +451,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
         for (int qd = 0; qd < 4; ++qd) {
           const f32x4 l4 = *reinterpret_cast<const f32x4*>(&Ls[buf][qs * 32 + 8 * qd + 4 * hh]);
           const f32x4 d4 = *reinterpret_cast<const f32x4*>(&Dl[buf][qs * 32 + 8 * qd + 4 * hh]);
+          // dropout bits: the elements (query, key) and (query, key ^ 1) share one 32-bit hash (Sp is even), i.e. the two
+          // lanes of a pair need the same 4 hashes for the 4 rows of this group: each computes two and they swap by DPP
+          bool keep4[4] = {true, true, true, true};
+          if (DROPOUT) {
+            const int odd = lane & 1;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const int qmine = q0 + qs * 32 + 8 * qd + 4 * hh + 2 * t + odd;      // even lane: row 2t, odd lane: row 2t+1
+              const uint32_t mine = hash32(((e_bh + (uint32_t)qmine) * (uint32_t)p.Sp + (uint32_t)key) >> 1, p.seed_lo, shi);
+              const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+              const uint32_t h0 = odd ? other : mine, h1 = odd ? mine : other;   // hashes of rows 2t and 2t+1
+              keep4[2 * t] = (odd ? (h0 >> 16) : (h0 & 0xFFFFu)) >= p.thr;
+              keep4[2 * t + 1] = (odd ? (h1 >> 16) : (h1 & 0xFFFFu)) >= p.thr;
+            }
+          }
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int r = 4 * qd + e;
@@ -454,7 +474,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
             float dpv = dp[r];
             float pd = pv;
             if (DROPOUT) {
-              const bool keep = drop_keep((e_bh + (uint32_t)query) * (uint32_t)p.Sp + (uint32_t)key, p.thr, p.seed_lo, shi);
+              const bool keep = keep4[e];
               dpv = keep ? dpv * p.inv_keep : 0.f;
               pd = keep ? pv * p.inv_keep : 0.f;
             }
