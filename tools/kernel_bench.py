@@ -57,13 +57,20 @@ def bench_gemm():
             row[tag] = "%.1f us  %.0f TF/s" % (us, fl / us / 1e6)
         lib.get().ttts_debug_set_flags(0)
         out[name + " M%d N%d K%d" % (M, N, K)] = row
-    for name, Mo, No in (("dW c_attn", 512, 1536), ("dW c_fc", 512, 2048), ("dW mlp c_proj", 2048, 512), ("dW attn c_proj", 512, 512)):
-        at = torch.randn(M, Mo, device=dev).to(torch.bfloat16)
-        bt = torch.randn(M, No, device=dev).to(torch.bfloat16)
+    Kr = 9280      # the engine zero-pads the reduction rows to a multiple of 64
+    for name, Mo, No in (("dW c_attn", 512, 1536), ("dW c_fc", 512, 2048), ("dW mlp c_proj", 2048, 512), ("dW attn c_proj", 512, 512),
+                         ("dW mel_head", 1032, 512)):
+        at = torch.randn(Kr, (Mo + 7) // 8 * 8, device=dev).to(torch.bfloat16)
+        bt = torch.randn(Kr, No, device=dev).to(torch.bfloat16)
         c = torch.zeros(Mo, No, device=dev)
-        ws = ops.gemm_tn_workspace(Mo, No, M, dev)
-        us = timeit(lambda: ops.gemm_tn_accum(at, bt, c, workspace=ws))
-        out[name] = "%.1f us  %.0f TF/s (incl. slab reduce)" % (us, 2.0 * M * Mo * No / us / 1e6)
+        row = {}
+        for flag, tag in ((512, "target256"), (0, "target384"), (1024, "target512")):
+            lib.get().ttts_debug_set_flags(flag)
+            ws = ops.gemm_tn_workspace(Mo, No, Kr, dev)
+            us = timeit(lambda: ops.gemm_tn_accum(at, bt, c, workspace=ws))
+            row[tag] = "%.1f us  %.0f TF/s (incl. slab reduce)" % (us, 2.0 * Kr * Mo * No / us / 1e6)
+        lib.get().ttts_debug_set_flags(0)
+        out[name] = row
     return out
 
 

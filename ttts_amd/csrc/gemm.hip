@@ -623,11 +623,14 @@ extern "C" int ttts_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int6
   return ttts_gemm_nt_bf16_ex(A, lda, B, ldb, C, ldc, bias, aux, M, N, K, epilogue, nullptr, 0.f, 0, stream);
 }
 
+extern int g_debug_flags;
 static void tn_plan(int Mo, int No, int Kr, int& splits, int& k_chunk) {
   const int tiles = (int)(cdiv(Mo, BM) * cdiv(No, BN));
   // enough workgroups to fill 256 CUs (~1.5 per CU), as few slabs as possible, >= 256 reduction rows per split;
   // k_chunk is a multiple of 64 so that the LDS-DMA kernel can take every split whole
-  splits = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(Kr, 256), (384 + tiles / 2) / tiles));
+  // measured (tools/kernel_bench.py gemm, MI355X): 384 workgroups beats 256 by 10-15 % and ties or beats 512 (more slabs)
+  const int target = (g_debug_flags & 512) ? 256 : ((g_debug_flags & 1024) ? 512 : 384);
+  splits = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(Kr, 256), (target + tiles / 2) / tiles));
   k_chunk = (int)(cdiv(cdiv(Kr, splits), 64) * 64);
   splits = (int)cdiv(Kr, k_chunk);
 }
