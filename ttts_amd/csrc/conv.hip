@@ -248,6 +248,213 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(const float* __restri
   }
 }
 
+// ---- grouped convolutions with few channels per group (DiscriminatorS: k41, stride 4, groups 4..256, 4 input channels
+// per group): one workgroup covers 32 consecutive channels of the FULL tensor, i.e. several groups at once, so the lanes
+// stay busy where the per-group kernels above would use 4 or 16 of their 32 channel rows. ------------------------------------
+// forward: p.Cin / p.Cout are per-group counts (cig / cog); requires cog % 4 == 0 and (32 % cog == 0 or cog % 32 == 0)
+__global__ __launch_bounds__(256) void conv1d_fwd_grouped_kernel(ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) float cv_smem[];
+  const int cig = p.Cin, cog = p.Cout, CoutT = p.G * cog, CinT = p.G * cig;
+  const int ngt = cog >= CV_CT ? 1 : CV_CT / cog;            // groups per tile
+  const int nci = ngt * cig;                                 // input channels staged per tile
+  const int lin_t = (CV_LT - 1) * p.stride + (p.K - 1) * p.dil + 1;
+  float* xs = cv_smem;                      // [nci][lin_t]
+  float* ws = cv_smem + nci * lin_t;        // [CV_CT][cig][K]
+  const int tid = threadIdx.x, tl = tid & 31, tc = tid >> 5;
+  const int l0 = blockIdx.x * CV_LT, co0 = blockIdx.y * CV_CT, b = blockIdx.z;
+  const int g0 = co0 / cog, ci0 = g0 * cig;
+  const int in0 = l0 * p.stride - p.pad;
+  const float* xb = p.x + (int64_t)b * CinT * p.Lin;
+  for (int c = tid >> 6; c < nci; c += 4) {
+    const bool cok = ci0 + c < CinT;
+    const float* xr = xb + (int64_t)(ci0 + c) * p.Lin;
+    for (int pos = tid & 63; pos < lin_t; pos += 64) {
+      const int gi = in0 + pos;
+      xs[c * lin_t + pos] = (cok && gi >= 0 && gi < p.Lin) ? lrelu(xr[gi], p.in_slope) : 0.f;
+    }
+  }
+  const int wk = cig * p.K;
+  for (int i = tid; i < CV_CT * wk; i += 256) {
+    const int co = i / wk;
+    ws[i] = co0 + co < CoutT ? p.w[(int64_t)(co0 + co) * wk + (i - co * wk)] : 0.f;
+  }
+  __syncthreads();
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  const int gl = (co0 + tc * 4) / cog - g0;                  // this thread's group within the tile
+  for (int ci = 0; ci < cig; ++ci) {
+    const float* xr = xs + (gl * cig + ci) * lin_t;
+    for (int k = 0; k < p.K; ++k) {
+      float xv[4], wv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xv[j] = xr[(tl + 32 * j) * p.stride + k * p.dil];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wv[i] = ws[(tc * 4 + i) * wk + ci * p.K + k];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(wv[i], xv[j], acc[i][j]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int cg = co0 + tc * 4 + i;
+    if (cg >= CoutT) continue;
+    float bv = p.bias ? p.bias[cg] : 0.f;
+    if (p.bbias) bv += p.bbias[(int64_t)b * CoutT + cg];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int l = l0 + tl + 32 * j;
+      if (l >= p.Lout) continue;
+      const int64_t o = ((int64_t)b * CoutT + cg) * p.Lout + l;
+      float v = acc[i][j] + bv;
+      if (p.gate) v *= (p.gate[o] > 0.f ? 1.f : p.gate_slope);
+      if (p.resid) v += p.resid[o];
+      if (p.out_act == 1) v = tanhf(v);
+      else if (p.out_act == 2) v = lrelu(v, p.out_slope);
+      if (p.omask) v *= p.omask[(int64_t)b * p.Lout + l];
+      v *= p.out_scale;
+      p.y[o] = p.accumulate ? p.y[o] + v : v;
+    }
+  }
+}
+
+// data gradient, grouped: tile = 32 consecutive INPUT channels (32 / cig groups) x 128 positions; cig % 4 == 0, 32 % cig == 0
+__global__ __launch_bounds__(256) void conv1d_dgrad_grouped_kernel(ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) float cv_smem[];
+  const int cig = p.Cin, cog = p.Cout, CoutT = p.G * cog, CinT = p.G * cig;
+  const int ngt = CV_CT / cig, nco = ngt * cog;              // groups / output channels feeding this tile
+  const int j0 = blockIdx.x * CV_LT, ci0 = blockIdx.y * CV_CT, b = blockIdx.z;
+  const int g0 = ci0 / cig, co0 = g0 * cog;
+  const int lo = j0 + p.pad - (p.K - 1) * p.dil;
+  const int lmin = lo <= 0 ? 0 : (lo + p.stride - 1) / p.stride;
+  const int lt = (CV_LT - 1 + (p.K - 1) * p.dil) / p.stride + 2;
+  float* ds = cv_smem;                  // [nco][lt]
+  float* ws = cv_smem + nco * lt;       // [nco][cig][K]
+  const int tid = threadIdx.x, tl = tid & 31, tc = tid >> 5;
+  const float* dyb = p.x + (int64_t)b * CoutT * p.Lout;
+  for (int c = tid >> 6; c < nco; c += 4) {
+    const bool cok = co0 + c < CoutT;
+    const float* dr = dyb + (int64_t)(co0 + c) * p.Lout;
+    for (int pos = tid & 63; pos < lt; pos += 64) {
+      const int l = lmin + pos;
+      ds[c * lt + pos] = (cok && l < p.Lout) ? lrelu(dr[l], p.in_slope) : 0.f;
+    }
+  }
+  const int wk = cig * p.K;
+  for (int i = tid; i < nco * wk; i += 256) {
+    const int co = i / wk;
+    ws[i] = co0 + co < CoutT ? p.w[(int64_t)(co0 + co) * wk + (i - co * wk)] : 0.f;
+  }
+  __syncthreads();
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  const int gl = (tc * 4) / cig, cl = (tc * 4) % cig;       // group within the tile, first input channel within the group
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    const int t0 = j0 + tl + 32 * jj + p.pad;
+    const int kfirst = p.stride == 1 ? 0 : t0 % p.stride;
+    for (int k = kfirst; k < p.K; k += p.stride) {
+      const int t = t0 - k * p.dil;
+      if (t < 0) break;
+      const int l = t / p.stride;
+      if (l >= p.Lout) continue;
+      const int pos = l - lmin;
+      if (pos < 0 || pos >= lt) continue;
+      for (int co = 0; co < cog; ++co) {
+        const float dv = ds[(gl * cog + co) * lt + pos];
+        const float* wr = ws + (gl * cog + co) * wk + cl * p.K + k;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][jj] = fmaf(wr[i * p.K], dv, acc[i][jj]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int cg = ci0 + tc * 4 + i;
+    if (cg >= CinT) continue;
+    const float bv = p.bias ? p.bias[cg] : 0.f;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int j = j0 + tl + 32 * jj;
+      if (j >= p.Lin) continue;
+      const int64_t o = ((int64_t)b * CinT + cg) * p.Lin + j;
+      float v = acc[i][jj] + bv;
+      if (p.gate) v *= (p.gate[o] > 0.f ? 1.f : p.gate_slope);
+      if (p.resid) v += p.resid[o];
+      if (p.omask) v *= p.omask[(int64_t)b * p.Lin + j];
+      v *= p.out_scale;
+      p.y[o] = p.accumulate ? p.y[o] + v : v;
+    }
+  }
+}
+
+// weight gradient, grouped: workgroup = 16 consecutive output channels x all cig*K taps (<= 256), thread = one channel x
+// up to 16 taps; 64 output positions of one batch element per stage
+constexpr int WGG_ACC = 16;
+__global__ __launch_bounds__(256) void conv1d_wgrad_grouped_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                   float* __restrict__ dw, int B, int cig, int Lin, int cog,
+                                                                   int Lout, int K, int stride, int pad, int dil, int G,
+                                                                   float dy_slope, float x_slope, int chunks_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float cv_smem[];
+  const int CoutT = G * cog, CinT = G * cig, wk = cig * K;
+  const int lin_t = (WG_L - 1) * stride + (K - 1) * dil + 1;
+  const int ngt = cog >= 16 ? 1 : 16 / cog, nci = ngt * cig;
+  float* dys = cv_smem;                     // [16][WG_L + 1]
+  float* xs = cv_smem + 16 * (WG_L + 1);    // [nci][lin_t]
+  const int tid = threadIdx.x, tco = tid >> 4, tq = tid & 15;
+  const int co0 = blockIdx.x * 16, g0 = co0 / cog, ci0 = g0 * cig;
+  const int gl = (co0 + tco) / cog - g0;
+  int off[WGG_ACC];
+#pragma unroll
+  for (int t = 0; t < WGG_ACC; ++t) {
+    const int f = tq + 16 * t;
+    off[t] = f < wk ? (gl * cig + f / K) * lin_t + (f % K) * dil : -1;
+  }
+  float acc[WGG_ACC];
+#pragma unroll
+  for (int t = 0; t < WGG_ACC; ++t) acc[t] = 0.f;
+  const int nlc = (Lout + WG_L - 1) / WG_L;
+  for (int cc = 0; cc < chunks_per_block; ++cc) {
+    const int chunk = blockIdx.y * chunks_per_block + cc;
+    if (chunk >= B * nlc) break;
+    const int b = chunk / nlc, l0 = (chunk % nlc) * WG_L, in0 = l0 * stride - pad;
+    __syncthreads();
+    for (int i = tid; i < 16 * WG_L; i += 256) {
+      const int co = i / WG_L, l = i % WG_L;
+      dys[co * (WG_L + 1) + l] = (co0 + co < CoutT && l0 + l < Lout) ? lrelu(dy[((int64_t)b * CoutT + co0 + co) * Lout + l0 + l], dy_slope) : 0.f;
+    }
+    for (int c = tid >> 6; c < nci; c += 4) {
+      const bool cok = ci0 + c < CinT;
+      const float* xr = x + ((int64_t)b * CinT + ci0 + c) * Lin;
+      for (int pos = tid & 63; pos < lin_t; pos += 64) {
+        const int gi = in0 + pos;
+        xs[c * lin_t + pos] = (cok && gi >= 0 && gi < Lin) ? lrelu(xr[gi], x_slope) : 0.f;
+      }
+    }
+    __syncthreads();
+    const float* dr = dys + tco * (WG_L + 1);
+    for (int l = 0; l < WG_L; ++l) {
+      const float dv = dr[l];
+#pragma unroll
+      for (int t = 0; t < WGG_ACC; ++t)
+        if (off[t] >= 0) acc[t] = fmaf(dv, xs[off[t] + l * stride], acc[t]);
+    }
+  }
+  if (co0 + tco < CoutT) {
+    float* o = dw + (int64_t)(co0 + tco) * wk;
+#pragma unroll
+    for (int t = 0; t < WGG_ACC; ++t)
+      if (off[t] >= 0) atomicAdd(o + tq + 16 * t, acc[t]);
+  }
+}
+
 // db[c] += sum_{b,l} dy[b][c][l];  grid (C, splits): a block sums rows b = blockIdx.y, blockIdx.y + gridDim.y, ...
 __global__ __launch_bounds__(256) void conv1d_bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db, int B,
                                                                int C, int L, int lchunks) {
@@ -378,6 +585,20 @@ extern "C" int ttts_conv1d_fwd_f32(const float* x, const float* w, const float* 
     if (rc || handled) return rc;
   }
   const int lin_t = (CV_LT - 1) * stride + (K - 1) * dil + 1;
+  if (groups > 1 && !(g_debug_flags & 256)) {
+    const int cig = Cin / groups, cog = Cout / groups;
+    const int nci = (cog >= CV_CT ? 1 : CV_CT / cog) * cig;
+    const size_t gsmem = ((size_t)nci * lin_t + (size_t)CV_CT * cig * K) * sizeof(float);
+    if (cog % 4 == 0 && (CV_CT % cog == 0 || cog % CV_CT == 0) && nci <= 32 && gsmem <= 150 * 1024) {
+      static bool gattr = false;
+      rc = set_smem_attr(reinterpret_cast<const void*>(conv1d_fwd_grouped_kernel), gattr);
+      if (rc) return rc;
+      ConvParams p{x, w, bias, bbias, resid, omask, gate, y, B, cig, Lin, cog, Lout, K, stride, pad, dil, groups,
+                   in_slope, gate_slope, out_act, out_slope, out_scale, accumulate};
+      conv1d_fwd_grouped_kernel<<<dim3((unsigned)cdiv(Lout, CV_LT), (unsigned)cdiv(Cout, CV_CT), (unsigned)B), 256, gsmem, as_stream(stream)>>>(p);
+      return check_launch("conv1d_fwd_grouped");
+    }
+  }
   const size_t smem = ((size_t)CV_CI * lin_t + (size_t)CV_CT * CV_CI * K) * sizeof(float);
   TTTS_REQUIRE(smem <= 160 * 1024, "conv1d_fwd: tile does not fit LDS (K=%d stride=%d dil=%d)", K, stride, dil);
   static bool attr = false;
@@ -414,6 +635,20 @@ extern "C" int ttts_conv1d_dgrad_f32(const float* dy, const float* w, const floa
     if (rc2 || handled) return rc2;
   }
   const int lt = (CV_LT - 1 + (K - 1) * dil) / stride + 2;
+  if (groups > 1 && !(g_debug_flags & 256)) {
+    const int cig = Cin / groups, cog = Cout / groups;
+    const int nco = cig <= CV_CT && cig % 4 == 0 && CV_CT % cig == 0 ? (CV_CT / cig) * cog : 0;
+    const size_t gsmem = ((size_t)nco * lt + (size_t)nco * cig * K) * sizeof(float);
+    if (nco > 0 && gsmem <= 150 * 1024) {
+      static bool gattr = false;
+      int rc = set_smem_attr(reinterpret_cast<const void*>(conv1d_dgrad_grouped_kernel), gattr);
+      if (rc) return rc;
+      ConvParams p{dy, w, bias, nullptr, resid, omask, gate, dx, B, cig, Lin, cog, Lout, K, stride, pad, dil, groups,
+                   in_slope, gate_slope, 0, 1.f, out_scale, accumulate};
+      conv1d_dgrad_grouped_kernel<<<dim3((unsigned)cdiv(Lin, CV_LT), (unsigned)cdiv(Cin, CV_CT), (unsigned)B), 256, gsmem, as_stream(stream)>>>(p);
+      return check_launch("conv1d_dgrad_grouped");
+    }
+  }
   const size_t smem = ((size_t)CV_CI * lt + (size_t)CV_CI * CV_CT * K) * sizeof(float);
   TTTS_REQUIRE(smem <= 160 * 1024, "conv1d_dgrad: tile does not fit LDS");
   static bool attr = false;
@@ -436,6 +671,24 @@ extern "C" int ttts_conv1d_wgrad_f32(const float* dy, const float* x, float* dw,
     int rc2 = conv1d_wgrad_mfma_try(dy, x, dw, B, Cin, Lin, Cout, Lout, K, stride, pad, dil, dy_slope, x_slope,
                                     as_stream(stream), &handled);
     if (rc2 || handled) return rc2;
+  }
+  if (groups > 1 && !(g_debug_flags & 256)) {
+    const int cig = Cin / groups, cog = Cout / groups;
+    const int nci = (cog >= 16 ? 1 : 16 / cog) * cig;
+    const int lin_g = (WG_L - 1) * stride + (K - 1) * dil + 1;
+    const size_t gsmem = ((size_t)16 * (WG_L + 1) + (size_t)nci * lin_g) * sizeof(float);
+    if (cig * K <= 16 * WGG_ACC && (16 % cog == 0 || cog % 16 == 0) && gsmem <= 150 * 1024) {
+      static bool gattr = false;
+      int rc = set_smem_attr(reinterpret_cast<const void*>(conv1d_wgrad_grouped_kernel), gattr);
+      if (rc) return rc;
+      const int chunks = B * (int)cdiv(Lout, WG_L);
+      const int tiles = (int)cdiv(Cout, 16);
+      const int by = (int)std::max<int64_t>(1, std::min<int64_t>(chunks, cdiv(1024, tiles)));
+      const int cpb = (int)cdiv(chunks, by);
+      conv1d_wgrad_grouped_kernel<<<dim3(tiles, (unsigned)cdiv(chunks, cpb)), 256, gsmem, as_stream(stream)>>>(
+          dy, x, dw, B, cig, Lin, cog, Lout, K, stride, pad, dil, groups, dy_slope, x_slope, cpb);
+      return check_launch("conv1d_wgrad_grouped");
+    }
   }
   Cin /= groups; Cout /= groups;
   TTTS_REQUIRE(B > 0 && Cin > 0 && Lin > 0 && Cout > 0 && Lout > 0 && stride > 0 && dil > 0 && pad >= 0, "conv1d_wgrad: bad shape");
