@@ -17,6 +17,8 @@
 
 #include "common.hpp"
 
+extern int g_debug_flags;   // gemm.hip (ttts_debug_set_flags); 2048 = allow the small tile shapes
+
 namespace ttts {
 
 struct ConvMfmaParams {
@@ -41,11 +43,16 @@ struct ConvMfmaParams {
 
 __device__ __forceinline__ float lrelu_f(float v, float s) { return v > 0.f ? v : v * s; }
 
-// WCO = waves along the output-channel axis (1 or 2); the other 4 / WCO waves tile positions.
-template <int WCO>
-__global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvMfmaParams p) {
+// WCO = waves along the output-channel axis (1 or 2), NW = waves per workgroup (1, 2 or 4); the NW / WCO remaining waves tile
+// positions.  Tile shapes (channels x positions): <2,4> 64x128, <1,4> 32x256, <2,2> 64x64, <1,2> 32x128, <1,1> 32x64 -- the
+// small ones exist so that short / narrow layers (192 channels x 256 frames x batch 32 = 192 big tiles on 256 CUs) still put
+// several workgroups on every CU, which is what hides the global -> LDS staging latency of a stage behind another
+// workgroup's MFMAs.
+template <int WCO, int NW>
+__global__ __launch_bounds__(64 * NW) void conv1d_mfma_kernel(ConvMfmaParams p) {
+  constexpr int NTHR = 64 * NW;
   constexpr int MT = 32 * WCO;                 // output channels per workgroup
-  constexpr int WL = 4 / WCO;                  // waves along positions
+  constexpr int WL = NW / WCO;                 // waves along positions
   constexpr int LT = 64 * WL;                  // positions per workgroup
   extern __shared__ __attribute__((aligned(16))) float cm_smem[];
   const int NT = p.NT;
@@ -62,9 +69,9 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvMfmaParams p) {
   const int wco = wave % WCO, wl = wave / WCO;
   const int j0 = blockIdx.x * LT, m0 = blockIdx.y * MT, b0 = blockIdx.z * nseg;   // folded tiles: gridDim.x == 1, j0 == 0
   const int in0 = j0 * p.stride - p.pad;
-  for (int f = tid; f < KK; f += 256) foff[f] = (f / p.K) * lin_t + (f % p.K) * p.dil;
+  for (int f = tid; f < KK; f += NTHR) foff[f] = (f / p.K) * lin_t + (f % p.K) * p.dil;
   if (p.transposed)
-    for (int i = tid; i < MT * p.Kmem; i += 256) {
+    for (int i = tid; i < MT * p.Kmem; i += NTHR) {
       const int km = i % p.Kmem - p.tap_off;          // memory tap -> effective tap q (if on this phase) -> flipped slot
       tmap[i] = (km >= 0 && km % p.tap_stride == 0 && km / p.tap_stride < p.K) ? (i / p.Kmem) * wpitch + (p.K - 1 - km / p.tap_stride) : -1;
     }
@@ -76,11 +83,11 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvMfmaParams p) {
   // column c of the tile -> segment c / SEG (a 32-column MFMA tile never straddles segments), position c % SEG
   const int c0 = wl * 64 + col, c1 = c0 + 32;
   const int bpos0 = (c0 / SEG) * lin_s + (c0 % SEG) * p.stride, bpos1 = (c1 / SEG) * lin_s + (c1 % SEG) * p.stride;
-  const int lrow = tid / (256 / MT), lq = tid % (256 / MT);     // weight loader: 256 / MT threads per output-channel row
+  const int lrow = tid / (NTHR / MT), lq = tid % (NTHR / MT);   // weight loader: NTHR / MT threads per output-channel row
   for (int n0 = 0; n0 < p.N; n0 += NT) {
     __syncthreads();
     // input strip: one wave per channel row at a time, lanes along positions (coalesced, no index arithmetic)
-    for (int n = wave; n < NT; n += 4) {
+    for (int n = wave; n < NT; n += NW) {
       const bool nok = n0 + n < p.N;
       for (int sg = 0; sg < nseg; ++sg) {
         const bool bok = nok && b0 + sg < p.B;
@@ -99,11 +106,11 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(ConvMfmaParams p) {
         // A[m][n][k] = w[m][n][k]: the stage's KK values of a row are contiguous in memory
         const float* wr = p.w + ((int64_t)(m0 + lrow) * p.N + n0) * p.K;
         const int flim = mok ? min(KK, (p.N - n0) * p.K) : 0;
-        for (int f = lq; f < KK; f += 256 / MT) wd[f] = f < flim ? wr[f] : 0.f;
+        for (int f = lq; f < KK; f += NTHR / MT) wd[f] = f < flim ? wr[f] : 0.f;
       } else {
         // A[m][n][k] = w[n][m][K-1-k]  (w is [N][M][K] here): for one n the MT*K values w[n][m0 .. m0+MT)[:] are contiguous
         const int cnt = min(MT, p.M - m0) * p.Kmem;
-        for (int n = wave; n < NT; n += 4) {
+        for (int n = wave; n < NT; n += NW) {
           const bool nok = n0 + n < p.N;
           const float* wr = p.w + ((int64_t)(n0 + n) * p.M + m0) * p.Kmem;
           for (int i = lane; i < MT * p.Kmem; i += 64) {
@@ -155,6 +162,8 @@ struct WgradMfmaParams {
   int B, Cin, Lin, Cout, Lout, K, stride, pad, dil;
   float dy_slope, x_slope;
   int chunks_per_block;
+  int SEGW;            // positions per segment of a 64-position reduction chunk: 64, or 16 for short rows (a chunk then holds
+                       // 4 (batch element, 16-position window) segments: DiscriminatorP rows are 23..127 positions long)
 };
 constexpr int WM_L = 64;
 
@@ -163,10 +172,11 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_mfma_kernel(WgradMfmaParams 
   const int NK = p.Cin * p.K;
   const int n0 = blockIdx.x * 64, co0 = blockIdx.y * 64;
   const int ci_first = n0 / p.K, ci_last = min(p.Cin - 1, (n0 + 63) / p.K), nch = ci_last - ci_first + 1;
-  const int lin_t = (WM_L - 1) * p.stride + (p.K - 1) * p.dil + 1;
-  const int xpitch = lin_t | 1;
+  const int SEGW = p.SEGW, nsg = WM_L / SEGW;
+  const int lin_s = (SEGW - 1) * p.stride + (p.K - 1) * p.dil + 1;      // input strip of one segment
+  const int xpitch = (nsg * lin_s) | 1;
   float* dys = cm_smem;                        // [64 co][WM_L + 1]
-  float* xs = cm_smem + 64 * (WM_L + 1);       // [nch][xpitch]
+  float* xs = cm_smem + 64 * (WM_L + 1);       // [nch][nsg][lin_s]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, col = lane & 31;
   const int wco = wave & 1, wn = wave >> 1;
   const int n = n0 + wn * 32 + col;            // this lane's output column (ci, k)
@@ -177,29 +187,39 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_mfma_kernel(WgradMfmaParams 
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const int nlc = (p.Lout + WM_L - 1) / WM_L;
+  const int nsl = (p.Lout + SEGW - 1) / SEGW;          // segments per batch element
+  const int nsegs = p.B * nsl;                          // segments in all
   for (int cc = 0; cc < p.chunks_per_block; ++cc) {
     const int chunk = blockIdx.z * p.chunks_per_block + cc;
-    if (chunk >= p.B * nlc) break;
-    const int b = chunk / nlc, l0 = (chunk % nlc) * WM_L, in0 = l0 * p.stride - p.pad;
+    if (chunk * nsg >= nsegs) break;
     __syncthreads();
-    for (int i = tid; i < 64 * WM_L; i += 256) {
-      const int co = i / WM_L, l = i % WM_L;
-      dys[co * (WM_L + 1) + l] = (co0 + co < p.Cout && l0 + l < p.Lout)
-                                     ? lrelu_f(p.dy[((int64_t)b * p.Cout + co0 + co) * p.Lout + l0 + l], p.dy_slope) : 0.f;
+    {
+      // thread -> fixed chunk position lc (256 % 64 == 0), rows co = wave, wave + 4, ...: the segment arithmetic is per chunk
+      const int lc = lane, sgi = chunk * nsg + lc / SEGW;  // global segment -> (batch element, window)
+      const int b = sgi / nsl, l = (sgi % nsl) * SEGW + lc % SEGW;
+      const bool ok = sgi < nsegs && l < p.Lout;
+      const float* src = p.dy + ((int64_t)b * p.Cout + co0) * p.Lout + l;
+      for (int co = wave; co < 64; co += 4)
+        dys[co * (WM_L + 1) + lc] = (ok && co0 + co < p.Cout) ? lrelu_f(src[(int64_t)co * p.Lout], p.dy_slope) : 0.f;
     }
-    for (int c = wave; c < nch; c += 4) {
-      const float* xr = p.x + ((int64_t)b * p.Cin + ci_first + c) * p.Lin;
-      for (int pos = lane; pos < lin_t; pos += 64) {
-        const int gi = in0 + pos;
-        xs[c * xpitch + pos] = (gi >= 0 && gi < p.Lin) ? lrelu_f(xr[gi], p.x_slope) : 0.f;
+    for (int c = wave; c < nch; c += 4)
+      for (int sg = 0; sg < nsg; ++sg) {
+        const int sgi = chunk * nsg + sg;
+        const int b = sgi / nsl, in0 = (sgi % nsl) * SEGW * p.stride - p.pad;
+        const float* xr = p.x + ((int64_t)b * p.Cin + ci_first + c) * p.Lin;
+        for (int pos = lane; pos < lin_s; pos += 64) {
+          const int gi = in0 + pos;
+          xs[c * xpitch + sg * lin_s + pos] = (sgi < nsegs && gi >= 0 && gi < p.Lin) ? lrelu_f(xr[gi], p.x_slope) : 0.f;
+        }
       }
-    }
     __syncthreads();
-    const float* bcol = xs + boff + hh * p.stride;
+    for (int sg = 0; sg < nsg; ++sg) {
+      const float* ar = arow + sg * SEGW;
+      const float* bcol = xs + boff + sg * lin_s + hh * p.stride;
 #pragma unroll 4
-    for (int l = 0; l < WM_L; l += 2)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[l + hh], ncol_ok ? bcol[l * p.stride] : 0.f, acc, 0, 0, 0);
+      for (int l = 0; l < SEGW; l += 2)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[l + hh], ncol_ok ? bcol[l * p.stride] : 0.f, acc, 0, 0, 0);
+    }
   }
   if (ncol_ok) {
 #pragma unroll
@@ -209,6 +229,8 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_mfma_kernel(WgradMfmaParams 
     }
   }
 }
+
+#define g_debug_flags_conv ::g_debug_flags
 
 static int set_attr_once(const void* fn, bool& done) {
   if (done) return TTTS_OK;
@@ -220,12 +242,10 @@ static int set_attr_once(const void* fn, bool& done) {
 
 // ---- dispatch helpers used by conv.hip ------------------------------------------------------------------------------------
 // Returns TTTS_OK and sets *handled when the MFMA path took the launch.
-static int conv1d_mfma_launch(ConvMfmaParams p, hipStream_t stream, bool* handled) {
-  *handled = false;
-  const bool narrow = p.M <= 32;
-  const int LT = narrow ? 256 : 128, MT = narrow ? 32 : 64;
-  const int K = p.K;
-  const int SEG = (p.Lout <= 32 && p.B > 1) ? 32 : ((p.Lout <= 64 && p.B > 1) ? 64 : LT);
+template <int WCO, int NW>
+static int conv1d_mfma_launch_t(ConvMfmaParams p, hipStream_t stream, bool* handled) {
+  constexpr int MT = 32 * WCO, LT = 64 * (NW / WCO);
+  const int K = p.K, SEG = p.SEG > LT ? LT : p.SEG;
   p.SEG = SEG;
   const int lin_t = (LT / SEG) * ((SEG - 1) * p.stride + (K - 1) * p.dil + 1);
   auto smem_for = [&](int nt) {
@@ -238,18 +258,35 @@ static int conv1d_mfma_launch(ConvMfmaParams p, hipStream_t stream, bool* handle
   if (smem > 96 * 1024) return TTTS_OK;
   p.NT = NT;
   dim3 grid((unsigned)cdiv(p.Lout, SEG == LT ? LT : SEG), (unsigned)cdiv(p.M, MT), (unsigned)cdiv(p.B, LT / SEG));
-  static bool a1 = false, a2 = false;
-  if (narrow) {
-    int rc = set_attr_once(reinterpret_cast<const void*>(conv1d_mfma_kernel<1>), a1);
-    if (rc) return rc;
-    conv1d_mfma_kernel<1><<<grid, 256, smem, stream>>>(p);
-  } else {
-    int rc = set_attr_once(reinterpret_cast<const void*>(conv1d_mfma_kernel<2>), a2);
-    if (rc) return rc;
-    conv1d_mfma_kernel<2><<<grid, 256, smem, stream>>>(p);
-  }
+  static bool attr = false;
+  int rc = set_attr_once(reinterpret_cast<const void*>(conv1d_mfma_kernel<WCO, NW>), attr);
+  if (rc) return rc;
+  conv1d_mfma_kernel<WCO, NW><<<grid, 64 * NW, smem, stream>>>(p);
   *handled = true;
   return check_launch("conv1d_mfma");
+}
+
+static int conv1d_mfma_launch(ConvMfmaParams p, hipStream_t stream, bool* handled) {
+  *handled = false;
+  // batch folding for short rows (see SEG); requested segment length, clipped to the tile by the launcher
+  p.SEG = (p.Lout <= 32 && p.B > 1) ? 32 : ((p.Lout <= 64 && p.B > 1) ? 64 : 1 << 20);
+  // tile choice: always the largest tile.  Measured (tools/conv_bench.py, B = 32): the smaller tiles <2,2>, <1,2>, <1,1> --
+  // meant to put more workgroups on a CU for the 192-channel x 256-frame layers -- are 2-2.5x SLOWER there (WN in_layer
+  // dgrad 346 -> 738 us): the kernel is bound by the global -> LDS staging work per MFMA, so less reuse per staged slab
+  // costs more than the extra overlap gains.  They stay instantiable for experiments (flag 2048).
+  if (g_debug_flags_conv & 2048) {
+    auto wgs = [&](int MT, int LT) {
+      const int seg = p.SEG > LT ? LT : p.SEG;
+      return cdiv(p.Lout, seg == LT ? LT : seg) * cdiv(p.M, MT) * cdiv(p.B, LT / seg);
+    };
+    if (p.M > 32 && wgs(64, 128) < 512) {
+      if (wgs(64, 64) >= 512) return conv1d_mfma_launch_t<2, 2>(p, stream, handled);
+      if (wgs(32, 128) >= 512) return conv1d_mfma_launch_t<1, 2>(p, stream, handled);
+      return conv1d_mfma_launch_t<1, 1>(p, stream, handled);
+    }
+  }
+  if (p.M <= 32) return conv1d_mfma_launch_t<1, 4>(p, stream, handled);
+  return conv1d_mfma_launch_t<2, 4>(p, stream, handled);
 }
 
 // Returns TTTS_OK and sets *handled when the MFMA path took the launch.
@@ -294,15 +331,18 @@ int conv1d_wgrad_mfma_try(const float* dy, const float* x, float* dw, int B, int
                           int stride, int pad, int dil, float dy_slope, float x_slope, hipStream_t stream, bool* handled) {
   *handled = false;
   if (Cin * K < 32 || Cout < 16) return TTTS_OK;
-  const int lin_t = (WM_L - 1) * stride + (K - 1) * dil + 1;
+  // short rows: 16-position segments when whole 64-position chunks would be mostly padding
+  const double waste64 = (double)cdiv(Lout, 64) * 64 / Lout, waste16 = (double)cdiv(Lout, 16) * 16 / Lout;
+  const int SEGW = (waste64 > 1.15 * waste16) ? 16 : 64;
+  const int lin_s = (SEGW - 1) * stride + (K - 1) * dil + 1;
   const int nch_max = 64 / K + 2;
-  const size_t smem = ((size_t)64 * (WM_L + 1) + (size_t)nch_max * (lin_t | 1)) * sizeof(float);
+  const size_t smem = ((size_t)64 * (WM_L + 1) + (size_t)nch_max * (((WM_L / SEGW) * lin_s) | 1)) * sizeof(float);
   if (smem > 96 * 1024) return TTTS_OK;
-  const int chunks = B * (int)cdiv(Lout, WM_L);
+  const int chunks = (int)cdiv((int64_t)B * cdiv(Lout, SEGW), WM_L / SEGW);
   const int tiles = (int)(cdiv(Cin * K, 64) * cdiv(Cout, 64));
   const int splits = (int)std::max<int64_t>(1, std::min<int64_t>(chunks, cdiv(2048, tiles)));
   const int cpb = (int)cdiv(chunks, splits);
-  WgradMfmaParams p{dy, x, dw, B, Cin, Lin, Cout, Lout, K, stride, pad, dil, dy_slope, x_slope, cpb};
+  WgradMfmaParams p{dy, x, dw, B, Cin, Lin, Cout, Lout, K, stride, pad, dil, dy_slope, x_slope, cpb, SEGW};
   static bool a = false;
   int rc = set_attr_once(reinterpret_cast<const void*>(conv1d_wgrad_mfma_kernel), a);
   if (rc) return rc;
