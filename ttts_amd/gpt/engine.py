@@ -17,6 +17,8 @@ The whole step is free of host reads of device data, hence capturable in one hip
 """
 import math
 
+import os
+
 import torch
 
 from .. import ops
@@ -81,6 +83,7 @@ class GptEngine:
         self.training = True
         self.seed = int(seed)
         self.step_count = 0                 # optimizer steps taken (host mirror)
+        self.overlap_dw = os.environ.get("TTTS_OVERLAP_DW", "1") != "0"   # dW GEMMs on a side stream (see backward)
         self.seed_ctr = ops.dropout_counter(self.device)   # device-side dropout stream counter (graph-replay safe)
         self.spec = param_spec(self.c)
         self.shapes = dict(self.spec)
@@ -279,13 +282,37 @@ class GptEngine:
         p = self._p()
         P = lambda k: self.view(self.params, k)  # noqa: E731
         G = lambda k: self.view(self.grads, k)   # noqa: E731
+        # Weight-gradient GEMMs (dW = X^T dY, + bias column sums) run on a SIDE stream: they only feed the optimizer, so they
+        # overlap with the data-gradient chain (dX GEMMs, attention backward, LayerNorm backward) on the main stream and
+        # fill the CUs that chain leaves idle (292-tile GEMMs on 256 CUs, causal tails, store phases).  Events order the
+        # reuse of the scratch buffers (dres_bf, d_fc, dqkv) between the two streams; both streams are captured in the graph.
+        main = torch.cuda.current_stream()
+        side = self._side_stream() if self.overlap_dw else main
+
+        def fork():                      # side waits for everything issued on main so far
+            if side is not main:
+                side.wait_stream(main)
+
+        def done():                      # marker on the side stream that main can wait on before overwriting an operand
+            if side is main:
+                return None
+            ev = torch.cuda.Event()
+            ev.record(side)
+            return ev
+
+        def wait(ev):
+            if ev is not None:
+                main.wait_event(ev)
+
         ops.ce_bwd(b["logits_t"], b["text_tar"], b["rows_t"][1], b["dlog_t"], self.nt, w_text, g_text_dev)
         ops.ce_bwd(b["logits_m"], b["mel_tar"], b["rows_m"][1], b["dlog_m"], self.nm, w_mel, g_mel_dev)
         enc_t, enc_m = b["enc"][:B * Tt], b["enc"][B * Tt:]
-        ops.gemm_tn_accum(b["dlog_t"], enc_t, G("text_head.weight"), mo=self.nt, workspace=b["tn_ws"])
-        ops.gemm_tn_accum(b["dlog_m"], enc_m, G("mel_head.weight"), mo=self.nm, workspace=b["tn_ws"])
-        ops.colsum_accum(b["dlog_t"], G("text_head.bias"), n=self.nt)
-        ops.colsum_accum(b["dlog_m"], G("mel_head.bias"), n=self.nm)
+        fork()
+        with torch.cuda.stream(side):
+            ops.gemm_tn_accum(b["dlog_t"], enc_t, G("text_head.weight"), mo=self.nt, workspace=b["tn_ws"])
+            ops.gemm_tn_accum(b["dlog_m"], enc_m, G("mel_head.weight"), mo=self.nm, workspace=b["tn_ws"])
+            ops.colsum_accum(b["dlog_t"], G("text_head.bias"), n=self.nt)
+            ops.colsum_accum(b["dlog_m"], G("mel_head.bias"), n=self.nm)
         ops.gemm_nt(b["dlog_t"], self.wT["text_head.weight"], b["d_enc"][:B * Tt])
         ops.gemm_nt(b["dlog_m"], self.wT["mel_head.weight"], b["d_enc"][B * Tt:])
         fs = b["fstats"]
@@ -294,29 +321,46 @@ class GptEngine:
         ops.layernorm_bwd(b["d_tmp"], b["xs"][2 * L], P("gpt.ln_f.weight"), fs[0], fs[1], None, b["dres"], b["dres_bf"],
                           G("gpt.ln_f.weight"), G("gpt.ln_f.bias"), b["ln_ws"], dropout_p=p,
                           seed=self._seed(16 * (L - 1) + 4), dcolsum=G("gpt.h.%d.mlp.c_proj.bias" % (L - 1)))
+        ev_fc = ev_qkv = None            # side-stream reads of d_fc / dqkv by the previous layer
         for i in reversed(range(L)):
             pre = "gpt.h.%d." % i
             st = b["stats"][i]
             x0, x1 = b["xs"][2 * i], b["xs"][2 * i + 1]
             dy = b["dres_bf"]                                  # gradient entering mlp.c_proj (resid dropout applied)
-            ops.gemm_tn_accum(self._padded(b["fc_act"][i]), self._padded(dy), G(pre + "mlp.c_proj.weight"), workspace=b["tn_ws"])
+            fork()
+            with torch.cuda.stream(side):
+                ops.gemm_tn_accum(self._padded(b["fc_act"][i]), self._padded(dy), G(pre + "mlp.c_proj.weight"), workspace=b["tn_ws"])
+            ev_dy = done()
+            wait(ev_fc)                                        # the previous layer's dW c_fc has consumed d_fc
             ops.gemm_nt(dy, self.w(pre + "mlp.c_proj.weight"), b["d_fc"], aux=b["fc_pre"][i], epilogue=EPI_DGELU_BF16)
-            ops.gemm_tn_accum(self._padded(b["ln2"][i]), self._padded(b["d_fc"]), G(pre + "mlp.c_fc.weight"), workspace=b["tn_ws"])
-            ops.colsum_accum(b["d_fc"], G(pre + "mlp.c_fc.bias"))
+            fork()
+            with torch.cuda.stream(side):
+                ops.gemm_tn_accum(self._padded(b["ln2"][i]), self._padded(b["d_fc"]), G(pre + "mlp.c_fc.weight"), workspace=b["tn_ws"])
+                ops.colsum_accum(b["d_fc"], G(pre + "mlp.c_fc.bias"))
+            ev_fc = done()
             ops.gemm_nt(b["d_fc"], self.w(pre + "mlp.c_fc.weight"), b["d_ln"])
+            wait(ev_dy)                                        # dres_bf is rewritten by the LayerNorm backward below
             ops.layernorm_bwd(b["d_ln"], x1, P(pre + "ln_2.weight"), st[2], st[3], b["dres"], b["dres"], b["dres_bf"],
                               G(pre + "ln_2.weight"), G(pre + "ln_2.bias"), b["ln_ws"], dropout_p=p,
                               seed=self._seed(16 * i + 3), dcolsum=G(pre + "attn.c_proj.bias"))
             dy = b["dres_bf"]                                  # gradient entering attn.c_proj
-            ops.gemm_tn_accum(self._padded(b["att"][i]), self._padded(dy), G(pre + "attn.c_proj.weight"), workspace=b["tn_ws"])
+            fork()
+            with torch.cuda.stream(side):
+                ops.gemm_tn_accum(self._padded(b["att"][i]), self._padded(dy), G(pre + "attn.c_proj.weight"), workspace=b["tn_ws"])
+            ev_dy = done()
             ops.gemm_nt(dy, self.w(pre + "attn.c_proj.weight"), b["d_att"])
             qkv, dqkv = b["qkv"][i], b["dqkv"]
+            wait(ev_qkv)                                       # the previous layer's dW c_attn has consumed dqkv
             ops.attn_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], b["att"][i], b["d_att"], b["lse"][i], dqkv, dqkv[:, D:],
                          dqkv[:, 2 * D:], b["delta"], B, H, S, dh, (S * 3 * D, 3 * D), (S * D, D), dh ** -0.5, p,
                          self._seed(16 * i + 2))
-            ops.gemm_tn_accum(self._padded(b["ln1"][i]), self._padded(dqkv), G(pre + "attn.c_attn.weight"), workspace=b["tn_ws"])
-            ops.colsum_accum(dqkv, G(pre + "attn.c_attn.bias"))
+            fork()
+            with torch.cuda.stream(side):
+                ops.gemm_tn_accum(self._padded(b["ln1"][i]), self._padded(dqkv), G(pre + "attn.c_attn.weight"), workspace=b["tn_ws"])
+                ops.colsum_accum(dqkv, G(pre + "attn.c_attn.bias"))
+            ev_qkv = done()
             ops.gemm_nt(dqkv, self.w(pre + "attn.c_attn.weight"), b["d_ln"])
+            wait(ev_dy)
             ops.layernorm_bwd(b["d_ln"], x0, P(pre + "ln_1.weight"), st[0], st[1], b["dres"], b["dres"],
                               b["dres_bf"] if i > 0 else None, G(pre + "ln_1.weight"), G(pre + "ln_1.bias"),
                               b["ln_ws"], dropout_p=p if i > 0 else 0.0, seed=self._seed(16 * (i - 1) + 4),
@@ -324,6 +368,13 @@ class GptEngine:
         ops.embed_bwd(b["text_inp"], b["mel_inp"], b["dres"], G("text_embedding.weight"),
                       G("text_pos_embedding.emb.weight"), G("mel_embedding.weight"), G("mel_pos_embedding.emb.weight"),
                       p, self._seed(1))
+        if side is not main:
+            main.wait_stream(side)       # join: the optimizer / all-reduce needs every dW
+
+    def _side_stream(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
 
     # ---- optimizer ---------------------------------------------------------------------------------------------
     def optimizer_step(self, lr=1e-4, betas=(0.9, 0.96), eps=1e-8, weight_decay=0.01, max_norm=1.0, warmup_steps=500):
