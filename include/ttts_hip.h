@@ -249,6 +249,11 @@ int ttts_conv1d_dgrad_f32(const float* dy, const float* w, const float* bias, co
 int ttts_conv1d_wgrad_f32(const float* dy, const float* x, float* dw, int32_t B, int32_t Cin, int32_t Lin,
                           int32_t Cout, int32_t Lout, int32_t K, int32_t stride, int32_t pad, int32_t dil,
                           int32_t groups, float dy_slope, float x_slope, void* stream);
+/* Optional caller-owned scratch (16-byte aligned, >= 32 MB covers every layer of the path) that enables the split-bf16
+ * matrix-core path of conv1d_fwd / conv1d_dgrad (weights pre-split into hi/lo bf16 there: x*w accumulated in fp32 as
+ * hi*hi + hi*lo + lo*hi, relative error ~2^-16).  One scratch per process; convolutions that use it must be ordered on
+ * one stream.  NULL restores the exact-fp32 MFMA kernels. */
+int ttts_conv_set_workspace(void* workspace, int64_t bytes);
 int ttts_conv1d_bias_grad_f32(const float* dy, float* db, int32_t B, int32_t C, int32_t L, void* stream);
 int ttts_weight_norm_fwd_f32(const float* v, const float* g, float* w, float* norm, int32_t rows, int32_t n,
                              void* stream);

@@ -10,6 +10,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 def pytest_configure(config):
+    config.addinivalue_line("markers", "bf16x3: VQ-VAE conv tests on the default split-bf16 matrix-core path")
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with `-m gpu`)")
 
 

@@ -38,6 +38,8 @@ struct ConvMfmaParams {
                        // (DiscriminatorP's late layers: 23..127 positions) fold several batch elements into one tile
   float in_slope, gate_slope;
   int out_act; float out_slope, out_scale; int accumulate;
+  // split-bf16 path: weights pre-split into hi / lo bf16 in [N/16 blocks][Mpad][K][16] order (conv_weight_split_kernel)
+  const bf16* a_hi; const bf16* a_lo; int Mpad;
 };
 
 
@@ -130,6 +132,130 @@ __global__ __launch_bounds__(64 * NW) void conv1d_mfma_kernel(ConvMfmaParams p) 
     }
   }
   // ---- epilogue
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int ct = wl * 64 + t * 32 + col;
+    const int b = b0 + ct / SEG, jt = j0 + ct % SEG;
+    if (jt >= p.Lout || b >= p.B) continue;
+    const int j = p.out_off + jt * p.out_stride;
+    const float om = p.omask ? p.omask[(int64_t)b * p.LoutTotal + j] : 1.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wco * 32 + acc_row(r, hh);
+      if (m >= p.M) continue;
+      const int64_t o = ((int64_t)b * p.M + m) * p.LoutTotal + j;
+      float v = (t == 0 ? acc0[r] : acc1[r]) + (p.bias ? p.bias[m] : 0.f);
+      if (p.bbias) v += p.bbias[(int64_t)b * p.M + m];
+      if (p.gate) v *= (p.gate[o] > 0.f ? 1.f : p.gate_slope);
+      if (p.resid) v += p.resid[o];
+      if (p.out_act == 1) v = tanhf(v);
+      else if (p.out_act == 2) v = lrelu_f(v, p.out_slope);
+      v *= om * p.out_scale;
+      p.y[o] = p.accumulate ? p.y[o] + v : v;
+    }
+  }
+}
+
+// ---- split-bf16 ("bf16 x 3") implicit GEMM on the bf16 matrix cores ----------------------------------------------------------
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi); the product is accumulated in fp32 as hi*hi + hi*lo + lo*hi (the dropped
+// lo*lo term and the representation residue are ~2^-16 relative: ~100x tighter than the TF32 the reference's cuDNN
+// convolutions run with).  v_mfma_f32_32x32x16_bf16 is 16x the rate of the f32-input MFMA, so three of them per product still
+// leave a 5x head-room.  Reduction order: (tap, channel) with the 16 channels of a stage minor, so that a lane's 8 k-values are
+// one 16-byte LDS read: the input strip is staged position-major [pos][16 ch] (hi and lo), the weights arrive pre-split and
+// pre-ordered [n/16][m][tap][16] from conv_weight_split_kernel -- which also bakes in the transposition / tap flip / polyphase
+// tap selection of the data-gradient forms, so this kernel only ever sees a plain forward convolution.
+__global__ __launch_bounds__(256) void conv_weight_split_kernel(const float* __restrict__ w, bf16* __restrict__ a_hi,
+                                                                bf16* __restrict__ a_lo, int M, int N, int Mpad, int nblk,
+                                                                int K, int Kmem, int transposed, int tap_off, int tap_stride) {
+  const int64_t total = (int64_t)nblk * Mpad * K * 16;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i & 15), k = (int)((i >> 4) % K), m = (int)((i >> 4) / K % Mpad), nb = (int)((i >> 4) / K / Mpad);
+    const int n = nb * 16 + c;
+    float v = 0.f;
+    if (m < M && n < N) {
+      // forward: A[m][k][n] = w[m][n][k];  data gradient: A[m][k][n] = w[n][m][tap_off + tap_stride * (K - 1 - k)]
+      v = transposed ? w[((int64_t)n * M + m) * Kmem + tap_off + tap_stride * (K - 1 - k)] : w[((int64_t)m * N + n) * Kmem + k];
+    }
+    const bf16 h = (bf16)v;
+    a_hi[i] = h;
+    a_lo[i] = (bf16)(v - (float)h);
+  }
+}
+
+template <int WCO>
+__global__ __launch_bounds__(256) void conv1d_bf16x3_kernel(ConvMfmaParams p) {
+  constexpr int MT = 32 * WCO, WL = 4 / WCO, LT = 64 * WL;
+  extern __shared__ __attribute__((aligned(16))) float cm_smem[];
+  const int K = p.K, SEG = p.SEG, nseg = LT / SEG;
+  const int lin_s = (SEG - 1) * p.stride + (K - 1) * p.dil + 1, lin_t = nseg * lin_s;
+  const int apitch = K * 16 + 8;                      // bf16 elements per weight row (+8: spreads rows over the banks)
+  bf16* xh = reinterpret_cast<bf16*>(cm_smem);        // [lin_t][16]
+  bf16* xl = xh + lin_t * 16;
+  bf16* ah = xl + lin_t * 16;                         // [MT][apitch]
+  bf16* al = ah + MT * apitch;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, col = lane & 31;
+  const int wco = wave % WCO, wl = wave / WCO;
+  const int j0 = blockIdx.x * LT, m0 = blockIdx.y * MT, b0 = blockIdx.z * nseg;
+  const int in0 = j0 * p.stride - p.pad;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+  const int c0 = wl * 64 + col, c1 = c0 + 32;
+  const int bpos0 = ((c0 / SEG) * lin_s + (c0 % SEG) * p.stride) * 16 + hh * 8;
+  const int bpos1 = ((c1 / SEG) * lin_s + (c1 % SEG) * p.stride) * 16 + hh * 8;
+  const int arow = (wco * 32 + col) * apitch + hh * 8;
+  const int nblk = (p.N + 15) / 16;
+  const int64_t slab = (int64_t)p.Mpad * K * 16;      // elements per channel block of the split weights
+  for (int nb = 0; nb < nblk; ++nb) {
+    __syncthreads();
+    // input strip: one thread per position, 16 channels each (every global read is a coalesced row segment)
+    for (int pp = tid; pp < lin_t; pp += 256) {
+      const int sg = pp / lin_s, pos = pp - sg * lin_s, gi = in0 + pos;
+      const bool ok = b0 + sg < p.B && gi >= 0 && gi < p.Lin;
+      const float* xr = p.x + ((int64_t)(b0 + sg) * p.N + nb * 16) * p.Lin + gi;
+      bf16x8 h0, h1, l0, l1;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        float v = (ok && nb * 16 + c < p.N) ? xr[(int64_t)c * p.Lin] : 0.f;
+        v = lrelu_f(v, p.in_slope);
+        const bf16 hv = (bf16)v;
+        const bf16 lv = (bf16)(v - (float)hv);
+        if (c < 8) { h0[c] = hv; l0[c] = lv; } else { h1[c - 8] = hv; l1[c - 8] = lv; }
+      }
+      *reinterpret_cast<bf16x8*>(xh + pp * 16) = h0;
+      *reinterpret_cast<bf16x8*>(xh + pp * 16 + 8) = h1;
+      *reinterpret_cast<bf16x8*>(xl + pp * 16) = l0;
+      *reinterpret_cast<bf16x8*>(xl + pp * 16 + 8) = l1;
+    }
+    // weights: the stage's [MT][K][16] slab is contiguous in the split arrays; 16-byte chunks
+    {
+      const bf16* gh = p.a_hi + nb * slab + (int64_t)m0 * K * 16;
+      const bf16* gl = p.a_lo + nb * slab + (int64_t)m0 * K * 16;
+      const int chunks = MT * K * 2;
+      for (int ch = tid; ch < chunks; ch += 256) {
+        const int m = ch / (K * 2), r = ch - m * (K * 2);
+        *reinterpret_cast<bf16x8*>(ah + m * apitch + r * 8) = *reinterpret_cast<const bf16x8*>(gh + (int64_t)ch * 8);
+        *reinterpret_cast<bf16x8*>(al + m * apitch + r * 8) = *reinterpret_cast<const bf16x8*>(gl + (int64_t)ch * 8);
+      }
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int k = 0; k < K; ++k) {
+      const bf16x8 a_h = *reinterpret_cast<const bf16x8*>(ah + arow + k * 16);
+      const bf16x8 a_l = *reinterpret_cast<const bf16x8*>(al + arow + k * 16);
+      const int ko = k * p.dil * 16;
+      const bf16x8 b0h = *reinterpret_cast<const bf16x8*>(xh + bpos0 + ko);
+      const bf16x8 b0l = *reinterpret_cast<const bf16x8*>(xl + bpos0 + ko);
+      const bf16x8 b1h = *reinterpret_cast<const bf16x8*>(xh + bpos1 + ko);
+      const bf16x8 b1l = *reinterpret_cast<const bf16x8*>(xl + bpos1 + ko);
+      acc0 = mfma32(a_l, b0h, acc0);
+      acc1 = mfma32(a_l, b1h, acc1);
+      acc0 = mfma32(a_h, b0l, acc0);
+      acc1 = mfma32(a_h, b1l, acc1);
+      acc0 = mfma32(a_h, b0h, acc0);
+      acc1 = mfma32(a_h, b1h, acc1);
+    }
+  }
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int ct = wl * 64 + t * 32 + col;
@@ -266,10 +392,44 @@ static int conv1d_mfma_launch_t(ConvMfmaParams p, hipStream_t stream, bool* hand
   return check_launch("conv1d_mfma");
 }
 
+// caller-owned scratch for the split weights (ttts_conv_set_workspace); the split-bf16 path is used only while it is set
+static void* g_conv_ws = nullptr;
+static int64_t g_conv_ws_bytes = 0;
+
+template <int WCO>
+static int conv1d_bf16x3_launch_t(ConvMfmaParams p, hipStream_t stream, bool* handled) {
+  constexpr int MT = 32 * WCO, LT = 64 * (4 / WCO);
+  const int K = p.K, SEG = p.SEG > LT ? LT : p.SEG;
+  p.SEG = SEG;
+  const int lin_t = (LT / SEG) * ((SEG - 1) * p.stride + (K - 1) * p.dil + 1);
+  const size_t smem = ((size_t)2 * lin_t * 16 + (size_t)2 * MT * (K * 16 + 8)) * sizeof(bf16);
+  if (smem > 64 * 1024) return TTTS_OK;
+  const int nblk = (p.N + 15) / 16;
+  p.Mpad = (int)(cdiv(p.M, MT) * MT);
+  const int64_t elems = (int64_t)nblk * p.Mpad * K * 16;
+  if (2 * elems * (int64_t)sizeof(bf16) > g_conv_ws_bytes) return TTTS_OK;
+  bf16* hi = static_cast<bf16*>(g_conv_ws);
+  bf16* lo = hi + elems;
+  p.a_hi = hi; p.a_lo = lo;
+  conv_weight_split_kernel<<<(int)std::min<int64_t>(cdiv(elems, 256), 2048), 256, 0, stream>>>(p.w, hi, lo, p.M, p.N, p.Mpad, nblk, K, p.Kmem,
+                                                                                            p.transposed, p.tap_off, p.tap_stride);
+  dim3 grid((unsigned)cdiv(p.Lout, SEG == LT ? LT : SEG), (unsigned)cdiv(p.M, MT), (unsigned)cdiv(p.B, LT / SEG));
+  static bool attr = false;
+  int rc = set_attr_once(reinterpret_cast<const void*>(conv1d_bf16x3_kernel<WCO>), attr);
+  if (rc) return rc;
+  conv1d_bf16x3_kernel<WCO><<<grid, 256, smem, stream>>>(p);
+  *handled = true;
+  return check_launch("conv1d_bf16x3");
+}
+
 static int conv1d_mfma_launch(ConvMfmaParams p, hipStream_t stream, bool* handled) {
   *handled = false;
   // batch folding for short rows (see SEG); requested segment length, clipped to the tile by the launcher
   p.SEG = (p.Lout <= 32 && p.B > 1) ? 32 : ((p.Lout <= 64 && p.B > 1) ? 64 : 1 << 20);
+  if (g_conv_ws && p.N >= 16 && !(g_debug_flags_conv & 4096)) {
+    int rc = p.M <= 32 ? conv1d_bf16x3_launch_t<1>(p, stream, handled) : conv1d_bf16x3_launch_t<2>(p, stream, handled);
+    if (rc || *handled) return rc;
+  }
   // tile choice: always the largest tile.  Measured (tools/conv_bench.py, B = 32): the smaller tiles <2,2>, <1,2>, <1,1> --
   // meant to put more workgroups on a CU for the 192-channel x 256-frame layers -- are 2-2.5x SLOWER there (WN in_layer
   // dgrad 346 -> 738 us): the kernel is bound by the global -> LDS staging work per MFMA, so less reuse per staged slab
@@ -297,7 +457,7 @@ int conv1d_mfma_try(const float* x, const float* w, const float* bias, const flo
   *handled = false;
   if (N < 8 || M < 8 || K > 16) return TTTS_OK;            // thin layers / long taps stay on the direct kernels
   ConvMfmaParams p{x, w, bias, bbias, resid, omask, gate, y, B, M, N, Lin, Lout, K, stride, pad, dil, transposed, 0,
-                   K, 0, 1, 1, 0, Lout, 0, in_slope, gate_slope, out_act, out_slope, out_scale, accumulate};
+                   K, 0, 1, 1, 0, Lout, 0, in_slope, gate_slope, out_act, out_slope, out_scale, accumulate, nullptr, nullptr, 0};
   return conv1d_mfma_launch(p, stream, handled);
 }
 
@@ -317,7 +477,7 @@ int conv1d_dgrad_strided_mfma_try(const float* dy, const float* w, const float* 
     if (off >= Lin) continue;
     const int T = (Lin - 1 - off) / stride + 1;
     ConvMfmaParams p{dy, w, bias, nullptr, resid, omask, gate, dx, B, Cin, Cout, Lout, T, Kp, 1, (Kp - 1) - tmin, 1, 1, 0,
-                     K, phi, stride, stride, off, Lin, 0, in_slope, gate_slope, 0, 1.f, out_scale, accumulate};
+                     K, phi, stride, stride, off, Lin, 0, in_slope, gate_slope, 0, 1.f, out_scale, accumulate, nullptr, nullptr, 0};
     bool h = false;
     int rc = conv1d_mfma_launch(p, stream, &h);
     if (rc) return rc;
@@ -352,4 +512,15 @@ int conv1d_wgrad_mfma_try(const float* dy, const float* x, float* dw, int B, int
   return check_launch("conv1d_wgrad_mfma");
 }
 
+int conv_set_workspace(void* p, int64_t bytes) {
+  g_conv_ws = p;
+  g_conv_ws_bytes = p ? bytes : 0;
+  return TTTS_OK;
+}
+
 }  // namespace ttts
+
+extern "C" int ttts_conv_set_workspace(void* workspace, int64_t bytes) {
+  TTTS_REQUIRE(bytes >= 0 && (!workspace || ttts::aligned16(workspace)), "conv_set_workspace: bad arguments");
+  return ttts::conv_set_workspace(workspace, bytes);
+}

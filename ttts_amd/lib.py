@@ -116,6 +116,7 @@ SIGNATURES = {
                                      _F, _F, _F, _I32, _P]),
     "ttts_conv1d_wgrad_f32": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _F, _F,
                                      _P]),
+    "ttts_conv_set_workspace": (_I32, [_P, _I64]),
     "ttts_lrelu_bwd_f32": (_I32, [_P, _P, _P, _F, _I64, _P]),
     "ttts_conv1d_bias_grad_f32": (_I32, [_P, _P, _I32, _I32, _I32, _P]),
     "ttts_weight_norm_fwd_f32": (_I32, [_P, _P, _P, _P, _I32, _I32, _P]),

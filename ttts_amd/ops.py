@@ -5,6 +5,8 @@ raises `TttsError` on any failure -- there is no eager / CPU fallback.
 import ctypes
 
 import numpy as np
+import os
+
 import torch
 
 from . import lib as _l
@@ -294,6 +296,22 @@ def conv_out_len(lin, k, stride, pad, dil):
 
 
 _OUT_ACT = {None: 0, "none": 0, "tanh": 1, "lrelu": 2}
+_conv_scratch = {}
+
+
+def _conv_workspace(device):
+    """Registers (once per process) the caller-owned scratch that enables the split-bf16 matrix-core convolution path
+    (include/ttts_hip.h: ttts_conv_set_workspace).  TTTS_CONV_FP32=1 keeps the exact-fp32 MFMA kernels."""
+    key = str(device)
+    if key not in _conv_scratch:
+        if os.environ.get("TTTS_CONV_FP32", "0") == "1":
+            _conv_scratch[key] = None
+        else:
+            buf = torch.empty(64 << 20, dtype=torch.uint8, device=device)
+            check(_l.get().ttts_conv_set_workspace(_p(buf), buf.numel()), "conv_set_workspace")
+            _conv_scratch[key] = buf
+    return _conv_scratch[key]
+
 
 
 def conv1d_fwd(x, w, bias=None, resid=None, stride=1, pad=0, dil=1, in_slope=1.0, out_act=None, out_scale=1.0,
@@ -304,6 +322,7 @@ def conv1d_fwd(x, w, bias=None, resid=None, stride=1, pad=0, dil=1, in_slope=1.0
     for t, n in ((x, "x"), (w, "w"), (bias, "bias"), (resid, "resid"), (bbias, "bbias"), (gate, "gate")):
         _req(t, torch.float32, n)
     x = x.contiguous(); w = w.contiguous()
+    _conv_workspace(x.device)
     B, Cin, Lin = x.shape
     Cout, _, K = w.shape
     Lout = conv_out_len(Lin, K, stride, pad, dil)
@@ -321,6 +340,7 @@ def conv1d_dgrad(dy, w, lin, stride=1, pad=0, dil=1, gate=None, gate_slope=1.0, 
     (then `in_slope` is the leaky-relu fused on its input and `bias` its bias)."""
     _req(dy, torch.float32, "dy"); _req(w, torch.float32, "w")
     dy = dy.contiguous(); w = w.contiguous()
+    _conv_workspace(dy.device)
     B, Cout, Lout = dy.shape
     Cin, K = w.shape[1] * groups, w.shape[2]
     dx = out if out is not None else torch.empty(B, Cin, lin, dtype=torch.float32, device=dy.device)
