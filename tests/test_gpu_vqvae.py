@@ -575,3 +575,20 @@ def test_full_vqvae_gan_step_split_bf16(golden_dir):
     np.testing.assert_allclose([out["grad_norm_d"].item(), out["grad_norm_g"].item()], g["grad_norms"], rtol=5e-3)
     cb = tr.net_g.quantizer.vq.layers[0]._codebook
     np.testing.assert_allclose(cb.cluster_size.cpu().numpy(), g["cb_cluster_size"], rtol=1e-5)
+
+
+@pytest.mark.bf16x3
+@pytest.mark.parametrize("case", [(64, 64, 11, 1, 25, 5, 2048), (192, 384, 5, 1, 2, 1, 256), (512, 1024, 5, 3, 2, 1, 253),
+                                  (32, 16, 16, 1, 7, 1, 400), (16, 32, 16, 10, 7, 1, 3000), (48, 40, 7, 2, 3, 1, 333)])
+def test_split_bf16_weight_gradient_accuracy(case):
+    """Weight gradient on the default path (pre-split / phase-de-interleaved operands, one tap per workgroup)."""
+    from ttts_amd import ops
+    cin, cout, k, s, pad, dil, L = case
+    g = torch.Generator().manual_seed(cin * 3 + k)
+    x = torch.randn(3, cin, L, generator=g)
+    lout = (L + 2 * pad - dil * (k - 1) - 1) // s + 1
+    dy = torch.randn(3, cout, lout, generator=g)
+    dwr = torch.nn.grad.conv1d_weight(F.leaky_relu(x.double(), 0.1), (cout, cin, k), dy.double(), stride=s, padding=pad, dilation=dil)
+    dw = ops.conv1d_wgrad(dy.to(_dev()), x.to(_dev()), k, s, pad, dil, x_slope=0.1)
+    _close(dw, dwr, 2e-5, 0, "dw")
+    assert _rel_l2(dw, dwr) < 1e-5

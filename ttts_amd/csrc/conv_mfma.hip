@@ -487,9 +487,155 @@ int conv1d_dgrad_strided_mfma_try(const float* dy, const float* w, const float* 
   return TTTS_OK;
 }
 
+// ---- weight gradient on the bf16 matrix cores (split-bf16) ----------------------------------------------------------------
+// dw[co][ci][k] += sum_{b,l} dy[b][co][l] * x[b][ci][l*stride - pad + k*dil].  One workgroup owns ONE tap k, so that both
+// operands become plain row segments: dy[co][l0 .. l0+63] and, after a pre-pass that splits x into hi / lo bf16 and
+// de-interleaves it by phase (position mod stride), x'[ci][phase(k)][l0 + d(k) .. +63].  The pre-passes also apply the fused
+// leaky-relus and zero-pad the rows, so the main loop is: 16-byte loads -> LDS -> 3 MFMAs per k-step, no bounds tests.
+//   dy split:  DY[b][co][Lq]           Lq = roundup64(Lout), zero beyond Lout
+//   x split:   XS[par][b][ci][r][Li]   element i of phase r of parity copy `par` holds x[(i + par)*stride + r - PL]
+//              (PL = roundup_stride(pad)); the odd copy lets every row segment start on a 4-byte boundary
+__global__ __launch_bounds__(256) void wgrad_split_dy_kernel(const float* __restrict__ dy, bf16* __restrict__ hi,
+                                                             bf16* __restrict__ lo, int64_t rows, int Lout, int Lq, float slope) {
+  const int64_t total = rows * Lq;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int l = (int)(i % Lq);
+    const int64_t r = i / Lq;
+    const float v = l < Lout ? lrelu_f(dy[r * Lout + l], slope) : 0.f;
+    const bf16 h = (bf16)v;
+    hi[i] = h;
+    lo[i] = (bf16)(v - (float)h);
+  }
+}
+__global__ __launch_bounds__(256) void wgrad_split_x_kernel(const float* __restrict__ x, bf16* __restrict__ hi,
+                                                            bf16* __restrict__ lo, int64_t rows, int Lin, int stride, int Li,
+                                                            int PL, float slope) {
+  const int64_t per = rows * stride * Li, total = 2 * per;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int par = (int)(i / per);
+    const int64_t j = i - par * per;
+    const int ii = (int)(j % Li), r = (int)((j / Li) % stride);
+    const int64_t row = j / Li / stride;
+    const int64_t q = (int64_t)(ii + par) * stride + r - PL;
+    const float v = (q >= 0 && q < Lin) ? lrelu_f(x[row * Lin + q], slope) : 0.f;
+    const bf16 h = (bf16)v;
+    hi[i] = h;
+    lo[i] = (bf16)(v - (float)h);
+  }
+}
+
+struct WgradB3Params {
+  const bf16* dyh; const bf16* dyl; const bf16* xh; const bf16* xl; float* dw;
+  int B, Cin, Cout, K, stride, dil, Lq, Li, PLmPad;   // PLmPad = PL - pad >= 0
+  int64_t xpar;        // elements per parity copy of XS
+  int chunks_per_block, nchunks, nlc;                 // chunks = (b, 64-position window) pairs; nlc = Lq / 64
+};
+
+// TILE = 64: workgroup tile 64 co x 64 ci, waves 2 x 2, each wave all four 16-position k-steps of a chunk
+// TILE = 32: workgroup tile 32 co x 32 ci, the four waves split the k-steps of a chunk (partial sums meet in the atomics)
+template <int TILE>
+__global__ __launch_bounds__(256) void conv1d_wgrad_bf16x3_kernel(WgradB3Params p) {
+  constexpr int PITCH = 72;                           // 64 positions + 8: 144-byte rows keep 16-byte alignment, spread banks
+  __shared__ __attribute__((aligned(16))) bf16 sm[4 * TILE * PITCH];
+  bf16* ah = sm; bf16* al = sm + TILE * PITCH; bf16* bh = sm + 2 * TILE * PITCH; bf16* bl = sm + 3 * TILE * PITCH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, col = lane & 31;
+  const int ci0 = blockIdx.x * TILE, co0 = blockIdx.y * TILE;
+  const int k = blockIdx.z % p.K, split = blockIdx.z / p.K;
+  const int c = k * p.dil + p.PLmPad, r = c % p.stride, d = c / p.stride;   // tap k reads phase r at l + d
+  const int par = d & 1, dd = d - par;                                      // parity copy `par` starts at an even element
+  const int wco = TILE == 64 ? (wave & 1) : 0, wci = TILE == 64 ? (wave >> 1) : 0;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const bf16* xh = p.xh + par * p.xpar;
+  const bf16* xl = p.xl + par * p.xpar;
+  for (int cc = 0; cc < p.chunks_per_block; ++cc) {
+    const int chunk = split * p.chunks_per_block + cc;
+    if (chunk >= p.nchunks) break;
+    const int b = chunk / p.nlc, l0 = (chunk % p.nlc) * 64;
+    __syncthreads();
+    // TILE rows x 8 sixteen-byte pieces per operand half
+    for (int i = tid; i < TILE * 8; i += 256) {
+      const int row = i >> 3, pc = i & 7;
+      bf16x8 vh = zero8(), vl = zero8(), wh = zero8(), wl = zero8();
+      if (co0 + row < p.Cout) {
+        const int64_t o = ((int64_t)b * p.Cout + co0 + row) * p.Lq + l0 + pc * 8;
+        vh = *reinterpret_cast<const bf16x8*>(p.dyh + o);
+        vl = *reinterpret_cast<const bf16x8*>(p.dyl + o);
+      }
+      if (ci0 + row < p.Cin) {
+        const int64_t o = (((int64_t)b * p.Cin + ci0 + row) * p.stride + r) * p.Li + l0 + dd + pc * 8;   // even: 4-byte aligned
+        __builtin_memcpy(&wh, __builtin_assume_aligned(xh + o, 4), 16);
+        __builtin_memcpy(&wl, __builtin_assume_aligned(xl + o, 4), 16);
+      }
+      *reinterpret_cast<bf16x8*>(ah + row * PITCH + pc * 8) = vh;
+      *reinterpret_cast<bf16x8*>(al + row * PITCH + pc * 8) = vl;
+      *reinterpret_cast<bf16x8*>(bh + row * PITCH + pc * 8) = wh;
+      *reinterpret_cast<bf16x8*>(bl + row * PITCH + pc * 8) = wl;
+    }
+    __syncthreads();
+    const int arow = (wco * 32 + col) * PITCH + hh * 8, brow = (wci * 32 + col) * PITCH + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (TILE == 32 && ks != wave) continue;
+      const bf16x8 a_h = *reinterpret_cast<const bf16x8*>(ah + arow + ks * 16);
+      const bf16x8 a_l = *reinterpret_cast<const bf16x8*>(al + arow + ks * 16);
+      const bf16x8 b_h = *reinterpret_cast<const bf16x8*>(bh + brow + ks * 16);
+      const bf16x8 b_l = *reinterpret_cast<const bf16x8*>(bl + brow + ks * 16);
+      acc = mfma32(a_l, b_h, acc);
+      acc = mfma32(a_h, b_l, acc);
+      acc = mfma32(a_h, b_h, acc);
+    }
+  }
+  const int ci = ci0 + wci * 32 + col;
+  if (ci < p.Cin) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int co = co0 + wco * 32 + acc_row(i, hh);
+      if (co < p.Cout) atomicAdd(p.dw + ((int64_t)co * p.Cin + ci) * p.K + k, acc[i]);
+    }
+  }
+}
+
+static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, int B, int Cin, int Lin, int Cout, int Lout,
+                                   int K, int stride, int pad, int dil, float dy_slope, float x_slope, hipStream_t stream,
+                                   bool* handled) {
+  *handled = false;
+  if (!g_conv_ws || Cin < 16 || Cout < 16 || (g_debug_flags_conv & 4096)) return TTTS_OK;
+  const int Lq = (int)(cdiv(Lout, 64) * 64);
+  const int PL = (int)(cdiv(pad, stride) * stride);
+  const int64_t qmax = (int64_t)(Lq - 1) * stride + (int64_t)(K - 1) * dil + PL - pad;
+  const int Li = (int)((qmax / stride + 1 + 1 + 8 + 7) / 8 * 8);     // +1: odd parity copy, +8: 16-byte over-read slack
+  const int64_t dy_el = (int64_t)B * Cout * Lq, x_par = (int64_t)B * Cin * stride * Li, x_el = 2 * x_par;
+  const int64_t need = (2 * dy_el + 2 * x_el) * (int64_t)sizeof(bf16) + 64;
+  if (need > g_conv_ws_bytes) return TTTS_OK;
+  bf16* dyh = static_cast<bf16*>(g_conv_ws);
+  bf16* dyl = dyh + (dy_el + 7) / 8 * 8;
+  bf16* xh = dyl + (dy_el + 7) / 8 * 8;
+  bf16* xl = xh + x_el;
+  wgrad_split_dy_kernel<<<(int)std::min<int64_t>(cdiv(dy_el, 256), 8192), 256, 0, stream>>>(dy, dyh, dyl, (int64_t)B * Cout, Lout, Lq, dy_slope);
+  wgrad_split_x_kernel<<<(int)std::min<int64_t>(cdiv(x_el, 256), 8192), 256, 0, stream>>>(x, xh, xl, (int64_t)B * Cin, Lin, stride, Li, PL, x_slope);
+  const bool small = Cin <= 32 && Cout <= 32;
+  const int TILE = small ? 32 : 64;
+  const int nlc = Lq / 64, nchunks = B * nlc;
+  const int tiles = (int)(cdiv(Cin, TILE) * cdiv(Cout, TILE)) * K;
+  const int splits = (int)std::max<int64_t>(1, std::min<int64_t>(nchunks, cdiv(1536, tiles)));
+  const int cpb = (int)cdiv(nchunks, splits);
+  WgradB3Params p{dyh, dyl, xh, xl, dw, B, Cin, Cout, K, stride, dil, Lq, Li, PL - pad, x_par, cpb, nchunks, nlc};
+  dim3 grid((unsigned)cdiv(Cin, TILE), (unsigned)cdiv(Cout, TILE), (unsigned)(K * cdiv(nchunks, cpb)));
+  if (small) conv1d_wgrad_bf16x3_kernel<32><<<grid, 256, 0, stream>>>(p);
+  else conv1d_wgrad_bf16x3_kernel<64><<<grid, 256, 0, stream>>>(p);
+  *handled = true;
+  return check_launch("conv1d_wgrad_bf16x3");
+}
+
 int conv1d_wgrad_mfma_try(const float* dy, const float* x, float* dw, int B, int Cin, int Lin, int Cout, int Lout, int K,
                           int stride, int pad, int dil, float dy_slope, float x_slope, hipStream_t stream, bool* handled) {
   *handled = false;
+  {
+    int rc = conv1d_wgrad_bf16x3_try(dy, x, dw, B, Cin, Lin, Cout, Lout, K, stride, pad, dil, dy_slope, x_slope, stream, handled);
+    if (rc || *handled) return rc;
+  }
   if (Cin * K < 32 || Cout < 16) return TTTS_OK;
   // short rows: 16-position segments when whole 64-position chunks would be mostly padding
   const double waste64 = (double)cdiv(Lout, 64) * 64 / Lout, waste16 = (double)cdiv(Lout, 16) * 16 / Lout;

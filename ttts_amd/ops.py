@@ -307,7 +307,7 @@ def _conv_workspace(device):
         if os.environ.get("TTTS_CONV_FP32", "0") == "1":
             _conv_scratch[key] = None
         else:
-            buf = torch.empty(64 << 20, dtype=torch.uint8, device=device)
+            buf = torch.empty(int(os.environ.get("TTTS_CONV_SCRATCH_MB", "1536")) << 20, dtype=torch.uint8, device=device)
             check(_l.get().ttts_conv_set_workspace(_p(buf), buf.numel()), "conv_set_workspace")
             _conv_scratch[key] = buf
     return _conv_scratch[key]
