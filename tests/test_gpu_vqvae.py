@@ -589,6 +589,9 @@ def test_split_bf16_weight_gradient_accuracy(case):
     lout = (L + 2 * pad - dil * (k - 1) - 1) // s + 1
     dy = torch.randn(3, cout, lout, generator=g)
     dwr = torch.nn.grad.conv1d_weight(F.leaky_relu(x.double(), 0.1), (cout, cin, k), dy.double(), stride=s, padding=pad, dilation=dil)
+    from ttts_amd import lib
+    lib.get().ttts_debug_set_flags(8192)          # force the split-bf16 kernel for every shape (it is heuristic-gated)
     dw = ops.conv1d_wgrad(dy.to(_dev()), x.to(_dev()), k, s, pad, dil, x_slope=0.1)
+    lib.get().ttts_debug_set_flags(0)
     _close(dw, dwr, 2e-5, 0, "dw")
     assert _rel_l2(dw, dwr) < 1e-5

@@ -601,7 +601,12 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, i
                                    int K, int stride, int pad, int dil, float dy_slope, float x_slope, hipStream_t stream,
                                    bool* handled) {
   *handled = false;
-  if (!g_conv_ws || Cin < 16 || Cout < 16 || (g_debug_flags_conv & 4096)) return TTTS_OK;
+  if (!g_conv_ws || (g_debug_flags_conv & 4096)) return TTTS_OK;
+  // measured (tools/conv_bench.py, B = 32): one-tap-per-workgroup staging costs K x the operand traffic of the fp32 kernel,
+  // so this path wins for few taps and wide layers (DiscriminatorP/S 1024-channel k5: 1.9-2.8x, FFN k3 1.6x, 1x1 1.4x) and
+  // loses for the 7/11-tap ResBlock convolutions and for narrow long rows (pre-pass bytes); flag 8192 forces it (tests)
+  if (!(g_debug_flags_conv & 8192) && !(K <= 5 && Cin >= 128 && Cout >= 128)) return TTTS_OK;
+  if (Cin < 16 || Cout < 16) return TTTS_OK;
   const int Lq = (int)(cdiv(Lout, 64) * 64);
   const int PL = (int)(cdiv(pad, stride) * stride);
   const int64_t qmax = (int64_t)(Lq - 1) * stride + (int64_t)(K - 1) * dil + PL - pad;
