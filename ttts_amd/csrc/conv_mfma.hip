@@ -455,7 +455,8 @@ int conv1d_mfma_try(const float* x, const float* w, const float* bias, const flo
                     int stride, int pad, int dil, int transposed, float in_slope, float gate_slope, int out_act,
                     float out_slope, float out_scale, int accumulate, hipStream_t stream, bool* handled) {
   *handled = false;
-  if (N < 8 || M < 8 || K > 16) return TTTS_OK;            // thin layers / long taps stay on the direct kernels
+  if (N < 8 || K > 16) return TTTS_OK;       // thin inputs / long taps stay on the direct kernels (M = 1 heads are fine:
+                                             // a 32-row tile with one live row beats looping 1024 channels on the vector ALUs)
   ConvMfmaParams p{x, w, bias, bbias, resid, omask, gate, y, B, M, N, Lin, Lout, K, stride, pad, dil, transposed, 0,
                    K, 0, 1, 1, 0, Lout, 0, in_slope, gate_slope, out_act, out_slope, out_scale, accumulate, nullptr, nullptr, 0};
   return conv1d_mfma_launch(p, stream, handled);
@@ -469,7 +470,7 @@ int conv1d_dgrad_strided_mfma_try(const float* dy, const float* w, const float* 
                                   int Lout, int K, int stride, int pad, float in_slope, float gate_slope, float out_scale,
                                   int accumulate, hipStream_t stream, bool* handled) {
   *handled = false;
-  if (Cout < 8 || Cin < 8 || K > 16 * stride || K < stride) return TTTS_OK;
+  if (Cout < 8 || K > 16 * stride || K < stride) return TTTS_OK;
   for (int phi = 0; phi < stride; ++phi) {
     const int Kp = (K - phi + stride - 1) / stride;                       // taps of this phase (>= 1 since K >= stride)
     const int tmin = phi >= pad ? 0 : (pad - phi + stride - 1) / stride;  // first t' with a non-negative output position
@@ -641,7 +642,7 @@ int conv1d_wgrad_mfma_try(const float* dy, const float* x, float* dw, int B, int
     int rc = conv1d_wgrad_bf16x3_try(dy, x, dw, B, Cin, Lin, Cout, Lout, K, stride, pad, dil, dy_slope, x_slope, stream, handled);
     if (rc || *handled) return rc;
   }
-  if (Cin * K < 32 || Cout < 16) return TTTS_OK;
+  if (Cin * K < 32) return TTTS_OK;
   // short rows: 16-position segments when whole 64-position chunks would be mostly padding
   const double waste64 = (double)cdiv(Lout, 64) * 64 / Lout, waste16 = (double)cdiv(Lout, 16) * 16 / Lout;
   const int SEGW = (waste64 > 1.15 * waste16) ? 16 : 64;
