@@ -362,10 +362,11 @@ def conv1d_wgrad(dy, x, k, stride=1, pad=0, dil=1, x_slope=1.0, dy_slope=1.0, ou
     return dw
 
 
-def conv1d_bias_grad(dy):
+def conv1d_bias_grad(dy, out=None):
+    """db[c] (+)= sum_{b,l} dy; `out` accumulates in place."""
     dy = dy.contiguous()
     B, C, L = dy.shape
-    db = torch.zeros(C, dtype=torch.float32, device=dy.device)
+    db = torch.zeros(C, dtype=torch.float32, device=dy.device) if out is None else out
     check(_l.get().ttts_conv1d_bias_grad_f32(_p(dy), _p(db), B, C, L, _stream()), "conv1d_bias_grad")
     return db
 
@@ -379,11 +380,12 @@ def weight_norm_fwd(v, g):
     return w, norm
 
 
-def weight_norm_bwd(dw, v, g, norm):
+def weight_norm_bwd(dw, v, g, norm, dv=None, dg=None):
+    """dv, dg given: accumulate into them (the kernels add), e.g. straight into the flat gradient arena."""
     v = v.contiguous(); dw = dw.contiguous()
     rows, n = v.shape[0], v.numel() // v.shape[0]
-    dv = torch.zeros_like(v)
-    dg = torch.zeros_like(g).contiguous()
+    dv = torch.zeros_like(v) if dv is None else dv
+    dg = torch.zeros_like(g).contiguous() if dg is None else dg
     check(_l.get().ttts_weight_norm_bwd_f32(_p(dw), _p(v), _p(g.contiguous()), _p(norm), _p(dv), _p(dg), rows, n, _stream()),
           "weight_norm_bwd")
     return dv, dg

@@ -27,16 +27,31 @@ def get_padding(kernel_size, dilation=1):
 
 
 # ---- autograd glue ------------------------------------------------------------------------------------------------------
+def _grad_slot(p):
+    """A leaf parameter whose `.grad` already exists (FlatAdamW gives every parameter a persistent view of the flat
+    gradient arena): the backward kernels, which all ACCUMULATE, then write straight into it and the Function returns
+    None for that input -- no zero-filled temporary and no autograd `grad += temp` launch per parameter (the two were
+    ~3000 of the ~14000 launches of a VQ-VAE-GAN step).  Returns None when the ordinary autograd route must be used."""
+    if p is not None and p.is_leaf and p.requires_grad and p.grad is not None and p.grad.is_contiguous():
+        return p.grad
+    return None
+
+
 class _WeightNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, v, g):
         w, norm = ops.weight_norm_fwd(v, g)
         ctx.save_for_backward(v, g, norm)
+        ctx.refs = (v, g)
         return w
 
     @staticmethod
     def backward(ctx, dw):
         v, g, norm = ctx.saved_tensors
+        sv, sg = _grad_slot(ctx.refs[0]), _grad_slot(ctx.refs[1])
+        if sv is not None and sg is not None:
+            ops.weight_norm_bwd(dw, v, g, norm, dv=sv, dg=sg)
+            return None, None
         dv, dg = ops.weight_norm_bwd(dw, v, g, norm)
         return dv, dg
 
@@ -54,6 +69,7 @@ class _Conv1dFn(torch.autograd.Function):
         ctx.save_for_backward(x, w, y if out_act else None, omask)
         ctx.cfg = (stride, pad, dil, in_slope, out_act, groups, out_slope, bias is not None, resid is not None,
                    bbias is not None)
+        ctx.refs = (w, bias)
         return y
 
     @staticmethod
@@ -73,9 +89,15 @@ class _Conv1dFn(torch.autograd.Function):
             gate = x if in_slope != 1.0 else None
             dx = ops.conv1d_dgrad(dy, w, x.shape[2], stride, pad, dil, gate=gate, gate_slope=in_slope, groups=groups)
         if need[1]:
-            dw = ops.conv1d_wgrad(dy, x, w.shape[2], stride, pad, dil, x_slope=in_slope, groups=groups)
+            slot = _grad_slot(ctx.refs[0])
+            dw = ops.conv1d_wgrad(dy, x, w.shape[2], stride, pad, dil, x_slope=in_slope, groups=groups, out=slot)
+            if slot is not None:
+                dw = None
         if has_b and need[2]:
-            db = ops.conv1d_bias_grad(dy)
+            slot = _grad_slot(ctx.refs[1])
+            db = ops.conv1d_bias_grad(dy, out=slot)
+            if slot is not None:
+                db = None
         if has_bb and need[4]:
             B, C, L = dy.shape
             dbb = ops.conv1d_bias_grad(dy.view(1, B * C, L)).view(B, C)
@@ -91,6 +113,7 @@ class _ConvTranspose1dFn(torch.autograd.Function):
         y = ops.conv1d_dgrad(x, w, lout, stride, pad, 1, bias=bias, in_slope=in_slope)
         ctx.save_for_backward(x, w)
         ctx.cfg = (stride, pad, in_slope, bias is not None)
+        ctx.refs = (w, bias)
         return y
 
     @staticmethod
@@ -103,9 +126,15 @@ class _ConvTranspose1dFn(torch.autograd.Function):
         if need[0]:
             dx = ops.conv1d_fwd(dy, w, stride=stride, pad=pad, gate=x if in_slope != 1.0 else None, gate_slope=in_slope)
         if need[1]:
-            dw = ops.conv1d_wgrad(x, dy, w.shape[2], stride, pad, 1, dy_slope=in_slope)
+            slot = _grad_slot(ctx.refs[0])
+            dw = ops.conv1d_wgrad(x, dy, w.shape[2], stride, pad, 1, dy_slope=in_slope, out=slot)
+            if slot is not None:
+                dw = None
         if has_b and need[2]:
-            db = ops.conv1d_bias_grad(dy)
+            slot = _grad_slot(ctx.refs[1])
+            db = ops.conv1d_bias_grad(dy, out=slot)
+            if slot is not None:
+                db = None
         return dx, dw, db, None, None, None
 
 
@@ -430,6 +459,7 @@ class _WNFn(torch.autograd.Function):
             xi = x_next
         ctx.save_for_backward(m2, *saved, *params)
         ctx.cfg = (n_layers, K, dil_rate, gcond is not None, H)
+        ctx.prefs = params
         return out
 
     @staticmethod
@@ -450,25 +480,37 @@ class _WNFn(torch.autograd.Function):
             dil = dil_rate ** i
             pad = int((K * dil - dil) / 2)
             dw_rs = torch.zeros_like(w_rs)
+            slots = [_grad_slot(t) for t in ctx.prefs[6 * i:6 * i + 6]]      # in_v, in_g, in_b, rs_v, rs_g, rs_b
+            direct = all(sl is not None for sl in slots)
             if i < n_layers - 1:
                 dacts = ops.conv1d_dgrad(dres, w_rs[:H], T)
                 ops.conv1d_dgrad(dsk, w_rs[H:], T, out=dacts, accumulate=True)
                 ops.conv1d_wgrad(dres, acts, 1, out=dw_rs[:H])
                 ops.conv1d_wgrad(dsk, acts, 1, out=dw_rs[H:])
-                db_rs = torch.cat([ops.conv1d_bias_grad(dres), ops.conv1d_bias_grad(dsk)])
+                if direct:
+                    ops.conv1d_bias_grad(dres, out=slots[5][:H]); ops.conv1d_bias_grad(dsk, out=slots[5][H:])
+                    db_rs = None
+                else:
+                    db_rs = torch.cat([ops.conv1d_bias_grad(dres), ops.conv1d_bias_grad(dsk)])
             else:
                 dacts = ops.conv1d_dgrad(dsk, w_rs, T)
                 ops.conv1d_wgrad(dsk, acts, 1, out=dw_rs)
-                db_rs = ops.conv1d_bias_grad(dsk)
+                db_rs = ops.conv1d_bias_grad(dsk, out=slots[5] if direct else None)
+                if direct:
+                    db_rs = None
             dx_in = ops.gate_bwd(dacts, x_in, ops.GATE_TANH_SIGMOID)
             if has_g:
                 dgs[i] = ops.conv1d_bias_grad(dx_in.view(1, B * 2 * H, T)).view(B, 2 * H)
-            db_in = ops.conv1d_bias_grad(dx_in)
+            db_in = ops.conv1d_bias_grad(dx_in, out=slots[2] if direct else None)
             dw_in = ops.conv1d_wgrad(dx_in, xi, K, 1, pad, dil)
             dres = ops.conv1d_dgrad(dx_in, w_in, T, 1, pad, dil, resid=dres, omask=m2 if i > 0 else None)
-            dv_in, dg_in = ops.weight_norm_bwd(dw_in, in_v, in_g, n_in)
-            dv_rs, dg_rs = ops.weight_norm_bwd(dw_rs, rs_v, rs_g, n_rs)
-            pgrads[6 * i:6 * i + 6] = [dv_in, dg_in, db_in, dv_rs, dg_rs, db_rs]
+            if direct:
+                ops.weight_norm_bwd(dw_in, in_v, in_g, n_in, dv=slots[0], dg=slots[1])
+                ops.weight_norm_bwd(dw_rs, rs_v, rs_g, n_rs, dv=slots[3], dg=slots[4])
+            else:
+                dv_in, dg_in = ops.weight_norm_bwd(dw_in, in_v, in_g, n_in)
+                dv_rs, dg_rs = ops.weight_norm_bwd(dw_rs, rs_v, rs_g, n_rs)
+                pgrads[6 * i:6 * i + 6] = [dv_in, dg_in, db_in, dv_rs, dg_rs, db_rs]
         dg = torch.cat(dgs, dim=1).unsqueeze(-1) if has_g else None
         return (dres, None, dg, None, None, None, *pgrads)
 
