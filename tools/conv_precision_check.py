@@ -1,5 +1,6 @@
+"""Compares the default split-bf16 convolution kernels with the exact f32-MFMA kernels (flag 4096) on a few path shapes: max relative difference of forward and data gradient.  usage (GPU box): python tools/conv_precision_check.py"""
 import sys, os
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ttts_amd import lib, ops
 dev = torch.device("cuda", 0)
