@@ -530,6 +530,8 @@ struct WgradB3Params {
   int B, Cin, Cout, K, stride, dil, Lq, Li, PLmPad;   // PLmPad = PL - pad >= 0
   int64_t xpar;        // elements per parity copy of XS
   int chunks_per_block, nchunks, nlc;                 // chunks = (b, 64-position window) pairs; nlc = Lq / 64
+  float* slab;         // all-taps kernel: per-split partial sums [split][k][co][ci] (plain coalesced stores; device-scope fp32
+                       // atomics onto a 128x128x11 weight from 128 splits were the dominant cost), summed by wgrad_slab_reduce
 };
 
 // TILE = 64: workgroup tile 64 co x 64 ci, waves 2 x 2, each wave all four 16-position k-steps of a chunk
@@ -598,11 +600,174 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_bf16x3_kernel(WgradB3Params 
   }
 }
 
+// ---- split-bf16 weight gradient, ALL taps per workgroup (stride 1; the 3/7/11-tap dilated ResBlock1 convolutions) ---------
+// Same pre-split operands as above, but the workgroup stages one x window of 64 + (K-1)*DIL positions and every tap reads it at
+// its own offset k*DIL, so the operand traffic no longer grows with K.  An offset that is not a multiple of 8 elements is
+// served by two aligned 16-byte LDS reads and a compile-time element shuffle (K and DIL are template parameters), K
+// accumulators per wave (K = 11: 176 VGPRs, two waves per SIMD).  Per 64-position chunk a wave issues 12 K MFMAs against
+// ~12 sixteen-byte global loads per thread: matrix-core bound.
+typedef __attribute__((ext_vector_type(16))) __bf16 bf16x16;
+
+template <int S>
+__device__ __forceinline__ bf16x8 window8(bf16x8 lo, bf16x8 hi) {
+  const bf16x16 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+  return __builtin_shufflevector(v, v, S, S + 1, S + 2, S + 3, S + 4, S + 5, S + 6, S + 7);
+}
+
+// taps [K0, K0 + KN) of a K-tap convolution (K = 11 runs as two launches of 6 + 5 taps: 11 accumulators would spill)
+template <int K, int DIL, int K0, int KN>
+__global__ __launch_bounds__(256, 2) void conv1d_wgrad_bf16x3_taps_kernel(WgradB3Params p) {
+  constexpr int PITCH = 72;
+  constexpr int BASE = (K0 * DIL) / 8 * 8;                // aligned start of the staged window (tap K0 begins at K0*DIL)
+  constexpr int WIN = 64 + (K0 + KN - 1) * DIL - BASE;    // window positions
+  constexpr int WP = ((WIN + 7) / 8 * 8 + 8) | 8;         // row pitch: an ODD number of 16-byte pieces (a 256-byte pitch
+                                                          // would put all 32 rows of a fragment read on the same banks)
+  __shared__ __attribute__((aligned(16))) bf16 sm[2 * 64 * PITCH + 2 * 64 * WP];
+  bf16* ah = sm; bf16* al = sm + 64 * PITCH; bf16* bh = sm + 2 * 64 * PITCH; bf16* bl = bh + 64 * WP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, col = lane & 31;
+  const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64, split = blockIdx.z;
+  const int wco = wave & 1, wci = wave >> 1;
+  f32x16 acc[KN];
+#pragma unroll
+  for (int k = 0; k < KN; ++k)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
+  // stride 1: tap k reads x'[l + k*DIL + (PL - pad)] with PL == pad, parity copy 0 (element i holds x[i - pad])
+  for (int cc = 0; cc < p.chunks_per_block; ++cc) {
+    const int chunk = split * p.chunks_per_block + cc;
+    if (chunk >= p.nchunks) break;
+    const int b = chunk / p.nlc, l0 = (chunk % p.nlc) * 64;
+    __syncthreads();
+    for (int i = tid; i < 64 * 8; i += 256) {
+      const int row = i >> 3, pc = i & 7;
+      bf16x8 vh = zero8(), vl = zero8();
+      if (co0 + row < p.Cout) {
+        const int64_t o = ((int64_t)b * p.Cout + co0 + row) * p.Lq + l0 + pc * 8;
+        vh = *reinterpret_cast<const bf16x8*>(p.dyh + o);
+        vl = *reinterpret_cast<const bf16x8*>(p.dyl + o);
+      }
+      *reinterpret_cast<bf16x8*>(ah + row * PITCH + pc * 8) = vh;
+      *reinterpret_cast<bf16x8*>(al + row * PITCH + pc * 8) = vl;
+    }
+    for (int i = tid; i < 64 * (WP / 8); i += 256) {
+      const int row = i / (WP / 8), pc = i % (WP / 8);
+      bf16x8 wh = zero8(), wl = zero8();
+      if (ci0 + row < p.Cin) {
+        const int64_t o = ((int64_t)b * p.Cin + ci0 + row) * p.Li + l0 + BASE + pc * 8;   // Li % 8 == 0, l0 % 64 == 0: 16-byte aligned
+        wh = *reinterpret_cast<const bf16x8*>(p.xh + o);
+        wl = *reinterpret_cast<const bf16x8*>(p.xl + o);
+      }
+      *reinterpret_cast<bf16x8*>(bh + row * WP + pc * 8) = wh;
+      *reinterpret_cast<bf16x8*>(bl + row * WP + pc * 8) = wl;
+    }
+    __syncthreads();
+    const bf16* arow_h = ah + (wco * 32 + col) * PITCH + hh * 8;
+    const bf16* arow_l = al + (wco * 32 + col) * PITCH + hh * 8;
+    const bf16* brow_h = bh + (wci * 32 + col) * WP + hh * 8;
+    const bf16* brow_l = bl + (wci * 32 + col) * WP + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8 a_h = *reinterpret_cast<const bf16x8*>(arow_h + ks * 16);
+      const bf16x8 a_l = *reinterpret_cast<const bf16x8*>(arow_l + ks * 16);
+#pragma unroll
+      for (int k = 0; k < KN; ++k) {
+        const int toff = (K0 + k) * DIL - BASE;             // tap offset inside the staged window (compile-time)
+        const int off = ks * 16 + (toff / 8) * 8;           // its aligned part
+        const bf16x8 h0 = *reinterpret_cast<const bf16x8*>(brow_h + off), h1 = *reinterpret_cast<const bf16x8*>(brow_h + off + 8);
+        const bf16x8 l0v = *reinterpret_cast<const bf16x8*>(brow_l + off), l1v = *reinterpret_cast<const bf16x8*>(brow_l + off + 8);
+        bf16x8 b_h, b_l;
+        switch (toff & 7) {                                  // compile-time after unrolling
+          case 0: b_h = h0; b_l = l0v; break;
+          case 1: b_h = window8<1>(h0, h1); b_l = window8<1>(l0v, l1v); break;
+          case 2: b_h = window8<2>(h0, h1); b_l = window8<2>(l0v, l1v); break;
+          case 3: b_h = window8<3>(h0, h1); b_l = window8<3>(l0v, l1v); break;
+          case 4: b_h = window8<4>(h0, h1); b_l = window8<4>(l0v, l1v); break;
+          case 5: b_h = window8<5>(h0, h1); b_l = window8<5>(l0v, l1v); break;
+          case 6: b_h = window8<6>(h0, h1); b_l = window8<6>(l0v, l1v); break;
+          default: b_h = window8<7>(h0, h1); b_l = window8<7>(l0v, l1v); break;
+        }
+        acc[k] = mfma32(a_l, b_h, acc[k]);
+        acc[k] = mfma32(a_h, b_l, acc[k]);
+        acc[k] = mfma32(a_h, b_h, acc[k]);
+      }
+    }
+  }
+  const int ci = ci0 + wci * 32 + col;
+  if (ci < p.Cin) {
+    float* sl = p.slab + (int64_t)split * K * p.Cout * p.Cin;
+#pragma unroll
+    for (int k = 0; k < KN; ++k)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int co = co0 + wco * 32 + acc_row(i, hh);
+        if (co < p.Cout) sl[((int64_t)(K0 + k) * p.Cout + co) * p.Cin + ci] = acc[k][i];
+      }
+  }
+}
+
+// dw[co][ci][k] += sum_split slab[split][k][co][ci]
+__global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsplit,
+                                                                int K, int Cout, int Cin) {
+  const int64_t per = (int64_t)K * Cout * Cin;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (int64_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) s += slab[sp * per + i];
+    const int ci = (int)(i % Cin), co = (int)((i / Cin) % Cout), k = (int)(i / Cin / Cout);
+    dw[((int64_t)co * Cin + ci) * K + k] += s;
+  }
+}
+
+template <int K, int DIL>
+static void launch_wgrad_taps(const WgradB3Params& p, dim3 grid, hipStream_t stream) {
+  if (K <= 7) {
+    conv1d_wgrad_bf16x3_taps_kernel<K, DIL, 0, (K <= 7 ? K : 1)><<<grid, 256, 0, stream>>>(p);
+  } else {
+    conv1d_wgrad_bf16x3_taps_kernel<K, DIL, 0, 6><<<grid, 256, 0, stream>>>(p);
+    conv1d_wgrad_bf16x3_taps_kernel<K, DIL, 6, (K > 6 ? K - 6 : 1)><<<grid, 256, 0, stream>>>(p);
+  }
+}
+
 static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, int B, int Cin, int Lin, int Cout, int Lout,
                                    int K, int stride, int pad, int dil, float dy_slope, float x_slope, hipStream_t stream,
                                    bool* handled) {
   *handled = false;
   if (!g_conv_ws || (g_debug_flags_conv & 4096)) return TTTS_OK;
+  // all-taps kernel: stride 1, "same" padding of the ResBlock1 family (K in {3, 7, 11}, dilation in {1, 3, 5}), >= 32 channels
+  const bool taps = stride == 1 && (K == 3 || K == 7 || K == 11) && (dil == 1 || dil == 3 || dil == 5) &&
+                    ((Cin >= 128 && Cout >= 128) || ((g_debug_flags_conv & 8192) && Cin >= 32 && Cout >= 32)) &&   // measured: 1.9x at
+                    !(g_debug_flags_conv & 16384);   // C = 128/256, slower below (one 64x64 tile: 512 slabs, or half-empty tiles)
+  if (taps) {
+    const int Lq = (int)(cdiv(Lout, 64) * 64);
+    const int WPmax = ((64 + (K - 1) * dil + 7) / 8 * 8 + 8) | 8;
+    const int Li = (int)(((int64_t)Lq + (K - 1) * dil + WPmax + 8 + 7) / 8 * 8);   // every staged 16-byte piece stays inside the row
+    const int64_t dy_el = (int64_t)B * Cout * Lq, x_par = (int64_t)B * Cin * Li;
+    const int nlc0 = Lq / 64, nchunks0 = B * nlc0;
+    const int tiles0 = (int)(cdiv(Cin, 64) * cdiv(Cout, 64));
+    const int splits0 = (int)std::max<int64_t>(1, std::min<int64_t>(nchunks0, cdiv(512, tiles0)));
+    const int cpb0 = (int)cdiv(nchunks0, splits0);
+    const int nsplit = (int)cdiv(nchunks0, cpb0);
+    const int64_t slab_el = (int64_t)nsplit * K * Cout * Cin;
+    const int64_t need = (2 * dy_el + 4 * x_par) * (int64_t)sizeof(bf16) + slab_el * (int64_t)sizeof(float) + 128;
+    if (need <= g_conv_ws_bytes) {
+      bf16* dyh = static_cast<bf16*>(g_conv_ws);
+      bf16* dyl = dyh + (dy_el + 7) / 8 * 8;
+      bf16* xh = dyl + (dy_el + 7) / 8 * 8;
+      bf16* xl = xh + 2 * x_par;
+      wgrad_split_dy_kernel<<<(int)std::min<int64_t>(cdiv(dy_el, 256), 8192), 256, 0, stream>>>(dy, dyh, dyl, (int64_t)B * Cout, Lout, Lq, dy_slope);
+      wgrad_split_x_kernel<<<(int)std::min<int64_t>(cdiv(2 * x_par, 256), 8192), 256, 0, stream>>>(x, xh, xl, (int64_t)B * Cin, Lin, 1, Li, pad, x_slope);
+      const int nlc = nlc0, nchunks = nchunks0, cpb = cpb0;
+      float* slab = reinterpret_cast<float*>(reinterpret_cast<char*>(xl + 2 * x_par) + ((16 - (reinterpret_cast<uintptr_t>(xl + 2 * x_par) & 15)) & 15));
+      WgradB3Params p{dyh, dyl, xh, xl, dw, B, Cin, Cout, K, 1, dil, Lq, Li, 0, x_par, cpb, nchunks, nlc, slab};
+      dim3 grid((unsigned)cdiv(Cin, 64), (unsigned)cdiv(Cout, 64), (unsigned)nsplit);
+#define TTTS_TAPS(KK, DD) if (K == KK && dil == DD) launch_wgrad_taps<KK, DD>(p, grid, stream);
+      TTTS_TAPS(3, 1) TTTS_TAPS(3, 3) TTTS_TAPS(3, 5) TTTS_TAPS(7, 1) TTTS_TAPS(7, 3) TTTS_TAPS(7, 5)
+      TTTS_TAPS(11, 1) TTTS_TAPS(11, 3) TTTS_TAPS(11, 5)
+#undef TTTS_TAPS
+      wgrad_slab_reduce_kernel<<<(int)std::min<int64_t>(cdiv((int64_t)K * Cout * Cin, 256), 4096), 256, 0, stream>>>(slab, dw, nsplit, K, Cout, Cin);
+      *handled = true;
+      return check_launch("conv1d_wgrad_bf16x3_taps");
+    }
+  }
   // measured (tools/conv_bench.py, B = 32): one-tap-per-workgroup staging costs K x the operand traffic of the fp32 kernel,
   // so this path wins for few taps and wide layers (DiscriminatorP/S 1024-channel k5: 1.9-2.8x, FFN k3 1.6x, 1x1 1.4x) and
   // loses for the 7/11-tap ResBlock convolutions and for narrow long rows (pre-pass bytes); flag 8192 forces it (tests)
@@ -627,7 +792,7 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, i
   const int tiles = (int)(cdiv(Cin, TILE) * cdiv(Cout, TILE)) * K;
   const int splits = (int)std::max<int64_t>(1, std::min<int64_t>(nchunks, cdiv(1536, tiles)));
   const int cpb = (int)cdiv(nchunks, splits);
-  WgradB3Params p{dyh, dyl, xh, xl, dw, B, Cin, Cout, K, stride, dil, Lq, Li, PL - pad, x_par, cpb, nchunks, nlc};
+  WgradB3Params p{dyh, dyl, xh, xl, dw, B, Cin, Cout, K, stride, dil, Lq, Li, PL - pad, x_par, cpb, nchunks, nlc, nullptr};
   dim3 grid((unsigned)cdiv(Cin, TILE), (unsigned)cdiv(Cout, TILE), (unsigned)(K * cdiv(nchunks, cpb)));
   if (small) conv1d_wgrad_bf16x3_kernel<32><<<grid, 256, 0, stream>>>(p);
   else conv1d_wgrad_bf16x3_kernel<64><<<grid, 256, 0, stream>>>(p);
