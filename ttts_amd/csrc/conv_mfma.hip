@@ -280,6 +280,20 @@ __global__ __launch_bounds__(256) void conv1d_bf16x3_kernel(ConvMfmaParams p) {
   }
 }
 
+// dw[i] += sum_split slab[split][i];  blockIdx.y sums a group of SLAB_G splits and adds its partial with one atomic (a single
+// thread walking 1000 splits of a small weight tensor would be latency-bound; nsplit / SLAB_G atomics per element are few)
+constexpr int SLAB_G = 16;
+__global__ __launch_bounds__(256) void wgrad_slab_sum_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsplit,
+                                                             int64_t per) {
+  const int s0 = blockIdx.y * SLAB_G, s1 = min(nsplit, s0 + SLAB_G);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (int64_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int sp = s0; sp < s1; ++sp) s += slab[sp * per + i];
+    if (gridDim.y == 1) dw[i] += s;
+    else atomicAdd(dw + i, s);
+  }
+}
+
 // ---- weight gradient ---------------------------------------------------------------------------------------------------
 // dw[co][n] += sum_{b, l} lrelu(dy[b][co][l]) * lrelu(x[b][n / K][l*stride - pad + (n % K)*dil]),  n in [0, Cin*K)
 // workgroup tile 64 co x 64 n; waves 2 (co) x 2 (n); reduction chunk = 64 positions of one batch element per stage.
@@ -288,6 +302,7 @@ struct WgradMfmaParams {
   int B, Cin, Lin, Cout, Lout, K, stride, pad, dil;
   float dy_slope, x_slope;
   int chunks_per_block;
+  float* slab;         // non-NULL: per-split partial sums [split][Cout][Cin*K] (plain stores) instead of atomics into dw
   int SEGW;            // positions per segment of a 64-position reduction chunk: 64, or 16 for short rows (a chunk then holds
                        // 4 (batch element, 16-position window) segments: DiscriminatorP rows are 23..127 positions long)
 };
@@ -348,10 +363,14 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_mfma_kernel(WgradMfmaParams 
     }
   }
   if (ncol_ok) {
+    float* sl = p.slab ? p.slab + (int64_t)blockIdx.z * p.Cout * NK : nullptr;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + wco * 32 + acc_row(r, hh);
-      if (co < p.Cout) atomicAdd(p.dw + (int64_t)co * NK + n, acc[r]);
+      if (co < p.Cout) {
+        if (sl) sl[(int64_t)co * NK + n] = acc[r];
+        else atomicAdd(p.dw + (int64_t)co * NK + n, acc[r]);
+      }
     }
   }
 }
@@ -592,10 +611,15 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_bf16x3_kernel(WgradB3Params 
   }
   const int ci = ci0 + wci * 32 + col;
   if (ci < p.Cin) {
+    // TILE 64: one wave owns an output element of its split -> plain slab stores; TILE 32: four waves share it -> atomics
+    float* sl = (p.slab && TILE == 64) ? p.slab + ((int64_t)split * p.K + k) * p.Cout * p.Cin : nullptr;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int co = co0 + wco * 32 + acc_row(i, hh);
-      if (co < p.Cout) atomicAdd(p.dw + ((int64_t)co * p.Cin + ci) * p.K + k, acc[i]);
+      if (co < p.Cout) {
+        if (sl) sl[(int64_t)co * p.Cin + ci] = acc[i];
+        else atomicAdd(p.dw + ((int64_t)co * p.Cin + ci) * p.K + k, acc[i]);
+      }
     }
   }
 }
@@ -709,11 +733,14 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad_bf16x3_taps_kernel(WgradB
 __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsplit,
                                                                 int K, int Cout, int Cin) {
   const int64_t per = (int64_t)K * Cout * Cin;
+  const int s0 = blockIdx.y * SLAB_G, s1 = min(nsplit, s0 + SLAB_G);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (int64_t)gridDim.x * 256) {
     float s = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) s += slab[sp * per + i];
+    for (int sp = s0; sp < s1; ++sp) s += slab[sp * per + i];
     const int ci = (int)(i % Cin), co = (int)((i / Cin) % Cout), k = (int)(i / Cin / Cout);
-    dw[((int64_t)co * Cin + ci) * K + k] += s;
+    float* o = dw + ((int64_t)co * Cin + ci) * K + k;
+    if (gridDim.y == 1) *o += s;
+    else atomicAdd(o, s);
   }
 }
 
@@ -763,7 +790,7 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, i
       TTTS_TAPS(3, 1) TTTS_TAPS(3, 3) TTTS_TAPS(3, 5) TTTS_TAPS(7, 1) TTTS_TAPS(7, 3) TTTS_TAPS(7, 5)
       TTTS_TAPS(11, 1) TTTS_TAPS(11, 3) TTTS_TAPS(11, 5)
 #undef TTTS_TAPS
-      wgrad_slab_reduce_kernel<<<(int)std::min<int64_t>(cdiv((int64_t)K * Cout * Cin, 256), 4096), 256, 0, stream>>>(slab, dw, nsplit, K, Cout, Cin);
+      wgrad_slab_reduce_kernel<<<dim3((unsigned)std::min<int64_t>(cdiv((int64_t)K * Cout * Cin, 256), 4096), (unsigned)cdiv(nsplit, SLAB_G)), 256, 0, stream>>>(slab, dw, nsplit, K, Cout, Cin);
       *handled = true;
       return check_launch("conv1d_wgrad_bf16x3_taps");
     }
@@ -792,10 +819,19 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, i
   const int tiles = (int)(cdiv(Cin, TILE) * cdiv(Cout, TILE)) * K;
   const int splits = (int)std::max<int64_t>(1, std::min<int64_t>(nchunks, cdiv(1536, tiles)));
   const int cpb = (int)cdiv(nchunks, splits);
-  WgradB3Params p{dyh, dyl, xh, xl, dw, B, Cin, Cout, K, stride, dil, Lq, Li, PL - pad, x_par, cpb, nchunks, nlc, nullptr};
-  dim3 grid((unsigned)cdiv(Cin, TILE), (unsigned)cdiv(Cout, TILE), (unsigned)(K * cdiv(nchunks, cpb)));
+  const int nsp = (int)cdiv(nchunks, cpb);
+  float* slab = nullptr;
+  {
+    char* end = reinterpret_cast<char*>(xl + x_el);
+    end += (16 - (reinterpret_cast<uintptr_t>(end) & 15)) & 15;
+    const int64_t slab_bytes = (int64_t)nsp * K * Cout * Cin * (int64_t)sizeof(float);
+    if (!small && nsp > 1 && (end - static_cast<char*>(g_conv_ws)) + slab_bytes <= g_conv_ws_bytes) slab = reinterpret_cast<float*>(end);
+  }
+  WgradB3Params p{dyh, dyl, xh, xl, dw, B, Cin, Cout, K, stride, dil, Lq, Li, PL - pad, x_par, cpb, nchunks, nlc, slab};
+  dim3 grid((unsigned)cdiv(Cin, TILE), (unsigned)cdiv(Cout, TILE), (unsigned)(K * nsp));
   if (small) conv1d_wgrad_bf16x3_kernel<32><<<grid, 256, 0, stream>>>(p);
   else conv1d_wgrad_bf16x3_kernel<64><<<grid, 256, 0, stream>>>(p);
+  if (slab) wgrad_slab_reduce_kernel<<<dim3((unsigned)std::min<int64_t>(cdiv((int64_t)K * Cout * Cin, 256), 4096), (unsigned)cdiv(nsp, SLAB_G)), 256, 0, stream>>>(slab, dw, nsp, K, Cout, Cin);
   *handled = true;
   return check_launch("conv1d_wgrad_bf16x3");
 }
@@ -819,12 +855,19 @@ int conv1d_wgrad_mfma_try(const float* dy, const float* x, float* dw, int B, int
   const int tiles = (int)(cdiv(Cin * K, 64) * cdiv(Cout, 64));
   const int splits = (int)std::max<int64_t>(1, std::min<int64_t>(chunks, cdiv(2048, tiles)));
   const int cpb = (int)cdiv(chunks, splits);
-  WgradMfmaParams p{dy, x, dw, B, Cin, Lin, Cout, Lout, K, stride, pad, dil, dy_slope, x_slope, cpb, SEGW};
+  const int nz = (int)cdiv(chunks, cpb);
+  // partial sums go to per-split slabs + one reduce pass when the caller-owned scratch is available (deterministic, and
+  // device-scope fp32 atomics from hundreds of splits onto a small weight tensor cost more than the GEMM itself)
+  float* slab = nullptr;
+  const int64_t per = (int64_t)Cout * Cin * K;
+  if (g_conv_ws && nz > 1 && (int64_t)nz * per * (int64_t)sizeof(float) <= g_conv_ws_bytes) slab = static_cast<float*>(g_conv_ws);
+  WgradMfmaParams p{dy, x, dw, B, Cin, Lin, Cout, Lout, K, stride, pad, dil, dy_slope, x_slope, cpb, slab, SEGW};
   static bool a = false;
   int rc = set_attr_once(reinterpret_cast<const void*>(conv1d_wgrad_mfma_kernel), a);
   if (rc) return rc;
-  dim3 grid((unsigned)cdiv(Cin * K, 64), (unsigned)cdiv(Cout, 64), (unsigned)cdiv(chunks, cpb));
+  dim3 grid((unsigned)cdiv(Cin * K, 64), (unsigned)cdiv(Cout, 64), (unsigned)nz);
   conv1d_wgrad_mfma_kernel<<<grid, 256, smem, stream>>>(p);
+  if (slab) wgrad_slab_sum_kernel<<<dim3((unsigned)std::min<int64_t>(cdiv(per, 256), 4096), (unsigned)cdiv(nz, SLAB_G)), 256, 0, stream>>>(slab, dw, nz, per);
   *handled = true;
   return check_launch("conv1d_wgrad_mfma");
 }
