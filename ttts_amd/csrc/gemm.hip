@@ -51,17 +51,20 @@ struct GemmNtParams {
 
 // ---- shared epilogue: accumulators -> fp32 LDS stage (64 rows at a time) -> coalesced global access ---------------
 // stage: >= 64 * ST_LD floats of LDS that no wave reads any more (callers end their main loop with a barrier).
-template <int EPI>
+// NJ = 32-column blocks per wave: 2 for the 128 x 128 tile, 1 for the 128 x 64 tile (N = 512 GEMMs: 292 -> 584 tiles)
+template <int EPI, int NJ = 2>
 __device__ __forceinline__ void tile_epilogue(const GemmEpi& e, f32x16 (&acc)[2][2], float* stage, int m0, int n0,
                                               int tid) {
+  constexpr int TPR = 8 * NJ;              // threads per 64*NJ-column row (8 columns each)
+  constexpr int RPP = 256 / TPR;           // rows per read-back pass
   const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, h = lane >> 5;
   const bool bf16_out = (EPI == TTTS_EPI_STORE_BF16 || EPI == TTTS_EPI_GELU_BF16 || EPI == TTTS_EPI_DGELU_BF16);
   const bool vec_ok = bf16_out ? ((e.ldc & 7) == 0) : ((e.ldc & 3) == 0);
-  // this thread stores columns n0 + (tid & 15)*8 .. +8 of every row it touches: fetch their bias once
+  // this thread stores columns n0 + (tid % TPR)*8 .. +8 of every row it touches: fetch their bias once
   float bias8[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
-    const int n = n0 + (tid & 15) * 8 + t;
+    const int n = n0 + (tid % TPR) * 8 + t;
     const float b = (e.bias && n < e.N) ? e.bias[n] : 0.f;
     bias8[t] = (EPI == TTTS_EPI_STORE_F32) ? b : (float)(bf16)b;  // autocast rounds the bias to bf16
   }
@@ -71,25 +74,25 @@ __device__ __forceinline__ void tile_epilogue(const GemmEpi& e, f32x16 (&acc)[2]
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const int col = wn * 64 + j * 32 + 8 * q + 4 * h;
+            const int col = wn * (32 * NJ) + j * 32 + 8 * q + 4 * h;
             const float4 v = make_float4(acc[j][i][4 * q], acc[j][i][4 * q + 1], acc[j][i][4 * q + 2], acc[j][i][4 * q + 3]);
             *reinterpret_cast<float4*>(&stage[(i * 32 + (lane & 31)) * ST_LD + col]) = v;
           }
     }
     __syncthreads();
 #pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-      const int row_l = pass * 16 + (tid >> 4);
+    for (int pass = 0; pass < 64 / RPP; ++pass) {
+      const int row_l = pass * RPP + tid / TPR;
       const int m = m0 + half * 64 + row_l;
-      const int n = n0 + (tid & 15) * 8;
+      const int n = n0 + (tid % TPR) * 8;
       if (m >= e.M || n >= e.N) continue;
       float v[8];
       {
-        const float4 a = *reinterpret_cast<const float4*>(&stage[row_l * ST_LD + (tid & 15) * 8]);
-        const float4 b = *reinterpret_cast<const float4*>(&stage[row_l * ST_LD + (tid & 15) * 8 + 4]);
+        const float4 a = *reinterpret_cast<const float4*>(&stage[row_l * ST_LD + (tid % TPR) * 8]);
+        const float4 b = *reinterpret_cast<const float4*>(&stage[row_l * ST_LD + (tid % TPR) * 8 + 4]);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
       }
 #pragma unroll
@@ -220,42 +223,50 @@ __device__ __forceinline__ bool debug_drop(int debug, f32x16 (&acc)[2][2], void*
 // (r >> 2) & 3 for 64-byte rows (BKT = 32): ds_read_b128 of a 16-lane service group then hits 64 distinct banks.
 // BKT = 64: 64 KB LDS, 2 workgroups per CU.  BKT = 32: 33.8 KB, 3 workgroups per CU -- their store phases and main
 // loops interleave instead of running in lock-step.
-template <int EPI, int BKT>
+template <int EPI, int BKT, int NJ = 2>
 __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_nt_glds_kernel(GemmNtParams p) {
+  constexpr int BNT = 64 * NJ;           // tile columns: 128, or 64 for the narrow-N GEMMs
   constexpr int CPR = BKT / 8;           // 16-byte chunks per row
   constexpr int RPI = 64 / CPR;          // rows per wave instruction
-  constexpr int IPW = 128 / RPI / 4;     // instructions per wave and operand
-  constexpr int TILE = BM * BKT;
+  constexpr int IPW = 128 / RPI / 4;     // instructions per wave for the A tile
+  constexpr int IPWB = BNT / RPI / 4;    // ... and for the B tile
+  constexpr int TILE = BM * BKT;         // elements per buffer slot (the B slot is only partly used when BNT = 64)
   constexpr int SMEM = (4 * TILE * 2 > 64 * ST_LD * 4) ? 4 * TILE : 64 * ST_LD * 2;  // elements
   __shared__ __attribute__((aligned(16))) bf16 smem[SMEM];  // [buf][A|B][128*BKT]; reused as the epilogue stage
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int tiles_n = (p.e.N + BN - 1) / BN;
+  const int tiles_n = (p.e.N + BNT - 1) / BNT;
   const int tile = (p.debug & 128) ? (int)blockIdx.x : xcd_tile(blockIdx.x, gridDim.x);
-  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BNT;
   const int nk = p.K / BKT;
   auto fsw = [](int r) { return BKT == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
 
   // this lane's DMA source rows (clamped: rows beyond M / N are loaded from the last valid row and never stored)
   const bf16* ga[IPW];
-  const bf16* gb[IPW];
+  const bf16* gb[IPWB];
 #pragma unroll
   for (int i = 0; i < IPW; ++i) {
     const int r = wave * (IPW * RPI) + i * RPI + lane / CPR;
     const int chunk = (lane % CPR) ^ fsw(r);
     ga[i] = p.A + (int64_t)min(m0 + r, p.e.M - 1) * p.lda + chunk * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < IPWB; ++i) {
+    const int r = wave * (IPWB * RPI) + i * RPI + lane / CPR;
+    const int chunk = (lane % CPR) ^ fsw(r);
     gb[i] = p.B + (int64_t)min(n0 + r, p.e.N - 1) * p.ldb + chunk * 8;
   }
   auto issue = [&](int kt, int buf) {
     bf16* as = smem + (buf * 2 + 0) * TILE + wave * (IPW * RPI) * BKT;
-    bf16* bs = smem + (buf * 2 + 1) * TILE + wave * (IPW * RPI) * BKT;
+    bf16* bs = smem + (buf * 2 + 1) * TILE + wave * (IPWB * RPI) * BKT;
 #pragma unroll
-    for (int i = 0; i < IPW; ++i) {
+    for (int i = 0; i < IPW; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[i] + kt * BKT),
                                        (__attribute__((address_space(3))) void*)(as + i * RPI * BKT), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < IPWB; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb[i] + kt * BKT),
                                        (__attribute__((address_space(3))) void*)(bs + i * RPI * BKT), 16, 0, 0);
-    }
   };
 
   f32x16 acc[2][2];  // [j: 32-col block of N][i: 32-row block of M]; D = Btile . Atile^T (rows = n, cols = m)
@@ -266,7 +277,7 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_nt_glds_kernel(
   int aoff[2], boff[2], sw[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int ra = wm * 64 + i * 32 + (lane & 31), rb = wn * 64 + i * 32 + (lane & 31);
+    const int ra = wm * 64 + i * 32 + (lane & 31), rb = wn * (32 * NJ) + (i % NJ) * 32 + (lane & 31);
     aoff[i] = ra * BKT;
     boff[i] = rb * BKT;
     sw[0][i] = fsw(ra);
@@ -284,17 +295,17 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_nt_glds_kernel(
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         af[i] = *reinterpret_cast<const bf16x8*>(as + aoff[i] + ((lc ^ sw[0][i]) << 3));
-        bfr[i] = *reinterpret_cast<const bf16x8*>(bs + boff[i] + ((lc ^ sw[1][i]) << 3));
+        if (i < NJ) bfr[i] = *reinterpret_cast<const bf16x8*>(bs + boff[i] + ((lc ^ sw[1][i]) << 3));
       }
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int i = 0; i < 2; ++i) acc[j][i] = mfma32(bfr[j], af[i], acc[j][i]);
     }
     __syncthreads();  // next tile landed (vmcnt(0)) and everyone is done reading this one
   }
   if (debug_drop(p.debug, acc, p.e.C)) return;
-  tile_epilogue<EPI>(p.e, acc, reinterpret_cast<float*>(smem), m0, n0, tid);
+  tile_epilogue<EPI, NJ>(p.e, acc, reinterpret_cast<float*>(smem), m0, n0, tid);
 }
 
 // ---- NT, register-staged main loop (any K % 8 == 0; zero-fills ragged K) ---------------------------------------------
@@ -583,6 +594,15 @@ extern "C" int ttts_debug_set_flags(int32_t flags) {
 
 template <int EPI>
 static void launch_nt(const GemmNtParams& p, int grid, hipStream_t s) {
+  // Experiment kept behind flag 32768: 128 x 64 tiles for the narrow-N GEMMs (N = 512: 292 tiles of 128 x 128 = 1.14 per
+  // CU).  Measured SLOWER on MI355X (mlp c_proj 40.2 -> 47.5 us, dX c_fc 33.6 -> 43.6 us, step +0.14 ms): with two
+  // co-resident workgroups per CU the 292-tile launch is not the imbalance it looks like, and the half-width tile re-reads
+  // the A panel twice.
+  const int tiles64 = (int)(cdiv(p.e.M, BM) * cdiv(p.e.N, 64));
+  if (p.K % 64 == 0 && !(g_debug_flags & (8 | 64)) && (g_debug_flags & 32768) && grid < 512 && tiles64 >= 384) {
+    gemm_nt_glds_kernel<EPI, 64, 1><<<tiles64, 256, 0, s>>>(p);
+    return;
+  }
   if (p.K % 64 == 0 && !(g_debug_flags & (8 | 64))) gemm_nt_glds_kernel<EPI, 64><<<grid, 256, 0, s>>>(p);
   else if (p.K % 32 == 0 && !(g_debug_flags & 8)) gemm_nt_glds_kernel<EPI, 32><<<grid, 256, 0, s>>>(p);
   else gemm_nt_kernel<EPI><<<grid, 256, 0, s>>>(p);
