@@ -597,3 +597,39 @@ def test_split_bf16_weight_gradient_accuracy(case):
     lib.get().ttts_debug_set_flags(0)
     _close(dw, dwr, 2e-5, 0, "dw")
     assert _rel_l2(dw, dwr) < 1e-5
+
+
+def test_extract_vq_codes_and_gpt_data_path(tmp_path, golden_dir):
+    """VQ-VAE encoder + quantizer -> `.vq.pth` list-of-int file -> GptTtsDataset / GptTtsCollater ->
+    prepare_tokens (the tensors the GPT engine consumes)."""
+    from ttts_amd.gpt.dataset import GptTtsCollater, GptTtsDataset
+    from ttts_amd.gpt.engine import resolve_config
+    from ttts_amd.gpt.model import prepare_tokens
+    from ttts_amd.prepare.extract_vq import extract_vq_codes, process_vq
+    g, tr, data, inject = _step_setup(golden_dir)
+    codes = extract_vq_codes(tr.net_g, data["wav"], tr.hps.data, data["wav_lengths"])
+    assert codes.shape == (2, 1, 25) and codes.dtype == torch.int64 and int(codes.min()) >= 0 and int(codes.max()) < 1024
+    assert torch.equal(codes, extract_vq_codes(tr.net_g, data["wav"], tr.hps.data, data["wav_lengths"]))   # deterministic
+    assert tr.net_g.training                                   # mode restored
+    # the codes are the ones the training forward quantises when the same (zero) posterior noise is injected
+    spec = __import__("ttts_amd.utils.data_utils", fromlist=["x"]).spectrogram_torch(data["wav"], 2048, 640, 2048)
+    cb = {k: v.clone() for k, v in tr.net_g.quantizer.state_dict().items()}
+    with torch.no_grad():
+        out = tr.net_g(data["wav"], data["wav"], data["wav_lengths"], spec, spec, data["wav_lengths"] // 640, data["text"],
+                       data["text_lengths"], noise_p=torch.zeros(2, 192, 50, device=_dev()), noise_q=inject["noise_q"],
+                       ids_slice=inject["ids_slice"])
+    tr.net_g.quantizer.load_state_dict(cb)
+    deq = tr.net_g.quantizer.decode(codes.transpose(0, 1))
+    assert torch.allclose(out[5][:, :, ::2], deq, atol=1e-6)
+    # file format + GPT data path
+    p0 = process_vq(tr.net_g, str(tmp_path / "a.wav"), data["wav"][0], tr.hps.data)
+    assert torch.load(p0) == codes[0, 0].tolist()
+    p1 = process_vq(tr.net_g, str(tmp_path / "b.wav"), data["wav"][1, :25600], tr.hps.data)
+    (tmp_path / "d.jsonl").write_text("\n".join(json.dumps({"path": str(tmp_path / n), "text_ids": [5, 6, 7][:k], "wav_length": w})
+                                                for n, k, w in (("a.wav", 3, 24000), ("b.wav", 2, 19200))))
+    ds = GptTtsDataset(str(tmp_path / "d.jsonl"))
+    batch = GptTtsCollater()([ds[0], ds[1]])
+    assert batch["padded_qmel"].shape == (2, 25) and batch["qmel_lengths"].tolist() == [25, len(torch.load(p1))]
+    cfg = resolve_config(json.load(open(os.path.join(os.path.dirname(golden_dir), "..", "ttts_amd", "gpt", "config.json")))["gpt"])
+    toks = prepare_tokens(cfg, batch["padded_text"], batch["text_lengths"], batch["padded_qmel"], batch["wav_lens"])
+    assert toks[2].shape[0] == 2 and toks[2].dtype == torch.int64

@@ -222,3 +222,27 @@ def test_flat_data_parallel_gloo_world2(tmp_path):
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "rank0-ok" in r.stdout and "rank1-ok" in r.stdout
+
+
+def test_gpt_collater_and_vq_file_format(tmp_path):
+    """ttts/gpt/dataset.py:65-97 semantics: None items filtered, zero right-padding, length tensors; `.vq.pth` holds a plain
+    list of ints (ttts/prepare/extract_vq.py:22) that the dataset reads back."""
+    from ttts_amd.gpt.dataset import GptTtsCollater, GptTtsDataset
+    from ttts_amd.prepare.extract_vq import save_vq
+    paths = []
+    for i, n in enumerate((5, 9)):
+        p = str(tmp_path / ("utt%d.wav" % i))
+        out = save_vq(p, torch.arange(n) * 3 + i)
+        assert out == p + ".vq.pth" and torch.load(out) == [int(v) for v in (torch.arange(n) * 3 + i)]
+        paths.append(p)
+    jl = tmp_path / "data.jsonl"
+    jl.write_text("\n".join(json.dumps({"path": p, "text_ids": list(range(1, 4 + i)), "wav_length": 24000 * (i + 1)})
+                            for i, p in enumerate(paths)) + "\n" + json.dumps({"path": "missing", "text_ids": [1], "wav_length": 1}) + "\n")
+    ds = GptTtsDataset(str(jl))
+    assert len(ds) == 3 and ds[2] is None
+    batch = GptTtsCollater()([ds[0], ds[1], ds[2]])
+    assert batch["padded_text"].tolist() == [[1, 2, 3, 0], [1, 2, 3, 4]]
+    assert batch["text_lengths"].tolist() == [3, 4] and batch["qmel_lengths"].tolist() == [5, 9]
+    assert batch["padded_qmel"].shape == (2, 9) and batch["padded_qmel"][0, 5:].eq(0).all()
+    assert batch["wav_lens"].tolist() == [24000, 48000]
+    assert GptTtsCollater()([None, None]) is None

@@ -294,3 +294,20 @@ class SynthesizerTrn(nn.Module):
         z_slice, ids_slice = rand_slice_segments(z, y_lengths, self.segment_size, ids_slice)
         o = self.dec(z_slice, g=ge)
         return o, commit_loss, ids_slice, y_mask, (z, z_p, m_p, logs_p, m_q, logs_q), quantized
+
+    @torch.no_grad()
+    def extract_latent(self, wav, y, y_lengths=None):
+        """Code extraction (vq2.py:912-920): ref_enc -> enc_p -> proj -> quantizer; returns codes (B, n_q, T // 2) int64.
+        The reference body uses an undefined `y_lengths` and multiplies the stride-2 projection by the full-rate mask
+        (SURVEY.md App. B), so this follows the training forward instead: lengths default to the full clip and there is
+        no mask around `proj`.  The reference also quantises a SAMPLED posterior (enc_p draws randn noise even here);
+        extraction uses the posterior mean (zero noise) so that the stored codes are reproducible."""
+        if y_lengths is None:
+            y_lengths = torch.full((y.size(0),), y.size(2), dtype=torch.long, device=y.device)
+        y_mask = torch.unsqueeze(sequence_mask(y_lengths, y.size(2)), 1).to(y.dtype)
+        ge = self.ref_enc(modules.mul_mask(y, y_mask), y_mask)
+        x, _, _ = self.enc_p(y, wav.unsqueeze(1), y_mask, g=ge, noise=torch.zeros(y.size(0), self.inter_channels, y.size(2),
+                                                                                 dtype=y.dtype, device=y.device))
+        x = self.proj(x)
+        quantized, codes, commit_loss, quantized_list = self.quantizer(x)
+        return codes.transpose(0, 1)
