@@ -40,6 +40,7 @@ struct ConvMfmaParams {
   int out_act; float out_slope, out_scale; int accumulate;
   // split-bf16 path: weights pre-split into hi / lo bf16 in [N/16 blocks][Mpad][K][16] order (conv_weight_split_kernel)
   const bf16* a_hi; const bf16* a_lo; int Mpad;
+  const bf16* x_hi; const bf16* x_lo;   // pre-split input [B][N/16 blocks][Lin][16] (conv_input_split_kernel)
 };
 
 
@@ -164,6 +165,33 @@ __global__ __launch_bounds__(64 * NW) void conv1d_mfma_kernel(ConvMfmaParams p) 
 // one 16-byte LDS read: the input strip is staged position-major [pos][16 ch] (hi and lo), the weights arrive pre-split and
 // pre-ordered [n/16][m][tap][16] from conv_weight_split_kernel -- which also bakes in the transposition / tap flip / polyphase
 // tap selection of the data-gradient forms, so this kernel only ever sees a plain forward convolution.
+// input pre-pass: x fp32 [B][N][L] -> leaky-relu -> hi / lo bf16 in [B][N/16][L][16] order, so that the strip a workgroup
+// stages (16 channels x a window of positions) is ONE contiguous run of 32-byte records: the main kernel's staging becomes
+// plain 16-byte copies (PMC before this pass: 12 VALU instructions per MFMA, mostly fp32 -> bf16 splitting, and VALU time
+// above MFMA time)
+__global__ __launch_bounds__(256) void conv_input_split_kernel(const float* __restrict__ x, bf16* __restrict__ hi,
+                                                               bf16* __restrict__ lo, int B, int N, int L, int nblk, float slope) {
+  const int64_t total = (int64_t)B * nblk * L;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int pos = (int)(i % L), nb = (int)((i / L) % nblk);
+    const int64_t b = i / L / nblk;
+    const float* xr = x + (b * N + nb * 16) * L + pos;
+    bf16x8 h0, h1, l0, l1;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      float v = nb * 16 + c < N ? xr[(int64_t)c * L] : 0.f;
+      v = lrelu_f(v, slope);
+      const bf16 hv = (bf16)v;
+      const bf16 lv = (bf16)(v - (float)hv);
+      if (c < 8) { h0[c] = hv; l0[c] = lv; } else { h1[c - 8] = hv; l1[c - 8] = lv; }
+    }
+    *reinterpret_cast<bf16x8*>(hi + i * 16) = h0;
+    *reinterpret_cast<bf16x8*>(hi + i * 16 + 8) = h1;
+    *reinterpret_cast<bf16x8*>(lo + i * 16) = l0;
+    *reinterpret_cast<bf16x8*>(lo + i * 16 + 8) = l1;
+  }
+}
+
 __global__ __launch_bounds__(256) void conv_weight_split_kernel(const float* __restrict__ w, bf16* __restrict__ a_hi,
                                                                 bf16* __restrict__ a_lo, int M, int N, int Mpad, int nblk,
                                                                 int K, int Kmem, int transposed, int tap_off, int tap_stride) {
@@ -208,24 +236,40 @@ __global__ __launch_bounds__(256) void conv1d_bf16x3_kernel(ConvMfmaParams p) {
   const int64_t slab = (int64_t)p.Mpad * K * 16;      // elements per channel block of the split weights
   for (int nb = 0; nb < nblk; ++nb) {
     __syncthreads();
-    // input strip: one thread per position, 16 channels each (every global read is a coalesced row segment)
-    for (int pp = tid; pp < lin_t; pp += 256) {
-      const int sg = pp / lin_s, pos = pp - sg * lin_s, gi = in0 + pos;
-      const bool ok = b0 + sg < p.B && gi >= 0 && gi < p.Lin;
-      const float* xr = p.x + ((int64_t)(b0 + sg) * p.N + nb * 16) * p.Lin + gi;
-      bf16x8 h0, h1, l0, l1;
-#pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        float v = (ok && nb * 16 + c < p.N) ? xr[(int64_t)c * p.Lin] : 0.f;
-        v = lrelu_f(v, p.in_slope);
-        const bf16 hv = (bf16)v;
-        const bf16 lv = (bf16)(v - (float)hv);
-        if (c < 8) { h0[c] = hv; l0[c] = lv; } else { h1[c - 8] = hv; l1[c - 8] = lv; }
+    if (p.x_hi) {
+      // input strip: 16-byte copies of the pre-split records (two per position and half), zero outside the row
+      for (int q = tid; q < lin_t * 2; q += 256) {
+        const int pp = q >> 1, half = q & 1;
+        const int sg = pp / lin_s, pos = pp - sg * lin_s, gi = in0 + pos;
+        bf16x8 vh = zero8(), vl = zero8();
+        if (b0 + sg < p.B && gi >= 0 && gi < p.Lin) {
+          const int64_t o = ((((int64_t)(b0 + sg) * nblk + nb) * p.Lin + gi) * 16) + half * 8;
+          vh = *reinterpret_cast<const bf16x8*>(p.x_hi + o);
+          vl = *reinterpret_cast<const bf16x8*>(p.x_lo + o);
+        }
+        *reinterpret_cast<bf16x8*>(xh + pp * 16 + half * 8) = vh;
+        *reinterpret_cast<bf16x8*>(xl + pp * 16 + half * 8) = vl;
       }
-      *reinterpret_cast<bf16x8*>(xh + pp * 16) = h0;
-      *reinterpret_cast<bf16x8*>(xh + pp * 16 + 8) = h1;
-      *reinterpret_cast<bf16x8*>(xl + pp * 16) = l0;
-      *reinterpret_cast<bf16x8*>(xl + pp * 16 + 8) = l1;
+    } else {
+      // few output-channel tiles: split on the fly -- one thread per position, 16 channels each (coalesced row segments)
+      for (int pp = tid; pp < lin_t; pp += 256) {
+        const int sg = pp / lin_s, pos = pp - sg * lin_s, gi = in0 + pos;
+        const bool ok = b0 + sg < p.B && gi >= 0 && gi < p.Lin;
+        const float* xr = p.x + ((int64_t)(b0 + sg) * p.N + nb * 16) * p.Lin + gi;
+        bf16x8 h0, h1, l0, l1;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          float v = (ok && nb * 16 + c < p.N) ? xr[(int64_t)c * p.Lin] : 0.f;
+          v = lrelu_f(v, p.in_slope);
+          const bf16 hv = (bf16)v;
+          const bf16 lv = (bf16)(v - (float)hv);
+          if (c < 8) { h0[c] = hv; l0[c] = lv; } else { h1[c - 8] = hv; l1[c - 8] = lv; }
+        }
+        *reinterpret_cast<bf16x8*>(xh + pp * 16) = h0;
+        *reinterpret_cast<bf16x8*>(xh + pp * 16 + 8) = h1;
+        *reinterpret_cast<bf16x8*>(xl + pp * 16) = l0;
+        *reinterpret_cast<bf16x8*>(xl + pp * 16 + 8) = l1;
+      }
     }
     // weights: the stage's [MT][K][16] slab is contiguous in the split arrays; 16-byte chunks
     {
@@ -426,12 +470,22 @@ static int conv1d_bf16x3_launch_t(ConvMfmaParams p, hipStream_t stream, bool* ha
   const int nblk = (p.N + 15) / 16;
   p.Mpad = (int)(cdiv(p.M, MT) * MT);
   const int64_t elems = (int64_t)nblk * p.Mpad * K * 16;
-  if (2 * elems * (int64_t)sizeof(bf16) > g_conv_ws_bytes) return TTTS_OK;
-  bf16* hi = static_cast<bf16*>(g_conv_ws);
+  // pre-split the input only when it is re-read by >= 3 output-channel tiles (measured: a full extra pass over x costs more
+  // than on-the-fly splitting for the 16..64-channel long-row layers, and wins from 192 channels up)
+  const bool presplit = p.x_hi != nullptr || cdiv(p.M, MT) >= 3;
+  const int64_t xel = presplit ? (int64_t)p.B * nblk * p.Lin * 16 : 0;
+  if (2 * (elems + xel) * (int64_t)sizeof(bf16) > g_conv_ws_bytes) return TTTS_OK;
+  bf16* xhi = static_cast<bf16*>(g_conv_ws);       // scratch layout: [x hi][x lo][w hi][w lo] (the input split comes first so
+  bf16* xlo = xhi + xel;                             // that the phases of a strided data gradient can share it)
+  bf16* hi = xlo + xel;
   bf16* lo = hi + elems;
   p.a_hi = hi; p.a_lo = lo;
   conv_weight_split_kernel<<<(int)std::min<int64_t>(cdiv(elems, 256), 2048), 256, 0, stream>>>(p.w, hi, lo, p.M, p.N, p.Mpad, nblk, K, p.Kmem,
                                                                                             p.transposed, p.tap_off, p.tap_stride);
+  if (presplit && !p.x_hi) {   // (polyphase data gradients share one split of dy across their phase launches)
+    conv_input_split_kernel<<<(int)std::min<int64_t>(cdiv(xel / 16, 256), 8192), 256, 0, stream>>>(p.x, xhi, xlo, p.B, p.N, p.Lin, nblk, p.in_slope);
+    p.x_hi = xhi; p.x_lo = xlo;
+  }
   dim3 grid((unsigned)cdiv(p.Lout, SEG == LT ? LT : SEG), (unsigned)cdiv(p.M, MT), (unsigned)cdiv(p.B, LT / SEG));
   static bool attr = false;
   int rc = set_attr_once(reinterpret_cast<const void*>(conv1d_bf16x3_kernel<WCO>), attr);
@@ -477,7 +531,7 @@ int conv1d_mfma_try(const float* x, const float* w, const float* bias, const flo
   if (N < 8 || K > 16) return TTTS_OK;       // thin inputs / long taps stay on the direct kernels (M = 1 heads are fine:
                                              // a 32-row tile with one live row beats looping 1024 channels on the vector ALUs)
   ConvMfmaParams p{x, w, bias, bbias, resid, omask, gate, y, B, M, N, Lin, Lout, K, stride, pad, dil, transposed, 0,
-                   K, 0, 1, 1, 0, Lout, 0, in_slope, gate_slope, out_act, out_slope, out_scale, accumulate, nullptr, nullptr, 0};
+                   K, 0, 1, 1, 0, Lout, 0, in_slope, gate_slope, out_act, out_slope, out_scale, accumulate, nullptr, nullptr, 0, nullptr, nullptr};
   return conv1d_mfma_launch(p, stream, handled);
 }
 
@@ -490,6 +544,18 @@ int conv1d_dgrad_strided_mfma_try(const float* dy, const float* w, const float* 
                                   int accumulate, hipStream_t stream, bool* handled) {
   *handled = false;
   if (Cout < 8 || K > 16 * stride || K < stride) return TTTS_OK;
+  // split-bf16 path: split dy ONCE for all phases (same place conv1d_bf16x3_launch_t would put it)
+  const bf16* xs_hi = nullptr;
+  const bf16* xs_lo = nullptr;
+  if (g_conv_ws && Cout >= 16 && Cin >= 192 && !(g_debug_flags_conv & 4096)) {
+    const int nblk = (Cout + 15) / 16;
+    const int64_t xel = (int64_t)B * nblk * Lout * 16;
+    if (2 * xel * (int64_t)sizeof(bf16) + (32 << 20) <= g_conv_ws_bytes) {
+      bf16* xh = static_cast<bf16*>(g_conv_ws);
+      conv_input_split_kernel<<<(int)std::min<int64_t>(cdiv(xel / 16, 256), 8192), 256, 0, stream>>>(dy, xh, xh + xel, B, Cout, Lout, nblk, in_slope);
+      xs_hi = xh; xs_lo = xh + xel;
+    }
+  }
   for (int phi = 0; phi < stride; ++phi) {
     const int Kp = (K - phi + stride - 1) / stride;                       // taps of this phase (>= 1 since K >= stride)
     const int tmin = phi >= pad ? 0 : (pad - phi + stride - 1) / stride;  // first t' with a non-negative output position
@@ -497,7 +563,7 @@ int conv1d_dgrad_strided_mfma_try(const float* dy, const float* w, const float* 
     if (off >= Lin) continue;
     const int T = (Lin - 1 - off) / stride + 1;
     ConvMfmaParams p{dy, w, bias, nullptr, resid, omask, gate, dx, B, Cin, Cout, Lout, T, Kp, 1, (Kp - 1) - tmin, 1, 1, 0,
-                     K, phi, stride, stride, off, Lin, 0, in_slope, gate_slope, 0, 1.f, out_scale, accumulate, nullptr, nullptr, 0};
+                     K, phi, stride, stride, off, Lin, 0, in_slope, gate_slope, 0, 1.f, out_scale, accumulate, nullptr, nullptr, 0, xs_hi, xs_lo};
     bool h = false;
     int rc = conv1d_mfma_launch(p, stream, &h);
     if (rc) return rc;
