@@ -357,3 +357,26 @@ def mel_style_encoder_forward(sd, pfx, x, mask, hidden=128, n_head=2):
     x = lin(x, "fc.fc")
     x = x.masked_fill(pad.unsqueeze(-1), 0).sum(dim=1) / (~pad).sum(dim=1).unsqueeze(1)
     return x.unsqueeze(-1)
+
+
+# ---- SynthesizerTrn.forward (vq2.py:842-871): the composition of everything above ------------------------------------------
+def synthesizer_forward(sd, cfg, buffers, wav, wav_aug, wav_lengths, y, y_aug, y_lengths, text, text_lengths, noise_p, noise_q,
+                        ids_slice, segment_size=32, training=True):
+    """sd: reference-keyed generator state dict; cfg: the `vqvae` block of vqvae/config.json; buffers: the codebook buffers
+    dict(embed, embed_avg, cluster_size) (updated in place when training); the three random draws are injected.
+    Returns the reference's 6-tuple (o, commit_loss, ids_slice, y_mask, (z, z_p, m_p, logs_p, m_q, logs_q), quantized)."""
+    from oracle import vq_ref
+    y_mask = seq_mask(y_lengths, y.size(2)).unsqueeze(1).to(y.dtype)
+    ge = mel_style_encoder_forward(sd, "ref_enc.", y * y_mask, y_mask)
+    x, _, _ = posterior_audio_encoder_forward(sd, "enc_p.", y_aug, wav_aug.unsqueeze(1), y_mask, ge, noise_p)
+    x = F.conv1d(x, sd["proj.weight"], sd["proj.bias"], stride=2)
+    quantized, codes, commit_loss, _ = vq_ref.rvq_forward(x, buffers, training)
+    quantized = F.interpolate(quantized, size=int(quantized.shape[-1] * 2), mode="nearest")
+    _, m_p, logs_p = text_encoder_forward(sd, "enc_p_2.", quantized, y_lengths, text, text_lengths, ge, cfg["n_heads"],
+                                          cfg["n_layers"], cfg["kernel_size"], cfg["inter_channels"])
+    z, m_q, logs_q = posterior_audio_encoder_forward(sd, "enc_q.", y, wav.unsqueeze(1), y_mask, ge, noise_q)
+    z_p = coupling_block_forward(z, y_mask, sd, "flow.", cfg["inter_channels"], cfg["hidden_channels"], 5, 1, 4, 4, ge)
+    idx = ids_slice.view(-1, 1) + torch.arange(segment_size).view(1, -1)
+    z_slice = torch.gather(z, 2, idx.unsqueeze(1).expand(-1, z.size(1), -1))
+    o = generator_forward(sd, cfg, z_slice, ge, pfx="dec.")
+    return o, commit_loss, ids_slice, y_mask, (z, z_p, m_p, logs_p, m_q, logs_q), quantized

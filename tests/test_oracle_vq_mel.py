@@ -216,3 +216,30 @@ def test_attention_stacks_restatement(golden_dir):
     np.testing.assert_allclose(w.detach().numpy(), g["se_w"], rtol=1e-4, atol=1e-5)
     (w * T(g["se_ct"])).sum().backward()
     np.testing.assert_allclose(x.grad.numpy(), g["se_dx"], rtol=1e-3, atol=1e-5 * np.abs(g["se_dx"]).max())
+
+
+def test_synthesizer_forward_restatement(golden_dir):
+    """oracle.vqvae_ref.synthesizer_forward (the composition: style encoder, two posterior encoders, stride-2 projection,
+    codebook, text encoder + MRTE, coupling flow, segment slice, HiFi-GAN decoder) vs the reference's full forward in
+    tests/golden/vqvae_step.npz (78.6 M det_fill parameters, injected noise / segment starts)."""
+    import json
+    from oracle import mel_ref, vqvae_ref
+    g = np.load(os.path.join(golden_dir, "vqvae_step.npz"))
+    surf = json.load(open(os.path.join(golden_dir, "surface.json")))
+    cfg = json.loads(str(g["cfg"]))
+    T = torch.from_numpy
+    sd = {k: vqvae_ref.det_fill(k, s, 0.4) for k, s, *_ in surf["vqvae_g"] if not k.startswith("quantizer.") and not k.endswith("filter")}
+    embed = vqvae_ref.det_fill("codebook.embed", (1024, 192)) * 2.0
+    buffers = {"embed": embed.clone(), "embed_avg": embed * 4.0, "cluster_size": torch.full((1024,), 4.0)}
+    wav = T(g["wav"]); wav_lengths = T(g["wav_lengths"])
+    spec = mel_ref.spectrogram(wav, 2048, 640, 2048)
+    with torch.no_grad():
+        o, commit, _, y_mask, (z, z_p, m_p, logs_p, m_q, logs_q), quantized = vqvae_ref.synthesizer_forward(
+            sd, cfg, buffers, wav, wav, wav_lengths, spec, spec, wav_lengths // 640, T(g["text"]), T(g["text_lengths"]),
+            T(g["noise_p"]), T(g["noise_q"]), T(g["ids_slice"]))
+    for a, k, tol in ((z, "z", 1e-4), (m_q, "m_q", 1e-4), (logs_q, "logs_q", 1e-4), (quantized, "quantized", 1e-4),
+                      (m_p, "m_p", 3e-4), (logs_p, "logs_p", 3e-4), (z_p, "z_p", 3e-4), (o, "o", 1e-3)):
+        err = np.abs(a.numpy() - g[k]).max()
+        assert err <= tol * np.abs(g[k]).max() + 1e-6, (k, err, np.abs(g[k]).max())
+    np.testing.assert_allclose(commit.item(), g["commit"], rtol=1e-4)
+    np.testing.assert_allclose(buffers["cluster_size"].numpy(), g["cb_cluster_size"], rtol=1e-5)
