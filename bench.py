@@ -177,6 +177,7 @@ def main():
     elapsed = dp.max_over_ranks(time.perf_counter() - t0)
     lt, lm = eng.losses()
     assert lt == lt and lm == lm, "non-finite loss"
+    graphed = args.mode != "eager" and eng._graph is not None and eng._graph[0] is not None   # False after a refused capture
 
     # per-kernel HIP-event timing (same kernels, shapes and data; eager launches), right after the timed steps
     # EVERY rank runs the instrumented steps (they contain the gradient all-reduce); only rank 0 records events.
@@ -227,7 +228,7 @@ def main():
                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": "VALL-E GPT train step (ttts/gpt/config.json model: 6 layers, d512, 8 heads, 21.46 M "
                                       "params), batch 8 per GPU x (128 text + 1024 audio tokens) = S 1156, fwd+bwd+clip+AdamW, "
-                                      "dropout %.1f, %s" % (dropout, "eager launches" if args.mode == "eager" else ("hipGraph replay" if world == 1 else
+                                      "dropout %.1f, %s" % (dropout, "eager launches" if not graphed else ("hipGraph replay" if world == 1 else
                                                                        "hipGraph replay around one RCCL all-reduce")),
                           "global_batch": world * B_PER_GPU, "seq_len": TEXT_LEN + 2 + MEL_LEN + 2, "parallelism": "dp%d" % world,
                           "mode": args.mode},

@@ -407,25 +407,48 @@ class GptEngine:
         else:
             key = (self._bufs_key, w_text, w_mel, tuple(sorted(opt.items())), exchange is not None)
             if self._graph is None or self._graph_key != key:
-                torch.cuda.synchronize()
-                ga = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga):
-                    self.forward()
-                    self.backward(w_text, w_mel)
-                    if exchange is None:
-                        self.optimizer_step(**opt)
-                gb = None
-                if exchange is not None:
-                    gb = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gb):
-                        self.optimizer_step(**opt)
-                self._graph, self._graph_key = (ga, gb), key
+                self._graph, self._graph_key = self._capture_step(w_text, w_mel, exchange is not None, opt), key
             ga, gb = self._graph
-            ga.replay()   # capture only records; every step (the first included) is a replay
-            if gb is not None:
-                exchange()
-                gb.replay()
+            if ga is None:           # capture was refused (see _capture_step): launch by launch, same kernels
+                self.forward()
+                self.backward(w_text, w_mel)
+                if exchange is not None:
+                    exchange()
+                self.optimizer_step(**opt)
+            else:
+                ga.replay()   # capture only records; every step (the first included) is a replay
+                if gb is not None:
+                    exchange()
+                    gb.replay()
         self.step_count += 1
+
+    def _capture_step(self, w_text, w_mel, with_exchange, opt):
+        """Record the step into hipGraphs: (forward + backward + optimizer, None) or, around a collective,
+        (forward + backward, optimizer).  With a process group alive its watchdog thread polls events while we record,
+        so that case captures in thread-local mode.  A refused capture is reported once on stderr and the engine keeps
+        running launch by launch -- slower on the host, identical on the device."""
+        torch.cuda.synchronize()
+        mode = "thread_local" if with_exchange else "global"
+        try:
+            ga = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga, capture_error_mode=mode):
+                self.forward()
+                self.backward(w_text, w_mel)
+                if not with_exchange:
+                    self.optimizer_step(**opt)
+            gb = None
+            if with_exchange:
+                gb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gb, capture_error_mode=mode):
+                    self.optimizer_step(**opt)
+            return ga, gb
+        except RuntimeError as err:
+            import sys
+            print("ttts_amd: hipGraph capture of the train step failed (%s); running it eagerly" % str(err).splitlines()[0],
+                  file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+            self.grads.zero_()     # a partially recorded step leaves nothing behind, but be explicit
+            return None, None
 
     def losses(self):
         """(loss_text, loss_mel) as Python floats -- host sync; call it off the hot path."""
