@@ -225,6 +225,30 @@ int ttts_mel_log_bwd_f32(const float* dmel, const float* mel, const float* basis
 int ttts_stft_mag_bwd_f32(const float* wav, const float* window, const float* twiddle2, const float* dspec,
                           float* dwav, int32_t B, int32_t T, int32_t n_fft, int32_t hop, void* stream);
 
+/* ---- parametric-equaliser augmentation -------------------------------------------------------
+ * Replaces Augment.forward's PEQ path (ttts/vqvae/augment/__init__.py:37-97) and ParametricEqualizer
+ * (ttts/vqvae/augment/peq.py:19-116): torch.stft(center=True, hann) -> per-clip biquad product -> torch.istft ->
+ * clamp(-1, 1) -> divide by the clip's peak.  The Praat stage (augment/praat.py) is a CPU library and stays outside.
+ *  ttts_peq_response_f32: H c64 [B, n_fft/2+1] (interleaved re, im) = prod_f fir_f / iir_f with
+ *    freq / gain (dB) / q f32 [B, n_filters], kind i32 [n_filters] (TTTS_PEQ_PEAK | _LOW_SHELF | _HIGH_SHELF);
+ *    closed form of rfft([c0, c1, c2], n_fft) (peq.py:19-30), evaluated in double (the 3-tap sums cancel near DC).
+ *  ttts_stft_filter_frames_f32: frames_out f32 [B, frames, n_fft], frames = ttts_stft_center_frames(T, hop) = 1 + T/hop:
+ *    frame t = window * irfft(H * rfft(window * reflect_pad(wav, n_fft/2)[t hop : t hop + n_fft])); H NULL = identity.
+ *  ttts_istft_ola_f32: out f32 [B, hop (frames - 1)] = overlap-add / window-envelope, trimmed as torch.istft does,
+ *    optionally clamped to [-1, 1]; peak_bits u32 [B] receives the float bits of max |out| per clip (zeroed here).
+ *  ttts_peak_scale_f32: x[b] /= max(peak[b], eps) in place. */
+#define TTTS_PEQ_PEAK 0
+#define TTTS_PEQ_LOW_SHELF 1
+#define TTTS_PEQ_HIGH_SHELF 2
+int ttts_peq_response_f32(const float* freq, const float* gain, const float* q, const int32_t* kind, float* H,
+                          int32_t B, int32_t n_filters, int32_t n_fft, float sample_rate, void* stream);
+int32_t ttts_stft_center_frames(int32_t T, int32_t hop);
+int ttts_stft_filter_frames_f32(const float* wav, const float* window, const float* twiddle, const float* H,
+                                float* frames_out, int32_t B, int32_t T, int32_t n_fft, int32_t hop, void* stream);
+int ttts_istft_ola_f32(const float* frames_in, const float* window, float* out, void* peak_bits, int32_t B,
+                       int32_t frames, int32_t n_fft, int32_t hop, int32_t clamp, void* stream);
+int ttts_peak_scale_f32(float* x, const void* peak_bits, int32_t B, int32_t T, float eps, void* stream);
+
 /* ---- 1-D convolution family (fp32, (B, C, L) layout, groups = 1) ---------------------------------------------
  * Replaces: nn.Conv1d (incl. groups) / Conv2d with (k,1) kernels / ConvTranspose1d / weight_norm + the leaky-relu, bias, residual-add and tanh around them in
  * ResBlock1 (ttts/vqvae/modules.py:224-318), Generator (ttts/vqvae/vq2.py:341-415), PosteriorAudioEncoder (:667-745),

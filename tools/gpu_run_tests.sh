@@ -9,5 +9,6 @@ run attention tests/test_gpu_kernels.py -k "attention"
 run vq_stft tests/test_gpu_kernels.py -k "vq or stft"
 run gpt tests/test_gpu_gpt.py
 run vqvae tests/test_gpu_vqvae.py
+run peq tests/test_gpu_peq.py
 } > gpurun_out/pytest_gpu.log 2>&1
 grep -E "^===|passed|failed|error" gpurun_out/pytest_gpu.log | tail -40

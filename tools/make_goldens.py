@@ -547,8 +547,54 @@ def gen_step():
     print("G8 step losses:", rec["losses"], "norms", rec["grad_norms"], "unused g params:", int((g_grad_abs < 0).sum()))
 
 
+PEQ_CFGS = [dict(sampling_rate=32000, win_length=2048, hop_length=640, cutoff_lowpass=60, cutoff_highpass=10000, num_peak=8,
+                 q_min=2, q_max=5, T=9000),
+            dict(sampling_rate=22050, win_length=1024, hop_length=256, cutoff_lowpass=60, cutoff_highpass=10000, num_peak=8,
+                 q_min=2, q_max=5, T=4096)]
+
+
+def gen_peq():
+    """the reference's Augment.forward (PEQ path, no Praat) and the three ParametricEqualizer responses
+    on seeded clips, for vqvae/config.json's settings and a 22.05 kHz / 1024 / 256 set."""
+    import types
+    pm = types.ModuleType("parselmouth")      # imported (and used in an annotation) by augment/praat.py; Praat stage excluded
+    pm.Sound = type("Sound", (), {})
+    sys.modules.setdefault("parselmouth", pm)
+    from ttts.vqvae.augment import Augment
+    rec = {"cfgs": np.array(json.dumps(PEQ_CFGS))}
+    for ci, c in enumerate(PEQ_CFGS):
+        hp = types.SimpleNamespace(
+            data=types.SimpleNamespace(sampling_rate=c["sampling_rate"], win_length=c["win_length"], hop_length=c["hop_length"]),
+            train=types.SimpleNamespace(cutoff_lowpass=c["cutoff_lowpass"], cutoff_highpass=c["cutoff_highpass"],
+                                        num_peak=c["num_peak"], q_min=c["q_min"], q_max=c["q_max"]))
+        aug = Augment(hp)
+        g = torch.Generator().manual_seed(77 + ci)
+        B, T = 3, c["T"]
+        t = torch.arange(T) / c["sampling_rate"]
+        wav = sum(torch.rand(B, 1, generator=g) * torch.sin(2 * np.pi * (80. + 4000. * torch.rand(B, 1, generator=g)) * t[None]
+                                                             + 6.28 * torch.rand(B, 1, generator=g)) for _ in range(6)) / 4.0
+        wav = (wav + 0.05 * torch.randn(B, T, generator=g)).clamp(-1, 1).float()
+        wav[2] *= 3.0                                                   # drives the clamp
+        power = torch.rand(B, c["num_peak"] + 2, generator=g)
+        gain = torch.rand(B, c["num_peak"] + 2, generator=g) * 24 - 12
+        with torch.no_grad():
+            out = aug(wav, quality_power=power, gain=gain)
+            out_id = aug(wav)                                           # no equaliser: stft -> istft -> clamp -> normalise
+            q = c["q_min"] * (c["q_max"] / c["q_min"]) ** power
+            center = aug.peak_centers[None].repeat(B, 1)
+            peaks = aug.peq.peaking_equalizer(center, gain[:, :-2], q[:, :-2])
+            low = aug.peq.low_shelving(c["cutoff_lowpass"], gain[:, -2], q[:, -2])
+            high = aug.peq.high_shelving(c["cutoff_highpass"], gain[:, -1], q[:, -1])
+        k = "c%d_" % ci
+        rec.update({k + "wav": wav.numpy(), k + "power": power.numpy(), k + "gain": gain.numpy(), k + "out": out.numpy(),
+                    k + "out_identity": out_id.numpy(), k + "peaks": peaks.numpy(), k + "low": low.numpy(), k + "high": high.numpy(),
+                    k + "peak_centers": aug.peak_centers.numpy()})
+        print("peq cfg", ci, "out", tuple(out.shape), "peak |H|", float((torch.prod(peaks, 1) * low * high).abs().max()))
+    np.savez_compressed(os.path.join(OUT, "vqvae_peq.npz"), **rec)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gpt", "vq", "mel", "vqvae", "disc", "flow", "attn", "step"]
+    which = sys.argv[1:] or ["gpt", "vq", "mel", "vqvae", "disc", "flow", "attn", "step", "peq"]
     with torch.no_grad() if False else torch.enable_grad():
         if "gpt" in which:
             gen_gpt()
@@ -566,4 +612,6 @@ if __name__ == "__main__":
             gen_attn()
         if "step" in which:
             gen_step()
+        if "peq" in which:
+            gen_peq()
     print("fixtures:", {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT))})

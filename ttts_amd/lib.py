@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(CSRC, "build")
 SO_PATH = os.path.join(HERE, "libttts_hip.so")
-SOURCES = ["lib.hip", "elementwise.hip", "gemm.hip", "attn.hip", "vq.hip", "stft.hip", "conv.hip", "conv_mfma.hip", "losses.hip", "vqvae_ops.hip", "attn_f32.hip"]
+SOURCES = ["lib.hip", "elementwise.hip", "gemm.hip", "attn.hip", "vq.hip", "stft.hip", "conv.hip", "conv_mfma.hip", "losses.hip", "vqvae_ops.hip", "attn_f32.hip", "peq.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-Wall", "-Wno-unused-variable"]
 
@@ -110,6 +110,11 @@ SIGNATURES = {
     "ttts_mel_log_fwd_f32": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "ttts_mel_log_bwd_f32": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "ttts_stft_mag_bwd_f32": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "ttts_peq_response_f32": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _F, _P]),
+    "ttts_stft_center_frames": (_I32, [_I32, _I32]),
+    "ttts_stft_filter_frames_f32": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "ttts_istft_ola_f32": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
+    "ttts_peak_scale_f32": (_I32, [_P, _P, _I32, _I32, _F, _P]),
     "ttts_conv1d_fwd_f32": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32,
                                    _F, _F, _I32, _F, _F, _I32, _P]),
     "ttts_conv1d_dgrad_f32": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32,

@@ -281,6 +281,48 @@ def stft_mag(wav, window, n_fft, hop):
     return spec
 
 
+PEQ_PEAK, PEQ_LOW_SHELF, PEQ_HIGH_SHELF = 0, 1, 2
+
+
+def peq_response(freq, gain, q, kind, n_fft, sample_rate):
+    """freq / gain (dB) / q f32 [B, NF], kind i32 [NF] -> complex64 [B, n_fft/2+1] product of the biquad responses."""
+    for t, nm in ((freq, "freq"), (gain, "gain"), (q, "q")):
+        _req(t, torch.float32, nm)
+    _req(kind, torch.int32, "kind")
+    B, NF = freq.shape
+    if gain.shape != freq.shape or q.shape != freq.shape or kind.numel() != NF:
+        raise TttsError("peq_response: freq / gain / q must be [B, NF] and kind [NF]")
+    H = torch.empty(B, n_fft // 2 + 1, 2, dtype=torch.float32, device=freq.device)
+    check(_l.get().ttts_peq_response_f32(_p(freq.contiguous()), _p(gain.contiguous()), _p(q.contiguous()), _p(kind),
+                                         _p(H), B, NF, n_fft, float(sample_rate), _stream()), "peq_response")
+    return torch.view_as_complex(H)
+
+
+def stft_filter_istft(wav, window, n_fft, hop, H=None, clamp=True, peak_normalize=True, eps=1e-7):
+    """istft(stft(wav, center=True) * H[..., None]) [.clamp(-1, 1)] [/ peak]: wav f32 [B, T] -> f32 [B, hop * (T // hop)].
+    H: complex64 [B, n_fft/2+1] or None (identity)."""
+    _req(wav, torch.float32, "wav"); _req(window, torch.float32, "window")
+    wav = wav.contiguous()
+    B, T = wav.shape
+    frames = _l.get().ttts_stft_center_frames(T, hop)
+    Hr = None
+    if H is not None:
+        if H.dtype != torch.complex64 or H.shape != (B, n_fft // 2 + 1):
+            raise TttsError("stft_filter_istft: H must be complex64 [B, n_fft/2+1]")
+        Hr = torch.view_as_real(H.contiguous())
+    fr = torch.empty(B, frames, n_fft, dtype=torch.float32, device=wav.device)
+    tw = stft_twiddle(n_fft, wav.device)
+    check(_l.get().ttts_stft_filter_frames_f32(_p(wav), _p(window), _p(tw), _p(Hr) if Hr is not None else None, _p(fr), B, T,
+                                               n_fft, hop, _stream()), "stft_filter_frames")
+    out = torch.empty(B, hop * (frames - 1), dtype=torch.float32, device=wav.device)
+    peak = torch.empty(B, dtype=torch.int32, device=wav.device)
+    check(_l.get().ttts_istft_ola_f32(_p(fr), _p(window), _p(out), _p(peak), B, frames, n_fft, hop, 1 if clamp else 0,
+                                      _stream()), "istft_ola")
+    if peak_normalize:
+        check(_l.get().ttts_peak_scale_f32(_p(out), _p(peak), B, out.shape[1], eps, _stream()), "peak_scale")
+    return out
+
+
 def mel_log(spec, basis):
     _req(spec, torch.float32, "spec"); _req(basis, torch.float32, "basis")
     spec = spec.contiguous(); basis = basis.contiguous()

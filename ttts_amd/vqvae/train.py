@@ -8,7 +8,9 @@ Host-side differences (all outside the arithmetic):
   * `FlatAdamW` replaces the two AdamW instances and the 1566 `.item()` calls of `clip_grad_value_(…, None)`;
   * losses stay on the device until `log_interval`;
   * data: `dataset.path == "synthetic"` feeds band-limited noise clips of the collater's dict shape;
-    the Praat/PEQ augmentation is outside the path, so `wav_aug = wav` (the reference's freeze_quantizer branch).
+    `wav_aug = wav` (the reference's freeze_quantizer branch) unless the trainer is built with `use_augment=True`
+    (config key `train.augment`), which runs the parametric-equaliser part of the reference's augmentation on the GPU
+    (`augment.py`; the Praat formant / pitch stage is a CPU library and stays outside).
 """
 import glob
 import json
@@ -23,6 +25,7 @@ from ..optim import FlatAdamW
 from ..parallel import FlatDataParallel, init_distributed
 from ..utils.data_utils import HParams, mel_spectrogram_torch, spec_to_mel_torch, spectrogram_torch
 from . import losses as L
+from .augment import Augment, augment
 from .vq2 import MultiPeriodDiscriminator, SynthesizerTrn, slice_segments
 
 global_step = 0
@@ -81,7 +84,7 @@ class SyntheticVqvaeBatches:
 class VqvaeTrainer:
     """Owns net_g / net_d / the two optimizers and runs the two-phase step."""
 
-    def __init__(self, hps, device=None, seed=None):
+    def __init__(self, hps, device=None, seed=None, use_augment=None):
         self.rank, self.world, local = init_distributed()
         self.device = torch.device("cuda", local) if device is None else torch.device(device)
         if self.device.type != "cuda":
@@ -93,6 +96,9 @@ class VqvaeTrainer:
                                     **hps.vqvae).to(self.device)
         self.net_d = MultiPeriodDiscriminator(getattr(hps.vqvae, "use_spectral_norm", False)).to(self.device)
         self.dp = FlatDataParallel()
+        if use_augment is None:
+            use_augment = bool(getattr(hps.train, "augment", False))
+        self.aug = Augment(hps).to(self.device) if use_augment else None      # train.py:185
         tr = hps.train
         self.optim_g = FlatAdamW(self.net_g.parameters(), tr.learning_rate, betas=tr.betas, eps=tr.eps)
         self.optim_d = FlatAdamW(self.net_d.parameters(), tr.learning_rate, betas=tr.betas, eps=tr.eps)
@@ -107,12 +113,18 @@ class VqvaeTrainer:
     def train_step(self, data, inject=None):
         """data: dict(wav (B, T) f32, wav_lengths, text, text_lengths) on the device.  Returns a dict of device scalars."""
         h, tr = self.hps.data, self.hps.train
-        inject = inject or {}
+        inject = dict(inject or {})
         wav, wav_lengths, text, text_lengths = data["wav"], data["wav_lengths"], data["text"], data["text_lengths"]
         y = wav
         spec = spectrogram_torch(wav, h.filter_length, h.hop_length, h.win_length, center=False)
         spec_lengths = torch.div(wav_lengths, h.hop_length, rounding_mode="floor")
-        wav_aug, spec_aug = wav, spec                                        # augmentation is outside the path
+        if "wav_aug" in inject:
+            wav_aug = inject.pop("wav_aug")                                   # tests: a fixed augmented clip
+        elif self.aug is None:
+            wav_aug = wav                                                     # train.py:335-336
+        else:
+            wav_aug = augment(wav, self.aug, self.hps)                        # train.py:337-338 (PEQ part)
+        spec_aug = spec if wav_aug is wav else spectrogram_torch(wav_aug, h.filter_length, h.hop_length, h.win_length, center=False)
         self._sync_buffers()
         y_hat, kl_ssl, ids_slice, z_mask, (z, z_p, m_p, logs_p, m_q, logs_q), quantized = self.net_g(
             wav, wav_aug, wav_lengths, spec, spec_aug, spec_lengths, text, text_lengths, **inject)
