@@ -225,6 +225,38 @@ int ttts_mel_log_bwd_f32(const float* dmel, const float* mel, const float* basis
 int ttts_stft_mag_bwd_f32(const float* wav, const float* window, const float* twiddle2, const float* dspec,
                           float* dwav, int32_t B, int32_t T, int32_t n_fft, int32_t hop, void* stream);
 
+/* ---- autoregressive decoding of the GPT --------------------------------------------------------
+ * Replaces: GPT2InferenceModel.forward with a KV cache (ttts/gpt/model.py:34-184), inference_speech (:533-562) and the
+ * sample loop + logits processors of transformers' GenerationMixin it calls (RepetitionPenaltyLogitsProcessor,
+ * TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper) plus ttts/utils/typical_sampling.py:5-35.
+ * All step-dependent positions come from `ctr`, an int32[4] block in DEVICE memory owned by the caller:
+ *   ctr[0] = tokens already in the cache (= sequence index of the token being processed), ctr[1] = tokens generated,
+ *   ctr[2] = sequences still running (written by ttts_decode_advance) -- so one captured hipGraph replays every step.
+ *  ttts_decode_embed_f32: x f32 [M, D] = emb[tokens[m]] + pos[ctr[0] + pos_offset]   (emb [V, D], pos [P, D]).
+ *  ttts_kv_cache_fill_bf16: K / V of a prefill pass, qkv bf16 [B*S, 3*H*dh] -> caches bf16 [B*rep, H, S_max, dh];
+ *    sequence b*rep + r is a copy of b (num_return_sequences, repeat_interleave order).
+ *  ttts_attn_decode_bf16: qkv bf16 [M, 3*H*dh] of the new token: appends K / V at index ctr[0], out bf16 [M, H*dh] =
+ *    softmax(scale q.K^T) V over keys 0..ctr[0].  head_dim in {32, 64, 128}.
+ *  ttts_sample_logits_f32: logits f32 row (m / row_div) of [*, ldl], vocabulary V <= 2048.  Order as HF builds it:
+ *    repetition penalty over history[m][0 .. hist_base + ctr[1]) -> typical filter (typical_mass > 0) -> and, when
+ *    do_sample: / temperature -> top_k (> 0) -> top_p (< 1) -> softmax -> inverse-CDF draw with a counter hash of
+ *    (seed, m, ctr[1]); do_sample 0: argmax (lowest id on ties).  Finished rows emit pad_token; a row finishes when it
+ *    draws eos_token.  Writes tokens[m], history[m][hist_base + ctr[1]], out[m][ctr[1]], finished[m]; optional
+ *    probs_out f32 [M, V] (sampling: final probabilities; greedy: processed scores) and u_out f32 [M] for tests.
+ *  ttts_decode_advance: ctr[0]++, ctr[1]++, ctr[2] = #unfinished. */
+int ttts_decode_embed_f32(const int64_t* tokens, const float* emb, const float* pos, const int32_t* ctr,
+                          int32_t pos_offset, float* x, int32_t M, int32_t D, int32_t V, int32_t P, void* stream);
+int ttts_kv_cache_fill_bf16(const void* qkv, void* k_cache, void* v_cache, int32_t B, int32_t S, int32_t H,
+                            int32_t head_dim, int32_t S_max, int32_t rep, void* stream);
+int ttts_attn_decode_bf16(const void* qkv, void* k_cache, void* v_cache, const int32_t* ctr, void* out, int32_t M,
+                          int32_t H, int32_t head_dim, int32_t S_max, float scale, void* stream);
+int ttts_sample_logits_f32(const float* logits, int64_t ldl, int32_t row_div, int32_t M, int32_t V, int64_t* history,
+                           int64_t hist_stride, int32_t hist_base, const int32_t* ctr, int64_t* tokens, int64_t* out,
+                           int64_t out_stride, uint8_t* finished, float repetition_penalty, float typical_mass,
+                           float temperature, int32_t top_k, float top_p, int32_t do_sample, int32_t eos_token,
+                           int32_t pad_token, uint64_t seed, float* probs_out, float* u_out, void* stream);
+int ttts_decode_advance(int32_t* ctr, const uint8_t* finished, int32_t M, void* stream);
+
 /* ---- parametric-equaliser augmentation -------------------------------------------------------
  * Replaces Augment.forward's PEQ path (ttts/vqvae/augment/__init__.py:37-97) and ParametricEqualizer
  * (ttts/vqvae/augment/peq.py:19-116): torch.stft(center=True, hann) -> per-clip biquad product -> torch.istft ->

@@ -263,3 +263,122 @@ def synthetic_batch(B=8, text_len=128, mel_len=1024, seed=1234, cfg=None):
     tl = torch.full((B,), text_len, dtype=torch.int64)
     wl = torch.full((B,), mel_len * c["mel_length_compression"], dtype=torch.int64)
     return text, tl, mel, wl
+
+
+# ---------------------------------------------------------------------------------------------------------
+# inference: latent export and autoregressive decoding
+
+def latent_forward(sd, cfg, text_inputs, text_lengths, mel_codes, wav_lengths, bf16=False, clip_inputs=False):
+    """UnifiedVoice.forward(..., return_latent=True) (ttts/gpt/model.py:429-430,499-501): final_norm hidden states of the
+    mel positions without the two tokens the forward added -> (B, mel_len, D)."""
+    c = full_cfg(cfg)
+    _, _, mel_inp, _ = prepare_tokens(text_inputs, text_lengths, mel_codes, wav_lengths, cfg, clip_inputs)
+    enc = unified_voice_forward(sd, cfg, text_inputs, text_lengths, mel_codes, wav_lengths, bf16=bf16,
+                                clip_inputs=clip_inputs, return_hidden=True)
+    return enc[:, -mel_inp.shape[1]:][:, :-2]
+
+
+def inference_logits(sd, cfg, text_inp, mel_tokens, bf16=False):
+    """One full (cache-less) pass of GPT2InferenceModel.forward (ttts/gpt/model.py:109-184) as inference_speech drives it
+    (:533-562, post_init_gpt2_config(kv_cache=False) as in api_zh.py:52): the cached prefix is the text embedding,
+    `mel_tokens` (B, n) = [start_mel, prompt codes..., generated...] get mel_embedding + positions 0..n-1, the stack runs
+    causally over [text ; mel], lm_head = final_norm -> mel_head.  Returns fp32 logits (B, Tt + n, classes)."""
+    c = full_cfg(cfg)
+    D, heads = c["model_dim"], c["heads"]
+    Tt, n = text_inp.shape[1], mel_tokens.shape[1]
+    text_emb = F.embedding(text_inp, sd["text_embedding.weight"]) + sd["text_pos_embedding.emb.weight"][:Tt]
+    mel_emb = F.embedding(mel_tokens, sd["mel_embedding.weight"]) + sd["mel_pos_embedding.emb.weight"][:n]
+    x = torch.cat([text_emb, mel_emb], dim=1)
+    for i in range(c["layers"]):
+        x = gpt2_block(x, sd, i, heads, bf16)
+    x = F.layer_norm(x, (D,), sd["gpt.ln_f.weight"], sd["gpt.ln_f.bias"], 1e-5)
+    enc = F.layer_norm(x, (D,), sd["final_norm.weight"], sd["final_norm.bias"], 1e-5)
+    return (_r(enc, bf16) @ _r(sd["mel_head.weight"], bf16).t() + sd["mel_head.bias"]).float()
+
+
+def inference_inputs(cfg, text_inputs, mel_codes):
+    """inference_speech's input assembly (model.py:536-547): text -> [start, text, stop]; prompt -> [start_mel, codes]."""
+    c = full_cfg(cfg)
+    text = F.pad(text_inputs, (0, 1), value=c["stop_text_token"])
+    text_inp = F.pad(text, (1, 0), value=c["start_text_token"])
+    mel_inp = F.pad(mel_codes, (1, 0), value=c["start_mel_token"])
+    return text_inp, mel_inp
+
+
+# transformers.generation.logits_process (third-party, unpinned; 5.15.0 installed here) + the reference's own
+# TypicalLogitsWarper (ttts/utils/typical_sampling.py:5-35); order of application as GenerationMixin._get_logits_processor
+# builds it for inference_speech: repetition penalty -> typical (custom list) -> temperature -> top-k -> top-p.
+
+def repetition_penalty_(scores, input_ids, penalty):
+    score = torch.gather(scores, 1, input_ids)
+    score = torch.where(score < 0, score * penalty, score / penalty)
+    return scores.scatter(1, input_ids, score)
+
+
+def typical_filter(scores, mass=0.9):
+    normalized = torch.log_softmax(scores, dim=-1)
+    p = torch.exp(normalized)
+    ent = -(normalized * p).nansum(-1, keepdim=True)
+    shifted = torch.abs((-normalized) - ent)
+    sorted_scores, sorted_idx = torch.sort(shifted, descending=False)
+    sorted_logits = scores.gather(-1, sorted_idx)
+    cum = sorted_logits.softmax(dim=-1).cumsum(dim=-1)
+    last_ind = (cum < mass).sum(dim=1)
+    last_ind = last_ind.clamp(min=0, max=scores.shape[-1] - 1)
+    remove_sorted = sorted_scores > sorted_scores.gather(1, last_ind.view(-1, 1))
+    remove = remove_sorted.scatter(1, sorted_idx, remove_sorted)
+    return scores.masked_fill(remove, float("-inf"))
+
+
+def top_k_filter(scores, top_k):
+    top_k = min(top_k, scores.shape[-1])
+    kth = torch.topk(scores, top_k)[0][..., -1, None]
+    return scores.masked_fill(scores < kth, float("-inf"))
+
+
+def top_p_filter(scores, top_p):
+    sorted_logits, sorted_idx = torch.sort(scores, descending=False)
+    cum = sorted_logits.softmax(dim=-1).cumsum(dim=-1)
+    remove_sorted = cum <= (1 - top_p)
+    remove_sorted[..., -1:] = False
+    remove = remove_sorted.scatter(1, sorted_idx, remove_sorted)
+    return scores.masked_fill(remove, float("-inf"))
+
+
+def process_logits(scores, input_ids, repetition_penalty=None, typical_mass=None, temperature=None, top_k=None, top_p=None):
+    if repetition_penalty is not None and repetition_penalty != 1.0:
+        scores = repetition_penalty_(scores, input_ids, repetition_penalty)
+    if typical_mass is not None:
+        scores = typical_filter(scores, typical_mass)
+    if temperature is not None and temperature != 1.0:
+        scores = scores / temperature
+    if top_k is not None and top_k > 0:
+        scores = top_k_filter(scores, top_k)
+    if top_p is not None and top_p < 1.0:
+        scores = top_p_filter(scores, top_p)
+    return scores
+
+
+def generate(sd, cfg, text_inputs, mel_codes, max_generate_length, bf16=False, choose=None, **proc):
+    """inference_speech (model.py:533-562) with the sample loop of GenerationMixin._sample: full recompute per token,
+    next = choose(processed scores) (default: argmax = do_sample False), finished rows emit pad (= stop_mel_token),
+    stops at max_length = prompt + max_generate_length or when every row has produced stop_mel_token.
+    Returns (codes (B, <= max_generate_length), per-step raw logits list)."""
+    c = full_cfg(cfg)
+    text_inp, mel = inference_inputs(cfg, text_inputs, mel_codes)
+    Tt, trunc = text_inp.shape[1], text_inp.shape[1] + mel.shape[1]
+    unfinished = torch.ones(mel.shape[0], dtype=torch.bool)
+    raw = []
+    for _ in range(max_generate_length):
+        logits = inference_logits(sd, cfg, text_inp, mel, bf16)[:, -1]
+        raw.append(logits)
+        # HF hands the processors the whole input_ids row: the fake text slots (value 1) and every mel token so far
+        ids = torch.cat([torch.ones(mel.shape[0], Tt, dtype=torch.long), mel], dim=1)
+        scores = process_logits(logits.clone(), ids, **proc)
+        nxt = scores.argmax(-1) if choose is None else choose(scores)
+        nxt = torch.where(unfinished, nxt, torch.full_like(nxt, c["stop_mel_token"]))
+        mel = torch.cat([mel, nxt[:, None]], dim=1)
+        unfinished = unfinished & (nxt != c["stop_mel_token"])
+        if not bool(unfinished.any()):
+            break
+    return mel[:, trunc - Tt:], raw

@@ -22,6 +22,7 @@ import ref_import  # noqa: E402
 
 librosa_mel_stub = ref_import.install()
 import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
 
 from oracle import gpt_ref  # noqa: E402  (only for det_fill / synthetic inputs -- not for expected outputs)
 from oracle import mel_ref  # noqa: E402
@@ -547,6 +548,67 @@ def gen_step():
     print("G8 step losses:", rec["losses"], "norms", rec["grad_norms"], "unused g params:", int((g_grad_abs < 0).sum()))
 
 
+def gen_infer():
+    """return_latent forward, and greedy decoding through the reference's GPT2InferenceModel.forward
+    (kv_cache=False, as api_zh.py:52).  transformers 5.x removed GenerationMixin from PreTrainedModel, so
+    `inference_model.generate` (model.py:559) cannot run here: the fixture drives inference_speech's own input assembly
+    (model.py:536-547) and the cache-less forward step by step with HF's greedy rule (argmax, pad after eos), and pins
+    the logits processors on seeded scores with the installed transformers classes + the reference's TypicalLogitsWarper."""
+    from transformers.generation import logits_process as lp
+    from ttts.utils.typical_sampling import TypicalLogitsWarper
+    m, sd = ref_gpt(TINY_GPT)
+    m.eval()
+    m.post_init_gpt2_config(kv_cache=False)
+    text, tl, mel, wl = tiny_inputs()
+    rec = {"cfg_json": np.array(json.dumps(TINY_GPT))}
+    with torch.no_grad():
+        lat = m(text.clone(), tl, mel.clone(), wl, return_latent=True, clip_inputs=False)
+        rec["latent"] = lat.numpy()
+        # ---- greedy decode, B = 2, equal-length text (12) and a 6-code prompt
+        g = torch.Generator().manual_seed(11)
+        itext = torch.randint(1, 255, (2, 12), generator=g)
+        prompt = torch.randint(0, 1024, (2, 6), generator=g)
+        steps = 10
+        t_in = F.pad(itext, (0, 1), value=m.stop_text_token)
+        t_in, _ = m.build_aligned_inputs_and_targets(t_in, m.start_text_token, m.stop_text_token)
+        emb = m.text_embedding(t_in) + m.text_pos_embedding(t_in)
+        mel_in, _ = m.build_aligned_inputs_and_targets(prompt, m.start_mel_token, m.stop_mel_token)
+        m.inference_model.store_mel_emb(emb)
+        ids = torch.full((2, emb.shape[1] + mel_in.shape[-1]), 1, dtype=torch.long)
+        ids[:, -mel_in.shape[1]:] = mel_in
+        trunc = ids.shape[1]
+        unfinished = torch.ones(2, dtype=torch.bool)
+        raw = []
+        for _ in range(steps):
+            out = m.inference_model(input_ids=ids, attention_mask=torch.ones_like(ids), return_dict=True)
+            logits = out.logits[:, -1].float()
+            raw.append(logits.numpy())
+            nxt = logits.argmax(-1)
+            nxt = torch.where(unfinished, nxt, torch.full_like(nxt, m.stop_mel_token))
+            ids = torch.cat([ids, nxt[:, None]], 1)
+            unfinished &= nxt != m.stop_mel_token
+        rec.update({"itext": itext.numpy(), "prompt": prompt.numpy(), "greedy_codes": ids[:, trunc:].numpy(),
+                    "greedy_logits": np.stack(raw), "first_pass_logits": m.inference_model(
+                        input_ids=ids[:, :trunc], attention_mask=torch.ones_like(ids[:, :trunc]), return_dict=True).logits.numpy()})
+        margins = np.sort(np.stack(raw), -1)
+        print("infer: greedy codes", ids[:, trunc:].tolist(), "min top-2 margin %.4f" % float((margins[..., -1] - margins[..., -2]).min()))
+        # ---- logits processors on seeded scores (B 3, V 1026), history of 9 tokens
+        scores = torch.randn(3, 1026, generator=g) * 3.0
+        hist = torch.randint(0, 1026, (3, 9), generator=g)
+        rec["proc_scores"], rec["proc_hist"] = scores.numpy(), hist.numpy()
+        rec["proc_rep2"] = lp.RepetitionPenaltyLogitsProcessor(2.0)(hist, scores.clone()).numpy()
+        rec["proc_temp08"] = lp.TemperatureLogitsWarper(0.8)(hist, scores.clone()).numpy()
+        rec["proc_topk50"] = lp.TopKLogitsWarper(50)(hist, scores.clone()).numpy()
+        rec["proc_topp08"] = lp.TopPLogitsWarper(0.8)(hist, scores.clone()).numpy()
+        rec["proc_typical09"] = TypicalLogitsWarper(mass=0.9)(hist, scores.clone()).numpy()
+        chain = lp.RepetitionPenaltyLogitsProcessor(2.0)(hist, scores.clone())
+        chain = lp.TemperatureLogitsWarper(0.8)(hist, chain)
+        chain = lp.TopKLogitsWarper(50)(hist, chain)
+        chain = lp.TopPLogitsWarper(0.8)(hist, chain)
+        rec["proc_chain"] = chain.numpy()
+    np.savez_compressed(os.path.join(OUT, "gpt_infer.npz"), **rec)
+
+
 PEQ_CFGS = [dict(sampling_rate=32000, win_length=2048, hop_length=640, cutoff_lowpass=60, cutoff_highpass=10000, num_peak=8,
                  q_min=2, q_max=5, T=9000),
             dict(sampling_rate=22050, win_length=1024, hop_length=256, cutoff_lowpass=60, cutoff_highpass=10000, num_peak=8,
@@ -594,7 +656,7 @@ def gen_peq():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gpt", "vq", "mel", "vqvae", "disc", "flow", "attn", "step", "peq"]
+    which = sys.argv[1:] or ["gpt", "vq", "mel", "vqvae", "disc", "flow", "attn", "step", "peq", "infer"]
     with torch.no_grad() if False else torch.enable_grad():
         if "gpt" in which:
             gen_gpt()
@@ -614,4 +676,6 @@ if __name__ == "__main__":
             gen_step()
         if "peq" in which:
             gen_peq()
+        if "infer" in which:
+            gen_infer()
     print("fixtures:", {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT))})

@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .decode import GptDecoder
 from .engine import GptEngine, resolve_config
 
 
@@ -167,6 +168,51 @@ class UnifiedVoice(nn.Module):
         eng.forward()
         lo = eng.b["losses"]
         return lo[0].clone(), lo[1].clone(), eng.mel_logits()
+
+
+    # ---- inference (ttts/gpt/model.py:357-396, 533-562) ---------------------------------------------------------------
+    def post_init_gpt2_config(self, use_deepspeed=False, kv_cache=False, half=False):
+        """The reference builds its HF `GPT2InferenceModel` wrapper here.  This build decodes on `GptDecoder` (always with a
+        KV cache, bf16 matmuls as in training); the arguments are accepted for source compatibility and change nothing:
+        results follow the reference's cache-less path whatever `kv_cache` says (see gpt/decode.py)."""
+        if use_deepspeed:
+            raise NotImplementedError("deepspeed inference kernels are CUDA-only and not part of this build")
+        self.__dict__["decoder"] = GptDecoder(self.engine)
+        return self
+
+    def build_aligned_inputs_and_targets(self, input, start_token, stop_token):
+        """model.py:397-400."""
+        return F.pad(input, (1, 0), value=start_token), F.pad(input, (0, 1), value=stop_token)
+
+    @torch.no_grad()
+    def inference_speech(self, text_inputs, mel_codes, input_tokens=None, num_return_sequences=1, max_generate_length=None,
+                         typical_sampling=False, typical_mass=.9, **hf_generate_kwargs):
+        """Sample mel codes after the prompt `mel_codes` for `text_inputs` (model.py:533-562).  Supported HF generate
+        keywords: do_sample, temperature, top_k, top_p, repetition_penalty, length_penalty (beam-search only in HF:
+        accepted and ignored), plus `seed` for the counter-hash sampler.  num_beams > 1 and `input_tokens` continuation
+        are not built.  Returns int64 (B * num_return_sequences, <= max length) codes, finished rows padded with
+        stop_mel_token."""
+        if input_tokens is not None:
+            raise NotImplementedError("continuing from input_tokens is not part of this build")
+        kw = dict(hf_generate_kwargs)
+        if kw.pop("num_beams", 1) != 1:
+            raise NotImplementedError("beam search is not part of this build")
+        kw.pop("length_penalty", None)
+        sampler = dict(do_sample=kw.pop("do_sample", False), temperature=kw.pop("temperature", 1.0) or 1.0,
+                       top_k=kw.pop("top_k", 0) or 0, top_p=kw.pop("top_p", 1.0) or 1.0,
+                       repetition_penalty=kw.pop("repetition_penalty", 1.0) or 1.0, seed=kw.pop("seed", 0))
+        if kw:
+            raise TypeError("unsupported generate arguments: %s" % sorted(kw))
+        if "decoder" not in self.__dict__:
+            self.post_init_gpt2_config()
+        dev = self.engine.device
+        text_inputs = F.pad(text_inputs.to(dev), (0, 1), value=self.stop_text_token)
+        text_inp, _ = self.build_aligned_inputs_and_targets(text_inputs, self.start_text_token, self.stop_text_token)
+        mel_inp, _ = self.build_aligned_inputs_and_targets(mel_codes.to(dev), self.start_mel_token, self.stop_mel_token)
+        n_new = self.max_mel_tokens - 1 if max_generate_length is None else int(max_generate_length)
+        n_new = min(n_new, self.max_mel_tokens + 2 - mel_inp.shape[1])        # the learned position table ends there
+        return self.decoder.generate(text_inp.long(), mel_inp.long(), n_new, num_return_sequences=num_return_sequences,
+                                     typical_mass=typical_mass if typical_sampling else 0.0, **sampler)
 
 
 class FusedAdamW:

@@ -281,6 +281,59 @@ def stft_mag(wav, window, n_fft, hop):
     return spec
 
 
+# ---- autoregressive decoding (csrc/decode.hip) ------------------------------------------------------------------------
+def decode_embed(tokens, emb, pos, ctr, pos_offset, x):
+    _req(tokens, torch.int64, "tokens"); _req(emb, torch.float32, "emb"); _req(pos, torch.float32, "pos")
+    _req(ctr, torch.int32, "ctr"); _req(x, torch.float32, "x")
+    M, D = x.shape
+    check(_l.get().ttts_decode_embed_f32(_p(tokens), _p(emb), _p(pos), _p(ctr), int(pos_offset), _p(x), M, D, emb.shape[0],
+                                         pos.shape[0], _stream()), "decode_embed")
+    return x
+
+
+def kv_cache_fill(qkv, k_cache, v_cache, B, S, H, dh, rep=1):
+    """qkv bf16 [B*S, 3*H*dh] -> k_cache / v_cache bf16 [B*rep, H, S_max, dh] rows 0..S-1."""
+    _req(qkv, torch.bfloat16, "qkv"); _req(k_cache, torch.bfloat16, "k_cache"); _req(v_cache, torch.bfloat16, "v_cache")
+    if qkv.shape != (B * S, 3 * H * dh) or not qkv.is_contiguous():
+        raise TttsError("kv_cache_fill: qkv must be contiguous [B*S, 3*H*dh]")
+    if k_cache.shape != v_cache.shape or k_cache.shape[:2] != (B * rep, H) or k_cache.shape[3] != dh or not k_cache.is_contiguous():
+        raise TttsError("kv_cache_fill: caches must be contiguous [B*rep, H, S_max, dh]")
+    check(_l.get().ttts_kv_cache_fill_bf16(_p(qkv), _p(k_cache), _p(v_cache), B, S, H, dh, k_cache.shape[2], rep, _stream()),
+          "kv_cache_fill")
+
+
+def attn_decode(qkv, k_cache, v_cache, ctr, out, scale):
+    _req(qkv, torch.bfloat16, "qkv"); _req(k_cache, torch.bfloat16, "k_cache"); _req(v_cache, torch.bfloat16, "v_cache")
+    _req(ctr, torch.int32, "ctr"); _req(out, torch.bfloat16, "out")
+    M, H, S_max, dh = k_cache.shape
+    if qkv.shape != (M, 3 * H * dh) or out.shape != (M, H * dh) or not (qkv.is_contiguous() and out.is_contiguous()):
+        raise TttsError("attn_decode: qkv [M, 3*H*dh] / out [M, H*dh] contiguous")
+    check(_l.get().ttts_attn_decode_bf16(_p(qkv), _p(k_cache), _p(v_cache), _p(ctr), _p(out), M, H, dh, S_max, float(scale),
+                                         _stream()), "attn_decode")
+    return out
+
+
+def sample_logits(logits, ctr, tokens, finished, V, history=None, hist_base=0, out=None, row_div=1, repetition_penalty=1.0,
+                  typical_mass=0.0, temperature=1.0, top_k=0, top_p=1.0, do_sample=False, eos_token=-1, pad_token=0, seed=0,
+                  probs_out=None, u_out=None):
+    _req(logits, torch.float32, "logits"); _req(ctr, torch.int32, "ctr"); _req(tokens, torch.int64, "tokens")
+    _req(finished, torch.uint8, "finished"); _req(history, torch.int64, "history"); _req(out, torch.int64, "out")
+    _req(probs_out, torch.float32, "probs_out"); _req(u_out, torch.float32, "u_out")
+    M = tokens.shape[0]
+    check(_l.get().ttts_sample_logits_f32(_p(logits), _ld(logits), row_div, M, V, _p(history),
+                                          history.stride(0) if history is not None else 0, hist_base, _p(ctr), _p(tokens), _p(out),
+                                          out.stride(0) if out is not None else 0, _p(finished), float(repetition_penalty),
+                                          float(typical_mass), float(temperature), int(top_k or 0), float(top_p), int(bool(do_sample)),
+                                          int(eos_token), int(pad_token), int(seed) & (2 ** 64 - 1), _p(probs_out), _p(u_out),
+                                          _stream()), "sample_logits")
+    return tokens
+
+
+def decode_advance(ctr, finished):
+    _req(ctr, torch.int32, "ctr"); _req(finished, torch.uint8, "finished")
+    check(_l.get().ttts_decode_advance(_p(ctr), _p(finished), finished.shape[0], _stream()), "decode_advance")
+
+
 PEQ_PEAK, PEQ_LOW_SHELF, PEQ_HIGH_SHELF = 0, 1, 2
 
 
