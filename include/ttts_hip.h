@@ -244,6 +244,14 @@ int ttts_stft_mag_bwd_f32(const float* wav, const float* window, const float* tw
  *    draws eos_token.  Writes tokens[m], history[m][hist_base + ctr[1]], out[m][ctr[1]], finished[m]; optional
  *    probs_out f32 [M, V] (sampling: final probabilities; greedy: processed scores) and u_out f32 [M] for tests.
  *  ttts_decode_advance: ctr[0]++, ctr[1]++, ctr[2] = #unfinished. */
+/* Skinny linear layer of a decode step, M <= 16 rows: out[M, N] = epilogue(LN2(LN1(x))[M, K] . W[N, K]^T + bias) with the
+ * rounding points of ttts_gemm_nt_bf16 (operands bf16, bf16(acc + bias) before GELU / residual add).  x: bf16 [M, ldx], or
+ * f32 when x_is_f32 (then optionally layer-normed, eps 1e-5, by ln1 and ln2 -- NULL = skip); W bf16 [N, ldw];
+ * epilogue in {STORE_BF16, GELU_BF16 (out = gelu only, no aux), RESID_ADD_F32 (out = resid + ..), STORE_F32}. */
+int ttts_linear_decode_bf16(const void* x, int64_t ldx, int32_t x_is_f32, const float* ln1_gamma, const float* ln1_beta,
+                            const float* ln2_gamma, const float* ln2_beta, const void* W, int64_t ldw, const float* bias,
+                            void* out, int64_t ldc, const float* resid, int32_t M, int32_t N, int32_t K, int32_t epilogue,
+                            void* stream);
 int ttts_decode_embed_f32(const int64_t* tokens, const float* emb, const float* pos, const int32_t* ctr,
                           int32_t pos_offset, float* x, int32_t M, int32_t D, int32_t V, int32_t P, void* stream);
 int ttts_kv_cache_fill_bf16(const void* qkv, void* k_cache, void* v_cache, int32_t B, int32_t S, int32_t H,

@@ -56,6 +56,53 @@ def test_attn_decode_vs_torch(dh, H, t):
     assert torch.equal(kc, kc0) and torch.equal(vc, vc0)
 
 
+@pytest.mark.parametrize("M,K,N", [(1, 512, 1536), (8, 2048, 512), (16, 512, 1026), (5, 64, 48), (3, 256, 64)])
+def test_linear_decode_vs_torch(M, K, N):
+    """All epilogues and LayerNorm fusions of the skinny decode GEMM against torch with the same rounding points."""
+    from ttts_amd import ops
+    from ttts_amd.lib import EPI_GELU_BF16, EPI_RESID_ADD_F32, EPI_STORE_BF16, EPI_STORE_F32
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(M * 1000 + K + N)
+    dev = _dev()
+    r = lambda *s: torch.randn(*s, generator=g)
+    xf = (r(M, K) * 1.5 + 0.3).to(dev)
+    xb = r(M, K).to(torch.bfloat16).to(dev)
+    w = (r(N, K) / K ** 0.5).to(torch.bfloat16).to(dev)
+    bias = (r(N) * 0.1).to(dev)
+    g1, b1, g2, b2 = (1 + 0.1 * r(K)).to(dev), (0.1 * r(K)).to(dev), (1 + 0.1 * r(K)).to(dev), (0.1 * r(K)).to(dev)
+    ld = (N + 7) // 8 * 8
+    bfr = lambda t: t.to(torch.bfloat16).float()
+
+    def gelu_new(x):
+        return 0.5 * x * (1.0 + torch.tanh(0.7978845608028654 * (x + 0.044715 * x ** 3)))
+    # bf16 rows, store bf16
+    out = torch.zeros(M, ld, dtype=torch.bfloat16, device=dev)
+    ops.linear_decode(xb, w, out, bias, epilogue=EPI_STORE_BF16, n=N)
+    ref = xb.float() @ w.float().t() + bias
+    assert (out[:, :N].float() - bfr(ref)).abs().max().item() <= 2e-2 * ref.abs().max().item()
+    assert not out[:, N:].any()
+    # LN1-fused, GELU
+    out = torch.zeros(M, ld, dtype=torch.bfloat16, device=dev)
+    ops.linear_decode(xf, w, out, bias, epilogue=EPI_GELU_BF16, ln1=(g1, b1), n=N)
+    h = bfr(F.layer_norm(xf, (K,), g1, b1, 1e-5))
+    ref = bfr(gelu_new(bfr(h @ w.float().t() + bias)))
+    assert (out[:, :N].float() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item() + 1e-3
+    # residual add (fp32 stream)
+    res = r(M, ld).to(dev)
+    out = torch.zeros(M, ld, dtype=torch.float32, device=dev)
+    ops.linear_decode(xb, w, out, bias, epilogue=EPI_RESID_ADD_F32, resid=res, n=N)
+    ref = res[:, :N] + bfr(xb.float() @ w.float().t() + bias)
+    assert (out[:, :N] - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+    # two LayerNorms, fp32 logits
+    out = torch.zeros(M, ld, dtype=torch.float32, device=dev)
+    ops.linear_decode(xf, w, out, bias, epilogue=EPI_STORE_F32, ln1=(g1, b1), ln2=(g2, b2), n=N)
+    h = bfr(F.layer_norm(F.layer_norm(xf, (K,), g1, b1, 1e-5), (K,), g2, b2, 1e-5))
+    ref = h @ w.float().t() + bias
+    assert (out[:, :N] - ref).abs().max().item() <= 3e-3 * ref.abs().max().item() + 1e-4
+    with pytest.raises(Exception):
+        ops.linear_decode(torch.zeros(17, K, dtype=torch.bfloat16, device=dev), w, torch.zeros(17, ld, dtype=torch.bfloat16, device=dev))
+
+
 def test_kv_cache_fill_replicates():
     from ttts_amd import ops
     B, S, H, dh, rep, S_max = 2, 9, 4, 32, 3, 20

@@ -53,17 +53,18 @@ __global__ __launch_bounds__(256) void kv_cache_fill_kernel(const bf16* __restri
   }
 }
 
-// one workgroup (4 waves) per (head, sequence).  A key is handled by dh/8 adjacent lanes (16-byte slices of the row), so a
+// one workgroup (16 waves) per (head, sequence).  A key is handled by dh/8 adjacent lanes (16-byte slices of the row), so a
 // wave covers 64 / (dh/8) keys per pass.  Every lane group keeps an online-softmax state (m, l, acc[8]); states are merged
 // across the groups of a wave by shuffles and across waves through LDS.
+constexpr int AW = 16;   // waves per (sequence, head): 16 x (64 / (dh/8)) keys in flight per pass
 template <int DH>
-__global__ __launch_bounds__(256) void attn_decode_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ kc,
+__global__ __launch_bounds__(AW * 64) void attn_decode_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ kc,
                                                           bf16* __restrict__ vc, const int32_t* __restrict__ ctr,
                                                           bf16* __restrict__ out, int H, int S_max, float scale_log2) {
   constexpr int LPK = DH / 8;          // lanes per key
   constexpr int KPW = 64 / LPK;        // keys per wave and pass
-  __shared__ float sm_acc[4][DH];
-  __shared__ float sm_ml[4][2];
+  __shared__ float sm_acc[AW][DH];
+  __shared__ float sm_ml[AW][2];
   const int h = blockIdx.x, m = blockIdx.y;
   const int D = H * DH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16* __restrict
   float mx = -3.0e38f, l = 0.f, acc[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-  for (int k0 = wave * KPW; k0 <= t; k0 += 4 * KPW) {
+  for (int k0 = wave * KPW; k0 <= t; k0 += AW * KPW) {
     const int key = k0 + grp;
     if (key <= t) {   // lanes of one group agree
       const bf16* kp = key == t ? row + D : kbase + (int64_t)key * DH;
@@ -126,15 +127,149 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16* __restrict
   if (tid < DH) {
     float M = sm_ml[0][0];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) M = fmaxf(M, sm_ml[w][0]);
+    for (int w = 1; w < AW; ++w) M = fmaxf(M, sm_ml[w][0]);
     float L = 0.f, o = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < AW; ++w) {
       const float a = __builtin_amdgcn_exp2f(sm_ml[w][0] - M);
       L += sm_ml[w][1] * a;
       o += sm_acc[w][tid] * a;
     }
     out[(int64_t)m * D + h * DH + tid] = (bf16)(o / L);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// skinny linear layer for M <= 16 token rows: out[M, N] = epi(LN2(LN1(x))[M, K] . W[N, K]^T + bias).
+// The training path's 256 x 128-tile GEMM needs ~9-16 us for these shapes (2-4 workgroups stream the whole weight matrix);
+// here one workgroup owns 16 output columns: the (optionally layer-normed) rows are staged once in LDS as bf16, the 16
+// waves split K in 32-wide steps of v_mfma_f32_16x16x32_bf16 (A = 16 weight rows x 32 k straight from HBM, B = the staged
+// rows), partial tiles are summed through LDS and the epilogue rounds exactly like the GEMM kernel's
+// (bf16(acc + bias), then GELU / fp32 residual add / store).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+struct LinearDecodeParams {
+  const void* x; int64_t ldx; int x_is_f32;
+  const float *g1, *b1, *g2, *b2;       // optional LayerNorms applied to x (f32 input only); LN1 output stays fp32 if LN2 follows
+  const bf16* W; int64_t ldw;
+  const float* bias;
+  void* out; int64_t ldc;
+  const float* resid;
+  int M, N, K, epi;
+  float eps;
+};
+
+constexpr int LW = 16;   // waves per workgroup: every wave has at most K / 512 weight loads, all in flight at once
+__global__ __launch_bounds__(LW * 64) void linear_decode_kernel(LinearDecodeParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ld_smem[];
+  const int KP = p.K + 8;                                 // row pitch in bf16 (16-byte skew against bank conflicts)
+  bf16* xs = reinterpret_cast<bf16*>(ld_smem);            // [16][KP]
+  float* red = reinterpret_cast<float*>(ld_smem + (size_t)16 * KP * sizeof(bf16));   // [LW][16][16]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * 16;
+  // ---- stage the rows: one wave per row
+  {
+    const int r = tid >> 6, c = tid & 63;
+    if (!p.x_is_f32) {
+      const bf16* xr = static_cast<const bf16*>(p.x) + (int64_t)r * p.ldx;
+      for (int k = c * 8; k < p.K; k += 512)
+        *reinterpret_cast<bf16x8*>(xs + r * KP + k) = r < p.M ? *reinterpret_cast<const bf16x8*>(xr + k) : zero8();
+    } else {
+      const float* xr = static_cast<const float*>(p.x) + (int64_t)r * p.ldx;
+      float mean = 0.f, rstd = 1.f, mean2 = 0.f, rstd2 = 1.f;
+      if (p.g1) {   // two-pass statistics, as ln_fwd_kernel
+        float s = 0.f;
+        for (int k = c * 4; k < p.K; k += 256) {
+          const float4 v = r < p.M ? *reinterpret_cast<const float4*>(xr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+          s += (v.x + v.y) + (v.z + v.w);
+        }
+        for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
+        mean = s / (float)p.K;
+        float q = 0.f;
+        for (int k = c * 4; k < p.K; k += 256) {
+          const float4 v = r < p.M ? *reinterpret_cast<const float4*>(xr + k) : make_float4(mean, mean, mean, mean);
+          const float a = v.x - mean, b = v.y - mean, cc = v.z - mean, e = v.w - mean;
+          q += (a * a + b * b) + (cc * cc + e * e);
+        }
+        for (int o = 1; o < 64; o <<= 1) q += __shfl_xor(q, o, 64);
+        rstd = 1.0f / sqrtf(q / (float)p.K + p.eps);
+        if (p.g2) {   // statistics of y1 = LN1(x) for the second norm
+          float s2 = 0.f;
+          for (int k = c * 4; k < p.K; k += 256) {
+            const float4 v = r < p.M ? *reinterpret_cast<const float4*>(xr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 g = *reinterpret_cast<const float4*>(p.g1 + k), b = *reinterpret_cast<const float4*>(p.b1 + k);
+            s2 += (((v.x - mean) * rstd * g.x + b.x) + ((v.y - mean) * rstd * g.y + b.y)) +
+                  (((v.z - mean) * rstd * g.z + b.z) + ((v.w - mean) * rstd * g.w + b.w));
+          }
+          for (int o = 1; o < 64; o <<= 1) s2 += __shfl_xor(s2, o, 64);
+          mean2 = s2 / (float)p.K;
+          float q2 = 0.f;
+          for (int k = c * 4; k < p.K; k += 256) {
+            const float4 v = r < p.M ? *reinterpret_cast<const float4*>(xr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 g = *reinterpret_cast<const float4*>(p.g1 + k), b = *reinterpret_cast<const float4*>(p.b1 + k);
+            const float a = (v.x - mean) * rstd * g.x + b.x - mean2, bb = (v.y - mean) * rstd * g.y + b.y - mean2;
+            const float cc = (v.z - mean) * rstd * g.z + b.z - mean2, e = (v.w - mean) * rstd * g.w + b.w - mean2;
+            q2 += (a * a + bb * bb) + (cc * cc + e * e);
+          }
+          for (int o = 1; o < 64; o <<= 1) q2 += __shfl_xor(q2, o, 64);
+          rstd2 = 1.0f / sqrtf(q2 / (float)p.K + p.eps);
+        }
+      }
+      for (int k = c * 4; k < p.K; k += 256) {
+        float4 v = r < p.M ? *reinterpret_cast<const float4*>(xr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.g1) {
+          const float4 g = *reinterpret_cast<const float4*>(p.g1 + k), b = *reinterpret_cast<const float4*>(p.b1 + k);
+          v.x = (v.x - mean) * rstd * g.x + b.x; v.y = (v.y - mean) * rstd * g.y + b.y;
+          v.z = (v.z - mean) * rstd * g.z + b.z; v.w = (v.w - mean) * rstd * g.w + b.w;
+          if (p.g2) {
+            const float4 g2 = *reinterpret_cast<const float4*>(p.g2 + k), b2 = *reinterpret_cast<const float4*>(p.b2 + k);
+            v.x = (v.x - mean2) * rstd2 * g2.x + b2.x; v.y = (v.y - mean2) * rstd2 * g2.y + b2.y;
+            v.z = (v.z - mean2) * rstd2 * g2.z + b2.z; v.w = (v.w - mean2) * rstd2 * g2.w + b2.w;
+          }
+        }
+        bf16x4 o;
+        o[0] = (bf16)(r < p.M ? v.x : 0.f); o[1] = (bf16)(r < p.M ? v.y : 0.f);
+        o[2] = (bf16)(r < p.M ? v.z : 0.f); o[3] = (bf16)(r < p.M ? v.w : 0.f);
+        *reinterpret_cast<bf16x4*>(xs + r * KP + k) = o;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- K loop: wave w takes the 32-wide steps w, w + LW, ...
+  const int arow = lane & 15, kg = lane >> 4;
+  const int n = n0 + arow;
+  const bf16* wr = p.W + (int64_t)min(n, p.N - 1) * p.ldw + kg * 8;
+  const bf16* xr = xs + arow * KP + kg * 8;
+  f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+  const int steps = p.K >> 5;
+#pragma unroll 4
+  for (int st = wave; st < steps; st += LW) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(wr + st * 32);
+    const bf16x8 b = *reinterpret_cast<const bf16x8*>(xr + st * 32);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+  }
+  // D[i = weight row (4 * (lane >> 4) + r)][j = token row (lane & 15)]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[(wave * 16 + 4 * kg + r) * 16 + arow] = acc[r];
+  __syncthreads();
+  if (tid < 256) {
+    const int m = tid >> 4, nl = tid & 15, nn = n0 + nl;
+    if (m < p.M && nn < p.N) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < LW; ++w) v += red[(w * 16 + nl) * 16 + m];
+      if (p.bias) v += p.bias[nn];
+      const int64_t off = (int64_t)m * p.ldc + nn;
+      if (p.epi == TTTS_EPI_STORE_F32) {
+        static_cast<float*>(p.out)[off] = v;
+      } else if (p.epi == TTTS_EPI_RESID_ADD_F32) {
+        static_cast<float*>(p.out)[off] = p.resid[off] + (float)(bf16)v;
+      } else if (p.epi == TTTS_EPI_GELU_BF16) {
+        static_cast<bf16*>(p.out)[off] = (bf16)gelu_new_f((float)(bf16)v);
+      } else {
+        static_cast<bf16*>(p.out)[off] = (bf16)v;
+      }
+    }
   }
 }
 
@@ -157,19 +292,19 @@ struct SampleParams {
   float* u_out;                                          // optional [M]: the uniform draw
 };
 
+constexpr int ST = 1024;   // sampler threads: one compare-exchange per thread and bitonic stage at V <= 2048
 // bitonic sort of n (power of two) (key, idx) pairs in LDS, descending by key; ties by ascending idx (deterministic)
 __device__ __forceinline__ void bitonic_desc(float* key, uint16_t* idx, int n, int tid) {
   for (int k = 2; k <= n; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < n; i += 256) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const float a = key[i], b = key[ixj];
-          const uint16_t ia = idx[i], ib = idx[ixj];
-          const bool a_first = (a > b) || (a == b && ia < ib);      // desired order: a before b
-          const bool up = ((i & k) == 0);
-          if (up ? !a_first : a_first) { key[i] = b; key[ixj] = a; idx[i] = ib; idx[ixj] = ia; }
-        }
+      for (int pr = tid; pr < (n >> 1); pr += ST) {                  // one compare-exchange per pair (i, i + j)
+        const int i = ((pr & ~(j - 1)) << 1) | (pr & (j - 1));
+        const int ixj = i + j;
+        const float a = key[i], b = key[ixj];
+        const uint16_t ia = idx[i], ib = idx[ixj];
+        const bool a_first = (a > b) || (a == b && ia < ib);        // desired order: a before b
+        const bool up = ((i & k) == 0);
+        if (up ? !a_first : a_first) { key[i] = b; key[ixj] = a; idx[i] = ib; idx[ixj] = ia; }
       }
       __syncthreads();
     }
@@ -181,23 +316,29 @@ __device__ __forceinline__ float block_reduce_sum(float v, float* sh, int tid) {
   __syncthreads();
   if ((tid & 63) == 0) sh[tid >> 6] = v;
   __syncthreads();
-  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  float t = 0.f;
+#pragma unroll
+  for (int w = 0; w < ST / 64; ++w) t += sh[w];
+  return t;
 }
 __device__ __forceinline__ float block_reduce_max(float v, float* sh, int tid) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   __syncthreads();
   if ((tid & 63) == 0) sh[tid >> 6] = v;
   __syncthreads();
-  return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+  float t = sh[0];
+#pragma unroll
+  for (int w = 1; w < ST / 64; ++w) t = fmaxf(t, sh[w]);
+  return t;
 }
 
-// exclusive prefix sums of arr[0..n) in place order: returns through `pre` (LDS, n floats); 256 threads, chunked
+// exclusive prefix sums of arr[0..n) in place order: returns through `pre` (LDS, n floats); ST threads, chunked
 __device__ __forceinline__ void block_exclusive_scan(const float* arr, float* pre, int n, float* sh, int tid) {
-  const int per = (n + 255) / 256;
+  const int per = (n + ST - 1) / ST;
   const int lo = tid * per, hi = min(lo + per, n);
   float s = 0.f;
   for (int i = lo; i < hi; ++i) s += arr[i];
-  // scan of the 256 chunk sums: wave scan + wave offsets
+  // scan of the ST chunk sums: wave scan + wave offsets
   float inc = s;
   for (int o = 1; o < 64; o <<= 1) {
     const float v = __shfl_up(inc, o, 64);
@@ -213,14 +354,14 @@ __device__ __forceinline__ void block_exclusive_scan(const float* arr, float* pr
   __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void sample_logits_kernel(SampleParams p) {
+__global__ __launch_bounds__(ST) void sample_logits_kernel(SampleParams p) {
   __shared__ float sc[SAMPLE_MAXV];       // scores by token id
   __shared__ float key[SAMPLE_MAXV];      // sort keys / sorted scores / probabilities
   __shared__ float pre[SAMPLE_MAXV];      // probabilities in sort order / prefix sums
   __shared__ float cum[SAMPLE_MAXV];      // prefix sums
   __shared__ uint16_t idx[SAMPLE_MAXV];
   __shared__ uint32_t seen[SAMPLE_MAXV / 32];
-  __shared__ float sh[8];
+  __shared__ float sh[ST / 64];
   __shared__ int sh_i[2];
   const int m = blockIdx.x, tid = threadIdx.x;
   const int V = p.V;
@@ -229,92 +370,92 @@ __global__ __launch_bounds__(256) void sample_logits_kernel(SampleParams p) {
   const int step = p.ctr[CTR_STEP];
   const float NEG_INF = -INFINITY;
   const float* lrow = p.logits + (int64_t)(m / p.row_div) * p.ldl;
-  for (int i = tid; i < V; i += 256) sc[i] = lrow[i];
-  for (int i = tid; i < SAMPLE_MAXV / 32; i += 256) seen[i] = 0u;
+  for (int i = tid; i < V; i += ST) sc[i] = lrow[i];
+  for (int i = tid; i < SAMPLE_MAXV / 32; i += ST) seen[i] = 0u;
   __syncthreads();
   // 1. repetition penalty (RepetitionPenaltyLogitsProcessor): every token id that occurs in the row so far, once
   if (p.repetition_penalty != 1.0f) {
     const int hl = p.hist_base + step;
-    for (int j = tid; j < hl; j += 256) {
+    for (int j = tid; j < hl; j += ST) {
       const int64_t tk = p.history[(int64_t)m * p.hist_stride + j];
       if (tk >= 0 && tk < V) atomicOr(&seen[tk >> 5], 1u << (tk & 31));
     }
     __syncthreads();
-    for (int i = tid; i < V; i += 256)
+    for (int i = tid; i < V; i += ST)
       if (seen[i >> 5] & (1u << (i & 31))) { const float s = sc[i]; sc[i] = s < 0.f ? s * p.repetition_penalty : s / p.repetition_penalty; }
     __syncthreads();
   }
   // 2. typical filtering (ttts/utils/typical_sampling.py): keep the tokens whose surprise is closest to the entropy
   if (p.typical_mass > 0.f) {
     float mx = NEG_INF;
-    for (int i = tid; i < V; i += 256) mx = fmaxf(mx, sc[i]);
+    for (int i = tid; i < V; i += ST) mx = fmaxf(mx, sc[i]);
     mx = block_reduce_max(mx, sh, tid);
     float se = 0.f;
-    for (int i = tid; i < V; i += 256) se += expf(sc[i] - mx);
+    for (int i = tid; i < V; i += ST) se += expf(sc[i] - mx);
     se = block_reduce_sum(se, sh, tid);
     const float lse = mx + logf(se);
     float ent = 0.f;
-    for (int i = tid; i < V; i += 256) { const float lp = sc[i] - lse; const float t = lp * expf(lp); ent -= (t == t) ? t : 0.f; }
+    for (int i = tid; i < V; i += ST) { const float lp = sc[i] - lse; const float t = lp * expf(lp); ent -= (t == t) ? t : 0.f; }
     ent = block_reduce_sum(ent, sh, tid);
     // ascending by |(-logp) - ent|  ==  descending by its negative
-    for (int i = tid; i < n2; i += 256) { key[i] = i < V ? -fabsf(-(sc[i] - lse) - ent) : NEG_INF; idx[i] = (uint16_t)i; }
+    for (int i = tid; i < n2; i += ST) { key[i] = i < V ? -fabsf(-(sc[i] - lse) - ent) : NEG_INF; idx[i] = (uint16_t)i; }
     __syncthreads();
     bitonic_desc(key, idx, n2, tid);
     // cumulative softmax mass in that order
-    for (int i = tid; i < V; i += 256) pre[i] = expf(sc[idx[i]] - lse);
+    for (int i = tid; i < V; i += ST) pre[i] = expf(sc[idx[i]] - lse);
     __syncthreads();
     // inclusive cumsum = exclusive scan + own value; count how many are < mass
     block_exclusive_scan(pre, cum, V, sh, tid);
     int cnt = 0;
-    for (int i = tid; i < V; i += 256) cnt += (cum[i] + pre[i] < p.typical_mass) ? 1 : 0;
+    for (int i = tid; i < V; i += ST) cnt += (cum[i] + pre[i] < p.typical_mass) ? 1 : 0;
     float cntf = block_reduce_sum((float)cnt, sh, tid);
     int last = (int)(cntf + 0.5f);
     last = last < 0 ? 0 : (last > V - 1 ? V - 1 : last);
     const float thr = -key[last];                         // shifted score at the cut
-    for (int i = tid; i < V; i += 256)
+    for (int i = tid; i < V; i += ST)
       if (-key[i] > thr) sc[idx[i]] = NEG_INF;
     __syncthreads();
   }
   // 3. temperature
   if (p.do_sample && p.inv_temperature != 1.0f) {   // the warpers (3-5) exist only when sampling, as in HF
-    for (int i = tid; i < V; i += 256) sc[i] *= p.inv_temperature;
+    for (int i = tid; i < V; i += ST) sc[i] *= p.inv_temperature;
     __syncthreads();
   }
   // 4./5. top-k and top-p on one descending sort
   const bool need_sort = p.do_sample && ((p.top_k > 0 && p.top_k < V) || p.top_p < 1.0f);
   if (need_sort) {
-    for (int i = tid; i < n2; i += 256) { key[i] = i < V ? sc[i] : NEG_INF; idx[i] = (uint16_t)i; }
+    for (int i = tid; i < n2; i += ST) { key[i] = i < V ? sc[i] : NEG_INF; idx[i] = (uint16_t)i; }
     __syncthreads();
     bitonic_desc(key, idx, n2, tid);
     if (p.top_k > 0 && p.top_k < V) {
       const float kth = key[p.top_k - 1];
-      for (int i = tid; i < V; i += 256)
+      for (int i = tid; i < V; i += ST)
         if (key[i] < kth) { sc[idx[i]] = NEG_INF; key[i] = NEG_INF; }
       __syncthreads();
     }
     if (p.top_p < 1.0f) {
       const float mx = key[0];
       float se = 0.f;
-      for (int i = tid; i < V; i += 256) se += expf(key[i] - mx);
+      for (int i = tid; i < V; i += ST) se += expf(key[i] - mx);
       se = block_reduce_sum(se, sh, tid);
-      for (int i = tid; i < V; i += 256) pre[i] = expf(key[i] - mx) / se;      // probabilities, descending
+      for (int i = tid; i < V; i += ST) pre[i] = expf(key[i] - mx) / se;      // probabilities, descending
       __syncthreads();
       block_exclusive_scan(pre, cum, V, sh, tid);                              // cum[r] = mass of the ranks before r
       // TopPLogitsWarper sorts ascending: cumulative mass up to and including rank r from the small end is 1 - cum[r];
       // remove while that is <= 1 - top_p, never the best one
-      for (int r = tid; r < V; r += 256)
+      for (int r = tid; r < V; r += ST)
         if (r > 0 && (1.0f - cum[r]) <= (1.0f - p.top_p)) sc[idx[r]] = NEG_INF;
       __syncthreads();
     }
   }
   // 6. softmax over the survivors and the draw
   float mx = NEG_INF;
-  for (int i = tid; i < V; i += 256) mx = fmaxf(mx, sc[i]);
+  for (int i = tid; i < V; i += ST) mx = fmaxf(mx, sc[i]);
   mx = block_reduce_max(mx, sh, tid);
   int token;
   if (!p.do_sample) {
     int best = V;
-    for (int i = tid; i < V; i += 256)
+    for (int i = tid; i < V; i += ST)
       if (sc[i] == mx) { best = i; break; }
     __syncthreads();
     if (tid == 0) sh_i[0] = V;
@@ -323,10 +464,10 @@ __global__ __launch_bounds__(256) void sample_logits_kernel(SampleParams p) {
     __syncthreads();
     token = sh_i[0];
     if (p.probs_out)
-      for (int i = tid; i < V; i += 256) p.probs_out[(int64_t)m * V + i] = sc[i];     // greedy: the processed scores
+      for (int i = tid; i < V; i += ST) p.probs_out[(int64_t)m * V + i] = sc[i];     // greedy: the processed scores
   } else {
     float se = 0.f;
-    for (int i = tid; i < V; i += 256) { const float e = expf(sc[i] - mx); key[i] = e; se += e; }
+    for (int i = tid; i < V; i += ST) { const float e = expf(sc[i] - mx); key[i] = e; se += e; }
     se = block_reduce_sum(se, sh, tid);
     block_exclusive_scan(key, pre, V, sh, tid);
     const uint32_t r = hash32((uint32_t)m * 0x9E3779B1u + (uint32_t)step, p.seed_lo, p.seed_hi);
@@ -334,7 +475,7 @@ __global__ __launch_bounds__(256) void sample_logits_kernel(SampleParams p) {
     const float target = u * se;
     // first token id whose inclusive cumulative weight exceeds the target
     int best = V;
-    for (int i = tid; i < V; i += 256)
+    for (int i = tid; i < V; i += ST)
       if (key[i] > 0.f && pre[i] + key[i] > target) { best = i; break; }
     if (tid == 0) sh_i[0] = V;
     __syncthreads();
@@ -343,7 +484,7 @@ __global__ __launch_bounds__(256) void sample_logits_kernel(SampleParams p) {
     token = sh_i[0];
     if (token >= V) {   // rounding at the very top of the CDF: take the last survivor
       int lastv = -1;
-      for (int i = tid; i < V; i += 256)
+      for (int i = tid; i < V; i += ST)
         if (key[i] > 0.f) lastv = max(lastv, i);
       if (tid == 0) sh_i[1] = -1;
       __syncthreads();
@@ -352,7 +493,7 @@ __global__ __launch_bounds__(256) void sample_logits_kernel(SampleParams p) {
       token = sh_i[1];
     }
     if (p.probs_out)
-      for (int i = tid; i < V; i += 256) p.probs_out[(int64_t)m * V + i] = key[i] / se;
+      for (int i = tid; i < V; i += ST) p.probs_out[(int64_t)m * V + i] = key[i] / se;
     if (p.u_out && tid == 0) p.u_out[m] = u;
   }
   // 7. eos / pad bookkeeping (GenerationMixin._sample: finished rows emit pad_token_id)
@@ -405,12 +546,39 @@ extern "C" int ttts_attn_decode_bf16(const void* qkv, void* k_cache, void* v_cac
   const float sl2 = scale * 1.4426950408889634f;
   dim3 grid((unsigned)H, (unsigned)M);
   switch (head_dim) {
-    case 32: attn_decode_kernel<32><<<grid, 256, 0, as_stream(stream)>>>(static_cast<const bf16*>(qkv), static_cast<bf16*>(k_cache), static_cast<bf16*>(v_cache), ctr, static_cast<bf16*>(out), H, S_max, sl2); break;
-    case 64: attn_decode_kernel<64><<<grid, 256, 0, as_stream(stream)>>>(static_cast<const bf16*>(qkv), static_cast<bf16*>(k_cache), static_cast<bf16*>(v_cache), ctr, static_cast<bf16*>(out), H, S_max, sl2); break;
-    case 128: attn_decode_kernel<128><<<grid, 256, 0, as_stream(stream)>>>(static_cast<const bf16*>(qkv), static_cast<bf16*>(k_cache), static_cast<bf16*>(v_cache), ctr, static_cast<bf16*>(out), H, S_max, sl2); break;
+    case 32: attn_decode_kernel<32><<<grid, AW * 64, 0, as_stream(stream)>>>(static_cast<const bf16*>(qkv), static_cast<bf16*>(k_cache), static_cast<bf16*>(v_cache), ctr, static_cast<bf16*>(out), H, S_max, sl2); break;
+    case 64: attn_decode_kernel<64><<<grid, AW * 64, 0, as_stream(stream)>>>(static_cast<const bf16*>(qkv), static_cast<bf16*>(k_cache), static_cast<bf16*>(v_cache), ctr, static_cast<bf16*>(out), H, S_max, sl2); break;
+    case 128: attn_decode_kernel<128><<<grid, AW * 64, 0, as_stream(stream)>>>(static_cast<const bf16*>(qkv), static_cast<bf16*>(k_cache), static_cast<bf16*>(v_cache), ctr, static_cast<bf16*>(out), H, S_max, sl2); break;
     default: return fail(TTTS_EUNSUPPORTED, "attn_decode: head_dim %d (32, 64, 128)", head_dim);
   }
   return check_launch("attn_decode");
+}
+
+extern "C" int ttts_linear_decode_bf16(const void* x, int64_t ldx, int32_t x_is_f32, const float* ln1_gamma, const float* ln1_beta,
+                                       const float* ln2_gamma, const float* ln2_beta, const void* W, int64_t ldw,
+                                       const float* bias, void* out, int64_t ldc, const float* resid, int32_t M, int32_t N,
+                                       int32_t K, int32_t epilogue, void* stream) {
+  TTTS_REQUIRE(x && W && out && M > 0 && M <= 16 && N > 0, "linear_decode: bad arguments (1 <= M <= 16)");
+  TTTS_REQUIRE(K >= 32 && K % 32 == 0 && K <= 4096, "linear_decode: K must be a multiple of 32, <= 4096");
+  TTTS_REQUIRE(ldw % 8 == 0 && aligned16(W) && aligned16(x) && ldx % (x_is_f32 ? 4 : 8) == 0, "linear_decode: alignment");
+  TTTS_REQUIRE(x_is_f32 || !ln1_gamma, "linear_decode: LayerNorm fusion needs the fp32 rows");
+  TTTS_REQUIRE((!ln1_gamma || ln1_beta) && (!ln2_gamma || (ln2_beta && ln1_gamma)), "linear_decode: bad LayerNorm arguments");
+  TTTS_REQUIRE(epilogue == TTTS_EPI_STORE_BF16 || epilogue == TTTS_EPI_GELU_BF16 || epilogue == TTTS_EPI_RESID_ADD_F32 ||
+               epilogue == TTTS_EPI_STORE_F32, "linear_decode: unsupported epilogue %d", epilogue);
+  TTTS_REQUIRE(epilogue != TTTS_EPI_RESID_ADD_F32 || resid, "linear_decode: RESID_ADD needs resid");
+  LinearDecodeParams p;
+  p.x = x; p.ldx = ldx; p.x_is_f32 = x_is_f32; p.g1 = ln1_gamma; p.b1 = ln1_beta; p.g2 = ln2_gamma; p.b2 = ln2_beta;
+  p.W = static_cast<const bf16*>(W); p.ldw = ldw; p.bias = bias; p.out = out; p.ldc = ldc; p.resid = resid;
+  p.M = M; p.N = N; p.K = K; p.epi = epilogue; p.eps = 1e-5f;
+  const size_t smem = (size_t)16 * (K + 8) * sizeof(bf16) + (size_t)LW * 16 * 16 * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return fail(TTTS_EHIP, "linear_decode: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  linear_decode_kernel<<<(int)cdiv(N, 16), LW * 64, smem, as_stream(stream)>>>(p);
+  return check_launch("linear_decode");
 }
 
 extern "C" int ttts_sample_logits_f32(const float* logits, int64_t ldl, int32_t row_div, int32_t M, int32_t V, int64_t* history,
@@ -430,7 +598,7 @@ extern "C" int ttts_sample_logits_f32(const float* logits, int64_t ldl, int32_t 
   p.top_p = top_p; p.top_k = top_k; p.do_sample = do_sample; p.eos = eos_token; p.pad = pad_token;
   p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
   p.probs_out = probs_out; p.u_out = u_out;
-  sample_logits_kernel<<<M, 256, 0, as_stream(stream)>>>(p);
+  sample_logits_kernel<<<M, ST, 0, as_stream(stream)>>>(p);
   return check_launch("sample_logits");
 }
 

@@ -6,7 +6,8 @@ GPT2InferenceModel.forward (:109-184) driven by transformers' sample loop, re-de
             final-norm state gives the first logits.
   step    : embed(token, position) -> per layer: LN -> c_attn GEMM -> attn_decode (append K / V, attend) -> c_proj GEMM (+resid)
             -> LN -> c_fc GEMM (+GELU) -> c_proj GEMM (+resid) -> ln_f -> final_norm -> mel_head GEMM (fp32 logits)
-            -> sample_logits -> decode_advance.  All positions are device-side counters: the 48 launches are captured once
+            -> sample_logits -> decode_advance (for <= 16 sequences the LayerNorms are fused into `linear_decode`, 34 launches).
+            All positions are device-side counters: the launches are captured once
             and replayed per token; the host only looks at the `unfinished` counter every `poll` tokens.
 
 Semantics follow the reference's default cache-less path (post_init_gpt2_config(kv_cache=False), api_zh.py:52): the token
@@ -69,24 +70,43 @@ class GptDecoder:
         st = b["stats"]
         x = b["x"]
         ops.decode_embed(b["tokens"], P("mel_embedding.weight"), P("mel_pos_embedding.emb.weight"), b["ctr"], -Tt, x[0])
+        M = x[0].shape[0]
+        skinny = M <= 16        # M <= 16 rows: LayerNorm-fused 16-column MFMA kernel; more rows: the training path's tile GEMM
         cur = 0
         for i in range(L):
             pre = "gpt.h.%d." % i
             x0, x1, x2 = x[cur], x[(cur + 1) % 3], x[(cur + 2) % 3]
-            ops.layernorm_fwd(x0, P(pre + "ln_1.weight"), P(pre + "ln_1.bias"), b["ln"], st[0], st[1])
-            ops.gemm_nt(b["ln"], e.wT[pre + "attn.c_attn.weight"], b["qkv"], P(pre + "attn.c_attn.bias"))
+            if skinny:
+                ops.linear_decode(x0, e.wT[pre + "attn.c_attn.weight"], b["qkv"], P(pre + "attn.c_attn.bias"),
+                                  ln1=(P(pre + "ln_1.weight"), P(pre + "ln_1.bias")))
+            else:
+                ops.layernorm_fwd(x0, P(pre + "ln_1.weight"), P(pre + "ln_1.bias"), b["ln"], st[0], st[1])
+                ops.gemm_nt(b["ln"], e.wT[pre + "attn.c_attn.weight"], b["qkv"], P(pre + "attn.c_attn.bias"))
             ops.attn_decode(b["qkv"], b["kc"][i], b["vc"][i], b["ctr"], b["att"], dh ** -0.5)
-            ops.gemm_nt(b["att"], e.wT[pre + "attn.c_proj.weight"], x1, P(pre + "attn.c_proj.bias"),
-                        epilogue=EPI_RESID_ADD_F32, resid_in=x0)
-            ops.layernorm_fwd(x1, P(pre + "ln_2.weight"), P(pre + "ln_2.bias"), b["ln"], st[0], st[1])
-            ops.gemm_nt(b["ln"], e.wT[pre + "mlp.c_fc.weight"], b["fc_act"], P(pre + "mlp.c_fc.bias"), aux=b["fc_pre"],
-                        epilogue=EPI_GELU_BF16)
-            ops.gemm_nt(b["fc_act"], e.wT[pre + "mlp.c_proj.weight"], x2, P(pre + "mlp.c_proj.bias"),
-                        epilogue=EPI_RESID_ADD_F32, resid_in=x1)
+            if skinny:
+                ops.linear_decode(b["att"], e.wT[pre + "attn.c_proj.weight"], x1, P(pre + "attn.c_proj.bias"),
+                                  epilogue=EPI_RESID_ADD_F32, resid=x0)
+                ops.linear_decode(x1, e.wT[pre + "mlp.c_fc.weight"], b["fc_act"], P(pre + "mlp.c_fc.bias"),
+                                  epilogue=EPI_GELU_BF16, ln1=(P(pre + "ln_2.weight"), P(pre + "ln_2.bias")))
+                ops.linear_decode(b["fc_act"], e.wT[pre + "mlp.c_proj.weight"], x2, P(pre + "mlp.c_proj.bias"),
+                                  epilogue=EPI_RESID_ADD_F32, resid=x1)
+            else:
+                ops.gemm_nt(b["att"], e.wT[pre + "attn.c_proj.weight"], x1, P(pre + "attn.c_proj.bias"),
+                            epilogue=EPI_RESID_ADD_F32, resid_in=x0)
+                ops.layernorm_fwd(x1, P(pre + "ln_2.weight"), P(pre + "ln_2.bias"), b["ln"], st[0], st[1])
+                ops.gemm_nt(b["ln"], e.wT[pre + "mlp.c_fc.weight"], b["fc_act"], P(pre + "mlp.c_fc.bias"), aux=b["fc_pre"],
+                            epilogue=EPI_GELU_BF16)
+                ops.gemm_nt(b["fc_act"], e.wT[pre + "mlp.c_proj.weight"], x2, P(pre + "mlp.c_proj.bias"),
+                            epilogue=EPI_RESID_ADD_F32, resid_in=x1)
             cur = (cur + 2) % 3
-        ops.layernorm_fwd(x[cur], P("gpt.ln_f.weight"), P("gpt.ln_f.bias"), b["lnf"], st[0], st[1])
-        ops.layernorm_fwd(b["lnf"], P("final_norm.weight"), P("final_norm.bias"), b["enc"], st[0], st[1])
-        ops.gemm_nt(b["enc"], e.w("mel_head.weight"), b["logits"], P("mel_head.bias"), n=e.nm, epilogue=EPI_STORE_F32)
+        if skinny:
+            ops.linear_decode(x[cur], e.w("mel_head.weight"), b["logits"], P("mel_head.bias"), epilogue=EPI_STORE_F32,
+                              ln1=(P("gpt.ln_f.weight"), P("gpt.ln_f.bias")), ln2=(P("final_norm.weight"), P("final_norm.bias")),
+                              n=e.nm)
+        else:
+            ops.layernorm_fwd(x[cur], P("gpt.ln_f.weight"), P("gpt.ln_f.bias"), b["lnf"], st[0], st[1])
+            ops.layernorm_fwd(b["lnf"], P("final_norm.weight"), P("final_norm.bias"), b["enc"], st[0], st[1])
+            ops.gemm_nt(b["enc"], e.w("mel_head.weight"), b["logits"], P("mel_head.bias"), n=e.nm, epilogue=EPI_STORE_F32)
 
     def _sample(self, logits, row_div, hist_base, s, probs_out=None):
         b, c = self.b, self.eng.c

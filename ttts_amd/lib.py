@@ -110,6 +110,7 @@ SIGNATURES = {
     "ttts_mel_log_fwd_f32": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "ttts_mel_log_bwd_f32": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "ttts_stft_mag_bwd_f32": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "ttts_linear_decode_bf16": (_I32, [_P, _I64, _I32, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _I32, _P]),
     "ttts_decode_embed_f32": (_I32, [_P, _P, _P, _P, _I32, _P, _I32, _I32, _I32, _I32, _P]),
     "ttts_kv_cache_fill_bf16": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "ttts_attn_decode_bf16": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _P]),

@@ -291,6 +291,26 @@ def decode_embed(tokens, emb, pos, ctr, pos_offset, x):
     return x
 
 
+def linear_decode(x, w, out, bias=None, epilogue=EPI_STORE_BF16, resid=None, ln1=None, ln2=None, n=None):
+    """out[M, N] = epi(LN2(LN1(x)) @ w[N, K]^T + bias) for M <= 16 rows (decode steps).  x bf16, or f32 (+ optional
+    (gamma, beta) pairs ln1 / ln2).  Rounding points as gemm_nt."""
+    _req(w, torch.bfloat16, "w"); _req(bias, torch.float32, "bias"); _req(resid, torch.float32, "resid")
+    if x.dtype not in (torch.float32, torch.bfloat16) or not x.is_cuda:
+        raise TttsError("linear_decode: x must be a bf16 or f32 GPU tensor")
+    M, K = x.shape
+    N = w.shape[0] if n is None else n
+    want = torch.float32 if epilogue in (EPI_RESID_ADD_F32, EPI_STORE_F32) else torch.bfloat16
+    _req(out, want, "out")
+    if resid is not None and (resid.shape != out.shape or resid.stride() != out.stride()):
+        raise TttsError("linear_decode: resid must have the layout of out")
+    g1, b1 = ln1 if ln1 is not None else (None, None)
+    g2, b2 = ln2 if ln2 is not None else (None, None)
+    check(_l.get().ttts_linear_decode_bf16(_p(x), _ld(x), int(x.dtype == torch.float32), _p(g1), _p(b1), _p(g2), _p(b2), _p(w),
+                                           _ld(w), _p(bias), _p(out), _ld(out), _p(resid), M, N, K, epilogue, _stream()),
+          "linear_decode")
+    return out
+
+
 def kv_cache_fill(qkv, k_cache, v_cache, B, S, H, dh, rep=1):
     """qkv bf16 [B*S, 3*H*dh] -> k_cache / v_cache bf16 [B*rep, H, S_max, dh] rows 0..S-1."""
     _req(qkv, torch.bfloat16, "qkv"); _req(k_cache, torch.bfloat16, "k_cache"); _req(v_cache, torch.bfloat16, "v_cache")
