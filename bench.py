@@ -154,8 +154,9 @@ def main():
     def step():
         toks = prepare_tokens(eng.c, text_d, tl, mel_d, wl)   # token plumbing (lengths are host tensors: no sync)
         if args.mode != "eager":
+            # N > 1: the gradient all-reduce of the upper layers + heads overlaps the backward of the lower layers
             eng.train_step(toks, w_text, w_mel, capture=True, lr=tr["lr"],
-                           exchange=(lambda: dp.allreduce_grads_(eng.grads)) if world > 1 else None)
+                           exchange_range=(lambda lo, hi: dp.allreduce_range_(eng.grads, lo, hi)) if world > 1 else None)
             return
         eng.set_tokens(*toks)
         eng.forward()
@@ -229,7 +230,7 @@ def main():
                "config": {"workload": "VALL-E GPT train step (ttts/gpt/config.json model: 6 layers, d512, 8 heads, 21.46 M "
                                       "params), batch 8 per GPU x (128 text + 1024 audio tokens) = S 1156, fwd+bwd+clip+AdamW, "
                                       "dropout %.1f, %s" % (dropout, "eager launches" if not graphed else ("hipGraph replay" if world == 1 else
-                                                                       "hipGraph replay around one RCCL all-reduce")),
+                                                                       "hipGraph replay, RCCL all-reduce of the upper layers overlapped with the lower layers' backward")),
                           "global_batch": world * B_PER_GPU, "seq_len": TEXT_LEN + 2 + MEL_LEN + 2, "parallelism": "dp%d" % world,
                           "mode": args.mode},
                "final_loss_mel": round(lm, 4), "roofline": roof}

@@ -232,3 +232,16 @@ def test_bench_two_ranks_sharing_the_gpu(tmp_path):
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16 and out["value"] > 0 and out["scaling"] == "weak"
+
+
+def test_ranged_gradient_exchange_two_ranks_sharing_the_gpu():
+    """The overlapped exchange (backward in two graph sections, finished gradient ranges all-reduced in between) is
+    bit-identical to one whole-arena all-reduce and keeps the replicas identical (tools/dp_consistency.py, gloo, 2 ranks)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, TTTS_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(29900 + os.getpid() % 90),
+                        os.path.join(ROOT, "tools", "dp_consistency.py")], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "rank0-consistent" in r.stdout and "rank1-consistent" in r.stdout

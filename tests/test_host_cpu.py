@@ -206,6 +206,13 @@ grads = local * dp.loss_scale()
 dp.allreduce_grads_(grads)
 want = sum(torch.randn(1000, generator=torch.Generator().manual_seed(100 + r)) for r in range(2)) / 2
 assert torch.allclose(grads, want, atol=1e-6)
+# ranged asynchronous exchange (the overlapped schedule of GptEngine.train_step): same sums, range by range
+g2 = local * dp.loss_scale()
+handles = [dp.allreduce_range_(g2, lo, hi) for lo, hi in ((400, 1000), (0, 400), (5, 5))]
+assert handles[2] is None
+for h in handles[:2]:
+    h.wait()
+assert torch.equal(g2, grads)
 assert abs(dp.max_over_ranks(float(rank)) - 1.0) < 1e-12
 assert shard_indices(7, rank, world) == list(range(7))[rank::2]
 dp.barrier()

@@ -274,8 +274,11 @@ class GptEngine:
         ops.ce_fwd(b["logits_m"], b["mel_tar"], b["rows_m"][0], b["rows_m"][1], b["losses"][1:2], self.nm)
 
     # ---- backward ----------------------------------------------------------------------------------------------
-    def backward(self, w_text=0.01, w_mel=1.0, g_text_dev=None, g_mel_dev=None):
-        """Accumulates d(w_text*loss_text + w_mel*loss_mel) into self.grads (optionally scaled by device scalars)."""
+    def backward(self, w_text=0.01, w_mel=1.0, g_text_dev=None, g_mel_dev=None, part=None, split=None):
+        """Accumulates d(w_text*loss_text + w_mel*loss_mel) into self.grads (optionally scaled by device scalars).
+        part / split: run only a section of the chain so that a data-parallel exchange of the finished gradients can overlap
+        the rest -- part 0 = heads, final norms and layers L-1 .. split; part 1 = layers split-1 .. 0 and the embeddings
+        (all state between the two lives in the activation buffers)."""
         c, b = self.c, self.b
         B, Tt, Tm = self._bufs_key
         D, L, H = c["model_dim"], c["layers"], c["heads"]
@@ -288,7 +291,9 @@ class GptEngine:
         # fill the CUs that chain leaves idle (292-tile GEMMs on 256 CUs, causal tails, store phases).  Events order the
         # reuse of the scratch buffers (dres_bf, d_fc, dqkv) between the two streams; both streams are captured in the graph.
         main = torch.cuda.current_stream()
-        side = self._side_stream() if self.overlap_dw else main
+        side = self._side_stream() if (self.overlap_dw and part is None) else main
+        lo_layer = 0 if part in (None, 1) else split
+        hi_layer = L if part in (None, 0) else split
 
         def fork():                      # side waits for everything issued on main so far
             if side is not main:
@@ -305,6 +310,26 @@ class GptEngine:
             if ev is not None:
                 main.wait_event(ev)
 
+        if part in (None, 0):
+            self._backward_head(w_text, w_mel, g_text_dev, g_mel_dev, side, fork)
+        ev_fc = ev_qkv = None            # side-stream reads of d_fc / dqkv by the previous layer
+        for i in reversed(range(lo_layer, hi_layer)):
+            ev_fc, ev_qkv = self._backward_layer(i, side, fork, done, wait, ev_fc, ev_qkv)
+        if part in (None, 1):
+            ops.embed_bwd(b["text_inp"], b["mel_inp"], b["dres"], G("text_embedding.weight"),
+                          G("text_pos_embedding.emb.weight"), G("mel_embedding.weight"), G("mel_pos_embedding.emb.weight"),
+                          p, self._seed(1))
+        if side is not main:
+            main.wait_stream(side)       # join: the optimizer / all-reduce needs every dW
+
+    def _backward_head(self, w_text, w_mel, g_text_dev, g_mel_dev, side, fork):
+        c, b = self.c, self.b
+        B, Tt, Tm = self._bufs_key
+        L = c["layers"]
+        S = Tt + Tm
+        p = self._p()
+        P = lambda k: self.view(self.params, k)  # noqa: E731
+        G = lambda k: self.view(self.grads, k)   # noqa: E731
         ops.ce_bwd(b["logits_t"], b["text_tar"], b["rows_t"][1], b["dlog_t"], self.nt, w_text, g_text_dev)
         ops.ce_bwd(b["logits_m"], b["mel_tar"], b["rows_m"][1], b["dlog_m"], self.nm, w_mel, g_mel_dev)
         enc_t, enc_m = b["enc"][:B * Tt], b["enc"][B * Tt:]
@@ -322,55 +347,58 @@ class GptEngine:
         ops.layernorm_bwd(b["d_tmp"], b["xs"][2 * L], P("gpt.ln_f.weight"), fs[0], fs[1], None, b["dres"], b["dres_bf"],
                           G("gpt.ln_f.weight"), G("gpt.ln_f.bias"), b["ln_ws"], dropout_p=p,
                           seed=self._seed(16 * (L - 1) + 4), dcolsum=G("gpt.h.%d.mlp.c_proj.bias" % (L - 1)))
-        ev_fc = ev_qkv = None            # side-stream reads of d_fc / dqkv by the previous layer
-        for i in reversed(range(L)):
-            pre = "gpt.h.%d." % i
-            st = b["stats"][i]
-            x0, x1 = b["xs"][2 * i], b["xs"][2 * i + 1]
-            dy = b["dres_bf"]                                  # gradient entering mlp.c_proj (resid dropout applied)
-            fork()
-            with torch.cuda.stream(side):
-                ops.gemm_tn_accum(self._padded(b["fc_act"][i]), self._padded(dy), G(pre + "mlp.c_proj.weight"), workspace=b["tn_ws"])
-            ev_dy = done()
-            wait(ev_fc)                                        # the previous layer's dW c_fc has consumed d_fc
-            ops.gemm_nt(dy, self.w(pre + "mlp.c_proj.weight"), b["d_fc"], aux=b["fc_pre"][i], epilogue=EPI_DGELU_BF16)
-            fork()
-            with torch.cuda.stream(side):
-                ops.gemm_tn_accum(self._padded(b["ln2"][i]), self._padded(b["d_fc"]), G(pre + "mlp.c_fc.weight"), workspace=b["tn_ws"])
-                ops.colsum_accum(b["d_fc"], G(pre + "mlp.c_fc.bias"))
-            ev_fc = done()
-            ops.gemm_nt(b["d_fc"], self.w(pre + "mlp.c_fc.weight"), b["d_ln"])
-            wait(ev_dy)                                        # dres_bf is rewritten by the LayerNorm backward below
-            ops.layernorm_bwd(b["d_ln"], x1, P(pre + "ln_2.weight"), st[2], st[3], b["dres"], b["dres"], b["dres_bf"],
-                              G(pre + "ln_2.weight"), G(pre + "ln_2.bias"), b["ln_ws"], dropout_p=p,
-                              seed=self._seed(16 * i + 3), dcolsum=G(pre + "attn.c_proj.bias"))
-            dy = b["dres_bf"]                                  # gradient entering attn.c_proj
-            fork()
-            with torch.cuda.stream(side):
-                ops.gemm_tn_accum(self._padded(b["att"][i]), self._padded(dy), G(pre + "attn.c_proj.weight"), workspace=b["tn_ws"])
-            ev_dy = done()
-            ops.gemm_nt(dy, self.w(pre + "attn.c_proj.weight"), b["d_att"])
-            qkv, dqkv = b["qkv"][i], b["dqkv"]
-            wait(ev_qkv)                                       # the previous layer's dW c_attn has consumed dqkv
-            ops.attn_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], b["att"][i], b["d_att"], b["lse"][i], dqkv, dqkv[:, D:],
-                         dqkv[:, 2 * D:], b["delta"], B, H, S, dh, (S * 3 * D, 3 * D), (S * D, D), dh ** -0.5, p,
-                         self._seed(16 * i + 2))
-            fork()
-            with torch.cuda.stream(side):
-                ops.gemm_tn_accum(self._padded(b["ln1"][i]), self._padded(dqkv), G(pre + "attn.c_attn.weight"), workspace=b["tn_ws"])
-                ops.colsum_accum(dqkv, G(pre + "attn.c_attn.bias"))
-            ev_qkv = done()
-            ops.gemm_nt(dqkv, self.w(pre + "attn.c_attn.weight"), b["d_ln"])
-            wait(ev_dy)
-            ops.layernorm_bwd(b["d_ln"], x0, P(pre + "ln_1.weight"), st[0], st[1], b["dres"], b["dres"],
-                              b["dres_bf"] if i > 0 else None, G(pre + "ln_1.weight"), G(pre + "ln_1.bias"),
-                              b["ln_ws"], dropout_p=p if i > 0 else 0.0, seed=self._seed(16 * (i - 1) + 4),
-                              dcolsum=G("gpt.h.%d.mlp.c_proj.bias" % (i - 1)) if i > 0 else None)
-        ops.embed_bwd(b["text_inp"], b["mel_inp"], b["dres"], G("text_embedding.weight"),
-                      G("text_pos_embedding.emb.weight"), G("mel_embedding.weight"), G("mel_pos_embedding.emb.weight"),
-                      p, self._seed(1))
-        if side is not main:
-            main.wait_stream(side)       # join: the optimizer / all-reduce needs every dW
+
+    def _backward_layer(self, i, side, fork, done, wait, ev_fc, ev_qkv):
+        c, b = self.c, self.b
+        B, Tt, Tm = self._bufs_key
+        D, H = c["model_dim"], c["heads"]
+        S, dh = Tt + Tm, D // H
+        p = self._p()
+        P = lambda k: self.view(self.params, k)  # noqa: E731
+        G = lambda k: self.view(self.grads, k)   # noqa: E731
+        pre = "gpt.h.%d." % i
+        st = b["stats"][i]
+        x0, x1 = b["xs"][2 * i], b["xs"][2 * i + 1]
+        dy = b["dres_bf"]                                  # gradient entering mlp.c_proj (resid dropout applied)
+        fork()
+        with torch.cuda.stream(side):
+            ops.gemm_tn_accum(self._padded(b["fc_act"][i]), self._padded(dy), G(pre + "mlp.c_proj.weight"), workspace=b["tn_ws"])
+        ev_dy = done()
+        wait(ev_fc)                                        # the previous layer's dW c_fc has consumed d_fc
+        ops.gemm_nt(dy, self.w(pre + "mlp.c_proj.weight"), b["d_fc"], aux=b["fc_pre"][i], epilogue=EPI_DGELU_BF16)
+        fork()
+        with torch.cuda.stream(side):
+            ops.gemm_tn_accum(self._padded(b["ln2"][i]), self._padded(b["d_fc"]), G(pre + "mlp.c_fc.weight"), workspace=b["tn_ws"])
+            ops.colsum_accum(b["d_fc"], G(pre + "mlp.c_fc.bias"))
+        ev_fc = done()
+        ops.gemm_nt(b["d_fc"], self.w(pre + "mlp.c_fc.weight"), b["d_ln"])
+        wait(ev_dy)                                        # dres_bf is rewritten by the LayerNorm backward below
+        ops.layernorm_bwd(b["d_ln"], x1, P(pre + "ln_2.weight"), st[2], st[3], b["dres"], b["dres"], b["dres_bf"],
+                          G(pre + "ln_2.weight"), G(pre + "ln_2.bias"), b["ln_ws"], dropout_p=p,
+                          seed=self._seed(16 * i + 3), dcolsum=G(pre + "attn.c_proj.bias"))
+        dy = b["dres_bf"]                                  # gradient entering attn.c_proj
+        fork()
+        with torch.cuda.stream(side):
+            ops.gemm_tn_accum(self._padded(b["att"][i]), self._padded(dy), G(pre + "attn.c_proj.weight"), workspace=b["tn_ws"])
+        ev_dy = done()
+        ops.gemm_nt(dy, self.w(pre + "attn.c_proj.weight"), b["d_att"])
+        qkv, dqkv = b["qkv"][i], b["dqkv"]
+        wait(ev_qkv)                                       # the previous layer's dW c_attn has consumed dqkv
+        ops.attn_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], b["att"][i], b["d_att"], b["lse"][i], dqkv, dqkv[:, D:],
+                     dqkv[:, 2 * D:], b["delta"], B, H, S, dh, (S * 3 * D, 3 * D), (S * D, D), dh ** -0.5, p,
+                     self._seed(16 * i + 2))
+        fork()
+        with torch.cuda.stream(side):
+            ops.gemm_tn_accum(self._padded(b["ln1"][i]), self._padded(dqkv), G(pre + "attn.c_attn.weight"), workspace=b["tn_ws"])
+            ops.colsum_accum(dqkv, G(pre + "attn.c_attn.bias"))
+        ev_qkv = done()
+        ops.gemm_nt(dqkv, self.w(pre + "attn.c_attn.weight"), b["d_ln"])
+        wait(ev_dy)
+        ops.layernorm_bwd(b["d_ln"], x0, P(pre + "ln_1.weight"), st[0], st[1], b["dres"], b["dres"],
+                          b["dres_bf"] if i > 0 else None, G(pre + "ln_1.weight"), G(pre + "ln_1.bias"),
+                          b["ln_ws"], dropout_p=p if i > 0 else 0.0, seed=self._seed(16 * (i - 1) + 4),
+                          dcolsum=G("gpt.h.%d.mlp.c_proj.bias" % (i - 1)) if i > 0 else None)
+        return ev_fc, ev_qkv
 
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
@@ -392,63 +420,105 @@ class GptEngine:
         self.grads.zero_()
 
     # ---- whole step (optionally replayed from one hipGraph) ---------------------------------------------------
-    def train_step(self, tokens, w_text=0.01, w_mel=1.0, capture=False, exchange=None, **opt):
+    def grad_exchange_plan(self, split=None):
+        """Element ranges of the flat gradient arena that are final after backward part 0 / part 1 (see `backward`):
+        ([(lo, hi), ...] ready after the heads + layers L-1 .. split, [(lo, hi), ...] ready at the end).  The arena is in
+        state-dict order: embeddings, h.0 .. h.L-1, ln_f, position tables, final_norm, heads."""
+        L = self.c["layers"]
+        split = L // 2 if split is None else split
+        o = self.offsets
+        h_split = o["gpt.h.%d.ln_1.weight" % split]
+        pos0, fin0 = o["mel_pos_embedding.emb.weight"], o["final_norm.weight"]
+        return split, [(h_split, pos0), (fin0, self.n_arena)], [(0, h_split), (pos0, fin0)]
+
+    def train_step(self, tokens, w_text=0.01, w_mel=1.0, capture=False, exchange=None, exchange_range=None, **opt):
         """tokens = (text_inp, text_tar, mel_inp, mel_tar) int64 tensors (see model.prepare_tokens).
         exchange: optional callable run between backward and the optimizer (the data-parallel gradient all-reduce).
-        capture=True replays the step from hipGraphs: one graph without `exchange`, two (forward+backward | optimizer)
-        around the collective with it.  Returns nothing: losses stay on the device (no host sync in the hot loop)."""
+        exchange_range: optional callable (lo, hi) -> handle with .wait(): asynchronous all-reduce of grads[lo:hi].  With it
+        the backward runs in two sections and the ranges that are final after the first one (upper layers, heads: 46 % of
+        the bytes) are exchanged while the second section computes (`grad_exchange_plan`).
+        capture=True replays the step from hipGraphs: one graph without an exchange, two (forward+backward | optimizer)
+        around `exchange`, three (forward + backward part 0 | backward part 1 | optimizer) around `exchange_range`.
+        Returns nothing: losses stay on the device (no host sync in the hot loop)."""
         self.set_tokens(*tokens)
-        if not capture:
-            self.forward()
-            self.backward(w_text, w_mel)
+        mode = "range" if exchange_range is not None else ("whole" if exchange is not None else "none")
+        graphs = None
+        if capture:
+            key = (self._bufs_key, w_text, w_mel, tuple(sorted(opt.items())), mode)
+            if self._graph is None or self._graph_key != key:
+                self._graph, self._graph_key = self._capture_step(w_text, w_mel, mode, opt), key
+            graphs = self._graph if self._graph[0] is not None else None   # None: capture was refused, run launch by launch
+        if mode == "range":
+            split, first, second = self.grad_exchange_plan()
+            if graphs:
+                graphs[0].replay()
+            else:
+                self.forward()
+                self.backward(w_text, w_mel, part=0, split=split)
+            pending = [exchange_range(lo, hi) for lo, hi in first]
+            if graphs:
+                graphs[1].replay()
+            else:
+                self.backward(w_text, w_mel, part=1, split=split)
+            pending += [exchange_range(lo, hi) for lo, hi in second]
+            for h in pending:
+                if h is not None:
+                    h.wait()
+            if graphs:
+                graphs[2].replay()
+            else:
+                self.optimizer_step(**opt)
+        else:
+            if graphs:
+                graphs[0].replay()   # capture only records; every step (the first included) is a replay
+            else:
+                self.forward()
+                self.backward(w_text, w_mel)
             if exchange is not None:
                 exchange()
-            self.optimizer_step(**opt)
-        else:
-            key = (self._bufs_key, w_text, w_mel, tuple(sorted(opt.items())), exchange is not None)
-            if self._graph is None or self._graph_key != key:
-                self._graph, self._graph_key = self._capture_step(w_text, w_mel, exchange is not None, opt), key
-            ga, gb = self._graph
-            if ga is None:           # capture was refused (see _capture_step): launch by launch, same kernels
-                self.forward()
-                self.backward(w_text, w_mel)
-                if exchange is not None:
-                    exchange()
-                self.optimizer_step(**opt)
+            if graphs:
+                if graphs[1] is not None:
+                    graphs[1].replay()
             else:
-                ga.replay()   # capture only records; every step (the first included) is a replay
-                if gb is not None:
-                    exchange()
-                    gb.replay()
+                self.optimizer_step(**opt)
         self.step_count += 1
 
-    def _capture_step(self, w_text, w_mel, with_exchange, opt):
-        """Record the step into hipGraphs: (forward + backward + optimizer, None) or, around a collective,
-        (forward + backward, optimizer).  With a process group alive its watchdog thread polls events while we record,
-        so that case captures in thread-local mode.  A refused capture is reported once on stderr and the engine keeps
-        running launch by launch -- slower on the host, identical on the device."""
+    def _capture_step(self, w_text, w_mel, mode, opt):
+        """Record the step into hipGraphs: mode "none": (forward + backward + optimizer,); "whole": (forward + backward,
+        optimizer) around one collective; "range": (forward + backward part 0, backward part 1, optimizer).
+        With a process group alive its watchdog thread polls events while we record, so those cases capture in thread-local
+        mode.  A refused capture is reported once on stderr and the engine keeps running launch by launch -- slower on the
+        host, identical on the device."""
         torch.cuda.synchronize()
-        mode = "thread_local" if with_exchange else "global"
+        cmode = "global" if mode == "none" else "thread_local"
+
+        def record(fn):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode=cmode):
+                fn()
+            return g
         try:
-            ga = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga, capture_error_mode=mode):
-                self.forward()
-                self.backward(w_text, w_mel)
-                if not with_exchange:
-                    self.optimizer_step(**opt)
-            gb = None
-            if with_exchange:
-                gb = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gb, capture_error_mode=mode):
-                    self.optimizer_step(**opt)
-            return ga, gb
+            if mode == "none":
+                def whole():
+                    self.forward(); self.backward(w_text, w_mel); self.optimizer_step(**opt)
+                return (record(whole), None)
+            if mode == "whole":
+                def fb():
+                    self.forward(); self.backward(w_text, w_mel)
+                return (record(fb), record(lambda: self.optimizer_step(**opt)))
+            split = self.grad_exchange_plan()[0]
+
+            def fb0():
+                self.forward(); self.backward(w_text, w_mel, part=0, split=split)
+            return (record(fb0), record(lambda: self.backward(w_text, w_mel, part=1, split=split)),
+                    record(lambda: self.optimizer_step(**opt)))
         except RuntimeError as err:
             import sys
             print("ttts_amd: hipGraph capture of the train step failed (%s); running it eagerly" % str(err).splitlines()[0],
                   file=sys.stderr, flush=True)
             torch.cuda.synchronize()
             self.grads.zero_()     # a partially recorded step leaves nothing behind, but be explicit
-            return None, None
+            return (None, None)
 
     def losses(self):
         """(loss_text, loss_mel) as Python floats -- host sync; call it off the hot path."""

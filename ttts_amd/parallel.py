@@ -59,6 +59,12 @@ class FlatDataParallel:
             return None
         return dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
+    def allreduce_range_(self, flat_grads, lo, hi):
+        """Asynchronous SUM all-reduce of flat_grads[lo:hi]; returns a handle with .wait() (None when not distributed)."""
+        if not self.enabled or hi <= lo:
+            return None
+        return dist.all_reduce(flat_grads[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
     def barrier(self):
         if self.enabled:
             dist.barrier(group=self.group)
