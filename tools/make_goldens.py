@@ -609,6 +609,95 @@ def gen_infer():
     np.savez_compressed(os.path.join(OUT, "gpt_infer.npz"), **rec)
 
 
+TINY_DIFF = dict(model_channels=64, num_layers=2, in_channels=20, in_latent_channels=32, out_channels=40, dropout=0, num_heads=4,
+                 layer_drop=0.0, unconditioned_percentage=0.0)
+
+
+def gen_diffusion():
+    """the reference's AA_diffusion (tiny config, deterministic weights) through
+    SpacedDiffusion.training_losses with fixed t / noise (incl. t = 0: decoder-NLL branch), gradients, the surface of the full
+    config, one AttentionBlock and one ResBlock in isolation, and three optimizer steps of the trainer's recipe."""
+    from oracle import diffusion_ref as DR
+    from ttts.diffusion.aa_model import AA_diffusion, DiffusionLayer, ResBlock
+    from ttts.utils.utils import AttentionBlock
+    from ttts.utils.diffusion import SpacedDiffusion, space_timesteps, get_named_beta_schedule
+    import yaml
+    full_cfg = yaml.safe_load(open("/root/reference/ttts/diffusion/config.yaml"))["aa_diffusion"]
+    full = AA_diffusion(**full_cfg)
+    rec = {"cfg": np.array(json.dumps(TINY_DIFF)), "full_cfg": np.array(json.dumps(full_cfg)),
+           "full_surface": np.array(json.dumps([[k, list(v.shape)] for k, v in full.state_dict().items()]))}
+
+    def fill(mod, gain=1.0):
+        with torch.no_grad():
+            for k, p in mod.named_parameters():
+                p.copy_(DR.det_fill(k, p.shape, gain))
+    g = torch.Generator().manual_seed(21)
+    # ---- blocks
+    ab = AttentionBlock(64, 4, relative_pos_embeddings=True); fill(ab)
+    xa = torch.randn(2, 64, 37, generator=g).requires_grad_(True)
+    ya = ab(xa); (ya * torch.linspace(-1, 1, 37)).sum().backward()
+    rec.update({"ab_x": xa.detach().numpy(), "ab_y": ya.detach().numpy(), "ab_dx": xa.grad.numpy(),
+                "ab_dtable": ab.relative_pos_embeddings.relative_attention_bias.weight.grad.numpy(),
+                "ab_dqkv_w": ab.qkv.weight.grad.numpy()})
+    rb = ResBlock(64, 64, 0, dims=1, use_scale_shift_norm=True); fill(rb)
+    xr = torch.randn(2, 64, 29, generator=g).requires_grad_(True); er = torch.randn(2, 64, generator=g).requires_grad_(True)
+    yr = rb(xr, er); (yr * torch.linspace(-1, 1, 29)).sum().backward()
+    rec.update({"rb_x": xr.detach().numpy(), "rb_emb": er.detach().numpy(), "rb_y": yr.detach().numpy(), "rb_dx": xr.grad.numpy(),
+                "rb_demb": er.grad.numpy(), "rb_dgamma_out": rb.out_layers[0].weight.grad.numpy()})
+    # ---- model + loss
+    m = AA_diffusion(**TINY_DIFF); fill(m, 0.7); m.train()
+    d = SpacedDiffusion(use_timesteps=space_timesteps(1000, [1000]), model_mean_type="epsilon", model_var_type="learned_range",
+                        loss_type="mse", betas=get_named_beta_schedule("linear", 1000), conditioning_free=False, conditioning_free_k=2.0)
+    x0 = (torch.randn(3, 20, 48, generator=g) * 0.4).clamp(-1.2, 1.2); x0[0, 0, :4] = torch.tensor([-1.0, 1.0, -0.9995, 0.9995])
+    lat = torch.randn(3, 32, 12, generator=g); ref = torch.randn(3, 20, 30, generator=g) * 0.4
+    t = torch.tensor([0, 500, 999]); noise = torch.randn(3, 20, 48, generator=g)
+    out = d.training_losses(model=m, x_start=x0, t=t, model_kwargs={"latent": lat, "refer": ref}, noise=noise)
+    out["loss"].mean().backward()
+    with torch.no_grad():
+        x_t = d.q_sample(x0, t, noise=noise)
+        model_out = m(x_t, t, latent=lat, refer=ref)
+    rec.update({"x_start": x0.numpy(), "latent": lat.numpy(), "refer": ref.numpy(), "t": t.numpy(), "noise": noise.numpy(),
+                "x_t": x_t.numpy(), "model_out": model_out.numpy(), "loss": out["loss"].detach().numpy(),
+                "mse": out["mse"].detach().numpy(), "vb": out["vb"].detach().numpy()})
+    names = [k for k, p in m.named_parameters()]
+    rec["param_names"] = np.array(json.dumps(names))
+    rec["grad_abs_sum"] = np.array([float(p.grad.abs().sum()) if p.grad is not None else -1.0 for _, p in m.named_parameters()])
+    rec["grad_sum"] = np.array([float(p.grad.sum()) if p.grad is not None else 0.0 for _, p in m.named_parameters()])
+    for k in ("layers.0.attn.qkv.weight", "time_embed.0.weight", "refer_enc.4.latents", "inp_block.weight",
+              "layers.1.attn.relative_pos_embeddings.relative_attention_bias.weight", "out.2.weight",
+              "conditioning_timestep_integrator.0.resblk.emb_layers.1.weight", "latent_conditioner.0.weight"):
+        rec["grad:" + k] = dict(m.named_parameters())[k].grad.numpy()
+    # diffusion tables
+    for k in ("sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "posterior_log_variance_clipped", "posterior_mean_coef1",
+              "posterior_mean_coef2", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod"):
+        rec["tab:" + k] = getattr(d, k)
+    # unconditioned rows + dropped layer (the two random branches, forced)
+    m.eval()
+    with torch.no_grad():
+        rec["model_out_eval"] = m(x_t, t, latent=lat, refer=ref).numpy()
+        m.training = True; m.unconditioned_percentage = 2.0                 # rand < 2: every row unconditioned
+        rec["model_out_uncond"] = m(x_t, t, latent=lat, refer=ref).numpy()
+        m.unconditioned_percentage = 0.0
+    # ---- three steps of the trainer recipe (train.py:119-120,194-199)
+    m2 = AA_diffusion(**TINY_DIFF); fill(m2, 0.7); m2.train()
+    opt = torch.optim.AdamW(m2.parameters(), lr=1e-4, betas=(0.9, 0.999), weight_decay=0.01)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda s: float(s / 1000) if s < 1000 else 1)
+    sched.step()                                                           # step 0 has lr 0: start the record at step 1
+    before = {k: p.detach().clone() for k, p in m2.named_parameters()}
+    norms, losses = [], []
+    for s_ in range(3):
+        loss = d.training_losses(model=m2, x_start=x0, t=t, model_kwargs={"latent": lat, "refer": ref}, noise=noise)["loss"].mean()
+        loss.backward()
+        norms.append(float(torch.nn.utils.clip_grad_norm_(m2.parameters(), 1.0)))
+        opt.step(); opt.zero_grad(); sched.step()
+        losses.append(float(loss))
+    rec["step_norms"], rec["step_losses"] = np.array(norms), np.array(losses)
+    rec["step_delta_abs"] = np.array([float((p.detach() - before[k]).abs().sum()) for k, p in m2.named_parameters()])
+    np.savez_compressed(os.path.join(OUT, "diffusion.npz"), **rec)
+    print("diffusion: loss", rec["loss"], "mse", rec["mse"], "vb", rec["vb"], "norms", norms, "unused params",
+          int((rec["grad_abs_sum"] < 0).sum()), "tensors", len(names))
+
+
 PEQ_CFGS = [dict(sampling_rate=32000, win_length=2048, hop_length=640, cutoff_lowpass=60, cutoff_highpass=10000, num_peak=8,
                  q_min=2, q_max=5, T=9000),
             dict(sampling_rate=22050, win_length=1024, hop_length=256, cutoff_lowpass=60, cutoff_highpass=10000, num_peak=8,
@@ -656,7 +745,7 @@ def gen_peq():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gpt", "vq", "mel", "vqvae", "disc", "flow", "attn", "step", "peq", "infer"]
+    which = sys.argv[1:] or ["gpt", "vq", "mel", "vqvae", "disc", "flow", "attn", "step", "peq", "infer", "diffusion"]
     with torch.no_grad() if False else torch.enable_grad():
         if "gpt" in which:
             gen_gpt()
@@ -678,4 +767,6 @@ if __name__ == "__main__":
             gen_peq()
         if "infer" in which:
             gen_infer()
+        if "diffusion" in which:
+            gen_diffusion()
     print("fixtures:", {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT))})
