@@ -225,6 +225,59 @@ int ttts_mel_log_bwd_f32(const float* dmel, const float* mel, const float* basis
 int ttts_stft_mag_bwd_f32(const float* wav, const float* window, const float* twiddle2, const float* dspec,
                           float* dwav, int32_t B, int32_t T, int32_t n_fft, int32_t hop, void* stream);
 
+/* ---- diffusion mel-denoiser step ----------------------------------------------------------------
+ * The pieces of AA_diffusion / SpacedDiffusion.training_losses that the conv and attention families above do not cover
+ * (ttts/diffusion/aa_model.py:32-287, ttts/utils/utils.py:113-215, ttts/utils/xtransformers.py:146-185,
+ * ttts/utils/diffusion.py:17-82,243-282,903-1014).  Tensors are f32 (B, C, T).
+ *  groupnorm_fwd: GroupNorm32 (utils.py:113-133): y = act(((x - mean_g) rstd_g gamma + beta) (1 + scale) + shift);
+ *    scale_shift f32 [B, 2C] (scale | shift: the ResBlock's timestep modulation, aa_model.py:121-126) or NULL; silu != 0
+ *    applies x sigmoid(x) last.  mean / rstd f32 [B, groups] are saved for the backward.
+ *  groupnorm_bwd: dx, dgamma / dbeta [C] (accumulate != 0: +=), d_scale_shift [B, 2C]; workspace f32 [2 B C].
+ *  relpos_bias_fwd: RelativePositionBias.forward: bias f32 [H, Tq, Tk] = table[bucket[j - i + offset]][h] * scale with
+ *    table f32 [num_buckets, H] and bucket i32 [2 offset + 1] (host-built with `_relative_position_bucket`);
+ *    relpos_bias_bwd: dtable from dS f32 [B, H, Tq, Tk] (workspace: ttts_relpos_bias_bwd_workspace_bytes).
+ *  softmax_bias_fwd: in place softmax_j(scores[b,h,i,j] + bias[h,i,j]) (QKVAttentionLegacy, utils.py:157-162); backward =
+ *    ttts_attn_softmax_bwd_f32 without masks.
+ *  interp_nearest_fwd/bwd: F.interpolate(mode='nearest') along T for `rows` = B*C rows and its adjoint.
+ *  timestep_embedding: aa_model.py:32-51, t i64 [N], freqs f32 [dim/2] (= exp(-ln(max_period) k / (dim/2))) -> emb f32 [N, dim].
+ *  select_rows_fwd/bwd: out[b] = use[b] ? vec (C, broadcast over T) : a[b] (the unconditioned-embedding mask, :246-250).
+ *  q_sample: x_t = tab[t][0] x_0 + tab[t][1] noise.  table f32 [steps, 8]: sqrt_alphas_cumprod, sqrt_one_minus_alphas_cumprod,
+ *    sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod, posterior_mean_coef1, posterior_mean_coef2,
+ *    posterior_log_variance_clipped, log(betas) (built in float64 on the host as GaussianDiffusion.__init__ does).
+ *  diffusion_loss_fwd: model_out f32 [B, 2C, T] = (eps | var values): terms f32 [B, 3] = (mse, vb, mse + vb) of
+ *    training_losses (epsilon / learned_range / mse; the vb term sees eps detached), loss_mean = mean_b loss;
+ *    diffusion_loss_bwd: d loss_mean / d model_out (times gout[0] if given). */
+int ttts_groupnorm_fwd_f32(const float* x, const float* gamma, const float* beta, const float* scale_shift, float* y,
+                           float* mean, float* rstd, int32_t B, int32_t C, int32_t T, int32_t groups, float eps,
+                           int32_t silu, void* stream);
+int ttts_groupnorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* beta, const float* scale_shift,
+                           const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta,
+                           float* d_scale_shift, float* workspace, int32_t B, int32_t C, int32_t T, int32_t groups,
+                           int32_t silu, int32_t accumulate, void* stream);
+int ttts_relpos_bias_fwd_f32(const float* table, const int32_t* bucket, float* bias, int32_t H, int32_t Tq, int32_t Tk,
+                             int32_t bucket_offset, float scale, void* stream);
+int64_t ttts_relpos_bias_bwd_workspace_bytes(int32_t B, int32_t H, int32_t Tq, int32_t num_buckets);
+int ttts_relpos_bias_bwd_f32(const float* dS, const int32_t* bucket, float* dtable, float* workspace, int32_t B, int32_t H,
+                             int32_t Tq, int32_t Tk, int32_t bucket_offset, int32_t num_buckets, float scale,
+                             int32_t accumulate, void* stream);
+int ttts_softmax_bias_fwd_f32(float* scores, const float* bias, int32_t B, int32_t H, int32_t Tq, int32_t Tk, void* stream);
+int ttts_interp_nearest_fwd_f32(const float* x, float* y, int64_t rows, int32_t Tin, int32_t Tout, void* stream);
+int ttts_interp_nearest_bwd_f32(const float* dy, float* dx, int64_t rows, int32_t Tin, int32_t Tout, void* stream);
+int ttts_timestep_embedding_f32(const int64_t* t, const float* freqs, float* emb, int32_t N, int32_t dim, void* stream);
+int ttts_select_rows_fwd_f32(const uint8_t* use_vec, const float* a, const float* vec, float* out, int32_t B, int32_t C,
+                             int32_t T, void* stream);
+int ttts_select_rows_bwd_f32(const uint8_t* use_vec, const float* dout, float* da, float* dvec, int32_t B, int32_t C,
+                             int32_t T, int32_t accumulate, void* stream);
+int ttts_q_sample_f32(const float* x_start, const float* noise, const int64_t* t, const float* table, float* x_t, int32_t B,
+                      int64_t per_sample, void* stream);
+int64_t ttts_diffusion_loss_workspace_bytes(int32_t B);
+int ttts_diffusion_loss_fwd_f32(const float* model_out, const float* x_start, const float* x_t, const float* noise,
+                                const int64_t* t, const float* table, float* terms, float* loss_mean, float* workspace,
+                                int32_t B, int32_t C, int32_t T, void* stream);
+int ttts_diffusion_loss_bwd_f32(const float* model_out, const float* x_start, const float* x_t, const float* noise,
+                                const int64_t* t, const float* table, const float* gout, float* d_model_out, int32_t B,
+                                int32_t C, int32_t T, void* stream);
+
 /* ---- autoregressive decoding of the GPT --------------------------------------------------------
  * Replaces: GPT2InferenceModel.forward with a KV cache (ttts/gpt/model.py:34-184), inference_speech (:533-562) and the
  * sample loop + logits processors of transformers' GenerationMixin it calls (RepetitionPenaltyLogitsProcessor,
@@ -343,6 +396,7 @@ int ttts_add4_scale_f32(const float* a, const float* b, const float* c, const fl
  * layernorm_ch: modules.LayerNorm (modules.py:19-31): LayerNorm over C at every (b, t); mean/rstd [B*T] saved. */
 #define TTTS_ACT_RELU 0
 #define TTTS_ACT_MISH 1
+#define TTTS_ACT_SILU 2   /* x sigmoid(x): the diffusion model's nn.SiLU (ttts/diffusion/aa_model.py:98,103,112) */
 int ttts_gate_fwd_f32(const float* x, float* y, int32_t B, int32_t H, int32_t T, int32_t kind, void* stream);
 int ttts_gate_bwd_f32(const float* dy, const float* x, float* dx, int32_t B, int32_t H, int32_t T, int32_t kind,
                       void* stream);

@@ -107,3 +107,12 @@ def test_forced_random_branches(gold, tiny):
     np.testing.assert_allclose(a.numpy(), gold["model_out_eval"], atol=5e-5)
     np.testing.assert_allclose(b.numpy(), gold["model_out_uncond"], atol=5e-5)
     assert np.abs(gold["model_out_uncond"] - gold["model_out_eval"]).max() > 1e-3
+
+
+def test_product_module_surface_matches_reference(gold):
+    """ttts_amd.diffusion.AA_diffusion at the shipped config: state-dict keys, shapes and order of the reference (283 tensors)."""
+    from ttts_amd.diffusion import AA_diffusion
+    full = json.loads(str(gold["full_cfg"]))
+    m = AA_diffusion(**full)
+    assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == json.loads(str(gold["full_surface"]))
+    assert [k for k, _ in m.named_parameters()] == [k for k, _ in D.param_spec(full)]

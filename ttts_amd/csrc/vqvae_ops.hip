@@ -98,7 +98,7 @@ __device__ __forceinline__ float softplusf_(float x) { return x > 20.f ? x : log
 __global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, int op) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float v = x[i];
-    y[i] = op == TTTS_ACT_RELU ? fmaxf(v, 0.f) : v * tanhf(softplusf_(v));
+    y[i] = op == TTTS_ACT_RELU ? fmaxf(v, 0.f) : (op == TTTS_ACT_SILU ? v * sigmoidf_(v) : v * tanhf(softplusf_(v)));
   }
 }
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
@@ -108,6 +108,9 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
     float g;
     if (op == TTTS_ACT_RELU) {
       g = v > 0.f ? 1.f : 0.f;
+    } else if (op == TTTS_ACT_SILU) {   // d/dx x sigmoid(x) = s (1 + x (1 - s))
+      const float sg = sigmoidf_(v);
+      g = sg * (1.f + v * (1.f - sg));
     } else {  // mish: d/dx x tanh(sp(x)) = tanh(sp) + x (1 - tanh^2(sp)) sigmoid(x)
       const float t = tanhf(softplusf_(v));
       g = t + v * (1.f - t * t) * sigmoidf_(v);
@@ -405,12 +408,12 @@ extern "C" int ttts_upsample2_bwd_f32(const float* dy, float* dx, int64_t n, voi
   return check_launch("upsample2_bwd");
 }
 extern "C" int ttts_act_fwd_f32(const float* x, float* y, int64_t n, int32_t op, void* stream) {
-  TTTS_REQUIRE(x && y && n > 0 && (op == TTTS_ACT_RELU || op == TTTS_ACT_MISH), "act_fwd: bad arguments");
+  TTTS_REQUIRE(x && y && n > 0 && (op >= TTTS_ACT_RELU && op <= TTTS_ACT_SILU), "act_fwd: bad arguments");
   act_fwd_kernel<<<grid_for(n), 256, 0, as_stream(stream)>>>(x, y, n, op);
   return check_launch("act_fwd");
 }
 extern "C" int ttts_act_bwd_f32(const float* dy, const float* x, float* dx, int64_t n, int32_t op, void* stream) {
-  TTTS_REQUIRE(dy && x && dx && n > 0 && (op == TTTS_ACT_RELU || op == TTTS_ACT_MISH), "act_bwd: bad arguments");
+  TTTS_REQUIRE(dy && x && dx && n > 0 && (op >= TTTS_ACT_RELU && op <= TTTS_ACT_SILU), "act_bwd: bad arguments");
   act_bwd_kernel<<<grid_for(n), 256, 0, as_stream(stream)>>>(dy, x, dx, n, op);
   return check_launch("act_bwd");
 }

@@ -1,0 +1,72 @@
+"""Trainer of the diffusion mel-denoiser on the HIP kernels: the step body of ttts/diffusion/train.py:156-200 with the same
+recipe (AdamW(lr, (0.9, 0.999), wd 0.01) :119, LambdaLR warm-up over 1000 steps :69-73,120, clip 1.0 :195, checkpoint dict
+`{'step', 'model'}` :135-141) and config keys (ttts/diffusion/config.yaml: train.*, aa_diffusion.*).
+
+Host-side differences (outside the arithmetic): one process per GPU under torchrun with one flat gradient all-reduce
+(`parallel.FlatDataParallel`) instead of accelerate; `FlatAdamW` (one arena, fused grad-norm / clip / AdamW, no per-tensor
+`.item()`); the GPT latent is an input of `train_step` (the frozen GPT lives in `ttts_amd.gpt`, `return_latent=True`); data
+loading, EMA copy, vocoder previews and tensorboard are outside the path.
+"""
+import torch
+
+from ..optim import FlatAdamW
+from ..parallel import FlatDataParallel, init_distributed
+from .aa_model import AA_diffusion, normalize_tacotron_mel
+from .gaussian import SpacedDiffusion, get_named_beta_schedule, space_timesteps
+
+
+def warmup(step):
+    """train.py:69-73."""
+    return float(step / 1000) if step < 1000 else 1
+
+
+class DiffusionTrainer:
+    def __init__(self, cfg, device=None, seed=0):
+        """cfg: dict with the keys of ttts/diffusion/config.yaml (`train.lr`, `train.timesteps`, `aa_diffusion.*`)."""
+        self.rank, self.world, local = init_distributed()
+        self.device = torch.device("cuda", local) if device is None else torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("ttts_amd.diffusion.train needs a GPU (no CPU fallback)")
+        torch.cuda.set_device(self.device)
+        self.cfg = cfg
+        torch.manual_seed(seed)
+        self.diffusion = AA_diffusion(**cfg["aa_diffusion"]).to(self.device)
+        steps = int(cfg["train"].get("timesteps", 1000))
+        self.diffuser = SpacedDiffusion(use_timesteps=space_timesteps(steps, [steps]), model_mean_type="epsilon",
+                                        model_var_type="learned_range", loss_type="mse",
+                                        betas=get_named_beta_schedule("linear", steps), conditioning_free=False, conditioning_free_k=2.0)
+        self.desired_diffusion_steps = steps
+        self.dp = FlatDataParallel()
+        self.optimizer = FlatAdamW(self.diffusion.parameters(), cfg["train"]["lr"], betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+        self.dp.broadcast_(self.optimizer.flat_p)
+        self.base_lr = cfg["train"]["lr"]
+        self.step = 0
+        self.diffusion.train()
+
+    def train_step(self, mel, mel_refer, latent, t=None, noise=None, inject=None, normalized=False):
+        """mel (B, 100, T) / mel_refer (B, 100, Tr) raw log-mels (`normalized=True`: already through normalize_tacotron_mel),
+        latent (B, 512, T / 4) GPT latents (already transposed, train.py:161-165).  Returns {"loss", "grad_norm"} device scalars."""
+        x_start = mel if normalized else normalize_tacotron_mel(mel)
+        refer = mel_refer if normalized else normalize_tacotron_mel(mel_refer)
+        if t is None:
+            t = torch.randint(0, self.desired_diffusion_steps, (x_start.shape[0],), device=self.device)
+        kw = {"latent": latent, "refer": refer}
+        kw.update(inject or {})
+        out = self.diffuser.training_losses(self.diffusion, x_start, t, model_kwargs=kw, noise=noise)
+        loss = out["loss_mean"]
+        self.optimizer.zero_grad()
+        (loss * self.dp.loss_scale()).backward()
+        self.dp.allreduce_grads_(self.optimizer.flat_g)
+        lr = self.base_lr * warmup(self.step)                             # LambdaLR: the factor of the step being taken
+        self.optimizer.step(lr, max_norm=1.0)
+        self.step += 1
+        return {"loss": loss.detach(), "grad_norm": self.optimizer.grad_norm(), "terms": out}
+
+    def save(self, path):
+        if self.rank == 0:
+            torch.save({"step": self.step, "model": self.diffusion.state_dict()}, path)
+
+    def load(self, path):
+        data = torch.load(path, map_location=self.device)
+        self.step = data["step"]
+        self.diffusion.load_state_dict(data["model"], strict=False)

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(CSRC, "build")
 SO_PATH = os.path.join(HERE, "libttts_hip.so")
-SOURCES = ["lib.hip", "elementwise.hip", "gemm.hip", "attn.hip", "vq.hip", "stft.hip", "conv.hip", "conv_mfma.hip", "losses.hip", "vqvae_ops.hip", "attn_f32.hip", "peq.hip", "decode.hip"]
+SOURCES = ["lib.hip", "elementwise.hip", "gemm.hip", "attn.hip", "vq.hip", "stft.hip", "conv.hip", "conv_mfma.hip", "losses.hip", "vqvae_ops.hip", "attn_f32.hip", "peq.hip", "decode.hip", "diffusion_ops.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-Wall", "-Wno-unused-variable"]
 
@@ -110,6 +110,21 @@ SIGNATURES = {
     "ttts_mel_log_fwd_f32": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "ttts_mel_log_bwd_f32": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "ttts_stft_mag_bwd_f32": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "ttts_groupnorm_fwd_f32": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _I32, _P]),
+    "ttts_groupnorm_bwd_f32": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
+    "ttts_relpos_bias_fwd_f32": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _F, _P]),
+    "ttts_relpos_bias_bwd_workspace_bytes": (_I64, [_I32, _I32, _I32, _I32]),
+    "ttts_relpos_bias_bwd_f32": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _F, _I32, _P]),
+    "ttts_softmax_bias_fwd_f32": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _P]),
+    "ttts_interp_nearest_fwd_f32": (_I32, [_P, _P, _I64, _I32, _I32, _P]),
+    "ttts_interp_nearest_bwd_f32": (_I32, [_P, _P, _I64, _I32, _I32, _P]),
+    "ttts_timestep_embedding_f32": (_I32, [_P, _P, _P, _I32, _I32, _P]),
+    "ttts_select_rows_fwd_f32": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _P]),
+    "ttts_select_rows_bwd_f32": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "ttts_q_sample_f32": (_I32, [_P, _P, _P, _P, _P, _I32, _I64, _P]),
+    "ttts_diffusion_loss_workspace_bytes": (_I64, [_I32]),
+    "ttts_diffusion_loss_fwd_f32": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P]),
+    "ttts_diffusion_loss_bwd_f32": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P]),
     "ttts_linear_decode_bf16": (_I32, [_P, _I64, _I32, _P, _P, _P, _P, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _I32, _P]),
     "ttts_decode_embed_f32": (_I32, [_P, _P, _P, _P, _I32, _P, _I32, _I32, _I32, _I32, _P]),
     "ttts_kv_cache_fill_bf16": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),

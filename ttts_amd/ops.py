@@ -281,6 +281,141 @@ def stft_mag(wav, window, n_fft, hop):
     return spec
 
 
+# ---- diffusion mel-denoiser pieces (csrc/diffusion_ops.hip) ------------------------------------------------------------------------
+def groupnorm_fwd(x, gamma, beta, groups, ss=None, silu=False, eps=1e-5):
+    x = _f32c(x, "x")
+    B, C, T = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(B * groups, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    check(_l.get().ttts_groupnorm_fwd_f32(_p(x), _p(gamma), _p(beta), _p(ss), _p(y), _p(mean), _p(rstd), B, C, T, groups, eps,
+                                          int(silu), _stream()), "groupnorm_fwd")
+    return y, mean, rstd
+
+
+def groupnorm_bwd(dy, x, gamma, beta, ss, mean, rstd, groups, silu=False, dgamma=None, dbeta=None):
+    """Returns (dx, dgamma, dbeta, d_scale_shift); dgamma / dbeta given -> accumulated into them in place."""
+    dy = _f32c(dy, "dy")
+    B, C, T = x.shape
+    dx = torch.empty_like(x)
+    acc = dgamma is not None
+    if not acc:
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+    dss = torch.empty(B, 2 * C, dtype=torch.float32, device=x.device) if ss is not None else None
+    ws = torch.empty(2 * B * C, dtype=torch.float32, device=x.device)
+    check(_l.get().ttts_groupnorm_bwd_f32(_p(dy), _p(x), _p(gamma), _p(beta), _p(ss), _p(mean), _p(rstd), _p(dx), _p(dgamma), _p(dbeta),
+                                          _p(dss), _p(ws), B, C, T, groups, int(silu), int(acc), _stream()), "groupnorm_bwd")
+    return dx, dgamma, dbeta, dss
+
+
+def relpos_bias_fwd(table, bucket, H, Tq, Tk, scale):
+    _req(table, torch.float32, "table"); _req(bucket, torch.int32, "bucket")
+    off = (bucket.numel() - 1) // 2
+    bias = torch.empty(H, Tq, Tk, dtype=torch.float32, device=table.device)
+    check(_l.get().ttts_relpos_bias_fwd_f32(_p(table), _p(bucket), _p(bias), H, Tq, Tk, off, float(scale), _stream()), "relpos_bias_fwd")
+    return bias
+
+
+def relpos_bias_bwd(dS, bucket, num_buckets, scale, out=None):
+    B, H, Tq, Tk = dS.shape
+    off = (bucket.numel() - 1) // 2
+    acc = out is not None
+    if not acc:
+        out = torch.empty(num_buckets, H, dtype=torch.float32, device=dS.device)
+    ws = torch.empty(_l.get().ttts_relpos_bias_bwd_workspace_bytes(B, H, Tq, num_buckets) // 4, dtype=torch.float32, device=dS.device)
+    check(_l.get().ttts_relpos_bias_bwd_f32(_p(dS), _p(bucket), _p(out), _p(ws), B, H, Tq, Tk, off, num_buckets, float(scale), int(acc),
+                                            _stream()), "relpos_bias_bwd")
+    return out
+
+
+def softmax_bias_fwd(S, bias):
+    B, H, Tq, Tk = S.shape
+    check(_l.get().ttts_softmax_bias_fwd_f32(_p(S), _p(bias), B, H, Tq, Tk, _stream()), "softmax_bias_fwd")
+    return S
+
+
+def interp_nearest_fwd(x, Tout):
+    x = _f32c(x, "x")
+    B, C, Tin = x.shape
+    y = torch.empty(B, C, Tout, dtype=torch.float32, device=x.device)
+    check(_l.get().ttts_interp_nearest_fwd_f32(_p(x), _p(y), B * C, Tin, Tout, _stream()), "interp_nearest_fwd")
+    return y
+
+
+def interp_nearest_bwd(dy, Tin):
+    dy = _f32c(dy, "dy")
+    B, C, Tout = dy.shape
+    dx = torch.empty(B, C, Tin, dtype=torch.float32, device=dy.device)
+    check(_l.get().ttts_interp_nearest_bwd_f32(_p(dy), _p(dx), B * C, Tin, Tout, _stream()), "interp_nearest_bwd")
+    return dx
+
+
+_freq_cache = {}
+
+
+def timestep_embedding(t, dim, max_period=10000.0):
+    import math
+    _req(t, torch.int64, "t")
+    key = (dim, float(max_period), str(t.device))
+    if key not in _freq_cache:       # the reference's own fp32 expression (aa_model.py:43-45), evaluated once on the host
+        half = dim // 2
+        _freq_cache[key] = torch.exp(-math.log(max_period) * torch.arange(start=0, end=half, dtype=torch.float32) / half).to(t.device)
+    emb = torch.empty(t.shape[0], dim, dtype=torch.float32, device=t.device)
+    check(_l.get().ttts_timestep_embedding_f32(_p(t), _p(_freq_cache[key]), _p(emb), t.shape[0], dim, _stream()), "timestep_embedding")
+    return emb
+
+
+def select_rows_fwd(use, a, vec):
+    _req(use, torch.uint8, "use")
+    a = _f32c(a, "a")
+    B, C, T = a.shape
+    out = torch.empty_like(a)
+    check(_l.get().ttts_select_rows_fwd_f32(_p(use), _p(a), _p(vec), _p(out), B, C, T, _stream()), "select_rows_fwd")
+    return out
+
+
+def select_rows_bwd(use, dout, need_da=True, dvec_out=None):
+    dout = _f32c(dout, "dout")
+    B, C, T = dout.shape
+    da = torch.empty_like(dout) if need_da else None
+    acc = dvec_out is not None
+    dvec = dvec_out if acc else torch.empty(C, dtype=torch.float32, device=dout.device)
+    check(_l.get().ttts_select_rows_bwd_f32(_p(use), _p(dout), _p(da), _p(dvec), B, C, T, int(acc), _stream()), "select_rows_bwd")
+    return da, dvec
+
+
+def q_sample(x_start, noise, t, table):
+    x_start, noise = _f32c(x_start, "x_start"), _f32c(noise, "noise")
+    _req(t, torch.int64, "t"); _req(table, torch.float32, "table")
+    xt = torch.empty_like(x_start)
+    B = x_start.shape[0]
+    check(_l.get().ttts_q_sample_f32(_p(x_start), _p(noise), _p(t), _p(table), _p(xt), B, x_start.numel() // B, _stream()), "q_sample")
+    return xt
+
+
+def diffusion_loss_fwd(model_out, x_start, x_t, noise, t, table):
+    """Returns (terms (B, 3) = mse | vb | loss, loss_mean (1,))."""
+    model_out = _f32c(model_out, "model_out")
+    B, C, T = x_start.shape
+    terms = torch.empty(B, 3, dtype=torch.float32, device=x_start.device)
+    loss = torch.empty(1, dtype=torch.float32, device=x_start.device)
+    ws = torch.empty(_l.get().ttts_diffusion_loss_workspace_bytes(B) // 4, dtype=torch.float32, device=x_start.device)
+    check(_l.get().ttts_diffusion_loss_fwd_f32(_p(model_out), _p(x_start), _p(x_t), _p(noise), _p(t), _p(table), _p(terms), _p(loss), _p(ws),
+                                               B, C, T, _stream()), "diffusion_loss_fwd")
+    return terms, loss
+
+
+def diffusion_loss_bwd(model_out, x_start, x_t, noise, t, table, gout=None):
+    B, C, T = x_start.shape
+    d = torch.empty_like(model_out)
+    check(_l.get().ttts_diffusion_loss_bwd_f32(_p(model_out), _p(x_start), _p(x_t), _p(noise), _p(t), _p(table), _p(gout), _p(d), B, C, T,
+                                               _stream()), "diffusion_loss_bwd")
+    return d
+
+
+
+
 # ---- autoregressive decoding (csrc/decode.hip) ------------------------------------------------------------------------
 def decode_embed(tokens, emb, pos, ctr, pos_offset, x):
     _req(tokens, torch.int64, "tokens"); _req(emb, torch.float32, "emb"); _req(pos, torch.float32, "pos")
@@ -533,7 +668,7 @@ def add_scale(tensors, scale=1.0):
 
 
 GATE_TANH_SIGMOID, GATE_GLU = 0, 1
-ACT_RELU, ACT_MISH = 0, 1
+ACT_RELU, ACT_MISH, ACT_SILU = 0, 1, 2
 
 
 def _f32c(t, name):
