@@ -256,7 +256,7 @@ int ttts_groupnorm_bwd_f32(const float* dy, const float* x, const float* gamma, 
                            int32_t silu, int32_t accumulate, void* stream);
 int ttts_relpos_bias_fwd_f32(const float* table, const int32_t* bucket, float* bias, int32_t H, int32_t Tq, int32_t Tk,
                              int32_t bucket_offset, float scale, void* stream);
-int64_t ttts_relpos_bias_bwd_workspace_bytes(int32_t B, int32_t H, int32_t Tq, int32_t num_buckets);
+int64_t ttts_relpos_bias_bwd_workspace_bytes(int32_t B, int32_t H, int32_t Tq, int32_t Tk);
 int ttts_relpos_bias_bwd_f32(const float* dS, const int32_t* bucket, float* dtable, float* workspace, int32_t B, int32_t H,
                              int32_t Tq, int32_t Tk, int32_t bucket_offset, int32_t num_buckets, float scale,
                              int32_t accumulate, void* stream);

@@ -10,5 +10,7 @@ run vq_stft tests/test_gpu_kernels.py -k "vq or stft"
 run gpt tests/test_gpu_gpt.py
 run vqvae tests/test_gpu_vqvae.py
 run peq tests/test_gpu_peq.py
+run decode tests/test_gpu_decode.py
+run diffusion tests/test_gpu_diffusion.py
 } > gpurun_out/pytest_gpu.log 2>&1
 grep -E "^===|passed|failed|error" gpurun_out/pytest_gpu.log | tail -40

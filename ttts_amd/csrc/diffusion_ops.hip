@@ -123,56 +123,44 @@ __global__ __launch_bounds__(256) void relpos_bias_fwd_kernel(const float* __res
     bias[e] = table[bucket[j - i + off] * H + h] * scale;
   }
 }
-// partial[(blk)][NB] per (h, b, 8-row chunk): bucket sums of dS; summed over blocks by relpos_bias_bwd_reduce (fixed order).
-// A wave walks 64 consecutive keys of a row; keys far from the diagonal all share one bucket, so the wave first combines
-// the lanes that hit the same bucket (one LDS atomic per distinct bucket and wave instead of one per element -- the two far
-// buckets took ~90 % of the atomics and serialised).  Order of the float adds inside one block is not fixed: ~1 ulp noise.
-__global__ __launch_bounds__(256) void relpos_bias_bwd_kernel(const float* __restrict__ dS, const int32_t* __restrict__ bucket,
-                                                              float* __restrict__ partial, int B, int H, int Tq, int Tk, int off,
-                                                              int NB, int chunks) {
-  __shared__ float bins[64];
+// d table[bucket][h] = scale * sum_{b, i, j} dS[b][h][i][j] [bucket(j - i) == bucket]: the bias only depends on r = j - i, so
+//  1. relpos_diag_kernel: per (h, b, 64-row chunk) the diagonal sums D[r] = sum_i dS[i][i + r] -- thread-private accumulators,
+//     coalesced reads, no atomics -> partial[blk][Tq + Tk - 1]
+//  2. relpos_diag_reduce_kernel: sum the partials over (b, chunk) in fixed order -> D[h][r]
+//  3. relpos_bucket_kernel: 32 bucket sums over r (LDS atomics inside one block: ~1 ulp ordering noise) -> dtable
+constexpr int RP_ROWS = 64;
+__global__ __launch_bounds__(256) void relpos_diag_kernel(const float* __restrict__ dS, float* __restrict__ partial, int B, int H,
+                                                          int Tq, int Tk, int chunks) {
   const int ck = blockIdx.x % chunks, b = (blockIdx.x / chunks) % B, h = blockIdx.x / (chunks * B);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nR = Tq + Tk - 1;
+  const int i0 = ck * RP_ROWS, i1 = min(i0 + RP_ROWS, Tq);
+  const float* base = dS + ((int64_t)b * H + h) * Tq * Tk;
+  for (int ri = threadIdx.x; ri < nR; ri += 256) {
+    const int r = ri - (Tq - 1);
+    float acc = 0.f;
+    const int lo = max(i0, -r), hi = min(i1, Tk - r);      // rows with 0 <= i + r < Tk
+    for (int i = lo; i < hi; ++i) acc += base[(int64_t)i * Tk + i + r];
+    partial[(int64_t)blockIdx.x * nR + ri] = acc;
+  }
+}
+__global__ __launch_bounds__(256) void relpos_diag_reduce_kernel(const float* __restrict__ partial, float* __restrict__ D, int nR,
+                                                                 int per_head) {
+  const int h = blockIdx.y, ri = blockIdx.x * 256 + threadIdx.x;
+  if (ri >= nR) return;
+  float s = 0.f;
+  for (int k = 0; k < per_head; ++k) s += partial[((int64_t)h * per_head + k) * nR + ri];
+  D[(int64_t)h * nR + ri] = s;
+}
+__global__ __launch_bounds__(256) void relpos_bucket_kernel(const float* __restrict__ D, const int32_t* __restrict__ bucket,
+                                                            float* __restrict__ dtable, int H, int Tq, int nR, int off, int NB,
+                                                            float scale, int accumulate) {
+  __shared__ float bins[64];
+  const int h = blockIdx.x;
   if (threadIdx.x < 64) bins[threadIdx.x] = 0.f;
   __syncthreads();
-  const int i0 = ck * 8, i1 = min(i0 + 8, Tq);
-  for (int i = i0 + (wave >> 1); i < i1; i += 2) {          // two waves per row, four rows in flight
-    const float* row = dS + (((int64_t)b * H + h) * Tq + i) * Tk;
-    for (int j0 = (wave & 1) * 64; j0 < Tk; j0 += 128) {
-      const int j = j0 + lane;
-      int bk = j < Tk ? bucket[j - i + off] : -1;
-      float v = j < Tk ? row[j] : 0.f;
-      while (true) {                                          // wave-uniform loop over the distinct buckets of these 64 keys
-        const uint64_t live = __ballot(bk >= 0);
-        if (!live) break;
-        const int cur = __shfl(bk, __ffsll((long long)live) - 1, 64);
-        const float s = wave_sum(bk == cur ? v : 0.f);
-        if (lane == 0) atomicAdd(&bins[cur], s);
-        if (bk == cur) bk = -1;
-      }
-    }
-  }
+  for (int ri = threadIdx.x; ri < nR; ri += 256) atomicAdd(&bins[bucket[ri - (Tq - 1) + off]], D[(int64_t)h * nR + ri]);
   __syncthreads();
-  if (threadIdx.x < NB) partial[(int64_t)blockIdx.x * NB + threadIdx.x] = bins[threadIdx.x];
-}
-// dtable[k][h] (+)= scale * sum_r partial[h][r][k]: 8 row groups per block, fixed order
-__global__ __launch_bounds__(256) void relpos_bias_bwd_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dtable,
-                                                                     int H, int NB, int per_head, float scale, int accumulate) {
-  __shared__ float sh[8][32];
-  const int h = blockIdx.x, k = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  for (int k0 = 0; k0 < NB; k0 += 32) {
-    float s = 0.f;
-    if (k0 + k < NB)
-      for (int r = grp; r < per_head; r += 8) s += partial[((int64_t)h * per_head + r) * NB + k0 + k];
-    sh[grp][k] = s;
-    __syncthreads();
-    if (grp == 0 && k0 + k < NB) {
-      float t = 0.f;
-      for (int g2 = 0; g2 < 8; ++g2) t += sh[g2][k];
-      dtable[(k0 + k) * H + h] = (accumulate ? dtable[(k0 + k) * H + h] : 0.f) + t * scale;
-    }
-    __syncthreads();
-  }
+  if (threadIdx.x < NB) dtable[threadIdx.x * H + h] = (accumulate ? dtable[threadIdx.x * H + h] : 0.f) + bins[threadIdx.x] * scale;
 }
 
 // S[b][h][i][:] = softmax(S + bias[h][i][:]) in place; one wave per row
@@ -415,8 +403,9 @@ extern "C" int ttts_relpos_bias_fwd_f32(const float* table, const int32_t* bucke
   return check_launch("relpos_bias_fwd");
 }
 
-extern "C" int64_t ttts_relpos_bias_bwd_workspace_bytes(int32_t B, int32_t H, int32_t Tq, int32_t num_buckets) {
-  return (int64_t)H * B * cdiv(Tq, 8) * num_buckets * (int64_t)sizeof(float);
+extern "C" int64_t ttts_relpos_bias_bwd_workspace_bytes(int32_t B, int32_t H, int32_t Tq, int32_t Tk) {
+  const int64_t nR = (int64_t)Tq + Tk - 1;
+  return ((int64_t)H * B * cdiv(Tq, RP_ROWS) + H) * nR * (int64_t)sizeof(float);
 }
 
 extern "C" int ttts_relpos_bias_bwd_f32(const float* dS, const int32_t* bucket, float* dtable, float* workspace, int32_t B, int32_t H,
@@ -425,9 +414,11 @@ extern "C" int ttts_relpos_bias_bwd_f32(const float* dS, const int32_t* bucket, 
   TTTS_REQUIRE(dS && bucket && dtable && workspace && B > 0 && H > 0 && Tq > 0 && Tk > 0, "relpos_bias_bwd: bad arguments");
   TTTS_REQUIRE(num_buckets > 0 && num_buckets <= 64, "relpos_bias_bwd: at most 64 buckets");
   TTTS_REQUIRE(bucket_offset >= Tq - 1 && bucket_offset >= Tk - 1, "relpos_bias_bwd: bucket table too short");
-  const int chunks = (int)cdiv(Tq, 8);
-  relpos_bias_bwd_kernel<<<H * B * chunks, 256, 0, as_stream(stream)>>>(dS, bucket, workspace, B, H, Tq, Tk, bucket_offset, num_buckets, chunks);
-  relpos_bias_bwd_reduce_kernel<<<H, 256, 0, as_stream(stream)>>>(workspace, dtable, H, num_buckets, B * chunks, scale, accumulate);
+  const int chunks = (int)cdiv(Tq, RP_ROWS), nR = Tq + Tk - 1;
+  float* D = workspace + (int64_t)H * B * chunks * nR;
+  relpos_diag_kernel<<<H * B * chunks, 256, 0, as_stream(stream)>>>(dS, workspace, B, H, Tq, Tk, chunks);
+  relpos_diag_reduce_kernel<<<dim3((unsigned)cdiv(nR, 256), (unsigned)H), 256, 0, as_stream(stream)>>>(workspace, D, nR, B * chunks);
+  relpos_bucket_kernel<<<H, 256, 0, as_stream(stream)>>>(D, bucket, dtable, H, Tq, nR, bucket_offset, num_buckets, scale, accumulate);
   return check_launch("relpos_bias_bwd");
 }
 

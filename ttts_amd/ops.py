@@ -323,7 +323,7 @@ def relpos_bias_bwd(dS, bucket, num_buckets, scale, out=None):
     acc = out is not None
     if not acc:
         out = torch.empty(num_buckets, H, dtype=torch.float32, device=dS.device)
-    ws = torch.empty(_l.get().ttts_relpos_bias_bwd_workspace_bytes(B, H, Tq, num_buckets) // 4, dtype=torch.float32, device=dS.device)
+    ws = torch.empty(_l.get().ttts_relpos_bias_bwd_workspace_bytes(B, H, Tq, Tk) // 4, dtype=torch.float32, device=dS.device)
     check(_l.get().ttts_relpos_bias_bwd_f32(_p(dS), _p(bucket), _p(out), _p(ws), B, H, Tq, Tk, off, num_buckets, float(scale), int(acc),
                                             _stream()), "relpos_bias_bwd")
     return out
