@@ -18,14 +18,15 @@ from ..utils.data_utils import spectrogram_torch
 @torch.no_grad()
 def extract_vq_codes(model, wav, hps_data, wav_lengths=None):
     """wav (B, T) fp32 on the GPU -> int64 codes (B, n_q, T_spec // 2)."""
-    was_training = model.training
+    modes = [(m, m.training) for m in model.modules()]      # restore every sub-module's own flag (ref_enc may be in eval)
     model.eval()
     try:
         spec = spectrogram_torch(wav, hps_data.filter_length, hps_data.hop_length, hps_data.win_length, center=False)
         y_lengths = None if wav_lengths is None else torch.div(wav_lengths, hps_data.hop_length, rounding_mode="floor")
         return model.extract_latent(wav, spec, y_lengths)
     finally:
-        model.train(was_training)
+        for m, flag in modes:
+            m.training = flag
 
 
 def save_vq(path, codes_1d):
