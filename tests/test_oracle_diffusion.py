@@ -116,3 +116,27 @@ def test_product_module_surface_matches_reference(gold):
     m = AA_diffusion(**full)
     assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == json.loads(str(gold["full_surface"]))
     assert [k for k, _ in m.named_parameters()] == [k for k, _ in D.param_spec(full)]
+
+
+def test_product_host_schedule_logic(gold):
+    """Host side of ttts_amd.diffusion.gaussian (runs without a GPU): timestep spacing, beta schedules, the float64 coefficient
+    tables SpacedDiffusion hands to the kernels -- against the reference-generated fixture and the oracle's tables."""
+    from ttts_amd.diffusion.gaussian import SpacedDiffusion, get_named_beta_schedule, space_timesteps
+    assert sorted(space_timesteps(1000, [50])) == gold["space_50"].tolist()
+    assert sorted(space_timesteps(1000, "ddim25")) == gold["space_ddim25"].tolist()
+    assert sorted(space_timesteps(300, [10, 15, 20])) == gold["space_10_15_20"].tolist()
+    np.testing.assert_allclose(get_named_beta_schedule("cosine", 100), gold["betas_cosine_100"], rtol=1e-12)
+    d = SpacedDiffusion(space_timesteps(1000, [1000]), betas=get_named_beta_schedule("linear", 1000))
+    tab = D.diffusion_tables(1000)
+    cols = ("sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
+            "posterior_mean_coef1", "posterior_mean_coef2", "posterior_log_variance_clipped", "log_betas")
+    for i, k in enumerate(cols):
+        np.testing.assert_array_equal(d._table_host[:, i], tab[k].astype(np.float32))
+        if ("tab:" + k) in gold.files:
+            np.testing.assert_array_equal(getattr(d, k), gold["tab:" + k])
+    d50 = SpacedDiffusion(space_timesteps(1000, [50]), betas=get_named_beta_schedule("linear", 1000))
+    np.testing.assert_array_equal(d50.betas, gold["spaced50_betas"])
+    assert d50.timestep_map == gold["spaced50_map"].tolist() and d50.num_timesteps == 50
+    np.testing.assert_array_equal(d50.posterior_log_variance_clipped, gold["spaced50_post_logvar"])
+    with pytest.raises(NotImplementedError):
+        SpacedDiffusion(space_timesteps(10, [10]), betas=np.full(10, 0.01), loss_type="kl")

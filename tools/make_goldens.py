@@ -671,6 +671,15 @@ def gen_diffusion():
     for k in ("sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "posterior_log_variance_clipped", "posterior_mean_coef1",
               "posterior_mean_coef2", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod"):
         rec["tab:" + k] = getattr(d, k)
+    # host-side schedule helpers
+    rec["space_50"] = np.array(sorted(space_timesteps(1000, [50])))
+    rec["space_ddim25"] = np.array(sorted(space_timesteps(1000, "ddim25")))
+    rec["space_10_15_20"] = np.array(sorted(space_timesteps(300, [10, 15, 20])))
+    rec["betas_cosine_100"] = get_named_beta_schedule("cosine", 100)
+    d50 = SpacedDiffusion(use_timesteps=space_timesteps(1000, [50]), model_mean_type="epsilon", model_var_type="learned_range",
+                          loss_type="mse", betas=get_named_beta_schedule("linear", 1000))
+    rec["spaced50_betas"], rec["spaced50_map"] = d50.betas, np.array(d50.timestep_map)
+    rec["spaced50_post_logvar"] = d50.posterior_log_variance_clipped
     # unconditioned rows + dropped layer (the two random branches, forced)
     m.eval()
     with torch.no_grad():
