@@ -4,7 +4,8 @@
 Same config keys (ttts/gpt/config.json), same loss weighting (:109), gradient accumulation (:99-112), clip 1.0 (:115),
 AdamW / warm-up (:56-57), same checkpoint dict `{'step', 'model'}` (:70-77) and file naming `model-{step//1000}.pt`.
 Differences, all on the host side of the hot loop:
-  * one process per GPU under torchrun; gradients cross ranks as ONE flat RCCL all-reduce (`parallel.FlatDataParallel`)
+  * one process per GPU under torchrun; gradients cross ranks as flat RCCL all-reduces of the gradient arena, the upper
+    layers' half overlapped with the lower layers' backward (`parallel.FlatDataParallel`, `GptEngine.grad_exchange_plan`)
     instead of accelerate's bucketed DDP; the two `wait_for_everyone()` barriers per step (:117,121) are dropped --
     the all-reduce already orders the ranks;
   * losses / grad-norm are read back only every `val_freq` steps (the reference's `loss.item()` each micro-batch and
@@ -108,6 +109,22 @@ class Trainer(object):
     def train_step(self):
         eng = self.gpt.engine
         scale = self.dp.loss_scale() / self.gradient_accumulate_every
+        opt = dict(lr=self.lr, max_norm=1.0, warmup_steps=500)
+        if self.gradient_accumulate_every == 1:
+            data = next(self.dataloader)
+            if data is None:                      # the reference skips None batches but still steps the optimizer (:101-102,117-120)
+                self.dp.allreduce_grads_(eng.grads)
+                eng.optimizer_step(**opt)
+                eng.step_count += 1
+                return
+            toks = prepare_tokens(self.gpt.cfg, data["padded_text"], data["text_lengths"], data["padded_qmel"],
+                                  data["wav_lens"])
+            # data parallel: the gradients of the upper layers are all-reduced while the lower layers' backward runs
+            # (GptEngine.grad_exchange_plan); launch by launch here because real batches change shape every step
+            eng.train_step(toks, self.text_loss_weight * scale, self.mel_loss_weight * scale, capture=False,
+                           exchange_range=(lambda lo, hi: self.dp.allreduce_range_(eng.grads, lo, hi)) if self.dp.enabled else None,
+                           **opt)
+            return
         for _ in range(self.gradient_accumulate_every):
             data = next(self.dataloader)
             if data is None:
@@ -117,8 +134,8 @@ class Trainer(object):
             eng.set_tokens(*toks)
             eng.forward()
             eng.backward(self.text_loss_weight * scale, self.mel_loss_weight * scale)
-        self.dp.allreduce_grads_(eng.grads)      # ONE flat RCCL all-reduce (no-op at world size 1)
-        eng.optimizer_step(lr=self.lr, max_norm=1.0, warmup_steps=500)
+        self.dp.allreduce_grads_(eng.grads)      # accumulated micro-batches: ONE flat RCCL all-reduce (no-op at world size 1)
+        eng.optimizer_step(**opt)
         eng.step_count += 1
 
     def train(self):
