@@ -282,6 +282,33 @@ def test_attention_dropout_matches_mask(ops):
     assert rel_err(dqkv.view(B, S, 3 * D).float(), leaf.grad) < 2e-2
 
 
+@pytest.mark.parametrize("B,S,H,dh,p", [(2, 1156, 8, 64, 0.0), (2, 1156, 8, 64, 0.1), (1, 130, 2, 64, 0.1), (3, 64, 4, 64, 0.0),
+                                        (2, 38, 2, 32, 0.0), (1, 257, 1, 128, 0.1)])
+def test_attention_fwd_kv2_work_split_matches_default(ops, B, S, H, dh, p):
+    """The two forward work splits (128-query blocks: flag 131072 forces it; 64-query x 128-key blocks: flag 65536, the default
+    under dropout) compute the same attention: same dropout mask (same hash indices), outputs and log-sum-exp equal up to bf16
+    rounding of a different accumulation order."""
+    from ttts_amd import lib
+    D = H * dh
+    g = torch.Generator(device="cpu").manual_seed(S + dh)
+    qkv = _bf(torch.randn(B, S, 3 * D, generator=g)).to(dev())
+    q2 = qkv.view(B * S, 3 * D)
+
+    def run(flags):
+        o = torch.zeros(B, S, D, dtype=torch.bfloat16, device=dev()); lse = torch.zeros(B, H, S, device=dev())
+        lib.get().ttts_debug_set_flags(flags)
+        try:
+            ops.attn_fwd(q2, q2[:, D:], q2[:, 2 * D:], o, lse, B, H, S, dh, (S * 3 * D, 3 * D), (S * D, D), dh ** -0.5, p, 4242)
+        finally:
+            lib.get().ttts_debug_set_flags(0)
+        torch.cuda.synchronize()
+        return o.float(), lse
+    o1, l1 = run(131072)
+    o2, l2 = run(65536)
+    assert rel_err(o2, o1) < 6e-3
+    assert (l2 - l1).abs().max().item() < 2e-3
+
+
 def test_dropout_counter_gives_fresh_masks(ops):
     """The device-side stream counter (graph-replay-safe dropout): same seed + same counter -> same mask,
     counter + 1 -> a different mask with the same keep rate."""

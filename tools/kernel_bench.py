@@ -104,6 +104,11 @@ def bench_attn():
         us = timeit(lambda: ops.attn_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], o, do, lse, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], ws, B, H, S, dh,
                                          (S * 3 * D, 3 * D), (S * D, D), dh ** -0.5, p, 7))
         out["bwd p=%.1f" % p] = "%.1f us  %.0f TF/s (causal-useful, 5 matmuls)" % (us, 2.5 * fl / us / 1e6)
+        from ttts_amd import lib
+        lib.get().ttts_debug_set_flags(65536)     # the 64-query x 128-key forward work split
+        us = timeit(lambda: ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], o, lse, B, H, S, dh, (S * 3 * D, 3 * D), (S * D, D), dh ** -0.5, p, 7))
+        lib.get().ttts_debug_set_flags(0)
+        out["fwd kv2 p=%.1f" % p] = "%.1f us  %.0f TF/s (causal-useful)" % (us, fl / us / 1e6)
     return out
 
 

@@ -17,6 +17,8 @@
 
 #include "common.hpp"
 
+extern int g_debug_flags;   // gemm.hip (ttts_debug_set_flags)
+
 namespace ttts {
 
 struct AttnParams {
@@ -204,6 +206,190 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
       tile_store<DH, C::VSTR>(rv, Vs[buf ^ 1], tid);
     }
     __syncthreads();
+  }
+  l += __shfl_xor(l, 32, 64);
+  if (query < p.S) {
+    const float inv = 1.0f / l;
+    bf16* op = p.out + (int64_t)b * p.osb + (int64_t)query * p.oss + h * DH;
+#pragma unroll
+    for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16)(ot[nb][4 * qd + e] * inv);
+        *reinterpret_cast<bf16x4*>(op + nb * 32 + 8 * qd + 4 * hh) = o;
+      }
+    if (hh == 0) p.lse[(int64_t)(b * p.H + h) * p.S + query] = (m * p.c + __log2f(l)) * LN2;
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------
+// forward, second work split: the default when dropout is on (ttts_debug_set_flags(65536) forces it, 131072 forbids it).
+// Why: with 128-query workgroups the launch is 640 blocks of 2..19 KV tiles and is bound by its longest blocks (19 x ~3.9 k
+// cycles), not by the matrix cores.  Here a workgroup owns 64 queries and walks 128 keys per iteration: wave (qh, kh) takes
+// query half qh and the kh-th 64-key tile with its own online-softmax state; the two key halves of a query half are merged
+// through LDS once at the end.  1216 blocks of <= 10 iterations instead of 640 of <= 19; the per-wave tile code is the
+// kernel above.  K / V super tiles are single-buffered in LDS (43 KB at d_h 64) behind a register prefetch.
+// -------------------------------------------------------------------------------------------------------
+template <int DH, int ROWS>
+__device__ __forceinline__ void tile_load_rows(bf16x8 (&r)[ROWS * (DH / 8) / 256], const bf16* base, int64_t stride, int row0,
+                                               int nrows, int tid) {
+#pragma unroll
+  for (int i = 0; i < ROWS * (DH / 8) / 256; ++i) {
+    const int c = tid + i * 256, row = c / (DH / 8), dc = (c % (DH / 8)) * 8;
+    r[i] = (row0 + row < nrows) ? *reinterpret_cast<const bf16x8*>(base + (int64_t)(row0 + row) * stride + dc) : zero8();
+  }
+}
+template <int DH, int ROWS, int STR>
+__device__ __forceinline__ void tile_store_rows(const bf16x8 (&r)[ROWS * (DH / 8) / 256], bf16* lds, int tid) {
+#pragma unroll
+  for (int i = 0; i < ROWS * (DH / 8) / 256; ++i) {
+    const int c = tid + i * 256, row = c / (DH / 8), dc = (c % (DH / 8)) * 8;
+    *reinterpret_cast<bf16x8*>(lds + row * STR + dc) = r[i];
+  }
+}
+
+template <int DH, bool DROPOUT>
+__global__ __launch_bounds__(256, (DH <= 64 ? 3 : 1)) void attn_fwd_kv2_kernel(AttnParams p) {
+  using C = AttnCfg<DH>;
+  constexpr int CPT2 = 128 * (DH / 8) / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char kv2_smem[];
+  bf16* Ks = reinterpret_cast<bf16*>(kv2_smem);                 // [128][KSTR]
+  bf16* Vs = Ks + 128 * C::KSTR;                                // [128][VSTR]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qh = wave & 1, kh = wave >> 1;
+  const int hh = lane >> 5, g = lane >> 4, ip = lane & 15;
+  const int nqb = (p.S + 63) / 64;
+  const int nbh = gridDim.x / nqb;
+  const int qb = nqb - 1 - (int)(blockIdx.x / nbh);             // longest blocks first
+  const int bh = blockIdx.x % nbh, h = bh % p.H, b = bh / p.H;
+  const int q0 = qb * 64;
+  const int q_base = q0 + qh * 32;
+  const int query = q_base + (lane & 31);
+  const bf16* qp = p.q + (int64_t)b * p.sb + h * DH;
+  const bf16* kp = p.k + (int64_t)b * p.sb + h * DH;
+  const bf16* vp = p.v + (int64_t)b * p.sb + h * DH;
+
+  bf16x8 qf[C::KS];
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks)
+    qf[ks] = query < p.S ? *reinterpret_cast<const bf16x8*>(qp + (int64_t)query * p.ss + ks * 16 + hh * 8) : zero8();
+  f32x16 ot[C::NB];
+#pragma unroll
+  for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[nb][r] = 0.f;
+  float m = NEG_BIG, l = 0.f;
+
+  const int kv_end = min(p.S, q0 + 64);
+  const int nsup = (kv_end + 127) / 128;
+  bf16x8 rk[CPT2], rv[CPT2];
+  tile_load_rows<DH, 128>(rk, kp, p.ss, 0, p.S, tid);
+  tile_load_rows<DH, 128>(rv, vp, p.ss, 0, p.S, tid);
+  const int k_nat = (lane & 31) * C::KSTR + hh * 8;
+  const int v_tr = (4 * hh + (ip >> 2)) * C::VSTR + 16 * (g & 1) + 4 * (ip & 3);
+  const uint32_t e_row = (uint32_t)(((int64_t)(b * p.H + h) * p.S + query) * p.Sp);
+  const uint32_t shi = DROPOUT ? seed_mix(p.seed_hi, p.ctr) : 0u;
+
+  for (int js = 0; js < nsup; ++js) {
+    __syncthreads();                                            // every wave is done reading the previous super tile
+    tile_store_rows<DH, 128, C::KSTR>(rk, Ks, tid);
+    tile_store_rows<DH, 128, C::VSTR>(rv, Vs, tid);
+    __syncthreads();
+    if (js + 1 < nsup) {                                        // next super tile's loads fly under this one's MFMAs
+      tile_load_rows<DH, 128>(rk, kp, p.ss, (js + 1) * 128, p.S, tid);
+      tile_load_rows<DH, 128>(rv, vp, p.ss, (js + 1) * 128, p.S, tid);
+    }
+    const int kv0 = js * 128 + kh * 64;                         // this wave's 64-key tile
+    if (kv0 <= q_base + 31 && kv0 < p.S) {                      // wave-uniform: some (query, key) pair is unmasked
+      const bf16* Kt = Ks + kh * 64 * C::KSTR;
+      const bf16* Vt = Vs + kh * 64 * C::VSTR;
+      f32x16 s[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Kt[k_nat + kb * 32 * C::KSTR + ks * 16]);
+          s[kb] = mfma32(kf, qf[ks], s[kb]);
+        }
+      }
+      if (kv0 + 63 > q_base || kv0 + 63 >= p.S) {               // diagonal / ragged tile: mask
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kv0 + kb * 32 + acc_row(r, hh);
+            if (key > query || key >= p.S) s[kb][r] = NEG_BIG;
+          }
+      }
+      float mx = NEG_BIG;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m - m_new) * p.c);
+      m = m_new;
+      const float m2 = m_new * p.c;
+      l *= alpha;
+#pragma unroll
+      for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[nb][r] *= alpha;
+      bf16x8 pf[2][2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          bool keep[4] = {true, true, true, true};
+          if (DROPOUT) drop_keep4(e_row + (uint32_t)(kv0 + kb * 32 + 8 * qd + 4 * hh), p.thr, p.seed_lo, shi, keep);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * qd + e;
+            float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][r], p.c, -m2));
+            l += pv;
+            if (DROPOUT) pv = keep[e] ? pv * p.inv_keep : 0.f;
+            pf[kb][r >> 3][r & 7] = (bf16)pv;
+          }
+        }
+#pragma unroll
+      for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int cs = 0; cs < 2; ++cs) {
+            const bf16* vt = &Vt[v_tr + (kb * 32 + 16 * cs) * C::VSTR + nb * 32];
+            const bf16x8 vf = cat4(lds_tr_b64(vt), lds_tr_b64(vt + 8 * C::VSTR));
+            ot[nb] = mfma32(vf, pf[kb][cs], ot[nb]);
+          }
+    }
+  }
+  // merge the two key halves of each query half: wave (qh, 1) hands (m, l, O) to wave (qh, 0), lane for lane
+  __syncthreads();
+  float* mb = reinterpret_cast<float*>(kv2_smem) + (size_t)(qh * 64 + lane) * (2 + C::NB * 16);
+  if (kh == 1) {
+    mb[0] = m; mb[1] = l;
+#pragma unroll
+    for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mb[2 + nb * 16 + r] = ot[nb][r];
+  }
+  __syncthreads();
+  if (kh == 1) return;
+  {
+    const float m_o = mb[0], l_o = mb[1];
+    const float M = fmaxf(m, m_o);
+    const float a1 = __builtin_amdgcn_exp2f((m - M) * p.c), a2 = __builtin_amdgcn_exp2f((m_o - M) * p.c);
+    l = l * a1 + l_o * a2;
+#pragma unroll
+    for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ot[nb][r] = ot[nb][r] * a1 + mb[2 + nb * 16 + r] * a2;
+    m = M;
   }
   l += __shfl_xor(l, 32, 64);
   if (query < p.S) {
@@ -568,6 +754,28 @@ extern "C" int ttts_attn_causal_fwd_bf16(const void* q, const void* k, const voi
   p.q = (const bf16*)q; p.k = (const bf16*)k; p.v = (const bf16*)v; p.out = (bf16*)o; p.lse = lse;
   const int grid = ((S + 127) / 128) * H * B;
   hipStream_t s = as_stream(stream);
+  // work split: with dropout the 64-query x 128-key kernel wins (36.1 vs 43.8 us at the BASELINE shape: the longest block is half
+  // as long); without dropout the two are equal (31.2 vs 30.4 us) and the 128-query kernel stays.  Flags force either one.
+  const bool use_kv2 = (g_debug_flags & 65536) || (p.thr && !(g_debug_flags & 131072));
+  if (use_kv2) {
+    const int grid2 = ((S + 63) / 64) * H * B;
+#define FWD2(DH)                                                                                                         \
+    {                                                                                                                    \
+      using C2 = AttnCfg<DH>;                                                                                            \
+      const size_t smem = (size_t)128 * (C2::KSTR + C2::VSTR) * sizeof(bf16);                                            \
+      static bool attr_set = false;                                                                                      \
+      if (!attr_set) {                                                                                                   \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kv2_kernel<DH, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kv2_kernel<DH, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        attr_set = true;                                                                                                 \
+      }                                                                                                                  \
+      if (p.thr) attn_fwd_kv2_kernel<DH, true><<<grid2, 256, smem, s>>>(p);                                              \
+      else attn_fwd_kv2_kernel<DH, false><<<grid2, 256, smem, s>>>(p);                                                   \
+    }
+    if (head_dim == 32) FWD2(32) else if (head_dim == 64) FWD2(64) else FWD2(128)
+#undef FWD2
+    return check_launch("attn_fwd_kv2");
+  }
 #define FWD(DH)                                                        \
   if (p.thr) attn_fwd_kernel<DH, true><<<grid, 256, 0, s>>>(p);        \
   else attn_fwd_kernel<DH, false><<<grid, 256, 0, s>>>(p);

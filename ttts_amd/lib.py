@@ -198,6 +198,8 @@ def get():
             fn.restype, fn.argtypes = res, args
         if lib.ttts_abi_version() != 1:
             raise TttsError("libttts_hip.so ABI version mismatch")
+        if os.environ.get("TTTS_DEBUG_FLAGS"):      # kernel-selection experiments (see ttts_debug_set_flags), e.g. tools/kernel_bench.py
+            lib.ttts_debug_set_flags(int(os.environ["TTTS_DEBUG_FLAGS"]))
         _lib = lib
     return _lib
 
