@@ -309,6 +309,34 @@ def test_attention_fwd_kv2_work_split_matches_default(ops, B, S, H, dh, p):
     assert (l2 - l1).abs().max().item() < 2e-3
 
 
+@pytest.mark.skipif(os.environ.get("TTTS_EXPERIMENTAL") != "1", reason="opt-in: kernels behind debug flags that are not yet the default")
+@pytest.mark.parametrize("B,S,H,dh,p", [(2, 1156, 8, 64, 0.1), (1, 130, 2, 64, 0.0), (3, 64, 4, 64, 0.1), (2, 38, 2, 32, 0.0)])
+def test_attention_bwd_dq_kv2_work_split_matches_default(ops, B, S, H, dh, p):
+    """ttts_debug_set_flags(262144): dQ from 64-query x 128-key workgroups == dQ from the default kernel (same mask), dK / dV untouched."""
+    from ttts_amd import lib
+    D = H * dh
+    g = torch.Generator(device="cpu").manual_seed(S + dh + 1)
+    qkv = _bf(torch.randn(B, S, 3 * D, generator=g)).to(dev())
+    do = _bf(torch.randn(B, S, D, generator=g)).to(dev())
+    q2 = qkv.view(B * S, 3 * D)
+    o = torch.zeros(B, S, D, dtype=torch.bfloat16, device=dev()); lse = torch.zeros(B, H, S, device=dev())
+    ops.attn_fwd(q2, q2[:, D:], q2[:, 2 * D:], o, lse, B, H, S, dh, (S * 3 * D, 3 * D), (S * D, D), dh ** -0.5, p, 99)
+
+    def run(flags):
+        dqkv = torch.zeros(B * S, 3 * D, dtype=torch.bfloat16, device=dev()); ws = torch.empty(B * H * S, device=dev())
+        lib.get().ttts_debug_set_flags(flags)
+        try:
+            ops.attn_bwd(q2, q2[:, D:], q2[:, 2 * D:], o, do, lse, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], ws, B, H, S, dh,
+                         (S * 3 * D, 3 * D), (S * D, D), dh ** -0.5, p, 99)
+        finally:
+            lib.get().ttts_debug_set_flags(0)
+        torch.cuda.synchronize()
+        return dqkv.float()
+    a, b2 = run(0), run(262144)
+    assert torch.equal(a[:, D:], b2[:, D:])                       # dK, dV: same kernel
+    assert rel_err(b2[:, :D], a[:, :D]) < 6e-3
+
+
 def test_dropout_counter_gives_fresh_masks(ops):
     """The device-side stream counter (graph-replay-safe dropout): same seed + same counter -> same mask,
     counter + 1 -> a different mask with the same keep rate."""

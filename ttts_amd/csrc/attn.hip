@@ -549,6 +549,135 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
 }
 
 // -------------------------------------------------------------------------------------------------------
+// backward: dQ with the forward's second work split (EXPERIMENTAL: ttts_debug_set_flags(262144), default off, written at the
+// end of round 1 without GPU time left to measure it).  64 queries per workgroup, 128 keys per iteration, wave (qh, kh) =
+// query half x key half; dQ^T needs no running max, so the two key halves are simply summed through LDS at the end.
+// -------------------------------------------------------------------------------------------------------
+template <int DH, bool DROPOUT>
+__global__ __launch_bounds__(256, (DH <= 64 ? 3 : 1)) void attn_bwd_dq_kv2_kernel(AttnParams p) {
+  using C = AttnCfg<DH>;
+  constexpr int CPT2 = 128 * (DH / 8) / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dq2_smem[];
+  bf16* Ks = reinterpret_cast<bf16*>(dq2_smem);                 // [128][KSTR]
+  bf16* Vs = Ks + 128 * C::KSTR;                                // [128][KSTR]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qh = wave & 1, kh = wave >> 1;
+  const int hh = lane >> 5, g = lane >> 4, ip = lane & 15;
+  const int nqb = (p.S + 63) / 64;
+  const int nbh = gridDim.x / nqb;
+  const int qb = nqb - 1 - (int)(blockIdx.x / nbh);
+  const int bh = blockIdx.x % nbh, h = bh % p.H, b = bh / p.H;
+  const int q0 = qb * 64;
+  const int q_base = q0 + qh * 32;
+  const int query = q_base + (lane & 31);
+  const bf16* qp = p.q + (int64_t)b * p.sb + h * DH;
+  const bf16* kp = p.k + (int64_t)b * p.sb + h * DH;
+  const bf16* vp = p.v + (int64_t)b * p.sb + h * DH;
+  const bf16* dop = p.d_o + (int64_t)b * p.osb + h * DH;
+
+  bf16x8 qf[C::KS], dof[C::KS];
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks) {
+    qf[ks] = query < p.S ? *reinterpret_cast<const bf16x8*>(qp + (int64_t)query * p.ss + ks * 16 + hh * 8) : zero8();
+    dof[ks] = query < p.S ? *reinterpret_cast<const bf16x8*>(dop + (int64_t)query * p.oss + ks * 16 + hh * 8) : zero8();
+  }
+  const int64_t stat = (int64_t)(b * p.H + h) * p.S + query;
+  const float lse2 = query < p.S ? p.lse_in[stat] * LOG2E : 0.f;
+  const float delta = query < p.S ? p.delta[stat] : 0.f;
+  f32x16 dqt[C::NB];
+#pragma unroll
+  for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dqt[nb][r] = 0.f;
+
+  const int kv_end = min(p.S, q0 + 64);
+  const int nsup = (kv_end + 127) / 128;
+  bf16x8 rk[CPT2], rv[CPT2];
+  tile_load_rows<DH, 128>(rk, kp, p.ss, 0, p.S, tid);
+  tile_load_rows<DH, 128>(rv, vp, p.ss, 0, p.S, tid);
+  const int k_nat = (lane & 31) * C::KSTR + hh * 8;
+  const int k_tr = (4 * hh + (ip >> 2)) * C::KSTR + 16 * (g & 1) + 4 * (ip & 3);
+  const uint32_t e_row = (uint32_t)(((int64_t)(b * p.H + h) * p.S + query) * p.Sp);
+  const uint32_t shi = DROPOUT ? seed_mix(p.seed_hi, p.ctr) : 0u;
+
+  for (int js = 0; js < nsup; ++js) {
+    __syncthreads();
+    tile_store_rows<DH, 128, C::KSTR>(rk, Ks, tid);
+    tile_store_rows<DH, 128, C::KSTR>(rv, Vs, tid);
+    __syncthreads();
+    if (js + 1 < nsup) {
+      tile_load_rows<DH, 128>(rk, kp, p.ss, (js + 1) * 128, p.S, tid);
+      tile_load_rows<DH, 128>(rv, vp, p.ss, (js + 1) * 128, p.S, tid);
+    }
+    const int kv0 = js * 128 + kh * 64;
+    if (kv0 <= q_base + 31 && kv0 < p.S) {
+      const bf16* Kt = Ks + kh * 64 * C::KSTR;
+      const bf16* Vt = Vs + kh * 64 * C::KSTR;
+      bf16x8 dsf[2][2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Kt[k_nat + kb * 32 * C::KSTR + ks * 16]);
+          const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vt[k_nat + kb * 32 * C::KSTR + ks * 16]);
+          s = mfma32(kf, qf[ks], s);
+          dp = mfma32(vf, dof[ks], dp);
+        }
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          bool keep[4] = {true, true, true, true};
+          if (DROPOUT) drop_keep4(e_row + (uint32_t)(kv0 + kb * 32 + 8 * qd + 4 * hh), p.thr, p.seed_lo, shi, keep);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * qd + e;
+            const int key = kv0 + kb * 32 + 8 * qd + 4 * hh + e;
+            const float pv = (key > query || key >= p.S) ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[r], p.c, -lse2));
+            float dpv = dp[r];
+            if (DROPOUT) dpv = keep[e] ? dpv * p.inv_keep : 0.f;
+            dsf[kb][r >> 3][r & 7] = (bf16)(pv * (dpv - delta));
+          }
+        }
+      }
+#pragma unroll
+      for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int cs = 0; cs < 2; ++cs) {
+            const bf16* kt = &Kt[k_tr + (kb * 32 + 16 * cs) * C::KSTR + nb * 32];
+            const bf16x8 kf = cat4(lds_tr_b64(kt), lds_tr_b64(kt + 8 * C::KSTR));
+            dqt[nb] = mfma32(kf, dsf[kb][cs], dqt[nb]);
+          }
+    }
+  }
+  __syncthreads();
+  float* mb = reinterpret_cast<float*>(dq2_smem) + (size_t)(qh * 64 + lane) * (C::NB * 16);
+  if (kh == 1) {
+#pragma unroll
+    for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mb[nb * 16 + r] = dqt[nb][r];
+  }
+  __syncthreads();
+  if (kh == 1) return;
+  if (query < p.S) {
+    bf16* dq = p.dq + (int64_t)b * p.sb + (int64_t)query * p.ss + h * DH;
+#pragma unroll
+    for (int nb = 0; nb < C::NB; ++nb)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16)((dqt[nb][4 * qd + e] + mb[nb * 16 + 4 * qd + e]) * p.scale);
+        *reinterpret_cast<bf16x4*>(dq + nb * 32 + 8 * qd + 4 * hh) = o;
+      }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------
 // backward: dK, dV (S form, one key per lane; loops over query tiles from the diagonal down)
 // -------------------------------------------------------------------------------------------------------
 template <int DH, bool DROPOUT>
@@ -804,17 +933,26 @@ extern "C" int ttts_attn_causal_bwd_bf16(const void* q, const void* k, const voi
   hipStream_t s = as_stream(stream);
   const int grid = ((S + 127) / 128) * H * B;
   const int dgrid = (int)cdiv((int64_t)B * S * H, 256);
+  const bool dq_kv2 = (g_debug_flags & 262144) != 0;   // experimental dQ work split (attn_bwd_dq_kv2_kernel), default off
+  const int grid2 = ((S + 63) / 64) * H * B;
+#define DQ2(DH, DROP)                                                                                                     \
+  {                                                                                                                       \
+    const size_t smem = (size_t)2 * 128 * AttnCfg<DH>::KSTR * sizeof(bf16);                                               \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kv2_kernel<DH, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    attn_bwd_dq_kv2_kernel<DH, DROP><<<grid2, 256, smem, s>>>(p);                                                         \
+  }
 #define BWD(DH)                                                             \
   attn_delta_kernel<DH><<<dgrid, 256, 0, s>>>(p);                          \
   if (p.thr) {                                                              \
     attn_bwd_dkdv_kernel<DH, true><<<grid, 256, 0, s>>>(p);                 \
-    attn_bwd_dq_kernel<DH, true><<<grid, 256, 0, s>>>(p);                   \
+    if (dq_kv2) DQ2(DH, true) else attn_bwd_dq_kernel<DH, true><<<grid, 256, 0, s>>>(p);   \
   } else {                                                                  \
     attn_bwd_dkdv_kernel<DH, false><<<grid, 256, 0, s>>>(p);                \
-    attn_bwd_dq_kernel<DH, false><<<grid, 256, 0, s>>>(p);                  \
+    if (dq_kv2) DQ2(DH, false) else attn_bwd_dq_kernel<DH, false><<<grid, 256, 0, s>>>(p); \
   }
   if (head_dim == 32) { BWD(32) } else if (head_dim == 64) { BWD(64) } else { BWD(128) }
 #undef BWD
+#undef DQ2
   return check_launch("attn_bwd");
 }
 
