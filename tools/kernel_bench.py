@@ -109,6 +109,11 @@ def bench_attn():
         us = timeit(lambda: ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], o, lse, B, H, S, dh, (S * 3 * D, 3 * D), (S * D, D), dh ** -0.5, p, 7))
         lib.get().ttts_debug_set_flags(0)
         out["fwd kv2 p=%.1f" % p] = "%.1f us  %.0f TF/s (causal-useful)" % (us, fl / us / 1e6)
+        lib.get().ttts_debug_set_flags(262144)    # experimental dQ work split
+        us = timeit(lambda: ops.attn_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], o, do, lse, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], ws, B, H, S, dh,
+                                         (S * 3 * D, 3 * D), (S * D, D), dh ** -0.5, p, 7))
+        lib.get().ttts_debug_set_flags(0)
+        out["bwd dq-kv2 p=%.1f" % p] = "%.1f us" % us
     return out
 
 

@@ -549,8 +549,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
 }
 
 // -------------------------------------------------------------------------------------------------------
-// backward: dQ with the forward's second work split (EXPERIMENTAL: ttts_debug_set_flags(262144), default off, written at the
-// end of round 1 without GPU time left to measure it).  64 queries per workgroup, 128 keys per iteration, wave (qh, kh) =
+// backward: dQ with the forward's second work split (EXPERIMENTAL: ttts_debug_set_flags(262144), default off: correct, but
+// measured slower than the 128-query kernel in this first form -- backward 134 -> 156 us with dropout at the BASELINE shape).  64 queries per workgroup, 128 keys per iteration, wave (qh, kh) =
 // query half x key half; dQ^T needs no running max, so the two key halves are simply summed through LDS at the end.
 // -------------------------------------------------------------------------------------------------------
 template <int DH, bool DROPOUT>
