@@ -550,7 +550,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
 
 // -------------------------------------------------------------------------------------------------------
 // backward: dQ with the forward's second work split (EXPERIMENTAL: ttts_debug_set_flags(262144), default off: correct, but
-// measured slower than the 128-query kernel in this first form -- backward 134 -> 156 us with dropout at the BASELINE shape).  64 queries per workgroup, 128 keys per iteration, wave (qh, kh) =
+// measured slower than the 128-query kernel in this first form -- backward 134 -> 156 us with dropout at the BASELINE shape;
+// that measurement still paid a hipFuncSetAttribute call per launch, since removed: re-measure before deciding).  64 queries per workgroup, 128 keys per iteration, wave (qh, kh) =
 // query half x key half; dQ^T needs no running max, so the two key halves are simply summed through LDS at the end.
 // -------------------------------------------------------------------------------------------------------
 template <int DH, bool DROPOUT>
@@ -938,7 +939,11 @@ extern "C" int ttts_attn_causal_bwd_bf16(const void* q, const void* k, const voi
 #define DQ2(DH, DROP)                                                                                                     \
   {                                                                                                                       \
     const size_t smem = (size_t)2 * 128 * AttnCfg<DH>::KSTR * sizeof(bf16);                                               \
-    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kv2_kernel<DH, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    static bool attr_set = false;   /* once per instantiation: the attribute call is not free on the launch path */      \
+    if (!attr_set) {                                                                                                      \
+      hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kv2_kernel<DH, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      attr_set = true;                                                                                                    \
+    }                                                                                                                     \
     attn_bwd_dq_kv2_kernel<DH, DROP><<<grid2, 256, smem, s>>>(p);                                                         \
   }
 #define BWD(DH)                                                             \
