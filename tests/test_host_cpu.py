@@ -175,17 +175,34 @@ def test_mel_basis_matches_oracle():
 
 
 def test_dropout_threshold_and_hash_reference():
-    """The dropout keep rule documented in DESIGN.md: 16 random bits per element from hash32(e >> 1)."""
+    """The dropout keep rule documented in DESIGN.md: 16 random bits per element from hash32(e >> 1), hash32 = two rounds of
+    24-bit multiply + xor-shift (csrc/common.hpp).  numpy emulation of the device function: keep rate of both halves, independence
+    of the two halves and of neighbouring elements, fresh masks for the next stream-counter value."""
+    M = np.uint64(0xFFFFFFFF)
+
     def hash32(x, lo, hi):
-        m = 0xFFFFFFFF
-        x = ((x ^ lo) + hi) & m
-        x ^= x >> 16; x = (x * 0x7FEB352D) & m; x ^= x >> 15; x = (x * 0x846CA68B) & m; x ^= x >> 16
+        x = ((x ^ np.uint64(lo)) + np.uint64(hi)) & M
+        x ^= x >> np.uint64(16)
+        x = ((x & np.uint64(0xFFFFFF)) * np.uint64(0x9E3779)) & M
+        x ^= x >> np.uint64(15)
+        x = ((x & np.uint64(0xFFFFFF)) * np.uint64(0x85EBCB)) & M
+        x ^= x >> np.uint64(16)
         return x
     thr = int(0.1 * 65536 + 0.5)
-    e = np.arange(200000)
-    bits = np.array([(hash32(int(i) >> 1, 12345, 678) >> (16 * (int(i) & 1))) & 0xFFFF for i in e])
-    keep = (bits >= thr).mean()
-    assert abs(keep - 0.9) < 0.005, keep
+    n = 1 << 20
+    r = hash32(np.arange(n, dtype=np.uint64), 12345, 678)
+    lo16, hi16 = (r & np.uint64(0xFFFF)).astype(np.int64), (r >> np.uint64(16)).astype(np.int64)
+    ka, kb = lo16 >= thr, hi16 >= thr
+    sig = (0.09 / n) ** 0.5
+    assert abs(ka.mean() - 0.9) < 5 * sig and abs(kb.mean() - 0.9) < 5 * sig
+    corr = lambda u, v: float(np.corrcoef(u.astype(float), v.astype(float))[0, 1])   # noqa: E731
+    assert abs(corr(ka, kb)) < 5e-3 and abs(corr(ka[:-1], ka[1:])) < 5e-3 and abs(corr(ka[:-578], ka[578:])) < 5e-3
+    r2 = hash32(np.arange(n, dtype=np.uint64), 12345, (678 + 0x9E3779B1) & 0xFFFFFFFF)      # seed_mix: next counter value
+    k2 = (r2 & np.uint64(0xFFFF)).astype(np.int64) >= thr
+    assert abs((ka == k2).mean() - 0.82) < 5e-3
+    for half in (lo16, hi16):                                                              # 256-bin uniformity of the 16 bits
+        c = np.bincount(half >> 8, minlength=256)
+        assert ((c - n / 256) ** 2 / (n / 256)).sum() < 400
 
 
 # ---- data-parallel exchange under gloo, world_size 2 --------------------------------------------------------------

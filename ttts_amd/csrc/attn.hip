@@ -739,7 +739,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
   __syncthreads();
   const int q_nat = (lane & 31) * C::KSTR + hh * 8;
   const int q_tr = (4 * hh + (ip >> 2)) * C::KSTR + 16 * (g & 1) + 4 * (ip & 3);
-  const uint32_t e_bh = (uint32_t)((int64_t)(b * p.H + h) * p.S);
+  const uint32_t e_bh = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((int64_t)(b * p.H + h) * p.S));   // uniform: keep it scalar
+  // mask index of (query, key) = (e_bh + query) * Sp + key (mod 2^32), split so that no 32-bit multiply (quarter rate) is left
+  // in the tile loop: lane part once, tile part on the scalar unit, row part through 24-bit multiplies of small constants
+  const uint32_t e_lane = __umul24((uint32_t)(4 * hh + (lane & 1)), (uint32_t)p.Sp) + (uint32_t)key;
   const uint32_t shi = DROPOUT ? seed_mix(p.seed_hi, p.ctr) : 0u;
 
   for (int qt = qt0; qt < nqt; ++qt) {
@@ -774,8 +777,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
             const int odd = lane & 1;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-              const int qmine = q0 + qs * 32 + 8 * qd + 4 * hh + 2 * t + odd;      // even lane: row 2t, odd lane: row 2t+1
-              const uint32_t mine = hash32(((e_bh + (uint32_t)qmine) * (uint32_t)p.Sp + (uint32_t)key) >> 1, p.seed_lo, shi);
+              // row q0 + qs*32 + 8*qd + 4*hh + 2*t + odd (even lane: row 2t, odd lane: row 2t+1)
+              const uint32_t e_tile = (e_bh + (uint32_t)(q0 + qs * 32)) * (uint32_t)p.Sp;                  // wave-uniform
+              const uint32_t mine = hash32((e_tile + __umul24((uint32_t)(8 * qd + 2 * t), (uint32_t)p.Sp) + e_lane) >> 1, p.seed_lo, shi);
               const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
               const uint32_t h0 = odd ? other : mine, h1 = odd ? mine : other;   // hashes of rows 2t and 2t+1
               keep4[2 * t] = (odd ? (h0 >> 16) : (h0 & 0xFFFFu)) >= p.thr;

@@ -85,14 +85,19 @@ __device__ __forceinline__ bf16x8 zero8() {
   return r;
 }
 
-// counter hash -> 32 random bits (dropout masks; deterministic in (seed, index), identical in forward and backward).
-// "lowbias32" finaliser (2 multiplies, 3 xor-shifts) over index ^ seed_lo, offset by seed_hi.
+// counter hash -> 32 random bits (dropout masks, sampler draws; deterministic in (seed, index), identical in forward and backward).
+// Two multiply / xor-shift rounds over index ^ seed_lo, offset by seed_hi, with 24-BIT multiplies: v_mul_u32_u24 is full rate
+// on CDNA while v_mul_lo_u32 is quarter rate -- with the 32-bit "lowbias32" finaliser the 32 multiplies per 32 x 64 score tile
+// cost as many cycles (512) as the tile's 16 MFMAs.  The xor-shifts fold the bits a 24-bit multiply ignores back in.  Not a
+// bijection (90 % distinct outputs over 2^22 consecutive indices) -- irrelevant for masks; keep rate, 256-bin chi-square of
+// both 16-bit halves, serial / cross-seed correlation and avalanche (0.494 .. 0.516 over all 32 input bits) are on par with
+// lowbias32 (numpy emulation, tests/test_host_cpu.py::test_dropout_threshold_and_hash_reference).
 __device__ __forceinline__ uint32_t hash32(uint32_t x, uint32_t seed_lo, uint32_t seed_hi) {
   x = (x ^ seed_lo) + seed_hi;
   x ^= x >> 16;
-  x *= 0x7FEB352Du;
+  x = __umul24(x, 0x9E3779u);      // low 24 bits of both operands, low 32 bits of the product
   x ^= x >> 15;
-  x *= 0x846CA68Bu;
+  x = __umul24(x, 0x85EBCBu);
   x ^= x >> 16;
   return x;
 }
