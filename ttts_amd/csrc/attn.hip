@@ -52,6 +52,15 @@ template <int DH> struct AttnCfg {
   static constexpr int CPR = DH / 8;                       // 16-byte chunks per row
 };
 
+// two fp32 -> one packed bf16 pair (v_cvt_pk_bf16_f32); the probability fragments are assembled from these words
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+
 // keep-mask bit for attention element e = ((b*H + h)*S + query)*Sp + key: 16 random bits, two elements per hash
 __device__ __forceinline__ bool drop_keep(uint32_t e, uint32_t thr, uint32_t slo, uint32_t shi) {
   const uint32_t r = hash32(e >> 1, slo, shi);
@@ -176,20 +185,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         for (int r = 0; r < 16; ++r) ot[nb][r] *= alpha;
       bf16x8 pf[2][2];
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < 2; ++kb) {
+        u32x4_t pw[2];
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
           bool keep[4] = {true, true, true, true};
           if (DROPOUT) drop_keep4(e_row + (uint32_t)(kv0 + kb * 32 + 8 * qd + 4 * hh), p.thr, p.seed_lo, shi, keep);
+          float pv[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const int r = 4 * qd + e;
-            float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][r], p.c, -m2));
-            l += pv;
-            if (DROPOUT) pv = keep[e] ? pv * p.inv_keep : 0.f;
-            pf[kb][r >> 3][r & 7] = (bf16)pv;
+            pv[e] = __builtin_amdgcn_exp2f(fmaf(s[kb][4 * qd + e], p.c, -m2));
+            l += pv[e];
+            if (DROPOUT) pv[e] = keep[e] ? pv[e] : 0.f;    // the 1 / keep factor is applied once, with 1 / l, at the end
           }
+          pw[qd >> 1][2 * (qd & 1)] = pack_bf16x2(pv[0], pv[1]);
+          pw[qd >> 1][2 * (qd & 1) + 1] = pack_bf16x2(pv[2], pv[3]);
         }
+        pf[kb][0] = __builtin_bit_cast(bf16x8, pw[0]);
+        pf[kb][1] = __builtin_bit_cast(bf16x8, pw[1]);
+      }
 #pragma unroll
       for (int nb = 0; nb < C::NB; ++nb)
 #pragma unroll
@@ -209,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   }
   l += __shfl_xor(l, 32, 64);
   if (query < p.S) {
-    const float inv = 1.0f / l;
+    const float inv = (DROPOUT ? p.inv_keep : 1.0f) / l;
     bf16* op = p.out + (int64_t)b * p.osb + (int64_t)query * p.oss + h * DH;
 #pragma unroll
     for (int nb = 0; nb < C::NB; ++nb)
@@ -342,20 +356,25 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 3 : 1)) void attn_fwd_kv2_kernel(A
         for (int r = 0; r < 16; ++r) ot[nb][r] *= alpha;
       bf16x8 pf[2][2];
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < 2; ++kb) {
+        u32x4_t pw[2];
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
           bool keep[4] = {true, true, true, true};
           if (DROPOUT) drop_keep4(e_row + (uint32_t)(kv0 + kb * 32 + 8 * qd + 4 * hh), p.thr, p.seed_lo, shi, keep);
+          float pv[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const int r = 4 * qd + e;
-            float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][r], p.c, -m2));
-            l += pv;
-            if (DROPOUT) pv = keep[e] ? pv * p.inv_keep : 0.f;
-            pf[kb][r >> 3][r & 7] = (bf16)pv;
+            pv[e] = __builtin_amdgcn_exp2f(fmaf(s[kb][4 * qd + e], p.c, -m2));
+            l += pv[e];
+            if (DROPOUT) pv[e] = keep[e] ? pv[e] : 0.f;    // the 1 / keep factor is applied once, with 1 / l, at the end
           }
+          pw[qd >> 1][2 * (qd & 1)] = pack_bf16x2(pv[0], pv[1]);
+          pw[qd >> 1][2 * (qd & 1) + 1] = pack_bf16x2(pv[2], pv[3]);
         }
+        pf[kb][0] = __builtin_bit_cast(bf16x8, pw[0]);
+        pf[kb][1] = __builtin_bit_cast(bf16x8, pw[1]);
+      }
 #pragma unroll
       for (int nb = 0; nb < C::NB; ++nb)
 #pragma unroll
@@ -393,7 +412,7 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 3 : 1)) void attn_fwd_kv2_kernel(A
   }
   l += __shfl_xor(l, 32, 64);
   if (query < p.S) {
-    const float inv = 1.0f / l;
+    const float inv = (DROPOUT ? p.inv_keep : 1.0f) / l;
     bf16* op = p.out + (int64_t)b * p.osb + (int64_t)query * p.oss + h * DH;
 #pragma unroll
     for (int nb = 0; nb < C::NB; ++nb)
@@ -502,10 +521,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
           s = mfma32(kf, qf[ks], s);
           dp = mfma32(vf, dof[ks], dp);
         }
+        u32x4_t dsw[2];
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
           bool keep[4] = {true, true, true, true};
           if (DROPOUT) drop_keep4(e_row + (uint32_t)(kv0 + kb * 32 + 8 * qd + 4 * hh), p.thr, p.seed_lo, shi, keep);
+          float ds[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int r = 4 * qd + e;
@@ -513,9 +534,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
             const float pv = (key > query || key >= p.S) ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[r], p.c, -lse2));
             float dpv = dp[r];
             if (DROPOUT) dpv = keep[e] ? dpv * p.inv_keep : 0.f;
-            dsf[kb][r >> 3][r & 7] = (bf16)(pv * (dpv - delta));
+            ds[e] = pv * (dpv - delta);
           }
+          dsw[qd >> 1][2 * (qd & 1)] = pack_bf16x2(ds[0], ds[1]);
+          dsw[qd >> 1][2 * (qd & 1) + 1] = pack_bf16x2(ds[2], ds[3]);
         }
+        dsf[kb][0] = __builtin_bit_cast(bf16x8, dsw[0]);
+        dsf[kb][1] = __builtin_bit_cast(bf16x8, dsw[1]);
       }
 #pragma unroll
       for (int nb = 0; nb < C::NB; ++nb)
@@ -551,11 +576,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
 // -------------------------------------------------------------------------------------------------------
 // backward: dQ with the forward's second work split (EXPERIMENTAL: ttts_debug_set_flags(262144), default off: correct, but
 // measured slower than the 128-query kernel in this first form -- backward 134 -> 156 us with dropout at the BASELINE shape;
-// that measurement still paid a hipFuncSetAttribute call per launch, since removed: re-measure before deciding).  64 queries per workgroup, 128 keys per iteration, wave (qh, kh) =
+// that build was forced to 3 waves/SIMD and spilled 77 VGPRs (it needs ~200 with the 128-row prefetch registers) and paid a
+// hipFuncSetAttribute call per launch; both fixed since: re-measure before deciding).  64 queries per workgroup, 128 keys per iteration, wave (qh, kh) =
 // query half x key half; dQ^T needs no running max, so the two key halves are simply summed through LDS at the end.
 // -------------------------------------------------------------------------------------------------------
 template <int DH, bool DROPOUT>
-__global__ __launch_bounds__(256, (DH <= 64 ? 3 : 1)) void attn_bwd_dq_kv2_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_bwd_dq_kv2_kernel(AttnParams p) {
   using C = AttnCfg<DH>;
   constexpr int CPT2 = 128 * (DH / 8) / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char dq2_smem[];
@@ -627,10 +653,12 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 3 : 1)) void attn_bwd_dq_kv2_kerne
           s = mfma32(kf, qf[ks], s);
           dp = mfma32(vf, dof[ks], dp);
         }
+        u32x4_t dsw[2];
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
           bool keep[4] = {true, true, true, true};
           if (DROPOUT) drop_keep4(e_row + (uint32_t)(kv0 + kb * 32 + 8 * qd + 4 * hh), p.thr, p.seed_lo, shi, keep);
+          float ds[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int r = 4 * qd + e;
@@ -638,9 +666,13 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 3 : 1)) void attn_bwd_dq_kv2_kerne
             const float pv = (key > query || key >= p.S) ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[r], p.c, -lse2));
             float dpv = dp[r];
             if (DROPOUT) dpv = keep[e] ? dpv * p.inv_keep : 0.f;
-            dsf[kb][r >> 3][r & 7] = (bf16)(pv * (dpv - delta));
+            ds[e] = pv * (dpv - delta);
           }
+          dsw[qd >> 1][2 * (qd & 1)] = pack_bf16x2(ds[0], ds[1]);
+          dsw[qd >> 1][2 * (qd & 1) + 1] = pack_bf16x2(ds[2], ds[3]);
         }
+        dsf[kb][0] = __builtin_bit_cast(bf16x8, dsw[0]);
+        dsf[kb][1] = __builtin_bit_cast(bf16x8, dsw[1]);
       }
 #pragma unroll
       for (int nb = 0; nb < C::NB; ++nb)
@@ -766,6 +798,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
           dp = mfma32(da, vf[ks], dp);
         }
         bf16x8 pf[2], dsf[2];
+        u32x4_t pw[2], dsw[2];
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
           const f32x4 l4 = *reinterpret_cast<const f32x4*>(&Ls[buf][qs * 32 + 8 * qd + 4 * hh]);
@@ -786,22 +819,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
               keep4[2 * t + 1] = (odd ? (h1 >> 16) : (h1 & 0xFFFFu)) >= p.thr;
             }
           }
+          float pd[4], ds[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int r = 4 * qd + e;
             const int query = q0 + qs * 32 + 8 * qd + 4 * hh + e;
-            float pv = (key > query || query >= p.S) ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[r], p.c, -l4[e]));
+            const float pv = (key > query || query >= p.S) ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[r], p.c, -l4[e]));
             float dpv = dp[r];
-            float pd = pv;
+            pd[e] = pv;
             if (DROPOUT) {
               const bool keep = keep4[e];
               dpv = keep ? dpv * p.inv_keep : 0.f;
-              pd = keep ? pv * p.inv_keep : 0.f;
+              pd[e] = keep ? pv : 0.f;                     // dV's 1 / keep factor is applied once, when dV is stored
             }
-            pf[r >> 3][r & 7] = (bf16)pd;
-            dsf[r >> 3][r & 7] = (bf16)(pv * (dpv - d4[e]));
+            ds[e] = pv * (dpv - d4[e]);
           }
+          pw[qd >> 1][2 * (qd & 1)] = pack_bf16x2(pd[0], pd[1]);
+          pw[qd >> 1][2 * (qd & 1) + 1] = pack_bf16x2(pd[2], pd[3]);
+          dsw[qd >> 1][2 * (qd & 1)] = pack_bf16x2(ds[0], ds[1]);
+          dsw[qd >> 1][2 * (qd & 1) + 1] = pack_bf16x2(ds[2], ds[3]);
         }
+        pf[0] = __builtin_bit_cast(bf16x8, pw[0]); pf[1] = __builtin_bit_cast(bf16x8, pw[1]);
+        dsf[0] = __builtin_bit_cast(bf16x8, dsw[0]); dsf[1] = __builtin_bit_cast(bf16x8, dsw[1]);
 #pragma unroll
         for (int nb = 0; nb < C::NB; ++nb)
 #pragma unroll
@@ -833,7 +872,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           ok[e] = (bf16)(dkt[nb][4 * qd + e] * p.scale);
-          ov[e] = (bf16)dvt[nb][4 * qd + e];
+          ov[e] = (bf16)(DROPOUT ? dvt[nb][4 * qd + e] * p.inv_keep : dvt[nb][4 * qd + e]);
         }
         *reinterpret_cast<bf16x4*>(dk + nb * 32 + 8 * qd + 4 * hh) = ok;
         *reinterpret_cast<bf16x4*>(dv + nb * 32 + 8 * qd + 4 * hh) = ov;
