@@ -311,8 +311,9 @@ def test_attention_fwd_kv2_work_split_matches_default(ops, B, S, H, dh, p):
 
 @pytest.mark.skipif(os.environ.get("TTTS_EXPERIMENTAL") != "1", reason="opt-in: kernels behind debug flags that are not yet the default")
 @pytest.mark.parametrize("B,S,H,dh,p", [(2, 1156, 8, 64, 0.1), (1, 130, 2, 64, 0.0), (3, 64, 4, 64, 0.1), (2, 38, 2, 32, 0.0)])
-def test_attention_bwd_dq_kv2_work_split_matches_default(ops, B, S, H, dh, p):
-    """ttts_debug_set_flags(262144): dQ from 64-query x 128-key workgroups == dQ from the default kernel (same mask), dK / dV untouched."""
+def test_attention_bwd_kv2_work_splits_match_default(ops, B, S, H, dh, p):
+    """ttts_debug_set_flags(262144) / (524288): dQ resp. dK, dV from the 64 x 128 work splits == the default kernels' (same mask);
+    the other outputs are untouched."""
     from ttts_amd import lib
     D = H * dh
     g = torch.Generator(device="cpu").manual_seed(S + dh + 1)
@@ -335,6 +336,9 @@ def test_attention_bwd_dq_kv2_work_split_matches_default(ops, B, S, H, dh, p):
     a, b2 = run(0), run(262144)
     assert torch.equal(a[:, D:], b2[:, D:])                       # dK, dV: same kernel
     assert rel_err(b2[:, :D], a[:, :D]) < 6e-3
+    c = run(524288)                                               # dK / dV from 64-key x 128-query workgroups, dQ untouched
+    assert torch.equal(a[:, :D], c[:, :D])
+    assert rel_err(c[:, D:2 * D], a[:, D:2 * D]) < 6e-3 and rel_err(c[:, 2 * D:], a[:, 2 * D:]) < 6e-3
 
 
 def test_dropout_counter_gives_fresh_masks(ops):

@@ -14,6 +14,8 @@ echo "=== bench, default"
 timeout 120 python bench.py --no-cpu-baseline 2>/dev/null | python -c "import sys, json; d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['all_kernels_ms_per_step'])"
 echo "=== bench, dQ work split (flag 262144)"
 TTTS_DEBUG_FLAGS=262144 timeout 120 python bench.py --no-cpu-baseline 2>/dev/null | python -c "import sys, json; d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['all_kernels_ms_per_step'])"
+echo "=== bench, dK/dV work split (flag 524288)"
+TTTS_DEBUG_FLAGS=524288 timeout 120 python bench.py --no-cpu-baseline 2>/dev/null | python -c "import sys, json; d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['all_kernels_ms_per_step'])"
 echo "=== bench, forward forced to the 128-query kernel (flag 131072)"
 TTTS_DEBUG_FLAGS=131072 timeout 120 python bench.py --no-cpu-baseline 2>/dev/null | python -c "import sys, json; d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['all_kernels_ms_per_step'])"
 } > gpurun_out/round2_first.log 2>&1

@@ -114,6 +114,12 @@ def bench_attn():
                                          (S * 3 * D, 3 * D), (S * D, D), dh ** -0.5, p, 7))
         lib.get().ttts_debug_set_flags(0)
         out["bwd dq-kv2 p=%.1f" % p] = "%.1f us" % us
+        for fl_, tag in ((524288, "dkdv-kv2"), (262144 | 524288, "dq+dkdv-kv2")):
+            lib.get().ttts_debug_set_flags(fl_)
+            us = timeit(lambda: ops.attn_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], o, do, lse, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], ws, B, H, S, dh,
+                                             (S * 3 * D, 3 * D), (S * D, D), dh ** -0.5, p, 7))
+            lib.get().ttts_debug_set_flags(0)
+            out["bwd %s p=%.1f" % (tag, p)] = "%.1f us" % us
     return out
 
 
