@@ -18,10 +18,10 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden", "diffusion.npz")
 @pytest.fixture(autouse=True)
 def _exact_convs():
     """fp32-tolerance parity: run the exact convolution kernels (see tests/test_gpu_vqvae.py)."""
-    from ttts_amd import lib
-    lib.get().ttts_debug_set_flags(4096)
+    from ttts_amd import ops as _ops
+    _ops.set_conv_precision("exact")
     yield
-    lib.get().ttts_debug_set_flags(0)
+    _ops.set_conv_precision("split_bf16")
 
 
 def _dev():

@@ -181,10 +181,25 @@ def test_trainer_entry_point(gpt, tmp_path):
     ckpts = sorted(tr.logs_folder.glob("model-*.pt"))
     assert ckpts, list(tr.logs_folder.iterdir())
     data = torch.load(ckpts[-1], map_location="cpu")
-    assert set(data.keys()) == {"step", "model"} and len(data["model"]) == 12 * 2 + 12
+    # the reference's two keys (ttts/gpt/train.py:70-77) + the AdamW moments its loader ignores
+    assert set(data.keys()) == {"step", "model", "optimizer"} and len(data["model"]) == 12 * 2 + 12
     tr2 = Trainer(str(p))
     tr2.load(str(ckpts[-1]))
     assert data["step"] == 2 and torch.equal(tr2.gpt.engine.params.cpu(), tr.gpt.engine.params.cpu())
+    assert float(tr2.gpt.engine.opt_state[0]) == 3.0 and torch.equal(tr2.gpt.engine.exp_avg.cpu(), data["optimizer"]["exp_avg"])
+    # a reference-format checkpoint ({'step','model'} only) resumes like the reference: fresh AdamW, warm-up restarted
+    ref_ck = tmp_path / "ref.pt"
+    torch.save({"step": data["step"], "model": data["model"]}, ref_ck)
+    tr2.load(str(ref_ck))
+    assert float(tr2.gpt.engine.opt_state[0]) == 0.0 and float(tr2.gpt.engine.exp_avg.abs().sum()) == 0.0
+    # reference-style callers: .cuda() / .to(device) / zero_grad() keep the arena views intact
+    m = tr2.gpt
+    assert m.cuda() is m and m.to(m.engine.device) is m
+    with pytest.raises(NotImplementedError):
+        m.half()
+    m.engine.grads.fill_(1.0)
+    m.zero_grad()
+    assert float(m.engine.grads.abs().sum()) == 0.0 and m.mel_head.weight.grad.data_ptr() == m.engine.view(m.engine.grads, "mel_head.weight").data_ptr()
     log = [json.loads(l) for l in open(tr.logs_folder / "train_log.jsonl")]
     assert len(log) == 3 and all(np.isfinite(r["loss"]) for r in log)
 

@@ -270,3 +270,63 @@ def test_gpt_collater_and_vq_file_format(tmp_path):
     assert batch["padded_qmel"].shape == (2, 9) and batch["padded_qmel"][0, 5:].eq(0).all()
     assert batch["wav_lens"].tolist() == [24000, 48000]
     assert GptTtsCollater()([None, None]) is None
+
+
+def test_bucket_sampler_matches_reference_batches(golden_dir):
+    """DistributedBucketSampler: every batch of every rank, two epochs, five configurations, against the batches the
+    reference's own class produced (tools/make_goldens.py gen_sampler)."""
+    from ttts_amd.vqvae.dataset import DistributedBucketSampler, VQVAECollater
+    fx = json.load(open(os.path.join(golden_dir, "sampler.json")))
+
+    class DS:
+        lengths = fx["lengths"]
+
+        def __len__(self):
+            return len(self.lengths)
+    for case in fx["cases"]:
+        seen = []
+        for rank, want in enumerate(case["ranks"]):
+            smp = DistributedBucketSampler(DS(), case["batch_size"], list(case["boundaries"]), num_replicas=case["world"],
+                                           rank=rank, shuffle=case["shuffle"])
+            assert len(smp) == want["len"] and list(smp.boundaries) == want["boundaries_after"]
+            assert list(smp.num_samples_per_bucket) == want["num_samples_per_bucket"]
+            for epoch in ("1", "2"):
+                smp.set_epoch(int(epoch))
+                got = [list(b) for b in smp]
+                assert got == want["batches"][epoch], (case["world"], rank, epoch)
+            seen.append(got)
+        # data-parallel property: same number of batches on every rank, k-th batches come from the same bucket
+        assert len({len(s) for s in seen}) == 1
+    # collater: zero padding, rows by decreasing wav length, None items dropped
+    items = [(torch.ones(1, 5), torch.tensor([1, 2])), None, (torch.ones(1, 9) * 2, torch.tensor([3])), (torch.ones(1, 7) * 3, torch.tensor([4, 5, 6]))]
+    out = VQVAECollater()(items)
+    assert out["wav"].shape == (3, 9) and out["wav_lengths"].tolist() == [9, 7, 5] and out["text_lengths"].tolist() == [1, 3, 2]
+    assert out["wav"][1, 7:].abs().sum() == 0 and out["text"][0].tolist() == [3, 0, 0]
+
+
+def test_reference_import_names_and_signatures():
+    """The drop-in boundary: the reference's module paths and entry-point signatures resolve to this build."""
+    import inspect
+    import ttts.gpt.model, ttts.gpt.train, ttts.vqvae.train, ttts.vqvae.vq2, ttts.vqvae.modules, ttts.vqvae.attentions  # noqa: E401
+    import ttts.vqvae.losses, ttts.vqvae.quantize, ttts.vqvae.core_vq, ttts.vqvae.dataset, ttts.utils.data_utils  # noqa: E401
+    import ttts.utils.commons, ttts.utils.vc_utils, ttts.utils.utils, ttts.diffusion.aa_model, ttts.prepare.extract_vq  # noqa: E401
+    import ttts_amd
+    assert ttts.gpt.model.UnifiedVoice is ttts_amd.gpt.UnifiedVoice
+    assert list(inspect.signature(ttts.vqvae.train.train_and_evaluate).parameters) == [
+        "rank", "epoch", "hps", "nets", "optims", "schedulers", "scaler", "loaders", "logger", "writers", "aug"]   # ttts/vqvae/train.py:298-300
+    assert list(inspect.signature(ttts.vqvae.train.run).parameters)[:3] == ["rank", "n_gpus", "hps"]                 # :119
+    assert callable(ttts.vqvae.train.main) and callable(ttts.gpt.train.Trainer.train)
+    p = inspect.signature(ttts.gpt.train.Trainer.__init__).parameters
+    assert list(p)[:2] == ["self", "cfg_path"]
+    fwd = list(inspect.signature(ttts.gpt.model.UnifiedVoice.forward).parameters)
+    assert fwd == ["self", "text_inputs", "text_lengths", "mel_codes", "wav_lengths", "types", "text_first", "raw_mels",
+                   "return_attentions", "return_latent", "clip_inputs"]
+    for name in ("SynthesizerTrn", "MultiPeriodDiscriminator", "Generator", "PosteriorAudioEncoder", "TextEncoder", "MRTE",
+                 "ResidualCouplingBlock", "DiscriminatorP", "DiscriminatorS"):
+        assert hasattr(ttts.vqvae.vq2, name), name
+    for name in ("spectrogram_torch", "spec_to_mel_torch", "mel_spectrogram_torch", "HParams"):
+        assert hasattr(ttts.utils.data_utils, name), name
+    # `python -m ttts.gpt.train` / `python -m ttts.vqvae.train` exist as runnable modules
+    import importlib.util
+    for mod in ("ttts.gpt.train", "ttts.vqvae.train"):
+        assert importlib.util.find_spec(mod) is not None

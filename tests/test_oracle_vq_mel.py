@@ -243,3 +243,28 @@ def test_synthesizer_forward_restatement(golden_dir):
         assert err <= tol * np.abs(g[k]).max() + 1e-6, (k, err, np.abs(g[k]).max())
     np.testing.assert_allclose(commit.item(), g["commit"], rtol=1e-4)
     np.testing.assert_allclose(buffers["cluster_size"].numpy(), g["cb_cluster_size"], rtol=1e-5)
+
+
+def kmeans_case(g, name):
+    seed, N, Kc = (int(v) for v in g[name + ":x_seed_N_K"])
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((N, D), dtype=np.float32)
+    x[: N // 2] += rng.standard_normal((1, D), dtype=np.float32) * 2.0
+    return torch.from_numpy(x), Kc, [torch.from_numpy(d) for d in g[name + ":draws"]]
+
+
+def test_kmeans_init_and_dead_code_expiry(golden_dir):
+    """First training batch of an un-initialised codebook (core_vq.py:141-168,205-230), random index draws injected."""
+    g = np.load(os.path.join(golden_dir, "vq.npz"))
+    for name in ("kmeans_perm", "kmeans_randint"):
+        x, Kc, draws = kmeans_case(g, name)
+        assert int(g[name + ":n_draws_used"]) == 2          # the k-means seed AND the expiry draw were consumed
+        buf = {"embed": torch.zeros(Kc, D), "embed_avg": torch.zeros(Kc, D), "cluster_size": torch.zeros(Kc),
+               "inited": torch.zeros(1)}
+        q, ind = vq_ref.codebook_forward(x, buf, True, kmeans_iters=4, draws=draws)
+        assert np.array_equal(ind.numpy(), g[name + ":ind"]), name
+        np.testing.assert_allclose(q.numpy(), g[name + ":quantize"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(buf["cluster_size"].numpy(), g[name + ":cluster_size"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(buf["embed_avg"].numpy(), g[name + ":embed_avg"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(buf["embed"].numpy(), g[name + ":embed"], rtol=1e-5, atol=1e-5)
+        assert float(buf["inited"]) == float(g[name + ":inited"][0]) == 1.0

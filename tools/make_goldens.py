@@ -195,6 +195,39 @@ def gen_vq():
     rec["train:cluster_size"] = code.cluster_size.numpy().copy()
     rec["train:embed_avg_sample"] = sample(code.embed_avg, 8192)
     rec["train:embed_sample"] = sample(code.embed, 8192)
+    # (d) first training batch of an un-initialised codebook: k-means init (core_vq.py:71-93,141-148), then the search, then
+    #     dead-code expiry (:152-168), EMA and normalisation (:216-228).  The only random draws are the index vectors of
+    #     `sample_vectors` (randperm[:num] when there are enough samples, randint otherwise): they are injected.
+    for name, Kc, N, seed in (("kmeans_perm", 64, 300, 41), ("kmeans_randint", 512, 300, 42)):
+        rng = np.random.default_rng(seed)
+        x = rng.standard_normal((N, D), dtype=np.float32)
+        x[: N // 2] += rng.standard_normal((1, D), dtype=np.float32) * 2.0        # two loose clouds
+        draws = [rng.permutation(N)[:Kc] if N >= Kc else rng.integers(0, N, Kc), rng.permutation(N)[:Kc] if N >= Kc else rng.integers(0, N, Kc)]
+        queue = [torch.from_numpy(d.astype(np.int64)) for d in draws]
+        used = []
+
+        def injected(samples, num, _q=queue, _u=used):
+            idx = _q.pop(0)
+            assert idx.numel() == num and int(idx.max()) < samples.shape[0]
+            _u.append(num)
+            return samples[idx]
+        cbk = cv.EuclideanCodebook(dim=D, codebook_size=Kc, kmeans_init=True, kmeans_iters=4, threshold_ema_dead_code=2)
+        cbk.train()
+        orig = cv.sample_vectors
+        cv.sample_vectors = injected
+        try:
+            qz, ind = cbk(torch.from_numpy(x))
+        finally:
+            cv.sample_vectors = orig
+        rec[name + ":x_seed_N_K"] = np.array([seed, N, Kc], np.int64)
+        rec[name + ":draws"] = np.stack(draws).astype(np.int64)
+        rec[name + ":n_draws_used"] = np.int64(len(used))
+        rec[name + ":ind"] = ind.numpy().astype(np.int64)
+        rec[name + ":quantize"] = qz.numpy()
+        rec[name + ":cluster_size"] = cbk.cluster_size.numpy().copy()
+        rec[name + ":embed_avg"] = cbk.embed_avg.numpy().copy()
+        rec[name + ":embed"] = cbk.embed.numpy().copy()
+        rec[name + ":inited"] = cbk.inited.numpy().copy()
     np.savez_compressed(os.path.join(OUT, "vq.npz"), **rec)
     print("G3 vq:", {k: v.shape for k, v in rec.items() if k.endswith("idx")}, "commit", float(commit))
 
@@ -501,6 +534,28 @@ def gen_step():
     g_before = {k: p.detach().clone() for k, p in net_g.named_parameters()}
     d_before = {k: p.detach().clone() for k, p in net_d.named_parameters()}
     orig_randn_like, orig_slice = torch.randn_like, commons.rand_slice_segments
+    # code extraction (vq2.py:912-919 is not runnable as written: undefined `y_lengths`, full-rate mask on the half-rate
+    # projection -- SURVEY App. B): the same reference modules composed as the training forward composes them
+    # (ref_enc -> enc_p -> proj -> quantizer), eval mode, posterior noise zero, on a copy taken BEFORE the step
+    ng_eval = vq2.SynthesizerTrn(h["filter_length"] // 2 + 1, h["segment_size"] // h["hop_length"], **cfg)
+    ng_eval.load_state_dict(net_g.state_dict())
+    ng_eval.eval()
+    torch.randn_like = lambda t_, *a, **k: torch.zeros_like(t_)
+    try:
+        with torch.no_grad():
+            spec0 = du.spectrogram_torch(wav, h["filter_length"], h["hop_length"], h["win_length"], center=False).squeeze(0)
+            sl0 = torch.LongTensor([x // h["hop_length"] for x in wav_lengths])
+            m0 = torch.unsqueeze(commons.sequence_mask(sl0, spec0.size(2)), 1).to(spec0.dtype)
+            ge0 = ng_eval.ref_enc(spec0 * m0, m0)
+            x0, _, _ = ng_eval.enc_p(spec0, wav.unsqueeze(1), m0, g=ge0)
+            _, latent_codes, _, _ = ng_eval.quantizer(ng_eval.proj(x0))
+            latent_codes = latent_codes.transpose(0, 1).clone()
+    finally:
+        torch.randn_like = orig_randn_like
+    box = {}
+    def grab(mod, inp, out):          # a forward hook must return None, or its value replaces the module output
+        box["codes"] = out[1].detach().clone()
+    hook = net_g.quantizer.register_forward_hook(grab)
     torch.randn_like = fake_randn_like; commons.rand_slice_segments = fake_slice
     try:
         spec = du.spectrogram_torch(wav, h["filter_length"], h["hop_length"], h["win_length"], center=False).squeeze(0)
@@ -509,6 +564,7 @@ def gen_step():
             wav, wav, wav_lengths, spec, spec, spec_lengths, text, text_lengths)
     finally:
         torch.randn_like = orig_randn_like; commons.rand_slice_segments = orig_slice
+        hook.remove()
     assert calls["n"] == 2
     mel = du.spec_to_mel_torch(spec, h["filter_length"], h["n_mel_channels"], h["sampling_rate"], h["mel_fmin"], h["mel_fmax"])
     y_mel = commons.slice_segments(mel, ids_slice, h["segment_size"] // h["hop_length"])
@@ -543,7 +599,8 @@ def gen_step():
            "g_delta_abs": np.array([(p.detach() - g_before[k]).abs().sum().item() for k, p in net_g.named_parameters()]),
            "d_delta_abs": np.array([(p.detach() - d_before[k]).abs().sum().item() for k, p in net_d.named_parameters()]),
            "cb_cluster_size": cb.cluster_size.numpy(), "cb_embed_avg_sum": cb.embed_avg.sum(1).numpy(),
-           "cb_embed_head": cb.embed[:8].numpy(), "hps": np.array(json.dumps(h)), "cfg": np.array(json.dumps(cfg))}
+           "cb_embed_head": cb.embed[:8].numpy(), "hps": np.array(json.dumps(h)), "cfg": np.array(json.dumps(cfg)),
+           "codes": box["codes"].numpy().astype(np.int64), "latent_codes": latent_codes.numpy().astype(np.int64)}
     np.savez_compressed(os.path.join(OUT, "vqvae_step.npz"), **rec)
     print("G8 step losses:", rec["losses"], "norms", rec["grad_norms"], "unused g params:", int((g_grad_abs < 0).sum()))
 
@@ -753,8 +810,45 @@ def gen_peq():
     np.savez_compressed(os.path.join(OUT, "vqvae_peq.npz"), **rec)
 
 
+def gen_sampler():
+    """Batches of the reference's DistributedBucketSampler (ttts/vqvae/dataset.py:212-307).  The module imports torchaudio /
+    torchvision / pypinyin at import time (absent here), so only the class body is executed: its source segment is compiled
+    from the reference file in this process; nothing of it is stored -- the fixture holds lengths, arguments and batches."""
+    import ast
+    src = open("/root/reference/ttts/vqvae/dataset.py").read()
+    node = [n for n in ast.parse(src).body if isinstance(n, ast.ClassDef) and n.name == "DistributedBucketSampler"][0]
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=[node], type_ignores=[]), "ref_sampler", "exec"), ns)
+    Ref = ns["DistributedBucketSampler"]
+
+    class DS:
+        def __init__(self, lengths):
+            self.lengths = lengths
+
+        def __len__(self):
+            return len(self.lengths)
+    rng = np.random.default_rng(5)
+    lengths = [int(v) for v in np.concatenate([rng.integers(20, 2100, 700), [32, 33, 300, 301, 1900, 1901]])]
+    bounds = [32, 300, 400, 500, 600, 700, 800, 900, 1000, 1100, 1200, 1300, 1400, 1500, 1600, 1700, 1800, 1900]
+    cases = []
+    for world, bs, shuffle, bnd in ((1, 8, True, bounds), (2, 8, True, bounds), (4, 3, True, bounds), (2, 8, False, bounds),
+                                   (2, 4, True, [32, 300, 305, 310, 2000])):
+        per_rank = []
+        for rank in range(world):
+            smp = Ref(DS(lengths), bs, list(bnd), num_replicas=world, rank=rank, shuffle=shuffle)
+            ep = {}
+            for epoch in (1, 2):
+                smp.set_epoch(epoch)
+                ep[str(epoch)] = [list(map(int, b)) for b in smp]
+            per_rank.append({"batches": ep, "len": len(smp), "boundaries_after": list(smp.boundaries),
+                             "num_samples_per_bucket": list(smp.num_samples_per_bucket)})
+        cases.append({"world": world, "batch_size": bs, "shuffle": shuffle, "boundaries": list(bnd), "ranks": per_rank})
+    json.dump({"lengths": lengths, "cases": cases}, open(os.path.join(OUT, "sampler.json"), "w"))
+    print("sampler:", [(c["world"], c["ranks"][0]["len"]) for c in cases])
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gpt", "vq", "mel", "vqvae", "disc", "flow", "attn", "step", "peq", "infer", "diffusion"]
+    which = sys.argv[1:] or ["gpt", "vq", "mel", "vqvae", "disc", "flow", "attn", "step", "peq", "infer", "diffusion", "sampler"]
     with torch.no_grad() if False else torch.enable_grad():
         if "gpt" in which:
             gen_gpt()
@@ -778,4 +872,6 @@ if __name__ == "__main__":
             gen_infer()
         if "diffusion" in which:
             gen_diffusion()
+        if "sampler" in which:
+            gen_sampler()
     print("fixtures:", {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT))})

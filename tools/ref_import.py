@@ -23,6 +23,13 @@ def install():
     sys.dont_write_bytecode = True  # reference tree is read-only; never emit .pyc there
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
+    # the repo root carries its own regular package `ttts` (the drop-in import names, re-exporting ttts_amd); the reference's
+    # `ttts` is a namespace package and would lose to it on any sys.path order -> bind the name to the reference explicitly
+    for name in [m for m in sys.modules if m == "ttts" or m.startswith("ttts.")]:
+        del sys.modules[name]
+    ref_pkg = types.ModuleType("ttts")
+    ref_pkg.__path__ = [REFERENCE_ROOT + "/ttts"]
+    sys.modules["ttts"] = ref_pkg
     import torch  # noqa: F401
     import transformers  # noqa: F401  (real transformers first: its lazy module probes torchaudio)
     from transformers import GPT2Config, GPT2Model  # noqa: F401

@@ -39,6 +39,10 @@ class DiffusionTrainer:
         self.dp = FlatDataParallel()
         self.optimizer = FlatAdamW(self.diffusion.parameters(), cfg["train"]["lr"], betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
         self.dp.broadcast_(self.optimizer.flat_p)
+        # t and the noise are drawn per rank (accelerate leaves every process its own RNG stream): a shared seed would
+        # put the same timesteps and noise on every replica
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(int(seed) + 7919 * self.dp.rank + 1)
         self.base_lr = cfg["train"]["lr"]
         self.step = 0
         self.diffusion.train()
@@ -49,7 +53,9 @@ class DiffusionTrainer:
         x_start = mel if normalized else normalize_tacotron_mel(mel)
         refer = mel_refer if normalized else normalize_tacotron_mel(mel_refer)
         if t is None:
-            t = torch.randint(0, self.desired_diffusion_steps, (x_start.shape[0],), device=self.device)
+            t = torch.randint(0, self.desired_diffusion_steps, (x_start.shape[0],), device=self.device, generator=self.gen)
+        if noise is None:
+            noise = torch.randn(x_start.shape, device=self.device, dtype=x_start.dtype, generator=self.gen)
         kw = {"latent": latent, "refer": refer}
         kw.update(inject or {})
         out = self.diffuser.training_losses(self.diffusion, x_start, t, model_kwargs=kw, noise=noise)
@@ -58,7 +64,7 @@ class DiffusionTrainer:
         (loss * self.dp.loss_scale()).backward()
         self.dp.allreduce_grads_(self.optimizer.flat_g)
         lr = self.base_lr * warmup(self.step)                             # LambdaLR: the factor of the step being taken
-        self.optimizer.step(lr, max_norm=1.0)
+        self.optimizer.step(lr=lr, max_norm=1.0)
         self.step += 1
         return {"loss": loss.detach(), "grad_norm": self.optimizer.grad_norm(), "terms": out}
 

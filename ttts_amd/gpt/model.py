@@ -144,8 +144,21 @@ class UnifiedVoice(nn.Module):
         return self
 
     def _apply(self, fn, recurse=True):
-        raise NotImplementedError("UnifiedVoice lives on the GPU it was created on (parameters are arena views); "
-                                  "construct it with device=... instead of calling .to()/.cuda()/.half()")
+        """`.cuda()` / `.to(device)` / `accelerator.prepare(model)` from reference-style callers: a no-op when it asks for
+        what the model already is (fp32 parameters on its own GPU); anything that would really move or re-type the
+        parameters is refused, because they are views into the engine's arenas."""
+        probe = self.engine.params[:1]
+        out = fn(probe)
+        if out.device != probe.device or out.dtype != probe.dtype:
+            raise NotImplementedError("UnifiedVoice lives on the GPU it was created on (%s, fp32 master parameters in flat "
+                                      "arenas); construct it with device=... instead of moving / casting it" % probe.device)
+        return self
+
+    def zero_grad(self, set_to_none=False):
+        """Zeroes the flat gradient arena and keeps the `.grad` views attached (the nn.Module default would drop the views
+        and leave stale gradients in the arena)."""
+        self.engine.zero_grad()
+        self.attach_grads()
 
     def forward(self, text_inputs, text_lengths, mel_codes, wav_lengths, types=None, text_first=True, raw_mels=None,
                 return_attentions=False, return_latent=False, clip_inputs=True):

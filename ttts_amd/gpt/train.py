@@ -32,6 +32,29 @@ def warmup(step):
     return float(step / 500) if step < 500 else 1
 
 
+def cycle(dl):
+    """ttts/gpt/train.py:32-35."""
+    while True:
+        for data in dl:
+            yield data
+
+
+def get_grad_norm(model):
+    """ttts/gpt/train.py:22-31 as ONE reduction over the flat gradient arena (the reference does 84 `.item()` reads);
+    returns a Python float (one host sync)."""
+    eng = model.engine
+    state = torch.zeros(8, dtype=torch.float32, device=eng.device)
+    from .. import ops
+    ops.gradnorm(eng.grads, 0.0, state, eng.gn_ws)
+    return float(state[4])
+
+
+def _default_cfg_path():
+    """The reference's default is the relative path 'ttts/gpt/config.json' (train.py:42); honour it when it exists in the
+    working directory, otherwise use the packaged config."""
+    return "ttts/gpt/config.json" if os.path.exists("ttts/gpt/config.json") else os.path.join(os.path.dirname(__file__), "config.json")
+
+
 class SyntheticGptBatches:
     """Endless seeded batches with the keys of GptTtsCollater (gpt/dataset.py:91-97)."""
 
@@ -59,7 +82,8 @@ def clean_checkpoints(path_to_models, n_ckpts_to_keep=3):
 
 
 class Trainer(object):
-    def __init__(self, cfg_path=os.path.join(os.path.dirname(__file__), "config.json"), dataloader=None, seed=0):
+    def __init__(self, cfg_path=None, dataloader=None, seed=0):
+        cfg_path = _default_cfg_path() if cfg_path is None else cfg_path
         self.rank, self.world, self.local_rank = init_distributed()
         self.device = torch.device("cuda", self.local_rank)
         torch.cuda.set_device(self.device)
@@ -79,7 +103,7 @@ class Trainer(object):
                 raise NotImplementedError("ttts_amd.gpt.train ships the synthetic data source only; pass a dataloader "
                                           "yielding GptTtsCollater-style dicts for real data")
             dataloader = SyntheticGptBatches(self.gpt.cfg, self.cfg["dataloader"]["batch_size"], seed=1234 + self.rank)
-        self.dataloader = iter(dataloader)
+        self.dataloader = iter(dataloader) if isinstance(dataloader, SyntheticGptBatches) else cycle(dataloader)   # train.py:59
         self.step = 0
         self.is_main = self.rank == 0
         if self.is_main:
@@ -96,14 +120,29 @@ class Trainer(object):
     def save(self, milestone):
         if not self.is_main:
             return
-        data = {"step": self.step, "model": {k: v.cpu() for k, v in self.gpt.engine.state_dict().items()}}
+        eng = self.gpt.engine
+        data = {"step": self.step, "model": {k: v.cpu() for k, v in eng.state_dict().items()},
+                # beyond the reference's two keys (its loader ignores them): the AdamW moments, so that a resumed run
+                # continues instead of restarting the optimizer
+                "optimizer": {"exp_avg": eng.exp_avg.cpu(), "exp_avg_sq": eng.exp_avg_sq.cpu(), "step": float(eng.opt_state[0])}}
         torch.save(data, str(self.logs_folder / f"model-{milestone}.pt"))
 
     def load(self, model_path):
+        """Reference checkpoints ({'step','model'}) resume like the reference does: weights + step counter, a FRESH AdamW
+        and warm-up (train.py:56-57,79-88 never restore the optimizer).  Checkpoints written by `save` above also carry
+        the moments and the optimizer step, and continue exactly."""
         data = torch.load(model_path, map_location="cpu")
+        eng = self.gpt.engine
         self.step = data["step"]
-        self.gpt.engine.load_state_dict(data["model"])
-        self.gpt.engine.opt_state[0] = float(self.step)
+        eng.load_state_dict(data["model"])
+        opt = data.get("optimizer")
+        if opt is not None and opt["exp_avg"].numel() == eng.exp_avg.numel():
+            eng.exp_avg.copy_(opt["exp_avg"]); eng.exp_avg_sq.copy_(opt["exp_avg_sq"])
+            eng.opt_state[0] = float(opt["step"])
+        else:
+            eng.exp_avg.zero_(); eng.exp_avg_sq.zero_()
+            eng.opt_state[0] = 0.0
+        eng.step_count = int(eng.opt_state[0])
 
     # ---- one optimizer step (ttts/gpt/train.py:96-121) -----------------------------------------------------------
     def train_step(self):
@@ -113,7 +152,13 @@ class Trainer(object):
         if self.gradient_accumulate_every == 1:
             data = next(self.dataloader)
             if data is None:                      # the reference skips None batches but still steps the optimizer (:101-102,117-120)
-                self.dp.allreduce_grads_(eng.grads)
+                # same collective sequence as the peers that did get a batch (ranged exchange below): a rank that
+                # issued one whole-arena all-reduce against their four ranged ones would hang or corrupt RCCL
+                if self.dp.enabled:
+                    _, first, second = eng.grad_exchange_plan()
+                    for h in [self.dp.allreduce_range_(eng.grads, lo, hi) for lo, hi in first + second]:
+                        if h is not None:
+                            h.wait()
                 eng.optimizer_step(**opt)
                 eng.step_count += 1
                 return
@@ -134,6 +179,8 @@ class Trainer(object):
             eng.set_tokens(*toks)
             eng.forward()
             eng.backward(self.text_loss_weight * scale, self.mel_loss_weight * scale)
+            eng.seed_ctr.add_(1)                 # every micro-batch draws its own dropout masks (forward + backward of one
+                                                 # micro-batch share the value; optimizer_step advances it once more)
         self.dp.allreduce_grads_(eng.grads)      # accumulated micro-batches: ONE flat RCCL all-reduce (no-op at world size 1)
         eng.optimizer_step(**opt)
         eng.step_count += 1

@@ -549,6 +549,32 @@ _OUT_ACT = {None: 0, "none": 0, "tanh": 1, "lrelu": 2}
 _conv_scratch = {}
 
 
+def set_conv_precision(mode):
+    """'split_bf16' (default: fp32 products as hi*hi + hi*lo + lo*hi on the bf16 matrix cores, fp32 accumulation) or 'exact'
+    (fp32-input MFMA, bit-for-bit an fmaf chain).  Returns the previous mode."""
+    if mode not in ("split_bf16", "exact"):
+        raise ValueError("conv precision must be 'split_bf16' or 'exact'")
+    prev = _state["conv_precision"]
+    _state["conv_precision"] = mode
+    _apply_flags()
+    return prev
+
+
+def set_variant_flags(flags):
+    """Kernel-selection switches for experiments (tools/kernel_bench.py, heuristics overrides in tests).  0 = shipped defaults."""
+    prev = _state["variant"]
+    _state["variant"] = int(flags)
+    _apply_flags()
+    return prev
+
+
+_state = {"conv_precision": "split_bf16", "variant": int(os.environ.get("TTTS_DEBUG_FLAGS", "0") or 0)}
+
+
+def _apply_flags():
+    check(_l.get().ttts_debug_set_flags(_state["variant"] | (4096 if _state["conv_precision"] == "exact" else 0)), "set_flags")
+
+
 def _conv_workspace(device):
     """Registers (once per process) the caller-owned scratch that enables the split-bf16 matrix-core convolution path
     (include/ttts_hip.h: ttts_conv_set_workspace).  TTTS_CONV_FP32=1 keeps the exact-fp32 MFMA kernels."""

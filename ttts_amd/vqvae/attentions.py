@@ -19,6 +19,11 @@ class _SeedSource:
     counter = 0x5EED0000
 
     @classmethod
+    def reseed(cls, seed, rank=0):
+        """Fold the training seed and the data-parallel rank into the stream (replicas must not share dropout masks)."""
+        cls.counter = 0x5EED0000 + ((int(seed) * 1000003 + int(rank) * 7919) & 0x3FFFFFFF) * 4096
+
+    @classmethod
     def next(cls):
         cls.counter += 1
         return (cls.counter * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF

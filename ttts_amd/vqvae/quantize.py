@@ -6,8 +6,9 @@ on the HIP kernels `ttts_vq_nearest_f32` (exact-fp32 nearest code, bit-identical
 (commitment MSE + its gradient) and `ttts_vq_ema_update_f32` (scatter-add EMA, no 4096 x 1024 one-hot).
 
 The two RNG-driven, once-in-a-while paths -- k-means initialisation on the first batch (core_vq.py:71-93,141-148) and
-dead-code replacement (core_vq.py:152-168) -- are host-orchestrated torch ops on the GPU (they are not part of the
-steady-state step; parity fixtures exclude them because they draw from torch's global RNG).
+dead-code replacement (core_vq.py:152-168) -- are host-orchestrated around the same kernels (nearest-code search for the
+Lloyd assignment) and torch index ops; they are not part of the steady-state step.  Their only random input, the index
+vector of `sample_vectors`, can be injected (`index_source`), which is how tests/golden/vq.npz `kmeans_*` pins them.
 """
 import torch
 import torch.nn as nn
@@ -15,9 +16,16 @@ import torch.nn as nn
 from .. import ops
 
 
+index_source = None     # tests: callable (n, num) -> LongTensor(num) replacing the random index draw of _sample_vectors
+
+
 def _sample_vectors(samples, num):
+    """core_vq.py:60-68: `num` rows of `samples`, without replacement when there are enough of them."""
     n = samples.shape[0]
-    idx = torch.randperm(n, device=samples.device)[:num] if n >= num else torch.randint(0, n, (num,), device=samples.device)
+    if index_source is not None:
+        idx = index_source(n, num).to(samples.device)
+    else:
+        idx = torch.randperm(n, device=samples.device)[:num] if n >= num else torch.randint(0, n, (num,), device=samples.device)
     return samples[idx]
 
 

@@ -25,7 +25,7 @@ from ..optim import FlatAdamW
 from ..parallel import FlatDataParallel, init_distributed
 from ..utils.data_utils import HParams, mel_spectrogram_torch, spec_to_mel_torch, spectrogram_torch
 from . import losses as L
-from .augment import Augment, augment
+from .augment import Augment, augment, sample_like  # noqa: F401
 from .vq2 import MultiPeriodDiscriminator, SynthesizerTrn, slice_segments
 
 global_step = 0
@@ -81,36 +81,19 @@ class SyntheticVqvaeBatches:
                 "text_lengths": torch.full((self.B,), self.tl, dtype=torch.int64, device=self.device)}
 
 
-class VqvaeTrainer:
-    """Owns net_g / net_d / the two optimizers and runs the two-phase step."""
+class VqvaeStep:
+    """The two-phase step body of `train_and_evaluate` (ttts/vqvae/train.py:313-406) over caller-owned parts:
+    `nets = [net_g, net_d]`, `optims = [optim_g, optim_d]` (FlatAdamW), `aug` (Augment or None)."""
 
-    def __init__(self, hps, device=None, seed=None, use_augment=None):
-        self.rank, self.world, local = init_distributed()
-        self.device = torch.device("cuda", local) if device is None else torch.device(device)
-        if self.device.type != "cuda":
-            raise ops.TttsError("ttts_amd.vqvae.train needs a GPU (no CPU fallback)")
-        torch.cuda.set_device(self.device)
-        self.hps = hps
-        torch.manual_seed(hps.train.seed if seed is None else seed)
-        self.net_g = SynthesizerTrn(hps.data.filter_length // 2 + 1, hps.train.segment_size // hps.data.hop_length,
-                                    **hps.vqvae).to(self.device)
-        self.net_d = MultiPeriodDiscriminator(getattr(hps.vqvae, "use_spectral_norm", False)).to(self.device)
-        self.dp = FlatDataParallel()
-        if use_augment is None:
-            use_augment = bool(getattr(hps.train, "augment", False))
-        self.aug = Augment(hps).to(self.device) if use_augment else None      # train.py:185
-        tr = hps.train
-        self.optim_g = FlatAdamW(self.net_g.parameters(), tr.learning_rate, betas=tr.betas, eps=tr.eps)
-        self.optim_d = FlatAdamW(self.net_d.parameters(), tr.learning_rate, betas=tr.betas, eps=tr.eps)
-        self.dp.broadcast_(self.optim_g.flat_p, self.optim_d.flat_p)        # DDP construction: rank-0 parameters
-        self.lr = tr.learning_rate
-        self.net_g.train(); self.net_d.train()
+    def __init__(self, hps, net_g, net_d, optim_g, optim_d, aug=None, dp=None):
+        self.hps, self.net_g, self.net_d, self.optim_g, self.optim_d, self.aug = hps, net_g, net_d, optim_g, optim_d, aug
+        self.dp = dp if dp is not None else FlatDataParallel()
 
     def _sync_buffers(self):
         if self.dp.enabled:                                                  # DDP broadcast_buffers=True (rank-0 codebook)
             self.dp.broadcast_(*[b for b in self.net_g.buffers() if b.is_floating_point()])
 
-    def train_step(self, data, inject=None):
+    def __call__(self, data, inject=None):
         """data: dict(wav (B, T) f32, wav_lengths, text, text_lengths) on the device.  Returns a dict of device scalars."""
         h, tr = self.hps.data, self.hps.train
         inject = dict(inject or {})
@@ -120,7 +103,7 @@ class VqvaeTrainer:
         spec_lengths = torch.div(wav_lengths, h.hop_length, rounding_mode="floor")
         if "wav_aug" in inject:
             wav_aug = inject.pop("wav_aug")                                   # tests: a fixed augmented clip
-        elif self.aug is None:
+        elif self.aug is None or getattr(self.hps.vqvae, "freeze_quantizer", None) is True:
             wav_aug = wav                                                     # train.py:335-336
         else:
             wav_aug = augment(wav, self.aug, self.hps)                        # train.py:337-338 (PEQ part)
@@ -140,7 +123,7 @@ class VqvaeTrainer:
         self.optim_d.zero_grad()
         (loss_disc * scale).backward()
         self.dp.allreduce_grads_(self.optim_d.flat_g)
-        self.optim_d.step(self.lr)
+        self.optim_d.step()
         # ---- generator phase
         y_d_hat_r, y_d_hat_g, fmap_r, fmap_g = self.net_d(y, y_hat)
         loss_mel = L.l1_loss(y_mel, y_hat_mel) * tr.c_mel
@@ -152,11 +135,53 @@ class VqvaeTrainer:
         (loss_gen_all * scale).backward()
         self.optim_d.zero_grad()                                             # the G backward also reached net_d's arena
         self.dp.allreduce_grads_(self.optim_g.flat_g)
-        self.optim_g.step(self.lr)
+        self.optim_g.step()
         return {"loss_disc": loss_disc.detach(), "loss_gen": loss_gen.detach(), "loss_fm": loss_fm.detach(),
                 "loss_mel": loss_mel.detach(), "kl_ssl": kl_ssl.detach(), "loss_kl": loss_kl.detach(),
                 "grad_norm_d": self.optim_d.grad_norm(), "grad_norm_g": self.optim_g.grad_norm(),
                 "loss_gen_all": loss_gen_all.detach()}
+
+
+def build_parts(hps, device, seed=None, use_augment=None):
+    """net_g, net_d, optim_g, optim_d, aug as `run` builds them (ttts/vqvae/train.py:175-205); rank-0 parameters are
+    broadcast like DDP's constructor does (:207-208)."""
+    torch.manual_seed(hps.train.seed if seed is None else seed)
+    net_g = SynthesizerTrn(hps.data.filter_length // 2 + 1, hps.train.segment_size // hps.data.hop_length, **hps.vqvae).to(device)
+    net_d = MultiPeriodDiscriminator(getattr(hps.vqvae, "use_spectral_norm", False)).to(device)
+    if use_augment is None:
+        use_augment = bool(getattr(hps.train, "augment", False))
+    aug = Augment(hps).to(device) if use_augment else None                  # train.py:185
+    tr = hps.train
+    optim_g = FlatAdamW(net_g.parameters(), tr.learning_rate, betas=tr.betas, eps=tr.eps)
+    optim_d = FlatAdamW(net_d.parameters(), tr.learning_rate, betas=tr.betas, eps=tr.eps)
+    dp = FlatDataParallel()
+    dp.broadcast_(optim_g.flat_p, optim_d.flat_p)
+    if dp.enabled:      # dropout / sampling streams must differ across ranks (DDP leaves per-process RNG independent)
+        from .attentions import _SeedSource
+        _SeedSource.reseed(hps.train.seed if seed is None else seed, dp.rank)
+        torch.manual_seed((hps.train.seed if seed is None else seed) + 7919 * dp.rank)
+    net_g.train(); net_d.train()
+    return net_g, net_d, optim_g, optim_d, aug, dp
+
+
+class VqvaeTrainer:
+    """Convenience owner of the parts + the step (tests, bench): `VqvaeTrainer(hps).train_step(batch)`."""
+
+    def __init__(self, hps, device=None, seed=None, use_augment=None):
+        self.rank, self.world, local = init_distributed()
+        self.device = torch.device("cuda", local) if device is None else torch.device(device)
+        if self.device.type != "cuda":
+            raise ops.TttsError("ttts_amd.vqvae.train needs a GPU (no CPU fallback)")
+        torch.cuda.set_device(self.device)
+        self.hps = hps
+        self.net_g, self.net_d, self.optim_g, self.optim_d, self.aug, self.dp = build_parts(hps, self.device, seed, use_augment)
+        self.step_fn = VqvaeStep(hps, self.net_g, self.net_d, self.optim_g, self.optim_d, self.aug, self.dp)
+
+    lr = property(lambda self: self.optim_g.lr,
+                  lambda self, v: (setattr(self.optim_g, "lr", v), setattr(self.optim_d, "lr", v)) and None)
+
+    def train_step(self, data, inject=None):
+        return self.step_fn(data, inject)
 
     def save(self, step):
         if self.rank != 0:
@@ -169,45 +194,132 @@ class VqvaeTrainer:
     def load_latest(self):
         d = self.hps.train.exp_dir
         _, _, _, it = load_checkpoint(latest_checkpoint_path(d, "D_*.pth"), self.net_d, self.optim_d)
-        _, _, self.lr, it = load_checkpoint(latest_checkpoint_path(d, "G_*.pth"), self.net_g, self.optim_g)
+        _, _, lr, it = load_checkpoint(latest_checkpoint_path(d, "G_*.pth"), self.net_g, self.optim_g)
         return it
 
 
-def train_and_evaluate(rank, epoch, hps, trainer, loader, steps_per_epoch, logger=None):
-    """One epoch of the step body (train.py:298-406); `loader` yields collater dicts."""
+class _NoScaler:
+    """Stand-in for `GradScaler(enabled=False)` (train.py:297; fp16_run is False in the shipped config): the step body
+    never scales, so the object only has to exist in the reference's argument list."""
+    def scale(self, loss): return loss
+    def unscale_(self, optimizer): pass
+    def step(self, optimizer): optimizer.step()
+    def update(self): pass
+
+
+_steps = {}
+
+
+def _step_for(hps, nets, optims, aug):
+    key = (id(nets[0]), id(nets[1]), id(optims[0]), id(optims[1]))
+    if key not in _steps:
+        _steps.clear()
+        _steps[key] = VqvaeStep(hps, nets[0], nets[1], optims[0], optims[1], aug)
+    return _steps[key]
+
+
+def train_and_evaluate(rank, epoch, hps, nets, optims, schedulers, scaler, loaders, logger, writers, aug):
+    """One epoch, the reference's signature and flow (ttts/vqvae/train.py:298-470): `nets = [net_g, net_d]`,
+    `optims = [optim_g, optim_d]` (FlatAdamW), `schedulers` / `scaler` untouched here as there (the caller steps the
+    schedulers once per epoch; GradScaler is disabled), `loaders = [train_loader, eval_loader]` yielding VQVAECollater
+    dicts, `writers = [writer, writer_eval]` or None, `aug` = Augment or None.  Losses are read back only every
+    `log_interval` steps (the reference reads 12 + 1566 scalars per step)."""
     global global_step
-    for batch_idx in range(steps_per_epoch):
-        data = next(loader)
-        out = trainer.train_step(data)
+    net_g, net_d = nets
+    optim_g, optim_d = optims
+    train_loader, eval_loader = loaders
+    writer = writers[0] if writers is not None else None
+    sampler = getattr(train_loader, "batch_sampler", None)
+    if hasattr(sampler, "set_epoch"):
+        sampler.set_epoch(epoch)
+    step = _step_for(hps, nets, optims, aug)
+    dev = next(net_g.parameters()).device
+    net_g.train(); net_d.train()
+    n_batches = len(train_loader) if hasattr(train_loader, "__len__") else None
+    for batch_idx, data in enumerate(train_loader):
+        data = {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in data.items()}
+        out = step(data)
         if rank == 0 and global_step % hps.train.log_interval == 0:
+            lr = optim_g.param_groups[0]["lr"]
             vals = {k: float(v) for k, v in out.items()}
-            msg = "Train Epoch: {} [{:.0f}%] step {} lr {:.3e} {}".format(epoch, 100.0 * batch_idx / steps_per_epoch,
-                                                                          global_step, trainer.lr, json.dumps(vals))
-            (logger.info if logger else print)(msg)
-        if rank == 0 and global_step % hps.train.save_freq == 0 and global_step > 0:
-            trainer.save(global_step)
+            head = "Train Epoch: {} [{:.0f}%]".format(epoch, 100.0 * batch_idx / n_batches if n_batches else 0.0)
+            row = [vals[k] for k in ("loss_disc", "loss_gen", "loss_fm", "loss_mel", "kl_ssl", "loss_kl")] + [global_step, lr]
+            if logger is not None:
+                logger.info(head); logger.info(row)
+            else:
+                print(head, row, flush=True)
+            if writer is not None:
+                scalars = {"loss/g/total": vals["loss_gen_all"], "loss/d/total": vals["loss_disc"], "learning_rate": lr,
+                           "grad_norm_d": vals["grad_norm_d"], "grad_norm_g": vals["grad_norm_g"], "loss/g/fm": vals["loss_fm"],
+                           "loss/g/mel": vals["loss_mel"], "loss/g/kl_ssl": vals["kl_ssl"], "loss/g/kl": vals["loss_kl"]}
+                for k, v in scalars.items():
+                    writer.add_scalar(k, v, global_step)
         global_step += 1
+    if epoch % hps.train.save_every_epoch == 0 and rank == 0:               # train.py:459-489
+        tag = global_step if hps.train.if_save_latest == 0 else 233333333333
+        os.makedirs(hps.train.exp_dir, exist_ok=True)
+        save_checkpoint(net_g, optim_g, hps.train.learning_rate, epoch, os.path.join(hps.train.exp_dir, "G_{}.pth".format(tag)))
+        save_checkpoint(net_d, optim_d, hps.train.learning_rate, epoch, os.path.join(hps.train.exp_dir, "D_{}.pth".format(tag)))
+    if rank == 0 and logger is not None:
+        logger.info("====> Epoch: {}".format(epoch))
 
 
-def run(rank, n_gpus, hps, steps_per_epoch=100):
+class _EpochLoader:
+    """`steps_per_epoch` batches of an endless source per pass, with the `batch_sampler.set_epoch` hook of the reference loader."""
+
+    def __init__(self, source, steps_per_epoch):
+        self.source, self.n = source, steps_per_epoch
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        for _ in range(self.n):
+            yield next(self.source)
+
+
+def run(rank, n_gpus, hps, train_loader=None, steps_per_epoch=100):
+    """ttts/vqvae/train.py:119-296: build the parts, resume from the newest G_/D_ pair, ExponentialLR stepped once per
+    epoch, `train_and_evaluate` per epoch.  One process per GPU (torchrun): `rank` / `n_gpus` are informational, the
+    process group comes from the environment.  `train_loader`: any iterable of VQVAECollater dicts (default: the
+    synthetic source, `dataset.path == "synthetic"`)."""
     global global_step
-    trainer = VqvaeTrainer(hps)
+    r, world, local = init_distributed()
+    device = torch.device("cuda", local)
+    if not torch.cuda.is_available():
+        raise ops.TttsError("ttts.vqvae.train needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(device)
+    net_g, net_d, optim_g, optim_d, aug, dp = build_parts(hps, device)
+    if train_loader is None:
+        if getattr(hps.dataset, "path", "synthetic") != "synthetic":
+            raise NotImplementedError("ttts.vqvae.train ships the synthetic data source; pass train_loader= for real data "
+                                      "(ttts_amd.vqvae.dataset.DistributedBucketSampler gives the reference's batching)")
+        src = iter(SyntheticVqvaeBatches(hps.train.batch_size, seed=hps.train.seed + r, device=device))
+        train_loader = _EpochLoader(src, steps_per_epoch)
     try:
-        it = trainer.load_latest()
-        global_step = it
-        epoch_str = it // steps_per_epoch + 1
+        _, _, _, epoch_str = load_checkpoint(latest_checkpoint_path(hps.train.exp_dir, "D_*.pth"), net_d, optim_d)
+        _, _, _, epoch_str = load_checkpoint(latest_checkpoint_path(hps.train.exp_dir, "G_*.pth"), net_g, optim_g)
+        global_step = (epoch_str - 1) * len(train_loader)
     except Exception:
         epoch_str, global_step = 1, 0
-    loader = iter(SyntheticVqvaeBatches(hps.train.batch_size, seed=hps.train.seed + trainer.rank, device=trainer.device))
+    for opt in (optim_g, optim_d):                                            # a resumed optimizer carries a decayed lr
+        opt.param_groups[0]["lr"] = hps.train.learning_rate
+        opt.param_groups[0].pop("initial_lr", None)
+    scheduler_g = torch.optim.lr_scheduler.ExponentialLR(optim_g, gamma=hps.train.lr_decay, last_epoch=-1)
+    scheduler_d = torch.optim.lr_scheduler.ExponentialLR(optim_d, gamma=hps.train.lr_decay, last_epoch=-1)
+    for _ in range(epoch_str):
+        scheduler_g.step(); scheduler_d.step()
+    scaler = _NoScaler()
     for epoch in range(epoch_str, hps.train.epochs + 1):
-        trainer.lr = hps.train.learning_rate * hps.train.lr_decay ** epoch    # ExponentialLR stepped once per epoch
-        train_and_evaluate(trainer.rank, epoch, hps, trainer, loader, steps_per_epoch)
+        train_and_evaluate(r, epoch, hps, [net_g, net_d], [optim_g, optim_d], [scheduler_g, scheduler_d], scaler,
+                           [train_loader, None], None, None, aug)
+        scheduler_g.step(); scheduler_d.step()
 
 
 def main():
+    """ttts/vqvae/train.py:44-60.  The reference spawns one process per visible GPU itself; here the launcher does
+    (`torchrun --nproc-per-node N -m ttts.vqvae.train`), so main() is the per-process body."""
     hps = get_hparams(*sys.argv[1:2])
-    if getattr(hps.dataset, "path", "synthetic") != "synthetic":
-        raise NotImplementedError("ttts_amd.vqvae.train ships the synthetic data source only")
     n_gpus = int(os.environ.get("WORLD_SIZE", "1"))
     run(int(os.environ.get("RANK", "0")), n_gpus, hps)
 
