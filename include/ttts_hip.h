@@ -12,8 +12,8 @@
  *  - plain C: raw DEVICE pointers (tensor.data_ptr()), explicit sizes/strides in ELEMENTS, scalars by value;
  *    no torch / C++ types cross the boundary.
  *  - the CALLER owns all memory (inputs, outputs, workspaces; sizes from the *_workspace_bytes helpers);
- *    the library never allocates or frees device memory and keeps no mutable global state besides a
- *    thread-local error string and the option table of ttts_set_option().
+ *    the library never allocates or frees device memory and keeps NO mutable global state (only a
+ *    thread-local error string): dropout stream counters and the convolution scratch are explicit arguments.
  *  - launches are asynchronous on `stream` (a hipStream_t passed as void*; NULL = the default stream);
  *    no internal synchronisation; every kernel is hipGraph-capturable (no host reads of device data).
  *  - return value: TTTS_OK (0) or a negative error code; ttts_last_error() gives the message.
@@ -34,16 +34,16 @@ extern "C" {
 #define TTTS_EHIP (-2)         /* a HIP runtime call or kernel launch failed */
 #define TTTS_EUNSUPPORTED (-3) /* valid request this build has no kernel for */
 
-#define TTTS_ABI_VERSION 1
+#define TTTS_ABI_VERSION 2
 
 /* ---- library ------------------------------------------------------------------------------------ */
 int ttts_abi_version(void);
 const char* ttts_last_error(void);
-/* Process-wide dropout stream counter: `device_counter` points to a uint32 in DEVICE memory owned by the caller (or
- * NULL to disable).  Every dropout-capable kernel adds it to its `seed` at run time; incrementing it once per step
- * (on the stream) gives fresh masks on each replay of a captured hipGraph.  Forward and backward of one step must
- * see the same value. */
-int ttts_set_dropout_counter(const uint32_t* device_counter);
+/* Dropout stream counter (argument `dropout_counter` of every entry point that takes a dropout `seed`): a pointer to a
+ * uint32 in DEVICE memory owned by the caller, or NULL.  The kernel adds it to `seed` at run time; incrementing it once
+ * per step (on the stream) gives fresh masks on each replay of a captured hipGraph (kernel arguments are frozen by
+ * capture, device memory is not).  Forward and backward of one step must see the same value.  The library itself holds
+ * no mutable state: every entry point is re-entrant across threads and streams. */
 /* Device query: writes {gfx arch number (950), CU count, wavefront size, LDS bytes/CU}. */
 int ttts_device_info(int32_t out[4]);
 
@@ -69,7 +69,8 @@ int ttts_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, vo
  * dropout_p/seed: residual dropout (GPT-2 resid_pdrop, modeling_gpt2.py:223,241) on element index m*N + n. */
 int ttts_gemm_nt_bf16_ex(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                          const float* bias, void* aux, int32_t M, int32_t N, int32_t K, int32_t epilogue,
-                         const float* resid_in, float dropout_p, uint64_t seed, void* stream);
+                         const float* resid_in, float dropout_p, uint64_t seed, const uint32_t* dropout_counter,
+                         void* stream);
 /* C[Mo,No] += At[Kr,Mo]^T . Bt[Kr,No]: the weight-gradient GEMM.  The reduction is split over workgroups into fp32
  * slabs in `workspace` (ttts_gemm_tn_workspace_bytes; may be 0 -> NULL) that a second kernel sums in a fixed order
  * (deterministic; no atomics); both operands are row-major with the REDUCTION dimension as rows ("TN").
@@ -103,7 +104,7 @@ int ttts_cast_bf16_batched(const ttts_cast_desc* desc, int32_t n_desc, int32_t t
 int ttts_attn_causal_fwd_bf16(const void* q, const void* k, const void* v, void* o, float* lse,
                               int32_t B, int32_t H, int32_t S, int32_t head_dim,
                               int64_t qkv_stride_b, int64_t qkv_stride_s, int64_t o_stride_b, int64_t o_stride_s,
-                              float scale, float dropout_p, uint64_t seed, void* stream);
+                              float scale, float dropout_p, uint64_t seed, const uint32_t* dropout_counter, void* stream);
 /* delta: f32 workspace [B,H,S] (ttts_attn_bwd_workspace_bytes).  dq/dk/dv use the qkv strides (a packed
  * [B,S,3*H*dh] gradient buffer is written in place); do/o use the o strides. */
 int64_t ttts_attn_bwd_workspace_bytes(int32_t B, int32_t H, int32_t S);
@@ -111,10 +112,10 @@ int ttts_attn_causal_bwd_bf16(const void* q, const void* k, const void* v, const
                               const float* lse, void* dq, void* dk, void* dv, void* workspace,
                               int32_t B, int32_t H, int32_t S, int32_t head_dim,
                               int64_t qkv_stride_b, int64_t qkv_stride_s, int64_t o_stride_b, int64_t o_stride_s,
-                              float scale, float dropout_p, uint64_t seed, void* stream);
+                              float scale, float dropout_p, uint64_t seed, const uint32_t* dropout_counter, void* stream);
 /* Debug/test aid: materialise the attention-dropout keep mask (uint8 [B,H,S,S], 1 = keep). */
 int ttts_attn_dropout_mask_u8(uint8_t* mask, int32_t B, int32_t H, int32_t S, float dropout_p, uint64_t seed,
-                              void* stream);
+                              const uint32_t* dropout_counter, void* stream);
 
 /* ---- LayerNorm (fp32 statistics) -----------------------------------------------------------------
  * Replaces: nn.LayerNorm in GPT2Block (modeling_gpt2.py:254,256), ln_f, final_norm (ttts/gpt/model.py:347,427).
@@ -140,7 +141,7 @@ int ttts_layernorm_bwd_ex(const void* dy, int32_t dy_is_bf16, const float* x, co
                           const float* mean, const float* rstd, const float* dx_in, float* dx, void* dx_bf16,
                           float* dgamma, float* dbeta, float* dcolsum, void* workspace, int32_t M, int32_t D,
                           int32_t split_S, int32_t split_T, float bf16_dropout_p, uint64_t bf16_dropout_seed,
-                          void* stream);
+                          const uint32_t* dropout_counter, void* stream);
 
 /* ---- embeddings ----------------------------------------------------------------------------------
  * Replaces: ttts/gpt/model.py:488,494-495,418 -- token + learned-position embedding sums of the text
@@ -148,10 +149,11 @@ int ttts_layernorm_bwd_ex(const void* dy, int32_t dy_is_bf16, const float* x, co
 int ttts_gpt_embed_fwd(const int64_t* text_inp, const int64_t* mel_inp, const float* text_emb,
                        const float* text_pos, const float* mel_emb, const float* mel_pos, float* x,
                        int32_t B, int32_t Tt, int32_t Tm, int32_t D, int32_t n_text, int32_t n_mel,
-                       float dropout_p, uint64_t seed, void* stream);
+                       float dropout_p, uint64_t seed, const uint32_t* dropout_counter, void* stream);
 int ttts_gpt_embed_bwd(const int64_t* text_inp, const int64_t* mel_inp, const float* dx, float* d_text_emb,
                        float* d_text_pos, float* d_mel_emb, float* d_mel_pos,
-                       int32_t B, int32_t Tt, int32_t Tm, int32_t D, float dropout_p, uint64_t seed, void* stream);
+                       int32_t B, int32_t Tt, int32_t Tm, int32_t D, float dropout_p, uint64_t seed,
+                       const uint32_t* dropout_counter, void* stream);
 
 /* ---- cross-entropy -------------------------------------------------------------------------------
  * Replaces: F.cross_entropy(logits.permute, targets) mean reduction, ttts/gpt/model.py:508-509.
@@ -354,23 +356,39 @@ int ttts_peak_scale_f32(float* x, const void* peak_bits, int32_t B, int32_t T, f
  *        IS the transposed convolution's forward (and fwd is its data gradient); stride > 1 requires dil == 1.
  * wgrad: dw += sum_{b,l} lrelu(dy, dy_slope) * lrelu(x, x_slope) (shifted).   bias_grad: db[c] += sum_{b,l} dy.
  * weight_norm (dim 0): w[r] = g[r] v[r] / ||v[r]||, norm[r] saved; bwd accumulates dv, dg. */
+/* Caller-owned context of the convolution family (plain data; the library keeps no copy and no global of it).
+ *  workspace: optional 16-byte aligned scratch (>= 32 MB covers every layer of the path; 1.5 GB also holds the pre-split
+ *             activations and weight-gradient slabs of the BASELINE batch).  With it conv1d_fwd / dgrad / wgrad run the
+ *             split-bf16 matrix-core kernels (fp32 operands carried as hi + lo bf16, x*w accumulated in fp32 as
+ *             hi*hi + hi*lo + lo*hi, relative error ~2^-16) and stage their pre-split operands / partial sums there;
+ *             convolutions sharing one workspace must be ordered on one stream.  NULL (or ctx == NULL): exact kernels.
+ *  flags:     TTTS_CONV_EXACT_F32 keeps the exact-fp32 MFMA kernels (bit-for-bit fmaf chains) even with a workspace;
+ *             the remaining bits override tile / kernel heuristics for experiments (tools/conv_bench.py) and are 0 in
+ *             normal operation. */
+typedef struct ttts_conv_ctx {
+  void* workspace;
+  int64_t workspace_bytes;
+  int32_t flags;
+  int32_t reserved;
+} ttts_conv_ctx;
+#define TTTS_CONV_EXACT_F32 4096
+#define TTTS_CONV_DIRECT_ONLY 256        /* experiments: every convolution on the direct (non-MFMA) kernels */
+#define TTTS_CONV_SMALL_TILES 2048       /* experiments: allow the small MFMA tile shapes */
+#define TTTS_CONV_FORCE_SPLIT_WGRAD 8192 /* tests: split-bf16 weight gradient for every shape */
+#define TTTS_CONV_NO_TAPS_WGRAD 16384    /* experiments: disable the all-taps weight-gradient kernel */
 int ttts_conv1d_fwd_f32(const float* x, const float* w, const float* bias, const float* bbias, const float* resid,
                         const float* gate, const float* omask, float* y, int32_t B, int32_t Cin, int32_t Lin, int32_t Cout, int32_t Lout,
                         int32_t K, int32_t stride, int32_t pad, int32_t dil, int32_t groups, float in_slope,
                         float gate_slope, int32_t out_act, float out_slope, float out_scale, int32_t accumulate,
-                        void* stream);
+                        const ttts_conv_ctx* ctx, void* stream);
 int ttts_conv1d_dgrad_f32(const float* dy, const float* w, const float* bias, const float* resid,
                           const float* gate, const float* omask, float* dx, int32_t B, int32_t Cin, int32_t Lin, int32_t Cout,
                           int32_t Lout, int32_t K, int32_t stride, int32_t pad, int32_t dil, int32_t groups,
-                          float in_slope, float gate_slope, float out_scale, int32_t accumulate, void* stream);
+                          float in_slope, float gate_slope, float out_scale, int32_t accumulate,
+                          const ttts_conv_ctx* ctx, void* stream);
 int ttts_conv1d_wgrad_f32(const float* dy, const float* x, float* dw, int32_t B, int32_t Cin, int32_t Lin,
                           int32_t Cout, int32_t Lout, int32_t K, int32_t stride, int32_t pad, int32_t dil,
-                          int32_t groups, float dy_slope, float x_slope, void* stream);
-/* Optional caller-owned scratch (16-byte aligned, >= 32 MB covers every layer of the path) that enables the split-bf16
- * matrix-core path of conv1d_fwd / conv1d_dgrad (weights pre-split into hi/lo bf16 there: x*w accumulated in fp32 as
- * hi*hi + hi*lo + lo*hi, relative error ~2^-16).  One scratch per process; convolutions that use it must be ordered on
- * one stream.  NULL restores the exact-fp32 MFMA kernels. */
-int ttts_conv_set_workspace(void* workspace, int64_t bytes);
+                          int32_t groups, float dy_slope, float x_slope, const ttts_conv_ctx* ctx, void* stream);
 int ttts_conv1d_bias_grad_f32(const float* dy, float* db, int32_t B, int32_t C, int32_t L, void* stream);
 int ttts_weight_norm_fwd_f32(const float* v, const float* g, float* w, float* norm, int32_t rows, int32_t n,
                              void* stream);
@@ -477,8 +495,6 @@ int ttts_kl_loss_bwd_f32(const float* z_p, const float* logs_q, const float* m_p
 /* out_c f32 [64 lanes][16 regs]: raw accumulators of one 32x32x16 bf16 MFMA with D[i][j] = (i+1) + 64*(j+1);
  * out_tr i32 [64 lanes][8]: the uint16 LDS element indices two ds_read_b64_tr_b16 return for the kernels' address map. */
 int ttts_probe_mfma_layout(float* out_c, int32_t* out_tr, void* stream);
-/* Timing ablations for tools/kernel_bench.py (0 = normal operation; results are WRONG when non-zero). */
-int ttts_debug_set_flags(int32_t flags);
 
 #ifdef __cplusplus
 }

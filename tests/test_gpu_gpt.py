@@ -44,6 +44,11 @@ def _oracle_grads(cfg, sd, batch, bf16, device):
     return lt.item(), lm.item(), logits.detach(), {k: v.grad for k, v in leaves.items()}
 
 
+def _diag(name, obj):
+    os.makedirs(os.path.join(ROOT, "gpurun_out", "diag"), exist_ok=True)
+    json.dump(obj, open(os.path.join(ROOT, "gpurun_out", "diag", name + ".json"), "w"), indent=1)
+
+
 def test_tiny_matches_reference_fixture(gpt, golden_dir):
     from oracle import gpt_ref
     g = np.load(os.path.join(golden_dir, "gpt_tiny.npz"))
@@ -57,8 +62,9 @@ def test_tiny_matches_reference_fixture(gpt, golden_dir):
     lt, lm, logits = model(batch[0].cuda(), batch[1], batch[2].cuda(), batch[3])
     assert torch.equal(batch[2], mel_before)
     (lt * 0.01 + lm).backward()
-    np.testing.assert_allclose(lt.item(), g["loss_text"], rtol=1e-2)
-    np.testing.assert_allclose(lm.item(), g["loss_mel"], rtol=1e-2)
+    _diag("tiny_losses", {"loss_text": [lt.item(), float(g["loss_text"])], "loss_mel": [lm.item(), float(g["loss_mel"])]})
+    np.testing.assert_allclose(lt.item(), g["loss_text"], rtol=3e-3)
+    np.testing.assert_allclose(lm.item(), g["loss_mel"], rtol=3e-3)
     assert logits.shape == tuple(g["mel_logits"].shape)
     assert rel_err(logits.float(), torch.from_numpy(g["mel_logits"])) < 3e-2
     eng = model.engine
@@ -73,7 +79,7 @@ def test_tiny_matches_reference_fixture(gpt, golden_dir):
             assert rel_err(got, ref) < 5e-2 and cosine(got, ref) > 0.998, (k, rel_err(got, ref))
         e = rel_err(p.grad, og[k]) if float(og[k].norm()) > 1e-6 else 0.0
         worst[k] = e
-        assert e < 2e-2, (k, e)
+        assert e < 8e-3, (k, e)                      # measured worst 3.7e-3 (bf16 rounding of different summation orders)
     os.makedirs(os.path.join(ROOT, "gpurun_out", "diag"), exist_ok=True)
     json.dump(worst, open(os.path.join(ROOT, "gpurun_out", "diag", "tiny_grad_err.json"), "w"), indent=1)
 
@@ -87,8 +93,9 @@ def test_full_config_b1_fixture(gpt, golden_dir):
     batch = gpt_ref.synthetic_batch(B=1, seed=int(g["seed"]))
     lt, lm, logits = model(batch[0].cuda(), batch[1], batch[2].cuda(), batch[3])
     (lt * 0.01 + lm).backward()
-    np.testing.assert_allclose(lt.item(), g["loss_text"], rtol=1e-2)
-    np.testing.assert_allclose(lm.item(), g["loss_mel"], rtol=1e-2)
+    _diag("full_b1_losses", {"loss_text": [lt.item(), float(g["loss_text"])], "loss_mel": [lm.item(), float(g["loss_mel"])]})
+    np.testing.assert_allclose(lt.item(), g["loss_text"], rtol=3e-3)
+    np.testing.assert_allclose(lm.item(), g["loss_mel"], rtol=3e-3)
     assert rel_err(logits[0, ::64, ::64].float(), torch.from_numpy(g["logits_slice"])) < 3e-2
     eng = model.engine
     gn = float(eng.grads.double().norm())
@@ -125,10 +132,12 @@ def test_train_steps_match_bf16_oracle_full_shape(gpt):
             lt, lm = eng.losses()
             got.append((lt, lm, float(eng.opt_state[4])))
         results[capture] = (got, eng.params.clone())
+        # the oracle here runs on the GPU through torch ops (rocBLAS GEMMs with the same bf16 rounding points) -- an independent
+        # implementation, not the HIP path.  Measured on MI355X: losses 5e-6, grad-norm 7e-5 relative; asserted at ~10x that.
         for (lt, lm, gn), (rt, rm, rn) in zip(got, ref_losses):
-            np.testing.assert_allclose(lt, rt, rtol=5e-3)
-            np.testing.assert_allclose(lm, rm, rtol=5e-3)
-            np.testing.assert_allclose(gn, rn, rtol=3e-2)
+            np.testing.assert_allclose(lt, rt, rtol=1e-4)
+            np.testing.assert_allclose(lm, rm, rtol=1e-4)
+            np.testing.assert_allclose(gn, rn, rtol=1e-3)
         delta = eng.view(eng.params, "gpt.h.3.mlp.c_fc.weight").cpu() - sd["gpt.h.3.mlp.c_fc.weight"]
         rdelta = ref_sd["gpt.h.3.mlp.c_fc.weight"].cpu() - sd["gpt.h.3.mlp.c_fc.weight"]
         assert cosine(delta, rdelta) > 0.98

@@ -282,63 +282,49 @@ def test_attention_dropout_matches_mask(ops):
     assert rel_err(dqkv.view(B, S, 3 * D).float(), leaf.grad) < 2e-2
 
 
-@pytest.mark.parametrize("B,S,H,dh,p", [(2, 1156, 8, 64, 0.0), (2, 1156, 8, 64, 0.1), (1, 130, 2, 64, 0.1), (3, 64, 4, 64, 0.0),
-                                        (2, 38, 2, 32, 0.0), (1, 257, 1, 128, 0.1)])
-def test_attention_fwd_kv2_work_split_matches_default(ops, B, S, H, dh, p):
-    """The two forward work splits (128-query blocks: flag 131072 forces it; 64-query x 128-key blocks: flag 65536, the default
-    under dropout) compute the same attention: same dropout mask (same hash indices), outputs and log-sum-exp equal up to bf16
-    rounding of a different accumulation order."""
+def test_c_abi_is_reentrant_across_threads_and_streams(ops):
+    """no mutable library state.  Two host threads, each on its own stream, with its OWN dropout counter and its
+    OWN convolution context (one split-bf16 with scratch, one exact without), hammer the same entry points concurrently;
+    every result must equal the single-threaded result of the same call."""
+    import ctypes
+    import threading
     from ttts_amd import lib
+    l = lib.get()
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    B, H, S, dh = 2, 2, 160, 64
     D = H * dh
-    g = torch.Generator(device="cpu").manual_seed(S + dh)
-    qkv = _bf(torch.randn(B, S, 3 * D, generator=g)).to(dev())
-    q2 = qkv.view(B * S, 3 * D)
+    g = torch.Generator(device="cpu").manual_seed(11)
+    qkv = _bf(torch.randn(B * S, 3 * D, generator=g)).to(dev())
+    x = torch.randn(2, 64, 300, generator=g).to(dev()); w = (torch.randn(64, 64, 5, generator=g) / 18).to(dev())
+    ctrs = [torch.full((1,), 3, dtype=torch.int32, device=dev()), torch.full((1,), 9, dtype=torch.int32, device=dev())]
+    scratch = torch.empty(64 << 20, dtype=torch.uint8, device=dev())
+    ctxs = [lib.ConvCtx(P(scratch), scratch.numel(), 0, 0), lib.ConvCtx(None, 0, 4096, 0)]
 
-    def run(flags):
-        o = torch.zeros(B, S, D, dtype=torch.bfloat16, device=dev()); lse = torch.zeros(B, H, S, device=dev())
-        lib.get().ttts_debug_set_flags(flags)
-        try:
-            ops.attn_fwd(q2, q2[:, D:], q2[:, 2 * D:], o, lse, B, H, S, dh, (S * 3 * D, 3 * D), (S * D, D), dh ** -0.5, p, 4242)
-        finally:
-            lib.get().ttts_debug_set_flags(0)
-        torch.cuda.synchronize()
-        return o.float(), lse
-    o1, l1 = run(131072)
-    o2, l2 = run(65536)
-    assert rel_err(o2, o1) < 6e-3
-    assert (l2 - l1).abs().max().item() < 2e-3
-
-
-@pytest.mark.skipif(os.environ.get("TTTS_EXPERIMENTAL") != "1", reason="opt-in: kernels behind debug flags that are not yet the default")
-@pytest.mark.parametrize("B,S,H,dh,p", [(2, 1156, 8, 64, 0.1), (1, 130, 2, 64, 0.0), (3, 64, 4, 64, 0.1), (2, 38, 2, 32, 0.0)])
-def test_attention_bwd_kv2_work_splits_match_default(ops, B, S, H, dh, p):
-    """ttts_debug_set_flags(262144) / (524288): dQ resp. dK, dV from the 64 x 128 work splits == the default kernels' (same mask);
-    the other outputs are untouched."""
-    from ttts_amd import lib
-    D = H * dh
-    g = torch.Generator(device="cpu").manual_seed(S + dh + 1)
-    qkv = _bf(torch.randn(B, S, 3 * D, generator=g)).to(dev())
-    do = _bf(torch.randn(B, S, D, generator=g)).to(dev())
-    q2 = qkv.view(B * S, 3 * D)
-    o = torch.zeros(B, S, D, dtype=torch.bfloat16, device=dev()); lse = torch.zeros(B, H, S, device=dev())
-    ops.attn_fwd(q2, q2[:, D:], q2[:, 2 * D:], o, lse, B, H, S, dh, (S * 3 * D, 3 * D), (S * D, D), dh ** -0.5, p, 99)
-
-    def run(flags):
-        dqkv = torch.zeros(B * S, 3 * D, dtype=torch.bfloat16, device=dev()); ws = torch.empty(B * H * S, device=dev())
-        lib.get().ttts_debug_set_flags(flags)
-        try:
-            ops.attn_bwd(q2, q2[:, D:], q2[:, 2 * D:], o, do, lse, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], ws, B, H, S, dh,
-                         (S * 3 * D, 3 * D), (S * D, D), dh ** -0.5, p, 99)
-        finally:
-            lib.get().ttts_debug_set_flags(0)
-        torch.cuda.synchronize()
-        return dqkv.float()
-    a, b2 = run(0), run(262144)
-    assert torch.equal(a[:, D:], b2[:, D:])                       # dK, dV: same kernel
-    assert rel_err(b2[:, :D], a[:, :D]) < 6e-3
-    c = run(524288)                                               # dK / dV from 64-key x 128-query workgroups, dQ untouched
-    assert torch.equal(a[:, :D], c[:, :D])
-    assert rel_err(c[:, D:2 * D], a[:, D:2 * D]) < 6e-3 and rel_err(c[:, 2 * D:], a[:, 2 * D:]) < 6e-3
+    def work(i, stream, n, out):
+        o = torch.zeros(B * S, D, dtype=torch.bfloat16, device=dev()); lse = torch.zeros(B * H * S, device=dev())
+        y = torch.zeros(2, 64, 300, device=dev())
+        sp = ctypes.c_void_p(stream.cuda_stream)
+        for _ in range(n):
+            rc = l.ttts_attn_causal_fwd_bf16(P(qkv), P(qkv[:, D:]), P(qkv[:, 2 * D:]), P(o), P(lse), B, H, S, dh, S * 3 * D, 3 * D,
+                                             S * D, D, dh ** -0.5, 0.1, 77, P(ctrs[i]), sp)
+            assert rc == 0, l.ttts_last_error()
+            rc = l.ttts_conv1d_fwd_f32(P(x), P(w), None, None, None, None, None, P(y), 2, 64, 300, 64, 300, 5, 1, 2, 1, 1, 1.0, 1.0, 0,
+                                       1.0, 1.0, 0, ctypes.byref(ctxs[i]), sp)
+            assert rc == 0, l.ttts_last_error()
+        stream.synchronize()
+        out[i] = (o.clone(), y.clone())
+    torch.cuda.synchronize()
+    ref, got = {}, {}
+    for i in range(2):                                     # single-threaded references, one configuration at a time
+        work(i, torch.cuda.Stream(), 1, ref)
+    ths = [threading.Thread(target=work, args=(i, torch.cuda.Stream(), 40, got)) for i in range(2)]
+    [t.start() for t in ths]; [t.join() for t in ths]
+    for i in range(2):
+        assert torch.equal(got[i][0], ref[i][0]) and torch.equal(got[i][1], ref[i][1]), i
+    assert not torch.equal(ref[0][0], ref[1][0])           # different counters -> different dropout masks
+    assert not torch.equal(ref[0][1], ref[1][1]) and rel_err(ref[0][1], ref[1][1]) < 1e-4   # split-bf16 vs exact convolution
+    # an error in one thread does not leak into the other's thread-local message
+    assert l.ttts_gemm_nt_bf16(None, 8, None, 8, None, 8, None, None, 4, 4, 8, 0, None) == -1
 
 
 def test_dropout_counter_gives_fresh_masks(ops):

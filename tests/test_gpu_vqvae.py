@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _conv_precision_mode(request):
     """The fp32-tolerance parity tests run the EXACT convolution kernels (f32-input MFMA, bit-for-bit fmaf chains:
-    ttts_debug_set_flags(4096)); tests marked `bf16x3` run the default fast path (split-bf16 products on the bf16 matrix
+    ttts_conv_ctx.flags = TTTS_CONV_EXACT_F32); tests marked `bf16x3` run the default fast path (split-bf16 products on the bf16 matrix
     cores, ~2^-17 relative per product) against its own stated tolerances."""
     from ttts_amd import lib
     from ttts_amd import ops as _ops

@@ -32,7 +32,7 @@ def test_header_symbols_exported_and_bound(lib):
     for name in declared:
         assert hasattr(handle, name), "header declares %s but libttts_hip.so does not export it" % name
     assert declared == set(lib.SIGNATURES), declared ^ set(lib.SIGNATURES)
-    assert lib.get().ttts_abi_version() == 1
+    assert lib.get().ttts_abi_version() == lib.ABI_VERSION == 2
 
 
 def test_argument_validation_without_gpu(lib):
@@ -44,7 +44,7 @@ def test_argument_validation_without_gpu(lib):
     p = (p + 15) // 16 * 16
     assert l.ttts_gemm_nt_bf16(p, 12, p, 8, p, 8, None, None, 4, 4, 12, 0, None) == -1   # K % 8 != 0
     assert b"multiples of 8" in l.ttts_last_error()
-    assert l.ttts_attn_causal_fwd_bf16(p, p, p, p, p, 1, 1, 16, 48, 16, 16, 16, 16, 1.0, 0.0, 0, None) == -1
+    assert l.ttts_attn_causal_fwd_bf16(p, p, p, p, p, 1, 1, 16, 48, 16, 16, 16, 16, 1.0, 0.0, 0, None, None) == -1
     assert b"head_dim" in l.ttts_last_error()
     assert l.ttts_vq_nearest_f32(p, p, p, None, None, p, 8, 8, 7, None) == -1                # odd D
     assert l.ttts_layernorm_bwd_workspace_bytes(9248, 512) == 1156 * 3 * 512 * 4

@@ -1,5 +1,5 @@
 """Micro-benchmark of the conv1d family at shapes of the VQ-VAE-GAN step, B = 8.
-usage: python tools/conv_bench.py [flags]   (flags -> ttts_debug_set_flags, 256 = direct kernels only)"""
+usage: python tools/conv_bench.py [flags]   (flags -> ttts_conv_ctx.flags, e.g. 256 = direct kernels only, 4096 = exact fp32)"""
 import json
 import os
 import sys
@@ -13,7 +13,7 @@ ge.build()
 from ttts_amd import lib, ops
 
 flags = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-lib.get().ttts_debug_set_flags(flags)
+ops.set_variant_flags(flags)
 dev = torch.device("cuda", 0)
 B = int(os.environ.get("CB_B", "8"))
 SHAPES = [  # name, Cin, Cout, K, stride, pad, dil, L

@@ -1,4 +1,4 @@
-"""Compares the default split-bf16 convolution kernels with the exact f32-MFMA kernels (flag 4096) on a few path shapes: max relative difference of forward and data gradient.  usage (GPU box): python tools/conv_precision_check.py"""
+"""Compares the default split-bf16 convolution kernels with the exact f32-MFMA kernels (ttts_conv_ctx.flags = TTTS_CONV_EXACT_F32) on a few path shapes: max relative difference of forward and data gradient.  usage (GPU box): python tools/conv_precision_check.py"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,11 +14,11 @@ for (cin, cout, k, s, pad, dil, L, B) in [(64, 64, 11, 1, 25, 5, 2048, 2), (64, 
     res = torch.randn(B, cin, L, device=dev) * 1e-5
     out = {}
     for flag in (4096, 0):
-        lib.get().ttts_debug_set_flags(flag)
+        ops.set_conv_precision('exact' if flag else 'split_bf16')
         y = ops.conv1d_fwd(x, w, None, None, s, pad, dil, in_slope=0.1)
         dx = ops.conv1d_dgrad(dy, w, L, s, pad, dil, gate=x, gate_slope=0.1, resid=res)
         dx2 = ops.conv1d_dgrad(dy, w, L, s, pad, dil)
         out[flag] = (y.clone(), dx.clone(), dx2.clone())
-    lib.get().ttts_debug_set_flags(0)
+    ops.set_conv_precision('split_bf16')
     print((cin, cout, k, s, pad, dil, L), "fwd rel %.2e  dgrad(gate,resid) rel %.2e  dgrad plain rel %.2e" % (
         rel(out[0][0], out[4096][0]), rel(out[0][1], out[4096][1]), rel(out[0][2], out[4096][2])))

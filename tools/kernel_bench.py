@@ -50,27 +50,17 @@ def bench_gemm():
         aux = torch.zeros(M, N, dtype=torch.bfloat16, device=dev) if epi in (EPI_GELU_BF16, EPI_DGELU_BF16) else None
         rin = torch.randn(M, N, device=dev) if epi == EPI_RESID_ADD_F32 else None
         fl = 2.0 * M * N * K
-        row = {}
-        for flag, tag in ((0, "xcd_swizzle"), (128, "linear"), (1, "xcd_no_epi"), (129, "linear_no_epi")) if os.environ.get("KB_QUICK") else ((0, "full"), (1, "no_epilogue"), (16, "epi_no_gstore"), (32, "epi_no_lds_stage"), (48, "epi_neither")):
-            lib.get().ttts_debug_set_flags(flag)
-            us = timeit(lambda: ops.gemm_nt(a, b, c, bias, aux=aux, epilogue=epi, resid_in=rin))
-            row[tag] = "%.1f us  %.0f TF/s" % (us, fl / us / 1e6)
-        lib.get().ttts_debug_set_flags(0)
-        out[name + " M%d N%d K%d" % (M, N, K)] = row
+        us = timeit(lambda: ops.gemm_nt(a, b, c, bias, aux=aux, epilogue=epi, resid_in=rin))
+        out[name + " M%d N%d K%d" % (M, N, K)] = "%.1f us  %.0f TF/s" % (us, fl / us / 1e6)
     Kr = 9280      # the engine zero-pads the reduction rows to a multiple of 64
     for name, Mo, No in (("dW c_attn", 512, 1536), ("dW c_fc", 512, 2048), ("dW mlp c_proj", 2048, 512), ("dW attn c_proj", 512, 512),
                          ("dW mel_head", 1032, 512)):
         at = torch.randn(Kr, (Mo + 7) // 8 * 8, device=dev).to(torch.bfloat16)
         bt = torch.randn(Kr, No, device=dev).to(torch.bfloat16)
         c = torch.zeros(Mo, No, device=dev)
-        row = {}
-        for flag, tag in ((512, "target256"), (0, "target384"), (1024, "target512")):
-            lib.get().ttts_debug_set_flags(flag)
-            ws = ops.gemm_tn_workspace(Mo, No, Kr, dev)
-            us = timeit(lambda: ops.gemm_tn_accum(at, bt, c, workspace=ws))
-            row[tag] = "%.1f us  %.0f TF/s (incl. slab reduce)" % (us, 2.0 * Kr * Mo * No / us / 1e6)
-        lib.get().ttts_debug_set_flags(0)
-        out[name] = row
+        ws = ops.gemm_tn_workspace(Mo, No, Kr, dev)
+        us = timeit(lambda: ops.gemm_tn_accum(at, bt, c, workspace=ws))
+        out[name] = "%.1f us  %.0f TF/s (incl. slab reduce)" % (us, 2.0 * Kr * Mo * No / us / 1e6)
     return out
 
 
@@ -104,22 +94,6 @@ def bench_attn():
         us = timeit(lambda: ops.attn_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], o, do, lse, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], ws, B, H, S, dh,
                                          (S * 3 * D, 3 * D), (S * D, D), dh ** -0.5, p, 7))
         out["bwd p=%.1f" % p] = "%.1f us  %.0f TF/s (causal-useful, 5 matmuls)" % (us, 2.5 * fl / us / 1e6)
-        from ttts_amd import lib
-        lib.get().ttts_debug_set_flags(65536)     # the 64-query x 128-key forward work split
-        us = timeit(lambda: ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], o, lse, B, H, S, dh, (S * 3 * D, 3 * D), (S * D, D), dh ** -0.5, p, 7))
-        lib.get().ttts_debug_set_flags(0)
-        out["fwd kv2 p=%.1f" % p] = "%.1f us  %.0f TF/s (causal-useful)" % (us, fl / us / 1e6)
-        lib.get().ttts_debug_set_flags(262144)    # experimental dQ work split
-        us = timeit(lambda: ops.attn_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], o, do, lse, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], ws, B, H, S, dh,
-                                         (S * 3 * D, 3 * D), (S * D, D), dh ** -0.5, p, 7))
-        lib.get().ttts_debug_set_flags(0)
-        out["bwd dq-kv2 p=%.1f" % p] = "%.1f us" % us
-        for fl_, tag in ((524288, "dkdv-kv2"), (262144 | 524288, "dq+dkdv-kv2")):
-            lib.get().ttts_debug_set_flags(fl_)
-            us = timeit(lambda: ops.attn_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], o, do, lse, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], ws, B, H, S, dh,
-                                             (S * 3 * D, 3 * D), (S * D, D), dh ** -0.5, p, 7))
-            lib.get().ttts_debug_set_flags(0)
-            out["bwd %s p=%.1f" % (tag, p)] = "%.1f us" % us
     return out
 
 

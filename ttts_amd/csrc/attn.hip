@@ -17,8 +17,6 @@
 
 #include "common.hpp"
 
-extern int g_debug_flags;   // gemm.hip (ttts_debug_set_flags)
-
 namespace ttts {
 
 struct AttnParams {
@@ -36,7 +34,7 @@ struct AttnParams {
   uint32_t thr;      // dropout threshold on 16 random bits (0 = no dropout)
   float inv_keep;
   uint32_t seed_lo, seed_hi;
-  const uint32_t* ctr;  // process-wide dropout stream counter (device) or NULL
+  const uint32_t* ctr;  // caller-owned dropout stream counter (device) or NULL
 };
 
 constexpr float NEG_BIG = -1.0e30f;
@@ -239,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 }
 
 // -------------------------------------------------------------------------------------------------------
-// forward, second work split: the default when dropout is on (ttts_debug_set_flags(65536) forces it, 131072 forbids it).
+// forward, second work split: the one launched when dropout is on.
 // Why: with 128-query workgroups the launch is 640 blocks of 2..19 KV tiles and is bound by its longest blocks (19 x ~3.9 k
 // cycles), not by the matrix cores.  Here a workgroup owns 64 queries and walks 128 keys per iteration: wave (qh, kh) takes
 // query half qh and the kh-th 64-key tile with its own online-softmax state; the two key halves of a query half are merged
@@ -574,143 +572,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
 }
 
 // -------------------------------------------------------------------------------------------------------
-// backward: dQ with the forward's second work split (EXPERIMENTAL: ttts_debug_set_flags(262144), default off: correct, but
-// measured slower than the 128-query kernel in this first form -- backward 134 -> 156 us with dropout at the BASELINE shape;
-// that build was forced to 3 waves/SIMD and spilled 77 VGPRs (it needs ~200 with the 128-row prefetch registers) and paid a
-// hipFuncSetAttribute call per launch; both fixed since: re-measure before deciding).  64 queries per workgroup, 128 keys per iteration, wave (qh, kh) =
-// query half x key half; dQ^T needs no running max, so the two key halves are simply summed through LDS at the end.
-// -------------------------------------------------------------------------------------------------------
-template <int DH, bool DROPOUT>
-__global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_bwd_dq_kv2_kernel(AttnParams p) {
-  using C = AttnCfg<DH>;
-  constexpr int CPT2 = 128 * (DH / 8) / 256;
-  extern __shared__ __attribute__((aligned(16))) unsigned char dq2_smem[];
-  bf16* Ks = reinterpret_cast<bf16*>(dq2_smem);                 // [128][KSTR]
-  bf16* Vs = Ks + 128 * C::KSTR;                                // [128][KSTR]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int qh = wave & 1, kh = wave >> 1;
-  const int hh = lane >> 5, g = lane >> 4, ip = lane & 15;
-  const int nqb = (p.S + 63) / 64;
-  const int nbh = gridDim.x / nqb;
-  const int qb = nqb - 1 - (int)(blockIdx.x / nbh);
-  const int bh = blockIdx.x % nbh, h = bh % p.H, b = bh / p.H;
-  const int q0 = qb * 64;
-  const int q_base = q0 + qh * 32;
-  const int query = q_base + (lane & 31);
-  const bf16* qp = p.q + (int64_t)b * p.sb + h * DH;
-  const bf16* kp = p.k + (int64_t)b * p.sb + h * DH;
-  const bf16* vp = p.v + (int64_t)b * p.sb + h * DH;
-  const bf16* dop = p.d_o + (int64_t)b * p.osb + h * DH;
-
-  bf16x8 qf[C::KS], dof[C::KS];
-#pragma unroll
-  for (int ks = 0; ks < C::KS; ++ks) {
-    qf[ks] = query < p.S ? *reinterpret_cast<const bf16x8*>(qp + (int64_t)query * p.ss + ks * 16 + hh * 8) : zero8();
-    dof[ks] = query < p.S ? *reinterpret_cast<const bf16x8*>(dop + (int64_t)query * p.oss + ks * 16 + hh * 8) : zero8();
-  }
-  const int64_t stat = (int64_t)(b * p.H + h) * p.S + query;
-  const float lse2 = query < p.S ? p.lse_in[stat] * LOG2E : 0.f;
-  const float delta = query < p.S ? p.delta[stat] : 0.f;
-  f32x16 dqt[C::NB];
-#pragma unroll
-  for (int nb = 0; nb < C::NB; ++nb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dqt[nb][r] = 0.f;
-
-  const int kv_end = min(p.S, q0 + 64);
-  const int nsup = (kv_end + 127) / 128;
-  bf16x8 rk[CPT2], rv[CPT2];
-  tile_load_rows<DH, 128>(rk, kp, p.ss, 0, p.S, tid);
-  tile_load_rows<DH, 128>(rv, vp, p.ss, 0, p.S, tid);
-  const int k_nat = (lane & 31) * C::KSTR + hh * 8;
-  const int k_tr = (4 * hh + (ip >> 2)) * C::KSTR + 16 * (g & 1) + 4 * (ip & 3);
-  const uint32_t e_row = (uint32_t)(((int64_t)(b * p.H + h) * p.S + query) * p.Sp);
-  const uint32_t shi = DROPOUT ? seed_mix(p.seed_hi, p.ctr) : 0u;
-
-  for (int js = 0; js < nsup; ++js) {
-    __syncthreads();
-    tile_store_rows<DH, 128, C::KSTR>(rk, Ks, tid);
-    tile_store_rows<DH, 128, C::KSTR>(rv, Vs, tid);
-    __syncthreads();
-    if (js + 1 < nsup) {
-      tile_load_rows<DH, 128>(rk, kp, p.ss, (js + 1) * 128, p.S, tid);
-      tile_load_rows<DH, 128>(rv, vp, p.ss, (js + 1) * 128, p.S, tid);
-    }
-    const int kv0 = js * 128 + kh * 64;
-    if (kv0 <= q_base + 31 && kv0 < p.S) {
-      const bf16* Kt = Ks + kh * 64 * C::KSTR;
-      const bf16* Vt = Vs + kh * 64 * C::KSTR;
-      bf16x8 dsf[2][2];
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        f32x16 s, dp;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-        for (int ks = 0; ks < C::KS; ++ks) {
-          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Kt[k_nat + kb * 32 * C::KSTR + ks * 16]);
-          const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vt[k_nat + kb * 32 * C::KSTR + ks * 16]);
-          s = mfma32(kf, qf[ks], s);
-          dp = mfma32(vf, dof[ks], dp);
-        }
-        u32x4_t dsw[2];
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          bool keep[4] = {true, true, true, true};
-          if (DROPOUT) drop_keep4(e_row + (uint32_t)(kv0 + kb * 32 + 8 * qd + 4 * hh), p.thr, p.seed_lo, shi, keep);
-          float ds[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = 4 * qd + e;
-            const int key = kv0 + kb * 32 + 8 * qd + 4 * hh + e;
-            const float pv = (key > query || key >= p.S) ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[r], p.c, -lse2));
-            float dpv = dp[r];
-            if (DROPOUT) dpv = keep[e] ? dpv * p.inv_keep : 0.f;
-            ds[e] = pv * (dpv - delta);
-          }
-          dsw[qd >> 1][2 * (qd & 1)] = pack_bf16x2(ds[0], ds[1]);
-          dsw[qd >> 1][2 * (qd & 1) + 1] = pack_bf16x2(ds[2], ds[3]);
-        }
-        dsf[kb][0] = __builtin_bit_cast(bf16x8, dsw[0]);
-        dsf[kb][1] = __builtin_bit_cast(bf16x8, dsw[1]);
-      }
-#pragma unroll
-      for (int nb = 0; nb < C::NB; ++nb)
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int cs = 0; cs < 2; ++cs) {
-            const bf16* kt = &Kt[k_tr + (kb * 32 + 16 * cs) * C::KSTR + nb * 32];
-            const bf16x8 kf = cat4(lds_tr_b64(kt), lds_tr_b64(kt + 8 * C::KSTR));
-            dqt[nb] = mfma32(kf, dsf[kb][cs], dqt[nb]);
-          }
-    }
-  }
-  __syncthreads();
-  float* mb = reinterpret_cast<float*>(dq2_smem) + (size_t)(qh * 64 + lane) * (C::NB * 16);
-  if (kh == 1) {
-#pragma unroll
-    for (int nb = 0; nb < C::NB; ++nb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mb[nb * 16 + r] = dqt[nb][r];
-  }
-  __syncthreads();
-  if (kh == 1) return;
-  if (query < p.S) {
-    bf16* dq = p.dq + (int64_t)b * p.sb + (int64_t)query * p.ss + h * DH;
-#pragma unroll
-    for (int nb = 0; nb < C::NB; ++nb)
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        bf16x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (bf16)((dqt[nb][4 * qd + e] + mb[nb * 16 + 4 * qd + e]) * p.scale);
-        *reinterpret_cast<bf16x4*>(dq + nb * 32 + 8 * qd + 4 * hh) = o;
-      }
-  }
-}
-
-// -------------------------------------------------------------------------------------------------------
 // backward: dK, dV (S form, one key per lane; loops over query tiles from the diagonal down)
 // -------------------------------------------------------------------------------------------------------
 template <int DH, bool DROPOUT>
@@ -880,176 +741,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
   }
 }
 
-// -------------------------------------------------------------------------------------------------------
-// backward: dK, dV with the mirrored work split (EXPERIMENTAL: ttts_debug_set_flags(524288), default off, written at the end
-// of round 1 with no GPU time left: not yet run).  64 keys per workgroup, 128 queries per iteration: wave (kh, qh) = key half
-// (32 keys) x query half (one 64-query tile of the super tile); the two query halves of a key half are summed through LDS at
-// the end.  The super tile (Q, dO, lse, delta of 128 queries) goes global -> LDS at the top of each iteration (no register
-// prefetch: the v1 kernel already uses 241 VGPRs), two workgroups per CU cover each other's load latency.
-// -------------------------------------------------------------------------------------------------------
-template <int DH, bool DROPOUT>
-__global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_bwd_dkdv_kv2_kernel(AttnParams p) {
-  using C = AttnCfg<DH>;
-  constexpr int CPT2 = 128 * (DH / 8) / 256;
-  extern __shared__ __attribute__((aligned(16))) unsigned char dkv2_smem[];
-  bf16* Qs = reinterpret_cast<bf16*>(dkv2_smem);                 // [128][KSTR]
-  bf16* Ds = Qs + 128 * C::KSTR;                                 // [128][KSTR]
-  float* Ls = reinterpret_cast<float*>(Ds + 128 * C::KSTR);      // [128] lse * log2(e)
-  float* Dl = Ls + 128;                                          // [128] delta
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int kh = wave & 1, qh = wave >> 1;
-  const int hh = lane >> 5, g = lane >> 4, ip = lane & 15;
-  const int nkb = (p.S + 63) / 64;
-  const int nbh = gridDim.x / nkb;
-  const int kblk = (int)(blockIdx.x / nbh);                      // earliest key blocks see the most queries: they come first
-  const int bh = blockIdx.x % nbh, h = bh % p.H, b = bh / p.H;
-  const int k_base = kblk * 64 + kh * 32;
-  const int key = k_base + (lane & 31);
-  const bf16* qp = p.q + (int64_t)b * p.sb + h * DH;
-  const bf16* kp = p.k + (int64_t)b * p.sb + h * DH;
-  const bf16* vp = p.v + (int64_t)b * p.sb + h * DH;
-  const bf16* dop = p.d_o + (int64_t)b * p.osb + h * DH;
-  const float* lsep = p.lse_in + (int64_t)(b * p.H + h) * p.S;
-  const float* delp = p.delta + (int64_t)(b * p.H + h) * p.S;
-
-  bf16x8 kf[C::KS], vf[C::KS];
-#pragma unroll
-  for (int ks = 0; ks < C::KS; ++ks) {
-    kf[ks] = key < p.S ? *reinterpret_cast<const bf16x8*>(kp + (int64_t)key * p.ss + ks * 16 + hh * 8) : zero8();
-    vf[ks] = key < p.S ? *reinterpret_cast<const bf16x8*>(vp + (int64_t)key * p.ss + ks * 16 + hh * 8) : zero8();
-  }
-  f32x16 dkt[C::NB], dvt[C::NB];
-#pragma unroll
-  for (int nb = 0; nb < C::NB; ++nb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { dkt[nb][r] = 0.f; dvt[nb][r] = 0.f; }
-
-  const int js0 = (kblk * 64) / 128;
-  const int nsup = (p.S + 127) / 128;
-  const int q_nat = (lane & 31) * C::KSTR + hh * 8;
-  const int q_tr = (4 * hh + (ip >> 2)) * C::KSTR + 16 * (g & 1) + 4 * (ip & 3);
-  const uint32_t e_bh = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((int64_t)(b * p.H + h) * p.S));
-  const uint32_t e_lane = __umul24((uint32_t)(4 * hh + (lane & 1)), (uint32_t)p.Sp) + (uint32_t)key;
-  const uint32_t shi = DROPOUT ? seed_mix(p.seed_hi, p.ctr) : 0u;
-
-  for (int js = js0; js < nsup; ++js) {
-    __syncthreads();                                             // every wave is done with the previous super tile
-    {
-      bf16x8 rq[CPT2], rd[CPT2];
-      tile_load_rows<DH, 128>(rq, qp, p.ss, js * 128, p.S, tid);
-      tile_load_rows<DH, 128>(rd, dop, p.oss, js * 128, p.S, tid);
-      const int qi = js * 128 + (tid & 127);
-      const float st = qi < p.S ? (tid < 128 ? lsep[qi] * LOG2E : delp[qi]) : 0.f;
-      tile_store_rows<DH, 128, C::KSTR>(rq, Qs, tid);
-      tile_store_rows<DH, 128, C::KSTR>(rd, Ds, tid);
-      if (tid < 128) Ls[tid] = st; else Dl[tid - 128] = st;
-    }
-    __syncthreads();
-    const int q0 = js * 128 + qh * 64;                           // this wave's 64-query tile
-    if (q0 + 63 >= k_base && q0 < p.S) {                         // wave-uniform: some query of the tile can see some key of the wave
-      const bf16* Qt = Qs + qh * 64 * C::KSTR;
-      const bf16* Dt = Ds + qh * 64 * C::KSTR;
-      const float* Lt = Ls + qh * 64;
-      const float* Dlt = Dl + qh * 64;
-#pragma unroll
-      for (int qs = 0; qs < 2; ++qs) {
-        f32x16 s, dp;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-        for (int ks = 0; ks < C::KS; ++ks) {
-          const bf16x8 qa = *reinterpret_cast<const bf16x8*>(&Qt[q_nat + qs * 32 * C::KSTR + ks * 16]);
-          const bf16x8 da = *reinterpret_cast<const bf16x8*>(&Dt[q_nat + qs * 32 * C::KSTR + ks * 16]);
-          s = mfma32(qa, kf[ks], s);
-          dp = mfma32(da, vf[ks], dp);
-        }
-        bf16x8 pf[2], dsf[2];
-        u32x4_t pw[2], dsw[2];
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          const f32x4 l4 = *reinterpret_cast<const f32x4*>(&Lt[qs * 32 + 8 * qd + 4 * hh]);
-          const f32x4 d4 = *reinterpret_cast<const f32x4*>(&Dlt[qs * 32 + 8 * qd + 4 * hh]);
-          bool keep4[4] = {true, true, true, true};
-          if (DROPOUT) {                                         // pair-shared hashes, as in attn_bwd_dkdv_kernel
-            const int odd = lane & 1;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-              const uint32_t e_tile = (e_bh + (uint32_t)(q0 + qs * 32)) * (uint32_t)p.Sp;
-              const uint32_t mine = hash32((e_tile + __umul24((uint32_t)(8 * qd + 2 * t), (uint32_t)p.Sp) + e_lane) >> 1, p.seed_lo, shi);
-              const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xF, 0xF, true);
-              const uint32_t h0 = odd ? other : mine, h1 = odd ? mine : other;
-              keep4[2 * t] = (odd ? (h0 >> 16) : (h0 & 0xFFFFu)) >= p.thr;
-              keep4[2 * t + 1] = (odd ? (h1 >> 16) : (h1 & 0xFFFFu)) >= p.thr;
-            }
-          }
-          float pd[4], ds[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = 4 * qd + e;
-            const int query = q0 + qs * 32 + 8 * qd + 4 * hh + e;
-            const float pv = (key > query || query >= p.S) ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[r], p.c, -l4[e]));
-            float dpv = dp[r];
-            pd[e] = pv;
-            if (DROPOUT) {
-              const bool keep = keep4[e];
-              dpv = keep ? dpv * p.inv_keep : 0.f;
-              pd[e] = keep ? pv : 0.f;
-            }
-            ds[e] = pv * (dpv - d4[e]);
-          }
-          pw[qd >> 1][2 * (qd & 1)] = pack_bf16x2(pd[0], pd[1]);
-          pw[qd >> 1][2 * (qd & 1) + 1] = pack_bf16x2(pd[2], pd[3]);
-          dsw[qd >> 1][2 * (qd & 1)] = pack_bf16x2(ds[0], ds[1]);
-          dsw[qd >> 1][2 * (qd & 1) + 1] = pack_bf16x2(ds[2], ds[3]);
-        }
-        pf[0] = __builtin_bit_cast(bf16x8, pw[0]); pf[1] = __builtin_bit_cast(bf16x8, pw[1]);
-        dsf[0] = __builtin_bit_cast(bf16x8, dsw[0]); dsf[1] = __builtin_bit_cast(bf16x8, dsw[1]);
-#pragma unroll
-        for (int nb = 0; nb < C::NB; ++nb)
-#pragma unroll
-          for (int cs = 0; cs < 2; ++cs) {
-            const bf16* dt = &Dt[q_tr + (qs * 32 + 16 * cs) * C::KSTR + nb * 32];
-            const bf16* qt_ = &Qt[q_tr + (qs * 32 + 16 * cs) * C::KSTR + nb * 32];
-            const bf16x8 dof = cat4(lds_tr_b64(dt), lds_tr_b64(dt + 8 * C::KSTR));
-            const bf16x8 qf = cat4(lds_tr_b64(qt_), lds_tr_b64(qt_ + 8 * C::KSTR));
-            dvt[nb] = mfma32(dof, pf[cs], dvt[nb]);
-            dkt[nb] = mfma32(qf, dsf[cs], dkt[nb]);
-          }
-      }
-    }
-  }
-  // sum the two query halves of each key half through LDS
-  __syncthreads();
-  float* mb = reinterpret_cast<float*>(dkv2_smem) + (size_t)(kh * 64 + lane) * (2 * C::NB * 16);
-  if (qh == 1) {
-#pragma unroll
-    for (int nb = 0; nb < C::NB; ++nb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { mb[nb * 16 + r] = dkt[nb][r]; mb[C::NB * 16 + nb * 16 + r] = dvt[nb][r]; }
-  }
-  __syncthreads();
-  if (qh == 1) return;
-  if (key < p.S) {
-    bf16* dk = p.dk + (int64_t)b * p.sb + (int64_t)key * p.ss + h * DH;
-    bf16* dv = p.dv + (int64_t)b * p.sb + (int64_t)key * p.ss + h * DH;
-#pragma unroll
-    for (int nb = 0; nb < C::NB; ++nb)
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        bf16x4 ok, ov;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float dkv = dkt[nb][4 * qd + e] + mb[nb * 16 + 4 * qd + e];
-          const float dvv = dvt[nb][4 * qd + e] + mb[C::NB * 16 + nb * 16 + 4 * qd + e];
-          ok[e] = (bf16)(dkv * p.scale);
-          ov[e] = (bf16)(DROPOUT ? dvv * p.inv_keep : dvv);
-        }
-        *reinterpret_cast<bf16x4*>(dk + nb * 32 + 8 * qd + 4 * hh) = ok;
-        *reinterpret_cast<bf16x4*>(dv + nb * 32 + 8 * qd + 4 * hh) = ov;
-      }
-  }
-}
-
 __global__ __launch_bounds__(256) void attn_dropout_mask_kernel(uint8_t* mask, int64_t total, int S, int Sp,
                                                                 uint32_t thr, uint32_t slo, uint32_t shi,
                                                                 const uint32_t* ctr) {
@@ -1062,7 +753,7 @@ __global__ __launch_bounds__(256) void attn_dropout_mask_kernel(uint8_t* mask, i
 }
 
 static int fill_params(AttnParams& p, int B, int H, int S, int head_dim, int64_t sb, int64_t ss, int64_t osb,
-                       int64_t oss, float scale, float dropout_p, uint64_t seed) {
+                       int64_t oss, float scale, float dropout_p, uint64_t seed, const uint32_t* dropout_counter) {
   TTTS_REQUIRE(B > 0 && H > 0 && S > 0, "attn: bad shape B=%d H=%d S=%d", B, H, S);
   TTTS_REQUIRE(head_dim == 32 || head_dim == 64 || head_dim == 128, "attn: head_dim %d not in {32,64,128}", head_dim);
   TTTS_REQUIRE(ss % 8 == 0 && sb % 8 == 0 && oss % 8 == 0 && osb % 8 == 0, "attn: strides must be multiples of 8 elements");
@@ -1077,7 +768,7 @@ static int fill_params(AttnParams& p, int B, int H, int S, int head_dim, int64_t
   p.inv_keep = p.thr ? 65536.0f / (65536.0f - (float)p.thr) : 1.0f;
   p.seed_lo = (uint32_t)seed;
   p.seed_hi = (uint32_t)(seed >> 32);
-  p.ctr = dropout_counter();
+  p.ctr = dropout_counter;
   return TTTS_OK;
 }
 
@@ -1088,18 +779,18 @@ using namespace ttts;
 extern "C" int ttts_attn_causal_fwd_bf16(const void* q, const void* k, const void* v, void* o, float* lse, int32_t B,
                                          int32_t H, int32_t S, int32_t head_dim, int64_t qkv_stride_b,
                                          int64_t qkv_stride_s, int64_t o_stride_b, int64_t o_stride_s, float scale,
-                                         float dropout_p, uint64_t seed, void* stream) {
+                                         float dropout_p, uint64_t seed, const uint32_t* dropout_counter, void* stream) {
   TTTS_REQUIRE(q && k && v && o && lse, "attn_fwd: null pointer");
   TTTS_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(o), "attn_fwd: 16-byte alignment required");
   AttnParams p{};
-  int rc = fill_params(p, B, H, S, head_dim, qkv_stride_b, qkv_stride_s, o_stride_b, o_stride_s, scale, dropout_p, seed);
+  int rc = fill_params(p, B, H, S, head_dim, qkv_stride_b, qkv_stride_s, o_stride_b, o_stride_s, scale, dropout_p, seed, dropout_counter);
   if (rc) return rc;
   p.q = (const bf16*)q; p.k = (const bf16*)k; p.v = (const bf16*)v; p.out = (bf16*)o; p.lse = lse;
   const int grid = ((S + 127) / 128) * H * B;
   hipStream_t s = as_stream(stream);
   // work split: with dropout the 64-query x 128-key kernel wins (36.1 vs 43.8 us at the BASELINE shape: the longest block is half
-  // as long); without dropout the two are equal (31.2 vs 30.4 us) and the 128-query kernel stays.  Flags force either one.
-  const bool use_kv2 = (g_debug_flags & 65536) || (p.thr && !(g_debug_flags & 131072));
+  // as long); without dropout the two are equal (31.2 vs 30.4 us) and the 128-query kernel stays.
+  const bool use_kv2 = p.thr != 0;
   if (use_kv2) {
     const int grid2 = ((S + 63) / 64) * H * B;
 #define FWD2(DH)                                                                                                         \
@@ -1135,64 +826,39 @@ extern "C" int ttts_attn_causal_bwd_bf16(const void* q, const void* k, const voi
                                          const float* lse, void* dq, void* dk, void* dv, void* workspace, int32_t B,
                                          int32_t H, int32_t S, int32_t head_dim, int64_t qkv_stride_b,
                                          int64_t qkv_stride_s, int64_t o_stride_b, int64_t o_stride_s, float scale,
-                                         float dropout_p, uint64_t seed, void* stream) {
+                                         float dropout_p, uint64_t seed, const uint32_t* dropout_counter, void* stream) {
   TTTS_REQUIRE(q && k && v && o && d_o && lse && dq && dk && dv && workspace, "attn_bwd: null pointer");
   TTTS_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(o) && aligned16(d_o) && aligned16(dq) &&
                aligned16(dk) && aligned16(dv), "attn_bwd: 16-byte alignment required");
   AttnParams p{};
-  int rc = fill_params(p, B, H, S, head_dim, qkv_stride_b, qkv_stride_s, o_stride_b, o_stride_s, scale, dropout_p, seed);
+  int rc = fill_params(p, B, H, S, head_dim, qkv_stride_b, qkv_stride_s, o_stride_b, o_stride_s, scale, dropout_p, seed, dropout_counter);
   if (rc) return rc;
   p.q = (const bf16*)q; p.k = (const bf16*)k; p.v = (const bf16*)v; p.o = (const bf16*)o; p.d_o = (const bf16*)d_o;
   p.lse_in = lse; p.dq = (bf16*)dq; p.dk = (bf16*)dk; p.dv = (bf16*)dv; p.delta = (float*)workspace;
   hipStream_t s = as_stream(stream);
   const int grid = ((S + 127) / 128) * H * B;
   const int dgrid = (int)cdiv((int64_t)B * S * H, 256);
-  const bool dq_kv2 = (g_debug_flags & 262144) != 0;   // experimental dQ work split (attn_bwd_dq_kv2_kernel), default off
-  const int grid2 = ((S + 63) / 64) * H * B;
-#define DQ2(DH, DROP)                                                                                                     \
-  {                                                                                                                       \
-    const size_t smem = (size_t)2 * 128 * AttnCfg<DH>::KSTR * sizeof(bf16);                                               \
-    static bool attr_set = false;   /* once per instantiation: the attribute call is not free on the launch path */      \
-    if (!attr_set) {                                                                                                      \
-      hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kv2_kernel<DH, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-      attr_set = true;                                                                                                    \
-    }                                                                                                                     \
-    attn_bwd_dq_kv2_kernel<DH, DROP><<<grid2, 256, smem, s>>>(p);                                                         \
-  }
-  const bool dkdv_kv2 = (g_debug_flags & 524288) != 0;   // experimental dK/dV work split (attn_bwd_dkdv_kv2_kernel), default off
-#define DKV2(DH, DROP)                                                                                                    \
-  {                                                                                                                       \
-    const size_t smem = (size_t)2 * 128 * AttnCfg<DH>::KSTR * sizeof(bf16) + 256 * sizeof(float);                         \
-    static bool attr_set = false;                                                                                         \
-    if (!attr_set) {                                                                                                      \
-      hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_kv2_kernel<DH, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-      attr_set = true;                                                                                                    \
-    }                                                                                                                     \
-    attn_bwd_dkdv_kv2_kernel<DH, DROP><<<grid2, 256, smem, s>>>(p);                                                       \
-  }
 #define BWD(DH)                                                             \
   attn_delta_kernel<DH><<<dgrid, 256, 0, s>>>(p);                          \
   if (p.thr) {                                                              \
-    if (dkdv_kv2) DKV2(DH, true) else attn_bwd_dkdv_kernel<DH, true><<<grid, 256, 0, s>>>(p);   \
-    if (dq_kv2) DQ2(DH, true) else attn_bwd_dq_kernel<DH, true><<<grid, 256, 0, s>>>(p);   \
+    attn_bwd_dkdv_kernel<DH, true><<<grid, 256, 0, s>>>(p);                 \
+    attn_bwd_dq_kernel<DH, true><<<grid, 256, 0, s>>>(p);                   \
   } else {                                                                  \
-    if (dkdv_kv2) DKV2(DH, false) else attn_bwd_dkdv_kernel<DH, false><<<grid, 256, 0, s>>>(p); \
-    if (dq_kv2) DQ2(DH, false) else attn_bwd_dq_kernel<DH, false><<<grid, 256, 0, s>>>(p); \
+    attn_bwd_dkdv_kernel<DH, false><<<grid, 256, 0, s>>>(p);                \
+    attn_bwd_dq_kernel<DH, false><<<grid, 256, 0, s>>>(p);                  \
   }
   if (head_dim == 32) { BWD(32) } else if (head_dim == 64) { BWD(64) } else { BWD(128) }
 #undef BWD
-#undef DQ2
-#undef DKV2
   return check_launch("attn_bwd");
 }
 
 extern "C" int ttts_attn_dropout_mask_u8(uint8_t* mask, int32_t B, int32_t H, int32_t S, float dropout_p, uint64_t seed,
-                                         void* stream) {
+                                         const uint32_t* dropout_counter, void* stream) {
   TTTS_REQUIRE(mask && B > 0 && H > 0 && S > 0 && dropout_p >= 0.f && dropout_p < 1.f, "dropout_mask: bad arguments");
   const int64_t total = (int64_t)B * H * S * S;
   const int Sp = (S + 3) & ~3;
   TTTS_REQUIRE((int64_t)B * H * S * Sp < (int64_t)1 << 32, "dropout_mask: index space exceeds 2^32");
   attn_dropout_mask_kernel<<<(int)std::min<int64_t>(cdiv(total, 256), 8192), 256, 0, as_stream(stream)>>>(
-      mask, total, S, Sp, dropout_threshold(dropout_p), (uint32_t)seed, (uint32_t)(seed >> 32), dropout_counter());
+      mask, total, S, Sp, dropout_threshold(dropout_p), (uint32_t)seed, (uint32_t)(seed >> 32), dropout_counter);
   return check_launch("dropout_mask");
 }

@@ -32,6 +32,22 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// The convolution family's caller-owned context (include/ttts_hip.h: ttts_conv_ctx), as the internal launchers see it.
+struct ConvCtx {
+  void* ws = nullptr;      // scratch for split-bf16 operand copies / weight-gradient slabs; NULL: exact-fp32 kernels only
+  int64_t ws_bytes = 0;
+  int flags = 0;           // TTTS_CONV_EXACT_F32 | heuristic overrides (tests, tools/conv_bench.py)
+};
+inline ConvCtx conv_ctx_of(const ttts_conv_ctx* c) {
+  ConvCtx cx;
+  if (c) {
+    cx.ws = c->workspace;
+    cx.ws_bytes = c->workspace ? c->workspace_bytes : 0;
+    cx.flags = c->flags;
+  }
+  return cx;
+}
+
 // ---- device types ----------------------------------------------------------------------------------
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -101,10 +117,9 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x, uint32_t seed_lo, uint32_
   x ^= x >> 16;
   return x;
 }
-// Process-wide dropout stream counter: a uint32 in DEVICE memory owned by the caller (ttts_set_dropout_counter).
-// Kernels add it to their seed at run time, so a step captured once in a hipGraph draws fresh masks on every
+// Dropout stream counter: a uint32 in DEVICE memory owned by the caller, passed to every entry point that takes a dropout
+// seed.  Kernels add it to their seed at run time, so a step captured once in a hipGraph draws fresh masks on every
 // replay (kernel arguments are frozen by capture, device memory is not).  NULL = disabled.
-const uint32_t* dropout_counter();
 __device__ __forceinline__ uint32_t seed_mix(uint32_t seed_hi, const uint32_t* ctr) {
   return ctr ? seed_hi + *ctr * 0x9E3779B1u : seed_hi;
 }

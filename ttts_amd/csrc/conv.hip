@@ -21,13 +21,13 @@ namespace ttts {
 int conv1d_mfma_try(const float* x, const float* w, const float* bias, const float* bbias, const float* resid,
                     const float* gate, const float* omask, float* y, int B, int M, int N, int Lin, int Lout, int K,
                     int stride, int pad, int dil, int transposed, float in_slope, float gate_slope, int out_act,
-                    float out_slope, float out_scale, int accumulate, hipStream_t stream, bool* handled);
+                    float out_slope, float out_scale, int accumulate, const ConvCtx& cx, hipStream_t stream, bool* handled);
 int conv1d_wgrad_mfma_try(const float* dy, const float* x, float* dw, int B, int Cin, int Lin, int Cout, int Lout, int K,
-                          int stride, int pad, int dil, float dy_slope, float x_slope, hipStream_t stream, bool* handled);
+                          int stride, int pad, int dil, float dy_slope, float x_slope, const ConvCtx& cx, hipStream_t stream, bool* handled);
 int conv1d_dgrad_strided_mfma_try(const float* dy, const float* w, const float* bias, const float* resid,
                                   const float* gate, const float* omask, float* dx, int B, int Cin, int Lin, int Cout,
                                   int Lout, int K, int stride, int pad, float in_slope, float gate_slope, float out_scale,
-                                  int accumulate, hipStream_t stream, bool* handled);
+                                  int accumulate, const ConvCtx& cx, hipStream_t stream, bool* handled);
 
 constexpr int CV_CT = 32;   // output-channel tile
 constexpr int CV_LT = 128;  // position tile
@@ -560,8 +560,6 @@ static int set_smem_attr(const void* fn, bool& done) {
 
 using namespace ttts;
 
-extern int g_debug_flags;   // gemm.hip (ttts_debug_set_flags); 256 = keep every convolution on the direct kernels
-
 static int conv_check(int B, int Cin, int Lin, int Cout, int Lout, int K, int stride, int pad, int dil, int G) {
   TTTS_REQUIRE(G > 0 && Cin % G == 0 && Cout % G == 0, "conv1d: channels (%d -> %d) not divisible by groups %d", Cin, Cout, G);
   TTTS_REQUIRE(B > 0 && Cin > 0 && Lin > 0 && Cout > 0 && Lout > 0 && K > 0 && stride > 0 && dil > 0 && pad >= 0, "conv1d: bad shape");
@@ -573,19 +571,21 @@ extern "C" int ttts_conv1d_fwd_f32(const float* x, const float* w, const float* 
                                    const float* resid, const float* gate, const float* omask, float* y, int32_t B, int32_t Cin, int32_t Lin,
                                    int32_t Cout, int32_t Lout, int32_t K, int32_t stride, int32_t pad, int32_t dil,
                                    int32_t groups, float in_slope, float gate_slope, int32_t out_act, float out_slope,
-                                   float out_scale, int32_t accumulate, void* stream) {
+                                   float out_scale, int32_t accumulate, const ttts_conv_ctx* ctx, void* stream) {
   TTTS_REQUIRE(x && w && y, "conv1d_fwd: null pointer");
+  TTTS_REQUIRE(!ctx || !ctx->workspace || aligned16(ctx->workspace), "conv1d_fwd: ctx workspace must be 16-byte aligned");
+  const ConvCtx cx = conv_ctx_of(ctx);
   TTTS_REQUIRE(out_act >= 0 && out_act <= 2, "conv1d_fwd: out_act must be 0 (none), 1 (tanh) or 2 (leaky-relu)");
   int rc = conv_check(B, Cin, Lin, Cout, Lout, K, stride, pad, dil, groups);
   if (rc) return rc;
-  if (groups == 1 && !(g_debug_flags & 256)) {
+  if (groups == 1 && !(cx.flags & 256)) {
     bool handled = false;
     rc = conv1d_mfma_try(x, w, bias, bbias, resid, gate, omask, y, B, Cout, Cin, Lin, Lout, K, stride, pad, dil, 0, in_slope,
-                         gate_slope, out_act, out_slope, out_scale, accumulate, as_stream(stream), &handled);
+                         gate_slope, out_act, out_slope, out_scale, accumulate, cx, as_stream(stream), &handled);
     if (rc || handled) return rc;
   }
   const int lin_t = (CV_LT - 1) * stride + (K - 1) * dil + 1;
-  if (groups > 1 && !(g_debug_flags & 256)) {
+  if (groups > 1 && !(cx.flags & 256)) {
     const int cig = Cin / groups, cog = Cout / groups;
     const int nci = (cog >= CV_CT ? 1 : CV_CT / cog) * cig;
     const size_t gsmem = ((size_t)nci * lin_t + (size_t)CV_CT * cig * K) * sizeof(float);
@@ -615,27 +615,29 @@ extern "C" int ttts_conv1d_dgrad_f32(const float* dy, const float* w, const floa
                                      const float* gate, const float* omask, float* dx, int32_t B, int32_t Cin, int32_t Lin, int32_t Cout,
                                      int32_t Lout, int32_t K, int32_t stride, int32_t pad, int32_t dil, int32_t groups,
                                      float in_slope, float gate_slope, float out_scale, int32_t accumulate,
-                                     void* stream) {
+                                     const ttts_conv_ctx* ctx, void* stream) {
   TTTS_REQUIRE(dy && w && dx, "conv1d_dgrad: null pointer");
+  TTTS_REQUIRE(!ctx || !ctx->workspace || aligned16(ctx->workspace), "conv1d_dgrad: ctx workspace must be 16-byte aligned");
+  const ConvCtx cx = conv_ctx_of(ctx);
   TTTS_REQUIRE(groups > 0 && Cin % groups == 0 && Cout % groups == 0, "conv1d_dgrad: channels not divisible by groups");
   TTTS_REQUIRE(B > 0 && Cin > 0 && Lin > 0 && Cout > 0 && Lout > 0 && K > 0 && stride > 0 && dil > 0 && pad >= 0, "conv1d_dgrad: bad shape");
   TTTS_REQUIRE(stride == 1 || dil == 1, "conv1d_dgrad: stride > 1 requires dilation 1");
   TTTS_REQUIRE((Lout - 1) * stride - 2 * pad + dil * (K - 1) + 1 <= Lin, "conv1d_dgrad: Lin too small for Lout");
-  if (groups == 1 && stride == 1 && !(g_debug_flags & 256)) {
+  if (groups == 1 && stride == 1 && !(cx.flags & 256)) {
     // stride-1 data gradient == forward convolution of dy with the transposed, tap-flipped weights and pad' = dil (K-1) - pad
     bool handled = false;
     int rc2 = conv1d_mfma_try(dy, w, bias, nullptr, resid, gate, omask, dx, B, Cin, Cout, Lout, Lin, K, 1, dil * (K - 1) - pad,
-                              dil, 1, in_slope, gate_slope, 0, 1.f, out_scale, accumulate, as_stream(stream), &handled);
+                              dil, 1, in_slope, gate_slope, 0, 1.f, out_scale, accumulate, cx, as_stream(stream), &handled);
     if (rc2 || handled) return rc2;
   }
-  if (groups == 1 && stride > 1 && dil == 1 && !(g_debug_flags & 256)) {
+  if (groups == 1 && stride > 1 && dil == 1 && !(cx.flags & 256)) {
     bool handled = false;
     int rc2 = conv1d_dgrad_strided_mfma_try(dy, w, bias, resid, gate, omask, dx, B, Cin, Lin, Cout, Lout, K, stride, pad, in_slope,
-                                            gate_slope, out_scale, accumulate, as_stream(stream), &handled);
+                                            gate_slope, out_scale, accumulate, cx, as_stream(stream), &handled);
     if (rc2 || handled) return rc2;
   }
   const int lt = (CV_LT - 1 + (K - 1) * dil) / stride + 2;
-  if (groups > 1 && !(g_debug_flags & 256)) {
+  if (groups > 1 && !(cx.flags & 256)) {
     const int cig = Cin / groups, cog = Cout / groups;
     const int nco = cig <= CV_CT && cig % 4 == 0 && CV_CT % cig == 0 ? (CV_CT / cig) * cog : 0;
     const size_t gsmem = ((size_t)nco * lt + (size_t)nco * cig * K) * sizeof(float);
@@ -663,16 +665,18 @@ extern "C" int ttts_conv1d_dgrad_f32(const float* dy, const float* w, const floa
 
 extern "C" int ttts_conv1d_wgrad_f32(const float* dy, const float* x, float* dw, int32_t B, int32_t Cin, int32_t Lin,
                                      int32_t Cout, int32_t Lout, int32_t K, int32_t stride, int32_t pad, int32_t dil,
-                                     int32_t groups, float dy_slope, float x_slope, void* stream) {
+                                     int32_t groups, float dy_slope, float x_slope, const ttts_conv_ctx* ctx, void* stream) {
   TTTS_REQUIRE(dy && x && dw, "conv1d_wgrad: null pointer");
+  TTTS_REQUIRE(!ctx || !ctx->workspace || aligned16(ctx->workspace), "conv1d_wgrad: ctx workspace must be 16-byte aligned");
+  const ConvCtx cx = conv_ctx_of(ctx);
   TTTS_REQUIRE(groups > 0 && Cin % groups == 0 && Cout % groups == 0, "conv1d_wgrad: channels not divisible by groups");
-  if (groups == 1 && !(g_debug_flags & 256)) {
+  if (groups == 1 && !(cx.flags & 256)) {
     bool handled = false;
     int rc2 = conv1d_wgrad_mfma_try(dy, x, dw, B, Cin, Lin, Cout, Lout, K, stride, pad, dil, dy_slope, x_slope,
-                                    as_stream(stream), &handled);
+                                    cx, as_stream(stream), &handled);
     if (rc2 || handled) return rc2;
   }
-  if (groups > 1 && !(g_debug_flags & 256)) {
+  if (groups > 1 && !(cx.flags & 256)) {
     const int cig = Cin / groups, cog = Cout / groups;
     const int nci = (cog >= 16 ? 1 : 16 / cog) * cig;
     const int lin_g = (WG_L - 1) * stride + (K - 1) * dil + 1;

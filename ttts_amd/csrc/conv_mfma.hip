@@ -17,7 +17,6 @@
 
 #include "common.hpp"
 
-extern int g_debug_flags;   // gemm.hip (ttts_debug_set_flags); 2048 = allow the small tile shapes
 
 namespace ttts {
 
@@ -419,7 +418,6 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_mfma_kernel(WgradMfmaParams 
   }
 }
 
-#define g_debug_flags_conv ::g_debug_flags
 
 static int set_attr_once(const void* fn, bool& done) {
   if (done) return TTTS_OK;
@@ -432,7 +430,7 @@ static int set_attr_once(const void* fn, bool& done) {
 // ---- dispatch helpers used by conv.hip ------------------------------------------------------------------------------------
 // Returns TTTS_OK and sets *handled when the MFMA path took the launch.
 template <int WCO, int NW>
-static int conv1d_mfma_launch_t(ConvMfmaParams p, hipStream_t stream, bool* handled) {
+static int conv1d_mfma_launch_t(ConvMfmaParams p, const ConvCtx& cx, hipStream_t stream, bool* handled) {
   constexpr int MT = 32 * WCO, LT = 64 * (NW / WCO);
   const int K = p.K, SEG = p.SEG > LT ? LT : p.SEG;
   p.SEG = SEG;
@@ -455,12 +453,9 @@ static int conv1d_mfma_launch_t(ConvMfmaParams p, hipStream_t stream, bool* hand
   return check_launch("conv1d_mfma");
 }
 
-// caller-owned scratch for the split weights (ttts_conv_set_workspace); the split-bf16 path is used only while it is set
-static void* g_conv_ws = nullptr;
-static int64_t g_conv_ws_bytes = 0;
 
 template <int WCO>
-static int conv1d_bf16x3_launch_t(ConvMfmaParams p, hipStream_t stream, bool* handled) {
+static int conv1d_bf16x3_launch_t(ConvMfmaParams p, const ConvCtx& cx, hipStream_t stream, bool* handled) {
   constexpr int MT = 32 * WCO, LT = 64 * (4 / WCO);
   const int K = p.K, SEG = p.SEG > LT ? LT : p.SEG;
   p.SEG = SEG;
@@ -474,8 +469,8 @@ static int conv1d_bf16x3_launch_t(ConvMfmaParams p, hipStream_t stream, bool* ha
   // than on-the-fly splitting for the 16..64-channel long-row layers, and wins from 192 channels up)
   const bool presplit = p.x_hi != nullptr || cdiv(p.M, MT) >= 3;
   const int64_t xel = presplit ? (int64_t)p.B * nblk * p.Lin * 16 : 0;
-  if (2 * (elems + xel) * (int64_t)sizeof(bf16) > g_conv_ws_bytes) return TTTS_OK;
-  bf16* xhi = static_cast<bf16*>(g_conv_ws);       // scratch layout: [x hi][x lo][w hi][w lo] (the input split comes first so
+  if (2 * (elems + xel) * (int64_t)sizeof(bf16) > cx.ws_bytes) return TTTS_OK;
+  bf16* xhi = static_cast<bf16*>(cx.ws);       // scratch layout: [x hi][x lo][w hi][w lo] (the input split comes first so
   bf16* xlo = xhi + xel;                             // that the phases of a strided data gradient can share it)
   bf16* hi = xlo + xel;
   bf16* lo = hi + elems;
@@ -495,44 +490,44 @@ static int conv1d_bf16x3_launch_t(ConvMfmaParams p, hipStream_t stream, bool* ha
   return check_launch("conv1d_bf16x3");
 }
 
-static int conv1d_mfma_launch(ConvMfmaParams p, hipStream_t stream, bool* handled) {
+static int conv1d_mfma_launch(ConvMfmaParams p, const ConvCtx& cx, hipStream_t stream, bool* handled) {
   *handled = false;
   // batch folding for short rows (see SEG); requested segment length, clipped to the tile by the launcher
   p.SEG = (p.Lout <= 32 && p.B > 1) ? 32 : ((p.Lout <= 64 && p.B > 1) ? 64 : 1 << 20);
-  if (g_conv_ws && p.N >= 16 && !(g_debug_flags_conv & 4096)) {
-    int rc = p.M <= 32 ? conv1d_bf16x3_launch_t<1>(p, stream, handled) : conv1d_bf16x3_launch_t<2>(p, stream, handled);
+  if (cx.ws && p.N >= 16 && !(cx.flags & 4096)) {
+    int rc = p.M <= 32 ? conv1d_bf16x3_launch_t<1>(p, cx, stream, handled) : conv1d_bf16x3_launch_t<2>(p, cx, stream, handled);
     if (rc || *handled) return rc;
   }
   // tile choice: always the largest tile.  Measured (tools/conv_bench.py, B = 32): the smaller tiles <2,2>, <1,2>, <1,1> --
   // meant to put more workgroups on a CU for the 192-channel x 256-frame layers -- are 2-2.5x SLOWER there (WN in_layer
   // dgrad 346 -> 738 us): the kernel is bound by the global -> LDS staging work per MFMA, so less reuse per staged slab
   // costs more than the extra overlap gains.  They stay instantiable for experiments (flag 2048).
-  if (g_debug_flags_conv & 2048) {
+  if (cx.flags & 2048) {
     auto wgs = [&](int MT, int LT) {
       const int seg = p.SEG > LT ? LT : p.SEG;
       return cdiv(p.Lout, seg == LT ? LT : seg) * cdiv(p.M, MT) * cdiv(p.B, LT / seg);
     };
     if (p.M > 32 && wgs(64, 128) < 512) {
-      if (wgs(64, 64) >= 512) return conv1d_mfma_launch_t<2, 2>(p, stream, handled);
-      if (wgs(32, 128) >= 512) return conv1d_mfma_launch_t<1, 2>(p, stream, handled);
-      return conv1d_mfma_launch_t<1, 1>(p, stream, handled);
+      if (wgs(64, 64) >= 512) return conv1d_mfma_launch_t<2, 2>(p, cx, stream, handled);
+      if (wgs(32, 128) >= 512) return conv1d_mfma_launch_t<1, 2>(p, cx, stream, handled);
+      return conv1d_mfma_launch_t<1, 1>(p, cx, stream, handled);
     }
   }
-  if (p.M <= 32) return conv1d_mfma_launch_t<1, 4>(p, stream, handled);
-  return conv1d_mfma_launch_t<2, 4>(p, stream, handled);
+  if (p.M <= 32) return conv1d_mfma_launch_t<1, 4>(p, cx, stream, handled);
+  return conv1d_mfma_launch_t<2, 4>(p, cx, stream, handled);
 }
 
 // Returns TTTS_OK and sets *handled when the MFMA path took the launch.
 int conv1d_mfma_try(const float* x, const float* w, const float* bias, const float* bbias, const float* resid,
                     const float* gate, const float* omask, float* y, int B, int M, int N, int Lin, int Lout, int K,
                     int stride, int pad, int dil, int transposed, float in_slope, float gate_slope, int out_act,
-                    float out_slope, float out_scale, int accumulate, hipStream_t stream, bool* handled) {
+                    float out_slope, float out_scale, int accumulate, const ConvCtx& cx, hipStream_t stream, bool* handled) {
   *handled = false;
   if (N < 8 || K > 16) return TTTS_OK;       // thin inputs / long taps stay on the direct kernels (M = 1 heads are fine:
                                              // a 32-row tile with one live row beats looping 1024 channels on the vector ALUs)
   ConvMfmaParams p{x, w, bias, bbias, resid, omask, gate, y, B, M, N, Lin, Lout, K, stride, pad, dil, transposed, 0,
                    K, 0, 1, 1, 0, Lout, 0, in_slope, gate_slope, out_act, out_slope, out_scale, accumulate, nullptr, nullptr, 0, nullptr, nullptr};
-  return conv1d_mfma_launch(p, stream, handled);
+  return conv1d_mfma_launch(p, cx, stream, handled);
 }
 
 // Data gradient of a stride-s convolution (== forward of a ConvTranspose1d), dilation 1, as s stride-1 sub-convolutions:
@@ -541,17 +536,17 @@ int conv1d_mfma_try(const float* x, const float* w, const float* bias, const flo
 int conv1d_dgrad_strided_mfma_try(const float* dy, const float* w, const float* bias, const float* resid,
                                   const float* gate, const float* omask, float* dx, int B, int Cin, int Lin, int Cout,
                                   int Lout, int K, int stride, int pad, float in_slope, float gate_slope, float out_scale,
-                                  int accumulate, hipStream_t stream, bool* handled) {
+                                  int accumulate, const ConvCtx& cx, hipStream_t stream, bool* handled) {
   *handled = false;
   if (Cout < 8 || K > 16 * stride || K < stride) return TTTS_OK;
   // split-bf16 path: split dy ONCE for all phases (same place conv1d_bf16x3_launch_t would put it)
   const bf16* xs_hi = nullptr;
   const bf16* xs_lo = nullptr;
-  if (g_conv_ws && Cout >= 16 && Cin >= 192 && !(g_debug_flags_conv & 4096)) {
+  if (cx.ws && Cout >= 16 && Cin >= 192 && !(cx.flags & 4096)) {
     const int nblk = (Cout + 15) / 16;
     const int64_t xel = (int64_t)B * nblk * Lout * 16;
-    if (2 * xel * (int64_t)sizeof(bf16) + (32 << 20) <= g_conv_ws_bytes) {
-      bf16* xh = static_cast<bf16*>(g_conv_ws);
+    if (2 * xel * (int64_t)sizeof(bf16) + (32 << 20) <= cx.ws_bytes) {
+      bf16* xh = static_cast<bf16*>(cx.ws);
       conv_input_split_kernel<<<(int)std::min<int64_t>(cdiv(xel / 16, 256), 8192), 256, 0, stream>>>(dy, xh, xh + xel, B, Cout, Lout, nblk, in_slope);
       xs_hi = xh; xs_lo = xh + xel;
     }
@@ -565,7 +560,7 @@ int conv1d_dgrad_strided_mfma_try(const float* dy, const float* w, const float* 
     ConvMfmaParams p{dy, w, bias, nullptr, resid, omask, gate, dx, B, Cin, Cout, Lout, T, Kp, 1, (Kp - 1) - tmin, 1, 1, 0,
                      K, phi, stride, stride, off, Lin, 0, in_slope, gate_slope, 0, 1.f, out_scale, accumulate, nullptr, nullptr, 0, xs_hi, xs_lo};
     bool h = false;
-    int rc = conv1d_mfma_launch(p, stream, &h);
+    int rc = conv1d_mfma_launch(p, cx, stream, &h);
     if (rc) return rc;
     if (!h) return phi == 0 ? TTTS_OK : fail(TTTS_EUNSUPPORTED, "conv1d_dgrad: polyphase tile does not fit LDS");
   }
@@ -821,14 +816,14 @@ static void launch_wgrad_taps(const WgradB3Params& p, dim3 grid, hipStream_t str
 }
 
 static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, int B, int Cin, int Lin, int Cout, int Lout,
-                                   int K, int stride, int pad, int dil, float dy_slope, float x_slope, hipStream_t stream,
-                                   bool* handled) {
+                                   int K, int stride, int pad, int dil, float dy_slope, float x_slope, const ConvCtx& cx,
+                                   hipStream_t stream, bool* handled) {
   *handled = false;
-  if (!g_conv_ws || (g_debug_flags_conv & 4096)) return TTTS_OK;
+  if (!cx.ws || (cx.flags & 4096)) return TTTS_OK;
   // all-taps kernel: stride 1, "same" padding of the ResBlock1 family (K in {3, 7, 11}, dilation in {1, 3, 5}), >= 32 channels
   const bool taps = stride == 1 && (K == 3 || K == 7 || K == 11) && (dil == 1 || dil == 3 || dil == 5) &&
-                    ((Cin >= 128 && Cout >= 128) || ((g_debug_flags_conv & 8192) && Cin >= 32 && Cout >= 32)) &&   // measured: 1.9x at
-                    !(g_debug_flags_conv & 16384);   // C = 128/256, slower below (one 64x64 tile: 512 slabs, or half-empty tiles)
+                    ((Cin >= 128 && Cout >= 128) || ((cx.flags & 8192) && Cin >= 32 && Cout >= 32)) &&   // measured: 1.9x at
+                    !(cx.flags & 16384);   // C = 128/256, slower below (one 64x64 tile: 512 slabs, or half-empty tiles)
   if (taps) {
     const int Lq = (int)(cdiv(Lout, 64) * 64);
     const int WPmax = ((64 + (K - 1) * dil + 7) / 8 * 8 + 8) | 8;
@@ -841,8 +836,8 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, i
     const int nsplit = (int)cdiv(nchunks0, cpb0);
     const int64_t slab_el = (int64_t)nsplit * K * Cout * Cin;
     const int64_t need = (2 * dy_el + 4 * x_par) * (int64_t)sizeof(bf16) + slab_el * (int64_t)sizeof(float) + 128;
-    if (need <= g_conv_ws_bytes) {
-      bf16* dyh = static_cast<bf16*>(g_conv_ws);
+    if (need <= cx.ws_bytes) {
+      bf16* dyh = static_cast<bf16*>(cx.ws);
       bf16* dyl = dyh + (dy_el + 7) / 8 * 8;
       bf16* xh = dyl + (dy_el + 7) / 8 * 8;
       bf16* xl = xh + 2 * x_par;
@@ -864,7 +859,7 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, i
   // measured (tools/conv_bench.py, B = 32): one-tap-per-workgroup staging costs K x the operand traffic of the fp32 kernel,
   // so this path wins for few taps and wide layers (DiscriminatorP/S 1024-channel k5: 1.9-2.8x, FFN k3 1.6x, 1x1 1.4x) and
   // loses for the 7/11-tap ResBlock convolutions and for narrow long rows (pre-pass bytes); flag 8192 forces it (tests)
-  if (!(g_debug_flags_conv & 8192) && !(K <= 5 && Cin >= 128 && Cout >= 128)) return TTTS_OK;
+  if (!(cx.flags & 8192) && !(K <= 5 && Cin >= 128 && Cout >= 128)) return TTTS_OK;
   if (Cin < 16 || Cout < 16) return TTTS_OK;
   const int Lq = (int)(cdiv(Lout, 64) * 64);
   const int PL = (int)(cdiv(pad, stride) * stride);
@@ -872,8 +867,8 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, i
   const int Li = (int)((qmax / stride + 1 + 1 + 8 + 7) / 8 * 8);     // +1: odd parity copy, +8: 16-byte over-read slack
   const int64_t dy_el = (int64_t)B * Cout * Lq, x_par = (int64_t)B * Cin * stride * Li, x_el = 2 * x_par;
   const int64_t need = (2 * dy_el + 2 * x_el) * (int64_t)sizeof(bf16) + 64;
-  if (need > g_conv_ws_bytes) return TTTS_OK;
-  bf16* dyh = static_cast<bf16*>(g_conv_ws);
+  if (need > cx.ws_bytes) return TTTS_OK;
+  bf16* dyh = static_cast<bf16*>(cx.ws);
   bf16* dyl = dyh + (dy_el + 7) / 8 * 8;
   bf16* xh = dyl + (dy_el + 7) / 8 * 8;
   bf16* xl = xh + x_el;
@@ -891,7 +886,7 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, i
     char* end = reinterpret_cast<char*>(xl + x_el);
     end += (16 - (reinterpret_cast<uintptr_t>(end) & 15)) & 15;
     const int64_t slab_bytes = (int64_t)nsp * K * Cout * Cin * (int64_t)sizeof(float);
-    if (!small && nsp > 1 && (end - static_cast<char*>(g_conv_ws)) + slab_bytes <= g_conv_ws_bytes) slab = reinterpret_cast<float*>(end);
+    if (!small && nsp > 1 && (end - static_cast<char*>(cx.ws)) + slab_bytes <= cx.ws_bytes) slab = reinterpret_cast<float*>(end);
   }
   WgradB3Params p{dyh, dyl, xh, xl, dw, B, Cin, Cout, K, stride, dil, Lq, Li, PL - pad, x_par, cpb, nchunks, nlc, slab};
   dim3 grid((unsigned)cdiv(Cin, TILE), (unsigned)cdiv(Cout, TILE), (unsigned)(K * nsp));
@@ -903,10 +898,10 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, i
 }
 
 int conv1d_wgrad_mfma_try(const float* dy, const float* x, float* dw, int B, int Cin, int Lin, int Cout, int Lout, int K,
-                          int stride, int pad, int dil, float dy_slope, float x_slope, hipStream_t stream, bool* handled) {
+                          int stride, int pad, int dil, float dy_slope, float x_slope, const ConvCtx& cx, hipStream_t stream, bool* handled) {
   *handled = false;
   {
-    int rc = conv1d_wgrad_bf16x3_try(dy, x, dw, B, Cin, Lin, Cout, Lout, K, stride, pad, dil, dy_slope, x_slope, stream, handled);
+    int rc = conv1d_wgrad_bf16x3_try(dy, x, dw, B, Cin, Lin, Cout, Lout, K, stride, pad, dil, dy_slope, x_slope, cx, stream, handled);
     if (rc || *handled) return rc;
   }
   if (Cin * K < 32) return TTTS_OK;
@@ -926,7 +921,7 @@ int conv1d_wgrad_mfma_try(const float* dy, const float* x, float* dw, int B, int
   // device-scope fp32 atomics from hundreds of splits onto a small weight tensor cost more than the GEMM itself)
   float* slab = nullptr;
   const int64_t per = (int64_t)Cout * Cin * K;
-  if (g_conv_ws && nz > 1 && (int64_t)nz * per * (int64_t)sizeof(float) <= g_conv_ws_bytes) slab = static_cast<float*>(g_conv_ws);
+  if (cx.ws && nz > 1 && (int64_t)nz * per * (int64_t)sizeof(float) <= cx.ws_bytes) slab = static_cast<float*>(cx.ws);
   WgradMfmaParams p{dy, x, dw, B, Cin, Lin, Cout, Lout, K, stride, pad, dil, dy_slope, x_slope, cpb, slab, SEGW};
   static bool a = false;
   int rc = set_attr_once(reinterpret_cast<const void*>(conv1d_wgrad_mfma_kernel), a);
@@ -938,15 +933,4 @@ int conv1d_wgrad_mfma_try(const float* dy, const float* x, float* dw, int B, int
   return check_launch("conv1d_wgrad_mfma");
 }
 
-int conv_set_workspace(void* p, int64_t bytes) {
-  g_conv_ws = p;
-  g_conv_ws_bytes = p ? bytes : 0;
-  return TTTS_OK;
-}
-
 }  // namespace ttts
-
-extern "C" int ttts_conv_set_workspace(void* workspace, int64_t bytes) {
-  TTTS_REQUIRE(bytes >= 0 && (!workspace || ttts::aligned16(workspace)), "conv_set_workspace: bad arguments");
-  return ttts::conv_set_workspace(workspace, bytes);
-}

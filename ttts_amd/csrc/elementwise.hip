@@ -536,7 +536,7 @@ using namespace ttts;
 extern "C" int ttts_gpt_embed_fwd(const int64_t* text_inp, const int64_t* mel_inp, const float* text_emb,
                                   const float* text_pos, const float* mel_emb, const float* mel_pos, float* x,
                                   int32_t B, int32_t Tt, int32_t Tm, int32_t D, int32_t n_text, int32_t n_mel,
-                                  float dropout_p, uint64_t seed, void* stream) {
+                                  float dropout_p, uint64_t seed, const uint32_t* dropout_counter, void* stream) {
   TTTS_REQUIRE(text_inp && mel_inp && text_emb && text_pos && mel_emb && mel_pos && x, "embed_fwd: null pointer");
   TTTS_REQUIRE(B > 0 && Tt >= 0 && Tm >= 0 && Tt + Tm > 0 && D > 0 && D % 4 == 0, "embed_fwd: bad shape B=%d Tt=%d Tm=%d D=%d", B, Tt, Tm, D);
   TTTS_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "embed_fwd: dropout_p out of range");
@@ -546,13 +546,14 @@ extern "C" int ttts_gpt_embed_fwd(const int64_t* text_inp, const int64_t* mel_in
   const float inv_keep = thr ? 65536.0f / (65536.0f - (float)thr) : 1.0f;
   embed_fwd_kernel<<<grid, 256, 0, as_stream(stream)>>>(text_inp, mel_inp, text_emb, text_pos, mel_emb, mel_pos, x, B,
                                                         Tt, Tm, D, n_text, n_mel, thr, inv_keep, (uint32_t)seed,
-                                                        (uint32_t)(seed >> 32), dropout_counter());
+                                                        (uint32_t)(seed >> 32), dropout_counter);
   return check_launch("embed_fwd");
 }
 
 extern "C" int ttts_gpt_embed_bwd(const int64_t* text_inp, const int64_t* mel_inp, const float* dx, float* d_text_emb,
                                   float* d_text_pos, float* d_mel_emb, float* d_mel_pos, int32_t B, int32_t Tt,
-                                  int32_t Tm, int32_t D, float dropout_p, uint64_t seed, void* stream) {
+                                  int32_t Tm, int32_t D, float dropout_p, uint64_t seed, const uint32_t* dropout_counter,
+                                  void* stream) {
   TTTS_REQUIRE(text_inp && mel_inp && dx && d_text_emb && d_text_pos && d_mel_emb && d_mel_pos, "embed_bwd: null pointer");
   TTTS_REQUIRE(B > 0 && Tt + Tm > 0 && D > 0 && D % 4 == 0, "embed_bwd: bad shape");
   const int64_t total = (int64_t)(Tt + Tm) * (D / 4);
@@ -560,7 +561,7 @@ extern "C" int ttts_gpt_embed_bwd(const int64_t* text_inp, const int64_t* mel_in
   const float inv_keep = thr ? 65536.0f / (65536.0f - (float)thr) : 1.0f;
   embed_bwd_kernel<<<(int)cdiv(total, 256), 256, 0, as_stream(stream)>>>(text_inp, mel_inp, dx, d_text_emb, d_text_pos,
                                                                          d_mel_emb, d_mel_pos, B, Tt, Tm, D, thr,
-                                                                         inv_keep, (uint32_t)seed, (uint32_t)(seed >> 32), dropout_counter());
+                                                                         inv_keep, (uint32_t)seed, (uint32_t)(seed >> 32), dropout_counter);
   return check_launch("embed_bwd");
 }
 
@@ -588,7 +589,7 @@ extern "C" int64_t ttts_layernorm_bwd_workspace_bytes(int32_t M, int32_t D) {
 static int layernorm_bwd_impl(const void* dy, int dy_is_bf16, const float* x, const float* gamma, const float* mean,
                               const float* rstd, const float* dx_in, float* dx, void* dx_bf16, float* dgamma,
                               float* dbeta, float* dcolsum, void* workspace, int M, int D, int split_S, int split_T,
-                              float drop_p, uint64_t seed, hipStream_t s) {
+                              float drop_p, uint64_t seed, const uint32_t* dropout_counter, hipStream_t s) {
   TTTS_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && workspace, "layernorm_bwd: null pointer");
   TTTS_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "layernorm_bwd: need 0 < D <= 1024, D %% 4 == 0 (D=%d)", D);
   TTTS_REQUIRE(split_S <= 0 || (M % split_S == 0 && split_T >= 0 && split_T <= split_S), "layernorm_bwd: bad split");
@@ -601,10 +602,10 @@ static int layernorm_bwd_impl(const void* dy, int dy_is_bf16, const float* x, co
 #define LN_BWD(V)                                                                                                   \
   if (dy_is_bf16)                                                                                                   \
     ln_bwd_kernel<V, true><<<nblk, 256, smem, s>>>(dy, x, gamma, mean, rstd, dx_in, dx, (bf16*)dx_bf16, partial, M, D, \
-                                                   split_S, split_T, thr, inv_keep, (uint32_t)seed, (uint32_t)(seed >> 32), dropout_counter()); \
+                                                   split_S, split_T, thr, inv_keep, (uint32_t)seed, (uint32_t)(seed >> 32), dropout_counter); \
   else                                                                                                              \
     ln_bwd_kernel<V, false><<<nblk, 256, smem, s>>>(dy, x, gamma, mean, rstd, dx_in, dx, (bf16*)dx_bf16, partial, M, D, \
-                                                    split_S, split_T, thr, inv_keep, (uint32_t)seed, (uint32_t)(seed >> 32), dropout_counter());
+                                                    split_S, split_T, thr, inv_keep, (uint32_t)seed, (uint32_t)(seed >> 32), dropout_counter);
   if (D <= 256) { LN_BWD(1) } else if (D <= 512) { LN_BWD(2) } else { LN_BWD(4) }
 #undef LN_BWD
   int rc = check_launch("layernorm_bwd");
@@ -618,17 +619,17 @@ extern "C" int ttts_layernorm_bwd(const void* dy, int32_t dy_is_bf16, const floa
                                   float* dgamma, float* dbeta, void* workspace, int32_t M, int32_t D, int32_t split_S,
                                   int32_t split_T, void* stream) {
   return layernorm_bwd_impl(dy, dy_is_bf16, x, gamma, mean, rstd, dx_in, dx, dx_bf16, dgamma, dbeta, nullptr, workspace,
-                            M, D, split_S, split_T, 0.f, 0, as_stream(stream));
+                            M, D, split_S, split_T, 0.f, 0, nullptr, as_stream(stream));
 }
 
 extern "C" int ttts_layernorm_bwd_ex(const void* dy, int32_t dy_is_bf16, const float* x, const float* gamma,
                                      const float* mean, const float* rstd, const float* dx_in, float* dx, void* dx_bf16,
                                      float* dgamma, float* dbeta, float* dcolsum, void* workspace, int32_t M, int32_t D,
                                      int32_t split_S, int32_t split_T, float bf16_dropout_p, uint64_t bf16_dropout_seed,
-                                     void* stream) {
+                                     const uint32_t* dropout_counter, void* stream) {
   TTTS_REQUIRE(bf16_dropout_p >= 0.f && bf16_dropout_p < 1.f, "layernorm_bwd: dropout_p out of range");
   return layernorm_bwd_impl(dy, dy_is_bf16, x, gamma, mean, rstd, dx_in, dx, dx_bf16, dgamma, dbeta, dcolsum, workspace,
-                            M, D, split_S, split_T, bf16_dropout_p, bf16_dropout_seed, as_stream(stream));
+                            M, D, split_S, split_T, bf16_dropout_p, bf16_dropout_seed, dropout_counter, as_stream(stream));
 }
 
 extern "C" int ttts_ce_fwd_bf16(const void* logits, int64_t ldl, const int64_t* targets, float* row_loss,

@@ -37,15 +37,13 @@ struct GemmEpi {
   const float* resid_in;  // RESID_ADD: C = resid_in + dropout(bf16(acc + bias)); NULL -> in place (C += ...)
   int M, N;
   uint32_t thr; float inv_keep; uint32_t seed_lo, seed_hi;  // residual dropout (RESID_ADD only; thr = 0: off)
-  int debug;  // ablations: 16 = skip the global stores of the epilogue, 32 = skip the LDS staging
-  const uint32_t* ctr;  // process-wide dropout stream counter (device) or NULL
+  const uint32_t* ctr;  // caller-owned dropout stream counter (device) or NULL
 };
 
 struct GemmNtParams {
   const bf16* A; int64_t lda;
   const bf16* B; int64_t ldb;
   int K;
-  int debug;  // timing ablations (tools/kernel_bench.py): 1 = no epilogue, 2 = no global loads, 4 = no MFMA
   GemmEpi e;
 };
 
@@ -70,7 +68,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmEpi& e, f32x16 (&acc)[2]
   }
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
-    if (wm == half && !(e.debug & 32)) {
+    if (wm == half) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -99,7 +97,6 @@ __device__ __forceinline__ void tile_epilogue(const GemmEpi& e, f32x16 (&acc)[2]
       for (int t = 0; t < 8; ++t) v[t] += bias8[t];
       const int64_t off = (int64_t)m * e.ldc + n;
       const bool full = vec_ok && (n + 8 <= e.N);
-      if ((e.debug & 16) && v[0] + v[3] != 123456.75f) continue;
       if (EPI == TTTS_EPI_STORE_BF16) {
         bf16* c = reinterpret_cast<bf16*>(e.C) + off;
         if (full) {
@@ -203,19 +200,6 @@ __device__ __forceinline__ int xcd_tile(int bid, int nblk) {
   _Pragma("unroll") for (int i = 0; i < 2; ++i)       \
   _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
 
-__device__ __forceinline__ bool debug_drop(int debug, f32x16 (&acc)[2][2], void* C) {
-  if (!(debug & 1)) return false;  // ablation: keep the accumulators live, store (almost) nothing
-  float t = 0.f;
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) t += acc[j][i][r];
-  if (t == 123456.75f) reinterpret_cast<float*>(C)[0] = t;
-  return true;
-}
-
 // ---- NT, LDS-DMA main loop (K % BKT == 0) --------------------------------------------------------------------------
 // LDS image per operand and buffer: [128 rows][BKT k] bf16, NO padding (the DMA writes lane-linearly: one wave
 // instruction = 1 KB = 64*8/BKT... rows; lane l -> row += l / CPR, 16-byte slot l % CPR, CPR = BKT/8 chunks per row).
@@ -236,7 +220,7 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_nt_glds_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int tiles_n = (p.e.N + BNT - 1) / BNT;
-  const int tile = (p.debug & 128) ? (int)blockIdx.x : xcd_tile(blockIdx.x, gridDim.x);
+  const int tile = xcd_tile(blockIdx.x, gridDim.x);
   const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BNT;
   const int nk = p.K / BKT;
   auto fsw = [](int r) { return BKT == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
@@ -285,7 +269,7 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_nt_glds_kernel(
   }
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk && !(p.debug & 2)) issue(kt + 1, buf ^ 1);
+    if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
     const bf16* as = smem + (buf * 2 + 0) * TILE;
     const bf16* bs = smem + (buf * 2 + 1) * TILE;
 #pragma unroll
@@ -304,7 +288,6 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_nt_glds_kernel(
     }
     __syncthreads();  // next tile landed (vmcnt(0)) and everyone is done reading this one
   }
-  if (debug_drop(p.debug, acc, p.e.C)) return;
   tile_epilogue<EPI, NJ>(p.e, acc, reinterpret_cast<float*>(smem), m0, n0, tid);
 }
 
@@ -368,7 +351,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNtParams p) {
     if (kt + 1 < nk) store_lds(buf ^ 1);
     __syncthreads();
   }
-  if (debug_drop(p.debug, acc, p.e.C)) return;
   tile_epilogue<EPI>(p.e, acc, reinterpret_cast<float*>(smem), m0, n0, tid);
 }
 
@@ -586,31 +568,18 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __rest
 
 using namespace ttts;
 
-int g_debug_flags = 0;  // shared with conv.hip (flag 256: direct conv kernels only)
-extern "C" int ttts_debug_set_flags(int32_t flags) {
-  g_debug_flags = flags;
-  return TTTS_OK;
-}
-
 template <int EPI>
 static void launch_nt(const GemmNtParams& p, int grid, hipStream_t s) {
-  // Experiment kept behind flag 32768: 128 x 64 tiles for the narrow-N GEMMs (N = 512: 292 tiles of 128 x 128 = 1.14 per
-  // CU).  Measured SLOWER on MI355X (mlp c_proj 40.2 -> 47.5 us, dX c_fc 33.6 -> 43.6 us, step +0.14 ms): with two
-  // co-resident workgroups per CU the 292-tile launch is not the imbalance it looks like, and the half-width tile re-reads
-  // the A panel twice.
-  const int tiles64 = (int)(cdiv(p.e.M, BM) * cdiv(p.e.N, 64));
-  if (p.K % 64 == 0 && !(g_debug_flags & (8 | 64)) && (g_debug_flags & 32768) && grid < 512 && tiles64 >= 384) {
-    gemm_nt_glds_kernel<EPI, 64, 1><<<tiles64, 256, 0, s>>>(p);
-    return;
-  }
-  if (p.K % 64 == 0 && !(g_debug_flags & (8 | 64))) gemm_nt_glds_kernel<EPI, 64><<<grid, 256, 0, s>>>(p);
-  else if (p.K % 32 == 0 && !(g_debug_flags & 8)) gemm_nt_glds_kernel<EPI, 32><<<grid, 256, 0, s>>>(p);
+  // (a 128 x 64 tile for the N = 512 GEMMs was measured slower on MI355X -- mlp c_proj 40.2 -> 47.5 us -- and removed)
+  if (p.K % 64 == 0) gemm_nt_glds_kernel<EPI, 64><<<grid, 256, 0, s>>>(p);
+  else if (p.K % 32 == 0) gemm_nt_glds_kernel<EPI, 32><<<grid, 256, 0, s>>>(p);
   else gemm_nt_kernel<EPI><<<grid, 256, 0, s>>>(p);
 }
 
 extern "C" int ttts_gemm_nt_bf16_ex(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                                     const float* bias, void* aux, int32_t M, int32_t N, int32_t K, int32_t epilogue,
-                                    const float* resid_in, float dropout_p, uint64_t seed, void* stream) {
+                                    const float* resid_in, float dropout_p, uint64_t seed, const uint32_t* dropout_counter,
+                                    void* stream) {
   TTTS_REQUIRE(A && B && C, "gemm_nt: null pointer");
   TTTS_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_nt: bad shape M=%d N=%d K=%d", M, N, K);
   TTTS_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K, "gemm_nt: K, lda, ldb must be multiples of 8 (K=%d lda=%lld ldb=%lld)", K, (long long)lda, (long long)ldb);
@@ -620,9 +589,9 @@ extern "C" int ttts_gemm_nt_bf16_ex(const void* A, int64_t lda, const void* B, i
   TTTS_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "gemm_nt: dropout_p out of range");
   TTTS_REQUIRE(dropout_p == 0.f || (epilogue == TTTS_EPI_RESID_ADD_F32 && N % 8 == 0), "gemm_nt: dropout only with RESID_ADD and N %% 8 == 0");
   TTTS_REQUIRE(!resid_in || aligned16(resid_in), "gemm_nt: resid_in must be 16-byte aligned");
-  GemmNtParams p{(const bf16*)A, lda, (const bf16*)B, ldb, K, g_debug_flags,
+  GemmNtParams p{(const bf16*)A, lda, (const bf16*)B, ldb, K,
                  GemmEpi{C, ldc, bias, (bf16*)aux, resid_in, M, N, dropout_threshold(dropout_p), 1.0f, (uint32_t)seed,
-                         (uint32_t)(seed >> 32), g_debug_flags, dropout_counter()}};
+                         (uint32_t)(seed >> 32), dropout_counter}};
   if (p.e.thr) p.e.inv_keep = 65536.0f / (65536.0f - (float)p.e.thr);
   const int grid = (int)(cdiv(M, BM) * cdiv(N, BN));
   hipStream_t s = as_stream(stream);
@@ -640,16 +609,15 @@ extern "C" int ttts_gemm_nt_bf16_ex(const void* A, int64_t lda, const void* B, i
 extern "C" int ttts_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                                  const float* bias, void* aux, int32_t M, int32_t N, int32_t K, int32_t epilogue,
                                  void* stream) {
-  return ttts_gemm_nt_bf16_ex(A, lda, B, ldb, C, ldc, bias, aux, M, N, K, epilogue, nullptr, 0.f, 0, stream);
+  return ttts_gemm_nt_bf16_ex(A, lda, B, ldb, C, ldc, bias, aux, M, N, K, epilogue, nullptr, 0.f, 0, nullptr, stream);
 }
 
-extern int g_debug_flags;
 static void tn_plan(int Mo, int No, int Kr, int& splits, int& k_chunk) {
   const int tiles = (int)(cdiv(Mo, BM) * cdiv(No, BN));
   // enough workgroups to fill 256 CUs (~1.5 per CU), as few slabs as possible, >= 256 reduction rows per split;
   // k_chunk is a multiple of 64 so that the LDS-DMA kernel can take every split whole
   // measured (tools/kernel_bench.py gemm, MI355X): 384 workgroups beats 256 by 10-15 % and ties or beats 512 (more slabs)
-  const int target = (g_debug_flags & 512) ? 256 : ((g_debug_flags & 1024) ? 512 : 384);
+  const int target = 384;
   splits = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(Kr, 256), (target + tiles / 2) / tiles));
   k_chunk = (int)(cdiv(cdiv(Kr, splits), 64) * 64);
   splits = (int)cdiv(Kr, k_chunk);
@@ -675,7 +643,7 @@ extern "C" int ttts_gemm_tn_bf16_accum_f32(const void* At, int64_t ldat, const v
   const int tiles = (int)(cdiv(Mo, BM) * cdiv(No, BN));
   const int64_t ldp = ((int64_t)No + 7) / 8 * 8;
   hipStream_t s = as_stream(stream);
-  const int kr_main = (g_debug_flags & 8) ? 0 : Kr / 64 * 64;  // whole 64-row tiles: LDS-DMA kernel
+  const int kr_main = Kr / 64 * 64;  // whole 64-row tiles: LDS-DMA kernel
   if (kr_main > 0) {
     const int sp = (int)cdiv(kr_main, k_chunk);
     GemmTnParams p{(const bf16*)At, ldat, (const bf16*)Bt, ldbt, C, ldc, (float*)workspace, ldp, Mo, No, kr_main, k_chunk, sp};

@@ -2,9 +2,6 @@
 #include "common.hpp"
 
 namespace ttts {
-static const uint32_t* g_dropout_counter = nullptr;
-const uint32_t* dropout_counter() { return g_dropout_counter; }
-void set_dropout_counter(const uint32_t* p) { g_dropout_counter = p; }
 char* error_buffer() {
   static thread_local char buf[512] = "";
   return buf;
@@ -45,11 +42,6 @@ __global__ __launch_bounds__(64) void probe_kernel(float* out_c, int* out_tr) {
 
 using namespace ttts;
 
-namespace ttts { void set_dropout_counter(const uint32_t* p); }
-extern "C" int ttts_set_dropout_counter(const uint32_t* device_counter) {
-  ttts::set_dropout_counter(device_counter);
-  return TTTS_OK;
-}
 extern "C" int ttts_abi_version(void) { return TTTS_ABI_VERSION; }
 extern "C" const char* ttts_last_error(void) { return error_buffer(); }
 

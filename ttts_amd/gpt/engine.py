@@ -85,7 +85,8 @@ class GptEngine:
         self.step_count = 0                 # optimizer steps taken (host mirror)
         self.overlap_dw = os.environ.get("TTTS_OVERLAP_DW", "0") == "1"   # dW GEMMs on a side stream (see backward);
         # off by default: measured +0.7 % only, and concurrent kernels blur per-kernel profiles
-        self.seed_ctr = ops.dropout_counter(self.device)   # device-side dropout stream counter (graph-replay safe)
+        self.seed_ctr = torch.zeros(1, dtype=torch.int32, device=self.device)   # this replica's dropout stream counter (device side:
+        # graph-replay safe); handed to every dropout-capable kernel call -- the library holds no state of its own
         self.spec = param_spec(self.c)
         self.shapes = dict(self.spec)
         self.offsets = {}
@@ -246,7 +247,7 @@ class GptEngine:
         p = self._p()
         P = lambda k: self.view(self.params, k)  # noqa: E731
         ops.embed_fwd(b["text_inp"], b["mel_inp"], P("text_embedding.weight"), P("text_pos_embedding.emb.weight"),
-                      P("mel_embedding.weight"), P("mel_pos_embedding.emb.weight"), b["xs"][0], p, self._seed(1))
+                      P("mel_embedding.weight"), P("mel_pos_embedding.emb.weight"), b["xs"][0], p, self._seed(1), counter=self.seed_ctr)
         for i in range(L):
             pre = "gpt.h.%d." % i
             x0, x1, x2 = b["xs"][2 * i], b["xs"][2 * i + 1], b["xs"][2 * i + 2]
@@ -255,14 +256,14 @@ class GptEngine:
             ops.gemm_nt(b["ln1"][i], self.wT[pre + "attn.c_attn.weight"], b["qkv"][i], P(pre + "attn.c_attn.bias"))
             qkv = b["qkv"][i]
             ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], b["att"][i], b["lse"][i], B, H, S, dh, (S * 3 * D, 3 * D),
-                         (S * D, D), dh ** -0.5, p, self._seed(16 * i + 2))
+                         (S * D, D), dh ** -0.5, p, self._seed(16 * i + 2), counter=self.seed_ctr)
             ops.gemm_nt(b["att"][i], self.wT[pre + "attn.c_proj.weight"], x1, P(pre + "attn.c_proj.bias"),
-                        epilogue=EPI_RESID_ADD_F32, resid_in=x0, dropout_p=p, seed=self._seed(16 * i + 3))
+                        epilogue=EPI_RESID_ADD_F32, resid_in=x0, dropout_p=p, seed=self._seed(16 * i + 3), counter=self.seed_ctr)
             ops.layernorm_fwd(x1, P(pre + "ln_2.weight"), P(pre + "ln_2.bias"), b["ln2"][i], st[2], st[3])
             ops.gemm_nt(b["ln2"][i], self.wT[pre + "mlp.c_fc.weight"], b["fc_act"][i], P(pre + "mlp.c_fc.bias"),
                         aux=b["fc_pre"][i], epilogue=EPI_GELU_BF16)
             ops.gemm_nt(b["fc_act"][i], self.wT[pre + "mlp.c_proj.weight"], x2, P(pre + "mlp.c_proj.bias"),
-                        epilogue=EPI_RESID_ADD_F32, resid_in=x1, dropout_p=p, seed=self._seed(16 * i + 4))
+                        epilogue=EPI_RESID_ADD_F32, resid_in=x1, dropout_p=p, seed=self._seed(16 * i + 4), counter=self.seed_ctr)
         fs = b["fstats"]
         ops.layernorm_fwd(b["xs"][2 * L], P("gpt.ln_f.weight"), P("gpt.ln_f.bias"), b["lnf"], fs[0], fs[1])
         ops.layernorm_fwd(b["lnf"], P("final_norm.weight"), P("final_norm.bias"), b["enc"], fs[2], fs[3],
@@ -318,7 +319,7 @@ class GptEngine:
         if part in (None, 1):
             ops.embed_bwd(b["text_inp"], b["mel_inp"], b["dres"], G("text_embedding.weight"),
                           G("text_pos_embedding.emb.weight"), G("mel_embedding.weight"), G("mel_pos_embedding.emb.weight"),
-                          p, self._seed(1))
+                          p, self._seed(1), counter=self.seed_ctr)
         if side is not main:
             main.wait_stream(side)       # join: the optimizer / all-reduce needs every dW
 
@@ -346,7 +347,7 @@ class GptEngine:
                           G("final_norm.weight"), G("final_norm.bias"), b["ln_ws"], split=(S, Tt))
         ops.layernorm_bwd(b["d_tmp"], b["xs"][2 * L], P("gpt.ln_f.weight"), fs[0], fs[1], None, b["dres"], b["dres_bf"],
                           G("gpt.ln_f.weight"), G("gpt.ln_f.bias"), b["ln_ws"], dropout_p=p,
-                          seed=self._seed(16 * (L - 1) + 4), dcolsum=G("gpt.h.%d.mlp.c_proj.bias" % (L - 1)))
+                          seed=self._seed(16 * (L - 1) + 4), dcolsum=G("gpt.h.%d.mlp.c_proj.bias" % (L - 1)), counter=self.seed_ctr)
 
     def _backward_layer(self, i, side, fork, done, wait, ev_fc, ev_qkv):
         c, b = self.c, self.b
@@ -375,7 +376,7 @@ class GptEngine:
         wait(ev_dy)                                        # dres_bf is rewritten by the LayerNorm backward below
         ops.layernorm_bwd(b["d_ln"], x1, P(pre + "ln_2.weight"), st[2], st[3], b["dres"], b["dres"], b["dres_bf"],
                           G(pre + "ln_2.weight"), G(pre + "ln_2.bias"), b["ln_ws"], dropout_p=p,
-                          seed=self._seed(16 * i + 3), dcolsum=G(pre + "attn.c_proj.bias"))
+                          seed=self._seed(16 * i + 3), dcolsum=G(pre + "attn.c_proj.bias"), counter=self.seed_ctr)
         dy = b["dres_bf"]                                  # gradient entering attn.c_proj
         fork()
         with torch.cuda.stream(side):
@@ -386,7 +387,7 @@ class GptEngine:
         wait(ev_qkv)                                       # the previous layer's dW c_attn has consumed dqkv
         ops.attn_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], b["att"][i], b["d_att"], b["lse"][i], dqkv, dqkv[:, D:],
                      dqkv[:, 2 * D:], b["delta"], B, H, S, dh, (S * 3 * D, 3 * D), (S * D, D), dh ** -0.5, p,
-                     self._seed(16 * i + 2))
+                     self._seed(16 * i + 2), counter=self.seed_ctr)
         fork()
         with torch.cuda.stream(side):
             ops.gemm_tn_accum(self._padded(b["ln1"][i]), self._padded(dqkv), G(pre + "attn.c_attn.weight"), workspace=b["tn_ws"])
@@ -397,7 +398,7 @@ class GptEngine:
         ops.layernorm_bwd(b["d_ln"], x0, P(pre + "ln_1.weight"), st[0], st[1], b["dres"], b["dres"],
                           b["dres_bf"] if i > 0 else None, G(pre + "ln_1.weight"), G(pre + "ln_1.bias"),
                           b["ln_ws"], dropout_p=p if i > 0 else 0.0, seed=self._seed(16 * (i - 1) + 4),
-                          dcolsum=G("gpt.h.%d.mlp.c_proj.bias" % (i - 1)) if i > 0 else None)
+                          dcolsum=G("gpt.h.%d.mlp.c_proj.bias" % (i - 1)) if i > 0 else None, counter=self.seed_ctr)
         return ev_fc, ev_qkv
 
     def _side_stream(self):

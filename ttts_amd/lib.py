@@ -63,6 +63,14 @@ _c = ctypes
 _P, _I32, _I64, _U64, _F = _c.c_void_p, _c.c_int32, _c.c_int64, _c.c_uint64, _c.c_float
 
 
+ABI_VERSION = 2
+
+
+class ConvCtx(ctypes.Structure):
+    """include/ttts_hip.h: ttts_conv_ctx (caller-owned; the library keeps no copy)."""
+    _fields_ = [("workspace", _P), ("workspace_bytes", _I64), ("flags", _I32), ("reserved", _I32)]
+
+
 class CastDesc(ctypes.Structure):
     _fields_ = [("src", _P), ("dst", _P), ("dst_t", _P), ("rows", _I32), ("cols", _I32), ("tile_begin", _I32),
                 ("ldt", _I32)]
@@ -73,27 +81,26 @@ SIGNATURES = {
     "ttts_abi_version": (_I32, []),
     "ttts_last_error": (_c.c_char_p, []),
     "ttts_device_info": (_I32, [_P]),
-    "ttts_set_dropout_counter": (_I32, [_P]),
     "ttts_gemm_nt_bf16": (_I32, [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I32, _I32, _I32, _I32, _P]),
-    "ttts_gemm_nt_bf16_ex": (_I32, [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I32, _I32, _I32, _I32, _P, _F, _U64, _P]),
+    "ttts_gemm_nt_bf16_ex": (_I32, [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I32, _I32, _I32, _I32, _P, _F, _U64, _P, _P]),
     "ttts_gemm_tn_workspace_bytes": (_I64, [_I32, _I32, _I32]),
     "ttts_gemm_tn_bf16_accum_f32": (_I32, [_P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _P]),
     "ttts_colsum_bf16_accum_f32": (_I32, [_P, _I64, _P, _I32, _I32, _P]),
     "ttts_cast_desc_tiles": (_I32, [_I32, _I32]),
     "ttts_cast_bf16_batched": (_I32, [_P, _I32, _I32, _P]),
     "ttts_attn_causal_fwd_bf16": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _F, _F,
-                                         _U64, _P]),
+                                         _U64, _P, _P]),
     "ttts_attn_bwd_workspace_bytes": (_I64, [_I32, _I32, _I32]),
     "ttts_attn_causal_bwd_bf16": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I64, _I64,
-                                         _I64, _I64, _F, _F, _U64, _P]),
-    "ttts_attn_dropout_mask_u8": (_I32, [_P, _I32, _I32, _I32, _F, _U64, _P]),
+                                         _I64, _I64, _F, _F, _U64, _P, _P]),
+    "ttts_attn_dropout_mask_u8": (_I32, [_P, _I32, _I32, _I32, _F, _U64, _P, _P]),
     "ttts_layernorm_fwd": (_I32, [_P, _P, _P, _P, _I32, _P, _P, _I32, _I32, _F, _I32, _I32, _P]),
     "ttts_layernorm_bwd_workspace_bytes": (_I64, [_I32, _I32]),
     "ttts_layernorm_bwd": (_I32, [_P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "ttts_layernorm_bwd_ex": (_I32, [_P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F,
-                                     _U64, _P]),
-    "ttts_gpt_embed_fwd": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _F, _U64, _P]),
-    "ttts_gpt_embed_bwd": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _U64, _P]),
+                                     _U64, _P, _P]),
+    "ttts_gpt_embed_fwd": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _F, _U64, _P, _P]),
+    "ttts_gpt_embed_bwd": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _U64, _P, _P]),
     "ttts_ce_fwd_bf16": (_I32, [_P, _I64, _P, _P, _P, _P, _I32, _I32, _P]),
     "ttts_ce_bwd_bf16": (_I32, [_P, _I64, _P, _P, _P, _F, _P, _I32, _I32, _P]),
     "ttts_adamw_schedule": (_I32, [_P, _F, _F, _F, _I32, _P]),
@@ -138,12 +145,11 @@ SIGNATURES = {
     "ttts_istft_ola_f32": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
     "ttts_peak_scale_f32": (_I32, [_P, _P, _I32, _I32, _F, _P]),
     "ttts_conv1d_fwd_f32": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32,
-                                   _F, _F, _I32, _F, _F, _I32, _P]),
+                                   _F, _F, _I32, _F, _F, _I32, _P, _P]),
     "ttts_conv1d_dgrad_f32": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32,
-                                     _F, _F, _F, _I32, _P]),
+                                     _F, _F, _F, _I32, _P, _P]),
     "ttts_conv1d_wgrad_f32": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _F, _F,
-                                     _P]),
-    "ttts_conv_set_workspace": (_I32, [_P, _I64]),
+                                     _P, _P]),
     "ttts_lrelu_bwd_f32": (_I32, [_P, _P, _P, _F, _I64, _P]),
     "ttts_conv1d_bias_grad_f32": (_I32, [_P, _P, _I32, _I32, _I32, _P]),
     "ttts_weight_norm_fwd_f32": (_I32, [_P, _P, _P, _P, _I32, _I32, _P]),
@@ -179,7 +185,6 @@ SIGNATURES = {
     "ttts_kl_loss_fwd_f32": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P]),
     "ttts_kl_loss_bwd_f32": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
     "ttts_probe_mfma_layout": (_I32, [_P, _P, _P]),
-    "ttts_debug_set_flags": (_I32, [_I32]),
 }
 
 _lib = None
@@ -196,10 +201,8 @@ def get():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is missing
             fn.restype, fn.argtypes = res, args
-        if lib.ttts_abi_version() != 1:
-            raise TttsError("libttts_hip.so ABI version mismatch")
-        if os.environ.get("TTTS_DEBUG_FLAGS"):      # kernel-selection experiments (see ttts_debug_set_flags), e.g. tools/kernel_bench.py
-            lib.ttts_debug_set_flags(int(os.environ["TTTS_DEBUG_FLAGS"]))
+        if lib.ttts_abi_version() != ABI_VERSION:
+            raise TttsError("libttts_hip.so ABI version mismatch (rebuild: python __graft_entry__.py)")
         _lib = lib
     return _lib
 

@@ -47,7 +47,7 @@ def _ld(t):
 
 
 def gemm_nt(a, b, c, bias=None, aux=None, epilogue=EPI_STORE_BF16, n=None, k=None, resid_in=None, dropout_p=0.0,
-            seed=0):
+            seed=0, counter=None):
     """c[M,N] = epi(a[M,K] @ b[N,K]^T).  a/b bf16 row-major views; c bf16 or f32 (per epilogue)."""
     _req(resid_in, torch.float32, "resid_in")
     _req(a, torch.bfloat16, "a"); _req(b, torch.bfloat16, "b"); _req(bias, torch.float32, "bias")
@@ -60,7 +60,7 @@ def gemm_nt(a, b, c, bias=None, aux=None, epilogue=EPI_STORE_BF16, n=None, k=Non
     if resid_in is not None and (resid_in.shape != c.shape or resid_in.stride() != c.stride()):
         raise TttsError("resid_in must have the layout of c")
     check(_l.get().ttts_gemm_nt_bf16_ex(_p(a), _ld(a), _p(b), _ld(b), _p(c), _ld(c), _p(bias), _p(aux), M, N, K,
-                                        epilogue, _p(resid_in), dropout_p, seed, _stream()), "gemm_nt")
+                                        epilogue, _p(resid_in), dropout_p, seed, _ctr(counter, c, dropout_p), _stream()), "gemm_nt")
     return c
 
 
@@ -94,17 +94,17 @@ def colsum_accum(x, out, n=None):
     return out
 
 
-def attn_fwd(q, k, v, o, lse, B, H, S, dh, qkv_strides, o_strides, scale, dropout_p=0.0, seed=0):
+def attn_fwd(q, k, v, o, lse, B, H, S, dh, qkv_strides, o_strides, scale, dropout_p=0.0, seed=0, counter=None):
     for t, nm in ((q, "q"), (k, "k"), (v, "v"), (o, "o")):
         _req(t, torch.bfloat16, nm)
     _req(lse, torch.float32, "lse")
     check(_l.get().ttts_attn_causal_fwd_bf16(_p(q), _p(k), _p(v), _p(o), _p(lse), B, H, S, dh, qkv_strides[0],
                                              qkv_strides[1], o_strides[0], o_strides[1], scale, dropout_p, seed,
-                                             _stream()), "attn_fwd")
+                                             _ctr(counter, q, dropout_p), _stream()), "attn_fwd")
 
 
 def attn_bwd(q, k, v, o, d_o, lse, dq, dk, dv, workspace, B, H, S, dh, qkv_strides, o_strides, scale, dropout_p=0.0,
-             seed=0):
+             seed=0, counter=None):
     for t, nm in ((q, "q"), (k, "k"), (v, "v"), (o, "o"), (d_o, "d_o"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
         _req(t, torch.bfloat16, nm)
     _req(lse, torch.float32, "lse")
@@ -112,12 +112,12 @@ def attn_bwd(q, k, v, o, d_o, lse, dq, dk, dv, workspace, B, H, S, dh, qkv_strid
         raise TttsError("attn_bwd workspace too small")
     check(_l.get().ttts_attn_causal_bwd_bf16(_p(q), _p(k), _p(v), _p(o), _p(d_o), _p(lse), _p(dq), _p(dk), _p(dv),
                                              _p(workspace), B, H, S, dh, qkv_strides[0], qkv_strides[1], o_strides[0],
-                                             o_strides[1], scale, dropout_p, seed, _stream()), "attn_bwd")
+                                             o_strides[1], scale, dropout_p, seed, _ctr(counter, q, dropout_p), _stream()), "attn_bwd")
 
 
-def attn_dropout_mask(B, H, S, p, seed, device):
+def attn_dropout_mask(B, H, S, p, seed, device, counter=None):
     m = torch.empty(B, H, S, S, dtype=torch.uint8, device=device)
-    check(_l.get().ttts_attn_dropout_mask_u8(_p(m), B, H, S, p, seed, _stream()), "dropout_mask")
+    check(_l.get().ttts_attn_dropout_mask_u8(_p(m), B, H, S, p, seed, _ctr(counter, m, p), _stream()), "dropout_mask")
     return m
 
 
@@ -134,32 +134,33 @@ def layernorm_bwd_workspace(M, D, device):
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx_in, dx, dx_bf16, dgamma, dbeta, workspace, split=(0, 0), dropout_p=0.0,
-                  seed=0, dcolsum=None):
+                  seed=0, dcolsum=None, counter=None):
     _req(x, torch.float32, "x"); _req(dx, torch.float32, "dx"); _req(dx_bf16, torch.bfloat16, "dx_bf16")
     M, D = x.shape
     check(_l.get().ttts_layernorm_bwd_ex(_p(dy), int(dy.dtype == torch.bfloat16), _p(x), _p(gamma), _p(mean), _p(rstd),
                                          _p(dx_in), _p(dx), _p(dx_bf16), _p(dgamma), _p(dbeta), _p(dcolsum),
-                                         _p(workspace), M, D, split[0], split[1], dropout_p, seed, _stream()),
-          "layernorm_bwd")
+                                         _p(workspace), M, D, split[0], split[1], dropout_p, seed, _ctr(counter, x, dropout_p),
+                                         _stream()), "layernorm_bwd")
 
 
-def embed_fwd(text_inp, mel_inp, text_emb, text_pos, mel_emb, mel_pos, x, dropout_p=0.0, seed=0):
+def embed_fwd(text_inp, mel_inp, text_emb, text_pos, mel_emb, mel_pos, x, dropout_p=0.0, seed=0, counter=None):
     _req(text_inp, torch.int64, "text_inp"); _req(mel_inp, torch.int64, "mel_inp"); _req(x, torch.float32, "x")
     B, Tt = text_inp.shape
     Tm = mel_inp.shape[1]
     D = x.shape[-1]
     check(_l.get().ttts_gpt_embed_fwd(_p(text_inp), _p(mel_inp), _p(text_emb), _p(text_pos), _p(mel_emb), _p(mel_pos),
                                       _p(x), B, Tt, Tm, D, text_emb.shape[0], mel_emb.shape[0], dropout_p, seed,
-                                      _stream()), "embed_fwd")
+                                      _ctr(counter, x, dropout_p), _stream()), "embed_fwd")
     return x
 
 
-def embed_bwd(text_inp, mel_inp, dx, d_text_emb, d_text_pos, d_mel_emb, d_mel_pos, dropout_p=0.0, seed=0):
+def embed_bwd(text_inp, mel_inp, dx, d_text_emb, d_text_pos, d_mel_emb, d_mel_pos, dropout_p=0.0, seed=0, counter=None):
     B, Tt = text_inp.shape
     Tm = mel_inp.shape[1]
     D = dx.shape[-1]
     check(_l.get().ttts_gpt_embed_bwd(_p(text_inp), _p(mel_inp), _p(dx), _p(d_text_emb), _p(d_text_pos), _p(d_mel_emb),
-                                      _p(d_mel_pos), B, Tt, Tm, D, dropout_p, seed, _stream()), "embed_bwd")
+                                      _p(d_mel_pos), B, Tt, Tm, D, dropout_p, seed, _ctr(counter, dx, dropout_p), _stream()),
+          "embed_bwd")
 
 
 def ce_fwd(logits, targets, row_loss, row_lse, loss_mean, C):
@@ -546,7 +547,7 @@ def conv_out_len(lin, k, stride, pad, dil):
 
 
 _OUT_ACT = {None: 0, "none": 0, "tanh": 1, "lrelu": 2}
-_conv_scratch = {}
+_conv_ctxs = {}
 
 
 def set_conv_precision(mode):
@@ -572,21 +573,23 @@ _state = {"conv_precision": "split_bf16", "variant": int(os.environ.get("TTTS_DE
 
 
 def _apply_flags():
-    check(_l.get().ttts_debug_set_flags(_state["variant"] | (4096 if _state["conv_precision"] == "exact" else 0)), "set_flags")
+    for ctx, _buf in _conv_ctxs.values():
+        ctx.flags = _state["variant"] | (4096 if _state["conv_precision"] == "exact" else 0)
 
 
-def _conv_workspace(device):
-    """Registers (once per process) the caller-owned scratch that enables the split-bf16 matrix-core convolution path
-    (include/ttts_hip.h: ttts_conv_set_workspace).  TTTS_CONV_FP32=1 keeps the exact-fp32 MFMA kernels."""
+def _conv_ctx(device):
+    """The convolution context of `device` (include/ttts_hip.h: ttts_conv_ctx), created on first use: a caller-owned struct
+    + the scratch tensor that enables the split-bf16 matrix-core path.  Python-side state only -- the C library keeps none;
+    every conv entry point receives the struct by pointer.  TTTS_CONV_FP32=1 creates it without scratch (exact kernels)."""
     key = str(device)
-    if key not in _conv_scratch:
-        if os.environ.get("TTTS_CONV_FP32", "0") == "1":
-            _conv_scratch[key] = None
-        else:
+    if key not in _conv_ctxs:
+        buf = None
+        if os.environ.get("TTTS_CONV_FP32", "0") != "1":
             buf = torch.empty(int(os.environ.get("TTTS_CONV_SCRATCH_MB", "1536")) << 20, dtype=torch.uint8, device=device)
-            check(_l.get().ttts_conv_set_workspace(_p(buf), buf.numel()), "conv_set_workspace")
-            _conv_scratch[key] = buf
-    return _conv_scratch[key]
+        ctx = _l.ConvCtx(_p(buf), buf.numel() if buf is not None else 0, 0, 0)
+        _conv_ctxs[key] = (ctx, buf)
+        _apply_flags()
+    return ctypes.byref(_conv_ctxs[key][0])
 
 
 
@@ -598,7 +601,6 @@ def conv1d_fwd(x, w, bias=None, resid=None, stride=1, pad=0, dil=1, in_slope=1.0
     for t, n in ((x, "x"), (w, "w"), (bias, "bias"), (resid, "resid"), (bbias, "bbias"), (gate, "gate")):
         _req(t, torch.float32, n)
     x = x.contiguous(); w = w.contiguous()
-    _conv_workspace(x.device)
     B, Cin, Lin = x.shape
     Cout, _, K = w.shape
     Lout = conv_out_len(Lin, K, stride, pad, dil)
@@ -606,7 +608,7 @@ def conv1d_fwd(x, w, bias=None, resid=None, stride=1, pad=0, dil=1, in_slope=1.0
     c = lambda t: t.contiguous() if t is not None else None
     check(_l.get().ttts_conv1d_fwd_f32(_p(x), _p(w), _p(c(bias)), _p(c(bbias)), _p(c(resid)), _p(c(gate)), _p(c(omask)), _p(y), B, Cin, Lin,
                                        Cout, Lout, K, stride, pad, dil, groups, in_slope, gate_slope, _OUT_ACT[out_act],
-                                       out_slope, out_scale, int(accumulate), _stream()), "conv1d_fwd")
+                                       out_slope, out_scale, int(accumulate), _conv_ctx(x.device), _stream()), "conv1d_fwd")
     return y
 
 
@@ -616,14 +618,13 @@ def conv1d_dgrad(dy, w, lin, stride=1, pad=0, dil=1, gate=None, gate_slope=1.0, 
     (then `in_slope` is the leaky-relu fused on its input and `bias` its bias)."""
     _req(dy, torch.float32, "dy"); _req(w, torch.float32, "w")
     dy = dy.contiguous(); w = w.contiguous()
-    _conv_workspace(dy.device)
     B, Cout, Lout = dy.shape
     Cin, K = w.shape[1] * groups, w.shape[2]
     dx = out if out is not None else torch.empty(B, Cin, lin, dtype=torch.float32, device=dy.device)
     c = lambda t: t.contiguous() if t is not None else None
     check(_l.get().ttts_conv1d_dgrad_f32(_p(dy), _p(w), _p(c(bias)), _p(c(resid)), _p(c(gate)), _p(c(omask)), _p(dx), B, Cin, lin, Cout, Lout,
                                          K, stride, pad, dil, groups, in_slope, gate_slope, out_scale, int(accumulate),
-                                         _stream()), "conv1d_dgrad")
+                                         _conv_ctx(dy.device), _stream()), "conv1d_dgrad")
     return dx
 
 
@@ -634,7 +635,7 @@ def conv1d_wgrad(dy, x, k, stride=1, pad=0, dil=1, x_slope=1.0, dy_slope=1.0, ou
     _, Cin, Lin = x.shape
     dw = out if out is not None else torch.zeros(Cout, Cin // groups, k, dtype=torch.float32, device=dy.device)
     check(_l.get().ttts_conv1d_wgrad_f32(_p(dy), _p(x), _p(dw), B, Cin, Lin, Cout, Lout, k, stride, pad, dil, groups, dy_slope,
-                                         x_slope, _stream()), "conv1d_wgrad")
+                                         x_slope, _conv_ctx(dy.device), _stream()), "conv1d_wgrad")
     return dw
 
 
@@ -934,14 +935,21 @@ _dropout_counters = {}
 
 
 def dropout_counter(device):
-    """The process-wide dropout stream counter (int32 [1] on `device`), registered with the library on first use and
-    never freed.  Increment it once per training step (`counter.add_(1)`, capturable) for fresh masks."""
+    """The dropout stream counter of `device` (int32 [1], created on first use, owned here -- the C library is stateless and
+    receives the pointer as an explicit argument of every dropout-capable call).  Increment it once per training step
+    (`counter.add_(1)`, capturable) for fresh masks; operators called with dropout_p > 0 and no explicit `counter=` use it."""
     key = str(torch.device(device))
     if key not in _dropout_counters:
-        t = torch.zeros(1, dtype=torch.int32, device=device)
-        check(_l.get().ttts_set_dropout_counter(_p(t)), "set_dropout_counter")
-        _dropout_counters[key] = t
+        _dropout_counters[key] = torch.zeros(1, dtype=torch.int32, device=device)
     return _dropout_counters[key]
+
+
+def _ctr(counter, like, dropout_p):
+    """Device pointer of the dropout counter an operator call uses: the explicit one, else (when dropout is on) the
+    device's default counter if one was created, else NULL."""
+    if counter is None and dropout_p > 0.0:
+        counter = _dropout_counters.get(str(like.device))
+    return _p(counter)
 
 
 def stft_mag_bwd(wav, window, dspec, n_fft, hop):
