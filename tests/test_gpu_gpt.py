@@ -63,8 +63,8 @@ def test_tiny_matches_reference_fixture(gpt, golden_dir):
     assert torch.equal(batch[2], mel_before)
     (lt * 0.01 + lm).backward()
     _diag("tiny_losses", {"loss_text": [lt.item(), float(g["loss_text"])], "loss_mel": [lm.item(), float(g["loss_mel"])]})
-    np.testing.assert_allclose(lt.item(), g["loss_text"], rtol=3e-3)
-    np.testing.assert_allclose(lm.item(), g["loss_mel"], rtol=3e-3)
+    np.testing.assert_allclose(lt.item(), g["loss_text"], rtol=3e-4)     # bf16 path vs the fp32 reference: measured <= 9e-5
+    np.testing.assert_allclose(lm.item(), g["loss_mel"], rtol=3e-4)
     assert logits.shape == tuple(g["mel_logits"].shape)
     assert rel_err(logits.float(), torch.from_numpy(g["mel_logits"])) < 3e-2
     eng = model.engine
@@ -94,8 +94,8 @@ def test_full_config_b1_fixture(gpt, golden_dir):
     lt, lm, logits = model(batch[0].cuda(), batch[1], batch[2].cuda(), batch[3])
     (lt * 0.01 + lm).backward()
     _diag("full_b1_losses", {"loss_text": [lt.item(), float(g["loss_text"])], "loss_mel": [lm.item(), float(g["loss_mel"])]})
-    np.testing.assert_allclose(lt.item(), g["loss_text"], rtol=3e-3)
-    np.testing.assert_allclose(lm.item(), g["loss_mel"], rtol=3e-3)
+    np.testing.assert_allclose(lt.item(), g["loss_text"], rtol=3e-4)     # bf16 path vs the fp32 reference: measured <= 9e-5
+    np.testing.assert_allclose(lm.item(), g["loss_mel"], rtol=3e-4)
     assert rel_err(logits[0, ::64, ::64].float(), torch.from_numpy(g["logits_slice"])) < 3e-2
     eng = model.engine
     gn = float(eng.grads.double().norm())
