@@ -66,10 +66,33 @@ def _bf(x):
     return x.to(torch.bfloat16)
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 200, 128), (1040, 257, 512), (128, 128, 64), (9248, 1536, 512), (777, 512, 2048)])
-def test_gemm_nt_epilogues(ops, M, N, K):
+_NT_WS = {}
+
+
+def _nt_ws(ops):
+    if "ws" not in _NT_WS:
+        _NT_WS["ws"] = ops.gemm_nt_workspace(dev())
+    return _NT_WS["ws"]
+
+
+@pytest.mark.parametrize("persist", [False, True])
+@pytest.mark.parametrize("M,N,K", [(300, 200, 128), (1040, 257, 512), (128, 128, 64), (9248, 1536, 512), (777, 512, 2048),
+                                   (256, 256, 4096), (200, 130, 1024), (9248, 512, 2048), (2000, 2048, 512), (129, 1026, 512)])
+def test_gemm_nt_epilogues(ops, M, N, K, persist):
+    """persist=True: the persistent wave-specialised kernel (workspace given; K % 64 == 0, K >= 256 -- other shapes fall back),
+    incl. shapes whose tiles are cut by the unit split several times ((256, 256, 4096): every tile is finished from the
+    partial slots of up to 7 other workgroups) and ragged M / N edges."""
     from ttts_amd.lib import EPI_DGELU_BF16, EPI_GELU_BF16, EPI_RESID_ADD_F32, EPI_STORE_BF16, EPI_STORE_F32
     from oracle.gpt_ref import gelu_new
+    _gemm = ops.gemm_nt
+    if persist:
+        ws = _nt_ws(ops)
+
+        class _P:      # same call surface, workspace added
+            @staticmethod
+            def gemm_nt(*a, **k):
+                return _gemm(*a, workspace=ws, **k)
+        ops = _P
     g = torch.Generator(device="cpu").manual_seed(M * 7 + N)
     a = _bf(torch.randn(M, K, generator=g)).to(dev())
     b = _bf(torch.randn(N, K, generator=g) * 0.1).to(dev())
@@ -105,6 +128,33 @@ def test_gemm_nt_epilogues(ops, M, N, K):
         x = pre[:, :N].float().requires_grad_(True)
         gelu_new(x).sum().backward()
         assert rel_err(dg[:, :N].float(), (a.float() @ b.float().t()) * x.grad) < 5e-3
+    if persist:
+        # the workspace is left clean (every partial consumed, every flag reset): same call again, same bits; and the
+        # one-tile-per-workgroup kernel agrees up to the fp32 summation order of split tiles
+        assert int(ws[:1024].abs().sum()) == 0
+        cf2 = torch.zeros_like(cf)
+        for _ in range(3):
+            ops.gemm_nt(a, b, cf2, None, n=N, epilogue=EPI_STORE_F32)
+            assert torch.equal(cf2, cf)
+        cf3 = torch.zeros_like(cf)
+        _gemm(a, b, cf3, None, n=N, epilogue=EPI_STORE_F32)
+        assert rel_err(cf2[:, :N], cf3[:, :N]) < 1e-6
+
+
+def test_gemm_nt_persistent_dropout_matches_one_tile_kernel(ops):
+    """Residual dropout in the persistent epilogue draws the same mask (same element index -> same hash) as the
+    one-tile-per-workgroup kernel."""
+    from ttts_amd.lib import EPI_RESID_ADD_F32
+    g = torch.Generator(device="cpu").manual_seed(3)
+    M, N, K = 1156, 512, 512
+    a = _bf(torch.randn(M, K, generator=g)).to(dev()); b = _bf(torch.randn(N, K, generator=g) * 0.1).to(dev())
+    bias = torch.randn(N, generator=g).to(dev()); r_in = torch.randn(M, N, generator=g).to(dev())
+    ctr = torch.full((1,), 5, dtype=torch.int32, device=dev())
+    o1, o2 = torch.empty_like(r_in), torch.empty_like(r_in)
+    ops.gemm_nt(a, b, o1, bias, epilogue=EPI_RESID_ADD_F32, resid_in=r_in, dropout_p=0.1, seed=99, counter=ctr)
+    ops.gemm_nt(a, b, o2, bias, epilogue=EPI_RESID_ADD_F32, resid_in=r_in, dropout_p=0.1, seed=99, counter=ctr, workspace=_nt_ws(ops))
+    assert torch.equal(o1, o2)
+    assert abs(float((o1 == r_in).float().mean()) - 0.1) < 0.01
 
 
 @pytest.mark.parametrize("Kr,Mo,No", [(1000, 257, 512), (9248, 512, 1536), (333, 128, 128), (2080, 2048, 512), (8208, 1026, 512)])

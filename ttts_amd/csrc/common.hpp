@@ -135,18 +135,23 @@ __device__ __forceinline__ float fast_tanh(float u) {
   const float e = __builtin_amdgcn_exp2f(u * 2.885390081777927f);  // e^(2u) = 2^(2u log2 e)
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
 }
+// gelu_new(x) = 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3)  ==  x * sigmoid(2u): seven instructions
+// (x^2, fma, mul, exp2, add, rcp, mul) instead of eleven -- the GELU epilogue is VALU-bound beside the MFMA stream.
+//   -2u log2(e) = x * (GC1 + GC2 x^2)
+constexpr float GELU_C1 = -2.0f * 0.7978845608028654f * 1.4426950408889634f;             // -2 sqrt(2/pi) log2(e)
+constexpr float GELU_C2 = GELU_C1 * 0.044715f;
 __device__ __forceinline__ float gelu_new_f(float x) {
-  const float k0 = 0.7978845608028654f;  // sqrt(2/pi)
-  const float u = k0 * (x + 0.044715f * x * x * x);
-  return 0.5f * x * (1.0f + fast_tanh(u));
+  const float t = x * x;
+  const float e = __builtin_amdgcn_exp2f(x * fmaf(t, GELU_C2, GELU_C1));                  // e^(-2u); inf for very negative x
+  return x * __builtin_amdgcn_rcpf(1.0f + e);                                               // x * sigmoid(2u); -> 0 as e -> inf
 }
+// d/dx gelu_new = s + x s (1 - s) d(2u)/dx with s = sigmoid(2u), d(2u)/dx = 2 sqrt(2/pi) (1 + 3 * 0.044715 x^2)
 __device__ __forceinline__ float gelu_new_grad_f(float x) {
-  const float k0 = 0.7978845608028654f;
-  const float x2 = x * x;
-  const float u = k0 * (x + 0.044715f * x * x2);
-  const float t = fast_tanh(u);
-  const float du = k0 * (1.0f + 3.0f * 0.044715f * x2);
-  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
+  const float t = x * x;
+  const float e = __builtin_amdgcn_exp2f(x * fmaf(t, GELU_C2, GELU_C1));
+  const float s = __builtin_amdgcn_rcpf(1.0f + e);
+  const float dz = fmaf(t, 3.0f * 0.044715f * 2.0f * 0.7978845608028654f, 2.0f * 0.7978845608028654f);
+  return s * fmaf((1.0f - s) * x, dz, 1.0f);
 }
 
 }  // namespace ttts

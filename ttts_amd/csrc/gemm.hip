@@ -576,10 +576,16 @@ static void launch_nt(const GemmNtParams& p, int grid, hipStream_t s) {
   else gemm_nt_kernel<EPI><<<grid, 256, 0, s>>>(p);
 }
 
+namespace ttts {
+int gemm_nt_persist_try(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias,
+                        void* aux, int M, int N, int K, int epilogue, const float* resid_in, uint32_t thr, float inv_keep,
+                        uint64_t seed, const uint32_t* dropout_counter, void* workspace, hipStream_t s, bool* handled);
+}
+
 extern "C" int ttts_gemm_nt_bf16_ex(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                                     const float* bias, void* aux, int32_t M, int32_t N, int32_t K, int32_t epilogue,
                                     const float* resid_in, float dropout_p, uint64_t seed, const uint32_t* dropout_counter,
-                                    void* stream) {
+                                    void* workspace, void* stream) {
   TTTS_REQUIRE(A && B && C, "gemm_nt: null pointer");
   TTTS_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_nt: bad shape M=%d N=%d K=%d", M, N, K);
   TTTS_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K, "gemm_nt: K, lda, ldb must be multiples of 8 (K=%d lda=%lld ldb=%lld)", K, (long long)lda, (long long)ldb);
@@ -595,6 +601,13 @@ extern "C" int ttts_gemm_nt_bf16_ex(const void* A, int64_t lda, const void* B, i
   if (p.e.thr) p.e.inv_keep = 65536.0f / (65536.0f - (float)p.e.thr);
   const int grid = (int)(cdiv(M, BM) * cdiv(N, BN));
   hipStream_t s = as_stream(stream);
+  TTTS_REQUIRE(!workspace || aligned16(workspace), "gemm_nt: workspace must be 16-byte aligned");
+  {  // persistent wave-specialised kernel (gemm_persist.hip) when the caller provides its workspace
+    bool handled = false;
+    const int rc = gemm_nt_persist_try(A, lda, B, ldb, C, ldc, bias, aux, M, N, K, epilogue, resid_in, p.e.thr, p.e.inv_keep, seed,
+                                       dropout_counter, workspace, s, &handled);
+    if (rc || handled) return rc;
+  }
   switch (epilogue) {
     case TTTS_EPI_STORE_BF16: launch_nt<TTTS_EPI_STORE_BF16>(p, grid, s); break;
     case TTTS_EPI_GELU_BF16: launch_nt<TTTS_EPI_GELU_BF16>(p, grid, s); break;
@@ -609,7 +622,7 @@ extern "C" int ttts_gemm_nt_bf16_ex(const void* A, int64_t lda, const void* B, i
 extern "C" int ttts_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                                  const float* bias, void* aux, int32_t M, int32_t N, int32_t K, int32_t epilogue,
                                  void* stream) {
-  return ttts_gemm_nt_bf16_ex(A, lda, B, ldb, C, ldc, bias, aux, M, N, K, epilogue, nullptr, 0.f, 0, nullptr, stream);
+  return ttts_gemm_nt_bf16_ex(A, lda, B, ldb, C, ldc, bias, aux, M, N, K, epilogue, nullptr, 0.f, 0, nullptr, nullptr, stream);
 }
 
 static void tn_plan(int Mo, int No, int Kr, int& splits, int& k_chunk) {

@@ -46,8 +46,13 @@ def _ld(t):
     return t.stride(0)
 
 
+def gemm_nt_workspace(device):
+    """Zeroed workspace that selects the persistent wave-specialised NT GEMM (include/ttts_hip.h: ttts_gemm_nt_bf16_ex)."""
+    return torch.zeros(_l.get().ttts_gemm_nt_workspace_bytes() // 4, dtype=torch.int32, device=device)
+
+
 def gemm_nt(a, b, c, bias=None, aux=None, epilogue=EPI_STORE_BF16, n=None, k=None, resid_in=None, dropout_p=0.0,
-            seed=0, counter=None):
+            seed=0, counter=None, workspace=None):
     """c[M,N] = epi(a[M,K] @ b[N,K]^T).  a/b bf16 row-major views; c bf16 or f32 (per epilogue)."""
     _req(resid_in, torch.float32, "resid_in")
     _req(a, torch.bfloat16, "a"); _req(b, torch.bfloat16, "b"); _req(bias, torch.float32, "bias")
@@ -60,7 +65,8 @@ def gemm_nt(a, b, c, bias=None, aux=None, epilogue=EPI_STORE_BF16, n=None, k=Non
     if resid_in is not None and (resid_in.shape != c.shape or resid_in.stride() != c.stride()):
         raise TttsError("resid_in must have the layout of c")
     check(_l.get().ttts_gemm_nt_bf16_ex(_p(a), _ld(a), _p(b), _ld(b), _p(c), _ld(c), _p(bias), _p(aux), M, N, K,
-                                        epilogue, _p(resid_in), dropout_p, seed, _ctr(counter, c, dropout_p), _stream()), "gemm_nt")
+                                        epilogue, _p(resid_in), dropout_p, seed, _ctr(counter, c, dropout_p), _p(workspace),
+                                        _stream()), "gemm_nt")
     return c
 
 
