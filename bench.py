@@ -23,7 +23,166 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0      # HBM3E peak (same guide; ~6300 GB/s is what a float4 copy reaches)
 B_PER_GPU, TEXT_LEN, MEL_LEN = 8, 128, 1024
+
+
+def _event_time_us(fn, reps=20):
+    """Average device time of `fn` (one or more launches on torch's current stream) over `reps` back-to-back calls."""
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+def hbm_kernel_table(dev):
+    """The HBM-bound kernels north_star names, each at its BASELINE shape: algorithmic bytes / measured
+    device time -> GB/s and fraction of the 8 TB/s peak.  Measured live with HIP events on the launch stream."""
+    from ttts_amd import ops
+    from ttts_amd.utils.data_utils import spec_to_mel_torch, spectrogram_torch
+    rows = {}
+
+    def add(name, nbytes, fn, reps=20):
+        us = _event_time_us(fn, reps)
+        rows[name] = {"us": round(us, 1), "algorithmic_MB": round(nbytes / 1e6, 2), "GBps": round(nbytes / us / 1e3, 1),
+                      "frac_of_8TBps": round(nbytes / us / 1e3 / PEAK_HBM_GBS, 4)}
+    g = torch.Generator().manual_seed(0)
+    wav = (torch.rand(32, 163840, generator=g) * 2 - 1).to(dev)
+    add("stft_mag (32 x 163840 -> 32 x 1025 x 256)", 32 * (163840 + 1025 * 256) * 4, lambda: spectrogram_torch(wav, 2048, 640, 2048))
+    spec = spectrogram_torch(wav, 2048, 640, 2048)
+    add("mel_log (32 x 1025 x 256 -> 32 x 128 x 256)", 32 * (1025 + 128) * 256 * 4, lambda: spec_to_mel_torch(spec, 2048, 128, 32000, 0.0, None))
+    x = torch.randn(4096, 192, generator=g).to(dev); cb = torch.randn(1024, 192, generator=g).to(dev)
+    add("vq_nearest (4096 x 192 vs 1024 codes)", (4096 * 192 * 2 + 1024 * 192) * 4 + 4096 * 8, lambda: ops.vq_nearest(x, cb))
+    idx = ops.vq_nearest(x, cb, want_xq=False)[0]
+    cs, ea, em = torch.full((1024,), 4.0, device=dev), cb.clone() * 4, cb.clone()
+    add("vq_ema_update (4096 rows, 1024 codes)", (4096 * 192 + 3 * 1024 * 192 + 2 * 1024) * 4 + 4096 * 8,
+        lambda: ops.vq_ema_update(x, idx, cs, ea, em, 0.99, 1e-5))
+    M, D = 9248, 512
+    xs = torch.randn(M, D, generator=g).to(dev); gam, bet = torch.ones(D, device=dev), torch.zeros(D, device=dev)
+    y = torch.empty(M, D, dtype=torch.bfloat16, device=dev); mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    add("layernorm_fwd (9248 x 512, f32 -> bf16)", M * D * 6 + M * 8, lambda: ops.layernorm_fwd(xs, gam, bet, y, mean, rstd))
+    n = 21_460_000 // 8 * 8
+    pp, gg, m1, m2 = (torch.zeros(n, device=dev) for _ in range(4))
+    sh = torch.zeros(n, dtype=torch.bfloat16, device=dev); state = torch.zeros(8, device=dev)
+    ops.adamw_schedule(state, 1e-4, 0.9, 0.96, 500)
+    add("adamw (21.46 M parameters, + bf16 shadow, zero-grad)", n * 34, lambda: ops.adamw(pp, gg, m1, m2, sh, state, 0.9, 0.96, 1e-8, 0.01, zero_grad=True))
+    return rows
+
+
+def vqvae_leg(dev, steps, warmup, cpu_leg=True):
+    """BASELINE.json metric, second clause: spectrogram frames/s of the full two-phase VQ-VAE-GAN step (config #3: B 32 x
+    163 840 samples = 256 frames, fp32 arithmetic with split-bf16 matrix-core convolutions).  Returns the "vqvae" object."""
+    from ttts_amd import ops
+    from ttts_amd.vqvae.train import SyntheticVqvaeBatches, VqvaeTrainer, get_hparams
+    B, NS = 32, 163840
+    hps = get_hparams()
+    tr = VqvaeTrainer(hps, device=dev)
+    cb = tr.net_g.quantizer.vq.layers[0]._codebook
+    with torch.no_grad():          # codebook pre-initialised (k-means excluded from timing, SURVEY.md 8d #3)
+        cb.inited.fill_(1); cb.embed.normal_(0, 0.3); cb.embed_avg.copy_(cb.embed * 4); cb.cluster_size.fill_(4.0)
+    data = next(iter(SyntheticVqvaeBatches(B, n_samples=NS, device=dev)))       # resident in HBM before the timed region
+    for _ in range(warmup):
+        out = tr.train_step_graphed(data)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = tr.train_step_graphed(data)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    graphed = tr._graph_state["graph"] is not None
+    vals = {k: float(v) for k, v in out.items()}
+    assert all(v == v for v in vals.values()), vals
+    # dominant kernel family: the convolutions (implicit GEMM on the matrix cores), timed eagerly with HIP events
+    fam = {"conv1d_fwd": [0, 0.0, 0.0], "conv1d_dgrad": [0, 0.0, 0.0], "conv1d_wgrad": [0, 0.0, 0.0]}
+    saved, recs = {}, []
+
+    def wrap(name, flops_fn):
+        fn = getattr(ops, name); saved[name] = fn
+
+        def w(*a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); r = fn(*a, **kw); e1.record()
+            recs.append((name, flops_fn(r, *a), e0, e1))
+            return r
+        setattr(ops, name, w)
+    # algorithmic FLOPs = 2 x (output elements) x (reduction length C_in / groups x taps)
+    wrap("conv1d_fwd", lambda y, x, w_, *a: 2.0 * y.numel() * w_.shape[1] * w_.shape[2])
+    wrap("conv1d_dgrad", lambda dx, dy, w_, *a: 2.0 * dy.numel() * w_.shape[1] * w_.shape[2])
+    wrap("conv1d_wgrad", lambda dw, dy, x, *a: 2.0 * dy.shape[0] * dy.shape[2] * dw.numel())
+    try:
+        if hasattr(torch.cuda, "_sleep"):
+            torch.cuda._sleep(int(8e7))         # park the device so the host runs ahead: event pairs then measure device time
+        tr.train_step(data)
+        torch.cuda.synchronize()
+    finally:
+        for k, v in saved.items():
+            setattr(ops, k, v)
+    for name, fl, e0, e1 in recs:
+        f = fam[name]; f[0] += 1; f[1] += e0.elapsed_time(e1) * 1e-3; f[2] += fl
+    tot_s, tot_f, tot_n = sum(f[1] for f in fam.values()), sum(f[2] for f in fam.values()), sum(f[0] for f in fam.values())
+    ach = tot_f / tot_s / 1e12
+    peak = PEAK_BF16_TFLOPS / 3.0               # an fp32 product costs three bf16 MFMA products (hi*hi + hi*lo + lo*hi)
+    res = {"metric": "vqvae_gan_train_frames_per_sec", "value": round(B * 256 / dt, 1), "unit": "frames/s",
+           "ms_per_step": round(dt * 1e3, 2), "steps": steps, "warmup": warmup, "dtype": "f32 (conv products as split-bf16 x3 on the bf16 MFMA, fp32 accumulate)",
+           "config": {"workload": "VQ-VAE-GAN two-phase step (spectrograms, SynthesizerTrn, mel, MPD x2, 6 losses, 2 x AdamW, codebook EMA), "
+                                  "batch 32 x 163 840 samples (256 frames), %s" % ("one hipGraph replay per step" if graphed else "eager launches (capture refused)")},
+           "algorithmic_tflops": round(1.97e9 * B * 256 / dt / 1e12, 1),
+           "roofline": {"bound": "mfma", "kernel": "conv1d_{fwd,dgrad,wgrad} (split-bf16 implicit GEMM; %d launches per step)" % tot_n,
+                        "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                        "ms_per_step": round(tot_s * 1e3, 2), "timing": "HIP events around every launch of one eager step",
+                        "families_ms": {k: round(v[1] * 1e3, 2) for k, v in fam.items()}},
+           "losses": {k: round(v, 4) for k, v in vals.items()}, "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+    if cpu_leg:
+        res["cpu_baseline"] = vqvae_cpu_baseline()
+    return res
+
+
+def vqvae_cpu_baseline():
+    """The oracle's restatement of the same two-phase step (oracle/vqvae_ref.gan_step_losses + CPU autograd + AdamW on the
+    discriminator between the phases) on the host cores, bounded sample: ONE clip of 64 frames (40 960 samples)."""
+    from oracle import vqvae_ref
+    from ttts_amd.vqvae.train import get_hparams
+    threads = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(threads)
+    surf = json.load(open(os.path.join(ROOT, "tests", "golden", "surface.json")))
+    hps = get_hparams()
+    cfg = {k: getattr(hps.vqvae, k) for k in ("n_heads", "n_layers", "kernel_size", "inter_channels", "hidden_channels", "resblock",
+                                               "resblock_kernel_sizes", "resblock_dilation_sizes", "upsample_rates",
+                                               "upsample_initial_channel", "upsample_kernel_sizes")}
+    h = {k: getattr(hps.data, k) for k in ("filter_length", "hop_length", "win_length", "n_mel_channels", "sampling_rate", "mel_fmin", "mel_fmax")}
+    h.update({k: getattr(hps.train, k) for k in ("segment_size", "c_mel", "c_kl", "learning_rate", "betas", "eps")})
+    sd_g = {k: vqvae_ref.det_fill(k, s, 0.4) for k, s, *_ in surf["vqvae_g"] if not k.startswith("quantizer.") and not k.endswith("filter")}
+    for k, v in sd_g.items():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    sd_d = {k: vqvae_ref.det_fill(k, s, 0.6).requires_grad_(True) for k, s, *_ in surf["vqvae_d"]}
+    embed = vqvae_ref.det_fill("codebook.embed", (1024, 192)) * 2.0
+    frames = 64
+    g = torch.Generator().manual_seed(7)
+    wav = (torch.rand(1, frames * 640, generator=g) - 0.5)
+    opt_d = torch.optim.AdamW(list(sd_d.values()), h["learning_rate"], betas=h["betas"], eps=h["eps"])
+    opt_g = torch.optim.AdamW([v for v in sd_g.values() if v.requires_grad], h["learning_rate"], betas=h["betas"], eps=h["eps"])
+
+    def one_step():
+        buffers = {"embed": embed.clone(), "embed_avg": embed * 4.0, "cluster_size": torch.full((1024,), 4.0)}
+
+        def d_phase(ld):
+            ld.backward(); opt_d.step(); opt_d.zero_grad()
+        _, lg, _ = vqvae_ref.gan_step_losses(sd_g, sd_d, cfg, h, buffers, wav, torch.tensor([frames * 640]), torch.randint(1, 255, (1, 16), generator=g),
+                                             torch.tensor([16]), torch.randn(1, 192, frames, generator=g), torch.randn(1, 192, frames, generator=g),
+                                             torch.tensor([frames - 32]), d_update=d_phase)
+        lg.backward(); opt_g.step(); opt_g.zero_grad(); opt_d.zero_grad()
+    t0 = time.time(); one_step(); warm = time.time() - t0
+    n, t0 = 0, time.time()
+    while n < 1 or (time.time() - t0 + 1.5 * warm < 20.0 and n < 4):
+        one_step(); n += 1
+    dt = (time.time() - t0) / n
+    return {"value": round(frames / dt, 2), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": "%d full two-phase steps (fwd, D backward + AdamW, G backward + AdamW) of the oracle on ONE clip of %d frames "
+                      "(%d samples, 32-frame decoder segment), fp32, after 1 warm-up step; %.2f s/step" % (n, frames, frames * 640, dt)}
 
 
 class KernelTimer:
@@ -121,13 +280,18 @@ def cpu_baseline(seconds_budget=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--mode", default="train", choices=["train", "eager", "graph_nodropout"],
                     help="train: reference training mode (dropout 0.1), whole step replayed from one hipGraph (N = 1) -- "
                          "the headline; eager: same, launch by launch; graph_nodropout: dropout off (diagnostic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--exchange", default="ranged", choices=["ranged", "whole"],
+                    help="N > 1: 'ranged' = four range all-reduces, the upper layers' overlapped with the lower layers' backward "
+                         "(three graphs); 'whole' = one all-reduce of the whole gradient arena after the backward (two graphs)")
+    ap.add_argument("--no-vqvae", action="store_true", help="skip the VQ-VAE-GAN leg (second clause of the metric; N = 1 only)")
+    ap.add_argument("--vqvae-steps", type=int, default=8)
     args = ap.parse_args()
 
     from ttts_amd import ops
@@ -168,8 +332,11 @@ def main():
         toks = prepare_tokens(eng.c, text_d, tl, mel_d, wl)   # token plumbing (lengths are host tensors: no sync)
         if args.mode != "eager":
             # N > 1: the gradient all-reduce of the upper layers + heads overlaps the backward of the lower layers
-            eng.train_step(toks, w_text, w_mel, capture=True, lr=tr["lr"],
-                           exchange_range=(lambda lo, hi: dp.allreduce_range_(eng.grads, lo, hi)) if world > 1 else None)
+            if world > 1 and args.exchange == "whole":
+                eng.train_step(toks, w_text, w_mel, capture=True, lr=tr["lr"], exchange=lambda: dp.allreduce_grads_(eng.grads))
+            else:
+                eng.train_step(toks, w_text, w_mel, capture=True, lr=tr["lr"],
+                               exchange_range=(lambda lo, hi: dp.allreduce_range_(eng.grads, lo, hi)) if world > 1 else None)
             return
         eng.set_tokens(*toks)
         eng.forward()
@@ -223,6 +390,8 @@ def main():
             traffic = None
         roof = {"bound": "mfma", "kernel": fam, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                "timing": "HIP events on the launch stream around every launch, min over %d instrumented eager steps; traffic from the "
+                          "committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), not measured in this run" % args.profile_steps,
                 "launches_per_step": cnt // args.profile_steps, "avg_launch_us": round(secs / cnt * 1e6, 2),
                 "avg_gflop_per_launch": round(flops / cnt / 1e9, 3),
                 "all_kernels_ms_per_step": {k: round(v[1] / args.profile_steps * 1e3, 3) for k, v in sorted(agg.items())},
@@ -247,10 +416,18 @@ def main():
                                       "dropout %.1f, %s" % (dropout, "eager launches" if not graphed else ("hipGraph replay" if world == 1 else
                                                                        "hipGraph replay, RCCL all-reduce of the upper layers overlapped with the lower layers' backward")),
                           "global_batch": world * B_PER_GPU, "seq_len": TEXT_LEN + 2 + MEL_LEN + 2, "parallelism": "dp%d" % world,
-                          "mode": args.mode},
+                          "mode": args.mode, "graph_replay": bool(graphed),
+                          "exchange": (args.exchange if world > 1 else None),
+                          "dist_backend": (torch.distributed.get_backend() if world > 1 else None), "world_size": world},
                "final_loss_mel": round(lm, 4), "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+        if world == 1:
+            out["hbm_kernels"] = hbm_kernel_table(dev)
+        if world == 1 and not args.no_vqvae:
+            del eng
+            torch.cuda.empty_cache()
+            out["vqvae"] = vqvae_leg(dev, args.vqvae_steps, 2, cpu_leg=not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
 
 

@@ -433,7 +433,8 @@ int ttts_upsample2_fwd_f32(const float* x, float* y, int64_t n, void* stream);
 int ttts_upsample2_bwd_f32(const float* dy, float* dx, int64_t n, void* stream);
 int ttts_act_fwd_f32(const float* x, float* y, int64_t n, int32_t op, void* stream);
 int ttts_act_bwd_f32(const float* dy, const float* x, float* dx, int64_t n, int32_t op, void* stream);
-int ttts_dropout_f32(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
+int ttts_dropout_f32(const float* x, float* y, int64_t n, float p, uint64_t seed, const uint32_t* dropout_counter,
+                     void* stream);
 int ttts_snake_aa_fwd_f32(const float* x, const float* alpha, const float* beta, const float* up_filter,
                           const float* down_filter, float* y, int32_t B, int32_t C, int32_t T, void* stream);
 int ttts_snake_aa_bwd_f32(const float* dy, const float* x, const float* alpha, const float* beta,

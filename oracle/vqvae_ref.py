@@ -380,3 +380,41 @@ def synthesizer_forward(sd, cfg, buffers, wav, wav_aug, wav_lengths, y, y_aug, y
     z_slice = torch.gather(z, 2, idx.unsqueeze(1).expand(-1, z.size(1), -1))
     o = generator_forward(sd, cfg, z_slice, ge, pfx="dec.")
     return o, commit_loss, ids_slice, y_mask, (z, z_p, m_p, logs_p, m_q, logs_q), quantized
+
+
+# ---- the two-phase GAN step body (ttts/vqvae/train.py:313-406) as loss functions over state dicts --------------------------
+def gan_step_losses(sd_g, sd_d, cfg, hps, buffers, wav, wav_lengths, text, text_lengths, noise_p, noise_q, ids_slice,
+                    d_update=None):
+    """One training step up to the generator loss: spectrogram, SynthesizerTrn.forward, mel of the slice and of y_hat,
+    MultiPeriodDiscriminator on (y, y_hat.detach()) -> loss_disc -> `d_update(loss_disc)` (the caller's discriminator phase:
+    backward, grad norm, AdamW step on the leaves of `sd_d` IN PLACE, train.py:365-369) -> MultiPeriodDiscriminator again on
+    (y, y_hat) with the UPDATED discriminator -> the five generator-side losses (:371-381).  `sd_g` / `sd_d`: reference-keyed
+    parameter dicts; `hps`: dict with the data.* / train.* keys used below.  Returns (loss_disc, loss_gen_all, the six losses);
+    the caller runs loss_gen_all.backward() (:383-387).  wav_aug = wav (the freeze_quantizer branch)."""
+    from oracle import mel_ref
+    h = hps
+    spec = mel_ref.spectrogram(wav, h["filter_length"], h["hop_length"], h["win_length"])
+    spec_lengths = wav_lengths // h["hop_length"]
+    seg = h["segment_size"] // h["hop_length"]
+    y_hat, kl_ssl, ids, z_mask, (z, z_p, m_p, logs_p, m_q, logs_q), _ = synthesizer_forward(
+        sd_g, cfg, buffers, wav, wav, wav_lengths, spec, spec, spec_lengths, text, text_lengths, noise_p, noise_q, ids_slice,
+        segment_size=seg, training=True)
+    mel = mel_ref.spec_to_mel(spec, h["filter_length"], h["n_mel_channels"], h["sampling_rate"], h["mel_fmin"], h["mel_fmax"])
+    idx = ids.view(-1, 1) + torch.arange(seg).view(1, -1)
+    y_mel = torch.gather(mel, 2, idx.unsqueeze(1).expand(-1, mel.size(1), -1))
+    y_hat_mel = mel_ref.mel_spectrogram(y_hat.squeeze(1), h["filter_length"], h["n_mel_channels"], h["sampling_rate"], h["hop_length"],
+                                        h["win_length"], h["mel_fmin"], h["mel_fmax"])
+    widx = (ids * h["hop_length"]).view(-1, 1) + torch.arange(h["segment_size"]).view(1, -1)
+    y = torch.gather(wav, 1, widx).unsqueeze(1)
+    dr, dg, _, _ = mpd_forward(sd_d, y, y_hat.detach())
+    loss_disc = discriminator_loss(dr, dg)
+    if d_update is not None:
+        d_update(loss_disc)
+    dr, dg, fr, fg = mpd_forward(sd_d, y, y_hat)
+    loss_mel = F.l1_loss(y_mel, y_hat_mel) * h["c_mel"]
+    loss_kl = kl_loss(z_p, logs_q, m_p, logs_p, z_mask) * h["c_kl"]
+    loss_fm = feature_loss(fr, fg)
+    loss_gen = generator_loss(dg)
+    loss_gen_all = loss_gen + loss_fm + loss_mel + kl_ssl + loss_kl
+    return loss_disc, loss_gen_all, {"loss_disc": loss_disc, "loss_gen": loss_gen, "loss_fm": loss_fm, "loss_mel": loss_mel,
+                                     "kl_ssl": kl_ssl, "loss_kl": loss_kl}

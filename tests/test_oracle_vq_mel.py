@@ -268,3 +268,38 @@ def test_kmeans_init_and_dead_code_expiry(golden_dir):
         np.testing.assert_allclose(buf["embed_avg"].numpy(), g[name + ":embed_avg"], rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(buf["embed"].numpy(), g[name + ":embed"], rtol=1e-5, atol=1e-5)
         assert float(buf["inited"]) == float(g[name + ":inited"][0]) == 1.0
+
+
+def test_gan_step_restatement_losses_and_grad_norms(golden_dir):
+    """oracle.vqvae_ref.gan_step_losses (the two-phase step body, train.py:313-406) vs the reference's own step in
+    tests/golden/vqvae_step.npz: six losses, and both gradient 2-norms through CPU autograd."""
+    import json
+    from oracle import vqvae_ref
+    g = np.load(os.path.join(golden_dir, "vqvae_step.npz"))
+    surf = json.load(open(os.path.join(golden_dir, "surface.json")))
+    cfg = json.loads(str(g["cfg"])); hps = json.loads(str(g["hps"]))
+    T = torch.from_numpy
+    params_g = set(json.loads(str(g["g_names"])))
+    sd_g = {k: vqvae_ref.det_fill(k, s, 0.4) for k, s, *_ in surf["vqvae_g"] if not k.startswith("quantizer.") and not k.endswith("filter")}
+    for k in sd_g:
+        if k in params_g:
+            sd_g[k].requires_grad_(True)
+    sd_d = {k: vqvae_ref.det_fill(k, s, 0.6).requires_grad_(True) for k, s, *_ in surf["vqvae_d"]}
+    embed = vqvae_ref.det_fill("codebook.embed", (1024, 192)) * 2.0
+    buffers = {"embed": embed.clone(), "embed_avg": embed * 4.0, "cluster_size": torch.full((1024,), 4.0)}
+    opt_d = torch.optim.AdamW(list(sd_d.values()), hps["learning_rate"], betas=hps["betas"], eps=hps["eps"])
+    norms = {}
+
+    def d_phase(loss_disc):                      # train.py:365-369: backward, norm, optimizer step -- BEFORE the generator phase
+        loss_disc.backward()
+        norms["d"] = sum(float(p.grad.double().pow(2).sum()) for p in sd_d.values()) ** 0.5
+        opt_d.step()
+        opt_d.zero_grad()
+    ld, lg, terms = vqvae_ref.gan_step_losses(sd_g, sd_d, cfg, hps, buffers, T(g["wav"]), T(g["wav_lengths"]), T(g["text"]),
+                                              T(g["text_lengths"]), T(g["noise_p"]), T(g["noise_q"]), T(g["ids_slice"]), d_update=d_phase)
+    got = np.array([terms[k].item() for k in ("loss_disc", "loss_gen", "loss_fm", "loss_mel", "kl_ssl", "loss_kl")])
+    np.testing.assert_allclose(got, g["losses"], rtol=2e-4)
+    nd = norms["d"]
+    lg.backward()
+    ng = sum(float(p.grad.double().pow(2).sum()) for p in sd_g.values() if p.grad is not None) ** 0.5
+    np.testing.assert_allclose([nd, ng], g["grad_norms"], rtol=2e-3)

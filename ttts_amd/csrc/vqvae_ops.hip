@@ -122,7 +122,9 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
 // y = keep(e) ? x / (1 - p) : 0 with the keep rule of the GPT kernels (16 hash bits per element); the same call with
 // dy as x is the backward.
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n,
-                                                      uint32_t thr, float inv_keep, uint32_t s_lo, uint32_t s_hi) {
+                                                      uint32_t thr, float inv_keep, uint32_t s_lo, uint32_t s_hi,
+                                                      const uint32_t* ctr) {
+  s_hi = seed_mix(s_hi, ctr);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const uint32_t h = hash32((uint32_t)(i >> 1), s_lo, s_hi);
     const uint32_t bits = (h >> (16 * (uint32_t)(i & 1))) & 0xFFFFu;
@@ -417,10 +419,11 @@ extern "C" int ttts_act_bwd_f32(const float* dy, const float* x, float* dx, int6
   act_bwd_kernel<<<grid_for(n), 256, 0, as_stream(stream)>>>(dy, x, dx, n, op);
   return check_launch("act_bwd");
 }
-extern "C" int ttts_dropout_f32(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream) {
+extern "C" int ttts_dropout_f32(const float* x, float* y, int64_t n, float p, uint64_t seed, const uint32_t* dropout_counter,
+                                void* stream) {
   TTTS_REQUIRE(x && y && n > 0 && p >= 0.f && p < 1.f, "dropout: bad arguments");
   const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
-  dropout_kernel<<<grid_for(n), 256, 0, as_stream(stream)>>>(x, y, n, dropout_threshold(p), 1.f / (1.f - p), lo, hi);
+  dropout_kernel<<<grid_for(n), 256, 0, as_stream(stream)>>>(x, y, n, dropout_threshold(p), 1.f / (1.f - p), lo, hi, dropout_counter);
   return check_launch("dropout");
 }
 extern "C" int ttts_snake_aa_fwd_f32(const float* x, const float* alpha, const float* beta, const float* up_filter,

@@ -166,7 +166,7 @@ SIGNATURES = {
     "ttts_upsample2_bwd_f32": (_I32, [_P, _P, _I64, _P]),
     "ttts_act_fwd_f32": (_I32, [_P, _P, _I64, _I32, _P]),
     "ttts_act_bwd_f32": (_I32, [_P, _P, _P, _I64, _I32, _P]),
-    "ttts_dropout_f32": (_I32, [_P, _P, _I64, _F, _U64, _P]),
+    "ttts_dropout_f32": (_I32, [_P, _P, _I64, _F, _U64, _P, _P]),
     "ttts_snake_aa_fwd_f32": (_I32, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P]),
     "ttts_snake_aa_bwd_f32": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P]),
     "ttts_layernorm_ch_fwd_f32": (_I32, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _F, _P]),

@@ -781,10 +781,10 @@ def act_bwd(dy, x, op):
     return dx
 
 
-def dropout(x, p, seed):
+def dropout(x, p, seed, counter=None):
     x = _f32c(x, "x")
     y = torch.empty_like(x)
-    check(_l.get().ttts_dropout_f32(_p(x), _p(y), x.numel(), p, seed, _stream()), "dropout")
+    check(_l.get().ttts_dropout_f32(_p(x), _p(y), x.numel(), p, seed, _ctr(counter, x, p), _stream()), "dropout")
     return y
 
 

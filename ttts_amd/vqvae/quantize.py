@@ -91,19 +91,35 @@ class EuclideanCodebook(nn.Module):
         self.register_buffer("embed", embed)
         self.register_buffer("embed_avg", embed.clone())
 
+    _inited_host = False       # host mirror of `inited` once it is known to be set (a device read per forward is a sync)
+
     @torch.no_grad()
     def init_embed_(self, data):
+        if self._inited_host:
+            return
         if bool(self.inited):
+            self._inited_host = True
             return
         embed, cluster_size = _kmeans(data, self.codebook_size, self.kmeans_iters)
         self.embed.copy_(embed)
         self.embed_avg.copy_(embed)
         self.cluster_size.copy_(cluster_size)
         self.inited.fill_(1)
+        self._inited_host = True
+
+    def _load_from_state_dict(self, *a, **k):
+        self._inited_host = False                          # a loaded checkpoint decides again
+        return super()._load_from_state_dict(*a, **k)
+
+    sync_free = False    # True (hipGraph capture / no host read-back in the step): skip the dead-code replacement -- see below
 
     @torch.no_grad()
     def expire_codes_(self, batch_samples):
-        if self.threshold_ema_dead_code == 0:
+        """core_vq.py:152-168.  NOTE (reference behaviour, kept): the rows this writes into `embed` are overwritten a few
+        lines later in the same forward by `embed = embed_avg / smoothed cluster_size` (core_vq.py:225-228), so the
+        replacement never survives a training step -- its only lasting effect is the random draw it consumes.  In
+        `sync_free` mode (a captured step cannot read `any(expired)` back to the host) it is therefore skipped."""
+        if self.threshold_ema_dead_code == 0 or self.sync_free:
             return
         expired = self.cluster_size < self.threshold_ema_dead_code
         if not bool(torch.any(expired)):

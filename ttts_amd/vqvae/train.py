@@ -181,7 +181,57 @@ class VqvaeTrainer:
                   lambda self, v: (setattr(self.optim_g, "lr", v), setattr(self.optim_d, "lr", v)) and None)
 
     def train_step(self, data, inject=None):
+        ops.dropout_counter(self.device).add_(1)          # fresh dropout masks per step (also under graph replay)
         return self.step_fn(data, inject)
+
+    # ---- the whole two-phase step as ONE hipGraph ----------------------------------------------------------------------------
+    def train_step_graphed(self, data):
+        """Replays the complete step (spectrograms, G forward, both D passes, six losses, both backward passes, both AdamW
+        updates, codebook EMA: ~10 k kernel launches) from one captured hipGraph.  `data` is copied into static input
+        buffers; the returned loss scalars are the graph's static outputs (read them before the next call).  Requirements:
+        one fixed batch shape, world size 1 (collectives are not captured), codebook initialised.  The first call with a new
+        shape runs two eager warm-up steps and records; if capture is refused the trainer says so ONCE and keeps running
+        launch by launch."""
+        key = tuple((k, tuple(v.shape)) for k, v in sorted(data.items()))
+        st = getattr(self, "_graph_state", None)
+        if st is None or st["key"] != key:
+            st = self._capture(data, key)
+            self._graph_state = st
+        if st["graph"] is None:
+            return self.train_step(data)
+        for k, v in data.items():
+            st["inputs"][k].copy_(v)
+        st["graph"].replay()
+        return st["out"]
+
+    def _capture(self, data, key):
+        if self.dp.enabled:
+            return {"key": key, "graph": None}
+        cb = self.net_g.quantizer.vq.layers[0]._codebook
+        if not bool(cb.inited):
+            raise ops.TttsError("train_step_graphed: run the first (k-means initialising) step eagerly")
+        from .quantize import EuclideanCodebook
+        inputs = {k: v.clone() for k, v in data.items()}
+        prev = EuclideanCodebook.sync_free
+        EuclideanCodebook.sync_free = True                   # no host read-backs inside the step (see expire_codes_)
+        try:
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                    # warm-up on a side stream, as torch's capture recipe asks
+                for _ in range(2):
+                    self.train_step(inputs)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self.train_step(inputs)
+            return {"key": key, "graph": g, "inputs": inputs, "out": out}
+        except Exception as err:                             # noqa: BLE001 -- any refusal: report once, run eagerly
+            print("ttts_amd: hipGraph capture of the VQ-VAE-GAN step failed (%s); running it launch by launch"
+                  % str(err).splitlines()[0][:200], file=sys.stderr, flush=True)
+            EuclideanCodebook.sync_free = prev
+            torch.cuda.synchronize()
+            return {"key": key, "graph": None}
 
     def save(self, step):
         if self.rank != 0:
