@@ -220,8 +220,11 @@ int ttts_vq_ema_update_f32(const float* x, const int64_t* idx, float* cluster_si
 int ttts_stft_twiddle_host(float* host_out, int32_t n_fft);
 int ttts_stft_mag_fwd_f32(const float* wav, const float* window, const float* twiddle, float* spec,
                           int32_t B, int32_t T, int32_t n_fft, int32_t hop, void* stream);
-/* spec_to_mel_torch (:90-103): mel f32 [B, n_mels, frames] = log(clamp(basis[n_mels, n_bins] @ spec, 1e-5)). */
-int ttts_mel_log_fwd_f32(const float* spec, const float* basis, float* mel, int32_t B, int32_t n_bins,
+/* spec_to_mel_torch (:90-103): mel f32 [B, n_mels, frames] = log(clamp(basis[n_mels, n_bins] @ spec, 1e-5)).
+ * bands: optional DEVICE int32 [n_mels][2] = {first, last} non-zero column of every basis row (a mel filterbank row is a
+ * narrow band; the caller computes this once per basis).  NULL: every workgroup finds the bands itself (slower).  Results
+ * do not depend on it: the exact-zero terms it skips leave an fmaf chain unchanged. */
+int ttts_mel_log_fwd_f32(const float* spec, const float* basis, const int32_t* bands, float* mel, int32_t B, int32_t n_bins,
                          int32_t n_mels, int32_t frames, void* stream);
 
 /* Backward of the two functions above (mel_spectrogram_torch on the generated audio is differentiated in the VQ-VAE

@@ -13,22 +13,38 @@
 
 namespace ttts {
 
-constexpr int STFT_FR = 16;  // frames per workgroup
+constexpr int STFT_FR = 8;  // frames per workgroup (8: 59 KB of LDS -> two workgroups per CU cover each other's barrier stalls)
 
 __global__ __launch_bounds__(256) void stft_mag_kernel(const float* __restrict__ wav, const float* __restrict__ window,
                                                        const float2* __restrict__ tw, float* __restrict__ spec, int T,
-                                                       int n_fft, int hop, int frames, int log2L) {
+                                                       int n_fft, int hop, int frames, int log2L, int span_lds) {
   extern __shared__ __attribute__((aligned(16))) float stft_smem[];
   const int L = n_fft >> 1;  // complex FFT length
   float2* buf0 = reinterpret_cast<float2*>(stft_smem);
   float2* buf1 = buf0 + L;
   float* outs = reinterpret_cast<float*>(buf1 + L);  // [L + 1][STFT_FR + 1]
+  // (round 2) everything a frame needs sits in LDS before the frame loop: the twiddle table (a global load per butterfly
+  // and pass exposed one L2 latency in each of the log2 L barrier intervals) and -- when it fits (span_lds) -- the 16
+  // frames' whole sample span, reflect-padded, loaded once with coalesced reads (consecutive frames overlap by n_fft - hop)
+  float2* tws = reinterpret_cast<float2*>(outs + (L + 1) * (STFT_FR + 1) + ((L + 1) & 1));   // [L], 8-byte aligned
+  float* span = reinterpret_cast<float*>(tws + L);  // [(STFT_FR - 1) * hop + n_fft] when span_lds
   const int tid = threadIdx.x;
   const int fblocks = (frames + STFT_FR - 1) / STFT_FR;
   const int b = blockIdx.x / fblocks;
   const int f0 = (blockIdx.x % fblocks) * STFT_FR;
   const int pad = (n_fft - hop) / 2;
   const float* w = wav + (int64_t)b * T;
+  for (int k = tid; k < L; k += 256) tws[k] = tw[k];
+  if (span_lds) {
+    const int nspan = (min(STFT_FR, frames - f0) - 1) * hop + n_fft;
+    for (int sidx = tid; sidx < nspan; sidx += 256) {
+      int i = f0 * hop + sidx - pad;
+      if (i < 0) i = -i;
+      if (i >= T) i = 2 * (T - 1) - i;
+      span[sidx] = w[i];
+    }
+  }
+  __syncthreads();
 
   for (int ff = 0; ff < STFT_FR; ++ff) {
     const int frame = f0 + ff;
@@ -38,10 +54,16 @@ __global__ __launch_bounds__(256) void stft_mag_kernel(const float* __restrict__
       float v[2];
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        int i = frame * hop + 2 * n + e - pad;
-        if (i < 0) i = -i;
-        if (i >= T) i = 2 * (T - 1) - i;
-        v[e] = w[i] * window[2 * n + e];
+        float xv;
+        if (span_lds) {
+          xv = span[ff * hop + 2 * n + e];
+        } else {
+          int i = frame * hop + 2 * n + e - pad;
+          if (i < 0) i = -i;
+          if (i >= T) i = 2 * (T - 1) - i;
+          xv = w[i];
+        }
+        v[e] = xv * window[2 * n + e];
       }
       buf0[n] = make_float2(v[0], v[1]);
     }
@@ -55,7 +77,7 @@ __global__ __launch_bounds__(256) void stft_mag_kernel(const float* __restrict__
         const int k = j & (Ns - 1);
         const float2 a = src[j];
         const float2 bb = src[j + (L >> 1)];
-        const float2 t = tw[k * (n_fft >> (ps + 1))];  // exp(-2 pi i k / (2 Ns))
+        const float2 t = tws[k * (n_fft >> (ps + 1))];  // exp(-2 pi i k / (2 Ns))
         const float2 bt = make_float2(bb.x * t.x - bb.y * t.y, bb.x * t.y + bb.y * t.x);
         const int j0 = (j << 1) - k;
         dst[j0] = make_float2(a.x + bt.x, a.y + bt.y);
@@ -76,7 +98,7 @@ __global__ __launch_bounds__(256) void stft_mag_kernel(const float* __restrict__
         const float2 zc = src[L - k];
         const float er = 0.5f * (zk.x + zc.x), ei = 0.5f * (zk.y - zc.y);
         const float orr = 0.5f * (zk.y + zc.y), oi = -0.5f * (zk.x - zc.x);
-        const float2 t = tw[k];
+        const float2 t = tws[k];
         re = er + (orr * t.x - oi * t.y);
         im = ei + (orr * t.y + oi * t.x);
       }
@@ -91,44 +113,53 @@ __global__ __launch_bounds__(256) void stft_mag_kernel(const float* __restrict__
   }
 }
 
-// mel[b][m][f] = log(max(sum_k basis[m][k] spec[b][k][f], 1e-5)); tile 32 mels x 64 frames, k chunks of 32
+// mel[b][m][f] = log(max(sum_k basis[m][k] spec[b][k][f], 1e-5)).
+// (round 2) A mel filterbank row is a narrow band (Slaney triangles: ~2 x 1025 non-zeros in 128 x 1025), so the dense
+// 32 x 64 x 32 tiled product of round 1 (166 us for 32 clips: 2.9 % of the HBM roof, all of it multiplying zeros) is replaced
+// by a band-limited row kernel: each wave finds the first / last non-zero of its basis row (one pass over the row, no
+// assumption about the basis beyond "zeros are zeros"), then accumulates basis[m][k] * spec[b][k][f] over that band in
+// increasing k -- the same fmaf chain as the dense loop minus its exact-zero terms, i.e. bit-identical results -- with the
+// 64 lanes on 64 consecutive frames (256-byte coalesced spec reads, eight in flight).  A workgroup = (clip, 64 frames,
+// 32 mels interleaved over its 4 waves: narrow low bands and wide high bands balance out).
 __global__ __launch_bounds__(256) void mel_log_kernel(const float* __restrict__ spec, const float* __restrict__ basis,
-                                                      float* __restrict__ mel, int n_bins, int n_mels, int frames) {
-  __shared__ float As[32][33];
-  __shared__ float Bs[32][64];
-  const int tid = threadIdx.x, tm = tid >> 6, tf = tid & 63;
+                                                      const int* __restrict__ bands, float* __restrict__ mel, int n_bins,
+                                                      int n_mels, int frames) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ftiles = (frames + 63) / 64, mtiles = (n_mels + 31) / 32;
   const int b = blockIdx.x / (ftiles * mtiles);
   const int rem = blockIdx.x % (ftiles * mtiles);
-  const int m0 = (rem / ftiles) * 32, f0 = (rem % ftiles) * 64;
-  const float* sp = spec + (int64_t)b * n_bins * frames;
-  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < n_bins; k0 += 32) {
+  const int mg = rem / ftiles, f = (rem % ftiles) * 64 + lane;
+  const float* sp = spec + (int64_t)b * n_bins * frames + min(f, frames - 1);
+  for (int i = 0; i < 8; ++i) {
+    const int m = mg * 32 + i * 4 + wave;           // wave-uniform
+    if (m >= n_mels) break;
+    const float* brow = basis + (int64_t)m * n_bins;
+    int lo = n_bins, hi = -1;
+    if (bands) {                                   // caller-computed (once per basis)
+      lo = bands[2 * m]; hi = bands[2 * m + 1];
+    } else {                                       // one pass over the row (17 dependent L2 round trips: measurably slower)
+      for (int k = lane; k < n_bins; k += 64)
+        if (brow[k] != 0.f) { lo = min(lo, k); hi = max(hi, k); }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int e = tid + i * 256, m = e >> 5, k = e & 31;
-      As[m][k] = (m0 + m < n_mels && k0 + k < n_bins) ? basis[(int64_t)(m0 + m) * n_bins + k0 + k] : 0.f;
+      for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, __shfl_xor(lo, o, 64));
+        hi = max(hi, __shfl_xor(hi, o, 64));
+      }
     }
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    hi = __builtin_amdgcn_readfirstlane(hi);
+    float acc = 0.f;
+    int k = lo;
+    for (; k + 8 <= hi + 1; k += 8) {
+      float v[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int e = tid + i * 256, k = e >> 6, f = e & 63;
-      Bs[k][f] = (k0 + k < n_bins && f0 + f < frames) ? sp[(int64_t)(k0 + k) * frames + f0 + f] : 0.f;
-    }
-    __syncthreads();
-#pragma unroll 8
-    for (int k = 0; k < 32; ++k) {
-      const float bv = Bs[k][tf];
+      for (int j = 0; j < 8; ++j) v[j] = sp[(int64_t)(k + j) * frames];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc[i] = fmaf(As[tm * 8 + i][k], bv, acc[i]);
+      for (int j = 0; j < 8; ++j) acc = fmaf(brow[k + j], v[j], acc);
     }
-    __syncthreads();
-  }
-  if (f0 + tf < frames) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int m = m0 + tm * 8 + i;
-      if (m < n_mels) mel[((int64_t)b * n_mels + m) * frames + f0 + tf] = logf(fmaxf(acc[i], 1e-5f));
-    }
+    for (; k <= hi; ++k) acc = fmaf(brow[k], sp[(int64_t)k * frames], acc);
+    if (f < frames) mel[((int64_t)b * n_mels + m) * frames + f] = logf(fmaxf(acc, 1e-5f));
   }
 }
 
@@ -312,25 +343,24 @@ extern "C" int ttts_stft_mag_fwd_f32(const float* wav, const float* window, cons
   const int L = n_fft / 2;
   int log2L = 0;
   while ((1 << log2L) < L) ++log2L;
-  const size_t smem = (size_t)2 * L * sizeof(float2) + (size_t)(L + 1) * (STFT_FR + 1) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stft_mag_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return fail(TTTS_EHIP, "stft: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
+  size_t smem = (size_t)2 * L * sizeof(float2) + ((size_t)(L + 1) * (STFT_FR + 1) + ((L + 1) & 1)) * sizeof(float) + (size_t)L * sizeof(float2);
+  const size_t span_bytes = ((size_t)(STFT_FR - 1) * hop + n_fft) * sizeof(float);
+  const int span_lds = smem + span_bytes <= 80 * 1024;   // only where it does not cost the second workgroup per CU
+  if (span_lds) smem += span_bytes;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(stft_mag_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (attr != hipSuccess) return fail(TTTS_EHIP, "stft: hipFuncSetAttribute: %s", hipGetErrorString(attr));
   const int grid = B * (int)cdiv(frames, STFT_FR);
   stft_mag_kernel<<<grid, 256, smem, as_stream(stream)>>>(wav, window, reinterpret_cast<const float2*>(twiddle), spec, T,
-                                                          n_fft, hop, frames, log2L);
+                                                          n_fft, hop, frames, log2L, span_lds);
   return check_launch("stft_mag_fwd");
 }
 
-extern "C" int ttts_mel_log_fwd_f32(const float* spec, const float* basis, float* mel, int32_t B, int32_t n_bins,
-                                    int32_t n_mels, int32_t frames, void* stream) {
+extern "C" int ttts_mel_log_fwd_f32(const float* spec, const float* basis, const int32_t* bands, float* mel, int32_t B,
+                                    int32_t n_bins, int32_t n_mels, int32_t frames, void* stream) {
   TTTS_REQUIRE(spec && basis && mel && B > 0 && n_bins > 0 && n_mels > 0 && frames > 0, "mel_log: bad arguments");
   const int grid = B * (int)cdiv(frames, 64) * (int)cdiv(n_mels, 32);
-  mel_log_kernel<<<grid, 256, 0, as_stream(stream)>>>(spec, basis, mel, n_bins, n_mels, frames);
+  mel_log_kernel<<<grid, 256, 0, as_stream(stream)>>>(spec, basis, bands, mel, n_bins, n_mels, frames);
   return check_launch("mel_log_fwd");
 }
 

@@ -109,6 +109,132 @@ __global__ __launch_bounds__(256) void vq_nearest_kernel(const float* __restrict
   }
 }
 
+// ---- nearest code, second generation (D % 4 == 0) -------------------------------------------------------------------------
+// The first kernel above needed 233 us for the BASELINE search (4096 rows x 1024 codes x 192: 1.6 GFLOP, 7 MB) -- 24 GB/s,
+// 0.3 % of the HBM roof -- because (a) only N / 32 = 128 workgroups existed for 256 CUs and (b) its LDS staging loop issued
+// ONE 4-byte global load per iteration and waited for it (768 serialised L2 round trips per workgroup).  This one:
+//   * splits the codebook into slices of 256 codes: grid = (N / 32) x (K / 256) = 512 workgroups, each 32 rows x 256 codes;
+//   * stages with 16-byte loads, eight in flight per lane, one row per wave instruction (no index division);
+//   * computes |e|^2 of its codes itself (same k-ordered fmaf chain as vq_code_norm_kernel, from LDS: no extra launch);
+//   * writes (best distance, best index) per (row, slice); vq_nearest_final_kernel merges the slices in slice order (ties ->
+//     lowest index, as before) and gathers the winning code rows.
+// The arithmetic per (row, code) pair is unchanged: one k-ordered fmaf chain on v_mfma_f32_32x32x2_f32, then
+// -((|x|^2 - 2 dot) + |e|^2) in that expression order, so indices AND distances stay bit-exact (tests/test_gpu_kernels.py).
+constexpr int VQ_SLICE = 256;  // codes per workgroup (two LDS chunks of VQ_CODES)
+
+__device__ __forceinline__ void vq_stage_rows(float* dst, int LD, const float* __restrict__ src, int row0, int nrows_valid,
+                                              int rows, int D4, int wave, int lane) {
+  // rows `wave, wave + 4, ...` of a [rows][D] block -> LDS with row pitch LD (odd: conflict-free column reads); lane = float4 column
+  for (int r0 = wave; r0 < rows; r0 += 32) {
+    float4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = r0 + 4 * j;
+      v[j] = (r < rows && r < nrows_valid && lane < D4) ? reinterpret_cast<const float4*>(src + (int64_t)(row0 + r) * (D4 * 4))[lane]
+                                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = r0 + 4 * j;
+      if (r < rows && lane < D4) {
+        float* d = dst + r * LD + lane * 4;
+        d[0] = v[j].x; d[1] = v[j].y; d[2] = v[j].z; d[3] = v[j].w;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void vq_nearest_slice_kernel(const float* __restrict__ x, const float* __restrict__ cb,
+                                                               float2* __restrict__ part, int N, int K, int D, int SL) {
+  extern __shared__ __attribute__((aligned(16))) float vq_smem[];
+  const int LD = D + 1, D4 = D >> 2;
+  float* xs = vq_smem;                       // [VQ_ROWS][LD]
+  float* es = xs + VQ_ROWS * LD;             // [VQ_CODES][LD]
+  float* red_d = es + VQ_CODES * LD;         // [4][VQ_ROWS]
+  int* red_i = reinterpret_cast<int*>(red_d + 4 * VQ_ROWS);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+  const int r0 = blockIdx.x * VQ_ROWS, sl = blockIdx.y, cs0 = sl * VQ_SLICE;
+  vq_stage_rows(xs, LD, x, r0, N - r0, VQ_ROWS, D4, wave, lane);
+  float best = -INFINITY;
+  int best_i = 0;
+  float x2 = 0.f;
+  const float* xrow = xs + (lane & 31) * LD;
+  for (int c0 = cs0; c0 < min(K, cs0 + VQ_SLICE); c0 += VQ_CODES) {
+    __syncthreads();                           // previous chunk consumed (first pass: nothing pending)
+    vq_stage_rows(es, LD, cb, c0, K - c0, VQ_CODES, D4, wave, lane);
+    __syncthreads();
+    if (c0 == cs0)
+      for (int d = 0; d < D; ++d) x2 = fmaf(xrow[d], xrow[d], x2);
+    const int cw = c0 + wave * 32;             // this wave's 32 codes
+    if (cw < K) {
+      const float* erow = es + (wave * 32 + (lane & 31)) * LD;
+      float e2 = 0.f;                          // |e|^2 of code cw + (lane & 31): the k-ordered chain every row uses
+      for (int d = 0; d < D; ++d) e2 = fmaf(erow[d], erow[d], e2);
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      for (int d = 0; d < D; d += 2)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(erow[d + hh], xrow[d + hh], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cl = acc_row(r, hh);         // code inside the tile: its |e|^2 lives in lane cl (either half)
+        const float e2c = __shfl(e2, cl, 64);
+        const int code = cw + cl;
+        if (code < K) {
+          const float dist = -((x2 - 2.0f * acc[r]) + e2c);
+          if (dist > best) { best = dist; best_i = code; }
+        }
+      }
+    }
+  }
+  {
+    const float od = __shfl_xor(best, 32, 64);
+    const int oi = __shfl_xor(best_i, 32, 64);
+    if (od > best || (od == best && oi < best_i)) { best = od; best_i = oi; }
+  }
+  if (lane < 32) {
+    red_d[wave * VQ_ROWS + lane] = best;
+    red_i[wave * VQ_ROWS + lane] = best_i;
+  }
+  __syncthreads();
+  if (tid < VQ_ROWS && r0 + tid < N) {
+    float bd = red_d[tid];
+    int bi = red_i[tid];
+    for (int w = 1; w < 4; ++w) {
+      const float od = red_d[w * VQ_ROWS + tid];
+      const int oi = red_i[w * VQ_ROWS + tid];
+      if (od > bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+    }
+    part[(int64_t)(r0 + tid) * SL + sl] = make_float2(bd, __int_as_float(bi));
+  }
+}
+
+__global__ __launch_bounds__(256) void vq_nearest_final_kernel(const float2* __restrict__ part, const float* __restrict__ cb,
+                                                               int64_t* __restrict__ idx, float* __restrict__ xq,
+                                                               float* __restrict__ best_dist, int N, int D, int SL) {
+  __shared__ int win[VQ_ROWS];
+  const int tid = threadIdx.x, r0 = blockIdx.x * VQ_ROWS;
+  if (tid < VQ_ROWS && r0 + tid < N) {
+    float2 b = part[(int64_t)(r0 + tid) * SL];
+    for (int s = 1; s < SL; ++s) {             // slices hold increasing code ranges: strict > keeps the lowest index on ties
+      const float2 o = part[(int64_t)(r0 + tid) * SL + s];
+      if (o.x > b.x) b = o;
+    }
+    win[tid] = __float_as_int(b.y);
+    idx[r0 + tid] = (int64_t)__float_as_int(b.y);
+    if (best_dist) best_dist[r0 + tid] = b.x;
+  }
+  __syncthreads();
+  if (xq) {
+    const int D4 = D >> 2;
+    for (int i = tid; i < VQ_ROWS * D4; i += 256) {
+      const int r = i / D4, c = i - r * D4;
+      if (r0 + r < N)
+        reinterpret_cast<float4*>(xq + (int64_t)(r0 + r) * D)[c] = reinterpret_cast<const float4*>(cb + (int64_t)win[r] * D)[c];
+    }
+  }
+}
+
 // commitment: t = x + (xq - x); loss = mean((t - x)^2); dx += gs * 2 (x - t) / n
 __global__ __launch_bounds__(256) void vq_commit_kernel(const float* __restrict__ x, const float* __restrict__ xq,
                                                         float* __restrict__ dx, float gscale, int64_t n,
@@ -202,8 +328,8 @@ __global__ __launch_bounds__(256) void vq_ema_embed_kernel(float* __restrict__ e
 using namespace ttts;
 
 extern "C" int64_t ttts_vq_workspace_bytes(int32_t N, int32_t K) {
-  (void)N;
-  return (int64_t)K * (int64_t)sizeof(float) + 1024 * (int64_t)sizeof(double);
+  // code norms (generic kernel) / commitment partials, then the (distance, index) pairs of the sliced search
+  return cdiv(K, 4) * 16 + 1024 * (int64_t)sizeof(double) + (int64_t)N * cdiv(K, VQ_SLICE) * (int64_t)sizeof(float2);
 }
 
 extern "C" int ttts_vq_nearest_f32(const float* x, const float* codebook, int64_t* idx, float* xq, float* best_dist,
@@ -211,18 +337,26 @@ extern "C" int ttts_vq_nearest_f32(const float* x, const float* codebook, int64_
   TTTS_REQUIRE(x && codebook && idx && workspace, "vq_nearest: null pointer");
   TTTS_REQUIRE(N > 0 && K > 0 && D > 0 && D % 2 == 0 && D <= 256, "vq_nearest: need even D <= 256 (D=%d)", D);
   hipStream_t s = as_stream(stream);
-  float* e2 = reinterpret_cast<float*>(workspace);
+  const size_t smem = ((size_t)(VQ_ROWS + VQ_CODES) * (D + 1) + 8 * VQ_ROWS) * sizeof(float);
+  static const hipError_t attr = [] {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(vq_nearest_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return e != hipSuccess ? e : hipFuncSetAttribute(reinterpret_cast<const void*>(vq_nearest_slice_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }();
+  if (attr != hipSuccess) return fail(TTTS_EHIP, "vq_nearest: hipFuncSetAttribute: %s", hipGetErrorString(attr));
+  if (D % 4 == 0 && aligned16(x) && aligned16(codebook) && (!xq || aligned16(xq))) {
+    const int SL = (int)cdiv(K, VQ_SLICE);
+    float2* part = reinterpret_cast<float2*>(static_cast<char*>(workspace) + cdiv(K, 4) * 16 + 1024 * sizeof(double));
+    vq_nearest_slice_kernel<<<dim3((unsigned)cdiv(N, VQ_ROWS), (unsigned)SL), 256, smem, s>>>(x, codebook, part, N, K, D, SL);
+    int rc = check_launch("vq_nearest_slice");
+    if (rc) return rc;
+    vq_nearest_final_kernel<<<(int)cdiv(N, VQ_ROWS), 256, 0, s>>>(part, codebook, idx, xq, best_dist, N, D, SL);
+    return check_launch("vq_nearest_final");
+  }
+  float* e2 = reinterpret_cast<float*>(workspace);   // generic path (D % 4 != 0): first-generation kernel
   vq_code_norm_kernel<<<(int)cdiv(K, 256), 256, 0, s>>>(codebook, e2, K, D);
   int rc = check_launch("vq_code_norm");
   if (rc) return rc;
-  const size_t smem = ((size_t)(VQ_ROWS + VQ_CODES) * (D + 1) + 8 * VQ_ROWS) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(vq_nearest_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return fail(TTTS_EHIP, "vq_nearest: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
   vq_nearest_kernel<<<(int)cdiv(N, VQ_ROWS), 256, smem, s>>>(x, codebook, e2, idx, xq, best_dist, N, K, D);
   return check_launch("vq_nearest");
 }

@@ -115,7 +115,7 @@ SIGNATURES = {
     "ttts_vq_ema_update_f32": (_I32, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _F, _F, _P]),
     "ttts_stft_twiddle_host": (_I32, [_P, _I32]),
     "ttts_stft_mag_fwd_f32": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
-    "ttts_mel_log_fwd_f32": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "ttts_mel_log_fwd_f32": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "ttts_mel_log_bwd_f32": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "ttts_stft_mag_bwd_f32": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "ttts_groupnorm_fwd_f32": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _I32, _P]),

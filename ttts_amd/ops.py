@@ -538,13 +538,31 @@ def stft_filter_istft(wav, window, n_fft, hop, H=None, clamp=True, peak_normaliz
     return out
 
 
+_mel_bands = {}
+
+
+def mel_bands(basis):
+    """int32 [n_mels, 2] = first / last non-zero column of every basis row (cached per basis tensor; one host computation)."""
+    key = (basis.data_ptr(), tuple(basis.shape), basis._version)
+    if key not in _mel_bands:
+        nz = (basis != 0).cpu()
+        n_bins = basis.shape[1]
+        cols = torch.arange(n_bins)
+        lo = torch.where(nz, cols, torch.full_like(cols, n_bins)).min(dim=1).values
+        hi = torch.where(nz, cols, torch.full_like(cols, -1)).max(dim=1).values
+        _mel_bands.clear()
+        _mel_bands[key] = torch.stack([lo, hi], dim=1).to(torch.int32).contiguous().to(basis.device)
+    return _mel_bands[key]
+
+
 def mel_log(spec, basis):
     _req(spec, torch.float32, "spec"); _req(basis, torch.float32, "basis")
     spec = spec.contiguous(); basis = basis.contiguous()
     B, n_bins, frames = spec.shape
     n_mels = basis.shape[0]
     mel = torch.empty(B, n_mels, frames, dtype=torch.float32, device=spec.device)
-    check(_l.get().ttts_mel_log_fwd_f32(_p(spec), _p(basis), _p(mel), B, n_bins, n_mels, frames, _stream()), "mel_log")
+    check(_l.get().ttts_mel_log_fwd_f32(_p(spec), _p(basis), _p(mel_bands(basis)), _p(mel), B, n_bins, n_mels, frames, _stream()),
+          "mel_log")
     return mel
 
 
