@@ -207,6 +207,15 @@ __device__ __forceinline__ int xcd_tile(int bid, int nblk) {
 // (r >> 2) & 3 for 64-byte rows (BKT = 32): ds_read_b128 of a 16-lane service group then hits 64 distinct banks.
 // BKT = 64: 64 KB LDS, 2 workgroups per CU.  BKT = 32: 33.8 KB, 3 workgroups per CU -- their store phases and main
 // loops interleave instead of running in lock-step.
+// Round-2 measurements on this kernel (c_attn shape 9248 x 1536 x 512, 28.3 us = 514 TF/s; all variants parity-tested):
+//  * PMC: 25 % MFMA-busy, 44 % of wave cycles parked in s_waitcnt / barrier, 30 % issue stalls, 5.4 VALU per MFMA;
+//  * an LDS-DMA RING (3 or 4 stages, loads 2-3 k-steps ahead, counted vmcnt across raw s_barriers) does NOT help: 64-deep
+//    stages x 3 (96 KB, one workgroup per CU) 37.9 us; 32-deep x 3 (3 per CU) 30.3 us; 32-deep x 4 31.1 us -- deeper prefetch
+//    is not the limit, co-resident workgroups already cover the load latency;
+//  * ablation of the 2-stage loop: fill only (no ds_read / MFMA) + epilogue 22.7 us, MFMA only (no DMA) + epilogue 21.6 us,
+//    both 28.9 us, epilogue ~8 us: LDS fill (230 MB at ~15 TB/s) and compute (1.07 PF/s with its LDS reads) each need
+//    ~14 us and overlap only half.  The next step is fewer fill bytes per flop (256-row tiles) and a store phase that does
+//    not occupy the issuing waves -- see gemm_persist.hip for what a first attempt at the latter taught.
 template <int EPI, int BKT, int NJ = 2>
 __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_nt_glds_kernel(GemmNtParams p) {
   constexpr int BNT = 64 * NJ;           // tile columns: 128, or 64 for the narrow-N GEMMs
