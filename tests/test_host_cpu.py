@@ -330,3 +330,41 @@ def test_reference_import_names_and_signatures():
     import importlib.util
     for mod in ("ttts.gpt.train", "ttts.vqvae.train"):
         assert importlib.util.find_spec(mod) is not None
+
+
+def test_attention_dropout_product_scheme_statistics():
+    """numpy emulation of the attention keep-mask (csrc/attn.hip: row hash R, odd 24-bit column multiplier M with the top bit
+    set, keep iff (R[23:0] * M + R) mod 2^32 >= thr << 16): keep rate, 256-bin chi-square of the compared word, lag-1..8 row /
+    column correlations, the 2 x 2 interaction and per-row / per-column drop rates all at the level of independent draws."""
+    def hash32(x, lo, hi):
+        x = (np.uint32(x) ^ np.uint32(lo)) + np.uint32(hi)
+        x ^= x >> np.uint32(16)
+        x = ((x & np.uint32(0xFFFFFF)).astype(np.uint64) * np.uint64(0x9E3779) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        x ^= x >> np.uint32(15)
+        x = ((x & np.uint32(0xFFFFFF)).astype(np.uint64) * np.uint64(0x85EBCB) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        x ^= x >> np.uint32(16)
+        return x
+
+    def corr(a, b):
+        a = a - a.mean(); b = b - b.mean()
+        return float((a * b).mean() / np.sqrt((a * a).mean() * (b * b).mean()))
+    S, thr = 1156, 6554
+    ids = np.arange(S, dtype=np.uint32) + np.uint32(3 * S)              # (b*H + h)*S + position for some (b, h)
+    with np.errstate(over="ignore"):
+        for seed_lo, seed_hi in ((0x1234567, 0x89ABCDE), (7, 0xC0FFEE), (0xDEADBEEF, 1)):
+            R = hash32(ids, seed_lo, seed_hi).astype(np.uint64)
+            M = ((hash32(ids, seed_lo ^ 0x5BD1E995, seed_hi) & np.uint32(0xFFFFFF)) | np.uint32(0x800001)).astype(np.uint64)
+            word = ((R[:, None] & 0xFFFFFF) * M[None, :] + R[:, None]) & 0xFFFFFFFF
+            keep = word >= (thr << 16)
+            assert abs(keep.mean() - 0.9) < 2e-3
+            hist = np.bincount((word >> 24).ravel().astype(np.int64), minlength=256)
+            chi = float(((hist - word.size / 256) ** 2 / (word.size / 256)).sum())
+            assert chi < 400, chi                                        # 255 degrees of freedom
+            d = (~keep).astype(np.float64)
+            for lag in range(1, 9):
+                assert abs(corr(d[:, :-lag].ravel(), d[:, lag:].ravel())) < 5e-3
+                assert abs(corr(d[:-lag].ravel(), d[lag:].ravel())) < 5e-3
+            x = (keep[:-1, :-1] ^ keep[:-1, 1:]).astype(np.float64); y = (keep[1:, :-1] ^ keep[1:, 1:]).astype(np.float64)
+            assert abs(corr(x.ravel(), y.ravel())) < 5e-3
+            binom = np.sqrt(0.09 / S)
+            assert 0.8 * binom < d.mean(1).std() < 1.25 * binom and 0.8 * binom < d.mean(0).std() < 1.25 * binom

@@ -59,18 +59,27 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
-// keep-mask bit for attention element e = ((b*H + h)*S + query)*Sp + key: 16 random bits, two elements per hash
-__device__ __forceinline__ bool drop_keep(uint32_t e, uint32_t thr, uint32_t slo, uint32_t shi) {
-  const uint32_t r = hash32(e >> 1, slo, shi);
-  return ((e & 1u) ? (r >> 16) : (r & 0xFFFFu)) >= thr;
+// Attention dropout keep-mask (round 2): PRODUCT scheme.  Every query row gets one strong 32-bit hash R (of
+// (b*H + h)*S + query), every key column one odd 24-bit multiplier M with its top bit set (a hash of (b*H + h)*S + key under a
+// tweaked seed); the pair (query, key) is kept iff  (R[23:0] * M + R) mod 2^32  >=  thr << 16  -- one v_mad_u32_u24, one
+// compare, one select per score (the pair-shared counter hash of round 1 cost ~9 VALU per score: more cycles than the
+// tile's MFMAs).  For a fixed column the map R -> R*M is a bijection of the low 24 bits and wraps >= 2^15 times around 2^32, for
+// a fixed row the M are independent: keep rate, 256-bin chi-square, lag-1..8 row / column correlations, the 2 x 2
+// interaction and per-row / per-column rates are indistinguishable from independent Bernoulli draws in a numpy emulation
+// (tests/test_host_cpu.py::test_attention_dropout_product_scheme_statistics).  Both layouts evaluate it cheaply: the
+// lane-owned operand is hashed once per kernel, the other comes from a 64-entry LDS table filled once per tile.
+__device__ __forceinline__ uint32_t drop_row_hash(uint32_t rowid, uint32_t slo, uint32_t shi) { return hash32(rowid, slo, shi); }
+__device__ __forceinline__ uint32_t drop_col_mult(uint32_t colid, uint32_t slo, uint32_t shi) {
+  return (hash32(colid, slo ^ 0x5BD1E995u, shi) & 0xFFFFFFu) | 0x800001u;
 }
-// the same for four consecutive elements e0 .. e0+3 (e0 % 4 == 0): two hashes
-__device__ __forceinline__ void drop_keep4(uint32_t e0, uint32_t thr, uint32_t slo, uint32_t shi, bool (&k)[4]) {
-  const uint32_t r0 = hash32(e0 >> 1, slo, shi), r1 = hash32((e0 >> 1) + 1, slo, shi);
-  k[0] = (r0 & 0xFFFFu) >= thr;
-  k[1] = (r0 >> 16) >= thr;
-  k[2] = (r1 & 0xFFFFu) >= thr;
-  k[3] = (r1 >> 16) >= thr;
+__device__ __forceinline__ bool drop_keep(uint32_t rowh, uint32_t colm, uint32_t thr32) {
+  return __umul24(rowh, colm) + rowh >= thr32;      // v_mad_u32_u24 uses the low 24 bits of both factors
+}
+// lane = query layouts: four consecutive keys' multipliers from the tile table
+__device__ __forceinline__ void drop_keep4(uint32_t rowh, const uint32_t* colm4, uint32_t thr32, bool (&k)[4]) {
+  const u32x4_t m = *reinterpret_cast<const u32x4_t*>(colm4);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) k[e] = drop_keep(rowh, m[e], thr32);
 }
 
 // load / store a 64 x DH bf16 tile (rows row0.. of a [*, stride] matrix, zero beyond nrows)
@@ -100,6 +109,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   using C = AttnCfg<DH>;
   __shared__ __attribute__((aligned(16))) bf16 Ks[2][64 * C::KSTR];
   __shared__ __attribute__((aligned(16))) bf16 Vs[2][64 * C::VSTR];
+  __shared__ __attribute__((aligned(16))) uint32_t Bm[2][64];   // dropout column multipliers of the staged key tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, g = lane >> 4, ip = lane & 15;
   const int nqb = (p.S + 127) / 128;
@@ -133,11 +143,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   tile_load<DH>(rv, vp, p.ss, 0, p.S, tid);
   tile_store<DH, C::KSTR>(rk, Ks[0], tid);
   tile_store<DH, C::VSTR>(rv, Vs[0], tid);
+  const uint32_t shi = DROPOUT ? seed_mix(p.seed_hi, p.ctr) : 0u;
+  const uint32_t id_bh = (uint32_t)((b * p.H + h) * p.S), thr32 = p.thr << 16;
+  const uint32_t rowh = DROPOUT ? drop_row_hash(id_bh + (uint32_t)query, p.seed_lo, shi) : 0u;
+  if (DROPOUT && tid < 64) Bm[0][tid] = drop_col_mult(id_bh + (uint32_t)tid, p.seed_lo, shi);
   __syncthreads();
   const int k_nat = (lane & 31) * C::KSTR + hh * 8;
   const int v_tr = (4 * hh + (ip >> 2)) * C::VSTR + 16 * (g & 1) + 4 * (ip & 3);
-  const uint32_t e_row = (uint32_t)(((int64_t)(b * p.H + h) * p.S + query) * p.Sp);
-  const uint32_t shi = DROPOUT ? seed_mix(p.seed_hi, p.ctr) : 0u;
 
   for (int jt = 0; jt < nt; ++jt) {
     const int buf = jt & 1, kv0 = jt * 64;
@@ -188,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
           bool keep[4] = {true, true, true, true};
-          if (DROPOUT) drop_keep4(e_row + (uint32_t)(kv0 + kb * 32 + 8 * qd + 4 * hh), p.thr, p.seed_lo, shi, keep);
+          if (DROPOUT) drop_keep4(rowh, &Bm[buf][kb * 32 + 8 * qd + 4 * hh], thr32, keep);
           float pv[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -216,6 +228,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     if (jt + 1 < nt) {
       tile_store<DH, C::KSTR>(rk, Ks[buf ^ 1], tid);
       tile_store<DH, C::VSTR>(rv, Vs[buf ^ 1], tid);
+      if (DROPOUT && tid < 64) Bm[buf ^ 1][tid] = drop_col_mult(id_bh + (uint32_t)(kv0 + 64 + tid), p.seed_lo, shi);
     }
     __syncthreads();
   }
@@ -269,6 +282,7 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 3 : 1)) void attn_fwd_kv2_kernel(A
   extern __shared__ __attribute__((aligned(16))) unsigned char kv2_smem[];
   bf16* Ks = reinterpret_cast<bf16*>(kv2_smem);                 // [128][KSTR]
   bf16* Vs = Ks + 128 * C::KSTR;                                // [128][VSTR]
+  uint32_t* Bm = reinterpret_cast<uint32_t*>(Vs + 128 * C::VSTR);   // [128] dropout column multipliers of the super tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qh = wave & 1, kh = wave >> 1;
   const int hh = lane >> 5, g = lane >> 4, ip = lane & 15;
@@ -301,13 +315,15 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 3 : 1)) void attn_fwd_kv2_kernel(A
   tile_load_rows<DH, 128>(rv, vp, p.ss, 0, p.S, tid);
   const int k_nat = (lane & 31) * C::KSTR + hh * 8;
   const int v_tr = (4 * hh + (ip >> 2)) * C::VSTR + 16 * (g & 1) + 4 * (ip & 3);
-  const uint32_t e_row = (uint32_t)(((int64_t)(b * p.H + h) * p.S + query) * p.Sp);
   const uint32_t shi = DROPOUT ? seed_mix(p.seed_hi, p.ctr) : 0u;
+  const uint32_t id_bh = (uint32_t)((b * p.H + h) * p.S), thr32 = p.thr << 16;
+  const uint32_t rowh = DROPOUT ? drop_row_hash(id_bh + (uint32_t)query, p.seed_lo, shi) : 0u;
 
   for (int js = 0; js < nsup; ++js) {
     __syncthreads();                                            // every wave is done reading the previous super tile
     tile_store_rows<DH, 128, C::KSTR>(rk, Ks, tid);
     tile_store_rows<DH, 128, C::VSTR>(rv, Vs, tid);
+    if (DROPOUT && tid < 128) Bm[tid] = drop_col_mult(id_bh + (uint32_t)(js * 128 + tid), p.seed_lo, shi);
     __syncthreads();
     if (js + 1 < nsup) {                                        // next super tile's loads fly under this one's MFMAs
       tile_load_rows<DH, 128>(rk, kp, p.ss, (js + 1) * 128, p.S, tid);
@@ -359,7 +375,7 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 3 : 1)) void attn_fwd_kv2_kernel(A
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
           bool keep[4] = {true, true, true, true};
-          if (DROPOUT) drop_keep4(e_row + (uint32_t)(kv0 + kb * 32 + 8 * qd + 4 * hh), p.thr, p.seed_lo, shi, keep);
+          if (DROPOUT) drop_keep4(rowh, &Bm[kh * 64 + kb * 32 + 8 * qd + 4 * hh], thr32, keep);
           float pv[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -457,6 +473,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
   using C = AttnCfg<DH>;
   __shared__ __attribute__((aligned(16))) bf16 Ks[2][64 * C::KSTR];
   __shared__ __attribute__((aligned(16))) bf16 Vs[2][64 * C::KSTR];
+  __shared__ __attribute__((aligned(16))) uint32_t Bm[2][64];   // dropout column multipliers of the staged key tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, g = lane >> 4, ip = lane & 15;
   const int nqb = (p.S + 127) / 128;
@@ -493,11 +510,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
   tile_load<DH>(rv, vp, p.ss, 0, p.S, tid);
   tile_store<DH, C::KSTR>(rk, Ks[0], tid);
   tile_store<DH, C::KSTR>(rv, Vs[0], tid);
+  const uint32_t shi = DROPOUT ? seed_mix(p.seed_hi, p.ctr) : 0u;
+  const uint32_t id_bh = (uint32_t)((b * p.H + h) * p.S), thr32 = p.thr << 16;
+  const uint32_t rowh = DROPOUT ? drop_row_hash(id_bh + (uint32_t)query, p.seed_lo, shi) : 0u;
+  if (DROPOUT && tid < 64) Bm[0][tid] = drop_col_mult(id_bh + (uint32_t)tid, p.seed_lo, shi);
   __syncthreads();
   const int k_nat = (lane & 31) * C::KSTR + hh * 8;
   const int k_tr = (4 * hh + (ip >> 2)) * C::KSTR + 16 * (g & 1) + 4 * (ip & 3);
-  const uint32_t e_row = (uint32_t)(((int64_t)(b * p.H + h) * p.S + query) * p.Sp);
-  const uint32_t shi = DROPOUT ? seed_mix(p.seed_hi, p.ctr) : 0u;
 
   for (int jt = 0; jt < nt; ++jt) {
     const int buf = jt & 1, kv0 = jt * 64;
@@ -523,7 +542,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
           bool keep[4] = {true, true, true, true};
-          if (DROPOUT) drop_keep4(e_row + (uint32_t)(kv0 + kb * 32 + 8 * qd + 4 * hh), p.thr, p.seed_lo, shi, keep);
+          if (DROPOUT) drop_keep4(rowh, &Bm[buf][kb * 32 + 8 * qd + 4 * hh], thr32, keep);
           float ds[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -554,6 +573,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
     if (jt + 1 < nt) {
       tile_store<DH, C::KSTR>(rk, Ks[buf ^ 1], tid);
       tile_store<DH, C::KSTR>(rv, Vs[buf ^ 1], tid);
+      if (DROPOUT && tid < 64) Bm[buf ^ 1][tid] = drop_col_mult(id_bh + (uint32_t)(kv0 + 64 + tid), p.seed_lo, shi);
     }
     __syncthreads();
   }
@@ -581,6 +601,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) bf16 Ds[2][64 * C::KSTR];
   __shared__ __attribute__((aligned(16))) float Ls[2][64];
   __shared__ __attribute__((aligned(16))) float Dl[2][64];
+  __shared__ __attribute__((aligned(16))) uint32_t Am[2][64];   // dropout row hashes of the staged query tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, g = lane >> 4, ip = lane & 15;
   const int nkb = (p.S + 127) / 128;
@@ -618,26 +639,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
     const int qi = (q0) + (tid & 63);                                                    \
     if (tid < 128) rstat = qi < p.S ? (tid < 64 ? lsep[qi] * LOG2E : delp[qi]) : 0.f;    \
   }
-#define STORE_STATS(buf)                           \
-  {                                                \
-    if (tid < 64) Ls[buf][tid] = rstat;            \
-    else if (tid < 128) Dl[buf][tid - 64] = rstat; \
+#define STORE_STATS(buf, q0_)                                                                                         \
+  {                                                                                                                  \
+    if (tid < 64) Ls[buf][tid] = rstat;                                                                              \
+    else if (tid < 128) Dl[buf][tid - 64] = rstat;                                                                   \
+    else if (DROPOUT && tid < 192) Am[buf][tid - 128] = drop_row_hash(id_bh + (uint32_t)((q0_) + tid - 128), p.seed_lo, shi); \
   }
+  const uint32_t shi = DROPOUT ? seed_mix(p.seed_hi, p.ctr) : 0u;
+  const uint32_t id_bh = (uint32_t)((b * p.H + h) * p.S), thr32 = p.thr << 16;
+  const uint32_t colm = DROPOUT ? drop_col_mult(id_bh + (uint32_t)key, p.seed_lo, shi) : 0u;
   tile_load<DH>(rq, qp, p.ss, qt0 * 64, p.S, tid);
   tile_load<DH>(rd, dop, p.oss, qt0 * 64, p.S, tid);
   LOAD_STATS(qt0 * 64)
   tile_store<DH, C::KSTR>(rq, Qs[0], tid);
   tile_store<DH, C::KSTR>(rd, Ds[0], tid);
-  STORE_STATS(0)
+  STORE_STATS(0, qt0 * 64)
   __syncthreads();
   const int q_nat = (lane & 31) * C::KSTR + hh * 8;
   const int q_tr = (4 * hh + (ip >> 2)) * C::KSTR + 16 * (g & 1) + 4 * (ip & 3);
-  const uint32_t e_bh = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((int64_t)(b * p.H + h) * p.S));   // uniform: keep it scalar
-  // mask index of (query, key) = (e_bh + query) * Sp + key (mod 2^32), split so that no 32-bit multiply (quarter rate) is left
-  // in the tile loop: lane part once, tile part on the scalar unit, row part through 24-bit multiplies of small constants
-  const uint32_t e_lane = __umul24((uint32_t)(4 * hh + (lane & 1)), (uint32_t)p.Sp) + (uint32_t)key;
-  const uint32_t shi = DROPOUT ? seed_mix(p.seed_hi, p.ctr) : 0u;
-
   for (int qt = qt0; qt < nqt; ++qt) {
     const int buf = (qt - qt0) & 1, q0 = qt * 64;
     if (qt + 1 < nqt) {
@@ -664,21 +683,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
         for (int qd = 0; qd < 4; ++qd) {
           const f32x4 l4 = *reinterpret_cast<const f32x4*>(&Ls[buf][qs * 32 + 8 * qd + 4 * hh]);
           const f32x4 d4 = *reinterpret_cast<const f32x4*>(&Dl[buf][qs * 32 + 8 * qd + 4 * hh]);
-          // dropout bits: the elements (query, key) and (query, key ^ 1) share one 32-bit hash (Sp is even), i.e. the two
-          // lanes of a pair need the same 4 hashes for the 4 rows of this group: each computes two and they swap by DPP
           bool keep4[4] = {true, true, true, true};
-          if (DROPOUT) {
-            const int odd = lane & 1;
+          if (DROPOUT) {                   // product scheme: this lane's column multiplier x the four rows' hashes from the tile table
+            const u32x4_t rh = *reinterpret_cast<const u32x4_t*>(&Am[buf][qs * 32 + 8 * qd + 4 * hh]);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-              // row q0 + qs*32 + 8*qd + 4*hh + 2*t + odd (even lane: row 2t, odd lane: row 2t+1)
-              const uint32_t e_tile = (e_bh + (uint32_t)(q0 + qs * 32)) * (uint32_t)p.Sp;                  // wave-uniform
-              const uint32_t mine = hash32((e_tile + __umul24((uint32_t)(8 * qd + 2 * t), (uint32_t)p.Sp) + e_lane) >> 1, p.seed_lo, shi);
-              const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
-              const uint32_t h0 = odd ? other : mine, h1 = odd ? mine : other;   // hashes of rows 2t and 2t+1
-              keep4[2 * t] = (odd ? (h0 >> 16) : (h0 & 0xFFFFu)) >= p.thr;
-              keep4[2 * t + 1] = (odd ? (h1 >> 16) : (h1 & 0xFFFFu)) >= p.thr;
-            }
+            for (int e = 0; e < 4; ++e) keep4[e] = drop_keep(rh[e], colm, thr32);
           }
           float pd[4], ds[4];
 #pragma unroll
@@ -718,7 +727,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
     if (qt + 1 < nqt) {
       tile_store<DH, C::KSTR>(rq, Qs[buf ^ 1], tid);
       tile_store<DH, C::KSTR>(rd, Ds[buf ^ 1], tid);
-      STORE_STATS(buf ^ 1)
+      STORE_STATS(buf ^ 1, q0 + 64)
     }
     __syncthreads();
   }
@@ -748,7 +757,8 @@ __global__ __launch_bounds__(256) void attn_dropout_mask_kernel(uint8_t* mask, i
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t row = i / S;  // (b*H + h)*S + query
     const int key = (int)(i % S);
-    mask[i] = thr == 0 ? 1 : (drop_keep((uint32_t)(row * Sp + key), thr, slo, shi) ? 1 : 0);
+    const uint32_t colid = (uint32_t)((row / S) * S + key);   // (b*H + h)*S + key
+    mask[i] = thr == 0 ? 1 : (drop_keep(drop_row_hash((uint32_t)row, slo, shi), drop_col_mult(colid, slo, shi), thr << 16) ? 1 : 0);
   }
 }
 
@@ -759,7 +769,7 @@ static int fill_params(AttnParams& p, int B, int H, int S, int head_dim, int64_t
   TTTS_REQUIRE(ss % 8 == 0 && sb % 8 == 0 && oss % 8 == 0 && osb % 8 == 0, "attn: strides must be multiples of 8 elements");
   TTTS_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "attn: dropout_p out of range");
   p.Sp = (S + 3) & ~3;
-  TTTS_REQUIRE((int64_t)B * H * S * p.Sp < (int64_t)1 << 32 || dropout_p == 0.f, "attn: dropout index space exceeds 2^32");
+  TTTS_REQUIRE((int64_t)B * H * S < (int64_t)1 << 32 || dropout_p == 0.f, "attn: dropout row-id space exceeds 2^32");
   p.B = B; p.H = H; p.S = S;
   p.sb = sb; p.ss = ss; p.osb = osb; p.oss = oss;
   p.scale = scale;
@@ -788,15 +798,16 @@ extern "C" int ttts_attn_causal_fwd_bf16(const void* q, const void* k, const voi
   p.q = (const bf16*)q; p.k = (const bf16*)k; p.v = (const bf16*)v; p.out = (bf16*)o; p.lse = lse;
   const int grid = ((S + 127) / 128) * H * B;
   hipStream_t s = as_stream(stream);
-  // work split: with dropout the 64-query x 128-key kernel wins (36.1 vs 43.8 us at the BASELINE shape: the longest block is half
-  // as long); without dropout the two are equal (31.2 vs 30.4 us) and the 128-query kernel stays.
+  // work split: with dropout the 64-query x 128-key kernel is used (round 1, pair-hash mask: 36.1 vs 43.8 us at the BASELINE shape;
+  // round 2, product-scheme mask: 35.5 vs 36.0 us -- the cheaper mask closed the gap); without dropout the 128-query kernel
+  // (30.3 vs 33.8 us).
   const bool use_kv2 = p.thr != 0;
   if (use_kv2) {
     const int grid2 = ((S + 63) / 64) * H * B;
 #define FWD2(DH)                                                                                                         \
     {                                                                                                                    \
       using C2 = AttnCfg<DH>;                                                                                            \
-      const size_t smem = (size_t)128 * (C2::KSTR + C2::VSTR) * sizeof(bf16);                                            \
+      const size_t smem = (size_t)128 * (C2::KSTR + C2::VSTR) * sizeof(bf16) + 128 * sizeof(uint32_t);                    \
       static bool attr_set = false;                                                                                      \
       if (!attr_set) {                                                                                                   \
         hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kv2_kernel<DH, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
