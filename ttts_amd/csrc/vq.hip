@@ -120,7 +120,8 @@ __global__ __launch_bounds__(256) void vq_nearest_kernel(const float* __restrict
 //     lowest index, as before) and gathers the winning code rows.
 // The arithmetic per (row, code) pair is unchanged: one k-ordered fmaf chain on v_mfma_f32_32x32x2_f32, then
 // -((|x|^2 - 2 dot) + |e|^2) in that expression order, so indices AND distances stay bit-exact (tests/test_gpu_kernels.py).
-constexpr int VQ_SLICE = 256;  // codes per workgroup (two LDS chunks of VQ_CODES)
+constexpr int VQ_SLICE = 256;  // codes per workgroup: two 32-code tiles per wave (128: same 38 us -- the code loads are not what bounds it;
+                               // note hipcc waits vmcnt(0) at the first use of a prefetched group, so the in-wave prefetch overlaps little)
 
 __device__ __forceinline__ void vq_stage_rows(float* dst, int LD, const float* __restrict__ src, int row0, int nrows_valid,
                                               int rows, int D4, int wave, int lane) {
@@ -144,46 +145,69 @@ __device__ __forceinline__ void vq_stage_rows(float* dst, int LD, const float* _
   }
 }
 
+// Third step (round 2): the codes never touch LDS.  A lane of the A operand needs e[code = lane & 31][d + hh] for even d -- its
+// own code row, every other element -- so each lane streams ITS row with 16-byte global loads (lanes l and l + 32 fetch the same
+// row; a 32-code tile is 24 KB and stays L1-resident), eight loads in flight while the previous eight feed the MFMAs, and the
+// |e|^2 chain runs on the same registers.  No barrier after the one that publishes the x tile: the four waves of a workgroup
+// (and the 2 workgroups per CU) overlap freely.  52 -> ~25 us at the BASELINE search.
 __global__ __launch_bounds__(256) void vq_nearest_slice_kernel(const float* __restrict__ x, const float* __restrict__ cb,
                                                                float2* __restrict__ part, int N, int K, int D, int SL) {
   extern __shared__ __attribute__((aligned(16))) float vq_smem[];
   const int LD = D + 1, D4 = D >> 2;
   float* xs = vq_smem;                       // [VQ_ROWS][LD]
-  float* es = xs + VQ_ROWS * LD;             // [VQ_CODES][LD]
-  float* red_d = es + VQ_CODES * LD;         // [4][VQ_ROWS]
+  float* red_d = xs + VQ_ROWS * LD;          // [4][VQ_ROWS]
   int* red_i = reinterpret_cast<int*>(red_d + 4 * VQ_ROWS);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
   const int r0 = blockIdx.x * VQ_ROWS, sl = blockIdx.y, cs0 = sl * VQ_SLICE;
   vq_stage_rows(xs, LD, x, r0, N - r0, VQ_ROWS, D4, wave, lane);
+  __syncthreads();
+  const float* xrow = xs + (lane & 31) * LD;
+  float x2 = 0.f;
+  for (int d = 0; d < D; ++d) x2 = fmaf(xrow[d], xrow[d], x2);
   float best = -INFINITY;
   int best_i = 0;
-  float x2 = 0.f;
-  const float* xrow = xs + (lane & 31) * LD;
-  for (int c0 = cs0; c0 < min(K, cs0 + VQ_SLICE); c0 += VQ_CODES) {
-    __syncthreads();                           // previous chunk consumed (first pass: nothing pending)
-    vq_stage_rows(es, LD, cb, c0, K - c0, VQ_CODES, D4, wave, lane);
-    __syncthreads();
-    if (c0 == cs0)
-      for (int d = 0; d < D; ++d) x2 = fmaf(xrow[d], xrow[d], x2);
-    const int cw = c0 + wave * 32;             // this wave's 32 codes
-    if (cw < K) {
-      const float* erow = es + (wave * 32 + (lane & 31)) * LD;
-      float e2 = 0.f;                          // |e|^2 of code cw + (lane & 31): the k-ordered chain every row uses
-      for (int d = 0; d < D; ++d) e2 = fmaf(erow[d], erow[d], e2);
-      f32x16 acc;
+  for (int t = 0; t < VQ_SLICE / 128; ++t) {   // this wave's tiles: codes cs0 + t * 128 + wave * 32 + 0..31
+    const int cw = cs0 + t * 128 + wave * 32;
+    if (cw >= K) break;                        // wave-uniform
+    const int code_l = min(cw + (lane & 31), K - 1);                 // (clamped: rows beyond K are computed and ignored)
+    const float4* erow = reinterpret_cast<const float4*>(cb + (int64_t)code_l * D);
+    f32x16 acc;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      for (int d = 0; d < D; d += 2)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(erow[d + hh], xrow[d + hh], acc, 0, 0, 0);
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float e2 = 0.f;                            // |e|^2 of this lane's code: the k-ordered chain every row uses
+    float4 cur[8], nxt[8];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int cl = acc_row(r, hh);         // code inside the tile: its |e|^2 lives in lane cl (either half)
-        const float e2c = __shfl(e2, cl, 64);
-        const int code = cw + cl;
-        if (code < K) {
-          const float dist = -((x2 - 2.0f * acc[r]) + e2c);
-          if (dist > best) { best = dist; best_i = code; }
+    for (int j = 0; j < 8; ++j) cur[j] = (j < D4) ? erow[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j0 = 0; j0 < D4; j0 += 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) nxt[j] = (j0 + 8 + j < D4) ? erow[j0 + 8 + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      float xa[8], xb[8];                      // this group's 16 x operands up front: their LDS latency must not sit between MFMAs
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int d = min(j0 + j, D4 - 1) * 4;
+        xa[j] = xrow[d + hh];
+        xb[j] = xrow[d + 2 + hh];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (j0 + j < D4) {                     // (D4 % 8 != 0: the last group is partial)
+          const float4 v = cur[j];
+          e2 = fmaf(v.x, v.x, e2); e2 = fmaf(v.y, v.y, e2); e2 = fmaf(v.z, v.z, e2); e2 = fmaf(v.w, v.w, e2);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hh ? v.y : v.x, xa[j], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hh ? v.w : v.z, xb[j], acc, 0, 0, 0);
         }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cur[j] = nxt[j];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int cl = acc_row(r, hh);           // code inside the tile: its |e|^2 lives in lane cl (either half)
+      const float e2c = __shfl(e2, cl, 64);
+      const int code = cw + cl;
+      if (code < K) {
+        const float dist = -((x2 - 2.0f * acc[r]) + e2c);
+        if (dist > best) { best = dist; best_i = code; }
       }
     }
   }
@@ -347,7 +371,8 @@ extern "C" int ttts_vq_nearest_f32(const float* x, const float* codebook, int64_
   if (D % 4 == 0 && aligned16(x) && aligned16(codebook) && (!xq || aligned16(xq))) {
     const int SL = (int)cdiv(K, VQ_SLICE);
     float2* part = reinterpret_cast<float2*>(static_cast<char*>(workspace) + cdiv(K, 4) * 16 + 1024 * sizeof(double));
-    vq_nearest_slice_kernel<<<dim3((unsigned)cdiv(N, VQ_ROWS), (unsigned)SL), 256, smem, s>>>(x, codebook, part, N, K, D, SL);
+    const size_t smem_x = ((size_t)VQ_ROWS * (D + 1) + 8 * VQ_ROWS) * sizeof(float);
+    vq_nearest_slice_kernel<<<dim3((unsigned)cdiv(N, VQ_ROWS), (unsigned)SL), 256, smem_x, s>>>(x, codebook, part, N, K, D, SL);
     int rc = check_launch("vq_nearest_slice");
     if (rc) return rc;
     vq_nearest_final_kernel<<<(int)cdiv(N, VQ_ROWS), 256, 0, s>>>(part, codebook, idx, xq, best_dist, N, D, SL);
