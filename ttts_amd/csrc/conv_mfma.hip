@@ -39,7 +39,8 @@ struct ConvMfmaParams {
   int out_act; float out_slope, out_scale; int accumulate;
   // split-bf16 path: weights pre-split into hi / lo bf16 in [N/16 blocks][Mpad][K][16] order (conv_weight_split_kernel)
   const bf16* a_hi; const bf16* a_lo; int Mpad;
-  const bf16* x_hi; const bf16* x_lo;   // pre-split input [B][N/16 blocks][Lin][16] (conv_input_split_kernel)
+  const bf16* x_hi; const bf16* x_lo;   // pre-split, zero-padded input [B][N/16 blocks][2 channel halves][Lp][8] (conv_input_split_kernel)
+  int Lp, PADL;        // padded row length of the pre-split input; element i of a row holds position i - PADL
 };
 
 
@@ -169,37 +170,44 @@ __global__ __launch_bounds__(64 * NW) void conv1d_mfma_kernel(ConvMfmaParams p) 
 // plain 16-byte copies (PMC before this pass: 12 VALU instructions per MFMA, mostly fp32 -> bf16 splitting, and VALU time
 // above MFMA time)
 __global__ __launch_bounds__(256) void conv_input_split_kernel(const float* __restrict__ x, bf16* __restrict__ hi,
-                                                               bf16* __restrict__ lo, int B, int N, int L, int nblk, float slope) {
-  const int64_t total = (int64_t)B * nblk * L;
+                                                               bf16* __restrict__ lo, int B, int N, int L, int nblk, float slope,
+                                                               int Lp, int PADL) {
+  // one thread per (batch element, 16-channel block, padded position): 16 coalesced row reads, four 16-byte stores
+  const int64_t total = (int64_t)B * nblk * Lp;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int pos = (int)(i % L), nb = (int)((i / L) % nblk);
-    const int64_t b = i / L / nblk;
+    const int pp = (int)(i % Lp), nb = (int)((i / Lp) % nblk), pos = pp - PADL;
+    const int64_t b = i / Lp / nblk;
+    const bool inside = pos >= 0 && pos < L;
     const float* xr = x + (b * N + nb * 16) * L + pos;
     bf16x8 h0, h1, l0, l1;
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
-      float v = nb * 16 + c < N ? xr[(int64_t)c * L] : 0.f;
+      float v = (inside && nb * 16 + c < N) ? xr[(int64_t)c * L] : 0.f;
       v = lrelu_f(v, slope);
       const bf16 hv = (bf16)v;
       const bf16 lv = (bf16)(v - (float)hv);
       if (c < 8) { h0[c] = hv; l0[c] = lv; } else { h1[c - 8] = hv; l1[c - 8] = lv; }
     }
-    *reinterpret_cast<bf16x8*>(hi + i * 16) = h0;
-    *reinterpret_cast<bf16x8*>(hi + i * 16 + 8) = h1;
-    *reinterpret_cast<bf16x8*>(lo + i * 16) = l0;
-    *reinterpret_cast<bf16x8*>(lo + i * 16 + 8) = l1;
+    const int64_t o = (((b * nblk + nb) * 2) * Lp + pp) * 8;        // half 0; half 1 is Lp * 8 elements further
+    *reinterpret_cast<bf16x8*>(hi + o) = h0;
+    *reinterpret_cast<bf16x8*>(hi + o + (int64_t)Lp * 8) = h1;
+    *reinterpret_cast<bf16x8*>(lo + o) = l0;
+    *reinterpret_cast<bf16x8*>(lo + o + (int64_t)Lp * 8) = l1;
   }
 }
 
 __global__ __launch_bounds__(256) void conv_weight_split_kernel(const float* __restrict__ w, bf16* __restrict__ a_hi,
                                                                 bf16* __restrict__ a_lo, int M, int N, int Mpad, int nblk,
-                                                                int K, int Kmem, int transposed, int tap_off, int tap_stride) {
-  const int64_t total = (int64_t)nblk * Mpad * K * 16;
+                                                                int K, int Kmem, int transposed, int tap_off, int tap_stride, int AP) {
+  // rows of AP >= K*16 elements ([tap][16 channels], zero tail): AP = K*16 + 8 is the LDS row pitch of the DMA-fed kernel,
+  // whose stages are verbatim copies of [MT rows][AP] runs of these arrays
+  const int64_t total = (int64_t)nblk * Mpad * AP;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int c = (int)(i & 15), k = (int)((i >> 4) % K), m = (int)((i >> 4) / K % Mpad), nb = (int)((i >> 4) / K / Mpad);
+    const int e = (int)(i % AP), m = (int)(i / AP % Mpad), nb = (int)(i / AP / Mpad);
+    const int c = e & 15, k = e >> 4;
     const int n = nb * 16 + c;
     float v = 0.f;
-    if (m < M && n < N) {
+    if (k < K && m < M && n < N) {
       // forward: A[m][k][n] = w[m][n][k];  data gradient: A[m][k][n] = w[n][m][tap_off + tap_stride * (K - 1 - k)]
       v = transposed ? w[((int64_t)n * M + m) * Kmem + tap_off + tap_stride * (K - 1 - k)] : w[((int64_t)m * N + n) * Kmem + k];
     }
@@ -209,96 +217,10 @@ __global__ __launch_bounds__(256) void conv_weight_split_kernel(const float* __r
   }
 }
 
+// fused epilogue of the split-bf16 kernels: two 32 x 32 accumulators of a wave (positions wl*64 + {0, 32} + col)
 template <int WCO>
-__global__ __launch_bounds__(256) void conv1d_bf16x3_kernel(ConvMfmaParams p) {
-  constexpr int MT = 32 * WCO, WL = 4 / WCO, LT = 64 * WL;
-  extern __shared__ __attribute__((aligned(16))) float cm_smem[];
-  const int K = p.K, SEG = p.SEG, nseg = LT / SEG;
-  const int lin_s = (SEG - 1) * p.stride + (K - 1) * p.dil + 1, lin_t = nseg * lin_s;
-  const int apitch = K * 16 + 8;                      // bf16 elements per weight row (+8: spreads rows over the banks)
-  bf16* xh = reinterpret_cast<bf16*>(cm_smem);        // [lin_t][16]
-  bf16* xl = xh + lin_t * 16;
-  bf16* ah = xl + lin_t * 16;                         // [MT][apitch]
-  bf16* al = ah + MT * apitch;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, col = lane & 31;
-  const int wco = wave % WCO, wl = wave / WCO;
-  const int j0 = blockIdx.x * LT, m0 = blockIdx.y * MT, b0 = blockIdx.z * nseg;
-  const int in0 = j0 * p.stride - p.pad;
-  f32x16 acc0, acc1;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-  const int c0 = wl * 64 + col, c1 = c0 + 32;
-  const int bpos0 = ((c0 / SEG) * lin_s + (c0 % SEG) * p.stride) * 16 + hh * 8;
-  const int bpos1 = ((c1 / SEG) * lin_s + (c1 % SEG) * p.stride) * 16 + hh * 8;
-  const int arow = (wco * 32 + col) * apitch + hh * 8;
-  const int nblk = (p.N + 15) / 16;
-  const int64_t slab = (int64_t)p.Mpad * K * 16;      // elements per channel block of the split weights
-  for (int nb = 0; nb < nblk; ++nb) {
-    __syncthreads();
-    if (p.x_hi) {
-      // input strip: 16-byte copies of the pre-split records (two per position and half), zero outside the row
-      for (int q = tid; q < lin_t * 2; q += 256) {
-        const int pp = q >> 1, half = q & 1;
-        const int sg = pp / lin_s, pos = pp - sg * lin_s, gi = in0 + pos;
-        bf16x8 vh = zero8(), vl = zero8();
-        if (b0 + sg < p.B && gi >= 0 && gi < p.Lin) {
-          const int64_t o = ((((int64_t)(b0 + sg) * nblk + nb) * p.Lin + gi) * 16) + half * 8;
-          vh = *reinterpret_cast<const bf16x8*>(p.x_hi + o);
-          vl = *reinterpret_cast<const bf16x8*>(p.x_lo + o);
-        }
-        *reinterpret_cast<bf16x8*>(xh + pp * 16 + half * 8) = vh;
-        *reinterpret_cast<bf16x8*>(xl + pp * 16 + half * 8) = vl;
-      }
-    } else {
-      // few output-channel tiles: split on the fly -- one thread per position, 16 channels each (coalesced row segments)
-      for (int pp = tid; pp < lin_t; pp += 256) {
-        const int sg = pp / lin_s, pos = pp - sg * lin_s, gi = in0 + pos;
-        const bool ok = b0 + sg < p.B && gi >= 0 && gi < p.Lin;
-        const float* xr = p.x + ((int64_t)(b0 + sg) * p.N + nb * 16) * p.Lin + gi;
-        bf16x8 h0, h1, l0, l1;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          float v = (ok && nb * 16 + c < p.N) ? xr[(int64_t)c * p.Lin] : 0.f;
-          v = lrelu_f(v, p.in_slope);
-          const bf16 hv = (bf16)v;
-          const bf16 lv = (bf16)(v - (float)hv);
-          if (c < 8) { h0[c] = hv; l0[c] = lv; } else { h1[c - 8] = hv; l1[c - 8] = lv; }
-        }
-        *reinterpret_cast<bf16x8*>(xh + pp * 16) = h0;
-        *reinterpret_cast<bf16x8*>(xh + pp * 16 + 8) = h1;
-        *reinterpret_cast<bf16x8*>(xl + pp * 16) = l0;
-        *reinterpret_cast<bf16x8*>(xl + pp * 16 + 8) = l1;
-      }
-    }
-    // weights: the stage's [MT][K][16] slab is contiguous in the split arrays; 16-byte chunks
-    {
-      const bf16* gh = p.a_hi + nb * slab + (int64_t)m0 * K * 16;
-      const bf16* gl = p.a_lo + nb * slab + (int64_t)m0 * K * 16;
-      const int chunks = MT * K * 2;
-      for (int ch = tid; ch < chunks; ch += 256) {
-        const int m = ch / (K * 2), r = ch - m * (K * 2);
-        *reinterpret_cast<bf16x8*>(ah + m * apitch + r * 8) = *reinterpret_cast<const bf16x8*>(gh + (int64_t)ch * 8);
-        *reinterpret_cast<bf16x8*>(al + m * apitch + r * 8) = *reinterpret_cast<const bf16x8*>(gl + (int64_t)ch * 8);
-      }
-    }
-    __syncthreads();
-#pragma unroll 2
-    for (int k = 0; k < K; ++k) {
-      const bf16x8 a_h = *reinterpret_cast<const bf16x8*>(ah + arow + k * 16);
-      const bf16x8 a_l = *reinterpret_cast<const bf16x8*>(al + arow + k * 16);
-      const int ko = k * p.dil * 16;
-      const bf16x8 b0h = *reinterpret_cast<const bf16x8*>(xh + bpos0 + ko);
-      const bf16x8 b0l = *reinterpret_cast<const bf16x8*>(xl + bpos0 + ko);
-      const bf16x8 b1h = *reinterpret_cast<const bf16x8*>(xh + bpos1 + ko);
-      const bf16x8 b1l = *reinterpret_cast<const bf16x8*>(xl + bpos1 + ko);
-      acc0 = mfma32(a_l, b0h, acc0);
-      acc1 = mfma32(a_l, b1h, acc1);
-      acc0 = mfma32(a_h, b0l, acc0);
-      acc1 = mfma32(a_h, b1l, acc1);
-      acc0 = mfma32(a_h, b0h, acc0);
-      acc1 = mfma32(a_h, b1h, acc1);
-    }
-  }
+__device__ __forceinline__ void conv_tile_epilogue(const ConvMfmaParams& p, const f32x16& acc0, const f32x16& acc1, int wl,
+                                                   int wco, int col, int hh, int j0, int m0, int b0, int SEG) {
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int ct = wl * 64 + t * 32 + col;
@@ -321,6 +243,198 @@ __global__ __launch_bounds__(256) void conv1d_bf16x3_kernel(ConvMfmaParams p) {
       p.y[o] = p.accumulate ? p.y[o] + v : v;
     }
   }
+}
+
+// Variant 1: the input is split ON THE FLY while it is staged (few output-channel tiles re-read it: the 16..128-channel
+// long-row layers, where a separate split pass would cost more HBM traffic than it saves).  Single LDS stage; overlap comes
+// from several workgroups per CU.
+template <int WCO>
+__global__ __launch_bounds__(256) void conv1d_bf16x3_kernel(ConvMfmaParams p) {
+  constexpr int MT = 32 * WCO, WL = 4 / WCO, LT = 64 * WL;
+  extern __shared__ __attribute__((aligned(16))) float cm_smem[];
+  const int K = p.K, SEG = p.SEG, nseg = LT / SEG;
+  const int lin_s = (SEG - 1) * p.stride + (K - 1) * p.dil + 1, lin_t = nseg * lin_s;
+  const int apitch = K * 16 + 8;                      // bf16 elements per weight row (+8: spreads rows over the banks)
+  // input strip, hi and lo: [2 channel halves][lin_t positions][8 channels].  A lane's 16-byte B fragment is (its position,
+  // its channel half = lane >> 5), so the 16 lanes of a ds_read_b128 group read 16 consecutive positions of ONE half: 16
+  // distinct 16-byte slots, conflict-free for stride 1 and 3 (the position-major [pos][16 ch] records this replaces put a
+  // group on 8 slots: 2-way conflicts on four of the six fragment reads per k-step, PMC: SQ_LDS_BANK_CONFLICT 1.56x
+  // SQ_ACTIVE_INST_LDS, and the loop is LDS-bound)
+  bf16* xh = reinterpret_cast<bf16*>(cm_smem);        // [2][lin_t][8]
+  bf16* xl = xh + lin_t * 16;
+  const int xhalf = lin_t * 8;
+  bf16* ah = xl + lin_t * 16;                         // [MT][apitch]
+  bf16* al = ah + MT * apitch;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, col = lane & 31;
+  const int wco = wave % WCO, wl = wave / WCO;
+  const int j0 = blockIdx.x * LT, m0 = blockIdx.y * MT, b0 = blockIdx.z * nseg;
+  const int in0 = j0 * p.stride - p.pad;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+  const int c0 = wl * 64 + col, c1 = c0 + 32;
+  const int bpos0 = ((c0 / SEG) * lin_s + (c0 % SEG) * p.stride) * 8 + hh * xhalf;
+  const int bpos1 = ((c1 / SEG) * lin_s + (c1 % SEG) * p.stride) * 8 + hh * xhalf;
+  const int arow = (wco * 32 + col) * apitch + hh * 8;
+  const int nblk = (p.N + 15) / 16;
+  const int64_t slab = (int64_t)p.Mpad * K * 16;      // elements per channel block of the split weights
+  for (int nb = 0; nb < nblk; ++nb) {
+    __syncthreads();
+    // one thread per position, 16 channels each (coalesced row segments)
+    for (int pp = tid; pp < lin_t; pp += 256) {
+      const int sg = pp / lin_s, pos = pp - sg * lin_s, gi = in0 + pos;
+      const bool ok = b0 + sg < p.B && gi >= 0 && gi < p.Lin;
+      const float* xr = p.x + ((int64_t)(b0 + sg) * p.N + nb * 16) * p.Lin + gi;
+      bf16x8 h0, h1, l0, l1;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        float v = (ok && nb * 16 + c < p.N) ? xr[(int64_t)c * p.Lin] : 0.f;
+        v = lrelu_f(v, p.in_slope);
+        const bf16 hv = (bf16)v;
+        const bf16 lv = (bf16)(v - (float)hv);
+        if (c < 8) { h0[c] = hv; l0[c] = lv; } else { h1[c - 8] = hv; l1[c - 8] = lv; }
+      }
+      *reinterpret_cast<bf16x8*>(xh + pp * 8) = h0;
+      *reinterpret_cast<bf16x8*>(xh + xhalf + pp * 8) = h1;
+      *reinterpret_cast<bf16x8*>(xl + pp * 8) = l0;
+      *reinterpret_cast<bf16x8*>(xl + xhalf + pp * 8) = l1;
+    }
+    // weights: the stage's [MT][K][16] slab is contiguous in the split arrays; 16-byte chunks
+    {
+      const bf16* gh = p.a_hi + nb * slab + (int64_t)m0 * K * 16;
+      const bf16* gl = p.a_lo + nb * slab + (int64_t)m0 * K * 16;
+      const int chunks = MT * K * 2;
+      for (int ch = tid; ch < chunks; ch += 256) {
+        const int m = ch / (K * 2), r = ch - m * (K * 2);
+        *reinterpret_cast<bf16x8*>(ah + m * apitch + r * 8) = *reinterpret_cast<const bf16x8*>(gh + (int64_t)ch * 8);
+        *reinterpret_cast<bf16x8*>(al + m * apitch + r * 8) = *reinterpret_cast<const bf16x8*>(gl + (int64_t)ch * 8);
+      }
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int k = 0; k < K; ++k) {
+      const bf16x8 a_h = *reinterpret_cast<const bf16x8*>(ah + arow + k * 16);
+      const bf16x8 a_l = *reinterpret_cast<const bf16x8*>(al + arow + k * 16);
+      const int ko = k * p.dil * 8;
+      const bf16x8 b0h = *reinterpret_cast<const bf16x8*>(xh + bpos0 + ko);
+      const bf16x8 b0l = *reinterpret_cast<const bf16x8*>(xl + bpos0 + ko);
+      const bf16x8 b1h = *reinterpret_cast<const bf16x8*>(xh + bpos1 + ko);
+      const bf16x8 b1l = *reinterpret_cast<const bf16x8*>(xl + bpos1 + ko);
+      acc0 = mfma32(a_l, b0h, acc0);
+      acc1 = mfma32(a_l, b1h, acc1);
+      acc0 = mfma32(a_h, b0l, acc0);
+      acc1 = mfma32(a_h, b1l, acc1);
+      acc0 = mfma32(a_h, b0h, acc0);
+      acc1 = mfma32(a_h, b1h, acc1);
+    }
+  }
+  conv_tile_epilogue<WCO>(p, acc0, acc1, wl, wco, col, hh, j0, m0, b0, SEG);
+}
+
+// Variant 2: PRE-SPLIT operands, LDS-DMA double buffer (layers whose input is re-read by >= 3 output-channel tiles).
+// Both operands arrive as bf16 hi / lo arrays laid out so that an LDS stage is a verbatim copy of global memory:
+//   input   [B][N/16][2 halves][Lp][8]  zero-padded rows (no bounds tests; conv_input_split_kernel writes the pads)
+//   weights [N/16][Mpad][AP = K*16 + 8] rows already carry the LDS bank padding (conv_weight_split_kernel)
+// so every stage is filled by global_load_lds_dwordx4 (16 bytes per lane straight into LDS, lane-linear destination: no VGPR
+// round trip, no ds_write_b128 at 13 cycles each) while the previous stage feeds the matrix cores.  Tile 64 co x 128
+// positions, waves 2 x 2, 16 input channels x K taps per stage.
+constexpr int V2_XC = 4;   // most 64-slot DMA chunks of one input array a wave issues per stage
+constexpr int V2_WC = 6;   // ... of one weight array
+__global__ __launch_bounds__(256) void conv1d_bf16x3_dma_kernel(ConvMfmaParams p) {
+  constexpr int MT = 64, LT = 128;
+  extern __shared__ __attribute__((aligned(16))) float cm_smem[];
+  const int K = p.K, SEG = p.SEG, nseg = LT / SEG;
+  const int lin_s = (SEG - 1) * p.stride + (K - 1) * p.dil + 1, lin_t = nseg * lin_s;
+  const int AP = K * 16 + 8;
+  const int nxs = 2 * lin_t, nws = MT * (2 * K + 1);         // 16-byte slots per input / weight array and stage
+  const int nxc = (nxs + 63) >> 6, nwc = (nws + 63) >> 6;    // 64-slot chunks (the tail chunk over-writes into padding)
+  const int XS = nxc * 512, WS = nwc * 512;                  // elements per array and stage
+  const int STAGE = 2 * (XS + WS);                           // [x hi][x lo][w hi][w lo]
+  bf16* smem = reinterpret_cast<bf16*>(cm_smem);
+  const int xhalf = lin_t * 8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, col = lane & 31;
+  const int wco = wave & 1, wl = wave >> 1;
+  const int j0 = blockIdx.x * LT, m0 = blockIdx.y * MT, b0 = blockIdx.z * nseg;
+  const int in0 = j0 * p.stride - p.pad;
+  const int nblk = (p.N + 15) / 16;
+  // this lane's DMA sources for stage 0 (stage nb adds a constant); chunk c belongs to wave c % 4
+  const bf16* xsrc[V2_XC];
+  const bf16* wsrc[V2_WC];
+#pragma unroll
+  for (int i = 0; i < V2_XC; ++i) {
+    const int q = min((wave + 4 * i) * 64 + lane, nxs - 1);
+    const int half = q >= lin_t, pp = q - half * lin_t;
+    const int sg = pp / lin_s, pos = pp - sg * lin_s;
+    const int b = min(b0 + sg, p.B - 1);
+    xsrc[i] = p.x_hi + ((((int64_t)b * nblk) * 2 + half) * p.Lp + (p.PADL + in0 + pos)) * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < V2_WC; ++i) {
+    const int q = min((wave + 4 * i) * 64 + lane, nws - 1);
+    wsrc[i] = p.a_hi + (int64_t)m0 * AP + (int64_t)q * 8;
+  }
+  const int64_t xlo_d = p.x_lo - p.x_hi, wlo_d = p.a_lo - p.a_hi;
+  const int64_t xstep = (int64_t)2 * p.Lp * 8, wstep = (int64_t)p.Mpad * AP;
+  auto issue = [&](int nb, int buf) {
+    bf16* st = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < V2_XC; ++i) {
+      const int c = wave + 4 * i;
+      if (c < nxc) {
+        const bf16* g = xsrc[i] + nb * xstep;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(st + c * 512), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + xlo_d),
+                                         (__attribute__((address_space(3))) void*)(st + XS + c * 512), 16, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < V2_WC; ++i) {
+      const int c = wave + 4 * i;
+      if (c < nwc) {
+        const bf16* g = wsrc[i] + nb * wstep;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(st + 2 * XS + c * 512), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + wlo_d),
+                                         (__attribute__((address_space(3))) void*)(st + 2 * XS + WS + c * 512), 16, 0, 0);
+      }
+    }
+  };
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+  const int c0 = wl * 64 + col, c1 = c0 + 32;
+  const int bpos0 = ((c0 / SEG) * lin_s + (c0 % SEG) * p.stride) * 8 + hh * xhalf;
+  const int bpos1 = ((c1 / SEG) * lin_s + (c1 % SEG) * p.stride) * 8 + hh * xhalf;
+  const int arow = (wco * 32 + col) * AP + hh * 8;
+  issue(0, 0);
+  for (int nb = 0; nb < nblk; ++nb) {
+    // stage nb has landed (every wave drains its own DMA before the barrier) and nobody still reads the other buffer
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (nb + 1 < nblk) issue(nb + 1, (nb + 1) & 1);
+    const bf16* xh = smem + (nb & 1) * STAGE;
+    const bf16* xl = xh + XS;
+    const bf16* ah = xh + 2 * XS;
+    const bf16* al = ah + WS;
+#pragma unroll 2
+    for (int k = 0; k < K; ++k) {
+      const bf16x8 a_h = *reinterpret_cast<const bf16x8*>(ah + arow + k * 16);
+      const bf16x8 a_l = *reinterpret_cast<const bf16x8*>(al + arow + k * 16);
+      const int ko = k * p.dil * 8;
+      const bf16x8 b0h = *reinterpret_cast<const bf16x8*>(xh + bpos0 + ko);
+      const bf16x8 b0l = *reinterpret_cast<const bf16x8*>(xl + bpos0 + ko);
+      const bf16x8 b1h = *reinterpret_cast<const bf16x8*>(xh + bpos1 + ko);
+      const bf16x8 b1l = *reinterpret_cast<const bf16x8*>(xl + bpos1 + ko);
+      acc0 = mfma32(a_l, b0h, acc0);
+      acc1 = mfma32(a_l, b1h, acc1);
+      acc0 = mfma32(a_h, b0l, acc0);
+      acc1 = mfma32(a_h, b1l, acc1);
+      acc0 = mfma32(a_h, b0h, acc0);
+      acc1 = mfma32(a_h, b1h, acc1);
+    }
+  }
+  conv_tile_epilogue<2>(p, acc0, acc1, wl, wco, col, hh, j0, m0, b0, SEG);
 }
 
 // dw[i] += sum_split slab[split][i];  blockIdx.y sums a group of SLAB_G splits and adds its partial with one atomic (a single
@@ -454,9 +568,72 @@ static int conv1d_mfma_launch_t(ConvMfmaParams p, const ConvCtx& cx, hipStream_t
 }
 
 
+// ---- split-bf16 launchers ------------------------------------------------------------------------------------------------
+// requested segment length (batch folding for short rows), clipped to the tile by the launchers
+static int conv_seg_request(int Lout, int B) { return (Lout <= 32 && B > 1) ? 32 : ((Lout <= 64 && B > 1) ? 64 : 1 << 20); }
+
+// geometry of the DMA-fed kernel for one launch: LDS bytes, chunk counts, and the zero pads its pre-split input rows need
+struct DmaGeom { size_t smem; int nxc, nwc, padl, padr; bool ok; };
+static DmaGeom conv_dma_geom(const ConvMfmaParams& p) {
+  constexpr int MT = 64, LT = 128;
+  const int SEG = p.SEG > LT ? LT : p.SEG, K = p.K;
+  const int lin_t = (LT / SEG) * ((SEG - 1) * p.stride + (K - 1) * p.dil + 1);
+  DmaGeom g;
+  g.nxc = (2 * lin_t + 63) / 64;
+  g.nwc = (MT * (2 * K + 1) + 63) / 64;
+  g.smem = (size_t)2 * 2 * (g.nxc + g.nwc) * 512 * sizeof(bf16);
+  const int last = (SEG == LT ? (int)cdiv(p.Lout, LT) * LT : SEG) - 1;   // last row-relative output position a tile touches
+  g.padl = std::max(0, p.pad);
+  g.padr = std::max(0, last * p.stride + (K - 1) * p.dil - p.pad + 1 - p.Lin);
+  g.ok = g.nxc <= 4 * V2_XC && g.nwc <= 4 * V2_WC && g.smem <= 150 * 1024 && p.M > 32 && p.N >= 16;
+  return g;
+}
+
+static int conv1d_bf16x3_dma_launch(ConvMfmaParams p, const ConvCtx& cx, hipStream_t stream, bool* handled) {
+  constexpr int MT = 64, LT = 128;
+  const int K = p.K, SEG = p.SEG > LT ? LT : p.SEG;
+  p.SEG = SEG;
+  const DmaGeom g = conv_dma_geom(p);
+  if (!g.ok) return TTTS_OK;
+  const int nblk = (p.N + 15) / 16, AP = K * 16 + 8;
+  p.Mpad = (int)(cdiv(p.M, MT) * MT);
+  if (!p.x_hi) { p.PADL = g.padl; p.Lp = (int)cdiv(g.padl + p.Lin + g.padr, 8) * 8; }
+  else if (p.PADL < g.padl || p.Lp - p.PADL - p.Lin < g.padr) return fail(TTTS_EINVAL, "conv1d: shared input split lacks padding");
+  const int64_t welems = (int64_t)nblk * p.Mpad * AP + 512;                 // +512: the clamped tail chunk stays inside
+  const int64_t xel = (int64_t)p.B * nblk * 2 * p.Lp * 8;
+  if (2 * (welems + xel) * (int64_t)sizeof(bf16) > cx.ws_bytes) return TTTS_OK;
+  bf16* xhi = static_cast<bf16*>(cx.ws);       // scratch layout: [x hi][x lo][w hi][w lo] (the input split comes first so
+  bf16* xlo = xhi + xel;                       // that the phases of a strided data gradient can share it)
+  bf16* hi = xlo + xel;
+  bf16* lo = hi + welems;
+  p.a_hi = hi; p.a_lo = lo;
+  conv_weight_split_kernel<<<(int)std::min<int64_t>(cdiv(welems, 256), 2048), 256, 0, stream>>>(p.w, hi, lo, p.M, p.N, p.Mpad, nblk, K, p.Kmem,
+                                                                                             p.transposed, p.tap_off, p.tap_stride, AP);
+  if (!p.x_hi) {   // (polyphase data gradients share one split of dy across their phase launches)
+    conv_input_split_kernel<<<(int)std::min<int64_t>(cdiv(xel / 16, 256), 8192), 256, 0, stream>>>(p.x, xhi, xlo, p.B, p.N, p.Lin, nblk, p.in_slope,
+                                                                                                   p.Lp, p.PADL);
+    p.x_hi = xhi; p.x_lo = xlo;
+  }
+  dim3 grid((unsigned)cdiv(p.Lout, SEG == LT ? LT : SEG), (unsigned)cdiv(p.M, MT), (unsigned)cdiv(p.B, LT / SEG));
+  static bool attr = false;
+  int rc = set_attr_once(reinterpret_cast<const void*>(conv1d_bf16x3_dma_kernel), attr);
+  if (rc) return rc;
+  conv1d_bf16x3_dma_kernel<<<grid, 256, g.smem, stream>>>(p);
+  *handled = true;
+  return check_launch("conv1d_bf16x3_dma");
+}
+
 template <int WCO>
 static int conv1d_bf16x3_launch_t(ConvMfmaParams p, const ConvCtx& cx, hipStream_t stream, bool* handled) {
   constexpr int MT = 32 * WCO, LT = 64 * (4 / WCO);
+  // pre-split + DMA kernel when the input is re-read by >= 3 output-channel tiles (measured: a full extra pass over x costs
+  // more than on-the-fly splitting for the 16..64-channel long-row layers, and wins from 192 channels up); flag 32768:
+  // from one tile, flag 65536: never (tools/conv_bench.py)
+  if (WCO == 2 && !(cx.flags & 65536) && (p.x_hi != nullptr || cdiv(p.M, MT) >= ((cx.flags & 32768) ? 1 : 3))) {
+    int rc = conv1d_bf16x3_dma_launch(p, cx, stream, handled);
+    if (rc || *handled) return rc;
+    if (p.x_hi) return fail(TTTS_EUNSUPPORTED, "conv1d: shared input split without the DMA kernel");
+  }
   const int K = p.K, SEG = p.SEG > LT ? LT : p.SEG;
   p.SEG = SEG;
   const int lin_t = (LT / SEG) * ((SEG - 1) * p.stride + (K - 1) * p.dil + 1);
@@ -465,22 +642,12 @@ static int conv1d_bf16x3_launch_t(ConvMfmaParams p, const ConvCtx& cx, hipStream
   const int nblk = (p.N + 15) / 16;
   p.Mpad = (int)(cdiv(p.M, MT) * MT);
   const int64_t elems = (int64_t)nblk * p.Mpad * K * 16;
-  // pre-split the input only when it is re-read by >= 3 output-channel tiles (measured: a full extra pass over x costs more
-  // than on-the-fly splitting for the 16..64-channel long-row layers, and wins from 192 channels up)
-  const bool presplit = p.x_hi != nullptr || cdiv(p.M, MT) >= 3;
-  const int64_t xel = presplit ? (int64_t)p.B * nblk * p.Lin * 16 : 0;
-  if (2 * (elems + xel) * (int64_t)sizeof(bf16) > cx.ws_bytes) return TTTS_OK;
-  bf16* xhi = static_cast<bf16*>(cx.ws);       // scratch layout: [x hi][x lo][w hi][w lo] (the input split comes first so
-  bf16* xlo = xhi + xel;                             // that the phases of a strided data gradient can share it)
-  bf16* hi = xlo + xel;
+  if (2 * elems * (int64_t)sizeof(bf16) > cx.ws_bytes) return TTTS_OK;
+  bf16* hi = static_cast<bf16*>(cx.ws);
   bf16* lo = hi + elems;
   p.a_hi = hi; p.a_lo = lo;
   conv_weight_split_kernel<<<(int)std::min<int64_t>(cdiv(elems, 256), 2048), 256, 0, stream>>>(p.w, hi, lo, p.M, p.N, p.Mpad, nblk, K, p.Kmem,
-                                                                                            p.transposed, p.tap_off, p.tap_stride);
-  if (presplit && !p.x_hi) {   // (polyphase data gradients share one split of dy across their phase launches)
-    conv_input_split_kernel<<<(int)std::min<int64_t>(cdiv(xel / 16, 256), 8192), 256, 0, stream>>>(p.x, xhi, xlo, p.B, p.N, p.Lin, nblk, p.in_slope);
-    p.x_hi = xhi; p.x_lo = xlo;
-  }
+                                                                                            p.transposed, p.tap_off, p.tap_stride, K * 16);
   dim3 grid((unsigned)cdiv(p.Lout, SEG == LT ? LT : SEG), (unsigned)cdiv(p.M, MT), (unsigned)cdiv(p.B, LT / SEG));
   static bool attr = false;
   int rc = set_attr_once(reinterpret_cast<const void*>(conv1d_bf16x3_kernel<WCO>), attr);
@@ -493,7 +660,7 @@ static int conv1d_bf16x3_launch_t(ConvMfmaParams p, const ConvCtx& cx, hipStream
 static int conv1d_mfma_launch(ConvMfmaParams p, const ConvCtx& cx, hipStream_t stream, bool* handled) {
   *handled = false;
   // batch folding for short rows (see SEG); requested segment length, clipped to the tile by the launcher
-  p.SEG = (p.Lout <= 32 && p.B > 1) ? 32 : ((p.Lout <= 64 && p.B > 1) ? 64 : 1 << 20);
+  p.SEG = conv_seg_request(p.Lout, p.B);
   if (cx.ws && p.N >= 16 && !(cx.flags & 4096)) {
     int rc = p.M <= 32 ? conv1d_bf16x3_launch_t<1>(p, cx, stream, handled) : conv1d_bf16x3_launch_t<2>(p, cx, stream, handled);
     if (rc || *handled) return rc;
@@ -539,16 +706,33 @@ int conv1d_dgrad_strided_mfma_try(const float* dy, const float* w, const float* 
                                   int accumulate, const ConvCtx& cx, hipStream_t stream, bool* handled) {
   *handled = false;
   if (Cout < 8 || K > 16 * stride || K < stride) return TTTS_OK;
-  // split-bf16 path: split dy ONCE for all phases (same place conv1d_bf16x3_launch_t would put it)
+  // split-bf16 path: split dy ONCE for all phases (same place conv1d_bf16x3_dma_launch would put it), padded for the
+  // phase that reaches furthest; only if every phase fits the DMA kernel
   const bf16* xs_hi = nullptr;
   const bf16* xs_lo = nullptr;
-  if (cx.ws && Cout >= 16 && Cin >= 192 && !(cx.flags & 4096)) {
+  int sh_Lp = 0, sh_padl = 0;
+  if (cx.ws && Cout >= 16 && Cin >= 192 && !(cx.flags & (4096 | 65536))) {
+    bool all_ok = true;
+    int padl = 0, padr = 0;
+    for (int phi = 0; phi < stride && all_ok; ++phi) {
+      const int Kp = (K - phi + stride - 1) / stride;
+      const int tmin = phi >= pad ? 0 : (pad - phi + stride - 1) / stride;
+      const int off = stride * tmin + phi - pad;
+      if (off >= Lin) continue;
+      ConvMfmaParams q{};
+      q.B = B; q.M = Cin; q.N = Cout; q.Lin = Lout; q.Lout = (Lin - 1 - off) / stride + 1; q.K = Kp; q.stride = 1;
+      q.pad = (Kp - 1) - tmin; q.dil = 1; q.SEG = conv_seg_request(q.Lout, B);
+      const DmaGeom g = conv_dma_geom(q);
+      all_ok = g.ok;
+      padl = std::max(padl, g.padl); padr = std::max(padr, g.padr);
+    }
     const int nblk = (Cout + 15) / 16;
-    const int64_t xel = (int64_t)B * nblk * Lout * 16;
-    if (2 * xel * (int64_t)sizeof(bf16) + (32 << 20) <= cx.ws_bytes) {
+    const int Lp = (int)cdiv(padl + Lout + padr, 8) * 8;
+    const int64_t xel = (int64_t)B * nblk * 2 * Lp * 8;
+    if (all_ok && 2 * xel * (int64_t)sizeof(bf16) + (32 << 20) <= cx.ws_bytes) {
       bf16* xh = static_cast<bf16*>(cx.ws);
-      conv_input_split_kernel<<<(int)std::min<int64_t>(cdiv(xel / 16, 256), 8192), 256, 0, stream>>>(dy, xh, xh + xel, B, Cout, Lout, nblk, in_slope);
-      xs_hi = xh; xs_lo = xh + xel;
+      conv_input_split_kernel<<<(int)std::min<int64_t>(cdiv(xel / 16, 256), 8192), 256, 0, stream>>>(dy, xh, xh + xel, B, Cout, Lout, nblk, in_slope, Lp, padl);
+      xs_hi = xh; xs_lo = xh + xel; sh_Lp = Lp; sh_padl = padl;
     }
   }
   for (int phi = 0; phi < stride; ++phi) {
@@ -558,7 +742,7 @@ int conv1d_dgrad_strided_mfma_try(const float* dy, const float* w, const float* 
     if (off >= Lin) continue;
     const int T = (Lin - 1 - off) / stride + 1;
     ConvMfmaParams p{dy, w, bias, nullptr, resid, omask, gate, dx, B, Cin, Cout, Lout, T, Kp, 1, (Kp - 1) - tmin, 1, 1, 0,
-                     K, phi, stride, stride, off, Lin, 0, in_slope, gate_slope, 0, 1.f, out_scale, accumulate, nullptr, nullptr, 0, xs_hi, xs_lo};
+                     K, phi, stride, stride, off, Lin, 0, in_slope, gate_slope, 0, 1.f, out_scale, accumulate, nullptr, nullptr, 0, xs_hi, xs_lo, sh_Lp, sh_padl};
     bool h = false;
     int rc = conv1d_mfma_launch(p, cx, stream, &h);
     if (rc) return rc;
