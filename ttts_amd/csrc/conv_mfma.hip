@@ -245,6 +245,52 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvMfmaParams& p, cons
   }
 }
 
+// ---- inner loop shared by the split-bf16 kernels: CW 32-row blocks of output channels x two 32-position blocks per wave,
+// fragments, then 6 CW MFMAs per tap
+template <int CW>
+struct B3Frag { bf16x8 ah[CW], al[CW], bh[2], bl[2]; };
+template <int CW>
+__device__ __forceinline__ void b3_load(B3Frag<CW>& f, const bf16* xh, const bf16* xl, const bf16* ah, const bf16* al,
+                                        const int (&arow)[CW], int bpos0, int bpos1, int k, int dil8) {
+#pragma unroll
+  for (int i = 0; i < CW; ++i) {
+    f.ah[i] = *reinterpret_cast<const bf16x8*>(ah + arow[i] + k * 16);
+    f.al[i] = *reinterpret_cast<const bf16x8*>(al + arow[i] + k * 16);
+  }
+  const int ko = k * dil8;
+  f.bh[0] = *reinterpret_cast<const bf16x8*>(xh + bpos0 + ko);
+  f.bl[0] = *reinterpret_cast<const bf16x8*>(xl + bpos0 + ko);
+  f.bh[1] = *reinterpret_cast<const bf16x8*>(xh + bpos1 + ko);
+  f.bl[1] = *reinterpret_cast<const bf16x8*>(xl + bpos1 + ko);
+}
+template <int CW>
+__device__ __forceinline__ void b3_mma(const B3Frag<CW>& f, f32x16 (&acc)[CW][2]) {
+#pragma unroll
+  for (int i = 0; i < CW; ++i)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) acc[i][t] = mfma32(f.al[i], f.bh[t], acc[i][t]);
+#pragma unroll
+  for (int i = 0; i < CW; ++i)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) acc[i][t] = mfma32(f.ah[i], f.bl[t], acc[i][t]);
+#pragma unroll
+  for (int i = 0; i < CW; ++i)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) acc[i][t] = mfma32(f.ah[i], f.bh[t], acc[i][t]);
+}
+template <int CW>
+__device__ __forceinline__ void b3_stage(const bf16* xh, const bf16* xl, const bf16* ah, const bf16* al, const int (&arow)[CW],
+                                         int bpos0, int bpos1, int K, int dil8, f32x16 (&acc)[CW][2]) {
+  // (an explicit two-deep fragment prefetch across taps measured 10-14 % SLOWER than this plain loop: +44 VGPRs and
+  // branchy control for reads the second resident wave already overlaps)
+#pragma unroll 2
+  for (int k = 0; k < K; ++k) {
+    B3Frag<CW> f;
+    b3_load<CW>(f, xh, xl, ah, al, arow, bpos0, bpos1, k, dil8);
+    b3_mma<CW>(f, acc);
+  }
+}
+
 // Variant 1: the input is split ON THE FLY while it is staged (few output-channel tiles re-read it: the 16..128-channel
 // long-row layers, where a separate split pass would cost more HBM traffic than it saves).  Single LDS stage; overlap comes
 // from several workgroups per CU.
@@ -269,13 +315,13 @@ __global__ __launch_bounds__(256) void conv1d_bf16x3_kernel(ConvMfmaParams p) {
   const int wco = wave % WCO, wl = wave / WCO;
   const int j0 = blockIdx.x * LT, m0 = blockIdx.y * MT, b0 = blockIdx.z * nseg;
   const int in0 = j0 * p.stride - p.pad;
-  f32x16 acc0, acc1;
+  f32x16 acc[1][2];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+  for (int r = 0; r < 16; ++r) { acc[0][0][r] = 0.f; acc[0][1][r] = 0.f; }
   const int c0 = wl * 64 + col, c1 = c0 + 32;
   const int bpos0 = ((c0 / SEG) * lin_s + (c0 % SEG) * p.stride) * 8 + hh * xhalf;
   const int bpos1 = ((c1 / SEG) * lin_s + (c1 % SEG) * p.stride) * 8 + hh * xhalf;
-  const int arow = (wco * 32 + col) * apitch + hh * 8;
+  const int arow[1] = {(wco * 32 + col) * apitch + hh * 8};
   const int nblk = (p.N + 15) / 16;
   const int64_t slab = (int64_t)p.Mpad * K * 16;      // elements per channel block of the split weights
   for (int nb = 0; nb < nblk; ++nb) {
@@ -311,24 +357,9 @@ __global__ __launch_bounds__(256) void conv1d_bf16x3_kernel(ConvMfmaParams p) {
       }
     }
     __syncthreads();
-#pragma unroll 2
-    for (int k = 0; k < K; ++k) {
-      const bf16x8 a_h = *reinterpret_cast<const bf16x8*>(ah + arow + k * 16);
-      const bf16x8 a_l = *reinterpret_cast<const bf16x8*>(al + arow + k * 16);
-      const int ko = k * p.dil * 8;
-      const bf16x8 b0h = *reinterpret_cast<const bf16x8*>(xh + bpos0 + ko);
-      const bf16x8 b0l = *reinterpret_cast<const bf16x8*>(xl + bpos0 + ko);
-      const bf16x8 b1h = *reinterpret_cast<const bf16x8*>(xh + bpos1 + ko);
-      const bf16x8 b1l = *reinterpret_cast<const bf16x8*>(xl + bpos1 + ko);
-      acc0 = mfma32(a_l, b0h, acc0);
-      acc1 = mfma32(a_l, b1h, acc1);
-      acc0 = mfma32(a_h, b0l, acc0);
-      acc1 = mfma32(a_h, b1l, acc1);
-      acc0 = mfma32(a_h, b0h, acc0);
-      acc1 = mfma32(a_h, b1h, acc1);
-    }
+    b3_stage<1>(xh, xl, ah, al, arow, bpos0, bpos1, K, p.dil * 8, acc);
   }
-  conv_tile_epilogue<WCO>(p, acc0, acc1, wl, wco, col, hh, j0, m0, b0, SEG);
+  conv_tile_epilogue<WCO>(p, acc[0][0], acc[0][1], wl, wco, col, hh, j0, m0, b0, SEG);
 }
 
 // Variant 2: PRE-SPLIT operands, LDS-DMA double buffer (layers whose input is re-read by >= 3 output-channel tiles).
@@ -338,10 +369,14 @@ __global__ __launch_bounds__(256) void conv1d_bf16x3_kernel(ConvMfmaParams p) {
 // so every stage is filled by global_load_lds_dwordx4 (16 bytes per lane straight into LDS, lane-linear destination: no VGPR
 // round trip, no ds_write_b128 at 13 cycles each) while the previous stage feeds the matrix cores.  Tile 64 co x 128
 // positions, waves 2 x 2, 16 input channels x K taps per stage.
-constexpr int V2_XC = 4;   // most 64-slot DMA chunks of one input array a wave issues per stage
-constexpr int V2_WC = 6;   // ... of one weight array
+// CW = 1: waves 2 (co) x 2 (positions), wave tile 32 x 64, workgroup tile 64 x 128.
+// CW = 2: waves 1 x 4, wave tile 64 x 64, workgroup tile 64 x 256: 8 fragment reads feed 12 MFMAs (6 : 6 above) and a weight
+//         stage is amortised over twice the positions -- for launches that still fill the chip with the larger tile.
+constexpr int V2_WC = 6;   // most 64-slot DMA chunks of one weight array a wave issues per stage (K <= 11)
+template <int CW>
 __global__ __launch_bounds__(256) void conv1d_bf16x3_dma_kernel(ConvMfmaParams p) {
-  constexpr int MT = 64, LT = 128;
+  constexpr int MT = 64, LT = 128 * CW, WCO = 2 / CW;
+  constexpr int XC = CW == 1 ? 4 : 7;                       // most DMA chunks of one input array per wave and stage
   extern __shared__ __attribute__((aligned(16))) float cm_smem[];
   const int K = p.K, SEG = p.SEG, nseg = LT / SEG;
   const int lin_s = (SEG - 1) * p.stride + (K - 1) * p.dil + 1, lin_t = nseg * lin_s;
@@ -353,15 +388,15 @@ __global__ __launch_bounds__(256) void conv1d_bf16x3_dma_kernel(ConvMfmaParams p
   bf16* smem = reinterpret_cast<bf16*>(cm_smem);
   const int xhalf = lin_t * 8;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, col = lane & 31;
-  const int wco = wave & 1, wl = wave >> 1;
+  const int wco = wave % WCO, wl = wave / WCO;
   const int j0 = blockIdx.x * LT, m0 = blockIdx.y * MT, b0 = blockIdx.z * nseg;
   const int in0 = j0 * p.stride - p.pad;
   const int nblk = (p.N + 15) / 16;
   // this lane's DMA sources for stage 0 (stage nb adds a constant); chunk c belongs to wave c % 4
-  const bf16* xsrc[V2_XC];
+  const bf16* xsrc[XC];
   const bf16* wsrc[V2_WC];
 #pragma unroll
-  for (int i = 0; i < V2_XC; ++i) {
+  for (int i = 0; i < XC; ++i) {
     const int q = min((wave + 4 * i) * 64 + lane, nxs - 1);
     const int half = q >= lin_t, pp = q - half * lin_t;
     const int sg = pp / lin_s, pos = pp - sg * lin_s;
@@ -378,7 +413,7 @@ __global__ __launch_bounds__(256) void conv1d_bf16x3_dma_kernel(ConvMfmaParams p
   auto issue = [&](int nb, int buf) {
     bf16* st = smem + buf * STAGE;
 #pragma unroll
-    for (int i = 0; i < V2_XC; ++i) {
+    for (int i = 0; i < XC; ++i) {
       const int c = wave + 4 * i;
       if (c < nxc) {
         const bf16* g = xsrc[i] + nb * xstep;
@@ -400,13 +435,17 @@ __global__ __launch_bounds__(256) void conv1d_bf16x3_dma_kernel(ConvMfmaParams p
       }
     }
   };
-  f32x16 acc0, acc1;
+  f32x16 acc[CW][2];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+  for (int i = 0; i < CW; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[i][0][r] = 0.f; acc[i][1][r] = 0.f; }
   const int c0 = wl * 64 + col, c1 = c0 + 32;
   const int bpos0 = ((c0 / SEG) * lin_s + (c0 % SEG) * p.stride) * 8 + hh * xhalf;
   const int bpos1 = ((c1 / SEG) * lin_s + (c1 % SEG) * p.stride) * 8 + hh * xhalf;
-  const int arow = (wco * 32 + col) * AP + hh * 8;
+  int arow[CW];
+#pragma unroll
+  for (int i = 0; i < CW; ++i) arow[i] = ((wco * CW + i) * 32 + col) * AP + hh * 8;
   issue(0, 0);
   for (int nb = 0; nb < nblk; ++nb) {
     // stage nb has landed (every wave drains its own DMA before the barrier) and nobody still reads the other buffer
@@ -414,27 +453,11 @@ __global__ __launch_bounds__(256) void conv1d_bf16x3_dma_kernel(ConvMfmaParams p
     __syncthreads();
     if (nb + 1 < nblk) issue(nb + 1, (nb + 1) & 1);
     const bf16* xh = smem + (nb & 1) * STAGE;
-    const bf16* xl = xh + XS;
-    const bf16* ah = xh + 2 * XS;
-    const bf16* al = ah + WS;
-#pragma unroll 2
-    for (int k = 0; k < K; ++k) {
-      const bf16x8 a_h = *reinterpret_cast<const bf16x8*>(ah + arow + k * 16);
-      const bf16x8 a_l = *reinterpret_cast<const bf16x8*>(al + arow + k * 16);
-      const int ko = k * p.dil * 8;
-      const bf16x8 b0h = *reinterpret_cast<const bf16x8*>(xh + bpos0 + ko);
-      const bf16x8 b0l = *reinterpret_cast<const bf16x8*>(xl + bpos0 + ko);
-      const bf16x8 b1h = *reinterpret_cast<const bf16x8*>(xh + bpos1 + ko);
-      const bf16x8 b1l = *reinterpret_cast<const bf16x8*>(xl + bpos1 + ko);
-      acc0 = mfma32(a_l, b0h, acc0);
-      acc1 = mfma32(a_l, b1h, acc1);
-      acc0 = mfma32(a_h, b0l, acc0);
-      acc1 = mfma32(a_h, b1l, acc1);
-      acc0 = mfma32(a_h, b0h, acc0);
-      acc1 = mfma32(a_h, b1h, acc1);
-    }
+    b3_stage<CW>(xh, xh + XS, xh + 2 * XS, xh + 2 * XS + WS, arow, bpos0, bpos1, K, p.dil * 8, acc);
   }
-  conv_tile_epilogue<2>(p, acc0, acc1, wl, wco, col, hh, j0, m0, b0, SEG);
+#pragma unroll
+  for (int i = 0; i < CW; ++i)
+    conv_tile_epilogue<1>(p, acc[i][0], acc[i][1], wl, 0, col, hh, j0, m0 + (wco * CW + i) * 32, b0, SEG);
 }
 
 // dw[i] += sum_split slab[split][i];  blockIdx.y sums a group of SLAB_G splits and adds its partial with one atomic (a single
@@ -570,12 +593,15 @@ static int conv1d_mfma_launch_t(ConvMfmaParams p, const ConvCtx& cx, hipStream_t
 
 // ---- split-bf16 launchers ------------------------------------------------------------------------------------------------
 // requested segment length (batch folding for short rows), clipped to the tile by the launchers
-static int conv_seg_request(int Lout, int B) { return (Lout <= 32 && B > 1) ? 32 : ((Lout <= 64 && B > 1) ? 64 : 1 << 20); }
+static int conv_seg_request(int Lout, int B) {
+  if (B <= 1) return 1 << 20;
+  return Lout <= 32 ? 32 : (Lout <= 64 ? 64 : (Lout <= 128 ? 128 : 1 << 20));
+}
 
 // geometry of the DMA-fed kernel for one launch: LDS bytes, chunk counts, and the zero pads its pre-split input rows need
-struct DmaGeom { size_t smem; int nxc, nwc, padl, padr; bool ok; };
-static DmaGeom conv_dma_geom(const ConvMfmaParams& p) {
-  constexpr int MT = 64, LT = 128;
+struct DmaGeom { size_t smem; int nxc, nwc, padl, padr; int64_t wgs; bool ok; };
+static DmaGeom conv_dma_geom(const ConvMfmaParams& p, int CW) {
+  const int MT = 64, LT = 128 * CW;
   const int SEG = p.SEG > LT ? LT : p.SEG, K = p.K;
   const int lin_t = (LT / SEG) * ((SEG - 1) * p.stride + (K - 1) * p.dil + 1);
   DmaGeom g;
@@ -585,15 +611,22 @@ static DmaGeom conv_dma_geom(const ConvMfmaParams& p) {
   const int last = (SEG == LT ? (int)cdiv(p.Lout, LT) * LT : SEG) - 1;   // last row-relative output position a tile touches
   g.padl = std::max(0, p.pad);
   g.padr = std::max(0, last * p.stride + (K - 1) * p.dil - p.pad + 1 - p.Lin);
-  g.ok = g.nxc <= 4 * V2_XC && g.nwc <= 4 * V2_WC && g.smem <= 150 * 1024 && p.M > 32 && p.N >= 16;
+  g.wgs = cdiv(p.Lout, SEG == LT ? LT : SEG) * cdiv(p.M, MT) * cdiv(p.B, LT / SEG);
+  g.ok = g.nxc <= 4 * (CW == 1 ? 4 : 7) && g.nwc <= 4 * V2_WC && g.smem <= 150 * 1024 && p.M > 32 && p.N >= 16;
   return g;
 }
+// the 64 x 256 tile when it still yields >= 2 workgroups per CU (flag 131072: never, flag 262144: whenever it fits)
+static int conv_dma_pick(const ConvMfmaParams& p, const ConvCtx& cx) {
+  const DmaGeom w = conv_dma_geom(p, 2);
+  if ((cx.flags & 131072) || !w.ok) return 1;
+  return (w.wgs >= 512 || (cx.flags & 262144)) ? 2 : 1;
+}
 
-static int conv1d_bf16x3_dma_launch(ConvMfmaParams p, const ConvCtx& cx, hipStream_t stream, bool* handled) {
-  constexpr int MT = 64, LT = 128;
+static int conv1d_bf16x3_dma_launch(ConvMfmaParams p, const ConvCtx& cx, hipStream_t stream, bool* handled, int CW) {
+  const int MT = 64, LT = 128 * CW;
   const int K = p.K, SEG = p.SEG > LT ? LT : p.SEG;
+  const DmaGeom g = conv_dma_geom(p, CW);
   p.SEG = SEG;
-  const DmaGeom g = conv_dma_geom(p);
   if (!g.ok) return TTTS_OK;
   const int nblk = (p.N + 15) / 16, AP = K * 16 + 8;
   p.Mpad = (int)(cdiv(p.M, MT) * MT);
@@ -615,10 +648,12 @@ static int conv1d_bf16x3_dma_launch(ConvMfmaParams p, const ConvCtx& cx, hipStre
     p.x_hi = xhi; p.x_lo = xlo;
   }
   dim3 grid((unsigned)cdiv(p.Lout, SEG == LT ? LT : SEG), (unsigned)cdiv(p.M, MT), (unsigned)cdiv(p.B, LT / SEG));
-  static bool attr = false;
-  int rc = set_attr_once(reinterpret_cast<const void*>(conv1d_bf16x3_dma_kernel), attr);
+  static bool attr1 = false, attr2 = false;
+  int rc = CW == 1 ? set_attr_once(reinterpret_cast<const void*>(conv1d_bf16x3_dma_kernel<1>), attr1)
+                   : set_attr_once(reinterpret_cast<const void*>(conv1d_bf16x3_dma_kernel<2>), attr2);
   if (rc) return rc;
-  conv1d_bf16x3_dma_kernel<<<grid, 256, g.smem, stream>>>(p);
+  if (CW == 1) conv1d_bf16x3_dma_kernel<1><<<grid, 256, g.smem, stream>>>(p);
+  else conv1d_bf16x3_dma_kernel<2><<<grid, 256, g.smem, stream>>>(p);
   *handled = true;
   return check_launch("conv1d_bf16x3_dma");
 }
@@ -630,7 +665,7 @@ static int conv1d_bf16x3_launch_t(ConvMfmaParams p, const ConvCtx& cx, hipStream
   // more than on-the-fly splitting for the 16..64-channel long-row layers, and wins from 192 channels up); flag 32768:
   // from one tile, flag 65536: never (tools/conv_bench.py)
   if (WCO == 2 && !(cx.flags & 65536) && (p.x_hi != nullptr || cdiv(p.M, MT) >= ((cx.flags & 32768) ? 1 : 3))) {
-    int rc = conv1d_bf16x3_dma_launch(p, cx, stream, handled);
+    int rc = conv1d_bf16x3_dma_launch(p, cx, stream, handled, conv_dma_pick(p, cx));
     if (rc || *handled) return rc;
     if (p.x_hi) return fail(TTTS_EUNSUPPORTED, "conv1d: shared input split without the DMA kernel");
   }
@@ -722,7 +757,7 @@ int conv1d_dgrad_strided_mfma_try(const float* dy, const float* w, const float* 
       ConvMfmaParams q{};
       q.B = B; q.M = Cin; q.N = Cout; q.Lin = Lout; q.Lout = (Lin - 1 - off) / stride + 1; q.K = Kp; q.stride = 1;
       q.pad = (Kp - 1) - tmin; q.dil = 1; q.SEG = conv_seg_request(q.Lout, B);
-      const DmaGeom g = conv_dma_geom(q);
+      const DmaGeom g = conv_dma_geom(q, conv_dma_pick(q, cx));
       all_ok = g.ok;
       padl = std::max(padl, g.padl); padr = std::max(padr, g.padr);
     }
