@@ -45,7 +45,10 @@ def timeit(fn, reps=10):
 
 
 rows = []
+ONLY = os.environ.get("CB_ONLY", "")          # substring filter on the shape name
 for name, cin, cout, k, s, pad, dil, L in SHAPES:
+    if ONLY and ONLY not in name:
+        continue
     bb = B * 3 if "p=3" in name else B
     x = torch.randn(bb, cin, L, device=dev); w = torch.randn(cout, cin, k, device=dev) * 0.05
     lout = ops.conv_out_len(L, k, s, pad, dil)

@@ -462,13 +462,19 @@ __global__ __launch_bounds__(256) void conv1d_bf16x3_dma_kernel(ConvMfmaParams p
 
 // dw[i] += sum_split slab[split][i];  blockIdx.y sums a group of SLAB_G splits and adds its partial with one atomic (a single
 // thread walking 1000 splits of a small weight tensor would be latency-bound; nsplit / SLAB_G atomics per element are few)
-constexpr int SLAB_G = 16;
+constexpr int SLAB_G = 32;
 __global__ __launch_bounds__(256) void wgrad_slab_sum_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsplit,
                                                              int64_t per) {
   const int s0 = blockIdx.y * SLAB_G, s1 = min(nsplit, s0 + SLAB_G);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (int64_t)gridDim.x * 256) {
-    float s = 0.f;
-    for (int sp = s0; sp < s1; ++sp) s += slab[sp * per + i];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;        // four loads in flight per step
+    int sp = s0;
+    for (; sp + 4 <= s1; sp += 4) {
+      const float v0 = slab[sp * per + i], v1 = slab[(sp + 1) * per + i], v2 = slab[(sp + 2) * per + i], v3 = slab[(sp + 3) * per + i];
+      a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+    }
+    for (; sp < s1; ++sp) a0 += slab[sp * per + i];
+    const float s = (a0 + a1) + (a2 + a3);
     if (gridDim.y == 1) dw[i] += s;
     else atomicAdd(dw + i, s);
   }
@@ -795,33 +801,50 @@ int conv1d_dgrad_strided_mfma_try(const float* dy, const float* w, const float* 
 //   dy split:  DY[b][co][Lq]           Lq = roundup64(Lout), zero beyond Lout
 //   x split:   XS[par][b][ci][r][Li]   element i of phase r of parity copy `par` holds x[(i + par)*stride + r - PL]
 //              (PL = roundup_stride(pad)); the odd copy lets every row segment start on a 4-byte boundary
+// (2-D grids: blockIdx.y walks rows, a thread converts two adjacent elements -- the flat-index form spent most of its time in
+// 64-bit divisions)
 __global__ __launch_bounds__(256) void wgrad_split_dy_kernel(const float* __restrict__ dy, bf16* __restrict__ hi,
                                                              bf16* __restrict__ lo, int64_t rows, int Lout, int Lq, float slope) {
-  const int64_t total = rows * Lq;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int l = (int)(i % Lq);
-    const int64_t r = i / Lq;
-    const float v = l < Lout ? lrelu_f(dy[r * Lout + l], slope) : 0.f;
-    const bf16 h = (bf16)v;
-    hi[i] = h;
-    lo[i] = (bf16)(v - (float)h);
+  const int l = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (l >= Lq) return;
+  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+    const float* src = dy + r * Lout;
+    const float v0 = l < Lout ? lrelu_f(src[l], slope) : 0.f, v1 = l + 1 < Lout ? lrelu_f(src[l + 1], slope) : 0.f;
+    bf16x2 h, w;
+    h[0] = (bf16)v0; h[1] = (bf16)v1;
+    w[0] = (bf16)(v0 - (float)h[0]); w[1] = (bf16)(v1 - (float)h[1]);
+    *reinterpret_cast<bf16x2*>(hi + r * Lq + l) = h;
+    *reinterpret_cast<bf16x2*>(lo + r * Lq + l) = w;
   }
 }
+// blockIdx.z = parity copy * stride + phase
 __global__ __launch_bounds__(256) void wgrad_split_x_kernel(const float* __restrict__ x, bf16* __restrict__ hi,
                                                             bf16* __restrict__ lo, int64_t rows, int Lin, int stride, int Li,
                                                             int PL, float slope) {
-  const int64_t per = rows * stride * Li, total = 2 * per;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int par = (int)(i / per);
-    const int64_t j = i - par * per;
-    const int ii = (int)(j % Li), r = (int)((j / Li) % stride);
-    const int64_t row = j / Li / stride;
-    const int64_t q = (int64_t)(ii + par) * stride + r - PL;
-    const float v = (q >= 0 && q < Lin) ? lrelu_f(x[row * Lin + q], slope) : 0.f;
-    const bf16 h = (bf16)v;
-    hi[i] = h;
-    lo[i] = (bf16)(v - (float)h);
+  const int ii = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (ii >= Li) return;
+  const int par = blockIdx.z / stride, r = blockIdx.z % stride;
+  const int64_t per = rows * stride * Li;
+  const int64_t q0 = (int64_t)(ii + par) * stride + r - PL, q1 = q0 + stride;
+  for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {
+    const float* src = x + row * Lin;
+    const float v0 = (q0 >= 0 && q0 < Lin) ? lrelu_f(src[q0], slope) : 0.f;
+    const float v1 = (q1 >= 0 && q1 < Lin) ? lrelu_f(src[q1], slope) : 0.f;
+    bf16x2 h, w;
+    h[0] = (bf16)v0; h[1] = (bf16)v1;
+    w[0] = (bf16)(v0 - (float)h[0]); w[1] = (bf16)(v1 - (float)h[1]);
+    const int64_t o = par * per + (row * stride + r) * Li + ii;
+    *reinterpret_cast<bf16x2*>(hi + o) = h;
+    *reinterpret_cast<bf16x2*>(lo + o) = w;
   }
+}
+static void launch_wgrad_splits(const float* dy, const float* x, bf16* dyh, bf16* dyl, bf16* xh, bf16* xl, int64_t rows_dy, int Lout,
+                                int Lq, float dy_slope, int64_t rows_x, int Lin, int stride, int Li, int PL, float x_slope, int npar,
+                                hipStream_t stream) {
+  wgrad_split_dy_kernel<<<dim3((unsigned)cdiv(Lq / 2, 256), (unsigned)std::min<int64_t>(rows_dy, 32768)), 256, 0, stream>>>(
+      dy, dyh, dyl, rows_dy, Lout, Lq, dy_slope);
+  wgrad_split_x_kernel<<<dim3((unsigned)cdiv(Li / 2, 256), (unsigned)std::min<int64_t>(rows_x, 32768), (unsigned)(npar * stride)), 256, 0, stream>>>(
+      x, xh, xl, rows_x, Lin, stride, Li, PL, x_slope);
 }
 
 struct WgradB3Params {
@@ -919,58 +942,93 @@ __device__ __forceinline__ bf16x8 window8(bf16x8 lo, bf16x8 hi) {
 }
 
 // taps [K0, K0 + KN) of a K-tap convolution (K = 11 runs as two launches of 6 + 5 taps: 11 accumulators would spill)
-template <int K, int DIL, int K0, int KN>
+// TILE = 64: workgroup tile 64 co x 64 ci, waves 2 x 2, every wave all four 16-position k-steps of a chunk.
+// TILE = 32: workgroup tile 32 co x 32 ci (the 16..96-channel long-row ResBlock layers, where a 64 x 64 tile is mostly
+//            padding and the exact-fp32 MFMA kernel ran at 15-60 TF/s): the four waves split the k-steps of a chunk and
+//            their partial tiles are summed through LDS in wave order (deterministic) before the one slab store.
+// Staging: LDS-DMA double buffer.  A stage is [dy hi][dy lo][x hi][x lo] with padded rows (PITCH / WP elements); the DMA
+// destination is lane-linear (16-byte slot s = row * slots_per_row + piece), the SOURCE address is per lane, so the row padding
+// costs one junk slot per row and nothing else; rows beyond Cout / Cin are clamped (their products are never stored).
+template <int K, int DIL, int K0, int KN, int TILE>
 __global__ __launch_bounds__(256, 2) void conv1d_wgrad_bf16x3_taps_kernel(WgradB3Params p) {
   constexpr int PITCH = 72;
   constexpr int BASE = (K0 * DIL) / 8 * 8;                // aligned start of the staged window (tap K0 begins at K0*DIL)
   constexpr int WIN = 64 + (K0 + KN - 1) * DIL - BASE;    // window positions
   constexpr int WP = ((WIN + 7) / 8 * 8 + 8) | 8;         // row pitch: an ODD number of 16-byte pieces (a 256-byte pitch
                                                           // would put all 32 rows of a fragment read on the same banks)
-  __shared__ __attribute__((aligned(16))) bf16 sm[2 * 64 * PITCH + 2 * 64 * WP];
-  bf16* ah = sm; bf16* al = sm + 64 * PITCH; bf16* bh = sm + 2 * 64 * PITCH; bf16* bl = bh + 64 * WP;
+  constexpr int AS = TILE * (PITCH / 8), BS = TILE * (WP / 8);            // 16-byte slots per dy / x array
+  constexpr int AC = (AS + 63) / 64, BC = (BS + 63) / 64;                 // 64-slot DMA chunks
+  constexpr int AI = (AC + 3) / 4, BI = (BC + 3) / 4;                     // ... per wave
+  constexpr int STAGE_EL = 2 * (AC + BC) * 512;
+  constexpr int RED_EL = TILE == 32 ? KN * 32 * 32 * 2 : 0;   // fp32 reduction buffer, in bf16 elements
+  extern __shared__ __attribute__((aligned(16))) float cm_smem[];
+  bf16* sm = reinterpret_cast<bf16*>(cm_smem);             // 2 stages (>= RED_EL, checked by the launcher)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, col = lane & 31;
-  const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64, split = blockIdx.z;
-  const int wco = wave & 1, wci = wave >> 1;
+  const int ci0 = blockIdx.x * TILE, co0 = blockIdx.y * TILE, split = blockIdx.z;
+  const int wco = TILE == 64 ? (wave & 1) : 0, wci = TILE == 64 ? (wave >> 1) : 0;
   f32x16 acc[KN];
 #pragma unroll
   for (int k = 0; k < KN; ++k)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
-  // stride 1: tap k reads x'[l + k*DIL + (PL - pad)] with PL == pad, parity copy 0 (element i holds x[i - pad])
-  for (int cc = 0; cc < p.chunks_per_block; ++cc) {
-    const int chunk = split * p.chunks_per_block + cc;
-    if (chunk >= p.nchunks) break;
+  // this lane's DMA sources relative to (batch element 0, position 0)
+  int aoff[AI], boff[BI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int sl = min((wave + 4 * i) * 64 + lane, AS - 1), row = sl / (PITCH / 8), pc = min(sl % (PITCH / 8), 7);
+    aoff[i] = min(co0 + row, p.Cout - 1) * p.Lq + pc * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int sl = min((wave + 4 * i) * 64 + lane, BS - 1), row = sl / (WP / 8), pc = sl % (WP / 8);
+    boff[i] = min(ci0 + row, p.Cin - 1) * p.Li + BASE + pc * 8;      // Li % 8 == 0, l0 % 64 == 0: 16-byte aligned, inside the row
+  }
+  const int64_t dyl_d = p.dyl - p.dyh, xl_d = p.xl - p.xh;
+  auto issue = [&](int chunk, int buf) {
     const int b = chunk / p.nlc, l0 = (chunk % p.nlc) * 64;
-    __syncthreads();
-    for (int i = tid; i < 64 * 8; i += 256) {
-      const int row = i >> 3, pc = i & 7;
-      bf16x8 vh = zero8(), vl = zero8();
-      if (co0 + row < p.Cout) {
-        const int64_t o = ((int64_t)b * p.Cout + co0 + row) * p.Lq + l0 + pc * 8;
-        vh = *reinterpret_cast<const bf16x8*>(p.dyh + o);
-        vl = *reinterpret_cast<const bf16x8*>(p.dyl + o);
+    const bf16* ga = p.dyh + (int64_t)b * p.Cout * p.Lq + l0;
+    const bf16* gb = p.xh + (int64_t)b * p.Cin * p.Li + l0;
+    bf16* st = sm + buf * STAGE_EL;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int c = wave + 4 * i;
+      if (c < AC) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + aoff[i]),
+                                         (__attribute__((address_space(3))) void*)(st + c * 512), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + aoff[i] + dyl_d),
+                                         (__attribute__((address_space(3))) void*)(st + (AC + c) * 512), 16, 0, 0);
       }
-      *reinterpret_cast<bf16x8*>(ah + row * PITCH + pc * 8) = vh;
-      *reinterpret_cast<bf16x8*>(al + row * PITCH + pc * 8) = vl;
     }
-    for (int i = tid; i < 64 * (WP / 8); i += 256) {
-      const int row = i / (WP / 8), pc = i % (WP / 8);
-      bf16x8 wh = zero8(), wl = zero8();
-      if (ci0 + row < p.Cin) {
-        const int64_t o = ((int64_t)b * p.Cin + ci0 + row) * p.Li + l0 + BASE + pc * 8;   // Li % 8 == 0, l0 % 64 == 0: 16-byte aligned
-        wh = *reinterpret_cast<const bf16x8*>(p.xh + o);
-        wl = *reinterpret_cast<const bf16x8*>(p.xl + o);
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int c = wave + 4 * i;
+      if (c < BC) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + boff[i]),
+                                         (__attribute__((address_space(3))) void*)(st + (2 * AC + c) * 512), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + boff[i] + xl_d),
+                                         (__attribute__((address_space(3))) void*)(st + (2 * AC + BC + c) * 512), 16, 0, 0);
       }
-      *reinterpret_cast<bf16x8*>(bh + row * WP + pc * 8) = wh;
-      *reinterpret_cast<bf16x8*>(bl + row * WP + pc * 8) = wl;
     }
-    __syncthreads();
+  };
+  // stride 1: tap k reads x'[l + k*DIL + (PL - pad)] with PL == pad, parity copy 0 (element i holds x[i - pad])
+  const int chunk0 = split * p.chunks_per_block;
+  const int nmine = max(0, min(p.chunks_per_block, p.nchunks - chunk0));
+  if (nmine > 0) issue(chunk0, 0);
+  for (int cc = 0; cc < nmine; ++cc) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                       // stage cc landed; the other buffer is free
+    if (cc + 1 < nmine) issue(chunk0 + cc + 1, (cc + 1) & 1);
+    const bf16* ah = sm + (cc & 1) * STAGE_EL;
+    const bf16* al = ah + AC * 512;
+    const bf16* bh = al + AC * 512;
+    const bf16* bl = bh + BC * 512;
     const bf16* arow_h = ah + (wco * 32 + col) * PITCH + hh * 8;
     const bf16* arow_l = al + (wco * 32 + col) * PITCH + hh * 8;
     const bf16* brow_h = bh + (wci * 32 + col) * WP + hh * 8;
     const bf16* brow_l = bl + (wci * 32 + col) * WP + hh * 8;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
+      if (TILE == 32 && ks != wave) continue;
       const bf16x8 a_h = *reinterpret_cast<const bf16x8*>(arow_h + ks * 16);
       const bf16x8 a_l = *reinterpret_cast<const bf16x8*>(arow_l + ks * 16);
 #pragma unroll
@@ -996,6 +1054,38 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad_bf16x3_taps_kernel(WgradB
       }
     }
   }
+  if (TILE == 32) {
+    // sum the four waves' partial tiles in wave order: red[k][reg][lane]
+    float* red = reinterpret_cast<float*>(sm);
+    __syncthreads();                                       // staging buffers are free
+    const int wv = __builtin_amdgcn_readfirstlane(wave);     // scalar: one branch per phase (a per-element `if (w == ...)` chain
+    if (wv == 0) {                                           // compiled to ~30 moves and 7 exec-mask branches per element)
+  #pragma unroll
+      for (int k = 0; k < KN; ++k)
+  #pragma unroll
+        for (int i = 0; i < 16; ++i) red[(k * 16 + i) * 64 + lane] = acc[k][i];
+    }
+    __syncthreads();
+    if (wv == 1) {
+  #pragma unroll
+      for (int k = 0; k < KN; ++k)
+  #pragma unroll
+        for (int i = 0; i < 16; ++i) red[(k * 16 + i) * 64 + lane] += acc[k][i];
+    }
+    __syncthreads();
+    if (wv == 2) {
+  #pragma unroll
+      for (int k = 0; k < KN; ++k)
+  #pragma unroll
+        for (int i = 0; i < 16; ++i) red[(k * 16 + i) * 64 + lane] += acc[k][i];
+    }
+    __syncthreads();
+    if (wv != 3) return;
+  #pragma unroll
+    for (int k = 0; k < KN; ++k)
+  #pragma unroll
+      for (int i = 0; i < 16; ++i) acc[k][i] += red[(k * 16 + i) * 64 + lane];
+  }
   const int ci = ci0 + wci * 32 + col;
   if (ci < p.Cin) {
     float* sl = p.slab + (int64_t)split * K * p.Cout * p.Cin;
@@ -1009,14 +1099,164 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad_bf16x3_taps_kernel(WgradB
   }
 }
 
+// ---- narrow layers (16..96 channels, long rows): ONE pass over the fp32 operands ------------------------------------------
+// The pre-split kernels above move every operand byte four times (fp32 read, bf16 hi/lo write, hi/lo read -- twice for K = 11);
+// with <= 96 channels there is almost no reuse to pay for that and the layer is HBM-bound.  Here a workgroup owns a 32 co x 32
+// ci tile and ALL K taps, reads the fp32 rows once, splits them into bf16 hi / lo on the way into LDS (two positions per
+// thread -> 4-byte LDS stores), and prefetches the next chunk into registers while the matrix cores work.  Wave w owns the
+// taps w, w + 4, w + 8 for all four 16-position k-steps of a chunk: <= 3 accumulators per wave (a wave holding all 11 taps
+// needs 392 registers: one workgroup per CU, nothing to hide the loads behind) and no cross-wave reduction.
+template <int K, int DIL, int W, int CH>
+__device__ __forceinline__ void fused_taps_compute(const bf16* ah, const bf16* al, const bf16* bh, const bf16* bl, int col, int hh,
+                                                   f32x16 (&acc)[3]) {
+  constexpr int PITCH = CH + 8;
+  constexpr int WIN = CH + (K - 1) * DIL, WP = ((WIN + 7) / 8 * 8 + 8) | 8;
+  constexpr int NT = W < K ? (K - W + 3) / 4 : 0;           // taps of this wave
+  const bf16* arow_h = ah + col * PITCH + hh * 8;
+  const bf16* arow_l = al + col * PITCH + hh * 8;
+  const bf16* brow_h = bh + col * WP + hh * 8;
+  const bf16* brow_l = bl + col * WP + hh * 8;
+#pragma unroll
+  for (int ks = 0; ks < CH / 16; ++ks) {
+    if (NT == 0) break;
+    const bf16x8 a_h = *reinterpret_cast<const bf16x8*>(arow_h + ks * 16);
+    const bf16x8 a_l = *reinterpret_cast<const bf16x8*>(arow_l + ks * 16);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int toff = (W + 4 * j) * DIL;                  // tap offset inside the window (compile-time after unrolling)
+      const int off = ks * 16 + (toff / 8) * 8;
+      const bf16x8 h0 = *reinterpret_cast<const bf16x8*>(brow_h + off), h1 = *reinterpret_cast<const bf16x8*>(brow_h + off + 8);
+      const bf16x8 l0v = *reinterpret_cast<const bf16x8*>(brow_l + off), l1v = *reinterpret_cast<const bf16x8*>(brow_l + off + 8);
+      bf16x8 b_h, b_l;
+      switch (toff & 7) {
+        case 0: b_h = h0; b_l = l0v; break;
+        case 1: b_h = window8<1>(h0, h1); b_l = window8<1>(l0v, l1v); break;
+        case 2: b_h = window8<2>(h0, h1); b_l = window8<2>(l0v, l1v); break;
+        case 3: b_h = window8<3>(h0, h1); b_l = window8<3>(l0v, l1v); break;
+        case 4: b_h = window8<4>(h0, h1); b_l = window8<4>(l0v, l1v); break;
+        case 5: b_h = window8<5>(h0, h1); b_l = window8<5>(l0v, l1v); break;
+        case 6: b_h = window8<6>(h0, h1); b_l = window8<6>(l0v, l1v); break;
+        default: b_h = window8<7>(h0, h1); b_l = window8<7>(l0v, l1v); break;
+      }
+      acc[j] = mfma32(a_l, b_h, acc[j]);
+      acc[j] = mfma32(a_h, b_l, acc[j]);
+      acc[j] = mfma32(a_h, b_h, acc[j]);
+    }
+  }
+}
+
+// CH = positions per chunk (64 or 128: the loop is bound by the load -> split -> LDS -> barrier round trip per chunk, so long
+// rows take 128)
+template <int K, int DIL, int CH>
+__global__ __launch_bounds__(256, 2) void conv1d_wgrad_fused_taps_kernel(WgradMfmaParams p) {
+  constexpr int PITCH = CH + 8;
+  constexpr int WIN = CH + (K - 1) * DIL;                 // staged window positions
+  constexpr int WP = ((WIN + 7) / 8 * 8 + 8) | 8;         // row pitch (odd number of 16-byte pieces)
+  constexpr int WPR = (WIN + 1) / 2;                      // position pairs per window row
+  constexpr int NA = CH / 16, NB = (32 * WPR + 255) / 256;   // pairs per thread: dy tile (32 rows x CH/2 pairs), x window
+  __shared__ __attribute__((aligned(16))) bf16 sm[2 * 32 * PITCH + 2 * 32 * WP];
+  bf16* ah = sm; bf16* al = sm + 32 * PITCH; bf16* bh = sm + 2 * 32 * PITCH; bf16* bl = bh + 32 * WP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, col = lane & 31;
+  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32, split = blockIdx.z;
+  const int nlc = (p.Lout + CH - 1) / CH, nchunks = p.B * nlc;
+  f32x16 acc[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
+  float ra[NA][2], rb[NB][2];
+  // (unconditional loads from clamped addresses + a select: a guarded load compiles to an exec-masked branch with its own
+  // s_waitcnt, which serialised the 48 loads of a chunk -- 11 us per chunk)
+  auto load_regs = [&](int chunk) {
+    const int b = chunk / nlc, l0 = (chunk % nlc) * CH;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int q = tid + 256 * i, row = q / (CH / 2), l = l0 + (q % (CH / 2)) * 2;
+      const float* src = p.dy + ((int64_t)b * p.Cout + min(co0 + row, p.Cout - 1)) * p.Lout;
+      const bool rok = co0 + row < p.Cout;
+      const float v0 = src[min(l, p.Lout - 1)], v1 = src[min(l + 1, p.Lout - 1)];
+      ra[i][0] = (rok && l < p.Lout) ? v0 : 0.f;
+      ra[i][1] = (rok && l + 1 < p.Lout) ? v1 : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int q = tid + 256 * i, row = q / WPR, g = l0 - p.pad + (q - row * WPR) * 2;
+      const float* src = p.x + ((int64_t)b * p.Cin + min(ci0 + min(row, 31), p.Cin - 1)) * p.Lin;
+      const bool rok = row < 32 && ci0 + row < p.Cin;
+      const float v0 = src[min(max(g, 0), p.Lin - 1)], v1 = src[min(max(g + 1, 0), p.Lin - 1)];
+      rb[i][0] = (rok && g >= 0 && g < p.Lin) ? v0 : 0.f;
+      rb[i][1] = (rok && g + 1 >= 0 && g + 1 < p.Lin) ? v1 : 0.f;
+    }
+  };
+  auto split2 = [](float v0, float v1, bf16x2& h, bf16x2& l) {
+    h[0] = (bf16)v0; h[1] = (bf16)v1;
+    l[0] = (bf16)(v0 - (float)h[0]); l[1] = (bf16)(v1 - (float)h[1]);
+  };
+  auto store_lds = [&]() {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int q = tid + 256 * i, row = q / (CH / 2), pj = q % (CH / 2);
+      bf16x2 h, l;
+      split2(lrelu_f(ra[i][0], p.dy_slope), lrelu_f(ra[i][1], p.dy_slope), h, l);
+      *reinterpret_cast<bf16x2*>(ah + row * PITCH + pj * 2) = h;
+      *reinterpret_cast<bf16x2*>(al + row * PITCH + pj * 2) = l;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int q = tid + 256 * i, row = q / WPR, pj = q - row * WPR;
+      if (row < 32) {
+        bf16x2 h, l;
+        split2(lrelu_f(rb[i][0], p.x_slope), lrelu_f(rb[i][1], p.x_slope), h, l);
+        *reinterpret_cast<bf16x2*>(bh + row * WP + pj * 2) = h;
+        *reinterpret_cast<bf16x2*>(bl + row * WP + pj * 2) = l;
+      }
+    }
+  };
+  const int chunk0 = split * p.chunks_per_block;
+  const int nmine = max(0, min(p.chunks_per_block, nchunks - chunk0));
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  if (nmine > 0) load_regs(chunk0);
+  for (int cc = 0; cc < nmine; ++cc) {
+    __syncthreads();                                       // everyone is done reading the previous chunk
+    store_lds();
+    __syncthreads();
+    if (cc + 1 < nmine) load_regs(chunk0 + cc + 1);        // in flight while the matrix cores run
+    if (wv == 0) fused_taps_compute<K, DIL, 0, CH>(ah, al, bh, bl, col, hh, acc);
+    else if (wv == 1) fused_taps_compute<K, DIL, 1, CH>(ah, al, bh, bl, col, hh, acc);
+    else if (wv == 2) fused_taps_compute<K, DIL, 2, CH>(ah, al, bh, bl, col, hh, acc);
+    else fused_taps_compute<K, DIL, 3, CH>(ah, al, bh, bl, col, hh, acc);
+  }
+  const int ci = ci0 + col;
+  if (ci < p.Cin) {
+    float* sl = p.slab + (int64_t)split * K * p.Cout * p.Cin;      // [split][k][co][ci], summed by wgrad_slab_reduce_kernel
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int k = wv + 4 * j;
+      if (k >= K) break;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int co = co0 + acc_row(i, hh);
+        if (co < p.Cout) sl[((int64_t)k * p.Cout + co) * p.Cin + ci] = acc[j][i];
+      }
+    }
+  }
+}
+
 // dw[co][ci][k] += sum_split slab[split][k][co][ci]
 __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsplit,
                                                                 int K, int Cout, int Cin) {
   const int64_t per = (int64_t)K * Cout * Cin;
   const int s0 = blockIdx.y * SLAB_G, s1 = min(nsplit, s0 + SLAB_G);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (int64_t)gridDim.x * 256) {
-    float s = 0.f;
-    for (int sp = s0; sp < s1; ++sp) s += slab[sp * per + i];
+    // four independent partial sums, four loads in flight per step (a plain `s += slab[...]` loop is one latency per split)
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int sp = s0;
+    for (; sp + 4 <= s1; sp += 4) {
+      const float v0 = slab[sp * per + i], v1 = slab[(sp + 1) * per + i], v2 = slab[(sp + 2) * per + i], v3 = slab[(sp + 3) * per + i];
+      a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+    }
+    for (; sp < s1; ++sp) a0 += slab[sp * per + i];
+    const float s = (a0 + a1) + (a2 + a3);
     const int ci = (int)(i % Cin), co = (int)((i / Cin) % Cout), k = (int)(i / Cin / Cout);
     float* o = dw + ((int64_t)co * Cin + ci) * K + k;
     if (gridDim.y == 1) *o += s;
@@ -1024,14 +1264,30 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __r
   }
 }
 
-template <int K, int DIL>
-static void launch_wgrad_taps(const WgradB3Params& p, dim3 grid, hipStream_t stream) {
+template <int K, int DIL, int K0, int KN, int TILE>
+static void launch_wgrad_taps_one(const WgradB3Params& p, dim3 grid, hipStream_t stream) {
+  constexpr int BASE = (K0 * DIL) / 8 * 8, WIN = 64 + (K0 + KN - 1) * DIL - BASE, WP = ((WIN + 7) / 8 * 8 + 8) | 8;
+  constexpr int AC = (TILE * 9 + 63) / 64, BC = (TILE * (WP / 8) + 63) / 64;
+  constexpr int STAGE_EL = 2 * (AC + BC) * 512, RED_EL = TILE == 32 ? KN * 32 * 32 * 2 : 0;
+  constexpr size_t smem = (size_t)(2 * STAGE_EL > RED_EL ? 2 * STAGE_EL : RED_EL) * sizeof(bf16);
+  static_assert(smem <= 160 * 1024, "taps stage too large");
+  static bool attr = false;
+  if (set_attr_once(reinterpret_cast<const void*>(conv1d_wgrad_bf16x3_taps_kernel<K, DIL, K0, KN, TILE>), attr)) return;
+  conv1d_wgrad_bf16x3_taps_kernel<K, DIL, K0, KN, TILE><<<grid, 256, smem, stream>>>(p);
+}
+template <int K, int DIL, int TILE>
+static void launch_wgrad_taps_t(const WgradB3Params& p, dim3 grid, hipStream_t stream) {
   if (K <= 7) {
-    conv1d_wgrad_bf16x3_taps_kernel<K, DIL, 0, (K <= 7 ? K : 1)><<<grid, 256, 0, stream>>>(p);
+    launch_wgrad_taps_one<K, DIL, 0, (K <= 7 ? K : 1), TILE>(p, grid, stream);
   } else {
-    conv1d_wgrad_bf16x3_taps_kernel<K, DIL, 0, 6><<<grid, 256, 0, stream>>>(p);
-    conv1d_wgrad_bf16x3_taps_kernel<K, DIL, 6, (K > 6 ? K - 6 : 1)><<<grid, 256, 0, stream>>>(p);
+    launch_wgrad_taps_one<K, DIL, 0, 6, TILE>(p, grid, stream);
+    launch_wgrad_taps_one<K, DIL, 6, (K > 6 ? K - 6 : 1), TILE>(p, grid, stream);
   }
+}
+template <int K, int DIL>
+static void launch_wgrad_taps(const WgradB3Params& p, dim3 grid, int tile, hipStream_t stream) {
+  if (tile == 32) launch_wgrad_taps_t<K, DIL, 32>(p, grid, stream);
+  else launch_wgrad_taps_t<K, DIL, 64>(p, grid, stream);
 }
 
 static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, int B, int Cin, int Lin, int Cout, int Lout,
@@ -1039,17 +1295,45 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, i
                                    hipStream_t stream, bool* handled) {
   *handled = false;
   if (!cx.ws || (cx.flags & 4096)) return TTTS_OK;
-  // all-taps kernel: stride 1, "same" padding of the ResBlock1 family (K in {3, 7, 11}, dilation in {1, 3, 5}), >= 32 channels
+  // all-taps kernel: stride 1, the ResBlock1 family (K in {3, 7, 11}, dilation in {1, 3, 5}).  64 x 64 tiles from 128
+  // channels (measured 1.9x over one tap per workgroup at C = 128 / 256); 32 x 32 tiles below (16..96-channel long rows: the
+  // exact-fp32 MFMA kernel they used to take ran at 15-60 TF/s).  Flag 16384: never; flag 1048576: not below 128 channels.
+  const bool wide_c = (int64_t)Cin * Cout > 128 * 128;     // pre-split 64 x 64 tiles above, the fused 32 x 32 kernel up to 128 x 128
+                                                           // channels (measured at 128: 153-167 us against 190; a tie at 256)
   const bool taps = stride == 1 && (K == 3 || K == 7 || K == 11) && (dil == 1 || dil == 3 || dil == 5) &&
-                    ((Cin >= 128 && Cout >= 128) || ((cx.flags & 8192) && Cin >= 32 && Cout >= 32)) &&   // measured: 1.9x at
-                    !(cx.flags & 16384);   // C = 128/256, slower below (one 64x64 tile: 512 slabs, or half-empty tiles)
+                    (wide_c || (Cin >= 16 && Cout >= 16 && !(cx.flags & 1048576))) && !(cx.flags & 16384);
+  const int TT = wide_c ? 64 : 32;
+  if (taps && !wide_c && !(cx.flags & 2097152)) {   // (flag 2097152: the pre-split kernels instead, for comparison)
+    const int CH = (Lout > 64 && !(K == 11 && dil >= 3)) ? 128 : 64;   // (K = 11 with dilation 3 / 5 would spill at 128)
+    const int nlc = (int)cdiv(Lout, CH), nchunks = B * nlc;
+    const int tiles = (int)(cdiv(Cin, 32) * cdiv(Cout, 32));
+    const int splits = (int)std::max<int64_t>(1, std::min<int64_t>(nchunks, cdiv(512, tiles)));
+    const int cpb = (int)cdiv(nchunks, splits), nsplit = (int)cdiv(nchunks, cpb);
+    const int64_t slab_bytes = (int64_t)nsplit * K * Cout * Cin * (int64_t)sizeof(float);
+    if (slab_bytes <= cx.ws_bytes) {
+      float* slab = static_cast<float*>(cx.ws);
+      WgradMfmaParams p{dy, x, dw, B, Cin, Lin, Cout, Lout, K, 1, pad, dil, dy_slope, x_slope, cpb, slab, 64};
+      dim3 grid((unsigned)cdiv(Cin, 32), (unsigned)cdiv(Cout, 32), (unsigned)nsplit);
+#define TTTS_FUSED(KK, DD)                                                                               \
+  if (K == KK && dil == DD) {                                                                            \
+    if (CH == 128) conv1d_wgrad_fused_taps_kernel<KK, DD, (KK == 11 && DD >= 3) ? 64 : 128><<<grid, 256, 0, stream>>>(p); \
+    else conv1d_wgrad_fused_taps_kernel<KK, DD, 64><<<grid, 256, 0, stream>>>(p);                        \
+  }
+      TTTS_FUSED(3, 1) TTTS_FUSED(3, 3) TTTS_FUSED(3, 5) TTTS_FUSED(7, 1) TTTS_FUSED(7, 3) TTTS_FUSED(7, 5)
+      TTTS_FUSED(11, 1) TTTS_FUSED(11, 3) TTTS_FUSED(11, 5)
+#undef TTTS_FUSED
+      wgrad_slab_reduce_kernel<<<dim3((unsigned)std::min<int64_t>(cdiv((int64_t)K * Cout * Cin, 256), 4096), (unsigned)cdiv(nsplit, SLAB_G)), 256, 0, stream>>>(slab, dw, nsplit, K, Cout, Cin);
+      *handled = true;
+      return check_launch("conv1d_wgrad_fused_taps");
+    }
+  }
   if (taps) {
     const int Lq = (int)(cdiv(Lout, 64) * 64);
     const int WPmax = ((64 + (K - 1) * dil + 7) / 8 * 8 + 8) | 8;
     const int Li = (int)(((int64_t)Lq + (K - 1) * dil + WPmax + 8 + 7) / 8 * 8);   // every staged 16-byte piece stays inside the row
     const int64_t dy_el = (int64_t)B * Cout * Lq, x_par = (int64_t)B * Cin * Li;
     const int nlc0 = Lq / 64, nchunks0 = B * nlc0;
-    const int tiles0 = (int)(cdiv(Cin, 64) * cdiv(Cout, 64));
+    const int tiles0 = (int)(cdiv(Cin, TT) * cdiv(Cout, TT));
     const int splits0 = (int)std::max<int64_t>(1, std::min<int64_t>(nchunks0, cdiv(512, tiles0)));
     const int cpb0 = (int)cdiv(nchunks0, splits0);
     const int nsplit = (int)cdiv(nchunks0, cpb0);
@@ -1060,13 +1344,12 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, i
       bf16* dyl = dyh + (dy_el + 7) / 8 * 8;
       bf16* xh = dyl + (dy_el + 7) / 8 * 8;
       bf16* xl = xh + 2 * x_par;
-      wgrad_split_dy_kernel<<<(int)std::min<int64_t>(cdiv(dy_el, 256), 8192), 256, 0, stream>>>(dy, dyh, dyl, (int64_t)B * Cout, Lout, Lq, dy_slope);
-      wgrad_split_x_kernel<<<(int)std::min<int64_t>(cdiv(2 * x_par, 256), 8192), 256, 0, stream>>>(x, xh, xl, (int64_t)B * Cin, Lin, 1, Li, pad, x_slope);
+      launch_wgrad_splits(dy, x, dyh, dyl, xh, xl, (int64_t)B * Cout, Lout, Lq, dy_slope, (int64_t)B * Cin, Lin, 1, Li, pad, x_slope, 1, stream);
       const int nlc = nlc0, nchunks = nchunks0, cpb = cpb0;
       float* slab = reinterpret_cast<float*>(reinterpret_cast<char*>(xl + 2 * x_par) + ((16 - (reinterpret_cast<uintptr_t>(xl + 2 * x_par) & 15)) & 15));
       WgradB3Params p{dyh, dyl, xh, xl, dw, B, Cin, Cout, K, 1, dil, Lq, Li, 0, x_par, cpb, nchunks, nlc, slab};
-      dim3 grid((unsigned)cdiv(Cin, 64), (unsigned)cdiv(Cout, 64), (unsigned)nsplit);
-#define TTTS_TAPS(KK, DD) if (K == KK && dil == DD) launch_wgrad_taps<KK, DD>(p, grid, stream);
+      dim3 grid((unsigned)cdiv(Cin, TT), (unsigned)cdiv(Cout, TT), (unsigned)nsplit);
+#define TTTS_TAPS(KK, DD) if (K == KK && dil == DD) launch_wgrad_taps<KK, DD>(p, grid, TT, stream);
       TTTS_TAPS(3, 1) TTTS_TAPS(3, 3) TTTS_TAPS(3, 5) TTTS_TAPS(7, 1) TTTS_TAPS(7, 3) TTTS_TAPS(7, 5)
       TTTS_TAPS(11, 1) TTTS_TAPS(11, 3) TTTS_TAPS(11, 5)
 #undef TTTS_TAPS
@@ -1091,8 +1374,7 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, i
   bf16* dyl = dyh + (dy_el + 7) / 8 * 8;
   bf16* xh = dyl + (dy_el + 7) / 8 * 8;
   bf16* xl = xh + x_el;
-  wgrad_split_dy_kernel<<<(int)std::min<int64_t>(cdiv(dy_el, 256), 8192), 256, 0, stream>>>(dy, dyh, dyl, (int64_t)B * Cout, Lout, Lq, dy_slope);
-  wgrad_split_x_kernel<<<(int)std::min<int64_t>(cdiv(x_el, 256), 8192), 256, 0, stream>>>(x, xh, xl, (int64_t)B * Cin, Lin, stride, Li, PL, x_slope);
+  launch_wgrad_splits(dy, x, dyh, dyl, xh, xl, (int64_t)B * Cout, Lout, Lq, dy_slope, (int64_t)B * Cin, Lin, stride, Li, PL, x_slope, 2, stream);
   const bool small = Cin <= 32 && Cout <= 32;
   const int TILE = small ? 32 : 64;
   const int nlc = Lq / 64, nchunks = B * nlc;
