@@ -79,6 +79,36 @@ def test_conv1d_family_vs_torch(case):
             _close(a.grad, r.grad, 5e-5, 1e-6, name)
 
 
+THIN_CASES = [  # Cin, Cout, K, stride, pad, L, B, act   (conv_thin.hip: one input channel / one output channel)
+    (1, 16, 7, 1, 3, 5000, 3, None), (1, 16, 15, 1, 7, 2500, 2, "lrelu"), (1, 32, 5, 3, 2, 1862, 5, "lrelu"),
+    (1, 32, 5, 3, 2, 700, 3, None), (1024, 1, 3, 1, 1, 23, 11, None), (256, 1, 3, 1, 1, 301, 2, None),
+]
+
+
+@pytest.mark.parametrize("case", THIN_CASES)
+def test_thin_conv_kernels_vs_torch(case):
+    """Streaming kernels for 1-channel inputs (forward + weight gradient) and 1-channel outputs (forward): exact fp32 fma
+    chains, compared with torch fp32 on the CPU at several chunk boundaries (rows longer than one 1024 / 2048-position chunk)."""
+    from ttts_amd import ops
+    cin, cout, k, s, pad, L, B, act = case
+    g = torch.Generator().manual_seed(cin * 7 + cout + k)
+    x = torch.randn(B, cin, L, generator=g)
+    w = torch.randn(cout, cin, k, generator=g) / (cin * k) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    xr = F.leaky_relu(x.double(), 0.1)
+    yr = F.conv1d(xr, w.double(), b.double(), stride=s, padding=pad)
+    if act == "lrelu":
+        yr = F.leaky_relu(yr, 0.2)
+    y = ops.conv1d_fwd(x.to(_dev()), w.to(_dev()), b.to(_dev()), None, s, pad, 1, in_slope=0.1, out_act=act, out_slope=0.2)
+    _close(y, yr, 2e-6, 1e-6, "y")
+    if cin == 1:
+        lout = yr.shape[2]
+        dy = torch.randn(B, cout, lout, generator=g)
+        dwr = torch.nn.grad.conv1d_weight(xr, (cout, cin, k), dy.double(), stride=s, padding=pad)
+        dw = ops.conv1d_wgrad(dy.to(_dev()), x.to(_dev()), k, s, pad, 1, x_slope=0.1)
+        _close(dw, dwr, 2e-5, 1e-5, "dw")
+
+
 CONVT_CASES = [  # Cin, Cout, K, stride, pad, L, in_slope
     (32, 16, 16, 8, 4, 40, 0.1),
     (16, 8, 2, 2, 0, 333, 0.1),

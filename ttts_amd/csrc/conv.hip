@@ -29,6 +29,14 @@ int conv1d_dgrad_strided_mfma_try(const float* dy, const float* w, const float* 
                                   int Lout, int K, int stride, int pad, float in_slope, float gate_slope, float out_scale,
                                   int accumulate, const ConvCtx& cx, hipStream_t stream, bool* handled);
 
+// conv_thin.hip: streaming kernels for one input channel / one output channel
+int conv1d_thin_fwd_try(const float* x, const float* w, const float* bias, const float* bbias, const float* resid,
+                        const float* gate, const float* omask, float* y, int B, int Cin, int Lin, int Cout, int Lout, int K,
+                        int stride, int pad, int dil, float in_slope, int out_act, float out_slope, float out_scale,
+                        int accumulate, hipStream_t stream, bool* handled);
+int conv1d_thin_wgrad_try(const float* dy, const float* x, float* dw, int B, int Cin, int Lin, int Cout, int Lout, int K,
+                          int stride, int pad, int dil, float dy_slope, float x_slope, hipStream_t stream, bool* handled);
+
 constexpr int CV_CT = 32;   // output-channel tile
 constexpr int CV_LT = 128;  // position tile
 constexpr int CV_CI = 8;    // input channels per LDS stage
@@ -578,6 +586,12 @@ extern "C" int ttts_conv1d_fwd_f32(const float* x, const float* w, const float* 
   TTTS_REQUIRE(out_act >= 0 && out_act <= 2, "conv1d_fwd: out_act must be 0 (none), 1 (tanh) or 2 (leaky-relu)");
   int rc = conv_check(B, Cin, Lin, Cout, Lout, K, stride, pad, dil, groups);
   if (rc) return rc;
+  if (groups == 1 && !(cx.flags & (256 | 8388608))) {   // (8388608: no thin-layer kernels, for comparison)
+    bool handled = false;
+    rc = conv1d_thin_fwd_try(x, w, bias, bbias, resid, gate, omask, y, B, Cin, Lin, Cout, Lout, K, stride, pad, dil, in_slope, out_act,
+                             out_slope, out_scale, accumulate, as_stream(stream), &handled);
+    if (rc || handled) return rc;
+  }
   if (groups == 1 && !(cx.flags & 256)) {
     bool handled = false;
     rc = conv1d_mfma_try(x, w, bias, bbias, resid, gate, omask, y, B, Cout, Cin, Lin, Lout, K, stride, pad, dil, 0, in_slope,
@@ -670,6 +684,11 @@ extern "C" int ttts_conv1d_wgrad_f32(const float* dy, const float* x, float* dw,
   TTTS_REQUIRE(!ctx || !ctx->workspace || aligned16(ctx->workspace), "conv1d_wgrad: ctx workspace must be 16-byte aligned");
   const ConvCtx cx = conv_ctx_of(ctx);
   TTTS_REQUIRE(groups > 0 && Cin % groups == 0 && Cout % groups == 0, "conv1d_wgrad: channels not divisible by groups");
+  if (groups == 1 && !(cx.flags & (256 | 8388608))) {
+    bool handled = false;
+    int rc2 = conv1d_thin_wgrad_try(dy, x, dw, B, Cin, Lin, Cout, Lout, K, stride, pad, dil, dy_slope, x_slope, as_stream(stream), &handled);
+    if (rc2 || handled) return rc2;
+  }
   if (groups == 1 && !(cx.flags & 256)) {
     bool handled = false;
     int rc2 = conv1d_wgrad_mfma_try(dy, x, dw, B, Cin, Lin, Cout, Lout, K, stride, pad, dil, dy_slope, x_slope,

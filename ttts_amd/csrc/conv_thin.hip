@@ -1,0 +1,216 @@
+// Thin convolutions: one input channel (the waveform-facing first layers: 1 -> 16 k7 / k15 over 163 840 samples, DiscriminatorP's
+// 1 -> 32 k5 stride 3) or one output channel (the discriminators' 1024 -> 1 k3 heads).  There is no GEMM in them -- a tile
+// kernel spends its time on padding (measured: 0.3 - 1.2 TF/s, 20-50x their HBM time) -- so these are plain streaming kernels:
+// every activation byte is read or written once, coalesced, the few weights sit in LDS / registers.
+#include <algorithm>
+
+#include "common.hpp"
+
+namespace ttts {
+
+__device__ __forceinline__ float thin_lrelu(float v, float s) { return v > 0.f ? v : v * s; }
+
+struct ThinFwdParams {
+  const float* x; const float* w; const float* bias; float* y;
+  int B, Lin, Cout, Lout, K, stride, pad, dil;
+  float in_slope; int out_act; float out_slope, out_scale;
+};
+
+// ---- forward, Cin = 1:  y[b][co][l] = act(bias[co] + sum_k w[co][k] * lrelu(x[b][l*stride - pad + k*dil])) * out_scale --------
+// workgroup = 256 threads x VEC positions (position j*256 + tid: dword loads / stores of a wave are one 256-byte run)
+constexpr int T1_VEC = 4, T1_KMAX = 16;
+__global__ __launch_bounds__(256) void conv1d_cin1_fwd_kernel(ThinFwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) float thin_smem[];
+  const int NP = 256 * T1_VEC;
+  const int win = (NP - 1) * p.stride + (p.K - 1) * p.dil + 1;
+  float* xs = thin_smem;                 // [win]
+  float* ws = thin_smem + win;           // [Cout][K]
+  const int tid = threadIdx.x, b = blockIdx.y, l0 = blockIdx.x * NP;
+  const int in0 = l0 * p.stride - p.pad;
+  const float* xr = p.x + (int64_t)b * p.Lin;
+  for (int i = tid; i < win; i += 256) {
+    const int g = in0 + i;
+    xs[i] = (g >= 0 && g < p.Lin) ? thin_lrelu(xr[g], p.in_slope) : 0.f;
+  }
+  for (int i = tid; i < p.Cout * p.K; i += 256) ws[i] = p.w[i];
+  __syncthreads();
+  float xv[T1_VEC][T1_KMAX];
+#pragma unroll
+  for (int j = 0; j < T1_VEC; ++j)
+#pragma unroll
+    for (int k = 0; k < T1_KMAX; ++k) xv[j][k] = k < p.K ? xs[(j * 256 + tid) * p.stride + k * p.dil] : 0.f;
+  for (int co = 0; co < p.Cout; ++co) {
+    const float bv = p.bias ? p.bias[co] : 0.f;
+    float acc[T1_VEC];
+#pragma unroll
+    for (int j = 0; j < T1_VEC; ++j) acc[j] = bv;
+#pragma unroll
+    for (int k = 0; k < T1_KMAX; ++k) {
+      if (k < p.K) {
+        const float wv = ws[co * p.K + k];             // same address in every lane: an LDS broadcast
+#pragma unroll
+        for (int j = 0; j < T1_VEC; ++j) acc[j] = fmaf(wv, xv[j][k], acc[j]);
+      }
+    }
+    float* yr = p.y + ((int64_t)b * p.Cout + co) * p.Lout;
+#pragma unroll
+    for (int j = 0; j < T1_VEC; ++j) {
+      const int l = l0 + j * 256 + tid;
+      float v = acc[j];
+      if (p.out_act == 1) v = tanhf(v);
+      else if (p.out_act == 2) v = thin_lrelu(v, p.out_slope);
+      if (l < p.Lout) yr[l] = v * p.out_scale;
+    }
+  }
+}
+
+// ---- weight gradient, Cin = 1:  dw[co][k] += sum_{b,l} lrelu(dy[b][co][l]) * lrelu(x[b][l*stride - pad + k*dil]) ---------------
+// workgroup = (batch element, chunk of T1_CH positions); wave w owns the rows co = w, w + 4, ...: RW x K accumulators per lane,
+// the x window of a 64-position block is read from LDS once and reused by all rows; one atomic per (co, k) and workgroup.
+constexpr int T1_CH = 2048;
+template <int K, int RW>
+__global__ __launch_bounds__(256) void conv1d_cin1_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                float* __restrict__ dw, int Lin, int Cout, int Lout, int stride,
+                                                                int pad, int dil, float dy_slope, float x_slope) {
+  extern __shared__ __attribute__((aligned(16))) float thin_smem[];
+  const int win = (T1_CH - 1) * stride + (K - 1) * dil + 1;
+  float* xs = thin_smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y, l0 = blockIdx.x * T1_CH;
+  const int in0 = l0 * stride - pad;
+  const float* xr = x + (int64_t)b * Lin;
+  for (int i = tid; i < win; i += 256) {
+    const int g = in0 + i;
+    xs[i] = (g >= 0 && g < Lin) ? thin_lrelu(xr[min(max(g, 0), Lin - 1)], x_slope) : 0.f;
+  }
+  __syncthreads();
+  float acc[RW][K];
+#pragma unroll
+  for (int r = 0; r < RW; ++r)
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[r][k] = 0.f;
+  const int nblk = min(T1_CH, Lout - l0);                // positions of this chunk
+  const float* dyb = dy + (int64_t)b * Cout * Lout + l0;
+  for (int pb = 0; pb < nblk; pb += 64) {
+    const int li = pb + lane;
+    const bool ok = li < nblk;
+    float xv[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) xv[k] = xs[min(li, T1_CH - 1) * stride + k * dil];
+    float dv[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const int co = min(wave + 4 * r, Cout - 1);
+      dv[r] = dyb[(int64_t)co * Lout + min(li, nblk - 1)];
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const float d = (ok && wave + 4 * r < Cout) ? thin_lrelu(dv[r], dy_slope) : 0.f;
+#pragma unroll
+      for (int k = 0; k < K; ++k) acc[r][k] = fmaf(d, xv[k], acc[r][k]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int co = wave + 4 * r;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float s = wave_sum(acc[r][k]);
+      if (lane == 0 && co < Cout) atomicAdd(dw + co * K + k, s);
+    }
+  }
+}
+
+// ---- forward, Cout = 1, stride 1:  y[b][0][l] = act(bias + sum_{ci,k} w[ci][k] * lrelu(x[b][ci][l - pad + k*dil])) -----------
+// positions of all batch elements flattened; workgroup = 16 positions x 16 channel groups, partial sums meet in LDS
+constexpr int TO_KMAX = 8;
+__global__ __launch_bounds__(256) void conv1d_cout1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, float* __restrict__ y, int B,
+                                                               int Cin, int Lin, int Lout, int K, int pad, int dil,
+                                                               float in_slope, int out_act, float out_slope, float out_scale) {
+  __shared__ float red[16][17];
+  const int tid = threadIdx.x, pi = tid & 15, cg = tid >> 4;
+  const int64_t P = (int64_t)B * Lout, pos = (int64_t)blockIdx.x * 16 + pi;
+  const bool pok = pos < P;
+  const int b = (int)(min(pos, P - 1) / Lout), l = (int)(min(pos, P - 1) % Lout);
+  int gi[TO_KMAX]; bool gok[TO_KMAX];
+#pragma unroll
+  for (int k = 0; k < TO_KMAX; ++k) {
+    const int g = l - pad + k * dil;
+    gok[k] = k < K && g >= 0 && g < Lin;
+    gi[k] = min(max(g, 0), Lin - 1);
+  }
+  float acc = 0.f;
+  const float* xb = x + (int64_t)b * Cin * Lin;
+#pragma unroll 4
+  for (int ci = cg; ci < Cin; ci += 16) {
+    const float* xr = xb + (int64_t)ci * Lin;
+    const float* wr = w + (int64_t)ci * K;
+#pragma unroll
+    for (int k = 0; k < TO_KMAX; ++k) {
+      if (k < K) {
+        const float v = xr[gi[k]];
+        acc = fmaf(wr[k], gok[k] ? thin_lrelu(v, in_slope) : 0.f, acc);
+      }
+    }
+  }
+  red[cg][pi] = acc;
+  __syncthreads();
+  if (tid < 16) {
+    float s = bias ? bias[0] : 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) s += red[g][tid];
+    if (out_act == 1) s = tanhf(s);
+    else if (out_act == 2) s = thin_lrelu(s, out_slope);
+    if (pok) y[pos] = s * out_scale;
+  }
+}
+
+// ---- dispatch (conv.hip) ------------------------------------------------------------------------------------------------------
+int conv1d_thin_fwd_try(const float* x, const float* w, const float* bias, const float* bbias, const float* resid,
+                        const float* gate, const float* omask, float* y, int B, int Cin, int Lin, int Cout, int Lout, int K,
+                        int stride, int pad, int dil, float in_slope, int out_act, float out_slope, float out_scale,
+                        int accumulate, hipStream_t stream, bool* handled) {
+  *handled = false;
+  if (bbias || resid || gate || omask || accumulate) return TTTS_OK;
+  if (Cin == 1 && K <= T1_KMAX && Cout <= 64) {
+    const int NP = 256 * T1_VEC;
+    const size_t smem = ((size_t)(NP - 1) * stride + (size_t)(K - 1) * dil + 1 + (size_t)Cout * K) * sizeof(float);
+    if (smem > 64 * 1024) return TTTS_OK;
+    ThinFwdParams p{x, w, bias, y, B, Lin, Cout, Lout, K, stride, pad, dil, in_slope, out_act, out_slope, out_scale};
+    conv1d_cin1_fwd_kernel<<<dim3((unsigned)cdiv(Lout, NP), (unsigned)B), 256, smem, stream>>>(p);
+    *handled = true;
+    return check_launch("conv1d_cin1_fwd");
+  }
+  if (Cout == 1 && stride == 1 && K <= TO_KMAX && Cin >= 64) {
+    conv1d_cout1_fwd_kernel<<<(unsigned)cdiv((int64_t)B * Lout, 16), 256, 0, stream>>>(x, w, bias, y, B, Cin, Lin, Lout, K, pad, dil, in_slope,
+                                                                                       out_act, out_slope, out_scale);
+    *handled = true;
+    return check_launch("conv1d_cout1_fwd");
+  }
+  return TTTS_OK;
+}
+
+template <int K, int RW>
+static int cin1_wgrad_launch(const float* dy, const float* x, float* dw, int B, int Lin, int Cout, int Lout, int stride, int pad,
+                             int dil, float dy_slope, float x_slope, hipStream_t stream) {
+  const size_t smem = ((size_t)(T1_CH - 1) * stride + (size_t)(K - 1) * dil + 1) * sizeof(float);
+  conv1d_cin1_wgrad_kernel<K, RW><<<dim3((unsigned)cdiv(Lout, T1_CH), (unsigned)B), 256, smem, stream>>>(dy, x, dw, Lin, Cout, Lout, stride, pad,
+                                                                                                      dil, dy_slope, x_slope);
+  return check_launch("conv1d_cin1_wgrad");
+}
+
+int conv1d_thin_wgrad_try(const float* dy, const float* x, float* dw, int B, int Cin, int Lin, int Cout, int Lout, int K,
+                          int stride, int pad, int dil, float dy_slope, float x_slope, hipStream_t stream, bool* handled) {
+  *handled = false;
+  if (Cin != 1 || (size_t)((T1_CH - 1) * stride + (K - 1) * dil + 1) * sizeof(float) > 60 * 1024) return TTTS_OK;
+  int rc = TTTS_OK;
+  if (K == 7 && Cout <= 16) rc = cin1_wgrad_launch<7, 4>(dy, x, dw, B, Lin, Cout, Lout, stride, pad, dil, dy_slope, x_slope, stream);
+  else if (K == 15 && Cout <= 16) rc = cin1_wgrad_launch<15, 4>(dy, x, dw, B, Lin, Cout, Lout, stride, pad, dil, dy_slope, x_slope, stream);
+  else if (K == 5 && Cout <= 32) rc = cin1_wgrad_launch<5, 8>(dy, x, dw, B, Lin, Cout, Lout, stride, pad, dil, dy_slope, x_slope, stream);
+  else if (K == 3 && Cout <= 32) rc = cin1_wgrad_launch<3, 8>(dy, x, dw, B, Lin, Cout, Lout, stride, pad, dil, dy_slope, x_slope, stream);
+  else return TTTS_OK;
+  *handled = rc == TTTS_OK;
+  return rc;
+}
+
+}  // namespace ttts
