@@ -37,6 +37,19 @@ int conv1d_thin_fwd_try(const float* x, const float* w, const float* bias, const
 int conv1d_thin_wgrad_try(const float* dy, const float* x, float* dw, int B, int Cin, int Lin, int Cout, int Lout, int K,
                           int stride, int pad, int dil, float dy_slope, float x_slope, hipStream_t stream, bool* handled);
 
+// conv_grouped.hip: few-channels-per-group convolutions on the f32-input matrix cores
+int conv1d_grouped_fwd_mfma_try(const float* x, const float* w, const float* bias, const float* bbias, const float* resid,
+                                const float* gate, const float* omask, float* y, int B, int Cin, int Lin, int Cout, int Lout,
+                                int K, int stride, int pad, int dil, int groups, float in_slope, float gate_slope, int out_act,
+                                float out_slope, float out_scale, int accumulate, hipStream_t stream, bool* handled);
+int conv1d_grouped_dgrad_mfma_try(const float* dy, const float* w, const float* bias, const float* resid, const float* gate,
+                                  const float* omask, float* dx, int B, int Cin, int Lin, int Cout, int Lout, int K, int stride,
+                                  int pad, int dil, int groups, float in_slope, float gate_slope, float out_scale, int accumulate,
+                                  hipStream_t stream, bool* handled);
+int conv1d_grouped_wgrad_mfma_try(const float* dy, const float* x, float* dw, int B, int Cin, int Lin, int Cout, int Lout, int K,
+                                  int stride, int pad, int dil, int groups, float dy_slope, float x_slope, const ConvCtx& cx,
+                                  hipStream_t stream, bool* handled);
+
 constexpr int CV_CT = 32;   // output-channel tile
 constexpr int CV_LT = 128;  // position tile
 constexpr int CV_CI = 8;    // input channels per LDS stage
@@ -598,6 +611,12 @@ extern "C" int ttts_conv1d_fwd_f32(const float* x, const float* w, const float* 
                          gate_slope, out_act, out_slope, out_scale, accumulate, cx, as_stream(stream), &handled);
     if (rc || handled) return rc;
   }
+  if (groups > 1 && !(cx.flags & (256 | 16777216))) {   // (16777216: the direct grouped kernels, for comparison)
+    bool handled = false;
+    rc = conv1d_grouped_fwd_mfma_try(x, w, bias, bbias, resid, gate, omask, y, B, Cin, Lin, Cout, Lout, K, stride, pad, dil, groups,
+                                     in_slope, gate_slope, out_act, out_slope, out_scale, accumulate, as_stream(stream), &handled);
+    if (rc || handled) return rc;
+  }
   const int lin_t = (CV_LT - 1) * stride + (K - 1) * dil + 1;
   if (groups > 1 && !(cx.flags & 256)) {
     const int cig = Cin / groups, cog = Cout / groups;
@@ -650,6 +669,12 @@ extern "C" int ttts_conv1d_dgrad_f32(const float* dy, const float* w, const floa
                                             gate_slope, out_scale, accumulate, cx, as_stream(stream), &handled);
     if (rc2 || handled) return rc2;
   }
+  if (groups > 1 && !(cx.flags & (256 | 16777216))) {
+    bool handled = false;
+    int rc2 = conv1d_grouped_dgrad_mfma_try(dy, w, bias, resid, gate, omask, dx, B, Cin, Lin, Cout, Lout, K, stride, pad, dil, groups,
+                                            in_slope, gate_slope, out_scale, accumulate, as_stream(stream), &handled);
+    if (rc2 || handled) return rc2;
+  }
   const int lt = (CV_LT - 1 + (K - 1) * dil) / stride + 2;
   if (groups > 1 && !(cx.flags & 256)) {
     const int cig = Cin / groups, cog = Cout / groups;
@@ -693,6 +718,12 @@ extern "C" int ttts_conv1d_wgrad_f32(const float* dy, const float* x, float* dw,
     bool handled = false;
     int rc2 = conv1d_wgrad_mfma_try(dy, x, dw, B, Cin, Lin, Cout, Lout, K, stride, pad, dil, dy_slope, x_slope,
                                     cx, as_stream(stream), &handled);
+    if (rc2 || handled) return rc2;
+  }
+  if (groups > 1 && !(cx.flags & (256 | 16777216))) {
+    bool handled = false;
+    int rc2 = conv1d_grouped_wgrad_mfma_try(dy, x, dw, B, Cin, Lin, Cout, Lout, K, stride, pad, dil, groups, dy_slope, x_slope, cx,
+                                            as_stream(stream), &handled);
     if (rc2 || handled) return rc2;
   }
   if (groups > 1 && !(cx.flags & 256)) {
