@@ -34,7 +34,7 @@ extern "C" {
 #define TTTS_EHIP (-2)         /* a HIP runtime call or kernel launch failed */
 #define TTTS_EUNSUPPORTED (-3) /* valid request this build has no kernel for */
 
-#define TTTS_ABI_VERSION 2
+#define TTTS_ABI_VERSION 3
 
 /* ---- library ------------------------------------------------------------------------------------ */
 int ttts_abi_version(void);
@@ -395,7 +395,9 @@ int ttts_conv1d_dgrad_f32(const float* dy, const float* w, const float* bias, co
                           int32_t Lout, int32_t K, int32_t stride, int32_t pad, int32_t dil, int32_t groups,
                           float in_slope, float gate_slope, float out_scale, int32_t accumulate,
                           const ttts_conv_ctx* ctx, void* stream);
-int ttts_conv1d_wgrad_f32(const float* dy, const float* x, float* dw, int32_t B, int32_t Cin, int32_t Lin,
+/* dw += weight gradient; db (optional, NULL to skip; requires dy_slope == 1): db[co] += sum_{b,l} dy[b][co][l], the bias
+ * gradient of the same layer, folded into the kernels that stream dy anyway (ABI v3; it was a separate pass over dy) */
+int ttts_conv1d_wgrad_f32(const float* dy, const float* x, float* dw, float* db, int32_t B, int32_t Cin, int32_t Lin,
                           int32_t Cout, int32_t Lout, int32_t K, int32_t stride, int32_t pad, int32_t dil,
                           int32_t groups, float dy_slope, float x_slope, const ttts_conv_ctx* ctx, void* stream);
 int ttts_conv1d_bias_grad_f32(const float* dy, float* db, int32_t B, int32_t C, int32_t L, void* stream);

@@ -22,8 +22,10 @@ int conv1d_mfma_try(const float* x, const float* w, const float* bias, const flo
                     const float* gate, const float* omask, float* y, int B, int M, int N, int Lin, int Lout, int K,
                     int stride, int pad, int dil, int transposed, float in_slope, float gate_slope, int out_act,
                     float out_slope, float out_scale, int accumulate, const ConvCtx& cx, hipStream_t stream, bool* handled);
-int conv1d_wgrad_mfma_try(const float* dy, const float* x, float* dw, int B, int Cin, int Lin, int Cout, int Lout, int K,
-                          int stride, int pad, int dil, float dy_slope, float x_slope, const ConvCtx& cx, hipStream_t stream, bool* handled);
+// db / db_done: bias gradient folded into the launch when the chosen kernel streams dy itself (*db_done set), else left to the caller
+int conv1d_wgrad_mfma_try(const float* dy, const float* x, float* dw, float* db, bool* db_done, int B, int Cin, int Lin, int Cout,
+                          int Lout, int K, int stride, int pad, int dil, float dy_slope, float x_slope, const ConvCtx& cx,
+                          hipStream_t stream, bool* handled);
 int conv1d_dgrad_strided_mfma_try(const float* dy, const float* w, const float* bias, const float* resid,
                                   const float* gate, const float* omask, float* dx, int B, int Cin, int Lin, int Cout,
                                   int Lout, int K, int stride, int pad, float in_slope, float gate_slope, float out_scale,
@@ -35,7 +37,7 @@ int conv1d_thin_fwd_try(const float* x, const float* w, const float* bias, const
                         int stride, int pad, int dil, float in_slope, int out_act, float out_slope, float out_scale,
                         int accumulate, hipStream_t stream, bool* handled);
 int conv1d_thin_wgrad_try(const float* dy, const float* x, float* dw, int B, int Cin, int Lin, int Cout, int Lout, int K,
-                          int stride, int pad, int dil, float dy_slope, float x_slope, hipStream_t stream, bool* handled);
+                          int stride, int pad, int dil, float dy_slope, float x_slope, const ConvCtx& cx, hipStream_t stream, bool* handled);
 
 // conv_grouped.hip: few-channels-per-group convolutions on the f32-input matrix cores
 int conv1d_grouped_fwd_mfma_try(const float* x, const float* w, const float* bias, const float* bbias, const float* resid,
@@ -702,7 +704,9 @@ extern "C" int ttts_conv1d_dgrad_f32(const float* dy, const float* w, const floa
   return check_launch("conv1d_dgrad");
 }
 
-extern "C" int ttts_conv1d_wgrad_f32(const float* dy, const float* x, float* dw, int32_t B, int32_t Cin, int32_t Lin,
+static int bias_grad_launch(const float* dy, float* db, int B, int C, int L, hipStream_t stream);
+
+static int conv1d_wgrad_impl(const float* dy, const float* x, float* dw, float* db, bool* db_done, int32_t B, int32_t Cin, int32_t Lin,
                                      int32_t Cout, int32_t Lout, int32_t K, int32_t stride, int32_t pad, int32_t dil,
                                      int32_t groups, float dy_slope, float x_slope, const ttts_conv_ctx* ctx, void* stream) {
   TTTS_REQUIRE(dy && x && dw, "conv1d_wgrad: null pointer");
@@ -711,12 +715,12 @@ extern "C" int ttts_conv1d_wgrad_f32(const float* dy, const float* x, float* dw,
   TTTS_REQUIRE(groups > 0 && Cin % groups == 0 && Cout % groups == 0, "conv1d_wgrad: channels not divisible by groups");
   if (groups == 1 && !(cx.flags & (256 | 8388608))) {
     bool handled = false;
-    int rc2 = conv1d_thin_wgrad_try(dy, x, dw, B, Cin, Lin, Cout, Lout, K, stride, pad, dil, dy_slope, x_slope, as_stream(stream), &handled);
+    int rc2 = conv1d_thin_wgrad_try(dy, x, dw, B, Cin, Lin, Cout, Lout, K, stride, pad, dil, dy_slope, x_slope, cx, as_stream(stream), &handled);
     if (rc2 || handled) return rc2;
   }
   if (groups == 1 && !(cx.flags & 256)) {
     bool handled = false;
-    int rc2 = conv1d_wgrad_mfma_try(dy, x, dw, B, Cin, Lin, Cout, Lout, K, stride, pad, dil, dy_slope, x_slope,
+    int rc2 = conv1d_wgrad_mfma_try(dy, x, dw, db, db_done, B, Cin, Lin, Cout, Lout, K, stride, pad, dil, dy_slope, x_slope,
                                     cx, as_stream(stream), &handled);
     if (rc2 || handled) return rc2;
   }
@@ -762,12 +766,26 @@ extern "C" int ttts_conv1d_wgrad_f32(const float* dy, const float* x, float* dw,
   return check_launch("conv1d_wgrad");
 }
 
-extern "C" int ttts_conv1d_bias_grad_f32(const float* dy, float* db, int32_t B, int32_t C, int32_t L, void* stream) {
-  TTTS_REQUIRE(dy && db && B > 0 && C > 0 && L > 0, "conv1d_bias_grad: bad arguments");
+extern "C" int ttts_conv1d_wgrad_f32(const float* dy, const float* x, float* dw, float* db, int32_t B, int32_t Cin, int32_t Lin,
+                                     int32_t Cout, int32_t Lout, int32_t K, int32_t stride, int32_t pad, int32_t dil,
+                                     int32_t groups, float dy_slope, float x_slope, const ttts_conv_ctx* ctx, void* stream) {
+  TTTS_REQUIRE(!db || dy_slope == 1.f, "conv1d_wgrad: the fused bias gradient needs dy_slope == 1");
+  bool db_done = false;
+  int rc = conv1d_wgrad_impl(dy, x, dw, db, &db_done, B, Cin, Lin, Cout, Lout, K, stride, pad, dil, groups, dy_slope, x_slope, ctx, stream);
+  if (rc || !db || db_done) return rc;
+  return bias_grad_launch(dy, db, B, Cout, Lout, as_stream(stream));     // the chosen kernel does not stream dy row-wise
+}
+
+static int bias_grad_launch(const float* dy, float* db, int B, int C, int L, hipStream_t stream) {
   const int lchunks = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(L, 2048), 64));
   const int splits = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)B * lchunks, cdiv(1024, C)));
-  conv1d_bias_grad_kernel<<<dim3(C, splits), 256, 0, as_stream(stream)>>>(dy, db, B, C, L, lchunks);
+  conv1d_bias_grad_kernel<<<dim3(C, splits), 256, 0, stream>>>(dy, db, B, C, L, lchunks);
   return check_launch("conv1d_bias_grad");
+}
+
+extern "C" int ttts_conv1d_bias_grad_f32(const float* dy, float* db, int32_t B, int32_t C, int32_t L, void* stream) {
+  TTTS_REQUIRE(dy && db && B > 0 && C > 0 && L > 0, "conv1d_bias_grad: bad arguments");
+  return bias_grad_launch(dy, db, B, C, L, as_stream(stream));
 }
 
 extern "C" int ttts_weight_norm_fwd_f32(const float* v, const float* g, float* w, float* norm, int32_t rows, int32_t n,

@@ -491,6 +491,7 @@ struct WgradMfmaParams {
   float* slab;         // non-NULL: per-split partial sums [split][Cout][Cin*K] (plain stores) instead of atomics into dw
   int SEGW;            // positions per segment of a 64-position reduction chunk: 64, or 16 for short rows (a chunk then holds
                        // 4 (batch element, 16-position window) segments: DiscriminatorP rows are 23..127 positions long)
+  float* bslab;        // fused-taps kernel: per-split row sums of dy [split][Cout] (the bias gradient), or NULL
 };
 constexpr int WM_L = 64;
 
@@ -679,7 +680,7 @@ static int conv1d_bf16x3_launch_t(ConvMfmaParams p, const ConvCtx& cx, hipStream
   p.SEG = SEG;
   const int lin_t = (LT / SEG) * ((SEG - 1) * p.stride + (K - 1) * p.dil + 1);
   const size_t smem = ((size_t)2 * lin_t * 16 + (size_t)2 * MT * (K * 16 + 8)) * sizeof(bf16);
-  if (smem > 64 * 1024) return TTTS_OK;
+  if (smem > 100 * 1024) return TTTS_OK;   // (long strips of the stride-8 / 10 resampling layers: one workgroup per CU still beats the direct kernel 5x)
   const int nblk = (p.N + 15) / 16;
   p.Mpad = (int)(cdiv(p.M, MT) * MT);
   const int64_t elems = (int64_t)nblk * p.Mpad * K * 16;
@@ -705,6 +706,10 @@ static int conv1d_mfma_launch(ConvMfmaParams p, const ConvCtx& cx, hipStream_t s
   if (cx.ws && p.N >= 16 && !(cx.flags & 4096)) {
     int rc = p.M <= 32 ? conv1d_bf16x3_launch_t<1>(p, cx, stream, handled) : conv1d_bf16x3_launch_t<2>(p, cx, stream, handled);
     if (rc || *handled) return rc;
+    if (p.M <= 32) {   // the 32 x 256 tile's input strip did not fit LDS (large stride): 64 x 128, half of its rows idle
+      rc = conv1d_bf16x3_launch_t<2>(p, cx, stream, handled);
+      if (rc || *handled) return rc;
+    }
   }
   // tile choice: always the largest tile.  Measured (tools/conv_bench.py, B = 32): the smaller tiles <2,2>, <1,2>, <1,1> --
   // meant to put more workgroups on a CU for the 192-channel x 256-frame layers -- are 2-2.5x SLOWER there (WN in_layer
@@ -804,17 +809,30 @@ int conv1d_dgrad_strided_mfma_try(const float* dy, const float* w, const float* 
 // (2-D grids: blockIdx.y walks rows, a thread converts two adjacent elements -- the flat-index form spent most of its time in
 // 64-bit divisions)
 __global__ __launch_bounds__(256) void wgrad_split_dy_kernel(const float* __restrict__ dy, bf16* __restrict__ hi,
-                                                             bf16* __restrict__ lo, int64_t rows, int Lout, int Lq, float slope) {
+                                                             bf16* __restrict__ lo, int64_t rows, int Lout, int Lq, float slope,
+                                                             float* __restrict__ db, int Cout) {
+  // db != NULL (slope == 1): the layer's bias gradient, db[row % Cout] += sum of the row -- this pass reads all of dy anyway.
+  // gridDim.y is a multiple of Cout then, so every row a workgroup walks belongs to the same channel.
+  __shared__ float sh[4];
   const int l = (blockIdx.x * 256 + threadIdx.x) * 2;
-  if (l >= Lq) return;
-  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
-    const float* src = dy + r * Lout;
-    const float v0 = l < Lout ? lrelu_f(src[l], slope) : 0.f, v1 = l + 1 < Lout ? lrelu_f(src[l + 1], slope) : 0.f;
-    bf16x2 h, w;
-    h[0] = (bf16)v0; h[1] = (bf16)v1;
-    w[0] = (bf16)(v0 - (float)h[0]); w[1] = (bf16)(v1 - (float)h[1]);
-    *reinterpret_cast<bf16x2*>(hi + r * Lq + l) = h;
-    *reinterpret_cast<bf16x2*>(lo + r * Lq + l) = w;
+  float bs = 0.f;
+  if (l < Lq) {
+    for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+      const float* src = dy + r * Lout;
+      const float v0 = l < Lout ? lrelu_f(src[l], slope) : 0.f, v1 = l + 1 < Lout ? lrelu_f(src[l + 1], slope) : 0.f;
+      bs += v0 + v1;
+      bf16x2 h, w;
+      h[0] = (bf16)v0; h[1] = (bf16)v1;
+      w[0] = (bf16)(v0 - (float)h[0]); w[1] = (bf16)(v1 - (float)h[1]);
+      *reinterpret_cast<bf16x2*>(hi + r * Lq + l) = h;
+      *reinterpret_cast<bf16x2*>(lo + r * Lq + l) = w;
+    }
+  }
+  if (db) {
+    bs = wave_sum(bs);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = bs;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(db + blockIdx.y % Cout, (sh[0] + sh[1]) + (sh[2] + sh[3]));
   }
 }
 // blockIdx.z = parity copy * stride + phase
@@ -840,9 +858,10 @@ __global__ __launch_bounds__(256) void wgrad_split_x_kernel(const float* __restr
 }
 static void launch_wgrad_splits(const float* dy, const float* x, bf16* dyh, bf16* dyl, bf16* xh, bf16* xl, int64_t rows_dy, int Lout,
                                 int Lq, float dy_slope, int64_t rows_x, int Lin, int stride, int Li, int PL, float x_slope, int npar,
-                                hipStream_t stream) {
-  wgrad_split_dy_kernel<<<dim3((unsigned)cdiv(Lq / 2, 256), (unsigned)std::min<int64_t>(rows_dy, 32768)), 256, 0, stream>>>(
-      dy, dyh, dyl, rows_dy, Lout, Lq, dy_slope);
+                                float* db, int Cout, hipStream_t stream) {
+  int64_t gy = std::min<int64_t>(rows_dy, 32768);
+  if (db && gy < rows_dy) gy = std::max<int64_t>(Cout, gy / Cout * Cout);       // rows r, r + gy, ... share a channel
+  wgrad_split_dy_kernel<<<dim3((unsigned)cdiv(Lq / 2, 256), (unsigned)gy), 256, 0, stream>>>(dy, dyh, dyl, rows_dy, Lout, Lq, dy_slope, db, Cout);
   wgrad_split_x_kernel<<<dim3((unsigned)cdiv(Li / 2, 256), (unsigned)std::min<int64_t>(rows_x, 32768), (unsigned)(npar * stride)), 256, 0, stream>>>(
       x, xh, xl, rows_x, Lin, stride, Li, PL, x_slope);
 }
@@ -1164,7 +1183,9 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad_fused_taps_kernel(WgradMf
   for (int k = 0; k < 3; ++k)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
-  float ra[NA][2], rb[NB][2];
+  float ra[NA][2], rb[NB][2], bsum[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) bsum[i] = 0.f;
   // (unconditional loads from clamped addresses + a select: a guarded load compiles to an exec-masked branch with its own
   // s_waitcnt, which serialised the 48 loads of a chunk -- 11 us per chunk)
   auto load_regs = [&](int chunk) {
@@ -1197,6 +1218,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad_fused_taps_kernel(WgradMf
     for (int i = 0; i < NA; ++i) {
       const int q = tid + 256 * i, row = q / (CH / 2), pj = q % (CH / 2);
       bf16x2 h, l;
+      bsum[i] += ra[i][0] + ra[i][1];
       split2(lrelu_f(ra[i][0], p.dy_slope), lrelu_f(ra[i][1], p.dy_slope), h, l);
       *reinterpret_cast<bf16x2*>(ah + row * PITCH + pj * 2) = h;
       *reinterpret_cast<bf16x2*>(al + row * PITCH + pj * 2) = l;
@@ -1226,6 +1248,18 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad_fused_taps_kernel(WgradMf
     else if (wv == 2) fused_taps_compute<K, DIL, 2, CH>(ah, al, bh, bl, col, hh, acc);
     else fused_taps_compute<K, DIL, 3, CH>(ah, al, bh, bl, col, hh, acc);
   }
+  if (p.bslab && blockIdx.x == 0) {
+    // bias gradient: row sums of dy seen by this split (a row of the tile belongs to one wave, or half-wave at CH = 64)
+    constexpr int RL = CH == 128 ? 64 : 32;                // lanes per row
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      float v = bsum[i];
+#pragma unroll
+      for (int o = RL / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      const int row = (tid + 256 * i) / (CH / 2);
+      if ((lane & (RL - 1)) == 0 && co0 + row < p.Cout) p.bslab[(int64_t)split * p.Cout + co0 + row] = v;
+    }
+  }
   const int ci = ci0 + col;
   if (ci < p.Cin) {
     float* sl = p.slab + (int64_t)split * K * p.Cout * p.Cin;      // [split][k][co][ci], summed by wgrad_slab_reduce_kernel
@@ -1244,7 +1278,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad_fused_taps_kernel(WgradMf
 
 // dw[co][ci][k] += sum_split slab[split][k][co][ci]
 __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsplit,
-                                                                int K, int Cout, int Cin) {
+                                                                int K, int Cout, int Cin, const float* __restrict__ bslab,
+                                                                float* __restrict__ db) {
   const int64_t per = (int64_t)K * Cout * Cin;
   const int s0 = blockIdx.y * SLAB_G, s1 = min(nsplit, s0 + SLAB_G);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (int64_t)gridDim.x * 256) {
@@ -1261,6 +1296,14 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __r
     float* o = dw + ((int64_t)co * Cin + ci) * K + k;
     if (gridDim.y == 1) *o += s;
     else atomicAdd(o, s);
+  }
+  if (bslab) {       // the fused kernel's per-split row sums of dy -> bias gradient
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < Cout; c += gridDim.x * 256) {
+      float s = 0.f;
+      for (int sp = s0; sp < s1; ++sp) s += bslab[(int64_t)sp * Cout + c];
+      if (gridDim.y == 1) db[c] += s;
+      else atomicAdd(db + c, s);
+    }
   }
 }
 
@@ -1290,9 +1333,9 @@ static void launch_wgrad_taps(const WgradB3Params& p, dim3 grid, int tile, hipSt
   else launch_wgrad_taps_t<K, DIL, 64>(p, grid, stream);
 }
 
-static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, int B, int Cin, int Lin, int Cout, int Lout,
-                                   int K, int stride, int pad, int dil, float dy_slope, float x_slope, const ConvCtx& cx,
-                                   hipStream_t stream, bool* handled) {
+static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, float* db, bool* db_done, int B, int Cin, int Lin,
+                                   int Cout, int Lout, int K, int stride, int pad, int dil, float dy_slope, float x_slope,
+                                   const ConvCtx& cx, hipStream_t stream, bool* handled) {
   *handled = false;
   if (!cx.ws || (cx.flags & 4096)) return TTTS_OK;
   // all-taps kernel: stride 1, the ResBlock1 family (K in {3, 7, 11}, dilation in {1, 3, 5}).  64 x 64 tiles from 128
@@ -1309,10 +1352,11 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, i
     const int tiles = (int)(cdiv(Cin, 32) * cdiv(Cout, 32));
     const int splits = (int)std::max<int64_t>(1, std::min<int64_t>(nchunks, cdiv(512, tiles)));
     const int cpb = (int)cdiv(nchunks, splits), nsplit = (int)cdiv(nchunks, cpb);
-    const int64_t slab_bytes = (int64_t)nsplit * K * Cout * Cin * (int64_t)sizeof(float);
+    const int64_t slab_bytes = (int64_t)nsplit * (K * Cout * Cin + Cout) * (int64_t)sizeof(float);
     if (slab_bytes <= cx.ws_bytes) {
       float* slab = static_cast<float*>(cx.ws);
-      WgradMfmaParams p{dy, x, dw, B, Cin, Lin, Cout, Lout, K, 1, pad, dil, dy_slope, x_slope, cpb, slab, 64};
+      float* bslab = db ? slab + (int64_t)nsplit * K * Cout * Cin : nullptr;
+      WgradMfmaParams p{dy, x, dw, B, Cin, Lin, Cout, Lout, K, 1, pad, dil, dy_slope, x_slope, cpb, slab, 64, bslab};
       dim3 grid((unsigned)cdiv(Cin, 32), (unsigned)cdiv(Cout, 32), (unsigned)nsplit);
 #define TTTS_FUSED(KK, DD)                                                                               \
   if (K == KK && dil == DD) {                                                                            \
@@ -1322,7 +1366,8 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, i
       TTTS_FUSED(3, 1) TTTS_FUSED(3, 3) TTTS_FUSED(3, 5) TTTS_FUSED(7, 1) TTTS_FUSED(7, 3) TTTS_FUSED(7, 5)
       TTTS_FUSED(11, 1) TTTS_FUSED(11, 3) TTTS_FUSED(11, 5)
 #undef TTTS_FUSED
-      wgrad_slab_reduce_kernel<<<dim3((unsigned)std::min<int64_t>(cdiv((int64_t)K * Cout * Cin, 256), 4096), (unsigned)cdiv(nsplit, SLAB_G)), 256, 0, stream>>>(slab, dw, nsplit, K, Cout, Cin);
+      wgrad_slab_reduce_kernel<<<dim3((unsigned)std::min<int64_t>(cdiv((int64_t)K * Cout * Cin, 256), 4096), (unsigned)cdiv(nsplit, SLAB_G)), 256, 0, stream>>>(slab, dw, nsplit, K, Cout, Cin, bslab, db);
+      if (db) *db_done = true;
       *handled = true;
       return check_launch("conv1d_wgrad_fused_taps");
     }
@@ -1344,7 +1389,8 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, i
       bf16* dyl = dyh + (dy_el + 7) / 8 * 8;
       bf16* xh = dyl + (dy_el + 7) / 8 * 8;
       bf16* xl = xh + 2 * x_par;
-      launch_wgrad_splits(dy, x, dyh, dyl, xh, xl, (int64_t)B * Cout, Lout, Lq, dy_slope, (int64_t)B * Cin, Lin, 1, Li, pad, x_slope, 1, stream);
+      launch_wgrad_splits(dy, x, dyh, dyl, xh, xl, (int64_t)B * Cout, Lout, Lq, dy_slope, (int64_t)B * Cin, Lin, 1, Li, pad, x_slope, 1, db, Cout, stream);
+      if (db) *db_done = true;
       const int nlc = nlc0, nchunks = nchunks0, cpb = cpb0;
       float* slab = reinterpret_cast<float*>(reinterpret_cast<char*>(xl + 2 * x_par) + ((16 - (reinterpret_cast<uintptr_t>(xl + 2 * x_par) & 15)) & 15));
       WgradB3Params p{dyh, dyl, xh, xl, dw, B, Cin, Cout, K, 1, dil, Lq, Li, 0, x_par, cpb, nchunks, nlc, slab};
@@ -1353,7 +1399,7 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, i
       TTTS_TAPS(3, 1) TTTS_TAPS(3, 3) TTTS_TAPS(3, 5) TTTS_TAPS(7, 1) TTTS_TAPS(7, 3) TTTS_TAPS(7, 5)
       TTTS_TAPS(11, 1) TTTS_TAPS(11, 3) TTTS_TAPS(11, 5)
 #undef TTTS_TAPS
-      wgrad_slab_reduce_kernel<<<dim3((unsigned)std::min<int64_t>(cdiv((int64_t)K * Cout * Cin, 256), 4096), (unsigned)cdiv(nsplit, SLAB_G)), 256, 0, stream>>>(slab, dw, nsplit, K, Cout, Cin);
+      wgrad_slab_reduce_kernel<<<dim3((unsigned)std::min<int64_t>(cdiv((int64_t)K * Cout * Cin, 256), 4096), (unsigned)cdiv(nsplit, SLAB_G)), 256, 0, stream>>>(slab, dw, nsplit, K, Cout, Cin, nullptr, nullptr);
       *handled = true;
       return check_launch("conv1d_wgrad_bf16x3_taps");
     }
@@ -1374,7 +1420,8 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, i
   bf16* dyl = dyh + (dy_el + 7) / 8 * 8;
   bf16* xh = dyl + (dy_el + 7) / 8 * 8;
   bf16* xl = xh + x_el;
-  launch_wgrad_splits(dy, x, dyh, dyl, xh, xl, (int64_t)B * Cout, Lout, Lq, dy_slope, (int64_t)B * Cin, Lin, stride, Li, PL, x_slope, 2, stream);
+  launch_wgrad_splits(dy, x, dyh, dyl, xh, xl, (int64_t)B * Cout, Lout, Lq, dy_slope, (int64_t)B * Cin, Lin, stride, Li, PL, x_slope, 2, db, Cout, stream);
+  if (db) *db_done = true;
   const bool small = Cin <= 32 && Cout <= 32;
   const int TILE = small ? 32 : 64;
   const int nlc = Lq / 64, nchunks = B * nlc;
@@ -1393,16 +1440,17 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, i
   dim3 grid((unsigned)cdiv(Cin, TILE), (unsigned)cdiv(Cout, TILE), (unsigned)(K * nsp));
   if (small) conv1d_wgrad_bf16x3_kernel<32><<<grid, 256, 0, stream>>>(p);
   else conv1d_wgrad_bf16x3_kernel<64><<<grid, 256, 0, stream>>>(p);
-  if (slab) wgrad_slab_reduce_kernel<<<dim3((unsigned)std::min<int64_t>(cdiv((int64_t)K * Cout * Cin, 256), 4096), (unsigned)cdiv(nsp, SLAB_G)), 256, 0, stream>>>(slab, dw, nsp, K, Cout, Cin);
+  if (slab) wgrad_slab_reduce_kernel<<<dim3((unsigned)std::min<int64_t>(cdiv((int64_t)K * Cout * Cin, 256), 4096), (unsigned)cdiv(nsp, SLAB_G)), 256, 0, stream>>>(slab, dw, nsp, K, Cout, Cin, nullptr, nullptr);
   *handled = true;
   return check_launch("conv1d_wgrad_bf16x3");
 }
 
-int conv1d_wgrad_mfma_try(const float* dy, const float* x, float* dw, int B, int Cin, int Lin, int Cout, int Lout, int K,
-                          int stride, int pad, int dil, float dy_slope, float x_slope, const ConvCtx& cx, hipStream_t stream, bool* handled) {
+int conv1d_wgrad_mfma_try(const float* dy, const float* x, float* dw, float* db, bool* db_done, int B, int Cin, int Lin, int Cout,
+                          int Lout, int K, int stride, int pad, int dil, float dy_slope, float x_slope, const ConvCtx& cx,
+                          hipStream_t stream, bool* handled) {
   *handled = false;
   {
-    int rc = conv1d_wgrad_bf16x3_try(dy, x, dw, B, Cin, Lin, Cout, Lout, K, stride, pad, dil, dy_slope, x_slope, cx, stream, handled);
+    int rc = conv1d_wgrad_bf16x3_try(dy, x, dw, db, db_done, B, Cin, Lin, Cout, Lout, K, stride, pad, dil, dy_slope, x_slope, cx, stream, handled);
     if (rc || *handled) return rc;
   }
   if (Cin * K < 32) return TTTS_OK;

@@ -70,8 +70,8 @@ __global__ __launch_bounds__(256) void conv1d_cin1_fwd_kernel(ThinFwdParams p) {
 constexpr int T1_CH = 2048;
 template <int K, int RW>
 __global__ __launch_bounds__(256) void conv1d_cin1_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                                float* __restrict__ dw, int Lin, int Cout, int Lout, int stride,
-                                                                int pad, int dil, float dy_slope, float x_slope) {
+                                                                float* __restrict__ dw, float* __restrict__ slab, int Lin, int Cout,
+                                                                int Lout, int stride, int pad, int dil, float dy_slope, float x_slope) {
   extern __shared__ __attribute__((aligned(16))) float thin_smem[];
   const int win = (T1_CH - 1) * stride + (K - 1) * dil + 1;
   float* xs = thin_smem;
@@ -109,15 +109,34 @@ __global__ __launch_bounds__(256) void conv1d_cin1_wgrad_kernel(const float* __r
       for (int k = 0; k < K; ++k) acc[r][k] = fmaf(d, xv[k], acc[r][k]);
     }
   }
+  // one partial per (workgroup, co, k): into the caller's slab when there is one (summed in a fixed order by
+  // thin_slab_sum_kernel) -- thousands of workgroups adding to the same 112 addresses serialise in L2 (measured: 1.05 ms of a
+  // 1.1 ms launch) -- else atomics
+  float* part = slab ? slab + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * Cout * K : nullptr;
 #pragma unroll
   for (int r = 0; r < RW; ++r) {
     const int co = wave + 4 * r;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const float s = wave_sum(acc[r][k]);
-      if (lane == 0 && co < Cout) atomicAdd(dw + co * K + k, s);
+      if (lane == 0 && co < Cout) {
+        if (part) part[co * K + k] = s;
+        else atomicAdd(dw + co * K + k, s);
+      }
     }
   }
+}
+
+// dw[i] += sum_p slab[p][i]: one workgroup per output element group, fixed summation order
+__global__ __launch_bounds__(256) void thin_slab_sum_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nparts, int per) {
+  __shared__ float sh[4];
+  const int i = blockIdx.x;
+  float s = 0.f;
+  for (int p = threadIdx.x; p < nparts; p += 256) s += slab[(int64_t)p * per + i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) dw[i] += (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
 // ---- forward, Cout = 1, stride 1:  y[b][0][l] = act(bias + sum_{ci,k} w[ci][k] * lrelu(x[b][ci][l - pad + k*dil])) -----------
@@ -192,22 +211,26 @@ int conv1d_thin_fwd_try(const float* x, const float* w, const float* bias, const
 
 template <int K, int RW>
 static int cin1_wgrad_launch(const float* dy, const float* x, float* dw, int B, int Lin, int Cout, int Lout, int stride, int pad,
-                             int dil, float dy_slope, float x_slope, hipStream_t stream) {
+                             int dil, float dy_slope, float x_slope, const ConvCtx& cx, hipStream_t stream) {
   const size_t smem = ((size_t)(T1_CH - 1) * stride + (size_t)(K - 1) * dil + 1) * sizeof(float);
-  conv1d_cin1_wgrad_kernel<K, RW><<<dim3((unsigned)cdiv(Lout, T1_CH), (unsigned)B), 256, smem, stream>>>(dy, x, dw, Lin, Cout, Lout, stride, pad,
-                                                                                                      dil, dy_slope, x_slope);
+  dim3 grid((unsigned)cdiv(Lout, T1_CH), (unsigned)B);
+  const int nparts = (int)(grid.x * grid.y), per = Cout * K;
+  float* slab = (cx.ws && nparts > 8 && (int64_t)nparts * per * (int64_t)sizeof(float) <= cx.ws_bytes) ? static_cast<float*>(cx.ws) : nullptr;
+  conv1d_cin1_wgrad_kernel<K, RW><<<grid, 256, smem, stream>>>(dy, x, dw, slab, Lin, Cout, Lout, stride, pad, dil, dy_slope, x_slope);
+  if (slab) thin_slab_sum_kernel<<<per, 256, 0, stream>>>(slab, dw, nparts, per);
   return check_launch("conv1d_cin1_wgrad");
 }
 
 int conv1d_thin_wgrad_try(const float* dy, const float* x, float* dw, int B, int Cin, int Lin, int Cout, int Lout, int K,
-                          int stride, int pad, int dil, float dy_slope, float x_slope, hipStream_t stream, bool* handled) {
+                          int stride, int pad, int dil, float dy_slope, float x_slope, const ConvCtx& cx, hipStream_t stream,
+                          bool* handled) {
   *handled = false;
   if (Cin != 1 || (size_t)((T1_CH - 1) * stride + (K - 1) * dil + 1) * sizeof(float) > 60 * 1024) return TTTS_OK;
   int rc = TTTS_OK;
-  if (K == 7 && Cout <= 16) rc = cin1_wgrad_launch<7, 4>(dy, x, dw, B, Lin, Cout, Lout, stride, pad, dil, dy_slope, x_slope, stream);
-  else if (K == 15 && Cout <= 16) rc = cin1_wgrad_launch<15, 4>(dy, x, dw, B, Lin, Cout, Lout, stride, pad, dil, dy_slope, x_slope, stream);
-  else if (K == 5 && Cout <= 32) rc = cin1_wgrad_launch<5, 8>(dy, x, dw, B, Lin, Cout, Lout, stride, pad, dil, dy_slope, x_slope, stream);
-  else if (K == 3 && Cout <= 32) rc = cin1_wgrad_launch<3, 8>(dy, x, dw, B, Lin, Cout, Lout, stride, pad, dil, dy_slope, x_slope, stream);
+  if (K == 7 && Cout <= 16) rc = cin1_wgrad_launch<7, 4>(dy, x, dw, B, Lin, Cout, Lout, stride, pad, dil, dy_slope, x_slope, cx, stream);
+  else if (K == 15 && Cout <= 16) rc = cin1_wgrad_launch<15, 4>(dy, x, dw, B, Lin, Cout, Lout, stride, pad, dil, dy_slope, x_slope, cx, stream);
+  else if (K == 5 && Cout <= 32) rc = cin1_wgrad_launch<5, 8>(dy, x, dw, B, Lin, Cout, Lout, stride, pad, dil, dy_slope, x_slope, cx, stream);
+  else if (K == 3 && Cout <= 32) rc = cin1_wgrad_launch<3, 8>(dy, x, dw, B, Lin, Cout, Lout, stride, pad, dil, dy_slope, x_slope, cx, stream);
   else return TTTS_OK;
   *handled = rc == TTTS_OK;
   return rc;

@@ -63,7 +63,7 @@ _c = ctypes
 _P, _I32, _I64, _U64, _F = _c.c_void_p, _c.c_int32, _c.c_int64, _c.c_uint64, _c.c_float
 
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class ConvCtx(ctypes.Structure):
@@ -149,7 +149,7 @@ SIGNATURES = {
                                    _F, _F, _I32, _F, _F, _I32, _P, _P]),
     "ttts_conv1d_dgrad_f32": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32,
                                      _F, _F, _F, _I32, _P, _P]),
-    "ttts_conv1d_wgrad_f32": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _F, _F,
+    "ttts_conv1d_wgrad_f32": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _F, _F,
                                      _P, _P]),
     "ttts_lrelu_bwd_f32": (_I32, [_P, _P, _P, _F, _I64, _P]),
     "ttts_conv1d_bias_grad_f32": (_I32, [_P, _P, _I32, _I32, _I32, _P]),

@@ -652,13 +652,14 @@ def conv1d_dgrad(dy, w, lin, stride=1, pad=0, dil=1, gate=None, gate_slope=1.0, 
     return dx
 
 
-def conv1d_wgrad(dy, x, k, stride=1, pad=0, dil=1, x_slope=1.0, dy_slope=1.0, out=None, groups=1):
-    """dw (Cout,Cin/groups,k) [+]= sum_{b,l} lrelu(dy, dy_slope) * lrelu(x, x_slope) (shifted); `out` accumulates."""
+def conv1d_wgrad(dy, x, k, stride=1, pad=0, dil=1, x_slope=1.0, dy_slope=1.0, out=None, groups=1, db=None):
+    """dw (Cout,Cin/groups,k) [+]= sum_{b,l} lrelu(dy, dy_slope) * lrelu(x, x_slope) (shifted); `out` accumulates.
+    db (Cout,), optional: db += sum_{b,l} dy in the same call (the layer's bias gradient; needs dy_slope == 1)."""
     dy = dy.contiguous(); x = x.contiguous()
     B, Cout, Lout = dy.shape
     _, Cin, Lin = x.shape
     dw = out if out is not None else torch.zeros(Cout, Cin // groups, k, dtype=torch.float32, device=dy.device)
-    check(_l.get().ttts_conv1d_wgrad_f32(_p(dy), _p(x), _p(dw), B, Cin, Lin, Cout, Lout, k, stride, pad, dil, groups, dy_slope,
+    check(_l.get().ttts_conv1d_wgrad_f32(_p(dy), _p(x), _p(dw), _p(db), B, Cin, Lin, Cout, Lout, k, stride, pad, dil, groups, dy_slope,
                                          x_slope, _conv_ctx(dy.device), _stream()), "conv1d_wgrad")
     return dw
 

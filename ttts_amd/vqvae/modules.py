@@ -88,16 +88,20 @@ class _Conv1dFn(torch.autograd.Function):
         if need[0]:
             gate = x if in_slope != 1.0 else None
             dx = ops.conv1d_dgrad(dy, w, x.shape[2], stride, pad, dil, gate=gate, gate_slope=in_slope, groups=groups)
+        want_b = has_b and need[2]
+        bslot = _grad_slot(ctx.refs[1]) if want_b else None
         if need[1]:
             slot = _grad_slot(ctx.refs[0])
-            dw = ops.conv1d_wgrad(dy, x, w.shape[2], stride, pad, dil, x_slope=in_slope, groups=groups, out=slot)
+            if want_b:      # the bias gradient rides on the weight-gradient call (its kernels stream dy anyway)
+                db = bslot if bslot is not None else torch.zeros(dy.shape[1], dtype=torch.float32, device=dy.device)
+            dw = ops.conv1d_wgrad(dy, x, w.shape[2], stride, pad, dil, x_slope=in_slope, groups=groups, out=slot,
+                                  db=db if want_b else None)
             if slot is not None:
                 dw = None
-        if has_b and need[2]:
-            slot = _grad_slot(ctx.refs[1])
-            db = ops.conv1d_bias_grad(dy, out=slot)
-            if slot is not None:
-                db = None
+        elif want_b:
+            db = ops.conv1d_bias_grad(dy, out=bslot)
+        if bslot is not None:
+            db = None
         if has_bb and need[4]:
             B, C, L = dy.shape
             dbb = ops.conv1d_bias_grad(dy.view(1, B * C, L)).view(B, C)
@@ -485,24 +489,21 @@ class _WNFn(torch.autograd.Function):
             if i < n_layers - 1:
                 dacts = ops.conv1d_dgrad(dres, w_rs[:H], T)
                 ops.conv1d_dgrad(dsk, w_rs[H:], T, out=dacts, accumulate=True)
-                ops.conv1d_wgrad(dres, acts, 1, out=dw_rs[:H])
-                ops.conv1d_wgrad(dsk, acts, 1, out=dw_rs[H:])
-                if direct:
-                    ops.conv1d_bias_grad(dres, out=slots[5][:H]); ops.conv1d_bias_grad(dsk, out=slots[5][H:])
-                    db_rs = None
-                else:
-                    db_rs = torch.cat([ops.conv1d_bias_grad(dres), ops.conv1d_bias_grad(dsk)])
+                # (bias gradients ride on the weight-gradient calls: the kernels stream dy anyway)
+                db_t = slots[5] if direct else torch.zeros_like(rs_b)
+                ops.conv1d_wgrad(dres, acts, 1, out=dw_rs[:H], db=db_t[:H])
+                ops.conv1d_wgrad(dsk, acts, 1, out=dw_rs[H:], db=db_t[H:])
+                db_rs = None if direct else db_t
             else:
                 dacts = ops.conv1d_dgrad(dsk, w_rs, T)
-                ops.conv1d_wgrad(dsk, acts, 1, out=dw_rs)
-                db_rs = ops.conv1d_bias_grad(dsk, out=slots[5] if direct else None)
-                if direct:
-                    db_rs = None
+                db_t = slots[5] if direct else torch.zeros_like(rs_b)
+                ops.conv1d_wgrad(dsk, acts, 1, out=dw_rs, db=db_t)
+                db_rs = None if direct else db_t
             dx_in = ops.gate_bwd(dacts, x_in, ops.GATE_TANH_SIGMOID)
             if has_g:
                 dgs[i] = ops.conv1d_bias_grad(dx_in.view(1, B * 2 * H, T)).view(B, 2 * H)
-            db_in = ops.conv1d_bias_grad(dx_in, out=slots[2] if direct else None)
-            dw_in = ops.conv1d_wgrad(dx_in, xi, K, 1, pad, dil)
+            db_in = slots[2] if direct else torch.zeros_like(in_b)
+            dw_in = ops.conv1d_wgrad(dx_in, xi, K, 1, pad, dil, db=db_in)
             dres = ops.conv1d_dgrad(dx_in, w_in, T, 1, pad, dil, resid=dres, omask=m2 if i > 0 else None)
             if direct:
                 ops.weight_norm_bwd(dw_in, in_v, in_g, n_in, dv=slots[0], dg=slots[1])
