@@ -856,6 +856,42 @@ __global__ __launch_bounds__(256) void wgrad_split_x_kernel(const float* __restr
     *reinterpret_cast<bf16x2*>(lo + o) = w;
   }
 }
+// Short rows (DiscriminatorP: 23..127 positions, hundreds of rows): the batch elements of a channel are laid end to end as ONE
+// virtual row, Lg = Lout + (K-1)*dil positions apart (zeros in between, so taps never reach the next element):
+//   dy'[co][b*Lg + j] = dy[b][co][j],   x'[ci][b*Lg + j] = x[b][ci][j - pad]
+// and sum_v dy'[v] x'[v + k*dil] is exactly the batch-summed weight gradient.  The all-taps kernel then runs with B = 1 and
+// 64-position chunks that are ~full instead of one mostly-padding chunk per row (L = 23: 36 % -> 85 % useful positions).
+__global__ __launch_bounds__(256) void wgrad_split_cat_kernel(const float* __restrict__ src, bf16* __restrict__ hi, bf16* __restrict__ lo,
+                                                              int B, int C, int L, int Lg, int shift, int Lrow, float slope,
+                                                              float* __restrict__ db) {
+  // blockIdx.y = channel; element v of the virtual row: b = v / Lg, j = v % Lg, source position j - shift
+  __shared__ float sh[4];
+  const int c = blockIdx.y, v0 = (blockIdx.x * 256 + threadIdx.x) * 2;
+  float bs = 0.f;
+  if (v0 < Lrow) {
+    float val[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int v = v0 + e, b = v / Lg, j = v - b * Lg - shift;
+      const bool ok = b < B && j >= 0 && j < L;
+      const float t = src[((int64_t)min(b, B - 1) * C + c) * L + min(max(j, 0), L - 1)];
+      val[e] = ok ? lrelu_f(t, slope) : 0.f;
+    }
+    bs = val[0] + val[1];
+    bf16x2 h, w;
+    h[0] = (bf16)val[0]; h[1] = (bf16)val[1];
+    w[0] = (bf16)(val[0] - (float)h[0]); w[1] = (bf16)(val[1] - (float)h[1]);
+    *reinterpret_cast<bf16x2*>(hi + (int64_t)c * Lrow + v0) = h;
+    *reinterpret_cast<bf16x2*>(lo + (int64_t)c * Lrow + v0) = w;
+  }
+  if (db) {
+    bs = wave_sum(bs);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = bs;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(db + c, (sh[0] + sh[1]) + (sh[2] + sh[3]));
+  }
+}
+
 static void launch_wgrad_splits(const float* dy, const float* x, bf16* dyh, bf16* dyl, bf16* xh, bf16* xl, int64_t rows_dy, int Lout,
                                 int Lq, float dy_slope, int64_t rows_x, int Lin, int stride, int Li, int PL, float x_slope, int npar,
                                 float* db, int Cout, hipStream_t stream) {
@@ -1329,8 +1365,8 @@ static void launch_wgrad_taps_t(const WgradB3Params& p, dim3 grid, hipStream_t s
 }
 template <int K, int DIL>
 static void launch_wgrad_taps(const WgradB3Params& p, dim3 grid, int tile, hipStream_t stream) {
-  if (tile == 32) launch_wgrad_taps_t<K, DIL, 32>(p, grid, stream);
-  else launch_wgrad_taps_t<K, DIL, 64>(p, grid, stream);
+  (void)tile;      // (a 32 x 32 variant of this pre-split kernel lost to the fused single-pass kernel below 128 channels)
+  launch_wgrad_taps_t<K, DIL, 64>(p, grid, stream);
 }
 
 static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, float* db, bool* db_done, int B, int Cin, int Lin,
@@ -1343,7 +1379,8 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, f
   // exact-fp32 MFMA kernel they used to take ran at 15-60 TF/s).  Flag 16384: never; flag 1048576: not below 128 channels.
   const bool wide_c = (int64_t)Cin * Cout > 128 * 128;     // pre-split 64 x 64 tiles above, the fused 32 x 32 kernel up to 128 x 128
                                                            // channels (measured at 128: 153-167 us against 190; a tie at 256)
-  const bool taps = stride == 1 && (K == 3 || K == 7 || K == 11) && (dil == 1 || dil == 3 || dil == 5) &&
+  const bool k5 = K == 5 && dil == 1 && wide_c;          // (DiscriminatorP / S and the WN in-layers; pre-split kernel only)
+  const bool taps = stride == 1 && (((K == 3 || K == 7 || K == 11) && (dil == 1 || dil == 3 || dil == 5)) || k5) &&
                     (wide_c || (Cin >= 16 && Cout >= 16 && !(cx.flags & 1048576))) && !(cx.flags & 16384);
   const int TT = wide_c ? 64 : 32;
   if (taps && !wide_c && !(cx.flags & 2097152)) {   // (flag 2097152: the pre-split kernels instead, for comparison)
@@ -1373,12 +1410,16 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, f
     }
   }
   if (taps) {
-    const int Lq = (int)(cdiv(Lout, 64) * 64);
+    // short rows: all batch elements of a channel as one virtual row (wgrad_split_cat_kernel)
+    const int Lg = Lout + (K - 1) * dil;
+    const bool cat = B > 1 && cdiv(Lout, 64) * 64 * 100 > (int64_t)Lg * 115;
+    const int Bk = cat ? 1 : B;                                                  // batch elements as the kernel sees them
+    const int Lq = (int)(cdiv(cat ? (int64_t)B * Lg : Lout, 64) * 64);
     const int WPmax = ((64 + (K - 1) * dil + 7) / 8 * 8 + 8) | 8;
     const int Li = (int)(((int64_t)Lq + (K - 1) * dil + WPmax + 8 + 7) / 8 * 8);   // every staged 16-byte piece stays inside the row
-    const int64_t dy_el = (int64_t)B * Cout * Lq, x_par = (int64_t)B * Cin * Li;
-    const int nlc0 = Lq / 64, nchunks0 = B * nlc0;
-    const int tiles0 = (int)(cdiv(Cin, TT) * cdiv(Cout, TT));
+    const int64_t dy_el = (int64_t)Bk * Cout * Lq, x_par = (int64_t)Bk * Cin * Li;
+    const int nlc0 = Lq / 64, nchunks0 = Bk * nlc0;
+    const int tiles0 = (int)(cdiv(Cin, 64) * cdiv(Cout, 64));
     const int splits0 = (int)std::max<int64_t>(1, std::min<int64_t>(nchunks0, cdiv(512, tiles0)));
     const int cpb0 = (int)cdiv(nchunks0, splits0);
     const int nsplit = (int)cdiv(nchunks0, cpb0);
@@ -1389,14 +1430,19 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, f
       bf16* dyl = dyh + (dy_el + 7) / 8 * 8;
       bf16* xh = dyl + (dy_el + 7) / 8 * 8;
       bf16* xl = xh + 2 * x_par;
-      launch_wgrad_splits(dy, x, dyh, dyl, xh, xl, (int64_t)B * Cout, Lout, Lq, dy_slope, (int64_t)B * Cin, Lin, 1, Li, pad, x_slope, 1, db, Cout, stream);
+      if (cat) {
+        wgrad_split_cat_kernel<<<dim3((unsigned)cdiv(Lq / 2, 256), (unsigned)Cout), 256, 0, stream>>>(dy, dyh, dyl, B, Cout, Lout, Lg, 0, Lq, dy_slope, db);
+        wgrad_split_cat_kernel<<<dim3((unsigned)cdiv(Li / 2, 256), (unsigned)Cin), 256, 0, stream>>>(x, xh, xl, B, Cin, Lin, Lg, pad, Li, x_slope, nullptr);
+      } else {
+        launch_wgrad_splits(dy, x, dyh, dyl, xh, xl, (int64_t)B * Cout, Lout, Lq, dy_slope, (int64_t)B * Cin, Lin, 1, Li, pad, x_slope, 1, db, Cout, stream);
+      }
       if (db) *db_done = true;
       const int nlc = nlc0, nchunks = nchunks0, cpb = cpb0;
       float* slab = reinterpret_cast<float*>(reinterpret_cast<char*>(xl + 2 * x_par) + ((16 - (reinterpret_cast<uintptr_t>(xl + 2 * x_par) & 15)) & 15));
-      WgradB3Params p{dyh, dyl, xh, xl, dw, B, Cin, Cout, K, 1, dil, Lq, Li, 0, x_par, cpb, nchunks, nlc, slab};
-      dim3 grid((unsigned)cdiv(Cin, TT), (unsigned)cdiv(Cout, TT), (unsigned)nsplit);
-#define TTTS_TAPS(KK, DD) if (K == KK && dil == DD) launch_wgrad_taps<KK, DD>(p, grid, TT, stream);
-      TTTS_TAPS(3, 1) TTTS_TAPS(3, 3) TTTS_TAPS(3, 5) TTTS_TAPS(7, 1) TTTS_TAPS(7, 3) TTTS_TAPS(7, 5)
+      WgradB3Params p{dyh, dyl, xh, xl, dw, Bk, Cin, Cout, K, 1, dil, Lq, Li, 0, x_par, cpb, nchunks, nlc, slab};
+      dim3 grid((unsigned)cdiv(Cin, 64), (unsigned)cdiv(Cout, 64), (unsigned)nsplit);
+#define TTTS_TAPS(KK, DD) if (K == KK && dil == DD) launch_wgrad_taps<KK, DD>(p, grid, 64, stream);
+      TTTS_TAPS(3, 1) TTTS_TAPS(3, 3) TTTS_TAPS(3, 5) TTTS_TAPS(5, 1) TTTS_TAPS(7, 1) TTTS_TAPS(7, 3) TTTS_TAPS(7, 5)
       TTTS_TAPS(11, 1) TTTS_TAPS(11, 3) TTTS_TAPS(11, 5)
 #undef TTTS_TAPS
       wgrad_slab_reduce_kernel<<<dim3((unsigned)std::min<int64_t>(cdiv((int64_t)K * Cout * Cin, 256), 4096), (unsigned)cdiv(nsplit, SLAB_G)), 256, 0, stream>>>(slab, dw, nsplit, K, Cout, Cin, nullptr, nullptr);
