@@ -178,11 +178,14 @@ __global__ __launch_bounds__(256) void conv_input_split_kernel(const float* __re
     const int pp = (int)(i % Lp), nb = (int)((i / Lp) % nblk), pos = pp - PADL;
     const int64_t b = i / Lp / nblk;
     const bool inside = pos >= 0 && pos < L;
-    const float* xr = x + (b * N + nb * 16) * L + pos;
+    const float* xr = x + (b * N) * L + min(max(pos, 0), L - 1);
+    float raw[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) raw[c] = xr[(int64_t)min(nb * 16 + c, N - 1) * L];   // unconditional (clamped) loads, then select
     bf16x8 h0, h1, l0, l1;
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
-      float v = (inside && nb * 16 + c < N) ? xr[(int64_t)c * L] : 0.f;
+      float v = (inside && nb * 16 + c < N) ? raw[c] : 0.f;
       v = lrelu_f(v, slope);
       const bf16 hv = (bf16)v;
       const bf16 lv = (bf16)(v - (float)hv);
@@ -278,23 +281,34 @@ __device__ __forceinline__ void b3_mma(const B3Frag<CW>& f, f32x16 (&acc)[CW][2]
 #pragma unroll
     for (int t = 0; t < 2; ++t) acc[i][t] = mfma32(f.ah[i], f.bh[t], acc[i][t]);
 }
-template <int CW>
+// KT = compile-time tap count (0: runtime K).  With the taps unrolled the scheduler hoists the LDS fragment reads of later
+// taps above the MFMAs of earlier ones; the runtime loop waits for its six reads before every group of six MFMAs.
+template <int CW, int KT>
 __device__ __forceinline__ void b3_stage(const bf16* xh, const bf16* xl, const bf16* ah, const bf16* al, const int (&arow)[CW],
                                          int bpos0, int bpos1, int K, int dil8, f32x16 (&acc)[CW][2]) {
-  // (an explicit two-deep fragment prefetch across taps measured 10-14 % SLOWER than this plain loop: +44 VGPRs and
-  // branchy control for reads the second resident wave already overlaps)
+  // (an explicit two-deep fragment prefetch across taps with runtime K measured 10-14 % SLOWER than the plain loop: +44 VGPRs
+  // and branchy control)
+  if (KT > 0) {
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      B3Frag<CW> f;
+      b3_load<CW>(f, xh, xl, ah, al, arow, bpos0, bpos1, k, dil8);
+      b3_mma<CW>(f, acc);
+    }
+  } else {
 #pragma unroll 2
-  for (int k = 0; k < K; ++k) {
-    B3Frag<CW> f;
-    b3_load<CW>(f, xh, xl, ah, al, arow, bpos0, bpos1, k, dil8);
-    b3_mma<CW>(f, acc);
+    for (int k = 0; k < K; ++k) {
+      B3Frag<CW> f;
+      b3_load<CW>(f, xh, xl, ah, al, arow, bpos0, bpos1, k, dil8);
+      b3_mma<CW>(f, acc);
+    }
   }
 }
 
 // Variant 1: the input is split ON THE FLY while it is staged (few output-channel tiles re-read it: the 16..128-channel
 // long-row layers, where a separate split pass would cost more HBM traffic than it saves).  Single LDS stage; overlap comes
 // from several workgroups per CU.
-template <int WCO>
+template <int WCO, int KT>
 __global__ __launch_bounds__(256) void conv1d_bf16x3_kernel(ConvMfmaParams p) {
   constexpr int MT = 32 * WCO, WL = 4 / WCO, LT = 64 * WL;
   extern __shared__ __attribute__((aligned(16))) float cm_smem[];
@@ -324,17 +338,34 @@ __global__ __launch_bounds__(256) void conv1d_bf16x3_kernel(ConvMfmaParams p) {
   const int arow[1] = {(wco * 32 + col) * apitch + hh * 8};
   const int nblk = (p.N + 15) / 16;
   const int64_t slab = (int64_t)p.Mpad * K * 16;      // elements per channel block of the split weights
+  // weight staging map, the same in every stage: chunk tid + 256 i of the [MT][K][16] slab -> LDS element offset (PMC: the
+  // per-chunk `ch / (2K)` made this loop 400 of the 512 VALU instructions a wave issued per stage -- as many issue cycles
+  // as its MFMAs)
+  constexpr int WCH = KT > 0 ? (MT * KT * 2 + 255) / 256 : MT * 16 * 2 / 256;   // chunks per thread (runtime K <= 16)
+  const int wchunks = MT * K * 2, nw = (wchunks + 255) >> 8;      // nw: wave-uniform trip count (no exec-masked branches:
+  int wlds[WCH];                                       // lanes beyond the slab load a clamped chunk and store it to a dump slot)
+#pragma unroll
+  for (int i = 0; i < WCH; ++i) {
+    const int ch = tid + 256 * i, m = ch / (K * 2), r = ch - m * (K * 2);
+    wlds[i] = ch < wchunks ? m * apitch + r * 8 : 2 * MT * apitch;            // dump slots: 2 x 8 elements behind `al`
+  }
+  const int wlast = (wchunks - 1 - tid) >> 8;          // last in-range chunk index of this thread (may be -1 -> clamp to 0)
   for (int nb = 0; nb < nblk; ++nb) {
     __syncthreads();
     // one thread per position, 16 channels each (coalesced row segments)
+    // (loads are unconditional from clamped addresses, then selected: a guarded load is an exec-masked branch with its own
+    // wait -- sixteen of them per position serialised the staging of every 16-channel block)
     for (int pp = tid; pp < lin_t; pp += 256) {
-      const int sg = pp / lin_s, pos = pp - sg * lin_s, gi = in0 + pos;
+      const int sg = nseg == 1 ? 0 : pp / lin_s, pos = pp - sg * lin_s, gi = in0 + pos;
       const bool ok = b0 + sg < p.B && gi >= 0 && gi < p.Lin;
-      const float* xr = p.x + ((int64_t)(b0 + sg) * p.N + nb * 16) * p.Lin + gi;
+      const float* xr = p.x + ((int64_t)min(b0 + sg, p.B - 1) * p.N) * p.Lin + min(max(gi, 0), p.Lin - 1);
+      float raw[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) raw[c] = xr[(int64_t)min(nb * 16 + c, p.N - 1) * p.Lin];
       bf16x8 h0, h1, l0, l1;
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
-        float v = (ok && nb * 16 + c < p.N) ? xr[(int64_t)c * p.Lin] : 0.f;
+        float v = (ok && nb * 16 + c < p.N) ? raw[c] : 0.f;
         v = lrelu_f(v, p.in_slope);
         const bf16 hv = (bf16)v;
         const bf16 lv = (bf16)(v - (float)hv);
@@ -345,19 +376,35 @@ __global__ __launch_bounds__(256) void conv1d_bf16x3_kernel(ConvMfmaParams p) {
       *reinterpret_cast<bf16x8*>(xl + pp * 8) = l0;
       *reinterpret_cast<bf16x8*>(xl + xhalf + pp * 8) = l1;
     }
-    // weights: the stage's [MT][K][16] slab is contiguous in the split arrays; 16-byte chunks
+    // weights: the stage's [MT][K][16] slab is contiguous in the split arrays; 16-byte chunks, LDS slots precomputed (wlds)
     {
-      const bf16* gh = p.a_hi + nb * slab + (int64_t)m0 * K * 16;
-      const bf16* gl = p.a_lo + nb * slab + (int64_t)m0 * K * 16;
-      const int chunks = MT * K * 2;
-      for (int ch = tid; ch < chunks; ch += 256) {
-        const int m = ch / (K * 2), r = ch - m * (K * 2);
-        *reinterpret_cast<bf16x8*>(ah + m * apitch + r * 8) = *reinterpret_cast<const bf16x8*>(gh + (int64_t)ch * 8);
-        *reinterpret_cast<bf16x8*>(al + m * apitch + r * 8) = *reinterpret_cast<const bf16x8*>(gl + (int64_t)ch * 8);
+      const bf16* gh = p.a_hi + nb * slab + (int64_t)m0 * K * 16 + tid * 8;
+      const bf16* gl = p.a_lo + nb * slab + (int64_t)m0 * K * 16 + tid * 8;
+      // groups of three chunks in flight (all of them at once costs 16 VGPRs per chunk: <2, 7> went from four waves per SIMD
+      // to three and lost 15 %)
+#pragma unroll
+      for (int g = 0; g < WCH; g += 3) {
+        bf16x8 vh[3], vl[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const int i = g + j;
+          if (i < WCH && i < nw) {
+            const int ii = max(min(i, wlast), 0) * 2048;
+            vh[j] = *reinterpret_cast<const bf16x8*>(gh + ii); vl[j] = *reinterpret_cast<const bf16x8*>(gl + ii);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const int i = g + j;
+          if (i < WCH && i < nw) {
+            *reinterpret_cast<bf16x8*>(ah + wlds[i]) = vh[j];
+            *reinterpret_cast<bf16x8*>(ah + (wlds[i] == 2 * MT * apitch ? 2 * MT * apitch + 8 : wlds[i] + MT * apitch)) = vl[j];
+          }
+        }
       }
     }
     __syncthreads();
-    b3_stage<1>(xh, xl, ah, al, arow, bpos0, bpos1, K, p.dil * 8, acc);
+    b3_stage<1, KT>(xh, xl, ah, al, arow, bpos0, bpos1, K, p.dil * 8, acc);
   }
   conv_tile_epilogue<WCO>(p, acc[0][0], acc[0][1], wl, wco, col, hh, j0, m0, b0, SEG);
 }
@@ -373,7 +420,7 @@ __global__ __launch_bounds__(256) void conv1d_bf16x3_kernel(ConvMfmaParams p) {
 // CW = 2: waves 1 x 4, wave tile 64 x 64, workgroup tile 64 x 256: 8 fragment reads feed 12 MFMAs (6 : 6 above) and a weight
 //         stage is amortised over twice the positions -- for launches that still fill the chip with the larger tile.
 constexpr int V2_WC = 6;   // most 64-slot DMA chunks of one weight array a wave issues per stage (K <= 11)
-template <int CW>
+template <int CW, int KT>
 __global__ __launch_bounds__(256) void conv1d_bf16x3_dma_kernel(ConvMfmaParams p) {
   constexpr int MT = 64, LT = 128 * CW, WCO = 2 / CW;
   constexpr int XC = CW == 1 ? 4 : 7;                       // most DMA chunks of one input array per wave and stage
@@ -453,7 +500,7 @@ __global__ __launch_bounds__(256) void conv1d_bf16x3_dma_kernel(ConvMfmaParams p
     __syncthreads();
     if (nb + 1 < nblk) issue(nb + 1, (nb + 1) & 1);
     const bf16* xh = smem + (nb & 1) * STAGE;
-    b3_stage<CW>(xh, xh + XS, xh + 2 * XS, xh + 2 * XS + WS, arow, bpos0, bpos1, K, p.dil * 8, acc);
+    b3_stage<CW, KT>(xh, xh + XS, xh + 2 * XS, xh + 2 * XS + WS, arow, bpos0, bpos1, K, p.dil * 8, acc);
   }
 #pragma unroll
   for (int i = 0; i < CW; ++i)
@@ -655,12 +702,22 @@ static int conv1d_bf16x3_dma_launch(ConvMfmaParams p, const ConvCtx& cx, hipStre
     p.x_hi = xhi; p.x_lo = xlo;
   }
   dim3 grid((unsigned)cdiv(p.Lout, SEG == LT ? LT : SEG), (unsigned)cdiv(p.M, MT), (unsigned)cdiv(p.B, LT / SEG));
-  static bool attr1 = false, attr2 = false;
-  int rc = CW == 1 ? set_attr_once(reinterpret_cast<const void*>(conv1d_bf16x3_dma_kernel<1>), attr1)
-                   : set_attr_once(reinterpret_cast<const void*>(conv1d_bf16x3_dma_kernel<2>), attr2);
-  if (rc) return rc;
-  if (CW == 1) conv1d_bf16x3_dma_kernel<1><<<grid, 256, g.smem, stream>>>(p);
-  else conv1d_bf16x3_dma_kernel<2><<<grid, 256, g.smem, stream>>>(p);
+  int rc = TTTS_OK;
+#define TTTS_DMA(CW_, KT_)                                                                                       \
+  {                                                                                                               \
+    static bool attr_ = false;                                                                                    \
+    rc = set_attr_once(reinterpret_cast<const void*>(conv1d_bf16x3_dma_kernel<CW_, KT_>), attr_);                 \
+    if (rc) return rc;                                                                                            \
+    conv1d_bf16x3_dma_kernel<CW_, KT_><<<grid, 256, g.smem, stream>>>(p);                                        \
+  }
+#define TTTS_DMA_K(CW_)                                                                                          \
+  switch ((cx.flags & 33554432) ? 0 : K) {   /* flag 33554432: runtime tap loop everywhere */                    \
+    case 1: TTTS_DMA(CW_, 1) break; case 3: TTTS_DMA(CW_, 3) break; case 5: TTTS_DMA(CW_, 5) break;              \
+    case 7: TTTS_DMA(CW_, 7) break; case 11: TTTS_DMA(CW_, 11) break; default: TTTS_DMA(CW_, 0) break;           \
+  }
+  if (CW == 1) TTTS_DMA_K(1) else TTTS_DMA_K(2)
+#undef TTTS_DMA_K
+#undef TTTS_DMA
   *handled = true;
   return check_launch("conv1d_bf16x3_dma");
 }
@@ -679,7 +736,7 @@ static int conv1d_bf16x3_launch_t(ConvMfmaParams p, const ConvCtx& cx, hipStream
   const int K = p.K, SEG = p.SEG > LT ? LT : p.SEG;
   p.SEG = SEG;
   const int lin_t = (LT / SEG) * ((SEG - 1) * p.stride + (K - 1) * p.dil + 1);
-  const size_t smem = ((size_t)2 * lin_t * 16 + (size_t)2 * MT * (K * 16 + 8)) * sizeof(bf16);
+  const size_t smem = ((size_t)2 * lin_t * 16 + (size_t)2 * MT * (K * 16 + 8) + 16) * sizeof(bf16);   // (+16: the dump slots)
   if (smem > 100 * 1024) return TTTS_OK;   // (long strips of the stride-8 / 10 resampling layers: one workgroup per CU still beats the direct kernel 5x)
   const int nblk = (p.N + 15) / 16;
   p.Mpad = (int)(cdiv(p.M, MT) * MT);
@@ -691,10 +748,19 @@ static int conv1d_bf16x3_launch_t(ConvMfmaParams p, const ConvCtx& cx, hipStream
   conv_weight_split_kernel<<<(int)std::min<int64_t>(cdiv(elems, 256), 2048), 256, 0, stream>>>(p.w, hi, lo, p.M, p.N, p.Mpad, nblk, K, p.Kmem,
                                                                                             p.transposed, p.tap_off, p.tap_stride, K * 16);
   dim3 grid((unsigned)cdiv(p.Lout, SEG == LT ? LT : SEG), (unsigned)cdiv(p.M, MT), (unsigned)cdiv(p.B, LT / SEG));
-  static bool attr = false;
-  int rc = set_attr_once(reinterpret_cast<const void*>(conv1d_bf16x3_kernel<WCO>), attr);
-  if (rc) return rc;
-  conv1d_bf16x3_kernel<WCO><<<grid, 256, smem, stream>>>(p);
+  int rc = TTTS_OK;
+#define TTTS_V1(KT_)                                                                                 \
+  {                                                                                                   \
+    static bool attr_ = false;                                                                        \
+    rc = set_attr_once(reinterpret_cast<const void*>(conv1d_bf16x3_kernel<WCO, KT_>), attr_);         \
+    if (rc) return rc;                                                                                \
+    conv1d_bf16x3_kernel<WCO, KT_><<<grid, 256, smem, stream>>>(p);                                  \
+  }
+  switch ((cx.flags & 33554432) ? 0 : K) {
+    case 1: TTTS_V1(1) break; case 3: TTTS_V1(3) break; case 5: TTTS_V1(5) break;
+    case 7: TTTS_V1(7) break; case 11: TTTS_V1(11) break; default: TTTS_V1(0) break;
+  }
+#undef TTTS_V1
   *handled = true;
   return check_launch("conv1d_bf16x3");
 }
