@@ -929,16 +929,16 @@ __global__ __launch_bounds__(256) void wgrad_split_x_kernel(const float* __restr
 // 64-position chunks that are ~full instead of one mostly-padding chunk per row (L = 23: 36 % -> 85 % useful positions).
 __global__ __launch_bounds__(256) void wgrad_split_cat_kernel(const float* __restrict__ src, bf16* __restrict__ hi, bf16* __restrict__ lo,
                                                               int B, int C, int L, int Lg, int shift, int Lrow, float slope,
-                                                              float* __restrict__ db) {
-  // blockIdx.y = channel; element v of the virtual row: b = v / Lg, j = v % Lg, source position j - shift
+                                                              float* __restrict__ db, int S) {
+  // blockIdx.y = channel * S + phase; element v of the virtual row: b = v / Lg, j = v % Lg, source position j*S + phase - shift
   __shared__ float sh[4];
-  const int c = blockIdx.y, v0 = (blockIdx.x * 256 + threadIdx.x) * 2;
+  const int c = blockIdx.y / S, ph = blockIdx.y % S, v0 = (blockIdx.x * 256 + threadIdx.x) * 2;
   float bs = 0.f;
   if (v0 < Lrow) {
     float val[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      const int v = v0 + e, b = v / Lg, j = v - b * Lg - shift;
+      const int v = v0 + e, b = v / Lg, j = (v - b * Lg) * S + ph - shift;
       const bool ok = b < B && j >= 0 && j < L;
       const float t = src[((int64_t)min(b, B - 1) * C + c) * L + min(max(j, 0), L - 1)];
       val[e] = ok ? lrelu_f(t, slope) : 0.f;
@@ -947,8 +947,8 @@ __global__ __launch_bounds__(256) void wgrad_split_cat_kernel(const float* __res
     bf16x2 h, w;
     h[0] = (bf16)val[0]; h[1] = (bf16)val[1];
     w[0] = (bf16)(val[0] - (float)h[0]); w[1] = (bf16)(val[1] - (float)h[1]);
-    *reinterpret_cast<bf16x2*>(hi + (int64_t)c * Lrow + v0) = h;
-    *reinterpret_cast<bf16x2*>(lo + (int64_t)c * Lrow + v0) = w;
+    *reinterpret_cast<bf16x2*>(hi + (int64_t)blockIdx.y * Lrow + v0) = h;
+    *reinterpret_cast<bf16x2*>(lo + (int64_t)blockIdx.y * Lrow + v0) = w;
   }
   if (db) {
     bs = wave_sum(bs);
@@ -1070,14 +1070,18 @@ __device__ __forceinline__ bf16x8 window8(bf16x8 lo, bf16x8 hi) {
 // Staging: LDS-DMA double buffer.  A stage is [dy hi][dy lo][x hi][x lo] with padded rows (PITCH / WP elements); the DMA
 // destination is lane-linear (16-byte slot s = row * slots_per_row + piece), the SOURCE address is per lane, so the row padding
 // costs one junk slot per row and nothing else; rows beyond Cout / Cin are clamped (their products are never stored).
-template <int K, int DIL, int K0, int KN, int TILE>
+// S > 1 (stride, DIL == 1): the input arrives de-interleaved by phase, XS[b][ci][r][i] = x[(i*S + r) - PL]; tap k reads phase
+// (k + PO) % S at shift (k + PO) / S with PO = PL - pad, so a row of the LDS tile is S phase windows of WP elements.
+template <int K, int DIL, int K0, int KN, int TILE, int S = 1, int PO = 0>
 __global__ __launch_bounds__(256, 2) void conv1d_wgrad_bf16x3_taps_kernel(WgradB3Params p) {
   constexpr int PITCH = 72;
-  constexpr int BASE = (K0 * DIL) / 8 * 8;                // aligned start of the staged window (tap K0 begins at K0*DIL)
-  constexpr int WIN = 64 + (K0 + KN - 1) * DIL - BASE;    // window positions
-  constexpr int WP = ((WIN + 7) / 8 * 8 + 8) | 8;         // row pitch: an ODD number of 16-byte pieces (a 256-byte pitch
-                                                          // would put all 32 rows of a fragment read on the same banks)
-  constexpr int AS = TILE * (PITCH / 8), BS = TILE * (WP / 8);            // 16-byte slots per dy / x array
+  constexpr int BASE = S > 1 ? 0 : (K0 * DIL) / 8 * 8;    // aligned start of the staged window (tap K0 begins at K0*DIL)
+  constexpr int WIN = S > 1 ? 64 + (K0 + KN - 1 + PO) / S : 64 + (K0 + KN - 1) * DIL - BASE;    // window positions (per phase)
+  constexpr int WP0 = (WIN + 7) / 8 * 8 + ((S > 1 && (WIN - 64) % 8 != 0) ? 0 : 8);   // (the second 16-byte piece of the last tap)
+  constexpr int WP = S > 1 ? ((S * (WP0 / 8)) % 2 ? WP0 : WP0 + 8) : (WP0 | 8);   // row pitch (S * WP): an ODD number of 16-byte
+                                                          // pieces (a 256-byte pitch would put all 32 rows of a fragment read on the same banks)
+  constexpr int RP = S * WP;                              // elements per LDS row
+  constexpr int AS = TILE * (PITCH / 8), BS = TILE * (RP / 8);            // 16-byte slots per dy / x array
   constexpr int AC = (AS + 63) / 64, BC = (BS + 63) / 64;                 // 64-slot DMA chunks
   constexpr int AI = (AC + 3) / 4, BI = (BC + 3) / 4;                     // ... per wave
   constexpr int STAGE_EL = 2 * (AC + BC) * 512;
@@ -1101,14 +1105,14 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad_bf16x3_taps_kernel(WgradB
   }
 #pragma unroll
   for (int i = 0; i < BI; ++i) {
-    const int sl = min((wave + 4 * i) * 64 + lane, BS - 1), row = sl / (WP / 8), pc = sl % (WP / 8);
-    boff[i] = min(ci0 + row, p.Cin - 1) * p.Li + BASE + pc * 8;      // Li % 8 == 0, l0 % 64 == 0: 16-byte aligned, inside the row
+    const int sl = min((wave + 4 * i) * 64 + lane, BS - 1), row = sl / (RP / 8), rem = sl % (RP / 8), ph = rem / (WP / 8), pc = rem % (WP / 8);
+    boff[i] = (min(ci0 + row, p.Cin - 1) * S + ph) * p.Li + BASE + pc * 8;      // Li % 8 == 0, l0 % 64 == 0: 16-byte aligned, inside the row
   }
   const int64_t dyl_d = p.dyl - p.dyh, xl_d = p.xl - p.xh;
   auto issue = [&](int chunk, int buf) {
     const int b = chunk / p.nlc, l0 = (chunk % p.nlc) * 64;
     const bf16* ga = p.dyh + (int64_t)b * p.Cout * p.Lq + l0;
-    const bf16* gb = p.xh + (int64_t)b * p.Cin * p.Li + l0;
+    const bf16* gb = p.xh + (int64_t)b * p.Cin * S * p.Li + l0;
     bf16* st = sm + buf * STAGE_EL;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
@@ -1145,8 +1149,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad_bf16x3_taps_kernel(WgradB
     const bf16* bl = bh + BC * 512;
     const bf16* arow_h = ah + (wco * 32 + col) * PITCH + hh * 8;
     const bf16* arow_l = al + (wco * 32 + col) * PITCH + hh * 8;
-    const bf16* brow_h = bh + (wci * 32 + col) * WP + hh * 8;
-    const bf16* brow_l = bl + (wci * 32 + col) * WP + hh * 8;
+    const bf16* brow_h = bh + (wci * 32 + col) * RP + hh * 8;
+    const bf16* brow_l = bl + (wci * 32 + col) * RP + hh * 8;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       if (TILE == 32 && ks != wave) continue;
@@ -1154,8 +1158,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad_bf16x3_taps_kernel(WgradB
       const bf16x8 a_l = *reinterpret_cast<const bf16x8*>(arow_l + ks * 16);
 #pragma unroll
       for (int k = 0; k < KN; ++k) {
-        const int toff = (K0 + k) * DIL - BASE;             // tap offset inside the staged window (compile-time)
-        const int off = ks * 16 + (toff / 8) * 8;           // its aligned part
+        const int toff = S > 1 ? (K0 + k + PO) / S : (K0 + k) * DIL - BASE;   // tap offset inside the staged window (compile-time)
+        const int off = ks * 16 + (toff / 8) * 8 + (S > 1 ? ((K0 + k + PO) % S) * WP : 0);   // its aligned part (+ phase window)
         const bf16x8 h0 = *reinterpret_cast<const bf16x8*>(brow_h + off), h1 = *reinterpret_cast<const bf16x8*>(brow_h + off + 8);
         const bf16x8 l0v = *reinterpret_cast<const bf16x8*>(brow_l + off), l1v = *reinterpret_cast<const bf16x8*>(brow_l + off + 8);
         bf16x8 b_h, b_l;
@@ -1409,16 +1413,17 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __r
   }
 }
 
-template <int K, int DIL, int K0, int KN, int TILE>
+template <int K, int DIL, int K0, int KN, int TILE, int S = 1, int PO = 0>
 static void launch_wgrad_taps_one(const WgradB3Params& p, dim3 grid, hipStream_t stream) {
-  constexpr int BASE = (K0 * DIL) / 8 * 8, WIN = 64 + (K0 + KN - 1) * DIL - BASE, WP = ((WIN + 7) / 8 * 8 + 8) | 8;
-  constexpr int AC = (TILE * 9 + 63) / 64, BC = (TILE * (WP / 8) + 63) / 64;
+  constexpr int BASE = S > 1 ? 0 : (K0 * DIL) / 8 * 8, WIN = S > 1 ? 64 + (K0 + KN - 1 + PO) / S : 64 + (K0 + KN - 1) * DIL - BASE;
+  constexpr int WP0 = (WIN + 7) / 8 * 8 + ((S > 1 && (WIN - 64) % 8 != 0) ? 0 : 8), WP = S > 1 ? ((S * (WP0 / 8)) % 2 ? WP0 : WP0 + 8) : (WP0 | 8);
+  constexpr int AC = (TILE * 9 + 63) / 64, BC = (TILE * (S * WP / 8) + 63) / 64;
   constexpr int STAGE_EL = 2 * (AC + BC) * 512, RED_EL = TILE == 32 ? KN * 32 * 32 * 2 : 0;
   constexpr size_t smem = (size_t)(2 * STAGE_EL > RED_EL ? 2 * STAGE_EL : RED_EL) * sizeof(bf16);
   static_assert(smem <= 160 * 1024, "taps stage too large");
   static bool attr = false;
-  if (set_attr_once(reinterpret_cast<const void*>(conv1d_wgrad_bf16x3_taps_kernel<K, DIL, K0, KN, TILE>), attr)) return;
-  conv1d_wgrad_bf16x3_taps_kernel<K, DIL, K0, KN, TILE><<<grid, 256, smem, stream>>>(p);
+  if (set_attr_once(reinterpret_cast<const void*>(conv1d_wgrad_bf16x3_taps_kernel<K, DIL, K0, KN, TILE, S, PO>), attr)) return;
+  conv1d_wgrad_bf16x3_taps_kernel<K, DIL, K0, KN, TILE, S, PO><<<grid, 256, smem, stream>>>(p);
 }
 template <int K, int DIL, int TILE>
 static void launch_wgrad_taps_t(const WgradB3Params& p, dim3 grid, hipStream_t stream) {
@@ -1497,8 +1502,8 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, f
       bf16* xh = dyl + (dy_el + 7) / 8 * 8;
       bf16* xl = xh + 2 * x_par;
       if (cat) {
-        wgrad_split_cat_kernel<<<dim3((unsigned)cdiv(Lq / 2, 256), (unsigned)Cout), 256, 0, stream>>>(dy, dyh, dyl, B, Cout, Lout, Lg, 0, Lq, dy_slope, db);
-        wgrad_split_cat_kernel<<<dim3((unsigned)cdiv(Li / 2, 256), (unsigned)Cin), 256, 0, stream>>>(x, xh, xl, B, Cin, Lin, Lg, pad, Li, x_slope, nullptr);
+        wgrad_split_cat_kernel<<<dim3((unsigned)cdiv(Lq / 2, 256), (unsigned)Cout), 256, 0, stream>>>(dy, dyh, dyl, B, Cout, Lout, Lg, 0, Lq, dy_slope, db, 1);
+        wgrad_split_cat_kernel<<<dim3((unsigned)cdiv(Li / 2, 256), (unsigned)Cin), 256, 0, stream>>>(x, xh, xl, B, Cin, Lin, Lg, pad, Li, x_slope, nullptr, 1);
       } else {
         launch_wgrad_splits(dy, x, dyh, dyl, xh, xl, (int64_t)B * Cout, Lout, Lq, dy_slope, (int64_t)B * Cin, Lin, 1, Li, pad, x_slope, 1, db, Cout, stream);
       }
@@ -1514,6 +1519,44 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, f
       wgrad_slab_reduce_kernel<<<dim3((unsigned)std::min<int64_t>(cdiv((int64_t)K * Cout * Cin, 256), 4096), (unsigned)cdiv(nsplit, SLAB_G)), 256, 0, stream>>>(slab, dw, nsplit, K, Cout, Cin, nullptr, nullptr);
       *handled = true;
       return check_launch("conv1d_wgrad_bf16x3_taps");
+    }
+  }
+  // stride-3 five-tap layers (DiscriminatorP's 32 -> 128 -> 512 -> 1024 chain): all taps per workgroup over the phase-
+  // de-interleaved input, short rows laid end to end like the stride-1 case (flag 67108864: the one-tap kernel instead)
+  if (stride == 3 && K == 5 && dil == 1 && pad == 2 && wide_c && !(cx.flags & (16384 | 67108864))) {
+    constexpr int S = 3, PO = 1, PL = 3, DMAX = (5 - 1 + PO) / S, WPK = 72;     // WPK: the kernel's phase-window pitch
+    const int Lg = Lout + DMAX;
+    const bool cat = B > 1 && cdiv(Lout, 64) * 64 * 100 > (int64_t)Lg * 115;
+    const int Bk = cat ? 1 : B;
+    const int Lq = (int)(cdiv(cat ? (int64_t)B * Lg : Lout, 64) * 64);
+    const int Li = (int)cdiv((int64_t)Lq + WPK + 8, 8) * 8;
+    const int64_t dy_el = (int64_t)Bk * Cout * Lq, x_el = (int64_t)Bk * Cin * S * Li;
+    const int nlc = Lq / 64, nchunks = Bk * nlc;
+    const int tiles = (int)(cdiv(Cin, 64) * cdiv(Cout, 64));
+    const int splits = (int)std::max<int64_t>(1, std::min<int64_t>(nchunks, cdiv(512, tiles)));
+    const int cpb = (int)cdiv(nchunks, splits), nsplit = (int)cdiv(nchunks, cpb);
+    const int64_t slab_el = (int64_t)nsplit * K * Cout * Cin;
+    const int64_t need = (2 * dy_el + 2 * x_el + 64) * (int64_t)sizeof(bf16) + slab_el * (int64_t)sizeof(float) + 128;
+    if (need <= cx.ws_bytes) {
+      bf16* dyh = static_cast<bf16*>(cx.ws);
+      bf16* dyl = dyh + (dy_el + 7) / 8 * 8;
+      bf16* xh = dyl + (dy_el + 7) / 8 * 8;
+      bf16* xl = xh + (x_el + 7) / 8 * 8;
+      if (cat) {
+        wgrad_split_cat_kernel<<<dim3((unsigned)cdiv(Lq / 2, 256), (unsigned)Cout), 256, 0, stream>>>(dy, dyh, dyl, B, Cout, Lout, Lg, 0, Lq, dy_slope, db, 1);
+        wgrad_split_cat_kernel<<<dim3((unsigned)cdiv(Li / 2, 256), (unsigned)(Cin * S)), 256, 0, stream>>>(x, xh, xl, B, Cin, Lin, Lg, PL, Li, x_slope, nullptr, S);
+      } else {
+        launch_wgrad_splits(dy, x, dyh, dyl, xh, xl, (int64_t)B * Cout, Lout, Lq, dy_slope, (int64_t)B * Cin, Lin, S, Li, PL, x_slope, 1, db, Cout, stream);
+      }
+      if (db) *db_done = true;
+      char* end = reinterpret_cast<char*>(xl + (x_el + 7) / 8 * 8);
+      float* slab = reinterpret_cast<float*>(end + ((16 - (reinterpret_cast<uintptr_t>(end) & 15)) & 15));
+      WgradB3Params p{dyh, dyl, xh, xl, dw, Bk, Cin, Cout, K, S, dil, Lq, Li, PO, x_el, cpb, nchunks, nlc, slab};
+      dim3 grid((unsigned)cdiv(Cin, 64), (unsigned)cdiv(Cout, 64), (unsigned)nsplit);
+      launch_wgrad_taps_one<5, 1, 0, 5, 64, S, PO>(p, grid, stream);
+      wgrad_slab_reduce_kernel<<<dim3((unsigned)std::min<int64_t>(cdiv((int64_t)K * Cout * Cin, 256), 4096), (unsigned)cdiv(nsplit, SLAB_G)), 256, 0, stream>>>(slab, dw, nsplit, K, Cout, Cin, nullptr, nullptr);
+      *handled = true;
+      return check_launch("conv1d_wgrad_bf16x3_taps_s3");
     }
   }
   // measured (tools/conv_bench.py, B = 32): one-tap-per-workgroup staging costs K x the operand traffic of the fp32 kernel,
