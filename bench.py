@@ -147,13 +147,20 @@ def vqvae_leg(dev, steps, warmup, cpu_leg=True):
     tot_s, tot_f, tot_n = sum(f[1] for f in fam.values()), sum(f[2] for f in fam.values()), sum(f[0] for f in fam.values())
     ach = tot_f / tot_s / 1e12
     peak = PEAK_BF16_TFLOPS / 3.0               # an fp32 product costs three bf16 MFMA products (hi*hi + hi*lo + lo*hi)
+    try:
+        conv_traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["vqvae_conv_family"]["bytes_per_step"]
+    except Exception:
+        conv_traffic = None
     res = {"metric": "vqvae_gan_train_frames_per_sec", "value": round(B * 256 / dt, 1), "unit": "frames/s",
            "ms_per_step": round(dt * 1e3, 2), "steps": steps, "warmup": warmup, "dtype": "f32 (conv products as split-bf16 x3 on the bf16 MFMA, fp32 accumulate)",
            "config": {"workload": "VQ-VAE-GAN two-phase step (spectrograms, SynthesizerTrn, mel, MPD x2, 6 losses, 2 x AdamW, codebook EMA), "
                                   "batch 32 x 163 840 samples (256 frames), %s" % ("one hipGraph replay per step" if graphed else "eager launches (capture refused)")},
            "algorithmic_tflops": round(1.97e9 * B * 256 / dt / 1e12, 1),
            "roofline": {"bound": "mfma", "kernel": "conv1d_{fwd,dgrad,wgrad} (split-bf16 implicit GEMM; %d launches per step)" % tot_n,
-                        "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                        "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                        "traffic": conv_traffic, "traffic_note": "HBM-side bytes of the whole family per STEP (incl. operand pre-passes "
+                        "and slab reductions) from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE), "
+                        "not measured in this run",
                         "ms_per_step": round(tot_s * 1e3, 2), "timing": "HIP events around every launch of one eager step",
                         "families_ms": {k: round(v[1] * 1e3, 2) for k, v in fam.items()}},
            "losses": {k: round(v, 4) for k, v in vals.items()}, "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
