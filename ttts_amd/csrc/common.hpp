@@ -59,6 +59,14 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 constexpr int WAVE = 64;  // CDNA wavefront
 
+// XCD-aware workgroup order: the hardware deals workgroup ids round-robin over the 8 XCDs (private L2s); this maps id -> logical
+// tile so that each XCD walks a CONTIGUOUS range of logical tiles (tiles that share an operand then hit the same L2).
+// Bijective for any count.
+__device__ __forceinline__ int xcd_order(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
