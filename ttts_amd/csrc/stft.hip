@@ -113,6 +113,129 @@ __global__ __launch_bounds__(256) void stft_mag_kernel(const float* __restrict__
   }
 }
 
+// (round 2, second version) The radix-2 kernel above spends its time in barriers: 12 barrier intervals per frame, frames
+// one after the other (96 per workgroup), each interval a dependent LDS round trip with two butterflies per thread in it.
+// Here the passes are radix-4 (5 instead of 10 for n_fft = 2048; one radix-2 pass first when log2 L is odd) and NF frames
+// go through every pass together: (5 + 2) x 8 / NF barrier intervals per workgroup and NF independent butterflies per
+// thread to cover the LDS latency inside an interval.
+template <int NF, int FR>
+__global__ __launch_bounds__(256) void stft_mag_r4_kernel(const float* __restrict__ wav, const float* __restrict__ window,
+                                                          const float2* __restrict__ tw, float* __restrict__ spec, int T,
+                                                          int n_fft, int hop, int frames, int log2L) {
+  extern __shared__ __attribute__((aligned(16))) float stft_smem[];
+  const int L = n_fft >> 1, Q = L >> 2, lq = log2L - 2;
+  float2* bufA = reinterpret_cast<float2*>(stft_smem);            // [NF][L]
+  float2* bufB = bufA + NF * L;
+  float* outs = reinterpret_cast<float*>(bufB + NF * L);           // [L + 1][FR + 1]
+  float2* tws = reinterpret_cast<float2*>(outs + (L + 1) * (FR + 1) + (((L + 1) * (FR + 1)) & 1));   // [L]
+  const int tid = threadIdx.x;
+  const int fblocks = (frames + FR - 1) / FR;
+  const int b = blockIdx.x / fblocks;
+  const int f0 = (blockIdx.x % fblocks) * FR;
+  const int pad = (n_fft - hop) / 2;
+  const float* w = wav + (int64_t)b * T;
+  for (int k = tid; k < L; k += 256) tws[k] = tw[k];
+  // this thread's packed points n = tid + 256 i of a frame group: frame n >> log2L, point n & (L - 1); up to NPT of them
+  constexpr int NPT = NF * 2048 / 256;                    // L <= 2048
+  const int npt = (NF * L) >> 8;
+  float2 win[NPT], xr[NPT];
+#pragma unroll
+  for (int i = 0; i < NPT; ++i) {
+    const int nn = (tid + 256 * i) & (L - 1);
+    win[i] = i < npt ? make_float2(window[2 * nn], window[2 * nn + 1]) : make_float2(0.f, 0.f);
+  }
+  // samples of group g (reflect-padded; frames beyond the clip read clamped positions and are never stored): unconditional
+  // loads, issued one group ahead so that they land behind the previous group's passes
+  auto load_group = [&](int ff0) {
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+      if (i < npt) {
+        const int n = tid + 256 * i, frame = min(f0 + ff0 + (n >> log2L), frames - 1), nn = n & (L - 1);
+        int i0 = frame * hop + 2 * nn - pad, i1 = i0 + 1;
+        i0 = i0 < 0 ? -i0 : i0; i1 = i1 < 0 ? -i1 : i1;
+        i0 = i0 >= T ? 2 * (T - 1) - i0 : i0; i1 = i1 >= T ? 2 * (T - 1) - i1 : i1;
+        xr[i] = make_float2(w[i0], w[i1]);
+      }
+    }
+  };
+  auto W = [&](int t) {                                  // exp(-2 pi i t / n_fft), t < n_fft; table holds t < n_fft / 2
+    const float2 v = tws[t & (L - 1)];
+    return t >= L ? make_float2(-v.x, -v.y) : v;
+  };
+  auto cmul = [](float2 a, float2 t) { return make_float2(a.x * t.x - a.y * t.y, a.x * t.y + a.y * t.x); };
+  load_group(0);
+  __syncthreads();
+  for (int ff0 = 0; ff0 < FR; ff0 += NF) {
+    if (f0 + ff0 >= frames) break;                       // block-uniform
+    // 1. windowed frames packed as z[n] = x[2n] + i x[2n+1]
+#pragma unroll
+    for (int i = 0; i < NPT; ++i)
+      if (i < npt) bufA[tid + 256 * i] = make_float2(xr[i].x * win[i].x, xr[i].y * win[i].y);
+    __syncthreads();
+    if (ff0 + NF < FR && f0 + ff0 + NF < frames) load_group(ff0 + NF);
+    float2* src = bufA;
+    float2* dst = bufB;
+    int Ns = 1;
+    if (log2L & 1) {                                     // one radix-2 pass (Ns = 1: unit twiddles)
+      for (int j = tid; j < NF * (L >> 1); j += 256) {
+        const int fq = j >> (log2L - 1), jj = j & ((L >> 1) - 1);
+        const float2 a = src[fq * L + jj], c = src[fq * L + jj + (L >> 1)];
+        dst[fq * L + 2 * jj] = make_float2(a.x + c.x, a.y + c.y);
+        dst[fq * L + 2 * jj + 1] = make_float2(a.x - c.x, a.y - c.y);
+      }
+      __syncthreads();
+      float2* tmp = src; src = dst; dst = tmp;
+      Ns = 2;
+    }
+    for (; Ns < L; Ns <<= 2) {                           // radix-4 Stockham passes
+      const int tstep = n_fft / (4 * Ns);                // twiddle index step: exp(-2 pi i r k / (4 Ns)) = W(r k tstep)
+      for (int j = tid; j < NF * Q; j += 256) {
+        const int fq = j >> lq, jj = j & (Q - 1), k = jj & (Ns - 1);
+        const float2* sp = src + fq * L + jj;
+        const float2 a = sp[0];
+        const float2 bb = cmul(sp[Q], W(k * tstep));
+        const float2 cc = cmul(sp[2 * Q], W(2 * k * tstep));
+        const float2 dd = cmul(sp[3 * Q], W(3 * k * tstep));
+        const float2 s0 = make_float2(a.x + cc.x, a.y + cc.y), s1 = make_float2(a.x - cc.x, a.y - cc.y);
+        const float2 s2 = make_float2(bb.x + dd.x, bb.y + dd.y), s3 = make_float2(bb.x - dd.x, bb.y - dd.y);
+        float2* dp = dst + fq * L + ((jj - k) << 2) + k;
+        dp[0] = make_float2(s0.x + s2.x, s0.y + s2.y);
+        dp[Ns] = make_float2(s1.x + s3.y, s1.y - s3.x);          // s1 - i s3
+        dp[2 * Ns] = make_float2(s0.x - s2.x, s0.y - s2.y);
+        dp[3 * Ns] = make_float2(s1.x - s3.y, s1.y + s3.x);      // s1 + i s3
+      }
+      __syncthreads();
+      float2* tmp = src; src = dst; dst = tmp;
+    }
+    // 3. unpack the real spectra: X[k] = E + w_k O, E = (Z[k] + conj Z[L-k])/2, O = -i (Z[k] - conj Z[L-k])/2
+    for (int i = tid; i < NF * (L + 1); i += 256) {
+      const int fq = i / (L + 1), k = i - fq * (L + 1);
+      const float2* z = src + fq * L;
+      float re, im;
+      if (k == 0 || k == L) {
+        const float2 z0 = z[0];
+        re = (k == 0) ? z0.x + z0.y : z0.x - z0.y;
+        im = 0.f;
+      } else {
+        const float2 zk = z[k];
+        const float2 zc = z[L - k];
+        const float er = 0.5f * (zk.x + zc.x), ei = 0.5f * (zk.y - zc.y);
+        const float orr = 0.5f * (zk.y + zc.y), oi = -0.5f * (zk.x - zc.x);
+        const float2 t = tws[k];
+        re = er + (orr * t.x - oi * t.y);
+        im = ei + (orr * t.y + oi * t.x);
+      }
+      outs[k * (FR + 1) + ff0 + fq] = sqrtf(re * re + im * im + 1e-6f);
+    }
+    __syncthreads();
+  }
+  const int nf = min(FR, frames - f0);
+  for (int i = tid; i < (L + 1) * FR; i += 256) {
+    const int k = i / FR, ff = i % FR;
+    if (ff < nf) spec[((int64_t)b * (L + 1) + k) * frames + f0 + ff] = outs[k * (FR + 1) + ff];
+  }
+}
+
 // mel[b][m][f] = log(max(sum_k basis[m][k] spec[b][k][f], 1e-5)).
 // (round 2) A mel filterbank row is a narrow band (Slaney triangles: ~2 x 1025 non-zeros in 128 x 1025), so the dense
 // 32 x 64 x 32 tiled product of round 1 (166 us for 32 clips: 2.9 % of the HBM roof, all of it multiplying zeros) is replaced
@@ -343,6 +466,18 @@ extern "C" int ttts_stft_mag_fwd_f32(const float* wav, const float* window, cons
   const int L = n_fft / 2;
   int log2L = 0;
   while ((1 << log2L) < L) ++log2L;
+  constexpr int NF = 2, FR4 = 8;                         // radix-4 kernel: frames per pass, frames per workgroup (16 frames =
+  const bool r4 = L >= 256 && L <= 2048;                 // 64-byte output runs, but 110 KB of LDS = one workgroup per CU: 120 us vs 91); short transforms keep radix-2
+  if (r4) {
+    const size_t smem4 = (size_t)2 * NF * L * sizeof(float2) + ((size_t)(L + 1) * (FR4 + 1) + (((L + 1) * (FR4 + 1)) & 1)) * sizeof(float) +
+                         (size_t)L * sizeof(float2);
+    static const hipError_t attr4 = hipFuncSetAttribute(reinterpret_cast<const void*>(stft_mag_r4_kernel<NF, FR4>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr4 != hipSuccess) return fail(TTTS_EHIP, "stft: hipFuncSetAttribute: %s", hipGetErrorString(attr4));
+    stft_mag_r4_kernel<NF, FR4><<<B * (int)cdiv(frames, FR4), 256, smem4, as_stream(stream)>>>(
+        wav, window, reinterpret_cast<const float2*>(twiddle), spec, T, n_fft, hop, frames, log2L);
+    return check_launch("stft_mag_fwd");
+  }
   size_t smem = (size_t)2 * L * sizeof(float2) + ((size_t)(L + 1) * (STFT_FR + 1) + ((L + 1) & 1)) * sizeof(float) + (size_t)L * sizeof(float2);
   const size_t span_bytes = ((size_t)(STFT_FR - 1) * hop + n_fft) * sizeof(float);
   const int span_lds = smem + span_bytes <= 80 * 1024;   // only where it does not cost the second workgroup per CU
