@@ -243,19 +243,20 @@ __global__ __launch_bounds__(256) void stft_mag_r4_kernel(const float* __restric
 // assumption about the basis beyond "zeros are zeros"), then accumulates basis[m][k] * spec[b][k][f] over that band in
 // increasing k -- the same fmaf chain as the dense loop minus its exact-zero terms, i.e. bit-identical results -- with the
 // 64 lanes on 64 consecutive frames (256-byte coalesced spec reads, eight in flight).  A workgroup = (clip, 64 frames,
-// 32 mels interleaved over its 4 waves: narrow low bands and wide high bands balance out).
+// MEL_MT mels, one per wave: 4096 small workgroups measured 13.8 us against 25.6 with 32 mels per workgroup).
+constexpr int MEL_MT = 4;    // mels per workgroup (interleaved over its 4 waves)
 __global__ __launch_bounds__(256) void mel_log_kernel(const float* __restrict__ spec, const float* __restrict__ basis,
                                                       const int* __restrict__ bands, float* __restrict__ mel, int n_bins,
                                                       int n_mels, int frames) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ftiles = (frames + 63) / 64, mtiles = (n_mels + 31) / 32;
+  const int ftiles = (frames + 63) / 64, mtiles = (n_mels + MEL_MT - 1) / MEL_MT;
   const int b = blockIdx.x / (ftiles * mtiles);
   const int rem = blockIdx.x % (ftiles * mtiles);
   const int mg = rem / ftiles, f = (rem % ftiles) * 64 + lane;
   const float* sp = spec + (int64_t)b * n_bins * frames + min(f, frames - 1);
-  for (int i = 0; i < 8; ++i) {
-    const int m = mg * 32 + i * 4 + wave;           // wave-uniform
+  for (int i = 0; i < MEL_MT / 4; ++i) {
+    const int m = mg * MEL_MT + i * 4 + wave;       // wave-uniform
     if (m >= n_mels) break;
     const float* brow = basis + (int64_t)m * n_bins;
     int lo = n_bins, hi = -1;
@@ -494,7 +495,7 @@ extern "C" int ttts_stft_mag_fwd_f32(const float* wav, const float* window, cons
 extern "C" int ttts_mel_log_fwd_f32(const float* spec, const float* basis, const int32_t* bands, float* mel, int32_t B,
                                     int32_t n_bins, int32_t n_mels, int32_t frames, void* stream) {
   TTTS_REQUIRE(spec && basis && mel && B > 0 && n_bins > 0 && n_mels > 0 && frames > 0, "mel_log: bad arguments");
-  const int grid = B * (int)cdiv(frames, 64) * (int)cdiv(n_mels, 32);
+  const int grid = B * (int)cdiv(frames, 64) * (int)cdiv(n_mels, MEL_MT);
   mel_log_kernel<<<grid, 256, 0, as_stream(stream)>>>(spec, basis, bands, mel, n_bins, n_mels, frames);
   return check_launch("mel_log_fwd");
 }
