@@ -1528,7 +1528,8 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, f
   }
   // stride-3 five-tap layers (DiscriminatorP's 32 -> 128 -> 512 -> 1024 chain): all taps per workgroup over the phase-
   // de-interleaved input, short rows laid end to end like the stride-1 case (flag 67108864: the one-tap kernel instead)
-  if (stride == 3 && K == 5 && dil == 1 && pad == 2 && wide_c && !(cx.flags & (16384 | 67108864))) {
+  if (stride == 3 && K == 5 && dil == 1 && pad == 2 && (wide_c || (Cin >= 32 && Cout >= 64)) && !(cx.flags & (16384 | 67108864))) {
+    // (from 32 input channels: a half-empty 64-channel tile on the bf16 matrix cores still beats the exact-f32 MFMA kernel)
     constexpr int S = 3, PO = 1, PL = 3, DMAX = (5 - 1 + PO) / S, WPK = 72;     // WPK: the kernel's phase-window pitch
     const int Lg = Lout + DMAX;
     const bool cat = B > 1 && cdiv(Lout, 64) * 64 * 100 > (int64_t)Lg * 115;
