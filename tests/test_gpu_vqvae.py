@@ -587,7 +587,8 @@ def _rel_l2(a, b):
 
 @pytest.mark.bf16x3
 @pytest.mark.parametrize("case", [(64, 64, 11, 1, 25, 5, 2048), (192, 384, 5, 1, 2, 1, 256), (512, 1024, 5, 3, 2, 1, 253),
-                                  (1024, 1024, 5, 1, 2, 1, 23), (32, 16, 16, 1, 7, 1, 400)])
+                                  (1024, 1024, 5, 1, 2, 1, 23), (32, 16, 16, 1, 7, 1, 400), (256, 320, 5, 1, 2, 1, 37),
+                                  (320, 256, 3, 1, 1, 1, 85), (192, 192, 5, 3, 2, 1, 150)])
 def test_split_bf16_conv_accuracy(case):
     """Default conv path: products as hi*hi + hi*lo + lo*hi on the bf16 matrix cores.  Stated tolerance: 2e-5 of the
     output range for the forward / data gradient (measured ~5e-6), i.e. ~100x tighter than TF32."""

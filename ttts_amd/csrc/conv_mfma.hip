@@ -41,6 +41,8 @@ struct ConvMfmaParams {
   const bf16* a_hi; const bf16* a_lo; int Mpad;
   const bf16* x_hi; const bf16* x_lo;   // pre-split, zero-padded input [B][N/16 blocks][2 channel halves][Lp][8] (conv_input_split_kernel)
   int Lp, PADL;        // padded row length of the pre-split input; element i of a row holds position i - PADL
+  int catLg, catLout;  // > 0: the batch is laid end to end as ONE virtual row (B == 1 here), output position v = b * catLg + j,
+                       // j < catLout real positions per batch element (short rows: DiscriminatorP's 23..127-position layers)
 };
 
 
@@ -136,8 +138,12 @@ __global__ __launch_bounds__(64 * NW) void conv1d_mfma_kernel(ConvMfmaParams p) 
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int ct = wl * 64 + t * 32 + col;
-    const int b = b0 + ct / SEG, jt = j0 + ct % SEG;
+    int b = b0 + ct / SEG, jt = j0 + ct % SEG;
     if (jt >= p.Lout || b >= p.B) continue;
+    if (p.catLg) {                                         // virtual row -> (batch element, position)
+      b = jt / p.catLg; jt -= b * p.catLg;
+      if (jt >= p.catLout) continue;
+    }
     const int j = p.out_off + jt * p.out_stride;
     const float om = p.omask ? p.omask[(int64_t)b * p.LoutTotal + j] : 1.f;
 #pragma unroll
@@ -171,17 +177,26 @@ __global__ __launch_bounds__(64 * NW) void conv1d_mfma_kernel(ConvMfmaParams p) 
 // above MFMA time)
 __global__ __launch_bounds__(256) void conv_input_split_kernel(const float* __restrict__ x, bf16* __restrict__ hi,
                                                                bf16* __restrict__ lo, int B, int N, int L, int nblk, float slope,
-                                                               int Lp, int PADL) {
-  // one thread per (batch element, 16-channel block, padded position): 16 coalesced row reads, four 16-byte stores
+                                                               int Lp, int PADL, int catW, int catB, int catL) {
+  // one thread per (batch element, 16-channel block, padded position): 16 coalesced row reads, four 16-byte stores.
+  // catW > 0: ONE destination row (B == 1) holding the catB source rows of length catL end to end, catW positions apart
   const int64_t total = (int64_t)B * nblk * Lp;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int pp = (int)(i % Lp), nb = (int)((i / Lp) % nblk), pos = pp - PADL;
-    const int64_t b = i / Lp / nblk;
-    const bool inside = pos >= 0 && pos < L;
-    const float* xr = x + (b * N) * L + min(max(pos, 0), L - 1);
+    const int pp = (int)(i % Lp), nb = (int)((i / Lp) % nblk);
+    int pos = pp - PADL;
+    int64_t b = i / Lp / nblk;
+    int Lr = L;
+    bool inside = pos >= 0 && pos < L;
+    if (catW) {
+      const int bb = pos >= 0 ? pos / catW : 0;
+      pos -= bb * catW;
+      inside = pos >= 0 && pos < catL && bb < catB;
+      b = min(bb, catB - 1); Lr = catL;
+    }
+    const float* xr = x + (b * N) * Lr + min(max(pos, 0), Lr - 1);
     float raw[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) raw[c] = xr[(int64_t)min(nb * 16 + c, N - 1) * L];   // unconditional (clamped) loads, then select
+    for (int c = 0; c < 16; ++c) raw[c] = xr[(int64_t)min(nb * 16 + c, N - 1) * Lr];   // unconditional (clamped) loads, then select
     bf16x8 h0, h1, l0, l1;
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
@@ -191,7 +206,7 @@ __global__ __launch_bounds__(256) void conv_input_split_kernel(const float* __re
       const bf16 lv = (bf16)(v - (float)hv);
       if (c < 8) { h0[c] = hv; l0[c] = lv; } else { h1[c - 8] = hv; l1[c - 8] = lv; }
     }
-    const int64_t o = (((b * nblk + nb) * 2) * Lp + pp) * 8;        // half 0; half 1 is Lp * 8 elements further
+    const int64_t o = ((((i / Lp / nblk) * nblk + nb) * 2) * Lp + pp) * 8;        // half 0; half 1 is Lp * 8 elements further
     *reinterpret_cast<bf16x8*>(hi + o) = h0;
     *reinterpret_cast<bf16x8*>(hi + o + (int64_t)Lp * 8) = h1;
     *reinterpret_cast<bf16x8*>(lo + o) = l0;
@@ -227,8 +242,12 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvMfmaParams& p, cons
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int ct = wl * 64 + t * 32 + col;
-    const int b = b0 + ct / SEG, jt = j0 + ct % SEG;
+    int b = b0 + ct / SEG, jt = j0 + ct % SEG;
     if (jt >= p.Lout || b >= p.B) continue;
+    if (p.catLg) {                                         // virtual row -> (batch element, position)
+      b = jt / p.catLg; jt -= b * p.catLg;
+      if (jt >= p.catLout) continue;
+    }
     const int j = p.out_off + jt * p.out_stride;
     const float om = p.omask ? p.omask[(int64_t)b * p.LoutTotal + j] : 1.f;
 #pragma unroll
@@ -682,6 +701,21 @@ static int conv_dma_pick(const ConvMfmaParams& p, const ConvCtx& cx) {
 }
 
 static int conv1d_bf16x3_dma_launch(ConvMfmaParams p, const ConvCtx& cx, hipStream_t stream, bool* handled, int CW) {
+  // short rows: instead of folding power-of-two segments of several batch elements into a tile (a 37-position row uses 58 %
+  // of a 64-position segment), lay the whole batch end to end as one virtual row with zero gaps wide enough for the taps
+  // (flag 134217728: keep the segment folding)
+  int cat_w = 0, cat_b = 0, cat_l = 0;
+  if (!p.x_hi && p.B > 1 && p.SEG <= 128 && p.out_stride == 1 && p.out_off == 0 && p.LoutTotal == p.Lout && !(cx.flags & 134217728)) {
+    const int S = p.stride;
+    const int reach = std::max(std::max(p.pad, S * (p.Lout - 1) - p.pad + (p.K - 1) * p.dil - (p.Lin - 1)), 0);
+    const int Lg = std::max(p.Lout, (int)cdiv(p.Lin + reach, S));
+    if ((int64_t)p.SEG * 100 > (int64_t)Lg * 115) {
+      cat_w = S * Lg; cat_b = p.B; cat_l = p.Lin;
+      p.catLg = Lg; p.catLout = p.Lout;
+      p.Lout = p.B * Lg; p.Lin = p.B * S * Lg; p.B = 1; p.SEG = 1 << 20;
+      CW = conv_dma_pick(p, cx);
+    }
+  }
   const int MT = 64, LT = 128 * CW;
   const int K = p.K, SEG = p.SEG > LT ? LT : p.SEG;
   const DmaGeom g = conv_dma_geom(p, CW);
@@ -703,7 +737,7 @@ static int conv1d_bf16x3_dma_launch(ConvMfmaParams p, const ConvCtx& cx, hipStre
                                                                                              p.transposed, p.tap_off, p.tap_stride, AP);
   if (!p.x_hi) {   // (polyphase data gradients share one split of dy across their phase launches)
     conv_input_split_kernel<<<(int)std::min<int64_t>(cdiv(xel / 16, 256), 8192), 256, 0, stream>>>(p.x, xhi, xlo, p.B, p.N, p.Lin, nblk, p.in_slope,
-                                                                                                   p.Lp, p.PADL);
+                                                                                                   p.Lp, p.PADL, cat_w, cat_b, cat_l);
     p.x_hi = xhi; p.x_lo = xlo;
   }
   dim3 grid((unsigned)cdiv(p.Lout, SEG == LT ? LT : SEG), (unsigned)cdiv(p.M, MT), (unsigned)cdiv(p.B, LT / SEG));
@@ -848,7 +882,7 @@ int conv1d_dgrad_strided_mfma_try(const float* dy, const float* w, const float* 
     const int64_t xel = (int64_t)B * nblk * 2 * Lp * 8;
     if (all_ok && 2 * xel * (int64_t)sizeof(bf16) + (32 << 20) <= cx.ws_bytes) {
       bf16* xh = static_cast<bf16*>(cx.ws);
-      conv_input_split_kernel<<<(int)std::min<int64_t>(cdiv(xel / 16, 256), 8192), 256, 0, stream>>>(dy, xh, xh + xel, B, Cout, Lout, nblk, in_slope, Lp, padl);
+      conv_input_split_kernel<<<(int)std::min<int64_t>(cdiv(xel / 16, 256), 8192), 256, 0, stream>>>(dy, xh, xh + xel, B, Cout, Lout, nblk, in_slope, Lp, padl, 0, 0, 0);
       xs_hi = xh; xs_lo = xh + xel; sh_Lp = Lp; sh_padl = padl;
     }
   }
