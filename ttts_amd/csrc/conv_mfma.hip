@@ -371,7 +371,8 @@ __global__ __launch_bounds__(256) void conv1d_bf16x3_kernel(ConvMfmaParams p) {
   const int wlast = (wchunks - 1 - tid) >> 8;          // last in-range chunk index of this thread (may be -1 -> clamp to 0)
   for (int nb = 0; nb < nblk; ++nb) {
     __syncthreads();
-    // one thread per position, 16 channels each (coalesced row segments)
+    // one thread per position, 16 channels each (coalesced row segments).  (Prefetching the next block's strip into registers
+    // during the MFMAs was measured and lost: +40 VGPRs cost a resident wave, RB1(64) k7 54 -> 69 us, RB1(32) k11 44 -> 51.)
     // (loads are unconditional from clamped addresses, then selected: a guarded load is an exec-masked branch with its own
     // wait -- sixteen of them per position serialised the staging of every 16-channel block)
     for (int pp = tid; pp < lin_t; pp += 256) {
