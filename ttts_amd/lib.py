@@ -198,6 +198,13 @@ def get():
         if not os.path.exists(SO_PATH):
             raise TttsError("libttts_hip.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`"
                             % SO_PATH)
+        # The process must hold ONE HIP runtime: torch ships its own libamdhip64 and every tensor / stream we are handed lives in
+        # it.  If this library were loaded first (build() then smoke() in one process) its kernels would bind to the system
+        # runtime under /opt/rocm and launch into a runtime that has no context ("no ROCm-capable device is detected").
+        try:
+            import torch  # noqa: F401  (loads torch's HIP runtime first; harmless when it is already imported)
+        except ImportError:
+            pass
         lib = ctypes.CDLL(SO_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is missing
