@@ -1103,10 +1103,8 @@ __device__ __forceinline__ bf16x8 window8(bf16x8 lo, bf16x8 hi) {
 }
 
 // taps [K0, K0 + KN) of a K-tap convolution (K = 11 runs as two launches of 6 + 5 taps: 11 accumulators would spill)
-// TILE = 64: workgroup tile 64 co x 64 ci, waves 2 x 2, every wave all four 16-position k-steps of a chunk.
-// TILE = 32: workgroup tile 32 co x 32 ci (the 16..96-channel long-row ResBlock layers, where a 64 x 64 tile is mostly
-//            padding and the exact-fp32 MFMA kernel ran at 15-60 TF/s): the four waves split the k-steps of a chunk and
-//            their partial tiles are summed through LDS in wave order (deterministic) before the one slab store.
+// Workgroup tile 64 co x 64 ci (TILE), waves 2 x 2, every wave all four 16-position k-steps of a chunk.  (A 32 x 32 tile with the
+// k-steps split over the waves was tried for narrow layers and lost to the fused single-pass kernel further down.)
 // Staging: LDS-DMA double buffer.  A stage is [dy hi][dy lo][x hi][x lo] with padded rows (PITCH / WP elements); the DMA
 // destination is lane-linear (16-byte slot s = row * slots_per_row + piece), the SOURCE address is per lane, so the row padding
 // costs one junk slot per row and nothing else; rows beyond Cout / Cin are clamped (their products are never stored).
@@ -1125,9 +1123,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad_bf16x3_taps_kernel(WgradB
   constexpr int AC = (AS + 63) / 64, BC = (BS + 63) / 64;                 // 64-slot DMA chunks
   constexpr int AI = (AC + 3) / 4, BI = (BC + 3) / 4;                     // ... per wave
   constexpr int STAGE_EL = 2 * (AC + BC) * 512;
-  constexpr int RED_EL = TILE == 32 ? KN * 32 * 32 * 2 : 0;   // fp32 reduction buffer, in bf16 elements
   extern __shared__ __attribute__((aligned(16))) float cm_smem[];
-  bf16* sm = reinterpret_cast<bf16*>(cm_smem);             // 2 stages (>= RED_EL, checked by the launcher)
+  bf16* sm = reinterpret_cast<bf16*>(cm_smem);             // 2 stages
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, col = lane & 31;
   const int ci0 = blockIdx.x * TILE, co0 = blockIdx.y * TILE, split = blockIdx.z;
   const int wco = TILE == 64 ? (wave & 1) : 0, wci = TILE == 64 ? (wave >> 1) : 0;
@@ -1193,7 +1190,6 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad_bf16x3_taps_kernel(WgradB
     const bf16* brow_l = bl + (wci * 32 + col) * RP + hh * 8;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      if (TILE == 32 && ks != wave) continue;
       const bf16x8 a_h = *reinterpret_cast<const bf16x8*>(arow_h + ks * 16);
       const bf16x8 a_l = *reinterpret_cast<const bf16x8*>(arow_l + ks * 16);
 #pragma unroll
@@ -1218,38 +1214,6 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad_bf16x3_taps_kernel(WgradB
         acc[k] = mfma32(a_h, b_h, acc[k]);
       }
     }
-  }
-  if (TILE == 32) {
-    // sum the four waves' partial tiles in wave order: red[k][reg][lane]
-    float* red = reinterpret_cast<float*>(sm);
-    __syncthreads();                                       // staging buffers are free
-    const int wv = __builtin_amdgcn_readfirstlane(wave);     // scalar: one branch per phase (a per-element `if (w == ...)` chain
-    if (wv == 0) {                                           // compiled to ~30 moves and 7 exec-mask branches per element)
-  #pragma unroll
-      for (int k = 0; k < KN; ++k)
-  #pragma unroll
-        for (int i = 0; i < 16; ++i) red[(k * 16 + i) * 64 + lane] = acc[k][i];
-    }
-    __syncthreads();
-    if (wv == 1) {
-  #pragma unroll
-      for (int k = 0; k < KN; ++k)
-  #pragma unroll
-        for (int i = 0; i < 16; ++i) red[(k * 16 + i) * 64 + lane] += acc[k][i];
-    }
-    __syncthreads();
-    if (wv == 2) {
-  #pragma unroll
-      for (int k = 0; k < KN; ++k)
-  #pragma unroll
-        for (int i = 0; i < 16; ++i) red[(k * 16 + i) * 64 + lane] += acc[k][i];
-    }
-    __syncthreads();
-    if (wv != 3) return;
-  #pragma unroll
-    for (int k = 0; k < KN; ++k)
-  #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[k][i] += red[(k * 16 + i) * 64 + lane];
   }
   const int ci = ci0 + wci * 32 + col;
   if (ci < p.Cin) {
@@ -1458,8 +1422,8 @@ static void launch_wgrad_taps_one(const WgradB3Params& p, dim3 grid, hipStream_t
   constexpr int BASE = S > 1 ? 0 : (K0 * DIL) / 8 * 8, WIN = S > 1 ? 64 + (K0 + KN - 1 + PO) / S : 64 + (K0 + KN - 1) * DIL - BASE;
   constexpr int WP0 = (WIN + 7) / 8 * 8 + ((S > 1 && (WIN - 64) % 8 != 0) ? 0 : 8), WP = S > 1 ? ((S * (WP0 / 8)) % 2 ? WP0 : WP0 + 8) : (WP0 | 8);
   constexpr int AC = (TILE * 9 + 63) / 64, BC = (TILE * (S * WP / 8) + 63) / 64;
-  constexpr int STAGE_EL = 2 * (AC + BC) * 512, RED_EL = TILE == 32 ? KN * 32 * 32 * 2 : 0;
-  constexpr size_t smem = (size_t)(2 * STAGE_EL > RED_EL ? 2 * STAGE_EL : RED_EL) * sizeof(bf16);
+  constexpr int STAGE_EL = 2 * (AC + BC) * 512;
+  constexpr size_t smem = (size_t)2 * STAGE_EL * sizeof(bf16);
   static_assert(smem <= 160 * 1024, "taps stage too large");
   static bool attr = false;
   if (set_attr_once(reinterpret_cast<const void*>(conv1d_wgrad_bf16x3_taps_kernel<K, DIL, K0, KN, TILE, S, PO>), attr)) return;
