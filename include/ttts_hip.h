@@ -385,6 +385,11 @@ typedef struct ttts_conv_ctx {
 #define TTTS_CONV_SMALL_TILES 2048       /* experiments: allow the small MFMA tile shapes */
 #define TTTS_CONV_FORCE_SPLIT_WGRAD 8192 /* tests: split-bf16 weight gradient for every shape */
 #define TTTS_CONV_NO_TAPS_WGRAD 16384    /* experiments: disable the all-taps weight-gradient kernel */
+/* further experiment bits (A/B switches of tools/conv_bench.py, documented where they are tested in csrc/conv*.hip):
+ * 32768 DMA kernel from one output-channel tile, 65536 never the DMA kernel, 131072 / 262144 never / always its 64 x 256 tile,
+ * 1048576 no narrow-layer weight-gradient kernels, 2097152 pre-split instead of fused narrow weight gradient, 8388608 no
+ * thin-layer (1-channel) kernels, 16777216 direct instead of MFMA grouped kernels, 33554432 run-time tap loops, 67108864
+ * one-tap instead of all-taps stride-3 weight gradient, 134217728 segment folding instead of virtual rows for short rows */
 int ttts_conv1d_fwd_f32(const float* x, const float* w, const float* bias, const float* bbias, const float* resid,
                         const float* gate, const float* omask, float* y, int32_t B, int32_t Cin, int32_t Lin, int32_t Cout, int32_t Lout,
                         int32_t K, int32_t stride, int32_t pad, int32_t dil, int32_t groups, float in_slope,
