@@ -23,6 +23,10 @@ struct BgemmParams {
 };
 constexpr int BG_T = 64, BG_K = 16;
 
+// (round 2) The 4 x 4-per-thread fmaf loop is replaced by v_mfma_f32_32x32x2_f32: the same k-ordered exact-fp32 chain per
+// output element (bit-identical results), one MFMA + two 4-byte LDS reads per 2 k where the VALU form needed 8 LDS values and
+// 32 issue slots per k -- this kernel was 32 % of the diffusion step and the attention of every VITS stack.
+// Waves 2 x 2 over the 64 x 64 tile, wave tile 32 x 32.
 __global__ __launch_bounds__(256) void bgemm_kernel(BgemmParams p) {
   __shared__ float As[BG_K][BG_T + 4];
   __shared__ float Bs[BG_K][BG_T + 4];
@@ -31,46 +35,41 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgemmParams p) {
   const float* B = p.B + zo * p.b_so + zi * p.b_si;
   float* C = p.C + zo * p.c_so + zi * p.c_si;
   const int m0 = blockIdx.y * BG_T, n0 = blockIdx.x * BG_T;
-  const int tid = threadIdx.x, tm = tid >> 4, tn = tid & 15;
-  float acc[4][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, hh = lane >> 5, col = lane & 31;
+  f32x16 acc;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const bool a_m_fast = p.a_sm == 1, b_n_fast = p.b_sn == 1;
   for (int k0 = 0; k0 < p.K; k0 += BG_K) {
+    // unconditional loads from clamped addresses, then a select (guarded loads compile to one branch each)
+    float av[4], bv[4];
+    int am[4], ak[4], bn[4], bk[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      int m, k;
-      if (a_m_fast) { m = tid & 63; k = (tid >> 6) + 4 * i; } else { k = tid & 15; m = (tid >> 4) + 16 * i; }
-      As[k][m] = (m0 + m < p.M && k0 + k < p.K) ? A[(int64_t)(m0 + m) * p.a_sm + (int64_t)(k0 + k) * p.a_sk] : 0.f;
-      int n, kb;
-      if (b_n_fast) { n = tid & 63; kb = (tid >> 6) + 4 * i; } else { kb = tid & 15; n = (tid >> 4) + 16 * i; }
-      Bs[kb][n] = (n0 + n < p.N && k0 + kb < p.K) ? B[(int64_t)(k0 + kb) * p.b_sk + (int64_t)(n0 + n) * p.b_sn] : 0.f;
+      if (a_m_fast) { am[i] = tid & 63; ak[i] = (tid >> 6) + 4 * i; } else { ak[i] = tid & 15; am[i] = (tid >> 4) + 16 * i; }
+      if (b_n_fast) { bn[i] = tid & 63; bk[i] = (tid >> 6) + 4 * i; } else { bk[i] = tid & 15; bn[i] = (tid >> 4) + 16 * i; }
+      av[i] = A[(int64_t)min(m0 + am[i], p.M - 1) * p.a_sm + (int64_t)min(k0 + ak[i], p.K - 1) * p.a_sk];
+      bv[i] = B[(int64_t)min(k0 + bk[i], p.K - 1) * p.b_sk + (int64_t)min(n0 + bn[i], p.N - 1) * p.b_sn];
+    }
+    __syncthreads();                                   // the previous stage's fragments have been read
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      As[ak[i]][am[i]] = (m0 + am[i] < p.M && k0 + ak[i] < p.K) ? av[i] : 0.f;
+      Bs[bk[i]][bn[i]] = (n0 + bn[i] < p.N && k0 + bk[i] < p.K) ? bv[i] : 0.f;
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < BG_K; ++k) {
-      const float4 a = *reinterpret_cast<const float4*>(&As[k][tm * 4]);
-      const float4 b = *reinterpret_cast<const float4*>(&Bs[k][tn * 4]);
-      const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
-    }
-    __syncthreads();
+    for (int k = 0; k < BG_K; k += 2)                  // A[m = lane & 31][k + (lane >> 5)], B[k + (lane >> 5)][n = lane & 31]
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k + hh][wm * 32 + col], Bs[k + hh][wn * 32 + col], acc, 0, 0, 0);
   }
+  const int n = n0 + wn * 32 + col;
+  if (n < p.N) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + tm * 4 + i;
-    if (m >= p.M) continue;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + tn * 4 + j;
-      if (n >= p.N) continue;
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 32 + acc_row(r, hh);
+      if (m >= p.M) continue;
       float* c = C + (int64_t)m * p.c_sm + (int64_t)n * p.c_sn;
-      const float v = p.alpha * acc[i][j];
+      const float v = p.alpha * acc[r];
       *c = p.beta != 0.f ? v + p.beta * *c : v;
     }
   }
