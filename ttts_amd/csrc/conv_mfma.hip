@@ -41,6 +41,8 @@ struct ConvMfmaParams {
   const bf16* a_hi; const bf16* a_lo; int Mpad;
   const bf16* x_hi; const bf16* x_lo;   // pre-split, zero-padded input [B][N/16 blocks][2 channel halves][Lp][8] (conv_input_split_kernel)
   int Lp, PADL;        // padded row length of the pre-split input; element i of a row holds position i - PADL
+  int NBS;             // DMA kernel: 16-channel blocks per pipeline stage (1, 2 or 4: 1 x 1 convolutions have 6 MFMAs per wave and
+                       // block -- a stage that short is all DMA latency)
   int catLg, catLout;  // > 0: the batch is laid end to end as ONE virtual row (B == 1 here), output position v = b * catLg + j,
                        // j < catLout real positions per batch element (short rows: DiscriminatorP's 23..127-position layers)
 };
@@ -451,7 +453,9 @@ __global__ __launch_bounds__(256) void conv1d_bf16x3_dma_kernel(ConvMfmaParams p
   const int nxs = 2 * lin_t, nws = MT * (2 * K + 1);         // 16-byte slots per input / weight array and stage
   const int nxc = (nxs + 63) >> 6, nwc = (nws + 63) >> 6;    // 64-slot chunks (the tail chunk over-writes into padding)
   const int XS = nxc * 512, WS = nwc * 512;                  // elements per array and stage
-  const int STAGE = 2 * (XS + WS);                           // [x hi][x lo][w hi][w lo]
+  const int NBS = p.NBS;                                     // channel blocks per stage
+  const int STAGE1 = 2 * (XS + WS);                          // one block: [x hi][x lo][w hi][w lo]
+  const int STAGE = NBS * STAGE1;
   bf16* smem = reinterpret_cast<bf16*>(cm_smem);
   const int xhalf = lin_t * 8;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, col = lane & 31;
@@ -464,46 +468,53 @@ __global__ __launch_bounds__(256) void conv1d_bf16x3_dma_kernel(ConvMfmaParams p
   const int j0 = bx * LT, m0 = by * MT, b0 = bz * nseg;
   const int in0 = j0 * p.stride - p.pad;
   const int nblk = (p.N + 15) / 16;
-  // this lane's DMA sources for stage 0 (stage nb adds a constant); chunk c belongs to wave c % 4
+  const int64_t xlo_d = p.x_lo - p.x_hi, wlo_d = p.a_lo - p.a_hi;
+  const int64_t xstep = (int64_t)2 * p.Lp * 8, wstep = (int64_t)p.Mpad * AP;
+  // this lane's DMA sources for stage 0 (stage s adds s * NBS blocks); chunk c = wave + 4 i of the stage's NBS * nxc (nwc)
+  // chunks: block c / nxc, chunk-in-block c % nxc
   const bf16* xsrc[XC];
   const bf16* wsrc[V2_WC];
+  int xdst[XC], wdst[V2_WC], xblk[XC], wblk[V2_WC];
 #pragma unroll
   for (int i = 0; i < XC; ++i) {
-    const int q = min((wave + 4 * i) * 64 + lane, nxs - 1);
+    const int c = wave + 4 * i, blk = c / nxc, cc = c - blk * nxc;
+    const int q = min(cc * 64 + lane, nxs - 1);
     const int half = q >= lin_t, pp = q - half * lin_t;
     const int sg = pp / lin_s, pos = pp - sg * lin_s;
     const int b = min(b0 + sg, p.B - 1);
-    xsrc[i] = p.x_hi + ((((int64_t)b * nblk) * 2 + half) * p.Lp + (p.PADL + in0 + pos)) * 8;
+    xsrc[i] = p.x_hi + ((((int64_t)b * nblk) * 2 + half) * p.Lp + (p.PADL + in0 + pos)) * 8 + blk * xstep;
+    xdst[i] = blk * STAGE1 + cc * 512;
+    xblk[i] = c < NBS * nxc ? blk : 1 << 20;
   }
 #pragma unroll
   for (int i = 0; i < V2_WC; ++i) {
-    const int q = min((wave + 4 * i) * 64 + lane, nws - 1);
-    wsrc[i] = p.a_hi + (int64_t)m0 * AP + (int64_t)q * 8;
+    const int c = wave + 4 * i, blk = c / nwc, cc = c - blk * nwc;
+    const int q = min(cc * 64 + lane, nws - 1);
+    wsrc[i] = p.a_hi + (int64_t)m0 * AP + (int64_t)q * 8 + blk * wstep;
+    wdst[i] = blk * STAGE1 + 2 * XS + cc * 512;
+    wblk[i] = c < NBS * nwc ? blk : 1 << 20;
   }
-  const int64_t xlo_d = p.x_lo - p.x_hi, wlo_d = p.a_lo - p.a_hi;
-  const int64_t xstep = (int64_t)2 * p.Lp * 8, wstep = (int64_t)p.Mpad * AP;
-  auto issue = [&](int nb, int buf) {
+  auto issue = [&](int st_i, int buf) {
     bf16* st = smem + buf * STAGE;
+    const int nb0 = st_i * NBS;
 #pragma unroll
     for (int i = 0; i < XC; ++i) {
-      const int c = wave + 4 * i;
-      if (c < nxc) {
-        const bf16* g = xsrc[i] + nb * xstep;
+      if (nb0 + xblk[i] < nblk) {                            // wave-uniform (blocks beyond the last one are skipped)
+        const bf16* g = xsrc[i] + nb0 * xstep;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(st + c * 512), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(st + xdst[i]), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + xlo_d),
-                                         (__attribute__((address_space(3))) void*)(st + XS + c * 512), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(st + xdst[i] + XS), 16, 0, 0);
       }
     }
 #pragma unroll
     for (int i = 0; i < V2_WC; ++i) {
-      const int c = wave + 4 * i;
-      if (c < nwc) {
-        const bf16* g = wsrc[i] + nb * wstep;
+      if (nb0 + wblk[i] < nblk) {
+        const bf16* g = wsrc[i] + nb0 * wstep;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(st + 2 * XS + c * 512), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(st + wdst[i]), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + wlo_d),
-                                         (__attribute__((address_space(3))) void*)(st + 2 * XS + WS + c * 512), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(st + wdst[i] + WS), 16, 0, 0);
       }
     }
   };
@@ -518,14 +529,19 @@ __global__ __launch_bounds__(256) void conv1d_bf16x3_dma_kernel(ConvMfmaParams p
   int arow[CW];
 #pragma unroll
   for (int i = 0; i < CW; ++i) arow[i] = ((wco * CW + i) * 32 + col) * AP + hh * 8;
+  const int nstage = (nblk + NBS - 1) / NBS;
   issue(0, 0);
-  for (int nb = 0; nb < nblk; ++nb) {
-    // stage nb has landed (every wave drains its own DMA before the barrier) and nobody still reads the other buffer
+  for (int si = 0; si < nstage; ++si) {
+    // stage si has landed (every wave drains its own DMA before the barrier) and nobody still reads the other buffer
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (nb + 1 < nblk) issue(nb + 1, (nb + 1) & 1);
-    const bf16* xh = smem + (nb & 1) * STAGE;
-    b3_stage<CW, KT>(xh, xh + XS, xh + 2 * XS, xh + 2 * XS + WS, arow, bpos0, bpos1, K, p.dil * 8, acc);
+    if (si + 1 < nstage) issue(si + 1, (si + 1) & 1);
+    const bf16* sb = smem + (si & 1) * STAGE;
+    for (int blk = 0; blk < NBS; ++blk) {
+      if (si * NBS + blk >= nblk) break;
+      const bf16* xh = sb + blk * STAGE1;
+      b3_stage<CW, KT>(xh, xh + XS, xh + 2 * XS, xh + 2 * XS + WS, arow, bpos0, bpos1, K, p.dil * 8, acc);
+    }
   }
 #pragma unroll
   for (int i = 0; i < CW; ++i)
@@ -678,7 +694,7 @@ static int conv_seg_request(int Lout, int B) {
 }
 
 // geometry of the DMA-fed kernel for one launch: LDS bytes, chunk counts, and the zero pads its pre-split input rows need
-struct DmaGeom { size_t smem; int nxc, nwc, padl, padr; int64_t wgs; bool ok; };
+struct DmaGeom { size_t smem; int nxc, nwc, padl, padr, nbs; int64_t wgs; bool ok; };
 static DmaGeom conv_dma_geom(const ConvMfmaParams& p, int CW) {
   const int MT = 64, LT = 128 * CW;
   const int SEG = p.SEG > LT ? LT : p.SEG, K = p.K;
@@ -686,12 +702,20 @@ static DmaGeom conv_dma_geom(const ConvMfmaParams& p, int CW) {
   DmaGeom g;
   g.nxc = (2 * lin_t + 63) / 64;
   g.nwc = (MT * (2 * K + 1) + 63) / 64;
-  g.smem = (size_t)2 * 2 * (g.nxc + g.nwc) * 512 * sizeof(bf16);
   const int last = (SEG == LT ? (int)cdiv(p.Lout, LT) * LT : SEG) - 1;   // last row-relative output position a tile touches
   g.padl = std::max(0, p.pad);
   g.padr = std::max(0, last * p.stride + (K - 1) * p.dil - p.pad + 1 - p.Lin);
   g.wgs = cdiv(p.Lout, SEG == LT ? LT : SEG) * cdiv(p.M, MT) * cdiv(p.B, LT / SEG);
-  g.ok = g.nxc <= 4 * (CW == 1 ? 4 : 7) && g.nwc <= 4 * V2_WC && g.smem <= 150 * 1024 && p.M > 32 && p.N >= 16;
+  // channel blocks per stage: as many as the chunk tables and LDS allow -- two workgroups per CU when the launch has more
+  // than one per CU, the whole LDS otherwise (a launch of <= 256 workgroups only has its own stages to hide latency behind)
+  const int xcmax = 4 * (CW == 1 ? 4 : 7), nblk = (p.N + 15) / 16;
+  const size_t stage1 = (size_t)2 * (g.nxc + g.nwc) * 512 * sizeof(bf16);
+  const size_t lds_cap = g.wgs > 256 ? 78 * 1024 : 150 * 1024;
+  g.nbs = 1;
+  for (int cand = 4; cand >= 2; cand >>= 1)
+    if (cand * g.nxc <= xcmax && cand * g.nwc <= 4 * V2_WC && cand <= nblk && 2 * cand * stage1 <= lds_cap) { g.nbs = cand; break; }
+  g.smem = 2 * g.nbs * stage1;
+  g.ok = g.nxc <= xcmax && g.nwc <= 4 * V2_WC && g.smem <= 150 * 1024 && p.M > 32 && p.N >= 16;
   return g;
 }
 // the 64 x 256 tile when it still yields >= 2 workgroups per CU (flag 131072: never, flag 262144: whenever it fits)
@@ -722,6 +746,8 @@ static int conv1d_bf16x3_dma_launch(ConvMfmaParams p, const ConvCtx& cx, hipStre
   const DmaGeom g = conv_dma_geom(p, CW);
   p.SEG = SEG;
   if (!g.ok) return TTTS_OK;
+  p.NBS = (cx.flags & 268435456) ? 1 : g.nbs;     // (flag 268435456: one channel block per stage, for comparison)
+  const size_t dma_smem = (size_t)2 * p.NBS * 2 * (g.nxc + g.nwc) * 512 * sizeof(bf16);
   const int nblk = (p.N + 15) / 16, AP = K * 16 + 8;
   p.Mpad = (int)(cdiv(p.M, MT) * MT);
   if (!p.x_hi) { p.PADL = g.padl; p.Lp = (int)cdiv(g.padl + p.Lin + g.padr, 8) * 8; }
@@ -748,7 +774,7 @@ static int conv1d_bf16x3_dma_launch(ConvMfmaParams p, const ConvCtx& cx, hipStre
     static bool attr_ = false;                                                                                    \
     rc = set_attr_once(reinterpret_cast<const void*>(conv1d_bf16x3_dma_kernel<CW_, KT_>), attr_);                 \
     if (rc) return rc;                                                                                            \
-    conv1d_bf16x3_dma_kernel<CW_, KT_><<<grid, 256, g.smem, stream>>>(p);                                        \
+    conv1d_bf16x3_dma_kernel<CW_, KT_><<<grid, 256, dma_smem, stream>>>(p);                                        \
   }
 #define TTTS_DMA_K(CW_)                                                                                          \
   switch ((cx.flags & 33554432) ? 0 : K) {   /* flag 33554432: runtime tap loop everywhere */                    \
