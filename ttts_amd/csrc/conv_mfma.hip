@@ -529,6 +529,9 @@ __global__ __launch_bounds__(256) void conv1d_bf16x3_dma_kernel(ConvMfmaParams p
   int arow[CW];
 #pragma unroll
   for (int i = 0; i < CW; ++i) arow[i] = ((wco * CW + i) * 32 + col) * AP + hh * 8;
+  // (A ring of 3-5 stage buffers with DEPTH - 1 stages in flight and counted vmcnt waits -- one block per stage -- was measured
+  // for the 1-tap / 3-tap layers and LOST: 1 x 1 convolution 33 -> 52 us.  The per-stage cost is the barrier + DMA issue, not the
+  // DMA latency, so FEWER, LARGER stages (NBS) is the lever, not deeper look-ahead.)
   const int nstage = (nblk + NBS - 1) / NBS;
   issue(0, 0);
   for (int si = 0; si < nstage; ++si) {
