@@ -669,7 +669,7 @@ def test_full_vqvae_gan_step_split_bf16(golden_dir):
                                   (32, 32, 3, 1, 3, 3, 1000), (128, 128, 7, 1, 3, 1, 320), (40, 48, 11, 1, 15, 3, 517),
                                   (96, 96, 11, 1, 5, 1, 129), (64, 64, 7, 1, 15, 5, 64), (256, 256, 3, 1, 5, 5, 320),
                                   (256, 256, 5, 1, 2, 1, 23), (128, 256, 3, 1, 1, 1, 37), (192, 192, 7, 1, 3, 1, 85),
-                                  (256, 128, 5, 3, 2, 1, 1200), (128, 512, 5, 3, 2, 1, 70), (32, 128, 5, 3, 2, 1, 621)])
+                                  (256, 128, 5, 3, 2, 1, 1200), (128, 512, 5, 3, 2, 1, 70), (32, 128, 5, 3, 2, 1, 621), (192, 384, 1, 1, 0, 1, 256), (512, 256, 1, 1, 0, 1, 100)])
 def test_split_bf16_weight_gradient_accuracy(case):
     """Weight gradient on the default path (pre-split / phase-de-interleaved operands, one tap per workgroup)."""
     from ttts_amd import ops

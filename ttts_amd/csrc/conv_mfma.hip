@@ -1483,7 +1483,7 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, f
   // exact-fp32 MFMA kernel they used to take ran at 15-60 TF/s).  Flag 16384: never; flag 1048576: not below 128 channels.
   const bool wide_c = (int64_t)Cin * Cout > 128 * 128;     // pre-split 64 x 64 tiles above, the fused 32 x 32 kernel up to 128 x 128
                                                            // channels (measured at 128: 153-167 us against 190; a tie at 256)
-  const bool k5 = K == 5 && dil == 1 && wide_c;          // (DiscriminatorP / S and the WN in-layers; pre-split kernel only)
+  const bool k5 = (K == 5 || K == 1) && dil == 1 && wide_c;   // (DiscriminatorP / S, the WN in-layers, 1 x 1 convolutions; pre-split kernel only)
   const bool taps = stride == 1 && (((K == 3 || K == 7 || K == 11) && (dil == 1 || dil == 3 || dil == 5)) || k5) &&
                     (wide_c || (Cin >= 16 && Cout >= 16 && !(cx.flags & 1048576))) && !(cx.flags & 16384);
   const int TT = wide_c ? 64 : 32;
@@ -1546,7 +1546,7 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, f
       WgradB3Params p{dyh, dyl, xh, xl, dw, Bk, Cin, Cout, K, 1, dil, Lq, Li, 0, x_par, cpb, nchunks, nlc, slab};
       dim3 grid((unsigned)cdiv(Cin, 64), (unsigned)cdiv(Cout, 64), (unsigned)nsplit);
 #define TTTS_TAPS(KK, DD) if (K == KK && dil == DD) launch_wgrad_taps<KK, DD>(p, grid, 64, stream);
-      TTTS_TAPS(3, 1) TTTS_TAPS(3, 3) TTTS_TAPS(3, 5) TTTS_TAPS(5, 1) TTTS_TAPS(7, 1) TTTS_TAPS(7, 3) TTTS_TAPS(7, 5)
+      TTTS_TAPS(1, 1) TTTS_TAPS(3, 1) TTTS_TAPS(3, 3) TTTS_TAPS(3, 5) TTTS_TAPS(5, 1) TTTS_TAPS(7, 1) TTTS_TAPS(7, 3) TTTS_TAPS(7, 5)
       TTTS_TAPS(11, 1) TTTS_TAPS(11, 3) TTTS_TAPS(11, 5)
 #undef TTTS_TAPS
       wgrad_slab_reduce_kernel<<<dim3((unsigned)std::min<int64_t>(cdiv((int64_t)K * Cout * Cin, 256), 4096), (unsigned)cdiv(nsplit, SLAB_G)), 256, 0, stream>>>(slab, dw, nsplit, K, Cout, Cin, nullptr, nullptr);
