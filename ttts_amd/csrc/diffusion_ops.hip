@@ -66,12 +66,15 @@ __global__ __launch_bounds__(256) void groupnorm_bwd_kernel(const float* __restr
   const int64_t base = ((int64_t)b * C + g * Cg) * T;
   const float mean = mean_in[blockIdx.x], rstd = rstd_in[blockIdx.x];
   float sum_dz = 0.f, sum_dzz = 0.f;      // group sums of dz and dz * z (thread-partial, reduced once at the end)
-  for (int cl = 0; cl < Cg; ++cl) {
+  // one channel per WAVE at a time: its four per-channel sums are wave reductions (the block-wide form cost four barrier pairs per
+  // channel, 64+ per workgroup)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int cl = wave; cl < Cg; cl += 4) {
     const int c = g * Cg + cl;
     const float gm = gamma[c], bt = beta[c];
     const float sc = ss ? ss[(int64_t)b * 2 * C + c] : 0.f, sf = ss ? ss[(int64_t)b * 2 * C + C + c] : 0.f;
     float s_da = 0.f, s_daz = 0.f, s_dua = 0.f, s_du = 0.f;
-    for (int t = threadIdx.x; t < T; t += 256) {
+    for (int t = lane; t < T; t += 64) {
       const int64_t o = base + (int64_t)cl * T + t;
       const float z = (x[o] - mean) * rstd;
       const float a = z * gm + bt;
@@ -83,9 +86,9 @@ __global__ __launch_bounds__(256) void groupnorm_bwd_kernel(const float* __restr
       const float dz = da * gm;
       sum_dz += dz; sum_dzz += dz * z;
     }
-    s_da = block_sum(s_da, sh); s_daz = block_sum(s_daz, sh);
-    if (ss) { s_dua = block_sum(s_dua, sh); s_du = block_sum(s_du, sh); }
-    if (threadIdx.x == 0) {
+    s_da = wave_sum(s_da); s_daz = wave_sum(s_daz);
+    if (ss) { s_dua = wave_sum(s_dua); s_du = wave_sum(s_du); }
+    if (lane == 0) {
       pg[(int64_t)b * C + c] = s_daz;
       pb[(int64_t)b * C + c] = s_da;
       if (ss) { dss[(int64_t)b * 2 * C + c] = s_dua; dss[(int64_t)b * 2 * C + C + c] = s_du; }
