@@ -82,14 +82,18 @@ __device__ __forceinline__ void drop_keep4(uint32_t rowh, const uint32_t* colm4,
   for (int e = 0; e < 4; ++e) k[e] = drop_keep(rowh, m[e], thr32);
 }
 
-// load / store a 64 x DH bf16 tile (rows row0.. of a [*, stride] matrix, zero beyond nrows)
-template <int DH>
+// load / store a 64 x DH bf16 tile (rows row0.. of a [*, stride] matrix).  Rows beyond nrows: the load is unconditional from the
+// last valid row (a guarded load compiles to an exec-masked branch per 16-byte piece -- 8 branches per loop iteration); ZERO
+// then selects zeros (needed where padding rows must contribute nothing: Q / dO rows of the dK-dV kernel), otherwise the
+// duplicate row is left in place -- K / V rows beyond the sequence only meet probabilities that are masked to exactly 0.
+template <int DH, bool ZERO = true>
 __device__ __forceinline__ void tile_load(bf16x8 (&r)[AttnCfg<DH>::CPT], const bf16* base, int64_t stride, int row0,
                                           int nrows, int tid) {
 #pragma unroll
   for (int i = 0; i < AttnCfg<DH>::CPT; ++i) {
     const int c = tid + i * 256, row = c / AttnCfg<DH>::CPR, dc = (c % AttnCfg<DH>::CPR) * 8;
-    r[i] = (row0 + row < nrows) ? *reinterpret_cast<const bf16x8*>(base + (int64_t)(row0 + row) * stride + dc) : zero8();
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(base + (int64_t)min(row0 + row, nrows - 1) * stride + dc);
+    r[i] = (!ZERO || row0 + row < nrows) ? v : zero8();
   }
 }
 template <int DH, int STR>
@@ -139,8 +143,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   const int kv_end = min(p.S, qb * 128 + 128);
   const int nt = (kv_end + 63) / 64;
   bf16x8 rk[C::CPT], rv[C::CPT];
-  tile_load<DH>(rk, kp, p.ss, 0, p.S, tid);
-  tile_load<DH>(rv, vp, p.ss, 0, p.S, tid);
+  tile_load<DH, false>(rk, kp, p.ss, 0, p.S, tid);
+  tile_load<DH, false>(rv, vp, p.ss, 0, p.S, tid);
   tile_store<DH, C::KSTR>(rk, Ks[0], tid);
   tile_store<DH, C::VSTR>(rv, Vs[0], tid);
   const uint32_t shi = DROPOUT ? seed_mix(p.seed_hi, p.ctr) : 0u;
@@ -154,8 +158,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   for (int jt = 0; jt < nt; ++jt) {
     const int buf = jt & 1, kv0 = jt * 64;
     if (jt + 1 < nt) {
-      tile_load<DH>(rk, kp, p.ss, kv0 + 64, p.S, tid);
-      tile_load<DH>(rv, vp, p.ss, kv0 + 64, p.S, tid);
+      tile_load<DH, false>(rk, kp, p.ss, kv0 + 64, p.S, tid);
+      tile_load<DH, false>(rv, vp, p.ss, kv0 + 64, p.S, tid);
     }
     if (kv0 <= q_base + 31) {  // wave-uniform: at least one (query, key) pair of this wave is unmasked
       f32x16 s[2];
@@ -260,10 +264,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 template <int DH, int ROWS>
 __device__ __forceinline__ void tile_load_rows(bf16x8 (&r)[ROWS * (DH / 8) / 256], const bf16* base, int64_t stride, int row0,
                                                int nrows, int tid) {
+  // K / V super tile: unconditional loads, rows beyond the sequence repeat the last one (see tile_load)
 #pragma unroll
   for (int i = 0; i < ROWS * (DH / 8) / 256; ++i) {
     const int c = tid + i * 256, row = c / (DH / 8), dc = (c % (DH / 8)) * 8;
-    r[i] = (row0 + row < nrows) ? *reinterpret_cast<const bf16x8*>(base + (int64_t)(row0 + row) * stride + dc) : zero8();
+    r[i] = *reinterpret_cast<const bf16x8*>(base + (int64_t)min(row0 + row, nrows - 1) * stride + dc);
   }
 }
 template <int DH, int ROWS, int STR>
@@ -506,8 +511,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
   const int kv_end = min(p.S, qb * 128 + 128);
   const int nt = (kv_end + 63) / 64;
   bf16x8 rk[C::CPT], rv[C::CPT];
-  tile_load<DH>(rk, kp, p.ss, 0, p.S, tid);
-  tile_load<DH>(rv, vp, p.ss, 0, p.S, tid);
+  tile_load<DH, false>(rk, kp, p.ss, 0, p.S, tid);
+  tile_load<DH, false>(rv, vp, p.ss, 0, p.S, tid);
   tile_store<DH, C::KSTR>(rk, Ks[0], tid);
   tile_store<DH, C::KSTR>(rv, Vs[0], tid);
   const uint32_t shi = DROPOUT ? seed_mix(p.seed_hi, p.ctr) : 0u;
@@ -521,8 +526,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
   for (int jt = 0; jt < nt; ++jt) {
     const int buf = jt & 1, kv0 = jt * 64;
     if (jt + 1 < nt) {
-      tile_load<DH>(rk, kp, p.ss, kv0 + 64, p.S, tid);
-      tile_load<DH>(rv, vp, p.ss, kv0 + 64, p.S, tid);
+      tile_load<DH, false>(rk, kp, p.ss, kv0 + 64, p.S, tid);
+      tile_load<DH, false>(rv, vp, p.ss, kv0 + 64, p.S, tid);
     }
     if (kv0 <= q_base + 31) {
       bf16x8 dsf[2][2];
