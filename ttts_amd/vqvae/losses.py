@@ -40,8 +40,14 @@ class _ReduceLoss(torch.autograd.Function):
         return d, None, None, None
 
 
+def _aligned(t):
+    """The reduction kernels read 16 bytes per lane: a view that starts mid-allocation (the generated half of a batched
+    discriminator output) is copied once; whole tensors pass through."""
+    return t if t is None or t.data_ptr() % 16 == 0 else t.clone()
+
+
 def _mean_term(a, b, mode, mult=1.0):
-    return _ReduceLoss.apply(a, b, mode, mult / a.numel())
+    return _ReduceLoss.apply(_aligned(a), _aligned(b), mode, mult / a.numel())
 
 
 def l1_loss(target, pred):

@@ -88,6 +88,7 @@ class VqvaeStep:
     def __init__(self, hps, net_g, net_d, optim_g, optim_d, aug=None, dp=None):
         self.hps, self.net_g, self.net_d, self.optim_g, self.optim_d, self.aug = hps, net_g, net_d, optim_g, optim_d, aug
         self.dp = dp if dp is not None else FlatDataParallel()
+        self._d_params = [prm for prm in net_d.parameters() if prm.requires_grad]
 
     def _sync_buffers(self):
         if self.dp.enabled:                                                  # DDP broadcast_buffers=True (rank-0 codebook)
@@ -124,7 +125,12 @@ class VqvaeStep:
         (loss_disc * scale).backward()
         self.dp.allreduce_grads_(self.optim_d.flat_g)
         self.optim_d.step()
-        # ---- generator phase
+        # ---- generator phase.  The reference lets this backward fill net_d's parameter gradients too and throws them away at
+        # the next `optim_d.zero_grad()` (vqvae/train.py:354-372 there): here the discriminator's parameters are frozen for the
+        # phase, so autograd only runs the data gradients the generator needs -- same losses, same updates, no discarded
+        # weight-gradient / weight-norm / bias-gradient launches.
+        for prm in self._d_params:
+            prm.requires_grad_(False)
         y_d_hat_r, y_d_hat_g, fmap_r, fmap_g = self.net_d(y, y_hat)
         loss_mel = L.l1_loss(y_mel, y_hat_mel) * tr.c_mel
         loss_kl = L.kl_loss(z_p, logs_q, m_p, logs_p, z_mask) * tr.c_kl
@@ -133,7 +139,9 @@ class VqvaeStep:
         loss_gen_all = loss_gen + loss_fm + loss_mel + kl_ssl * 1 + loss_kl
         self.optim_g.zero_grad()
         (loss_gen_all * scale).backward()
-        self.optim_d.zero_grad()                                             # the G backward also reached net_d's arena
+        for prm in self._d_params:
+            prm.requires_grad_(True)
+        self.optim_d.zero_grad()
         self.dp.allreduce_grads_(self.optim_g.flat_g)
         self.optim_g.step()
         return {"loss_disc": loss_disc.detach(), "loss_gen": loss_gen.detach(), "loss_fm": loss_fm.detach(),

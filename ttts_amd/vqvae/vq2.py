@@ -88,8 +88,23 @@ class MultiPeriodDiscriminator(nn.Module):
 
     def forward(self, y, y_hat):
         y_d_rs, y_d_gs, fmap_rs, fmap_gs = [], [], [], []
+        # Discriminator phase (no gradient flows to y_hat): real and generated clips go through each sub-discriminator as ONE
+        # batch of 2B -- the layers are per-sample (no batch statistics), so every output is the same, with half the launches,
+        # one weight-norm / operand split per layer instead of two, and fuller tiles on the short DiscriminatorP rows.
+        # Generator phase: separate calls, the real branch without an autograd graph (its features are detached constants).
+        if not (torch.is_grad_enabled() and y_hat.requires_grad):
+            both = torch.cat([y, y_hat], 0)
+            for d in self.discriminators:
+                out, fmap = d(both)
+                y_d_r, y_d_g = out.chunk(2, 0)
+                y_d_rs.append(y_d_r)
+                y_d_gs.append(y_d_g)
+                fmap_rs.append([f.chunk(2, 0)[0] for f in fmap])
+                fmap_gs.append([f.chunk(2, 0)[1] for f in fmap])
+            return y_d_rs, y_d_gs, fmap_rs, fmap_gs
         for d in self.discriminators:
-            y_d_r, fmap_r = d(y)
+            with torch.no_grad():
+                y_d_r, fmap_r = d(y)
             y_d_g, fmap_g = d(y_hat)
             y_d_rs.append(y_d_r)
             y_d_gs.append(y_d_g)
