@@ -156,6 +156,8 @@ def vqvae_leg(dev, steps, warmup, cpu_leg=True):
            "config": {"workload": "VQ-VAE-GAN two-phase step (spectrograms, SynthesizerTrn, mel, MPD x2, 6 losses, 2 x AdamW, codebook EMA), "
                                   "batch 32 x 163 840 samples (256 frames), %s" % ("one hipGraph replay per step" if graphed else "eager launches (capture refused)")},
            "algorithmic_tflops": round(1.97e9 * B * 256 / dt / 1e12, 1),
+           "algorithmic_tflops_note": "1.97 GFLOP per frame = the REFERENCE step, which also computes (and discards) the discriminator's "
+                                      "parameter gradients in the generator phase; this build skips them, so executed FLOPs are lower",
            "roofline": {"bound": "mfma", "kernel": "conv1d_{fwd,dgrad,wgrad} (split-bf16 implicit GEMM; %d launches per step)" % tot_n,
                         "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                         "traffic": conv_traffic, "traffic_note": "HBM-side bytes of the whole family per STEP (incl. operand pre-passes "
