@@ -131,16 +131,18 @@ class VqvaeStep:
         # weight-gradient / weight-norm / bias-gradient launches.
         for prm in self._d_params:
             prm.requires_grad_(False)
-        y_d_hat_r, y_d_hat_g, fmap_r, fmap_g = self.net_d(y, y_hat)
-        loss_mel = L.l1_loss(y_mel, y_hat_mel) * tr.c_mel
-        loss_kl = L.kl_loss(z_p, logs_q, m_p, logs_p, z_mask) * tr.c_kl
-        loss_fm = L.feature_loss(fmap_r, fmap_g)
-        loss_gen, losses_gen = L.generator_loss(y_d_hat_g)
-        loss_gen_all = loss_gen + loss_fm + loss_mel + kl_ssl * 1 + loss_kl
-        self.optim_g.zero_grad()
-        (loss_gen_all * scale).backward()
-        for prm in self._d_params:
-            prm.requires_grad_(True)
+        try:
+            y_d_hat_r, y_d_hat_g, fmap_r, fmap_g = self.net_d(y, y_hat)
+            loss_mel = L.l1_loss(y_mel, y_hat_mel) * tr.c_mel
+            loss_kl = L.kl_loss(z_p, logs_q, m_p, logs_p, z_mask) * tr.c_kl
+            loss_fm = L.feature_loss(fmap_r, fmap_g)
+            loss_gen, losses_gen = L.generator_loss(y_d_hat_g)
+            loss_gen_all = loss_gen + loss_fm + loss_mel + kl_ssl * 1 + loss_kl
+            self.optim_g.zero_grad()
+            (loss_gen_all * scale).backward()
+        finally:
+            for prm in self._d_params:
+                prm.requires_grad_(True)
         self.optim_d.zero_grad()
         self.dp.allreduce_grads_(self.optim_g.flat_g)
         self.optim_g.step()
