@@ -269,6 +269,38 @@ def test_discriminators_and_losses_match_reference_fixture(golden_dir):
         _close(z.grad, torch.from_numpy(want) * 3.0, 1e-5, 1e-7, "kl grad")
 
 
+def test_discriminator_batched_phase_equals_separate_calls():
+    """Discriminator phase: real + generated clips go through each sub-discriminator as one batch of 2B; generator phase:
+    two calls (real branch without a graph).  Same logits, same feature maps, same parameter gradients."""
+    from oracle import vqvae_ref
+    from ttts_amd.vqvae import losses as L
+    from ttts_amd.vqvae.vq2 import MultiPeriodDiscriminator
+    mpd = MultiPeriodDiscriminator()
+    mpd.load_state_dict({k: vqvae_ref.det_fill(k, v.shape) for k, v in mpd.state_dict().items()})
+    mpd = mpd.to(_dev())
+    g = torch.Generator().manual_seed(11)
+    y = (torch.rand(3, 1, 8192, generator=g) - 0.5).to(_dev()); y_hat = (torch.rand(3, 1, 8192, generator=g) - 0.5).to(_dev())
+    dr_b, dg_b, fr_b, fg_b = mpd(y, y_hat)                                   # batched (no gradient to y_hat)
+    loss_b, _, _ = L.discriminator_loss(dr_b, dg_b)
+    loss_b.backward()
+    grads_b = [p.grad.clone() for p in mpd.parameters()]
+    mpd.zero_grad()
+    yh = y_hat.clone().requires_grad_(True)
+    dr_s, dg_s, fr_s, fg_s = mpd(y, yh)                                      # separate calls
+    for a, b in zip(dr_b + dg_b, dr_s + dg_s):
+        _close(a, b, 1e-6, 1e-7, "logits")
+    for fa, fb in zip(fr_b + fg_b, fr_s + fg_s):
+        for a, b in zip(fa, fb):
+            _close(a, b, 1e-6, 1e-7, "fmap")
+    assert all(not t.requires_grad for fl in fr_s for t in fl)               # the real branch carries no graph
+    # parameter gradients of the discriminator loss through the two-call form (real branch re-run with a graph)
+    dr2 = [d(y)[0] for d in mpd.discriminators]
+    loss_s, _, _ = L.discriminator_loss(dr2, [t for t in dg_s])
+    loss_s.backward()
+    for pb, p in zip(grads_b, mpd.parameters()):
+        _close(p.grad, pb, 2e-4, 1e-7 * float(pb.abs().max()) + 1e-9, "param grad")
+
+
 def test_l1_loss_and_layout_agnostic_feature_pairs():
     from ttts_amd.vqvae import losses as L
     g = torch.Generator().manual_seed(9)
