@@ -259,11 +259,24 @@ class KernelTimer:
         self._wrap("gemm_tn_accum", f_tn)
         self._wrap("attn_fwd", f_af)
         self._wrap("attn_bwd", f_ab)
+        # the grouped weight-gradient launch (all dW GEMMs of a backward section in one grid) is a method of its plan object
+        plan_run = self.ops.TnPlan.run
+        self._plan_run = plan_run
+        timer = self
+
+        def timed_run(plan):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            plan_run(plan)
+            e1.record()
+            timer.records.append(("gemm_tn_grouped_kernel", plan.flops, e0, e1, timer.step))
+        self.ops.TnPlan.run = timed_run
         return self
 
     def __exit__(self, *exc):
         for k, v in self.saved.items():
             setattr(self.ops, k, v)
+        self.ops.TnPlan.run = self._plan_run
 
     def summary(self):
         """{family: [launches, seconds, flops]} over all instrumented steps.  Robust to one-off stalls: launch k of a family is

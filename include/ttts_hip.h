@@ -84,6 +84,25 @@ int ttts_gemm_nt_bf16_ex(const void* A, int64_t lda, const void* B, int64_t ldb,
 int64_t ttts_gemm_tn_workspace_bytes(int32_t Mo, int32_t No, int32_t Kr);
 int ttts_gemm_tn_bf16_accum_f32(const void* At, int64_t ldat, const void* Bt, int64_t ldbt, float* C,
                                 int64_t ldc, int32_t Mo, int32_t No, int32_t Kr, void* workspace, void* stream);
+/* Grouped form of the weight-gradient GEMM: several problems C_i[Mo_i,No_i] += At_i[Kr_i,Mo_i]^T . Bt_i[Kr_i,No_i] in ONE
+ * launch, one workgroup per 128x128 output tile over the tile's WHOLE reduction (no slabs, no second kernel; the result
+ * is deterministic).  Meant for a backward pass that keeps its dY buffers and runs all dW GEMMs together: the tiles of
+ * all problems fill the GPU where a single dW GEMM cannot (same reference call sites as ttts_gemm_tn_bf16_accum_f32:
+ * the Conv1D / Linear weight gradients of the GPT blocks, ttts/gpt/model.py:422 via autograd).
+ * desc_dev: DEVICE array of n_desc (<= 64) descriptors that ttts_tn_desc_prepare validated and completed on the host.
+ * Requirements per problem: Kr % 64 == 0 (zero-pad the operands' rows), ldat/ldbt % 8 == 0 and >= roundup8(Mo/No),
+ * ldc % 4 == 0, 16-byte aligned bases. */
+typedef struct {
+  const void* At; /* [Kr, ldat] bf16 */
+  const void* Bt; /* [Kr, ldbt] bf16 */
+  float* C;       /* [Mo, ldc] fp32, accumulated into */
+  int64_t ldat, ldbt, ldc;
+  int32_t Mo, No, Kr;
+  int32_t tile_begin; /* exclusive prefix sum of the 128x128 output tiles of earlier descriptors (filled by _prepare) */
+} ttts_tn_desc;
+int32_t ttts_tn_desc_tiles(int32_t Mo, int32_t No);
+int ttts_tn_desc_prepare(ttts_tn_desc* host_desc, int32_t n_desc, int32_t* total_tiles);
+int ttts_gemm_tn_grouped_bf16_accum_f32(const ttts_tn_desc* desc_dev, int32_t n_desc, int32_t total_tiles, void* stream);
 /* out[n] += sum_m X[m][n]   (bias gradients; X bf16 [M, ldx]) */
 int ttts_colsum_bf16_accum_f32(const void* X, int64_t ldx, float* out, int32_t M, int32_t N, void* stream);
 /* Batched fp32 -> bf16 cast (+ optional transposed copy) of parameter matrices.

@@ -172,6 +172,41 @@ def test_gemm_tn_accumulates(ops, Kr, Mo, No):
     assert rel_err(c, ref) < 3e-6   # fp32 accumulation, split-K atomics
 
 
+def test_gemm_tn_grouped_matches_fp64_and_is_deterministic(ops):
+    """Several weight-gradient problems in one launch (ttts_gemm_tn_grouped_bf16_accum_f32): every tile over its whole
+    reduction, C += acc; ragged Mo / No, different Kr per problem, problems whose tiles straddle the XCD ranges."""
+    g = torch.Generator(device="cpu").manual_seed(77)
+    shapes = [(9280, 512, 1536), (640, 257, 512), (2048, 136, 1000), (64, 128, 128), (1216, 2048, 512)]
+    entries, refs = [], []
+    for Kr, Mo, No in shapes:
+        lda, ldb = (Mo + 7) // 8 * 8, (No + 7) // 8 * 8
+        at = torch.zeros(Kr, lda, dtype=torch.bfloat16)
+        at[:, :Mo] = _bf(torch.randn(Kr, Mo, generator=g))
+        bt = torch.zeros(Kr, ldb, dtype=torch.bfloat16)
+        bt[:, :No] = _bf(torch.randn(Kr, No, generator=g) * 0.1)
+        at, bt = at.to(dev()), bt.to(dev())
+        c0 = torch.randn(Mo, No, generator=g).to(dev())
+        entries.append((at[:, :Mo], bt[:, :No], c0.clone()))
+        refs.append(c0.double() + at[:, :Mo].double().t() @ bt[:, :No].double())
+    plan = ops.TnPlan(entries, dev())
+    assert plan.tiles == sum(ops.tn_desc_tiles(mo, no) for _, mo, no in shapes)
+    plan.run()
+    for (_, _, c), ref in zip(entries, refs):
+        assert rel_err(c, ref) < 3e-6
+    first = [c.clone() for _, _, c in entries]
+    for (_, _, c), (_, mo, no) in zip(entries, shapes):   # second run on the same inputs: bit-identical increments
+        c.zero_()
+    plan.run()
+    again = [c.clone() for _, _, c in entries]
+    for (_, _, c) in entries:
+        c.zero_()
+    plan.run()
+    for a, (_, _, c) in zip(again, entries):
+        assert torch.equal(a, c)
+    with pytest.raises(Exception):   # reduction rows not a multiple of 64: refused on the host, nothing launched
+        ops.TnPlan([(entries[0][0][:100], entries[0][1][:100], entries[0][2])], dev())
+
+
 def test_colsum_and_cast(ops):
     g = torch.Generator(device="cpu").manual_seed(5)
     x = _bf(torch.randn(999, 264, generator=g)).to(dev())

@@ -51,6 +51,19 @@ def test_argument_validation_without_gpu(lib):
     assert l.ttts_gemm_tn_workspace_bytes(512, 1536, 9248) == 8 * 512 * 1536 * 4   # 48 tiles -> 8 slabs
     assert l.ttts_gemm_tn_workspace_bytes(128, 128, 200) == 0                       # single split: no workspace
     assert l.ttts_cast_desc_tiles(257, 512) == 9 * 16
+    # grouped weight-gradient GEMM: host-side descriptor preparation (validation + tile prefix sums), no launch
+    assert l.ttts_tn_desc_tiles(512, 1536) == 48 and l.ttts_tn_desc_tiles(257, 130) == 3 * 2
+    arr = (lib.TnDesc * 3)()
+    for i, (mo, no, kr) in enumerate([(512, 1536, 9280), (2048, 512, 9280), (136, 1000, 640)]):
+        arr[i].At, arr[i].Bt, arr[i].C = p, p, p
+        arr[i].ldat, arr[i].ldbt, arr[i].ldc = mo, no, no
+        arr[i].Mo, arr[i].No, arr[i].Kr = mo, no, kr
+    total = ctypes.c_int32(0)
+    assert l.ttts_tn_desc_prepare(arr, 3, ctypes.byref(total)) == 0
+    assert [arr[i].tile_begin for i in range(3)] == [0, 48, 112] and total.value == 112 + 2 * 8
+    arr[2].Kr = 650
+    assert l.ttts_tn_desc_prepare(arr, 3, ctypes.byref(total)) == -1 and b"multiple of 64" in l.ttts_last_error()
+    assert l.ttts_gemm_tn_grouped_bf16_accum_f32(None, 3, 128, None) == -1 and b"null descriptor" in l.ttts_last_error()
     tw = np.empty(2048, np.float32)
     assert l.ttts_stft_twiddle_host(tw.ctypes.data_as(ctypes.c_void_p), 2048) == 0
     np.testing.assert_allclose(tw[2 * 512:2 * 512 + 2], [0.0, -1.0], atol=1e-7)

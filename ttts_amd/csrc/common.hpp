@@ -96,6 +96,26 @@ __device__ __forceinline__ bf16x4 lds_tr_b64(const bf16* p) {
   s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
   return __builtin_bit_cast(bf16x4, t);
 }
+// LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane, lane-linear destination from a wave-uniform LDS byte address)
+// issued through INLINE ASM, for kernels that read the staged tile with ds_read_b64_tr_b16.  Why not the builtin there:
+// hipcc orders every LDS read that carries no alias-scope metadata -- and the transposed-read intrinsic never does --
+// behind ALL pending LDS-DMA with an s_waitcnt vmcnt(0), i.e. the prefetch of tile t + 1 is waited for before the first
+// fragment of tile t is read and nothing overlaps (seen in the ISA of the TN GEMM kernels; plain ds_read_b128 readers get
+// alias scopes from the LDS lowering pass and are not affected).  The asm form is invisible to that bookkeeping, so the
+// CALLER owns the protocol: lds_dma_wait_all() before the barrier that publishes a stage, and no read of a stage before
+// that barrier.  (Untracked VMEM ops only make the compiler's own vmcnt waits more conservative: loads return in order.)
+__device__ __forceinline__ uint32_t lds_byte_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void lds_dma16_untracked(const void* gsrc, uint32_t lds_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+               :: "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_base)) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+__device__ __forceinline__ void lds_dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 __device__ __forceinline__ bf16x8 cat4(bf16x4 a, bf16x4 b) {
   bf16x8 r;
   r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];

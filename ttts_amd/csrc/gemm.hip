@@ -489,21 +489,22 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(GemmTnParams p) {
     ga[i] = p.At + (int64_t)(kbeg + r) * p.ldat + m0 + min(lc, ca_max) * 8;
     gb[i] = p.Bt + (int64_t)(kbeg + r) * p.ldbt + n0 + min(lc, cb_max) * 8;
   }
+  // (inline-asm DMA: see lds_dma16_untracked in common.hpp -- the builtin would serialise prefetch and fragment reads)
+  const uint32_t lds0 = lds_byte_addr(smem);
   auto issue = [&](int kt, int buf) {
-    bf16* as = smem + (buf * 2 + 0) * 64 * 128 + wave * 16 * 128;
-    bf16* bs = smem + (buf * 2 + 1) * 64 * 128 + wave * 16 * 128;
+    const uint32_t as = lds0 + (uint32_t)(((buf * 2 + 0) * 64 * 128 + wave * 16 * 128) * sizeof(bf16));
+    const uint32_t bs = lds0 + (uint32_t)(((buf * 2 + 1) * 64 * 128 + wave * 16 * 128) * sizeof(bf16));
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[i] + (int64_t)kt * 64 * p.ldat),
-                                       (__attribute__((address_space(3))) void*)(as + i * 4 * 128), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb[i] + (int64_t)kt * 64 * p.ldbt),
-                                       (__attribute__((address_space(3))) void*)(bs + i * 4 * 128), 16, 0, 0);
+      lds_dma16_untracked(ga[i] + (int64_t)kt * 64 * p.ldat, as + (uint32_t)(i * 4 * 128 * sizeof(bf16)));
+      lds_dma16_untracked(gb[i] + (int64_t)kt * 64 * p.ldbt, bs + (uint32_t)(i * 4 * 128 * sizeof(bf16)));
     }
   };
 
   f32x16 acc[2][2];
   ZERO_ACC(acc)
   if (nk > 0) issue(0, 0);
+  lds_dma_wait_all();
   __syncthreads();
   // transposed-read lane map (see gemm_tn_kernel) on the permuted image: lane i' = lane & 15 of group g reads k-row
   // 8*(g >> 1) + (i' >> 2) (+4), logical column block + 16*(g & 1) + 4*(i' & 3)
@@ -537,7 +538,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(GemmTnParams p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) acc[j][i] = mfma32(bfr[j], af[i], acc[j][i]);
     }
-    __syncthreads();
+    lds_dma_wait_all();  // the next tile has landed (this wave's share; the barrier publishes everyone's)
+    __syncthreads();     // ... and everyone is done reading this one
   }
   GemmEpi e{};
   e.M = p.Mo;
@@ -551,6 +553,101 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(GemmTnParams p) {
     e.ldc = p.ldc;
     tile_epilogue<EPI_ACCUM_F32>(e, acc, reinterpret_cast<float*>(smem), m0, n0, tid);
   }
+}
+
+// ---- TN, grouped: several weight-gradient problems in ONE launch, every tile over its FULL reduction ----------------
+// Why: one dW GEMM of the GPT step has 16..64 output tiles, so it needs a split reduction (8-10 slabs, 25-40 MB of fp32
+// written and re-read, a second launch) to fill 256 CUs, and its main loop is 15-19 k-tiles long.  All dW GEMMs of a
+// backward pass together have >= 1000 tiles: launched as one grid each workgroup owns a whole tile (C += acc, no slabs,
+// no reduce kernel) with a 145-k-tile main loop.  The main loop is gemm_tn_glds_kernel's; a workgroup finds its problem
+// from the descriptors' tile prefix sums (one vector load + ballot), and the XCD-aware order keeps the tiles of one
+// problem -- which share the At / Bt panels -- on one XCD's L2.
+__global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const ttts_tn_desc* __restrict__ desc, int n_desc) {
+  __shared__ __attribute__((aligned(16))) bf16 smem[2 * 2 * 64 * 128];  // 64 KB: [buf][A|B][64*128]; reused as stage
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lin = xcd_tile(blockIdx.x, gridDim.x);
+  // problem lookup: lane i holds descriptor i's first tile (n_desc <= 64); the workgroup's problem is the last one that
+  // starts at or before its tile
+  const int tb = lane < n_desc ? desc[lane].tile_begin : 0x7fffffff;
+  const int q = __popcll(__ballot(lin >= tb)) - 1;
+  const ttts_tn_desc d = desc[q];
+  const bf16* At = reinterpret_cast<const bf16*>(d.At);
+  const bf16* Bt = reinterpret_cast<const bf16*>(d.Bt);
+  const int64_t ldat = d.ldat, ldbt = d.ldbt;
+  const int Mo = d.Mo, No = d.No;
+  const int tiles_n = (No + BN - 1) / BN;
+  const int tile = lin - d.tile_begin;
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  const int nk = d.Kr / 64;
+
+  // DMA sources: columns beyond Mo / No are clamped to the last valid 16-byte chunk (those outputs are never stored)
+  const int ca_max = max(0, ((Mo - m0 + 7) >> 3) - 1), cb_max = max(0, ((No - n0 + 7) >> 3) - 1);
+  const bf16* ga[4];
+  const bf16* gb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = wave * 16 + i * 4 + (lane >> 4);
+    const int lc = (lane & 15) ^ ((r & 3) << 2);
+    ga[i] = At + (int64_t)r * ldat + m0 + min(lc, ca_max) * 8;
+    gb[i] = Bt + (int64_t)r * ldbt + n0 + min(lc, cb_max) * 8;
+  }
+  const uint32_t lds0 = lds_byte_addr(smem);
+  auto issue = [&](int kt, int buf) {   // inline-asm DMA (lds_dma16_untracked): the prefetch overlaps the fragment reads
+    const uint32_t as = lds0 + (uint32_t)(((buf * 2 + 0) * 64 * 128 + wave * 16 * 128) * sizeof(bf16));
+    const uint32_t bs = lds0 + (uint32_t)(((buf * 2 + 1) * 64 * 128 + wave * 16 * 128) * sizeof(bf16));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      lds_dma16_untracked(ga[i] + (int64_t)kt * 64 * ldat, as + (uint32_t)(i * 4 * 128 * sizeof(bf16)));
+      lds_dma16_untracked(gb[i] + (int64_t)kt * 64 * ldbt, bs + (uint32_t)(i * 4 * 128 * sizeof(bf16)));
+    }
+  };
+
+  f32x16 acc[2][2];
+  ZERO_ACC(acc)
+  if (nk > 0) issue(0, 0);
+  lds_dma_wait_all();
+  __syncthreads();
+  // transposed-read lane map on the permuted image: see gemm_tn_glds_kernel
+  const int g = lane >> 4, ip = lane & 15;
+  const int krow = 8 * (g >> 1) + (ip >> 2);
+  const int sw = ((ip >> 2) & 3) << 2;
+  int offa[2], offb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ca = wm * 64 + i * 32 + 16 * (g & 1) + 4 * (ip & 3), cb = wn * 64 + i * 32 + 16 * (g & 1) + 4 * (ip & 3);
+    offa[i] = krow * 128 + (((ca >> 3) ^ sw) << 3) + (ca & 7);
+    offb[i] = krow * 128 + (((cb >> 3) ^ sw) << 3) + (cb & 7);
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
+    const bf16* as = smem + (buf * 2 + 0) * 64 * 128;
+    const bf16* bs = smem + (buf * 2 + 1) * 64 * 128;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bf16* pa = as + ks * 16 * 128 + offa[i];
+        const bf16* pb = bs + ks * 16 * 128 + offb[i];
+        af[i] = cat4(lds_tr_b64(pa), lds_tr_b64(pa + 4 * 128));
+        bfr[i] = cat4(lds_tr_b64(pb), lds_tr_b64(pb + 4 * 128));
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[j][i] = mfma32(bfr[j], af[i], acc[j][i]);
+    }
+    lds_dma_wait_all();  // the next tile has landed (this wave's share; the barrier publishes everyone's)
+    __syncthreads();     // ... and everyone is done reading this one
+  }
+  GemmEpi e{};
+  e.M = Mo;
+  e.N = No;
+  e.C = d.C;
+  e.ldc = d.ldc;
+  tile_epilogue<EPI_ACCUM_F32>(e, acc, reinterpret_cast<float*>(smem), m0, n0, tid);
 }
 
 // C[m][n] += sum_s partial[s][m][n]   (float4 per thread, slabs read in split order)
@@ -649,6 +746,40 @@ extern "C" int64_t ttts_gemm_tn_workspace_bytes(int32_t Mo, int32_t No, int32_t 
   int splits, k_chunk;
   tn_plan(Mo, No, Kr, splits, k_chunk);
   return splits > 1 ? (int64_t)splits * Mo * (((int64_t)No + 7) / 8 * 8) * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int32_t ttts_tn_desc_tiles(int32_t Mo, int32_t No) {
+  return (Mo > 0 && No > 0) ? (int32_t)(cdiv(Mo, BM) * cdiv(No, BN)) : 0;
+}
+
+// Validates HOST copies of the descriptors and fills their tile_begin fields; *total_tiles = the launch's grid.
+extern "C" int ttts_tn_desc_prepare(ttts_tn_desc* host_desc, int32_t n_desc, int32_t* total_tiles) {
+  TTTS_REQUIRE(host_desc && total_tiles, "tn_desc_prepare: null pointer");
+  TTTS_REQUIRE(n_desc > 0 && n_desc <= 64, "tn_desc_prepare: 1..64 descriptors (got %d)", n_desc);
+  int64_t tiles = 0;
+  for (int i = 0; i < n_desc; ++i) {
+    ttts_tn_desc& d = host_desc[i];
+    TTTS_REQUIRE(d.At && d.Bt && d.C, "tn_desc[%d]: null pointer", i);
+    TTTS_REQUIRE(d.Mo > 0 && d.No > 0 && d.Kr > 0, "tn_desc[%d]: bad shape", i);
+    TTTS_REQUIRE(d.Kr % 64 == 0, "tn_desc[%d]: Kr must be a multiple of 64 (zero-pad the operands' rows); got %d", i, d.Kr);
+    TTTS_REQUIRE(d.ldat % 8 == 0 && d.ldbt % 8 == 0 && d.ldat >= ((d.Mo + 7) / 8) * 8 && d.ldbt >= ((d.No + 7) / 8) * 8,
+                 "tn_desc[%d]: ldat/ldbt must be multiples of 8 and cover roundup8(Mo/No)", i);
+    TTTS_REQUIRE(d.ldc % 4 == 0 && d.ldc >= ((d.No + 3) / 4) * 4, "tn_desc[%d]: ldc must be a multiple of 4 and >= roundup4(No)", i);
+    TTTS_REQUIRE(aligned16(d.At) && aligned16(d.Bt) && aligned16(d.C), "tn_desc[%d]: 16-byte aligned bases required", i);
+    d.tile_begin = (int32_t)tiles;
+    tiles += ttts_tn_desc_tiles(d.Mo, d.No);
+    TTTS_REQUIRE(tiles < (int64_t)1 << 30, "tn_desc: too many tiles");
+  }
+  *total_tiles = (int32_t)tiles;
+  return TTTS_OK;
+}
+
+extern "C" int ttts_gemm_tn_grouped_bf16_accum_f32(const ttts_tn_desc* desc_dev, int32_t n_desc, int32_t total_tiles,
+                                                   void* stream) {
+  TTTS_REQUIRE(desc_dev, "gemm_tn_grouped: null descriptor table");
+  TTTS_REQUIRE(n_desc > 0 && n_desc <= 64 && total_tiles > 0, "gemm_tn_grouped: bad counts (n_desc=%d tiles=%d)", n_desc, total_tiles);
+  gemm_tn_grouped_kernel<<<total_tiles, 256, 0, as_stream(stream)>>>(desc_dev, n_desc);
+  return check_launch("gemm_tn_grouped");
 }
 
 extern "C" int ttts_gemm_tn_bf16_accum_f32(const void* At, int64_t ldat, const void* Bt, int64_t ldbt, float* C,

@@ -85,6 +85,11 @@ class GptEngine:
         self.step_count = 0                 # optimizer steps taken (host mirror)
         self.overlap_dw = os.environ.get("TTTS_OVERLAP_DW", "0") == "1"   # dW GEMMs on a side stream (see backward);
         # off by default: measured +0.7 % only, and concurrent kernels blur per-kernel profiles
+        # Deferred, grouped weight gradients (see _dw_plan): every layer keeps its four dY buffers and ALL dW GEMMs of a
+        # backward section run as one launch at its end, one workgroup per output tile over the whole token dimension --
+        # no split-reduction slabs, no reduce kernels.  TTTS_GROUPED_DW=0 restores one split-K dW GEMM per weight.
+        self.grouped_dw = os.environ.get("TTTS_GROUPED_DW", "1") == "1"
+        self._dw_plans = {}
         self.seed_ctr = torch.zeros(1, dtype=torch.int32, device=self.device)   # this replica's dropout stream counter (device side:
         # graph-replay safe); handed to every dropout-capable kernel call -- the library holds no state of its own
         self.spec = param_spec(self.c)
@@ -200,6 +205,11 @@ class GptEngine:
         b["d_att"] = e(M, D)
         b["dqkv"] = z(M, 3 * D)
         b["delta"] = e(B * H * S, dt=f32)
+        if self.grouped_dw:   # per-layer dY buffers (0.5 GB at the BASELINE shape): nothing is overwritten before the dW launch
+            b["dy_mlp"] = [z(M, D) for _ in range(L)]        # gradient entering mlp.c_proj  (was: dres_bf)
+            b["dy_att"] = [z(M, D) for _ in range(L)]        # gradient entering attn.c_proj (was: dres_bf)
+            b["d_fc_l"] = [z(M, 4 * D) for _ in range(L)]    # (was: d_fc)
+            b["dqkv_l"] = [z(M, 3 * D) for _ in range(L)]    # (was: dqkv)
         b["ln_ws"] = ops.layernorm_bwd_workspace(M, D, dev)
         tn_shapes = [(D, 3 * D, Mp), (D, D, Mp), (D, 4 * D, Mp), (4 * D, D, Mp), (self.nt, D, B * Tt), (self.nm, D, B * Tm)]
         b["tn_ws"] = max((ops.gemm_tn_workspace(mo, no, kr, dev) for mo, no, kr in tn_shapes), key=lambda t: t.numel())
@@ -212,6 +222,61 @@ class GptEngine:
         self.b = b
         self._bufs_key = key
         self._graph = None
+        self._dw_plans = {}
+        if self.grouped_dw:   # descriptor tables are built here, outside any graph capture (they upload a small table)
+            split = L // 2
+            for lo, hi in {(0, L), (split, L), (0, split)}:
+                if hi > lo:
+                    self._dw_plan(lo, hi)
+
+    def _dw_plan(self, lo, hi):
+        """Grouped dW launch for layers lo .. hi-1: (TnPlan | None, [problems left to the split-K path]).
+        A problem = (at, bt, grad view).  The grouped kernel gives every 128 x 128 output tile of every problem to one
+        workgroup; with 2 workgroups per CU resident, a tile count just above a multiple of 2 x CUs would cost a whole
+        extra, mostly empty round (1152 tiles on 512 slots: 2.25 -> 3 rounds).  So the smallest set of problems that
+        covers the remainder is taken out and run through the split-K kernel instead."""
+        key = (lo, hi)
+        if key in self._dw_plans:
+            return self._dw_plans[key]
+        if torch.cuda.is_current_stream_capturing():
+            raise TttsError("grouped dW plan for layers %d..%d must be built before graph capture" % (lo, hi))
+        b = self.b
+        G = lambda k: self.view(self.grads, k)   # noqa: E731
+        P_ = self._padded
+        probs = []
+        for i in reversed(range(lo, hi)):
+            pre = "gpt.h.%d." % i
+            probs += [(P_(b["ln2"][i]), P_(b["d_fc_l"][i]), G(pre + "mlp.c_fc.weight")),
+                      (P_(b["fc_act"][i]), P_(b["dy_mlp"][i]), G(pre + "mlp.c_proj.weight")),
+                      (P_(b["ln1"][i]), P_(b["dqkv_l"][i]), G(pre + "attn.c_attn.weight")),
+                      (P_(b["att"][i]), P_(b["dy_att"][i]), G(pre + "attn.c_proj.weight"))]
+        tiles = [ops.tn_desc_tiles(at.shape[1], bt.shape[1]) for at, bt, _ in probs]
+        slots = 2 * ops.device_info()["cus"]
+        total = sum(tiles)
+        rem = total % slots
+        out = set()
+        if total > slots and 0 < rem < (slots * 5) // 8:
+            # smallest tile sum >= rem over subsets of problems (subset-sum table over <= 64 small integers)
+            best = {0: ()}
+            for j, t in enumerate(tiles):
+                for ssum, sel in list(best.items()):
+                    if ssum < rem and (ssum + t) not in best:
+                        best[ssum + t] = sel + (j,)
+            cand = [ssum for ssum in best if ssum >= rem]
+            if cand and min(cand) < total:
+                out = set(best[min(cand)])
+        grouped = [pr for j, pr in enumerate(probs) if j not in out]
+        single = [pr for j, pr in enumerate(probs) if j in out]
+        plan = ops.TnPlan(grouped, self.device) if grouped else None
+        self._dw_plans[key] = (plan, single)
+        return self._dw_plans[key]
+
+    def _run_dw(self, lo, hi):
+        plan, single = self._dw_plan(lo, hi)
+        if plan is not None:
+            plan.run()
+        for at, bt, g in single:
+            ops.gemm_tn_accum(at, bt, g, workspace=self.b["tn_ws"])
 
     def _padded(self, t):
         """The zero-row-padded [Mp, c] buffer behind an [M, c] activation view (weight-gradient GEMM operand)."""
@@ -292,7 +357,7 @@ class GptEngine:
         # fill the CUs that chain leaves idle (292-tile GEMMs on 256 CUs, causal tails, store phases).  Events order the
         # reuse of the scratch buffers (dres_bf, d_fc, dqkv) between the two streams; both streams are captured in the graph.
         main = torch.cuda.current_stream()
-        side = self._side_stream() if (self.overlap_dw and part is None) else main
+        side = self._side_stream() if (self.overlap_dw and part is None and not self.grouped_dw) else main
         lo_layer = 0 if part in (None, 1) else split
         hi_layer = L if part in (None, 0) else split
 
@@ -316,6 +381,8 @@ class GptEngine:
         ev_fc = ev_qkv = None            # side-stream reads of d_fc / dqkv by the previous layer
         for i in reversed(range(lo_layer, hi_layer)):
             ev_fc, ev_qkv = self._backward_layer(i, side, fork, done, wait, ev_fc, ev_qkv)
+        if self.grouped_dw and hi_layer > lo_layer:
+            self._run_dw(lo_layer, hi_layer)
         if part in (None, 1):
             ops.embed_bwd(b["text_inp"], b["mel_inp"], b["dres"], G("text_embedding.weight"),
                           G("text_pos_embedding.emb.weight"), G("mel_embedding.weight"), G("mel_pos_embedding.emb.weight"),
@@ -345,7 +412,8 @@ class GptEngine:
         fs = b["fstats"]
         ops.layernorm_bwd(b["d_enc"], b["lnf"], P("final_norm.weight"), fs[2], fs[3], None, b["d_tmp"], None,
                           G("final_norm.weight"), G("final_norm.bias"), b["ln_ws"], split=(S, Tt))
-        ops.layernorm_bwd(b["d_tmp"], b["xs"][2 * L], P("gpt.ln_f.weight"), fs[0], fs[1], None, b["dres"], b["dres_bf"],
+        ops.layernorm_bwd(b["d_tmp"], b["xs"][2 * L], P("gpt.ln_f.weight"), fs[0], fs[1], None, b["dres"],
+                          b["dy_mlp"][L - 1] if self.grouped_dw else b["dres_bf"],
                           G("gpt.ln_f.weight"), G("gpt.ln_f.bias"), b["ln_ws"], dropout_p=p,
                           seed=self._seed(16 * (L - 1) + 4), dcolsum=G("gpt.h.%d.mlp.c_proj.bias" % (L - 1)), counter=self.seed_ctr)
 
@@ -360,6 +428,8 @@ class GptEngine:
         pre = "gpt.h.%d." % i
         st = b["stats"][i]
         x0, x1 = b["xs"][2 * i], b["xs"][2 * i + 1]
+        if self.grouped_dw:
+            return self._backward_layer_grouped(i)
         dy = b["dres_bf"]                                  # gradient entering mlp.c_proj (resid dropout applied)
         fork()
         with torch.cuda.stream(side):
@@ -400,6 +470,39 @@ class GptEngine:
                           b["ln_ws"], dropout_p=p if i > 0 else 0.0, seed=self._seed(16 * (i - 1) + 4),
                           dcolsum=G("gpt.h.%d.mlp.c_proj.bias" % (i - 1)) if i > 0 else None, counter=self.seed_ctr)
         return ev_fc, ev_qkv
+
+    def _backward_layer_grouped(self, i):
+        """The data-gradient chain of layer i alone: every dY goes to this layer's own buffer and the four weight
+        gradients are left to the grouped launch at the end of the section (_run_dw); bias gradients stay here."""
+        c, b = self.c, self.b
+        B, Tt, Tm = self._bufs_key
+        D, H = c["model_dim"], c["heads"]
+        S, dh = Tt + Tm, D // H
+        p = self._p()
+        P = lambda k: self.view(self.params, k)  # noqa: E731
+        G = lambda k: self.view(self.grads, k)   # noqa: E731
+        pre = "gpt.h.%d." % i
+        st = b["stats"][i]
+        x0, x1 = b["xs"][2 * i], b["xs"][2 * i + 1]
+        dy, d_fc, dy_att, dqkv = b["dy_mlp"][i], b["d_fc_l"][i], b["dy_att"][i], b["dqkv_l"][i]
+        ops.gemm_nt(dy, self.w(pre + "mlp.c_proj.weight"), d_fc, aux=b["fc_pre"][i], epilogue=EPI_DGELU_BF16)
+        ops.colsum_accum(d_fc, G(pre + "mlp.c_fc.bias"))
+        ops.gemm_nt(d_fc, self.w(pre + "mlp.c_fc.weight"), b["d_ln"])
+        ops.layernorm_bwd(b["d_ln"], x1, P(pre + "ln_2.weight"), st[2], st[3], b["dres"], b["dres"], dy_att,
+                          G(pre + "ln_2.weight"), G(pre + "ln_2.bias"), b["ln_ws"], dropout_p=p,
+                          seed=self._seed(16 * i + 3), dcolsum=G(pre + "attn.c_proj.bias"), counter=self.seed_ctr)
+        ops.gemm_nt(dy_att, self.w(pre + "attn.c_proj.weight"), b["d_att"])
+        qkv = b["qkv"][i]
+        ops.attn_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], b["att"][i], b["d_att"], b["lse"][i], dqkv, dqkv[:, D:],
+                     dqkv[:, 2 * D:], b["delta"], B, H, S, dh, (S * 3 * D, 3 * D), (S * D, D), dh ** -0.5, p,
+                     self._seed(16 * i + 2), counter=self.seed_ctr)
+        ops.colsum_accum(dqkv, G(pre + "attn.c_attn.bias"))
+        ops.gemm_nt(dqkv, self.w(pre + "attn.c_attn.weight"), b["d_ln"])
+        ops.layernorm_bwd(b["d_ln"], x0, P(pre + "ln_1.weight"), st[0], st[1], b["dres"], b["dres"],
+                          b["dy_mlp"][i - 1] if i > 0 else None, G(pre + "ln_1.weight"), G(pre + "ln_1.bias"),
+                          b["ln_ws"], dropout_p=p if i > 0 else 0.0, seed=self._seed(16 * (i - 1) + 4),
+                          dcolsum=G("gpt.h.%d.mlp.c_proj.bias" % (i - 1)) if i > 0 else None, counter=self.seed_ctr)
+        return None, None
 
     def _side_stream(self):
         if getattr(self, "_side", None) is None:

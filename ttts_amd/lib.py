@@ -76,6 +76,12 @@ class CastDesc(ctypes.Structure):
                 ("ldt", _I32)]
 
 
+class TnDesc(ctypes.Structure):
+    """include/ttts_hip.h: ttts_tn_desc (one problem of the grouped weight-gradient GEMM)."""
+    _fields_ = [("At", _P), ("Bt", _P), ("C", _P), ("ldat", _I64), ("ldbt", _I64), ("ldc", _I64), ("Mo", _I32),
+                ("No", _I32), ("Kr", _I32), ("tile_begin", _I32)]
+
+
 # name -> (restype, argtypes); every symbol include/ttts_hip.h declares
 SIGNATURES = {
     "ttts_abi_version": (_I32, []),
@@ -86,6 +92,9 @@ SIGNATURES = {
     "ttts_gemm_nt_workspace_bytes": (_I64, []),
     "ttts_gemm_tn_workspace_bytes": (_I64, [_I32, _I32, _I32]),
     "ttts_gemm_tn_bf16_accum_f32": (_I32, [_P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _P]),
+    "ttts_tn_desc_tiles": (_I32, [_I32, _I32]),
+    "ttts_tn_desc_prepare": (_I32, [_P, _I32, _P]),
+    "ttts_gemm_tn_grouped_bf16_accum_f32": (_I32, [_P, _I32, _I32, _P]),
     "ttts_colsum_bf16_accum_f32": (_I32, [_P, _I64, _P, _I32, _I32, _P]),
     "ttts_cast_desc_tiles": (_I32, [_I32, _I32]),
     "ttts_cast_bf16_batched": (_I32, [_P, _I32, _I32, _P]),

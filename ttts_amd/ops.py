@@ -14,7 +14,7 @@ from .lib import (EPI_DGELU_BF16, EPI_GELU_BF16, EPI_RESID_ADD_F32, EPI_STORE_BF
 
 __all__ = ["gemm_nt", "gemm_tn_accum", "colsum_accum", "attn_fwd", "attn_bwd", "layernorm_fwd", "layernorm_bwd",
            "embed_fwd", "embed_bwd", "ce_fwd", "ce_bwd", "gradnorm", "adamw", "adamw_schedule", "vq_nearest",
-           "vq_commit", "vq_ema_update", "stft_mag", "mel_log", "CastPlan", "probe_layout", "device_info"]
+           "vq_commit", "vq_ema_update", "stft_mag", "mel_log", "CastPlan", "TnPlan", "probe_layout", "device_info"]
 
 
 def _stream():
@@ -91,6 +91,39 @@ def gemm_tn_accum(at, bt, c, mo=None, no=None, workspace=None, kr=None):
     check(_l.get().ttts_gemm_tn_bf16_accum_f32(_p(at), _ld(at), _p(bt), _ld(bt), _p(c), _ld(c), Mo, No, Kr,
                                                _p(workspace), _stream()), "gemm_tn")
     return c
+
+
+class TnPlan:
+    """Device-resident descriptor table of a grouped weight-gradient GEMM: c_i[Mo,No] += at_i[Kr,Mo]^T @ bt_i[Kr,No] for
+    every entry in ONE launch, each 128x128 output tile reduced over its whole Kr by one workgroup (no slabs).
+    entries: list of (at bf16 [Kr, Mo], bt bf16 [Kr, No], c f32 [Mo, No]); Kr % 64 == 0 (zero-padded rows)."""
+
+    def __init__(self, entries, device):
+        if not entries:
+            raise TttsError("TnPlan: no entries")
+        arr = (_l.TnDesc * len(entries))()
+        for i, (at, bt, c) in enumerate(entries):
+            _req(at, torch.bfloat16, "at"); _req(bt, torch.bfloat16, "bt"); _req(c, torch.float32, "c")
+            if at.shape[0] != bt.shape[0] or c.shape[0] != at.shape[1] or c.shape[1] != bt.shape[1]:
+                raise TttsError("TnPlan entry %d: shapes at %s bt %s c %s" % (i, tuple(at.shape), tuple(bt.shape), tuple(c.shape)))
+            arr[i].At, arr[i].Bt, arr[i].C = at.data_ptr(), bt.data_ptr(), c.data_ptr()
+            arr[i].ldat, arr[i].ldbt, arr[i].ldc = _ld(at), _ld(bt), _ld(c)
+            arr[i].Mo, arr[i].No, arr[i].Kr = at.shape[1], bt.shape[1], at.shape[0]
+        total = ctypes.c_int32(0)
+        check(_l.get().ttts_tn_desc_prepare(arr, len(entries), ctypes.byref(total)), "tn_desc_prepare")
+        raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+        self.table = torch.from_numpy(raw).to(device)
+        self.n, self.tiles = len(entries), int(total.value)
+        self.tile_counts = [int(_l.get().ttts_tn_desc_tiles(at.shape[1], bt.shape[1])) for at, bt, _ in entries]
+        self.flops = float(sum(2.0 * at.shape[0] * at.shape[1] * bt.shape[1] for at, bt, _ in entries))   # algorithmic, per launch
+        self._keep = entries
+
+    def run(self):
+        check(_l.get().ttts_gemm_tn_grouped_bf16_accum_f32(_p(self.table), self.n, self.tiles, _stream()), "gemm_tn_grouped")
+
+
+def tn_desc_tiles(mo, no):
+    return int(_l.get().ttts_tn_desc_tiles(mo, no))
 
 
 def colsum_accum(x, out, n=None):
