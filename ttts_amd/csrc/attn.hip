@@ -14,6 +14,7 @@
 // staged global -> registers -> LDS (double buffered, next tile's loads in flight under the MFMAs).
 // Causality: tiles strictly above the diagonal are never loaded; workgroups are launched heaviest-first.
 #include <algorithm>
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -479,7 +480,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
 // backward: dQ (S^T form, one query per lane; loops over key tiles up to the diagonal)
 // -------------------------------------------------------------------------------------------------------
 template <int DH, bool DROPOUT>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, (DH <= 64 ? 3 : 2)) void attn_bwd_dq_kernel(AttnParams p) {
   using C = AttnCfg<DH>;
   __shared__ __attribute__((aligned(16))) bf16 Ks[2][64 * C::KSTR];
   __shared__ __attribute__((aligned(16))) bf16 Vs[2][64 * C::KSTR];
@@ -492,6 +493,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
   const int bh = blockIdx.x % nbh, h = bh % p.H, b = bh / p.H;
   const int q_base = qb * 128 + wave * 32;
   const int query = q_base + (lane & 31);
+  const int q_first = __builtin_amdgcn_readfirstlane(q_base);   // scalar copy for wave-uniform branches
   const bf16* qp = p.q + (int64_t)b * p.sb + h * DH;
   const bf16* kp = p.k + (int64_t)b * p.sb + h * DH;
   const bf16* vp = p.v + (int64_t)b * p.sb + h * DH;
@@ -549,23 +551,32 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
           dp = mfma32(vf, dof[ks], dp);
         }
         u32x4_t dsw[2];
+        // the causal / ragged test costs 3 VALU per score: only 32-key blocks that reach past the wave's first query or the
+        // end of the sequence need it (wave-uniform choice; both bodies compute identical values where no pair is masked)
+        auto scores_to_ds = [&](auto masked_c) {
+          constexpr bool MASKED = decltype(masked_c)::value;
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          bool keep[4] = {true, true, true, true};
-          if (DROPOUT) drop_keep4(rowh, &Bm[buf][kb * 32 + 8 * qd + 4 * hh], thr32, keep);
-          float ds[4];
+          for (int qd = 0; qd < 4; ++qd) {
+            bool keep[4] = {true, true, true, true};
+            if (DROPOUT) drop_keep4(rowh, &Bm[buf][kb * 32 + 8 * qd + 4 * hh], thr32, keep);
+            float ds[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = 4 * qd + e;
-            const int key = kv0 + kb * 32 + 8 * qd + 4 * hh + e;
-            const float pv = (key > query || key >= p.S) ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[r], p.c, -lse2));
-            float dpv = dp[r];
-            if (DROPOUT) dpv = keep[e] ? dpv * p.inv_keep : 0.f;
-            ds[e] = pv * (dpv - delta);
+            for (int e = 0; e < 4; ++e) {
+              const int r = 4 * qd + e;
+              const int key = kv0 + kb * 32 + 8 * qd + 4 * hh + e;
+              const float ex = __builtin_amdgcn_exp2f(fmaf(s[r], p.c, -lse2));
+              const float pv = (MASKED && (key > query || key >= p.S)) ? 0.f : ex;
+              float dpv = dp[r];
+              if (DROPOUT) dpv = keep[e] ? dpv * p.inv_keep : 0.f;
+              ds[e] = pv * (dpv - delta);
+            }
+            dsw[qd >> 1][2 * (qd & 1)] = pack_bf16x2(ds[0], ds[1]);
+            dsw[qd >> 1][2 * (qd & 1) + 1] = pack_bf16x2(ds[2], ds[3]);
           }
-          dsw[qd >> 1][2 * (qd & 1)] = pack_bf16x2(ds[0], ds[1]);
-          dsw[qd >> 1][2 * (qd & 1) + 1] = pack_bf16x2(ds[2], ds[3]);
-        }
+        };
+        const int last_key = kv0 + kb * 32 + 31;
+        if (last_key > q_first || last_key >= p.S) scores_to_ds(std::true_type{});
+        else scores_to_ds(std::false_type{});
         dsf[kb][0] = __builtin_bit_cast(bf16x8, dsw[0]);
         dsf[kb][1] = __builtin_bit_cast(bf16x8, dsw[1]);
       }
@@ -620,6 +631,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
   const int bh = blockIdx.x % nbh, h = bh % p.H, b = bh / p.H;
   const int k_base = kblk * 128 + wave * 32;
   const int key = k_base + (lane & 31);
+  const int k_last = __builtin_amdgcn_readfirstlane(k_base) + 31;   // scalar: the wave's last key, for wave-uniform branches
   const bf16* qp = p.q + (int64_t)b * p.sb + h * DH;
   const bf16* kp = p.k + (int64_t)b * p.sb + h * DH;
   const bf16* vp = p.v + (int64_t)b * p.sb + h * DH;
@@ -689,36 +701,45 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
         }
         bf16x8 pf[2], dsf[2];
         u32x4_t pw[2], dsw[2];
+        // causal / ragged test (3 VALU per score) only for 32-query blocks that start before the wave's last key or reach past
+        // the sequence (wave-uniform choice; identical values where no pair is masked)
+        auto scores_to_p_ds = [&](auto masked_c) {
+          constexpr bool MASKED = decltype(masked_c)::value;
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          const f32x4 l4 = *reinterpret_cast<const f32x4*>(&Ls[buf][qs * 32 + 8 * qd + 4 * hh]);
-          const f32x4 d4 = *reinterpret_cast<const f32x4*>(&Dl[buf][qs * 32 + 8 * qd + 4 * hh]);
-          bool keep4[4] = {true, true, true, true};
-          if (DROPOUT) {                   // product scheme: this lane's column multiplier x the four rows' hashes from the tile table
-            const u32x4_t rh = *reinterpret_cast<const u32x4_t*>(&Am[buf][qs * 32 + 8 * qd + 4 * hh]);
+          for (int qd = 0; qd < 4; ++qd) {
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(&Ls[buf][qs * 32 + 8 * qd + 4 * hh]);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(&Dl[buf][qs * 32 + 8 * qd + 4 * hh]);
+            bool keep4[4] = {true, true, true, true};
+            if (DROPOUT) {                 // product scheme: this lane's column multiplier x the four rows' hashes from the tile table
+              const u32x4_t rh = *reinterpret_cast<const u32x4_t*>(&Am[buf][qs * 32 + 8 * qd + 4 * hh]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) keep4[e] = drop_keep(rh[e], colm, thr32);
-          }
-          float pd[4], ds[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = 4 * qd + e;
-            const int query = q0 + qs * 32 + 8 * qd + 4 * hh + e;
-            const float pv = (key > query || query >= p.S) ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[r], p.c, -l4[e]));
-            float dpv = dp[r];
-            pd[e] = pv;
-            if (DROPOUT) {
-              const bool keep = keep4[e];
-              dpv = keep ? dpv * p.inv_keep : 0.f;
-              pd[e] = keep ? pv : 0.f;                     // dV's 1 / keep factor is applied once, when dV is stored
+              for (int e = 0; e < 4; ++e) keep4[e] = drop_keep(rh[e], colm, thr32);
             }
-            ds[e] = pv * (dpv - d4[e]);
+            float pd[4], ds[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int r = 4 * qd + e;
+              const int query = q0 + qs * 32 + 8 * qd + 4 * hh + e;
+              const float ex = __builtin_amdgcn_exp2f(fmaf(s[r], p.c, -l4[e]));
+              const float pv = (MASKED && (key > query || query >= p.S)) ? 0.f : ex;
+              float dpv = dp[r];
+              pd[e] = pv;
+              if (DROPOUT) {
+                const bool keep = keep4[e];
+                dpv = keep ? dpv * p.inv_keep : 0.f;
+                pd[e] = keep ? pv : 0.f;                   // dV's 1 / keep factor is applied once, when dV is stored
+              }
+              ds[e] = pv * (dpv - d4[e]);
+            }
+            pw[qd >> 1][2 * (qd & 1)] = pack_bf16x2(pd[0], pd[1]);
+            pw[qd >> 1][2 * (qd & 1) + 1] = pack_bf16x2(pd[2], pd[3]);
+            dsw[qd >> 1][2 * (qd & 1)] = pack_bf16x2(ds[0], ds[1]);
+            dsw[qd >> 1][2 * (qd & 1) + 1] = pack_bf16x2(ds[2], ds[3]);
           }
-          pw[qd >> 1][2 * (qd & 1)] = pack_bf16x2(pd[0], pd[1]);
-          pw[qd >> 1][2 * (qd & 1) + 1] = pack_bf16x2(pd[2], pd[3]);
-          dsw[qd >> 1][2 * (qd & 1)] = pack_bf16x2(ds[0], ds[1]);
-          dsw[qd >> 1][2 * (qd & 1) + 1] = pack_bf16x2(ds[2], ds[3]);
-        }
+        };
+        const int first_query = q0 + qs * 32;
+        if (k_last > first_query || first_query + 31 >= p.S) scores_to_p_ds(std::true_type{});
+        else scores_to_p_ds(std::false_type{});
         pf[0] = __builtin_bit_cast(bf16x8, pw[0]); pf[1] = __builtin_bit_cast(bf16x8, pw[1]);
         dsf[0] = __builtin_bit_cast(bf16x8, dsw[0]); dsf[1] = __builtin_bit_cast(bf16x8, dsw[1]);
 #pragma unroll
