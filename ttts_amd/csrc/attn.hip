@@ -90,6 +90,14 @@ __device__ __forceinline__ void drop_keep4(uint32_t rowh, const uint32_t* colm4,
 template <int DH, bool ZERO = true>
 __device__ __forceinline__ void tile_load(bf16x8 (&r)[AttnCfg<DH>::CPT], const bf16* base, int64_t stride, int row0,
                                           int nrows, int tid) {
+  if (ZERO && row0 + 64 <= nrows) {   // whole tile inside the sequence (workgroup-uniform): no clamp, no zero select
+#pragma unroll
+    for (int i = 0; i < AttnCfg<DH>::CPT; ++i) {
+      const int c = tid + i * 256, row = c / AttnCfg<DH>::CPR, dc = (c % AttnCfg<DH>::CPR) * 8;
+      r[i] = *reinterpret_cast<const bf16x8*>(base + (int64_t)(row0 + row) * stride + dc);
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < AttnCfg<DH>::CPT; ++i) {
     const int c = tid + i * 256, row = c / AttnCfg<DH>::CPR, dc = (c % AttnCfg<DH>::CPR) * 8;
@@ -566,9 +574,9 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 3 : 2)) void attn_bwd_dq_kernel(At
               const int key = kv0 + kb * 32 + 8 * qd + 4 * hh + e;
               const float ex = __builtin_amdgcn_exp2f(fmaf(s[r], p.c, -lse2));
               const float pv = (MASKED && (key > query || key >= p.S)) ? 0.f : ex;
-              float dpv = dp[r];
-              if (DROPOUT) dpv = keep[e] ? dpv * p.inv_keep : 0.f;
-              ds[e] = pv * (dpv - delta);
+              // dS = P o (dropout'(dP) - delta): select first, then ONE fma for the 1 / keep scale and the subtraction
+              const float dpv = DROPOUT ? (keep[e] ? dp[r] : 0.f) : dp[r];
+              ds[e] = pv * (DROPOUT ? fmaf(dpv, p.inv_keep, -delta) : dpv - delta);
             }
             dsw[qd >> 1][2 * (qd & 1)] = pack_bf16x2(ds[0], ds[1]);
             dsw[qd >> 1][2 * (qd & 1) + 1] = pack_bf16x2(ds[2], ds[3]);
@@ -726,10 +734,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
               pd[e] = pv;
               if (DROPOUT) {
                 const bool keep = keep4[e];
-                dpv = keep ? dpv * p.inv_keep : 0.f;
+                dpv = keep ? dpv : 0.f;
                 pd[e] = keep ? pv : 0.f;                   // dV's 1 / keep factor is applied once, when dV is stored
               }
-              ds[e] = pv * (dpv - d4[e]);
+              // dS = P o (dropout'(dP) - delta): ONE fma for the 1 / keep scale and the subtraction
+              ds[e] = pv * (DROPOUT ? fmaf(dpv, p.inv_keep, -d4[e]) : dpv - d4[e]);
             }
             pw[qd >> 1][2 * (qd & 1)] = pack_bf16x2(pd[0], pd[1]);
             pw[qd >> 1][2 * (qd & 1) + 1] = pack_bf16x2(pd[2], pd[3]);
