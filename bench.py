@@ -373,7 +373,10 @@ def main():
     w_text, w_mel = tr["text_weight"] * dp.loss_scale(), tr["mel_weight"] * dp.loss_scale()
 
     def step():
-        toks = prepare_tokens(eng.c, text_d, tl, mel_d, wl)   # token plumbing (lengths are host tensors: no sync)
+        # token plumbing of UnifiedVoice.forward (clip, mel padding -> STOP, START / STOP framing), one launch into the engine's
+        # static token buffers; lengths are host tensors: no sync.  (prepare_tokens is the ~20-launch torch form of the same.)
+        eng.set_tokens_raw(text_d, tl, mel_d, wl)
+        toks = None
         if args.mode != "eager":
             # N > 1: the gradient all-reduce of the upper layers + heads overlaps the backward of the lower layers
             if world > 1 and args.exchange == "whole":
@@ -382,7 +385,6 @@ def main():
                 eng.train_step(toks, w_text, w_mel, capture=True, lr=tr["lr"],
                                exchange_range=(lambda lo, hi: dp.allreduce_range_(eng.grads, lo, hi)) if world > 1 else None)
             return
-        eng.set_tokens(*toks)
         eng.forward()
         eng.backward(w_text, w_mel)
         dp.allreduce_grads_(eng.grads)

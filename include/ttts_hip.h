@@ -179,6 +179,16 @@ int ttts_gpt_embed_bwd(const int64_t* text_inp, const int64_t* mel_inp, const fl
                        float* d_text_pos, float* d_mel_emb, float* d_mel_pos,
                        int32_t B, int32_t Tt, int32_t Tm, int32_t D, float dropout_p, uint64_t seed,
                        const uint32_t* dropout_counter, void* stream);
+/* Token plumbing of UnifiedVoice.forward in ONE launch -- replaces ttts/gpt/model.py:474-489 (clip to the batch maximum,
+ * set_mel_padding: mel positions >= wav_len / mel_length_compression + 1 become STOP, append STOP) and
+ * build_aligned_inputs_and_targets (:397-414: inp = [START, seq], tar = [seq, STOP]).
+ * text int64 [B, ld_text], mel int64 [B, ld_mel] (device); Tt / Tm = the clipped lengths the caller computed on the host;
+ * mel_valid_host: HOST array of B ints (wav_len / compression + 1), copied into the launch (B <= 256).
+ * Outputs (device, int64): text_inp, text_tar [B, Tt + 2]; mel_inp, mel_tar [B, Tm + 2]. */
+int ttts_gpt_prepare_tokens(const int64_t* text, int64_t ld_text, const int64_t* mel, int64_t ld_mel,
+                            const int32_t* mel_valid_host, int32_t B, int32_t Tt, int32_t Tm,
+                            int32_t start_text, int32_t stop_text, int32_t start_mel, int32_t stop_mel,
+                            int64_t* text_inp, int64_t* text_tar, int64_t* mel_inp, int64_t* mel_tar, void* stream);
 
 /* ---- cross-entropy -------------------------------------------------------------------------------
  * Replaces: F.cross_entropy(logits.permute, targets) mean reduction, ttts/gpt/model.py:508-509.

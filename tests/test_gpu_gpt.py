@@ -271,6 +271,44 @@ def math_prod(shape):
     return n
 
 
+def test_fused_token_plumbing_equals_prepare_tokens(gpt):
+    """GptEngine.set_tokens_raw (ONE kernel: ttts_gpt_prepare_tokens) fills the engine's token buffers exactly like
+    model.prepare_tokens + set_tokens (the torch form of ttts/gpt/model.py:474-489,397-414): ragged lengths, clipping,
+    mel padding -> STOP, START / STOP framing; also with clipping off and with a padded (strided) input."""
+    from oracle import gpt_ref
+    cfg = dict(gpt_ref.GPT_CONFIG)
+    cfg["layers"] = 1
+    dev = torch.device("cuda:0")
+    sd = gpt_ref.det_state_dict(cfg)
+    g = torch.Generator().manual_seed(3)
+    for B, T_text, T_mel, tl, wl, clip in [
+            (4, 40, 300, [40, 33, 12, 25], [300 * 1024 + 7, 257 * 1024, 100 * 1024 + 1023, 299 * 1024], True),
+            (3, 50, 120, [20, 31, 7], [64 * 1024, 100 * 1024 + 5, 17 * 1024], True),      # clipped below the tensor widths
+            (2, 16, 64, [16, 9], [64 * 1024, 30 * 1024], False),
+            (1, 8, 8, [8], [8 * 1024], True)]:
+        text = torch.randint(1, 255, (B, T_text), generator=g)
+        mel = torch.randint(0, 1024, (B, T_mel), generator=g)
+        tl_t, wl_t = torch.tensor(tl), torch.tensor(wl)
+        eng = gpt.GptEngine(cfg, dev, dropout_p=0.0)
+        eng.load_state_dict(sd)
+        ref = gpt.prepare_tokens(eng.c, text, tl_t, mel, wl_t, clip_inputs=clip)
+        wide = torch.zeros(B, T_text + 5, dtype=torch.int64, device=dev)      # a strided view: row pitch > width
+        wide[:, :T_text] = text.to(dev)
+        eng.set_tokens_raw(wide[:, :T_text], tl_t, mel.to(dev), wl_t, clip_inputs=clip)
+        torch.cuda.synchronize()
+        got = (eng.b["text_inp"], eng.b["text_tar"], eng.b["mel_inp"], eng.b["mel_tar"])
+        for name, r, t in zip(("text_inp", "text_tar", "mel_inp", "mel_tar"), ref, got):
+            assert torch.equal(r.reshape(-1), t.cpu().reshape(-1)), (name, B, clip)
+        # and the step that follows sees the same tokens as through set_tokens
+        eng.forward()
+        a = eng.losses()
+        eng2 = gpt.GptEngine(cfg, dev, dropout_p=0.0)
+        eng2.load_state_dict(sd)
+        eng2.set_tokens(*[t.to(dev) for t in ref])
+        eng2.forward()
+        assert a == eng2.losses()
+
+
 def test_dropout_training_under_graph_replay(gpt):
     """Dropout masks come from (constant per-site seed + device-side stream counter): the whole step, dropout
     included, replays from ONE hipGraph and still draws fresh masks every step."""

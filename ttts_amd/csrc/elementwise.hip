@@ -267,24 +267,26 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
   }
 }
 
-// out[j] += sum over blocks of partial[b][j]: 64 columns per workgroup, 16 row lanes, fixed summation order
+// out[j] += sum over blocks of partial[b][j]: 16 columns (one 64-byte segment per partial row) x 64 row lanes per workgroup,
+// fixed summation order.  96 workgroups at D = 512 (the 64-column form had 24: 8.3 us for 7 MB, bound by what 24 CUs can pull)
+constexpr int LNF_COLS = 16, LNF_LANES = 64;
 __global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int D,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                float* __restrict__ dcolsum) {
-  __shared__ float sh[16][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int j = blockIdx.x * 64 + tx;
+  __shared__ float sh[LNF_LANES][LNF_COLS + 1];
+  const int tx = threadIdx.x % LNF_COLS, ty = threadIdx.x / LNF_COLS;
+  const int j = blockIdx.x * LNF_COLS + tx;
   float s = 0.f;
   if (j < 3 * D) {
 #pragma unroll 4
-    for (int b = ty; b < nblk; b += 16) s += partial[(size_t)b * 3 * D + j];
+    for (int b = ty; b < nblk; b += LNF_LANES) s += partial[(size_t)b * 3 * D + j];
   }
   sh[ty][tx] = s;
   __syncthreads();
   if (ty == 0 && j < 3 * D) {
     float t = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) t += sh[r][tx];
+    for (int r = 0; r < LNF_LANES; ++r) t += sh[r][tx];
     if (j < D) dgamma[j] += t;
     else if (j < 2 * D) dbeta[j - D] += t;
     else if (dcolsum) dcolsum[j - 2 * D] += t;
@@ -533,6 +535,59 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
 // ======================================================================================================
 using namespace ttts;
 
+// ---- token plumbing of UnifiedVoice.forward in one launch ----------------------------------------------------------
+// (the torch form is ~20 tiny launches per step: arange, where, six pads = fill + copy each, four buffer copies)
+constexpr int PREP_MAX_B = 256;
+struct PrepValid { int32_t v[PREP_MAX_B]; };   // per sample: first mel position rewritten to STOP (wav_len / compression + 1)
+
+__global__ __launch_bounds__(256) void gpt_prepare_tokens_kernel(const int64_t* __restrict__ text, int64_t ldt,
+                                                                 const int64_t* __restrict__ mel, int64_t ldm,
+                                                                 int64_t* __restrict__ text_inp, int64_t* __restrict__ text_tar,
+                                                                 int64_t* __restrict__ mel_inp, int64_t* __restrict__ mel_tar,
+                                                                 int B, int Tt, int Tm, int64_t start_text, int64_t stop_text,
+                                                                 int64_t start_mel, int64_t stop_mel, PrepValid valid) {
+  // thread (b, i): i in [0, Tt + 2) handles the text pair, i in [Tt + 2, Tt + Tm + 4) the mel pair
+  const int W = Tt + Tm + 4;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (int64_t)B * W) return;
+  const int b = (int)(t / W);
+  int i = (int)(t % W);
+  if (i < Tt + 2) {
+    // t1 = [text[0..Tt), STOP];  inp = [START, t1];  tar = [t1, STOP]
+    const int64_t inp = i == 0 ? start_text : (i - 1 < Tt ? text[(int64_t)b * ldt + i - 1] : stop_text);
+    const int64_t tar = i < Tt ? text[(int64_t)b * ldt + i] : stop_text;
+    text_inp[(int64_t)b * (Tt + 2) + i] = inp;
+    text_tar[(int64_t)b * (Tt + 2) + i] = tar;
+  } else {
+    i -= Tt + 2;
+    const int nv = valid.v[b];   // positions >= nv are padding: rewritten to STOP (set_mel_padding)
+    auto m1 = [&](int j) -> int64_t { return (j < Tm && j < nv) ? mel[(int64_t)b * ldm + j] : stop_mel; };
+    const int64_t inp = i == 0 ? start_mel : m1(i - 1);
+    const int64_t tar = i <= Tm ? m1(i) : stop_mel;
+    mel_inp[(int64_t)b * (Tm + 2) + i] = inp;
+    mel_tar[(int64_t)b * (Tm + 2) + i] = tar;
+  }
+}
+
+extern "C" int ttts_gpt_prepare_tokens(const int64_t* text, int64_t ld_text, const int64_t* mel, int64_t ld_mel,
+                                       const int32_t* mel_valid_host, int32_t B, int32_t Tt, int32_t Tm,
+                                       int32_t start_text, int32_t stop_text, int32_t start_mel, int32_t stop_mel,
+                                       int64_t* text_inp, int64_t* text_tar, int64_t* mel_inp, int64_t* mel_tar, void* stream) {
+  TTTS_REQUIRE(text && mel && mel_valid_host && text_inp && text_tar && mel_inp && mel_tar, "prepare_tokens: null pointer");
+  TTTS_REQUIRE(B > 0 && B <= PREP_MAX_B && Tt >= 0 && Tm >= 0, "prepare_tokens: bad shape B=%d (max %d) Tt=%d Tm=%d", B, PREP_MAX_B, Tt, Tm);
+  TTTS_REQUIRE(ld_text >= Tt && ld_mel >= Tm, "prepare_tokens: row pitch smaller than the clipped length");
+  PrepValid v;
+  for (int b = 0; b < B; ++b) {
+    TTTS_REQUIRE(mel_valid_host[b] >= 0, "prepare_tokens: negative valid length");
+    v.v[b] = mel_valid_host[b];
+  }
+  const int64_t total = (int64_t)B * (Tt + Tm + 4);
+  gpt_prepare_tokens_kernel<<<(int)cdiv(total, 256), 256, 0, as_stream(stream)>>>(text, ld_text, mel, ld_mel, text_inp, text_tar,
+                                                                                 mel_inp, mel_tar, B, Tt, Tm, start_text, stop_text,
+                                                                                 start_mel, stop_mel, v);
+  return check_launch("gpt_prepare_tokens");
+}
+
 extern "C" int ttts_gpt_embed_fwd(const int64_t* text_inp, const int64_t* mel_inp, const float* text_emb,
                                   const float* text_pos, const float* mel_emb, const float* mel_pos, float* x,
                                   int32_t B, int32_t Tt, int32_t Tm, int32_t D, int32_t n_text, int32_t n_mel,
@@ -610,7 +665,7 @@ static int layernorm_bwd_impl(const void* dy, int dy_is_bf16, const float* x, co
 #undef LN_BWD
   int rc = check_launch("layernorm_bwd");
   if (rc) return rc;
-  ln_bwd_finalize_kernel<<<(int)cdiv(3 * D, 64), 1024, 0, s>>>(partial, nblk, D, dgamma, dbeta, dcolsum);
+  ln_bwd_finalize_kernel<<<(int)cdiv(3 * D, LNF_COLS), 1024, 0, s>>>(partial, nblk, D, dgamma, dbeta, dcolsum);
   return check_launch("layernorm_bwd_finalize");
 }
 

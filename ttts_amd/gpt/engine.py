@@ -294,6 +294,27 @@ class GptEngine:
         b["mel_inp"].copy_(mel_inp, non_blocking=True)
         b["mel_tar"].copy_(mel_tar.reshape(-1), non_blocking=True)
 
+    def set_tokens_raw(self, text_inputs, text_lengths, mel_codes, wav_lengths, clip_inputs=True):
+        """model.prepare_tokens + set_tokens in ONE kernel launch (ttts_gpt_prepare_tokens): clip to the batch maximum,
+        mel padding -> STOP, START / STOP framing, straight into the engine's static token buffers
+        (ttts/gpt/model.py:474-489,397-414).  text_inputs / mel_codes: int64 on this GPU; the lengths are host tensors (a
+        GPU tensor costs the same two host reads the reference makes, model.py:477,479)."""
+        c = self.c
+        comp = c["mel_length_compression"]
+        tl = text_lengths.tolist() if torch.is_tensor(text_lengths) else list(text_lengths)
+        wl = wav_lengths.tolist() if torch.is_tensor(wav_lengths) else list(wav_lengths)
+        B = text_inputs.shape[0]
+        Tt, Tm = text_inputs.shape[1], mel_codes.shape[1]
+        if clip_inputs:
+            Tt, Tm = min(Tt, int(max(tl))), min(Tm, int(max(wl)) // comp)
+        if Tt + 2 > c["max_text_tokens"] + 2 or Tm + 2 > c["max_mel_tokens"] + 2:
+            raise ValueError("sequence exceeds the learned position tables (text %d, mel %d)" % (Tt + 2, Tm + 2))
+        self._ensure_buffers(B, Tt + 2, Tm + 2)
+        b = self.b
+        ops.gpt_prepare_tokens(text_inputs, mel_codes, [int(w) // comp + 1 for w in wl], Tt, Tm, c["start_text_token"],
+                               c["stop_text_token"], c["start_mel_token"], c["stop_mel_token"], b["text_inp"], b["text_tar"],
+                               b["mel_inp"], b["mel_tar"])
+
     # ---- dropout seeds: one stream per (step, site) ------------------------------------------------------------
     def _p(self):
         return self.dropout_p if self.training else 0.0
@@ -543,8 +564,10 @@ class GptEngine:
         the bytes) are exchanged while the second section computes (`grad_exchange_plan`).
         capture=True replays the step from hipGraphs: one graph without an exchange, two (forward+backward | optimizer)
         around `exchange`, three (forward + backward part 0 | backward part 1 | optimizer) around `exchange_range`.
+        tokens=None: the token buffers were already filled (set_tokens_raw).
         Returns nothing: losses stay on the device (no host sync in the hot loop)."""
-        self.set_tokens(*tokens)
+        if tokens is not None:
+            self.set_tokens(*tokens)
         mode = "range" if exchange_range is not None else ("whole" if exchange is not None else "none")
         graphs = None
         if capture:

@@ -110,6 +110,7 @@ SIGNATURES = {
     "ttts_layernorm_bwd_ex": (_I32, [_P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F,
                                      _U64, _P, _P]),
     "ttts_gpt_embed_fwd": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _F, _U64, _P, _P]),
+    "ttts_gpt_prepare_tokens": (_I32, [_P, _I64, _P, _I64, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
     "ttts_gpt_embed_bwd": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F, _U64, _P, _P]),
     "ttts_ce_fwd_bf16": (_I32, [_P, _I64, _P, _P, _P, _P, _I32, _I32, _P]),
     "ttts_ce_bwd_bf16": (_I32, [_P, _I64, _P, _P, _P, _F, _P, _I32, _I32, _P]),

@@ -182,6 +182,25 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx_in, dx, dx_bf16, dgamma, dbeta, w
                                          _stream()), "layernorm_bwd")
 
 
+def gpt_prepare_tokens(text, mel, mel_valid, Tt, Tm, start_text, stop_text, start_mel, stop_mel, text_inp, text_tar, mel_inp,
+                       mel_tar):
+    """One launch for UnifiedVoice.forward's token plumbing (include/ttts_hip.h: ttts_gpt_prepare_tokens).
+    text / mel: int64 [B, >= Tt / Tm] on the GPU (inner-contiguous); mel_valid: B host ints."""
+    for t_, nm in ((text, "text"), (mel, "mel"), (text_inp, "text_inp"), (text_tar, "text_tar"), (mel_inp, "mel_inp"),
+                   (mel_tar, "mel_tar")):
+        _req(t_, torch.int64, nm)
+    B = text.shape[0]
+    if mel.shape[0] != B or len(mel_valid) != B:
+        raise TttsError("gpt_prepare_tokens: batch sizes differ")
+    for t_, n_ in ((text_inp, B * (Tt + 2)), (text_tar, B * (Tt + 2)), (mel_inp, B * (Tm + 2)), (mel_tar, B * (Tm + 2))):
+        if t_.numel() != n_ or not t_.is_contiguous():
+            raise TttsError("gpt_prepare_tokens: output buffer has %d elements, expected %d (contiguous)" % (t_.numel(), n_))
+    valid = (ctypes.c_int32 * B)(*[int(v) for v in mel_valid])
+    check(_l.get().ttts_gpt_prepare_tokens(_p(text), _ld(text), _p(mel), _ld(mel), valid, B, Tt, Tm, start_text, stop_text,
+                                           start_mel, stop_mel, _p(text_inp), _p(text_tar), _p(mel_inp), _p(mel_tar),
+                                           _stream()), "gpt_prepare_tokens")
+
+
 def embed_fwd(text_inp, mel_inp, text_emb, text_pos, mel_emb, mel_pos, x, dropout_p=0.0, seed=0, counter=None):
     _req(text_inp, torch.int64, "text_inp"); _req(mel_inp, torch.int64, "mel_inp"); _req(x, torch.float32, "x")
     B, Tt = text_inp.shape
