@@ -264,33 +264,6 @@ def test_grouped_weight_gradients_equal_the_per_weight_gemms(gpt, monkeypatch):
                 assert rel_err(gb, ga) < 1e-5, k
 
 
-@pytest.mark.skipif(os.environ.get("TTTS_RUN_EXPERIMENTAL") != "1", reason="unmeasured experiment (TTTS_GROUPED_DW_OVERLAP); opt in with TTTS_RUN_EXPERIMENTAL=1")
-def test_grouped_dw_overlap_experiment_matches(gpt, monkeypatch):
-    """TTTS_GROUPED_DW_OVERLAP=1 (upper layers' grouped dW launch on a side stream beside the lower layers' chain): same
-    gradients as the in-order grouped path, eagerly and under graph replay."""
-    from oracle import gpt_ref
-    dev = torch.device("cuda:0")
-    sd = gpt_ref.det_state_dict(None)
-    batch = gpt_ref.synthetic_batch(B=8, seed=99)
-    res = {}
-    for flag in ("0", "1"):
-        monkeypatch.setenv("TTTS_GROUPED_DW_OVERLAP", flag)
-        eng = gpt.GptEngine(gpt_ref.GPT_CONFIG, dev, dropout_p=0.1, seed=5)
-        eng.load_state_dict(sd)
-        toks = gpt.prepare_tokens(eng.c, *batch)
-        eng.set_tokens(*toks)
-        eng.zero_grad(); eng.forward(); eng.backward()
-        torch.cuda.synchronize()
-        g_eager = eng.grads.clone()
-        for _ in range(2):
-            eng.train_step(toks, 0.01, 1.0, capture=True, lr=0.0)
-        torch.cuda.synchronize()
-        res[flag] = (g_eager, eng.losses())
-        del eng
-    assert rel_err(res["1"][0], res["0"][0]) < 1e-5
-    assert np.isfinite(res["1"][1][1])
-
-
 def math_prod(shape):
     n = 1
     for d in shape:

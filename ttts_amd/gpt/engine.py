@@ -89,10 +89,6 @@ class GptEngine:
         # backward section run as one launch at its end, one workgroup per output tile over the whole token dimension --
         # no split-reduction slabs, no reduce kernels.  TTTS_GROUPED_DW=0 restores one split-K dW GEMM per weight.
         self.grouped_dw = os.environ.get("TTTS_GROUPED_DW", "1") == "1"
-        # experiment (default off, not yet measured): the upper layers' grouped launch on a side stream, concurrent with the
-        # lower layers' data-gradient chain -- its workgroups (64 KB of LDS, like the NT GEMM's) can take the second slot of the
-        # CUs that the N = 512 GEMMs leave half empty (292 tiles on 256 CUs) and the gaps of the LayerNorm / column-sum kernels
-        self.grouped_dw_overlap = os.environ.get("TTTS_GROUPED_DW_OVERLAP", "0") == "1"
         self._dw_plans = {}
         self.seed_ctr = torch.zeros(1, dtype=torch.int32, device=self.device)   # this replica's dropout stream counter (device side:
         # graph-replay safe); handed to every dropout-capable kernel call -- the library holds no state of its own
@@ -217,8 +213,6 @@ class GptEngine:
         b["ln_ws"] = ops.layernorm_bwd_workspace(M, D, dev)
         tn_shapes = [(D, 3 * D, Mp), (D, D, Mp), (D, 4 * D, Mp), (4 * D, D, Mp), (self.nt, D, B * Tt), (self.nm, D, B * Tm)]
         b["tn_ws"] = max((ops.gemm_tn_workspace(mo, no, kr, dev) for mo, no, kr in tn_shapes), key=lambda t: t.numel())
-        if self.grouped_dw and self.grouped_dw_overlap:
-            b["tn_ws2"] = torch.empty_like(b["tn_ws"])   # split-K slabs of the side stream's left-out problems
         # static token buffers (graph replay reads them)
         i64 = torch.int64
         b["text_inp"] = torch.zeros(B, Tt, dtype=i64, device=dev)
@@ -277,12 +271,12 @@ class GptEngine:
         self._dw_plans[key] = (plan, single)
         return self._dw_plans[key]
 
-    def _run_dw(self, lo, hi, ws="tn_ws"):
+    def _run_dw(self, lo, hi):
         plan, single = self._dw_plan(lo, hi)
         if plan is not None:
             plan.run()
         for at, bt, g in single:
-            ops.gemm_tn_accum(at, bt, g, workspace=self.b[ws])
+            ops.gemm_tn_accum(at, bt, g, workspace=self.b["tn_ws"])
 
     def _padded(self, t):
         """The zero-row-padded [Mp, c] buffer behind an [M, c] activation view (weight-gradient GEMM operand)."""
@@ -406,22 +400,10 @@ class GptEngine:
         if part in (None, 0):
             self._backward_head(w_text, w_mel, g_text_dev, g_mel_dev, side, fork)
         ev_fc = ev_qkv = None            # side-stream reads of d_fc / dqkv by the previous layer
-        mid = L // 2
-        overlap = self.grouped_dw and self.grouped_dw_overlap and part is None and 0 < mid < L
-        dw_side = None
         for i in reversed(range(lo_layer, hi_layer)):
             ev_fc, ev_qkv = self._backward_layer(i, side, fork, done, wait, ev_fc, ev_qkv)
-            if overlap and i == mid:     # layers L-1 .. mid are done: their dW launch runs beside the lower layers' chain
-                dw_side = self._side_stream()
-                dw_side.wait_stream(main)
-                with torch.cuda.stream(dw_side):
-                    self._run_dw(mid, L, ws="tn_ws2")
         if self.grouped_dw and hi_layer > lo_layer:
-            if overlap:
-                self._run_dw(0, mid)
-                main.wait_stream(dw_side)
-            else:
-                self._run_dw(lo_layer, hi_layer)
+            self._run_dw(lo_layer, hi_layer)
         if part in (None, 1):
             ops.embed_bwd(b["text_inp"], b["mel_inp"], b["dres"], G("text_embedding.weight"),
                           G("text_pos_embedding.emb.weight"), G("mel_embedding.weight"), G("mel_pos_embedding.emb.weight"),
