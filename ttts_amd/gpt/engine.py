@@ -90,6 +90,9 @@ class GptEngine:
         # no split-reduction slabs, no reduce kernels.  TTTS_GROUPED_DW=0 restores one split-K dW GEMM per weight.
         self.grouped_dw = os.environ.get("TTTS_GROUPED_DW", "1") == "1"
         self._dw_plans = {}
+        # experiment (default off; written without GPU access at the end of round 2, see ttts_gemm_nt_split_bf16): the GEMMs whose
+        # tile count is 1 .. 1.5 x the CU count (N = 512: 292 tiles on 256 CUs) cut their surplus tiles along K
+        self.nt_split = os.environ.get("TTTS_NT_SPLIT", "0") == "1"
         self.seed_ctr = torch.zeros(1, dtype=torch.int32, device=self.device)   # this replica's dropout stream counter (device side:
         # graph-replay safe); handed to every dropout-capable kernel call -- the library holds no state of its own
         self.spec = param_spec(self.c)
@@ -205,6 +208,10 @@ class GptEngine:
         b["d_att"] = e(M, D)
         b["dqkv"] = z(M, 3 * D)
         b["delta"] = e(B * H * S, dt=f32)
+        if self.nt_split:
+            self._cus = ops.device_info()["cus"]
+            need = max(ops.gemm_nt_split_plan(M, n_, k_, self._cus)[0] for n_, k_ in ((D, D), (D, 4 * D), (D, 3 * D), (3 * D, D), (4 * D, D)))
+            b["nt_slabs"] = torch.empty(max(need, 16) // 4, dtype=f32, device=dev)
         if self.grouped_dw:   # per-layer dY buffers (0.5 GB at the BASELINE shape): nothing is overwritten before the dW launch
             b["dy_mlp"] = [z(M, D) for _ in range(L)]        # gradient entering mlp.c_proj  (was: dres_bf)
             b["dy_att"] = [z(M, D) for _ in range(L)]        # gradient entering attn.c_proj (was: dres_bf)
@@ -228,6 +235,12 @@ class GptEngine:
             for lo, hi in {(0, L), (split, L), (0, split)}:
                 if hi > lo:
                     self._dw_plan(lo, hi)
+
+    def _nt(self, a, w, c, *args, **kw):
+        """ops.gemm_nt, or its surplus-tile-split variant when TTTS_NT_SPLIT=1 (falls through for shapes it does not fit)."""
+        if self.nt_split:
+            return ops.gemm_nt_split(a, w, c, self.b["nt_slabs"], self._cus, *args, **kw)
+        return ops.gemm_nt(a, w, c, *args, **kw)
 
     def _dw_plan(self, lo, hi):
         """Grouped dW launch for layers lo .. hi-1: (TnPlan | None, [problems left to the split-K path]).
@@ -339,17 +352,17 @@ class GptEngine:
             x0, x1, x2 = b["xs"][2 * i], b["xs"][2 * i + 1], b["xs"][2 * i + 2]
             st = b["stats"][i]
             ops.layernorm_fwd(x0, P(pre + "ln_1.weight"), P(pre + "ln_1.bias"), b["ln1"][i], st[0], st[1])
-            ops.gemm_nt(b["ln1"][i], self.wT[pre + "attn.c_attn.weight"], b["qkv"][i], P(pre + "attn.c_attn.bias"))
+            self._nt(b["ln1"][i], self.wT[pre + "attn.c_attn.weight"], b["qkv"][i], P(pre + "attn.c_attn.bias"))
             qkv = b["qkv"][i]
             ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], b["att"][i], b["lse"][i], B, H, S, dh, (S * 3 * D, 3 * D),
                          (S * D, D), dh ** -0.5, p, self._seed(16 * i + 2), counter=self.seed_ctr)
-            ops.gemm_nt(b["att"][i], self.wT[pre + "attn.c_proj.weight"], x1, P(pre + "attn.c_proj.bias"),
-                        epilogue=EPI_RESID_ADD_F32, resid_in=x0, dropout_p=p, seed=self._seed(16 * i + 3), counter=self.seed_ctr)
+            self._nt(b["att"][i], self.wT[pre + "attn.c_proj.weight"], x1, P(pre + "attn.c_proj.bias"),
+                     epilogue=EPI_RESID_ADD_F32, resid_in=x0, dropout_p=p, seed=self._seed(16 * i + 3), counter=self.seed_ctr)
             ops.layernorm_fwd(x1, P(pre + "ln_2.weight"), P(pre + "ln_2.bias"), b["ln2"][i], st[2], st[3])
-            ops.gemm_nt(b["ln2"][i], self.wT[pre + "mlp.c_fc.weight"], b["fc_act"][i], P(pre + "mlp.c_fc.bias"),
-                        aux=b["fc_pre"][i], epilogue=EPI_GELU_BF16)
-            ops.gemm_nt(b["fc_act"][i], self.wT[pre + "mlp.c_proj.weight"], x2, P(pre + "mlp.c_proj.bias"),
-                        epilogue=EPI_RESID_ADD_F32, resid_in=x1, dropout_p=p, seed=self._seed(16 * i + 4), counter=self.seed_ctr)
+            self._nt(b["ln2"][i], self.wT[pre + "mlp.c_fc.weight"], b["fc_act"][i], P(pre + "mlp.c_fc.bias"),
+                     aux=b["fc_pre"][i], epilogue=EPI_GELU_BF16)
+            self._nt(b["fc_act"][i], self.wT[pre + "mlp.c_proj.weight"], x2, P(pre + "mlp.c_proj.bias"),
+                     epilogue=EPI_RESID_ADD_F32, resid_in=x1, dropout_p=p, seed=self._seed(16 * i + 4), counter=self.seed_ctr)
         fs = b["fstats"]
         ops.layernorm_fwd(b["xs"][2 * L], P("gpt.ln_f.weight"), P("gpt.ln_f.bias"), b["lnf"], fs[0], fs[1])
         ops.layernorm_fwd(b["lnf"], P("final_norm.weight"), P("final_norm.bias"), b["enc"], fs[2], fs[3],
@@ -457,13 +470,13 @@ class GptEngine:
             ops.gemm_tn_accum(self._padded(b["fc_act"][i]), self._padded(dy), G(pre + "mlp.c_proj.weight"), workspace=b["tn_ws"])
         ev_dy = done()
         wait(ev_fc)                                        # the previous layer's dW c_fc has consumed d_fc
-        ops.gemm_nt(dy, self.w(pre + "mlp.c_proj.weight"), b["d_fc"], aux=b["fc_pre"][i], epilogue=EPI_DGELU_BF16)
+        self._nt(dy, self.w(pre + "mlp.c_proj.weight"), b["d_fc"], aux=b["fc_pre"][i], epilogue=EPI_DGELU_BF16)
         fork()
         with torch.cuda.stream(side):
             ops.gemm_tn_accum(self._padded(b["ln2"][i]), self._padded(b["d_fc"]), G(pre + "mlp.c_fc.weight"), workspace=b["tn_ws"])
             ops.colsum_accum(b["d_fc"], G(pre + "mlp.c_fc.bias"))
         ev_fc = done()
-        ops.gemm_nt(b["d_fc"], self.w(pre + "mlp.c_fc.weight"), b["d_ln"])
+        self._nt(b["d_fc"], self.w(pre + "mlp.c_fc.weight"), b["d_ln"])
         wait(ev_dy)                                        # dres_bf is rewritten by the LayerNorm backward below
         ops.layernorm_bwd(b["d_ln"], x1, P(pre + "ln_2.weight"), st[2], st[3], b["dres"], b["dres"], b["dres_bf"],
                           G(pre + "ln_2.weight"), G(pre + "ln_2.bias"), b["ln_ws"], dropout_p=p,
@@ -473,7 +486,7 @@ class GptEngine:
         with torch.cuda.stream(side):
             ops.gemm_tn_accum(self._padded(b["att"][i]), self._padded(dy), G(pre + "attn.c_proj.weight"), workspace=b["tn_ws"])
         ev_dy = done()
-        ops.gemm_nt(dy, self.w(pre + "attn.c_proj.weight"), b["d_att"])
+        self._nt(dy, self.w(pre + "attn.c_proj.weight"), b["d_att"])
         qkv, dqkv = b["qkv"][i], b["dqkv"]
         wait(ev_qkv)                                       # the previous layer's dW c_attn has consumed dqkv
         ops.attn_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], b["att"][i], b["d_att"], b["lse"][i], dqkv, dqkv[:, D:],
@@ -484,7 +497,7 @@ class GptEngine:
             ops.gemm_tn_accum(self._padded(b["ln1"][i]), self._padded(dqkv), G(pre + "attn.c_attn.weight"), workspace=b["tn_ws"])
             ops.colsum_accum(dqkv, G(pre + "attn.c_attn.bias"))
         ev_qkv = done()
-        ops.gemm_nt(dqkv, self.w(pre + "attn.c_attn.weight"), b["d_ln"])
+        self._nt(dqkv, self.w(pre + "attn.c_attn.weight"), b["d_ln"])
         wait(ev_dy)
         ops.layernorm_bwd(b["d_ln"], x0, P(pre + "ln_1.weight"), st[0], st[1], b["dres"], b["dres"],
                           b["dres_bf"] if i > 0 else None, G(pre + "ln_1.weight"), G(pre + "ln_1.bias"),
@@ -506,19 +519,19 @@ class GptEngine:
         st = b["stats"][i]
         x0, x1 = b["xs"][2 * i], b["xs"][2 * i + 1]
         dy, d_fc, dy_att, dqkv = b["dy_mlp"][i], b["d_fc_l"][i], b["dy_att"][i], b["dqkv_l"][i]
-        ops.gemm_nt(dy, self.w(pre + "mlp.c_proj.weight"), d_fc, aux=b["fc_pre"][i], epilogue=EPI_DGELU_BF16)
+        self._nt(dy, self.w(pre + "mlp.c_proj.weight"), d_fc, aux=b["fc_pre"][i], epilogue=EPI_DGELU_BF16)
         ops.colsum_accum(d_fc, G(pre + "mlp.c_fc.bias"))
-        ops.gemm_nt(d_fc, self.w(pre + "mlp.c_fc.weight"), b["d_ln"])
+        self._nt(d_fc, self.w(pre + "mlp.c_fc.weight"), b["d_ln"])
         ops.layernorm_bwd(b["d_ln"], x1, P(pre + "ln_2.weight"), st[2], st[3], b["dres"], b["dres"], dy_att,
                           G(pre + "ln_2.weight"), G(pre + "ln_2.bias"), b["ln_ws"], dropout_p=p,
                           seed=self._seed(16 * i + 3), dcolsum=G(pre + "attn.c_proj.bias"), counter=self.seed_ctr)
-        ops.gemm_nt(dy_att, self.w(pre + "attn.c_proj.weight"), b["d_att"])
+        self._nt(dy_att, self.w(pre + "attn.c_proj.weight"), b["d_att"])
         qkv = b["qkv"][i]
         ops.attn_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], b["att"][i], b["d_att"], b["lse"][i], dqkv, dqkv[:, D:],
                      dqkv[:, 2 * D:], b["delta"], B, H, S, dh, (S * 3 * D, 3 * D), (S * D, D), dh ** -0.5, p,
                      self._seed(16 * i + 2), counter=self.seed_ctr)
         ops.colsum_accum(dqkv, G(pre + "attn.c_attn.bias"))
-        ops.gemm_nt(dqkv, self.w(pre + "attn.c_attn.weight"), b["d_ln"])
+        self._nt(dqkv, self.w(pre + "attn.c_attn.weight"), b["d_ln"])
         ops.layernorm_bwd(b["d_ln"], x0, P(pre + "ln_1.weight"), st[0], st[1], b["dres"], b["dres"],
                           b["dy_mlp"][i - 1] if i > 0 else None, G(pre + "ln_1.weight"), G(pre + "ln_1.bias"),
                           b["ln_ws"], dropout_p=p if i > 0 else 0.0, seed=self._seed(16 * (i - 1) + 4),

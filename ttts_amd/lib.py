@@ -90,6 +90,8 @@ SIGNATURES = {
     "ttts_gemm_nt_bf16": (_I32, [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "ttts_gemm_nt_bf16_ex": (_I32, [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I32, _I32, _I32, _I32, _P, _F, _U64, _P, _P, _P]),
     "ttts_gemm_nt_workspace_bytes": (_I64, []),
+    "ttts_gemm_nt_split_plan": (_I64, [_I32, _I32, _I32, _I32, _P]),
+    "ttts_gemm_nt_split_bf16": (_I32, [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I32, _I32, _I32, _I32, _P, _F, _U64, _P, _I32, _P, _P]),
     "ttts_gemm_tn_workspace_bytes": (_I64, [_I32, _I32, _I32]),
     "ttts_gemm_tn_bf16_accum_f32": (_I32, [_P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _P]),
     "ttts_tn_desc_tiles": (_I32, [_I32, _I32]),
