@@ -1,0 +1,21 @@
+#!/bin/bash
+# First GPU call of round 3: run what round 2 left unmeasured.
+#  1. gated parity tests of the surplus-tile-split NT GEMM (ttts_gemm_nt_split_bf16; written without GPU access)
+#  2. GPT bench with TTTS_NT_SPLIT=0 / 1 (same box, same build): per-family times in roofline.all_kernels_ms_per_step
+# Output: gpurun_out/r3first/{split_tests.log,b_split0.json,b_split1.json}
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+export TMPDIR=/tmp
+O=gpurun_out/r3first
+mkdir -p $O
+TTTS_RUN_EXPERIMENTAL=1 timeout 200 python -m pytest tests/test_gpu_kernels.py -q -k "surplus_split" > $O/split_tests.log 2>&1; echo "SPLIT TESTS rc=$?"; tail -5 $O/split_tests.log
+for f in 0 1; do
+  TTTS_NT_SPLIT=$f timeout 120 python bench.py --no-vqvae --no-cpu-baseline --steps 150 --warmup 10 > $O/b_split$f.json 2> $O/b_split$f.err; echo "bench TTTS_NT_SPLIT=$f rc=$?"
+  python - $f <<'PY'
+import json, sys
+try:
+    d = json.loads(open("gpurun_out/r3first/b_split%s.json" % sys.argv[1]).read().strip().splitlines()[-1])
+    print("TTTS_NT_SPLIT=%s ms/step %s" % (sys.argv[1], d["ms_per_step"]), d["roofline"]["all_kernels_ms_per_step"])
+except Exception as e:
+    print("unreadable:", e)
+PY
+done
