@@ -306,6 +306,8 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_nt_glds_kernel(
 // `full` tiles (= the CU count: one per CU, dispatched first) run whole; every surplus tile is cut along K into `pieces`
 // workgroups that land in the CUs' second slots, finish early and leave fp32 slabs; a small second launch sums a tile's
 // slabs in a fixed order and applies the epilogue.  Deterministic; the epilogue arithmetic is the one of tile_epilogue.
+// Placement premise, measured (tools/exp/placement_probe.hip): blocks 0 .. 255 of a 2-per-CU kernel land one per CU and
+// block b + 256 joins block b's CU -- so whole tiles first, pieces behind them, pairs one whole tile with one piece per CU.
 struct GemmNtSplitParams {
   GemmNtParams g;
   float* slabs;       // [surplus][pieces][128][128] fp32
