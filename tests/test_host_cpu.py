@@ -75,6 +75,24 @@ def test_argument_validation_without_gpu(lib):
     np.testing.assert_allclose(tw[2 * 512:2 * 512 + 2], [0.0, -1.0], atol=1e-7)
 
 
+def test_grouped_dw_left_out_selection():
+    """GptEngine._dw_plan's tile-count quantisation rule (pure host logic): which dW problems leave the grouped launch."""
+    from ttts_amd.gpt.engine import left_out_problems
+    layer = [64, 64, 48, 16]                       # c_fc, mlp c_proj, c_attn, attn c_proj at d 512
+    out = left_out_problems(layer * 6, 512)        # 1152 tiles: 2.25 rounds -> two 64-tile problems out, 1024 stay
+    assert sum((layer * 6)[j] for j in out) == 128 and len(out) == 2
+    out = left_out_problems(layer * 3, 512)        # one backward section: 576 -> 512 + one 64-tile problem
+    assert [(layer * 3)[j] for j in out] == [64]
+    assert left_out_problems(layer * 2, 512) == set()          # 384 tiles: fewer than one round, all grouped
+    assert left_out_problems([64] * 16, 512) == set()          # exact multiple
+    assert left_out_problems([64] * 15, 512) == set()          # 960: remainder 448 >= 5/8 of a round: keep the third round
+    tiles = [48, 16, 64, 64, 48, 16, 64, 64, 48]
+    out = left_out_problems(tiles, 256)            # 432 = 256 + 176 (>= 160 = 5/8): stays
+    assert out == set()
+    out = left_out_problems(tiles, 384)            # 432 = 384 + 48: exactly one 48-tile problem leaves
+    assert [tiles[j] for j in out] == [48]
+
+
 def test_product_path_fails_loudly_without_gpu():
     if torch.cuda.is_available():
         pytest.skip("GPU present")

@@ -71,6 +71,26 @@ def _up(x, m):
     return (x + m - 1) // m * m
 
 
+def left_out_problems(tiles, slots):
+    """Which problems of a grouped dW launch go to the split-K kernel instead (GptEngine._dw_plan): tiles[j] = 128 x 128 output
+    tiles of problem j, slots = resident workgroups (2 per CU).  A total just above a multiple of `slots` would cost a whole,
+    mostly empty extra round; the smallest-sum subset of problems that covers the remainder is taken out.  Returns a set of
+    indices (empty: everything stays grouped)."""
+    total = sum(tiles)
+    rem = total % slots
+    if total <= slots or rem == 0 or rem >= (slots * 5) // 8:
+        return set()
+    best = {0: ()}                      # reachable tile sums < rem + max(tiles) -> one subset each (first found)
+    for j, t in enumerate(tiles):
+        for ssum, sel in list(best.items()):
+            if ssum < rem and (ssum + t) not in best:
+                best[ssum + t] = sel + (j,)
+    cand = [ssum for ssum in best if ssum >= rem]
+    if not cand or min(cand) >= total:
+        return set()
+    return set(best[min(cand)])
+
+
 class GptEngine:
     """Owns the arenas and activation buffers of one model replica on one GPU."""
 
@@ -264,20 +284,7 @@ class GptEngine:
                       (P_(b["ln1"][i]), P_(b["dqkv_l"][i]), G(pre + "attn.c_attn.weight")),
                       (P_(b["att"][i]), P_(b["dy_att"][i]), G(pre + "attn.c_proj.weight"))]
         tiles = [ops.tn_desc_tiles(at.shape[1], bt.shape[1]) for at, bt, _ in probs]
-        slots = 2 * ops.device_info()["cus"]
-        total = sum(tiles)
-        rem = total % slots
-        out = set()
-        if total > slots and 0 < rem < (slots * 5) // 8:
-            # smallest tile sum >= rem over subsets of problems (subset-sum table over <= 64 small integers)
-            best = {0: ()}
-            for j, t in enumerate(tiles):
-                for ssum, sel in list(best.items()):
-                    if ssum < rem and (ssum + t) not in best:
-                        best[ssum + t] = sel + (j,)
-            cand = [ssum for ssum in best if ssum >= rem]
-            if cand and min(cand) < total:
-                out = set(best[min(cand)])
+        out = left_out_problems(tiles, 2 * ops.device_info()["cus"])
         grouped = [pr for j, pr in enumerate(probs) if j not in out]
         single = [pr for j, pr in enumerate(probs) if j in out]
         plan = ops.TnPlan(grouped, self.device) if grouped else None
