@@ -75,6 +75,45 @@ def test_argument_validation_without_gpu(lib):
     np.testing.assert_allclose(tw[2 * 512:2 * 512 + 2], [0.0, -1.0], atol=1e-7)
 
 
+def test_token_kernel_index_contract_matches_prepare_tokens():
+    """Executable statement of ttts_gpt_prepare_tokens' per-thread rule (csrc/elementwise.hip: gpt_prepare_tokens_kernel),
+    mirrored in Python and compared with model.prepare_tokens (the torch form of ttts/gpt/model.py:474-489,397-414).
+    The kernel itself is compared bit-for-bit on the GPU (test_fused_token_plumbing_equals_prepare_tokens)."""
+    from ttts_amd.gpt.engine import resolve_config
+    from ttts_amd.gpt.model import prepare_tokens
+    c = resolve_config({})
+    comp = c["mel_length_compression"]
+    st, sp, sm, pm = c["start_text_token"], c["stop_text_token"], c["start_mel_token"], c["stop_mel_token"]
+
+    def mirror(text, tl, mel, wl, clip):
+        B, Tt, Tm = text.shape[0], text.shape[1], mel.shape[1]
+        if clip:
+            Tt, Tm = min(Tt, max(tl)), min(Tm, max(wl) // comp)
+        valid = [w // comp + 1 for w in wl]
+        ti = torch.zeros(B, Tt + 2, dtype=torch.int64); tt = ti.clone()
+        mi = torch.zeros(B, Tm + 2, dtype=torch.int64); mt = mi.clone()
+        W = Tt + Tm + 4
+        for t in range(B * W):                       # one "thread" per (sample, position of either pair)
+            b, i = divmod(t, W)
+            if i < Tt + 2:
+                ti[b, i] = st if i == 0 else (text[b, i - 1] if i - 1 < Tt else sp)
+                tt[b, i] = text[b, i] if i < Tt else sp
+            else:
+                i -= Tt + 2
+                m1 = lambda j: mel[b, j] if (j < Tm and j < valid[b]) else pm   # noqa: E731
+                mi[b, i] = sm if i == 0 else m1(i - 1)
+                mt[b, i] = m1(i) if i <= Tm else pm
+        return ti, tt, mi, mt
+    g = torch.Generator().manual_seed(3)
+    for B, Tt, Tm, tl, wl, clip in [(4, 40, 300, [40, 33, 12, 25], [300 * 1024 + 7, 257 * 1024, 100 * 1024 + 1023, 299 * 1024], True),
+                                    (3, 50, 120, [20, 31, 7], [64 * 1024, 100 * 1024 + 5, 17 * 1024], True),
+                                    (2, 16, 64, [16, 9], [64 * 1024, 30 * 1024], False), (1, 8, 8, [8], [8 * 1024], True)]:
+        text = torch.randint(1, 255, (B, Tt), generator=g); mel = torch.randint(0, 1024, (B, Tm), generator=g)
+        ref = prepare_tokens(c, text, torch.tensor(tl), mel, torch.tensor(wl), clip_inputs=clip)
+        for r, m in zip(ref, mirror(text, tl, mel, wl, clip)):
+            assert torch.equal(r.reshape(m.shape), m)
+
+
 def test_grouped_dw_left_out_selection():
     """GptEngine._dw_plan's tile-count quantisation rule (pure host logic): which dW problems leave the grouped launch."""
     from ttts_amd.gpt.engine import left_out_problems
