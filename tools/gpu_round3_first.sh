@@ -19,3 +19,11 @@ except Exception as e:
     print("unreadable:", e)
 PY
 done
+# 3. where the attention kernels wait (they are latency-bound: 16 % MFMA-busy, 37 % VALU-busy, 30 % of wave cycles waiting):
+#    two counter passes over tools/gpt_step_once.py; read the attn_* blocks of the outputs
+bash tools/gpt_pmc.sh r03_pmc_attn_wait1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU
+bash tools/gpt_pmc.sh r03_pmc_attn_wait2 SQ_INSTS_VMEM SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VALU SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES
+grep -A9 "attn_bwd_dkdv" gpurun_out/pmc/r03_pmc_attn_wait1.txt | head -10
+grep -A9 "attn_bwd_dkdv" gpurun_out/pmc/r03_pmc_attn_wait2.txt | head -10
+# 4. placement of a 3-per-CU kernel (attention dq / forward): does block b + 512 join blocks b and b + 256?
+hipcc --offload-arch=gfx950 -O2 tools/exp/placement_probe.hip -o /tmp/pp && /tmp/pp 640 > $O/placement_640.txt && tail -1 $O/placement_640.txt
