@@ -27,3 +27,15 @@ grep -A9 "attn_bwd_dkdv" gpurun_out/pmc/r03_pmc_attn_wait1.txt | head -10
 grep -A9 "attn_bwd_dkdv" gpurun_out/pmc/r03_pmc_attn_wait2.txt | head -10
 # 4. placement of a 3-per-CU kernel (attention dq / forward): does block b + 512 join blocks b and b + 256?
 hipcc --offload-arch=gfx950 -O2 tools/exp/placement_probe.hip -o /tmp/pp && /tmp/pp 640 > $O/placement_640.txt && tail -1 $O/placement_640.txt
+# 5. dK / dV kernel with zero-fill and statistics scaling at the LDS store instead of at the global load (-DTTTS_DKDV_LATE=1:
+#    its ISA issues the tile prefetch back to back and waits after the MFMAs; the default waits four times in front of them).
+#    Builds the variant library on the box, runs the attention + GPT parity tests and the bench with it, then restores.
+cp ttts_amd/libttts_hip.so /tmp/lib_default.so
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -fPIC -Wno-unused-variable -Iinclude"
+hipcc $FLAGS -DTTTS_DKDV_LATE=1 -c ttts_amd/csrc/attn.hip -o /tmp/attn_late.o 2> $O/late_build.err \
+ && hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/lib_late.so $(ls ttts_amd/csrc/build/*.o | grep -v "build/attn.o") /tmp/attn_late.o \
+ && cp /tmp/lib_late.so ttts_amd/libttts_hip.so && touch ttts_amd/csrc/build/*.o && sleep 0.1 && touch ttts_amd/libttts_hip.so \
+ && { timeout 200 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_gpt.py -q -k "attn or attention or train_steps or tiny or full_config or dropout or grouped" > $O/late_tests.log 2>&1; echo "LATE TESTS rc=$?"; tail -3 $O/late_tests.log; \
+      timeout 120 python bench.py --no-vqvae --no-cpu-baseline --steps 150 --warmup 10 > $O/b_late.json 2> $O/b_late.err; \
+      python -c "import json; d=json.loads(open('$O/b_late.json').read().strip().splitlines()[-1]); print('DKDV_LATE ms/step', d['ms_per_step'], d['roofline']['all_kernels_ms_per_step'])"; }
+cp /tmp/lib_default.so ttts_amd/libttts_hip.so; touch ttts_amd/csrc/build/*.o; sleep 0.1; touch ttts_amd/libttts_hip.so

@@ -84,9 +84,10 @@ __device__ __forceinline__ void drop_keep4(uint32_t rowh, const uint32_t* colm4,
 }
 
 // load / store a 64 x DH bf16 tile (rows row0.. of a [*, stride] matrix).  Rows beyond nrows: the load is unconditional from the
-// last valid row (a guarded load compiles to an exec-masked branch per 16-byte piece -- 8 branches per loop iteration); ZERO
-// then selects zeros (needed where padding rows must contribute nothing: Q / dO rows of the dK-dV kernel), otherwise the
-// duplicate row is left in place -- K / V rows beyond the sequence only meet probabilities that are masked to exactly 0.
+// last valid row (a guarded load compiles to an exec-masked branch per 16-byte piece -- 8 branches per loop iteration).  With
+// ZERO = false the duplicate row is left in place -- K / V rows beyond the sequence only meet probabilities that are masked to
+// exactly 0.  ZERO = true selects zeros AT THE LOAD and is kept for reference only: hipcc sinks each load under the select's
+// condition and waits for it on the spot (see tile_store_zero, which the dK / dV kernel uses for its Q / dO tiles instead).
 template <int DH, bool ZERO = true>
 __device__ __forceinline__ void tile_load(bf16x8 (&r)[AttnCfg<DH>::CPT], const bf16* base, int64_t stride, int row0,
                                           int nrows, int tid) {
@@ -111,6 +112,19 @@ __device__ __forceinline__ void tile_store(const bf16x8 (&r)[AttnCfg<DH>::CPT], 
   for (int i = 0; i < AttnCfg<DH>::CPT; ++i) {
     const int c = tid + i * 256, row = c / AttnCfg<DH>::CPR, dc = (c % AttnCfg<DH>::CPR) * 8;
     *reinterpret_cast<bf16x8*>(lds + row * STR + dc) = r[i];
+  }
+}
+
+// tile_store with rows >= nrows written as zeros.  Pair it with tile_load<DH, false>: zeroing at the LOAD (cond ? loaded : 0)
+// makes hipcc turn each 16-byte load into an exec-masked branch with its own s_waitcnt vmcnt(0) -- the loads of a prefetch then
+// run one full memory latency after another IN FRONT of the compute they were meant to hide under (seen in the ISA of the
+// dK / dV kernel: four serialised round trips per 64-query tile).
+template <int DH, int STR>
+__device__ __forceinline__ void tile_store_zero(const bf16x8 (&r)[AttnCfg<DH>::CPT], bf16* lds, int tid, int row0, int nrows) {
+#pragma unroll
+  for (int i = 0; i < AttnCfg<DH>::CPT; ++i) {
+    const int c = tid + i * 256, row = c / AttnCfg<DH>::CPR, dc = (c % AttnCfg<DH>::CPR) * 8;
+    *reinterpret_cast<bf16x8*>(lds + row * STR + dc) = (row0 + row < nrows) ? r[i] : zero8();
   }
 }
 
@@ -623,7 +637,15 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 3 : 2)) void attn_bwd_dq_kernel(At
 // -------------------------------------------------------------------------------------------------------
 // backward: dK, dV (S form, one key per lane; loops over query tiles from the diagonal down)
 // -------------------------------------------------------------------------------------------------------
-template <int DH, bool DROPOUT>
+// LATE (round-3 candidate, compiled in but NOT selected: TTTS_DKDV_LATE below): Q / dO rows and the lse / delta statistics are
+// loaded unconditionally and zero-filled / scaled where they are STORED to LDS.  The default form does both at the load, which
+// hipcc turns into exec-masked loads each followed by s_waitcnt vmcnt(0): per 64-query tile four memory round trips run back
+// to back in front of the compute (ISA; the kernel is 16 % MFMA-busy with 30 % of its wave cycles waiting).  The LATE form's
+// ISA issues the five loads back to back and waits for them after the tile's MFMAs.  Same values reach LDS in both forms.
+#ifndef TTTS_DKDV_LATE
+#define TTTS_DKDV_LATE 0
+#endif
+template <int DH, bool DROPOUT, bool LATE = (TTTS_DKDV_LATE != 0)>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
   using C = AttnCfg<DH>;
   __shared__ __attribute__((aligned(16))) bf16 Qs[2][64 * C::KSTR];
@@ -663,26 +685,39 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
   const int nqt = (p.S + 63) / 64;
   bf16x8 rq[C::CPT], rd[C::CPT];
   // per-tile statistics: threads 0..63 stage lse (in log2 units), threads 64..127 stage delta
+  // the loaded value is not touched before STORE_STATS: any arithmetic on it up here would put an s_waitcnt vmcnt(0) -- for
+  // the whole prefetch -- in front of the tile's compute
   float rstat = 0.f;
+  const float* statp = tid < 64 ? lsep : delp;
 #define LOAD_STATS(q0)                                                                   \
   {                                                                                      \
     const int qi = (q0) + (tid & 63);                                                    \
-    if (tid < 128) rstat = qi < p.S ? (tid < 64 ? lsep[qi] * LOG2E : delp[qi]) : 0.f;    \
+    if (LATE) {                                                                          \
+      if (tid < 128) rstat = statp[min(qi, p.S - 1)];                                    \
+    } else {                                                                             \
+      if (tid < 128) rstat = qi < p.S ? (tid < 64 ? lsep[qi] * LOG2E : delp[qi]) : 0.f;  \
+    }                                                                                    \
   }
 #define STORE_STATS(buf, q0_)                                                                                         \
   {                                                                                                                  \
-    if (tid < 64) Ls[buf][tid] = rstat;                                                                              \
-    else if (tid < 128) Dl[buf][tid - 64] = rstat;                                                                   \
+    const bool live_ = (q0_) + (tid & 63) < p.S;                                                                     \
+    if (tid < 64) Ls[buf][tid] = LATE ? (live_ ? rstat * LOG2E : 0.f) : rstat;                                       \
+    else if (tid < 128) Dl[buf][tid - 64] = LATE ? (live_ ? rstat : 0.f) : rstat;                                    \
     else if (DROPOUT && tid < 192) Am[buf][tid - 128] = drop_row_hash(id_bh + (uint32_t)((q0_) + tid - 128), p.seed_lo, shi); \
   }
   const uint32_t shi = DROPOUT ? seed_mix(p.seed_hi, p.ctr) : 0u;
   const uint32_t id_bh = (uint32_t)((b * p.H + h) * p.S), thr32 = p.thr << 16;
   const uint32_t colm = DROPOUT ? drop_col_mult(id_bh + (uint32_t)key, p.seed_lo, shi) : 0u;
-  tile_load<DH>(rq, qp, p.ss, qt0 * 64, p.S, tid);
-  tile_load<DH>(rd, dop, p.oss, qt0 * 64, p.S, tid);
+  tile_load<DH, !LATE>(rq, qp, p.ss, qt0 * 64, p.S, tid);
+  tile_load<DH, !LATE>(rd, dop, p.oss, qt0 * 64, p.S, tid);
   LOAD_STATS(qt0 * 64)
-  tile_store<DH, C::KSTR>(rq, Qs[0], tid);
-  tile_store<DH, C::KSTR>(rd, Ds[0], tid);
+  if (LATE) {
+    tile_store_zero<DH, C::KSTR>(rq, Qs[0], tid, qt0 * 64, p.S);
+    tile_store_zero<DH, C::KSTR>(rd, Ds[0], tid, qt0 * 64, p.S);
+  } else {
+    tile_store<DH, C::KSTR>(rq, Qs[0], tid);
+    tile_store<DH, C::KSTR>(rd, Ds[0], tid);
+  }
   STORE_STATS(0, qt0 * 64)
   __syncthreads();
   const int q_nat = (lane & 31) * C::KSTR + hh * 8;
@@ -690,8 +725,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
   for (int qt = qt0; qt < nqt; ++qt) {
     const int buf = (qt - qt0) & 1, q0 = qt * 64;
     if (qt + 1 < nqt) {
-      tile_load<DH>(rq, qp, p.ss, q0 + 64, p.S, tid);
-      tile_load<DH>(rd, dop, p.oss, q0 + 64, p.S, tid);
+      tile_load<DH, !LATE>(rq, qp, p.ss, q0 + 64, p.S, tid);
+      tile_load<DH, !LATE>(rd, dop, p.oss, q0 + 64, p.S, tid);
       LOAD_STATS(q0 + 64)
     }
     if (q0 + 63 >= k_base) {  // wave-uniform: some query of this tile can see some key of this wave
@@ -765,8 +800,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
       }
     }
     if (qt + 1 < nqt) {
-      tile_store<DH, C::KSTR>(rq, Qs[buf ^ 1], tid);
-      tile_store<DH, C::KSTR>(rd, Ds[buf ^ 1], tid);
+      if (LATE) {
+        tile_store_zero<DH, C::KSTR>(rq, Qs[buf ^ 1], tid, q0 + 64, p.S);
+        tile_store_zero<DH, C::KSTR>(rd, Ds[buf ^ 1], tid, q0 + 64, p.S);
+      } else {
+        tile_store<DH, C::KSTR>(rq, Qs[buf ^ 1], tid);
+        tile_store<DH, C::KSTR>(rd, Ds[buf ^ 1], tid);
+      }
       STORE_STATS(buf ^ 1, q0 + 64)
     }
     __syncthreads();
