@@ -39,3 +39,12 @@ hipcc $FLAGS -DTTTS_DKDV_LATE=1 -c ttts_amd/csrc/attn.hip -o /tmp/attn_late.o 2>
       timeout 120 python bench.py --no-vqvae --no-cpu-baseline --steps 150 --warmup 10 > $O/b_late.json 2> $O/b_late.err; \
       python -c "import json; d=json.loads(open('$O/b_late.json').read().strip().splitlines()[-1]); print('DKDV_LATE ms/step', d['ms_per_step'], d['roofline']['all_kernels_ms_per_step'])"; }
 cp /tmp/lib_default.so ttts_amd/libttts_hip.so; touch ttts_amd/csrc/build/*.o; sleep 0.1; touch ttts_amd/libttts_hip.so
+# 6. fused single-pass conv weight gradient with the bounds masks at the LDS store (-DTTTS_WGRAD_LATE=1): the default's
+#    `cond ? loaded : 0` right behind each load makes its register prefetch synchronous (ISA).  VQ-VAE tests + step time.
+hipcc $FLAGS -DTTTS_WGRAD_LATE=1 -c ttts_amd/csrc/conv_mfma.hip -o /tmp/conv_late.o 2> $O/wgrad_late_build.err \
+ && hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/lib_wlate.so $(ls ttts_amd/csrc/build/*.o | grep -v "build/conv_mfma.o") /tmp/conv_late.o \
+ && cp /tmp/lib_wlate.so ttts_amd/libttts_hip.so && touch ttts_amd/csrc/build/*.o && sleep 0.1 && touch ttts_amd/libttts_hip.so \
+ && { timeout 300 python -m pytest tests/test_gpu_vqvae.py -q -k "wgrad or conv or step" > $O/wlate_tests.log 2>&1; echo "WGRAD_LATE TESTS rc=$?"; tail -3 $O/wlate_tests.log; \
+      timeout 200 python tools/vqvae_bench.py 32 6 1 > $O/vq_wlate.log 2>&1; tail -3 $O/vq_wlate.log; }
+cp /tmp/lib_default.so ttts_amd/libttts_hip.so; touch ttts_amd/csrc/build/*.o; sleep 0.1; touch ttts_amd/libttts_hip.so
+timeout 200 python tools/vqvae_bench.py 32 6 1 > $O/vq_default.log 2>&1; tail -3 $O/vq_default.log
