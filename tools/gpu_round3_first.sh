@@ -48,3 +48,12 @@ hipcc $FLAGS -DTTTS_WGRAD_LATE=1 -c ttts_amd/csrc/conv_mfma.hip -o /tmp/conv_lat
       timeout 200 python tools/vqvae_bench.py 32 6 1 > $O/vq_wlate.log 2>&1; tail -3 $O/vq_wlate.log; }
 cp /tmp/lib_default.so ttts_amd/libttts_hip.so; touch ttts_amd/csrc/build/*.o; sleep 0.1; touch ttts_amd/libttts_hip.so
 timeout 200 python tools/vqvae_bench.py 32 6 1 > $O/vq_default.log 2>&1; tail -3 $O/vq_default.log
+# 7. nearest-code search with unguarded (clamped-index) code-row loads + a branch-free full-group path (-DTTTS_VQ_UNGUARDED=1):
+#    the default's guarded prefetch is waited for before the MFMAs it should overlap (ISA).  Indices must stay bit-exact.
+hipcc $FLAGS -DTTTS_VQ_UNGUARDED=1 -c ttts_amd/csrc/vq.hip -o /tmp/vq_un.o 2> $O/vq_un_build.err \
+ && hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/lib_vqun.so $(ls ttts_amd/csrc/build/*.o | grep -v "build/vq.o") /tmp/vq_un.o \
+ && cp /tmp/lib_vqun.so ttts_amd/libttts_hip.so && touch ttts_amd/csrc/build/*.o && sleep 0.1 && touch ttts_amd/libttts_hip.so \
+ && { timeout 200 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_vqvae.py -q -k "vq" > $O/vqun_tests.log 2>&1; echo "VQ_UNGUARDED TESTS rc=$?"; tail -3 $O/vqun_tests.log; \
+      timeout 100 python tools/hbm_bench.py > $O/hbm_vqun.log 2>&1; grep -i "vq_nearest" $O/hbm_vqun.log | head -3; }
+cp /tmp/lib_default.so ttts_amd/libttts_hip.so; touch ttts_amd/csrc/build/*.o; sleep 0.1; touch ttts_amd/libttts_hip.so
+timeout 100 python tools/hbm_bench.py > $O/hbm_default.log 2>&1; grep -i "vq_nearest" $O/hbm_default.log | head -3
