@@ -38,6 +38,13 @@ hipcc $FLAGS -DTTTS_DKDV_LATE=1 -c ttts_amd/csrc/attn.hip -o /tmp/attn_late.o 2>
  && { timeout 200 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_gpt.py -q -k "attn or attention or train_steps or tiny or full_config or dropout or grouped" > $O/late_tests.log 2>&1; echo "LATE TESTS rc=$?"; tail -3 $O/late_tests.log; \
       timeout 120 python bench.py --no-vqvae --no-cpu-baseline --steps 150 --warmup 10 > $O/b_late.json 2> $O/b_late.err; \
       python -c "import json; d=json.loads(open('$O/b_late.json').read().strip().splitlines()[-1]); print('DKDV_LATE ms/step', d['ms_per_step'], d['roofline']['all_kernels_ms_per_step'])"; }
+#    5b. the same plus the key-block pairing order (-DTTTS_DKDV_PAIR=1: every CU gets 24 tile iterations instead of 30/26/22/18)
+hipcc $FLAGS -DTTTS_DKDV_LATE=1 -DTTTS_DKDV_PAIR=1 -c ttts_amd/csrc/attn.hip -o /tmp/attn_lp.o 2> $O/lp_build.err \
+ && hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/lib_lp.so $(ls ttts_amd/csrc/build/*.o | grep -v "build/attn.o") /tmp/attn_lp.o \
+ && cp /tmp/lib_lp.so ttts_amd/libttts_hip.so && touch ttts_amd/csrc/build/*.o && sleep 0.1 && touch ttts_amd/libttts_hip.so \
+ && { timeout 200 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_gpt.py -q -k "attn or attention or train_steps or tiny or full_config or dropout" > $O/lp_tests.log 2>&1; echo "LATE+PAIR TESTS rc=$?"; tail -3 $O/lp_tests.log; \
+      timeout 120 python bench.py --no-vqvae --no-cpu-baseline --steps 150 --warmup 10 > $O/b_lp.json 2> $O/b_lp.err; \
+      python -c "import json; d=json.loads(open('$O/b_lp.json').read().strip().splitlines()[-1]); print('DKDV_LATE+PAIR ms/step', d['ms_per_step'], d['roofline']['all_kernels_ms_per_step'])"; }
 cp /tmp/lib_default.so ttts_amd/libttts_hip.so; touch ttts_amd/csrc/build/*.o; sleep 0.1; touch ttts_amd/libttts_hip.so
 # 6. fused single-pass conv weight gradient with the bounds masks at the LDS store (-DTTTS_WGRAD_LATE=1): the default's
 #    `cond ? loaded : 0` right behind each load makes its register prefetch synchronous (ISA).  VQ-VAE tests + step time.

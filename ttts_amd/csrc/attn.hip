@@ -645,6 +645,17 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 3 : 2)) void attn_bwd_dq_kernel(At
 #ifndef TTTS_DKDV_LATE
 #define TTTS_DKDV_LATE 0
 #endif
+#ifndef TTTS_DKDV_PAIR
+#define TTTS_DKDV_PAIR 0
+#endif
+// slot -> key block for TTTS_DKDV_PAIR: slots [0, r) keep their block, [r, min(2r, G)) take theirs in reverse, the rest in
+// reverse too (a bijection of [0, G): three disjoint ranges mapped onto themselves)
+__device__ __forceinline__ int dkdv_pair_order(int slot, int G, int r) {
+  const int hi = min(2 * r, G);
+  if (slot < r) return slot;
+  if (slot < hi) return r + (hi - 1 - slot);
+  return hi + (G - 1 - slot);
+}
 template <int DH, bool DROPOUT, bool LATE = (TTTS_DKDV_LATE != 0)>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
   using C = AttnCfg<DH>;
@@ -657,7 +668,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
   const int hh = lane >> 5, g = lane >> 4, ip = lane & 15;
   const int nkb = (p.S + 127) / 128;
   const int nbh = gridDim.x / nkb;
+#if TTTS_DKDV_PAIR
+  // round-3 candidate (off): a 2-per-CU kernel's block b + 256 lands on block b's CU (tools/exp/placement_probe.hip).  In
+  // weight order the CU of a 19-tile workgroup also gets the 11-tile one (30 / 26 / 22 / 18 tile iterations per CU); with the
+  // second CU-layer of key blocks reversed every CU gets 24, and the tail (lightest blocks) is handed out lightest first.
+  const int kblk = dkdv_pair_order((int)(blockIdx.x / nbh), nkb, max(1, 256 / nbh));
+#else
   const int kblk = (int)(blockIdx.x / nbh);  // earliest key blocks see the most queries: all of them come first
+#endif
   const int bh = blockIdx.x % nbh, h = bh % p.H, b = bh / p.H;
   const int k_base = kblk * 128 + wave * 32;
   const int key = k_base + (lane & 31);
