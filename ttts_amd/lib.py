@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(CSRC, "build")
 SO_PATH = os.path.join(HERE, "libttts_hip.so")
-SOURCES = ["lib.hip", "elementwise.hip", "gemm.hip", "gemm_persist.hip", "attn.hip", "vq.hip", "stft.hip", "conv.hip", "conv_mfma.hip", "conv_thin.hip", "conv_grouped.hip", "losses.hip", "vqvae_ops.hip", "attn_f32.hip", "peq.hip", "decode.hip", "diffusion_ops.hip"]
+SOURCES = ["lib.hip", "elementwise.hip", "gemm.hip", "gemm_persist.hip", "attn.hip", "attn_dh64.hip", "vq.hip", "stft.hip", "conv.hip", "conv_mfma.hip", "conv_thin.hip", "conv_grouped.hip", "losses.hip", "vqvae_ops.hip", "attn_f32.hip", "peq.hip", "decode.hip", "diffusion_ops.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-Wall", "-Wno-unused-variable"]
 
