@@ -18,6 +18,9 @@ SOURCES = ["lib.hip", "elementwise.hip", "gemm.hip", "gemm_persist.hip", "attn.h
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-Wall", "-Wno-unused-variable"]
 
+# per-file additions (reasons in the file headers)
+EXTRA_FLAGS = {"attn_dh64.hip": ["-fno-honor-nans", "-fno-slp-vectorize"]}
+
 TTTS_OK = 0
 EPI_STORE_BF16, EPI_GELU_BF16, EPI_RESID_ADD_F32, EPI_DGELU_BF16, EPI_STORE_F32 = range(5)
 
@@ -42,7 +45,7 @@ def build(force=False, verbose=False):
         s = os.path.join(CSRC, src)
         o = os.path.join(BUILD, src.replace(".hip", ".o"))
         if force or _needs_rebuild(o, [s] + headers):
-            jobs.append([HIPCC] + FLAGS + ["-c", s, "-o", o])
+            jobs.append([HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o])
 
     def run(cmd):
         r = subprocess.run(cmd, capture_output=True, text=True)
