@@ -397,6 +397,36 @@ def test_attention_fwd_bwd(ops, B, S, H, dh):
         assert e < 1.5e-2, (name, e)
 
 
+@pytest.mark.parametrize("B,S,H,dh,scale", [(4, 342, 8, 64, 16.0), (3, 64, 4, 64, 6.0), (1, 1156, 2, 64, 8.0)])
+def test_attention_large_scores(ops, B, S, H, dh, scale):
+    """Scores of several hundred log2 units (|q|, |k| scaled up): the running maximum must be shared by the two lane halves of
+    a query and raised before a block is exponentiated, or probabilities overflow (found in round 3: a half-wave exchange that
+    returned its own half)."""
+    D = H * dh
+    g = torch.Generator(device="cpu").manual_seed(S)
+    qkv = _bf(torch.randn(B, S, 3 * D, generator=g) * scale).to(dev())
+    o = torch.zeros(B, S, D, dtype=torch.bfloat16, device=dev())
+    lse = torch.zeros(B, H, S, device=dev())
+    q2 = qkv.view(B * S, 3 * D)
+    ops.attn_fwd(q2, q2[:, D:], q2[:, 2 * D:], o, lse, B, H, S, dh, (S * 3 * D, 3 * D), (S * D, D), dh ** -0.5)
+    leaf = qkv.float().requires_grad_(True)
+    ref_o, ref_lse = _attn_ref(leaf, B, S, H, dh)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+    assert rel_err(lse, ref_lse) < 1e-5
+    assert rel_err(o.float(), ref_o) < 6e-3
+    do = _bf(torch.randn(B, S, D, generator=g)).to(dev())
+    ref_o.backward(do.float())
+    dqkv = torch.zeros(B * S, 3 * D, dtype=torch.bfloat16, device=dev())
+    ws = torch.empty(B * H * S, device=dev())
+    ops.attn_bwd(q2, q2[:, D:], q2[:, 2 * D:], o, do, lse, dqkv, dqkv[:, D:], dqkv[:, 2 * D:], ws, B, H, S, dh,
+                 (S * 3 * D, 3 * D), (S * D, D), dh ** -0.5)
+    got = dqkv.view(B, S, 3 * D).float()
+    assert torch.isfinite(got).all()
+    for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+        e = rel_err(got[..., sl], leaf.grad[..., sl])
+        assert e < 1.5e-2, (name, e)
+
+
 def test_attention_dropout_matches_mask(ops):
     B, S, H, dh, p, seed = 1, 200, 2, 64, 0.1, 1234567
     D = H * dh

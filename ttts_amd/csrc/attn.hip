@@ -1,4 +1,5 @@
-// Causal self-attention forward / backward for gfx950 (flash-style: the S x S score matrix never reaches HBM).
+// Causal self-attention forward / backward for gfx950 (flash-style: the S x S score matrix never reaches HBM): host entry
+// points and the generic kernels (head_dim 32 / 128).  head_dim 64 -- the GPT train step -- is served by attn_dh64.hip.
 // Replaces GPT2Attention's core (transformers modeling_gpt2.py:53-72) as reached from ttts/gpt/model.py:422.
 //
 // MFMA: v_mfma_f32_32x32x16_bf16.  All three kernels keep the softmax statistics lane-local by choosing which
@@ -13,8 +14,6 @@
 // Work split: 4 waves x 32 rows (queries resp. keys) per workgroup, 64-row tiles of the other sequence axis
 // staged global -> registers -> LDS (double buffered, next tile's loads in flight under the MFMAs).
 // Causality: tiles strictly above the diagonal are never loaded; workgroups are launched heaviest-first.
-#include <stdlib.h>
-
 #include <algorithm>
 #include <type_traits>
 
@@ -29,8 +28,7 @@ int attn_bwd_dq_dh64(const AttnParams& p, hipStream_t s);
 // load / store a 64 x DH bf16 tile (rows row0.. of a [*, stride] matrix).  Rows beyond nrows: the load is unconditional from the
 // last valid row (a guarded load compiles to an exec-masked branch per 16-byte piece -- 8 branches per loop iteration).  With
 // ZERO = false the duplicate row is left in place -- K / V rows beyond the sequence only meet probabilities that are masked to
-// exactly 0.  ZERO = true selects zeros AT THE LOAD and is kept for reference only: hipcc sinks each load under the select's
-// condition and waits for it on the spot (see tile_store_zero, which the dK / dV kernel uses for its Q / dO tiles instead).
+// exactly 0.  ZERO = true selects zeros at the load (the dK / dV kernel's Q / dO tiles: their rows beyond the sequence must be 0).
 template <int DH, bool ZERO = true>
 __device__ __forceinline__ void tile_load(bf16x8 (&r)[AttnCfg<DH>::CPT], const bf16* base, int64_t stride, int row0,
                                           int nrows, int tid) {
@@ -55,19 +53,6 @@ __device__ __forceinline__ void tile_store(const bf16x8 (&r)[AttnCfg<DH>::CPT], 
   for (int i = 0; i < AttnCfg<DH>::CPT; ++i) {
     const int c = tid + i * 256, row = c / AttnCfg<DH>::CPR, dc = (c % AttnCfg<DH>::CPR) * 8;
     *reinterpret_cast<bf16x8*>(lds + row * STR + dc) = r[i];
-  }
-}
-
-// tile_store with rows >= nrows written as zeros.  Pair it with tile_load<DH, false>: zeroing at the LOAD (cond ? loaded : 0)
-// makes hipcc turn each 16-byte load into an exec-masked branch with its own s_waitcnt vmcnt(0) -- the loads of a prefetch then
-// run one full memory latency after another IN FRONT of the compute they were meant to hide under (seen in the ISA of the
-// dK / dV kernel: four serialised round trips per 64-query tile).
-template <int DH, int STR>
-__device__ __forceinline__ void tile_store_zero(const bf16x8 (&r)[AttnCfg<DH>::CPT], bf16* lds, int tid, int row0, int nrows) {
-#pragma unroll
-  for (int i = 0; i < AttnCfg<DH>::CPT; ++i) {
-    const int c = tid + i * 256, row = c / AttnCfg<DH>::CPR, dc = (c % AttnCfg<DH>::CPR) * 8;
-    *reinterpret_cast<bf16x8*>(lds + row * STR + dc) = (row0 + row < nrows) ? r[i] : zero8();
   }
 }
 
@@ -580,26 +565,7 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 3 : 2)) void attn_bwd_dq_kernel(At
 // -------------------------------------------------------------------------------------------------------
 // backward: dK, dV (S form, one key per lane; loops over query tiles from the diagonal down)
 // -------------------------------------------------------------------------------------------------------
-// LATE (round-3 candidate, compiled in but NOT selected: TTTS_DKDV_LATE below): Q / dO rows and the lse / delta statistics are
-// loaded unconditionally and zero-filled / scaled where they are STORED to LDS.  The default form does both at the load, which
-// hipcc turns into exec-masked loads each followed by s_waitcnt vmcnt(0): per 64-query tile four memory round trips run back
-// to back in front of the compute (ISA; the kernel is 16 % MFMA-busy with 30 % of its wave cycles waiting).  The LATE form's
-// ISA issues the five loads back to back and waits for them after the tile's MFMAs.  Same values reach LDS in both forms.
-#ifndef TTTS_DKDV_LATE
-#define TTTS_DKDV_LATE 0
-#endif
-#ifndef TTTS_DKDV_PAIR
-#define TTTS_DKDV_PAIR 0
-#endif
-// slot -> key block for TTTS_DKDV_PAIR: slots [0, r) keep their block, [r, min(2r, G)) take theirs in reverse, the rest in
-// reverse too (a bijection of [0, G): three disjoint ranges mapped onto themselves)
-__device__ __forceinline__ int dkdv_pair_order(int slot, int G, int r) {
-  const int hi = min(2 * r, G);
-  if (slot < r) return slot;
-  if (slot < hi) return r + (hi - 1 - slot);
-  return hi + (G - 1 - slot);
-}
-template <int DH, bool DROPOUT, bool LATE = (TTTS_DKDV_LATE != 0)>
+template <int DH, bool DROPOUT>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
   using C = AttnCfg<DH>;
   __shared__ __attribute__((aligned(16))) bf16 Qs[2][64 * C::KSTR];
@@ -611,14 +577,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
   const int hh = lane >> 5, g = lane >> 4, ip = lane & 15;
   const int nkb = (p.S + 127) / 128;
   const int nbh = gridDim.x / nkb;
-#if TTTS_DKDV_PAIR
-  // round-3 candidate (off): a 2-per-CU kernel's block b + 256 lands on block b's CU (tools/exp/placement_probe.hip).  In
-  // weight order the CU of a 19-tile workgroup also gets the 11-tile one (30 / 26 / 22 / 18 tile iterations per CU); with the
-  // second CU-layer of key blocks reversed every CU gets 24, and the tail (lightest blocks) is handed out lightest first.
-  const int kblk = dkdv_pair_order((int)(blockIdx.x / nbh), nkb, max(1, 256 / nbh));
-#else
   const int kblk = (int)(blockIdx.x / nbh);  // earliest key blocks see the most queries: all of them come first
-#endif
   const int bh = blockIdx.x % nbh, h = bh % p.H, b = bh / p.H;
   const int k_base = kblk * 128 + wave * 32;
   const int key = k_base + (lane & 31);
@@ -649,36 +608,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
   // the loaded value is not touched before STORE_STATS: any arithmetic on it up here would put an s_waitcnt vmcnt(0) -- for
   // the whole prefetch -- in front of the tile's compute
   float rstat = 0.f;
-  const float* statp = tid < 64 ? lsep : delp;
 #define LOAD_STATS(q0)                                                                   \
   {                                                                                      \
     const int qi = (q0) + (tid & 63);                                                    \
-    if (LATE) {                                                                          \
-      if (tid < 128) rstat = statp[min(qi, p.S - 1)];                                    \
-    } else {                                                                             \
-      if (tid < 128) rstat = qi < p.S ? (tid < 64 ? lsep[qi] * LOG2E : delp[qi]) : 0.f;  \
-    }                                                                                    \
+    if (tid < 128) rstat = qi < p.S ? (tid < 64 ? lsep[qi] * LOG2E : delp[qi]) : 0.f;    \
   }
 #define STORE_STATS(buf, q0_)                                                                                         \
   {                                                                                                                  \
-    const bool live_ = (q0_) + (tid & 63) < p.S;                                                                     \
-    if (tid < 64) Ls[buf][tid] = LATE ? (live_ ? rstat * LOG2E : 0.f) : rstat;                                       \
-    else if (tid < 128) Dl[buf][tid - 64] = LATE ? (live_ ? rstat : 0.f) : rstat;                                    \
+    if (tid < 64) Ls[buf][tid] = rstat;                                                                              \
+    else if (tid < 128) Dl[buf][tid - 64] = rstat;                                                                   \
     else if (DROPOUT && tid < 192) Am[buf][tid - 128] = drop_row_hash(id_bh + (uint32_t)((q0_) + tid - 128), p.seed_lo, shi); \
   }
   const uint32_t shi = DROPOUT ? seed_mix(p.seed_hi, p.ctr) : 0u;
   const uint32_t id_bh = (uint32_t)((b * p.H + h) * p.S), thr32 = p.thr << 16;
   const uint32_t colm = DROPOUT ? drop_col_mult(id_bh + (uint32_t)key, p.seed_lo, shi) : 0u;
-  tile_load<DH, !LATE>(rq, qp, p.ss, qt0 * 64, p.S, tid);
-  tile_load<DH, !LATE>(rd, dop, p.oss, qt0 * 64, p.S, tid);
+  tile_load<DH, true>(rq, qp, p.ss, qt0 * 64, p.S, tid);
+  tile_load<DH, true>(rd, dop, p.oss, qt0 * 64, p.S, tid);
   LOAD_STATS(qt0 * 64)
-  if (LATE) {
-    tile_store_zero<DH, C::KSTR>(rq, Qs[0], tid, qt0 * 64, p.S);
-    tile_store_zero<DH, C::KSTR>(rd, Ds[0], tid, qt0 * 64, p.S);
-  } else {
-    tile_store<DH, C::KSTR>(rq, Qs[0], tid);
-    tile_store<DH, C::KSTR>(rd, Ds[0], tid);
-  }
+  tile_store<DH, C::KSTR>(rq, Qs[0], tid);
+  tile_store<DH, C::KSTR>(rd, Ds[0], tid);
   STORE_STATS(0, qt0 * 64)
   __syncthreads();
   const int q_nat = (lane & 31) * C::KSTR + hh * 8;
@@ -686,8 +634,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
   for (int qt = qt0; qt < nqt; ++qt) {
     const int buf = (qt - qt0) & 1, q0 = qt * 64;
     if (qt + 1 < nqt) {
-      tile_load<DH, !LATE>(rq, qp, p.ss, q0 + 64, p.S, tid);
-      tile_load<DH, !LATE>(rd, dop, p.oss, q0 + 64, p.S, tid);
+      tile_load<DH, true>(rq, qp, p.ss, q0 + 64, p.S, tid);
+      tile_load<DH, true>(rd, dop, p.oss, q0 + 64, p.S, tid);
       LOAD_STATS(q0 + 64)
     }
     if (q0 + 63 >= k_base) {  // wave-uniform: some query of this tile can see some key of this wave
@@ -761,13 +709,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
       }
     }
     if (qt + 1 < nqt) {
-      if (LATE) {
-        tile_store_zero<DH, C::KSTR>(rq, Qs[buf ^ 1], tid, q0 + 64, p.S);
-        tile_store_zero<DH, C::KSTR>(rd, Ds[buf ^ 1], tid, q0 + 64, p.S);
-      } else {
-        tile_store<DH, C::KSTR>(rq, Qs[buf ^ 1], tid);
-        tile_store<DH, C::KSTR>(rd, Ds[buf ^ 1], tid);
-      }
+      tile_store<DH, C::KSTR>(rq, Qs[buf ^ 1], tid);
+      tile_store<DH, C::KSTR>(rd, Ds[buf ^ 1], tid);
       STORE_STATS(buf ^ 1, q0 + 64)
     }
     __syncthreads();
@@ -839,7 +782,7 @@ extern "C" int ttts_attn_causal_fwd_bf16(const void* q, const void* k, const voi
   p.q = (const bf16*)q; p.k = (const bf16*)k; p.v = (const bf16*)v; p.out = (bf16*)o; p.lse = lse;
   const int grid = ((S + 127) / 128) * H * B;
   hipStream_t s = as_stream(stream);
-  if (head_dim == 64 && !getenv("TTTS_ATTN_OLD")) return attn_fwd_dh64(p, s);
+  if (head_dim == 64) return attn_fwd_dh64(p, s);   // attn_dh64.hip; the kernels below serve head_dim 32 / 128
   // work split: with dropout the 64-query x 128-key kernel is used (round 1, pair-hash mask: 36.1 vs 43.8 us at the BASELINE shape;
   // round 2, product-scheme mask: 35.5 vs 36.0 us -- the cheaper mask closed the gap); without dropout the 128-query kernel
   // (30.3 vs 33.8 us).
@@ -900,16 +843,11 @@ extern "C" int ttts_attn_causal_bwd_bf16(const void* q, const void* k, const voi
     attn_bwd_dkdv_kernel<DH, false><<<grid, 256, 0, s>>>(p);                \
     attn_bwd_dq_kernel<DH, false><<<grid, 256, 0, s>>>(p);                  \
   }
-  if (head_dim == 64) {
+  if (head_dim == 64) {                               // attn_dh64.hip
     attn_delta_kernel<64><<<dgrid, 256, 0, s>>>(p);
-    int rc2 = TTTS_OK;
-    if (getenv("TTTS_ATTN_OLD_DKDV")) {
-      if (p.thr) attn_bwd_dkdv_kernel<64, true><<<grid, 256, 0, s>>>(p); else attn_bwd_dkdv_kernel<64, false><<<grid, 256, 0, s>>>(p);
-    } else if ((rc2 = attn_bwd_dkdv_dh64(p, s)) != TTTS_OK) return rc2;
-    if (getenv("TTTS_ATTN_OLD_DQ")) {
-      if (p.thr) attn_bwd_dq_kernel<64, true><<<grid, 256, 0, s>>>(p); else attn_bwd_dq_kernel<64, false><<<grid, 256, 0, s>>>(p);
-    } else if ((rc2 = attn_bwd_dq_dh64(p, s)) != TTTS_OK) return rc2;
-    return check_launch("attn_bwd");
+    int rc2 = attn_bwd_dkdv_dh64(p, s);
+    if (rc2 == TTTS_OK) rc2 = attn_bwd_dq_dh64(p, s);
+    return rc2;
   }
   if (head_dim == 32) { BWD(32) } else { BWD(128) }
 #undef BWD

@@ -91,7 +91,8 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
 __device__ __forceinline__ float xhalf_max(float v) {
   const uint32_t u = __builtin_bit_cast(uint32_t, v);
   const u32x2_t r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+  const uint32_t lo = r[0], hi = r[1];   // (bit_cast applied to r[1] directly reads element 0: a hipcc quirk)
+  return fmaxf(__builtin_bit_cast(float, lo), __builtin_bit_cast(float, hi));
 }
 // This file is built with -fno-honor-nans (no v_max canonicalisation in front of fmaxf on MFMA outputs: nothing here produces
 // or consumes a NaN -- masked scores are the finite NEG_BIG) and -fno-slp-vectorize (hipcc would pack adjacent f32 adds /
