@@ -34,7 +34,7 @@ extern "C" {
 #define TTTS_EHIP (-2)         /* a HIP runtime call or kernel launch failed */
 #define TTTS_EUNSUPPORTED (-3) /* valid request this build has no kernel for */
 
-#define TTTS_ABI_VERSION 3
+#define TTTS_ABI_VERSION 4
 
 /* ---- library ------------------------------------------------------------------------------------ */
 int ttts_abi_version(void);
@@ -66,28 +66,11 @@ int ttts_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, vo
                       const float* bias, void* aux, int32_t M, int32_t N, int32_t K, int32_t epilogue,
                       void* stream);
 /* Same, plus: resid_in (RESID_ADD_F32 only): C = resid_in + dropout(bf16(acc + bias)) out of place (NULL: C += ...);
- * dropout_p/seed: residual dropout (GPT-2 resid_pdrop, modeling_gpt2.py:223,241) on element index m*N + n.
- * workspace: NULL, or ttts_gemm_nt_workspace_bytes() of caller-owned device memory, ZEROED ONCE before its first use
- *   (the kernel leaves it zeroed-where-it-matters): selects the persistent, wave-specialised kernel (one workgroup per CU
- *   walking an evenly split stream of (tile, k-step) units; a tile cut by a split boundary is completed through fp32
- *   partial slots in the workspace).  One workspace serves any sequence of calls on ONE stream; concurrent streams need
- *   their own.  Results are identical to the workspace-less kernels up to the fp32 summation order of split tiles. */
-int64_t ttts_gemm_nt_workspace_bytes(void);
+ * dropout_p/seed: residual dropout (GPT-2 resid_pdrop, modeling_gpt2.py:223,241) on element index m*N + n. */
 int ttts_gemm_nt_bf16_ex(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                          const float* bias, void* aux, int32_t M, int32_t N, int32_t K, int32_t epilogue,
                          const float* resid_in, float dropout_p, uint64_t seed, const uint32_t* dropout_counter,
-                         void* workspace, void* stream);
-/* OPT-IN variant of ttts_gemm_nt_bf16_ex for launches whose tile count is between 1 and 1.5 times the CU count (the N = 512
- * GEMMs of the GPT step: 292 tiles of 128x128 on 256 CUs): `cus` tiles run whole, one per CU, and every surplus tile is cut
- * along K into pieces that run in the CUs' second workgroup slots and leave fp32 slabs; a second small launch sums a tile's
- * slabs in a fixed order and applies the epilogue (same arithmetic, deterministic).  ttts_gemm_nt_split_plan returns the slab
- * bytes (0 = the split does not apply; the call then runs the ordinary kernel) and fills plan = {whole tiles, surplus tiles,
- * pieces per surplus tile}.  K % 64 == 0.  STATUS: written at the end of round 2, not yet measured; nothing calls it by default. */
-int64_t ttts_gemm_nt_split_plan(int32_t M, int32_t N, int32_t K, int32_t cus, int32_t plan[3]);
-int ttts_gemm_nt_split_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
-                            const float* bias, void* aux, int32_t M, int32_t N, int32_t K, int32_t epilogue,
-                            const float* resid_in, float dropout_p, uint64_t seed, const uint32_t* dropout_counter,
-                            int32_t cus, float* slabs, void* stream);
+                         void* stream);
 /* C[Mo,No] += At[Kr,Mo]^T . Bt[Kr,No]: the weight-gradient GEMM.  The reduction is split over workgroups into fp32
  * slabs in `workspace` (ttts_gemm_tn_workspace_bytes; may be 0 -> NULL) that a second kernel sums in a fixed order
  * (deterministic; no atomics); both operands are row-major with the REDUCTION dimension as rows ("TN").

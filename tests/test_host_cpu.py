@@ -32,7 +32,7 @@ def test_header_symbols_exported_and_bound(lib):
     for name in declared:
         assert hasattr(handle, name), "header declares %s but libttts_hip.so does not export it" % name
     assert declared == set(lib.SIGNATURES), declared ^ set(lib.SIGNATURES)
-    assert lib.get().ttts_abi_version() == lib.ABI_VERSION == 3
+    assert lib.get().ttts_abi_version() == lib.ABI_VERSION == 4
 
 
 def test_argument_validation_without_gpu(lib):
@@ -64,12 +64,6 @@ def test_argument_validation_without_gpu(lib):
     arr[2].Kr = 650
     assert l.ttts_tn_desc_prepare(arr, 3, ctypes.byref(total)) == -1 and b"multiple of 64" in l.ttts_last_error()
     assert l.ttts_gemm_tn_grouped_bf16_accum_f32(None, 3, 128, None) == -1 and b"null descriptor" in l.ttts_last_error()
-    # opt-in surplus-tile split of the NT GEMM: planner only (no launch)
-    plan = (ctypes.c_int32 * 3)()
-    assert l.ttts_gemm_nt_split_plan(9248, 512, 2048, 256, plan) == 36 * 7 * 128 * 128 * 4 and list(plan) == [256, 36, 7]
-    assert l.ttts_gemm_nt_split_plan(9248, 512, 512, 256, plan) == 36 * 4 * 128 * 128 * 4 and list(plan) == [256, 36, 4]
-    assert l.ttts_gemm_nt_split_plan(9248, 1536, 512, 256, plan) == 0 and list(plan) == [876, 0, 0]   # 3.4 tiles per CU: no
-    assert l.ttts_gemm_nt_split_plan(1024, 512, 512, 256, plan) == 0 and list(plan) == [32, 0, 0]     # fewer tiles than CUs
     tw = np.empty(2048, np.float32)
     assert l.ttts_stft_twiddle_host(tw.ctypes.data_as(ctypes.c_void_p), 2048) == 0
     np.testing.assert_allclose(tw[2 * 512:2 * 512 + 2], [0.0, -1.0], atol=1e-7)

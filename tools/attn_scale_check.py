@@ -1,6 +1,7 @@
-"""Debug helper: forward / backward attention vs the fp32 torch reference at several shapes and input scales."""
+"""Forward / backward attention vs the fp32 torch reference at several shapes and input scales (scores of hundreds of log2 units).
+   python tools/attn_scale_check.py      (GPU box)"""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ttts_amd import ops
 dev = torch.device("cuda:0")
 

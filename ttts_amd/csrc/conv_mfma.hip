@@ -1305,15 +1305,9 @@ __device__ __forceinline__ void fused_taps_compute(const bf16* ah, const bf16* a
 
 // CH = positions per chunk (64 or 128: the loop is bound by the load -> split -> LDS -> barrier round trip per chunk, so long
 // rows take 128)
-// LATE (round-3 candidate, compiled in but NOT selected: TTTS_WGRAD_LATE): the bounds masks of the prefetched dy / x values
-// are applied where the registers are written to LDS, not where they are loaded.  In the default form every `cond ? loaded : 0`
-// sits right behind its load, so the s_waitcnt for a chunk's 16-34 loads stands in FRONT of the matrix-core work of the
-// previous chunk (ISA: vmcnt(15) .. vmcnt(0) directly after the loads; the CH = 64 variants even wait after every pair) --
-// the "prefetch" is synchronous.
-#ifndef TTTS_WGRAD_LATE
-#define TTTS_WGRAD_LATE 0
-#endif
-template <int K, int DIL, int CH, bool LATE = (TTTS_WGRAD_LATE != 0)>
+// (Round 3 measured a variant that masks the prefetched values at the LDS store instead of at the load: 168.7 vs 165.9 ms per
+// VQ-VAE-GAN step -- no gain, removed.)
+template <int K, int DIL, int CH>
 __global__ __launch_bounds__(256, 2) void conv1d_wgrad_fused_taps_kernel(WgradMfmaParams p) {
   constexpr int PITCH = CH + 8;
   constexpr int WIN = CH + (K - 1) * DIL;                 // staged window positions
@@ -1343,8 +1337,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad_fused_taps_kernel(WgradMf
       const float* src = p.dy + ((int64_t)b * p.Cout + min(co0 + row, p.Cout - 1)) * p.Lout;
       const bool rok = co0 + row < p.Cout;
       const float v0 = src[min(l, p.Lout - 1)], v1 = src[min(l + 1, p.Lout - 1)];
-      ra[i][0] = (LATE || (rok && l < p.Lout)) ? v0 : 0.f;
-      ra[i][1] = (LATE || (rok && l + 1 < p.Lout)) ? v1 : 0.f;
+      ra[i][0] = (rok && l < p.Lout) ? v0 : 0.f;
+      ra[i][1] = (rok && l + 1 < p.Lout) ? v1 : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -1352,32 +1346,15 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad_fused_taps_kernel(WgradMf
       const float* src = p.x + ((int64_t)b * p.Cin + min(ci0 + min(row, 31), p.Cin - 1)) * p.Lin;
       const bool rok = row < 32 && ci0 + row < p.Cin;
       const float v0 = src[min(max(g, 0), p.Lin - 1)], v1 = src[min(max(g + 1, 0), p.Lin - 1)];
-      rb[i][0] = (LATE || (rok && g >= 0 && g < p.Lin)) ? v0 : 0.f;
-      rb[i][1] = (LATE || (rok && g + 1 >= 0 && g + 1 < p.Lin)) ? v1 : 0.f;
+      rb[i][0] = (rok && g >= 0 && g < p.Lin) ? v0 : 0.f;
+      rb[i][1] = (rok && g + 1 >= 0 && g + 1 < p.Lin) ? v1 : 0.f;
     }
   };
   auto split2 = [](float v0, float v1, bf16x2& h, bf16x2& l) {
     h[0] = (bf16)v0; h[1] = (bf16)v1;
     l[0] = (bf16)(v0 - (float)h[0]); l[1] = (bf16)(v1 - (float)h[1]);
   };
-  auto store_lds = [&](int chunk) {     // chunk: the one whose values load_regs left in ra / rb (LATE masks them here)
-    const int l0 = (chunk % nlc) * CH;
-    if (LATE) {
-#pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        const int q = tid + 256 * i, row = q / (CH / 2), l = l0 + (q % (CH / 2)) * 2;
-        const bool rok = co0 + row < p.Cout;
-        ra[i][0] = (rok && l < p.Lout) ? ra[i][0] : 0.f;
-        ra[i][1] = (rok && l + 1 < p.Lout) ? ra[i][1] : 0.f;
-      }
-#pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const int q = tid + 256 * i, row = q / WPR, g = l0 - p.pad + (q - row * WPR) * 2;
-        const bool rok = row < 32 && ci0 + row < p.Cin;
-        rb[i][0] = (rok && g >= 0 && g < p.Lin) ? rb[i][0] : 0.f;
-        rb[i][1] = (rok && g + 1 >= 0 && g + 1 < p.Lin) ? rb[i][1] : 0.f;
-      }
-    }
+  auto store_lds = [&](int chunk) {     // chunk: the one whose values load_regs left in ra / rb
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int q = tid + 256 * i, row = q / (CH / 2), pj = q % (CH / 2);

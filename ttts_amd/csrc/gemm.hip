@@ -214,8 +214,9 @@ __device__ __forceinline__ int xcd_tile(int bid, int nblk) {
 //    is not the limit, co-resident workgroups already cover the load latency;
 //  * ablation of the 2-stage loop: fill only (no ds_read / MFMA) + epilogue 22.7 us, MFMA only (no DMA) + epilogue 21.6 us,
 //    both 28.9 us, epilogue ~8 us: LDS fill (230 MB at ~15 TB/s) and compute (1.07 PF/s with its LDS reads) each need
-//    ~14 us and overlap only half.  The next step is fewer fill bytes per flop (256-row tiles) and a store phase that does
-//    not occupy the issuing waves -- see gemm_persist.hip for what a first attempt at the latter taught.
+//    ~14 us and overlap only half.  Two follow-ups were built, measured and removed: a persistent 8-wave kernel with store
+//    waves (1.6x slower: its tile hand-off serialised on LDS slots) and a K-split of the surplus tiles of the 292-tile
+//    launches (round 3: GPT step 4.01 vs 3.61 ms -- the fix-up launch and the fp32 slabs cost more than the tail they fill).
 template <int EPI, int BKT, int NJ = 2>
 __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_nt_glds_kernel(GemmNtParams p) {
   constexpr int BNT = 64 * NJ;           // tile columns: 128, or 64 for the narrow-N GEMMs
@@ -298,230 +299,6 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_nt_glds_kernel(
     __syncthreads();  // next tile landed (vmcnt(0)) and everyone is done reading this one
   }
   tile_epilogue<EPI, NJ>(p.e, acc, reinterpret_cast<float*>(smem), m0, n0, tid);
-}
-
-// ---- NT, surplus tiles split along K (OPT-IN, round 3 candidate: not measured yet) ----------------------------------
-// Why: the N = 512 GEMMs of the GPT step have 292 tiles on 256 CUs.  36 CUs run two tiles (two co-resident workgroups at
-// ~1.2 us per k-tile each) while 220 CUs finish one and idle: the launch lasts 1.75 x its balanced time.  Here the first
-// `full` tiles (= the CU count: one per CU, dispatched first) run whole; every surplus tile is cut along K into `pieces`
-// workgroups that land in the CUs' second slots, finish early and leave fp32 slabs; a small second launch sums a tile's
-// slabs in a fixed order and applies the epilogue.  Deterministic; the epilogue arithmetic is the one of tile_epilogue.
-// Placement premise, measured (tools/exp/placement_probe.hip): blocks 0 .. 255 of a 2-per-CU kernel land one per CU and
-// block b + 256 joins block b's CU -- so whole tiles first, pieces behind them, pairs one whole tile with one piece per CU.
-struct GemmNtSplitParams {
-  GemmNtParams g;
-  float* slabs;       // [surplus][pieces][128][128] fp32
-  int full, pieces;   // tiles 0 .. full-1 whole; tile full + s is cut into `pieces` k-ranges
-};
-
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt_split_kernel(GemmNtSplitParams sp) {
-  constexpr int BKT = 64, CPR = BKT / 8, RPI = 64 / CPR, IPW = 128 / RPI / 4, TILE = BM * BKT;
-  __shared__ __attribute__((aligned(16))) bf16 smem[4 * TILE];  // [buf][A|B][128*64]; reused as the epilogue stage
-  const GemmNtParams& p = sp.g;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int tiles_n = (p.e.N + BN - 1) / BN;
-  const int nk = p.K / BKT;
-  // block -> (tile, k range).  Whole tiles keep the XCD-contiguous order among themselves.
-  int tile, kt0 = 0, kt1 = nk, piece = -1;
-  if ((int)blockIdx.x < sp.full) {
-    tile = xcd_tile(blockIdx.x, sp.full);
-  } else {
-    const int q = (int)blockIdx.x - sp.full;
-    tile = sp.full + q / sp.pieces;
-    piece = q % sp.pieces;
-    kt0 = (int)((int64_t)piece * nk / sp.pieces);
-    kt1 = (int)((int64_t)(piece + 1) * nk / sp.pieces);
-  }
-  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-  auto fsw = [](int r) { return (r >> 1) & 7; };
-
-  const bf16* ga[IPW];
-  const bf16* gb[IPW];
-#pragma unroll
-  for (int i = 0; i < IPW; ++i) {
-    const int r = wave * (IPW * RPI) + i * RPI + lane / CPR;
-    const int chunk = (lane % CPR) ^ fsw(r);
-    ga[i] = p.A + (int64_t)min(m0 + r, p.e.M - 1) * p.lda + chunk * 8;
-    gb[i] = p.B + (int64_t)min(n0 + r, p.e.N - 1) * p.ldb + chunk * 8;
-  }
-  auto issue = [&](int kt, int buf) {
-    bf16* as = smem + (buf * 2 + 0) * TILE + wave * (IPW * RPI) * BKT;
-    bf16* bs = smem + (buf * 2 + 1) * TILE + wave * (IPW * RPI) * BKT;
-#pragma unroll
-    for (int i = 0; i < IPW; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[i] + kt * BKT),
-                                       (__attribute__((address_space(3))) void*)(as + i * RPI * BKT), 16, 0, 0);
-#pragma unroll
-    for (int i = 0; i < IPW; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb[i] + kt * BKT),
-                                       (__attribute__((address_space(3))) void*)(bs + i * RPI * BKT), 16, 0, 0);
-  };
-
-  f32x16 acc[2][2];
-  ZERO_ACC(acc)
-  if (kt1 > kt0) issue(kt0, 0);
-  __syncthreads();
-  const int hh = lane >> 5;
-  int aoff[2], boff[2], sw[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int ra = wm * 64 + i * 32 + (lane & 31), rb = wn * 64 + i * 32 + (lane & 31);
-    aoff[i] = ra * BKT;
-    boff[i] = rb * BKT;
-    sw[0][i] = fsw(ra);
-    sw[1][i] = fsw(rb);
-  }
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const int buf = (kt - kt0) & 1;
-    if (kt + 1 < kt1) issue(kt + 1, buf ^ 1);
-    const bf16* as = smem + (buf * 2 + 0) * TILE;
-    const bf16* bs = smem + (buf * 2 + 1) * TILE;
-#pragma unroll
-    for (int ks = 0; ks < BKT / 16; ++ks) {
-      bf16x8 af[2], bfr[2];
-      const int lc = ks * 2 + hh;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        af[i] = *reinterpret_cast<const bf16x8*>(as + aoff[i] + ((lc ^ sw[0][i]) << 3));
-        bfr[i] = *reinterpret_cast<const bf16x8*>(bs + boff[i] + ((lc ^ sw[1][i]) << 3));
-      }
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) acc[j][i] = mfma32(bfr[j], af[i], acc[j][i]);
-    }
-    __syncthreads();
-  }
-  if (piece < 0) {
-    tile_epilogue<EPI>(p.e, acc, reinterpret_cast<float*>(smem), m0, n0, tid);
-  } else {  // a piece: its fp32 accumulators, all 128 x 128 of them, as slab [tile - full][piece]
-    GemmEpi e{};
-    e.M = BM;
-    e.N = BN;
-    e.ldc = BN;
-    e.C = sp.slabs + ((int64_t)(tile - sp.full) * sp.pieces + piece) * (BM * BN);
-    tile_epilogue<EPI_SLAB_F32>(e, acc, reinterpret_cast<float*>(smem), 0, 0, tid);
-  }
-}
-
-// second launch: one workgroup per surplus tile; thread = (row, 8 columns) like tile_epilogue's read-back, 16 rows per pass.
-// v = sum of the tile's slabs in piece order, then the SAME epilogue arithmetic as tile_epilogue (kept in step with it).
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_split_fixup_kernel(GemmNtSplitParams sp) {
-  const GemmEpi& e = sp.g.e;
-  const int tid = threadIdx.x;
-  const int tiles_n = (e.N + BN - 1) / BN;
-  const int tile = sp.full + (int)blockIdx.x;
-  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-  const float* slab0 = sp.slabs + (int64_t)blockIdx.x * sp.pieces * (BM * BN);
-  const bool bf16_out = (EPI == TTTS_EPI_STORE_BF16 || EPI == TTTS_EPI_GELU_BF16 || EPI == TTTS_EPI_DGELU_BF16);
-  const bool vec_ok = bf16_out ? ((e.ldc & 7) == 0) : ((e.ldc & 3) == 0);
-  const int cl = (tid & 15) * 8;           // this thread's 8 columns within the tile
-  float bias8[8];
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    const int n = n0 + cl + t;
-    const float b = (e.bias && n < e.N) ? e.bias[n] : 0.f;
-    bias8[t] = (EPI == TTTS_EPI_STORE_F32) ? b : (float)(bf16)b;
-  }
-  for (int pass = 0; pass < BM / 16; ++pass) {
-    const int row_l = pass * 16 + (tid >> 4);
-    const int m = m0 + row_l, n = n0 + cl;
-    if (m >= e.M || n >= e.N) continue;
-    float v[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) v[t] = 0.f;
-    for (int q = 0; q < sp.pieces; ++q) {
-      const float* sl = slab0 + (int64_t)q * (BM * BN) + row_l * BN + cl;
-      const float4 a = *reinterpret_cast<const float4*>(sl), b = *reinterpret_cast<const float4*>(sl + 4);
-      v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
-    }
-#pragma unroll
-    for (int t = 0; t < 8; ++t) v[t] += bias8[t];
-    const int64_t off = (int64_t)m * e.ldc + n;
-    const bool full = vec_ok && (n + 8 <= e.N);
-    if (EPI == TTTS_EPI_STORE_BF16) {
-      bf16* c = reinterpret_cast<bf16*>(e.C) + off;
-      if (full) {
-        bf16x8 o;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) o[t] = (bf16)v[t];
-        *reinterpret_cast<bf16x8*>(c) = o;
-      } else {
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-          if (n + t < e.N) c[t] = (bf16)v[t];
-      }
-    } else if (EPI == TTTS_EPI_GELU_BF16) {
-      bf16* c = reinterpret_cast<bf16*>(e.C) + off;
-      bf16* ax = e.aux + off;
-      bf16x8 pre, act;
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        pre[t] = (bf16)v[t];
-        act[t] = (bf16)gelu_new_f((float)pre[t]);
-      }
-      if (full) {
-        *reinterpret_cast<bf16x8*>(ax) = pre;
-        *reinterpret_cast<bf16x8*>(c) = act;
-      } else {
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-          if (n + t < e.N) { ax[t] = pre[t]; c[t] = act[t]; }
-      }
-    } else if (EPI == TTTS_EPI_RESID_ADD_F32) {
-      float* c = reinterpret_cast<float*>(e.C) + off;
-      const float* rin = e.resid_in ? e.resid_in + off : c;
-      float y[8];
-#pragma unroll
-      for (int t = 0; t < 8; ++t) y[t] = (float)(bf16)v[t];
-      if (e.thr) {
-        const uint32_t lin = (uint32_t)(((int64_t)m * e.N + n) >> 1);
-        const uint32_t shi = seed_mix(e.seed_hi, e.ctr);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const uint32_t r = hash32(lin + t, e.seed_lo, shi);
-          y[2 * t] = (r & 0xFFFFu) >= e.thr ? y[2 * t] * e.inv_keep : 0.f;
-          y[2 * t + 1] = (r >> 16) >= e.thr ? y[2 * t + 1] * e.inv_keep : 0.f;
-        }
-      }
-      if (full) {
-        const float4 r0 = *reinterpret_cast<const float4*>(rin), r1 = *reinterpret_cast<const float4*>(rin + 4);
-        *reinterpret_cast<float4*>(c) = make_float4(r0.x + y[0], r0.y + y[1], r0.z + y[2], r0.w + y[3]);
-        *reinterpret_cast<float4*>(c + 4) = make_float4(r1.x + y[4], r1.y + y[5], r1.z + y[6], r1.w + y[7]);
-      } else {
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-          if (n + t < e.N) c[t] = rin[t] + y[t];
-      }
-    } else if (EPI == TTTS_EPI_DGELU_BF16) {
-      bf16* c = reinterpret_cast<bf16*>(e.C) + off;
-      const bf16* ax = e.aux + off;
-      if (full) {
-        const bf16x8 pre = *reinterpret_cast<const bf16x8*>(ax);
-        bf16x8 o;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) o[t] = (bf16)(v[t] * gelu_new_grad_f((float)pre[t]));
-        *reinterpret_cast<bf16x8*>(c) = o;
-      } else {
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-          if (n + t < e.N) c[t] = (bf16)(v[t] * gelu_new_grad_f((float)ax[t]));
-      }
-    } else {  // STORE_F32
-      float* c = reinterpret_cast<float*>(e.C) + off;
-      if (full) {
-        *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
-      } else {
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-          if (n + t < e.N) c[t] = v[t];
-      }
-    }
-  }
 }
 
 // ---- NT, register-staged main loop (any K % 8 == 0; zero-fills ragged K) ---------------------------------------------
@@ -906,16 +683,10 @@ static void launch_nt(const GemmNtParams& p, int grid, hipStream_t s) {
   else gemm_nt_kernel<EPI><<<grid, 256, 0, s>>>(p);
 }
 
-namespace ttts {
-int gemm_nt_persist_try(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias,
-                        void* aux, int M, int N, int K, int epilogue, const float* resid_in, uint32_t thr, float inv_keep,
-                        uint64_t seed, const uint32_t* dropout_counter, void* workspace, hipStream_t s, bool* handled);
-}
-
 extern "C" int ttts_gemm_nt_bf16_ex(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                                     const float* bias, void* aux, int32_t M, int32_t N, int32_t K, int32_t epilogue,
                                     const float* resid_in, float dropout_p, uint64_t seed, const uint32_t* dropout_counter,
-                                    void* workspace, void* stream) {
+                                    void* stream) {
   TTTS_REQUIRE(A && B && C, "gemm_nt: null pointer");
   TTTS_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_nt: bad shape M=%d N=%d K=%d", M, N, K);
   TTTS_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K, "gemm_nt: K, lda, ldb must be multiples of 8 (K=%d lda=%lld ldb=%lld)", K, (long long)lda, (long long)ldb);
@@ -931,13 +702,6 @@ extern "C" int ttts_gemm_nt_bf16_ex(const void* A, int64_t lda, const void* B, i
   if (p.e.thr) p.e.inv_keep = 65536.0f / (65536.0f - (float)p.e.thr);
   const int grid = (int)(cdiv(M, BM) * cdiv(N, BN));
   hipStream_t s = as_stream(stream);
-  TTTS_REQUIRE(!workspace || aligned16(workspace), "gemm_nt: workspace must be 16-byte aligned");
-  {  // persistent wave-specialised kernel (gemm_persist.hip) when the caller provides its workspace
-    bool handled = false;
-    const int rc = gemm_nt_persist_try(A, lda, B, ldb, C, ldc, bias, aux, M, N, K, epilogue, resid_in, p.e.thr, p.e.inv_keep, seed,
-                                       dropout_counter, workspace, s, &handled);
-    if (rc || handled) return rc;
-  }
   switch (epilogue) {
     case TTTS_EPI_STORE_BF16: launch_nt<TTTS_EPI_STORE_BF16>(p, grid, s); break;
     case TTTS_EPI_GELU_BF16: launch_nt<TTTS_EPI_GELU_BF16>(p, grid, s); break;
@@ -949,69 +713,10 @@ extern "C" int ttts_gemm_nt_bf16_ex(const void* A, int64_t lda, const void* B, i
   return check_launch("gemm_nt");
 }
 
-// Planner of the surplus-tile split: plan[0] = tiles run whole (= cus), plan[1] = surplus tiles, plan[2] = pieces per surplus
-// tile; returns the fp32 slab bytes the launch needs, 0 when the split does not apply (then plan is {tiles, 0, 0}).
-extern "C" int64_t ttts_gemm_nt_split_plan(int32_t M, int32_t N, int32_t K, int32_t cus, int32_t plan[3]) {
-  if (!plan) return 0;
-  const int64_t tiles = (M > 0 && N > 0) ? cdiv(M, BM) * cdiv(N, BN) : 0;
-  plan[0] = (int32_t)tiles; plan[1] = 0; plan[2] = 0;
-  if (cus <= 0 || K <= 0 || K % 64 != 0) return 0;
-  const int nk = K / 64;
-  // applies when a second, mostly empty round would follow one workgroup per CU: cus < tiles <= 1.5 cus, K long enough to cut
-  if (tiles <= cus || tiles * 2 > (int64_t)cus * 3 || nk < 4) return 0;
-  const int surplus = (int)(tiles - cus);
-  int pieces = (cus + surplus / 2) / surplus;          // ~ one piece per CU
-  pieces = std::max(2, std::min(pieces, std::min(nk / 2, 8)));
-  plan[0] = cus; plan[1] = surplus; plan[2] = pieces;
-  return (int64_t)surplus * pieces * BM * BN * (int64_t)sizeof(float);
-}
-
-extern "C" int ttts_gemm_nt_split_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
-                                       const float* bias, void* aux, int32_t M, int32_t N, int32_t K, int32_t epilogue,
-                                       const float* resid_in, float dropout_p, uint64_t seed, const uint32_t* dropout_counter,
-                                       int32_t cus, float* slabs, void* stream) {
-  int32_t plan[3];
-  const int64_t need = ttts_gemm_nt_split_plan(M, N, K, cus, plan);
-  if (need == 0)   // not a shape the split helps: the one-tile-per-workgroup kernel
-    return ttts_gemm_nt_bf16_ex(A, lda, B, ldb, C, ldc, bias, aux, M, N, K, epilogue, resid_in, dropout_p, seed, dropout_counter,
-                                nullptr, stream);
-  TTTS_REQUIRE(A && B && C && slabs, "gemm_nt_split: null pointer");
-  TTTS_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K, "gemm_nt_split: lda, ldb must be multiples of 8 and >= K");
-  TTTS_REQUIRE(ldc % 4 == 0 && ldc >= ((N + 3) / 4) * 4, "gemm_nt_split: ldc must be a multiple of 4 and >= roundup4(N)");
-  TTTS_REQUIRE(aligned16(A) && aligned16(B) && aligned16(C) && aligned16(slabs), "gemm_nt_split: 16-byte aligned bases required");
-  TTTS_REQUIRE((epilogue != TTTS_EPI_GELU_BF16 && epilogue != TTTS_EPI_DGELU_BF16) || (aux && aligned16(aux)), "gemm_nt_split: epilogue needs a 16-byte aligned aux");
-  TTTS_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "gemm_nt_split: dropout_p out of range");
-  TTTS_REQUIRE(dropout_p == 0.f || (epilogue == TTTS_EPI_RESID_ADD_F32 && N % 8 == 0), "gemm_nt_split: dropout only with RESID_ADD and N %% 8 == 0");
-  TTTS_REQUIRE(!resid_in || aligned16(resid_in), "gemm_nt_split: resid_in must be 16-byte aligned");
-  GemmNtSplitParams sp{};
-  sp.g = GemmNtParams{(const bf16*)A, lda, (const bf16*)B, ldb, K,
-                      GemmEpi{C, ldc, bias, (bf16*)aux, resid_in, M, N, dropout_threshold(dropout_p), 1.0f, (uint32_t)seed,
-                              (uint32_t)(seed >> 32), dropout_counter}};
-  if (sp.g.e.thr) sp.g.e.inv_keep = 65536.0f / (65536.0f - (float)sp.g.e.thr);
-  sp.slabs = slabs;
-  sp.full = plan[0];
-  sp.pieces = plan[2];
-  const int grid = plan[0] + plan[1] * plan[2];
-  hipStream_t s = as_stream(stream);
-#define SPLIT_LAUNCH(E)                                                  \
-  gemm_nt_split_kernel<E><<<grid, 256, 0, s>>>(sp);                      \
-  gemm_nt_split_fixup_kernel<E><<<plan[1], 256, 0, s>>>(sp);
-  switch (epilogue) {
-    case TTTS_EPI_STORE_BF16: SPLIT_LAUNCH(TTTS_EPI_STORE_BF16) break;
-    case TTTS_EPI_GELU_BF16: SPLIT_LAUNCH(TTTS_EPI_GELU_BF16) break;
-    case TTTS_EPI_RESID_ADD_F32: SPLIT_LAUNCH(TTTS_EPI_RESID_ADD_F32) break;
-    case TTTS_EPI_DGELU_BF16: SPLIT_LAUNCH(TTTS_EPI_DGELU_BF16) break;
-    case TTTS_EPI_STORE_F32: SPLIT_LAUNCH(TTTS_EPI_STORE_F32) break;
-    default: return fail(TTTS_EUNSUPPORTED, "gemm_nt_split: unknown epilogue %d", epilogue);
-  }
-#undef SPLIT_LAUNCH
-  return check_launch("gemm_nt_split");
-}
-
 extern "C" int ttts_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                                  const float* bias, void* aux, int32_t M, int32_t N, int32_t K, int32_t epilogue,
                                  void* stream) {
-  return ttts_gemm_nt_bf16_ex(A, lda, B, ldb, C, ldc, bias, aux, M, N, K, epilogue, nullptr, 0.f, 0, nullptr, nullptr, stream);
+  return ttts_gemm_nt_bf16_ex(A, lda, B, ldb, C, ldc, bias, aux, M, N, K, epilogue, nullptr, 0.f, 0, nullptr, stream);
 }
 
 static void tn_plan(int Mo, int No, int Kr, int& splits, int& k_chunk) {

@@ -150,15 +150,8 @@ __device__ __forceinline__ void vq_stage_rows(float* dst, int LD, const float* _
 // row; a 32-code tile is 24 KB and stays L1-resident), eight loads in flight while the previous eight feed the MFMAs, and the
 // |e|^2 chain runs on the same registers.  No barrier after the one that publishes the x tile: the four waves of a workgroup
 // (and the 2 workgroups per CU) overlap freely.  52 -> ~25 us at the BASELINE search.
-// UNGUARDED (round-3 candidate, compiled in but NOT selected: TTTS_VQ_UNGUARDED): the code-row loads come from a clamped index
-// instead of `in range ? load : 0`.  The guarded form compiles to exec-masked loads followed by s_waitcnt vmcnt(0) BEFORE the
-// current group's MFMAs (ISA), i.e. the "eight loads in flight while the previous eight feed the MFMAs" of the comment above
-// never happened; values loaded past the row end are never consumed (the MFMA loop has its own range test), so no zeroing
-// is needed and the distances -- and indices -- are bit-identical.
-#ifndef TTTS_VQ_UNGUARDED
-#define TTTS_VQ_UNGUARDED 0
-#endif
-template <bool UNGUARDED>
+// (Round 3 measured unguarded, clamped-index code-row loads with a branch-free full-group path: 37.7 vs 38.4 us -- inside the
+// run-to-run spread, removed.)
 __global__ __launch_bounds__(256) void vq_nearest_slice_kernel(const float* __restrict__ x, const float* __restrict__ cb,
                                                                float2* __restrict__ part, int N, int K, int D, int SL) {
   extern __shared__ __attribute__((aligned(16))) float vq_smem[];
@@ -187,12 +180,11 @@ __global__ __launch_bounds__(256) void vq_nearest_slice_kernel(const float* __re
     float4 cur[8], nxt[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-      cur[j] = UNGUARDED ? erow[min(j, D4 - 1)] : ((j < D4) ? erow[j] : make_float4(0.f, 0.f, 0.f, 0.f));
+      cur[j] = (j < D4) ? erow[j] : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int j0 = 0; j0 < D4; j0 += 8) {
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        nxt[j] = UNGUARDED ? erow[min(j0 + 8 + j, D4 - 1)]
-                           : ((j0 + 8 + j < D4) ? erow[j0 + 8 + j] : make_float4(0.f, 0.f, 0.f, 0.f));
+        nxt[j] = (j0 + 8 + j < D4) ? erow[j0 + 8 + j] : make_float4(0.f, 0.f, 0.f, 0.f);
       float xa[8], xb[8];                      // this group's 16 x operands up front: their LDS latency must not sit between MFMAs
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -200,23 +192,13 @@ __global__ __launch_bounds__(256) void vq_nearest_slice_kernel(const float* __re
         xa[j] = xrow[d + hh];
         xb[j] = xrow[d + 2 + hh];
       }
-      if (UNGUARDED && j0 + 8 <= D4) {         // whole group (every group when D % 32 == 0): 16 MFMAs with no branch between them
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < 8; ++j) {
+        if (j0 + j < D4) {                   // (D4 % 8 != 0: the last group is partial)
           const float4 v = cur[j];
           e2 = fmaf(v.x, v.x, e2); e2 = fmaf(v.y, v.y, e2); e2 = fmaf(v.z, v.z, e2); e2 = fmaf(v.w, v.w, e2);
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hh ? v.y : v.x, xa[j], acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hh ? v.w : v.z, xb[j], acc, 0, 0, 0);
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          if (j0 + j < D4) {                   // (D4 % 8 != 0: the last group is partial)
-            const float4 v = cur[j];
-            e2 = fmaf(v.x, v.x, e2); e2 = fmaf(v.y, v.y, e2); e2 = fmaf(v.z, v.z, e2); e2 = fmaf(v.w, v.w, e2);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hh ? v.y : v.x, xa[j], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hh ? v.w : v.z, xb[j], acc, 0, 0, 0);
-          }
         }
       }
 #pragma unroll
@@ -386,7 +368,7 @@ extern "C" int ttts_vq_nearest_f32(const float* x, const float* codebook, int64_
   const size_t smem = ((size_t)(VQ_ROWS + VQ_CODES) * (D + 1) + 8 * VQ_ROWS) * sizeof(float);
   static const hipError_t attr = [] {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(vq_nearest_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    return e != hipSuccess ? e : hipFuncSetAttribute(reinterpret_cast<const void*>(vq_nearest_slice_kernel<(TTTS_VQ_UNGUARDED != 0)>),
+    return e != hipSuccess ? e : hipFuncSetAttribute(reinterpret_cast<const void*>(vq_nearest_slice_kernel),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }();
   if (attr != hipSuccess) return fail(TTTS_EHIP, "vq_nearest: hipFuncSetAttribute: %s", hipGetErrorString(attr));
@@ -394,7 +376,7 @@ extern "C" int ttts_vq_nearest_f32(const float* x, const float* codebook, int64_
     const int SL = (int)cdiv(K, VQ_SLICE);
     float2* part = reinterpret_cast<float2*>(static_cast<char*>(workspace) + cdiv(K, 4) * 16 + 1024 * sizeof(double));
     const size_t smem_x = ((size_t)VQ_ROWS * (D + 1) + 8 * VQ_ROWS) * sizeof(float);
-    vq_nearest_slice_kernel<(TTTS_VQ_UNGUARDED != 0)><<<dim3((unsigned)cdiv(N, VQ_ROWS), (unsigned)SL), 256, smem_x, s>>>(x, codebook, part, N, K, D, SL);
+    vq_nearest_slice_kernel<<<dim3((unsigned)cdiv(N, VQ_ROWS), (unsigned)SL), 256, smem_x, s>>>(x, codebook, part, N, K, D, SL);
     int rc = check_launch("vq_nearest_slice");
     if (rc) return rc;
     vq_nearest_final_kernel<<<(int)cdiv(N, VQ_ROWS), 256, 0, s>>>(part, codebook, idx, xq, best_dist, N, D, SL);

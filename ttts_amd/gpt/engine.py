@@ -110,9 +110,6 @@ class GptEngine:
         # no split-reduction slabs, no reduce kernels.  TTTS_GROUPED_DW=0 restores one split-K dW GEMM per weight.
         self.grouped_dw = os.environ.get("TTTS_GROUPED_DW", "1") == "1"
         self._dw_plans = {}
-        # experiment (default off; written without GPU access at the end of round 2, see ttts_gemm_nt_split_bf16): the GEMMs whose
-        # tile count is 1 .. 1.5 x the CU count (N = 512: 292 tiles on 256 CUs) cut their surplus tiles along K
-        self.nt_split = os.environ.get("TTTS_NT_SPLIT", "0") == "1"
         self.seed_ctr = torch.zeros(1, dtype=torch.int32, device=self.device)   # this replica's dropout stream counter (device side:
         # graph-replay safe); handed to every dropout-capable kernel call -- the library holds no state of its own
         self.spec = param_spec(self.c)
@@ -228,10 +225,6 @@ class GptEngine:
         b["d_att"] = e(M, D)
         b["dqkv"] = z(M, 3 * D)
         b["delta"] = e(B * H * S, dt=f32)
-        if self.nt_split:
-            self._cus = ops.device_info()["cus"]
-            need = max(ops.gemm_nt_split_plan(M, n_, k_, self._cus)[0] for n_, k_ in ((D, D), (D, 4 * D), (D, 3 * D), (3 * D, D), (4 * D, D)))
-            b["nt_slabs"] = torch.empty(max(need, 16) // 4, dtype=f32, device=dev)
         if self.grouped_dw:   # per-layer dY buffers (0.5 GB at the BASELINE shape): nothing is overwritten before the dW launch
             b["dy_mlp"] = [z(M, D) for _ in range(L)]        # gradient entering mlp.c_proj  (was: dres_bf)
             b["dy_att"] = [z(M, D) for _ in range(L)]        # gradient entering attn.c_proj (was: dres_bf)
@@ -257,9 +250,6 @@ class GptEngine:
                     self._dw_plan(lo, hi)
 
     def _nt(self, a, w, c, *args, **kw):
-        """ops.gemm_nt, or its surplus-tile-split variant when TTTS_NT_SPLIT=1 (falls through for shapes it does not fit)."""
-        if self.nt_split:
-            return ops.gemm_nt_split(a, w, c, self.b["nt_slabs"], self._cus, *args, **kw)
         return ops.gemm_nt(a, w, c, *args, **kw)
 
     def _dw_plan(self, lo, hi):

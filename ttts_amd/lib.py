@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(CSRC, "build")
 SO_PATH = os.path.join(HERE, "libttts_hip.so")
-SOURCES = ["lib.hip", "elementwise.hip", "gemm.hip", "gemm_persist.hip", "attn.hip", "attn_dh64.hip", "vq.hip", "stft.hip", "conv.hip", "conv_mfma.hip", "conv_thin.hip", "conv_grouped.hip", "losses.hip", "vqvae_ops.hip", "attn_f32.hip", "peq.hip", "decode.hip", "diffusion_ops.hip"]
+SOURCES = ["lib.hip", "elementwise.hip", "gemm.hip", "attn.hip", "attn_dh64.hip", "vq.hip", "stft.hip", "conv.hip", "conv_mfma.hip", "conv_thin.hip", "conv_grouped.hip", "losses.hip", "vqvae_ops.hip", "attn_f32.hip", "peq.hip", "decode.hip", "diffusion_ops.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-Wall", "-Wno-unused-variable"]
 
@@ -66,7 +66,7 @@ _c = ctypes
 _P, _I32, _I64, _U64, _F = _c.c_void_p, _c.c_int32, _c.c_int64, _c.c_uint64, _c.c_float
 
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class ConvCtx(ctypes.Structure):
@@ -91,10 +91,7 @@ SIGNATURES = {
     "ttts_last_error": (_c.c_char_p, []),
     "ttts_device_info": (_I32, [_P]),
     "ttts_gemm_nt_bf16": (_I32, [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I32, _I32, _I32, _I32, _P]),
-    "ttts_gemm_nt_bf16_ex": (_I32, [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I32, _I32, _I32, _I32, _P, _F, _U64, _P, _P, _P]),
-    "ttts_gemm_nt_workspace_bytes": (_I64, []),
-    "ttts_gemm_nt_split_plan": (_I64, [_I32, _I32, _I32, _I32, _P]),
-    "ttts_gemm_nt_split_bf16": (_I32, [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I32, _I32, _I32, _I32, _P, _F, _U64, _P, _I32, _P, _P]),
+    "ttts_gemm_nt_bf16_ex": (_I32, [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I32, _I32, _I32, _I32, _P, _F, _U64, _P, _P]),
     "ttts_gemm_tn_workspace_bytes": (_I64, [_I32, _I32, _I32]),
     "ttts_gemm_tn_bf16_accum_f32": (_I32, [_P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _P]),
     "ttts_tn_desc_tiles": (_I32, [_I32, _I32]),

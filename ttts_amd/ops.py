@@ -46,13 +46,8 @@ def _ld(t):
     return t.stride(0)
 
 
-def gemm_nt_workspace(device):
-    """Zeroed workspace that selects the persistent wave-specialised NT GEMM (include/ttts_hip.h: ttts_gemm_nt_bf16_ex)."""
-    return torch.zeros(_l.get().ttts_gemm_nt_workspace_bytes() // 4, dtype=torch.int32, device=device)
-
-
 def gemm_nt(a, b, c, bias=None, aux=None, epilogue=EPI_STORE_BF16, n=None, k=None, resid_in=None, dropout_p=0.0,
-            seed=0, counter=None, workspace=None):
+            seed=0, counter=None):
     """c[M,N] = epi(a[M,K] @ b[N,K]^T).  a/b bf16 row-major views; c bf16 or f32 (per epilogue)."""
     _req(resid_in, torch.float32, "resid_in")
     _req(a, torch.bfloat16, "a"); _req(b, torch.bfloat16, "b"); _req(bias, torch.float32, "bias")
@@ -65,35 +60,7 @@ def gemm_nt(a, b, c, bias=None, aux=None, epilogue=EPI_STORE_BF16, n=None, k=Non
     if resid_in is not None and (resid_in.shape != c.shape or resid_in.stride() != c.stride()):
         raise TttsError("resid_in must have the layout of c")
     check(_l.get().ttts_gemm_nt_bf16_ex(_p(a), _ld(a), _p(b), _ld(b), _p(c), _ld(c), _p(bias), _p(aux), M, N, K,
-                                        epilogue, _p(resid_in), dropout_p, seed, _ctr(counter, c, dropout_p), _p(workspace),
-                                        _stream()), "gemm_nt")
-    return c
-
-
-def gemm_nt_split_plan(M, N, K, cus):
-    """(slab bytes, (whole tiles, surplus tiles, pieces)) of the opt-in surplus-tile split (0 bytes: does not apply)."""
-    plan = (ctypes.c_int32 * 3)()
-    nbytes = int(_l.get().ttts_gemm_nt_split_plan(M, N, K, cus, plan))
-    return nbytes, (plan[0], plan[1], plan[2])
-
-
-def gemm_nt_split(a, b, c, slabs, cus, bias=None, aux=None, epilogue=EPI_STORE_BF16, n=None, k=None, resid_in=None,
-                  dropout_p=0.0, seed=0, counter=None):
-    """gemm_nt through ttts_gemm_nt_split_bf16 (OPT-IN, unmeasured): surplus tiles cut along K, slabs f32 scratch."""
-    _req(resid_in, torch.float32, "resid_in")
-    _req(a, torch.bfloat16, "a"); _req(b, torch.bfloat16, "b"); _req(bias, torch.float32, "bias")
-    _req(aux, torch.bfloat16, "aux"); _req(slabs, torch.float32, "slabs")
-    M = a.shape[0]
-    K = a.shape[1] if k is None else k
-    N = b.shape[0] if n is None else n
-    want = torch.float32 if epilogue in (EPI_RESID_ADD_F32, EPI_STORE_F32) else torch.bfloat16
-    _req(c, want, "c")
-    need, _ = gemm_nt_split_plan(M, N, K, cus)
-    if slabs.numel() * 4 < need:
-        raise TttsError("gemm_nt_split: slab workspace too small (%d < %d bytes)" % (slabs.numel() * 4, need))
-    check(_l.get().ttts_gemm_nt_split_bf16(_p(a), _ld(a), _p(b), _ld(b), _p(c), _ld(c), _p(bias), _p(aux), M, N, K, epilogue,
-                                           _p(resid_in), dropout_p, seed, _ctr(counter, c, dropout_p), cus, _p(slabs),
-                                           _stream()), "gemm_nt_split")
+                                        epilogue, _p(resid_in), dropout_p, seed, _ctr(counter, c, dropout_p), _stream()), "gemm_nt")
     return c
 
 
