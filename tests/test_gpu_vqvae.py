@@ -640,16 +640,51 @@ def test_split_bf16_conv_accuracy(case):
 
 @pytest.mark.bf16x3
 def test_codes_through_model_split_bf16_near_tie_audit(golden_dir):
-    """Default (split-bf16) convolutions perturb the quantizer input by ~5e-6 of its range: the code indices of the assembled
-    model still equal the reference's except where the two nearest codes are closer than that perturbation (reported)."""
+    """The benchmarked (split-bf16) convolution path carries the code-index claim: the indices of the assembled model equal the
+    reference's on every WELL-SEPARATED row.  A row may differ only if the quantizer-input perturbation delta this path
+    introduces (measured here against the exact-fp32 path, whose codes are bit-equal to the reference) can actually change the
+    winner: gap(best, second) <= 2 |delta| |e_best - e_second| (Cauchy-Schwarz on d_a - d_b = -2 delta.(e_a - e_b)), with a
+    factor 2 of slack; and oracle/vq_ref.near_tie_audit must flag every such row as a near tie at the matching ulp budget."""
     from oracle import vq_ref
+    from ttts_amd import ops as _ops
     from ttts_amd.prepare.extract_vq import extract_vq_codes
     g, tr, data, inject = _step_setup(golden_dir)
-    lat = extract_vq_codes(tr.net_g, data["wav"], tr.hps.data, data["wav_lengths"]).cpu()
     want = torch.from_numpy(g["latent_codes"])
-    diff = int((lat != want).sum())
-    print("split-bf16 path: %d of %d code indices differ from the reference" % (diff, want.numel()))
-    assert diff <= max(1, want.numel() // 25)
+    box = {}
+    hook = tr.net_g.quantizer.register_forward_pre_hook(lambda mod, inp: box.__setitem__("x", inp[0].detach().clone()))
+    try:
+        _ops.set_conv_precision("exact")
+        lat_exact = extract_vq_codes(tr.net_g, data["wav"], tr.hps.data, data["wav_lengths"]).cpu()
+        x_exact = box["x"].double().cpu()
+        _ops.set_conv_precision("split_bf16")
+        lat = extract_vq_codes(tr.net_g, data["wav"], tr.hps.data, data["wav_lengths"]).cpu()
+        x_fast = box["x"].double().cpu()
+    finally:
+        hook.remove()
+    assert torch.equal(lat_exact, want)                       # the anchor: exact path == reference, index by index
+    embed = tr.net_g.quantizer.vq.layers[0]._codebook.embed.detach().double().cpu()
+    flat_e = x_exact.transpose(1, 2).reshape(-1, x_exact.shape[1])        # (B * T, D) rows as the quantizer sees them
+    flat_f = x_fast.transpose(1, 2).reshape(-1, x_fast.shape[1])
+    delta = (flat_f - flat_e).norm(dim=1)
+    rng = float(flat_e.abs().max())
+    print("split-bf16 quantizer input: max |delta| / range = %.2e" % (float((flat_f - flat_e).abs().max()) / rng))
+    assert float((flat_f - flat_e).abs().max()) <= 2e-5 * rng  # the per-convolution bound of the split-bf16 products, end to end
+    d = (flat_e * flat_e).sum(1, keepdim=True) - 2 * flat_e @ embed.t() + (embed * embed).sum(1)[None]
+    top2 = torch.topk(-d, 2, dim=1)
+    gap = (top2.values[:, 0] - top2.values[:, 1]).abs()
+    esep = (embed[top2.indices[:, 0]] - embed[top2.indices[:, 1]]).norm(dim=1)
+    can_flip = gap <= 2.0 * (2.0 * delta * esep)
+    diff = (lat.reshape(-1) != want.reshape(-1))
+    ndiff = int(diff.sum())
+    print("split-bf16 path: %d of %d code indices differ from the reference; %d rows are within the flip bound" % (
+        ndiff, want.numel(), int(can_flip.sum())))
+    assert int((diff & ~can_flip).sum()) == 0, "codes differ on %d well-separated rows" % int((diff & ~can_flip).sum())
+    # the oracle's own audit at the ulp budget that corresponds to the measured perturbation flags the same rows
+    mag = d.abs().max(dim=1).values.clamp_min(1e-30)
+    ulps = float((2.0 * (2.0 * delta * esep) / (mag * float(np.finfo(np.float32).eps))).max()) + 1.0
+    near = vq_ref.near_tie_audit(flat_e.float(), embed.float(), want.reshape(-1), ulps=ulps)
+    assert int((diff & ~near).sum()) == 0
+    assert ndiff <= max(1, want.numel() // 100)
 
 
 def test_kmeans_init_and_dead_code_expiry_vs_reference_fixture(golden_dir):
