@@ -255,10 +255,7 @@ class KernelTimer:
 
         def f_ab(q, k, v, o, d_o, lse, dq, dk, dv, ws, B, H, S, dh, *a, **kw):
             return "attn_bwd(delta+dkdv+dq)", 10.0 * B * H * dh * S * (S + 1) / 2  # 5 causal-useful matmuls
-        def f_nts(a, b, c, slabs, cus, bias=None, aux=None, epilogue=0, n=None, k=None, **kw):   # TTTS_NT_SPLIT=1 (opt-in)
-            return f_nt(a, b, c, bias, aux, epilogue, n, k)
         self._wrap("gemm_nt", f_nt)
-        self._wrap("gemm_nt_split", f_nts)
         self._wrap("gemm_tn_accum", f_tn)
         self._wrap("attn_fwd", f_af)
         self._wrap("attn_bwd", f_ab)

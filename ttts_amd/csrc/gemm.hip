@@ -47,6 +47,98 @@ struct GemmNtParams {
   GemmEpi e;
 };
 
+// one output row piece: 8 consecutive columns n .. n + 7 of row m, v = acc + bias (fp32), through epilogue EPI
+template <int EPI>
+__device__ __forceinline__ void epi_row8(const GemmEpi& e, int m, int n, float (&v)[8], bool vec_ok) {
+  const int64_t off = (int64_t)m * e.ldc + n;
+  const bool full = vec_ok && (n + 8 <= e.N);
+  if (EPI == TTTS_EPI_STORE_BF16) {
+    bf16* c = reinterpret_cast<bf16*>(e.C) + off;
+    if (full) {
+      bf16x8 o;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) o[t] = (bf16)v[t];
+      *reinterpret_cast<bf16x8*>(c) = o;
+    } else {
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        if (n + t < e.N) c[t] = (bf16)v[t];
+    }
+  } else if (EPI == TTTS_EPI_GELU_BF16) {
+    bf16* c = reinterpret_cast<bf16*>(e.C) + off;
+    bf16* ax = e.aux + off;
+    bf16x8 pre, act;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      pre[t] = (bf16)v[t];
+      act[t] = (bf16)gelu_new_f((float)pre[t]);
+    }
+    if (full) {
+      *reinterpret_cast<bf16x8*>(ax) = pre;
+      *reinterpret_cast<bf16x8*>(c) = act;
+    } else {
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        if (n + t < e.N) { ax[t] = pre[t]; c[t] = act[t]; }
+    }
+  } else if (EPI == TTTS_EPI_RESID_ADD_F32) {
+    float* c = reinterpret_cast<float*>(e.C) + off;
+    const float* rin = e.resid_in ? e.resid_in + off : c;
+    float y[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) y[t] = (float)(bf16)v[t];
+    if (e.thr) {  // resid_pdrop: element index m*N + n, 16 random bits per element (two elements per hash)
+      const uint32_t lin = (uint32_t)(((int64_t)m * e.N + n) >> 1);
+      const uint32_t shi = seed_mix(e.seed_hi, e.ctr);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const uint32_t r = hash32(lin + t, e.seed_lo, shi);
+        y[2 * t] = (r & 0xFFFFu) >= e.thr ? y[2 * t] * e.inv_keep : 0.f;
+        y[2 * t + 1] = (r >> 16) >= e.thr ? y[2 * t + 1] * e.inv_keep : 0.f;
+      }
+    }
+    if (full) {
+      const float4 r0 = *reinterpret_cast<const float4*>(rin), r1 = *reinterpret_cast<const float4*>(rin + 4);
+      *reinterpret_cast<float4*>(c) = make_float4(r0.x + y[0], r0.y + y[1], r0.z + y[2], r0.w + y[3]);
+      *reinterpret_cast<float4*>(c + 4) = make_float4(r1.x + y[4], r1.y + y[5], r1.z + y[6], r1.w + y[7]);
+    } else {
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        if (n + t < e.N) c[t] = rin[t] + y[t];
+    }
+  } else if (EPI == TTTS_EPI_DGELU_BF16) {
+    bf16* c = reinterpret_cast<bf16*>(e.C) + off;
+    const bf16* ax = e.aux + off;
+    if (full) {
+      const bf16x8 pre = *reinterpret_cast<const bf16x8*>(ax);
+      bf16x8 o;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) o[t] = (bf16)(v[t] * gelu_new_grad_f((float)pre[t]));
+      *reinterpret_cast<bf16x8*>(c) = o;
+    } else {
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        if (n + t < e.N) c[t] = (bf16)(v[t] * gelu_new_grad_f((float)ax[t]));
+    }
+  } else {  // STORE_F32 / ACCUM_F32 / SLAB_F32
+    float* c = reinterpret_cast<float*>(e.C) + off;
+    if (full) {
+      float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
+      if (EPI == EPI_ACCUM_F32) {
+        const float4 c0 = *reinterpret_cast<const float4*>(c), c1 = *reinterpret_cast<const float4*>(c + 4);
+        o0 = make_float4(c0.x + o0.x, c0.y + o0.y, c0.z + o0.z, c0.w + o0.w);
+        o1 = make_float4(c1.x + o1.x, c1.y + o1.y, c1.z + o1.z, c1.w + o1.w);
+      }
+      *reinterpret_cast<float4*>(c) = o0;
+      *reinterpret_cast<float4*>(c + 4) = o1;
+    } else {
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        if (n + t < e.N) c[t] = (EPI == EPI_ACCUM_F32 ? c[t] : 0.f) + v[t];
+    }
+  }
+}
+
 // ---- shared epilogue: accumulators -> fp32 LDS stage (64 rows at a time) -> coalesced global access ---------------
 // stage: >= 64 * ST_LD floats of LDS that no wave reads any more (callers end their main loop with a barrier).
 // NJ = 32-column blocks per wave: 2 for the 128 x 128 tile, 1 for the 128 x 64 tile (N = 512 GEMMs: 292 -> 584 tiles)
@@ -95,93 +187,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmEpi& e, f32x16 (&acc)[2]
       }
 #pragma unroll
       for (int t = 0; t < 8; ++t) v[t] += bias8[t];
-      const int64_t off = (int64_t)m * e.ldc + n;
-      const bool full = vec_ok && (n + 8 <= e.N);
-      if (EPI == TTTS_EPI_STORE_BF16) {
-        bf16* c = reinterpret_cast<bf16*>(e.C) + off;
-        if (full) {
-          bf16x8 o;
-#pragma unroll
-          for (int t = 0; t < 8; ++t) o[t] = (bf16)v[t];
-          *reinterpret_cast<bf16x8*>(c) = o;
-        } else {
-#pragma unroll
-          for (int t = 0; t < 8; ++t)
-            if (n + t < e.N) c[t] = (bf16)v[t];
-        }
-      } else if (EPI == TTTS_EPI_GELU_BF16) {
-        bf16* c = reinterpret_cast<bf16*>(e.C) + off;
-        bf16* ax = e.aux + off;
-        bf16x8 pre, act;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          pre[t] = (bf16)v[t];
-          act[t] = (bf16)gelu_new_f((float)pre[t]);
-        }
-        if (full) {
-          *reinterpret_cast<bf16x8*>(ax) = pre;
-          *reinterpret_cast<bf16x8*>(c) = act;
-        } else {
-#pragma unroll
-          for (int t = 0; t < 8; ++t)
-            if (n + t < e.N) { ax[t] = pre[t]; c[t] = act[t]; }
-        }
-      } else if (EPI == TTTS_EPI_RESID_ADD_F32) {
-        float* c = reinterpret_cast<float*>(e.C) + off;
-        const float* rin = e.resid_in ? e.resid_in + off : c;
-        float y[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) y[t] = (float)(bf16)v[t];
-        if (e.thr) {  // resid_pdrop: element index m*N + n, 16 random bits per element (two elements per hash)
-          const uint32_t lin = (uint32_t)(((int64_t)m * e.N + n) >> 1);
-          const uint32_t shi = seed_mix(e.seed_hi, e.ctr);
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const uint32_t r = hash32(lin + t, e.seed_lo, shi);
-            y[2 * t] = (r & 0xFFFFu) >= e.thr ? y[2 * t] * e.inv_keep : 0.f;
-            y[2 * t + 1] = (r >> 16) >= e.thr ? y[2 * t + 1] * e.inv_keep : 0.f;
-          }
-        }
-        if (full) {
-          const float4 r0 = *reinterpret_cast<const float4*>(rin), r1 = *reinterpret_cast<const float4*>(rin + 4);
-          *reinterpret_cast<float4*>(c) = make_float4(r0.x + y[0], r0.y + y[1], r0.z + y[2], r0.w + y[3]);
-          *reinterpret_cast<float4*>(c + 4) = make_float4(r1.x + y[4], r1.y + y[5], r1.z + y[6], r1.w + y[7]);
-        } else {
-#pragma unroll
-          for (int t = 0; t < 8; ++t)
-            if (n + t < e.N) c[t] = rin[t] + y[t];
-        }
-      } else if (EPI == TTTS_EPI_DGELU_BF16) {
-        bf16* c = reinterpret_cast<bf16*>(e.C) + off;
-        const bf16* ax = e.aux + off;
-        if (full) {
-          const bf16x8 pre = *reinterpret_cast<const bf16x8*>(ax);
-          bf16x8 o;
-#pragma unroll
-          for (int t = 0; t < 8; ++t) o[t] = (bf16)(v[t] * gelu_new_grad_f((float)pre[t]));
-          *reinterpret_cast<bf16x8*>(c) = o;
-        } else {
-#pragma unroll
-          for (int t = 0; t < 8; ++t)
-            if (n + t < e.N) c[t] = (bf16)(v[t] * gelu_new_grad_f((float)ax[t]));
-        }
-      } else {  // STORE_F32 / ACCUM_F32 / SLAB_F32
-        float* c = reinterpret_cast<float*>(e.C) + off;
-        if (full) {
-          float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
-          if (EPI == EPI_ACCUM_F32) {
-            const float4 c0 = *reinterpret_cast<const float4*>(c), c1 = *reinterpret_cast<const float4*>(c + 4);
-            o0 = make_float4(c0.x + o0.x, c0.y + o0.y, c0.z + o0.z, c0.w + o0.w);
-            o1 = make_float4(c1.x + o1.x, c1.y + o1.y, c1.z + o1.z, c1.w + o1.w);
-          }
-          *reinterpret_cast<float4*>(c) = o0;
-          *reinterpret_cast<float4*>(c + 4) = o1;
-        } else {
-#pragma unroll
-          for (int t = 0; t < 8; ++t)
-            if (n + t < e.N) c[t] = (EPI == EPI_ACCUM_F32 ? c[t] : 0.f) + v[t];
-        }
-      }
+      epi_row8<EPI>(e, m, n, v, vec_ok);
     }
     __syncthreads();
   }
@@ -299,6 +305,158 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_nt_glds_kernel(
     __syncthreads();  // next tile landed (vmcnt(0)) and everyone is done reading this one
   }
   tile_epilogue<EPI, NJ>(p.e, acc, reinterpret_cast<float*>(smem), m0, n0, tid);
+}
+
+// ---- NT, tall tile + deep ring for the narrow-N GEMMs (N <= 512: attn / mlp c_proj, dX of c_attn / c_fc) ------------------
+// At M = 9248 a 128 x 128 tiling of an N = 512 GEMM has 292 tiles for 256 CUs: about one workgroup per CU, i.e. nothing
+// to overlap a workgroup's own waits with.  Measured (round 3): 1.24 us per k-step of 64 -- 2 800 cycles around 512 cycles of
+// MFMA work -- whatever the tile count per CU (a 232-tile single-round tiling alone gained 4 %): every k-step waits one full
+// L2 / HBM round trip for the tile it issued one step earlier.  So this kernel keeps THREE k-tiles in flight behind the one
+// being consumed: a 4-slot LDS ring (4 x 36 KB: one workgroup per CU, which is all these launches have anyway), LDS-DMA issued
+// through the untracked asm form (hipcc would drain it with vmcnt(0) at every barrier) and counted waits -- vmcnt(18) leaves
+// the two newest k-tiles (9 pieces each per wave) in flight.  One barrier per k-step: it publishes tile kt and, because every
+// wave has finished tile kt - 1 when it arrives, frees slot (kt + 3) % 4 for the next issue.
+// Tile: (32 MI) x (32 NW), NW waves: wave w owns output columns 32 w .. 32 w + 31 of all MI row blocks (MI accumulators; per
+// k-step of 16 it reads MI A fragments and one B fragment).  Instance in use: MI 5, 4 waves, 160 x 128, 4-slot ring -- 58 x 4 =
+// 232 tiles, one round (mlp c_proj 41.2 -> 36.3 us, dX c_fc 35.9 -> 30.4, attn c_proj 19.1 -> 17.5; GPT step -0.10 ms).
+// Measured and not kept: MI 8, 8 waves, 256 x 256, 2-slot ring for the N >= 1536 GEMMs (half the operand bytes per flop):
+// c_attn 30.4 vs 28.8 us, c_fc 58.0 vs 43.0 us (296 tiles: two rounds) -- with one workgroup per CU the main loops and the
+// output stores of all CUs run in phases instead of interleaving.
+template <int EPI, int MI, int NW, int NST>
+__global__ __launch_bounds__(64 * NW, 1) void gemm_nt_tall_kernel(GemmNtParams p) {
+  constexpr int BKT = 64, TM = 32 * MI, TN = 32 * NW, NT = 64 * NW;   // NW waves, one 32-column strip each
+  constexpr int ACH = TM / 8, BCH = TN / 8;        // 1-KB DMA chunks (8 rows) per operand tile
+  constexpr int A_EL = TM * BKT, B_EL = TN * BKT, STAGE_EL = A_EL + B_EL;
+  constexpr int PPW = (ACH + BCH) / NW;            // DMA pieces per wave and k-tile
+  static_assert(ACH % NW == 0 && BCH % NW == 0, "chunks are dealt evenly to the waves");
+  constexpr int ST_W = TN + 4;                     // fp32 staging row pitch (floats)
+  extern __shared__ __attribute__((aligned(16))) unsigned char tall_smem[];
+  bf16* smem = reinterpret_cast<bf16*>(tall_smem);  // [NST][A | B]; reused as the fp32 epilogue stage
+  const uint32_t lds0 = lds_byte_addr(tall_smem);
+  const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = (p.e.N + TN - 1) / TN;
+  const int tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int m0 = (tile / tiles_n) * TM, n0 = (tile % tiles_n) * TN;
+  const int nk = p.K / BKT;
+  auto fsw = [](int r) { return (r >> 1) & 7; };
+
+  // this lane's DMA source rows (clamped: rows beyond M / N are loaded from the last valid row and never stored)
+  const bf16* ga[ACH / NW];
+  const bf16* gb[BCH / NW];
+#pragma unroll
+  for (int i = 0; i < ACH / NW; ++i) {
+    const int r = (wave * (ACH / NW) + i) * 8 + (lane >> 3);
+    ga[i] = p.A + (int64_t)min(m0 + r, p.e.M - 1) * p.lda + (((lane & 7) ^ fsw(r)) << 3);
+  }
+#pragma unroll
+  for (int i = 0; i < BCH / NW; ++i) {
+    const int r = (wave * (BCH / NW) + i) * 8 + (lane >> 3);
+    gb[i] = p.B + (int64_t)min(n0 + r, p.e.N - 1) * p.ldb + (((lane & 7) ^ fsw(r)) << 3);
+  }
+  auto issue = [&](int kt) {                       // k-tile kt -> ring slot kt % NST (PPW untracked DMA pieces)
+    const uint32_t as = lds0 + ((kt & (NST - 1)) * STAGE_EL + wave * (ACH / NW) * 8 * BKT) * 2;
+    const uint32_t bs = lds0 + ((kt & (NST - 1)) * STAGE_EL + A_EL + wave * (BCH / NW) * 8 * BKT) * 2;
+#pragma unroll
+    for (int i = 0; i < ACH / NW; ++i) lds_dma16_untracked(ga[i] + kt * BKT, as + i * 1024);
+#pragma unroll
+    for (int i = 0; i < BCH / NW; ++i) lds_dma16_untracked(gb[i] + kt * BKT, bs + i * 1024);
+  };
+
+  f32x16 acc[MI];                                   // [i: 32-row block of M]; D = Btile . Atile^T (rows = n, cols = m)
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+  for (int t = 0; t < NST - 1; ++t)
+    if (t < nk) issue(t);
+  const int rl = lane & 31, swl = fsw(rl);          // fsw(32 i + rl) = fsw(rl)
+  const int boff = (wave * 32 + rl) * BKT;
+  // tile `kt` has landed when at most the pieces of the (up to two) newer tiles are outstanding
+  auto wait_tile = [&](int kt) {
+    const int newer = min(NST - 2, nk - 1 - kt);
+    // (lgkmcnt(0): this wave's fragment reads of the slot that is about to be refilled have really left the LDS)
+    if (newer >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(2 * PPW) : "memory");
+    else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(PPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  // fragments of k-step ks (16 k-values) of tile kt: one B fragment, MI A fragments
+  bf16x8 fb[2], fa[2][MI];
+  auto load_frags = [&](int set, int kt, int ks) {
+    const bf16* as = smem + (kt & (NST - 1)) * STAGE_EL;
+    const int ch = ((ks * 2 + hh) ^ swl) << 3;       // this lane's 8 k-values: physical 16-byte chunk
+    fb[set] = *reinterpret_cast<const bf16x8*>(as + A_EL + boff + ch);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) fa[set][i] = *reinterpret_cast<const bf16x8*>(as + (i * 32 + rl) * BKT + ch);
+  };
+  // Software pipeline, order pinned: the fragments of the NEXT k-step are requested in front of the current k-step's MI MFMAs
+  // (with one workgroup per CU nothing else hides the LDS latency: the compiler's own order waited 20 times per tile).  The
+  // barrier that publishes tile kt + 1 sits in front of tile kt's last k-step: by then every wave holds that k-step's
+  // fragments in registers, so slot kt % 4 is free for tile kt + 4.
+  wait_tile(0);
+  if (NST - 1 < nk) issue(NST - 1);
+  load_frags(0, 0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+    for (int ks = 0; ks < BKT / 16; ++ks) {
+      const int cur = ks & 1, nxt = cur ^ 1;
+      if (ks + 1 < BKT / 16) {
+        load_frags(nxt, kt, ks + 1);
+      } else if (kt + 1 < nk) {
+        wait_tile(kt + 1);
+        if (kt + NST < nk) issue(kt + NST);
+        load_frags(nxt, kt + 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) acc[i] = mfma32(fb[cur], fa[cur][i], acc[i]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __syncthreads();                                  // every wave is done reading the ring: it becomes the epilogue stage
+  // epilogue: two row blocks (64 rows) at a time through the fp32 stage, whole rows out (TN / 8 threads x 8 columns per row)
+  float* stage = reinterpret_cast<float*>(tall_smem);
+  const bool bf16_out = (EPI == TTTS_EPI_STORE_BF16 || EPI == TTTS_EPI_GELU_BF16 || EPI == TTTS_EPI_DGELU_BF16);
+  const bool vec_ok = bf16_out ? ((p.e.ldc & 7) == 0) : ((p.e.ldc & 3) == 0);
+  float bias8[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int n = n0 + (tid % (TN / 8)) * 8 + t;
+    const float b = (p.e.bias && n < p.e.N) ? p.e.bias[n] : 0.f;
+    bias8[t] = (EPI == TTTS_EPI_STORE_F32) ? b : (float)(bf16)b;
+  }
+#pragma unroll
+  for (int pass = 0; pass < (MI + 1) / 2; ++pass) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+      const int i = 2 * pass + ii;
+      if (i < MI) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = make_float4(acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]);
+          *reinterpret_cast<float4*>(&stage[(ii * 32 + rl) * ST_W + wave * 32 + 8 * q + 4 * hh]) = v;
+        }
+      }
+    }
+    __syncthreads();
+    const int rows = (2 * pass + 1 < MI) ? 64 : 32;
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      const int row_l = sub * 16 + tid / (TN / 8);
+      const int m = m0 + pass * 64 + row_l, n = n0 + (tid % (TN / 8)) * 8;
+      if (row_l >= rows || m >= p.e.M || n >= p.e.N) continue;
+      float v[8];
+      const float4 a = *reinterpret_cast<const float4*>(&stage[row_l * ST_W + (tid % (TN / 8)) * 8]);
+      const float4 b = *reinterpret_cast<const float4*>(&stage[row_l * ST_W + (tid % (TN / 8)) * 8 + 4]);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] += bias8[t];
+      epi_row8<EPI>(p.e, m, n, v, vec_ok);
+    }
+    __syncthreads();
+  }
 }
 
 // ---- NT, register-staged main loop (any K % 8 == 0; zero-fills ragged K) ---------------------------------------------
@@ -678,6 +836,19 @@ using namespace ttts;
 template <int EPI>
 static void launch_nt(const GemmNtParams& p, int grid, hipStream_t s) {
   // (a 128 x 64 tile for the N = 512 GEMMs was measured slower on MI355X -- mlp c_proj 40.2 -> 47.5 us -- and removed)
+  // tall tile + deep ring: when the 128 x 128 tiling has about one tile per CU (tiles in (CUs, 1.6 CUs]) and 160-row tiles fit one round
+  constexpr int CUS = 256;
+  const int tall_grid = (int)(cdiv(p.e.M, 160) * cdiv(p.e.N, 128));
+  if (p.K % 64 == 0 && grid > CUS && grid <= CUS * 8 / 5 && tall_grid <= CUS) {
+    constexpr size_t smem = (size_t)4 * (160 + 128) * 64 * sizeof(bf16);   // the 4-slot ring: 144 KB
+    static bool attr = false;
+    if (!attr) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_tall_kernel<EPI, 5, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      attr = true;
+    }
+    gemm_nt_tall_kernel<EPI, 5, 4, 4><<<tall_grid, 256, smem, s>>>(p);
+    return;
+  }
   if (p.K % 64 == 0) gemm_nt_glds_kernel<EPI, 64><<<grid, 256, 0, s>>>(p);
   else if (p.K % 32 == 0) gemm_nt_glds_kernel<EPI, 32><<<grid, 256, 0, s>>>(p);
   else gemm_nt_kernel<EPI><<<grid, 256, 0, s>>>(p);
