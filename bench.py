@@ -173,7 +173,8 @@ def vqvae_leg(dev, steps, warmup, cpu_leg=True):
 
 def vqvae_cpu_baseline():
     """The oracle's restatement of the same two-phase step (oracle/vqvae_ref.gan_step_losses + CPU autograd + AdamW on the
-    discriminator between the phases) on the host cores, bounded sample: ONE clip of 64 frames (40 960 samples)."""
+    discriminator between the phases) on the host cores, bounded sample: ONE clip of BASELINE config #3's length (256 frames =
+    163 840 samples, 32-frame decoder segment) instead of the batch of 32 -- frames/s is per clip, so the figure scales linearly."""
     from oracle import vqvae_ref
     from ttts_amd.vqvae.train import get_hparams
     threads = min(os.cpu_count() or 1, 32)
@@ -191,7 +192,7 @@ def vqvae_cpu_baseline():
             v.requires_grad_(True)
     sd_d = {k: vqvae_ref.det_fill(k, s, 0.6).requires_grad_(True) for k, s, *_ in surf["vqvae_d"]}
     embed = vqvae_ref.det_fill("codebook.embed", (1024, 192)) * 2.0
-    frames = 64
+    frames = int(os.environ.get("TTTS_CPU_BASELINE_FRAMES", "256"))   # BASELINE config #3's clip length; one clip instead of 32
     g = torch.Generator().manual_seed(7)
     wav = (torch.rand(1, frames * 640, generator=g) - 0.5)
     opt_d = torch.optim.AdamW(list(sd_d.values()), h["learning_rate"], betas=h["betas"], eps=h["eps"])
@@ -208,12 +209,13 @@ def vqvae_cpu_baseline():
         lg.backward(); opt_g.step(); opt_g.zero_grad(); opt_d.zero_grad()
     t0 = time.time(); one_step(); warm = time.time() - t0
     n, t0 = 0, time.time()
-    while n < 1 or (time.time() - t0 + 1.5 * warm < 20.0 and n < 4):
+    while n < 1 or (time.time() - t0 + 1.5 * warm < 20.0 and n < 3):
         one_step(); n += 1
     dt = (time.time() - t0) / n
     return {"value": round(frames / dt, 2), "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": "%d full two-phase steps (fwd, D backward + AdamW, G backward + AdamW) of the oracle on ONE clip of %d frames "
-                      "(%d samples, 32-frame decoder segment), fp32, after 1 warm-up step; %.2f s/step" % (n, frames, frames * 640, dt)}
+                      "(%d samples, 32-frame decoder segment; config #3 is 32 such clips), fp32, %d threads, after 1 warm-up step; "
+                      "%.2f s/step" % (n, frames, frames * 640, threads, dt)}
 
 
 class KernelTimer:
@@ -299,26 +301,46 @@ class KernelTimer:
         return agg
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """The oracle (CPU restatement of the reference train step: fp32, eager, all host cores) on a bounded sample."""
+def cpu_baseline(seconds_budget=24.0):
+    """The oracle (CPU restatement of the reference train step, eager) on the host cores, BASELINE.md section 3's protocol inside a
+    bounded budget: the main line is fp32 on all cores (capped at 32 threads: torch's intra-op pool degrades beyond that here) at
+    the LARGEST batch of {8, 4, 2, 1} x (128 text + 1024 audio tokens) whose projected step fits the budget (tokens/s is per
+    step, so a smaller batch is the same workload at a lower arithmetic intensity -- stated in `sample`); two more lines at
+    batch 1 give the 8-thread and the bf16-autocast figures of the survey's table."""
     from oracle import gpt_ref
-    threads = min(os.cpu_count() or 1, 32)   # torch's intra-op pool stops scaling (and degrades) beyond ~32 threads here
+    threads = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(threads)
     sd = gpt_ref.det_state_dict(None)
     opt = gpt_ref.new_opt_state(sd)
+
+    def timed(bs, bf16=False, reps=1):
+        batch = gpt_ref.synthetic_batch(B=bs, seed=1234)
+        t0 = time.time()
+        for _ in range(reps):
+            gpt_ref.gpt_train_step(sd, opt, batch, None, None, bf16=bf16, dropout_p=0.1)
+        return (time.time() - t0) / reps
+    timed(1)                                   # warm-up (allocations, thread pool)
+    t1 = timed(1)
     bs = 1
-    batch = gpt_ref.synthetic_batch(B=bs, seed=1234)
-    t0 = time.time()
-    gpt_ref.gpt_train_step(sd, opt, batch, None, None, bf16=False, dropout_p=0.1)   # warm-up (allocations, threads)
-    warm = time.time() - t0
-    n, t0 = 0, time.time()
-    while n < 1 or (time.time() - t0 + 1.5 * warm < seconds_budget and n < 8):
-        gpt_ref.gpt_train_step(sd, opt, batch, None, None, bf16=False, dropout_p=0.1)
-        n += 1
-    dt = (time.time() - t0) / n
-    return {"value": bs * MEL_LEN / dt, "unit": "audio-tokens/s", "cores": threads, "kind": "port",
-            "sample": "%d fp32 train steps (fwd+bwd+clip+AdamW, dropout 0.1) of the oracle at batch %d x (128 text + 1024 "
-                      "audio tokens), full 6-layer model, after 1 warm-up step; %.2f s/step" % (n, bs, dt)}
+    for cand in (8, 4, 2):                     # a batch-B step costs at most B x the batch-1 step
+        if cand * t1 <= seconds_budget * 0.5:
+            bs = cand
+            break
+    dt = timed(bs) if bs > 1 else t1
+    out = {"value": bs * MEL_LEN / dt, "unit": "audio-tokens/s", "cores": threads, "kind": "port",
+           "sample": "one fp32 train step (fwd+bwd+clip+AdamW, dropout 0.1) of the oracle at batch %d x (128 text + 1024 audio tokens), "
+                     "full 6-layer model, %d threads, after a warm-up step; %.2f s/step (batch 1: %.2f s/step)" % (bs, threads, dt, t1)}
+    t_bf = timed(1, bf16=True)
+    out["bf16_autocast"] = {"value": MEL_LEN / t_bf, "unit": "audio-tokens/s", "cores": threads,
+                            "sample": "one step at batch 1 with the bf16 rounding points of torch.autocast; %.2f s/step" % t_bf}
+    if threads > 8:
+        torch.set_num_threads(8)
+        timed(1)
+        t8 = timed(1)
+        out["threads8"] = {"value": MEL_LEN / t8, "unit": "audio-tokens/s", "cores": 8,
+                           "sample": "one fp32 step at batch 1 on 8 threads (the survey container's core count); %.2f s/step" % t8}
+        torch.set_num_threads(threads)
+    return out
 
 
 def main():
@@ -401,7 +423,28 @@ def main():
     torch.cuda.synchronize()
     dp.barrier()
     torch.cuda.synchronize()
-    elapsed = dp.max_over_ranks(time.perf_counter() - t0)
+    my_elapsed = time.perf_counter() - t0
+    elapsed = dp.max_over_ranks(my_elapsed)
+    # per-rank step times (every rank's own clock around the same barrier-bracketed region) and, for N > 1, the cost of the
+    # exchange by itself: one SUM all-reduce of the whole fp32 gradient arena, HIP events on the current stream, 5 repetitions
+    per_rank_ms = [round(my_elapsed / args.steps * 1e3, 3)]
+    allreduce_ms = None
+    if world > 1:
+        import torch.distributed as dist
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_rank_ms[0])
+        per_rank_ms = gathered
+        scratch = torch.zeros_like(eng.grads)
+        dp.allreduce_grads_(scratch)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dp.allreduce_grads_(scratch)
+        e1.record()
+        torch.cuda.synchronize()
+        allreduce_ms = dp.max_over_ranks(e0.elapsed_time(e1) / 5)
+        del scratch
     lt, lm = eng.losses()
     assert lt == lt and lm == lm, "non-finite loss"
     graphed = args.mode != "eager" and eng._graph is not None and eng._graph[0] is not None   # False after a refused capture
@@ -465,7 +508,9 @@ def main():
                           "mode": args.mode, "graph_replay": bool(graphed),
                           "exchange": (args.exchange if world > 1 else None),
                           "dist_backend": (torch.distributed.get_backend() if world > 1 else None), "world_size": world},
-               "final_loss_mel": round(lm, 4), "roofline": roof}
+               "final_loss_mel": round(lm, 4), "per_rank_ms_per_step": per_rank_ms,
+               "allreduce_arena_ms": (None if allreduce_ms is None else round(allreduce_ms, 3)),
+               "allreduce_arena_mb": (None if allreduce_ms is None else round(eng.grads.numel() * 4 / 2 ** 20, 1)), "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         if world == 1:

@@ -148,6 +148,38 @@ def test_train_steps_match_bf16_oracle_full_shape(gpt):
               open(os.path.join(ROOT, "gpurun_out", "diag", "train_steps.json"), "w"), indent=1)
 
 
+def test_grouped_dw_more_than_64_problems(gpt):
+    """17 layers = 68 weight-gradient problems: more than one grouped launch takes (64 descriptors); the chunked plans must give
+    the gradients of the one-GEMM-per-weight path."""
+    from oracle import gpt_ref
+    cfg = {"model_dim": 64, "max_mel_tokens": 64, "max_text_tokens": 32, "heads": 2, "layers": 17, "number_text_tokens": 256,
+           "number_mel_codes": 1026, "start_mel_token": 1024, "stop_mel_token": 1025, "start_text_token": 255}
+    g = torch.Generator().manual_seed(4)
+    text = torch.randint(1, 255, (2, 12), generator=g); mel = torch.randint(0, 1024, (2, 24), generator=g)
+    tl = torch.tensor([12, 9]); wl = torch.tensor([24, 20]) * 1024
+    grads = {}
+    prev = os.environ.get("TTTS_GROUPED_DW")
+    try:
+        for flag in ("1", "0"):
+            os.environ["TTTS_GROUPED_DW"] = flag
+            model = gpt.UnifiedVoice(**cfg, device="cuda:0", dropout_p=0.0, seed=3)
+            model.load_state_dict(gpt_ref.det_state_dict(cfg))
+            lt, lm, _ = model(text.cuda(), tl, mel.cuda(), wl)
+            (lt * 0.01 + lm).backward()
+            torch.cuda.synchronize()
+            if flag == "1":
+                plans, single = model.engine._dw_plan(0, 17)
+                assert len(plans) >= 2 and max(p_.n for p_ in plans) <= 64 and sum(p_.n for p_ in plans) + len(single) == 68
+            grads[flag] = model.engine.grads.clone()
+    finally:
+        if prev is None:
+            os.environ.pop("TTTS_GROUPED_DW", None)
+        else:
+            os.environ["TTTS_GROUPED_DW"] = prev
+    assert torch.isfinite(grads["1"]).all()
+    assert float((grads["1"] - grads["0"]).norm() / grads["0"].norm()) < 1e-5
+
+
 def test_ragged_batch_and_dropout_training(gpt):
     """Unequal lengths (clip + STOP padding) and dropout-on training: finite, and the loss goes down."""
     from oracle import gpt_ref
@@ -242,9 +274,10 @@ def test_grouped_weight_gradients_equal_the_per_weight_gemms(gpt, monkeypatch):
             eng.backward()
         torch.cuda.synchronize()
         if flag == "1":
-            plan, single = eng._dw_plan(0, eng.c["layers"])
-            _diag("grouped_dw_plan", {"grouped_tiles": plan.tiles, "grouped_problems": plan.n, "split_k_problems": len(single)})
-            assert plan.n + len(single) == 4 * eng.c["layers"]
+            plans, single = eng._dw_plan(0, eng.c["layers"])
+            _diag("grouped_dw_plan", {"grouped_tiles": sum(p_.tiles for p_ in plans), "grouped_problems": sum(p_.n for p_ in plans),
+                                      "split_k_problems": len(single)})
+            assert sum(p_.n for p_ in plans) + len(single) == 4 * eng.c["layers"]
         out[(flag, parts)] = (eng.grads.clone(), eng.losses(), dict(eng.offsets), {k: math_prod(s_) for k, s_ in eng.spec})
         del eng
     a, la, offs, sizes = out[("0", False)]
@@ -363,5 +396,42 @@ def test_ranged_gradient_exchange_two_ranks_sharing_the_gpu():
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                         "--master-addr", "127.0.0.1", "--master-port", str(29900 + os.getpid() % 90),
                         os.path.join(ROOT, "tools", "dp_consistency.py")], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "rank0-consistent" in r.stdout and "rank1-consistent" in r.stdout
+
+
+def _torchrun(script_args, port, env_extra=None, timeout=300):
+    import subprocess
+    import sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("TTTS_SHARE_GPU", None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                           "--master-addr", "127.0.0.1", "--master-port", str(port)] + script_args,
+                          capture_output=True, text=True, env=env, timeout=timeout)
+
+
+needs_two_gpus = pytest.mark.skipif(not torch.cuda.is_available() or torch.cuda.device_count() < 2,
+                                    reason="needs two GPUs: the RCCL (backend nccl) path, one rank per GPU")
+
+
+@needs_two_gpus
+def test_bench_two_ranks_nccl():
+    """bench.py --gpus 2 on the real multi-GPU path: one rank per GPU, RCCL all-reduce of the flat gradient arena on a side
+    stream next to the captured step graphs (auto-skipped on the 1-GPU test box; runs on any multi-GPU lease)."""
+    r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-vqvae",
+                   "--profile-steps", "1"], 29300 + os.getpid() % 90)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16 and out["value"] > 0 and out["scaling"] == "weak"
+    assert out["config"]["parallelism"] == "dp2" and len(out["per_rank_ms_per_step"]) == 2
+
+
+@needs_two_gpus
+def test_ranged_gradient_exchange_two_ranks_nccl():
+    """tools/dp_consistency.py on backend nccl: the overlapped ranged exchange == one whole-arena all-reduce, replicas identical."""
+    r = _torchrun([os.path.join(ROOT, "tools", "dp_consistency.py")], 29700 + os.getpid() % 90)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     assert "rank0-consistent" in r.stdout and "rank1-consistent" in r.stdout

@@ -403,7 +403,7 @@ def test_reference_import_names_and_signatures():
 
 
 def test_attention_dropout_product_scheme_statistics():
-    """numpy emulation of the attention keep-mask (csrc/attn.hip: row hash R, odd 24-bit column multiplier M with the top bit
+    """numpy emulation of the attention keep-mask (csrc/attn_common.hpp: row hash R with bit 23 set, odd 24-bit column multiplier M with the top bit
     set, keep iff (R[23:0] * M + R) mod 2^32 >= thr << 16): keep rate, 256-bin chi-square of the compared word, lag-1..8 row /
     column correlations, the 2 x 2 interaction and per-row / per-column drop rates all at the level of independent draws."""
     def hash32(x, lo, hi):
@@ -422,7 +422,7 @@ def test_attention_dropout_product_scheme_statistics():
     ids = np.arange(S, dtype=np.uint32) + np.uint32(3 * S)              # (b*H + h)*S + position for some (b, h)
     with np.errstate(over="ignore"):
         for seed_lo, seed_hi in ((0x1234567, 0x89ABCDE), (7, 0xC0FFEE), (0xDEADBEEF, 1)):
-            R = hash32(ids, seed_lo, seed_hi).astype(np.uint64)
+            R = (hash32(ids, seed_lo, seed_hi) | np.uint32(0x800000)).astype(np.uint64)   # drop_row_hash: bit 23 forced
             M = ((hash32(ids, seed_lo ^ 0x5BD1E995, seed_hi) & np.uint32(0xFFFFFF)) | np.uint32(0x800001)).astype(np.uint64)
             word = ((R[:, None] & 0xFFFFFF) * M[None, :] + R[:, None]) & 0xFFFFFFFF
             keep = word >= (thr << 16)

@@ -44,7 +44,7 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
-// Attention dropout keep-mask (round 2): PRODUCT scheme.  Every query row gets one strong 32-bit hash R (of
+// Attention dropout keep-mask (round 2): PRODUCT scheme.  Every query row gets one strong 32-bit hash R with bit 23 set (of
 // (b*H + h)*S + query), every key column one odd 24-bit multiplier M with its top bit set (a hash of (b*H + h)*S + key under a
 // tweaked seed); the pair (query, key) is kept iff  (R[23:0] * M + R) mod 2^32  >=  thr << 16  -- one v_mad_u32_u24, one
 // compare, one select per score (the pair-shared counter hash of round 1 cost ~9 VALU per score: more cycles than the
@@ -53,7 +53,9 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
 // interaction and per-row / per-column rates are indistinguishable from independent Bernoulli draws in a numpy emulation
 // (tests/test_host_cpu.py::test_attention_dropout_product_scheme_statistics).  Both layouts evaluate it cheaply: the
 // lane-owned operand is hashed once per kernel, the other comes from a 64-entry LDS table filled once per tile.
-__device__ __forceinline__ uint32_t drop_row_hash(uint32_t rowid, uint32_t slo, uint32_t shi) { return hash32(rowid, slo, shi); }
+// (bit 23 of the row word is forced, like the multiplier's: with a small R[23:0] -- one row in 2^15 -- R[23:0] * M spans less than
+// one wrap of 2^32 and the whole row would be kept or dropped together)
+__device__ __forceinline__ uint32_t drop_row_hash(uint32_t rowid, uint32_t slo, uint32_t shi) { return hash32(rowid, slo, shi) | 0x800000u; }
 __device__ __forceinline__ uint32_t drop_col_mult(uint32_t colid, uint32_t slo, uint32_t shi) {
   return (hash32(colid, slo ^ 0x5BD1E995u, shi) & 0xFFFFFFu) | 0x800001u;
 }

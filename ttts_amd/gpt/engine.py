@@ -277,13 +277,15 @@ class GptEngine:
         out = left_out_problems(tiles, 2 * ops.device_info()["cus"])
         grouped = [pr for j, pr in enumerate(probs) if j not in out]
         single = [pr for j, pr in enumerate(probs) if j in out]
-        plan = ops.TnPlan(grouped, self.device) if grouped else None
-        self._dw_plans[key] = (plan, single)
+        # one launch takes at most 64 descriptors (the kernel finds its problem with one lane per descriptor): models deeper than
+        # 16 layers (the reference constructor accepts e.g. 30) run their grouped problems in chunks
+        plans = [ops.TnPlan(grouped[j:j + ops.TN_GROUP_MAX], self.device) for j in range(0, len(grouped), ops.TN_GROUP_MAX)]
+        self._dw_plans[key] = (plans, single)
         return self._dw_plans[key]
 
     def _run_dw(self, lo, hi):
-        plan, single = self._dw_plan(lo, hi)
-        if plan is not None:
+        plans, single = self._dw_plan(lo, hi)
+        for plan in plans:
             plan.run()
         for at, bt, g in single:
             ops.gemm_tn_accum(at, bt, g, workspace=self.b["tn_ws"])

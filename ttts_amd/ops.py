@@ -87,6 +87,9 @@ def gemm_tn_accum(at, bt, c, mo=None, no=None, workspace=None, kr=None):
     return c
 
 
+TN_GROUP_MAX = 64   # descriptors per grouped launch (include/ttts_hip.h: ttts_tn_desc_prepare)
+
+
 class TnPlan:
     """Device-resident descriptor table of a grouped weight-gradient GEMM: c_i[Mo,No] += at_i[Kr,Mo]^T @ bt_i[Kr,No] for
     every entry in ONE launch, each 128x128 output tile reduced over its whole Kr by one workgroup (no slabs).
@@ -584,21 +587,20 @@ def stft_filter_istft(wav, window, n_fft, hop, H=None, clamp=True, peak_normaliz
     return out
 
 
-_mel_bands = {}
-
-
 def mel_bands(basis):
-    """int32 [n_mels, 2] = first / last non-zero column of every basis row (cached per basis tensor; one host computation)."""
-    key = (basis.data_ptr(), tuple(basis.shape), basis._version)
-    if key not in _mel_bands:
+    """int32 [n_mels, 2] = first / last non-zero column of every basis row.  The table is attached to the basis tensor itself
+    (one host computation per basis, no global cache: two bases used alternately keep their own tables, and a table can never
+    outlive -- or be mistaken for that of -- another tensor at a recycled address)."""
+    tab = getattr(basis, "_ttts_bands", None)
+    if tab is None or tab[0] != basis._version:
         nz = (basis != 0).cpu()
         n_bins = basis.shape[1]
         cols = torch.arange(n_bins)
         lo = torch.where(nz, cols, torch.full_like(cols, n_bins)).min(dim=1).values
         hi = torch.where(nz, cols, torch.full_like(cols, -1)).max(dim=1).values
-        _mel_bands.clear()
-        _mel_bands[key] = torch.stack([lo, hi], dim=1).to(torch.int32).contiguous().to(basis.device)
-    return _mel_bands[key]
+        tab = (basis._version, torch.stack([lo, hi], dim=1).to(torch.int32).contiguous().to(basis.device))
+        basis._ttts_bands = tab
+    return tab[1]
 
 
 def mel_log(spec, basis):
@@ -1009,17 +1011,26 @@ def dropout_counter(device):
     """The dropout stream counter of `device` (int32 [1], created on first use, owned here -- the C library is stateless and
     receives the pointer as an explicit argument of every dropout-capable call).  Increment it once per training step
     (`counter.add_(1)`, capturable) for fresh masks; operators called with dropout_p > 0 and no explicit `counter=` use it."""
-    key = str(torch.device(device))
+    key = _device_key(device)
     if key not in _dropout_counters:
-        _dropout_counters[key] = torch.zeros(1, dtype=torch.int32, device=device)
+        _dropout_counters[key] = torch.zeros(1, dtype=torch.int32, device=key)
     return _dropout_counters[key]
+
+
+def _device_key(device):
+    """'cuda:<index>' for any spelling of a GPU device ('cuda' names the current one): a counter registered under 'cuda' must be
+    found by tensors that report 'cuda:0' -- otherwise graph replays would reuse one captured dropout mask."""
+    d = torch.device(device)
+    if d.type != "cuda":
+        return str(d)
+    return "cuda:%d" % (d.index if d.index is not None else torch.cuda.current_device())
 
 
 def _ctr(counter, like, dropout_p):
     """Device pointer of the dropout counter an operator call uses: the explicit one, else (when dropout is on) the
     device's default counter if one was created, else NULL."""
     if counter is None and dropout_p > 0.0:
-        counter = _dropout_counters.get(str(like.device))
+        counter = _dropout_counters.get(_device_key(like.device))
     return _p(counter)
 
 
