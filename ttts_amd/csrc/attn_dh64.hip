@@ -132,7 +132,9 @@ __device__ __forceinline__ uint32_t ds2(float p0, float p1, float dp0, float dp1
 
 // -------------------------------------------------------------------------------------------------------
 // forward: 128-query workgroups; wave w owns queries q0 + 32 w .. + 31 and walks all its 64-key tiles (a split of the key
-// range over wave pairs was measured: the per-wave prologue / merge / epilogue made up ~40 % of that kernel's VALU work).
+// range over wave pairs was measured: the per-wave prologue / merge / epilogue made up ~40 % of that kernel's VALU work; so was
+// a 64-query workgroup whose wave pairs split every tile's two 32-key blocks, one block per step: half the serial chain, +25 %
+// instructions, 34 us against this kernel's 30 -- DESIGN section 16 has the issue-rate model that explains both).
 // Pipelined per 32-key BLOCK: block b's softmax runs beside block b + 1's 4 score MFMAs and block b's own P.V MFMAs --
 // 32 score registers in flight, 144 VGPRs, three workgroups per CU.
 // K / V tiles live in two 3-slot rings.  Step j handles blocks 2j - 1 and 2j, which read K(j) only (for the next blocks'
