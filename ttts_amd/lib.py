@@ -39,7 +39,8 @@ def _needs_rebuild(obj, deps):
 def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 and link ttts_amd/libttts_hip.so (cross-compiles without a GPU)."""
     os.makedirs(BUILD, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.hpp"), os.path.join(os.path.dirname(HERE), "include", "ttts_hip.h")]
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp"))   # every source sees every header
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "ttts_hip.h"))
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
