@@ -34,7 +34,7 @@ extern "C" {
 #define TTTS_EHIP (-2)         /* a HIP runtime call or kernel launch failed */
 #define TTTS_EUNSUPPORTED (-3) /* valid request this build has no kernel for */
 
-#define TTTS_ABI_VERSION 4
+#define TTTS_ABI_VERSION 5
 
 /* ---- library ------------------------------------------------------------------------------------ */
 int ttts_abi_version(void);
@@ -112,6 +112,29 @@ typedef struct {
 } ttts_cast_desc;
 int32_t ttts_cast_desc_tiles(int32_t rows, int32_t cols);
 int ttts_cast_bf16_batched(const ttts_cast_desc* desc, int32_t n_desc, int32_t total_tiles, void* stream);
+/* Batched column sums (ABI v5): every bias gradient of a backward section in one launch -- the caller keeps its dY buffers
+ * until the end of the section, as for ttts_gemm_tn_grouped_bf16_accum_f32.  desc: DEVICE array, at most 64 entries;
+ * tile_begin = exclusive prefix sum of ttts_colsum_desc_tiles(M, N); same arithmetic per problem as the single call. */
+typedef struct {
+  const void* X;  /* bf16 [M, ldx]                         */
+  float* out;     /* f32 [N], accumulated                  */
+  int64_t ldx;    /* ldx % 8 == 0, ldx >= roundup8(N)      */
+  int32_t M, N;
+  int32_t tile_begin, reserved;
+} ttts_colsum_desc;
+int32_t ttts_colsum_desc_tiles(int32_t M, int32_t N);
+int ttts_colsum_bf16_accum_f32_batched(const ttts_colsum_desc* desc, int32_t n_desc, int32_t total_tiles, void* stream);
+/* Batched bf16 transpose (ABI v5): dst[c][r] = src[r][c] for up to 64 matrices in one launch (the second GEMM operand layout
+ * of the bf16 shadow weights, read from the bf16 shadow AdamW wrote instead of the fp32 master: half the read traffic of
+ * ttts_cast_bf16_batched's transposed path).  tile_begin = exclusive prefix sum of ttts_transpose_desc_tiles(rows, cols). */
+typedef struct {
+  const void* src; /* bf16 [rows, cols] row-major                    */
+  void* dst;       /* bf16 [cols, ldd] row-major, ldd >= rows        */
+  int32_t rows, cols;
+  int32_t ldd, tile_begin;
+} ttts_transpose_desc;
+int32_t ttts_transpose_desc_tiles(int32_t rows, int32_t cols);
+int ttts_transpose_bf16_batched(const ttts_transpose_desc* desc, int32_t n_desc, int32_t total_tiles, void* stream);
 
 /* ---- causal self-attention (flash-style, bf16 I/O, fp32 softmax) -----------------------------------
  * Replaces: GPT2Attention core, modeling_gpt2.py:53-72 (eager) / sdpa, reached from ttts/gpt/model.py:422.
@@ -161,6 +184,17 @@ int ttts_layernorm_bwd_ex(const void* dy, int32_t dy_is_bf16, const float* x, co
                           float* dgamma, float* dbeta, float* dcolsum, void* workspace, int32_t M, int32_t D,
                           int32_t split_S, int32_t split_T, float bf16_dropout_p, uint64_t bf16_dropout_seed,
                           const uint32_t* dropout_counter, void* stream);
+/* Deferred parameter gradients (ABI v5): with dgamma == dbeta == NULL the call leaves its per-workgroup partial sums in
+ * `workspace` (which then must be this call's own until the finalize) and ttts_layernorm_bwd_finalize_batched adds up the
+ * partial sums of up to 65535 such calls (same M, D) in one launch: 14 launches -> 1 in the GPT train step. */
+typedef struct {
+  const void* workspace;   /* the workspace a deferred ttts_layernorm_bwd_ex call wrote */
+  float* dgamma;           /* f32 [D], accumulated */
+  float* dbeta;            /* f32 [D], accumulated */
+  float* dcolsum;          /* f32 [D], accumulated; or NULL */
+} ttts_ln_finalize_desc;
+int ttts_layernorm_bwd_finalize_batched(const ttts_ln_finalize_desc* desc /* device */, int32_t n_desc, int32_t M, int32_t D,
+                                        void* stream);
 
 /* ---- embeddings ----------------------------------------------------------------------------------
  * Replaces: ttts/gpt/model.py:488,494-495,418 -- token + learned-position embedding sums of the text

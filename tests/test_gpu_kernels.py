@@ -175,6 +175,47 @@ def test_colsum_and_cast(ops):
     assert torch.equal(t2[:, :257], w2.t().to(torch.bfloat16)) and float(t2[:, 257:].abs().max()) == 0.0
 
 
+def test_batched_transpose_colsum_and_deferred_layernorm_finalize(ops):
+    """ABI v5 batched forms against their single-call forms: bf16 transposes (ragged and padded destinations), column sums
+    (several problems, a ragged N), LayerNorm parameter gradients left in per-call workspaces and finished in one launch."""
+    g = torch.Generator(device="cpu").manual_seed(11)
+    srcs = [_bf(torch.randn(r, c, generator=g)).to(dev()) for r, c in ((512, 1536), (257, 512), (70, 72), (64, 64))]
+    dsts = [torch.zeros(1536, 512, dtype=torch.bfloat16, device=dev()), torch.zeros(512, 264, dtype=torch.bfloat16, device=dev()),
+            torch.zeros(72, 70, dtype=torch.bfloat16, device=dev()), torch.zeros(64, 64, dtype=torch.bfloat16, device=dev())]
+    ops.TransposePlan([(srcs[0], dsts[0]), (srcs[1], dsts[1][:, :257]), (srcs[2], dsts[2]), (srcs[3], dsts[3])], dev()).run()
+    assert torch.equal(dsts[0], srcs[0].t()) and torch.equal(dsts[1][:, :257], srcs[1].t()) and float(dsts[1][:, 257:].abs().max()) == 0.0
+    assert torch.equal(dsts[2], srcs[2].t()) and torch.equal(dsts[3], srcs[3].t())
+    xs = [_bf(torch.randn(m, n, generator=g)).to(dev()) for m, n in ((999, 264), (9248, 1536), (300, 2048))]
+    outs = [torch.ones(n, device=dev()) for n in (257, 1536, 2048)]
+    refs = [o.clone() for o in outs]
+    for x, r, n in zip(xs, refs, (257, None, None)):
+        ops.colsum_accum(x, r, n=n)
+    ops.ColsumPlan([(xs[0], outs[0], 257), (xs[1], outs[1], None), (xs[2], outs[2], None)], dev()).run()
+    for o, r in zip(outs, refs):
+        assert rel_err(o, r) < 1e-5
+    M, D = 1300, 512
+    ent, want = [], []
+    for k in range(3):
+        x = torch.randn(M, D, generator=g).to(dev()); dy = _bf(torch.randn(M, D, generator=g)).to(dev())
+        gamma = (1 + 0.1 * torch.randn(D, generator=g)).to(dev())
+        mean = x.mean(1).contiguous(); rstd = (x.var(1, unbiased=False) + 1e-5).rsqrt().contiguous()
+        dx = torch.empty(M, D, device=dev()); dxb = torch.empty(M, D, dtype=torch.bfloat16, device=dev())
+        ref = [torch.zeros(D, device=dev()) for _ in range(3)]
+        ops.layernorm_bwd(dy, x, gamma, mean, rstd, None, dx, dxb, ref[0], ref[1], ops.layernorm_bwd_workspace(M, D, dev()),
+                          dcolsum=ref[2] if k != 1 else None)
+        ws = ops.layernorm_bwd_workspace(M, D, dev())
+        dx2 = torch.empty_like(dx); dxb2 = torch.empty_like(dxb)
+        ops.layernorm_bwd(dy, x, gamma, mean, rstd, None, dx2, dxb2, None, None, ws)
+        assert torch.equal(dx, dx2) and torch.equal(dxb, dxb2)
+        got = [torch.zeros(D, device=dev()) for _ in range(3)]
+        ent.append((ws, got[0], got[1], got[2] if k != 1 else None))
+        want.append((ref, got, k))
+    ops.LnFinalizePlan(ent, M, D, dev()).run()
+    for ref, got, k in want:
+        assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1])        # same kernels' sums in the same order
+        assert torch.equal(ref[2], got[2]) if k != 1 else float(got[2].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("M,D,split", [(520, 512, (0, 0)), (9248, 512, (1156, 130)), (76, 64, (38, 14)), (64, 1024, (0, 0))])
 def test_layernorm_fwd_bwd(ops, M, D, split):
     g = torch.Generator(device="cpu").manual_seed(M)

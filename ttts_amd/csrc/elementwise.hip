@@ -51,7 +51,8 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
   }
 }
 
-// one thread per (t, d4): deterministic batch sum for the positional tables, atomics for the token tables
+// one thread per (t, d): deterministic batch sum for the positional tables, atomics for the token tables.  A wave's 64 atomics
+// of one batch row cover 256 contiguous bytes of one table row (the float4-per-thread form spread them over 1 KB: 67 us -> 25 us).
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ text_inp,
                                                         const int64_t* __restrict__ mel_inp,
                                                         const float* __restrict__ dx, float* __restrict__ d_text_emb,
@@ -61,39 +62,26 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
                                                         uint32_t seed_hi, const uint32_t* ctr) {
   if (thr) seed_hi = seed_mix(seed_hi, ctr);
   const int S = Tt + Tm;
-  const int D4 = D >> 2;
-  const int64_t total = (int64_t)S * D4;
+  const int64_t total = (int64_t)S * D;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const int d4 = (int)(i % D4);
-  const int t = (int)(i / D4);
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int d = (int)(i % D);
+  const int t = (int)(i / D);
+  float acc = 0.f;
+#pragma unroll 4
   for (int b = 0; b < B; ++b) {
-    const int64_t lin = ((int64_t)b * S + t) * D4 + d4;
-    float4 g = reinterpret_cast<const float4*>(dx)[lin];
-    if (thr) {
-      const uint32_t r0 = hash32((uint32_t)(lin * 2), seed_lo, seed_hi);
-      const uint32_t r1 = hash32((uint32_t)(lin * 2 + 1), seed_lo, seed_hi);
-      g.x = (r0 & 0xFFFFu) >= thr ? g.x * inv_keep : 0.f;
-      g.y = (r0 >> 16) >= thr ? g.y * inv_keep : 0.f;
-      g.z = (r1 & 0xFFFFu) >= thr ? g.z * inv_keep : 0.f;
-      g.w = (r1 >> 16) >= thr ? g.w * inv_keep : 0.f;
+    const int64_t lin = ((int64_t)b * S + t) * D + d;
+    float g = dx[lin];
+    if (thr) {                                                  // the mask of embed_fwd: one hash word per element pair
+      const uint32_t r = hash32((uint32_t)(lin >> 1), seed_lo, seed_hi);
+      g = ((d & 1) ? (r >> 16) : (r & 0xFFFFu)) >= thr ? g * inv_keep : 0.f;
     }
-    acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
-    float* dst;
-    if (t < Tt) {
-      dst = d_text_emb + text_inp[(int64_t)b * Tt + t] * D + d4 * 4;
-    } else {
-      dst = d_mel_emb + mel_inp[(int64_t)b * Tm + (t - Tt)] * D + d4 * 4;
-    }
-    atomicAdd(dst + 0, g.x);
-    atomicAdd(dst + 1, g.y);
-    atomicAdd(dst + 2, g.z);
-    atomicAdd(dst + 3, g.w);
+    acc += g;
+    float* dst = t < Tt ? d_text_emb + text_inp[(int64_t)b * Tt + t] * D + d : d_mel_emb + mel_inp[(int64_t)b * Tm + (t - Tt)] * D + d;
+    atomicAdd(dst, g);
   }
-  float4* pos = reinterpret_cast<float4*>(t < Tt ? d_text_pos + (int64_t)t * D : d_mel_pos + (int64_t)(t - Tt) * D) + d4;
-  float4 old = *pos;
-  *pos = make_float4(old.x + acc.x, old.y + acc.y, old.z + acc.z, old.w + acc.w);
+  float* pos = (t < Tt ? d_text_pos + (int64_t)t * D : d_mel_pos + (int64_t)(t - Tt) * D) + d;
+  *pos += acc;
 }
 
 // ======================================================================================================
@@ -106,63 +94,80 @@ __device__ __forceinline__ int64_t split_row(int64_t row, int split_S, int split
   return t < split_T ? b * split_T + t : (int64_t)nB * split_T + b * (split_S - split_T) + (t - split_T);
 }
 
+constexpr int LN_FWD_RPW = 2;   // rows per wave: both rows' loads are in flight before the first reduction (no gain measured at M = 9248: 8.1 us either way, a latency-bound launch)
 template <int VPL, bool OUT_BF16>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, void* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out, int M,
                                                      int D, float eps, int split_S, int split_T) {
   const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
-  const float* xr = x + row * D;
-  float4 v[VPL];
-  float s = 0.f;
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_FWD_RPW;
+  if (row0 >= M) return;
+  float4 v[LN_FWD_RPW][VPL];
+  float s[LN_FWD_RPW];
 #pragma unroll
-  for (int i = 0; i < VPL; ++i) {
-    const int d = (lane + i * 64) * 4;
-    v[i] = d < D ? *reinterpret_cast<const float4*>(xr + d) : make_float4(0.f, 0.f, 0.f, 0.f);
-    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-  }
-  const float mean = wave_sum(s) / (float)D;
-  float q = 0.f;
+  for (int r = 0; r < LN_FWD_RPW; ++r) {
+    const float* xr = x + min(row0 + r, (int64_t)M - 1) * D;
+    s[r] = 0.f;
 #pragma unroll
-  for (int i = 0; i < VPL; ++i) {
-    const int d = (lane + i * 64) * 4;
-    if (d < D) {
-      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, e = v[i].w - mean;
-      q += (a * a + b * b) + (c * c + e * e);
+    for (int i = 0; i < VPL; ++i) {
+      const int d = (lane + i * 64) * 4;
+      v[r][i] = d < D ? *reinterpret_cast<const float4*>(xr + d) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
-  const float var = wave_sum(q) / (float)D;
-  const float rstd = 1.0f / sqrtf(var + eps);
-  if (lane == 0) {
-    mean_out[row] = mean;
-    rstd_out[row] = rstd;
-  }
-  const int64_t orow = split_row(row, split_S, split_T, split_S > 0 ? M / split_S : 0);
+  float4 g[VPL], bt[VPL];
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
     const int d = (lane + i * 64) * 4;
-    if (d < D) {
-      const float4 g = *reinterpret_cast<const float4*>(gamma + d);
-      const float4 b = *reinterpret_cast<const float4*>(beta + d);
-      float4 o;
-      o.x = (v[i].x - mean) * rstd * g.x + b.x;
-      o.y = (v[i].y - mean) * rstd * g.y + b.y;
-      o.z = (v[i].z - mean) * rstd * g.z + b.z;
-      o.w = (v[i].w - mean) * rstd * g.w + b.w;
-      if (OUT_BF16) {
-        bf16x4 ob;
-        ob[0] = (bf16)o.x; ob[1] = (bf16)o.y; ob[2] = (bf16)o.z; ob[3] = (bf16)o.w;
-        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(y) + orow * D + d) = ob;
-      } else {
-        *reinterpret_cast<float4*>(reinterpret_cast<float*>(y) + orow * D + d) = o;
+    g[i] = d < D ? *reinterpret_cast<const float4*>(gamma + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+    bt[i] = d < D ? *reinterpret_cast<const float4*>(beta + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int nB = split_S > 0 ? M / split_S : 0;
+#pragma unroll
+  for (int r = 0; r < LN_FWD_RPW; ++r) {
+    const int64_t row = row0 + r;
+    if (row >= M) break;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) s[r] += (v[r][i].x + v[r][i].y) + (v[r][i].z + v[r][i].w);
+    const float mean = wave_sum(s[r]) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int d = (lane + i * 64) * 4;
+      if (d < D) {
+        const float a = v[r][i].x - mean, b = v[r][i].y - mean, c = v[r][i].z - mean, e = v[r][i].w - mean;
+        q += (a * a + b * b) + (c * c + e * e);
+      }
+    }
+    const float var = wave_sum(q) / (float)D;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (lane == 0) {
+      mean_out[row] = mean;
+      rstd_out[row] = rstd;
+    }
+    const int64_t orow = split_row(row, split_S, split_T, nB);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int d = (lane + i * 64) * 4;
+      if (d < D) {
+        float4 o;
+        o.x = (v[r][i].x - mean) * rstd * g[i].x + bt[i].x;
+        o.y = (v[r][i].y - mean) * rstd * g[i].y + bt[i].y;
+        o.z = (v[r][i].z - mean) * rstd * g[i].z + bt[i].z;
+        o.w = (v[r][i].w - mean) * rstd * g[i].w + bt[i].w;
+        if (OUT_BF16) {
+          bf16x4 ob;
+          ob[0] = (bf16)o.x; ob[1] = (bf16)o.y; ob[2] = (bf16)o.z; ob[3] = (bf16)o.w;
+          *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(y) + orow * D + d) = ob;
+        } else {
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(y) + orow * D + d) = o;
+        }
       }
     }
   }
 }
 
-constexpr int LN_BWD_ROWS = 8;   // rows per block (2 per wave): 1156 workgroups at M = 9248 keep ~18 waves per CU in flight
+constexpr int LN_BWD_ROWS = 8;   // rows per block (2 per wave): 1156 workgroups at M = 9248 keep ~18 waves per CU in flight (16 rows: kernel 17 -> 21 us, more than the halved partial sums give back)
 
 template <int VPL, bool DY_BF16>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, const float* __restrict__ x,
@@ -293,6 +298,30 @@ __global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* __re
   }
 }
 
+// the same for several deferred ttts_layernorm_bwd_ex calls in one launch: blockIdx.y picks the call
+__global__ __launch_bounds__(1024) void ln_bwd_finalize_batched_kernel(const ttts_ln_finalize_desc* __restrict__ desc, int nblk, int D) {
+  __shared__ float sh[LNF_LANES][LNF_COLS + 1];
+  const ttts_ln_finalize_desc dd = desc[blockIdx.y];
+  const float* partial = reinterpret_cast<const float*>(dd.workspace);
+  const int tx = threadIdx.x % LNF_COLS, ty = threadIdx.x / LNF_COLS;
+  const int j = blockIdx.x * LNF_COLS + tx;
+  float s = 0.f;
+  if (j < 3 * D) {
+#pragma unroll 4
+    for (int b = ty; b < nblk; b += LNF_LANES) s += partial[(size_t)b * 3 * D + j];
+  }
+  sh[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && j < 3 * D) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < LNF_LANES; ++r) t += sh[r][tx];
+    if (j < D) dd.dgamma[j] += t;
+    else if (j < 2 * D) dd.dbeta[j - D] += t;
+    else if (dd.dcolsum) dd.dcolsum[j - 2 * D] += t;
+  }
+}
+
 // ======================================================================================================
 // cross-entropy: one wave per row of bf16 logits
 // ======================================================================================================
@@ -407,6 +436,43 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ X,
   }
 }
 
+// several column sums in one launch: a workgroup finds its descriptor from the tile prefix sums (at most 64 descriptors)
+__global__ __launch_bounds__(256) void colsum_batched_kernel(const ttts_colsum_desc* __restrict__ desc, int n_desc) {
+  __shared__ float sh[32][65];
+  int di = 0;
+  for (int i = 1; i < n_desc; ++i)
+    if ((int)blockIdx.x >= desc[i].tile_begin) di = i;
+  const ttts_colsum_desc d = desc[di];
+  const bf16* X = reinterpret_cast<const bf16*>(d.X);
+  const int tiles_n = (d.N + 63) >> 6;
+  const int tl = blockIdx.x - d.tile_begin;
+  const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+  const int n0 = (tl % tiles_n) * 64 + tx * 8;
+  const int m0 = (tl / tiles_n) * COLSUM_ROWS;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (n0 < d.N) {
+#pragma unroll
+    for (int r = 0; r < COLSUM_ROWS / 32; ++r) {
+      const int m = m0 + ty + 32 * r;
+      if (m < d.M) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(X + (int64_t)m * d.ldx + n0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) sh[ty][tx * 8 + j] = acc[j];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) s += sh[r][threadIdx.x];
+    const int n = (tl % tiles_n) * 64 + threadIdx.x;
+    if (n < d.N) atomicAdd(d.out + n, s);
+  }
+}
+
 // ======================================================================================================
 // batched fp32 -> bf16 cast with optional transposed copy (32x32 tiles through LDS)
 // ======================================================================================================
@@ -438,6 +504,52 @@ __global__ __launch_bounds__(256) void cast_batched_kernel(const ttts_cast_desc*
   for (int i = 0; i < 4; ++i) {
     const int c = c0 + ty + 8 * i, r = r0 + tx;
     if (r < d.rows && c < d.cols) dst_t[(int64_t)c * (d.ldt > 0 ? d.ldt : d.rows) + r] = (bf16)tile[tx][ty + 8 * i];
+  }
+}
+
+// batched bf16 transpose, 64 x 64 tiles through LDS: 16-byte loads along the source rows, 16-byte stores along the destination
+// rows (the transposed GEMM operand copies of the bf16 shadow weights AdamW has just written)
+__global__ __launch_bounds__(256) void transpose_bf16_batched_kernel(const ttts_transpose_desc* __restrict__ desc, int n_desc) {
+  __shared__ bf16 tile[64][66];
+  int di = 0;
+  for (int i = 1; i < n_desc; ++i)
+    if ((int)blockIdx.x >= desc[i].tile_begin) di = i;
+  const ttts_transpose_desc d = desc[di];
+  const bf16* src = reinterpret_cast<const bf16*>(d.src);
+  bf16* dst = reinterpret_cast<bf16*>(d.dst);
+  const int tiles_c = (d.cols + 63) >> 6;
+  const int tl = blockIdx.x - d.tile_begin;
+  const int r0 = (tl / tiles_c) * 64, c0 = (tl % tiles_c) * 64;
+  const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;           // 8 chunks of 8 elements x 32 rows
+  const bool vec_in = (d.cols & 7) == 0 && ((uintptr_t)src & 15) == 0;
+  const bool vec_out = (d.ldd & 7) == 0 && ((uintptr_t)dst & 15) == 0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = r0 + ty + 32 * i, c = c0 + tx * 8;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
+    if (r < d.rows) {
+      if (vec_in && c + 8 <= d.cols) v = *reinterpret_cast<const bf16x8*>(src + (int64_t)r * d.cols + c);
+      else
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (c + e < d.cols) v[e] = src[(int64_t)r * d.cols + c + e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) tile[ty + 32 * i][tx * 8 + e] = v[e];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = c0 + ty + 32 * i, r = r0 + tx * 8;                // destination row c, columns r .. r + 7
+    if (c >= d.cols) continue;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = tile[tx * 8 + e][ty + 32 * i];
+    if (vec_out && r + 8 <= d.rows) *reinterpret_cast<bf16x8*>(dst + (int64_t)c * d.ldd + r) = v;
+    else
+#pragma unroll
+      for (int e = 0; e < 8; ++e) if (r + e < d.rows) dst[(int64_t)c * d.ldd + r + e] = v[e];
   }
 }
 
@@ -611,7 +723,7 @@ extern "C" int ttts_gpt_embed_bwd(const int64_t* text_inp, const int64_t* mel_in
                                   void* stream) {
   TTTS_REQUIRE(text_inp && mel_inp && dx && d_text_emb && d_text_pos && d_mel_emb && d_mel_pos, "embed_bwd: null pointer");
   TTTS_REQUIRE(B > 0 && Tt + Tm > 0 && D > 0 && D % 4 == 0, "embed_bwd: bad shape");
-  const int64_t total = (int64_t)(Tt + Tm) * (D / 4);
+  const int64_t total = (int64_t)(Tt + Tm) * D;
   const uint32_t thr = dropout_threshold(dropout_p);
   const float inv_keep = thr ? 65536.0f / (65536.0f - (float)thr) : 1.0f;
   embed_bwd_kernel<<<(int)cdiv(total, 256), 256, 0, as_stream(stream)>>>(text_inp, mel_inp, dx, d_text_emb, d_text_pos,
@@ -626,7 +738,7 @@ extern "C" int ttts_layernorm_fwd(const float* x, const float* gamma, const floa
   TTTS_REQUIRE(x && gamma && beta && y && mean && rstd, "layernorm_fwd: null pointer");
   TTTS_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "layernorm_fwd: need 0 < D <= 1024, D %% 4 == 0 (D=%d)", D);
   TTTS_REQUIRE(split_S <= 0 || (M % split_S == 0 && split_T >= 0 && split_T <= split_S), "layernorm_fwd: bad split");
-  const int grid = (int)cdiv(M, 4);
+  const int grid = (int)cdiv(M, 4 * LN_FWD_RPW);
   hipStream_t s = as_stream(stream);
 #define LN_FWD(V)                                                                                                     \
   if (y_is_bf16) ln_fwd_kernel<V, true><<<grid, 256, 0, s>>>(x, gamma, beta, y, mean, rstd, M, D, eps, split_S, split_T); \
@@ -645,7 +757,8 @@ static int layernorm_bwd_impl(const void* dy, int dy_is_bf16, const float* x, co
                               const float* rstd, const float* dx_in, float* dx, void* dx_bf16, float* dgamma,
                               float* dbeta, float* dcolsum, void* workspace, int M, int D, int split_S, int split_T,
                               float drop_p, uint64_t seed, const uint32_t* dropout_counter, hipStream_t s) {
-  TTTS_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && workspace, "layernorm_bwd: null pointer");
+  TTTS_REQUIRE(dy && x && gamma && mean && rstd && dx && workspace, "layernorm_bwd: null pointer");
+  TTTS_REQUIRE((dgamma != nullptr) == (dbeta != nullptr), "layernorm_bwd: dgamma and dbeta are given or deferred together");
   TTTS_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "layernorm_bwd: need 0 < D <= 1024, D %% 4 == 0 (D=%d)", D);
   TTTS_REQUIRE(split_S <= 0 || (M % split_S == 0 && split_T >= 0 && split_T <= split_S), "layernorm_bwd: bad split");
   TTTS_REQUIRE(!dcolsum || dx_bf16, "layernorm_bwd: dcolsum needs the bf16 copy");
@@ -664,9 +777,17 @@ static int layernorm_bwd_impl(const void* dy, int dy_is_bf16, const float* x, co
   if (D <= 256) { LN_BWD(1) } else if (D <= 512) { LN_BWD(2) } else { LN_BWD(4) }
 #undef LN_BWD
   int rc = check_launch("layernorm_bwd");
-  if (rc) return rc;
+  if (rc || !dgamma) return rc;           // deferred: the partial sums wait in the workspace for ttts_layernorm_bwd_finalize_batched
   ln_bwd_finalize_kernel<<<(int)cdiv(3 * D, LNF_COLS), 1024, 0, s>>>(partial, nblk, D, dgamma, dbeta, dcolsum);
   return check_launch("layernorm_bwd_finalize");
+}
+
+extern "C" int ttts_layernorm_bwd_finalize_batched(const ttts_ln_finalize_desc* desc, int32_t n_desc, int32_t M, int32_t D,
+                                                   void* stream) {
+  TTTS_REQUIRE(desc && n_desc > 0 && M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "layernorm_bwd_finalize_batched: bad arguments");
+  dim3 grid((unsigned)cdiv(3 * D, LNF_COLS), (unsigned)n_desc);
+  ln_bwd_finalize_batched_kernel<<<grid, 1024, 0, as_stream(stream)>>>(desc, (int)cdiv(M, LN_BWD_ROWS), D);
+  return check_launch("layernorm_bwd_finalize_batched");
 }
 
 extern "C" int ttts_layernorm_bwd(const void* dy, int32_t dy_is_bf16, const float* x, const float* gamma,
@@ -714,6 +835,22 @@ extern "C" int ttts_colsum_bf16_accum_f32(const void* X, int64_t ldx, float* out
   dim3 grid((unsigned)cdiv(N, 64), (unsigned)cdiv(M, COLSUM_ROWS));
   colsum_kernel<<<grid, 256, 0, as_stream(stream)>>>((const bf16*)X, ldx, out, M, N);
   return check_launch("colsum");
+}
+
+extern "C" int32_t ttts_colsum_desc_tiles(int32_t M, int32_t N) { return (int32_t)(cdiv(N, 64) * cdiv(M, COLSUM_ROWS)); }
+
+extern "C" int ttts_colsum_bf16_accum_f32_batched(const ttts_colsum_desc* desc, int32_t n_desc, int32_t total_tiles, void* stream) {
+  TTTS_REQUIRE(desc && n_desc > 0 && n_desc <= 64 && total_tiles > 0, "colsum_batched: need 1 .. 64 descriptors");
+  colsum_batched_kernel<<<total_tiles, 256, 0, as_stream(stream)>>>(desc, n_desc);
+  return check_launch("colsum_batched");
+}
+
+extern "C" int32_t ttts_transpose_desc_tiles(int32_t rows, int32_t cols) { return ((rows + 63) / 64) * ((cols + 63) / 64); }
+
+extern "C" int ttts_transpose_bf16_batched(const ttts_transpose_desc* desc, int32_t n_desc, int32_t total_tiles, void* stream) {
+  TTTS_REQUIRE(desc && n_desc > 0 && n_desc <= 64 && total_tiles > 0, "transpose_batched: need 1 .. 64 descriptors");
+  transpose_bf16_batched_kernel<<<total_tiles, 256, 0, as_stream(stream)>>>(desc, n_desc);
+  return check_launch("transpose_batched");
 }
 
 extern "C" int32_t ttts_cast_desc_tiles(int32_t rows, int32_t cols) { return ((rows + 31) / 32) * ((cols + 31) / 32); }

@@ -141,13 +141,13 @@ class GptEngine:
                 src = self.view(self.params, k)
                 t = torch.zeros(src.shape[1], src.shape[0], dtype=torch.bfloat16, device=dev)
                 self.wT[k] = t
-                entries.append((src, None, t))
+                entries.append((self.view(self.shadow, k), t))
         for k, ld in (("text_head.weight", self.ld_t), ("mel_head.weight", self.ld_m)):
             src = self.view(self.params, k)
             t = torch.zeros(d, ld, dtype=torch.bfloat16, device=dev)   # [in, out padded]; pad columns stay zero
             self.wT[k] = t
-            entries.append((src, None, t[:, :src.shape[0]]))
-        self.cast_plan = ops.CastPlan(entries, dev)
+            entries.append((self.view(self.shadow, k), t[:, :src.shape[0]]))
+        self.cast_plan = ops.TransposePlan(entries, dev)   # bf16 shadow -> its transposed copy (half the read traffic of the fp32 master)
         self._bufs_key = None
         self._graph = None
         self._graph_key = None
@@ -231,6 +231,8 @@ class GptEngine:
             b["d_fc_l"] = [z(M, 4 * D) for _ in range(L)]    # (was: d_fc)
             b["dqkv_l"] = [z(M, 3 * D) for _ in range(L)]    # (was: dqkv)
         b["ln_ws"] = ops.layernorm_bwd_workspace(M, D, dev)
+        if self.grouped_dw:   # one workspace per LayerNorm backward: their parameter-gradient sums are finished in ONE launch at the
+            b["ln_ws_l"] = [ops.layernorm_bwd_workspace(M, D, dev) for _ in range(2 * L + 2)]   # end of the section (_run_dw)
         tn_shapes = [(D, 3 * D, Mp), (D, D, Mp), (D, 4 * D, Mp), (4 * D, D, Mp), (self.nt, D, B * Tt), (self.nm, D, B * Tm)]
         b["tn_ws"] = max((ops.gemm_tn_workspace(mo, no, kr, dev) for mo, no, kr in tn_shapes), key=lambda t: t.numel())
         # static token buffers (graph replay reads them)
@@ -280,15 +282,36 @@ class GptEngine:
         # one launch takes at most 64 descriptors (the kernel finds its problem with one lane per descriptor): models deeper than
         # 16 layers (the reference constructor accepts e.g. 30) run their grouped problems in chunks
         plans = [ops.TnPlan(grouped[j:j + ops.TN_GROUP_MAX], self.device) for j in range(0, len(grouped), ops.TN_GROUP_MAX)]
-        self._dw_plans[key] = (plans, single)
+        # the other reductions over the rows that only feed the optimizer, also one launch each per section: LayerNorm dgamma /
+        # dbeta (+ the bias gradient of the projection consuming the bf16 copy) from the per-call partial sums, and the bias
+        # gradients that are plain column sums of a kept dY buffer
+        L = self.c["layers"]
+        ln, cs = [], []
+        if hi == L:
+            ln += [(b["ln_ws_l"][2 * L], G("final_norm.weight"), G("final_norm.bias"), None),
+                   (b["ln_ws_l"][2 * L + 1], G("gpt.ln_f.weight"), G("gpt.ln_f.bias"), G("gpt.h.%d.mlp.c_proj.bias" % (L - 1)))]
+            cs += [(b["dlog_t"], G("text_head.bias"), self.nt), (b["dlog_m"], G("mel_head.bias"), self.nm)]
+        for i in reversed(range(lo, hi)):
+            pre = "gpt.h.%d." % i
+            ln += [(b["ln_ws_l"][2 * i + 1], G(pre + "ln_2.weight"), G(pre + "ln_2.bias"), G(pre + "attn.c_proj.bias")),
+                   (b["ln_ws_l"][2 * i], G(pre + "ln_1.weight"), G(pre + "ln_1.bias"),
+                    G("gpt.h.%d.mlp.c_proj.bias" % (i - 1)) if i > 0 else None)]
+            cs += [(b["d_fc_l"][i], G(pre + "mlp.c_fc.bias"), None), (b["dqkv_l"][i], G(pre + "attn.c_attn.bias"), None)]
+        M, D = b["d_fc_l"][0].shape[0], self.c["model_dim"]
+        ln_plan = ops.LnFinalizePlan(ln, M, D, self.device)
+        cs_plans = [ops.ColsumPlan(cs[j:j + 64], self.device) for j in range(0, len(cs), 64)]
+        self._dw_plans[key] = (plans, single, ln_plan, cs_plans)
         return self._dw_plans[key]
 
     def _run_dw(self, lo, hi):
-        plans, single = self._dw_plan(lo, hi)
+        plans, single, ln_plan, cs_plans = self._dw_plan(lo, hi)
         for plan in plans:
             plan.run()
         for at, bt, g in single:
             ops.gemm_tn_accum(at, bt, g, workspace=self.b["tn_ws"])
+        ln_plan.run()
+        for plan in cs_plans:
+            plan.run()
 
     def _padded(self, t):
         """The zero-row-padded [Mp, c] buffer behind an [M, c] activation view (weight-gradient GEMM operand)."""
@@ -414,7 +437,7 @@ class GptEngine:
         ev_fc = ev_qkv = None            # side-stream reads of d_fc / dqkv by the previous layer
         for i in reversed(range(lo_layer, hi_layer)):
             ev_fc, ev_qkv = self._backward_layer(i, side, fork, done, wait, ev_fc, ev_qkv)
-        if self.grouped_dw and hi_layer > lo_layer:
+        if self.grouped_dw and (hi_layer > lo_layer or part in (None, 0)):
             self._run_dw(lo_layer, hi_layer)
         if part in (None, 1):
             ops.embed_bwd(b["text_inp"], b["mel_inp"], b["dres"], G("text_embedding.weight"),
@@ -438,17 +461,21 @@ class GptEngine:
         with torch.cuda.stream(side):
             ops.gemm_tn_accum(b["dlog_t"], enc_t, G("text_head.weight"), mo=self.nt, workspace=b["tn_ws"])
             ops.gemm_tn_accum(b["dlog_m"], enc_m, G("mel_head.weight"), mo=self.nm, workspace=b["tn_ws"])
-            ops.colsum_accum(b["dlog_t"], G("text_head.bias"), n=self.nt)
-            ops.colsum_accum(b["dlog_m"], G("mel_head.bias"), n=self.nm)
+            if not self.grouped_dw:      # grouped: part of the section's batched column-sum launch (_run_dw)
+                ops.colsum_accum(b["dlog_t"], G("text_head.bias"), n=self.nt)
+                ops.colsum_accum(b["dlog_m"], G("mel_head.bias"), n=self.nm)
         ops.gemm_nt(b["dlog_t"], self.wT["text_head.weight"], b["d_enc"][:B * Tt])
         ops.gemm_nt(b["dlog_m"], self.wT["mel_head.weight"], b["d_enc"][B * Tt:])
         fs = b["fstats"]
+        gd = self.grouped_dw             # grouped: dgamma / dbeta / dcolsum are finished by the section's batched launch (_run_dw)
         ops.layernorm_bwd(b["d_enc"], b["lnf"], P("final_norm.weight"), fs[2], fs[3], None, b["d_tmp"], None,
-                          G("final_norm.weight"), G("final_norm.bias"), b["ln_ws"], split=(S, Tt))
+                          None if gd else G("final_norm.weight"), None if gd else G("final_norm.bias"),
+                          b["ln_ws_l"][2 * L] if gd else b["ln_ws"], split=(S, Tt))
         ops.layernorm_bwd(b["d_tmp"], b["xs"][2 * L], P("gpt.ln_f.weight"), fs[0], fs[1], None, b["dres"],
-                          b["dy_mlp"][L - 1] if self.grouped_dw else b["dres_bf"],
-                          G("gpt.ln_f.weight"), G("gpt.ln_f.bias"), b["ln_ws"], dropout_p=p,
-                          seed=self._seed(16 * (L - 1) + 4), dcolsum=G("gpt.h.%d.mlp.c_proj.bias" % (L - 1)), counter=self.seed_ctr)
+                          b["dy_mlp"][L - 1] if gd else b["dres_bf"],
+                          None if gd else G("gpt.ln_f.weight"), None if gd else G("gpt.ln_f.bias"),
+                          b["ln_ws_l"][2 * L + 1] if gd else b["ln_ws"], dropout_p=p, seed=self._seed(16 * (L - 1) + 4),
+                          dcolsum=None if gd else G("gpt.h.%d.mlp.c_proj.bias" % (L - 1)), counter=self.seed_ctr)
 
     def _backward_layer(self, i, side, fork, done, wait, ev_fc, ev_qkv):
         c, b = self.c, self.b
@@ -506,7 +533,8 @@ class GptEngine:
 
     def _backward_layer_grouped(self, i):
         """The data-gradient chain of layer i alone: every dY goes to this layer's own buffer and the four weight
-        gradients are left to the grouped launch at the end of the section (_run_dw); bias gradients stay here."""
+        gradients, the bias gradients and the LayerNorm parameter gradients are left to the batched launches at the end of the
+        section (_run_dw)."""
         c, b = self.c, self.b
         B, Tt, Tm = self._bufs_key
         D, H = c["model_dim"], c["heads"]
@@ -519,22 +547,18 @@ class GptEngine:
         x0, x1 = b["xs"][2 * i], b["xs"][2 * i + 1]
         dy, d_fc, dy_att, dqkv = b["dy_mlp"][i], b["d_fc_l"][i], b["dy_att"][i], b["dqkv_l"][i]
         self._nt(dy, self.w(pre + "mlp.c_proj.weight"), d_fc, aux=b["fc_pre"][i], epilogue=EPI_DGELU_BF16)
-        ops.colsum_accum(d_fc, G(pre + "mlp.c_fc.bias"))
         self._nt(d_fc, self.w(pre + "mlp.c_fc.weight"), b["d_ln"])
         ops.layernorm_bwd(b["d_ln"], x1, P(pre + "ln_2.weight"), st[2], st[3], b["dres"], b["dres"], dy_att,
-                          G(pre + "ln_2.weight"), G(pre + "ln_2.bias"), b["ln_ws"], dropout_p=p,
-                          seed=self._seed(16 * i + 3), dcolsum=G(pre + "attn.c_proj.bias"), counter=self.seed_ctr)
+                          None, None, b["ln_ws_l"][2 * i + 1], dropout_p=p, seed=self._seed(16 * i + 3), counter=self.seed_ctr)
         self._nt(dy_att, self.w(pre + "attn.c_proj.weight"), b["d_att"])
         qkv = b["qkv"][i]
         ops.attn_bwd(qkv, qkv[:, D:], qkv[:, 2 * D:], b["att"][i], b["d_att"], b["lse"][i], dqkv, dqkv[:, D:],
                      dqkv[:, 2 * D:], b["delta"], B, H, S, dh, (S * 3 * D, 3 * D), (S * D, D), dh ** -0.5, p,
                      self._seed(16 * i + 2), counter=self.seed_ctr)
-        ops.colsum_accum(dqkv, G(pre + "attn.c_attn.bias"))
         self._nt(dqkv, self.w(pre + "attn.c_attn.weight"), b["d_ln"])
         ops.layernorm_bwd(b["d_ln"], x0, P(pre + "ln_1.weight"), st[0], st[1], b["dres"], b["dres"],
-                          b["dy_mlp"][i - 1] if i > 0 else None, G(pre + "ln_1.weight"), G(pre + "ln_1.bias"),
-                          b["ln_ws"], dropout_p=p if i > 0 else 0.0, seed=self._seed(16 * (i - 1) + 4),
-                          dcolsum=G("gpt.h.%d.mlp.c_proj.bias" % (i - 1)) if i > 0 else None, counter=self.seed_ctr)
+                          b["dy_mlp"][i - 1] if i > 0 else None, None, None, b["ln_ws_l"][2 * i],
+                          dropout_p=p if i > 0 else 0.0, seed=self._seed(16 * (i - 1) + 4), counter=self.seed_ctr)
         return None, None
 
     def _side_stream(self):

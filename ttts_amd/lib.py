@@ -67,12 +67,24 @@ _c = ctypes
 _P, _I32, _I64, _U64, _F = _c.c_void_p, _c.c_int32, _c.c_int64, _c.c_uint64, _c.c_float
 
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class ConvCtx(ctypes.Structure):
     """include/ttts_hip.h: ttts_conv_ctx (caller-owned; the library keeps no copy)."""
     _fields_ = [("workspace", _P), ("workspace_bytes", _I64), ("flags", _I32), ("reserved", _I32)]
+
+
+class LnFinalizeDesc(ctypes.Structure):
+    _fields_ = [("workspace", _P), ("dgamma", _P), ("dbeta", _P), ("dcolsum", _P)]
+
+
+class ColsumDesc(ctypes.Structure):
+    _fields_ = [("X", _P), ("out", _P), ("ldx", _I64), ("M", _I32), ("N", _I32), ("tile_begin", _I32), ("reserved", _I32)]
+
+
+class TransposeDesc(ctypes.Structure):
+    _fields_ = [("src", _P), ("dst", _P), ("rows", _I32), ("cols", _I32), ("ldd", _I32), ("tile_begin", _I32)]
 
 
 class CastDesc(ctypes.Structure):
@@ -99,6 +111,11 @@ SIGNATURES = {
     "ttts_tn_desc_prepare": (_I32, [_P, _I32, _P]),
     "ttts_gemm_tn_grouped_bf16_accum_f32": (_I32, [_P, _I32, _I32, _P]),
     "ttts_colsum_bf16_accum_f32": (_I32, [_P, _I64, _P, _I32, _I32, _P]),
+    "ttts_layernorm_bwd_finalize_batched": (_I32, [_P, _I32, _I32, _I32, _P]),
+    "ttts_colsum_desc_tiles": (_I32, [_I32, _I32]),
+    "ttts_colsum_bf16_accum_f32_batched": (_I32, [_P, _I32, _I32, _P]),
+    "ttts_transpose_desc_tiles": (_I32, [_I32, _I32]),
+    "ttts_transpose_bf16_batched": (_I32, [_P, _I32, _I32, _P]),
     "ttts_cast_desc_tiles": (_I32, [_I32, _I32]),
     "ttts_cast_bf16_batched": (_I32, [_P, _I32, _I32, _P]),
     "ttts_attn_causal_fwd_bf16": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _F, _F,

@@ -14,7 +14,7 @@ from .lib import (EPI_DGELU_BF16, EPI_GELU_BF16, EPI_RESID_ADD_F32, EPI_STORE_BF
 
 __all__ = ["gemm_nt", "gemm_tn_accum", "colsum_accum", "attn_fwd", "attn_bwd", "layernorm_fwd", "layernorm_bwd",
            "embed_fwd", "embed_bwd", "ce_fwd", "ce_bwd", "gradnorm", "adamw", "adamw_schedule", "vq_nearest",
-           "vq_commit", "vq_ema_update", "stft_mag", "mel_log", "CastPlan", "TnPlan", "probe_layout", "device_info"]
+           "vq_commit", "vq_ema_update", "stft_mag", "mel_log", "CastPlan", "TransposePlan", "ColsumPlan", "LnFinalizePlan", "TnPlan", "probe_layout", "device_info"]
 
 
 def _stream():
@@ -250,6 +250,71 @@ def adamw(p, g, m, v, shadow, state, beta1, beta2, eps, wd, zero_grad=True):
     _req(shadow, torch.bfloat16, "shadow")
     check(_l.get().ttts_adamw_f32(_p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), _p(state), beta1, beta2, eps, wd,
                                   int(zero_grad), _stream()), "adamw")
+
+
+def _upload(arr, device):
+    return torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(device)
+
+
+class LnFinalizePlan:
+    """Descriptor table for ttts_layernorm_bwd_finalize_batched: entries (workspace, dgamma, dbeta, dcolsum | None), one per
+    layernorm_bwd call made with dgamma = dbeta = None (each with its own workspace)."""
+
+    def __init__(self, entries, M, D, device):
+        arr = (_l.LnFinalizeDesc * len(entries))()
+        for i, (ws, dg, db, dc) in enumerate(entries):
+            _req(dg, torch.float32, "dgamma"); _req(db, torch.float32, "dbeta")
+            arr[i].workspace, arr[i].dgamma, arr[i].dbeta = ws.data_ptr(), dg.data_ptr(), db.data_ptr()
+            arr[i].dcolsum = dc.data_ptr() if dc is not None else None
+        self.table, self.n, self.M, self.D, self._keep = _upload(arr, device), len(entries), M, D, entries
+
+    def run(self):
+        check(_l.get().ttts_layernorm_bwd_finalize_batched(_p(self.table), self.n, self.M, self.D, _stream()), "ln_finalize_batched")
+
+
+class ColsumPlan:
+    """Descriptor table for ttts_colsum_bf16_accum_f32_batched: entries (X bf16 [M, ld], out f32 [>= N], N | None)."""
+
+    def __init__(self, entries, device):
+        if not 0 < len(entries) <= 64:
+            raise TttsError("ColsumPlan: 1 .. 64 problems per launch")
+        arr = (_l.ColsumDesc * len(entries))()
+        tiles = 0
+        for i, (X, out, n) in enumerate(entries):
+            _req(X, torch.bfloat16, "X"); _req(out, torch.float32, "out")
+            M, N = X.shape[0], (X.shape[1] if n is None else n)
+            arr[i].X, arr[i].out, arr[i].ldx, arr[i].M, arr[i].N, arr[i].tile_begin = X.data_ptr(), out.data_ptr(), _ld(X), M, N, tiles
+            tiles += _l.get().ttts_colsum_desc_tiles(M, N)
+        self.table, self.n, self.tiles, self._keep = _upload(arr, device), len(entries), tiles, entries
+
+    def run(self):
+        check(_l.get().ttts_colsum_bf16_accum_f32_batched(_p(self.table), self.n, self.tiles, _stream()), "colsum_batched")
+
+
+class TransposePlan:
+    """Descriptor tables for ttts_transpose_bf16_batched: entries (src bf16 [r, c] contiguous, dst bf16 [c, >= r] row-major);
+    more than 64 entries run as several launches."""
+
+    def __init__(self, entries, device):
+        self.launches = []
+        for c0 in range(0, len(entries), 64):
+            chunk = entries[c0:c0 + 64]
+            arr = (_l.TransposeDesc * len(chunk))()
+            tiles = 0
+            for i, (src, dst) in enumerate(chunk):
+                _req(src, torch.bfloat16, "transpose src"); _req(dst, torch.bfloat16, "transpose dst")
+                r, c = src.shape
+                if not src.is_contiguous() or dst.shape[0] != c or dst.stride(0) < r or dst.stride(1) != 1:
+                    raise TttsError("transpose: src must be contiguous [r, c], dst a row-major [c, >= r] view")
+                arr[i].src, arr[i].dst, arr[i].rows, arr[i].cols, arr[i].ldd, arr[i].tile_begin = \
+                    src.data_ptr(), dst.data_ptr(), r, c, dst.stride(0), tiles
+                tiles += _l.get().ttts_transpose_desc_tiles(r, c)
+            self.launches.append((_upload(arr, device), len(chunk), tiles))
+        self._keep = entries
+
+    def run(self):
+        for table, n, tiles in self.launches:
+            check(_l.get().ttts_transpose_bf16_batched(_p(table), n, tiles, _stream()), "transpose_batched")
 
 
 class CastPlan:
