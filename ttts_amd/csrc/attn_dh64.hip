@@ -318,7 +318,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams p) {
     ks_next = ks_next == 2 * TILE64_B ? 0 : ks_next + TILE64_B;
   };
   auto step_close = [&]() {
-    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    // all but the two K(j + 2) pieces -- when this step issued them: near the end of the walk the newest pieces are V(j + 1),
+    // which the next step reads (found as a run-to-run difference of a few thousand output elements: tools/exp/fwd_determinism.py)
+    if (j + 2 < nt) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else lds_dma_wait_all();
     __syncthreads();
     // step_open has rotated vs_next to the slot of tile j + 2: it is slot 1 exactly when tile j sits in slot 2 (wave-uniform)
     const int adv = vs_next == TILE64_B ? -2 * TILE64_B : TILE64_B;

@@ -48,6 +48,23 @@ struct GemmNtParams {
 };
 
 // one output row piece: 8 consecutive columns n .. n + 7 of row m, v = acc + bias (fp32), through epilogue EPI
+// Epilogue traffic is streamed once (outputs feed the NEXT kernel; the residual and the saved pre-activation are read once): it
+// goes around the L2 with non-temporal accesses so that the operand panels, which every column / row tile of the launch
+// re-reads, stay resident (tools/ubench/fill_rate.hip: LDS-DMA fills a CU at ~50 B/clk from an L2-resident matrix, ~20 B/clk
+// once the matrix falls back to the MALL -- the rate these kernels' k-steps were running at).
+typedef __attribute__((ext_vector_type(4))) uint32_t nt_u32x4;
+template <typename T>
+__device__ __forceinline__ void nt_store16(void* ptr, const T& val) {
+  static_assert(sizeof(T) == 16, "16-byte values");
+  __builtin_nontemporal_store(__builtin_bit_cast(nt_u32x4, val), reinterpret_cast<nt_u32x4*>(ptr));
+}
+template <typename T>
+__device__ __forceinline__ T nt_load16(const void* ptr) {
+  static_assert(sizeof(T) == 16, "16-byte values");
+  return __builtin_bit_cast(T, __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4*>(ptr)));
+}
+#define NT_STORE(T, ptr, val) nt_store16<T>((ptr), (val))
+#define NT_LOAD(T, ptr) nt_load16<T>(ptr)
 template <int EPI>
 __device__ __forceinline__ void epi_row8(const GemmEpi& e, int m, int n, float (&v)[8], bool vec_ok) {
   const int64_t off = (int64_t)m * e.ldc + n;
@@ -58,7 +75,7 @@ __device__ __forceinline__ void epi_row8(const GemmEpi& e, int m, int n, float (
       bf16x8 o;
 #pragma unroll
       for (int t = 0; t < 8; ++t) o[t] = (bf16)v[t];
-      *reinterpret_cast<bf16x8*>(c) = o;
+      NT_STORE(bf16x8, c, o);
     } else {
 #pragma unroll
       for (int t = 0; t < 8; ++t)
@@ -74,8 +91,8 @@ __device__ __forceinline__ void epi_row8(const GemmEpi& e, int m, int n, float (
       act[t] = (bf16)gelu_new_f((float)pre[t]);
     }
     if (full) {
-      *reinterpret_cast<bf16x8*>(ax) = pre;
-      *reinterpret_cast<bf16x8*>(c) = act;
+      NT_STORE(bf16x8, ax, pre);
+      NT_STORE(bf16x8, c, act);
     } else {
 #pragma unroll
       for (int t = 0; t < 8; ++t)
@@ -98,9 +115,9 @@ __device__ __forceinline__ void epi_row8(const GemmEpi& e, int m, int n, float (
       }
     }
     if (full) {
-      const float4 r0 = *reinterpret_cast<const float4*>(rin), r1 = *reinterpret_cast<const float4*>(rin + 4);
-      *reinterpret_cast<float4*>(c) = make_float4(r0.x + y[0], r0.y + y[1], r0.z + y[2], r0.w + y[3]);
-      *reinterpret_cast<float4*>(c + 4) = make_float4(r1.x + y[4], r1.y + y[5], r1.z + y[6], r1.w + y[7]);
+      const float4 r0 = NT_LOAD(float4, rin), r1 = NT_LOAD(float4, rin + 4);
+      NT_STORE(float4, c, make_float4(r0.x + y[0], r0.y + y[1], r0.z + y[2], r0.w + y[3]));
+      NT_STORE(float4, c + 4, make_float4(r1.x + y[4], r1.y + y[5], r1.z + y[6], r1.w + y[7]));
     } else {
 #pragma unroll
       for (int t = 0; t < 8; ++t)
@@ -110,11 +127,11 @@ __device__ __forceinline__ void epi_row8(const GemmEpi& e, int m, int n, float (
     bf16* c = reinterpret_cast<bf16*>(e.C) + off;
     const bf16* ax = e.aux + off;
     if (full) {
-      const bf16x8 pre = *reinterpret_cast<const bf16x8*>(ax);
+      const bf16x8 pre = NT_LOAD(bf16x8, ax);
       bf16x8 o;
 #pragma unroll
       for (int t = 0; t < 8; ++t) o[t] = (bf16)(v[t] * gelu_new_grad_f((float)pre[t]));
-      *reinterpret_cast<bf16x8*>(c) = o;
+      NT_STORE(bf16x8, c, o);
     } else {
 #pragma unroll
       for (int t = 0; t < 8; ++t)
