@@ -66,11 +66,13 @@ int ttts_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, vo
                       const float* bias, void* aux, int32_t M, int32_t N, int32_t K, int32_t epilogue,
                       void* stream);
 /* Same, plus: resid_in (RESID_ADD_F32 only): C = resid_in + dropout(bf16(acc + bias)) out of place (NULL: C += ...);
- * dropout_p/seed: residual dropout (GPT-2 resid_pdrop, modeling_gpt2.py:223,241) on element index m*N + n. */
+ * dropout_p/seed: residual dropout (GPT-2 resid_pdrop, modeling_gpt2.py:223,241) on element index m*N + n;
+ * colsum (ABI v5; STORE_BF16 / DGELU_BF16 only, or NULL): colsum[n] += sum_m C[m][n] of the bf16 output -- the bias gradient
+ * of the layer whose dY this GEMM produces, taken in the epilogue instead of re-reading C (fp32 atomics, one per column and tile). */
 int ttts_gemm_nt_bf16_ex(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                          const float* bias, void* aux, int32_t M, int32_t N, int32_t K, int32_t epilogue,
                          const float* resid_in, float dropout_p, uint64_t seed, const uint32_t* dropout_counter,
-                         void* stream);
+                         float* colsum, void* stream);
 /* C[Mo,No] += At[Kr,Mo]^T . Bt[Kr,No]: the weight-gradient GEMM.  The reduction is split over workgroups into fp32
  * slabs in `workspace` (ttts_gemm_tn_workspace_bytes; may be 0 -> NULL) that a second kernel sums in a fixed order
  * (deterministic; no atomics); both operands are row-major with the REDUCTION dimension as rows ("TN").

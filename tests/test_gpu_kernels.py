@@ -175,6 +175,27 @@ def test_colsum_and_cast(ops):
     assert torch.equal(t2[:, :257], w2.t().to(torch.bfloat16)) and float(t2[:, 257:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("M,N,K", [(9248, 2048, 512), (9248, 512, 2048), (300, 136, 64), (1000, 264, 40)])
+def test_gemm_nt_epilogue_column_sums(ops, M, N, K):
+    """`colsum` of ttts_gemm_nt_bf16_ex: the column sums of the bf16 output taken in the epilogue (dGELU and plain store; the
+    128 x 128 LDS-DMA kernel, the 160 x 128 ring kernel, the register-staged kernel for ragged K) against sums of the stored C."""
+    from ttts_amd.lib import EPI_DGELU_BF16, EPI_STORE_BF16
+    g = torch.Generator(device="cpu").manual_seed(M + N)
+    a = _bf(torch.randn(M, K, generator=g) * 0.5).to(dev())
+    w = _bf(torch.randn(N, K, generator=g) * 0.1).to(dev())
+    ld = (N + 7) // 8 * 8
+    pre = _bf(torch.randn(M, ld, generator=g)).to(dev())
+    for epi in (EPI_DGELU_BF16, EPI_STORE_BF16):
+        c = torch.zeros(M, ld, dtype=torch.bfloat16, device=dev())
+        c0 = torch.zeros_like(c)
+        cs = torch.ones(N, device=dev())
+        ops.gemm_nt(a, w, c0[:, :N] if ld != N else c0, aux=pre if epi == EPI_DGELU_BF16 else None, epilogue=epi)
+        ops.gemm_nt(a, w, c[:, :N] if ld != N else c, aux=pre if epi == EPI_DGELU_BF16 else None, epilogue=epi, colsum=cs)
+        assert torch.equal(c, c0)
+        want = 1 + c[:, :N].float().sum(0)
+        assert float((cs - want).abs().max()) < 2e-3 * float(want.abs().max() + 1), (epi, float((cs - want).abs().max()))
+
+
 def test_batched_transpose_colsum_and_deferred_layernorm_finalize(ops):
     """ABI v5 batched forms against their single-call forms: bf16 transposes (ragged and padded destinations), column sums
     (several problems, a ragged N), LayerNorm parameter gradients left in per-call workspaces and finished in one launch."""

@@ -38,6 +38,8 @@ struct GemmEpi {
   int M, N;
   uint32_t thr; float inv_keep; uint32_t seed_lo, seed_hi;  // residual dropout (RESID_ADD only; thr = 0: off)
   const uint32_t* ctr;  // caller-owned dropout stream counter (device) or NULL
+  float* colsum;        // STORE_BF16 / DGELU_BF16: colsum[n] += sum over rows of the bf16 output (the bias gradient of the layer
+                        // whose dY this GEMM produces); NULL: off
 };
 
 struct GemmNtParams {
@@ -66,7 +68,7 @@ __device__ __forceinline__ T nt_load16(const void* ptr) {
 #define NT_STORE(T, ptr, val) nt_store16<T>((ptr), (val))
 #define NT_LOAD(T, ptr) nt_load16<T>(ptr)
 template <int EPI>
-__device__ __forceinline__ void epi_row8(const GemmEpi& e, int m, int n, float (&v)[8], bool vec_ok) {
+__device__ __forceinline__ void epi_row8(const GemmEpi& e, int m, int n, float (&v)[8], bool vec_ok, float (&cs)[8]) {
   const int64_t off = (int64_t)m * e.ldc + n;
   const bool full = vec_ok && (n + 8 <= e.N);
   if (EPI == TTTS_EPI_STORE_BF16) {
@@ -76,10 +78,14 @@ __device__ __forceinline__ void epi_row8(const GemmEpi& e, int m, int n, float (
 #pragma unroll
       for (int t = 0; t < 8; ++t) o[t] = (bf16)v[t];
       NT_STORE(bf16x8, c, o);
+      if (e.colsum) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) cs[t] += (float)o[t];
+      }
     } else {
 #pragma unroll
       for (int t = 0; t < 8; ++t)
-        if (n + t < e.N) c[t] = (bf16)v[t];
+        if (n + t < e.N) { c[t] = (bf16)v[t]; cs[t] += (float)(bf16)v[t]; }
     }
   } else if (EPI == TTTS_EPI_GELU_BF16) {
     bf16* c = reinterpret_cast<bf16*>(e.C) + off;
@@ -132,10 +138,14 @@ __device__ __forceinline__ void epi_row8(const GemmEpi& e, int m, int n, float (
 #pragma unroll
       for (int t = 0; t < 8; ++t) o[t] = (bf16)(v[t] * gelu_new_grad_f((float)pre[t]));
       NT_STORE(bf16x8, c, o);
+      if (e.colsum) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) cs[t] += (float)o[t];
+      }
     } else {
 #pragma unroll
       for (int t = 0; t < 8; ++t)
-        if (n + t < e.N) c[t] = (bf16)(v[t] * gelu_new_grad_f((float)ax[t]));
+        if (n + t < e.N) { c[t] = (bf16)(v[t] * gelu_new_grad_f((float)ax[t])); cs[t] += (float)c[t]; }
     }
   } else {  // STORE_F32 / ACCUM_F32 / SLAB_F32
     float* c = reinterpret_cast<float*>(e.C) + off;
@@ -153,6 +163,28 @@ __device__ __forceinline__ void epi_row8(const GemmEpi& e, int m, int n, float (
       for (int t = 0; t < 8; ++t)
         if (n + t < e.N) c[t] = (EPI == EPI_ACCUM_F32 ? c[t] : 0.f) + v[t];
     }
+  }
+}
+
+// Column sums of a tile's bf16 output (GemmEpi::colsum): every thread has summed its rows of ONE 8-column group (threads
+// tid % CG share a group); lanes of a wave that share it, then the waves through the idle stage, then one atomic per column.
+template <int CG, int NWAVES>
+__device__ __forceinline__ void colsum_flush(const GemmEpi& e, float (&cs)[8], float* stage, int n0, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int o = CG; o < 64; o <<= 1)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) cs[t] += __shfl_xor(cs[t], o, 64);
+  if (lane < CG) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) stage[wave * (CG * 8) + lane * 8 + t] = cs[t];
+  }
+  __syncthreads();
+  if (tid < CG * 8) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWAVES; ++w) s += stage[w * (CG * 8) + tid];
+    if (n0 + tid < e.N) atomicAdd(e.colsum + n0 + tid, s);
   }
 }
 
@@ -175,6 +207,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmEpi& e, f32x16 (&acc)[2]
     const float b = (e.bias && n < e.N) ? e.bias[n] : 0.f;
     bias8[t] = (EPI == TTTS_EPI_STORE_F32) ? b : (float)(bf16)b;  // autocast rounds the bias to bf16
   }
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     if (wm == half) {
@@ -204,10 +237,11 @@ __device__ __forceinline__ void tile_epilogue(const GemmEpi& e, f32x16 (&acc)[2]
       }
 #pragma unroll
       for (int t = 0; t < 8; ++t) v[t] += bias8[t];
-      epi_row8<EPI>(e, m, n, v, vec_ok);
+      epi_row8<EPI>(e, m, n, v, vec_ok, cs);
     }
     __syncthreads();
   }
+  if ((EPI == TTTS_EPI_STORE_BF16 || EPI == TTTS_EPI_DGELU_BF16) && e.colsum) colsum_flush<TPR, 4>(e, cs, stage, n0, tid);
 }
 
 // XCD-aware tile order: the dispatcher places workgroup b on XCD b % 8 (observed, speed only).  Remap so that each XCD
@@ -444,6 +478,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_nt_tall_kernel(GemmNtParams p
     const float b = (p.e.bias && n < p.e.N) ? p.e.bias[n] : 0.f;
     bias8[t] = (EPI == TTTS_EPI_STORE_F32) ? b : (float)(bf16)b;
   }
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int pass = 0; pass < (MI + 1) / 2; ++pass) {
 #pragma unroll
@@ -470,10 +505,11 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_nt_tall_kernel(GemmNtParams p
       v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 #pragma unroll
       for (int t = 0; t < 8; ++t) v[t] += bias8[t];
-      epi_row8<EPI>(p.e, m, n, v, vec_ok);
+      epi_row8<EPI>(p.e, m, n, v, vec_ok, cs);
     }
     __syncthreads();
   }
+  if ((EPI == TTTS_EPI_STORE_BF16 || EPI == TTTS_EPI_DGELU_BF16) && p.e.colsum) colsum_flush<TN / 8, NW>(p.e, cs, stage, n0, tid);
 }
 
 // ---- NT, register-staged main loop (any K % 8 == 0; zero-fills ragged K) ---------------------------------------------
@@ -874,8 +910,9 @@ static void launch_nt(const GemmNtParams& p, int grid, hipStream_t s) {
 extern "C" int ttts_gemm_nt_bf16_ex(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                                     const float* bias, void* aux, int32_t M, int32_t N, int32_t K, int32_t epilogue,
                                     const float* resid_in, float dropout_p, uint64_t seed, const uint32_t* dropout_counter,
-                                    void* stream) {
+                                    float* colsum, void* stream) {
   TTTS_REQUIRE(A && B && C, "gemm_nt: null pointer");
+  TTTS_REQUIRE(!colsum || epilogue == TTTS_EPI_STORE_BF16 || epilogue == TTTS_EPI_DGELU_BF16, "gemm_nt: colsum only with the bf16 STORE / DGELU epilogues");
   TTTS_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_nt: bad shape M=%d N=%d K=%d", M, N, K);
   TTTS_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K, "gemm_nt: K, lda, ldb must be multiples of 8 (K=%d lda=%lld ldb=%lld)", K, (long long)lda, (long long)ldb);
   TTTS_REQUIRE(ldc % 4 == 0 && ldc >= ((N + 3) / 4) * 4, "gemm_nt: ldc must be a multiple of 4 and >= roundup4(N)");
@@ -886,7 +923,7 @@ extern "C" int ttts_gemm_nt_bf16_ex(const void* A, int64_t lda, const void* B, i
   TTTS_REQUIRE(!resid_in || aligned16(resid_in), "gemm_nt: resid_in must be 16-byte aligned");
   GemmNtParams p{(const bf16*)A, lda, (const bf16*)B, ldb, K,
                  GemmEpi{C, ldc, bias, (bf16*)aux, resid_in, M, N, dropout_threshold(dropout_p), 1.0f, (uint32_t)seed,
-                         (uint32_t)(seed >> 32), dropout_counter}};
+                         (uint32_t)(seed >> 32), dropout_counter, colsum}};
   if (p.e.thr) p.e.inv_keep = 65536.0f / (65536.0f - (float)p.e.thr);
   const int grid = (int)(cdiv(M, BM) * cdiv(N, BN));
   hipStream_t s = as_stream(stream);
@@ -904,7 +941,7 @@ extern "C" int ttts_gemm_nt_bf16_ex(const void* A, int64_t lda, const void* B, i
 extern "C" int ttts_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                                  const float* bias, void* aux, int32_t M, int32_t N, int32_t K, int32_t epilogue,
                                  void* stream) {
-  return ttts_gemm_nt_bf16_ex(A, lda, B, ldb, C, ldc, bias, aux, M, N, K, epilogue, nullptr, 0.f, 0, nullptr, stream);
+  return ttts_gemm_nt_bf16_ex(A, lda, B, ldb, C, ldc, bias, aux, M, N, K, epilogue, nullptr, 0.f, 0, nullptr, nullptr, stream);
 }
 
 static void tn_plan(int Mo, int No, int Kr, int& splits, int& k_chunk) {

@@ -296,7 +296,7 @@ class GptEngine:
             ln += [(b["ln_ws_l"][2 * i + 1], G(pre + "ln_2.weight"), G(pre + "ln_2.bias"), G(pre + "attn.c_proj.bias")),
                    (b["ln_ws_l"][2 * i], G(pre + "ln_1.weight"), G(pre + "ln_1.bias"),
                     G("gpt.h.%d.mlp.c_proj.bias" % (i - 1)) if i > 0 else None)]
-            cs += [(b["d_fc_l"][i], G(pre + "mlp.c_fc.bias"), None), (b["dqkv_l"][i], G(pre + "attn.c_attn.bias"), None)]
+            cs += [(b["dqkv_l"][i], G(pre + "attn.c_attn.bias"), None)]     # (mlp.c_fc.bias: dGELU epilogue)
         M, D = b["d_fc_l"][0].shape[0], self.c["model_dim"]
         ln_plan = ops.LnFinalizePlan(ln, M, D, self.device)
         cs_plans = [ops.ColsumPlan(cs[j:j + 64], self.device) for j in range(0, len(cs), 64)]
@@ -546,7 +546,8 @@ class GptEngine:
         st = b["stats"][i]
         x0, x1 = b["xs"][2 * i], b["xs"][2 * i + 1]
         dy, d_fc, dy_att, dqkv = b["dy_mlp"][i], b["d_fc_l"][i], b["dy_att"][i], b["dqkv_l"][i]
-        self._nt(dy, self.w(pre + "mlp.c_proj.weight"), d_fc, aux=b["fc_pre"][i], epilogue=EPI_DGELU_BF16)
+        self._nt(dy, self.w(pre + "mlp.c_proj.weight"), d_fc, aux=b["fc_pre"][i], epilogue=EPI_DGELU_BF16,
+                 colsum=G(pre + "mlp.c_fc.bias"))      # the c_fc bias gradient rides in the dGELU epilogue
         self._nt(d_fc, self.w(pre + "mlp.c_fc.weight"), b["d_ln"])
         ops.layernorm_bwd(b["d_ln"], x1, P(pre + "ln_2.weight"), st[2], st[3], b["dres"], b["dres"], dy_att,
                           None, None, b["ln_ws_l"][2 * i + 1], dropout_p=p, seed=self._seed(16 * i + 3), counter=self.seed_ctr)

@@ -47,9 +47,10 @@ def _ld(t):
 
 
 def gemm_nt(a, b, c, bias=None, aux=None, epilogue=EPI_STORE_BF16, n=None, k=None, resid_in=None, dropout_p=0.0,
-            seed=0, counter=None):
-    """c[M,N] = epi(a[M,K] @ b[N,K]^T).  a/b bf16 row-major views; c bf16 or f32 (per epilogue)."""
-    _req(resid_in, torch.float32, "resid_in")
+            seed=0, counter=None, colsum=None):
+    """c[M,N] = epi(a[M,K] @ b[N,K]^T).  a/b bf16 row-major views; c bf16 or f32 (per epilogue).
+    colsum (f32 [>= N], STORE_BF16 / DGELU_BF16): += the column sums of c, taken in the epilogue."""
+    _req(resid_in, torch.float32, "resid_in"); _req(colsum, torch.float32, "colsum")
     _req(a, torch.bfloat16, "a"); _req(b, torch.bfloat16, "b"); _req(bias, torch.float32, "bias")
     _req(aux, torch.bfloat16, "aux")
     M = a.shape[0]
@@ -60,7 +61,7 @@ def gemm_nt(a, b, c, bias=None, aux=None, epilogue=EPI_STORE_BF16, n=None, k=Non
     if resid_in is not None and (resid_in.shape != c.shape or resid_in.stride() != c.stride()):
         raise TttsError("resid_in must have the layout of c")
     check(_l.get().ttts_gemm_nt_bf16_ex(_p(a), _ld(a), _p(b), _ld(b), _p(c), _ld(c), _p(bias), _p(aux), M, N, K,
-                                        epilogue, _p(resid_in), dropout_p, seed, _ctr(counter, c, dropout_p), _stream()), "gemm_nt")
+                                        epilogue, _p(resid_in), dropout_p, seed, _ctr(counter, c, dropout_p), _p(colsum), _stream()), "gemm_nt")
     return c
 
 
