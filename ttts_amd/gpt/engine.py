@@ -296,10 +296,13 @@ class GptEngine:
             ln += [(b["ln_ws_l"][2 * i + 1], G(pre + "ln_2.weight"), G(pre + "ln_2.bias"), G(pre + "attn.c_proj.bias")),
                    (b["ln_ws_l"][2 * i], G(pre + "ln_1.weight"), G(pre + "ln_1.bias"),
                     G("gpt.h.%d.mlp.c_proj.bias" % (i - 1)) if i > 0 else None)]
-            cs += [(b["dqkv_l"][i], G(pre + "attn.c_attn.bias"), None)]     # (mlp.c_fc.bias: dGELU epilogue)
+            # (mlp.c_fc.bias rides in the dGELU epilogue.  The same on the attention backward's dq / dk / dv stores was measured
+            # and removed: 320 fp32 atomics per bias element from 2560 waves cost the two kernels +50 us each; so was computing delta in
+            # the dQ kernel's prologue instead of the 7 us pre-pass: the dQ kernel, then first to touch dO / O, lost 9 us)
+            cs += [(b["dqkv_l"][i], G(pre + "attn.c_attn.bias"), None)]
         M, D = b["d_fc_l"][0].shape[0], self.c["model_dim"]
         ln_plan = ops.LnFinalizePlan(ln, M, D, self.device)
-        cs_plans = [ops.ColsumPlan(cs[j:j + 64], self.device) for j in range(0, len(cs), 64)]
+        cs_plans = [ops.ColsumPlan(cs[j:j + 64], self.device) for j in range(0, len(cs), 64)]   # (may be empty)
         self._dw_plans[key] = (plans, single, ln_plan, cs_plans)
         return self._dw_plans[key]
 
