@@ -236,6 +236,140 @@ __global__ __launch_bounds__(256) void stft_mag_r4_kernel(const float* __restric
   }
 }
 
+// (round 3) The same radix-4 Stockham passes with everything that does not depend on the frame hoisted out of the frame loop.
+// PMC on the kernel above at n_fft 2048: 23.6 M VALU wave-instructions per launch = 144 per butterfly, of which ~34 are the
+// butterfly's arithmetic -- the rest is index arithmetic (j -> frame / point / k, Stockham output position), the twiddle lookups
+// with their range selects, the division by L + 1 of the unpack loop; VALU 52 % busy, LDS 32 %.  A thread's butterflies are the
+// same in every frame group, so its LDS offsets and twiddles are computed ONCE into registers (LOG2L even and compile-time:
+// LOG2L / 2 passes x NB butterflies x (1 read offset, 4 write offsets, 3 twiddles)); pass 0 (unit twiddles) skips its complex
+// multiplications; the index swizzle SW (8-byte bank pair ^= index bits 5..6: the strided Stockham writes of the first passes
+// hit 8 of 32 bank pairs otherwise, 57 % of the LDS-active cycles were conflict cycles) costs nothing at run time any more.
+template <int NF, int FR, int LOG2L>
+__global__ __launch_bounds__(256) void stft_mag_r4p_kernel(const float* __restrict__ wav, const float* __restrict__ window,
+                                                           const float2* __restrict__ tw, float* __restrict__ spec, int T,
+                                                           int hop, int frames) {
+  static_assert((LOG2L & 1) == 0 && LOG2L >= 8, "even log2 L: radix-4 passes only");
+  constexpr int L = 1 << LOG2L, Q = L >> 2, NP = LOG2L / 2, n_fft = 2 * L;
+  constexpr int NB = NF * Q / 256;                       // butterflies per thread and pass
+  constexpr int NPT = NF * L / 256;                      // packed points per thread and frame group
+  static_assert(NF * Q % 256 == 0, "whole butterflies per thread");
+  extern __shared__ __attribute__((aligned(16))) float stft_smem[];
+  float2* bufA = reinterpret_cast<float2*>(stft_smem);            // [NF][L]
+  float2* bufB = bufA + NF * L;
+  float* outs = reinterpret_cast<float*>(bufB + NF * L);           // [L + 1][FR + 1]
+  const int tid = threadIdx.x;
+  const int fblocks = (frames + FR - 1) / FR;
+  const int b = blockIdx.x / fblocks;
+  const int f0 = (blockIdx.x % fblocks) * FR;
+  const int pad = (n_fft - hop) / 2;
+  const float* w = wav + (int64_t)b * T;
+  auto SW = [](int i) {
+    const int bb = (i >> 5) & 3;
+    return i ^ bb ^ (bb << 2) ^ (((i >> 6) & 1) << 4);
+  };
+  auto Wg = [&](int t) {                                 // exp(-2 pi i t / n_fft), t < n_fft, from the global table (t < L)
+    const float2 v = tw[t & (L - 1)];
+    return t >= L ? make_float2(-v.x, -v.y) : v;
+  };
+  // per-thread tables
+  int rd[NP][NB], wr[NP][NB][4];
+  float2 tw1[NP][NB], tw2[NP][NB], tw3[NP][NB];
+#pragma unroll
+  for (int ps = 0; ps < NP; ++ps) {
+    const int Ns = 1 << (2 * ps), tstep = n_fft / (4 * Ns);
+#pragma unroll
+    for (int m = 0; m < NB; ++m) {
+      const int j = tid + 256 * m, fq = j / Q, jj = j & (Q - 1), k = jj & (Ns - 1);
+      rd[ps][m] = fq * L + SW(jj);                       // + c Q, c < 4: Q is a multiple of 128, the swizzle bits do not move
+      const int o = ((jj - k) << 2) + k;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) wr[ps][m][c] = fq * L + SW(o + c * Ns);
+      tw1[ps][m] = Wg(k * tstep); tw2[ps][m] = Wg(2 * k * tstep); tw3[ps][m] = Wg(3 * k * tstep);
+    }
+  }
+  float2 win[NPT], xr[NPT];
+  int pk[NPT];
+#pragma unroll
+  for (int i = 0; i < NPT; ++i) {
+    const int n = tid + 256 * i, nn = n & (L - 1);
+    win[i] = make_float2(window[2 * nn], window[2 * nn + 1]);
+    pk[i] = (n & ~(L - 1)) + SW(nn);
+  }
+  // unpack: this thread's bins k = tid + 256 u (u < L / 256) of every frame of the group, + bin L on thread 0
+  constexpr int NU = L / 256;
+  float2 twu[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) twu[u] = tw[tid + 256 * u];
+  auto load_group = [&](int ff0) {
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+      const int n = tid + 256 * i, frame = min(f0 + ff0 + (n >> LOG2L), frames - 1), nn = n & (L - 1);
+      int i0 = frame * hop + 2 * nn - pad, i1 = i0 + 1;
+      i0 = i0 < 0 ? -i0 : i0; i1 = i1 < 0 ? -i1 : i1;
+      i0 = i0 >= T ? 2 * (T - 1) - i0 : i0; i1 = i1 >= T ? 2 * (T - 1) - i1 : i1;
+      xr[i] = make_float2(w[i0], w[i1]);
+    }
+  };
+  auto cmul = [](float2 a, float2 t) { return make_float2(a.x * t.x - a.y * t.y, a.x * t.y + a.y * t.x); };
+  load_group(0);
+  for (int ff0 = 0; ff0 < FR; ff0 += NF) {
+    if (f0 + ff0 >= frames) break;                       // block-uniform
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) bufA[pk[i]] = make_float2(xr[i].x * win[i].x, xr[i].y * win[i].y);
+    __syncthreads();
+    if (ff0 + NF < FR && f0 + ff0 + NF < frames) load_group(ff0 + NF);
+    float2* src = bufA;
+    float2* dst = bufB;
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+#pragma unroll
+      for (int m = 0; m < NB; ++m) {
+        const float2* sp = src + rd[ps][m];
+        const float2 a = sp[0];
+        float2 bb = sp[Q], cc = sp[2 * Q], dd = sp[3 * Q];
+        if (ps > 0) { bb = cmul(bb, tw1[ps][m]); cc = cmul(cc, tw2[ps][m]); dd = cmul(dd, tw3[ps][m]); }
+        const float2 s0 = make_float2(a.x + cc.x, a.y + cc.y), s1 = make_float2(a.x - cc.x, a.y - cc.y);
+        const float2 s2 = make_float2(bb.x + dd.x, bb.y + dd.y), s3 = make_float2(bb.x - dd.x, bb.y - dd.y);
+        dst[wr[ps][m][0]] = make_float2(s0.x + s2.x, s0.y + s2.y);
+        dst[wr[ps][m][1]] = make_float2(s1.x + s3.y, s1.y - s3.x);          // s1 - i s3
+        dst[wr[ps][m][2]] = make_float2(s0.x - s2.x, s0.y - s2.y);
+        dst[wr[ps][m][3]] = make_float2(s1.x - s3.y, s1.y + s3.x);          // s1 + i s3
+      }
+      __syncthreads();
+      float2* tmp = src; src = dst; dst = tmp;
+    }
+    // unpack the real spectra: X[k] = E + w_k O, E = (Z[k] + conj Z[L-k]) / 2, O = -i (Z[k] - conj Z[L-k]) / 2
+#pragma unroll
+    for (int fq = 0; fq < NF; ++fq) {
+      const float2* z = src + fq * L;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int k = tid + 256 * u;
+        float re, im;
+        if (k == 0) {
+          const float2 z0 = z[0];
+          re = z0.x + z0.y; im = 0.f;
+          outs[L * (FR + 1) + ff0 + fq] = sqrtf((z0.x - z0.y) * (z0.x - z0.y) + 1e-6f);   // bin L
+        } else {
+          const float2 zk = z[SW(k)];
+          const float2 zc = z[SW(L - k)];
+          const float er = 0.5f * (zk.x + zc.x), ei = 0.5f * (zk.y - zc.y);
+          const float orr = 0.5f * (zk.y + zc.y), oi = -0.5f * (zk.x - zc.x);
+          re = er + (orr * twu[u].x - oi * twu[u].y);
+          im = ei + (orr * twu[u].y + oi * twu[u].x);
+        }
+        outs[k * (FR + 1) + ff0 + fq] = sqrtf(re * re + im * im + 1e-6f);
+      }
+    }
+    __syncthreads();
+  }
+  const int nf = min(FR, frames - f0);
+  for (int i = tid; i < (L + 1) * FR; i += 256) {
+    const int k = i / FR, ff = i % FR;
+    if (ff < nf) spec[((int64_t)b * (L + 1) + k) * frames + f0 + ff] = outs[k * (FR + 1) + ff];
+  }
+}
+
 // mel[b][m][f] = log(max(sum_k basis[m][k] spec[b][k][f], 1e-5)).
 // (round 2) A mel filterbank row is a narrow band (Slaney triangles: ~2 x 1025 non-zeros in 128 x 1025), so the dense
 // 32 x 64 x 32 tiled product of round 1 (166 us for 32 clips: 2.9 % of the HBM roof, all of it multiplying zeros) is replaced
@@ -469,6 +603,15 @@ extern "C" int ttts_stft_mag_fwd_f32(const float* wav, const float* window, cons
   while ((1 << log2L) < L) ++log2L;
   constexpr int NF = 2, FR4 = 8;                         // radix-4 kernel: frames per pass, frames per workgroup (16 frames =
   const bool r4 = L >= 256 && L <= 2048;                 // 64-byte output runs, but 110 KB of LDS = one workgroup per CU: 120 us vs 91); short transforms keep radix-2
+  if (L == 1024) {                                        // n_fft 2048 (the training configuration): per-thread tables, LDS swizzle
+    const size_t smemp = (size_t)2 * NF * L * sizeof(float2) + (size_t)(L + 1) * (FR4 + 1) * sizeof(float);
+    static const hipError_t attrp = hipFuncSetAttribute(reinterpret_cast<const void*>(stft_mag_r4p_kernel<NF, FR4, 10>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attrp != hipSuccess) return fail(TTTS_EHIP, "stft: hipFuncSetAttribute: %s", hipGetErrorString(attrp));
+    stft_mag_r4p_kernel<NF, FR4, 10><<<B * (int)cdiv(frames, FR4), 256, smemp, as_stream(stream)>>>(
+        wav, window, reinterpret_cast<const float2*>(twiddle), spec, T, hop, frames);
+    return check_launch("stft_mag_fwd");
+  }
   if (r4) {
     const size_t smem4 = (size_t)2 * NF * L * sizeof(float2) + ((size_t)(L + 1) * (FR4 + 1) + (((L + 1) * (FR4 + 1)) & 1)) * sizeof(float) +
                          (size_t)L * sizeof(float2);
