@@ -157,6 +157,24 @@ int ttts_attn_causal_bwd_bf16(const void* q, const void* k, const void* v, const
                               int32_t B, int32_t H, int32_t S, int32_t head_dim,
                               int64_t qkv_stride_b, int64_t qkv_stride_s, int64_t o_stride_b, int64_t o_stride_s,
                               float scale, float dropout_p, uint64_t seed, const uint32_t* dropout_counter, void* stream);
+/* ---- fused fp32 cross-attention (ABI v5) ------------------------------------------------------------
+ * Replaces: the text<->audio cross-attention of MRTE, vc_utils.MultiHeadAttention.attention (ttts/utils/vc_utils.py:597-627,
+ * reached from ttts/vqvae/vq2.py:41-43), and any other non-windowed, dropout-free attentions.MultiHeadAttention.attention call
+ * (ttts/vqvae/attentions.py:231-290) -- forward and backward in three kernels without the [B, H, Tq, Tk] score tensor.
+ * q [B, H*dk, Tq], k / v [B, H*dk, Tk], out [B, H*dk, Tq]: the reference's (B, C, T) tensors, head h = channel rows h*dk ..;
+ * qmask [B, Tq] / kmask [B, Tk] (or NULL): a score is replaced by `fill` (-1e4) where qmask * kmask == 0 (masked_fill), then
+ * softmax over all Tk keys; stats f32 [B, H, Tq][2] (ttts_attn_cross_stats_bytes) = a query's running (max, 1 / sum), kept for
+ * the backward.
+ * dk in {64, 96, 128} (else TTTS_EUNSUPPORTED).  Exact-fp32 products (v_mfma_f32_32x32x2_f32). */
+int64_t ttts_attn_cross_stats_bytes(int32_t B, int32_t H, int32_t Tq);
+int ttts_attn_cross_fwd_f32(const float* q, const float* k, const float* v, const float* qmask, const float* kmask,
+                            float* out, float* stats, int32_t B, int32_t H, int32_t dk, int32_t Tq, int32_t Tk,
+                            float scale, float fill, void* stream);
+int64_t ttts_attn_cross_bwd_workspace_bytes(int32_t B, int32_t H, int32_t Tq);
+int ttts_attn_cross_bwd_f32(const float* q, const float* k, const float* v, const float* qmask, const float* kmask,
+                            const float* out, const float* dout, const float* stats, float* dq, float* dk_out, float* dv,
+                            void* workspace, int32_t B, int32_t H, int32_t dk, int32_t Tq, int32_t Tk, float scale,
+                            float fill, void* stream);
 /* Debug/test aid: materialise the attention-dropout keep mask (uint8 [B,H,S,S], 1 = keep). */
 int ttts_attn_dropout_mask_u8(uint8_t* mask, int32_t B, int32_t H, int32_t S, float dropout_p, uint64_t seed,
                               const uint32_t* dropout_counter, void* stream);

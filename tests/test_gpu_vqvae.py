@@ -787,3 +787,47 @@ def test_extract_vq_codes_and_gpt_data_path(tmp_path, golden_dir):
     cfg = resolve_config(json.load(open(os.path.join(os.path.dirname(golden_dir), "..", "ttts_amd", "gpt", "config.json")))["gpt"])
     toks = prepare_tokens(cfg, batch["padded_text"], batch["text_lengths"], batch["padded_qmel"], batch["wav_lens"])
     assert toks[2].shape[0] == 2 and toks[2].dtype == torch.int64
+
+
+@pytest.mark.parametrize("B,H,dk,Tq,Tk,fill,use_q", [(32, 4, 128, 256, 100, -1e4, True), (3, 2, 96, 77, 50, -1e4, True),
+                                                       (2, 2, 64, 40, 130, -float("inf"), False), (4, 4, 128, 256, 256, -1e4, False)])
+def test_fused_cross_attention_forward_backward(B, H, dk, Tq, Tk, fill, use_q):
+    """csrc/attn_cross.hip (ttts_attn_cross_{fwd,bwd}_f32: the MRTE text<->audio cross-attention, ttts/utils/vc_utils.py:597-627)
+    against an fp64 torch restatement of the reference's masked_fill + softmax + matmul and against the bgemm + softmax path it
+    replaces: output and all three gradients; query / key masks (fully masked query rows keep the reference's uniform row), a
+    -inf fill, ragged Tq / Tk, d_k 64 / 96 / 128."""
+    import math
+    from ttts_amd.vqvae.attentions import _AttnCoreFn, _AttnFusedFn
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + Tk)
+    C = H * dk
+    q = torch.randn(B, C, Tq, generator=g).to(dev).requires_grad_(True)
+    k = torch.randn(B, C, Tk, generator=g).to(dev).requires_grad_(True)
+    v = torch.randn(B, C, Tk, generator=g).to(dev).requires_grad_(True)
+    do = torch.randn(B, C, Tq, generator=g).to(dev)
+    km = (torch.arange(Tk)[None] < torch.randint(Tk // 2, Tk + 1, (B, 1), generator=g)).float().to(dev)
+    qm = (torch.arange(Tq)[None] < torch.randint(Tq // 2, Tq + 1, (B, 1), generator=g)).float().to(dev) if use_q else None
+    scale = 1 / math.sqrt(dk)
+
+    def grads(fn):
+        out = fn()
+        out.backward(do.to(out.dtype))
+        gs = [t.grad.clone() for t in (q, k, v)]
+        for t in (q, k, v):
+            t.grad = None
+        return out.detach(), gs
+
+    def ref():
+        s = torch.einsum("bhdt,bhdj->bhtj", q.double().view(B, H, dk, Tq), k.double().view(B, H, dk, Tk)) * scale
+        m = (qm if qm is not None else torch.ones(B, Tq, device=dev))[:, None, :, None] * km[:, None, None, :]
+        p = torch.softmax(s.masked_fill(m == 0, fill), -1)
+        return torch.einsum("bhtj,bhdj->bhdt", p, v.double().view(B, H, dk, Tk)).reshape(B, C, Tq)
+
+    o, gs = grads(lambda: _AttnFusedFn.apply(q, k, v, qm, km, H, scale, fill))
+    ro, rgs = grads(ref)
+    rel = lambda a, b_: float((a.double() - b_.double()).norm() / b_.double().norm())   # noqa: E731
+    assert rel(o, ro) < 2e-6 and all(rel(a, b_) < 3e-6 for a, b_ in zip(gs, rgs)), (rel(o, ro), [rel(a, b_) for a, b_ in zip(gs, rgs)])
+    if fill > -1e30:
+        oo, ogs = grads(lambda: _AttnCoreFn.apply(q, k, v, None, None, qm if qm is not None else torch.ones(B, Tq, device=dev), km, H, 0,
+                                                  scale, fill, 0.0, 0))
+        assert rel(o, oo) < 2e-6 and all(rel(a, b_) < 3e-6 for a, b_ in zip(gs, ogs))

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(CSRC, "build")
 SO_PATH = os.path.join(HERE, "libttts_hip.so")
-SOURCES = ["lib.hip", "elementwise.hip", "gemm.hip", "attn.hip", "attn_dh64.hip", "vq.hip", "stft.hip", "conv.hip", "conv_mfma.hip", "conv_thin.hip", "conv_grouped.hip", "losses.hip", "vqvae_ops.hip", "attn_f32.hip", "peq.hip", "decode.hip", "diffusion_ops.hip"]
+SOURCES = ["lib.hip", "elementwise.hip", "gemm.hip", "attn.hip", "attn_dh64.hip", "vq.hip", "stft.hip", "conv.hip", "conv_mfma.hip", "conv_thin.hip", "conv_grouped.hip", "losses.hip", "vqvae_ops.hip", "attn_f32.hip", "attn_cross.hip", "peq.hip", "decode.hip", "diffusion_ops.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-Wall", "-Wno-unused-variable"]
 
@@ -123,6 +123,10 @@ SIGNATURES = {
     "ttts_attn_bwd_workspace_bytes": (_I64, [_I32, _I32, _I32]),
     "ttts_attn_causal_bwd_bf16": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I64, _I64,
                                          _I64, _I64, _F, _F, _U64, _P, _P]),
+    "ttts_attn_cross_fwd_f32": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _F, _P]),
+    "ttts_attn_cross_bwd_workspace_bytes": (_I64, [_I32, _I32, _I32]),
+    "ttts_attn_cross_stats_bytes": (_I64, [_I32, _I32, _I32]),
+    "ttts_attn_cross_bwd_f32": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _F, _P]),
     "ttts_attn_dropout_mask_u8": (_I32, [_P, _I32, _I32, _I32, _F, _U64, _P, _P]),
     "ttts_layernorm_fwd": (_I32, [_P, _P, _P, _P, _I32, _P, _P, _I32, _I32, _F, _I32, _I32, _P]),
     "ttts_layernorm_bwd_workspace_bytes": (_I64, [_I32, _I32]),

@@ -152,6 +152,29 @@ def attn_bwd(q, k, v, o, d_o, lse, dq, dk, dv, workspace, B, H, S, dh, qkv_strid
                                              o_strides[1], scale, dropout_p, seed, _ctr(counter, q, dropout_p), _stream()), "attn_bwd")
 
 
+def attn_cross_fwd(q, k, v, qmask, kmask, H, scale, fill):
+    """Fused fp32 attention on (B, C, T) tensors (include/ttts_hip.h: ttts_attn_cross_fwd_f32) -> (out [B, C, Tq], stats [B, H, Tq, 2])."""
+    for t_, nm in ((q, "q"), (k, "k"), (v, "v"), (qmask, "qmask"), (kmask, "kmask")):
+        _req(t_, torch.float32, nm)
+    B, C, Tq = q.shape
+    Tk = k.shape[2]
+    out = torch.empty_like(q)
+    lse = torch.empty(B, H, Tq, 2, dtype=torch.float32, device=q.device)
+    check(_l.get().ttts_attn_cross_fwd_f32(_p(q), _p(k), _p(v), _p(qmask), _p(kmask), _p(out), _p(lse), B, H, C // H, Tq, Tk,
+                                           scale, fill, _stream()), "attn_cross_fwd")
+    return out, lse
+
+
+def attn_cross_bwd(q, k, v, qmask, kmask, out, dout, lse, H, scale, fill):
+    B, C, Tq = q.shape
+    Tk = k.shape[2]
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    ws = torch.empty(_l.get().ttts_attn_cross_bwd_workspace_bytes(B, H, Tq) // 4, dtype=torch.float32, device=q.device)
+    check(_l.get().ttts_attn_cross_bwd_f32(_p(q), _p(k), _p(v), _p(qmask), _p(kmask), _p(out), _p(dout), _p(lse), _p(dq), _p(dk),
+                                           _p(dv), _p(ws), B, H, C // H, Tq, Tk, scale, fill, _stream()), "attn_cross_bwd")
+    return dq, dk, dv
+
+
 def attn_dropout_mask(B, H, S, p, seed, device, counter=None):
     m = torch.empty(B, H, S, S, dtype=torch.uint8, device=device)
     check(_l.get().ttts_attn_dropout_mask_u8(_p(m), B, H, S, p, seed, _ctr(counter, m, p), _stream()), "dropout_mask")

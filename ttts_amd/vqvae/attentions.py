@@ -73,6 +73,30 @@ class LayerNorm(nn.Module):
         return _LayerNormChFn.apply(x, self.gamma, self.beta, self.eps)
 
 
+class _AttnFusedFn(torch.autograd.Function):
+    """softmax(mask(scale q^T k)) v on (B, C, T) tensors without a window and without dropout: csrc/attn_cross.hip (three fused
+    kernels, no [B, H, Tq, Tk] tensors).  The MRTE text<->audio cross-attention and the style encoder's self-attention."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, qmask, kmask, H, scale, fill):
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        out, lse = ops.attn_cross_fwd(q, k, v, qmask, kmask, H, scale, fill)
+        ctx.save_for_backward(q, k, v, qmask, kmask, out, lse)
+        ctx.cfg = (H, scale, fill)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, qmask, kmask, out, lse = ctx.saved_tensors
+        H, scale, fill = ctx.cfg
+        dq, dk, dv = ops.attn_cross_bwd(q, k, v, qmask, kmask, out, dout.contiguous(), lse, H, scale, fill)
+        return dq, dk, dv, None, None, None, None, None
+
+
+def fused_attention_ok(C, H, window, p_drop):
+    return (not window) and p_drop == 0 and C % H == 0 and (C // H) in (64, 96, 128)
+
+
 class _AttnCoreFn(torch.autograd.Function):
     """softmax(mask(scale q^T k + rel_k)) (dropout) v + rel_v on (B, C, T) tensors; see csrc/attn_f32.hip."""
 
@@ -179,8 +203,11 @@ class MultiHeadAttention(nn.Module):
         if w:
             assert x.shape[2] == c.shape[2], "Relative attention is only available for self-attention."
         p = self.p_dropout if self.training else 0.0
-        out = _AttnCoreFn.apply(q, k, v, self.emb_rel_k if w else None, self.emb_rel_v if w else None, qm, km, self.n_heads,
-                                w, 1.0 / math.sqrt(self.k_channels), -1e4, p, _SeedSource.next() if p > 0 else 0)
+        if fused_attention_ok(q.shape[1], self.n_heads, w, p):      # the MRTE text<->audio cross-attention: fused kernels
+            out = _AttnFusedFn.apply(q, k, v, qm, km, self.n_heads, 1.0 / math.sqrt(self.k_channels), -1e4)
+        else:
+            out = _AttnCoreFn.apply(q, k, v, self.emb_rel_k if w else None, self.emb_rel_v if w else None, qm, km, self.n_heads,
+                                    w, 1.0 / math.sqrt(self.k_channels), -1e4, p, _SeedSource.next() if p > 0 else 0)
         return self.conv_o(out, resid=resid, bbias=bbias, omask=omask)
 
 
