@@ -592,13 +592,28 @@ chk = torch.stack([tr.optim_g.flat_p.double().sum(), tr.optim_d.flat_p.double().
 gathered = [torch.zeros_like(chk) for _ in range(2)]
 torch.distributed.all_gather(gathered, chk)
 assert torch.equal(gathered[0][:2], gathered[1][:2]), gathered
+# the same step recorded as three hipGraph segments around the two all-reduces (world size > 1 used to mean ~9 k eager launches)
+before = tr.optim_g.flat_p.clone()
+for _ in range(3):
+    out = tr.train_step_graphed(next(loader))
+torch.cuda.synchronize()
+st = tr._graph_state
+assert st["graph"] is not None and len(st["segments"]) == 3 and len(st["between"]) == 2, (st["graph"], st.get("segments"))
+vals = {k: float(v) for k, v in out.items()}
+assert all(v == v and abs(v) < 1e9 for v in vals.values()), vals
+assert not torch.equal(before, tr.optim_g.flat_p)
+chk = torch.stack([tr.optim_g.flat_p.double().sum(), tr.optim_d.flat_p.double().sum(), cb.embed.double().sum()]).cpu()
+gathered = [torch.zeros_like(chk) for _ in range(2)]
+torch.distributed.all_gather(gathered, chk)
+assert torch.equal(gathered[0][:2], gathered[1][:2]), gathered
 sys.stdout.write("rank" + str(tr.rank) + "-ok " + json.dumps(vals) + "\n")
 """
 
 
 def test_vqvae_two_ranks_sharing_the_gpu(tmp_path):
     """N > 1 control flow of the VQ-VAE-GAN trainer on the one GPU of the test box (gloo, both ranks on cuda:0): parameter
-    broadcast, codebook broadcast, the two flat gradient all-reduces; replicas stay bit-identical."""
+    broadcast, codebook broadcast, the two flat gradient all-reduces; replicas stay bit-identical -- eagerly, then with the step
+    recorded as three hipGraph segments around the two all-reduces."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -94,10 +94,23 @@ class VqvaeStep:
         if self.dp.enabled:                                                  # DDP broadcast_buffers=True (rank-0 codebook)
             self.dp.broadcast_(*[b for b in self.net_g.buffers() if b.is_floating_point()])
 
-    def __call__(self, data, inject=None):
+    def _exchange(self, which, cut):
+        """The step's collectives: 1 = discriminator gradients, 2 = generator gradients (flat SUM all-reduces).  `cut(fn)`, when
+        given, is how a caller that records the step as hipGraph segments takes the collective OUT of the recording: it ends
+        the current segment, runs fn, starts the next one (VqvaeTrainer._capture)."""
+        arena = self.optim_d.flat_g if which == 1 else self.optim_g.flat_g
+        fn = lambda: self.dp.allreduce_grads_(arena)   # noqa: E731
+        if cut is None:
+            fn()
+        else:
+            cut(fn)
+
+    def __call__(self, data, inject=None, cut=None, sync_buffers=True):
         """data: dict(wav (B, T) f32, wav_lengths, text, text_lengths) on the device.  Returns a dict of device scalars."""
         h, tr = self.hps.data, self.hps.train
         inject = dict(inject or {})
+        if sync_buffers:
+            self._sync_buffers()      # (first thing in the step: nothing before the generator forward touches a buffer)
         wav, wav_lengths, text, text_lengths = data["wav"], data["wav_lengths"], data["text"], data["text_lengths"]
         y = wav
         spec = spectrogram_torch(wav, h.filter_length, h.hop_length, h.win_length, center=False)
@@ -109,7 +122,6 @@ class VqvaeStep:
         else:
             wav_aug = augment(wav, self.aug, self.hps)                        # train.py:337-338 (PEQ part)
         spec_aug = spec if wav_aug is wav else spectrogram_torch(wav_aug, h.filter_length, h.hop_length, h.win_length, center=False)
-        self._sync_buffers()
         y_hat, kl_ssl, ids_slice, z_mask, (z, z_p, m_p, logs_p, m_q, logs_q), quantized = self.net_g(
             wav, wav_aug, wav_lengths, spec, spec_aug, spec_lengths, text, text_lengths, **inject)
         mel = spec_to_mel_torch(spec, h.filter_length, h.n_mel_channels, h.sampling_rate, h.mel_fmin, h.mel_fmax)
@@ -123,7 +135,7 @@ class VqvaeStep:
         loss_disc, losses_disc_r, losses_disc_g = L.discriminator_loss(y_d_hat_r, y_d_hat_g)
         self.optim_d.zero_grad()
         (loss_disc * scale).backward()
-        self.dp.allreduce_grads_(self.optim_d.flat_g)
+        self._exchange(1, cut)
         self.optim_d.step()
         # ---- generator phase.  The reference lets this backward fill net_d's parameter gradients too and throws them away at
         # the next `optim_d.zero_grad()` (vqvae/train.py:354-372 there): here the discriminator's parameters are frozen for the
@@ -144,7 +156,7 @@ class VqvaeStep:
             for prm in self._d_params:
                 prm.requires_grad_(True)
         self.optim_d.zero_grad()
-        self.dp.allreduce_grads_(self.optim_g.flat_g)
+        self._exchange(2, cut)
         self.optim_g.step()
         return {"loss_disc": loss_disc.detach(), "loss_gen": loss_gen.detach(), "loss_fm": loss_fm.detach(),
                 "loss_mel": loss_mel.detach(), "kl_ssl": kl_ssl.detach(), "loss_kl": loss_kl.detach(),
@@ -190,16 +202,17 @@ class VqvaeTrainer:
     lr = property(lambda self: self.optim_g.lr,
                   lambda self, v: (setattr(self.optim_g, "lr", v), setattr(self.optim_d, "lr", v)) and None)
 
-    def train_step(self, data, inject=None):
+    def train_step(self, data, inject=None, cut=None, sync_buffers=True):
         ops.dropout_counter(self.device).add_(1)          # fresh dropout masks per step (also under graph replay)
-        return self.step_fn(data, inject)
+        return self.step_fn(data, inject, cut=cut, sync_buffers=sync_buffers)
 
     # ---- the whole two-phase step as ONE hipGraph ----------------------------------------------------------------------------
     def train_step_graphed(self, data):
         """Replays the complete step (spectrograms, G forward, both D passes, six losses, both backward passes, both AdamW
         updates, codebook EMA: ~10 k kernel launches) from one captured hipGraph.  `data` is copied into static input
         buffers; the returned loss scalars are the graph's static outputs (read them before the next call).  Requirements:
-        one fixed batch shape, world size 1 (collectives are not captured), codebook initialised.  The first call with a new
+        one fixed batch shape, codebook initialised.  With world size > 1 the step is recorded as three graphs around the two
+        gradient all-reduces (see _capture).  The first call with a new
         shape runs two eager warm-up steps and records; if capture is refused the trainer says so ONCE and keeps running
         launch by launch."""
         key = tuple((k, tuple(v.shape)) for k, v in sorted(data.items()))
@@ -211,12 +224,17 @@ class VqvaeTrainer:
             return self.train_step(data)
         for k, v in data.items():
             st["inputs"][k].copy_(v)
-        st["graph"].replay()
+        if st.get("segments"):            # data-parallel: three recorded segments around the two gradient all-reduces
+            self.step_fn._sync_buffers()
+            for i, g in enumerate(st["segments"]):
+                g.replay()
+                if i < len(st["between"]):
+                    st["between"][i]()
+        else:
+            st["graph"].replay()
         return st["out"]
 
     def _capture(self, data, key):
-        if self.dp.enabled:
-            return {"key": key, "graph": None}
         cb = self.net_g.quantizer.vq.layers[0]._codebook
         if not bool(cb.inited):
             raise ops.TttsError("train_step_graphed: run the first (k-means initialising) step eagerly")
@@ -232,6 +250,29 @@ class VqvaeTrainer:
                     self.train_step(inputs)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
+            if self.dp.enabled:
+                # World size > 1: the collectives cannot be recorded, so the step is recorded as THREE graphs that share one
+                # memory pool (tensors and the autograd graph of an earlier segment stay valid in the later ones) with the two
+                # flat gradient all-reduces between them -- and the codebook broadcast in front -- issued eagerly at replay.
+                # (Their overlap with compute is limited by the step itself: the generator phase's discriminator forward
+                # needs the UPDATED discriminator, i.e. the first all-reduce, and nothing follows the second one.)
+                segs, between = [torch.cuda.CUDAGraph()], []
+                ctx = [torch.cuda.graph(segs[0])]
+
+                def cut(fn):
+                    ctx[0].__exit__(None, None, None)
+                    between.append(fn)
+                    fn()                                     # (keeps the ranks' collective sequences aligned during recording)
+                    segs.append(torch.cuda.CUDAGraph())
+                    ctx[0] = torch.cuda.graph(segs[-1], pool=segs[0].pool())
+                    ctx[0].__enter__()
+                self.step_fn._sync_buffers()
+                ctx[0].__enter__()
+                try:
+                    out = self.train_step(inputs, cut=cut, sync_buffers=False)
+                finally:
+                    ctx[0].__exit__(None, None, None)
+                return {"key": key, "graph": segs[0], "segments": segs, "between": between, "inputs": inputs, "out": out}
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 out = self.train_step(inputs)
