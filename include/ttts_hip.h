@@ -483,7 +483,9 @@ int ttts_conv1d_wgrad_f32(const float* dy, const float* x, float* dw, float* db,
                           int32_t Cout, int32_t Lout, int32_t K, int32_t stride, int32_t pad, int32_t dil,
                           int32_t groups, float dy_slope, float x_slope, const ttts_conv_ctx* ctx, void* stream);
 int ttts_conv1d_bias_grad_f32(const float* dy, float* db, int32_t B, int32_t C, int32_t L, void* stream);
-int ttts_weight_norm_fwd_f32(const float* v, const float* g, float* w, float* norm, int32_t rows, int32_t n,
+/* zero_out (ABI v5; or NULL): a second [rows][n] buffer cleared in the same pass -- the buffer the layer's weight-gradient call
+ * will accumulate into (ttts_conv1d_wgrad_f32 adds), so that the backward needs no fill launch for it */
+int ttts_weight_norm_fwd_f32(const float* v, const float* g, float* w, float* norm, float* zero_out, int32_t rows, int32_t n,
                              void* stream);
 int ttts_weight_norm_bwd_f32(const float* dw, const float* v, const float* g, const float* norm, float* dv,
                              float* dg, int32_t rows, int32_t n, void* stream);

@@ -498,9 +498,11 @@ __global__ __launch_bounds__(256) void conv1d_bias_grad_kernel(const float* __re
 }
 
 // weight norm over dim 0 (torch.nn.utils.weight_norm / parametrizations.weight_norm): w[r] = g[r] * v[r] / ||v[r]||
+// zero (optional): a [rows][n] buffer cleared in the same pass -- the accumulate-into buffer of this layer's weight gradient
+// (the backward used to launch one fill per weight-normed convolution for it: ~420 per VQ-VAE-GAN step)
 __global__ __launch_bounds__(256) void weight_norm_fwd_kernel(const float* __restrict__ v, const float* __restrict__ g,
-                                                              float* __restrict__ w, float* __restrict__ norm, int rows,
-                                                              int n) {
+                                                              float* __restrict__ w, float* __restrict__ norm, float* __restrict__ zero,
+                                                              int rows, int n) {
   __shared__ float sh[4];
   const int r = blockIdx.x;
   float s = 0.f;
@@ -511,7 +513,10 @@ __global__ __launch_bounds__(256) void weight_norm_fwd_kernel(const float* __res
   const float nr = sqrtf((sh[0] + sh[1]) + (sh[2] + sh[3]));
   if (threadIdx.x == 0) norm[r] = nr;
   const float sc = g[r] / nr;
-  for (int i = threadIdx.x; i < n; i += 256) w[(int64_t)r * n + i] = v[(int64_t)r * n + i] * sc;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    w[(int64_t)r * n + i] = v[(int64_t)r * n + i] * sc;
+    if (zero) zero[(int64_t)r * n + i] = 0.f;
+  }
 }
 // dg[r] += <dw[r], v[r]> / ||v||;   dv[r] += g/||v|| * (dw[r] - v[r] * <dw[r], v[r]> / ||v||^2)
 __global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __restrict__ dw, const float* __restrict__ v,
@@ -788,10 +793,10 @@ extern "C" int ttts_conv1d_bias_grad_f32(const float* dy, float* db, int32_t B, 
   return bias_grad_launch(dy, db, B, C, L, as_stream(stream));
 }
 
-extern "C" int ttts_weight_norm_fwd_f32(const float* v, const float* g, float* w, float* norm, int32_t rows, int32_t n,
-                                        void* stream) {
+extern "C" int ttts_weight_norm_fwd_f32(const float* v, const float* g, float* w, float* norm, float* zero_out, int32_t rows,
+                                        int32_t n, void* stream) {
   TTTS_REQUIRE(v && g && w && norm && rows > 0 && n > 0, "weight_norm_fwd: bad arguments");
-  weight_norm_fwd_kernel<<<rows, 256, 0, as_stream(stream)>>>(v, g, w, norm, rows, n);
+  weight_norm_fwd_kernel<<<rows, 256, 0, as_stream(stream)>>>(v, g, w, norm, zero_out, rows, n);
   return check_launch("weight_norm_fwd");
 }
 

@@ -187,7 +187,7 @@ SIGNATURES = {
                                      _P, _P]),
     "ttts_lrelu_bwd_f32": (_I32, [_P, _P, _P, _F, _I64, _P]),
     "ttts_conv1d_bias_grad_f32": (_I32, [_P, _P, _I32, _I32, _I32, _P]),
-    "ttts_weight_norm_fwd_f32": (_I32, [_P, _P, _P, _P, _I32, _I32, _P]),
+    "ttts_weight_norm_fwd_f32": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _P]),
     "ttts_weight_norm_bwd_f32": (_I32, [_P, _P, _P, _P, _P, _P, _I32, _I32, _P]),
     "ttts_tanh_bwd_f32": (_I32, [_P, _P, _P, _I64, _P]),
     "ttts_add4_scale_f32": (_I32, [_P, _P, _P, _P, _F, _P, _I64, _P]),

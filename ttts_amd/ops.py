@@ -810,13 +810,16 @@ def conv1d_bias_grad(dy, out=None):
     return db
 
 
-def weight_norm_fwd(v, g):
+def weight_norm_fwd(v, g, want_zero=False):
+    """w = g v / |v| per output row.  want_zero: also returns a cleared buffer of w's shape, written by the same kernel (the
+    accumulate-into buffer of the layer's weight gradient)."""
     v = v.contiguous()
     rows, n = v.shape[0], v.numel() // v.shape[0]
     w = torch.empty_like(v)
+    zero = torch.empty_like(v) if want_zero else None
     norm = torch.empty(rows, dtype=torch.float32, device=v.device)
-    check(_l.get().ttts_weight_norm_fwd_f32(_p(v), _p(g.contiguous()), _p(w), _p(norm), rows, n, _stream()), "weight_norm_fwd")
-    return w, norm
+    check(_l.get().ttts_weight_norm_fwd_f32(_p(v), _p(g.contiguous()), _p(w), _p(norm), _p(zero), rows, n, _stream()), "weight_norm_fwd")
+    return (w, norm, zero) if want_zero else (w, norm)
 
 
 def weight_norm_bwd(dw, v, g, norm, dv=None, dg=None):

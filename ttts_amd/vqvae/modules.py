@@ -27,6 +27,14 @@ def get_padding(kernel_size, dilation=1):
 
 
 # ---- autograd glue ------------------------------------------------------------------------------------------------------
+def _take_dw_buffer(w):
+    """The pre-cleared weight-gradient buffer _WeightNormFn.forward attached to its output (once), else None."""
+    z = getattr(w, "_ttts_dw_zero", None)
+    if z is not None:
+        w._ttts_dw_zero = None
+    return z
+
+
 def _grad_slot(p):
     """A leaf parameter whose `.grad` already exists (FlatAdamW gives every parameter a persistent view of the flat
     gradient arena): the backward kernels, which all ACCUMULATE, then write straight into it and the Function returns
@@ -40,7 +48,15 @@ def _grad_slot(p):
 class _WeightNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, v, g):
-        w, norm = ops.weight_norm_fwd(v, g)
+        # The same launch clears the buffer this layer's weight-gradient kernels will accumulate into (they add; w is not a leaf,
+        # so there is no .grad slot for it): the first convolution backward that uses `w` takes it from the tensor
+        # (_take_dw_buffer), later uses of the same w fall back to a fresh zero-filled buffer.
+        want = torch.is_grad_enabled() and (v.requires_grad or g.requires_grad)
+        if want:
+            w, norm, zero = ops.weight_norm_fwd(v, g, want_zero=True)
+            w._ttts_dw_zero = zero
+        else:
+            w, norm = ops.weight_norm_fwd(v, g)
         ctx.save_for_backward(v, g, norm)
         ctx.refs = (v, g)
         return w
@@ -92,10 +108,12 @@ class _Conv1dFn(torch.autograd.Function):
         bslot = _grad_slot(ctx.refs[1]) if want_b else None
         if need[1]:
             slot = _grad_slot(ctx.refs[0])
+            if slot is None:
+                slot_w = _take_dw_buffer(ctx.refs[0])      # weight-normed: the buffer its forward cleared (None: a fresh one)
             if want_b:      # the bias gradient rides on the weight-gradient call (its kernels stream dy anyway)
                 db = bslot if bslot is not None else torch.zeros(dy.shape[1], dtype=torch.float32, device=dy.device)
-            dw = ops.conv1d_wgrad(dy, x, w.shape[2], stride, pad, dil, x_slope=in_slope, groups=groups, out=slot,
-                                  db=db if want_b else None)
+            dw = ops.conv1d_wgrad(dy, x, w.shape[2], stride, pad, dil, x_slope=in_slope, groups=groups,
+                                  out=slot if slot is not None else slot_w, db=db if want_b else None)
             if slot is not None:
                 dw = None
         elif want_b:
@@ -131,7 +149,8 @@ class _ConvTranspose1dFn(torch.autograd.Function):
             dx = ops.conv1d_fwd(dy, w, stride=stride, pad=pad, gate=x if in_slope != 1.0 else None, gate_slope=in_slope)
         if need[1]:
             slot = _grad_slot(ctx.refs[0])
-            dw = ops.conv1d_wgrad(x, dy, w.shape[2], stride, pad, 1, dy_slope=in_slope, out=slot)
+            dw = ops.conv1d_wgrad(x, dy, w.shape[2], stride, pad, 1, dy_slope=in_slope,
+                                  out=slot if slot is not None else _take_dw_buffer(ctx.refs[0]))
             if slot is not None:
                 dw = None
         if has_b and need[2]:
