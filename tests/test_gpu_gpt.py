@@ -435,3 +435,27 @@ def test_ranged_gradient_exchange_two_ranks_nccl():
     r = _torchrun([os.path.join(ROOT, "tools", "dp_consistency.py")], 29700 + os.getpid() % 90)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     assert "rank0-consistent" in r.stdout and "rank1-consistent" in r.stdout
+
+
+def test_engine_keeps_buffers_plans_and_graphs_of_recent_shapes(gpt):
+    """Real batches change (B, Tt, Tm) every step: a shape that comes back must find its buffers, descriptor tables and captured
+    step again (GptEngine._ensure_buffers' shape cache) and give the same losses as before."""
+    from oracle import gpt_ref
+    dev = torch.device("cuda:0")
+    cfg = dict(gpt_ref.GPT_CONFIG, layers=2)
+    eng = gpt.GptEngine(cfg, dev, dropout_p=0.0, seed=1)
+    eng.load_state_dict(gpt_ref.det_state_dict(cfg))
+    g = torch.Generator().manual_seed(5)
+
+    def batch(B, tt, tm):
+        text = torch.randint(1, 250, (B, tt), generator=g).to(dev); mel = torch.randint(0, 1024, (B, tm), generator=g).to(dev)
+        return gpt.prepare_tokens(eng.c, text, torch.full((B,), tt), mel, torch.full((B,), tm * 1024))
+
+    ta, tb = batch(2, 20, 50), batch(3, 12, 70)
+    eng.set_tokens(*ta); eng.zero_grad(); eng.forward(); eng.backward(); torch.cuda.synchronize()
+    la, ptr_a, plans_a = eng.losses(), eng.b["xs"][0].data_ptr(), eng._dw_plans
+    eng.set_tokens(*tb); eng.zero_grad(); eng.forward(); eng.backward(); torch.cuda.synchronize()
+    assert eng.b["xs"][0].shape[0] == 3 * (14 + 72)
+    eng.set_tokens(*ta); eng.zero_grad(); eng.forward(); eng.backward(); torch.cuda.synchronize()
+    assert eng.b["xs"][0].data_ptr() == ptr_a and eng._dw_plans is plans_a and eng.losses() == la
+    assert len(eng._shape_cache) == 1

@@ -15,6 +15,7 @@ as a fixed sequence of hand-written HIP kernels (C ABI, `ttts_amd.ops`) over mem
 
 The whole step is free of host reads of device data, hence capturable in one hipGraph (`capture=True`).
 """
+import collections
 import math
 
 import os
@@ -186,6 +187,20 @@ class GptEngine:
         key = (B, Tt, Tm)
         if self._bufs_key == key:
             return
+        # Real batches change shape from step to step (the reference clips every batch to its own longest text / clip): the
+        # buffers, grouped-launch descriptor tables and captured graphs of the last few shapes are kept (TTTS_SHAPE_CACHE, default
+        # 4 shapes: 288 GB of HBM is the budget this is sized for), so a shape that comes back costs neither allocations nor the
+        # synchronous descriptor uploads nor a re-capture.
+        cache = self.__dict__.setdefault("_shape_cache", collections.OrderedDict())
+        if self._bufs_key is not None:
+            cache[self._bufs_key] = (self.b, self._Mp, self._dw_plans, self._graph, self._graph_key)
+            cache.move_to_end(self._bufs_key)
+            while len(cache) > max(1, int(os.environ.get("TTTS_SHAPE_CACHE", "4"))):
+                cache.popitem(last=False)
+        if key in cache:
+            self.b, self._Mp, self._dw_plans, self._graph, self._graph_key = cache.pop(key)
+            self._bufs_key = key
+            return
         c, dev = self.c, self.device
         D, L, H = c["model_dim"], c["layers"], c["heads"]
         S = Tt + Tm
@@ -276,7 +291,9 @@ class GptEngine:
                       (P_(b["ln1"][i]), P_(b["dqkv_l"][i]), G(pre + "attn.c_attn.weight")),
                       (P_(b["att"][i]), P_(b["dy_att"][i]), G(pre + "attn.c_proj.weight"))]
         tiles = [ops.tn_desc_tiles(at.shape[1], bt.shape[1]) for at, bt, _ in probs]
-        out = left_out_problems(tiles, 2 * ops.device_info()["cus"])
+        if not hasattr(self, "_cus"):
+            self._cus = ops.device_info()["cus"]
+        out = left_out_problems(tiles, 2 * self._cus)
         grouped = [pr for j, pr in enumerate(probs) if j not in out]
         single = [pr for j, pr in enumerate(probs) if j in out]
         # one launch takes at most 64 descriptors (the kernel finds its problem with one lane per descriptor): models deeper than
