@@ -315,7 +315,9 @@ class GptEngine:
                     G("gpt.h.%d.mlp.c_proj.bias" % (i - 1)) if i > 0 else None)]
             # (mlp.c_fc.bias rides in the dGELU epilogue.  The same on the attention backward's dq / dk / dv stores was measured
             # and removed: 320 fp32 atomics per bias element from 2560 waves cost the two kernels +50 us each; so was computing delta in
-            # the dQ kernel's prologue instead of the 7 us pre-pass: the dQ kernel, then first to touch dO / O, lost 9 us)
+            # the dQ kernel's prologue instead of the 7 us pre-pass: the dQ kernel, then first to touch dO / O, lost 9 us; and running dQ on a
+            # side stream beside dK / dV (they only share the delta pre-pass): GPT step 3.60 vs 3.47 ms -- the two kernels' workgroups
+            # crowd each other out of the CUs instead of filling each other's tails)
             cs += [(b["dqkv_l"][i], G(pre + "attn.c_attn.bias"), None)]
         M, D = b["d_fc_l"][0].shape[0], self.c["model_dim"]
         ln_plan = ops.LnFinalizePlan(ln, M, D, self.device)
