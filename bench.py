@@ -413,7 +413,9 @@ def main():
         eng.optimizer_step(lr=tr["lr"], max_norm=1.0, warmup_steps=500)
         eng.step_count += 1
 
-    for _ in range(args.warmup):
+    # W untimed warm-up steps -- and, when W is small, enough further untimed steps that the timed region starts with the chip at
+    # its steady clock (the first replays after an idle stretch run below it; 50 steps = 0.17 s)
+    for _ in range(max(args.warmup, 50)):
         step()
     dp.barrier()
     torch.cuda.synchronize()
