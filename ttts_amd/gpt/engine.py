@@ -222,15 +222,17 @@ class GptEngine:
         b["fc_act"] = [z(M, 4 * D) for _ in range(L)]
         b["lnf"] = e(M, D, dt=f32)
         b["fstats"] = [e(M, dt=f32) for _ in range(4)]
-        b["enc"] = e(M, D)                                   # split layout: text rows, then mel rows
+        # (split layout: text rows, then mel rows.  Zero-filled with 64 spare rows, and the dlogits buffers below are zero-padded to
+        # whole 64-row tiles: the two head weight gradients ride in the grouped dW launch, whose reduction runs over padded rows)
+        b["enc"] = torch.zeros(M + 64, D, dtype=bf, device=dev)[:M]
         b["logits_t"] = torch.zeros(B * Tt, self.ld_t, dtype=bf, device=dev)
         b["logits_m"] = torch.zeros(B * Tm, self.ld_m, dtype=bf, device=dev)
         b["rows_t"] = [e(B * Tt, dt=f32) for _ in range(2)]  # row_loss, row_lse
         b["rows_m"] = [e(B * Tm, dt=f32) for _ in range(2)]
         b["losses"] = torch.zeros(2, dtype=f32, device=dev)  # loss_text, loss_mel
         # backward temporaries
-        b["dlog_t"] = torch.zeros(B * Tt, self.ld_t, dtype=bf, device=dev)
-        b["dlog_m"] = torch.zeros(B * Tm, self.ld_m, dtype=bf, device=dev)
+        b["dlog_t"] = torch.zeros(_up(B * Tt, 64), self.ld_t, dtype=bf, device=dev)[:B * Tt]
+        b["dlog_m"] = torch.zeros(_up(B * Tm, 64), self.ld_m, dtype=bf, device=dev)[:B * Tm]
         b["d_enc"] = e(M, D)
         b["d_tmp"] = e(M, D, dt=f32)
         b["dres"] = e(M, D, dt=f32)
@@ -290,6 +292,12 @@ class GptEngine:
                       (P_(b["fc_act"][i]), P_(b["dy_mlp"][i]), G(pre + "mlp.c_proj.weight")),
                       (P_(b["ln1"][i]), P_(b["dqkv_l"][i]), G(pre + "attn.c_attn.weight")),
                       (P_(b["att"][i]), P_(b["dy_att"][i]), G(pre + "attn.c_proj.weight"))]
+        if hi == self.c["layers"]:        # the two head weight gradients (reduction over the text / mel rows of the split layout)
+            rows64 = lambda t, r: torch.as_strided(t, (_up(r, 64), t.shape[1]), t.stride(), t.storage_offset())   # noqa: E731
+            Bt_, Tt_, Tm_ = self._bufs_key
+            nt_rows, nm_rows = Bt_ * Tt_, Bt_ * Tm_
+            probs += [(rows64(b["dlog_t"], nt_rows)[:, :self.nt], rows64(b["enc"][:nt_rows], nt_rows), G("text_head.weight")),
+                      (rows64(b["dlog_m"], nm_rows)[:, :self.nm], rows64(b["enc"][nt_rows:], nm_rows), G("mel_head.weight"))]
         tiles = [ops.tn_desc_tiles(at.shape[1], bt.shape[1]) for at, bt, _ in probs]
         if not hasattr(self, "_cus"):
             self._cus = ops.device_info()["cus"]
@@ -481,8 +489,9 @@ class GptEngine:
         enc_t, enc_m = b["enc"][:B * Tt], b["enc"][B * Tt:]
         fork()
         with torch.cuda.stream(side):
-            ops.gemm_tn_accum(b["dlog_t"], enc_t, G("text_head.weight"), mo=self.nt, workspace=b["tn_ws"])
-            ops.gemm_tn_accum(b["dlog_m"], enc_m, G("mel_head.weight"), mo=self.nm, workspace=b["tn_ws"])
+            if not self.grouped_dw:      # grouped: the head weight gradients are two more problems of the section's grouped launch
+                ops.gemm_tn_accum(b["dlog_t"], enc_t, G("text_head.weight"), mo=self.nt, workspace=b["tn_ws"])
+                ops.gemm_tn_accum(b["dlog_m"], enc_m, G("mel_head.weight"), mo=self.nm, workspace=b["tn_ws"])
             if not self.grouped_dw:      # grouped: part of the section's batched column-sum launch (_run_dw)
                 ops.colsum_accum(b["dlog_t"], G("text_head.bias"), n=self.nt)
                 ops.colsum_accum(b["dlog_m"], G("mel_head.bias"), n=self.nm)
