@@ -298,19 +298,26 @@ __global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* __re
   }
 }
 
-// the same for several deferred ttts_layernorm_bwd_ex calls in one launch: blockIdx.y picks the call
+// the same for several deferred ttts_layernorm_bwd_ex calls in one launch: blockIdx.y picks the call.  With 14 calls' worth of
+// workgroups the columns can be 32 wide (128-byte row segments instead of 64): each thread carries the two row classes ty and
+// ty + 32 of the single-call kernel separately, so the sums are formed in exactly its order (bitwise equal results)
+constexpr int LNB_COLS = 32;
 __global__ __launch_bounds__(1024) void ln_bwd_finalize_batched_kernel(const ttts_ln_finalize_desc* __restrict__ desc, int nblk, int D) {
-  __shared__ float sh[LNF_LANES][LNF_COLS + 1];
+  __shared__ float sh[LNF_LANES][LNB_COLS + 1];
   const ttts_ln_finalize_desc dd = desc[blockIdx.y];
   const float* partial = reinterpret_cast<const float*>(dd.workspace);
-  const int tx = threadIdx.x % LNF_COLS, ty = threadIdx.x / LNF_COLS;
-  const int j = blockIdx.x * LNF_COLS + tx;
-  float s = 0.f;
+  const int tx = threadIdx.x % LNB_COLS, ty = threadIdx.x / LNB_COLS;      // ty < 32
+  const int j = blockIdx.x * LNB_COLS + tx;
+  float s0 = 0.f, s1 = 0.f;
   if (j < 3 * D) {
 #pragma unroll 4
-    for (int b = ty; b < nblk; b += LNF_LANES) s += partial[(size_t)b * 3 * D + j];
+    for (int b = ty; b < nblk; b += LNF_LANES) {
+      s0 += partial[(size_t)b * 3 * D + j];
+      if (b + 32 < nblk) s1 += partial[(size_t)(b + 32) * 3 * D + j];
+    }
   }
-  sh[ty][tx] = s;
+  sh[ty][tx] = s0;
+  sh[ty + 32][tx] = s1;
   __syncthreads();
   if (ty == 0 && j < 3 * D) {
     float t = 0.f;
@@ -785,7 +792,7 @@ static int layernorm_bwd_impl(const void* dy, int dy_is_bf16, const float* x, co
 extern "C" int ttts_layernorm_bwd_finalize_batched(const ttts_ln_finalize_desc* desc, int32_t n_desc, int32_t M, int32_t D,
                                                    void* stream) {
   TTTS_REQUIRE(desc && n_desc > 0 && M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "layernorm_bwd_finalize_batched: bad arguments");
-  dim3 grid((unsigned)cdiv(3 * D, LNF_COLS), (unsigned)n_desc);
+  dim3 grid((unsigned)cdiv(3 * D, LNB_COLS), (unsigned)n_desc);
   ln_bwd_finalize_batched_kernel<<<grid, 1024, 0, as_stream(stream)>>>(desc, (int)cdiv(M, LN_BWD_ROWS), D);
   return check_launch("layernorm_bwd_finalize_batched");
 }
