@@ -51,7 +51,7 @@ class _WeightNormFn(torch.autograd.Function):
         # The same launch clears the buffer this layer's weight-gradient kernels will accumulate into (they add; w is not a leaf,
         # so there is no .grad slot for it): the first convolution backward that uses `w` takes it from the tensor
         # (_take_dw_buffer), later uses of the same w fall back to a fresh zero-filled buffer.
-        want = torch.is_grad_enabled() and (v.requires_grad or g.requires_grad)
+        want = any(ctx.needs_input_grad[:2])          # (grad mode is off inside a Function's forward: ask the ctx)
         if want:
             w, norm, zero = ops.weight_norm_fwd(v, g, want_zero=True)
             w._ttts_dw_zero = zero
