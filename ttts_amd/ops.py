@@ -976,11 +976,13 @@ def layernorm_ch_fwd(x, gamma, beta, eps=1e-5):
     return y, mean, rstd
 
 
-def layernorm_ch_bwd(dy, x, gamma, mean, rstd):
+def layernorm_ch_bwd(dy, x, gamma, mean, rstd, dg=None, db=None):
+    """dg / db given: the kernels ACCUMULATE into them (e.g. the parameters' .grad slices of a flat gradient arena)."""
     dy = _f32c(dy, "dy")
     B, C, T = x.shape
     dx = torch.empty_like(x)
-    dg = torch.zeros_like(gamma); db = torch.zeros_like(gamma)
+    dg = torch.zeros_like(gamma) if dg is None else dg
+    db = torch.zeros_like(gamma) if db is None else db
     check(_l.get().ttts_layernorm_ch_bwd_f32(_p(dy), _p(x), _p(gamma.contiguous()), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db),
                                              B, C, T, _stream()), "layernorm_ch_bwd")
     return dx, dg, db

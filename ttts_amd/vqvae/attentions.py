@@ -51,11 +51,17 @@ class _LayerNormChFn(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, eps):
         y, mean, rstd = ops.layernorm_ch_fwd(x, gamma, beta, eps)
         ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.refs = (gamma, beta)
         return y
 
     @staticmethod
     def backward(ctx, dy):
+        from .modules import _grad_slot
         x, gamma, mean, rstd = ctx.saved_tensors
+        sg, sb = _grad_slot(ctx.refs[0]), _grad_slot(ctx.refs[1])
+        if sg is not None and sb is not None:     # straight into the flat gradient arena: no zero fills, no autograd adds
+            dx, _, _ = ops.layernorm_ch_bwd(dy, x, gamma, mean, rstd, dg=sg, db=sb)
+            return dx, None, None, None
         dx, dg, db = ops.layernorm_ch_bwd(dy, x, gamma, mean, rstd)
         return dx, dg, db, None
 
