@@ -463,12 +463,20 @@ class _WNFn(torch.autograd.Function):
         m2 = mask.reshape(B, T).contiguous() if mask is not None else None
         out = torch.empty_like(x)
         saved, xi = [], x.contiguous()
+        want_dw = any(ctx.needs_input_grad[6:])
+        dwz = []
+        ctx.dwz = dwz
         for i in range(n_layers):
             in_v, in_g, in_b, rs_v, rs_g, rs_b = params[6 * i:6 * i + 6]
             dil = dil_rate ** i
             pad = int((K * dil - dil) / 2)
-            w_in, n_in = ops.weight_norm_fwd(in_v, in_g)
-            w_rs, n_rs = ops.weight_norm_fwd(rs_v, rs_g)
+            if want_dw:       # the same launches clear the buffers the backward's weight-gradient kernels accumulate into
+                w_in, n_in, z_in = ops.weight_norm_fwd(in_v, in_g, want_zero=True)
+                w_rs, n_rs, z_rs = ops.weight_norm_fwd(rs_v, rs_g, want_zero=True)
+                dwz += [z_in, z_rs]
+            else:
+                w_in, n_in = ops.weight_norm_fwd(in_v, in_g)
+                w_rs, n_rs = ops.weight_norm_fwd(rs_v, rs_g)
             bb = gcond[:, 2 * H * i:2 * H * (i + 1), 0].contiguous() if gcond is not None else None
             x_in = ops.conv1d_fwd(xi, w_in, in_b, None, 1, pad, dil, bbias=bb)
             acts = ops.gate_fwd(x_in, ops.GATE_TANH_SIGMOID)
@@ -502,7 +510,11 @@ class _WNFn(torch.autograd.Function):
             in_v, in_g, in_b, rs_v, rs_g, rs_b = params[6 * i:6 * i + 6]
             dil = dil_rate ** i
             pad = int((K * dil - dil) / 2)
-            dw_rs = torch.zeros_like(w_rs)
+            pre = (None, None)                                   # the buffers the forward cleared (used once)
+            if len(ctx.dwz) == 2 * n_layers and ctx.dwz[2 * i] is not None:
+                pre = (ctx.dwz[2 * i], ctx.dwz[2 * i + 1])
+                ctx.dwz[2 * i] = ctx.dwz[2 * i + 1] = None
+            dw_rs = pre[1] if pre[1] is not None else torch.zeros_like(w_rs)
             slots = [_grad_slot(t) for t in ctx.prefs[6 * i:6 * i + 6]]      # in_v, in_g, in_b, rs_v, rs_g, rs_b
             direct = all(sl is not None for sl in slots)
             if i < n_layers - 1:
@@ -522,7 +534,7 @@ class _WNFn(torch.autograd.Function):
             if has_g:
                 dgs[i] = ops.conv1d_bias_grad(dx_in.view(1, B * 2 * H, T)).view(B, 2 * H)
             db_in = slots[2] if direct else torch.zeros_like(in_b)
-            dw_in = ops.conv1d_wgrad(dx_in, xi, K, 1, pad, dil, db=db_in)
+            dw_in = ops.conv1d_wgrad(dx_in, xi, K, 1, pad, dil, db=db_in, out=pre[0])
             dres = ops.conv1d_dgrad(dx_in, w_in, T, 1, pad, dil, resid=dres, omask=m2 if i > 0 else None)
             if direct:
                 ops.weight_norm_bwd(dw_in, in_v, in_g, n_in, dv=slots[0], dg=slots[1])
