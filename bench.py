@@ -222,8 +222,9 @@ class KernelTimer:
     """Brackets every launch of the instrumented ops with HIP events on the launch stream (torch's current stream,
     which is the stream handed to the C ABI) and accumulates (time, algorithmic flops) per kernel family."""
 
-    def __init__(self, ops):
+    def __init__(self, ops, k_true=None):
         self.ops, self.records, self.saved, self.step = ops, [], {}, 0
+        self.k_true = k_true or {}     # padded reduction length -> algorithmic one (the heads' dX GEMMs run over the logits pitch)
 
     def next_step(self):
         self.step += 1
@@ -247,7 +248,7 @@ class KernelTimer:
 
         def f_nt(a, b, c, bias=None, aux=None, epilogue=0, n=None, k=None, **kw):
             M, K, N = a.shape[0], (a.shape[1] if k is None else k), (b.shape[0] if n is None else n)
-            return "gemm_nt_kernel<%s>" % epi[epilogue], 2.0 * M * N * K
+            return "gemm_nt_kernel<%s>" % epi[epilogue], 2.0 * M * N * self.k_true.get(K, K)
 
         def f_tn(at, bt, c, mo=None, no=None, **kw):
             return "gemm_tn_kernel", 2.0 * at.shape[0] * (at.shape[1] if mo is None else mo) * (bt.shape[1] if no is None else no)
@@ -459,7 +460,7 @@ def main():
     saved_overlap, eng.overlap_dw = eng.overlap_dw, False   # one stream: an event pair then brackets exactly one kernel
     step()                                    # one eager step untimed: absorbs first-eager-launch costs on every rank
     if rank == 0:
-        with KernelTimer(ops) as kt:
+        with KernelTimer(ops, {eng.ld_m: eng.nm, eng.ld_t: eng.nt}) as kt:
             for _ in range(args.profile_steps):
                 kt.next_step()
                 # park the GPU for ~20 ms first: the host then runs ahead of the device while it enqueues the step's ~300

@@ -47,6 +47,7 @@ struct GemmNtParams {
   const bf16* B; int64_t ldb;
   int K;
   GemmEpi e;
+  int phase;   // gemm_nt_glds_kernel: start-up delay per co-resident workgroup slot, in units of 1024 cycles (0: none)
 };
 
 // one output row piece: 8 consecutive columns n .. n + 7 of row m, v = acc + bias (fp32), through epilogue EPI
@@ -191,11 +192,11 @@ __device__ __forceinline__ void colsum_flush(const GemmEpi& e, float (&cs)[8], f
 // ---- shared epilogue: accumulators -> fp32 LDS stage (64 rows at a time) -> coalesced global access ---------------
 // stage: >= 64 * ST_LD floats of LDS that no wave reads any more (callers end their main loop with a barrier).
 // NJ = 32-column blocks per wave: 2 for the 128 x 128 tile, 1 for the 128 x 64 tile (N = 512 GEMMs: 292 -> 584 tiles)
-template <int EPI, int NJ = 2>
+template <int EPI, int NJ = 2, int NWM = 2>
 __device__ __forceinline__ void tile_epilogue(const GemmEpi& e, f32x16 (&acc)[2][2], float* stage, int m0, int n0,
                                               int tid) {
   constexpr int TPR = 8 * NJ;              // threads per 64*NJ-column row (8 columns each)
-  constexpr int RPP = 256 / TPR;           // rows per read-back pass
+  constexpr int RPP = 128 * NWM / TPR;     // rows per read-back pass (NWM = 64-row wave groups of the workgroup: 2 or 4)
   const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, h = lane >> 5;
   const bool bf16_out = (EPI == TTTS_EPI_STORE_BF16 || EPI == TTTS_EPI_GELU_BF16 || EPI == TTTS_EPI_DGELU_BF16);
   const bool vec_ok = bf16_out ? ((e.ldc & 7) == 0) : ((e.ldc & 3) == 0);
@@ -209,7 +210,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmEpi& e, f32x16 (&acc)[2]
   }
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
+  for (int half = 0; half < NWM; ++half) {
     if (wm == half) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -241,7 +242,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmEpi& e, f32x16 (&acc)[2]
     }
     __syncthreads();
   }
-  if ((EPI == TTTS_EPI_STORE_BF16 || EPI == TTTS_EPI_DGELU_BF16) && e.colsum) colsum_flush<TPR, 4>(e, cs, stage, n0, tid);
+  if ((EPI == TTTS_EPI_STORE_BF16 || EPI == TTTS_EPI_DGELU_BF16) && e.colsum) colsum_flush<TPR, 2 * NWM>(e, cs, stage, n0, tid);
 }
 
 // XCD-aware tile order: the dispatcher places workgroup b on XCD b % 8 (observed, speed only).  Remap so that each XCD
@@ -263,7 +264,7 @@ __device__ __forceinline__ int xcd_tile(int bid, int nblk) {
 // Slot s of row r holds the logical k-chunk s ^ f(r), f(r) = (r >> 1) & 7 for 128-byte rows (BKT = 64) and
 // (r >> 2) & 3 for 64-byte rows (BKT = 32): ds_read_b128 of a 16-lane service group then hits 64 distinct banks.
 // BKT = 64: 64 KB LDS, 2 workgroups per CU.  BKT = 32: 33.8 KB, 3 workgroups per CU -- their store phases and main
-// loops interleave instead of running in lock-step.
+// loops interleave instead of running in lock-step.  NWM = 4: eight waves on a 256 x 128 tile (see launch_nt).
 // Round-2 measurements on this kernel (c_attn shape 9248 x 1536 x 512, 28.3 us = 514 TF/s; all variants parity-tested):
 //  * PMC: 25 % MFMA-busy, 44 % of wave cycles parked in s_waitcnt / barrier, 30 % issue stalls, 5.4 VALU per MFMA;
 //  * an LDS-DMA RING (3 or 4 stages, loads 2-3 k-steps ahead, counted vmcnt across raw s_barriers) does NOT help: 64-deep
@@ -274,22 +275,39 @@ __device__ __forceinline__ int xcd_tile(int bid, int nblk) {
 //    ~14 us and overlap only half.  Two follow-ups were built, measured and removed: a persistent 8-wave kernel with store
 //    waves (1.6x slower: its tile hand-off serialised on LDS slots) and a K-split of the surplus tiles of the 292-tile
 //    launches (round 3: GPT step 4.01 vs 3.61 ms -- the fix-up launch and the fp32 slabs cost more than the tail they fill).
-template <int EPI, int BKT, int NJ = 2>
-__global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_nt_glds_kernel(GemmNtParams p) {
+template <int EPI, int BKT, int NJ = 2, int NWM = 2>
+__global__ __launch_bounds__(128 * NWM, (NWM == 4 ? 4 : BKT == 64 ? 2 : 3)) void gemm_nt_glds_kernel(GemmNtParams p) {
   constexpr int BNT = 64 * NJ;           // tile columns: 128, or 64 for the narrow-N GEMMs
+  constexpr int BMT = 64 * NWM;          // tile rows: 128 (four waves) or 256 (eight waves sharing the B stage)
+  constexpr int NWAVES = 2 * NWM;
   constexpr int CPR = BKT / 8;           // 16-byte chunks per row
   constexpr int RPI = 64 / CPR;          // rows per wave instruction
-  constexpr int IPW = 128 / RPI / 4;     // instructions per wave for the A tile
-  constexpr int IPWB = BNT / RPI / 4;    // ... and for the B tile
-  constexpr int TILE = BM * BKT;         // elements per buffer slot (the B slot is only partly used when BNT = 64)
-  constexpr int SMEM = (4 * TILE * 2 > 64 * ST_LD * 4) ? 4 * TILE : 64 * ST_LD * 2;  // elements
-  __shared__ __attribute__((aligned(16))) bf16 smem[SMEM];  // [buf][A|B][128*BKT]; reused as the epilogue stage
+  constexpr int IPW = BMT / RPI / NWAVES;   // instructions per wave for the A tile
+  constexpr int IPWB = BNT / RPI / NWAVES;  // ... and for the B tile
+  static_assert(IPWB >= 1, "tile too narrow for this many waves");
+  constexpr int TA = BMT * BKT, TB = BM * BKT;   // elements per A / B buffer slot (the B slot is only partly used when BNT = 64)
+  constexpr int SMEM = (2 * (TA + TB) * 2 > 64 * ST_LD * 4) ? 2 * (TA + TB) : 64 * ST_LD * 2;  // elements
+  __shared__ __attribute__((aligned(16))) bf16 smem[SMEM];  // [buf][A | B]; reused as the epilogue stage
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int tiles_n = (p.e.N + BNT - 1) / BNT;
   const int tile = xcd_tile(blockIdx.x, gridDim.x);
-  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BNT;
+  const int m0 = (tile / tiles_n) * BMT, n0 = (tile % tiles_n) * BNT;
   const int nk = p.K / BKT;
+  // The workgroups that share a CU start together and have equal lives, so their main loops (matrix cores + LDS fill) and
+  // their epilogues (VALU + HBM stores) fall on top of each other.  Where the launcher asks for it (p.phase: launches of many
+  // rounds, and the VALU-heavy dGELU epilogue) the first-round workgroup of wave slot s starts s * phase * 1024 cycles late, and
+  // the offset then carries through the rounds: the mel-head GEMM (8 rounds) -4 %, dGELU -4 % on top of their tile shapes
+  // (tools/ubench/nt_phase.cpp; the slot is read from HW_ID.wave_id -- if the hardware hands slots out differently the delay
+  // is merely useless).  Output bits do not depend on it.
+  constexpr int WGS_PER_CU = NWM == 4 ? 2 : BKT == 64 ? 2 : 3;
+  if (p.phase > 0 && blockIdx.x < 256 * WGS_PER_CU) {
+    if (wave == 0) {
+      const int slot = (int)((__builtin_amdgcn_s_getreg(6148) & 15u) / (NWM / 2)) % WGS_PER_CU;   // hwreg(HW_REG_HW_ID, 0, 4)
+      for (int i = 0; i < slot * p.phase; ++i) __builtin_amdgcn_s_sleep(16);                       // 16 x 64 cycles
+    }
+    __syncthreads();
+  }
   auto fsw = [](int r) { return BKT == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
 
   // this lane's DMA source rows (clamped: rows beyond M / N are loaded from the last valid row and never stored)
@@ -308,8 +326,8 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_nt_glds_kernel(
     gb[i] = p.B + (int64_t)min(n0 + r, p.e.N - 1) * p.ldb + chunk * 8;
   }
   auto issue = [&](int kt, int buf) {
-    bf16* as = smem + (buf * 2 + 0) * TILE + wave * (IPW * RPI) * BKT;
-    bf16* bs = smem + (buf * 2 + 1) * TILE + wave * (IPWB * RPI) * BKT;
+    bf16* as = smem + buf * (TA + TB) + wave * (IPW * RPI) * BKT;
+    bf16* bs = smem + buf * (TA + TB) + TA + wave * (IPWB * RPI) * BKT;
 #pragma unroll
     for (int i = 0; i < IPW; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[i] + kt * BKT),
@@ -337,8 +355,8 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_nt_glds_kernel(
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
-    const bf16* as = smem + (buf * 2 + 0) * TILE;
-    const bf16* bs = smem + (buf * 2 + 1) * TILE;
+    const bf16* as = smem + buf * (TA + TB);
+    const bf16* bs = as + TA;
 #pragma unroll
     for (int ks = 0; ks < BKT / 16; ++ks) {
       bf16x8 af[2], bfr[2];
@@ -355,7 +373,7 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_nt_glds_kernel(
     }
     __syncthreads();  // next tile landed (vmcnt(0)) and everyone is done reading this one
   }
-  tile_epilogue<EPI, NJ>(p.e, acc, reinterpret_cast<float*>(smem), m0, n0, tid);
+  tile_epilogue<EPI, NJ, NWM>(p.e, acc, reinterpret_cast<float*>(smem), m0, n0, tid);
 }
 
 // ---- NT, tall tile + deep ring for the narrow-N GEMMs (N <= 512: attn / mlp c_proj, dX of c_attn / c_fc) ------------------
@@ -370,7 +388,9 @@ __global__ __launch_bounds__(256, (BKT == 64 ? 2 : 3)) void gemm_nt_glds_kernel(
 // Tile: (32 MI) x (32 NW), NW waves: wave w owns output columns 32 w .. 32 w + 31 of all MI row blocks (MI accumulators; per
 // k-step of 16 it reads MI A fragments and one B fragment).  Instance in use: MI 5, 4 waves, 160 x 128, 4-slot ring -- 58 x 4 =
 // 232 tiles, one round (mlp c_proj 41.2 -> 36.3 us, dX c_fc 35.9 -> 30.4, attn c_proj 19.1 -> 17.5; GPT step -0.10 ms).
-// Measured and not kept: MI 8, 8 waves, 256 x 256, 2-slot ring for the N >= 1536 GEMMs (half the operand bytes per flop):
+// Measured and not kept: an L2 prefetch of the A panel 2 ... 12 k-tiles beyond the ring (one LDS-DMA dword per 128-byte line
+// into a dummy: +3 ... 8 % -- these launches are not waiting for HBM latency; tools/ubench/nt_phase.cpp);
+// MI 8, 8 waves, 256 x 256, 2-slot ring for the N >= 1536 GEMMs (half the operand bytes per flop):
 // c_attn 30.4 vs 28.8 us, c_fc 58.0 vs 43.0 us (296 tiles: two rounds) -- with one workgroup per CU the main loops and the
 // output stores of all CUs run in phases instead of interleaving.
 template <int EPI, int MI, int NW, int NST>
@@ -900,6 +920,27 @@ static void launch_nt(const GemmNtParams& p, int grid, hipStream_t s) {
       attr = true;
     }
     gemm_nt_tall_kernel<EPI, 5, 4, 4><<<tall_grid, 256, smem, s>>>(p);
+    return;
+  }
+  // eight waves on a 256 x 128 tile (four 64-row wave groups sharing every B stage; 32-deep stages, two workgroups per CU):
+  // 27 % fewer L2 -> LDS fill bytes per flop than two 128 x 128 workgroups, and the fill is what a k-step of the 128 x 128
+  // kernel waits for.  Taken where its tile count fills one round of the 2 x CUS slots or makes many rounds:
+  // c_attn 23.8 -> 21.9 us = 664 TF/s (37 x 12 = 444 tiles, was 876 in 1.7 rounds), an 8192 x 8194 head 140 -> 113 us (with the
+  // start-up stagger); NOT for N = 2048 at M = 9248 (592 tiles = 1.16 rounds: c_fc 38 -> 45 us).  Measured with
+  // tools/ubench/nt_phase.cpp (every variant bit-identical to the 128 x 128 kernel); also measured there and dropped: a
+  // 64-deep-stage version at one workgroup per CU (+8 %), ten waves on 320 x 128 (464 tiles for N = 2048, but 96 VGPRs: spills,
+  // +30 ... 58 %), s_setprio around the main loop (within noise), four 32-deep workgroups per CU (no change).
+  const int tiles8 = (int)(cdiv(p.e.M, 256) * cdiv(p.e.N, 128));
+  if (p.K % 64 == 0 && tiles8 > CUS && (tiles8 <= 2 * CUS || tiles8 >= 8 * CUS)) {
+    GemmNtParams q = p;
+    q.phase = tiles8 >= 8 * CUS ? 8 : 0;
+    gemm_nt_glds_kernel<EPI, 32, 2, 4><<<tiles8, 512, 0, s>>>(q);
+    return;
+  }
+  if (p.K % 64 == 0 && EPI == TTTS_EPI_DGELU_BF16) {   // 32-deep stages, three workgroups per CU, staggered: 52.2 -> 48.7 us
+    GemmNtParams q = p;
+    q.phase = 3;
+    gemm_nt_glds_kernel<EPI, 32><<<grid, 256, 0, s>>>(q);
     return;
   }
   if (p.K % 64 == 0) gemm_nt_glds_kernel<EPI, 64><<<grid, 256, 0, s>>>(p);

@@ -132,7 +132,9 @@ class GptEngine:
         d = self.c["model_dim"]
         self.nt = self.c["number_text_tokens"] * self.c["types"] + 1
         self.nm = self.c["number_mel_codes"]
-        self.ld_t, self.ld_m = _up(self.nt, 8), _up(self.nm, 8)
+        # row pitch of the logits / d-logits buffers = K of the heads' dX GEMMs: a multiple of 64 keeps those on the LDS-DMA kernels
+        # (mel head dX 8208 x 512 at K 1032: 23.8 us on the register-staged kernel; at K 1088: 17.3 us -- tools/ubench/nt_phase.cpp)
+        self.ld_t, self.ld_m = _up(self.nt, 64), _up(self.nm, 64)
         # transposed bf16 shadows: forward B operands of the Conv1D layers, dX B operands of the heads
         self.wT = {}
         entries = []
