@@ -47,6 +47,7 @@ int main(int argc, char** argv) {
       {"d(c_fc)  9248x512x2048  store", 9248, 512, 2048, 0},
       {"d(c_attn)9248x512x1536  store", 9248, 512, 1536, 0},
       {"attn c_proj 9248x512x512 resid", 9248, 512, 512, 2},
+      {"d(attn c_proj) 9248x512x512 store", 9248, 512, 512, 0},
       {"c_proj   9248x512x2048  resid", 9248, 512, 2048, 2},
   };
   const int NS = sizeof(shapes) / sizeof(shapes[0]);
@@ -123,6 +124,40 @@ int main(int argc, char** argv) {
       const double mn = t[li][0], med = t[li][ROUNDS / 2], base = t[0][ROUNDS / 2];
       printf("  %-44s min %7.2f  median %7.2f us  %6.1f TF/s  %+5.1f %%  %s\n", libs[li].path, mn, med,
              2.0 * s.M * s.N * s.K / med * 1e-6, (med / base - 1.0) * 100.0, same[li] ? "bit-identical" : "OUTPUT DIFFERS");
+    }
+    fflush(stdout);
+  }
+  // chains: a GEMM whose output is the next GEMM's A operand, timed as a pair (does the producer's store policy pay twice?)
+  struct Chain { const char* name; Shape a, b; };
+  const Chain chains[] = {
+      {"c_fc GELU -> mlp c_proj resid", {"", 9248, 2048, 512, 1}, {"", 9248, 512, 2048, 2}},
+      {"dGELU -> dX of c_fc", {"", 9248, 2048, 512, 3}, {"", 9248, 512, 2048, 0}},
+      {"c_attn -> (its output re-read as an A operand)", {"", 9248, 1536, 512, 0}, {"", 9248, 512, 1536, 0}},
+  };
+  void* dC2;
+  HIP(hipMalloc(&dC2, (size_t)Mx * 512 * 4));
+  for (const Chain& c : chains) {
+    std::vector<std::vector<float>> t(NL);
+    for (int r = 0; r < ROUNDS + 1; ++r)
+      for (int k = 0; k < NL; ++k) {
+        const Lib& l = libs[(k + r) % NL];
+        HIP(hipEventRecord(e0, st));
+        for (int i = 0; i < IT; ++i) {
+          int rc = l.nt(dA, c.a.K, dB, c.a.K, dC, c.a.N, dbias, dAux, c.a.M, c.a.N, c.a.K, c.a.epi, nullptr, 0.f, 0, nullptr, nullptr, st);
+          rc |= l.nt(dC, c.b.K, dB, c.b.K, dC2, c.b.N, dbias, nullptr, c.b.M, c.b.N, c.b.K, c.b.epi, nullptr, 0.f, 0, nullptr, nullptr, st);
+          if (rc) { fprintf(stderr, "chain rc %d: %s\n", rc, l.last()); exit(3); }
+        }
+        HIP(hipEventRecord(e1, st));
+        HIP(hipEventSynchronize(e1));
+        float ms;
+        HIP(hipEventElapsedTime(&ms, e0, e1));
+        if (r > 0) t[(k + r) % NL].push_back(ms * 1e3f / IT);
+      }
+    printf("== chain: %s\n", c.name);
+    for (int li = 0; li < NL; ++li) {
+      std::sort(t[li].begin(), t[li].end());
+      printf("  %-44s min %7.2f  median %7.2f us  %+5.1f %%\n", libs[li].path, t[li][0], t[li][ROUNDS / 2],
+             (t[li][ROUNDS / 2] / t[0][ROUNDS / 2] - 1.0) * 100.0);
     }
     fflush(stdout);
   }

@@ -98,7 +98,7 @@ __device__ __forceinline__ void epi_row8(const GemmEpi& e, int m, int n, float (
       act[t] = (bf16)gelu_new_f((float)pre[t]);
     }
     if (full) {
-      NT_STORE(bf16x8, ax, pre);
+      NT_STORE(bf16x8, ax, pre);   // (plain stores, for either output: GELU +8 ... 10 %, and the pair GELU -> c_proj +3 ... 4 %)
       NT_STORE(bf16x8, c, act);
     } else {
 #pragma unroll
@@ -908,7 +908,8 @@ using namespace ttts;
 
 template <int EPI>
 static void launch_nt(const GemmNtParams& p, int grid, hipStream_t s) {
-  // (a 128 x 64 tile for the N = 512 GEMMs was measured slower on MI355X -- mlp c_proj 40.2 -> 47.5 us -- and removed)
+  // (a 128 x 64 tile for the N = 512 GEMMs was measured slower on MI355X -- mlp c_proj 40.2 -> 47.5 us -- and removed; so were the
+  // 128 x 128 kernels for the K = 512, N = 512 pair: attn c_proj 19.0 -> 21.2 / 21.8 us with 32- / 64-deep stages)
   // tall tile + deep ring: when the 128 x 128 tiling has about one tile per CU (tiles in (CUs, 1.6 CUs]) and 160-row tiles fit one round
   constexpr int CUS = 256;
   const int tall_grid = (int)(cdiv(p.e.M, 160) * cdiv(p.e.N, 128));
