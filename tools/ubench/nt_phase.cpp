@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <algorithm>
 #include <vector>
@@ -37,6 +38,11 @@ int main(int argc, char** argv) {
       {"c_attn   9248x1536x512  store", 9248, 1536, 512, 0},
       {"c_fc     9248x2048x512  gelu ", 9248, 2048, 512, 1},
       {"d(c_proj)9248x2048x512  dgelu", 9248, 2048, 512, 3},
+      {"         9248x2048x512  store", 9248, 2048, 512, 0},
+      {"         9248x2048x512  resid", 9248, 2048, 512, 2},
+      {"         9248x2048x512  f32  ", 9248, 2048, 512, 4},
+      {"ragged   9001x2000x192  dgelu", 9001, 2000, 192, 3},
+      {"ragged   9001x2000x192  resid", 9001, 2000, 192, 2},
       {"mel head 8208x1026x512  store", 8208, 1026, 512, 0},
       {"text head 1040x257x512  store", 1040, 257, 512, 0},
       {"d(mel head) 8208x512x1032 store", 8208, 512, 1032, 0},
@@ -89,6 +95,8 @@ int main(int argc, char** argv) {
   }
   const int ROUNDS = 7, IT = 40, NL = (int)libs.size();
   std::vector<unsigned char> ref;
+  float* dcs;
+  HIP(hipMalloc(&dcs, Nx * 4));
   for (int si = 0; si < NS; ++si) {
     const Shape& s = shapes[si];
     const int ldc = (s.N + 7) / 8 * 8;
@@ -98,6 +106,8 @@ int main(int argc, char** argv) {
       if (rc) { fprintf(stderr, "gemm_nt rc %d: %s\n", rc, l.last()); exit(3); }
     };
     std::vector<int> same(NL, 1);
+    std::vector<float> cs_ref;
+    std::vector<double> cs_dev(NL, 0.0);
     for (int li = 0; li < NL; ++li) {            // one launch on a zeroed C (the resid-add epilogue accumulates)
       HIP(hipMemsetAsync(dC, 0, out_b, st));
       call(libs[li]);
@@ -105,6 +115,21 @@ int main(int argc, char** argv) {
       HIP(hipMemcpy(hout.data(), dC, out_b, hipMemcpyDeviceToHost));
       if (li == 0) ref.assign(hout.begin(), hout.begin() + out_b);
       else same[li] = memcmp(ref.data(), hout.data(), out_b) == 0;
+      if (s.epi == 0 || s.epi == 3) {           // column sums taken in the epilogue (fp32 atomics: compared with a tolerance)
+        HIP(hipMemsetAsync(dcs, 0, Nx * 4, st));
+        int rc = libs[li].nt(dA, s.K, dB, s.K, dC, ldc, dbias, dAux, s.M, s.N, s.K, s.epi, nullptr, 0.f, 0, nullptr, dcs, st);
+        if (rc) { fprintf(stderr, "gemm_nt colsum rc %d: %s\n", rc, libs[li].last()); exit(3); }
+        HIP(hipStreamSynchronize(st));
+        std::vector<float> cs(s.N);
+        HIP(hipMemcpy(cs.data(), dcs, s.N * 4, hipMemcpyDeviceToHost));
+        if (li == 0) cs_ref = cs;
+        else {
+          double worst = 0, scale = 1e-30;
+          for (int n = 0; n < s.N; ++n) { worst = std::max(worst, (double)fabsf(cs[n] - cs_ref[n])); scale = std::max(scale, (double)fabsf(cs_ref[n])); }
+          if (worst > 1e-4 * scale) same[li] = 0;
+          cs_dev[li] = worst / scale;
+        }
+      }
     }
     std::vector<std::vector<float>> t(NL);
     for (int r = 0; r < ROUNDS + 1; ++r)
@@ -124,6 +149,7 @@ int main(int argc, char** argv) {
       const double mn = t[li][0], med = t[li][ROUNDS / 2], base = t[0][ROUNDS / 2];
       printf("  %-44s min %7.2f  median %7.2f us  %6.1f TF/s  %+5.1f %%  %s\n", libs[li].path, mn, med,
              2.0 * s.M * s.N * s.K / med * 1e-6, (med / base - 1.0) * 100.0, same[li] ? "bit-identical" : "OUTPUT DIFFERS");
+      if (cs_dev[li] > 0) printf("      (column sums: max deviation %.2e of the largest)\n", cs_dev[li]);
     }
     fflush(stdout);
   }

@@ -48,6 +48,7 @@ struct GemmNtParams {
   int K;
   GemmEpi e;
   int phase;   // gemm_nt_glds_kernel: start-up delay per co-resident workgroup slot, in units of 1024 cycles (0: none)
+  int main_rt, tail_h;   // eight-wave kernel, split grid (tail_h > 0): main_rt 256-row tile rows, then tail_h-row tiles (see launch_nt)
 };
 
 // one output row piece: 8 consecutive columns n .. n + 7 of row m, v = acc + bias (fp32), through epilogue EPI
@@ -194,7 +195,7 @@ __device__ __forceinline__ void colsum_flush(const GemmEpi& e, float (&cs)[8], f
 // NJ = 32-column blocks per wave: 2 for the 128 x 128 tile, 1 for the 128 x 64 tile (N = 512 GEMMs: 292 -> 584 tiles)
 template <int EPI, int NJ = 2, int NWM = 2>
 __device__ __forceinline__ void tile_epilogue(const GemmEpi& e, f32x16 (&acc)[2][2], float* stage, int m0, int n0,
-                                              int tid) {
+                                              int tid, int nhalf = NWM) {   // nhalf: 64-row groups of the tile that hold rows (uniform)
   constexpr int TPR = 8 * NJ;              // threads per 64*NJ-column row (8 columns each)
   constexpr int RPP = 128 * NWM / TPR;     // rows per read-back pass (NWM = 64-row wave groups of the workgroup: 2 or 4)
   const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, h = lane >> 5;
@@ -211,6 +212,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmEpi& e, f32x16 (&acc)[2]
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int half = 0; half < NWM; ++half) {
+    if (half >= nhalf) break;
     if (wm == half) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -275,8 +277,9 @@ __device__ __forceinline__ int xcd_tile(int bid, int nblk) {
 //    ~14 us and overlap only half.  Two follow-ups were built, measured and removed: a persistent 8-wave kernel with store
 //    waves (1.6x slower: its tile hand-off serialised on LDS slots) and a K-split of the surplus tiles of the 292-tile
 //    launches (round 3: GPT step 4.01 vs 3.61 ms -- the fix-up launch and the fp32 slabs cost more than the tail they fill).
-template <int EPI, int BKT, int NJ = 2, int NWM = 2>
+template <int EPI, int BKT, int NJ = 2, int NWM = 2, bool SPLIT = false>
 __global__ __launch_bounds__(128 * NWM, (NWM == 4 ? 4 : BKT == 64 ? 2 : 3)) void gemm_nt_glds_kernel(GemmNtParams p) {
+  static_assert(!SPLIT || NWM == 4, "the split grid belongs to the eight-wave tile");
   constexpr int BNT = 64 * NJ;           // tile columns: 128, or 64 for the narrow-N GEMMs
   constexpr int BMT = 64 * NWM;          // tile rows: 128 (four waves) or 256 (eight waves sharing the B stage)
   constexpr int NWAVES = 2 * NWM;
@@ -291,8 +294,26 @@ __global__ __launch_bounds__(128 * NWM, (NWM == 4 ? 4 : BKT == 64 ? 2 : 3)) void
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int tiles_n = (p.e.N + BNT - 1) / BNT;
-  const int tile = xcd_tile(blockIdx.x, gridDim.x);
-  const int m0 = (tile / tiles_n) * BMT, n0 = (tile % tiles_n) * BNT;
+  int tile, m0, rows = BMT;
+  if (SPLIT) {
+    // split grid: the first main_rt * tiles_n workgroups (one full round of the chip's slots) take 256-row tiles, the rest the
+    // remaining rows in tail_h-row tiles, which follow them onto the slots as these free up (XCD-contiguous within each part)
+    const int main_tiles = p.main_rt * tiles_n;
+    if ((int)blockIdx.x < main_tiles) {
+      tile = xcd_tile(blockIdx.x, main_tiles);
+      m0 = (tile / tiles_n) * BMT;
+    } else {
+      tile = xcd_tile(blockIdx.x - main_tiles, gridDim.x - main_tiles);
+      m0 = p.main_rt * BMT + (tile / tiles_n) * p.tail_h;
+      rows = p.tail_h;
+    }
+  } else {
+    tile = xcd_tile(blockIdx.x, gridDim.x);
+    m0 = (tile / tiles_n) * BMT;
+  }
+  const int n0 = (tile % tiles_n) * BNT;
+  const int m_end = min(p.e.M, m0 + rows);
+  const int nact = SPLIT ? (m_end - m0 + 63) >> 6 : NWM;   // 64-row wave groups with rows to compute (workgroup-uniform)
   const int nk = p.K / BKT;
   // The workgroups that share a CU start together and have equal lives, so their main loops (matrix cores + LDS fill) and
   // their epilogues (VALU + HBM stores) fall on top of each other.  Where the launcher asks for it (p.phase: launches of many
@@ -325,13 +346,16 @@ __global__ __launch_bounds__(128 * NWM, (NWM == 4 ? 4 : BKT == 64 ? 2 : 3)) void
     const int chunk = (lane % CPR) ^ fsw(r);
     gb[i] = p.B + (int64_t)min(n0 + r, p.e.N - 1) * p.ldb + chunk * 8;
   }
+  const bool a_on = !SPLIT || wave * (IPW * RPI) < nact * 64;   // this wave's A rows belong to a wave group with work
   auto issue = [&](int kt, int buf) {
     bf16* as = smem + buf * (TA + TB) + wave * (IPW * RPI) * BKT;
     bf16* bs = smem + buf * (TA + TB) + TA + wave * (IPWB * RPI) * BKT;
+    if (a_on) {
 #pragma unroll
-    for (int i = 0; i < IPW; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[i] + kt * BKT),
-                                       (__attribute__((address_space(3))) void*)(as + i * RPI * BKT), 16, 0, 0);
+      for (int i = 0; i < IPW; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[i] + kt * BKT),
+                                         (__attribute__((address_space(3))) void*)(as + i * RPI * BKT), 16, 0, 0);
+    }
 #pragma unroll
     for (int i = 0; i < IPWB; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb[i] + kt * BKT),
@@ -357,23 +381,31 @@ __global__ __launch_bounds__(128 * NWM, (NWM == 4 ? 4 : BKT == 64 ? 2 : 3)) void
     if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
     const bf16* as = smem + buf * (TA + TB);
     const bf16* bs = as + TA;
+    if (!SPLIT || wm < nact) {
 #pragma unroll
-    for (int ks = 0; ks < BKT / 16; ++ks) {
-      bf16x8 af[2], bfr[2];
-      const int lc = ks * 2 + hh;  // logical 16-byte chunk of this lane's 8 k-values
+      for (int ks = 0; ks < BKT / 16; ++ks) {
+        bf16x8 af[2], bfr[2];
+        const int lc = ks * 2 + hh;  // logical 16-byte chunk of this lane's 8 k-values
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        af[i] = *reinterpret_cast<const bf16x8*>(as + aoff[i] + ((lc ^ sw[0][i]) << 3));
-        if (i < NJ) bfr[i] = *reinterpret_cast<const bf16x8*>(bs + boff[i] + ((lc ^ sw[1][i]) << 3));
+        for (int i = 0; i < 2; ++i) {
+          af[i] = *reinterpret_cast<const bf16x8*>(as + aoff[i] + ((lc ^ sw[0][i]) << 3));
+          if (i < NJ) bfr[i] = *reinterpret_cast<const bf16x8*>(bs + boff[i] + ((lc ^ sw[1][i]) << 3));
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) acc[j][i] = mfma32(bfr[j], af[i], acc[j][i]);
       }
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) acc[j][i] = mfma32(bfr[j], af[i], acc[j][i]);
     }
     __syncthreads();  // next tile landed (vmcnt(0)) and everyone is done reading this one
   }
-  tile_epilogue<EPI, NJ, NWM>(p.e, acc, reinterpret_cast<float*>(smem), m0, n0, tid);
+  if (SPLIT) {
+    GemmEpi el = p.e;
+    el.M = m_end;      // rows past this tile's own belong to another workgroup
+    tile_epilogue<EPI, NJ, NWM>(el, acc, reinterpret_cast<float*>(smem), m0, n0, tid, nact);
+  } else {
+    tile_epilogue<EPI, NJ, NWM>(p.e, acc, reinterpret_cast<float*>(smem), m0, n0, tid);
+  }
 }
 
 // ---- NT, tall tile + deep ring for the narrow-N GEMMs (N <= 512: attn / mlp c_proj, dX of c_attn / c_fc) ------------------
@@ -938,7 +970,24 @@ static void launch_nt(const GemmNtParams& p, int grid, hipStream_t s) {
     gemm_nt_glds_kernel<EPI, 32, 2, 4><<<tiles8, 512, 0, s>>>(q);
     return;
   }
-  if (p.K % 64 == 0 && EPI == TTTS_EPI_DGELU_BF16) {   // 32-deep stages, three workgroups per CU, staggered: 52.2 -> 48.7 us
+  // dGELU at N = 2048 (592 eight-wave tiles: 1.16 rounds): a split grid -- the first 2 x CUS workgroups take 256-row tiles
+  // (one full round), the remaining rows follow as 64-row tiles on the slots that free up, each a quarter of the work with three
+  // of its four wave groups idle: 49.7 -> 45.9 us.  Only for dGELU: the same grid costs the GELU / store / residual epilogues
+  // 2 ... 10 % (tools/ubench/nt_phase.cpp, profiles/r03_ubench_nt_variants.txt), and the tile bookkeeping costs the plain
+  // eight-wave kernel 4 %, hence the separate instantiation.
+  if (p.K % 64 == 0 && EPI == TTTS_EPI_DGELU_BF16 && tiles8 > 2 * CUS && tiles8 < 8 * CUS) {
+    constexpr int TAIL_H = 64;
+    const int ncol = (int)cdiv(p.e.N, 128), main_rt = 2 * CUS / ncol;
+    const int tail_rows = p.e.M - main_rt * 256, tail_tiles = (int)cdiv(tail_rows, TAIL_H) * ncol;
+    if (main_rt >= 1 && tail_rows > 0 && main_rt * ncol >= CUS * 3 / 2 && tail_tiles <= 2 * CUS) {
+      GemmNtParams q = p;
+      q.main_rt = main_rt;
+      q.tail_h = TAIL_H;
+      gemm_nt_glds_kernel<EPI, 32, 2, 4, true><<<main_rt * ncol + tail_tiles, 512, 0, s>>>(q);
+      return;
+    }
+  }
+  if (p.K % 64 == 0 && EPI == TTTS_EPI_DGELU_BF16) {   // otherwise: 32-deep stages, three workgroups per CU, staggered: 52.2 -> 48.7 us
     GemmNtParams q = p;
     q.phase = 3;
     gemm_nt_glds_kernel<EPI, 32><<<grid, 256, 0, s>>>(q);
