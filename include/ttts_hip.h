@@ -34,7 +34,7 @@ extern "C" {
 #define TTTS_EHIP (-2)         /* a HIP runtime call or kernel launch failed */
 #define TTTS_EUNSUPPORTED (-3) /* valid request this build has no kernel for */
 
-#define TTTS_ABI_VERSION 5
+#define TTTS_ABI_VERSION 6
 
 /* ---- library ------------------------------------------------------------------------------------ */
 int ttts_abi_version(void);
@@ -73,6 +73,24 @@ int ttts_gemm_nt_bf16_ex(const void* A, int64_t lda, const void* B, int64_t ldb,
                          const float* bias, void* aux, int32_t M, int32_t N, int32_t K, int32_t epilogue,
                          const float* resid_in, float dropout_p, uint64_t seed, const uint32_t* dropout_counter,
                          float* colsum, void* stream);
+/* Which kernel and grid ttts_gemm_nt_bf16(_ex) uses for a shape (ABI v6; host-side query, launches nothing, needs no GPU).
+ * The kernels differ in tile shape and pipeline only -- a shape's output bits are the same whichever runs -- and the choice is a
+ * table of measurements on the 256 CUs of an MI355X (csrc/gemm.hip plan_nt); tests pin the rules, benchmarks report them. */
+enum {
+  TTTS_NT_KERNEL_REG = 0,         /* 128 x 128, register-staged: any K % 8 == 0                                        */
+  TTTS_NT_KERNEL_DMA64 = 1,       /* 128 x 128, LDS-DMA, 64-deep stages, 2 workgroups per CU                           */
+  TTTS_NT_KERNEL_DMA32 = 2,       /* 128 x 128, LDS-DMA, 32-deep stages, 3 workgroups per CU                           */
+  TTTS_NT_KERNEL_RING160 = 3,     /* 160 x 128, 4-slot LDS-DMA ring, 1 workgroup per CU (narrow N)                     */
+  TTTS_NT_KERNEL_WAVE8 = 4,       /* 256 x 128, eight waves sharing each B stage, 2 workgroups per CU                  */
+  TTTS_NT_KERNEL_WAVE8_SPLIT = 5  /* the same, grid = main_row_tiles rows of 256-row tiles + tail_tile_rows-row tiles  */
+};
+typedef struct {
+  int32_t kernel, grid, block;    /* TTTS_NT_KERNEL_*, workgroups, threads per workgroup                                */
+  int32_t tile_m, tile_n;
+  int32_t phase;                  /* start-up stagger of co-resident workgroups, units of 1024 cycles (0: none)        */
+  int32_t main_row_tiles, tail_tile_rows;   /* WAVE8_SPLIT only                                                         */
+} ttts_gemm_nt_plan;
+int ttts_gemm_nt_plan_query(int32_t M, int32_t N, int32_t K, int32_t epilogue, ttts_gemm_nt_plan* out);
 /* C[Mo,No] += At[Kr,Mo]^T . Bt[Kr,No]: the weight-gradient GEMM.  The reduction is split over workgroups into fp32
  * slabs in `workspace` (ttts_gemm_tn_workspace_bytes; may be 0 -> NULL) that a second kernel sums in a fixed order
  * (deterministic; no atomics); both operands are row-major with the REDUCTION dimension as rows ("TN").

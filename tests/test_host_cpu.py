@@ -32,7 +32,52 @@ def test_header_symbols_exported_and_bound(lib):
     for name in declared:
         assert hasattr(handle, name), "header declares %s but libttts_hip.so does not export it" % name
     assert declared == set(lib.SIGNATURES), declared ^ set(lib.SIGNATURES)
-    assert lib.get().ttts_abi_version() == lib.ABI_VERSION == 5
+    assert lib.get().ttts_abi_version() == lib.ABI_VERSION == 6
+
+
+def test_gemm_nt_dispatch_table(lib):
+    """ttts_gemm_nt_plan_query: the kernel / grid the NT GEMM picks for the GPT step's shapes (B 8 x S 1156 = 9248 rows, d 512) and for
+    the corner cases of each rule.  The rules are measurements (csrc/gemm.hip plan_nt, profiles/r03_ubench_nt_variants.txt);
+    every kernel gives a shape the same output bits, so this table is about speed only -- but a silent change of it is a
+    performance regression no numerics test would see."""
+    def plan(M, N, K, epi=0):
+        pl = lib.GemmNtPlan()
+        assert lib.get().ttts_gemm_nt_plan_query(M, N, K, epi, ctypes.byref(pl)) == 0, lib.get().ttts_last_error()
+        return pl
+    E = lib
+    # c_attn: eight-wave 256 x 128 tiles, one round of the 512 slots, no stagger
+    pl = plan(9248, 1536, 512)
+    assert (pl.kernel, pl.grid, pl.block, pl.tile_m, pl.phase) == (E.NT_KERNEL_WAVE8, 37 * 12, 512, 256, 0)
+    # c_fc (GELU) at N = 2048: 592 eight-wave tiles would be 1.16 rounds -> the 128 x 128 kernel, 64-deep stages
+    pl = plan(9248, 2048, 512, E.EPI_GELU_BF16)
+    assert (pl.kernel, pl.grid, pl.block) == (E.NT_KERNEL_DMA64, 73 * 16, 256)
+    # dGELU at N = 2048: split grid = 32 x 16 tiles of 256 rows (one full round) + the remaining 1056 rows in 64-row tiles
+    pl = plan(9248, 2048, 512, E.EPI_DGELU_BF16)
+    assert (pl.kernel, pl.grid, pl.main_row_tiles, pl.tail_tile_rows) == (E.NT_KERNEL_WAVE8_SPLIT, 512 + 17 * 16, 32, 64)
+    assert pl.main_row_tiles * 256 + 17 * 64 >= 9248
+    # a dGELU the split grid does not fit (few rows): 32-deep stages, staggered
+    pl = plan(2000, 2048, 512, E.EPI_DGELU_BF16)
+    assert (pl.kernel, pl.phase, pl.grid) == (E.NT_KERNEL_DMA32, 3, 16 * 16)
+    # the four N = 512 GEMMs of a layer: 160 x 128 ring kernel, 58 x 4 tiles, one workgroup per CU
+    for K, epi in ((2048, E.EPI_RESID_ADD_F32), (512, E.EPI_RESID_ADD_F32), (2048, 0), (1536, 0)):
+        pl = plan(9248, 512, K, epi)
+        assert (pl.kernel, pl.grid, pl.tile_m) == (E.NT_KERNEL_RING160, 58 * 4, 160)
+    # heads: mel head forward (1026 classes) on eight waves; its dX GEMM runs over the logits pitch (1088 = up64(1026)) -> LDS-DMA
+    assert plan(8208, 1026, 512).kernel == E.NT_KERNEL_WAVE8 and plan(8208, 1026, 512).grid == 33 * 9
+    assert plan(8208, 512, 1088).kernel == E.NT_KERNEL_RING160
+    assert plan(8208, 512, 1032).kernel == E.NT_KERNEL_REG            # the old pitch (up8): register-staged kernel
+    # many rounds of eight-wave tiles: staggered start
+    pl = plan(8192, 8194, 512)
+    assert (pl.kernel, pl.grid, pl.phase) == (E.NT_KERNEL_WAVE8, 32 * 65, 8)
+    # ragged K
+    assert plan(1000, 264, 40).kernel == E.NT_KERNEL_REG and plan(1000, 264, 96).kernel == E.NT_KERNEL_DMA32
+    # small launches stay on the 128 x 128 kernel
+    assert plan(300, 200, 128).kernel == E.NT_KERNEL_DMA64 and plan(300, 200, 128).grid == 3 * 2
+    # validation
+    pl = lib.GemmNtPlan()
+    assert lib.get().ttts_gemm_nt_plan_query(16, 16, 12, 0, ctypes.byref(pl)) == -1 and b"bad shape" in lib.get().ttts_last_error()
+    assert lib.get().ttts_gemm_nt_plan_query(16, 16, 16, 9, ctypes.byref(pl)) == -1 and b"unknown epilogue" in lib.get().ttts_last_error()
+    assert lib.get().ttts_gemm_nt_plan_query(16, 16, 16, 0, None) == -1
 
 
 def test_argument_validation_without_gpu(lib):

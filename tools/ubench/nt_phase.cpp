@@ -16,6 +16,8 @@
 typedef int (*nt_fn)(const void*, int64_t, const void*, int64_t, void*, int64_t, const float*, void*, int32_t, int32_t, int32_t,
                      int32_t, const float*, float, uint64_t, const uint32_t*, float*, void*);
 typedef const char* (*err_fn)(void);
+struct NtPlan { int32_t kernel, grid, block, tile_m, tile_n, phase, main_row_tiles, tail_tile_rows; };   // ttts_gemm_nt_plan
+typedef int (*plan_fn)(int32_t, int32_t, int32_t, int32_t, NtPlan*);
 
 #define HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
 
@@ -84,12 +86,13 @@ int main(int argc, char** argv) {
 
   // all libraries first; then per shape: one correctness launch each, and ROUNDS interleaved timing passes (library order
   // rotates inside a round, so clock ramps and thermal drift hit every variant alike); min and median over the rounds
-  struct Lib { const char* path; nt_fn nt; err_fn last; };
+  struct Lib { const char* path; nt_fn nt; err_fn last; plan_fn plan; };
   std::vector<Lib> libs;
   for (int li = 1; li < argc; ++li) {
     void* h = dlopen(argv[li], RTLD_NOW | RTLD_LOCAL);
     if (!h) { fprintf(stderr, "dlopen %s: %s\n", argv[li], dlerror()); return 2; }
-    Lib l{argv[li], (nt_fn)dlsym(h, "ttts_gemm_nt_bf16_ex"), (err_fn)dlsym(h, "ttts_last_error")};
+    Lib l{argv[li], (nt_fn)dlsym(h, "ttts_gemm_nt_bf16_ex"), (err_fn)dlsym(h, "ttts_last_error"),
+          (plan_fn)dlsym(h, "ttts_gemm_nt_plan_query")};   // (libraries older than ABI v6 have no plan query)
     if (!l.nt || !l.last) { fprintf(stderr, "%s: symbols missing\n", argv[li]); return 2; }
     libs.push_back(l);
   }
@@ -147,8 +150,13 @@ int main(int argc, char** argv) {
     for (int li = 0; li < NL; ++li) {
       std::sort(t[li].begin(), t[li].end());
       const double mn = t[li][0], med = t[li][ROUNDS / 2], base = t[0][ROUNDS / 2];
-      printf("  %-44s min %7.2f  median %7.2f us  %6.1f TF/s  %+5.1f %%  %s\n", libs[li].path, mn, med,
-             2.0 * s.M * s.N * s.K / med * 1e-6, (med / base - 1.0) * 100.0, same[li] ? "bit-identical" : "OUTPUT DIFFERS");
+      char kern[64] = "";
+      NtPlan pl;
+      static const char* kname[] = {"reg", "dma64", "dma32", "ring160", "wave8", "wave8-split"};
+      if (libs[li].plan && libs[li].plan(s.M, s.N, s.K, s.epi, &pl) == 0)
+        snprintf(kern, sizeof kern, "  [%s x%d%s]", kname[pl.kernel], pl.grid, pl.phase ? " staggered" : "");
+      printf("  %-44s min %7.2f  median %7.2f us  %6.1f TF/s  %+5.1f %%  %s%s\n", libs[li].path, mn, med,
+             2.0 * s.M * s.N * s.K / med * 1e-6, (med / base - 1.0) * 100.0, same[li] ? "bit-identical" : "OUTPUT DIFFERS", kern);
       if (cs_dev[li] > 0) printf("      (column sums: max deviation %.2e of the largest)\n", cs_dev[li]);
     }
     fflush(stdout);

@@ -48,7 +48,7 @@ struct GemmNtParams {
   int K;
   GemmEpi e;
   int phase;   // gemm_nt_glds_kernel: start-up delay per co-resident workgroup slot, in units of 1024 cycles (0: none)
-  int main_rt, tail_h;   // eight-wave kernel, split grid (tail_h > 0): main_rt 256-row tile rows, then tail_h-row tiles (see launch_nt)
+  int main_rt, tail_h;   // eight-wave kernel, split grid (tail_h > 0): main_rt 256-row tile rows, then tail_h-row tiles (see plan_nt)
 };
 
 // one output row piece: 8 consecutive columns n .. n + 7 of row m, v = acc + bias (fp32), through epilogue EPI
@@ -266,7 +266,7 @@ __device__ __forceinline__ int xcd_tile(int bid, int nblk) {
 // Slot s of row r holds the logical k-chunk s ^ f(r), f(r) = (r >> 1) & 7 for 128-byte rows (BKT = 64) and
 // (r >> 2) & 3 for 64-byte rows (BKT = 32): ds_read_b128 of a 16-lane service group then hits 64 distinct banks.
 // BKT = 64: 64 KB LDS, 2 workgroups per CU.  BKT = 32: 33.8 KB, 3 workgroups per CU -- their store phases and main
-// loops interleave instead of running in lock-step.  NWM = 4: eight waves on a 256 x 128 tile (see launch_nt).
+// loops interleave instead of running in lock-step.  NWM = 4: eight waves on a 256 x 128 tile (see plan_nt).
 // Round-2 measurements on this kernel (c_attn shape 9248 x 1536 x 512, 28.3 us = 514 TF/s; all variants parity-tested):
 //  * PMC: 25 % MFMA-busy, 44 % of wave cycles parked in s_waitcnt / barrier, 30 % issue stalls, 5.4 VALU per MFMA;
 //  * an LDS-DMA RING (3 or 4 stages, loads 2-3 k-steps ahead, counted vmcnt across raw s_barriers) does NOT help: 64-deep
@@ -938,64 +938,94 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __rest
 
 using namespace ttts;
 
-template <int EPI>
-static void launch_nt(const GemmNtParams& p, int grid, hipStream_t s) {
-  // (a 128 x 64 tile for the N = 512 GEMMs was measured slower on MI355X -- mlp c_proj 40.2 -> 47.5 us -- and removed; so were the
-  // 128 x 128 kernels for the K = 512, N = 512 pair: attn c_proj 19.0 -> 21.2 / 21.8 us with 32- / 64-deep stages)
-  // tall tile + deep ring: when the 128 x 128 tiling has about one tile per CU (tiles in (CUs, 1.6 CUs]) and 160-row tiles fit one round
+// Which NT kernel runs a shape, and on what grid (host-side; ttts_gemm_nt_plan_query exposes it to tests and benchmarks).
+// All kernels produce the same bits for a shape (tools/ubench/nt_phase.cpp checks that); the rules are measurements on the 256 CUs
+// of an MI355X:
+//  * RING160: 160 x 128 tiles + a 4-slot ring, when the 128 x 128 tiling has about one tile per CU (tiles in (CUs, 1.6 CUs]) and
+//    the 160-row tiles fit one round (a 128 x 64 tile for the N = 512 GEMMs was measured slower -- mlp c_proj 40.2 -> 47.5 us --
+//    and removed; so were the 128 x 128 kernels for the K = 512, N = 512 pair: attn c_proj 19.0 -> 21.2 / 21.8 us);
+//  * WAVE8: eight waves on a 256 x 128 tile (four 64-row wave groups sharing every B stage; 32-deep stages, two workgroups per
+//    CU): 27 % fewer L2 -> LDS fill bytes per flop than two 128 x 128 workgroups, and the fill is what a k-step of the 128 x 128
+//    kernel waits for.  Taken where its tile count fills one round of the 2 x CUs slots or makes many rounds:
+//    c_attn 23.8 -> 21.9 us = 664 TF/s (37 x 12 = 444 tiles, was 876 in 1.7 rounds), an 8192 x 8194 head 140 -> 113 us (with the
+//    start-up stagger); NOT for N = 2048 at M = 9248 (592 tiles = 1.16 rounds: c_fc 38 -> 45 us).  Also measured and dropped: a
+//    64-deep-stage version at one workgroup per CU (+8 %), ten waves on 320 x 128 (464 tiles for N = 2048, but 96 VGPRs: spills,
+//    +30 ... 58 %), s_setprio around the main loop (within noise), four 32-deep workgroups per CU (no change);
+//  * WAVE8_SPLIT, dGELU at N = 2048 (592 eight-wave tiles: 1.16 rounds): the first 2 x CUs workgroups take 256-row tiles (one
+//    full round), the remaining rows follow as 64-row tiles on the slots that free up, each a quarter of the work with three of
+//    its four wave groups idle: 49.7 -> 45.3 us.  Only for dGELU: the same grid costs the GELU / store / residual epilogues
+//    2 ... 10 %, and the tile bookkeeping costs the plain eight-wave kernel 4 %, hence the separate instantiation;
+//  * DMA32 + stagger for any other dGELU (32-deep stages, three workgroups per CU, staggered: 52.2 -> 48.7 us);
+//  * DMA64 (128 x 128, 64-deep stages, two workgroups per CU) / DMA32 (K % 64 != 0) / REG (register-staged, ragged K) otherwise.
+static ttts_gemm_nt_plan plan_nt(int M, int N, int K, int epilogue) {
   constexpr int CUS = 256;
-  const int tall_grid = (int)(cdiv(p.e.M, 160) * cdiv(p.e.N, 128));
-  if (p.K % 64 == 0 && grid > CUS && grid <= CUS * 8 / 5 && tall_grid <= CUS) {
-    constexpr size_t smem = (size_t)4 * (160 + 128) * 64 * sizeof(bf16);   // the 4-slot ring: 144 KB
-    static bool attr = false;
-    if (!attr) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_tall_kernel<EPI, 5, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      attr = true;
+  ttts_gemm_nt_plan pl{};
+  pl.block = 256; pl.tile_m = 128; pl.tile_n = 128;
+  const int grid = (int)(cdiv(M, BM) * cdiv(N, BN));
+  pl.grid = grid;
+  if (K % 64 != 0) {
+    pl.kernel = K % 32 == 0 ? TTTS_NT_KERNEL_DMA32 : TTTS_NT_KERNEL_REG;
+    return pl;
+  }
+  const int tall_grid = (int)(cdiv(M, 160) * cdiv(N, 128));
+  if (grid > CUS && grid <= CUS * 8 / 5 && tall_grid <= CUS) {
+    pl.kernel = TTTS_NT_KERNEL_RING160; pl.grid = tall_grid; pl.tile_m = 160;
+    return pl;
+  }
+  const int tiles8 = (int)(cdiv(M, 256) * cdiv(N, 128));
+  if (tiles8 > CUS && (tiles8 <= 2 * CUS || tiles8 >= 8 * CUS)) {
+    pl.kernel = TTTS_NT_KERNEL_WAVE8; pl.grid = tiles8; pl.block = 512; pl.tile_m = 256;
+    pl.phase = tiles8 >= 8 * CUS ? 8 : 0;
+    return pl;
+  }
+  if (epilogue == TTTS_EPI_DGELU_BF16) {
+    if (tiles8 > 2 * CUS && tiles8 < 8 * CUS) {
+      constexpr int TAIL_H = 64;
+      const int ncol = (int)cdiv(N, 128), main_rt = 2 * CUS / ncol;
+      const int tail_rows = M - main_rt * 256, tail_tiles = (int)cdiv(tail_rows, TAIL_H) * ncol;
+      if (main_rt >= 1 && tail_rows > 0 && main_rt * ncol >= CUS * 3 / 2 && tail_tiles <= 2 * CUS) {
+        pl.kernel = TTTS_NT_KERNEL_WAVE8_SPLIT; pl.grid = main_rt * ncol + tail_tiles; pl.block = 512; pl.tile_m = 256;
+        pl.main_row_tiles = main_rt; pl.tail_tile_rows = TAIL_H;
+        return pl;
+      }
     }
-    gemm_nt_tall_kernel<EPI, 5, 4, 4><<<tall_grid, 256, smem, s>>>(p);
-    return;
+    pl.kernel = TTTS_NT_KERNEL_DMA32; pl.phase = 3;
+    return pl;
   }
-  // eight waves on a 256 x 128 tile (four 64-row wave groups sharing every B stage; 32-deep stages, two workgroups per CU):
-  // 27 % fewer L2 -> LDS fill bytes per flop than two 128 x 128 workgroups, and the fill is what a k-step of the 128 x 128
-  // kernel waits for.  Taken where its tile count fills one round of the 2 x CUS slots or makes many rounds:
-  // c_attn 23.8 -> 21.9 us = 664 TF/s (37 x 12 = 444 tiles, was 876 in 1.7 rounds), an 8192 x 8194 head 140 -> 113 us (with the
-  // start-up stagger); NOT for N = 2048 at M = 9248 (592 tiles = 1.16 rounds: c_fc 38 -> 45 us).  Measured with
-  // tools/ubench/nt_phase.cpp (every variant bit-identical to the 128 x 128 kernel); also measured there and dropped: a
-  // 64-deep-stage version at one workgroup per CU (+8 %), ten waves on 320 x 128 (464 tiles for N = 2048, but 96 VGPRs: spills,
-  // +30 ... 58 %), s_setprio around the main loop (within noise), four 32-deep workgroups per CU (no change).
-  const int tiles8 = (int)(cdiv(p.e.M, 256) * cdiv(p.e.N, 128));
-  if (p.K % 64 == 0 && tiles8 > CUS && (tiles8 <= 2 * CUS || tiles8 >= 8 * CUS)) {
-    GemmNtParams q = p;
-    q.phase = tiles8 >= 8 * CUS ? 8 : 0;
-    gemm_nt_glds_kernel<EPI, 32, 2, 4><<<tiles8, 512, 0, s>>>(q);
-    return;
-  }
-  // dGELU at N = 2048 (592 eight-wave tiles: 1.16 rounds): a split grid -- the first 2 x CUS workgroups take 256-row tiles
-  // (one full round), the remaining rows follow as 64-row tiles on the slots that free up, each a quarter of the work with three
-  // of its four wave groups idle: 49.7 -> 45.9 us.  Only for dGELU: the same grid costs the GELU / store / residual epilogues
-  // 2 ... 10 % (tools/ubench/nt_phase.cpp, profiles/r03_ubench_nt_variants.txt), and the tile bookkeeping costs the plain
-  // eight-wave kernel 4 %, hence the separate instantiation.
-  if (p.K % 64 == 0 && EPI == TTTS_EPI_DGELU_BF16 && tiles8 > 2 * CUS && tiles8 < 8 * CUS) {
-    constexpr int TAIL_H = 64;
-    const int ncol = (int)cdiv(p.e.N, 128), main_rt = 2 * CUS / ncol;
-    const int tail_rows = p.e.M - main_rt * 256, tail_tiles = (int)cdiv(tail_rows, TAIL_H) * ncol;
-    if (main_rt >= 1 && tail_rows > 0 && main_rt * ncol >= CUS * 3 / 2 && tail_tiles <= 2 * CUS) {
-      GemmNtParams q = p;
-      q.main_rt = main_rt;
-      q.tail_h = TAIL_H;
-      gemm_nt_glds_kernel<EPI, 32, 2, 4, true><<<main_rt * ncol + tail_tiles, 512, 0, s>>>(q);
-      return;
+  pl.kernel = TTTS_NT_KERNEL_DMA64;
+  return pl;
+}
+
+template <int EPI>
+static void launch_nt(const GemmNtParams& p, hipStream_t s) {
+  const ttts_gemm_nt_plan pl = plan_nt(p.e.M, p.e.N, p.K, EPI);
+  GemmNtParams q = p;
+  q.phase = pl.phase; q.main_rt = pl.main_row_tiles; q.tail_h = pl.tail_tile_rows;
+  switch (pl.kernel) {
+    case TTTS_NT_KERNEL_RING160: {
+      constexpr size_t smem = (size_t)4 * (160 + 128) * 64 * sizeof(bf16);   // the 4-slot ring: 144 KB
+      static bool attr = false;
+      if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_tall_kernel<EPI, 5, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr = true;
+      }
+      gemm_nt_tall_kernel<EPI, 5, 4, 4><<<pl.grid, 256, smem, s>>>(q);
+      break;
     }
+    case TTTS_NT_KERNEL_WAVE8: gemm_nt_glds_kernel<EPI, 32, 2, 4><<<pl.grid, 512, 0, s>>>(q); break;
+    case TTTS_NT_KERNEL_WAVE8_SPLIT: gemm_nt_glds_kernel<EPI, 32, 2, 4, true><<<pl.grid, 512, 0, s>>>(q); break;
+    case TTTS_NT_KERNEL_DMA64: gemm_nt_glds_kernel<EPI, 64><<<pl.grid, 256, 0, s>>>(q); break;
+    case TTTS_NT_KERNEL_DMA32: gemm_nt_glds_kernel<EPI, 32><<<pl.grid, 256, 0, s>>>(q); break;
+    default: gemm_nt_kernel<EPI><<<pl.grid, 256, 0, s>>>(q); break;
   }
-  if (p.K % 64 == 0 && EPI == TTTS_EPI_DGELU_BF16) {   // otherwise: 32-deep stages, three workgroups per CU, staggered: 52.2 -> 48.7 us
-    GemmNtParams q = p;
-    q.phase = 3;
-    gemm_nt_glds_kernel<EPI, 32><<<grid, 256, 0, s>>>(q);
-    return;
-  }
-  if (p.K % 64 == 0) gemm_nt_glds_kernel<EPI, 64><<<grid, 256, 0, s>>>(p);
-  else if (p.K % 32 == 0) gemm_nt_glds_kernel<EPI, 32><<<grid, 256, 0, s>>>(p);
-  else gemm_nt_kernel<EPI><<<grid, 256, 0, s>>>(p);
+}
+
+extern "C" int ttts_gemm_nt_plan_query(int32_t M, int32_t N, int32_t K, int32_t epilogue, ttts_gemm_nt_plan* out) {
+  TTTS_REQUIRE(out, "gemm_nt_plan_query: null pointer");
+  TTTS_REQUIRE(M > 0 && N > 0 && K > 0 && K % 8 == 0, "gemm_nt_plan_query: bad shape M=%d N=%d K=%d", M, N, K);
+  TTTS_REQUIRE(epilogue >= TTTS_EPI_STORE_BF16 && epilogue <= TTTS_EPI_STORE_F32, "gemm_nt_plan_query: unknown epilogue %d", epilogue);
+  *out = plan_nt(M, N, K, epilogue);
+  return TTTS_OK;
 }
 
 extern "C" int ttts_gemm_nt_bf16_ex(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
@@ -1016,14 +1046,13 @@ extern "C" int ttts_gemm_nt_bf16_ex(const void* A, int64_t lda, const void* B, i
                  GemmEpi{C, ldc, bias, (bf16*)aux, resid_in, M, N, dropout_threshold(dropout_p), 1.0f, (uint32_t)seed,
                          (uint32_t)(seed >> 32), dropout_counter, colsum}};
   if (p.e.thr) p.e.inv_keep = 65536.0f / (65536.0f - (float)p.e.thr);
-  const int grid = (int)(cdiv(M, BM) * cdiv(N, BN));
   hipStream_t s = as_stream(stream);
   switch (epilogue) {
-    case TTTS_EPI_STORE_BF16: launch_nt<TTTS_EPI_STORE_BF16>(p, grid, s); break;
-    case TTTS_EPI_GELU_BF16: launch_nt<TTTS_EPI_GELU_BF16>(p, grid, s); break;
-    case TTTS_EPI_RESID_ADD_F32: launch_nt<TTTS_EPI_RESID_ADD_F32>(p, grid, s); break;
-    case TTTS_EPI_DGELU_BF16: launch_nt<TTTS_EPI_DGELU_BF16>(p, grid, s); break;
-    case TTTS_EPI_STORE_F32: launch_nt<TTTS_EPI_STORE_F32>(p, grid, s); break;
+    case TTTS_EPI_STORE_BF16: launch_nt<TTTS_EPI_STORE_BF16>(p, s); break;
+    case TTTS_EPI_GELU_BF16: launch_nt<TTTS_EPI_GELU_BF16>(p, s); break;
+    case TTTS_EPI_RESID_ADD_F32: launch_nt<TTTS_EPI_RESID_ADD_F32>(p, s); break;
+    case TTTS_EPI_DGELU_BF16: launch_nt<TTTS_EPI_DGELU_BF16>(p, s); break;
+    case TTTS_EPI_STORE_F32: launch_nt<TTTS_EPI_STORE_F32>(p, s); break;
     default: return fail(TTTS_EUNSUPPORTED, "gemm_nt: unknown epilogue %d", epilogue);
   }
   return check_launch("gemm_nt");

@@ -67,7 +67,7 @@ _c = ctypes
 _P, _I32, _I64, _U64, _F = _c.c_void_p, _c.c_int32, _c.c_int64, _c.c_uint64, _c.c_float
 
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class ConvCtx(ctypes.Structure):
@@ -81,6 +81,14 @@ class LnFinalizeDesc(ctypes.Structure):
 
 class ColsumDesc(ctypes.Structure):
     _fields_ = [("X", _P), ("out", _P), ("ldx", _I64), ("M", _I32), ("N", _I32), ("tile_begin", _I32), ("reserved", _I32)]
+
+
+class GemmNtPlan(ctypes.Structure):
+    _fields_ = [("kernel", _I32), ("grid", _I32), ("block", _I32), ("tile_m", _I32), ("tile_n", _I32), ("phase", _I32),
+                ("main_row_tiles", _I32), ("tail_tile_rows", _I32)]
+
+
+NT_KERNEL_REG, NT_KERNEL_DMA64, NT_KERNEL_DMA32, NT_KERNEL_RING160, NT_KERNEL_WAVE8, NT_KERNEL_WAVE8_SPLIT = range(6)
 
 
 class TransposeDesc(ctypes.Structure):
@@ -105,6 +113,7 @@ SIGNATURES = {
     "ttts_device_info": (_I32, [_P]),
     "ttts_gemm_nt_bf16": (_I32, [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "ttts_gemm_nt_bf16_ex": (_I32, [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I32, _I32, _I32, _I32, _P, _F, _U64, _P, _P, _P]),
+    "ttts_gemm_nt_plan_query": (_I32, [_I32, _I32, _I32, _I32, _P]),
     "ttts_gemm_tn_workspace_bytes": (_I64, [_I32, _I32, _I32]),
     "ttts_gemm_tn_bf16_accum_f32": (_I32, [_P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _P]),
     "ttts_tn_desc_tiles": (_I32, [_I32, _I32]),

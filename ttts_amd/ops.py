@@ -46,6 +46,14 @@ def _ld(t):
     return t.stride(0)
 
 
+def gemm_nt_plan(M, N, K, epilogue=0):
+    """Which kernel / grid `gemm_nt` uses for a shape (host-side query of the library's dispatch table; needs no GPU):
+    a `lib.GemmNtPlan` (kernel = lib.NT_KERNEL_*, grid, block, tile_m, tile_n, phase, main_row_tiles, tail_tile_rows)."""
+    pl = _l.GemmNtPlan()
+    check(_l.get().ttts_gemm_nt_plan_query(int(M), int(N), int(K), int(epilogue), ctypes.byref(pl)), "gemm_nt_plan")
+    return pl
+
+
 def gemm_nt(a, b, c, bias=None, aux=None, epilogue=EPI_STORE_BF16, n=None, k=None, resid_in=None, dropout_p=0.0,
             seed=0, counter=None, colsum=None):
     """c[M,N] = epi(a[M,K] @ b[N,K]^T).  a/b bf16 row-major views; c bf16 or f32 (per epilogue).
