@@ -7,7 +7,9 @@
 //    across workgroups into fp32 slabs that a second kernel sums in a fixed order (no atomics).
 //
 // Tiling: 128x128 block tile, 4 waves (2x2), each wave a 64x64 sub-tile = 2x2 MFMA 32x32 tiles (64 fp32
-// accumulator VGPRs), double-buffered LDS operand tiles, ONE barrier per K-tile.
+// accumulator VGPRs), double-buffered LDS operand tiles, ONE barrier per K-tile.  The NT family has three more shapes of
+// the same wave tile -- 256x128 on eight waves (with a split grid for dGELU), 160x128 on a 4-slot ring for narrow N -- and
+// plan_nt() further down is the measured table of which shape / grid a problem gets (ttts_gemm_nt_plan_query).
 // What the first profiles showed and this file answers (tools/kernel_bench.py ablations, MI355X):
 //  - the register-staged main loop was LDS-WRITE bound (ds_write_b128 ~ 79 B/clk/CU): the NT main loop now fills LDS
 //    with global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip, no ds_write); the DMA image is lane-linear, so the
