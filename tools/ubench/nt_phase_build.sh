@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/../.."
 B=tools/ubench/bin
 mkdir -p $B
-rm -f $B/*
+rm -f $B/nt_*
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -fPIC -Iinclude -Ittts_amd/csrc"
 build() {  # name, -D flags
   local name=$1; shift
