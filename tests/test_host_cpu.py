@@ -80,6 +80,33 @@ def test_gemm_nt_dispatch_table(lib):
     assert lib.get().ttts_gemm_nt_plan_query(16, 16, 16, 0, None) == -1
 
 
+def test_gemm_nt_split_grid_covers_every_output_once(lib):
+    """The split grid of the eight-wave NT kernel (csrc/gemm.hip, gemm_nt_glds_kernel<..., SPLIT>): workgroup -> (first row, rows,
+    first column) restated here from the plan the library reports; every output element must belong to exactly one workgroup,
+    the first `main` workgroups must be the 256-row tiles, and the XCD remap must stay a bijection inside each part."""
+    def xcd_tile(bid, nblk):
+        q, r, x = nblk >> 3, nblk & 7, bid & 7
+        return (x * (q + 1) if x < r else r * (q + 1) + (x - r) * q) + (bid >> 3)
+    for M, N in ((9248, 2048), (9001, 2000), (8200, 1990), (16385, 1024)):
+        pl = lib.GemmNtPlan()
+        assert lib.get().ttts_gemm_nt_plan_query(M, N, 512, lib.EPI_DGELU_BF16, ctypes.byref(pl)) == 0
+        assert pl.kernel == lib.NT_KERNEL_WAVE8_SPLIT, (M, N, pl.kernel)
+        tiles_n = -(-N // 128)
+        main = pl.main_row_tiles * tiles_n
+        assert main <= 512 and pl.grid - main <= 512          # one round of the chip's slots each
+        cover = np.zeros((-(-M // 32), tiles_n), np.int32)     # 32-row granules x column tiles
+        for bid in range(pl.grid):
+            if bid < main:
+                t = xcd_tile(bid, main); m0 = (t // tiles_n) * 256; rows = 256
+            else:
+                t = xcd_tile(bid - main, pl.grid - main); m0 = pl.main_row_tiles * 256 + (t // tiles_n) * pl.tail_tile_rows
+                rows = pl.tail_tile_rows
+            m1 = min(M, m0 + rows)
+            assert m0 < M and m0 % 32 == 0
+            cover[m0 // 32:-(-m1 // 32), t % tiles_n] += 1
+        assert (cover == 1).all(), (M, N)
+
+
 def test_argument_validation_without_gpu(lib):
     l = lib.get()
     assert l.ttts_gemm_nt_bf16(None, 8, None, 8, None, 8, None, None, 4, 4, 8, 0, None) == -1
