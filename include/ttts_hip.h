@@ -82,13 +82,15 @@ enum {
   TTTS_NT_KERNEL_DMA32 = 2,       /* 128 x 128, LDS-DMA, 32-deep stages, 3 workgroups per CU                           */
   TTTS_NT_KERNEL_RING160 = 3,     /* 160 x 128, 4-slot LDS-DMA ring, 1 workgroup per CU (narrow N)                     */
   TTTS_NT_KERNEL_WAVE8 = 4,       /* 256 x 128, eight waves sharing each B stage, 2 workgroups per CU                  */
-  TTTS_NT_KERNEL_WAVE8_SPLIT = 5  /* the same, grid = main_row_tiles rows of 256-row tiles + tail_tile_rows-row tiles  */
+  TTTS_NT_KERNEL_WAVE8_SPLIT = 5, /* the same, grid = main_row_tiles rows of 256-row tiles + tail_tile_rows-row tiles  */
+  TTTS_NT_KERNEL_WREG = 6         /* K = 512, wide N: 256-column weight panel in REGISTERS, one persistent 8-wave workgroup
+                                     per CU walking 64-row tiles; grid = panels x main_row_tiles row groups               */
 };
 typedef struct {
   int32_t kernel, grid, block;    /* TTTS_NT_KERNEL_*, workgroups, threads per workgroup                                */
   int32_t tile_m, tile_n;
   int32_t phase;                  /* start-up stagger of co-resident workgroups, units of 1024 cycles (0: none)        */
-  int32_t main_row_tiles, tail_tile_rows;   /* WAVE8_SPLIT only                                                         */
+  int32_t main_row_tiles, tail_tile_rows;   /* WAVE8_SPLIT; WREG: main_row_tiles = row groups                            */
 } ttts_gemm_nt_plan;
 int ttts_gemm_nt_plan_query(int32_t M, int32_t N, int32_t K, int32_t epilogue, ttts_gemm_nt_plan* out);
 /* C[Mo,No] += At[Kr,Mo]^T . Bt[Kr,No]: the weight-gradient GEMM.  The reduction is split over workgroups into fp32

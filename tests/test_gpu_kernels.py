@@ -68,7 +68,8 @@ def _bf(x):
 
 @pytest.mark.parametrize("M,N,K", [(300, 200, 128), (1040, 257, 512), (128, 128, 64), (9248, 1536, 512), (777, 512, 2048),
                                    (256, 256, 4096), (200, 130, 1024), (9248, 512, 2048), (2000, 2048, 512), (129, 1026, 512), (9300, 500, 512),
-                                   (4100, 2000, 128), (8200, 8194, 64)])   # eight-wave 256 x 128 tiles: one ragged round; many rounds, staggered
+                                   (4100, 2000, 128), (8200, 8194, 64),   # eight-wave 256 x 128 tiles: one ragged round; many rounds, staggered
+                                   (9248, 2048, 512), (9001, 2000, 512), (5000, 1280, 512), (4096, 1024, 512)])   # weights-in-registers kernel: ragged rows / last panel
 def test_gemm_nt_epilogues(ops, M, N, K):
     from ttts_amd.lib import EPI_DGELU_BF16, EPI_GELU_BF16, EPI_RESID_ADD_F32, EPI_STORE_BF16, EPI_STORE_F32
     from oracle.gpt_ref import gelu_new
@@ -176,7 +177,7 @@ def test_colsum_and_cast(ops):
     assert torch.equal(t2[:, :257], w2.t().to(torch.bfloat16)) and float(t2[:, 257:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("M,N,K", [(9248, 2048, 512), (9248, 512, 2048), (300, 136, 64), (1000, 264, 40), (4100, 2000, 128)])
+@pytest.mark.parametrize("M,N,K", [(9248, 2048, 512), (9248, 512, 2048), (300, 136, 64), (1000, 264, 40), (4100, 2000, 128), (9001, 2000, 512)])
 def test_gemm_nt_epilogue_column_sums(ops, M, N, K):
     """`colsum` of ttts_gemm_nt_bf16_ex: the column sums of the bf16 output taken in the epilogue (dGELU and plain store; the
     128 x 128 LDS-DMA kernel, the 160 x 128 ring kernel, the register-staged kernel for ragged K, the eight-wave 256 x 128 kernel)

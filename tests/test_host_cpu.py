@@ -45,14 +45,28 @@ def test_gemm_nt_dispatch_table(lib):
         assert lib.get().ttts_gemm_nt_plan_query(M, N, K, epi, ctypes.byref(pl)) == 0, lib.get().ttts_last_error()
         return pl
     E = lib
-    # c_attn: eight-wave 256 x 128 tiles, one round of the 512 slots, no stagger
+    # K = 512, wide N, many rows: the weights-in-registers kernel -- one persistent eight-wave workgroup per CU, 256-column panels x
+    # (CUs / panels) row groups (round 4; c_attn 24.4 -> 22.8 us, c_fc + GELU 42.0 -> 33.4 us inside the step, same output bits)
     pl = plan(9248, 1536, 512)
-    assert (pl.kernel, pl.grid, pl.block, pl.tile_m, pl.phase) == (E.NT_KERNEL_WAVE8, 37 * 12, 512, 256, 0)
-    # c_fc (GELU) at N = 2048: 592 eight-wave tiles would be 1.16 rounds -> the 128 x 128 kernel, 64-deep stages
+    assert (pl.kernel, pl.grid, pl.block, pl.tile_m, pl.tile_n, pl.main_row_tiles) == (E.NT_KERNEL_WREG, 6 * 42, 512, 64, 256, 42)
     pl = plan(9248, 2048, 512, E.EPI_GELU_BF16)
+    assert (pl.kernel, pl.grid, pl.block, pl.main_row_tiles) == (E.NT_KERNEL_WREG, 8 * 32, 512, 32)
+    assert plan(9001, 2000, 512, E.EPI_GELU_BF16).kernel == E.NT_KERNEL_WREG       # last panel 208 of 256 columns: 2.4 % waste
+    assert plan(8208, 1026, 512).kernel != E.NT_KERNEL_WREG                        # 5 panels for 1026 columns would waste 25 %
+    assert plan(4000, 2048, 512).kernel != E.NT_KERNEL_WREG and plan(9248, 2048, 576).kernel != E.NT_KERNEL_WREG
+    # dGELU stays on the tiled kernels (in the train step its saved pre-activation comes from HBM: no gain measured):
+    # split grid = 32 x 16 tiles of 256 rows (one full round) + the remaining 1056 rows in 64-row tiles
+    pl = plan(9248, 2048, 512, E.EPI_DGELU_BF16)
+    assert (pl.kernel, pl.grid, pl.main_row_tiles, pl.tail_tile_rows) == (E.NT_KERNEL_WAVE8_SPLIT, 512 + 17 * 16, 32, 64)
+    # the tiled kernels' rules, at a reduction length the register kernel does not take:
+    # eight-wave 256 x 128 tiles, one round of the 512 slots, no stagger
+    pl = plan(9248, 1536, 1024)
+    assert (pl.kernel, pl.grid, pl.block, pl.tile_m, pl.phase) == (E.NT_KERNEL_WAVE8, 37 * 12, 512, 256, 0)
+    # N = 2048: 592 eight-wave tiles would be 1.16 rounds -> the 128 x 128 kernel, 64-deep stages
+    pl = plan(9248, 2048, 1024, E.EPI_GELU_BF16)
     assert (pl.kernel, pl.grid, pl.block) == (E.NT_KERNEL_DMA64, 73 * 16, 256)
     # dGELU at N = 2048: split grid = 32 x 16 tiles of 256 rows (one full round) + the remaining 1056 rows in 64-row tiles
-    pl = plan(9248, 2048, 512, E.EPI_DGELU_BF16)
+    pl = plan(9248, 2048, 1024, E.EPI_DGELU_BF16)
     assert (pl.kernel, pl.grid, pl.main_row_tiles, pl.tail_tile_rows) == (E.NT_KERNEL_WAVE8_SPLIT, 512 + 17 * 16, 32, 64)
     assert pl.main_row_tiles * 256 + 17 * 64 >= 9248
     # a dGELU the split grid does not fit (few rows): 32-deep stages, staggered
@@ -105,6 +119,25 @@ def test_gemm_nt_split_grid_covers_every_output_once(lib):
             assert m0 < M and m0 % 32 == 0
             cover[m0 // 32:-(-m1 // 32), t % tiles_n] += 1
         assert (cover == 1).all(), (M, N)
+
+
+def test_gemm_nt_register_kernel_row_groups_cover_every_row_once(lib):
+    """The weights-in-registers NT kernel (csrc/gemm.hip, gemm_nt_wreg_kernel): workgroup -> (column panel, row range) restated
+    here from the plan the library reports -- rows are dealt to the row groups in 32-row units; every (row, panel) must belong to
+    exactly one workgroup, no group may be empty, and the grid must fit one workgroup per CU."""
+    for M, N in ((9248, 1536), (9248, 2048), (9001, 2000), (4096, 1024), (5000, 1280), (70000, 4096)):
+        pl = lib.GemmNtPlan()
+        assert lib.get().ttts_gemm_nt_plan_query(M, N, 512, 0, ctypes.byref(pl)) == 0
+        assert pl.kernel == lib.NT_KERNEL_WREG, (M, N, pl.kernel)
+        npan, groups = -(-N // 256), pl.main_row_tiles
+        assert pl.grid == npan * groups and pl.grid <= 256 and pl.block == 512
+        units = -(-M // 32)
+        seen = np.zeros(M, np.int32)
+        for g in range(groups):
+            r0, r1 = (g * units // groups) * 32, min(M, ((g + 1) * units // groups) * 32)
+            assert r0 < r1, (M, N, g)
+            seen[r0:r1] += 1
+        assert (seen == 1).all(), (M, N)
 
 
 def test_argument_validation_without_gpu(lib):

@@ -29,6 +29,8 @@ def test_nt_gemm_kernels_fit_their_occupancy():
                 assert r["wg"] == 256 and r["vgpr"] <= 168 and 3 * r["lds"] <= 160 * 1024, (k, r)
             else:                 # two workgroups per CU
                 assert r["wg"] == 256 and r["vgpr"] <= 256 and 2 * r["lds"] <= 160 * 1024, (k, r)
+        if k.startswith("gemm_nt_wreg_kernel<"):     # one eight-wave workgroup per CU: 128 weight registers + accumulators + fragments
+            assert r["wg"] == 512 and r["vgpr"] <= 256 and r["lds"] == 0, (k, r)   # (its 160 KB of LDS are dynamic)
         if k.startswith("gemm_nt_tall_kernel<"):     # one workgroup per CU; the 144 KB ring is dynamic LDS
             assert r["vgpr"] <= 256 and r["lds"] == 0, (k, r)
         if k.startswith("gemm_tn_grouped_kernel") or k.startswith("gemm_tn_glds_kernel"):

@@ -152,7 +152,7 @@ int main(int argc, char** argv) {
       const double mn = t[li][0], med = t[li][ROUNDS / 2], base = t[0][ROUNDS / 2];
       char kern[64] = "";
       NtPlan pl;
-      static const char* kname[] = {"reg", "dma64", "dma32", "ring160", "wave8", "wave8-split"};
+      static const char* kname[] = {"reg", "dma64", "dma32", "ring160", "wave8", "wave8-split", "wreg"};
       if (libs[li].plan && libs[li].plan(s.M, s.N, s.K, s.epi, &pl) == 0)
         snprintf(kern, sizeof kern, "  [%s x%d%s]", kname[pl.kernel], pl.grid, pl.phase ? " staggered" : "");
       printf("  %-44s min %7.2f  median %7.2f us  %6.1f TF/s  %+5.1f %%  %s%s\n", libs[li].path, mn, med,

@@ -566,6 +566,282 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_nt_tall_kernel(GemmNtParams p
   if ((EPI == TTTS_EPI_STORE_BF16 || EPI == TTTS_EPI_DGELU_BF16) && p.e.colsum) colsum_flush<TN / 8, NW>(p.e, cs, stage, n0, tid);
 }
 
+// ---- NT, weights in REGISTERS, persistent over row tiles (K = 512, wide N: c_attn, c_fc + GELU) -------------------------------
+// What rounds 2 and 3 measured on the tiled kernels above for the K = 512, N >= 1536 GEMMs (c_attn 25 us, c_fc + GELU 42 us, dGELU
+// 51 us against 6 / 8 / 8 us of matrix-core time): a k-step waits for its 32 KB of L2 -> LDS fill (the W panel is re-fetched
+// for every row tile: 300 MB of fill per launch), and the epilogue of a tile runs with the matrix cores idle.  At K = 512 a
+// wave's share of a weight panel fits its REGISTER FILE: 32 output columns x 512 k = 32 KB per wave = 128 VGPRs per lane, as the
+// 32 MFMA A-operand fragments of the whole reduction.  So:
+//   * one workgroup of eight waves per CU owns a 256-column panel of W (wave w: columns 32 w .. 32 w + 31), loaded once --
+//     through the LDS in whole 1-KB rows (fragment-shaped global loads of it, 32 rows x 32 B per instruction, were L2-request
+//     bound: 8 us of a 29-us launch);
+//   * it walks its share of the rows in 64-row tiles; the ONLY operand that moves per tile is the activation tile (64 x 512 bf16 =
+//     64 KB by LDS-DMA, two buffers), which every wave reads whole: per 16-deep k-step two ds_read_b128 and two MFMAs, no B
+//     fragment reads, no k-loop barriers -- one tile = 64 MFMAs per wave straight through;
+//   * PING-PONG phases: waves 0-3 (columns 0-127) and waves 4-7 (columns 128-255) sit pairwise on the four SIMDs and alternate
+//     roles every phase, one barrier per phase: while one group runs the MFMAs of tile t, the other runs the epilogue of the
+//     tile it has just finished (VALU, LDS, stores) -- the matrix pipe of a SIMD always has exactly one wave feeding it and the
+//     epilogue never runs with the matrix cores idle.  (Two free-running workgroups per CU did not arrange themselves this way:
+//     measured 25 / 30 / 40 us for store / GELU / dGELU at N = 2048, against 19.5 us without any epilogue.)
+//   * every wave stages its own 64 x 32 accumulator block through a PRIVATE 4-KB LDS stage (no barrier inside a phase) and stores
+//     16 bytes per lane, through the same epi_row8 epilogues as every other kernel of the family: one bf16 round where the stored
+//     value is bf16(acc + bias) (store, GELU), two fp32 rounds of 32 rows otherwise.
+// Memory-counter protocol (LDS-DMA is issued untracked; vmcnt retires in order, stores included): every wave issues its eight
+// pieces of tile t + 2 at the start of the even phase in which the buffer is free.  Group 0 is computing then: it waits for them
+// at the start of its next (epilogue) phase, before its first store -- everything it has in flight is a phase old.  Group 1 is
+// in its epilogue then, so its pieces sit in front of that phase's stores: it waits at the end of its next (MFMA) phase.  The
+// barrier that ends odd phase 2 t + 3 publishes tile t + 2 to both groups.
+// Measured (round 4, MI355X; tools/ubench/nt_phase.cpp stand-alone, then rocprofv3 inside the train step, same box):
+//   c_attn 9248 x 1536:  23.6 -> 20.9 us stand-alone, 24.4 -> 22.8 us in the step;  c_fc + GELU 9248 x 2048: 39.3 -> 30.9 / 42.0 -> 33.4.
+//   Cycle stamps (tools/ubench/wreg_trace.cpp): prologue 12 k cycles (four weight passes, then the first tile: two DMA latencies),
+//   an MFMA phase 2.7 k cycles (64 MFMAs = 2.05 k) and 3.2 k with the eight DMA issues in it (~60-160 cycles each: a tile is
+//   64 wave-instructions whoever issues them), a store epilogue 1.8-2.0 k, +0.3 k per phase of barrier and memory waits.
+//   Stores stay non-temporal like the tiled kernels' (plain write-back stores: c_fc + GELU 34.0 vs 30.9 us stand-alone).
+//   dGELU is NOT taken: stand-alone 45.8 -> 39.2 us (pre-activation block by DMA into the private stage, replaced in place), but
+//   in the step, where the saved pre-activation comes from HBM, 45.6 us = the split-grid tiled kernel's time -- one workgroup
+//   per CU has nothing to cover that latency with, and no LDS is left to fetch it a phase earlier; an L2 prefetch queued in
+//   front of the pieces made it 47.3 us (in-order vmcnt).  The path was removed again.
+// Work split: ceil(N / 256) panels x (CUs / panels) row groups, rows dealt to the groups in 32-row units; the XCD-contiguous order
+// keeps the panels of a row group on one L2 (the activation tile is fetched from HBM once per group).  Output bits equal the tiled
+// kernels' (each element is the same k-ordered MFMA chain).
+constexpr int WR_K = 512, WR_KS = WR_K / 16, WR_TM = 64, WR_PN = 256;
+constexpr int WR_ABUF = WR_TM * WR_K * 2, WR_STAGE = 4096, WR_LDS = 2 * WR_ABUF + 8 * WR_STAGE;   // 2 x 64 KB tiles + 8 x 4 KB stages
+#ifndef WR_TRACE
+#define WR_TRACE 0
+#endif
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt_wreg_kernel(GemmNtParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char wreg_smem[];   // [2][64 rows][64 x 16 B], slot = chunk ^ (row & 15) | stages
+  const uint32_t lds0 = lds_byte_addr(wreg_smem);
+  const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, rl = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp2 = wave >> 2;                          // ping-pong group: 0 computes in even phases, 1 in odd phases
+  const int M = p.e.M, N = p.e.N;
+  const int np = (N + WR_PN - 1) / WR_PN, n_groups = p.main_rt;
+  const int id = xcd_tile(blockIdx.x, gridDim.x);
+  const int grp = id / np, n0 = (id % np) * WR_PN, nw = n0 + wave * 32;   // nw: this wave's first column
+  const int units = (M + 31) >> 5;
+  const int r0 = (int)((uint32_t)grp * (uint32_t)units / (uint32_t)n_groups) * 32;            // (grp < CUs, units < 2^22)
+  const int r1 = min(M, (int)((uint32_t)(grp + 1) * (uint32_t)units / (uint32_t)n_groups) * 32);
+  if (r0 >= r1) return;
+  const int ntile = (r1 - r0 + WR_TM - 1) / WR_TM;
+#if WR_TRACE
+  // debug build (tools/ubench/wreg_trace.cpp): cycle stamps of waves 0 and 4 of two workgroups into the colsum buffer
+  unsigned long long* trc = reinterpret_cast<unsigned long long*>(p.e.colsum);
+  int trc_n = 0;
+  const bool trc_on = trc && lane == 0 && (wave & 3) == 0 && (blockIdx.x == 3 || blockIdx.x == 200);
+  unsigned long long* trc_w = trc + ((blockIdx.x == 3 ? 0 : 2) + (wave >> 2)) * 128;
+#define WR_STAMP() do { if (trc_on && trc_n < 128) trc_w[trc_n++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WR_STAMP() do {} while (0)
+#endif
+  WR_STAMP();
+
+  // 64 rows x 1 KB of a row-major matrix -> tile buffer `buf`: eight 1-KB rows per wave; lane l fills slot l of its row with the
+  // row's logical 16-byte chunk l ^ (row & 15) (rows beyond row_max: clamped, never stored)
+  auto dma64 = [&](const bf16* base, int64_t ld, int row0, int row_max, int buf) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int R = wave * 8 + j;
+      lds_dma16_untracked(base + (int64_t)min(row0 + R, row_max) * ld + ((lane ^ (R & 15)) << 3), lds0 + buf * WR_ABUF + R * 1024);
+    }
+  };
+  auto bar = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  // fragment of row 32 i + rl of a tile buffer, k = 16 ks + 8 hh ..: logical chunk 2 ks + hh at slot (2 ks + hh) ^ (rl & 15)
+  const uint32_t fbase = rl * 1024 + ((hh ^ (rl & 15)) << 4);
+  auto frag = [&](const unsigned char* buf, int i, int ks) {
+    return *reinterpret_cast<const bf16x8*>(buf + i * 32768 + (ks >> 3) * 256 + (fbase ^ ((ks & 7) << 5)));
+  };
+  // this wave's 32 weight rows as the 32 A-operand fragments of the whole reduction, read out of 1-KB-row DMA images of the panel
+  bf16x8 w[WR_KS];
+#pragma unroll
+  for (int ks = 0; ks < WR_KS; ++ks) w[ks] = zero8();
+  // (four passes of 64 panel rows, alternating the two tile buffers, each pass's DMA issued two passes ahead; the first two
+  // activation tiles follow them into the buffers as these are released)
+  dma64(p.B, p.ldb, n0, N - 1, 0);
+  dma64(p.B, p.ldb, n0 + 64, N - 1, 1);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // pass r has landed (this wave's eight pieces of the next one may be in flight)
+    bar();
+    if ((wave >> 1) == r) {
+#pragma unroll
+      for (int ks = 0; ks < WR_KS; ++ks) w[ks] = frag(wreg_smem + (r & 1) * WR_ABUF, wave & 1, ks);
+    }
+    bar();
+    if (r < 2) dma64(p.B, p.ldb, n0 + 64 * (r + 2), N - 1, r & 1);
+    else dma64(p.A, p.lda, r0 + (r - 2) * WR_TM, M - 1, r & 1);   // tiles 0 and 1 (tile 1 of a one-tile group: clamped rows, never used)
+  }
+
+  constexpr bool STAGE_BF16 = (EPI == TTTS_EPI_STORE_BF16 || EPI == TTTS_EPI_GELU_BF16);   // the stored value IS bf16(acc + bias)
+  const bool bf16_out = (EPI == TTTS_EPI_STORE_BF16 || EPI == TTTS_EPI_GELU_BF16 || EPI == TTTS_EPI_DGELU_BF16);
+  const bool vec_ok = bf16_out ? ((p.e.ldc & 7) == 0) : ((p.e.ldc & 3) == 0);
+  // bias: added in the accumulator layout, where a lane's 16 columns depend only on its wave and its half -- the wave's 32
+  // values live in SGPRs (autocast-rounded once), a lane picks its half per use; no vector register is held for it.
+  float bias_s[32];
+#pragma unroll
+  for (int t = 0; t < 32; ++t) bias_s[t] = 0.f;
+  if (p.e.bias) {
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+      const float b0 = p.e.bias[min(nw + t, N - 1)];
+      const float b = (EPI == TTTS_EPI_STORE_F32) ? b0 : (float)(bf16)b0;
+      bias_s[t] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, b)));
+    }
+  }
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  unsigned char* stage = wreg_smem + 2 * WR_ABUF + wave * WR_STAGE;   // this wave's own 4 KB
+  const uint32_t stage_lds = lds0 + 2 * WR_ABUF + wave * WR_STAGE;
+  const int er = lane >> 2, ec = lane & 3;             // read-back: lane -> (row er of a 16-row pass, columns nw + 8 ec .. + 7)
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tiles 0 and 1 (this wave's pieces)
+  bar();
+
+  WR_STAMP();                                        // [1]: prologue done
+  for (int ph = 0; ph <= 2 * ntile; ++ph) {
+    WR_STAMP();                                      // phase start
+    // even phases: the tile buffer both groups finished with at the end of the previous phase is refilled two tiles ahead
+    if (!(ph & 1) && ph >= 2 && (ph >> 1) + 1 < ntile) dma64(p.A, p.lda, r0 + ((ph >> 1) + 1) * WR_TM, M - 1, ((ph >> 1) + 1) & 1);
+    const int t = (ph - grp2) >> 1;                    // the tile this wave computes (its MFMA phases) or has just computed
+    if ((ph & 1) == grp2) {
+      // ---------------- MFMA phase: tile t, 64 MFMAs ----------------
+      if (t < ntile) {
+        const int m0 = r0 + t * WR_TM;
+        const bool two = m0 + 32 < r1;                // the second 32-row block holds rows (workgroup-uniform)
+        const unsigned char* ab = wreg_smem + (t & 1) * WR_ABUF;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        // fragment pipeline, order pinned: the reads of k-step ks + 2 are issued in front of the MFMAs of k-step ks (this wave is
+        // the only one feeding its SIMD's matrix pipe: two k-steps = 128 cycles cover the LDS latency); it runs at raised priority --
+        // the partner wave's epilogue instructions take the issue slots the MFMA stream leaves
+        __builtin_amdgcn_s_setprio(2);
+        if (two) {
+          bf16x8 fa[3][2];
+          fa[0][0] = frag(ab, 0, 0); fa[0][1] = frag(ab, 1, 0);
+          fa[1][0] = frag(ab, 0, 1); fa[1][1] = frag(ab, 1, 1);
+#pragma unroll
+          for (int ks = 0; ks < WR_KS; ++ks) {
+            if (ks + 2 < WR_KS) { fa[(ks + 2) % 3][0] = frag(ab, 0, ks + 2); fa[(ks + 2) % 3][1] = frag(ab, 1, ks + 2); }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0] = mfma32(w[ks], fa[ks % 3][0], acc[0]);
+            acc[1] = mfma32(w[ks], fa[ks % 3][1], acc[1]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
+          bf16x8 fa[4];
+          fa[0] = frag(ab, 0, 0); fa[1] = frag(ab, 0, 1); fa[2] = frag(ab, 0, 2);
+#pragma unroll
+          for (int ks = 0; ks < WR_KS; ++ks) {
+            if (ks + 3 < WR_KS) fa[(ks + 3) & 3] = frag(ab, 0, ks + 3);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0] = mfma32(w[ks], fa[ks & 3], acc[0]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      WR_STAMP();                                    // MFMAs issued
+      __builtin_amdgcn_s_setprio(0);
+      // group 1 issued its tile pieces at the start of its previous (epilogue) phase and the tile is read two phases after that:
+      // it has to publish them here, behind that phase's stores.  Group 0 (pieces issued at the start of THIS phase) waits at
+      // the start of its epilogue phase instead, before it issues any store -- nothing young is in flight there.
+      if (grp2 == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (t >= 0 && t < ntile) {
+      // ---------------- epilogue phase: the tile computed in the previous phase ----------------
+      if (grp2 == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // a phase old: its tile pieces
+      const int m0 = r0 + t * WR_TM;
+      const bool two = m0 + 32 < r1;
+      if (STAGE_BF16) {
+        // private bf16 stage [64 rows][4 slots of 16 B], slot s of row m at s ^ ((m >> 2) & 3): conflict-free 8-byte writes
+        // (16 lanes = 16 rows of one slot) and 16-byte reads (16 lanes = 4 rows x 4 slots)
+        bf16* sb = reinterpret_cast<bf16*>(stage);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          if (i == 1 && !two) break;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16)(acc[i][4 * q + e] + (hh ? bias_s[8 * q + 4 + e] : bias_s[8 * q + e]));
+            *reinterpret_cast<bf16x4*>(sb + (i * 32 + rl) * 32 + ((q ^ ((rl >> 2) & 3)) << 3) + 4 * hh) = o;
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        constexpr int RB = 4;                         // all four read-back chunks in flight at once
+#pragma unroll
+        for (int pb = 0; pb < 4; pb += RB) {
+          bf16x8 ob[RB];
+#pragma unroll
+          for (int ps = 0; ps < RB; ++ps) ob[ps] = *reinterpret_cast<const bf16x8*>(sb + ((pb + ps) * 16 + er) * 32 + ((ec ^ ((((pb + ps) * 16 + er) >> 2) & 3)) << 3));
+          __builtin_amdgcn_sched_barrier(0);          // the reads are in flight before the first pass waits
+#pragma unroll
+          for (int ps = 0; ps < RB; ++ps) {
+            const int row = (pb + ps) * 16 + er, m = m0 + row, n = nw + ec * 8;
+            const bf16x8 o = ob[ps];
+            if (m >= r1 || n >= N) continue;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (float)o[e];   // exact: epi_row8 rounds it back to the same bf16
+            epi_row8<EPI>(p.e, m, n, v, vec_ok, cs);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // stage drained (the next MFMA phase's DMA may overwrite it)
+      } else {
+        // private fp32 stage, one 32-row block per round: [32 rows][8 slots of 16 B], slot s of row m at s ^ ((m >> 1) & 7)
+        float* sf = reinterpret_cast<float*>(stage);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          if (i == 1 && !two) break;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(sf + rl * 32 + (((2 * q + hh) ^ ((rl >> 1) & 7)) << 2)) =
+                make_float4(acc[i][4 * q] + (hh ? bias_s[8 * q + 4] : bias_s[8 * q]), acc[i][4 * q + 1] + (hh ? bias_s[8 * q + 5] : bias_s[8 * q + 1]),
+                            acc[i][4 * q + 2] + (hh ? bias_s[8 * q + 6] : bias_s[8 * q + 2]), acc[i][4 * q + 3] + (hh ? bias_s[8 * q + 7] : bias_s[8 * q + 3]));
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int ps = 0; ps < 2; ++ps) {
+            const int row = ps * 16 + er, m = m0 + i * 32 + row, n = nw + ec * 8;
+            const int x = (row >> 1) & 7;
+            const float4 a = *reinterpret_cast<const float4*>(sf + row * 32 + (((2 * ec) ^ x) << 2));
+            const float4 b = *reinterpret_cast<const float4*>(sf + row * 32 + (((2 * ec + 1) ^ x) << 2));
+            if (m >= r1 || n >= N) continue;
+            float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            epi_row8<EPI>(p.e, m, n, v, vec_ok, cs);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // round drained before the next one overwrites the stage
+        }
+      }
+    }
+    WR_STAMP();                                      // role done, before the barrier
+    bar();
+  }
+  WR_STAMP();
+  if (!WR_TRACE && EPI == TTTS_EPI_STORE_BF16 && p.e.colsum) {
+    // column sums: lanes l, l + 4, ... of a wave hold the same 8 columns; one atomic per column and wave (32 row groups: as
+    // contended as the tiled kernels' one atomic per column and tile)
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cs[e] += __shfl_xor(cs[e], o, 64);
+    if (lane < 4) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (nw + lane * 8 + e < N) atomicAdd(p.e.colsum + nw + lane * 8 + e, cs[e]);
+    }
+  }
+}
+
 // ---- NT, register-staged main loop (any K % 8 == 0; zero-fills ragged K) ---------------------------------------------
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNtParams p) {
@@ -959,8 +1235,23 @@ using namespace ttts;
 //    2 ... 10 %, and the tile bookkeeping costs the plain eight-wave kernel 4 %, hence the separate instantiation;
 //  * DMA32 + stagger for any other dGELU (32-deep stages, three workgroups per CU, staggered: 52.2 -> 48.7 us);
 //  * DMA64 (128 x 128, 64-deep stages, two workgroups per CU) / DMA32 (K % 64 != 0) / REG (register-staged, ragged K) otherwise.
+//  * WREG (round 4): weights in registers, one persistent workgroup per CU (gemm_nt_wreg_kernel) for K = 512 and wide N whose
+//    256-column panels waste < 10 % (c_attn, c_fc + GELU; not the 1026-column mel head), from 4096 rows up; never dGELU (its
+//    saved pre-activation arrives from HBM in a train step: measured no faster there than the split grid, see the kernel).
+// The thresholds scale with the CU count of the current device (256 on an MI355X; a host without a GPU plans for 256).
+static int device_cus() {
+  static int cached[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return 256; }
+  if (cached[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
+    cached[dev] = n;   // (benign race: every thread writes the same value)
+  }
+  return cached[dev];
+}
 static ttts_gemm_nt_plan plan_nt(int M, int N, int K, int epilogue) {
-  constexpr int CUS = 256;
+  const int CUS = device_cus();
   ttts_gemm_nt_plan pl{};
   pl.block = 256; pl.tile_m = 128; pl.tile_n = 128;
   const int grid = (int)(cdiv(M, BM) * cdiv(N, BN));
@@ -968,6 +1259,15 @@ static ttts_gemm_nt_plan plan_nt(int M, int N, int K, int epilogue) {
   if (K % 64 != 0) {
     pl.kernel = K % 32 == 0 ? TTTS_NT_KERNEL_DMA32 : TTTS_NT_KERNEL_REG;
     return pl;
+  }
+  if (epilogue != TTTS_EPI_DGELU_BF16 && K == WR_K && M >= 4096 && N >= 1024 && N % 8 == 0) {
+    const int np = (int)cdiv(N, WR_PN);
+    if (np <= CUS && (int64_t)np * WR_PN * 10 <= (int64_t)N * 11) {
+      const int groups = std::max(1, std::min(CUS / np, (int)cdiv(M, WR_TM)));
+      pl.kernel = TTTS_NT_KERNEL_WREG; pl.grid = np * groups; pl.block = 512; pl.tile_m = WR_TM; pl.tile_n = WR_PN;
+      pl.main_row_tiles = groups;
+      return pl;
+    }
   }
   const int tall_grid = (int)(cdiv(M, 160) * cdiv(N, 128));
   if (grid > CUS && grid <= CUS * 8 / 5 && tall_grid <= CUS) {
@@ -998,28 +1298,47 @@ static ttts_gemm_nt_plan plan_nt(int M, int N, int K, int epilogue) {
   return pl;
 }
 
+// Kernels that need more than 64 KB of dynamic LDS carry a per-function opt-in (hipFuncSetAttribute).  It is set once per
+// (function, device) -- an idempotent driver-side attribute of the code object, not state the results depend on -- and a refusal
+// is reported instead of being left to fail the launch.  slot: a small id per kernel instantiation.
+static bool nt_func_lds(const void* fn, int bytes, int slot) {
+  static bool done[16][16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+  if (done[dev][slot & 15]) return true;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+    fail(TTTS_EHIP, "gemm_nt: the device refused %d bytes of dynamic LDS: %s", bytes, hipGetErrorString(hipGetLastError()));
+    return false;
+  }
+  done[dev][slot & 15] = true;
+  return true;
+}
+
 template <int EPI>
-static void launch_nt(const GemmNtParams& p, hipStream_t s) {
+static int launch_nt(const GemmNtParams& p, hipStream_t s) {
   const ttts_gemm_nt_plan pl = plan_nt(p.e.M, p.e.N, p.K, EPI);
   GemmNtParams q = p;
   q.phase = pl.phase; q.main_rt = pl.main_row_tiles; q.tail_h = pl.tail_tile_rows;
   switch (pl.kernel) {
     case TTTS_NT_KERNEL_RING160: {
       constexpr size_t smem = (size_t)4 * (160 + 128) * 64 * sizeof(bf16);   // the 4-slot ring: 144 KB
-      static bool attr = false;
-      if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_tall_kernel<EPI, 5, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr = true;
-      }
+      if (!nt_func_lds(reinterpret_cast<const void*>(gemm_nt_tall_kernel<EPI, 5, 4, 4>), (int)smem, 2 * EPI)) return TTTS_EHIP;
       gemm_nt_tall_kernel<EPI, 5, 4, 4><<<pl.grid, 256, smem, s>>>(q);
       break;
     }
+    case TTTS_NT_KERNEL_WREG:
+      if constexpr (EPI != TTTS_EPI_DGELU_BF16) {   // (plan_nt never sends dGELU here: see its comment)
+        if (!nt_func_lds(reinterpret_cast<const void*>(gemm_nt_wreg_kernel<EPI>), WR_LDS, 1 + 2 * EPI)) return TTTS_EHIP;
+        gemm_nt_wreg_kernel<EPI><<<pl.grid, 512, WR_LDS, s>>>(q);
+      }
+      break;
     case TTTS_NT_KERNEL_WAVE8: gemm_nt_glds_kernel<EPI, 32, 2, 4><<<pl.grid, 512, 0, s>>>(q); break;
     case TTTS_NT_KERNEL_WAVE8_SPLIT: gemm_nt_glds_kernel<EPI, 32, 2, 4, true><<<pl.grid, 512, 0, s>>>(q); break;
     case TTTS_NT_KERNEL_DMA64: gemm_nt_glds_kernel<EPI, 64><<<pl.grid, 256, 0, s>>>(q); break;
     case TTTS_NT_KERNEL_DMA32: gemm_nt_glds_kernel<EPI, 32><<<pl.grid, 256, 0, s>>>(q); break;
     default: gemm_nt_kernel<EPI><<<pl.grid, 256, 0, s>>>(q); break;
   }
+  return TTTS_OK;
 }
 
 extern "C" int ttts_gemm_nt_plan_query(int32_t M, int32_t N, int32_t K, int32_t epilogue, ttts_gemm_nt_plan* out) {
@@ -1049,14 +1368,16 @@ extern "C" int ttts_gemm_nt_bf16_ex(const void* A, int64_t lda, const void* B, i
                          (uint32_t)(seed >> 32), dropout_counter, colsum}};
   if (p.e.thr) p.e.inv_keep = 65536.0f / (65536.0f - (float)p.e.thr);
   hipStream_t s = as_stream(stream);
+  int rc = TTTS_OK;
   switch (epilogue) {
-    case TTTS_EPI_STORE_BF16: launch_nt<TTTS_EPI_STORE_BF16>(p, s); break;
-    case TTTS_EPI_GELU_BF16: launch_nt<TTTS_EPI_GELU_BF16>(p, s); break;
-    case TTTS_EPI_RESID_ADD_F32: launch_nt<TTTS_EPI_RESID_ADD_F32>(p, s); break;
-    case TTTS_EPI_DGELU_BF16: launch_nt<TTTS_EPI_DGELU_BF16>(p, s); break;
-    case TTTS_EPI_STORE_F32: launch_nt<TTTS_EPI_STORE_F32>(p, s); break;
+    case TTTS_EPI_STORE_BF16: rc = launch_nt<TTTS_EPI_STORE_BF16>(p, s); break;
+    case TTTS_EPI_GELU_BF16: rc = launch_nt<TTTS_EPI_GELU_BF16>(p, s); break;
+    case TTTS_EPI_RESID_ADD_F32: rc = launch_nt<TTTS_EPI_RESID_ADD_F32>(p, s); break;
+    case TTTS_EPI_DGELU_BF16: rc = launch_nt<TTTS_EPI_DGELU_BF16>(p, s); break;
+    case TTTS_EPI_STORE_F32: rc = launch_nt<TTTS_EPI_STORE_F32>(p, s); break;
     default: return fail(TTTS_EUNSUPPORTED, "gemm_nt: unknown epilogue %d", epilogue);
   }
+  if (rc != TTTS_OK) return rc;
   return check_launch("gemm_nt");
 }
 

@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(CSRC, "build")
-SO_PATH = os.path.join(HERE, "libttts_hip.so")
+SO_PATH = os.environ.get("TTTS_LIB") or os.path.join(HERE, "libttts_hip.so")   # TTTS_LIB: an alternate build of the same ABI (same-box A/B runs: tools/gpu_ab_lib.sh)
 SOURCES = ["lib.hip", "elementwise.hip", "gemm.hip", "attn.hip", "attn_dh64.hip", "vq.hip", "stft.hip", "conv.hip", "conv_mfma.hip", "conv_thin.hip", "conv_grouped.hip", "losses.hip", "vqvae_ops.hip", "attn_f32.hip", "attn_cross.hip", "peq.hip", "decode.hip", "diffusion_ops.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-Wall", "-Wno-unused-variable"]
@@ -88,7 +88,7 @@ class GemmNtPlan(ctypes.Structure):
                 ("main_row_tiles", _I32), ("tail_tile_rows", _I32)]
 
 
-NT_KERNEL_REG, NT_KERNEL_DMA64, NT_KERNEL_DMA32, NT_KERNEL_RING160, NT_KERNEL_WAVE8, NT_KERNEL_WAVE8_SPLIT = range(6)
+NT_KERNEL_REG, NT_KERNEL_DMA64, NT_KERNEL_DMA32, NT_KERNEL_RING160, NT_KERNEL_WAVE8, NT_KERNEL_WAVE8_SPLIT, NT_KERNEL_WREG = range(7)
 
 
 class TransposeDesc(ctypes.Structure):
