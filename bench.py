@@ -152,7 +152,10 @@ def vqvae_leg(dev, steps, warmup, cpu_leg=True):
     except Exception:
         conv_traffic = None
     res = {"metric": "vqvae_gan_train_frames_per_sec", "value": round(B * 256 / dt, 1), "unit": "frames/s",
-           "ms_per_step": round(dt * 1e3, 2), "steps": steps, "warmup": warmup, "dtype": "f32 (conv products as split-bf16 x3 on the bf16 MFMA, fp32 accumulate)",
+           "ms_per_step": round(dt * 1e3, 2), "steps": steps, "warmup": warmup, "dtype": "f32 (conv products as split-bf16 x3 on the bf16 MFMA, fp32 accumulate; VQ distances on the exact f32 MFMA)",
+           "vq_code_parity": "nearest-code kernel bit-exact vs the C oracle; through the assembled model the split-bf16 convolutions perturb the "
+                             "quantizer input by <= 1.1e-5 of its range: code indices are held to 'differ only on audited near-tie rows, "
+                             "<= max(2, 1 %) of frames' (tests/test_gpu_fullsize.py, test_gpu_vqvae.py) -- measured 0 of 50 clips; exact-conv mode is bit-equal to the reference fixture",
            "config": {"workload": "VQ-VAE-GAN two-phase step (spectrograms, SynthesizerTrn, mel, MPD x2, 6 losses, 2 x AdamW, codebook EMA), "
                                   "batch 32 x 163 840 samples (256 frames), %s" % ("one hipGraph replay per step" if graphed else "eager launches (capture refused)")},
            "algorithmic_tflops": round(1.97e9 * B * 256 / dt / 1e12, 1),
@@ -218,6 +221,88 @@ def vqvae_cpu_baseline():
                       "%.2f s/step" % (n, frames, frames * 640, threads, dt)}
 
 
+def diffusion_leg(dev, steps, warmup, cpu_leg=True):
+    """BASELINE config #5: the diffusion mel-denoiser train step (AA_diffusion, ttts/diffusion/train.py:156-203) at batch 16,
+    x_start (16,100,400), latent (16,512,100), refer (16,100,200).  Arithmetic as built: fp32 with split-bf16 matrix-core
+    convolutions and exact-fp32 attention GEMMs -- WIDER than the config's "bf16 + fp8" (stated in `dtype`)."""
+    from ttts_amd.diffusion.train import DiffusionTrainer
+    B, C, T, Tl, Tr = 16, 512, 400, 100, 200
+    cfg = {"train": {"lr": 1e-4, "timesteps": 1000},
+           "aa_diffusion": dict(in_channels=100, out_channels=200, model_channels=C, num_heads=16, num_layers=6, in_latent_channels=512,
+                                dropout=0, layer_drop=0.1)}
+    tr = DiffusionTrainer(cfg, device=dev)
+    with torch.no_grad():      # the reference zero-initialises every attention output projection: give them signal
+        for k, p in tr.diffusion.named_parameters():
+            if k.endswith("proj_out.weight"):
+                p.normal_(0, 0.02)
+    g = torch.Generator().manual_seed(0)
+    mel = (torch.randn(B, 100, T, generator=g) * 2 - 4).to(dev); ref = (torch.randn(B, 100, Tr, generator=g) * 2 - 4).to(dev)
+    lat = torch.randn(B, 512, Tl, generator=g).to(dev)                     # inputs resident in HBM before the timed region
+    for _ in range(warmup):
+        out = tr.train_step(mel, ref, lat)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        out = tr.train_step(mel, ref, lat)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+    loss = float(out["loss"])
+    assert loss == loss, "non-finite diffusion loss"
+
+    def attn(t):      # qkv + proj 1x1 convs, QK^T and PV
+        return 2 * t * C * 3 * C + 2 * t * C * C + 4 * t * t * C
+
+    def resb(t):
+        return 2 * t * C * C + 2 * t * C * C * 3
+    fwd = (2 * Tl * 512 * C * 3 + 3 * attn(Tl)) + (2 * Tr * 100 * C * 3 + 3 * attn(Tr) + 2 * (Tr + 32) * C * C * 3 + 4 * attn(Tr + 32)) \
+        + 3 * (resb(T) + attn(T)) + 2 * T * 100 * C * 3 + 2 * T * 2 * C * C + 6 * (resb(T) + attn(T)) + 3 * resb(T) + 2 * T * C * 200 * 3
+    ach = 3.0 * fwd * B / dt / 1e12
+    peak = PEAK_BF16_TFLOPS / 3.0
+    res = {"metric": "diffusion_train_mel_frames_per_sec", "value": round(B * T / dt, 1), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 2),
+           "steps": steps, "warmup": warmup,
+           "dtype": "f32 (conv / linear products as split-bf16 x3 on the bf16 MFMA, attention GEMMs on the exact f32 MFMA) -- wider than config #5's bf16 + fp8",
+           "config": {"workload": "AA_diffusion train step (q_sample, model, mse + learned-range VB, backward, clip 1.0, AdamW), batch 16 x "
+                                  "(100 x 400 mel, 512 x 100 latent, 100 x 200 reference), 43.2 M parameters, eager launches"},
+           "roofline": {"bound": "mfma", "kernel": "whole step (convolution family + attention GEMMs)", "achieved": round(ach, 2),
+                        "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                        "note": "algorithmic FLOPs = 3 x forward (%.1f GFLOP per sample) / step time; peak = bf16 MFMA / 3 (an fp32 product "
+                                "costs three bf16 products)" % (fwd / 1e9)},
+           "loss": round(loss, 4), "grad_norm": round(float(out["grad_norm"]), 4)}
+    if cpu_leg:
+        res["cpu_baseline"] = diffusion_cpu_baseline()
+    return res
+
+
+def diffusion_cpu_baseline():
+    """The oracle's restatement of the same step (oracle/diffusion_ref: q_sample, AA_diffusion forward, training_losses, CPU autograd,
+    clip, AdamW) on the host cores: bounded sample = ONE item of config #5's shapes instead of the batch of 16 (frames/s per item)."""
+    from oracle import diffusion_ref as D
+    threads = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(threads)
+    cfg = dict(in_channels=100, out_channels=200, model_channels=512, num_heads=16, num_layers=6, in_latent_channels=512, dropout=0, layer_drop=0.1)
+    sd = {k: D.det_fill(k, shp, 0.5).requires_grad_(True) for k, shp in D.param_spec(cfg)}
+    opt = torch.optim.AdamW(list(sd.values()), 1e-4, betas=(0.9, 0.999), weight_decay=0.01)
+    tab = D.diffusion_tables(1000)
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.randn(1, 100, 400, generator=g).clamp(-1, 1); lat = torch.randn(1, 512, 100, generator=g); ref = torch.randn(1, 100, 200, generator=g)
+
+    def one_step():
+        t = torch.randint(0, 1000, (1,), generator=g)
+        noise = torch.randn(x0.shape, generator=g)
+        x_t = D.q_sample(tab, x0, t, noise)
+        out = D.aa_diffusion_forward(sd, cfg, x_t, t, lat, ref)
+        loss = D.training_losses(tab, out, x0, x_t, t, noise)["loss"].mean()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(list(sd.values()), 1.0)
+        opt.step(); opt.zero_grad()
+    t0 = time.time(); one_step(); warm = time.time() - t0
+    n, t0 = 0, time.time()
+    while n < 1 or (time.time() - t0 + 1.5 * warm < 15.0 and n < 25):
+        one_step(); n += 1
+    dt = (time.time() - t0) / n
+    return {"value": round(400 / dt, 2), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": "%d train steps of the oracle on ONE item of config #5's shapes (100 x 400 mel, 512 x 100 latent, 100 x 200 reference; "
+                      "the config is 16 such items), fp32, %d threads, after 1 warm-up step; %.2f s/step" % (n, threads, dt)}
+
+
 class KernelTimer:
     """Brackets every launch of the instrumented ops with HIP events on the launch stream (torch's current stream,
     which is the stream handed to the C ABI) and accumulates (time, algorithmic flops) per kernel family."""
@@ -238,8 +323,8 @@ class KernelTimer:
             e0.record()
             r = fn(*a, **kw)
             e1.record()
-            fam, fl = flops_fn(*a, **kw)
-            self.records.append((fam, fl, e0, e1, self.step))
+            fam, fl, by = flops_fn(*a, **kw)
+            self.records.append((fam, fl, e0, e1, self.step, by))
             return r
         setattr(self.ops, name, wrapped)
 
@@ -248,16 +333,20 @@ class KernelTimer:
 
         def f_nt(a, b, c, bias=None, aux=None, epilogue=0, n=None, k=None, **kw):
             M, K, N = a.shape[0], (a.shape[1] if k is None else k), (b.shape[0] if n is None else n)
-            return "gemm_nt_kernel<%s>" % epi[epilogue], 2.0 * M * N * self.k_true.get(K, K)
+            kt = self.k_true.get(K, K)
+            # algorithmic HBM bytes: both operands once, the output(s) once, what the epilogue reads once
+            out_b = {0: 2 * M * N, 1: 4 * M * N, 2: 8 * M * N, 3: 4 * M * N, 4: 4 * M * N}[epilogue]
+            return "gemm_nt_kernel<%s>" % epi[epilogue], 2.0 * M * N * kt, 2.0 * (M + N) * kt + out_b
 
         def f_tn(at, bt, c, mo=None, no=None, **kw):
-            return "gemm_tn_kernel", 2.0 * at.shape[0] * (at.shape[1] if mo is None else mo) * (bt.shape[1] if no is None else no)
+            mo_, no_ = (at.shape[1] if mo is None else mo), (bt.shape[1] if no is None else no)
+            return "gemm_tn_kernel", 2.0 * at.shape[0] * mo_ * no_, 2.0 * at.shape[0] * (mo_ + no_) + 8.0 * mo_ * no_
 
         def f_af(q, k, v, o, lse, B, H, S, dh, *a, **kw):
-            return "attn_fwd_kernel", 4.0 * B * H * dh * S * (S + 1) / 2      # causal-useful QK^T + PV
+            return "attn_fwd_kernel", 4.0 * B * H * dh * S * (S + 1) / 2, 2.0 * 4 * B * H * S * dh      # causal-useful QK^T + PV; q, k, v in, o out
 
         def f_ab(q, k, v, o, d_o, lse, dq, dk, dv, ws, B, H, S, dh, *a, **kw):
-            return "attn_bwd(delta+dkdv+dq)", 10.0 * B * H * dh * S * (S + 1) / 2  # 5 causal-useful matmuls
+            return "attn_bwd(delta+dkdv+dq)", 10.0 * B * H * dh * S * (S + 1) / 2, 2.0 * 13 * B * H * S * dh  # 5 causal-useful matmuls; q, k, v, o, dO x2 reads + 3 writes
         self._wrap("gemm_nt", f_nt)
         self._wrap("gemm_tn_accum", f_tn)
         self._wrap("attn_fwd", f_af)
@@ -272,7 +361,7 @@ class KernelTimer:
             e0.record()
             plan_run(plan)
             e1.record()
-            timer.records.append(("gemm_tn_grouped_kernel", plan.flops, e0, e1, timer.step))
+            timer.records.append(("gemm_tn_grouped_kernel", plan.flops, e0, e1, timer.step, plan.bytes))
         self.ops.TnPlan.run = timed_run
         return self
 
@@ -286,19 +375,21 @@ class KernelTimer:
         timed in every instrumented step, and the MINIMUM over the steps is what counts (a host hiccup while the device waits
         for work, or a clock ramp, lands between one event pair and would otherwise dominate a whole family)."""
         torch.cuda.synchronize()
-        per = {}                                  # (family, position within its step) -> [flops, [durations over steps]]
+        per = {}                                  # (family, position within its step) -> [flops, [durations over steps], bytes]
         pos = {}
-        for fam, fl, e0, e1, st in self.records:
+        for fam, fl, e0, e1, st, by in self.records:
             k = pos.get((fam, st), 0)
             pos[(fam, st)] = k + 1
-            per.setdefault((fam, k), [fl, []])[1].append(e0.elapsed_time(e1) * 1e-3)
+            per.setdefault((fam, k), [fl, [], by])[1].append(e0.elapsed_time(e1) * 1e-3)
         nsteps = max(1, self.step)
         agg = {}
-        for (fam, _k), (fl, durs) in per.items():
-            a = agg.setdefault(fam, [0, 0.0, 0.0])
+        for (fam, _k), (fl, durs, by) in per.items():
+            a = agg.setdefault(fam, [0, 0.0, 0.0, 0.0])
             a[0] += nsteps
             a[1] += min(durs) * nsteps
             a[2] += fl * nsteps
+            # the launch's own roof: whichever of the matrix cores (dense bf16 peak) and HBM (8 TB/s) its algorithmic work needs longer
+            a[3] += max(fl / (PEAK_BF16_TFLOPS * 1e12), by / (PEAK_HBM_GBS * 1e9)) * nsteps
         return agg
 
 
@@ -359,6 +450,10 @@ def main():
                          "(three graphs); 'whole' = one all-reduce of the whole gradient arena after the backward (two graphs)")
     ap.add_argument("--no-vqvae", action="store_true", help="skip the VQ-VAE-GAN leg (second clause of the metric; N = 1 only)")
     ap.add_argument("--vqvae-steps", type=int, default=8)
+    ap.add_argument("--no-diffusion", action="store_true", help="skip the diffusion leg (BASELINE config #5; N = 1 only)")
+    ap.add_argument("--diffusion-steps", type=int, default=10)
+    ap.add_argument("--grad-dtype", default="f32", choices=["f32", "bf16"],
+                    help="N > 1: element type of the gradient all-reduce (bf16 halves the bytes on the xGMI links; replicas stay bit-identical)")
     args = ap.parse_args()
 
     from ttts_amd import ops
@@ -382,7 +477,7 @@ def main():
                 p.fill_(1.0 if (k.endswith("weight")) else 0.0)
             else:
                 p.normal_(0.0, 0.02)
-    dp = FlatDataParallel()
+    dp = FlatDataParallel(grad_dtype=torch.bfloat16 if args.grad_dtype == "bf16" else None)
     dp.broadcast_(eng.params)
     eng.refresh_shadows()
 
@@ -420,14 +515,21 @@ def main():
         step()
     dp.barrier()
     torch.cuda.synchronize()
+    # per-step device times beside the wall clock: one HIP event after every step (on the launch stream; an event record costs the
+    # device nothing and the host ~1 us) -> the MEDIAN step, SURVEY 8(d)'s statistic.  `value` stays K steps / wall time.
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     dp.barrier()
     torch.cuda.synchronize()
     my_elapsed = time.perf_counter() - t0
     elapsed = dp.max_over_ranks(my_elapsed)
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = dp.max_over_ranks(step_ms[len(step_ms) // 2])
     # per-rank step times (every rank's own clock around the same barrier-bracketed region) and, for N > 1, the cost of the
     # exchange by itself: one SUM all-reduce of the whole fp32 gradient arena, HIP events on the current stream, 5 repetitions
     per_rank_ms = [round(my_elapsed / args.steps * 1e3, 3)]
@@ -470,16 +572,19 @@ def main():
                     torch.cuda._sleep(int(4e7))
                 step()
             agg = kt.summary()
-        fam, (cnt, secs, flops) = max(agg.items(), key=lambda kv: kv[1][1])
+        fam, (cnt, secs, flops, _roof) = max(agg.items(), key=lambda kv: kv[1][1])
         ach = flops / secs / 1e12
         # HBM-side bytes per launch from the separate rocprofv3 --pmc passes (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE), see
         # profiles/pmc_traffic.json; null when no counter run exists for this kernel family
-        traffic = None
+        traffic, attn_busy = None, None
         try:
             pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")))
             traffic = pmc["traffic_bytes_per_launch"].get(fam)
+            attn_busy = pmc.get("attention_mfma_busy")
         except Exception:
             traffic = None
+        step_flops = sum(v[2] for v in agg.values()) / args.profile_steps      # useful FLOPs of one step: every instrumented matrix-core kernel
+        step_s = elapsed / args.steps
         roof = {"bound": "mfma", "kernel": fam, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                 "timing": "HIP events on the launch stream around every launch, min over %d instrumented eager steps; traffic from the "
@@ -487,7 +592,14 @@ def main():
                 "launches_per_step": cnt // args.profile_steps, "avg_launch_us": round(secs / cnt * 1e6, 2),
                 "avg_gflop_per_launch": round(flops / cnt / 1e9, 3),
                 "all_kernels_ms_per_step": {k: round(v[1] / args.profile_steps * 1e3, 3) for k, v in sorted(agg.items())},
-                "all_kernels_tflops": {k: round(v[2] / v[1] / 1e12, 1) for k, v in sorted(agg.items())}}
+                "all_kernels_tflops": {k: round(v[2] / v[1] / 1e12, 1) for k, v in sorted(agg.items())},
+                # per family: the sum over its launches of max(MFMA time at 2.5 PF, HBM time at 8 TB/s of the algorithmic bytes) / measured time
+                "all_kernels_frac_of_own_roof": {k: round(v[3] / v[1], 3) for k, v in sorted(agg.items())},
+                # the number the north star is about: useful matrix-core FLOPs of the WHOLE step (attention counted causal-useful)
+                # / the headline step time / dense bf16 peak
+                "step_gflop": round(step_flops / 1e9, 1), "step_tflops": round(step_flops / step_s / 1e12, 1),
+                "step_frac": round(step_flops / step_s / 1e12 / PEAK_BF16_TFLOPS, 4),
+                "attention_mfma_busy": attn_busy}
     else:
         for _ in range(args.profile_steps):
             step()
@@ -501,7 +613,8 @@ def main():
         tokens = world * B_PER_GPU * MEL_LEN * args.steps
         out = {"metric": "gpt_train_audio_tokens_per_sec", "value": round(tokens / elapsed, 1), "unit": "audio-tokens/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": round(elapsed / args.steps * 1e3, 3), "ms_per_step_median": round(median_ms, 3),
+               "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": "VALL-E GPT train step (ttts/gpt/config.json model: 6 layers, d512, 8 heads, 21.46 M "
                                       "params), batch 8 per GPU x (128 text + 1024 audio tokens) = S 1156, fwd+bwd+clip+AdamW, "
@@ -510,7 +623,10 @@ def main():
                           "global_batch": world * B_PER_GPU, "seq_len": TEXT_LEN + 2 + MEL_LEN + 2, "parallelism": "dp%d" % world,
                           "mode": args.mode, "graph_replay": bool(graphed),
                           "exchange": (args.exchange if world > 1 else None),
-                          "dist_backend": (torch.distributed.get_backend() if world > 1 else None), "world_size": world},
+                          "dist_backend": (torch.distributed.get_backend() if world > 1 else None), "world_size": world,
+                          "ranks_seen_by_backend": (torch.distributed.get_world_size() if world > 1 else 1),
+                          "grad_exchange_dtype": (args.grad_dtype if world > 1 else None),
+                          "capture_note": getattr(eng, "_capture_error", None)},
                "final_loss_mel": round(lm, 4), "per_rank_ms_per_step": per_rank_ms,
                "allreduce_arena_ms": (None if allreduce_ms is None else round(allreduce_ms, 3)),
                "allreduce_arena_mb": (None if allreduce_ms is None else round(eng.grads.numel() * 4 / 2 ** 20, 1)), "roofline": roof}
@@ -518,10 +634,13 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         if world == 1:
             out["hbm_kernels"] = hbm_kernel_table(dev)
+        eng = None                                 # release the GPT replica before the other models' legs
+        torch.cuda.empty_cache()
         if world == 1 and not args.no_vqvae:
-            del eng
-            torch.cuda.empty_cache()
             out["vqvae"] = vqvae_leg(dev, args.vqvae_steps, 2, cpu_leg=not args.no_cpu_baseline)
+            torch.cuda.empty_cache()
+        if world == 1 and not args.no_diffusion:
+            out["diffusion"] = diffusion_leg(dev, args.diffusion_steps, 3, cpu_leg=not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
 
 

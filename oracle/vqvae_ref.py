@@ -197,6 +197,21 @@ def coupling_block_forward(x, x_mask, sd, pfx, channels, hidden, kernel_size, di
     return x
 
 
+def coupling_block_reverse(x, x_mask, sd, pfx, channels, hidden, kernel_size, dilation_rate, n_layers, n_flows, g=None):
+    """ResidualCouplingBlock.forward(reverse=True) (vq2.py:245-252: the flows in reversed order; Flip first, then the mean-only
+    layer's inverse x1 = (x1 - m) * mask, modules.py:456-459)."""
+    half = channels // 2
+    for f in reversed(range(n_flows)):
+        p = f"{pfx}flows.{2 * f}."
+        x = torch.flip(x, [1])
+        x0, x1 = torch.split(x, [half, half], 1)
+        h = F.conv1d(x0, sd[p + "pre.weight"], sd[p + "pre.bias"]) * x_mask
+        h = wn_forward(h, x_mask, sd, p + "enc.", hidden, kernel_size, dilation_rate, n_layers, g)
+        m = F.conv1d(h, sd[p + "post.weight"], sd[p + "post.bias"]) * x_mask
+        x = torch.cat([x0, (x1 - m) * x_mask], 1)
+    return x
+
+
 def kaiser_sinc_filter1d(cutoff, half_width, kernel_size):
     """alias_free_torch/filter.py:28-56."""
     import math
@@ -380,6 +395,40 @@ def synthesizer_forward(sd, cfg, buffers, wav, wav_aug, wav_lengths, y, y_aug, y
     z_slice = torch.gather(z, 2, idx.unsqueeze(1).expand(-1, z.size(1), -1))
     o = generator_forward(sd, cfg, z_slice, ge, pfx="dec.")
     return o, commit_loss, ids_slice, y_mask, (z, z_p, m_p, logs_p, m_q, logs_q), quantized
+
+
+def synthesizer_infer(sd, cfg, buffers, wav, wav_lengths, y, y_lengths, text, text_lengths, noise_p, noise, noise_scale=0.5):
+    """SynthesizerTrn.infer (vq2.py:873-889), eval mode: quantise the posterior of the clip itself, sample the prior with
+    `noise`, run the flow backwards, decode the WHOLE clip.  The two random draws are injected."""
+    from oracle import vq_ref
+    y_mask = seq_mask(y_lengths, y.size(2)).unsqueeze(1).to(y.dtype)
+    ge = mel_style_encoder_forward(sd, "ref_enc.", y * y_mask, y_mask)
+    x, _, _ = posterior_audio_encoder_forward(sd, "enc_p.", y, wav.unsqueeze(1), y_mask, ge, noise_p)
+    x = F.conv1d(x, sd["proj.weight"], sd["proj.bias"], stride=2)
+    quantized, _, _, _ = vq_ref.rvq_forward(x, buffers, False)
+    quantized = F.interpolate(quantized, size=int(quantized.shape[-1] * 2), mode="nearest")
+    _, m_p, logs_p = text_encoder_forward(sd, "enc_p_2.", quantized, y_lengths, text, text_lengths, ge, cfg["n_heads"],
+                                          cfg["n_layers"], cfg["kernel_size"], cfg["inter_channels"])
+    z_p = m_p + noise * torch.exp(logs_p) * noise_scale
+    z = coupling_block_reverse(z_p, y_mask, sd, "flow.", cfg["inter_channels"], cfg["hidden_channels"], 5, 1, 4, 4, ge)
+    return generator_forward(sd, cfg, z, ge, pfx="dec.")
+
+
+def synthesizer_decode(sd, cfg, buffers, codes, text, refer, noise, noise_scale=0.5):
+    """SynthesizerTrn.decode (vq2.py:891-910) as its body intends (it is not runnable as written: undefined `text_legnths` and
+    `y_mask`, and y_lengths taken before the x2 upsampling -- SURVEY App. B): codes (n_q, 1, T) -> codebook rows -> x2 nearest ->
+    enc_p_2 -> sample -> reverse flow -> dec, with the style vector of `refer` (1, spec_channels, Tr)."""
+    refer_mask = torch.ones(1, 1, refer.size(2), dtype=refer.dtype)
+    ge = mel_style_encoder_forward(sd, "ref_enc.", refer * refer_mask, refer_mask)
+    quantized = F.embedding(codes[0], buffers["embed"]).transpose(1, 2)      # n_q = 1: the layer's codebook rows, (1, D, T)
+    quantized = F.interpolate(quantized, size=int(quantized.shape[-1] * 2), mode="nearest")
+    y_lengths = torch.tensor([quantized.size(2)])
+    y_mask = torch.ones(1, 1, quantized.size(2), dtype=refer.dtype)
+    _, m_p, logs_p = text_encoder_forward(sd, "enc_p_2.", quantized, y_lengths, text, torch.tensor([text.size(1)]), ge, cfg["n_heads"],
+                                          cfg["n_layers"], cfg["kernel_size"], cfg["inter_channels"])
+    z_p = m_p + noise * torch.exp(logs_p) * noise_scale
+    z = coupling_block_reverse(z_p, y_mask, sd, "flow.", cfg["inter_channels"], cfg["hidden_channels"], 5, 1, 4, 4, ge)
+    return generator_forward(sd, cfg, z * y_mask, ge, pfx="dec.")
 
 
 # ---- the two-phase GAN step body (ttts/vqvae/train.py:313-406) as loss functions over state dicts --------------------------

@@ -168,7 +168,7 @@ def test_grouped_dw_more_than_64_problems(gpt):
             (lt * 0.01 + lm).backward()
             torch.cuda.synchronize()
             if flag == "1":
-                plans, single, _ln, _cs = model.engine._dw_plan(0, 17)
+                plans, single, _ln, _cs = model.engine._dw_plan(0, 17, True)
                 assert len(plans) >= 2 and max(p_.n for p_ in plans) <= 64 and sum(p_.n for p_ in plans) + len(single) == 70
             grads[flag] = model.engine.grads.clone()
     finally:
@@ -274,7 +274,7 @@ def test_grouped_weight_gradients_equal_the_per_weight_gemms(gpt, monkeypatch):
             eng.backward()
         torch.cuda.synchronize()
         if flag == "1":
-            plans, single, _ln, _cs = eng._dw_plan(0, eng.c["layers"])
+            plans, single, _ln, _cs = eng._dw_plan(0, eng.c["layers"], True)
             _diag("grouped_dw_plan", {"grouped_tiles": sum(p_.tiles for p_ in plans), "grouped_problems": sum(p_.n for p_ in plans),
                                       "split_k_problems": len(single)})
             assert sum(p_.n for p_ in plans) + len(single) == 4 * eng.c["layers"] + 2    # + the two head weight gradients

@@ -554,6 +554,37 @@ def test_full_vqvae_gan_step_matches_reference_fixture(golden_dir):
     np.testing.assert_allclose(cb.embed[:8].cpu().numpy(), g["cb_embed_head"], rtol=1e-4, atol=1e-6)
 
 
+def test_synthesizer_infer_and_decode_match_reference_fixture(golden_dir):
+    """SynthesizerTrn.infer / .decode (vq2.py:873-910; the reverse coupling flow and whole-clip decoding, the two entry points of
+    SURVEY 8(b1)'s surface beyond the training forward) against the reference-generated tests/golden/vqvae_infer.npz."""
+    from ttts_amd.utils.data_utils import spectrogram_torch
+    g, tr, data, inject = _step_setup(golden_dir)
+    gi = np.load(os.path.join(golden_dir, "vqvae_infer.npz"))
+    tr.net_g.eval()
+    h = tr.hps.data
+    spec = spectrogram_torch(data["wav"], h.filter_length, h.hop_length, h.win_length)
+    D = lambda k: torch.from_numpy(gi[k]).to(_dev())
+    o = tr.net_g.infer(data["wav"], data["wav_lengths"], spec, data["wav_lengths"] // h.hop_length, data["text"], data["text_lengths"],
+                       noise_scale=0.5, noise_p=D("noise_p"), noise=D("noise"))
+    assert tuple(o.shape) == (2, 1, 32000)
+    scale = float(np.abs(gi["o_head"]).max())
+    assert float((o[:, :, ::8].cpu() - torch.from_numpy(gi["o_sub8"])).abs().max()) <= 2e-3 * scale
+    assert float((o[:, :, :2048].cpu() - torch.from_numpy(gi["o_head"])).abs().max()) <= 2e-3 * scale
+    np.testing.assert_allclose(float(o.abs().sum()), gi["o_abs_sum"][0], rtol=2e-3)
+    n_text = int(data["text_lengths"][0])
+    od = tr.net_g.decode(D("dec_codes"), data["text"][:1, :n_text], spec[:1], noise_scale=0.5, noise=D("dec_noise"))
+    assert od.shape[-1] == int(gi["dec_len"][0])
+    assert float((od[:, :, :4096].cpu() - torch.from_numpy(gi["dec_o_head"])).abs().max()) <= 2e-3 * float(np.abs(gi["dec_o_head"]).max())
+    np.testing.assert_allclose(float(od.abs().sum()), gi["dec_o_abs_sum"][0], rtol=2e-3)
+    # reverse o forward of the flow is the identity on the masked region (the coupling layers are exactly invertible)
+    y_mask = torch.ones(2, 1, 50, device=_dev())
+    ge = torch.randn(2, 512, 1, device=_dev()) * 0.1
+    z = torch.randn(2, 192, 50, device=_dev())
+    with torch.no_grad():
+        back = tr.net_g.flow(tr.net_g.flow(z, y_mask, g=ge), y_mask, g=ge, reverse=True)
+    assert float((back - z).abs().max()) <= 1e-4 * float(z.abs().max())
+
+
 def test_vqvae_checkpoint_roundtrip(tmp_path, golden_dir):
     from ttts_amd.vqvae.train import latest_checkpoint_path, load_checkpoint
     g, tr, data, inject = _step_setup(golden_dir)

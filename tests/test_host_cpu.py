@@ -423,6 +423,102 @@ def test_flat_data_parallel_gloo_world2(tmp_path):
     assert "rank0-ok" in r.stdout and "rank1-ok" in r.stdout
 
 
+WORKER_N = r"""
+import os, sys, json
+sys.path.insert(0, %r)
+import torch
+import torch.distributed as dist
+from ttts_amd.parallel import FlatDataParallel, init_distributed
+from ttts_amd.gpt.engine import arena_layout, exchange_ranges, param_spec, resolve_config
+rank, world, _ = init_distributed("gloo")
+assert dist.get_world_size() == world and world == int(os.environ["WANT_WORLD"])
+cfg = resolve_config(json.load(open(os.path.join(%r, "ttts_amd", "gpt", "config.json")))["gpt"])
+offsets, n = arena_layout(param_spec(cfg))
+n_small = 20000                                   # the exchange protocol on a prefix-scaled arena (same four-range structure)
+split, first, second = exchange_ranges(offsets, n, cfg["layers"])
+scale = lambda r: tuple(int(v * n_small // n) for v in r)
+first_s, second_s = [scale(r) for r in first], [scale(r) for r in second]
+for bf in (False, True):
+    dp = FlatDataParallel(grad_dtype=torch.bfloat16 if bf else None)
+    assert dp.enabled and dp.world == world
+    params = torch.randn(n_small, generator=torch.Generator().manual_seed(7 + rank))   # ranks start DIFFERENT ...
+    dp.broadcast_(params)                                                            # ... rank 0's state wins
+    seeds = [1234 + r for r in range(world)]                                         # bench.py / Trainer: per-rank data + dropout seeds
+    assert len(set(seeds)) == world
+    for step in range(3):
+        g = torch.Generator().manual_seed(seeds[rank] * 100 + step)
+        grads = (torch.randn(n_small, generator=g) + params * 0.01) * dp.loss_scale()   # a "local gradient" that depends on rank data
+        local = grads.clone()
+        # the engine's schedule: ranges final after backward part 0 go out first, the rest after part 1; all are waited for before the optimizer
+        pending = [dp.allreduce_range_(grads, lo, hi) for lo, hi in first_s]
+        pending += [dp.allreduce_range_(grads, lo, hi) for lo, hi in second_s]
+        for h in pending:
+            if h is not None:
+                h.wait()
+        whole = local.clone()
+        FlatDataParallel().allreduce_grads_(whole)                                   # fp32 single all-reduce of the same data
+        if bf:
+            # every addend is rounded to bf16 (2^-8 relative) and so is every partial sum of the reduction: |error| <= world * 2^-8 * sum_r |g_r| (bf16 unit roundoff 2^-8)
+            absum = local.abs()
+            FlatDataParallel().allreduce_grads_(absum)
+            assert bool(((grads - whole).abs() <= world * 2.0 ** -8 * absum + 1e-7).all()), "bf16 exchange outside its bound"
+        else:
+            # same addends, but a collective sums a chunk in an order that depends on where the chunk sits in its message: bitwise
+            # equal to the whole-arena all-reduce only at world size 2 (one addition); what must hold is fp32-summation noise
+            assert float((grads - whole).abs().max()) <= 4e-7 * float(whole.abs().max()) * world, "ranged exchange differs from the whole-arena all-reduce"
+        params -= 0.1 * grads
+        gathered = [torch.empty_like(params) for _ in range(world)]
+        dist.all_gather(gathered, params)
+        assert all(torch.equal(gathered[0], t) for t in gathered), "replicas diverged (bf16=%%s, step %%d)" %% (bf, step)
+        gl = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(gl, local)
+        assert not torch.equal(gl[0], gl[1]), "ranks drew the same batch"
+assert FlatDataParallel().all_ranks_ok(True) and not FlatDataParallel().all_ranks_ok(rank != world - 1)
+dist.barrier()
+sys.stdout.write("rank" + str(rank) + "-ok\n")
+"""
+
+
+def test_exchange_ranges_tile_the_arena_exactly_once():
+    """GptEngine.grad_exchange_plan (pure host arithmetic, ttts_amd.gpt.engine.exchange_ranges): the four ranges of the overlapped
+    gradient exchange cover every element of the flat arena exactly once, for the shipped model and for other depths."""
+    from ttts_amd.gpt.engine import arena_layout, exchange_ranges, param_spec, resolve_config
+    base = json.load(open(os.path.join(ROOT, "ttts_amd", "gpt", "config.json")))["gpt"]
+    for layers in (base["layers"], 2, 7, 30):
+        cfg = resolve_config(dict(base, layers=layers))
+        offsets, n = arena_layout(param_spec(cfg))
+        for split in (None, 1, layers - 1):
+            sp, first, second = exchange_ranges(offsets, n, layers, split)
+            cover = np.zeros(n, np.int8)
+            for lo, hi in first + second:
+                assert 0 <= lo < hi <= n
+                cover[lo:hi] += 1
+            assert (cover == 1).all(), (layers, split)
+            # what part 0 releases is exactly layers sp .. L-1, ln_f, final_norm and the heads
+            early = np.zeros(n, bool)
+            for lo, hi in first:
+                early[lo:hi] = True
+            for k, o in offsets.items():
+                is_early = (k.startswith("gpt.h.") and int(k.split(".")[2]) >= sp) or k.startswith(("gpt.ln_f", "final_norm", "text_head", "mel_head"))
+                assert bool(early[o]) == is_early, (k, layers, split)
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_ranged_exchange_keeps_replicas_identical_gloo(tmp_path, world):
+    """The data-parallel protocol of the GPT step at world sizes 4 and 8 (gloo, CPU): rank-0 broadcast, per-rank seeds, the four
+    ranged asynchronous all-reduces == one whole-arena all-reduce up to the summation order, replicas bit-identical after 3 steps; the optional
+    bf16 gradient exchange keeps replicas bit-identical too and stays within its rounding bound of the fp32 sum."""
+    script = tmp_path / "worker_n.py"
+    script.write_text(WORKER_N % (ROOT, ROOT))
+    port = str(29000 + (os.getpid() * 7 + world) % 1000)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, WANT_WORLD=str(world), OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
+                        "--master-addr", "127.0.0.1", "--master-port", port, str(script)],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert all(("rank%d-ok" % k) in r.stdout for k in range(world))
+
+
 def test_gpt_collater_and_vq_file_format(tmp_path):
     """ttts/gpt/dataset.py:65-97 semantics: None items filtered, zero right-padding, length tensors; `.vq.pth` holds a plain
     list of ints (ttts/prepare/extract_vq.py:22) that the dataset reads back."""

@@ -245,6 +245,35 @@ def test_synthesizer_forward_restatement(golden_dir):
     np.testing.assert_allclose(buffers["cluster_size"].numpy(), g["cb_cluster_size"], rtol=1e-5)
 
 
+def test_synthesizer_infer_and_decode_restatement(golden_dir):
+    """oracle.vqvae_ref.synthesizer_infer / synthesizer_decode (reverse coupling flow + whole-clip HiFi-GAN decoding) vs the
+    reference's SynthesizerTrn.infer and the intended composition of its .decode (tests/golden/vqvae_infer.npz,
+    tools/make_goldens.py gen_vq_infer): sub-sampled waveform, its head, and the absolute sum."""
+    import json
+    from oracle import mel_ref, vqvae_ref
+    st = np.load(os.path.join(golden_dir, "vqvae_step.npz"))
+    g = np.load(os.path.join(golden_dir, "vqvae_infer.npz"))
+    surf = json.load(open(os.path.join(golden_dir, "surface.json")))
+    cfg = json.loads(str(st["cfg"]))
+    T = torch.from_numpy
+    sd = {k: vqvae_ref.det_fill(k, s, 0.4) for k, s, *_ in surf["vqvae_g"] if not k.startswith("quantizer.") and not k.endswith("filter")}
+    embed = vqvae_ref.det_fill("codebook.embed", (1024, 192)) * 2.0
+    buffers = {"embed": embed.clone(), "embed_avg": embed * 4.0, "cluster_size": torch.full((1024,), 4.0)}
+    wav, wav_lengths = T(st["wav"]), T(st["wav_lengths"])
+    spec = mel_ref.spectrogram(wav, 2048, 640, 2048)
+    with torch.no_grad():
+        o = vqvae_ref.synthesizer_infer(sd, cfg, buffers, wav, wav_lengths, spec, wav_lengths // 640, T(st["text"]), T(st["text_lengths"]),
+                                        T(g["noise_p"]), T(g["noise"]))
+        od = vqvae_ref.synthesizer_decode(sd, cfg, buffers, T(g["dec_codes"]), T(st["text"])[:1, :int(st["text_lengths"][0])], spec[:1],
+                                          T(g["dec_noise"]))
+    scale = np.abs(g["o_head"]).max()
+    assert tuple(o.shape) == (2, 1, 32000) and od.shape[-1] == int(g["dec_len"][0])
+    assert np.abs(o.numpy()[:, :, ::8] - g["o_sub8"]).max() <= 1e-3 * scale and np.abs(o.numpy()[:, :, :2048] - g["o_head"]).max() <= 1e-3 * scale
+    np.testing.assert_allclose(float(o.abs().sum()), g["o_abs_sum"][0], rtol=1e-3)
+    assert np.abs(od.numpy()[:, :, :4096] - g["dec_o_head"]).max() <= 1e-3 * np.abs(g["dec_o_head"]).max()
+    np.testing.assert_allclose(float(od.abs().sum()), g["dec_o_abs_sum"][0], rtol=1e-3)
+
+
 def kmeans_case(g, name):
     seed, N, Kc = (int(v) for v in g[name + ":x_seed_N_K"])
     rng = np.random.default_rng(seed)

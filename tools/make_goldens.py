@@ -605,6 +605,68 @@ def gen_step():
     print("G8 step losses:", rec["losses"], "norms", rec["grad_norms"], "unused g params:", int((g_grad_abs < 0).sum()))
 
 
+def gen_vq_infer():
+    """SynthesizerTrn.infer (vq2.py:873-889) and .decode (:891-910) of the reference on the clips of the G8 fixture, eval mode,
+    injected noise.  `infer` runs as written.  `decode` is not runnable as written (undefined `text_legnths`, `y_mask`; y_lengths
+    taken before the x2 upsampling -- SURVEY App. B): the same reference modules are composed the way its body intends
+    (ref_enc -> quantizer.decode -> x2 nearest -> enc_p_2 -> sample -> reverse flow -> dec) with y_lengths = the upsampled length."""
+    import ttts.vqvae.vq2 as vq2
+    import ttts.utils.commons as commons
+    import ttts.utils.data_utils as du
+    from oracle import vqvae_ref
+    h = STEP_HPS
+    st = np.load(os.path.join(OUT, "vqvae_step.npz"))
+    cfg = json.loads(str(st["cfg"]))
+    torch.manual_seed(0)
+    net_g = vq2.SynthesizerTrn(h["filter_length"] // 2 + 1, h["segment_size"] // h["hop_length"], **cfg)
+    _fill_det(net_g, STEP_GAIN)
+    net_g.eval()
+    cb = net_g.quantizer.vq.layers[0]._codebook
+    with torch.no_grad():
+        cb.inited.fill_(1)
+        cb.embed.copy_(vqvae_ref.det_fill("codebook.embed", cb.embed.shape) * 2.0)
+    wav, wav_lengths = torch.from_numpy(st["wav"]), torch.from_numpy(st["wav_lengths"])
+    text, text_lengths = torch.from_numpy(st["text"]), torch.from_numpy(st["text_lengths"])
+    rng = np.random.default_rng(77)
+    noises = [torch.from_numpy(rng.standard_normal((2, 192, 50)).astype(np.float32)) for _ in range(2)]
+    calls = {"n": 0}
+
+    def fake_randn_like(t_, *a, **k):
+        calls["n"] += 1
+        return noises[calls["n"] - 1]
+    orig = torch.randn_like
+    torch.randn_like = fake_randn_like
+    try:
+        with torch.no_grad():
+            spec = du.spectrogram_torch(wav, h["filter_length"], h["hop_length"], h["win_length"], center=False).squeeze(0)
+            spec_lengths = torch.LongTensor([x // h["hop_length"] for x in wav_lengths])
+            o = net_g.infer(wav, wav_lengths, spec, spec_lengths, text, text_lengths, noise_scale=0.5)
+    finally:
+        torch.randn_like = orig
+    assert calls["n"] == 2
+    # decode: one clip (the reference builds its lengths from single tensors), codes of the first clip's extraction
+    codes = torch.from_numpy(st["latent_codes"])[:1].transpose(0, 1).contiguous()   # (n_q, 1, T): the first clip
+    refer = spec[:1]
+    dn = torch.from_numpy(rng.standard_normal((1, 192, 2 * codes.size(2))).astype(np.float32))
+    with torch.no_grad():
+        refer_lengths = torch.LongTensor([refer.size(2)])
+        refer_mask = torch.unsqueeze(commons.sequence_mask(refer_lengths, refer.size(2)), 1).to(refer.dtype)
+        ge = net_g.ref_enc(refer * refer_mask, refer_mask)
+        quantized = net_g.quantizer.decode(codes)
+        quantized = torch.nn.functional.interpolate(quantized, size=int(quantized.shape[-1] * 2), mode="nearest")
+        y_lengths = torch.LongTensor([quantized.size(2)])
+        y_mask = torch.unsqueeze(commons.sequence_mask(y_lengths, quantized.size(2)), 1).to(refer.dtype)
+        _, m_p, logs_p = net_g.enc_p_2(quantized, y_lengths, text[:1, :int(text_lengths[0])], text_lengths[:1], ge)
+        z_p = m_p + dn * torch.exp(logs_p) * 0.5
+        z = net_g.flow(z_p, y_mask, g=ge, reverse=True)
+        od = net_g.dec(z * y_mask, g=ge)
+    np.savez_compressed(os.path.join(OUT, "vqvae_infer.npz"), noise_p=noises[0].numpy(), noise=noises[1].numpy(),
+                        o_sub8=o.numpy()[:, :, ::8].copy(), o_head=o.numpy()[:, :, :2048],
+                        o_abs_sum=np.array([float(o.abs().sum())]), dec_noise=dn.numpy(), dec_codes=codes.numpy().astype(np.int64),
+                        dec_o_head=od.numpy()[:, :, :4096], dec_o_abs_sum=np.array([float(od.abs().sum())]), dec_len=np.array([od.shape[-1]]))
+    print("vq infer:", tuple(o.shape), float(o.abs().mean()), "decode:", tuple(od.shape), float(od.abs().mean()))
+
+
 def gen_infer():
     """return_latent forward, and greedy decoding through the reference's GPT2InferenceModel.forward
     (kv_cache=False, as api_zh.py:52).  transformers 5.x removed GenerationMixin from PreTrainedModel, so
@@ -848,7 +910,7 @@ def gen_sampler():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gpt", "vq", "mel", "vqvae", "disc", "flow", "attn", "step", "peq", "infer", "diffusion", "sampler"]
+    which = sys.argv[1:] or ["gpt", "vq", "mel", "vqvae", "disc", "flow", "attn", "step", "vqinfer", "peq", "infer", "diffusion", "sampler"]
     with torch.no_grad() if False else torch.enable_grad():
         if "gpt" in which:
             gen_gpt()
@@ -866,6 +928,8 @@ if __name__ == "__main__":
             gen_attn()
         if "step" in which:
             gen_step()
+        if "vqinfer" in which:
+            gen_vq_infer()
         if "peq" in which:
             gen_peq()
         if "infer" in which:

@@ -2,7 +2,7 @@
 """Digest of the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/gpt_step_once.py (tools/gpt_pmc.sh output) into
 profiles/pmc_traffic.json["traffic_bytes_per_launch"]: HBM-side bytes per launch of every GPT kernel family bench.py reports
 (FETCH_SIZE x 2 on gfx950 -- 128-byte read requests are tallied at 64 bytes, MI355X_MICROARCH.md -- plus WRITE_SIZE; rocprofv3
-reports both in KB).   python tools/pmc_digest.py <fetch.txt> <write.txt> <tag>"""
+reports both in KB).   python tools/pmc_digest.py <fetch.txt> <write.txt> <tag> [<sq.txt>]"""
 import json
 import os
 import re
@@ -24,7 +24,7 @@ def read(path, counter):
 
 def family(name):
     epi = {"0": "store_bf16", "1": "gelu", "2": "resid_add", "3": "dgelu", "4": "store_f32"}
-    m = re.search(r"gemm_nt_(?:glds|tall)_kernel<(\d)", name)
+    m = re.search(r"gemm_nt_(?:glds|tall|wreg)_kernel<(\d)", name)
     if m:
         return "gemm_nt_kernel<%s>" % epi[m.group(1)]
     if "gemm_nt_kernel<" in name:
@@ -73,6 +73,16 @@ def main():
     doc["_note"] = ("HBM-side traffic per launch at the BASELINE shape (B 8, H 8, S 1156, d_h 64, dropout on). Units: bytes = (FETCH_SIZE x 2 + "
                     "WRITE_SIZE) x 1024; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B read requests at 64 B). "
                     "Fabric-side counters include Infinity-Cache hits.")
+    if len(sys.argv) > 4:     # the SQ pass of the same script: matrix-core busy fraction of the attention kernels (bench.py: roofline.attention_mfma_busy)
+        busy, gui = read(sys.argv[4], "SQ_VALU_MFMA_BUSY_CYCLES"), read(sys.argv[4], "GRBM_GUI_ACTIVE")
+        ab = {}
+        for k in busy:
+            name = "fwd" if "attn_fwd" in k else "dq" if "attn_bwd_dq" in k else "dkdv" if "attn_bwd_dkdv" in k else None
+            if name and k in gui and "dh64" in k:
+                # SQ_VALU_MFMA_BUSY_CYCLES sums over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs
+                ab[name] = round(busy[k][0] / (gui[k][0] / 8.0 * 1024.0), 4)
+        ab["source"] = "%s: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), rocprofv3 --pmc over tools/gpt_step_once.py (BASELINE shape, dropout 0.1)" % tag
+        doc["attention_mfma_busy"] = ab
     json.dump(doc, open(path, "w"), indent=1)
     print(json.dumps(traffic, indent=1))
 

@@ -536,10 +536,13 @@ extern "C" int ttts_vq_ema_update_f32(const float* x, const int64_t* idx, float*
   TTTS_REQUIRE(x && idx && cluster_size && embed_avg && embed && workspace, "vq_ema: null pointer");
   TTTS_REQUIRE(N > 0 && K > 0 && D > 0 && D % 4 == 0, "vq_ema: need D %% 4 == 0");
   hipStream_t s = as_stream(stream);
-  if (D <= 256 && (int64_t)K + N <= 15 * 1024) {   // one pass, no global atomics, no zero fill (+ the cluster-size commit); 60 KB LDS
+  // one pass, no global atomics, no zero fill (+ the cluster-size commit) when its dynamic LDS -- the histogram and the index /
+  // accumulator area, sized by whichever of the two is larger -- fits the 64 KB a kernel gets without an opt-in (+ 32 B static)
+  const size_t fused_lds = ((size_t)K + std::max<size_t>((size_t)N + 256, (size_t)4 * EMA_CODES * 256)) * sizeof(int);
+  if (D <= 256 && fused_lds + 32 <= 64 * 1024) {
     float* cs_new = reinterpret_cast<float*>(workspace);
-    vq_ema_fused_kernel<<<(int)cdiv(K, EMA_CODES), 256, ((size_t)K + std::max(N + 256, 4 * EMA_CODES * 256)) * sizeof(int), s>>>(x, idx, cluster_size, embed_avg, embed, cs_new,
-                                                                                   N, K, D, decay, epsilon);
+    vq_ema_fused_kernel<<<(int)cdiv(K, EMA_CODES), 256, fused_lds, s>>>(x, idx, cluster_size, embed_avg, embed, cs_new,
+                                                                         N, K, D, decay, epsilon);
     int rc0 = check_launch("vq_ema_fused");
     if (rc0) return rc0;
     vq_ema_commit_kernel<<<(int)cdiv(K, 256), 256, 0, s>>>(cluster_size, cs_new, K);

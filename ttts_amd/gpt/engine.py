@@ -72,6 +72,27 @@ def _up(x, m):
     return (x + m - 1) // m * m
 
 
+def arena_layout(spec):
+    """({key: element offset}, total elements) of the flat parameter / gradient arena: state-dict order, every tensor on an
+    8-element granule (fp32 float4 and bf16 16-byte alignment).  Pure host arithmetic (CPU tests restate nothing)."""
+    offsets, off = {}, 0
+    for k, shp in spec:
+        offsets[k] = off
+        off += _up(math.prod(shp), 8)
+    return offsets, off
+
+
+def exchange_ranges(offsets, n_arena, layers, split=None):
+    """Element ranges of the flat gradient arena that are final after backward part 0 / part 1 (GptEngine.backward):
+    (split, [(lo, hi), ...] ready after the heads + layers L-1 .. split, [(lo, hi), ...] ready at the end).  The arena is in
+    state-dict order: embeddings, h.0 .. h.L-1, ln_f, position tables, final_norm, heads -- so each group is contiguous, and
+    the four ranges tile [0, n_arena) exactly once (tests/test_host_cpu.py)."""
+    split = layers // 2 if split is None else split
+    h_split = offsets["gpt.h.%d.ln_1.weight" % split]
+    pos0, fin0 = offsets["mel_pos_embedding.emb.weight"], offsets["final_norm.weight"]
+    return split, [(h_split, pos0), (fin0, n_arena)], [(0, h_split), (pos0, fin0)]
+
+
 def left_out_problems(tiles, slots):
     """Which problems of a grouped dW launch go to the split-K kernel instead (GptEngine._dw_plan): tiles[j] = 128 x 128 output
     tiles of problem j, slots = resident workgroups (2 per CU).  A total just above a multiple of `slots` would cost a whole,
@@ -115,11 +136,7 @@ class GptEngine:
         # graph-replay safe); handed to every dropout-capable kernel call -- the library holds no state of its own
         self.spec = param_spec(self.c)
         self.shapes = dict(self.spec)
-        self.offsets = {}
-        off = 0
-        for k, shp in self.spec:
-            self.offsets[k] = off
-            off += _up(math.prod(shp), 8)   # 8-element granule: fp32 float4 and bf16 16-byte alignment
+        self.offsets, off = arena_layout(self.spec)
         self.n_arena = off
         dev = self.device
         self.params = torch.zeros(off, dtype=torch.float32, device=dev)
@@ -154,6 +171,9 @@ class GptEngine:
         self._bufs_key = None
         self._graph = None
         self._graph_key = None
+        # buffers / descriptor tables / captured graphs of the last few batch shapes (see _ensure_buffers)
+        self._shape_cache = collections.OrderedDict()
+        self._capture_error = None   # one line on why a hipGraph capture was refused (bench.py reports it), else None
 
     # ---- parameter plumbing -------------------------------------------------------------------------------
     def view(self, arena, key):
@@ -192,8 +212,13 @@ class GptEngine:
         # Real batches change shape from step to step (the reference clips every batch to its own longest text / clip): the
         # buffers, grouped-launch descriptor tables and captured graphs of the last few shapes are kept (TTTS_SHAPE_CACHE, default
         # 4 shapes: 288 GB of HBM is the budget this is sized for), so a shape that comes back costs neither allocations nor the
-        # synchronous descriptor uploads nor a re-capture.
-        cache = self.__dict__.setdefault("_shape_cache", collections.OrderedDict())
+        # synchronous descriptor uploads nor a re-capture.  Each cached shape holds a full activation set (~3.4 GB at B 8 x S 1156):
+        # the cache multiplies activation memory by up to TTTS_SHAPE_CACHE + 1.  It pays for data sources with a few recurring shapes
+        # (fixed-length crops, the benchmark); the reference clips every batch to its own longest text / clip, and rounding those
+        # lengths up to buckets is NOT done here: the padded positions are STOP targets that the reference's loss mean counts
+        # (model.py:508-509 has no ignore_index), so bucketing would change the loss.  Such a run re-allocates per new shape and
+        # runs launch by launch (gpt/train.py passes capture=False).
+        cache = self._shape_cache
         if self._bufs_key is not None:
             cache[self._bufs_key] = (self.b, self._Mp, self._dw_plans, self._graph, self._graph_key)
             cache.move_to_end(self._bufs_key)
@@ -266,24 +291,26 @@ class GptEngine:
         self._dw_plans = {}
         if self.grouped_dw:   # descriptor tables are built here, outside any graph capture (they upload a small table)
             split = L // 2
-            for lo, hi in {(0, L), (split, L), (0, split)}:
+            for lo, hi, heads in {(0, L, True), (split, L, True), (0, split, False)}:
                 if hi > lo:
-                    self._dw_plan(lo, hi)
+                    self._dw_plan(lo, hi, heads)
 
     def _nt(self, a, w, c, *args, **kw):
         return ops.gemm_nt(a, w, c, *args, **kw)
 
-    def _dw_plan(self, lo, hi):
-        """Grouped dW launch for layers lo .. hi-1: (TnPlan | None, [problems left to the split-K path]).
+    def _dw_plan(self, lo, hi, heads):
+        """Grouped dW launch for layers lo .. hi-1 (+ the two heads and the final norms when `heads`: the backward section that
+        ran _backward_head): (TnPlan | None, [problems left to the split-K path]).
         A problem = (at, bt, grad view).  The grouped kernel gives every 128 x 128 output tile of every problem to one
         workgroup; with 2 workgroups per CU resident, a tile count just above a multiple of 2 x CUs would cost a whole
         extra, mostly empty round (1152 tiles on 512 slots: 2.25 -> 3 rounds).  So the smallest set of problems that
         covers the remainder is taken out and run through the split-K kernel instead."""
-        key = (lo, hi)
+        key = (lo, hi, bool(heads))
         if key in self._dw_plans:
             return self._dw_plans[key]
         if torch.cuda.is_current_stream_capturing():
-            raise TttsError("grouped dW plan for layers %d..%d must be built before graph capture" % (lo, hi))
+            raise TttsError("grouped dW plan for layers %d..%d must be built before graph capture (only split = layers // 2 "
+                            "is prepared by _ensure_buffers)" % (lo, hi))
         b = self.b
         G = lambda k: self.view(self.grads, k)   # noqa: E731
         P_ = self._padded
@@ -294,7 +321,7 @@ class GptEngine:
                       (P_(b["fc_act"][i]), P_(b["dy_mlp"][i]), G(pre + "mlp.c_proj.weight")),
                       (P_(b["ln1"][i]), P_(b["dqkv_l"][i]), G(pre + "attn.c_attn.weight")),
                       (P_(b["att"][i]), P_(b["dy_att"][i]), G(pre + "attn.c_proj.weight"))]
-        if hi == self.c["layers"]:        # the two head weight gradients (reduction over the text / mel rows of the split layout)
+        if heads:                         # the two head weight gradients (reduction over the text / mel rows of the split layout)
             rows64 = lambda t, r: torch.as_strided(t, (_up(r, 64), t.shape[1]), t.stride(), t.storage_offset())   # noqa: E731
             Bt_, Tt_, Tm_ = self._bufs_key
             nt_rows, nm_rows = Bt_ * Tt_, Bt_ * Tm_
@@ -314,7 +341,7 @@ class GptEngine:
         # gradients that are plain column sums of a kept dY buffer
         L = self.c["layers"]
         ln, cs = [], []
-        if hi == L:
+        if heads:
             ln += [(b["ln_ws_l"][2 * L], G("final_norm.weight"), G("final_norm.bias"), None),
                    (b["ln_ws_l"][2 * L + 1], G("gpt.ln_f.weight"), G("gpt.ln_f.bias"), G("gpt.h.%d.mlp.c_proj.bias" % (L - 1)))]
             cs += [(b["dlog_t"], G("text_head.bias"), self.nt), (b["dlog_m"], G("mel_head.bias"), self.nm)]
@@ -335,8 +362,8 @@ class GptEngine:
         self._dw_plans[key] = (plans, single, ln_plan, cs_plans)
         return self._dw_plans[key]
 
-    def _run_dw(self, lo, hi):
-        plans, single, ln_plan, cs_plans = self._dw_plan(lo, hi)
+    def _run_dw(self, lo, hi, heads):
+        plans, single, ln_plan, cs_plans = self._dw_plan(lo, hi, heads)
         for plan in plans:
             plan.run()
         for at, bt, g in single:
@@ -446,6 +473,8 @@ class GptEngine:
         # reuse of the scratch buffers (dres_bf, d_fc, dqkv) between the two streams; both streams are captured in the graph.
         main = torch.cuda.current_stream()
         side = self._side_stream() if (self.overlap_dw and part is None and not self.grouped_dw) else main
+        if part is not None and not 0 < split < L:
+            raise ValueError("backward(part=%r): split must lie strictly inside the layer range (got %r of %d layers)" % (part, split, L))
         lo_layer = 0 if part in (None, 1) else split
         hi_layer = L if part in (None, 0) else split
 
@@ -470,7 +499,7 @@ class GptEngine:
         for i in reversed(range(lo_layer, hi_layer)):
             ev_fc, ev_qkv = self._backward_layer(i, side, fork, done, wait, ev_fc, ev_qkv)
         if self.grouped_dw and (hi_layer > lo_layer or part in (None, 0)):
-            self._run_dw(lo_layer, hi_layer)
+            self._run_dw(lo_layer, hi_layer, part in (None, 0))   # the head / final-norm gradients belong to the section that ran _backward_head
         if part in (None, 1):
             ops.embed_bwd(b["text_inp"], b["mel_inp"], b["dres"], G("text_embedding.weight"),
                           G("text_pos_embedding.emb.weight"), G("mel_embedding.weight"), G("mel_pos_embedding.emb.weight"),
@@ -619,12 +648,7 @@ class GptEngine:
         """Element ranges of the flat gradient arena that are final after backward part 0 / part 1 (see `backward`):
         ([(lo, hi), ...] ready after the heads + layers L-1 .. split, [(lo, hi), ...] ready at the end).  The arena is in
         state-dict order: embeddings, h.0 .. h.L-1, ln_f, position tables, final_norm, heads."""
-        L = self.c["layers"]
-        split = L // 2 if split is None else split
-        o = self.offsets
-        h_split = o["gpt.h.%d.ln_1.weight" % split]
-        pos0, fin0 = o["mel_pos_embedding.emb.weight"], o["final_norm.weight"]
-        return split, [(h_split, pos0), (fin0, self.n_arena)], [(0, h_split), (pos0, fin0)]
+        return exchange_ranges(self.offsets, self.n_arena, self.c["layers"], split)
 
     def train_step(self, tokens, w_text=0.01, w_mel=1.0, capture=False, exchange=None, exchange_range=None, **opt):
         """tokens = (text_inp, text_tar, mel_inp, mel_tar) int64 tensors (see model.prepare_tokens).
@@ -711,8 +735,8 @@ class GptEngine:
                     record(lambda: self.optimizer_step(**opt)))
         except RuntimeError as err:
             import sys
-            print("ttts_amd: hipGraph capture of the train step failed (%s); running it eagerly" % str(err).splitlines()[0],
-                  file=sys.stderr, flush=True)
+            self._capture_error = "hipGraph capture refused (%s): the step runs launch by launch, collectives eager" % str(err).splitlines()[0][:160]
+            print("ttts_amd: " + self._capture_error, file=sys.stderr, flush=True)
             torch.cuda.synchronize()
             self.grads.zero_()     # a partially recorded step leaves nothing behind, but be explicit
             return (None, None)

@@ -122,6 +122,7 @@ class TnPlan:
         self.n, self.tiles = len(entries), int(total.value)
         self.tile_counts = [int(_l.get().ttts_tn_desc_tiles(at.shape[1], bt.shape[1])) for at, bt, _ in entries]
         self.flops = float(sum(2.0 * at.shape[0] * at.shape[1] * bt.shape[1] for at, bt, _ in entries))   # algorithmic, per launch
+        self.bytes = float(sum(2.0 * at.shape[0] * (at.shape[1] + bt.shape[1]) + 8.0 * at.shape[1] * bt.shape[1] for at, bt, _ in entries))   # operands once, C read + written
         self._keep = entries
 
     def run(self):

@@ -588,7 +588,7 @@ class Flip(nn.Module):
 
 
 class ResidualCouplingLayer(nn.Module):
-    """modules.ResidualCouplingLayer (modules.py:403-459), forward direction; `mean_only=True` on the path."""
+    """modules.ResidualCouplingLayer (modules.py:403-459), both directions; `mean_only=True` on the path."""
 
     def __init__(self, channels, hidden_channels, kernel_size, dilation_rate, n_layers, p_dropout=0, gin_channels=0,
                  mean_only=False):
@@ -606,11 +606,17 @@ class ResidualCouplingLayer(nn.Module):
             self.post.bias.zero_()
 
     def forward(self, x, x_mask, g=None, reverse=False):
-        if reverse:
-            raise NotImplementedError("reverse flow (inference) is not on the training path")
         x0, x1 = torch.split(x, [self.half_channels] * 2, 1)
         h = self.pre(x0.contiguous(), omask=x_mask)
         h = self.enc(h, x_mask, g=g)
+        if reverse:
+            # inference direction (modules.py:456-459, logs = 0): x1 <- (x1 - m) * mask with m = post(h) * mask -- the subtraction is
+            # the convolution's own epilogue: y = x1 * mask, then y += -1 * (bias + conv(h)) * mask.  No autograd (infer / decode).
+            from .. import ops
+            y = mul_mask(x1.contiguous(), x_mask).contiguous()
+            ops.conv1d_fwd(h.detach(), self.post.effective_weight().detach(), self.post.bias.detach(), pad=self.post.padding, out_scale=-1.0,
+                           out=y, accumulate=True, omask=x_mask)
+            return torch.cat([x0, y], 1)
         x1 = self.post(h, resid=x1.contiguous(), omask=x_mask)      # m + x1 * mask  (logs = 0)
         x = torch.cat([x0, x1], 1)
         return x, torch.zeros(x.size(0), dtype=x.dtype, device=x.device)

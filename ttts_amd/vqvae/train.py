@@ -267,11 +267,25 @@ class VqvaeTrainer:
                     ctx[0] = torch.cuda.graph(segs[-1], pool=segs[0].pool())
                     ctx[0].__enter__()
                 self.step_fn._sync_buffers()
-                ctx[0].__enter__()
+                ok, err = 1, None
                 try:
-                    out = self.train_step(inputs, cut=cut, sync_buffers=False)
-                finally:
-                    ctx[0].__exit__(None, None, None)
+                    ctx[0].__enter__()
+                    try:
+                        out = self.train_step(inputs, cut=cut, sync_buffers=False)
+                    finally:
+                        ctx[0].__exit__(None, None, None)
+                except Exception as e:                       # noqa: BLE001 -- this rank's capture was refused
+                    ok, err = 0, e
+                    torch.cuda.synchronize()
+                    arenas = [self.optim_d.flat_g, self.optim_g.flat_g]
+                    while len(between) < 2:                  # keep the collective sequence aligned with the ranks that succeeded:
+                        self.dp.allreduce_grads_(arenas[len(between)])   # the cuts not reached issue their all-reduce here (the
+                        between.append(None)                 # sums are discarded: every rank then zeroes its gradients and runs eagerly)
+                    self.optim_d.flat_g.zero_(); self.optim_g.flat_g.zero_()
+                # the segments are only usable if EVERY rank recorded them: a rank that fell back to the eager step while its
+                # peers replay three graphs would issue a different collective sequence
+                if not self.dp.all_ranks_ok(ok):
+                    raise RuntimeError("capture refused on %s" % ("this rank: %s" % err if err is not None else "another rank"))
                 return {"key": key, "graph": segs[0], "segments": segs, "between": between, "inputs": inputs, "out": out}
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):

@@ -114,7 +114,7 @@ class MultiPeriodDiscriminator(nn.Module):
 
 
 class ResidualCouplingBlock(nn.Module):
-    """vq2.py:208-252: n_flows x (mean-only ResidualCouplingLayer, Flip), forward direction."""
+    """vq2.py:208-252: n_flows x (mean-only ResidualCouplingLayer, Flip), forward and reverse direction."""
 
     def __init__(self, channels, hidden_channels, kernel_size, dilation_rate, n_layers, n_flows=4, gin_channels=0):
         super().__init__()
@@ -127,8 +127,10 @@ class ResidualCouplingBlock(nn.Module):
             self.flows.append(modules.Flip())
 
     def forward(self, x, x_mask, g=None, reverse=False):
-        if reverse:
-            raise NotImplementedError("reverse flow (inference) is not on the training path")
+        if reverse:                                        # vq2.py:249-251
+            for flow in reversed(self.flows):
+                x = flow(x, x_mask, g=g, reverse=True)
+            return x
         for flow in self.flows:
             x, _ = flow(x, x_mask, g=g, reverse=reverse)
         return x
@@ -269,6 +271,13 @@ def rand_slice_segments(x, x_lengths=None, segment_size=4, ids_str=None):
     return slice_segments(x, ids_str, segment_size), ids_str
 
 
+def _prior_sample(m_p, logs_p, noise, noise_scale):
+    """z_p = m_p + randn * exp(logs_p) * noise_scale (vq2.py:886,903), the reparameterised-sample kernel of the training path."""
+    from .. import ops
+    eps = torch.randn_like(m_p) if noise is None else noise
+    return ops.gauss_sample_fwd(torch.cat([m_p, logs_p], 1), eps * noise_scale, None)
+
+
 class SynthesizerTrn(nn.Module):
     """Synthesizer for training (vq2.py:750-871): same constructor, `forward(wav, wav_aug, wav_lengths, y, y_aug,
     y_lengths, text, text_lengths)` and 6-tuple return.  Extra keyword-only hooks `noise_p`, `noise_q`, `ids_slice`
@@ -309,6 +318,39 @@ class SynthesizerTrn(nn.Module):
         z_slice, ids_slice = rand_slice_segments(z, y_lengths, self.segment_size, ids_slice)
         o = self.dec(z_slice, g=ge)
         return o, commit_loss, ids_slice, y_mask, (z, z_p, m_p, logs_p, m_q, logs_q), quantized
+
+    @torch.no_grad()
+    def infer(self, wav, wav_lengths, y, y_lengths, text, text_lengths, noise_scale=0.5, *, noise_p=None, noise=None):
+        """vq2.py:873-889: re-synthesis of a clip from its own codes -- posterior -> codebook -> text encoder prior -> sample ->
+        REVERSE flow -> decoder over the whole clip.  `noise_p` / `noise` inject the two randn draws (parity tests)."""
+        y_mask = torch.unsqueeze(sequence_mask(y_lengths, y.size(2)), 1).to(y.dtype)
+        ge = self.ref_enc(modules.mul_mask(y, y_mask), y_mask)
+        x, _, _ = self.enc_p(y, wav.unsqueeze(1), y_mask, g=ge, noise=noise_p)
+        x = self.proj(x)
+        quantized, codes, commit_loss, quantized_list = self.quantizer(x, layers=[0])
+        quantized = modules.upsample_nearest2(quantized)
+        x, m_p, logs_p = self.enc_p_2(quantized, y_lengths, text, text_lengths, ge)
+        z_p = _prior_sample(m_p, logs_p, noise, noise_scale)
+        z = self.flow(z_p, y_mask, g=ge, reverse=True)
+        return self.dec(z, g=ge)
+
+    @torch.no_grad()
+    def decode(self, codes, text, refer, noise_scale=0.5, *, noise=None):
+        """vq2.py:891-910 as its body intends: codes (n_q, 1, T) + text (1, Tt) + a reference spectrogram (1, spec_channels, Tr)
+        for the style vector -> waveform (1, 1, 2 T hop).  The reference body is not runnable as written (undefined
+        `text_legnths` / `y_mask`, and `y_lengths` taken before the x2 upsampling: SURVEY.md App. B); here the lengths are those
+        of the upsampled code sequence and the mask is all ones, which is what a single un-padded item means."""
+        refer_lengths = torch.tensor([refer.size(2)], dtype=torch.long, device=refer.device)
+        text_lengths = torch.tensor([text.size(1)], dtype=torch.long, device=text.device)
+        refer_mask = torch.unsqueeze(sequence_mask(refer_lengths, refer.size(2)), 1).to(refer.dtype)
+        ge = self.ref_enc(modules.mul_mask(refer, refer_mask), refer_mask)
+        quantized = modules.upsample_nearest2(self.quantizer.decode(codes))
+        y_lengths = torch.tensor([quantized.size(2)], dtype=torch.long, device=codes.device)
+        y_mask = torch.unsqueeze(sequence_mask(y_lengths, quantized.size(2)), 1).to(refer.dtype)
+        x, m_p, logs_p = self.enc_p_2(quantized, y_lengths, text, text_lengths, ge)
+        z_p = _prior_sample(m_p, logs_p, noise, noise_scale)
+        z = self.flow(z_p, y_mask, g=ge, reverse=True)
+        return self.dec(modules.mul_mask(z, y_mask), g=ge)
 
     @torch.no_grad()
     def extract_latent(self, wav, y, y_lengths=None):
