@@ -237,6 +237,110 @@ __global__ __launch_bounds__(256) void vq_nearest_slice_kernel(const float* __re
   }
 }
 
+// ---- nearest code, third generation (round 4; D in {64, 128, 192}) -----------------------------------------------------------
+// What held the slice kernel at 38 us (27 % of the exact-f32 matrix-core rate) was not the MFMA chain but how its operands
+// arrived: every lane fetched ITS code row with 16-byte global loads -- 32 rows x 16 B per wave instruction, i.e. 32 cache-line
+// requests for 512 useful bytes, 6 M line requests per launch: the L2 request rate, not its bandwidth (the same thing cost the
+// register-resident GEMM's weight load 8 us: csrc/gemm.hip).  Here nothing is loaded in fragment shape:
+//   * a workgroup = 128 x rows (one 32-row block per wave) x 128 codes (four 32-code tiles); grid (N / 128) x (K / 128) = 256
+//     workgroups at the BASELINE search, one per CU, one wave per SIMD;
+//   * x blocks and code tiles (32 rows x D floats = one "tile image") come in by LDS-DMA, whole rows, 16-byte chunk c of row r
+//     at chunk (c & ~15) | ((c & 15) ^ (r & 15)): the ds_read_b128 of 16 lanes = 16 rows then hits 16 distinct slots;
+//   * a wave reads its x block ONCE into registers (D / 2 per lane: the B operand of every MFMA it will issue) and its |x|^2;
+//   * the four code tiles are read by all four waves; per 16-byte chunk one ds_read_b128 feeds two MFMAs and the |e|^2 chain;
+//     the chunks are fetched four ahead of the MFMA chain, which is then never waited for (one dependent chain IS the pipe rate:
+//     tools/ubench/mfma_f32.hip);
+//   * the arg-max runs in registers across the four tiles; (best, index) per (row, slice) go to the same merge kernel.
+// Per (row, code) pair the arithmetic is unchanged -- one k-ordered fmaf chain on v_mfma_f32_32x32x2_f32, |e|^2 and |x|^2 as
+// k-ordered fmaf chains, -((|x|^2 - 2 dot) + |e|^2) in that order -- so indices AND distances stay bit-exact.
+constexpr int VQ3_ROWS = 128, VQ3_SLICE = 128;
+template <int D4>   // D / 4: 16-byte chunks per row
+__global__ __launch_bounds__(256, 1) void vq_nearest_tile_kernel(const float* __restrict__ x, const float* __restrict__ cb,
+                                                                 float2* __restrict__ part, int N, int K, int SL) {
+  constexpr int D = 4 * D4, TILE_B = 32 * D * 4, NDMA = D4 / 2;   // DMA instructions (1 KB) per tile image
+  extern __shared__ __attribute__((aligned(16))) unsigned char vq3_smem[];   // region A: 4 tile images (x blocks, then code tiles 2, 3) | region B: code tiles 0, 1
+  const uint32_t lds0 = lds_byte_addr(vq3_smem);
+  const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, rl = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r0 = blockIdx.x * VQ3_ROWS, sl = blockIdx.y, c0 = sl * VQ3_SLICE;
+  // one tile image: 32 rows of `src` starting at row0 (clamped to row_max) -> LDS at `dst`; the workgroup's 4 waves share the NDMA pieces
+  auto dma_tile = [&](const float* src, int row0, int row_max, uint32_t dst) {
+    for (int i = wave; i < NDMA; i += 4) {
+      const int L = 64 * i + lane, row = L / D4, pc = L % D4;
+      const int c = (pc & ~15) | ((pc & 15) ^ (row & 15));
+      lds_dma16_untracked(src + (int64_t)min(row0 + row, row_max) * D + c * 4, lds0 + dst + i * 1024);
+    }
+  };
+  for (int b = 0; b < 4; ++b) dma_tile(x, r0 + 32 * b, N - 1, b * TILE_B);
+  for (int t = 0; t < 2; ++t) dma_tile(cb, c0 + 32 * t, K - 1, (4 + t) * TILE_B);
+  constexpr int PPW = NDMA / 4;                      // pieces per wave and image (NDMA is a multiple of 4 for D = 64, 128, 192)
+  static_assert(NDMA % 4 == 0, "pieces are dealt evenly to the four waves");
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PPW) : "memory");   // the x blocks have landed; the two code tiles may still be in flight
+  __syncthreads();
+  // chunk c of row rl of a tile image
+  auto chunk = [&](uint32_t img, int c) {
+    return *reinterpret_cast<const float4*>(vq3_smem + img + rl * (D * 4) + (((c & ~15) | ((c & 15) ^ (rl & 15))) << 4));
+  };
+  float xr[2 * D4];
+  float x2 = 0.f;
+#pragma unroll
+  for (int c = 0; c < D4; ++c) {
+    const float4 v = chunk(wave * TILE_B, c);
+    x2 = fmaf(v.x, v.x, x2); x2 = fmaf(v.y, v.y, x2); x2 = fmaf(v.z, v.z, x2); x2 = fmaf(v.w, v.w, x2);
+    xr[2 * c] = hh ? v.y : v.x;
+    xr[2 * c + 1] = hh ? v.w : v.z;
+  }
+  lds_dma_wait_all();                                // code tiles 0, 1 (issued before the x reads)
+  __syncthreads();                                   // every wave holds its x block: region A is free; tiles 0, 1 are published
+  for (int t = 2; t < 4; ++t) dma_tile(cb, c0 + 32 * t, K - 1, (t - 2) * TILE_B);
+  float best = -INFINITY;
+  int best_i = 0;
+#pragma unroll 1
+  for (int t = 0; t < 4; ++t) {
+    const int cw = c0 + 32 * t;
+    if (cw >= K) break;                              // (workgroup-uniform)
+    if (t == 2) {                                    // tiles 2, 3 have had two tiles of MFMAs to land
+      lds_dma_wait_all();
+      __syncthreads();
+    }
+    const uint32_t img = (t < 2 ? 4 + t : t - 2) * TILE_B;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float e2 = 0.f;                                  // |e|^2 of this lane's code (both lane halves run the same chain)
+    float4 pf[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) pf[c] = chunk(img, c);
+#pragma unroll
+    for (int c = 0; c < D4; ++c) {
+      const float4 v = pf[c & 3];
+      if (c + 4 < D4) pf[c & 3] = chunk(img, c + 4);
+      __builtin_amdgcn_sched_barrier(0);
+      e2 = fmaf(v.x, v.x, e2); e2 = fmaf(v.y, v.y, e2); e2 = fmaf(v.z, v.z, e2); e2 = fmaf(v.w, v.w, e2);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hh ? v.y : v.x, xr[2 * c], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hh ? v.w : v.z, xr[2 * c + 1], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int cl = acc_row(r, hh);                 // code inside the tile: its |e|^2 lives in lane cl (either half)
+      const float e2c = __shfl(e2, cl, 64);
+      const int code = cw + cl;
+      if (code < K) {
+        const float dist = -((x2 - 2.0f * acc[r]) + e2c);
+        if (dist > best) { best = dist; best_i = code; }
+      }
+    }
+  }
+  {
+    const float od = __shfl_xor(best, 32, 64);
+    const int oi = __shfl_xor(best_i, 32, 64);
+    if (od > best || (od == best && oi < best_i)) { best = od; best_i = oi; }
+  }
+  const int row = r0 + wave * 32 + rl;
+  if (lane < 32 && row < N) part[(int64_t)row * SL + sl] = make_float2(best, __int_as_float(best_i));
+}
+
 __global__ __launch_bounds__(256) void vq_nearest_final_kernel(const float2* __restrict__ part, const float* __restrict__ cb,
                                                                int64_t* __restrict__ idx, float* __restrict__ xq,
                                                                float* __restrict__ best_dist, int N, int D, int SL) {
@@ -479,7 +583,7 @@ using namespace ttts;
 
 extern "C" int64_t ttts_vq_workspace_bytes(int32_t N, int32_t K) {
   // code norms (generic kernel) / commitment partials, then the (distance, index) pairs of the sliced search
-  return cdiv(K, 4) * 16 + 1024 * (int64_t)sizeof(double) + (int64_t)N * cdiv(K, VQ_SLICE) * (int64_t)sizeof(float2);
+  return cdiv(K, 4) * 16 + 1024 * (int64_t)sizeof(double) + (int64_t)N * cdiv(K, VQ3_SLICE) * (int64_t)sizeof(float2);   // (the finer of the two slicings)
 }
 
 extern "C" int ttts_vq_nearest_f32(const float* x, const float* codebook, int64_t* idx, float* xq, float* best_dist,
@@ -494,6 +598,27 @@ extern "C" int ttts_vq_nearest_f32(const float* x, const float* codebook, int64_
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }();
   if (attr != hipSuccess) return fail(TTTS_EHIP, "vq_nearest: hipFuncSetAttribute: %s", hipGetErrorString(attr));
+  if ((D == 64 || D == 128 || D == 192) && aligned16(x) && aligned16(codebook) && (!xq || aligned16(xq))) {
+    const int SL = (int)cdiv(K, VQ3_SLICE);
+    float2* part = reinterpret_cast<float2*>(static_cast<char*>(workspace) + cdiv(K, 4) * 16 + 1024 * sizeof(double));
+    const dim3 grid((unsigned)cdiv(N, VQ3_ROWS), (unsigned)SL);
+    const size_t lds = (size_t)6 * 32 * D * 4;       // six tile images: 144 KB at D = 192
+    hipError_t e = hipSuccess;
+#define VQ3_LAUNCH(D4_)                                                                                                          \
+    do {                                                                                                                          \
+      static const hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void*>(vq_nearest_tile_kernel<D4_>),                 \
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 32 * 4 * D4_ * 4);         \
+      e = a;                                                                                                                      \
+      if (e == hipSuccess) vq_nearest_tile_kernel<D4_><<<grid, 256, lds, s>>>(x, codebook, part, N, K, SL);                      \
+    } while (0)
+    if (D == 64) VQ3_LAUNCH(16); else if (D == 128) VQ3_LAUNCH(32); else VQ3_LAUNCH(48);   // (D = 256: six images would need 192 KB of LDS)
+#undef VQ3_LAUNCH
+    if (e != hipSuccess) return fail(TTTS_EHIP, "vq_nearest: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    int rc = check_launch("vq_nearest_tile");
+    if (rc) return rc;
+    vq_nearest_final_kernel<<<(int)cdiv(N, VQ_ROWS), 256, 0, s>>>(part, codebook, idx, xq, best_dist, N, D, SL);
+    return check_launch("vq_nearest_final");
+  }
   if (D % 4 == 0 && aligned16(x) && aligned16(codebook) && (!xq || aligned16(xq))) {
     const int SL = (int)cdiv(K, VQ_SLICE);
     float2* part = reinterpret_cast<float2*>(static_cast<char*>(workspace) + cdiv(K, 4) * 16 + 1024 * sizeof(double));
