@@ -34,7 +34,7 @@ extern "C" {
 #define TTTS_EHIP (-2)         /* a HIP runtime call or kernel launch failed */
 #define TTTS_EUNSUPPORTED (-3) /* valid request this build has no kernel for */
 
-#define TTTS_ABI_VERSION 6
+#define TTTS_ABI_VERSION 7
 
 /* ---- library ------------------------------------------------------------------------------------ */
 int ttts_abi_version(void);
@@ -73,6 +73,17 @@ int ttts_gemm_nt_bf16_ex(const void* A, int64_t lda, const void* B, int64_t ldb,
                          const float* bias, void* aux, int32_t M, int32_t N, int32_t K, int32_t epilogue,
                          const float* resid_in, float dropout_p, uint64_t seed, const uint32_t* dropout_counter,
                          float* colsum, void* stream);
+/* The residual GEMM AND the LayerNorm that consumes its output, one launch (ABI v7; N = 512 = whole rows of the GPT model width):
+ *   x_out[M,N] = resid_in + dropout(bf16(A[M,K] . B[N,K]^T + bias))        (resid_in NULL: x_out += ..., as RESID_ADD_F32)
+ *   y[M,N]     = LayerNorm(x_out; gamma, beta, eps)   (bf16 or f32),  mean[M], rstd[M]
+ * Replaces GPT2Block's  `hidden = attn_out + residual; hidden = ln_2(hidden)` and `hidden = residual + mlp_out;` + the NEXT block's
+ * ln_1 / the final ln_f (modeling_gpt2.py:229-309 via ttts/gpt/model.py:422).  Every output is bit-identical to
+ * ttts_gemm_nt_bf16_ex(RESID_ADD_F32) followed by ttts_layernorm_fwd (same dropout stream, same summation order).
+ * K % 64 == 0; N must be 512 (TTTS_EINVAL otherwise: use the two calls). */
+int ttts_gemm_nt_resid_ln_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, const float* bias,
+                               const float* resid_in, float* x_out, int32_t M, int32_t N, int32_t K, float dropout_p,
+                               uint64_t seed, const uint32_t* dropout_counter, const float* gamma, const float* beta,
+                               float eps, void* y, int32_t y_is_bf16, float* mean, float* rstd, void* stream);
 /* Which kernel and grid ttts_gemm_nt_bf16(_ex) uses for a shape (ABI v6; host-side query, launches nothing, needs no GPU).
  * The kernels differ in tile shape and pipeline only -- a shape's output bits are the same whichever runs -- and the choice is a
  * table of measurements on the 256 CUs of an MI355X (csrc/gemm.hip plan_nt); tests pin the rules, benchmarks report them. */

@@ -110,6 +110,41 @@ def test_gemm_nt_epilogues(ops, M, N, K):
         assert rel_err(dg[:, :N].float(), (a.float() @ b.float().t()) * x.grad) < 5e-3
 
 
+@pytest.mark.parametrize("M,K,p", [(9248, 512, 0.1), (9248, 2048, 0.1), (1000, 192, 0.0), (70, 64, 0.25), (9248, 512, 0.0)])
+def test_gemm_nt_resid_ln_is_bit_identical_to_the_two_launches(ops, M, K, p):
+    """ttts_gemm_nt_resid_ln_bf16 (the residual GEMM + the LayerNorm that follows it, whole 512-column rows, one launch) against
+    ttts_gemm_nt_bf16_ex(RESID_ADD_F32, dropout on) + ttts_layernorm_fwd on the same inputs: residual stream, statistics and the
+    normalised copy (bf16 and f32 forms) must be BIT-identical; and against a torch fp32 restatement with the materialised mask."""
+    from ttts_amd.lib import EPI_RESID_ADD_F32
+    N = 512
+    g = torch.Generator(device="cpu").manual_seed(M + K)
+    a = _bf(torch.randn(M, K, generator=g)).to(dev()); w = _bf(torch.randn(N, K, generator=g) * 0.1).to(dev())
+    bias = torch.randn(N, generator=g).to(dev()); resid = torch.randn(M, N, generator=g).to(dev())
+    gamma = (1 + 0.1 * torch.randn(N, generator=g)).to(dev()); beta = (0.1 * torch.randn(N, generator=g)).to(dev())
+    ctr = torch.full((1,), 5, dtype=torch.int32, device=dev())
+    x_ref = torch.empty(M, N, device=dev())
+    ops.gemm_nt(a, w, x_ref, bias, epilogue=EPI_RESID_ADD_F32, resid_in=resid, dropout_p=p, seed=77, counter=ctr)
+    for ydt in (torch.bfloat16, torch.float32):
+        y_ref = torch.empty(M, N, dtype=ydt, device=dev()); m_ref = torch.empty(M, device=dev()); r_ref = torch.empty(M, device=dev())
+        ops.layernorm_fwd(x_ref, gamma, beta, y_ref, m_ref, r_ref)
+        x = torch.full((M, N), float("nan"), device=dev()); y = torch.zeros(M, N, dtype=ydt, device=dev())
+        mean = torch.empty(M, device=dev()); rstd = torch.empty(M, device=dev())
+        ops.gemm_nt_resid_ln(a, w, x, gamma, beta, y, mean, rstd, bias=bias, resid_in=resid, dropout_p=p, seed=77, counter=ctr)
+        assert torch.equal(x, x_ref), "residual stream differs"
+        assert torch.equal(mean, m_ref) and torch.equal(rstd, r_ref), "row statistics differ"
+        assert torch.equal(y, y_ref), "normalised copy differs"
+    if p == 0.0:
+        want = resid + (a.float() @ w.float().t() + bias.to(torch.bfloat16).float()).to(torch.bfloat16).float()
+        assert rel_err(x, want) < 2e-5          # (a bf16 rounding of the GEMM term flips where torch's fp32 summation order differs)
+        assert rel_err(y.float(), torch.nn.functional.layer_norm(want, (N,), gamma, beta, 1e-5)) < 5e-5
+    # in place (resid_in = None): x_out += ...
+    x2 = resid.clone(); y2 = torch.zeros(M, N, dtype=torch.float32, device=dev())
+    ops.gemm_nt_resid_ln(a, w, x2, gamma, beta, y2, mean, rstd, bias=bias, dropout_p=p, seed=77, counter=ctr)
+    assert torch.equal(x2, x_ref)
+    with pytest.raises(Exception):
+        ops.gemm_nt_resid_ln(a, w[:256], x[:, :256].contiguous(), gamma[:256], beta[:256], y[:, :256].contiguous(), mean, rstd)
+
+
 @pytest.mark.parametrize("Kr,Mo,No", [(1000, 257, 512), (9248, 512, 1536), (333, 128, 128), (2080, 2048, 512), (8208, 1026, 512)])
 def test_gemm_tn_accumulates(ops, Kr, Mo, No):
     g = torch.Generator(device="cpu").manual_seed(Kr + Mo)

@@ -78,6 +78,37 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// LayerNorm row arithmetic shared by ln_fwd_kernel (elementwise.hip) and the fused residual-GEMM + LayerNorm kernel (gemm.hip): one
+// wave per row, a lane holds VPL float4 chunks.  Contraction is OFF in here so that both kernels form exactly the same roundings
+// whatever surrounds the call (the fused kernel's outputs are asserted bit-identical to the two-launch path).
+template <int VPL>
+__device__ __forceinline__ void ln_row_stats(const float4 (&v)[VPL], const bool (&ok)[VPL], int D, float eps, float& mean, float& rstd) {
+#pragma clang fp contract(off)
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    if (ok[i]) {
+      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, e = v[i].w - mean;
+      q += (a * a + b * b) + (c * c + e * e);
+    }
+  }
+  const float var = wave_sum(q) / (float)D;
+  rstd = 1.0f / sqrtf(var + eps);
+}
+__device__ __forceinline__ float4 ln_row_apply(const float4& v, float mean, float rstd, const float4& g, const float4& b) {
+#pragma clang fp contract(off)
+  float4 o;
+  o.x = (v.x - mean) * rstd * g.x + b.x;
+  o.y = (v.y - mean) * rstd * g.y + b.y;
+  o.z = (v.z - mean) * rstd * g.z + b.z;
+  o.w = (v.w - mean) * rstd * g.w + b.w;
+  return o;
+}
+
 // v_mfma_f32_32x32x16_bf16: D[32x32] += A[32x16] * B[16x32].
 //   A operand: lane l holds A[row = l & 31][k = 8*(l >> 5) + 0..7]
 //   B operand: lane l holds B[k = 8*(l >> 5) + 0..7][col = l & 31]

@@ -127,20 +127,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   for (int r = 0; r < LN_FWD_RPW; ++r) {
     const int64_t row = row0 + r;
     if (row >= M) break;
+    bool ok[VPL];
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) s[r] += (v[r][i].x + v[r][i].y) + (v[r][i].z + v[r][i].w);
-    const float mean = wave_sum(s[r]) / (float)D;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-      const int d = (lane + i * 64) * 4;
-      if (d < D) {
-        const float a = v[r][i].x - mean, b = v[r][i].y - mean, c = v[r][i].z - mean, e = v[r][i].w - mean;
-        q += (a * a + b * b) + (c * c + e * e);
-      }
-    }
-    const float var = wave_sum(q) / (float)D;
-    const float rstd = 1.0f / sqrtf(var + eps);
+    for (int i = 0; i < VPL; ++i) ok[i] = (lane + i * 64) * 4 < D;
+    float mean, rstd;
+    ln_row_stats<VPL>(v[r], ok, D, eps, mean, rstd);   // (common.hpp: shared with the fused residual-GEMM + LayerNorm kernel)
     if (lane == 0) {
       mean_out[row] = mean;
       rstd_out[row] = rstd;
@@ -150,11 +141,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     for (int i = 0; i < VPL; ++i) {
       const int d = (lane + i * 64) * 4;
       if (d < D) {
-        float4 o;
-        o.x = (v[r][i].x - mean) * rstd * g[i].x + bt[i].x;
-        o.y = (v[r][i].y - mean) * rstd * g[i].y + bt[i].y;
-        o.z = (v[r][i].z - mean) * rstd * g[i].z + bt[i].z;
-        o.w = (v[r][i].w - mean) * rstd * g[i].w + bt[i].w;
+        const float4 o = ln_row_apply(v[r][i], mean, rstd, g[i], bt[i]);
         if (OUT_BF16) {
           bf16x4 ob;
           ob[0] = (bf16)o.x; ob[1] = (bf16)o.y; ob[2] = (bf16)o.z; ob[3] = (bf16)o.w;

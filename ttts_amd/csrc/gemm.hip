@@ -842,6 +842,172 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_wreg_kernel(GemmNtParams p) {
   }
 }
 
+// ---- NT over WHOLE ROWS (N = 512 = the model width): residual GEMM + the LayerNorm that follows it, one launch -------------------
+// x_out = resid_in + dropout(bf16(A . W^T + bias)) is the fp32 residual stream; the next thing the model does with it is
+// LayerNorm (GPT2Block: ln_2 after the attention projection, the next block's ln_1 -- or ln_f -- after the MLP projection,
+// modeling_gpt2.py:229-309).  A 160 x 128 tile cannot normalise -- a row's statistics need all 512 columns -- so the LayerNorm was
+// its own launch re-reading x_out (8.7 us x 14 per step, a latency-bound kernel).  Here a workgroup owns 64 WHOLE rows: eight
+// waves x 64 columns, the 128 x 128 kernels' wave tile, two 72-KB LDS-DMA stages (64 rows of A + all 512 rows of W per 64-deep
+// k-step: the weight is re-streamed from the L2 by every workgroup -- the same fill bytes per flop as a 128 x 128 tile), and the
+// epilogue, through an fp32 stage of the whole 64 x 512 tile, does per row what epi_row8<RESID_ADD> and ln_fwd_kernel do: one
+// wave per row, lane l on columns 4 l .. 4 l + 3 and 256 + 4 l .. + 3 -- ln_fwd_kernel's own element -> lane map, so the sums
+// are formed in its order and x_out, mean, rstd and the normalised copy are BIT-IDENTICAL to the two-launch path
+// (tests/test_gpu_kernels.py).  Measured (round 4, profiles/r04_ab_fused_ln.txt): stand-alone at K = 512 25.1 us against 32.0 for
+// the two launches, at K = 2048 51.5 against 50.3 (145 workgroups = 57 % of the CUs stream 64 KB of weights per k-step each);
+// inside the train step the K = 512 form LOSES 3.5 us per layer (same-box A/B 3.393 vs 3.372 ms): there the fp32 residual and
+// the attention output come from HBM and 145 CUs cannot pull them as fast as 256.  The GPT engine therefore keeps the two
+// launches by default (TTTS_FUSED_LN=1 opts in); the entry point stays for shapes where a launch costs more than it does here.
+constexpr int RL_N = 512, RL_TM = 64, RL_BK = 64, RL_STAGE_EL = (RL_TM + RL_N) * RL_BK, RL_LDS = 2 * RL_STAGE_EL * 2;   // 2 x 72 KB
+struct RowLnParams {
+  const bf16* A; int64_t lda;
+  const bf16* B; int64_t ldb;
+  int M, K;
+  const float* bias; const float* resid_in; float* x_out;
+  uint32_t thr; float inv_keep; uint32_t seed_lo, seed_hi; const uint32_t* ctr;
+  const float* gamma; const float* beta; float eps;
+  void* y; int y_is_bf16; float* mean; float* rstd;
+};
+__global__ __launch_bounds__(512, 2) void gemm_nt_rowln_kernel(RowLnParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rl_smem[];   // [2][A 64 x 64 | W 512 x 64] bf16; reused as the fp32 stage
+  bf16* smem = reinterpret_cast<bf16*>(rl_smem);
+  const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, rl = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = xcd_tile(blockIdx.x, gridDim.x) * RL_TM;
+  const int nk = p.K / RL_BK;
+  auto fsw = [](int r) { return (r >> 1) & 7; };
+  // DMA: one wave instruction = 8 rows x 128 B; lane -> row l >> 3, slot l & 7 holding logical chunk (l & 7) ^ fsw(row).
+  // A: 8 pieces (one per wave), W: 64 pieces (eight per wave).
+  const bf16* ga;
+  const bf16* gb[8];
+  {
+    const int r = wave * 8 + (lane >> 3);
+    ga = p.A + (int64_t)min(m0 + r, p.M - 1) * p.lda + (((lane & 7) ^ fsw(r)) << 3);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int n = (wave * 8 + i) * 8 + (lane >> 3);
+      gb[i] = p.B + (int64_t)n * p.ldb + (((lane & 7) ^ fsw(n)) << 3);
+    }
+  }
+  auto issue = [&](int kt, int buf) {
+    bf16* st = smem + buf * RL_STAGE_EL;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + kt * RL_BK),
+                                     (__attribute__((address_space(3))) void*)(st + wave * 8 * RL_BK), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb[i] + kt * RL_BK),
+                                       (__attribute__((address_space(3))) void*)(st + RL_TM * RL_BK + (wave * 8 + i) * 8 * RL_BK), 16, 0, 0);
+  };
+  f32x16 acc[2][2];   // [j: 32-col block of this wave's 64 columns][i: 32-row block]; D = Wtile . Atile^T (rows = n, cols = m)
+  ZERO_ACC(acc)
+  issue(0, 0);
+  __syncthreads();    // (hipcc drains the LDS-DMA -- vmcnt(0) -- in front of the barrier)
+  int aoff[2], boff[2], sw[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ra = i * 32 + rl, rb = wave * 64 + i * 32 + rl;
+    aoff[i] = ra * RL_BK;
+    boff[i] = RL_TM * RL_BK + rb * RL_BK;
+    sw[0][i] = fsw(ra);
+    sw[1][i] = fsw(rb);
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
+    const bf16* st = smem + buf * RL_STAGE_EL;
+#pragma unroll
+    for (int ks = 0; ks < RL_BK / 16; ++ks) {
+      bf16x8 af[2], bfr[2];
+      const int lc = ks * 2 + hh;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = *reinterpret_cast<const bf16x8*>(st + aoff[i] + ((lc ^ sw[0][i]) << 3));
+        bfr[i] = *reinterpret_cast<const bf16x8*>(st + boff[i] + ((lc ^ sw[1][i]) << 3));
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[j][i] = mfma32(bfr[j], af[i], acc[j][i]);
+    }
+    __syncthreads();  // next stage landed and everyone is done reading this one
+  }
+  // ---- epilogue: fp32 stage [64 rows][128 slots of 16 B], slot s of row m at s ^ (m & 15) ------------------------------------
+  float* stage = reinterpret_cast<float*>(rl_smem);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = i * 32 + rl, slot = wave * 16 + j * 8 + 2 * q + hh;
+        *reinterpret_cast<float4*>(stage + row * RL_N + ((slot ^ (row & 15)) << 2)) =
+            make_float4(acc[j][i][4 * q], acc[j][i][4 * q + 1], acc[j][i][4 * q + 2], acc[j][i][4 * q + 3]);
+      }
+  __syncthreads();
+  // one wave per row, eight rows per wave; lane l: columns 4 l .. + 3 (c = 0) and 256 + 4 l .. + 3 (c = 1)
+  float4 bs[2], gm[2], bt[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int n = c * 256 + 4 * lane;
+    bs[c] = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    bs[c] = make_float4((float)(bf16)bs[c].x, (float)(bf16)bs[c].y, (float)(bf16)bs[c].z, (float)(bf16)bs[c].w);   // autocast rounds the bias
+    gm[c] = *reinterpret_cast<const float4*>(p.gamma + n);
+    bt[c] = *reinterpret_cast<const float4*>(p.beta + n);
+  }
+  const uint32_t shi = p.thr ? seed_mix(p.seed_hi, p.ctr) : 0u;
+  // all eight rows' residual loads first (16 x 16 B per lane in flight: the rows are then processed without a memory round trip each)
+  const float* rbase = p.resid_in ? p.resid_in : p.x_out;
+  float4 rsd[8][2];
+#pragma unroll
+  for (int rr = 0; rr < 8; ++rr) {
+    const int m = min(m0 + wave * 8 + rr, p.M - 1);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) rsd[rr][c] = nt_load16<float4>(rbase + (int64_t)m * RL_N + c * 256 + 4 * lane);
+  }
+#pragma unroll
+  for (int rr = 0; rr < 8; ++rr) {
+    const int row = wave * 8 + rr, m = m0 + row;
+    if (m >= p.M) break;                             // (wave-uniform)
+    float4 v[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int n = c * 256 + 4 * lane;
+      const float4 a = *reinterpret_cast<const float4*>(stage + row * RL_N + (((c * 64 + lane) ^ (row & 15)) << 2));
+      const float4 r = rsd[rr][c];
+      float y0 = (float)(bf16)(a.x + bs[c].x), y1 = (float)(bf16)(a.y + bs[c].y), y2 = (float)(bf16)(a.z + bs[c].z), y3 = (float)(bf16)(a.w + bs[c].w);
+      if (p.thr) {                                   // resid_pdrop: element index m * N + n, 16 random bits per element (two elements per hash)
+        const uint32_t lin = (uint32_t)(((int64_t)m * RL_N + n) >> 1);
+        const uint32_t h0 = hash32(lin, p.seed_lo, shi), h1 = hash32(lin + 1, p.seed_lo, shi);
+        y0 = (h0 & 0xFFFFu) >= p.thr ? y0 * p.inv_keep : 0.f;
+        y1 = (h0 >> 16) >= p.thr ? y1 * p.inv_keep : 0.f;
+        y2 = (h1 & 0xFFFFu) >= p.thr ? y2 * p.inv_keep : 0.f;
+        y3 = (h1 >> 16) >= p.thr ? y3 * p.inv_keep : 0.f;
+      }
+      v[c] = make_float4(r.x + y0, r.y + y1, r.z + y2, r.w + y3);
+      nt_store16<float4>(p.x_out + (int64_t)m * RL_N + n, v[c]);
+    }
+    // LayerNorm of the row: ln_fwd_kernel's own arithmetic (common.hpp), same element -> lane map, hence the same bits
+    const bool ok2[2] = {true, true};
+    float mean, rstd;
+    ln_row_stats<2>(v, ok2, RL_N, p.eps, mean, rstd);
+    if (lane == 0) {
+      p.mean[m] = mean;
+      p.rstd[m] = rstd;
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int n = c * 256 + 4 * lane;
+      const float4 o = ln_row_apply(v[c], mean, rstd, gm[c], bt[c]);
+      if (p.y_is_bf16) {
+        bf16x4 ob;
+        ob[0] = (bf16)o.x; ob[1] = (bf16)o.y; ob[2] = (bf16)o.z; ob[3] = (bf16)o.w;
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.y) + (int64_t)m * RL_N + n) = ob;
+      } else {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.y) + (int64_t)m * RL_N + n) = o;
+      }
+    }
+  }
+}
+
 // ---- NT, register-staged main loop (any K % 8 == 0; zero-fills ragged K) ---------------------------------------------
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNtParams p) {
@@ -1379,6 +1545,25 @@ extern "C" int ttts_gemm_nt_bf16_ex(const void* A, int64_t lda, const void* B, i
   }
   if (rc != TTTS_OK) return rc;
   return check_launch("gemm_nt");
+}
+
+extern "C" int ttts_gemm_nt_resid_ln_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, const float* bias,
+                                          const float* resid_in, float* x_out, int32_t M, int32_t N, int32_t K, float dropout_p,
+                                          uint64_t seed, const uint32_t* dropout_counter, const float* gamma, const float* beta,
+                                          float eps, void* y, int32_t y_is_bf16, float* mean, float* rstd, void* stream) {
+  TTTS_REQUIRE(A && B && x_out && gamma && beta && y && mean && rstd, "gemm_nt_resid_ln: null pointer");
+  TTTS_REQUIRE(N == RL_N, "gemm_nt_resid_ln: whole rows of N = %d only (got %d): use ttts_gemm_nt_bf16_ex + ttts_layernorm_fwd", RL_N, N);
+  TTTS_REQUIRE(M > 0 && K > 0 && K % RL_BK == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K,
+               "gemm_nt_resid_ln: K must be a multiple of %d, lda / ldb multiples of 8 (K=%d lda=%lld ldb=%lld)", RL_BK, K, (long long)lda, (long long)ldb);
+  TTTS_REQUIRE(aligned16(A) && aligned16(B) && aligned16(x_out) && aligned16(y) && aligned16(gamma) && aligned16(beta) &&
+               (!bias || aligned16(bias)) && (!resid_in || aligned16(resid_in)), "gemm_nt_resid_ln: 16-byte aligned bases required");
+  TTTS_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "gemm_nt_resid_ln: dropout_p out of range");
+  RowLnParams p{(const bf16*)A, lda, (const bf16*)B, ldb, M, K, bias, resid_in, x_out, dropout_threshold(dropout_p), 1.0f,
+                (uint32_t)seed, (uint32_t)(seed >> 32), dropout_counter, gamma, beta, eps, y, y_is_bf16, mean, rstd};
+  if (p.thr) p.inv_keep = 65536.0f / (65536.0f - (float)p.thr);
+  if (!nt_func_lds(reinterpret_cast<const void*>(gemm_nt_rowln_kernel), RL_LDS, 10)) return TTTS_EHIP;
+  gemm_nt_rowln_kernel<<<(int)cdiv(M, RL_TM), 512, RL_LDS, as_stream(stream)>>>(p);
+  return check_launch("gemm_nt_resid_ln");
 }
 
 extern "C" int ttts_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,

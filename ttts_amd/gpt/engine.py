@@ -131,6 +131,10 @@ class GptEngine:
         # backward section run as one launch at its end, one workgroup per output tile over the whole token dimension --
         # no split-reduction slabs, no reduce kernels.  TTTS_GROUPED_DW=0 restores one split-K dW GEMM per weight.
         self.grouped_dw = os.environ.get("TTTS_GROUPED_DW", "1") == "1"
+        # attention projection + residual add + ln_2 in one launch over whole rows (ttts_gemm_nt_resid_ln_bf16; same bits).  OFF by
+        # default: 25.1 vs 32.0 us stand-alone, but inside the step 3.393 vs 3.372 ms on the same box (profiles/r04_ab_fused_ln.txt) --
+        # its 145 workgroups pull the fp32 residual through 57 % of the CUs, and in the step that stream comes from HBM.
+        self.fused_ln = os.environ.get("TTTS_FUSED_LN", "0") == "1"
         self._dw_plans = {}
         self.seed_ctr = torch.zeros(1, dtype=torch.int32, device=self.device)   # this replica's dropout stream counter (device side:
         # graph-replay safe); handed to every dropout-capable kernel call -- the library holds no state of its own
@@ -437,9 +441,17 @@ class GptEngine:
             qkv = b["qkv"][i]
             ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], b["att"][i], b["lse"][i], B, H, S, dh, (S * 3 * D, 3 * D),
                          (S * D, D), dh ** -0.5, p, self._seed(16 * i + 2), counter=self.seed_ctr)
-            self._nt(b["att"][i], self.wT[pre + "attn.c_proj.weight"], x1, P(pre + "attn.c_proj.bias"),
-                     epilogue=EPI_RESID_ADD_F32, resid_in=x0, dropout_p=p, seed=self._seed(16 * i + 3), counter=self.seed_ctr)
-            ops.layernorm_fwd(x1, P(pre + "ln_2.weight"), P(pre + "ln_2.bias"), b["ln2"][i], st[2], st[3])
+            if D == 512 and self.fused_ln:
+                # opt-in: the attention projection, the residual add and ln_2 as ONE launch over whole 512-column rows (bit-identical
+                # to the two launches below; csrc/gemm.hip gemm_nt_rowln_kernel).  The MLP projection (K = 2048) is never fused:
+                # 51.5 vs 50.3 us even stand-alone -- its weight stream is 4 x longer and runs on 145 of the 256 CUs
+                ops.gemm_nt_resid_ln(b["att"][i], self.wT[pre + "attn.c_proj.weight"], x1, P(pre + "ln_2.weight"), P(pre + "ln_2.bias"),
+                                     b["ln2"][i], st[2], st[3], bias=P(pre + "attn.c_proj.bias"), resid_in=x0, dropout_p=p,
+                                     seed=self._seed(16 * i + 3), counter=self.seed_ctr)
+            else:
+                self._nt(b["att"][i], self.wT[pre + "attn.c_proj.weight"], x1, P(pre + "attn.c_proj.bias"),
+                         epilogue=EPI_RESID_ADD_F32, resid_in=x0, dropout_p=p, seed=self._seed(16 * i + 3), counter=self.seed_ctr)
+                ops.layernorm_fwd(x1, P(pre + "ln_2.weight"), P(pre + "ln_2.bias"), b["ln2"][i], st[2], st[3])
             self._nt(b["ln2"][i], self.wT[pre + "mlp.c_fc.weight"], b["fc_act"][i], P(pre + "mlp.c_fc.bias"),
                      aux=b["fc_pre"][i], epilogue=EPI_GELU_BF16)
             self._nt(b["fc_act"][i], self.wT[pre + "mlp.c_proj.weight"], x2, P(pre + "mlp.c_proj.bias"),

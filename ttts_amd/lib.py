@@ -67,7 +67,7 @@ _c = ctypes
 _P, _I32, _I64, _U64, _F = _c.c_void_p, _c.c_int32, _c.c_int64, _c.c_uint64, _c.c_float
 
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class ConvCtx(ctypes.Structure):
@@ -114,6 +114,7 @@ SIGNATURES = {
     "ttts_gemm_nt_bf16": (_I32, [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "ttts_gemm_nt_bf16_ex": (_I32, [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I32, _I32, _I32, _I32, _P, _F, _U64, _P, _P, _P]),
     "ttts_gemm_nt_plan_query": (_I32, [_I32, _I32, _I32, _I32, _P]),
+    "ttts_gemm_nt_resid_ln_bf16": (_I32, [_P, _I64, _P, _I64, _P, _P, _P, _I32, _I32, _I32, _F, _U64, _P, _P, _P, _F, _P, _I32, _P, _P, _P]),
     "ttts_gemm_tn_workspace_bytes": (_I64, [_I32, _I32, _I32]),
     "ttts_gemm_tn_bf16_accum_f32": (_I32, [_P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _P]),
     "ttts_tn_desc_tiles": (_I32, [_I32, _I32]),

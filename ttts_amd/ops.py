@@ -73,6 +73,25 @@ def gemm_nt(a, b, c, bias=None, aux=None, epilogue=EPI_STORE_BF16, n=None, k=Non
     return c
 
 
+def gemm_nt_resid_ln(a, b, x_out, gamma, beta, y, mean, rstd, bias=None, resid_in=None, dropout_p=0.0, seed=0, counter=None,
+                     eps=1e-5):
+    """x_out[M,512] = resid_in + dropout(bf16(a[M,K] @ b[512,K]^T + bias)); y = LayerNorm(x_out; gamma, beta) (bf16 or f32 by y's
+    dtype); mean / rstd [M] -- ONE launch, bit-identical to gemm_nt(RESID_ADD_F32) + layernorm_fwd (ttts_gemm_nt_resid_ln_bf16)."""
+    _req(a, torch.bfloat16, "a"); _req(b, torch.bfloat16, "b"); _req(bias, torch.float32, "bias"); _req(resid_in, torch.float32, "resid_in")
+    _req(x_out, torch.float32, "x_out"); _req(gamma, torch.float32, "gamma"); _req(beta, torch.float32, "beta")
+    _req(mean, torch.float32, "mean"); _req(rstd, torch.float32, "rstd")
+    if y.dtype not in (torch.bfloat16, torch.float32):
+        raise TttsError("gemm_nt_resid_ln: y must be bf16 or f32")
+    M, K, N = a.shape[0], a.shape[1], b.shape[0]
+    for t, nm in ((x_out, "x_out"), (y, "y"), (resid_in, "resid_in")):
+        if t is not None and (tuple(t.shape) != (M, N) or not t.is_contiguous()):
+            raise TttsError("gemm_nt_resid_ln: %s must be a contiguous [M, N] tensor" % nm)
+    check(_l.get().ttts_gemm_nt_resid_ln_bf16(_p(a), _ld(a), _p(b), _ld(b), _p(bias), _p(resid_in), _p(x_out), M, N, K, dropout_p, seed,
+                                              _ctr(counter, x_out, dropout_p), _p(gamma), _p(beta), eps, _p(y), int(y.dtype == torch.bfloat16),
+                                              _p(mean), _p(rstd), _stream()), "gemm_nt_resid_ln")
+    return x_out, y
+
+
 def gemm_tn_workspace(mo, no, kr, device):
     n = _l.get().ttts_gemm_tn_workspace_bytes(mo, no, kr)
     return torch.empty(max(n, 16) // 4, dtype=torch.float32, device=device)
