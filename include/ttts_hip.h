@@ -520,6 +520,17 @@ int ttts_weight_norm_fwd_f32(const float* v, const float* g, float* w, float* no
                              void* stream);
 int ttts_weight_norm_bwd_f32(const float* dw, const float* v, const float* g, const float* norm, float* dv,
                              float* dg, int32_t rows, int32_t n, void* stream);
+/* Batched forms (ABI v7): every weight-normed layer of a network in ONE launch each (one workgroup per weight row; bit-identical
+ * to the per-layer calls).  Descriptors live in device memory, ordered by row_begin (the layer's first row in the launch's grid);
+ * forward: w = g v / |v|, norm, and dw (if not NULL) cleared; backward: dv += ..., dg += ... from dw (fields the direction does
+ * not use may be NULL).  Replaces torch.nn.utils.weight_norm / parametrizations.weight_norm recomputation per forward
+ * (ttts/vqvae/vq2.py:10,364, ttts/vqvae/modules.py:8) and its autograd. */
+typedef struct {
+  const void* v; const void* g; void* w; void* norm; void* dw; void* dv; void* dg;
+  int32_t rows, n, row_begin, reserved;
+} ttts_wn_desc;
+int ttts_weight_norm_fwd_batched_f32(const ttts_wn_desc* desc_dev, int32_t n_desc, int32_t total_rows, void* stream);
+int ttts_weight_norm_bwd_batched_f32(const ttts_wn_desc* desc_dev, int32_t n_desc, int32_t total_rows, void* stream);
 int ttts_tanh_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, void* stream);
 int ttts_lrelu_bwd_f32(const float* dy, const float* y, float* dx, float slope, int64_t n, void* stream);
 /* y = scale * (a + b + c + d), b/c/d optional (NULL): `xs / num_kernels` of Generator.forward (vq2.py:396-403) and its

@@ -554,6 +554,25 @@ def test_full_vqvae_gan_step_matches_reference_fixture(golden_dir):
     np.testing.assert_allclose(cb.embed[:8].cpu().numpy(), g["cb_embed_head"], rtol=1e-4, atol=1e-6)
 
 
+def test_weight_norm_bank_step_equals_per_layer_step(golden_dir, monkeypatch):
+    """The batched weight normalisation (WeightNormBank: one launch per phase for all layers' w = g v/|v|, one for all
+    (dv, dg)) against the per-layer launches it replaces: same losses, gradient norms and parameter updates."""
+    res = {}
+    for bank in ("0", "1"):
+        monkeypatch.setenv("TTTS_WN_BANK", bank)
+        g, tr, data, inject = _step_setup(golden_dir)
+        assert (tr.step_fn.bank_g is not None) == (bank == "1")
+        outs = [tr.train_step(data, inject) for _ in range(2)]        # two steps: the bank's buffers are re-used across steps
+        res[bank] = ([{k: float(v) for k, v in o.items()} for o in outs], tr.optim_g.flat_p.clone(), tr.optim_d.flat_p.clone())
+    for a, b in zip(res["0"][0], res["1"][0]):
+        for k in a:
+            np.testing.assert_allclose(b[k], a[k], rtol=2e-5, err_msg=k)
+    for i in (1, 2):
+        a, b = res["0"][i], res["1"][i]
+        # Adam's first steps move an element by ~lr whatever the gradient's size; elements whose gradient is rounding noise may flip
+        assert ((a - b).abs() > 1e-5).float().mean().item() < 2e-3
+
+
 def test_synthesizer_infer_and_decode_match_reference_fixture(golden_dir):
     """SynthesizerTrn.infer / .decode (vq2.py:873-910; the reverse coupling flow and whole-clip decoding, the two entry points of
     SURVEY 8(b1)'s surface beyond the training forward) against the reference-generated tests/golden/vqvae_infer.npz."""

@@ -540,6 +540,57 @@ __global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __res
   }
 }
 
+// The same two kernels for ALL weight-normed layers of a network in one launch each (ABI v7): a VQ-VAE-GAN step has ~500 such
+// layers and ran ~920 five-microsecond launches for them (profiles/r03_vqvae_kernel_stats.csv: 5.3 ms a step at the launch floor).
+// One workgroup per weight row as before -- the per-row arithmetic and summation order are those of the single-layer kernels, so the
+// results are bit-identical -- its layer found by binary search over the descriptors' first-row offsets.
+__device__ __forceinline__ int wn_find(const ttts_wn_desc* __restrict__ d, int n_desc, int r) {
+  int lo = 0, hi = n_desc - 1;
+  while (lo < hi) {                                  // last descriptor with row_begin <= r (workgroup-uniform)
+    const int mid = (lo + hi + 1) >> 1;
+    if (d[mid].row_begin <= r) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+__global__ __launch_bounds__(256) void weight_norm_fwd_batched_kernel(const ttts_wn_desc* __restrict__ desc, int n_desc) {
+  __shared__ float sh[4];
+  const ttts_wn_desc d = desc[wn_find(desc, n_desc, blockIdx.x)];
+  const int r = blockIdx.x - d.row_begin, n = d.n;
+  const float* v = reinterpret_cast<const float*>(d.v) + (int64_t)r * n;
+  float* w = reinterpret_cast<float*>(d.w) + (int64_t)r * n;
+  float* zero = d.dw ? reinterpret_cast<float*>(d.dw) + (int64_t)r * n : nullptr;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) { const float t = v[i]; s += t * t; }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const float nr = sqrtf((sh[0] + sh[1]) + (sh[2] + sh[3]));
+  if (threadIdx.x == 0) reinterpret_cast<float*>(d.norm)[r] = nr;
+  const float sc = reinterpret_cast<const float*>(d.g)[r] / nr;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    w[i] = v[i] * sc;
+    if (zero) zero[i] = 0.f;
+  }
+}
+__global__ __launch_bounds__(256) void weight_norm_bwd_batched_kernel(const ttts_wn_desc* __restrict__ desc, int n_desc) {
+  __shared__ float sh[4];
+  const ttts_wn_desc d = desc[wn_find(desc, n_desc, blockIdx.x)];
+  const int r = blockIdx.x - d.row_begin, n = d.n;
+  const float* v = reinterpret_cast<const float*>(d.v) + (int64_t)r * n;
+  const float* dw = reinterpret_cast<const float*>(d.dw) + (int64_t)r * n;
+  float* dv = reinterpret_cast<float*>(d.dv) + (int64_t)r * n;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += dw[i] * v[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const float dot = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  const float nr = reinterpret_cast<const float*>(d.norm)[r], gr = reinterpret_cast<const float*>(d.g)[r];
+  if (threadIdx.x == 0) reinterpret_cast<float*>(d.dg)[r] += dot / nr;
+  const float a = gr / nr, bq = dot / (nr * nr);
+  for (int i = threadIdx.x; i < n; i += 256) dv[i] += a * (dw[i] - v[i] * bq);
+}
+
 // elementwise helpers of the stack: dy_pre = dy * (1 - y^2)  (tanh output), y = lrelu(x) variants live in the convs
 __global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                        float* __restrict__ dx, int64_t n) {
@@ -805,6 +856,17 @@ extern "C" int ttts_weight_norm_bwd_f32(const float* dw, const float* v, const f
   TTTS_REQUIRE(dw && v && g && norm && dv && dg && rows > 0 && n > 0, "weight_norm_bwd: bad arguments");
   weight_norm_bwd_kernel<<<rows, 256, 0, as_stream(stream)>>>(dw, v, g, norm, dv, dg, rows, n);
   return check_launch("weight_norm_bwd");
+}
+
+extern "C" int ttts_weight_norm_fwd_batched_f32(const ttts_wn_desc* desc_dev, int32_t n_desc, int32_t total_rows, void* stream) {
+  TTTS_REQUIRE(desc_dev && n_desc > 0 && total_rows > 0, "weight_norm_fwd_batched: bad arguments");
+  weight_norm_fwd_batched_kernel<<<total_rows, 256, 0, as_stream(stream)>>>(desc_dev, n_desc);
+  return check_launch("weight_norm_fwd_batched");
+}
+extern "C" int ttts_weight_norm_bwd_batched_f32(const ttts_wn_desc* desc_dev, int32_t n_desc, int32_t total_rows, void* stream) {
+  TTTS_REQUIRE(desc_dev && n_desc > 0 && total_rows > 0, "weight_norm_bwd_batched: bad arguments");
+  weight_norm_bwd_batched_kernel<<<total_rows, 256, 0, as_stream(stream)>>>(desc_dev, n_desc);
+  return check_launch("weight_norm_bwd_batched");
 }
 
 extern "C" int ttts_tanh_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, void* stream) {

@@ -83,6 +83,12 @@ class ColsumDesc(ctypes.Structure):
     _fields_ = [("X", _P), ("out", _P), ("ldx", _I64), ("M", _I32), ("N", _I32), ("tile_begin", _I32), ("reserved", _I32)]
 
 
+class WnDesc(ctypes.Structure):
+    """include/ttts_hip.h: ttts_wn_desc."""
+    _fields_ = [("v", _P), ("g", _P), ("w", _P), ("norm", _P), ("dw", _P), ("dv", _P), ("dg", _P),
+                ("rows", _I32), ("n", _I32), ("row_begin", _I32), ("reserved", _I32)]
+
+
 class GemmNtPlan(ctypes.Structure):
     _fields_ = [("kernel", _I32), ("grid", _I32), ("block", _I32), ("tile_m", _I32), ("tile_n", _I32), ("phase", _I32),
                 ("main_row_tiles", _I32), ("tail_tile_rows", _I32)]
@@ -199,6 +205,8 @@ SIGNATURES = {
     "ttts_conv1d_bias_grad_f32": (_I32, [_P, _P, _I32, _I32, _I32, _P]),
     "ttts_weight_norm_fwd_f32": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _P]),
     "ttts_weight_norm_bwd_f32": (_I32, [_P, _P, _P, _P, _P, _P, _I32, _I32, _P]),
+    "ttts_weight_norm_fwd_batched_f32": (_I32, [_P, _I32, _I32, _P]),
+    "ttts_weight_norm_bwd_batched_f32": (_I32, [_P, _I32, _I32, _P]),
     "ttts_tanh_bwd_f32": (_I32, [_P, _P, _P, _I64, _P]),
     "ttts_add4_scale_f32": (_I32, [_P, _P, _P, _P, _F, _P, _I64, _P]),
     "ttts_gate_fwd_f32": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _P]),

@@ -324,6 +324,39 @@ class LnFinalizePlan:
         check(_l.get().ttts_layernorm_bwd_finalize_batched(_p(self.table), self.n, self.M, self.D, _stream()), "ln_finalize_batched")
 
 
+class WeightNormPlan:
+    """Descriptor table for ttts_weight_norm_{fwd,bwd}_batched_f32: entries = dicts of fp32 tensors
+    {v [rows, ...], g [rows, ...], w (like v), norm [rows], dw (like v) | None, dv (like v) | None, dg (like g) | None}; one launch
+    covers all of them (one workgroup per weight row)."""
+
+    def __init__(self, entries, device):
+        if not entries:
+            raise TttsError("WeightNormPlan: no entries")
+        arr = (_l.WnDesc * len(entries))()
+        rows_total = 0
+        for i, e in enumerate(entries):
+            v = e["v"]
+            for k in ("v", "g", "w", "norm", "dw", "dv", "dg"):
+                t = e.get(k)
+                if t is not None:
+                    _req(t, torch.float32, k)
+                    if not t.is_contiguous():
+                        raise TttsError("WeightNormPlan: %s must be contiguous" % k)
+            rows, n = v.shape[0], v.numel() // v.shape[0]
+            ptr = lambda k: (e[k].data_ptr() if e.get(k) is not None else None)   # noqa: E731
+            arr[i].v, arr[i].g, arr[i].w, arr[i].norm = ptr("v"), ptr("g"), ptr("w"), ptr("norm")
+            arr[i].dw, arr[i].dv, arr[i].dg = ptr("dw"), ptr("dv"), ptr("dg")
+            arr[i].rows, arr[i].n, arr[i].row_begin = rows, n, rows_total
+            rows_total += rows
+        self.table, self.n, self.rows, self._keep = _upload(arr, device), len(entries), rows_total, entries
+
+    def forward(self):
+        check(_l.get().ttts_weight_norm_fwd_batched_f32(_p(self.table), self.n, self.rows, _stream()), "weight_norm_fwd_batched")
+
+    def backward(self):
+        check(_l.get().ttts_weight_norm_bwd_batched_f32(_p(self.table), self.n, self.rows, _stream()), "weight_norm_bwd_batched")
+
+
 class ColsumPlan:
     """Descriptor table for ttts_colsum_bf16_accum_f32_batched: entries (X bf16 [M, ld], out f32 [>= N], N | None)."""
 

@@ -72,6 +72,73 @@ class _WeightNormFn(torch.autograd.Function):
         return dv, dg
 
 
+class WeightNormBank:
+    """All weight-normed layers of one network (generator or discriminators) normalised by ONE launch per phase, and their
+    (dv, dg) formed from the accumulated effective-weight gradients by ONE launch at the end of the phase's backward
+    (ops.WeightNormPlan -> ttts_weight_norm_{fwd,bwd}_batched_f32) -- instead of one weight_norm_fwd per convolution call and one
+    weight_norm_bwd per layer (~920 launches a step at the 5 us launch floor).  Per layer the bank owns a LEAF tensor `w` (a view
+    of one flat buffer) whose .grad is a view of a flat dW buffer: the convolution backward kernels, which all accumulate, add
+    straight into it through the existing `_grad_slot` route.  `refresh()` rewrites every w from (v, g) and clears dW;
+    `finish()` turns dW into accumulations on v.grad / g.grad (views of the optimizer's flat gradient arena).  Outside a step
+    (`active` False) the layers recompute their weight per call as before."""
+
+    def __init__(self, net):
+        self.layers = [m for m in net.modules() if isinstance(m, _ConvBase) and m._wn is not None]
+        self.active = False
+        if not self.layers:
+            return
+        dev = self.layers[0]._v().device
+        sizes = [m._v().numel() for m in self.layers]
+        rows = [m._v().shape[0] for m in self.layers]
+        self.flat_w = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        self.flat_dw = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        self.flat_norm = torch.zeros(sum(rows), dtype=torch.float32, device=dev)
+        self.w, entries_f, entries_b = [], [], []
+        o = r = 0
+        for i, m in enumerate(self.layers):
+            v, g = m._v(), m._g()
+            shape = m._eff_shape(v.shape)
+            w = self.flat_w[o:o + sizes[i]].view(shape)
+            w.requires_grad_(v.requires_grad)
+            dw = self.flat_dw[o:o + sizes[i]].view(shape)
+            if v.requires_grad:
+                w.grad = dw
+            norm = self.flat_norm[r:r + rows[i]]
+            self.w.append(w)
+            e = {"v": v.detach(), "g": g.detach().reshape(-1), "w": w.detach(), "norm": norm, "dw": dw if v.requires_grad else None}
+            entries_f.append(e)
+            if v.requires_grad:
+                if v.grad is None or g.grad is None:
+                    raise ops.TttsError("WeightNormBank needs the parameters' persistent .grad views (build the FlatAdamW first)")
+                entries_b.append(dict(e, dv=v.grad, dg=g.grad.reshape(-1)))
+            object.__setattr__(m, "_bank_ref", (self, i))
+            o += sizes[i]; r += rows[i]
+        self.plan_f = ops.WeightNormPlan(entries_f, dev)
+        self.plan_b = ops.WeightNormPlan(entries_b, dev) if entries_b else None
+        self._trainable = [w.requires_grad for w in self.w]
+
+    def weight(self, i):
+        return self.w[i]
+
+    def refresh(self, requires_grad=True):
+        """Recompute every effective weight (and clear the dW buffer).  requires_grad False: a phase in which this network's
+        parameters are frozen (the generator phase's discriminator): no weight gradients are formed."""
+        if not self.layers:
+            return
+        self.plan_f.forward()
+        for w, t in zip(self.w, self._trainable):
+            w.requires_grad_(bool(requires_grad and t))
+        self.active = True
+
+    def finish(self):
+        """dW -> (dv, dg), accumulated into the parameters' gradient slots."""
+        if self.layers and self.plan_b is not None:
+            self.plan_b.backward()
+
+    def release(self):
+        self.active = False
+
+
 class _Conv1dFn(torch.autograd.Function):
     """y = act(bias + bbias + conv1d(lrelu(x, in_slope), w) + resid);  out_act None | 'tanh' | 'lrelu'."""
 
@@ -218,10 +285,24 @@ class _ConvBase(nn.Module):
     def _v(self):
         return self.weight_v if self._wn == "old" else self.parametrizations["weight"].original1
 
+    def _banked_weight(self):
+        """The WeightNormBank leaf holding this layer's effective weight while a step is running, else None."""
+        bank = getattr(self, "_bank_ref", None)
+        if self._wn is not None and bank is not None and bank[0].active:
+            return bank[0].weight(bank[1])
+        return None
+
     def effective_weight(self):
         if self._wn is None:
             return self.weight
+        w = self._banked_weight()       # the network's weights were all normalised by ONE launch at the phase start
+        if w is not None:
+            return w
         return _WeightNormFn.apply(self._v(), self._g())
+
+    def _eff_shape(self, shape):
+        """Shape the convolution consumes the effective weight in (Conv2dK1 drops its trailing unit axis)."""
+        return tuple(shape)
 
 
 class Conv1d(_ConvBase):
@@ -252,8 +333,12 @@ class Conv2dK1(_ConvBase):
         self.stride, self.padding = stride, padding
         self._init_params((out_channels, in_channels, kernel_size, 1), in_channels * kernel_size, out_channels, bias)
 
+    def _eff_shape(self, shape):
+        return tuple(shape[:3])
+
     def forward(self, x, in_slope=1.0, out_act=None, out_slope=LRELU_SLOPE):
-        return _Conv1dFn.apply(x, self.effective_weight().squeeze(-1), self.bias, None, None, self.stride, self.padding, 1,
+        w = self.effective_weight()
+        return _Conv1dFn.apply(x, w.squeeze(-1) if w.dim() == 4 else w, self.bias, None, None, self.stride, self.padding, 1,
                                float(in_slope), out_act, 1, float(out_slope))
 
 
@@ -470,7 +555,9 @@ class _WNFn(torch.autograd.Function):
             in_v, in_g, in_b, rs_v, rs_g, rs_b = params[6 * i:6 * i + 6]
             dil = dil_rate ** i
             pad = int((K * dil - dil) / 2)
-            if want_dw:       # the same launches clear the buffers the backward's weight-gradient kernels accumulate into
+            if in_g is None:  # banked: in_v / rs_v ARE the effective weights (WeightNormBank leaves, normalised once per phase)
+                w_in, n_in, w_rs, n_rs = in_v, None, rs_v, None
+            elif want_dw:     # the same launches clear the buffers the backward's weight-gradient kernels accumulate into
                 w_in, n_in, z_in = ops.weight_norm_fwd(in_v, in_g, want_zero=True)
                 w_rs, n_rs, z_rs = ops.weight_norm_fwd(rs_v, rs_g, want_zero=True)
                 dwz += [z_in, z_rs]
@@ -510,13 +597,16 @@ class _WNFn(torch.autograd.Function):
             in_v, in_g, in_b, rs_v, rs_g, rs_b = params[6 * i:6 * i + 6]
             dil = dil_rate ** i
             pad = int((K * dil - dil) / 2)
+            banked = in_g is None
             pre = (None, None)                                   # the buffers the forward cleared (used once)
-            if len(ctx.dwz) == 2 * n_layers and ctx.dwz[2 * i] is not None:
+            if banked:                                           # the bank's dW views (cleared by its refresh)
+                pre = (_grad_slot(ctx.prefs[6 * i]), _grad_slot(ctx.prefs[6 * i + 3]))
+            elif len(ctx.dwz) == 2 * n_layers and ctx.dwz[2 * i] is not None:
                 pre = (ctx.dwz[2 * i], ctx.dwz[2 * i + 1])
                 ctx.dwz[2 * i] = ctx.dwz[2 * i + 1] = None
             dw_rs = pre[1] if pre[1] is not None else torch.zeros_like(w_rs)
-            slots = [_grad_slot(t) for t in ctx.prefs[6 * i:6 * i + 6]]      # in_v, in_g, in_b, rs_v, rs_g, rs_b
-            direct = all(sl is not None for sl in slots)
+            slots = [_grad_slot(t) if t is not None else None for t in ctx.prefs[6 * i:6 * i + 6]]   # in_v, in_g, in_b, rs_v, ..
+            direct = all(sl is not None for sl, t in zip(slots, ctx.prefs[6 * i:6 * i + 6]) if t is not None)
             if i < n_layers - 1:
                 dacts = ops.conv1d_dgrad(dres, w_rs[:H], T)
                 ops.conv1d_dgrad(dsk, w_rs[H:], T, out=dacts, accumulate=True)
@@ -536,7 +626,9 @@ class _WNFn(torch.autograd.Function):
             db_in = slots[2] if direct else torch.zeros_like(in_b)
             dw_in = ops.conv1d_wgrad(dx_in, xi, K, 1, pad, dil, db=db_in, out=pre[0])
             dres = ops.conv1d_dgrad(dx_in, w_in, T, 1, pad, dil, resid=dres, omask=m2 if i > 0 else None)
-            if direct:
+            if banked:
+                pass                                             # WeightNormBank.finish() forms (dv, dg) for every layer at once
+            elif direct:
                 ops.weight_norm_bwd(dw_in, in_v, in_g, n_in, dv=slots[0], dg=slots[1])
                 ops.weight_norm_bwd(dw_rs, rs_v, rs_g, n_rs, dv=slots[3], dg=slots[4])
             else:
@@ -573,7 +665,12 @@ class WN(nn.Module):
         gcond = self.cond_layer(g) if g is not None else None
         params = []
         for a, b in zip(self.in_layers, self.res_skip_layers):
-            params += [a.weight_v, a.weight_g, a.bias, b.weight_v, b.weight_g, b.bias]
+            wa, wb = a._banked_weight(), b._banked_weight()
+            if wa is not None and wb is not None and all(
+                    _grad_slot(t) is not None for t in (wa, wb, a.bias, b.bias)):
+                params += [wa, None, a.bias, wb, None, b.bias]
+            else:
+                params += [a.weight_v, a.weight_g, a.bias, b.weight_v, b.weight_g, b.bias]
         return _WNFn.apply(x, x_mask, gcond, self.n_layers, self.kernel_size[0], self.dilation_rate, *params)
 
 

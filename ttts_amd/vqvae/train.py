@@ -89,6 +89,12 @@ class VqvaeStep:
         self.hps, self.net_g, self.net_d, self.optim_g, self.optim_d, self.aug = hps, net_g, net_d, optim_g, optim_d, aug
         self.dp = dp if dp is not None else FlatDataParallel()
         self._d_params = [prm for prm in net_d.parameters() if prm.requires_grad]
+        # every weight-normed layer of a network is (re)normalised by one launch per phase (modules.WeightNormBank); TTTS_WN_BANK=0
+        # restores one launch per convolution call
+        self.bank_g = self.bank_d = None
+        if os.environ.get("TTTS_WN_BANK", "1") == "1":
+            from .modules import WeightNormBank
+            self.bank_g, self.bank_d = WeightNormBank(net_g), WeightNormBank(net_d)
 
     def _sync_buffers(self):
         if self.dp.enabled:                                                  # DDP broadcast_buffers=True (rank-0 codebook)
@@ -122,6 +128,17 @@ class VqvaeStep:
         else:
             wav_aug = augment(wav, self.aug, self.hps)                        # train.py:337-338 (PEQ part)
         spec_aug = spec if wav_aug is wav else spectrogram_torch(wav_aug, h.filter_length, h.hop_length, h.win_length, center=False)
+        try:
+            return self._phases(wav, wav_aug, wav_lengths, spec, spec_aug, spec_lengths, text, text_lengths, y, inject, cut)
+        finally:
+            for bank in (self.bank_g, self.bank_d):
+                if bank is not None:
+                    bank.release()
+
+    def _phases(self, wav, wav_aug, wav_lengths, spec, spec_aug, spec_lengths, text, text_lengths, y, inject, cut):
+        h, tr = self.hps.data, self.hps.train
+        if self.bank_g is not None:
+            self.bank_g.refresh()
         y_hat, kl_ssl, ids_slice, z_mask, (z, z_p, m_p, logs_p, m_q, logs_q), quantized = self.net_g(
             wav, wav_aug, wav_lengths, spec, spec_aug, spec_lengths, text, text_lengths, **inject)
         mel = spec_to_mel_torch(spec, h.filter_length, h.n_mel_channels, h.sampling_rate, h.mel_fmin, h.mel_fmax)
@@ -131,10 +148,14 @@ class VqvaeStep:
         y = slice_segments(y.unsqueeze(1), ids_slice * h.hop_length, tr.segment_size)
         scale = self.dp.loss_scale()
         # ---- discriminator phase
+        if self.bank_d is not None:
+            self.bank_d.refresh()
         y_d_hat_r, y_d_hat_g, _, _ = self.net_d(y, y_hat.detach())
         loss_disc, losses_disc_r, losses_disc_g = L.discriminator_loss(y_d_hat_r, y_d_hat_g)
         self.optim_d.zero_grad()
         (loss_disc * scale).backward()
+        if self.bank_d is not None:
+            self.bank_d.finish()
         self._exchange(1, cut)
         self.optim_d.step()
         # ---- generator phase.  The reference lets this backward fill net_d's parameter gradients too and throws them away at
@@ -144,6 +165,8 @@ class VqvaeStep:
         for prm in self._d_params:
             prm.requires_grad_(False)
         try:
+            if self.bank_d is not None:
+                self.bank_d.refresh(requires_grad=False)          # the UPDATED discriminator, frozen
             y_d_hat_r, y_d_hat_g, fmap_r, fmap_g = self.net_d(y, y_hat)
             loss_mel = L.l1_loss(y_mel, y_hat_mel) * tr.c_mel
             loss_kl = L.kl_loss(z_p, logs_q, m_p, logs_p, z_mask) * tr.c_kl
@@ -152,6 +175,8 @@ class VqvaeStep:
             loss_gen_all = loss_gen + loss_fm + loss_mel + kl_ssl * 1 + loss_kl
             self.optim_g.zero_grad()
             (loss_gen_all * scale).backward()
+            if self.bank_g is not None:
+                self.bank_g.finish()
         finally:
             for prm in self._d_params:
                 prm.requires_grad_(True)
