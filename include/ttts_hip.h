@@ -34,7 +34,7 @@ extern "C" {
 #define TTTS_EHIP (-2)         /* a HIP runtime call or kernel launch failed */
 #define TTTS_EUNSUPPORTED (-3) /* valid request this build has no kernel for */
 
-#define TTTS_ABI_VERSION 7
+#define TTTS_ABI_VERSION 8
 
 /* ---- library ------------------------------------------------------------------------------------ */
 int ttts_abi_version(void);
@@ -531,6 +531,37 @@ typedef struct {
 } ttts_wn_desc;
 int ttts_weight_norm_fwd_batched_f32(const ttts_wn_desc* desc_dev, int32_t n_desc, int32_t total_rows, void* stream);
 int ttts_weight_norm_bwd_batched_f32(const ttts_wn_desc* desc_dev, int32_t n_desc, int32_t total_rows, void* stream);
+/* Weight-split cache (ABI v8).  The split-bf16 convolutions consume their weights as bf16 hi / lo arrays in a per-launch layout
+ * (transposed / tap-flipped / polyphase for data gradients, padded to the tile): formerly one ~5 us split launch in front of
+ * every forward and data-gradient call (1300 of them per VQ-VAE-GAN step).  The host registers an array the weights live in
+ * (the optimizer's flat parameter arena, a WeightNormBank's flat effective weights: [w_base, w_base + w_bytes)) with caller-owned
+ * `storage` (256-byte aligned; it holds the descriptor table and the split arrays).  While the cache is ARMED, the first
+ * convolution call with a given (weight pointer, layout) records a descriptor and splits into a persistent slot; later calls
+ * launch nothing, and ttts_conv_wsplit_cache_refresh -- to be called after every change of the weights, before they are next
+ * used -- rewrites all recorded splits in ONE launch and arms the cache.  Disarmed (initially, and after _disarm: call it when
+ * the step ends, since the arrays may then change without a refresh), when storage or max_entries run out, or on a first
+ * sighting during stream capture, calls split per launch into the workspace as before: the cache changes launch counts,
+ * never results.  No reference counterpart (cudnn picks its own weight layouts inside F.conv1d, ttts/vqvae/vq2.py:364-403). */
+int ttts_conv_wsplit_cache_create(const void* w_base, int64_t w_bytes, void* storage, int64_t storage_bytes, int32_t max_entries,
+                                  void** cache_out);
+int ttts_conv_wsplit_cache_refresh(void* cache, void* stream);
+int ttts_conv_wsplit_cache_disarm(void* cache);
+int ttts_conv_wsplit_cache_stats(void* cache, int64_t* out4 /* entries, storage bytes used, hits, misses */);
+int ttts_conv_wsplit_cache_destroy(void* cache);
+/* Deferred weight-gradient reduction (ABI v8).  The split-bf16 weight-gradient kernels write per-split partial sums ("slabs") and a
+ * reduce launch adds them into dw (and db); with the array the gradients accumulate into registered here ([dw_base, dw_base +
+ * dw_bytes): a WeightNormBank's flat dW, the optimizer's gradient arena) and the arena armed by _begin, each such call writes
+ * its slabs to a persistent slot in caller-owned `storage` (256-byte aligned) and launches no reduce; _reduce adds every slab
+ * set written since _begin into its dw / db in ONE launch and disarms.  Call _reduce before anything reads the gradients.  A
+ * second gradient into the same dw within a phase, exhausted storage, a first sighting during stream capture, or a bias gradient
+ * outside every registered range reduce immediately as before. */
+int ttts_conv_wgrad_arena_create(const void* dw_base, int64_t dw_bytes, void* storage, int64_t storage_bytes, int32_t max_entries,
+                                 void** arena_out);
+int ttts_conv_wgrad_arena_begin(void* arena);
+int ttts_conv_wgrad_arena_reduce(void* arena, void* stream);
+int ttts_conv_wgrad_arena_disarm(void* arena);      /* abandon the phase: nothing is added, later calls reduce immediately */
+int ttts_conv_wgrad_arena_stats(void* arena, int64_t* out5 /* entries, storage bytes used, deferred, fallbacks, partial reduces */);
+int ttts_conv_wgrad_arena_destroy(void* arena);
 int ttts_tanh_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, void* stream);
 int ttts_lrelu_bwd_f32(const float* dy, const float* y, float* dx, float slope, int64_t n, void* stream);
 /* y = scale * (a + b + c + d), b/c/d optional (NULL): `xs / num_kernels` of Generator.forward (vq2.py:396-403) and its

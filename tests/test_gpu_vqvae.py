@@ -554,23 +554,51 @@ def test_full_vqvae_gan_step_matches_reference_fixture(golden_dir):
     np.testing.assert_allclose(cb.embed[:8].cpu().numpy(), g["cb_embed_head"], rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.bf16x3
 def test_weight_norm_bank_step_equals_per_layer_step(golden_dir, monkeypatch):
     """The batched weight normalisation (WeightNormBank: one launch per phase for all layers' w = g v/|v|, one for all
-    (dv, dg)) against the per-layer launches it replaces: same losses, gradient norms and parameter updates."""
+    (dv, dg)) and the weight-split cache (one launch per phase for all bf16 hi/lo weight copies) against the per-layer /
+    per-call launches they replace: same losses, gradient norms and parameter updates."""
     res = {}
-    for bank in ("0", "1"):
+    for bank, cache in (("0", "0"), ("1", "0"), ("1", "1")):
         monkeypatch.setenv("TTTS_WN_BANK", bank)
+        monkeypatch.setenv("TTTS_WSPLIT_CACHE", cache)
+        monkeypatch.setenv("TTTS_WGRAD_ARENA", cache)
+        monkeypatch.setenv("TTTS_WGRAD_ARENA_MB", "8192,2048,1024,64")
         g, tr, data, inject = _step_setup(golden_dir)
         assert (tr.step_fn.bank_g is not None) == (bank == "1")
-        outs = [tr.train_step(data, inject) for _ in range(2)]        # two steps: the bank's buffers are re-used across steps
-        res[bank] = ([{k: float(v) for k, v in o.items()} for o in outs], tr.optim_g.flat_p.clone(), tr.optim_d.flat_p.clone())
-    for a, b in zip(res["0"][0], res["1"][0]):
-        for k in a:
-            np.testing.assert_allclose(b[k], a[k], rtol=2e-5, err_msg=k)
-    for i in (1, 2):
-        a, b = res["0"][i], res["1"][i]
-        # Adam's first steps move an element by ~lr whatever the gradient's size; elements whose gradient is rounding noise may flip
-        assert ((a - b).abs() > 1e-5).float().mean().item() < 2e-3
+        assert bool(tr.step_fn.wsplit_g) == (cache == "1")
+        outs = [tr.train_step(data, inject) for _ in range(2)]        # two steps: the persistent buffers are re-used across steps
+        key = bank + cache
+        res[key] = ([{k: float(v) for k, v in o.items()} for o in outs], tr.optim_g.flat_p.clone(), tr.optim_d.flat_p.clone())
+        if cache == "1":
+            st = [c.stats() for c in tr.step_fn.wsplit_g + tr.step_fn.wsplit_d]
+            assert all(s_["entries"] > 0 and s_["hits"] >= s_["entries"] for s_ in st), st      # step 2 ran on the cached splits
+            assert all(s_["misses"] == s_["entries"] for s_ in st), st                          # nothing fell back to per-call splits
+            sl = [a.stats() for a in tr.step_fn.slabs_g + tr.step_fn.slabs_d]
+            assert sum(s_["deferred"] for s_ in sl) > 0 and all(s_["partial_reduces"] == 0 for s_ in sl), sl
+            assert sum(s_["fallbacks"] for s_ in sl) * 20 <= sum(s_["deferred"] for s_ in sl), sl
+            # outside a step the cache is disarmed: a forward after the parameters changed must not see stale splits
+            with torch.no_grad():
+                for prm in tr.net_g.dec.parameters():
+                    prm.mul_(0.5)
+            h = tr.hps.data
+            from ttts_amd.utils.data_utils import spectrogram_torch
+            spec = spectrogram_torch(data["wav"], h.filter_length, h.hop_length, h.win_length)
+            with torch.no_grad():
+                o2 = tr.net_g(data["wav"], data["wav"], data["wav_lengths"], spec, spec, data["wav_lengths"] // h.hop_length,
+                              data["text"], data["text_lengths"], **inject)[0]
+            assert [c.stats()["hits"] for c in tr.step_fn.wsplit_g] == [s_["hits"] for s_ in st[:len(tr.step_fn.wsplit_g)]]
+            assert torch.isfinite(o2).all()
+    for key in ("10", "11"):
+        for a, b in zip(res["00"][0], res[key][0]):
+            for k in a:
+                # (not bit-equal: split-K atomics order differs run to run, and a 2^-17 change of a pre-activation flips leaky-relu gates)
+                np.testing.assert_allclose(b[k], a[k], rtol=2e-3, err_msg=k + " " + key)
+        for i in (1, 2):
+            a, b = res["00"][i], res[key][i]
+            # Adam's first steps move an element by ~lr whatever the gradient's size; elements whose gradient is rounding noise may flip
+            assert ((a - b).abs() > 1e-5).float().mean().item() < 2e-3
 
 
 def test_synthesizer_infer_and_decode_match_reference_fixture(golden_dir):

@@ -35,4 +35,6 @@ frames = B * (163840 // 640)
 print(json.dumps({"metric": "vqvae_gan_train_frames_per_s", "value": frames / dt, "unit": "frames/s", "ms_per_step": dt * 1e3,
                   "batch": B, "steps": steps, "warmup": warmup, "dtype": "f32 (conv products split-bf16 hi/lo x3 on the bf16 MFMA, fp32 accumulate; TTTS_CONV_FP32=1 for exact fp32 MFMA)", "data": "synthetic",
                   "tflops_algorithmic": 1.97e9 * frames / dt / 1e12, "max_mem_gb": torch.cuda.max_memory_allocated() / 2**30,
+                  "launch_batching": {"wsplit": [c.stats() for c in tr.step_fn.wsplit_g + tr.step_fn.wsplit_d],
+                                      "slabs": [a.stats() for a in tr.step_fn.slabs_g + tr.step_fn.slabs_d]},
                   "losses": {k: float(v) for k, v in out.items()}}))

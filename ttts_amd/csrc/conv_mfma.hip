@@ -14,6 +14,9 @@
 // same fused epilogue (bias, per-sample bias, leaky-relu gate, residual, tanh / leaky-relu, sequence mask, scale,
 // accumulate) as the direct kernels.
 #include <algorithm>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
 
 #include "common.hpp"
 
@@ -235,6 +238,117 @@ __global__ __launch_bounds__(256) void conv_weight_split_kernel(const float* __r
     a_hi[i] = h;
     a_lo[i] = (bf16)(v - (float)h);
   }
+}
+
+// ---- weight-split cache (ABI v8) -----------------------------------------------------------------------------------------
+// A training step calls every convolution's forward once and its data gradient once, each preceded by a ~5 us
+// conv_weight_split_kernel launch (1300 launches, 6.6 ms of a 160 ms VQ-VAE-GAN step).  The weights only change at known
+// points (the optimizer step, WeightNormBank.refresh), so the host registers the arrays they live in; the first call with a
+// given (weight pointer, layout) records a descriptor and a persistent destination, and from then on ONE launch at the phase
+// start (ttts_conv_wsplit_cache_refresh) rewrites every recorded split.  A disarmed cache (outside a step: the arrays may have
+// changed without a refresh) and any miss during stream capture fall back to the per-call split in scratch.
+struct WsplitDesc {
+  const float* w; bf16* hi; bf16* lo;
+  int M, N, Mpad, nblk, K, Kmem, transposed, tap_off, tap_stride, AP;
+  int block_begin, pad_;
+};
+constexpr int WSPLIT_EPB = 2048;      // elements per workgroup of the batched launch (8 per thread)
+
+__global__ __launch_bounds__(256) void conv_weight_split_batched_kernel(const WsplitDesc* __restrict__ table, int n_desc) {
+  int lo = 0, hi = n_desc - 1;        // last descriptor with block_begin <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const WsplitDesc d = table[lo];
+  const int64_t total = (int64_t)d.nblk * d.Mpad * d.AP;
+  const int64_t i = ((int64_t)(blockIdx.x - d.block_begin) * 256 + threadIdx.x) * 8;     // AP % 8 == 0: one (row, tap, half) run
+  if (i >= total) return;
+  const int e = (int)(i % d.AP), m = (int)(i / d.AP % d.Mpad), nb = (int)(i / d.AP / d.Mpad);
+  const int c0 = e & 15, k = e >> 4;
+  bf16x8 h, l;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int n = nb * 16 + c0 + c;
+    float v = 0.f;
+    if (k < d.K && m < d.M && n < d.N)
+      v = d.transposed ? d.w[((int64_t)n * d.M + m) * d.Kmem + d.tap_off + d.tap_stride * (d.K - 1 - k)]
+                       : d.w[((int64_t)m * d.N + n) * d.Kmem + k];
+    const bf16 hv = (bf16)v;
+    h[c] = hv;
+    l[c] = (bf16)(v - (float)hv);
+  }
+  *reinterpret_cast<bf16x8*>(d.hi + i) = h;
+  *reinterpret_cast<bf16x8*>(d.lo + i) = l;
+}
+
+struct WsplitKey {
+  const float* w; int M, N, Mpad, K, Kmem, transposed, tap_off, tap_stride, AP;
+  bool operator==(const WsplitKey& o) const {
+    return w == o.w && M == o.M && N == o.N && Mpad == o.Mpad && K == o.K && Kmem == o.Kmem && transposed == o.transposed &&
+           tap_off == o.tap_off && tap_stride == o.tap_stride && AP == o.AP;
+  }
+};
+struct WsplitKeyHash {
+  size_t operator()(const WsplitKey& k) const {
+    uint64_t h = reinterpret_cast<uint64_t>(k.w) * 0x9E3779B97F4A7C15ull;
+    for (int v : {k.M, k.N, k.Mpad, k.K, k.Kmem, k.transposed, k.tap_off, k.tap_stride, k.AP}) h = (h ^ (uint64_t)(uint32_t)v) * 0x100000001B3ull;
+    return (size_t)h;
+  }
+};
+struct WsplitCache {
+  const char* w_lo; const char* w_hi;
+  char* storage; int64_t bytes, used;       // [descriptor table: max_entries][256-byte aligned split arrays ...]
+  int max_entries;
+  bool armed = false;
+  std::vector<WsplitDesc> host;
+  std::unordered_map<WsplitKey, int, WsplitKeyHash> index;
+  int64_t blocks = 0, hits = 0, misses = 0, launches_saved = 0;
+};
+static std::mutex g_wsplit_mu;
+static std::vector<WsplitCache*> g_wsplit;
+
+// (hi, lo) of the persistent split of this call's weights, or false: split into scratch as before.  *need_split: the caller
+// launches the split itself (a descriptor recorded by this very call; the next refresh covers it).
+static bool wsplit_lookup(const ConvMfmaParams& p, int nblk, int AP, int64_t elems_alloc, hipStream_t stream, bf16** hi,
+                          bf16** lo, bool* need_split) {
+  std::lock_guard<std::mutex> g(g_wsplit_mu);
+  const char* wp = reinterpret_cast<const char*>(p.w);
+  for (WsplitCache* c : g_wsplit) {
+    if (wp < c->w_lo || wp >= c->w_hi) continue;
+    if (!c->armed) return false;
+    const WsplitKey key{p.w, p.M, p.N, p.Mpad, p.K, p.Kmem, p.transposed, p.tap_off, p.tap_stride, AP};
+    auto it = c->index.find(key);
+    if (it != c->index.end()) {
+      const WsplitDesc& d = c->host[it->second];
+      *hi = d.hi; *lo = d.lo; *need_split = false;
+      ++c->hits;
+      return true;
+    }
+    ++c->misses;
+    const int64_t need = ((2 * elems_alloc * (int64_t)sizeof(bf16) + 255) / 256) * 256;
+    if ((int)c->host.size() >= c->max_entries || c->used + need > c->bytes) return false;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
+    WsplitDesc d;
+    d.w = p.w; d.hi = reinterpret_cast<bf16*>(c->storage + c->used); d.lo = d.hi + elems_alloc;
+    d.M = p.M; d.N = p.N; d.Mpad = p.Mpad; d.nblk = nblk; d.K = p.K; d.Kmem = p.Kmem; d.transposed = p.transposed;
+    d.tap_off = p.tap_off; d.tap_stride = p.tap_stride; d.AP = AP; d.pad_ = 0;
+    d.block_begin = (int)c->blocks;
+    const int idx = (int)c->host.size();
+    c->host.push_back(d);                     // (reserved to max_entries: the element never moves under the copy below)
+    if (hipMemcpyAsync(c->storage + (int64_t)idx * sizeof(WsplitDesc), &c->host[idx], sizeof(WsplitDesc), hipMemcpyHostToDevice,
+                       stream) != hipSuccess) {
+      c->host.pop_back();
+      return false;
+    }
+    c->blocks += cdiv((int64_t)nblk * p.Mpad * AP, WSPLIT_EPB);
+    c->used += need;
+    c->index.emplace(key, idx);
+    *hi = d.hi; *lo = d.lo; *need_split = true;
+    return true;
+  }
+  return false;
 }
 
 // fused epilogue of the split-bf16 kernels: two 32 x 32 accumulators of a wave (positions wl*64 + {0, 32} + col)
@@ -762,9 +876,12 @@ static int conv1d_bf16x3_dma_launch(ConvMfmaParams p, const ConvCtx& cx, hipStre
   bf16* xlo = xhi + xel;                       // that the phases of a strided data gradient can share it)
   bf16* hi = xlo + xel;
   bf16* lo = hi + welems;
+  bool need_split = true;
+  wsplit_lookup(p, nblk, AP, welems, stream, &hi, &lo, &need_split);      // (persistent copies when the weights are cached)
   p.a_hi = hi; p.a_lo = lo;
-  conv_weight_split_kernel<<<(int)std::min<int64_t>(cdiv(welems, 256), 2048), 256, 0, stream>>>(p.w, hi, lo, p.M, p.N, p.Mpad, nblk, K, p.Kmem,
-                                                                                             p.transposed, p.tap_off, p.tap_stride, AP);
+  if (need_split)
+    conv_weight_split_kernel<<<(int)std::min<int64_t>(cdiv(welems, 256), 2048), 256, 0, stream>>>(p.w, hi, lo, p.M, p.N, p.Mpad, nblk, K, p.Kmem,
+                                                                                               p.transposed, p.tap_off, p.tap_stride, AP);
   if (!p.x_hi) {   // (polyphase data gradients share one split of dy across their phase launches)
     conv_input_split_kernel<<<(int)std::min<int64_t>(cdiv(xel / 16, 256), 8192), 256, 0, stream>>>(p.x, xhi, xlo, p.B, p.N, p.Lin, nblk, p.in_slope,
                                                                                                    p.Lp, p.PADL, cat_w, cat_b, cat_l);
@@ -813,9 +930,12 @@ static int conv1d_bf16x3_launch_t(ConvMfmaParams p, const ConvCtx& cx, hipStream
   if (2 * elems * (int64_t)sizeof(bf16) > cx.ws_bytes) return TTTS_OK;
   bf16* hi = static_cast<bf16*>(cx.ws);
   bf16* lo = hi + elems;
+  bool need_split = true;
+  wsplit_lookup(p, nblk, K * 16, elems, stream, &hi, &lo, &need_split);
   p.a_hi = hi; p.a_lo = lo;
-  conv_weight_split_kernel<<<(int)std::min<int64_t>(cdiv(elems, 256), 2048), 256, 0, stream>>>(p.w, hi, lo, p.M, p.N, p.Mpad, nblk, K, p.Kmem,
-                                                                                            p.transposed, p.tap_off, p.tap_stride, K * 16);
+  if (need_split)
+    conv_weight_split_kernel<<<(int)std::min<int64_t>(cdiv(elems, 256), 2048), 256, 0, stream>>>(p.w, hi, lo, p.M, p.N, p.Mpad, nblk, K, p.Kmem,
+                                                                                              p.transposed, p.tap_off, p.tap_stride, K * 16);
   dim3 grid((unsigned)cdiv(p.Lout, SEG == LT ? LT : SEG), (unsigned)cdiv(p.M, MT), (unsigned)cdiv(p.B, LT / SEG));
   int rc = TTTS_OK;
 #define TTTS_V1(KT_)                                                                                 \
@@ -943,16 +1063,15 @@ int conv1d_dgrad_strided_mfma_try(const float* dy, const float* w, const float* 
 //              (PL = roundup_stride(pad)); the odd copy lets every row segment start on a 4-byte boundary
 // (2-D grids: blockIdx.y walks rows, a thread converts two adjacent elements -- the flat-index form spent most of its time in
 // 64-bit divisions)
-__global__ __launch_bounds__(256) void wgrad_split_dy_kernel(const float* __restrict__ dy, bf16* __restrict__ hi,
-                                                             bf16* __restrict__ lo, int64_t rows, int Lout, int Lq, float slope,
-                                                             float* __restrict__ db, int Cout) {
+__device__ __forceinline__ void wgrad_split_dy_body(const float* __restrict__ dy, bf16* __restrict__ hi,
+                                                    bf16* __restrict__ lo, int64_t rows, int Lout, int Lq, float slope,
+                                                    float* __restrict__ db, int Cout, int bx, int by, int gy, float* sh) {
   // db != NULL (slope == 1): the layer's bias gradient, db[row % Cout] += sum of the row -- this pass reads all of dy anyway.
-  // gridDim.y is a multiple of Cout then, so every row a workgroup walks belongs to the same channel.
-  __shared__ float sh[4];
-  const int l = (blockIdx.x * 256 + threadIdx.x) * 2;
+  // gy is a multiple of Cout then, so every row a workgroup walks belongs to the same channel.
+  const int l = (bx * 256 + threadIdx.x) * 2;
   float bs = 0.f;
   if (l < Lq) {
-    for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+    for (int64_t r = by; r < rows; r += gy) {
       const float* src = dy + r * Lout;
       const float v0 = l < Lout ? lrelu_f(src[l], slope) : 0.f, v1 = l + 1 < Lout ? lrelu_f(src[l + 1], slope) : 0.f;
       bs += v0 + v1;
@@ -967,19 +1086,19 @@ __global__ __launch_bounds__(256) void wgrad_split_dy_kernel(const float* __rest
     bs = wave_sum(bs);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = bs;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(db + blockIdx.y % Cout, (sh[0] + sh[1]) + (sh[2] + sh[3]));
+    if (threadIdx.x == 0) atomicAdd(db + by % Cout, (sh[0] + sh[1]) + (sh[2] + sh[3]));
   }
 }
-// blockIdx.z = parity copy * stride + phase
-__global__ __launch_bounds__(256) void wgrad_split_x_kernel(const float* __restrict__ x, bf16* __restrict__ hi,
-                                                            bf16* __restrict__ lo, int64_t rows, int Lin, int stride, int Li,
-                                                            int PL, float slope) {
-  const int ii = (blockIdx.x * 256 + threadIdx.x) * 2;
+// bz = parity copy * stride + phase
+__device__ __forceinline__ void wgrad_split_x_body(const float* __restrict__ x, bf16* __restrict__ hi,
+                                                   bf16* __restrict__ lo, int64_t rows, int Lin, int stride, int Li,
+                                                   int PL, float slope, int bx, int by, int bz, int gy) {
+  const int ii = (bx * 256 + threadIdx.x) * 2;
   if (ii >= Li) return;
-  const int par = blockIdx.z / stride, r = blockIdx.z % stride;
+  const int par = bz / stride, r = bz % stride;
   const int64_t per = rows * stride * Li;
   const int64_t q0 = (int64_t)(ii + par) * stride + r - PL, q1 = q0 + stride;
-  for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {
+  for (int64_t row = by; row < rows; row += gy) {
     const float* src = x + row * Lin;
     const float v0 = (q0 >= 0 && q0 < Lin) ? lrelu_f(src[q0], slope) : 0.f;
     const float v1 = (q1 >= 0 && q1 < Lin) ? lrelu_f(src[q1], slope) : 0.f;
@@ -991,17 +1110,34 @@ __global__ __launch_bounds__(256) void wgrad_split_x_kernel(const float* __restr
     *reinterpret_cast<bf16x2*>(lo + o) = w;
   }
 }
+// Both operand splits of a weight gradient in ONE launch (they were two ~5 us launches per layer): workgroups [0, nb_dy) split
+// dy, the rest x; each role decodes its own (x, y, z) block coordinates from the flat index.
+struct WgradSplitPair {
+  const float* dy; bf16* dyh; bf16* dyl; int64_t rows_dy; int Lout, Lq; float dy_slope; float* db; int Cout;
+  int nbx_dy, gy_dy, nb_dy;
+  const float* x; bf16* xh; bf16* xl; int64_t rows_x; int Lin, stride, Li, PL; float x_slope;
+  int nbx_x, gy_x;
+};
+__global__ __launch_bounds__(256) void wgrad_split_pair_kernel(WgradSplitPair p) {
+  __shared__ float sh[4];
+  const int id = blockIdx.x;
+  if (id < p.nb_dy) {
+    wgrad_split_dy_body(p.dy, p.dyh, p.dyl, p.rows_dy, p.Lout, p.Lq, p.dy_slope, p.db, p.Cout, id % p.nbx_dy, id / p.nbx_dy, p.gy_dy, sh);
+  } else {
+    const int j = id - p.nb_dy, bx = j % p.nbx_x, t = j / p.nbx_x;
+    wgrad_split_x_body(p.x, p.xh, p.xl, p.rows_x, p.Lin, p.stride, p.Li, p.PL, p.x_slope, bx, t % p.gy_x, t / p.gy_x, p.gy_x);
+  }
+}
 // Short rows (DiscriminatorP: 23..127 positions, hundreds of rows): the batch elements of a channel are laid end to end as ONE
 // virtual row, Lg = Lout + (K-1)*dil positions apart (zeros in between, so taps never reach the next element):
 //   dy'[co][b*Lg + j] = dy[b][co][j],   x'[ci][b*Lg + j] = x[b][ci][j - pad]
 // and sum_v dy'[v] x'[v + k*dil] is exactly the batch-summed weight gradient.  The all-taps kernel then runs with B = 1 and
 // 64-position chunks that are ~full instead of one mostly-padding chunk per row (L = 23: 36 % -> 85 % useful positions).
-__global__ __launch_bounds__(256) void wgrad_split_cat_kernel(const float* __restrict__ src, bf16* __restrict__ hi, bf16* __restrict__ lo,
-                                                              int B, int C, int L, int Lg, int shift, int Lrow, float slope,
-                                                              float* __restrict__ db, int S) {
-  // blockIdx.y = channel * S + phase; element v of the virtual row: b = v / Lg, j = v % Lg, source position j*S + phase - shift
-  __shared__ float sh[4];
-  const int c = blockIdx.y / S, ph = blockIdx.y % S, v0 = (blockIdx.x * 256 + threadIdx.x) * 2;
+__device__ __forceinline__ void wgrad_split_cat_body(const float* __restrict__ src, bf16* __restrict__ hi, bf16* __restrict__ lo,
+                                                     int B, int C, int L, int Lg, int shift, int Lrow, float slope,
+                                                     float* __restrict__ db, int S, int bx, int by, float* sh) {
+  // by = channel * S + phase; element v of the virtual row: b = v / Lg, j = v % Lg, source position j*S + phase - shift
+  const int c = by / S, ph = by % S, v0 = (bx * 256 + threadIdx.x) * 2;
   float bs = 0.f;
   if (v0 < Lrow) {
     float val[2];
@@ -1016,8 +1152,8 @@ __global__ __launch_bounds__(256) void wgrad_split_cat_kernel(const float* __res
     bf16x2 h, w;
     h[0] = (bf16)val[0]; h[1] = (bf16)val[1];
     w[0] = (bf16)(val[0] - (float)h[0]); w[1] = (bf16)(val[1] - (float)h[1]);
-    *reinterpret_cast<bf16x2*>(hi + (int64_t)blockIdx.y * Lrow + v0) = h;
-    *reinterpret_cast<bf16x2*>(lo + (int64_t)blockIdx.y * Lrow + v0) = w;
+    *reinterpret_cast<bf16x2*>(hi + (int64_t)by * Lrow + v0) = h;
+    *reinterpret_cast<bf16x2*>(lo + (int64_t)by * Lrow + v0) = w;
   }
   if (db) {
     bs = wave_sum(bs);
@@ -1027,14 +1163,35 @@ __global__ __launch_bounds__(256) void wgrad_split_cat_kernel(const float* __res
   }
 }
 
+struct WgradCatSide { const float* src; bf16* hi; bf16* lo; int C, L, shift, Lrow; float slope; float* db; int S, nbx, nb; };
+__global__ __launch_bounds__(256) void wgrad_split_cat_pair_kernel(WgradCatSide a, WgradCatSide b, int B, int Lg) {
+  __shared__ float sh[4];          // (both sides of a weight gradient in one launch: workgroups [0, a.nb) lay out dy, the rest x)
+  const int id = blockIdx.x;
+  if (id < a.nb) wgrad_split_cat_body(a.src, a.hi, a.lo, B, a.C, a.L, Lg, a.shift, a.Lrow, a.slope, a.db, a.S, id % a.nbx, id / a.nbx, sh);
+  else wgrad_split_cat_body(b.src, b.hi, b.lo, B, b.C, b.L, Lg, b.shift, b.Lrow, b.slope, b.db, b.S, (id - a.nb) % b.nbx, (id - a.nb) / b.nbx, sh);
+}
+static void launch_wgrad_cat_pair(const float* dy, bf16* dyh, bf16* dyl, int Cout, int Lout, int Lq, float dy_slope, float* db,
+                                  const float* x, bf16* xh, bf16* xl, int Cin, int Lin, int shift, int Li, float x_slope, int S, int B,
+                                  int Lg, hipStream_t stream) {
+  WgradCatSide a{dy, dyh, dyl, Cout, Lout, 0, Lq, dy_slope, db, 1, (int)cdiv(Lq / 2, 256), 0};
+  a.nb = a.nbx * Cout;
+  WgradCatSide b{x, xh, xl, Cin, Lin, shift, Li, x_slope, nullptr, S, (int)cdiv(Li / 2, 256), 0};
+  b.nb = b.nbx * Cin * S;
+  wgrad_split_cat_pair_kernel<<<(unsigned)(a.nb + b.nb), 256, 0, stream>>>(a, b, B, Lg);
+}
+
 static void launch_wgrad_splits(const float* dy, const float* x, bf16* dyh, bf16* dyl, bf16* xh, bf16* xl, int64_t rows_dy, int Lout,
                                 int Lq, float dy_slope, int64_t rows_x, int Lin, int stride, int Li, int PL, float x_slope, int npar,
                                 float* db, int Cout, hipStream_t stream) {
   int64_t gy = std::min<int64_t>(rows_dy, 32768);
   if (db && gy < rows_dy) gy = std::max<int64_t>(Cout, gy / Cout * Cout);       // rows r, r + gy, ... share a channel
-  wgrad_split_dy_kernel<<<dim3((unsigned)cdiv(Lq / 2, 256), (unsigned)gy), 256, 0, stream>>>(dy, dyh, dyl, rows_dy, Lout, Lq, dy_slope, db, Cout);
-  wgrad_split_x_kernel<<<dim3((unsigned)cdiv(Li / 2, 256), (unsigned)std::min<int64_t>(rows_x, 32768), (unsigned)(npar * stride)), 256, 0, stream>>>(
-      x, xh, xl, rows_x, Lin, stride, Li, PL, x_slope);
+  WgradSplitPair p;
+  p.dy = dy; p.dyh = dyh; p.dyl = dyl; p.rows_dy = rows_dy; p.Lout = Lout; p.Lq = Lq; p.dy_slope = dy_slope; p.db = db; p.Cout = Cout;
+  p.nbx_dy = (int)cdiv(Lq / 2, 256); p.gy_dy = (int)gy; p.nb_dy = p.nbx_dy * p.gy_dy;
+  p.x = x; p.xh = xh; p.xl = xl; p.rows_x = rows_x; p.Lin = Lin; p.stride = stride; p.Li = Li; p.PL = PL; p.x_slope = x_slope;
+  p.nbx_x = (int)cdiv(Li / 2, 256); p.gy_x = (int)std::min<int64_t>(rows_x, 32768);
+  const int64_t nb = (int64_t)p.nb_dy + (int64_t)p.nbx_x * p.gy_x * npar * stride;
+  wgrad_split_pair_kernel<<<(unsigned)nb, 256, 0, stream>>>(p);
 }
 
 struct WgradB3Params {
@@ -1448,6 +1605,146 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __r
   }
 }
 
+// ---- deferred slab reduction (ABI v8) -------------------------------------------------------------------------------------
+// Every split-bf16 weight-gradient launch used to be followed by its own wgrad_slab_reduce launch over slabs in the shared
+// scratch (543 launches, 5.9 ms of a VQ-VAE-GAN step, most of them far too small to use the memory system).  The host
+// registers the array the gradients accumulate into (a WeightNormBank's flat dW, the optimizer's gradient arena); while the
+// arena is ARMED a weight-gradient call writes its slabs to a PERSISTENT slot (recorded on first sight, keyed by (dw, shape,
+// splits)) and skips the reduce, and ttts_conv_wgrad_arena_reduce sums every layer touched since _begin in one launch.
+struct SlabDesc {
+  const float* slab; float* dw; const float* bslab; float* db;
+  int nsplit, K, Cout, Cin;
+  int block_begin, pad_;
+};
+constexpr int SLABB_EPB = 64;        // elements per workgroup: wave g sums splits g, g + 4, ... of 64 consecutive elements
+
+__global__ __launch_bounds__(256) void wgrad_slab_reduce_batched_kernel(const SlabDesc* __restrict__ table, int n_desc, int block_base) {
+  __shared__ float part[4][SLABB_EPB];
+  const int gb = (int)blockIdx.x + block_base;       // (block_base: a launch over a single descriptor of the table)
+  int lo = 0, hi = n_desc - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].block_begin <= gb) lo = mid; else hi = mid - 1;
+  }
+  const SlabDesc d = table[lo];
+  const int64_t per = (int64_t)d.K * d.Cout * d.Cin;
+  const int nblk_w = (int)((per + SLABB_EPB - 1) / SLABB_EPB);
+  const int lb = gb - d.block_begin;
+  const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const bool bias_blk = lb >= nblk_w;          // trailing workgroups of a layer: its bias gradient [split][Cout] -> db
+  const float* src = bias_blk ? d.bslab : d.slab;
+  const int64_t len = bias_blk ? d.Cout : per;
+  const int64_t i = (int64_t)(bias_blk ? lb - nblk_w : lb) * SLABB_EPB + e;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (i < len) {
+    int sp = g;
+    for (; sp + 12 < d.nsplit; sp += 16) {
+      const float v0 = src[sp * len + i], v1 = src[(sp + 4) * len + i], v2 = src[(sp + 8) * len + i], v3 = src[(sp + 12) * len + i];
+      a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+    }
+    for (; sp < d.nsplit; sp += 4) a0 += src[sp * len + i];
+  }
+  part[g][e] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (g == 0 && i < len) {
+    const float sum = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+    if (bias_blk) {
+      d.db[i] += sum;
+    } else {
+      const int ci = (int)(i % d.Cin), co = (int)((i / d.Cin) % d.Cout), k = (int)(i / d.Cin / d.Cout);
+      d.dw[((int64_t)co * d.Cin + ci) * d.K + k] += sum;
+    }
+  }
+}
+
+struct SlabKey {
+  const float* dw; const float* db; int nsplit, K, Cout, Cin;
+  bool operator==(const SlabKey& o) const {
+    return dw == o.dw && db == o.db && nsplit == o.nsplit && K == o.K && Cout == o.Cout && Cin == o.Cin;
+  }
+};
+struct SlabKeyHash {
+  size_t operator()(const SlabKey& k) const {
+    uint64_t h = reinterpret_cast<uint64_t>(k.dw) * 0x9E3779B97F4A7C15ull ^ reinterpret_cast<uint64_t>(k.db);
+    for (int v : {k.nsplit, k.K, k.Cout, k.Cin}) h = (h ^ (uint64_t)(uint32_t)v) * 0x100000001B3ull;
+    return (size_t)h;
+  }
+};
+struct SlabArena {
+  const char* dw_lo; const char* dw_hi;
+  char* storage; int64_t bytes, used;       // [descriptor table: max_entries][slabs ...]
+  int max_entries;
+  bool armed = false;
+  std::vector<SlabDesc> host;
+  std::vector<uint8_t> touched;
+  int n_touched = 0;
+  std::unordered_map<SlabKey, int, SlabKeyHash> index;
+  int64_t blocks = 0, deferred = 0, fallbacks = 0, partial_reduces = 0;
+};
+static std::mutex g_slab_mu;
+static std::vector<SlabArena*> g_slab;
+
+static int slab_desc_blocks(const SlabDesc& d) {
+  return (int)(cdiv((int64_t)d.K * d.Cout * d.Cin, SLABB_EPB) + (d.bslab ? cdiv(d.Cout, SLABB_EPB) : 0));
+}
+
+// The persistent slab of this weight-gradient call when its reduce can be deferred (then *bslab_out is the matching bias slab,
+// or NULL without `db`), else NULL: slabs in scratch and an immediate reduce, as before.
+static float* slab_defer(float* dw, float* db, bool want_bslab, int nsplit, int K, int Cout, int Cin, hipStream_t stream,
+                         float** bslab_out) {
+  std::lock_guard<std::mutex> g(g_slab_mu);
+  const char* wp = reinterpret_cast<const char*>(dw);
+  if (want_bslab) {          // the bias gradient is summed later too: only into a persistent (registered) gradient array
+    const char* bp = reinterpret_cast<const char*>(db);
+    bool ok = false;
+    for (SlabArena* c : g_slab) ok = ok || (bp >= c->dw_lo && bp < c->dw_hi);
+    if (!ok) return nullptr;
+  }
+  for (SlabArena* c : g_slab) {
+    if (wp < c->dw_lo || wp >= c->dw_hi) continue;
+    if (!c->armed) return nullptr;
+    const SlabKey key{dw, want_bslab ? db : nullptr, nsplit, K, Cout, Cin};
+    auto it = c->index.find(key);
+    int idx;
+    if (it != c->index.end()) {
+      idx = it->second;
+      if (c->touched[idx]) { ++c->fallbacks; return nullptr; }     // a second gradient into the same dw in this phase
+    } else {
+      const int64_t per = (int64_t)K * Cout * Cin;
+      const int64_t need = (((int64_t)nsplit * (per + (want_bslab ? Cout : 0)) * (int64_t)sizeof(float) + 255) / 256) * 256;
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      if ((int)c->host.size() >= c->max_entries || c->used + need > c->bytes ||
+          hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+        ++c->fallbacks;
+        return nullptr;
+      }
+      SlabDesc d;
+      float* slab = reinterpret_cast<float*>(c->storage + c->used);
+      d.slab = slab; d.dw = dw; d.bslab = want_bslab ? slab + (int64_t)nsplit * per : nullptr; d.db = want_bslab ? db : nullptr;
+      d.nsplit = nsplit; d.K = K; d.Cout = Cout; d.Cin = Cin; d.pad_ = 0;
+      d.block_begin = (int)c->blocks;
+      idx = (int)c->host.size();
+      c->host.push_back(d);
+      if (hipMemcpyAsync(c->storage + (int64_t)idx * sizeof(SlabDesc), &c->host[idx], sizeof(SlabDesc), hipMemcpyHostToDevice,
+                         stream) != hipSuccess) {
+        c->host.pop_back();
+        ++c->fallbacks;
+        return nullptr;
+      }
+      c->touched.push_back(0);
+      c->blocks += slab_desc_blocks(d);
+      c->used += need;
+      c->index.emplace(key, idx);
+    }
+    c->touched[idx] = 1;
+    ++c->n_touched;
+    ++c->deferred;
+    *bslab_out = const_cast<float*>(c->host[idx].bslab);
+    return const_cast<float*>(c->host[idx].slab);
+  }
+  return nullptr;
+}
+
 template <int K, int DIL, int K0, int KN, int TILE, int S = 1, int PO = 0>
 static void launch_wgrad_taps_one(const WgradB3Params& p, dim3 grid, hipStream_t stream) {
   constexpr int BASE = S > 1 ? 0 : (K0 * DIL) / 8 * 8, WIN = S > 1 ? 64 + (K0 + KN - 1 + PO) / S : 64 + (K0 + KN - 1) * DIL - BASE;
@@ -1480,6 +1777,9 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, f
                                    const ConvCtx& cx, hipStream_t stream, bool* handled) {
   *handled = false;
   if (!cx.ws || (cx.flags & 4096)) return TTTS_OK;
+  // workgroups a launch aims for when it splits the reduction: 512 = two per CU; flag 536870912: one per CU (half the slab
+  // traffic, less latency hiding -- tools/gpu_ab_vq.sh)
+  const int wg_target = (cx.flags & 536870912) ? 256 : (cx.flags & 1073741824) ? 1024 : 512;   // (flag 1073741824: four per CU)
   // all-taps kernel: stride 1, the ResBlock1 family (K in {3, 7, 11}, dilation in {1, 3, 5}).  64 x 64 tiles from 128
   // channels (measured 1.9x over one tap per workgroup at C = 128 / 256); 32 x 32 tiles below (16..96-channel long rows: the
   // exact-fp32 MFMA kernel they used to take ran at 15-60 TF/s).  Flag 16384: never; flag 1048576: not below 128 channels.
@@ -1493,12 +1793,15 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, f
     const int CH = (Lout > 64 && !(K == 11 && dil >= 3)) ? 128 : 64;   // (K = 11 with dilation 3 / 5 would spill at 128)
     const int nlc = (int)cdiv(Lout, CH), nchunks = B * nlc;
     const int tiles = (int)(cdiv(Cin, 32) * cdiv(Cout, 32));
-    const int splits = (int)std::max<int64_t>(1, std::min<int64_t>(nchunks, cdiv(512, tiles)));
+    const int splits = (int)std::max<int64_t>(1, std::min<int64_t>(nchunks, cdiv(wg_target, tiles)));
     const int cpb = (int)cdiv(nchunks, splits), nsplit = (int)cdiv(nchunks, cpb);
     const int64_t slab_bytes = (int64_t)nsplit * (K * Cout * Cin + Cout) * (int64_t)sizeof(float);
     if (slab_bytes <= cx.ws_bytes) {
       float* slab = static_cast<float*>(cx.ws);
       float* bslab = db ? slab + (int64_t)nsplit * K * Cout * Cin : nullptr;
+      float* pb = nullptr;
+      float* ps = slab_defer(dw, db, db != nullptr, nsplit, K, Cout, Cin, stream, &pb);     // (persistent slabs: reduce deferred)
+      if (ps) { slab = ps; bslab = pb; }
       WgradMfmaParams p{dy, x, dw, B, Cin, Lin, Cout, Lout, K, 1, pad, dil, dy_slope, x_slope, cpb, slab, 64, bslab};
       dim3 grid((unsigned)cdiv(Cin, 32), (unsigned)cdiv(Cout, 32), (unsigned)nsplit);
 #define TTTS_FUSED(KK, DD)                                                                               \
@@ -1509,7 +1812,7 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, f
       TTTS_FUSED(3, 1) TTTS_FUSED(3, 3) TTTS_FUSED(3, 5) TTTS_FUSED(7, 1) TTTS_FUSED(7, 3) TTTS_FUSED(7, 5)
       TTTS_FUSED(11, 1) TTTS_FUSED(11, 3) TTTS_FUSED(11, 5)
 #undef TTTS_FUSED
-      wgrad_slab_reduce_kernel<<<dim3((unsigned)std::min<int64_t>(cdiv((int64_t)K * Cout * Cin, 256), 4096), (unsigned)cdiv(nsplit, SLAB_G)), 256, 0, stream>>>(slab, dw, nsplit, K, Cout, Cin, bslab, db);
+      if (!ps) wgrad_slab_reduce_kernel<<<dim3((unsigned)std::min<int64_t>(cdiv((int64_t)K * Cout * Cin, 256), 4096), (unsigned)cdiv(nsplit, SLAB_G)), 256, 0, stream>>>(slab, dw, nsplit, K, Cout, Cin, bslab, db);
       if (db) *db_done = true;
       *handled = true;
       return check_launch("conv1d_wgrad_fused_taps");
@@ -1526,7 +1829,7 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, f
     const int64_t dy_el = (int64_t)Bk * Cout * Lq, x_par = (int64_t)Bk * Cin * Li;
     const int nlc0 = Lq / 64, nchunks0 = Bk * nlc0;
     const int tiles0 = (int)(cdiv(Cin, 64) * cdiv(Cout, 64));
-    const int splits0 = (int)std::max<int64_t>(1, std::min<int64_t>(nchunks0, cdiv(512, tiles0)));
+    const int splits0 = (int)std::max<int64_t>(1, std::min<int64_t>(nchunks0, cdiv(wg_target, tiles0)));
     const int cpb0 = (int)cdiv(nchunks0, splits0);
     const int nsplit = (int)cdiv(nchunks0, cpb0);
     const int64_t slab_el = (int64_t)nsplit * K * Cout * Cin;
@@ -1537,21 +1840,23 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, f
       bf16* xh = dyl + (dy_el + 7) / 8 * 8;
       bf16* xl = xh + 2 * x_par;
       if (cat) {
-        wgrad_split_cat_kernel<<<dim3((unsigned)cdiv(Lq / 2, 256), (unsigned)Cout), 256, 0, stream>>>(dy, dyh, dyl, B, Cout, Lout, Lg, 0, Lq, dy_slope, db, 1);
-        wgrad_split_cat_kernel<<<dim3((unsigned)cdiv(Li / 2, 256), (unsigned)Cin), 256, 0, stream>>>(x, xh, xl, B, Cin, Lin, Lg, pad, Li, x_slope, nullptr, 1);
+        launch_wgrad_cat_pair(dy, dyh, dyl, Cout, Lout, Lq, dy_slope, db, x, xh, xl, Cin, Lin, pad, Li, x_slope, 1, B, Lg, stream);
       } else {
         launch_wgrad_splits(dy, x, dyh, dyl, xh, xl, (int64_t)B * Cout, Lout, Lq, dy_slope, (int64_t)B * Cin, Lin, 1, Li, pad, x_slope, 1, db, Cout, stream);
       }
       if (db) *db_done = true;
       const int nlc = nlc0, nchunks = nchunks0, cpb = cpb0;
       float* slab = reinterpret_cast<float*>(reinterpret_cast<char*>(xl + 2 * x_par) + ((16 - (reinterpret_cast<uintptr_t>(xl + 2 * x_par) & 15)) & 15));
+      float* pb = nullptr;
+      float* ps = slab_defer(dw, nullptr, false, nsplit, K, Cout, Cin, stream, &pb);
+      if (ps) slab = ps;
       WgradB3Params p{dyh, dyl, xh, xl, dw, Bk, Cin, Cout, K, 1, dil, Lq, Li, 0, x_par, cpb, nchunks, nlc, slab};
       dim3 grid((unsigned)cdiv(Cin, 64), (unsigned)cdiv(Cout, 64), (unsigned)nsplit);
 #define TTTS_TAPS(KK, DD) if (K == KK && dil == DD) launch_wgrad_taps<KK, DD>(p, grid, 64, stream);
       TTTS_TAPS(1, 1) TTTS_TAPS(3, 1) TTTS_TAPS(3, 3) TTTS_TAPS(3, 5) TTTS_TAPS(5, 1) TTTS_TAPS(7, 1) TTTS_TAPS(7, 3) TTTS_TAPS(7, 5)
       TTTS_TAPS(11, 1) TTTS_TAPS(11, 3) TTTS_TAPS(11, 5)
 #undef TTTS_TAPS
-      wgrad_slab_reduce_kernel<<<dim3((unsigned)std::min<int64_t>(cdiv((int64_t)K * Cout * Cin, 256), 4096), (unsigned)cdiv(nsplit, SLAB_G)), 256, 0, stream>>>(slab, dw, nsplit, K, Cout, Cin, nullptr, nullptr);
+      if (!ps) wgrad_slab_reduce_kernel<<<dim3((unsigned)std::min<int64_t>(cdiv((int64_t)K * Cout * Cin, 256), 4096), (unsigned)cdiv(nsplit, SLAB_G)), 256, 0, stream>>>(slab, dw, nsplit, K, Cout, Cin, nullptr, nullptr);
       *handled = true;
       return check_launch("conv1d_wgrad_bf16x3_taps");
     }
@@ -1569,7 +1874,7 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, f
     const int64_t dy_el = (int64_t)Bk * Cout * Lq, x_el = (int64_t)Bk * Cin * S * Li;
     const int nlc = Lq / 64, nchunks = Bk * nlc;
     const int tiles = (int)(cdiv(Cin, 64) * cdiv(Cout, 64));
-    const int splits = (int)std::max<int64_t>(1, std::min<int64_t>(nchunks, cdiv(512, tiles)));
+    const int splits = (int)std::max<int64_t>(1, std::min<int64_t>(nchunks, cdiv(wg_target, tiles)));
     const int cpb = (int)cdiv(nchunks, splits), nsplit = (int)cdiv(nchunks, cpb);
     const int64_t slab_el = (int64_t)nsplit * K * Cout * Cin;
     const int64_t need = (2 * dy_el + 2 * x_el + 64) * (int64_t)sizeof(bf16) + slab_el * (int64_t)sizeof(float) + 128;
@@ -1579,18 +1884,20 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, f
       bf16* xh = dyl + (dy_el + 7) / 8 * 8;
       bf16* xl = xh + (x_el + 7) / 8 * 8;
       if (cat) {
-        wgrad_split_cat_kernel<<<dim3((unsigned)cdiv(Lq / 2, 256), (unsigned)Cout), 256, 0, stream>>>(dy, dyh, dyl, B, Cout, Lout, Lg, 0, Lq, dy_slope, db, 1);
-        wgrad_split_cat_kernel<<<dim3((unsigned)cdiv(Li / 2, 256), (unsigned)(Cin * S)), 256, 0, stream>>>(x, xh, xl, B, Cin, Lin, Lg, PL, Li, x_slope, nullptr, S);
+        launch_wgrad_cat_pair(dy, dyh, dyl, Cout, Lout, Lq, dy_slope, db, x, xh, xl, Cin, Lin, PL, Li, x_slope, S, B, Lg, stream);
       } else {
         launch_wgrad_splits(dy, x, dyh, dyl, xh, xl, (int64_t)B * Cout, Lout, Lq, dy_slope, (int64_t)B * Cin, Lin, S, Li, PL, x_slope, 1, db, Cout, stream);
       }
       if (db) *db_done = true;
       char* end = reinterpret_cast<char*>(xl + (x_el + 7) / 8 * 8);
       float* slab = reinterpret_cast<float*>(end + ((16 - (reinterpret_cast<uintptr_t>(end) & 15)) & 15));
+      float* pb = nullptr;
+      float* ps = slab_defer(dw, nullptr, false, nsplit, K, Cout, Cin, stream, &pb);
+      if (ps) slab = ps;
       WgradB3Params p{dyh, dyl, xh, xl, dw, Bk, Cin, Cout, K, S, dil, Lq, Li, PO, x_el, cpb, nchunks, nlc, slab};
       dim3 grid((unsigned)cdiv(Cin, 64), (unsigned)cdiv(Cout, 64), (unsigned)nsplit);
       launch_wgrad_taps_one<5, 1, 0, 5, 64, S, PO>(p, grid, stream);
-      wgrad_slab_reduce_kernel<<<dim3((unsigned)std::min<int64_t>(cdiv((int64_t)K * Cout * Cin, 256), 4096), (unsigned)cdiv(nsplit, SLAB_G)), 256, 0, stream>>>(slab, dw, nsplit, K, Cout, Cin, nullptr, nullptr);
+      if (!ps) wgrad_slab_reduce_kernel<<<dim3((unsigned)std::min<int64_t>(cdiv((int64_t)K * Cout * Cin, 256), 4096), (unsigned)cdiv(nsplit, SLAB_G)), 256, 0, stream>>>(slab, dw, nsplit, K, Cout, Cin, nullptr, nullptr);
       *handled = true;
       return check_launch("conv1d_wgrad_bf16x3_taps_s3");
     }
@@ -1617,7 +1924,7 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, f
   const int TILE = small ? 32 : 64;
   const int nlc = Lq / 64, nchunks = B * nlc;
   const int tiles = (int)(cdiv(Cin, TILE) * cdiv(Cout, TILE)) * K;
-  const int splits = (int)std::max<int64_t>(1, std::min<int64_t>(nchunks, cdiv(1536, tiles)));
+  const int splits = (int)std::max<int64_t>(1, std::min<int64_t>(nchunks, cdiv(3 * wg_target, tiles)));
   const int cpb = (int)cdiv(nchunks, splits);
   const int nsp = (int)cdiv(nchunks, cpb);
   float* slab = nullptr;
@@ -1627,11 +1934,14 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, f
     const int64_t slab_bytes = (int64_t)nsp * K * Cout * Cin * (int64_t)sizeof(float);
     if (!small && nsp > 1 && (end - static_cast<char*>(cx.ws)) + slab_bytes <= cx.ws_bytes) slab = reinterpret_cast<float*>(end);
   }
+  float* pb = nullptr;
+  float* ps = slab ? slab_defer(dw, nullptr, false, nsp, K, Cout, Cin, stream, &pb) : nullptr;
+  if (ps) slab = ps;
   WgradB3Params p{dyh, dyl, xh, xl, dw, B, Cin, Cout, K, stride, dil, Lq, Li, PL - pad, x_par, cpb, nchunks, nlc, slab};
   dim3 grid((unsigned)cdiv(Cin, TILE), (unsigned)cdiv(Cout, TILE), (unsigned)(K * nsp));
   if (small) conv1d_wgrad_bf16x3_kernel<32><<<grid, 256, 0, stream>>>(p);
   else conv1d_wgrad_bf16x3_kernel<64><<<grid, 256, 0, stream>>>(p);
-  if (slab) wgrad_slab_reduce_kernel<<<dim3((unsigned)std::min<int64_t>(cdiv((int64_t)K * Cout * Cin, 256), 4096), (unsigned)cdiv(nsp, SLAB_G)), 256, 0, stream>>>(slab, dw, nsp, K, Cout, Cin, nullptr, nullptr);
+  if (slab && !ps) wgrad_slab_reduce_kernel<<<dim3((unsigned)std::min<int64_t>(cdiv((int64_t)K * Cout * Cin, 256), 4096), (unsigned)cdiv(nsp, SLAB_G)), 256, 0, stream>>>(slab, dw, nsp, K, Cout, Cin, nullptr, nullptr);
   *handled = true;
   return check_launch("conv1d_wgrad_bf16x3");
 }
@@ -1674,3 +1984,159 @@ int conv1d_wgrad_mfma_try(const float* dy, const float* x, float* dw, float* db,
 }
 
 }  // namespace ttts
+
+// C entry points of the weight-split cache (include/ttts_hip.h)
+extern "C" {
+
+int ttts_conv_wsplit_cache_create(const void* w_base, int64_t w_bytes, void* storage, int64_t storage_bytes, int32_t max_entries,
+                                  void** cache_out) {
+  using namespace ttts;
+  if (!w_base || w_bytes <= 0 || !storage || !cache_out || max_entries <= 0) return fail(TTTS_EINVAL, "wsplit cache: null / empty argument");
+  if (reinterpret_cast<uintptr_t>(storage) % 256) return fail(TTTS_EINVAL, "wsplit cache: storage must be 256-byte aligned");
+  const int64_t table = (((int64_t)max_entries * (int64_t)sizeof(WsplitDesc) + 255) / 256) * 256;
+  if (storage_bytes <= table) return fail(TTTS_EINVAL, "wsplit cache: storage smaller than its descriptor table");
+  WsplitCache* c = new WsplitCache();
+  c->w_lo = static_cast<const char*>(w_base); c->w_hi = c->w_lo + w_bytes;
+  c->storage = static_cast<char*>(storage); c->bytes = storage_bytes; c->used = table;
+  c->max_entries = max_entries;
+  c->host.reserve(max_entries);
+  std::lock_guard<std::mutex> g(g_wsplit_mu);
+  for (WsplitCache* o : g_wsplit)
+    if (c->w_lo < o->w_hi && o->w_lo < c->w_hi) { delete c; return fail(TTTS_EINVAL, "wsplit cache: weight range overlaps a registered one"); }
+  g_wsplit.push_back(c);
+  *cache_out = c;
+  return TTTS_OK;
+}
+
+int ttts_conv_wsplit_cache_refresh(void* cache, void* stream) {
+  using namespace ttts;
+  WsplitCache* c = static_cast<WsplitCache*>(cache);
+  if (!c) return fail(TTTS_EINVAL, "wsplit cache: null handle");
+  int n; int64_t blocks;
+  {
+    std::lock_guard<std::mutex> g(g_wsplit_mu);
+    c->armed = true;
+    n = (int)c->host.size(); blocks = c->blocks;
+    c->launches_saved += n;
+  }
+  if (n == 0) return TTTS_OK;
+  conv_weight_split_batched_kernel<<<(unsigned)blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(
+      reinterpret_cast<const WsplitDesc*>(c->storage), n);
+  return check_launch("conv_weight_split_batched");
+}
+
+int ttts_conv_wsplit_cache_disarm(void* cache) {
+  using namespace ttts;
+  WsplitCache* c = static_cast<WsplitCache*>(cache);
+  if (!c) return fail(TTTS_EINVAL, "wsplit cache: null handle");
+  std::lock_guard<std::mutex> g(g_wsplit_mu);
+  c->armed = false;
+  return TTTS_OK;
+}
+
+int ttts_conv_wsplit_cache_stats(void* cache, int64_t* out4) {
+  using namespace ttts;
+  WsplitCache* c = static_cast<WsplitCache*>(cache);
+  if (!c || !out4) return fail(TTTS_EINVAL, "wsplit cache: null argument");
+  std::lock_guard<std::mutex> g(g_wsplit_mu);
+  out4[0] = (int64_t)c->host.size(); out4[1] = c->used; out4[2] = c->hits; out4[3] = c->misses;
+  return TTTS_OK;
+}
+
+int ttts_conv_wsplit_cache_destroy(void* cache) {
+  using namespace ttts;
+  WsplitCache* c = static_cast<WsplitCache*>(cache);
+  if (!c) return TTTS_OK;
+  std::lock_guard<std::mutex> g(g_wsplit_mu);
+  g_wsplit.erase(std::remove(g_wsplit.begin(), g_wsplit.end(), c), g_wsplit.end());
+  delete c;
+  return TTTS_OK;
+}
+
+int ttts_conv_wgrad_arena_create(const void* dw_base, int64_t dw_bytes, void* storage, int64_t storage_bytes, int32_t max_entries,
+                                 void** arena_out) {
+  using namespace ttts;
+  if (!dw_base || dw_bytes <= 0 || !storage || !arena_out || max_entries <= 0) return fail(TTTS_EINVAL, "wgrad arena: null / empty argument");
+  if (reinterpret_cast<uintptr_t>(storage) % 256) return fail(TTTS_EINVAL, "wgrad arena: storage must be 256-byte aligned");
+  const int64_t table = (((int64_t)max_entries * (int64_t)sizeof(SlabDesc) + 255) / 256) * 256;
+  if (storage_bytes <= table) return fail(TTTS_EINVAL, "wgrad arena: storage smaller than its descriptor table");
+  SlabArena* c = new SlabArena();
+  c->dw_lo = static_cast<const char*>(dw_base); c->dw_hi = c->dw_lo + dw_bytes;
+  c->storage = static_cast<char*>(storage); c->bytes = storage_bytes; c->used = table;
+  c->max_entries = max_entries;
+  c->host.reserve(max_entries); c->touched.reserve(max_entries);
+  std::lock_guard<std::mutex> g(g_slab_mu);
+  for (SlabArena* o : g_slab)
+    if (c->dw_lo < o->dw_hi && o->dw_lo < c->dw_hi) { delete c; return fail(TTTS_EINVAL, "wgrad arena: gradient range overlaps a registered one"); }
+  g_slab.push_back(c);
+  *arena_out = c;
+  return TTTS_OK;
+}
+
+int ttts_conv_wgrad_arena_begin(void* arena) {
+  using namespace ttts;
+  SlabArena* c = static_cast<SlabArena*>(arena);
+  if (!c) return fail(TTTS_EINVAL, "wgrad arena: null handle");
+  std::lock_guard<std::mutex> g(g_slab_mu);
+  std::fill(c->touched.begin(), c->touched.end(), 0);
+  c->n_touched = 0;
+  c->armed = true;
+  return TTTS_OK;
+}
+
+int ttts_conv_wgrad_arena_reduce(void* arena, void* stream_) {
+  using namespace ttts;
+  SlabArena* c = static_cast<SlabArena*>(arena);
+  if (!c) return fail(TTTS_EINVAL, "wgrad arena: null handle");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  std::lock_guard<std::mutex> g(g_slab_mu);
+  const bool was_armed = c->armed;
+  c->armed = false;
+  if (!was_armed || c->n_touched == 0) return TTTS_OK;
+  const int n = (int)c->host.size();
+  if (c->n_touched == n) {          // the usual case: every recorded layer ran exactly once -> one launch over the whole table
+    wgrad_slab_reduce_batched_kernel<<<(unsigned)c->blocks, 256, 0, stream>>>(reinterpret_cast<const SlabDesc*>(c->storage), n, 0);
+  } else {                          // some recorded layers did not run in this phase: their slabs are stale -> per-layer launches
+    ++c->partial_reduces;
+    for (int i = 0; i < n; ++i) {
+      if (!c->touched[i]) continue;
+      wgrad_slab_reduce_batched_kernel<<<(unsigned)slab_desc_blocks(c->host[i]), 256, 0, stream>>>(
+          reinterpret_cast<const SlabDesc*>(c->storage) + i, 1, c->host[i].block_begin);
+    }
+  }
+  std::fill(c->touched.begin(), c->touched.end(), 0);
+  c->n_touched = 0;
+  return check_launch("wgrad_slab_reduce_batched");
+}
+
+int ttts_conv_wgrad_arena_disarm(void* arena) {
+  using namespace ttts;
+  SlabArena* c = static_cast<SlabArena*>(arena);
+  if (!c) return fail(TTTS_EINVAL, "wgrad arena: null handle");
+  std::lock_guard<std::mutex> g(g_slab_mu);
+  c->armed = false;
+  std::fill(c->touched.begin(), c->touched.end(), 0);
+  c->n_touched = 0;
+  return TTTS_OK;
+}
+
+int ttts_conv_wgrad_arena_stats(void* arena, int64_t* out5) {
+  using namespace ttts;
+  SlabArena* c = static_cast<SlabArena*>(arena);
+  if (!c || !out5) return fail(TTTS_EINVAL, "wgrad arena: null argument");
+  std::lock_guard<std::mutex> g(g_slab_mu);
+  out5[0] = (int64_t)c->host.size(); out5[1] = c->used; out5[2] = c->deferred; out5[3] = c->fallbacks; out5[4] = c->partial_reduces;
+  return TTTS_OK;
+}
+
+int ttts_conv_wgrad_arena_destroy(void* arena) {
+  using namespace ttts;
+  SlabArena* c = static_cast<SlabArena*>(arena);
+  if (!c) return TTTS_OK;
+  std::lock_guard<std::mutex> g(g_slab_mu);
+  g_slab.erase(std::remove(g_slab.begin(), g_slab.end(), c), g_slab.end());
+  delete c;
+  return TTTS_OK;
+}
+
+}  // extern "C"

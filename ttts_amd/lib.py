@@ -67,7 +67,7 @@ _c = ctypes
 _P, _I32, _I64, _U64, _F = _c.c_void_p, _c.c_int32, _c.c_int64, _c.c_uint64, _c.c_float
 
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class ConvCtx(ctypes.Structure):
@@ -207,6 +207,17 @@ SIGNATURES = {
     "ttts_weight_norm_bwd_f32": (_I32, [_P, _P, _P, _P, _P, _P, _I32, _I32, _P]),
     "ttts_weight_norm_fwd_batched_f32": (_I32, [_P, _I32, _I32, _P]),
     "ttts_weight_norm_bwd_batched_f32": (_I32, [_P, _I32, _I32, _P]),
+    "ttts_conv_wsplit_cache_create": (_I32, [_P, _I64, _P, _I64, _I32, ctypes.POINTER(ctypes.c_void_p)]),
+    "ttts_conv_wsplit_cache_refresh": (_I32, [_P, _P]),
+    "ttts_conv_wsplit_cache_disarm": (_I32, [_P]),
+    "ttts_conv_wsplit_cache_stats": (_I32, [_P, ctypes.POINTER(ctypes.c_int64)]),
+    "ttts_conv_wsplit_cache_destroy": (_I32, [_P]),
+    "ttts_conv_wgrad_arena_create": (_I32, [_P, _I64, _P, _I64, _I32, ctypes.POINTER(ctypes.c_void_p)]),
+    "ttts_conv_wgrad_arena_begin": (_I32, [_P]),
+    "ttts_conv_wgrad_arena_reduce": (_I32, [_P, _P]),
+    "ttts_conv_wgrad_arena_disarm": (_I32, [_P]),
+    "ttts_conv_wgrad_arena_stats": (_I32, [_P, ctypes.POINTER(ctypes.c_int64)]),
+    "ttts_conv_wgrad_arena_destroy": (_I32, [_P]),
     "ttts_tanh_bwd_f32": (_I32, [_P, _P, _P, _I64, _P]),
     "ttts_add4_scale_f32": (_I32, [_P, _P, _P, _P, _F, _P, _I64, _P]),
     "ttts_gate_fwd_f32": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _P]),

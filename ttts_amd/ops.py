@@ -357,6 +357,89 @@ class WeightNormPlan:
         check(_l.get().ttts_weight_norm_bwd_batched_f32(_p(self.table), self.n, self.rows, _stream()), "weight_norm_bwd_batched")
 
 
+class WeightSplitCache:
+    """Persistent bf16 hi/lo splits of every convolution weight living in `weights` (a flat fp32 tensor: an optimizer's parameter
+    arena or a WeightNormBank's effective weights), rewritten by ONE launch per `refresh()` instead of one split launch in front
+    of every convolution call (include/ttts_hip.h: ttts_conv_wsplit_cache_*).  `refresh()` after every change of the weights and
+    before their next use; `disarm()` when the step ends (calls then split per launch again).  Results never change."""
+
+    def __init__(self, weights, bytes_per_elem=16, slack=64 << 20, max_entries=8192):
+        _req(weights, torch.float32, "weights")
+        if not weights.is_contiguous():
+            raise TttsError("WeightSplitCache: weights must be contiguous")
+        self.weights = weights
+        self.storage = torch.empty(weights.numel() * bytes_per_elem + slack + max_entries * 96, dtype=torch.uint8, device=weights.device)
+        h = ctypes.c_void_p()
+        check(_l.get().ttts_conv_wsplit_cache_create(_p(weights), weights.numel() * 4, _p(self.storage), self.storage.numel(),
+                                                     max_entries, ctypes.byref(h)), "wsplit_cache_create")
+        self._h = h
+
+    def refresh(self):
+        check(_l.get().ttts_conv_wsplit_cache_refresh(self._h, _stream()), "wsplit_cache_refresh")
+
+    def disarm(self):
+        check(_l.get().ttts_conv_wsplit_cache_disarm(self._h), "wsplit_cache_disarm")
+
+    def stats(self):
+        out = (ctypes.c_int64 * 4)()
+        check(_l.get().ttts_conv_wsplit_cache_stats(self._h, out), "wsplit_cache_stats")
+        return {"entries": out[0], "bytes_used": out[1], "hits": out[2], "misses": out[3]}
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            _l.get().ttts_conv_wsplit_cache_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class WgradSlabArena:
+    """Persistent split-K slabs for every convolution weight gradient accumulating into `grads` (a flat fp32 tensor: a
+    WeightNormBank's dW buffer or the optimizer's gradient arena), summed by ONE launch in `reduce()` instead of a reduce launch
+    behind every weight-gradient call (include/ttts_hip.h: ttts_conv_wgrad_arena_*).  `begin()` before the backward, `reduce()`
+    after it and before anything reads the gradients."""
+
+    def __init__(self, grads, storage_bytes, max_entries=8192):
+        _req(grads, torch.float32, "grads")
+        if not grads.is_contiguous():
+            raise TttsError("WgradSlabArena: grads must be contiguous")
+        self.grads = grads
+        self.storage = torch.empty(int(storage_bytes) + max_entries * 64 + 4096, dtype=torch.uint8, device=grads.device)
+        h = ctypes.c_void_p()
+        check(_l.get().ttts_conv_wgrad_arena_create(_p(grads), grads.numel() * 4, _p(self.storage), self.storage.numel(),
+                                                    max_entries, ctypes.byref(h)), "wgrad_arena_create")
+        self._h = h
+
+    def begin(self):
+        check(_l.get().ttts_conv_wgrad_arena_begin(self._h), "wgrad_arena_begin")
+
+    def reduce(self):
+        check(_l.get().ttts_conv_wgrad_arena_reduce(self._h, _stream()), "wgrad_arena_reduce")
+
+    def disarm(self):
+        check(_l.get().ttts_conv_wgrad_arena_disarm(self._h), "wgrad_arena_disarm")
+
+    def stats(self):
+        out = (ctypes.c_int64 * 5)()
+        check(_l.get().ttts_conv_wgrad_arena_stats(self._h, out), "wgrad_arena_stats")
+        return {"entries": out[0], "bytes_used": out[1], "deferred": out[2], "fallbacks": out[3], "partial_reduces": out[4]}
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            _l.get().ttts_conv_wgrad_arena_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ColsumPlan:
     """Descriptor table for ttts_colsum_bf16_accum_f32_batched: entries (X bf16 [M, ld], out f32 [>= N], N | None)."""
 

@@ -95,6 +95,25 @@ class VqvaeStep:
         if os.environ.get("TTTS_WN_BANK", "1") == "1":
             from .modules import WeightNormBank
             self.bank_g, self.bank_d = WeightNormBank(net_g), WeightNormBank(net_d)
+        # the bf16 hi/lo operand copies of every convolution weight are rewritten by one launch per phase as well
+        # (ops.WeightSplitCache over the banks' effective weights and the generator's parameter arena); TTTS_WSPLIT_CACHE=0: one
+        # split launch in front of every convolution call
+        self.wsplit_g, self.wsplit_d = [], []
+        if self.bank_g is not None and os.environ.get("TTTS_WSPLIT_CACHE", "1") == "1":
+            from .. import ops
+            self.wsplit_g = [ops.WeightSplitCache(t) for t in (getattr(self.bank_g, "flat_w", None), optim_g.flat_p) if t is not None]
+            self.wsplit_d = [ops.WeightSplitCache(t) for t in (getattr(self.bank_d, "flat_w", None),) if t is not None]
+        # ... and the split-K partial sums of every weight gradient are added into dW / the gradient arena by one launch per
+        # backward (ops.WgradSlabArena; TTTS_WGRAD_ARENA=0: a reduce launch behind every weight-gradient call).  Storage in MiB:
+        # TTTS_WGRAD_ARENA_MB = "generator bank, generator arena, discriminator bank, discriminator arena"
+        self.slabs_g, self.slabs_d = [], []
+        if self.bank_g is not None and os.environ.get("TTTS_WGRAD_ARENA", "1") == "1":
+            from .. import ops
+            mb = [int(v) << 20 for v in os.environ.get("TTTS_WGRAD_ARENA_MB", "8192,2048,1024,64").split(",")]
+            self.slabs_g = [ops.WgradSlabArena(t, n) for t, n in ((getattr(self.bank_g, "flat_dw", None), mb[0]), (optim_g.flat_g, mb[1]))
+                            if t is not None]
+            self.slabs_d = [ops.WgradSlabArena(t, n) for t, n in ((getattr(self.bank_d, "flat_dw", None), mb[2]), (optim_d.flat_g, mb[3]))
+                            if t is not None]
 
     def _sync_buffers(self):
         if self.dp.enabled:                                                  # DDP broadcast_buffers=True (rank-0 codebook)
@@ -134,11 +153,17 @@ class VqvaeStep:
             for bank in (self.bank_g, self.bank_d):
                 if bank is not None:
                     bank.release()
+            for c in self.wsplit_g + self.wsplit_d + self.slabs_g + self.slabs_d:
+                c.disarm()
 
     def _phases(self, wav, wav_aug, wav_lengths, spec, spec_aug, spec_lengths, text, text_lengths, y, inject, cut):
         h, tr = self.hps.data, self.hps.train
         if self.bank_g is not None:
             self.bank_g.refresh()
+        for c in self.wsplit_g:
+            c.refresh()
+        for a in self.slabs_g:
+            a.begin()
         y_hat, kl_ssl, ids_slice, z_mask, (z, z_p, m_p, logs_p, m_q, logs_q), quantized = self.net_g(
             wav, wav_aug, wav_lengths, spec, spec_aug, spec_lengths, text, text_lengths, **inject)
         mel = spec_to_mel_torch(spec, h.filter_length, h.n_mel_channels, h.sampling_rate, h.mel_fmin, h.mel_fmax)
@@ -150,10 +175,16 @@ class VqvaeStep:
         # ---- discriminator phase
         if self.bank_d is not None:
             self.bank_d.refresh()
+        for c in self.wsplit_d:
+            c.refresh()
+        for a in self.slabs_d:
+            a.begin()
         y_d_hat_r, y_d_hat_g, _, _ = self.net_d(y, y_hat.detach())
         loss_disc, losses_disc_r, losses_disc_g = L.discriminator_loss(y_d_hat_r, y_d_hat_g)
         self.optim_d.zero_grad()
         (loss_disc * scale).backward()
+        for a in self.slabs_d:
+            a.reduce()
         if self.bank_d is not None:
             self.bank_d.finish()
         self._exchange(1, cut)
@@ -167,6 +198,8 @@ class VqvaeStep:
         try:
             if self.bank_d is not None:
                 self.bank_d.refresh(requires_grad=False)          # the UPDATED discriminator, frozen
+            for c in self.wsplit_d:
+                c.refresh()
             y_d_hat_r, y_d_hat_g, fmap_r, fmap_g = self.net_d(y, y_hat)
             loss_mel = L.l1_loss(y_mel, y_hat_mel) * tr.c_mel
             loss_kl = L.kl_loss(z_p, logs_q, m_p, logs_p, z_mask) * tr.c_kl
@@ -175,6 +208,8 @@ class VqvaeStep:
             loss_gen_all = loss_gen + loss_fm + loss_mel + kl_ssl * 1 + loss_kl
             self.optim_g.zero_grad()
             (loss_gen_all * scale).backward()
+            for a in self.slabs_g:
+                a.reduce()
             if self.bank_g is not None:
                 self.bank_g.finish()
         finally:
