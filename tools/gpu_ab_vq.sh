@@ -9,7 +9,8 @@ if [ -n "$2" ]; then
 fi
 for rep in 1 2; do
   for v in $A $Bv; do
-    env $1=$v timeout 200 python tools/vqvae_bench.py 32 8 3 2>/dev/null | python -c "
+    vv=$v; [ "$v" == "default" ] && vv=""
+    env $1=$vv timeout 200 python tools/vqvae_bench.py 32 8 3 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1=$v', round(d['ms_per_step'], 2), d['losses']['loss_gen_all'], d['max_mem_gb'], d['launch_batching']['slabs'])" | tee -a gpurun_out/ab_vq_$1.txt
   done

@@ -416,6 +416,60 @@ __device__ __forceinline__ void b3_mma(const B3Frag<CW>& f, f32x16 (&acc)[CW][2]
 #pragma unroll
     for (int t = 0; t < 2; ++t) acc[i][t] = mfma32(f.ah[i], f.bh[t], acc[i][t]);
 }
+// Software-pipelined form of a stage for compile-time tap counts (round 4).  The plain unrolled loop below compiles to
+// "read six fragments, s_waitcnt lgkmcnt(0), a few MFMAs" twelve times per 60 MFMAs: every wait drains ALL reads in flight, so
+// the matrix pipe idles for an LDS latency a dozen times per 16-channel block.  Here tap k + 1's fragments are requested before
+// tap k's MFMAs (a second fragment set, +16 CW VGPRs; the compiler's counted lgkmcnt then only waits for the older set), the
+// schedule is pinned by sched_barrier, and the three MFMA groups of a tap are separated by `piece(slot)` -- the DMA kernel
+// issues the NEXT stage's global_load_lds there, one or two at a time in the shadow of the running MFMAs, instead of a burst
+// of ~26 in front of the stage during which the wave feeds nothing to the matrix cores.  Same MFMA order as b3_mma: results
+// are bit-identical.
+template <int CW, int KT, typename Piece>
+__device__ __forceinline__ void b3_stage_pipe(const bf16* xh, const bf16* xl, const bf16* ah, const bf16* al, const int (&arow)[CW],
+                                              int bpos0, int bpos1, int dil8, f32x16 (&acc)[CW][2], Piece&& piece) {
+  B3Frag<CW> f[2];
+  b3_load<CW>(f[0], xh, xl, ah, al, arow, bpos0, bpos1, 0, dil8);
+  __builtin_amdgcn_sched_barrier(0);       // (tap 0's reads stay ahead of tap 1's: the first wait is then counted too)
+#pragma unroll
+  for (int k = 0; k < KT; ++k) {
+    const B3Frag<CW>& c = f[k & 1];
+    if (k + 1 < KT) b3_load<CW>(f[(k + 1) & 1], xh, xl, ah, al, arow, bpos0, bpos1, k + 1, dil8);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < CW; ++i)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc[i][t] = mfma32(c.al[i], c.bh[t], acc[i][t]);
+    __builtin_amdgcn_sched_barrier(0);
+    piece(3 * k);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < CW; ++i)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc[i][t] = mfma32(c.ah[i], c.bl[t], acc[i][t]);
+    __builtin_amdgcn_sched_barrier(0);
+    piece(3 * k + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < CW; ++i)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc[i][t] = mfma32(c.ah[i], c.bh[t], acc[i][t]);
+    __builtin_amdgcn_sched_barrier(0);
+    piece(3 * k + 2);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+struct B3NoPiece { __device__ __forceinline__ void operator()(int) const {} };
+// where the pipelined form is used: compile-time taps, except the 64 x 64 wave tile with 11 taps (its per-tap fragment
+// addresses + the second fragment set need 289 VGPRs: one wave per SIMD).  -DTTTS_CONV_NO_PIPE: nowhere (A/B builds).
+template <int CW, int KT>
+__host__ __device__ constexpr bool b3_pipe() {
+#ifdef TTTS_CONV_NO_PIPE
+  return false;
+#else
+  return KT > 0 && !(CW == 2 && KT > 7);
+#endif
+}
+
 // KT = compile-time tap count (0: runtime K).  With the taps unrolled the scheduler hoists the LDS fragment reads of later
 // taps above the MFMAs of earlier ones; the runtime loop waits for its six reads before every group of six MFMAs.
 template <int CW, int KT>
@@ -424,11 +478,15 @@ __device__ __forceinline__ void b3_stage(const bf16* xh, const bf16* xl, const b
   // (an explicit two-deep fragment prefetch across taps with runtime K measured 10-14 % SLOWER than the plain loop: +44 VGPRs
   // and branchy control)
   if (KT > 0) {
+    if constexpr (b3_pipe<CW, KT>()) {
+      b3_stage_pipe<CW, KT>(xh, xl, ah, al, arow, bpos0, bpos1, dil8, acc, B3NoPiece());
+    } else {
 #pragma unroll
-    for (int k = 0; k < KT; ++k) {
-      B3Frag<CW> f;
-      b3_load<CW>(f, xh, xl, ah, al, arow, bpos0, bpos1, k, dil8);
-      b3_mma<CW>(f, acc);
+      for (int k = 0; k < KT; ++k) {
+        B3Frag<CW> f;
+        b3_load<CW>(f, xh, xl, ah, al, arow, bpos0, bpos1, k, dil8);
+        b3_mma<CW>(f, acc);
+      }
     }
   } else {
 #pragma unroll 2
@@ -608,29 +666,32 @@ __global__ __launch_bounds__(256) void conv1d_bf16x3_dma_kernel(ConvMfmaParams p
     wdst[i] = blk * STAGE1 + 2 * XS + cc * 512;
     wblk[i] = c < NBS * nwc ? blk : 1 << 20;
   }
-  auto issue = [&](int st_i, int buf) {
-    bf16* st = smem + buf * STAGE;
+  // piece i of a stage's DMA work for this wave: i < XC an input chunk, else a weight chunk (hi and lo array each).  Inline-asm
+  // DMA (lds_dma16_untracked): with the builtin in the kernel hipcc drains ALL LDS reads (lgkmcnt(0)) in front of every MFMA
+  // group instead of counting, which defeats the fragment pipeline; the protocol is the stage-top vmcnt(0) + barrier below.
+  const uint32_t lds0 = lds_byte_addr(smem);
+  auto issue_piece = [&](int st_i, int buf, int i) {
+    const uint32_t st = lds0 + (uint32_t)(buf * STAGE) * (uint32_t)sizeof(bf16);
     const int nb0 = st_i * NBS;
-#pragma unroll
-    for (int i = 0; i < XC; ++i) {
-      if (nb0 + xblk[i] < nblk) {                            // wave-uniform (blocks beyond the last one are skipped)
-        const bf16* g = xsrc[i] + nb0 * xstep;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(st + xdst[i]), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + xlo_d),
-                                         (__attribute__((address_space(3))) void*)(st + xdst[i] + XS), 16, 0, 0);
+    if (i < XC) {
+      const int j = i < XC ? i : 0;
+      if (nb0 + __builtin_amdgcn_readfirstlane(xblk[j]) < nblk) {      // wave-uniform: a scalar branch
+        const bf16* g = xsrc[j] + nb0 * xstep;
+        lds_dma16_untracked(g, st + (uint32_t)xdst[j] * 2u);
+        lds_dma16_untracked(g + xlo_d, st + (uint32_t)(xdst[j] + XS) * 2u);
+      }
+    } else {
+      const int j = i >= XC ? i - XC : 0;
+      if (nb0 + __builtin_amdgcn_readfirstlane(wblk[j]) < nblk) {
+        const bf16* g = wsrc[j] + nb0 * wstep;
+        lds_dma16_untracked(g, st + (uint32_t)wdst[j] * 2u);
+        lds_dma16_untracked(g + wlo_d, st + (uint32_t)(wdst[j] + WS) * 2u);
       }
     }
+  };
+  auto issue = [&](int st_i, int buf) {
 #pragma unroll
-    for (int i = 0; i < V2_WC; ++i) {
-      if (nb0 + wblk[i] < nblk) {
-        const bf16* g = wsrc[i] + nb0 * wstep;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(st + wdst[i]), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + wlo_d),
-                                         (__attribute__((address_space(3))) void*)(st + wdst[i] + WS), 16, 0, 0);
-      }
-    }
+    for (int i = 0; i < XC + V2_WC; ++i) issue_piece(st_i, buf, i);
   };
   f32x16 acc[CW][2];
 #pragma unroll
@@ -652,12 +713,31 @@ __global__ __launch_bounds__(256) void conv1d_bf16x3_dma_kernel(ConvMfmaParams p
     // stage si has landed (every wave drains its own DMA before the barrier) and nobody still reads the other buffer
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (si + 1 < nstage) issue(si + 1, (si + 1) & 1);
     const bf16* sb = smem + (si & 1) * STAGE;
-    for (int blk = 0; blk < NBS; ++blk) {
-      if (si * NBS + blk >= nblk) break;
-      const bf16* xh = sb + blk * STAGE1;
-      b3_stage<CW, KT>(xh, xh + XS, xh + 2 * XS, xh + 2 * XS + WS, arow, bpos0, bpos1, K, p.dil * 8, acc);
+    constexpr bool PIPE = b3_pipe<CW, KT>();
+    if constexpr (PIPE) {
+      // the next stage's DMA is issued piecewise between the MFMA groups of this stage's first block (3 KT slots)
+      const bool more = si + 1 < nstage;
+      constexpr int NSLOT = 3 * (KT > 0 ? KT : 1), NPIECE = XC + V2_WC;
+      b3_stage_pipe<CW, (KT > 0 ? KT : 1)>(sb, sb + XS, sb + 2 * XS, sb + 2 * XS + WS, arow, bpos0, bpos1, p.dil * 8, acc, [&](int slot) {
+        if (more) {
+#pragma unroll
+          for (int i = 0; i < NPIECE; ++i)
+            if (i % NSLOT == slot) issue_piece(si + 1, (si + 1) & 1, i);
+        }
+      });
+      for (int blk = 1; blk < NBS; ++blk) {
+        if (si * NBS + blk >= nblk) break;
+        const bf16* xh = sb + blk * STAGE1;
+        b3_stage<CW, KT>(xh, xh + XS, xh + 2 * XS, xh + 2 * XS + WS, arow, bpos0, bpos1, K, p.dil * 8, acc);
+      }
+    } else {
+      if (si + 1 < nstage) issue(si + 1, (si + 1) & 1);
+      for (int blk = 0; blk < NBS; ++blk) {
+        if (si * NBS + blk >= nblk) break;
+        const bf16* xh = sb + blk * STAGE1;
+        b3_stage<CW, KT>(xh, xh + XS, xh + 2 * XS, xh + 2 * XS + WS, arow, bpos0, bpos1, K, p.dil * 8, acc);
+      }
     }
   }
 #pragma unroll

@@ -886,7 +886,9 @@ def _conv_ctx(device):
     """The convolution context of `device` (include/ttts_hip.h: ttts_conv_ctx), created on first use: a caller-owned struct
     + the scratch tensor that enables the split-bf16 matrix-core path.  Python-side state only -- the C library keeps none;
     every conv entry point receives the struct by pointer.  TTTS_CONV_FP32=1 creates it without scratch (exact kernels)."""
-    key = str(device)
+    # one scratch per (device, stream): convolutions issued on different streams (the sub-discriminators run concurrently,
+    # vq2.MultiPeriodDiscriminator) must not share operand-split buffers
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
     if key not in _conv_ctxs:
         buf = None
         if os.environ.get("TTTS_CONV_FP32", "0") != "1":

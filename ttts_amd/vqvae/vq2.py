@@ -5,6 +5,8 @@ Built so far: `Generator` (:341-415, in modules.py), `DiscriminatorP` (:418-494)
 `MultiPeriodDiscriminator` (:527-551), `ResidualCouplingBlock` (:208-252), `PosteriorAudioEncoder` (:667-745),
 `MRTE` (:17-46), `TextEncoder` (:90-164), `SynthesizerTrn` (:750-871, training forward).
 """
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -86,26 +88,63 @@ class MultiPeriodDiscriminator(nn.Module):
         discs = discs + [DiscriminatorP(i, use_spectral_norm=use_spectral_norm) for i in periods]
         self.discriminators = nn.ModuleList(discs)
 
+    def _side_streams(self, device):
+        """TTTS_D_STREAMS (default 3) side streams the six sub-discriminators are spread over: they are independent, and most of
+        their launches either under-fill the chip or end in a nearly empty last round of workgroups (DiscriminatorP's
+        1024-channel layers: 528..608 workgroups of 64 x 256 outputs on 512 slots) -- on separate streams one branch's tail
+        overlaps another's next launch.  The backward runs on the same streams (autograd replays a node on its forward
+        stream).  0: everything on the caller's stream."""
+        n = int(os.environ.get("TTTS_D_STREAMS", "3"))
+        if n <= 0 or device.type != "cuda":
+            return []
+        pool = getattr(self, "_streams", None)
+        if pool is None or len(pool) != n or pool[0].device != device:
+            pool = [torch.cuda.Stream(device=device) for _ in range(n)]
+            object.__setattr__(self, "_streams", pool)
+        return pool
+
     def forward(self, y, y_hat):
         y_d_rs, y_d_gs, fmap_rs, fmap_gs = [], [], [], []
+        pool = self._side_streams(y.device)
+        main = torch.cuda.current_stream(y.device) if pool else None
+
+        def on(i, fn):
+            """fn() on side stream i (after everything queued on the caller's stream so far)."""
+            if not pool:
+                return fn()
+            s = pool[i % len(pool)]
+            s.wait_stream(main)
+            with torch.cuda.stream(s):
+                return fn()
+
+        def join():
+            for s in pool:
+                main.wait_stream(s)
+
         # Discriminator phase (no gradient flows to y_hat): real and generated clips go through each sub-discriminator as ONE
         # batch of 2B -- the layers are per-sample (no batch statistics), so every output is the same, with half the launches,
         # one weight-norm / operand split per layer instead of two, and fuller tiles on the short DiscriminatorP rows.
         # Generator phase: separate calls, the real branch without an autograd graph (its features are detached constants).
         if not (torch.is_grad_enabled() and y_hat.requires_grad):
             both = torch.cat([y, y_hat], 0)
-            for d in self.discriminators:
-                out, fmap = d(both)
+            outs = [on(i, lambda d=d: d(both)) for i, d in enumerate(self.discriminators)]
+            join()
+            for out, fmap in outs:
                 y_d_r, y_d_g = out.chunk(2, 0)
                 y_d_rs.append(y_d_r)
                 y_d_gs.append(y_d_g)
                 fmap_rs.append([f.chunk(2, 0)[0] for f in fmap])
                 fmap_gs.append([f.chunk(2, 0)[1] for f in fmap])
             return y_d_rs, y_d_gs, fmap_rs, fmap_gs
-        for d in self.discriminators:
+
+        def real(d):
             with torch.no_grad():
-                y_d_r, fmap_r = d(y)
-            y_d_g, fmap_g = d(y_hat)
+                return d(y)
+        outs = []
+        for i, d in enumerate(self.discriminators):
+            outs.append((on(i + 1, lambda d=d: real(d)), on(i, lambda d=d: d(y_hat))))
+        join()
+        for (y_d_r, fmap_r), (y_d_g, fmap_g) in outs:
             y_d_rs.append(y_d_r)
             y_d_gs.append(y_d_g)
             fmap_rs.append(fmap_r)
