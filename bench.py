@@ -106,15 +106,25 @@ def vqvae_leg(dev, steps, warmup, cpu_leg=True):
     with torch.no_grad():          # codebook pre-initialised (k-means excluded from timing)
         cb.inited.fill_(1); cb.embed.normal_(0, 0.3); cb.embed_avg.copy_(cb.embed * 4); cb.cluster_size.fill_(4.0)
     data = next(iter(SyntheticVqvaeBatches(B, n_samples=NS, device=dev)))       # resident in HBM before the timed region
-    for _ in range(warmup):
-        out = tr.train_step_graphed(data)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        out = tr.train_step_graphed(data)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    def timed(step):
+        for _ in range(warmup):
+            o = step(data)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            o = step(data)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps, o
+    # two ways to issue the same step: eager launches with the independent branches (sub-discriminators, prior / posterior paths,
+    # the three ResBlocks of every MRF stage) on side streams, and one hipGraph replay (the generator's nested fan-out cannot be
+    # recorded, modules.side_streams).  `value` is the faster one; both are reported.
+    dt_eager, out = timed(tr.train_step)
+    dt_graph, out_g = timed(tr.train_step_graphed)
     graphed = tr._graph_state["graph"] is not None
+    if dt_graph < dt_eager and graphed:
+        dt, out, mode = dt_graph, out_g, "one hipGraph replay per step"
+    else:
+        dt, mode = dt_eager, "eager launches, independent branches on side streams"
     vals = {k: float(v) for k, v in out.items()}
     assert all(v == v for v in vals.values()), vals
     # dominant kernel family: the convolutions (implicit GEMM on the matrix cores), timed eagerly with HIP events
@@ -135,6 +145,10 @@ def vqvae_leg(dev, steps, warmup, cpu_leg=True):
     wrap("conv1d_dgrad", lambda dx, dy, w_, *a: 2.0 * dy.numel() * w_.shape[1] * w_.shape[2])
     wrap("conv1d_wgrad", lambda dw, dy, x, *a: 2.0 * dy.shape[0] * dy.shape[2] * dw.numel())
     try:
+        # (one stream for this pass: with the branches on side streams, overlapping launches would share the chip and every
+        # event pair would read longer than the kernel alone)
+        env_prev = {k: os.environ.get(k) for k in ("TTTS_BRANCH_STREAMS", "TTTS_D_STREAMS")}
+        os.environ.update({"TTTS_BRANCH_STREAMS": "0", "TTTS_D_STREAMS": "0"})
         if hasattr(torch.cuda, "_sleep"):
             torch.cuda._sleep(int(8e7))         # park the device so the host runs ahead: event pairs then measure device time
         tr.train_step(data)
@@ -142,6 +156,11 @@ def vqvae_leg(dev, steps, warmup, cpu_leg=True):
     finally:
         for k, v in saved.items():
             setattr(ops, k, v)
+        for k, v in env_prev.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     for name, fl, e0, e1 in recs:
         f = fam[name]; f[0] += 1; f[1] += e0.elapsed_time(e1) * 1e-3; f[2] += fl
     tot_s, tot_f, tot_n = sum(f[1] for f in fam.values()), sum(f[2] for f in fam.values()), sum(f[0] for f in fam.values())
@@ -152,12 +171,13 @@ def vqvae_leg(dev, steps, warmup, cpu_leg=True):
     except Exception:
         conv_traffic = None
     res = {"metric": "vqvae_gan_train_frames_per_sec", "value": round(B * 256 / dt, 1), "unit": "frames/s",
-           "ms_per_step": round(dt * 1e3, 2), "steps": steps, "warmup": warmup, "dtype": "f32 (conv products as split-bf16 x3 on the bf16 MFMA, fp32 accumulate; VQ distances on the exact f32 MFMA)",
+           "ms_per_step": round(dt * 1e3, 2), "ms_per_step_eager_streams": round(dt_eager * 1e3, 2),
+           "ms_per_step_graph_replay": round(dt_graph * 1e3, 2) if graphed else None, "steps": steps, "warmup": warmup, "dtype": "f32 (conv products as split-bf16 x3 on the bf16 MFMA, fp32 accumulate; VQ distances on the exact f32 MFMA)",
            "vq_code_parity": "nearest-code kernel bit-exact vs the C oracle; through the assembled model the split-bf16 convolutions perturb the "
                              "quantizer input by <= 1.1e-5 of its range: code indices are held to 'differ only on audited near-tie rows, "
                              "<= max(2, 1 %) of frames' (tests/test_gpu_fullsize.py, test_gpu_vqvae.py) -- measured 0 of 50 clips; exact-conv mode is bit-equal to the reference fixture",
            "config": {"workload": "VQ-VAE-GAN two-phase step (spectrograms, SynthesizerTrn, mel, MPD x2, 6 losses, 2 x AdamW, codebook EMA), "
-                                  "batch 32 x 163 840 samples (256 frames), %s" % ("one hipGraph replay per step" if graphed else "eager launches (capture refused)")},
+                                  "batch 32 x 163 840 samples (256 frames), %s" % mode},
            "algorithmic_tflops": round(1.97e9 * B * 256 / dt / 1e12, 1),
            "algorithmic_tflops_note": "1.97 GFLOP per frame = the REFERENCE step, which also computes (and discards) the discriminator's "
                                       "parameter gradients in the generator phase; this build skips them, so executed FLOPs are lower",

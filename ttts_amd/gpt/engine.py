@@ -125,6 +125,7 @@ class GptEngine:
         self.training = True
         self.seed = int(seed)
         self.step_count = 0                 # optimizer steps taken (host mirror)
+        self.dw_split_overlap = os.environ.get("TTTS_DW_SPLIT_OVERLAP", "0") == "1"   # grouped dW of the upper half under the lower half's chain
         self.overlap_dw = os.environ.get("TTTS_OVERLAP_DW", "0") == "1"   # dW GEMMs on a side stream (see backward);
         # off by default: measured +0.7 % only, and concurrent kernels blur per-kernel profiles
         # Deferred, grouped weight gradients (see _dw_plan): every layer keeps its four dY buffers and ALL dW GEMMs of a
@@ -505,6 +506,27 @@ class GptEngine:
             if ev is not None:
                 main.wait_event(ev)
 
+        if part is None and self.grouped_dw and self.dw_split_overlap and L >= 2 and (L // 2, L, True) in self._dw_plans:
+            # Grouped weight gradients of the UPPER half of the layers (+ heads) on a side stream while the main stream runs the
+            # data-gradient chain of the lower half: the section's batched launches read per-layer buffers only, and the chain's
+            # 292-tile GEMMs / causal tails / row kernels leave CUs for them.  The lower half's weight gradients follow on the
+            # main stream after the join (they share the split-K workspace and the gradient arena's LayerNorm rows).
+            half = L // 2
+            self._backward_head(w_text, w_mel, g_text_dev, g_mel_dev, main, fork)
+            for i in reversed(range(half, L)):
+                self._backward_layer(i, main, fork, done, wait, None, None)
+            dws = self._side_stream()
+            dws.wait_stream(main)
+            with torch.cuda.stream(dws):
+                self._run_dw(half, L, True)
+            for i in reversed(range(0, half)):
+                self._backward_layer(i, main, fork, done, wait, None, None)
+            ops.embed_bwd(b["text_inp"], b["mel_inp"], b["dres"], G("text_embedding.weight"),
+                          G("text_pos_embedding.emb.weight"), G("mel_embedding.weight"), G("mel_pos_embedding.emb.weight"),
+                          p, self._seed(1), counter=self.seed_ctr)
+            main.wait_stream(dws)
+            self._run_dw(0, half, False)
+            return
         if part in (None, 0):
             self._backward_head(w_text, w_mel, g_text_dev, g_mel_dev, side, fork)
         ev_fc = ev_qkv = None            # side-stream reads of d_fc / dqkv by the previous layer

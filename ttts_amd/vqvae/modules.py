@@ -12,6 +12,7 @@ all of their gradients run in `libttts_hip.so`; torch provides autograd bookkeep
 path: the ops raise `TttsError` off-GPU.
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -33,6 +34,70 @@ def _take_dw_buffer(w):
     if z is not None:
         w._ttts_dw_zero = None
     return z
+
+
+_branch_pools = {}
+_dirty_streams = []
+
+
+def side_streams(pool, device, n=None):
+    """The named set of side streams of `device` (created on first use); [] when disabled (TTTS_BRANCH_STREAMS=0) or not a GPU."""
+    n = int(os.environ.get("TTTS_BRANCH_STREAMS", "3")) if n is None else n
+    if n <= 0 or device.type != "cuda":
+        return []
+    if pool not in os.environ.get("TTTS_CAPTURE_POOLS", "disc,synth").split(",") and torch.cuda.is_current_stream_capturing():
+        # hipStreamEndCapture crashes (SIGSEGV, ROCm 7.2) on a capture that holds NESTED fan-outs (synth -> mrf); each level alone
+        # records fine (tools/exp/capture_debug.sh): recorded steps keep the outer levels (TTTS_CAPTURE_POOLS)
+        return []
+    key = (pool, device.index if device.index is not None else torch.cuda.current_device(), n)
+    streams = _branch_pools.get(key)
+    if streams is None:
+        streams = _branch_pools[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+    return streams
+
+
+def fork_to(stream, main):
+    """`stream` continues from everything queued on `main` so far; remembered for join_side_streams()."""
+    stream.wait_stream(main)
+    if stream not in _dirty_streams:
+        _dirty_streams.append(stream)
+
+
+def join_side_streams(device):
+    """The caller's stream waits for every side stream used since the last call.  Needed after a BACKWARD pass: autograd replays
+    each node on its forward stream and only synchronises along gradient edges and with the streams of AccumulateGrad nodes --
+    a node that writes its parameter gradients straight into the optimizer's arena (`_grad_slot`) and whose input needs no
+    gradient (a sub-discriminator's first layer in the discriminator phase) hands nothing to anybody, so nothing would ever
+    wait for its weight-gradient kernels (and a stream capture would end with an un-joined fork)."""
+    if device.type != "cuda":
+        return
+    main = torch.cuda.current_stream(device)
+    while _dirty_streams:
+        main.wait_stream(_dirty_streams.pop())
+
+
+def run_branches(fns, device, pool="mrf"):
+    """Independent sub-graphs (callables) on side streams, results in order.  Most convolution launches of the VQ-VAE-GAN step
+    either under-fill the 256 CUs or end in a nearly empty last round of workgroups; issued on separate streams, one branch's
+    tail overlaps another branch's next launch (and autograd replays every node on its forward stream, so the backward overlaps
+    the same way -- call join_side_streams() after it).  Every side stream first waits for the caller's stream and the caller's
+    stream waits for all of them before returning, so the call is ordered like a plain sequential one.  `pool` names a set of
+    TTTS_BRANCH_STREAMS (default 3; 0: run sequentially on the caller's stream) streams; nested fan-outs use different pools."""
+    streams = side_streams(pool, device) if len(fns) >= 2 else []
+    if not streams:
+        return [f() for f in fns]
+    main = torch.cuda.current_stream(device)
+    outs, used = [], []
+    for i, f in enumerate(fns):
+        st = streams[i % len(streams)]
+        fork_to(st, main)
+        with torch.cuda.stream(st):
+            outs.append(f())
+        if st not in used:
+            used.append(st)
+    for st in used:
+        main.wait_stream(st)
+    return outs
 
 
 def _grad_slot(p):
@@ -228,6 +293,20 @@ class _ConvTranspose1dFn(torch.autograd.Function):
         return dx, dw, db, None, None, None
 
 
+_alive = []
+
+
+def _keep_until_backward_ends(t):
+    """Hold a reference to a gradient that ONE backward node hands to several consumers until the backward pass is over.  The
+    summands of an add may have been computed on different streams (run_branches); autograd then replays their backward nodes
+    on those streams, all reading this tensor.  Without the extra reference the last consumer to be dispatched sees a uniquely
+    owned tensor and the engine accumulates the next gradient INTO it in place -- while the other streams' reads are still
+    queued (seen as deterministic 10-40 % gradient errors in PosteriorAudioEncoder).  With it the engine adds out of place."""
+    if not _alive:
+        torch.autograd.Variable._execution_engine.queue_callback(_alive.clear)
+    _alive.append(t)
+
+
 class _AddScaleFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, scale, *xs):
@@ -237,6 +316,7 @@ class _AddScaleFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         g = ops.add_scale([dy], ctx.scale) if ctx.scale != 1.0 else dy
+        _keep_until_backward_ends(g)
         return (None,) + (g,) * ctx.n
 
 
@@ -412,7 +492,7 @@ class Generator(nn.Module):
         x = self.conv_pre(x, bbias=bbias)
         for i in range(self.num_upsamples):
             x = self.ups[i](x, in_slope=LRELU_SLOPE)
-            xs = [self.resblocks[i * self.num_kernels + j](x) for j in range(self.num_kernels)]
+            xs = run_branches([lambda j=j: self.resblocks[i * self.num_kernels + j](x) for j in range(self.num_kernels)], x.device)
             x = add_scale(xs, 1.0 / self.num_kernels)
         return self.conv_post(x, in_slope=0.01, out_act="tanh")   # F.leaky_relu default slope (vq2.py:404)
 

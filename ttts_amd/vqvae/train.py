@@ -26,6 +26,7 @@ from ..parallel import FlatDataParallel, init_distributed
 from ..utils.data_utils import HParams, mel_spectrogram_torch, spec_to_mel_torch, spectrogram_torch
 from . import losses as L
 from .augment import Augment, augment, sample_like  # noqa: F401
+from .modules import join_side_streams
 from .vq2 import MultiPeriodDiscriminator, SynthesizerTrn, slice_segments
 
 global_step = 0
@@ -183,6 +184,7 @@ class VqvaeStep:
         loss_disc, losses_disc_r, losses_disc_g = L.discriminator_loss(y_d_hat_r, y_d_hat_g)
         self.optim_d.zero_grad()
         (loss_disc * scale).backward()
+        join_side_streams(y.device)
         for a in self.slabs_d:
             a.reduce()
         if self.bank_d is not None:
@@ -208,6 +210,7 @@ class VqvaeStep:
             loss_gen_all = loss_gen + loss_fm + loss_mel + kl_ssl * 1 + loss_kl
             self.optim_g.zero_grad()
             (loss_gen_all * scale).backward()
+            join_side_streams(y.device)
             for a in self.slabs_g:
                 a.reduce()
             if self.bank_g is not None:

@@ -88,24 +88,13 @@ class MultiPeriodDiscriminator(nn.Module):
         discs = discs + [DiscriminatorP(i, use_spectral_norm=use_spectral_norm) for i in periods]
         self.discriminators = nn.ModuleList(discs)
 
-    def _side_streams(self, device):
-        """TTTS_D_STREAMS (default 3) side streams the six sub-discriminators are spread over: they are independent, and most of
-        their launches either under-fill the chip or end in a nearly empty last round of workgroups (DiscriminatorP's
-        1024-channel layers: 528..608 workgroups of 64 x 256 outputs on 512 slots) -- on separate streams one branch's tail
-        overlaps another's next launch.  The backward runs on the same streams (autograd replays a node on its forward
-        stream).  0: everything on the caller's stream."""
-        n = int(os.environ.get("TTTS_D_STREAMS", "3"))
-        if n <= 0 or device.type != "cuda":
-            return []
-        pool = getattr(self, "_streams", None)
-        if pool is None or len(pool) != n or pool[0].device != device:
-            pool = [torch.cuda.Stream(device=device) for _ in range(n)]
-            object.__setattr__(self, "_streams", pool)
-        return pool
-
     def forward(self, y, y_hat):
+        # The six sub-discriminators are independent, and most of their launches either under-fill the chip or end in a nearly
+        # empty last round of workgroups (DiscriminatorP's 1024-channel layers: 528..608 workgroups of 64 x 256 outputs on 512
+        # slots): spread over TTTS_D_STREAMS (default 3; 0: the caller's stream) side streams, one branch's tail overlaps
+        # another's next launch.  The backward runs on the same streams (modules.join_side_streams after it).
         y_d_rs, y_d_gs, fmap_rs, fmap_gs = [], [], [], []
-        pool = self._side_streams(y.device)
+        pool = modules.side_streams("disc", y.device, int(os.environ.get("TTTS_D_STREAMS", "3")))
         main = torch.cuda.current_stream(y.device) if pool else None
 
         def on(i, fn):
@@ -113,7 +102,7 @@ class MultiPeriodDiscriminator(nn.Module):
             if not pool:
                 return fn()
             s = pool[i % len(pool)]
-            s.wait_stream(main)
+            modules.fork_to(s, main)
             with torch.cuda.stream(s):
                 return fn()
 
@@ -205,7 +194,8 @@ class PosteriorAudioEncoder(nn.Module):
         x_audio = self.down_pre(x_audio)
         for i in range(5):
             x_audio = self.downs[i](x_audio)
-            xs = [self.resblocks[i * self.num_kernels + j](x_audio) for j in range(self.num_kernels)]
+            xs = modules.run_branches([lambda j=j: self.resblocks[i * self.num_kernels + j](x_audio) for j in range(self.num_kernels)],
+                                      x_audio.device)
             x_audio = modules.add_scale(xs, 1.0 / self.num_kernels)
         x_audio = self.activation_post(x_audio)
         assert x_audio.shape[-1] == x_mask.shape[-1]
@@ -347,15 +337,29 @@ class SynthesizerTrn(nn.Module):
                 ids_slice=None):
         y_mask = torch.unsqueeze(sequence_mask(y_lengths, y.size(2)), 1).to(y.dtype)
         ge = self.ref_enc(modules.mul_mask(y, y_mask), y_mask)
-        x, _, _ = self.enc_p(y_aug, wav_aug.unsqueeze(1), y_mask, g=ge, noise=noise_p)
-        x = self.proj(x)
-        quantized, codes, commit_loss, quantized_list = self.quantizer(x, layers=[0])
-        quantized = modules.upsample_nearest2(quantized)
-        x, m_p, logs_p = self.enc_p_2(quantized, y_lengths, text, text_lengths, ge)
-        z, m_q, logs_q = self.enc_q(y, wav.unsqueeze(1), y_mask, g=ge, noise=noise_q)
-        z_p = self.flow(z, y_mask, g=ge)
-        z_slice, ids_slice = rand_slice_segments(z, y_lengths, self.segment_size, ids_slice)
-        o = self.dec(z_slice, g=ge)
+        # the prior path (augmented clip -> codes -> text-conditioned prior) and the posterior / flow / decoder path only share
+        # the style vector: two concurrent branches.  The randn draws happen here, in the reference's order (enc_p first).
+        if noise_p is None:
+            noise_p = torch.randn(y.size(0), self.inter_channels, y.size(2), dtype=y.dtype, device=y.device)
+        if noise_q is None:
+            noise_q = torch.randn(y.size(0), self.inter_channels, y.size(2), dtype=y.dtype, device=y.device)
+
+        def prior():
+            x, _, _ = self.enc_p(y_aug, wav_aug.unsqueeze(1), y_mask, g=ge, noise=noise_p)
+            x = self.proj(x)
+            quantized, codes, commit_loss, quantized_list = self.quantizer(x, layers=[0])
+            quantized = modules.upsample_nearest2(quantized)
+            x, m_p, logs_p = self.enc_p_2(quantized, y_lengths, text, text_lengths, ge)
+            return quantized, commit_loss, m_p, logs_p
+
+        def posterior():
+            z, m_q, logs_q = self.enc_q(y, wav.unsqueeze(1), y_mask, g=ge, noise=noise_q)
+            z_p = self.flow(z, y_mask, g=ge)
+            z_slice, ids = rand_slice_segments(z, y_lengths, self.segment_size, ids_slice)
+            return z, m_q, logs_q, z_p, ids, self.dec(z_slice, g=ge)
+
+        (quantized, commit_loss, m_p, logs_p), (z, m_q, logs_q, z_p, ids_slice, o) = modules.run_branches(
+            [prior, posterior], y.device, pool="synth")
         return o, commit_loss, ids_slice, y_mask, (z, z_p, m_p, logs_p, m_q, logs_q), quantized
 
     @torch.no_grad()
