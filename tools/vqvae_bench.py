@@ -27,12 +27,26 @@ for _ in range(warmup):
     out = tr.train_step(data)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
+issue = 0.0
 for _ in range(steps):
+    ti = time.perf_counter()
     out = tr.train_step(data)
+    issue += time.perf_counter() - ti
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
+# host side alone: the same step with the device parked (every launch only queues), i.e. the time Python + ctypes + autograd need
+# to ISSUE a step -- when this approaches ms_per_step the step is host-bound and faster kernels no longer show
+if hasattr(torch.cuda, "_sleep"):
+    torch.cuda.synchronize()
+    torch.cuda._sleep(int(4e8))
+    ti = time.perf_counter()
+    tr.train_step(data)
+    host_ms = (time.perf_counter() - ti) * 1e3
+    torch.cuda.synchronize()
+else:
+    host_ms = None
 frames = B * (163840 // 640)
-print(json.dumps({"metric": "vqvae_gan_train_frames_per_s", "value": frames / dt, "unit": "frames/s", "ms_per_step": dt * 1e3,
+print(json.dumps({"metric": "vqvae_gan_train_frames_per_s", "value": frames / dt, "unit": "frames/s", "ms_per_step": dt * 1e3, "host_issue_ms_device_parked": host_ms, "host_issue_ms_in_loop": issue / steps * 1e3,
                   "batch": B, "steps": steps, "warmup": warmup, "dtype": "f32 (conv products split-bf16 hi/lo x3 on the bf16 MFMA, fp32 accumulate; TTTS_CONV_FP32=1 for exact fp32 MFMA)", "data": "synthetic",
                   "tflops_algorithmic": 1.97e9 * frames / dt / 1e12, "max_mem_gb": torch.cuda.max_memory_allocated() / 2**30,
                   "launch_batching": {"wsplit": [c.stats() for c in tr.step_fn.wsplit_g + tr.step_fn.wsplit_d],
