@@ -543,9 +543,35 @@ __global__ __launch_bounds__(256) void vq_ema_fused_kernel(const float* __restri
       }
     }
   }
+  // The rows left after the scan (all of them, unless a code overflowed its 64 slots above): the four codes TOGETHER, four rows
+  // of each per round with all 64 loads in flight -- with ~1 row per code and wave (N / K = 4) the per-code flushes were four
+  // dependent HBM latencies in a row, most of this kernel's 21 us.  Per code the rows are still added in ascending order.
+  {
+    constexpr int RB = 4;
+    int most = 0;
 #pragma unroll
-  for (int c = 0; c < EMA_CODES; ++c)
-    if (live[c]) flush(mine[c], have[c], acc[c]);
+    for (int c = 0; c < EMA_CODES; ++c) most = max(most, live[c] ? have[c] : 0);
+    for (int i = 0; i < most; i += RB) {
+      float v[EMA_CODES][RB][4];
+#pragma unroll
+      for (int c = 0; c < EMA_CODES; ++c)
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+          const int r = __builtin_amdgcn_readlane(mine[c], max(min(i + u, have[c] - 1), 0));
+          const float* xr = x + (int64_t)((live[c] && have[c] > 0) ? r : 0) * D;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[c][u][j] = (lane + 64 * j < D) ? xr[lane + 64 * j] : 0.f;
+        }
+#pragma unroll
+      for (int c = 0; c < EMA_CODES; ++c)
+#pragma unroll
+        for (int u = 0; u < RB; ++u)
+          if (live[c] && i + u < have[c]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[c][j] += v[c][u][j];
+          }
+    }
+  }
   __syncthreads();                                       // everyone is done with ema_idx: it becomes the [wave][code][256] stage
   float* stagep = reinterpret_cast<float*>(ema_idx);
 #pragma unroll

@@ -76,6 +76,23 @@ def join_side_streams(device):
         main.wait_stream(_dirty_streams.pop())
 
 
+_wgrad_rr = [0]
+
+
+def wgrad_side_stream(device):
+    """A side stream (forked from the caller's stream, remembered for join_side_streams) for a weight-gradient launch of a
+    backward node, or None: TTTS_WGRAD_STREAMS streams, taken in turn.  Default 0 (off): measured 146.6 ms against 136-139 ms per step with 2 streams
+    (profiles/r04_ab_wgrad_streams.txt) -- with the branch streams already filling the chip the extra fork per convolution costs more
+    than the overlap returns."""
+    streams = side_streams("wgrad", device, int(os.environ.get("TTTS_WGRAD_STREAMS", "0")))
+    if not streams:
+        return None
+    _wgrad_rr[0] = (_wgrad_rr[0] + 1) % len(streams)
+    st = streams[_wgrad_rr[0]]
+    fork_to(st, torch.cuda.current_stream(device))
+    return st
+
+
 def run_branches(fns, device, pool="mrf"):
     """Independent sub-graphs (callables) on side streams, results in order.  Most convolution launches of the VQ-VAE-GAN step
     either under-fill the 256 CUs or end in a nearly empty last round of workgroups; issued on separate streams, one branch's
@@ -233,11 +250,26 @@ class _Conv1dFn(torch.autograd.Function):
             dy = ops.lrelu_bwd(dy, y, out_slope)
         need = ctx.needs_input_grad
         dx = dw = db = dbb = None
+        want_b = has_b and need[2]
+        bslot = _grad_slot(ctx.refs[1]) if want_b else None
+        # The weight gradient only feeds the optimizer: when it lands in persistent slots (nothing returns to autograd) it goes to
+        # a side stream and overlaps the data-gradient chain, whose launches leave CUs idle (wgrad_side_stream).
+        if need[1] and need[0] and _grad_slot(ctx.refs[0]) is not None and (not want_b or bslot is not None):
+            ws = wgrad_side_stream(dy.device)
+            if ws is not None:
+                with torch.cuda.stream(ws):
+                    ops.conv1d_wgrad(dy, x, w.shape[2], stride, pad, dil, x_slope=in_slope, groups=groups,
+                                     out=_grad_slot(ctx.refs[0]), db=bslot if want_b else None)
+                dy.record_stream(ws); x.record_stream(ws)
+                gate = x if in_slope != 1.0 else None
+                dx = ops.conv1d_dgrad(dy, w, x.shape[2], stride, pad, dil, gate=gate, gate_slope=in_slope, groups=groups)
+                if has_bb and need[4]:
+                    B, C, L = dy.shape
+                    dbb = ops.conv1d_bias_grad(dy.view(1, B * C, L)).view(B, C)
+                return dx, None, None, (dy if has_r and need[3] else None), dbb, None, None, None, None, None, None, None, None
         if need[0]:
             gate = x if in_slope != 1.0 else None
             dx = ops.conv1d_dgrad(dy, w, x.shape[2], stride, pad, dil, gate=gate, gate_slope=in_slope, groups=groups)
-        want_b = has_b and need[2]
-        bslot = _grad_slot(ctx.refs[1]) if want_b else None
         if need[1]:
             slot = _grad_slot(ctx.refs[0])
             if slot is None:
