@@ -36,7 +36,7 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
 # host side alone: the same step with the device parked (every launch only queues), i.e. the time Python + ctypes + autograd need
 # to ISSUE a step -- when this approaches ms_per_step the step is host-bound and faster kernels no longer show
-if hasattr(torch.cuda, "_sleep"):
+if os.environ.get("TTTS_BENCH_HOST", "0") == "1" and hasattr(torch.cuda, "_sleep"):
     torch.cuda.synchronize()
     torch.cuda._sleep(int(4e8))
     ti = time.perf_counter()
