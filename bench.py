@@ -82,6 +82,11 @@ def hbm_kernel_table(dev):
     cs, ea, em = torch.full((1024,), 4.0, device=dev), cb.clone() * 4, cb.clone()
     add("vq_ema_update (4096 rows, 1024 codes)", (4096 * 192 + 3 * 1024 * 192 + 2 * 1024) * 4 + 4096 * 8,
         lambda: ops.vq_ema_update(x, idx, cs, ea, em, 0.99, 1e-5))
+    # (the nearest codes of Gaussian rows against a Gaussian codebook are skewed: the fullest code takes ~200 of the 4096 rows and
+    # its gather chain sets the time; evenly used codes -- a trained codebook's regime -- are the second row)
+    idx_u = torch.randint(0, 1024, (4096,), generator=g).to(dev)
+    add("vq_ema_update (4096 rows, 1024 codes, evenly used)", (4096 * 192 + 3 * 1024 * 192 + 2 * 1024) * 4 + 4096 * 8,
+        lambda: ops.vq_ema_update(x, idx_u, cs, ea, em, 0.99, 1e-5))
     M, D = 9248, 512
     xs = torch.randn(M, D, generator=g).to(dev); gam, bet = torch.ones(D, device=dev), torch.zeros(D, device=dev)
     y = torch.empty(M, D, dtype=torch.bfloat16, device=dev); mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)

@@ -546,6 +546,11 @@ __global__ __launch_bounds__(256) void vq_ema_fused_kernel(const float* __restri
   // The rows left after the scan (all of them, unless a code overflowed its 64 slots above): the four codes TOGETHER, four rows
   // of each per round with all 64 loads in flight -- with ~1 row per code and wave (N / K = 4) the per-code flushes were four
   // dependent HBM latencies in a row, most of this kernel's 21 us.  Per code the rows are still added in ascending order.
+  // A crowded code (more than four rows in this wave's quarter: 198 of 4096 rows fall on one code in the benchmark's data) is
+  // flushed alone first, sixteen rows a round -- four a round would be a dozen dependent latencies for it.
+#pragma unroll
+  for (int c = 0; c < EMA_CODES; ++c)
+    if (live[c] && have[c] > 4) flush(mine[c], have[c], acc[c]);
   {
     constexpr int RB = 4;
     int most = 0;
