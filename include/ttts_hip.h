@@ -43,7 +43,9 @@ const char* ttts_last_error(void);
  * uint32 in DEVICE memory owned by the caller, or NULL.  The kernel adds it to `seed` at run time; incrementing it once
  * per step (on the stream) gives fresh masks on each replay of a captured hipGraph (kernel arguments are frozen by
  * capture, device memory is not).  Forward and backward of one step must see the same value.  The library itself holds
- * no mutable state: every entry point is re-entrant across threads and streams. */
+ * no implicit state: every entry point is re-entrant across threads and streams.  The only state kept between calls sits
+ * behind handles the CALLER creates over its own storage (the convolutions' weight-split cache and slab arena, ABI v8); a
+ * process-wide, mutex-guarded list of live handles is how convolution calls find them, by pointer range. */
 /* Device query: writes {gfx arch number (950), CU count, wavefront size, LDS bytes/CU}. */
 int ttts_device_info(int32_t out[4]);
 
