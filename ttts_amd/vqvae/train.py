@@ -102,8 +102,15 @@ class VqvaeStep:
         self.wsplit_g, self.wsplit_d = [], []
         if self.bank_g is not None and os.environ.get("TTTS_WSPLIT_CACHE", "1") == "1":
             from .. import ops
-            self.wsplit_g = [ops.WeightSplitCache(t) for t in (getattr(self.bank_g, "flat_w", None), optim_g.flat_p) if t is not None]
-            self.wsplit_d = [ops.WeightSplitCache(t) for t in (getattr(self.bank_d, "flat_w", None),) if t is not None]
+            def _try(make, t, *a):      # (a second step object over the same arrays -- trainer + train_and_evaluate -- finds the
+                if t is None:           # range registered already: it runs without its own cache / arena, results are the same)
+                    return []
+                try:
+                    return [make(t, *a)]
+                except ops.TttsError:
+                    return []
+            self.wsplit_g = _try(ops.WeightSplitCache, getattr(self.bank_g, "flat_w", None)) + _try(ops.WeightSplitCache, optim_g.flat_p)
+            self.wsplit_d = _try(ops.WeightSplitCache, getattr(self.bank_d, "flat_w", None))
         # ... and the split-K partial sums of every weight gradient are added into dW / the gradient arena by one launch per
         # backward (ops.WgradSlabArena; TTTS_WGRAD_ARENA=0: a reduce launch behind every weight-gradient call).  Storage in MiB:
         # TTTS_WGRAD_ARENA_MB = "generator bank, generator arena, discriminator bank, discriminator arena"
@@ -111,10 +118,15 @@ class VqvaeStep:
         if self.bank_g is not None and os.environ.get("TTTS_WGRAD_ARENA", "1") == "1":
             from .. import ops
             mb = [int(v) << 20 for v in os.environ.get("TTTS_WGRAD_ARENA_MB", "8192,2048,1024,64").split(",")]
-            self.slabs_g = [ops.WgradSlabArena(t, n) for t, n in ((getattr(self.bank_g, "flat_dw", None), mb[0]), (optim_g.flat_g, mb[1]))
-                            if t is not None]
-            self.slabs_d = [ops.WgradSlabArena(t, n) for t, n in ((getattr(self.bank_d, "flat_dw", None), mb[2]), (optim_d.flat_g, mb[3]))
-                            if t is not None]
+            def _try_a(t, n):
+                if t is None:
+                    return []
+                try:
+                    return [ops.WgradSlabArena(t, n)]
+                except ops.TttsError:
+                    return []
+            self.slabs_g = _try_a(getattr(self.bank_g, "flat_dw", None), mb[0]) + _try_a(optim_g.flat_g, mb[1])
+            self.slabs_d = _try_a(getattr(self.bank_d, "flat_dw", None), mb[2]) + _try_a(optim_d.flat_g, mb[3])
 
     def _sync_buffers(self):
         if self.dp.enabled:                                                  # DDP broadcast_buffers=True (rank-0 codebook)
