@@ -334,8 +334,7 @@ def _keep_until_backward_ends(t):
     on those streams, all reading this tensor.  Without the extra reference the last consumer to be dispatched sees a uniquely
     owned tensor and the engine accumulates the next gradient INTO it in place -- while the other streams' reads are still
     queued (seen as deterministic 10-40 % gradient errors in PosteriorAudioEncoder).  With it the engine adds out of place."""
-    if not _alive:
-        torch.autograd.Variable._execution_engine.queue_callback(_alive.clear)
+    torch.autograd.Variable._execution_engine.queue_callback(_alive.clear)   # (every time: a backward that raised never ran its callbacks)
     _alive.append(t)
 
 
