@@ -7,7 +7,11 @@ Host-side differences (outside the arithmetic): one process per GPU under torchr
 `.item()`); the GPT latent is an input of `train_step` (the frozen GPT lives in `ttts_amd.gpt`, `return_latent=True`); data
 loading, EMA copy, vocoder previews and tensorboard are outside the path.
 """
+import os
+
 import torch
+
+from .. import ops
 
 from ..optim import FlatAdamW
 from ..parallel import FlatDataParallel, init_distributed
@@ -46,6 +50,16 @@ class DiffusionTrainer:
         self.base_lr = cfg["train"]["lr"]
         self.step = 0
         self.diffusion.train()
+        # launch batching shared with the VQ-VAE-GAN step (ops.WeightSplitCache / ops.WgradSlabArena): the bf16 hi/lo copies of
+        # every convolution weight rewritten by one launch per step, all split-K weight-gradient slabs summed by one launch
+        self._wsplit, self._slabs = [], []
+        try:
+            if os.environ.get("TTTS_WSPLIT_CACHE", "1") == "1":
+                self._wsplit = [ops.WeightSplitCache(self.optimizer.flat_p)]
+            if os.environ.get("TTTS_WGRAD_ARENA", "1") == "1":
+                self._slabs = [ops.WgradSlabArena(self.optimizer.flat_g, int(os.environ.get("TTTS_DIFFUSION_ARENA_MB", "2048")) << 20)]
+        except ops.TttsError:           # (a second trainer over the same arrays: it runs without them)
+            pass
 
     def train_step(self, mel, mel_refer, latent, t=None, noise=None, inject=None, normalized=False):
         """mel (B, 100, T) / mel_refer (B, 100, Tr) raw log-mels (`normalized=True`: already through normalize_tacotron_mel),
@@ -58,10 +72,20 @@ class DiffusionTrainer:
             noise = torch.randn(x_start.shape, device=self.device, dtype=x_start.dtype, generator=self.gen)
         kw = {"latent": latent, "refer": refer}
         kw.update(inject or {})
-        out = self.diffuser.training_losses(self.diffusion, x_start, t, model_kwargs=kw, noise=noise)
-        loss = out["loss_mean"]
-        self.optimizer.zero_grad()
-        (loss * self.dp.loss_scale()).backward()
+        try:
+            for c in self._wsplit:
+                c.refresh()
+            out = self.diffuser.training_losses(self.diffusion, x_start, t, model_kwargs=kw, noise=noise)
+            loss = out["loss_mean"]
+            self.optimizer.zero_grad()
+            for a in self._slabs:
+                a.begin()
+            (loss * self.dp.loss_scale()).backward()
+            for a in self._slabs:
+                a.reduce()
+        finally:
+            for c in self._wsplit + self._slabs:
+                c.disarm()
         self.dp.allreduce_grads_(self.optimizer.flat_g)
         lr = self.base_lr * warmup(self.step)                             # LambdaLR: the factor of the step being taken
         self.optimizer.step(lr=lr, max_norm=1.0)
