@@ -45,3 +45,31 @@ def test_dh64_attention_kernels_fit_their_occupancy():
             assert r["vgpr"] <= 168, (k, r)
         else:                             # dQ, dK/dV: two per CU
             assert r["vgpr"] <= 256, (k, r)
+
+
+def test_split_bf16_conv_kernels_keep_two_waves_per_simd():
+    """The split-bf16 forward / data-gradient kernels run two workgroups per CU (the DMA kernel's 80 KB stages are sized for it):
+    the pipelined stage loop (second fragment set + per-tap addresses) must stay within 256 registers per lane -- which is why the
+    64 x 64 wave tile with 11 taps keeps the plain loop (b3_pipe)."""
+    t = _table("conv_mfma.hip")
+    seen = 0
+    for k, r in t.items():
+        if k.startswith("conv1d_bf16x3_dma_kernel<") or k.startswith("conv1d_bf16x3_kernel<"):
+            seen += 1
+            assert r["spill"] == 0 and r["scratch"] == 0, (k, r)
+            # (<2, 11>: the 64 x 64 wave tile with 11 unrolled taps has always needed 264 -- one wave per SIMD; it serves the few
+            # >= 192-channel k11 calls whose launch fills the chip with 64 x 256 tiles, 12 launches a step)
+            assert r["wg"] == 256 and r["vgpr"] <= (264 if k.startswith("conv1d_bf16x3_dma_kernel<2, 11>") else 256), (k, r)
+    assert seen >= 20
+
+
+def test_run_branches_is_a_plain_loop_without_a_gpu():
+    """vqvae.modules.run_branches / join_side_streams on a CPU device: results in order, no streams involved."""
+    import torch
+    from ttts_amd.vqvae import modules as M
+    dev = torch.device("cpu")
+    order = []
+    outs = M.run_branches([lambda i=i: order.append(i) or i * i for i in range(4)], dev)
+    assert outs == [0, 1, 4, 9] and order == [0, 1, 2, 3]
+    assert M.side_streams("mrf", dev) == [] and M.wgrad_side_stream(dev) is None
+    M.join_side_streams(dev)
