@@ -57,9 +57,7 @@ def test_split_bf16_conv_kernels_keep_two_waves_per_simd():
         if k.startswith("conv1d_bf16x3_dma_kernel<") or k.startswith("conv1d_bf16x3_kernel<"):
             seen += 1
             assert r["spill"] == 0 and r["scratch"] == 0, (k, r)
-            # (<2, 11>: the 64 x 64 wave tile with 11 unrolled taps has always needed 264 -- one wave per SIMD; it serves the few
-            # >= 192-channel k11 calls whose launch fills the chip with 64 x 256 tiles, 12 launches a step)
-            assert r["wg"] == 256 and r["vgpr"] <= (264 if k.startswith("conv1d_bf16x3_dma_kernel<2, 11>") else 256), (k, r)
+            assert r["wg"] == 256 and r["vgpr"] <= 256, (k, r)      # (the DMA kernel asks for two waves per SIMD: amdgpu_waves_per_eu)
     assert seen >= 20
 
 

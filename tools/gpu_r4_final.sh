@@ -15,7 +15,7 @@ timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "BENCH rc=$?"
 python - <<'PY'
 import json
 d = json.loads(open("gpurun_out/r4f/bench.json").read().strip().splitlines()[-1])
-print("GPT ms/step", d["ms_per_step"], "median", d.get("ms_per_step_median"), "tok/s", d["value"], "roof", d["roofline"]["kernel"], d["roofline"]["achieved"], d["roofline"]["frac"], "step_frac", d.get("step_frac"))
+print("GPT ms/step", d["ms_per_step"], "median", d.get("ms_per_step_median"), "tok/s", d["value"], "roof", d["roofline"]["kernel"], d["roofline"]["achieved"], d["roofline"]["frac"], "step_frac", d["roofline"].get("step_frac"))
 print("cpu", {k: (v if not isinstance(v, dict) else v.get("value")) for k, v in d.get("cpu_baseline", {}).items() if k != "sample"})
 v = d.get("vqvae") or {}
 print("vqvae", v.get("ms_per_step"), v.get("ms_per_step_eager_streams"), v.get("ms_per_step_graph_replay"), v.get("value"), (v.get("roofline") or {}).get("frac"))

@@ -615,7 +615,7 @@ __global__ __launch_bounds__(256) void conv1d_bf16x3_kernel(ConvMfmaParams p) {
 //         stage is amortised over twice the positions -- for launches that still fill the chip with the larger tile.
 constexpr int V2_WC = 6;   // most 64-slot DMA chunks of one weight array a wave issues per stage (K <= 11)
 template <int CW, int KT>
-__global__ __launch_bounds__(256) void conv1d_bf16x3_dma_kernel(ConvMfmaParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv1d_bf16x3_dma_kernel(ConvMfmaParams p) {
   constexpr int MT = 64, LT = 128 * CW, WCO = 2 / CW;
   constexpr int XC = CW == 1 ? 4 : 7;                       // most DMA chunks of one input array per wave and stage
   extern __shared__ __attribute__((aligned(16))) float cm_smem[];
