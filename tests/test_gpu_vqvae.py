@@ -81,7 +81,7 @@ def test_conv1d_family_vs_torch(case):
 
 THIN_CASES = [  # Cin, Cout, K, stride, pad, L, B, act   (conv_thin.hip: one input channel / one output channel)
     (1, 16, 7, 1, 3, 5000, 3, None), (1, 16, 15, 1, 7, 2500, 2, "lrelu"), (1, 32, 5, 3, 2, 1862, 5, "lrelu"),
-    (1, 32, 5, 3, 2, 700, 3, None), (1024, 1, 3, 1, 1, 23, 11, None), (256, 1, 3, 1, 1, 301, 2, None),
+    (1, 32, 5, 3, 2, 700, 3, None), (1024, 1, 3, 1, 1, 23, 11, None), (256, 1, 3, 1, 1, 301, 2, None), (1024, 1, 3, 1, 1, 127, 40, None),
 ]
 
 
@@ -107,6 +107,17 @@ def test_thin_conv_kernels_vs_torch(case):
         dwr = torch.nn.grad.conv1d_weight(xr, (cout, cin, k), dy.double(), stride=s, padding=pad)
         dw = ops.conv1d_wgrad(dy.to(_dev()), x.to(_dev()), k, s, pad, 1, x_slope=0.1)
         _close(dw, dwr, 2e-5, 1e-5, "dw")
+    if cout == 1:      # the heads' data and weight gradients (round 4: streaming kernels), plain and with the bias gradient alongside
+        lout = yr.shape[2]
+        dy = torch.randn(B, cout, lout, generator=g)
+        dxr = torch.nn.grad.conv1d_input((B, cin, L), w.double(), dy.double(), stride=s, padding=pad)
+        dx = ops.conv1d_dgrad(dy.to(_dev()), w.to(_dev()), L, s, pad, 1)
+        _close(dx, dxr, 2e-6, 1e-6, "dx")
+        dwr = torch.nn.grad.conv1d_weight(x.double(), (cout, cin, k), dy.double(), stride=s, padding=pad)
+        db = torch.zeros(cout, device=_dev())
+        dw = ops.conv1d_wgrad(dy.to(_dev()), x.to(_dev()), k, s, pad, 1, db=db)
+        _close(dw, dwr, 2e-5, 1e-5, "dw (cout 1)")
+        _close(db, dy.double().sum((0, 2)), 2e-5, 1e-5, "db (cout 1)")
 
 
 CONVT_CASES = [  # Cin, Cout, K, stride, pad, L, in_slope
@@ -713,7 +724,11 @@ def _rel_l2(a, b):
 @pytest.mark.bf16x3
 @pytest.mark.parametrize("case", [(64, 64, 11, 1, 25, 5, 2048), (192, 384, 5, 1, 2, 1, 256), (512, 1024, 5, 3, 2, 1, 253),
                                   (1024, 1024, 5, 1, 2, 1, 23), (32, 16, 16, 1, 7, 1, 400), (256, 320, 5, 1, 2, 1, 37),
-                                  (320, 256, 3, 1, 1, 1, 85), (192, 192, 5, 3, 2, 1, 150)])
+                                  (320, 256, 3, 1, 1, 1, 85), (192, 192, 5, 3, 2, 1, 150),
+                                  # strided data gradients (round 4: the phase-merged form): the encoders' k16 stride-10 / stride-8 layers,
+                                  # a row length that is not a multiple of the stride, K = stride, a wide transposed-convolution shape
+                                  (16, 32, 16, 10, 7, 1, 3000), (32, 64, 16, 8, 4, 1, 1027), (24, 48, 4, 4, 0, 1, 403),
+                                  (256, 512, 16, 10, 3, 1, 320), (128, 256, 16, 8, 4, 1, 333), (40, 24, 7, 2, 3, 1, 501)])
 def test_split_bf16_conv_accuracy(case):
     """Default conv path: products as hi*hi + hi*lo + lo*hi on the bf16 matrix cores.  Stated tolerance: 2e-5 of the
     output range for the forward / data gradient (measured ~5e-6), i.e. ~100x tighter than TF32."""

@@ -72,7 +72,7 @@ def dgrad(dy, w, lin, stride=1, pad=0, dil=1, gate=None, gate_slope=1.0, bias=No
                                 groups, omask)
 
 
-def wgrad(dy, x, k, stride=1, pad=0, dil=1, x_slope=1.0, dy_slope=1.0, out=None, groups=1):
+def wgrad(dy, x, k, stride=1, pad=0, dil=1, x_slope=1.0, dy_slope=1.0, out=None, groups=1, db=None):
     sig = (shp(dy), shp(x), k, stride, pad, dil, groups, x_slope != 1.0, dy_slope != 1.0)
     ds, xs = dy.shape, x.shape
 
@@ -81,7 +81,7 @@ def wgrad(dy, x, k, stride=1, pad=0, dil=1, x_slope=1.0, dy_slope=1.0, out=None,
         o = torch.zeros(ds[1], xs[1] // groups, k, device=dy.device)
         return lambda: orig["conv1d_wgrad"](dd, xx, k, stride, pad, dil, x_slope, dy_slope, out=o, groups=groups)
     rec("wgrad", sig, make)
-    return orig["conv1d_wgrad"](dy, x, k, stride, pad, dil, x_slope, dy_slope, out, groups)
+    return orig["conv1d_wgrad"](dy, x, k, stride, pad, dil, x_slope, dy_slope, out, groups, db=db)
 
 
 def bgrad(dy, out=None):

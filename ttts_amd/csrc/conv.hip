@@ -38,6 +38,9 @@ int conv1d_thin_fwd_try(const float* x, const float* w, const float* bias, const
                         int accumulate, hipStream_t stream, bool* handled);
 int conv1d_thin_wgrad_try(const float* dy, const float* x, float* dw, int B, int Cin, int Lin, int Cout, int Lout, int K,
                           int stride, int pad, int dil, float dy_slope, float x_slope, const ConvCtx& cx, hipStream_t stream, bool* handled);
+int conv1d_thin_dgrad_try(const float* dy, const float* w, const float* bias, const float* resid, const float* gate,
+                          const float* omask, float* dx, int B, int Cin, int Lin, int Cout, int Lout, int K, int stride, int pad,
+                          int dil, float in_slope, float out_scale, int accumulate, hipStream_t stream, bool* handled);
 
 // conv_grouped.hip: few-channels-per-group convolutions on the f32-input matrix cores
 int conv1d_grouped_fwd_mfma_try(const float* x, const float* w, const float* bias, const float* bbias, const float* resid,
@@ -714,6 +717,12 @@ extern "C" int ttts_conv1d_dgrad_f32(const float* dy, const float* w, const floa
   TTTS_REQUIRE(B > 0 && Cin > 0 && Lin > 0 && Cout > 0 && Lout > 0 && K > 0 && stride > 0 && dil > 0 && pad >= 0, "conv1d_dgrad: bad shape");
   TTTS_REQUIRE(stride == 1 || dil == 1, "conv1d_dgrad: stride > 1 requires dilation 1");
   TTTS_REQUIRE((Lout - 1) * stride - 2 * pad + dil * (K - 1) + 1 <= Lin, "conv1d_dgrad: Lin too small for Lout");
+  if (groups == 1 && !(cx.flags & (256 | 8388608))) {       // one output channel: a streaming kernel (conv_thin.hip)
+    bool handled = false;
+    int rc2 = conv1d_thin_dgrad_try(dy, w, bias, resid, gate, omask, dx, B, Cin, Lin, Cout, Lout, K, stride, pad, dil, in_slope, out_scale,
+                                    accumulate, as_stream(stream), &handled);
+    if (rc2 || handled) return rc2;
+  }
   if (groups == 1 && stride == 1 && !(cx.flags & 256)) {
     // stride-1 data gradient == forward convolution of dy with the transposed, tap-flipped weights and pad' = dil (K-1) - pad
     bool handled = false;

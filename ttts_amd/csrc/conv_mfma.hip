@@ -48,6 +48,10 @@ struct ConvMfmaParams {
                        // block -- a stage that short is all DMA latency)
   int catLg, catLout;  // > 0: the batch is laid end to end as ONE virtual row (B == 1 here), output position v = b * catLg + j,
                        // j < catLout real positions per batch element (short rows: DiscriminatorP's 23..127-position layers)
+  int rowS, rpad;      // rowS > 0: PHASE-MERGED strided data gradient (round 4).  Row m of the GEMM is (channel m / rowS, phase
+                       // m % rowS) of dx: dx[ci][rowS j + r] = sum_{n, e} w[n][ci][k(r, e)] dy[n][j + e], one stride-1 convolution
+                       // with rowS x the rows and ceil(K / rowS) + 1 taps instead of rowS launches with M = Cin rows each
+                       // (conv1d_dgrad_strided_mfma_try); rpad = the strided convolution's own padding, p.pad = -min e
 };
 
 
@@ -219,9 +223,19 @@ __global__ __launch_bounds__(256) void conv_input_split_kernel(const float* __re
   }
 }
 
+// the merged-phase weight of row m, virtual tap k: w[n][ci][kk] with ci = m / S, r = m % S, t = (r + rpad) / S - (k - vpad),
+// kk = (r + rpad) % S + S t -- or zero when that tap does not exist
+__device__ __forceinline__ float merged_phase_weight(const float* __restrict__ w, int m, int n, int k, int Cin, int Kmem, int S,
+                                                     int rpad, int vpad) {
+  const int ci = m / S, r = m - ci * S;
+  const int t = (r + rpad) / S - (k - vpad), kk = (r + rpad) % S + S * t;
+  return (t >= 0 && kk < Kmem) ? w[((int64_t)n * Cin + ci) * Kmem + kk] : 0.f;
+}
+
 __global__ __launch_bounds__(256) void conv_weight_split_kernel(const float* __restrict__ w, bf16* __restrict__ a_hi,
                                                                 bf16* __restrict__ a_lo, int M, int N, int Mpad, int nblk,
-                                                                int K, int Kmem, int transposed, int tap_off, int tap_stride, int AP) {
+                                                                int K, int Kmem, int transposed, int tap_off, int tap_stride, int AP,
+                                                                int rowS = 0, int rpad = 0, int vpad = 0) {
   // rows of AP >= K*16 elements ([tap][16 channels], zero tail): AP = K*16 + 8 is the LDS row pitch of the DMA-fed kernel,
   // whose stages are verbatim copies of [MT rows][AP] runs of these arrays
   const int64_t total = (int64_t)nblk * Mpad * AP;
@@ -232,7 +246,8 @@ __global__ __launch_bounds__(256) void conv_weight_split_kernel(const float* __r
     float v = 0.f;
     if (k < K && m < M && n < N) {
       // forward: A[m][k][n] = w[m][n][k];  data gradient: A[m][k][n] = w[n][m][tap_off + tap_stride * (K - 1 - k)]
-      v = transposed ? w[((int64_t)n * M + m) * Kmem + tap_off + tap_stride * (K - 1 - k)] : w[((int64_t)m * N + n) * Kmem + k];
+      if (rowS > 0) v = merged_phase_weight(w, m, n, k, M / rowS, Kmem, rowS, rpad, vpad);
+      else v = transposed ? w[((int64_t)n * M + m) * Kmem + tap_off + tap_stride * (K - 1 - k)] : w[((int64_t)m * N + n) * Kmem + k];
     }
     const bf16 h = (bf16)v;
     a_hi[i] = h;
@@ -250,7 +265,7 @@ __global__ __launch_bounds__(256) void conv_weight_split_kernel(const float* __r
 struct WsplitDesc {
   const float* w; bf16* hi; bf16* lo;
   int M, N, Mpad, nblk, K, Kmem, transposed, tap_off, tap_stride, AP;
-  int block_begin, pad_;
+  int block_begin, rowS, rpad, vpad;
 };
 constexpr int WSPLIT_EPB = 2048;      // elements per workgroup of the batched launch (8 per thread)
 
@@ -271,9 +286,11 @@ __global__ __launch_bounds__(256) void conv_weight_split_batched_kernel(const Ws
   for (int c = 0; c < 8; ++c) {
     const int n = nb * 16 + c0 + c;
     float v = 0.f;
-    if (k < d.K && m < d.M && n < d.N)
-      v = d.transposed ? d.w[((int64_t)n * d.M + m) * d.Kmem + d.tap_off + d.tap_stride * (d.K - 1 - k)]
-                       : d.w[((int64_t)m * d.N + n) * d.Kmem + k];
+    if (k < d.K && m < d.M && n < d.N) {
+      if (d.rowS > 0) v = merged_phase_weight(d.w, m, n, k, d.M / d.rowS, d.Kmem, d.rowS, d.rpad, d.vpad);
+      else v = d.transposed ? d.w[((int64_t)n * d.M + m) * d.Kmem + d.tap_off + d.tap_stride * (d.K - 1 - k)]
+                            : d.w[((int64_t)m * d.N + n) * d.Kmem + k];
+    }
     const bf16 hv = (bf16)v;
     h[c] = hv;
     l[c] = (bf16)(v - (float)hv);
@@ -283,16 +300,17 @@ __global__ __launch_bounds__(256) void conv_weight_split_batched_kernel(const Ws
 }
 
 struct WsplitKey {
-  const float* w; int M, N, Mpad, K, Kmem, transposed, tap_off, tap_stride, AP;
+  const float* w; int M, N, Mpad, K, Kmem, transposed, tap_off, tap_stride, AP, rowS, rpad, vpad;
   bool operator==(const WsplitKey& o) const {
     return w == o.w && M == o.M && N == o.N && Mpad == o.Mpad && K == o.K && Kmem == o.Kmem && transposed == o.transposed &&
-           tap_off == o.tap_off && tap_stride == o.tap_stride && AP == o.AP;
+           tap_off == o.tap_off && tap_stride == o.tap_stride && AP == o.AP && rowS == o.rowS && rpad == o.rpad && vpad == o.vpad;
   }
 };
 struct WsplitKeyHash {
   size_t operator()(const WsplitKey& k) const {
     uint64_t h = reinterpret_cast<uint64_t>(k.w) * 0x9E3779B97F4A7C15ull;
-    for (int v : {k.M, k.N, k.Mpad, k.K, k.Kmem, k.transposed, k.tap_off, k.tap_stride, k.AP}) h = (h ^ (uint64_t)(uint32_t)v) * 0x100000001B3ull;
+    for (int v : {k.M, k.N, k.Mpad, k.K, k.Kmem, k.transposed, k.tap_off, k.tap_stride, k.AP, k.rowS, k.rpad, k.vpad})
+      h = (h ^ (uint64_t)(uint32_t)v) * 0x100000001B3ull;
     return (size_t)h;
   }
 };
@@ -317,7 +335,7 @@ static bool wsplit_lookup(const ConvMfmaParams& p, int nblk, int AP, int64_t ele
   for (WsplitCache* c : g_wsplit) {
     if (wp < c->w_lo || wp >= c->w_hi) continue;
     if (!c->armed) return false;
-    const WsplitKey key{p.w, p.M, p.N, p.Mpad, p.K, p.Kmem, p.transposed, p.tap_off, p.tap_stride, AP};
+    const WsplitKey key{p.w, p.M, p.N, p.Mpad, p.K, p.Kmem, p.transposed, p.tap_off, p.tap_stride, AP, p.rowS, p.rpad, p.pad};
     auto it = c->index.find(key);
     if (it != c->index.end()) {
       const WsplitDesc& d = c->host[it->second];
@@ -333,7 +351,7 @@ static bool wsplit_lookup(const ConvMfmaParams& p, int nblk, int AP, int64_t ele
     WsplitDesc d;
     d.w = p.w; d.hi = reinterpret_cast<bf16*>(c->storage + c->used); d.lo = d.hi + elems_alloc;
     d.M = p.M; d.N = p.N; d.Mpad = p.Mpad; d.nblk = nblk; d.K = p.K; d.Kmem = p.Kmem; d.transposed = p.transposed;
-    d.tap_off = p.tap_off; d.tap_stride = p.tap_stride; d.AP = AP; d.pad_ = 0;
+    d.tap_off = p.tap_off; d.tap_stride = p.tap_stride; d.AP = AP; d.rowS = p.rowS; d.rpad = p.rpad; d.vpad = p.pad;
     d.block_begin = (int)c->blocks;
     const int idx = (int)c->host.size();
     c->host.push_back(d);                     // (reserved to max_entries: the element never moves under the copy below)
@@ -366,6 +384,23 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvMfmaParams& p, cons
     }
     const int j = p.out_off + jt * p.out_stride;
     const float om = p.omask ? p.omask[(int64_t)b * p.LoutTotal + j] : 1.f;
+    if (p.rowS > 0) {                                      // phase-merged data gradient: row (ci, r) -> dx[b][ci][rowS jt + r]
+      const int nch = p.M / p.rowS;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wco * 32 + acc_row(r, hh);
+        if (m >= p.M) continue;
+        const int ci = m / p.rowS, jj = jt * p.rowS + (m - ci * p.rowS);
+        if (jj >= p.LoutTotal) continue;
+        const int64_t o = ((int64_t)b * nch + ci) * p.LoutTotal + jj;
+        float v = (t == 0 ? acc0[r] : acc1[r]) + (p.bias ? p.bias[ci] : 0.f);
+        if (p.gate) v *= (p.gate[o] > 0.f ? 1.f : p.gate_slope);
+        if (p.resid) v += p.resid[o];
+        v *= (p.omask ? p.omask[(int64_t)b * p.LoutTotal + jj] : 1.f) * p.out_scale;
+        p.y[o] = p.accumulate ? p.y[o] + v : v;
+      }
+      continue;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = m0 + wco * 32 + acc_row(r, hh);
@@ -961,7 +996,7 @@ static int conv1d_bf16x3_dma_launch(ConvMfmaParams p, const ConvCtx& cx, hipStre
   p.a_hi = hi; p.a_lo = lo;
   if (need_split)
     conv_weight_split_kernel<<<(int)std::min<int64_t>(cdiv(welems, 256), 2048), 256, 0, stream>>>(p.w, hi, lo, p.M, p.N, p.Mpad, nblk, K, p.Kmem,
-                                                                                               p.transposed, p.tap_off, p.tap_stride, AP);
+                                                                                               p.transposed, p.tap_off, p.tap_stride, AP, p.rowS, p.rpad, p.pad);
   if (!p.x_hi) {   // (polyphase data gradients share one split of dy across their phase launches)
     conv_input_split_kernel<<<(int)std::min<int64_t>(cdiv(xel / 16, 256), 8192), 256, 0, stream>>>(p.x, xhi, xlo, p.B, p.N, p.Lin, nblk, p.in_slope,
                                                                                                    p.Lp, p.PADL, cat_w, cat_b, cat_l);
@@ -1015,7 +1050,7 @@ static int conv1d_bf16x3_launch_t(ConvMfmaParams p, const ConvCtx& cx, hipStream
   p.a_hi = hi; p.a_lo = lo;
   if (need_split)
     conv_weight_split_kernel<<<(int)std::min<int64_t>(cdiv(elems, 256), 2048), 256, 0, stream>>>(p.w, hi, lo, p.M, p.N, p.Mpad, nblk, K, p.Kmem,
-                                                                                              p.transposed, p.tap_off, p.tap_stride, K * 16);
+                                                                                              p.transposed, p.tap_off, p.tap_stride, K * 16, p.rowS, p.rpad, p.pad);
   dim3 grid((unsigned)cdiv(p.Lout, SEG == LT ? LT : SEG), (unsigned)cdiv(p.M, MT), (unsigned)cdiv(p.B, LT / SEG));
   int rc = TTTS_OK;
 #define TTTS_V1(KT_)                                                                                 \
@@ -1046,6 +1081,7 @@ static int conv1d_mfma_launch(ConvMfmaParams p, const ConvCtx& cx, hipStream_t s
       if (rc || *handled) return rc;
     }
   }
+  if (p.rowS > 0) return TTTS_OK;        // (the phase-merged form exists in the split-bf16 kernels only: the caller falls back)
   // tile choice: always the largest tile.  Measured (tools/conv_bench.py, B = 32): the smaller tiles <2,2>, <1,2>, <1,1> --
   // meant to put more workgroups on a CU for the 192-channel x 256-frame layers -- are 2-2.5x SLOWER there (WN in_layer
   // dgrad 346 -> 738 us): the kernel is bound by the global -> LDS staging work per MFMA, so less reuse per staged slab
@@ -1087,6 +1123,29 @@ int conv1d_dgrad_strided_mfma_try(const float* dy, const float* w, const float* 
                                   int accumulate, const ConvCtx& cx, hipStream_t stream, bool* handled) {
   *handled = false;
   if (Cout < 8 || K > 16 * stride || K < stride) return TTTS_OK;
+  // Phase-merged form (round 4): ONE stride-1 convolution whose rows are (channel, phase) pairs.  The per-phase launches below run
+  // with M = Cin rows each -- 16 of a 64-row tile for the encoders' 16 -> 32 k16 stride-10 layer: 1600 us for 0.3 GB of output --
+  // re-read dy `stride` times and reduce over one or two taps; merged, the launch has Cin x stride rows, reads dy once and reduces
+  // over Cout x (ceil(K / stride) + 1) taps.  Split-bf16 kernels only: flag 4096 (exact fp32) and flag 4194304 (A/B switch) keep the
+  // per-phase launches.
+  if (cx.ws && Cout >= 16 && (int64_t)Cin * stride <= 8192 && !(cx.flags & 4096) && !(cx.flags & 4194304)) {
+    int emax = (stride - 1 + pad) / stride, emin = emax;
+    for (int r = 0; r < stride; ++r) {
+      const int qr = (r + pad) / stride, rem = (r + pad) % stride;
+      if (rem >= K) continue;                              // (cannot happen with K >= stride)
+      emin = std::min(emin, qr - (K - 1 - rem) / stride);
+    }
+    const int Kv = emax - emin + 1, T = (int)cdiv(Lin, stride);
+    ConvMfmaParams p{dy, w, bias, nullptr, resid, omask, gate, dx, B, Cin * stride, Cout, Lout, T, Kv, 1, -emin, 1, 1, 0,
+                     K, 0, 1, 1, 0, Lin, 0, in_slope, gate_slope, 0, 1.f, out_scale, accumulate, nullptr, nullptr, 0, nullptr, nullptr, 0, 0};
+    p.rowS = stride; p.rpad = pad;
+    if (-emin >= 0) {
+      bool h = false;
+      int rc = conv1d_mfma_launch(p, cx, stream, &h);
+      if (rc) return rc;
+      if (h) { *handled = true; return TTTS_OK; }
+    }
+  }
   // split-bf16 path: split dy ONCE for all phases (same place conv1d_bf16x3_dma_launch would put it), padded for the
   // phase that reaches furthest; only if every phase fits the DMA kernel
   const bf16* xs_hi = nullptr;

@@ -184,6 +184,69 @@ __global__ __launch_bounds__(256) void conv1d_cout1_fwd_kernel(const float* __re
   }
 }
 
+// ---- data gradient, Cout = 1, stride 1:  dx[b][ci][i] = out_scale * sum_k w[ci][k] * dy[b][i + pad - k*dil] -------------------------
+// (round 4: DiscriminatorP's 1024 -> 1 heads ran the tile kernels at 0.4 TF/s, 190-250 us for 66 MB of output.)  One output element
+// per thread, flat over (b, ci, i): stores are fully coalesced, the 3 weights and the 23..127-sample dy row come from L1.
+__global__ __launch_bounds__(256) void conv1d_cout1_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                                 float* __restrict__ dx, int64_t total, int Cin, int Lin, int Lout,
+                                                                 int K, int pad, int dil, float out_scale) {
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int i = (int)(idx % Lin);
+    const int64_t r = idx / Lin;
+    const int ci = (int)(r % Cin);
+    const int64_t b = r / Cin;
+    const float* dyr = dy + b * Lout;
+    const float* wr = w + (int64_t)ci * K;
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const int j = i + pad - k * dil;
+      if (j >= 0 && j < Lout) acc = fmaf(wr[k], dyr[j], acc);
+    }
+    dx[idx] = acc * out_scale;
+  }
+}
+
+// ---- weight gradient, Cout = 1, stride 1:  dw[ci][k] += sum_{b,l} dy[b][l] * x[b][ci][l - pad + k*dil] ---------------------------
+// One wave per (input channel, batch slice): lane = position (rows of 23..127 samples: one or two passes of 64), the row of x is one
+// coalesced load, tap k's operand is the same row read at a shifted position (L1).  Eight rows in flight per wave; the per-slice
+// partial sums go to a slab [slice][ci][k] and are added in slice order (thin_slab_sum_kernel): deterministic.
+constexpr int TO_WG_SLICES = 16;
+__global__ __launch_bounds__(256) void conv1d_cout1_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                 float* __restrict__ slab, int B, int Cin, int Lin, int Lout, int K,
+                                                                 int pad, int dil) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ci = blockIdx.x * 4 + wave, slice = blockIdx.y;
+  if (ci >= Cin) return;
+  const int bper = (B + TO_WG_SLICES - 1) / TO_WG_SLICES, b0 = slice * bper, b1 = min(B, b0 + bper);
+  float acc[TO_KMAX];
+#pragma unroll
+  for (int k = 0; k < TO_KMAX; ++k) acc[k] = 0.f;
+  for (int l0 = 0; l0 < Lout; l0 += 64) {
+    const int l = l0 + lane;
+    const bool lok = l < Lout;
+#pragma unroll 4
+    for (int b = b0; b < b1; ++b) {
+      const float d = lok ? dy[(int64_t)b * Lout + l] : 0.f;
+      const float* xr = x + ((int64_t)b * Cin + ci) * Lin;
+#pragma unroll
+      for (int k = 0; k < TO_KMAX; ++k) {
+        if (k < K) {
+          const int g = l - pad + k * dil;
+          const float v = (lok && g >= 0 && g < Lin) ? xr[g] : 0.f;
+          acc[k] = fmaf(d, v, acc[k]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < TO_KMAX; ++k) {
+    if (k < K) {
+      const float s = wave_sum(acc[k]);
+      if (lane == 0) slab[((int64_t)slice * Cin + ci) * K + k] = s;
+    }
+  }
+}
+
 // ---- dispatch (conv.hip) ------------------------------------------------------------------------------------------------------
 int conv1d_thin_fwd_try(const float* x, const float* w, const float* bias, const float* bbias, const float* resid,
                         const float* gate, const float* omask, float* y, int B, int Cin, int Lin, int Cout, int Lout, int K,
@@ -209,6 +272,21 @@ int conv1d_thin_fwd_try(const float* x, const float* w, const float* bias, const
   return TTTS_OK;
 }
 
+int conv1d_thin_dgrad_try(const float* dy, const float* w, const float* bias, const float* resid, const float* gate,
+                          const float* omask, float* dx, int B, int Cin, int Lin, int Cout, int Lout, int K, int stride, int pad,
+                          int dil, float in_slope, float out_scale, int accumulate, hipStream_t stream, bool* handled) {
+  *handled = false;
+  if (bias || resid || gate || omask || accumulate || in_slope != 1.f) return TTTS_OK;
+  if (Cout == 1 && stride == 1 && K <= TO_KMAX && Cin >= 64) {
+    const int64_t total = (int64_t)B * Cin * Lin;
+    conv1d_cout1_dgrad_kernel<<<(unsigned)std::min<int64_t>(cdiv(total, 256), 65536), 256, 0, stream>>>(dy, w, dx, total, Cin, Lin, Lout, K, pad,
+                                                                                                     dil, out_scale);
+    *handled = true;
+    return check_launch("conv1d_cout1_dgrad");
+  }
+  return TTTS_OK;
+}
+
 template <int K, int RW>
 static int cin1_wgrad_launch(const float* dy, const float* x, float* dw, int B, int Lin, int Cout, int Lout, int stride, int pad,
                              int dil, float dy_slope, float x_slope, const ConvCtx& cx, hipStream_t stream) {
@@ -225,6 +303,14 @@ int conv1d_thin_wgrad_try(const float* dy, const float* x, float* dw, int B, int
                           int stride, int pad, int dil, float dy_slope, float x_slope, const ConvCtx& cx, hipStream_t stream,
                           bool* handled) {
   *handled = false;
+  if (Cout == 1 && stride == 1 && K <= TO_KMAX && Cin >= 64 && dy_slope == 1.f && x_slope == 1.f && cx.ws &&
+      (int64_t)TO_WG_SLICES * Cin * K * (int64_t)sizeof(float) <= cx.ws_bytes) {
+    float* slab = static_cast<float*>(cx.ws);
+    conv1d_cout1_wgrad_kernel<<<dim3((unsigned)cdiv(Cin, 4), TO_WG_SLICES), 256, 0, stream>>>(dy, x, slab, B, Cin, Lin, Lout, K, pad, dil);
+    thin_slab_sum_kernel<<<Cin * K, 256, 0, stream>>>(slab, dw, TO_WG_SLICES, Cin * K);
+    *handled = true;
+    return check_launch("conv1d_cout1_wgrad");
+  }
   if (Cin != 1 || (size_t)((T1_CH - 1) * stride + (K - 1) * dil + 1) * sizeof(float) > 60 * 1024) return TTTS_OK;
   int rc = TTTS_OK;
   if (K == 7 && Cout <= 16) rc = cin1_wgrad_launch<7, 4>(dy, x, dw, B, Lin, Cout, Lout, stride, pad, dil, dy_slope, x_slope, cx, stream);
