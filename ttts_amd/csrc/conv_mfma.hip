@@ -52,6 +52,10 @@ struct ConvMfmaParams {
                        // m % rowS) of dx: dx[ci][rowS j + r] = sum_{n, e} w[n][ci][k(r, e)] dy[n][j + e], one stride-1 convolution
                        // with rowS x the rows and ceil(K / rowS) + 1 taps instead of rowS launches with M = Cin rows each
                        // (conv1d_dgrad_strided_mfma_try); rpad = the strided convolution's own padding, p.pad = -min e
+                       // rowS < 0: PHASE-MERGED strided FORWARD with S = -rowS: input channel n of the GEMM is (channel n / S, phase
+                       // n % S) of x, x'[(ci, r)][j] = x[ci][S j + r] (the pre-split pass de-interleaves), y[co][l] = sum w[co][ci][S t
+                       // + r + rpad] x'[(ci, r)][l + t]: a stride-1 convolution over Cin x S channels with ~K / S + 1 taps (DMA kernel only)
+  int Lreal;           // rowS < 0: row length of the real input x
 };
 
 
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(64 * NW) void conv1d_mfma_kernel(ConvMfmaParams p) 
 // above MFMA time)
 __global__ __launch_bounds__(256) void conv_input_split_kernel(const float* __restrict__ x, bf16* __restrict__ hi,
                                                                bf16* __restrict__ lo, int B, int N, int L, int nblk, float slope,
-                                                               int Lp, int PADL, int catW, int catB, int catL) {
+                                                               int Lp, int PADL, int catW, int catB, int catL, int inS = 0, int Lreal = 0) {
   // one thread per (batch element, 16-channel block, padded position): 16 coalesced row reads, four 16-byte stores.
   // catW > 0: ONE destination row (B == 1) holding the catB source rows of length catL end to end, catW positions apart
   const int64_t total = (int64_t)B * nblk * Lp;
@@ -202,14 +206,28 @@ __global__ __launch_bounds__(256) void conv_input_split_kernel(const float* __re
       inside = pos >= 0 && pos < catL && bb < catB;
       b = min(bb, catB - 1); Lr = catL;
     }
-    const float* xr = x + (b * N) * Lr + min(max(pos, 0), Lr - 1);
     float raw[16];
+    bool okc[16];
+    if (inS > 0) {       // phase-de-interleaved view: channel n = (ci, r), position pos  <-  x[b][ci][inS pos + r]  (catW == 0 here)
+      const int Cin = N / inS;
+      const float* xb = x + (b * Cin) * Lreal;
+      const int64_t base = (int64_t)inS * max(pos, 0);
 #pragma unroll
-    for (int c = 0; c < 16; ++c) raw[c] = xr[(int64_t)min(nb * 16 + c, N - 1) * Lr];   // unconditional (clamped) loads, then select
+      for (int c = 0; c < 16; ++c) {
+        const int n = min(nb * 16 + c, N - 1), ci = n / inS, r = n - ci * inS;
+        const int64_t q = base + r;
+        okc[c] = q < Lreal;
+        raw[c] = xb[(int64_t)ci * Lreal + min(q, (int64_t)Lreal - 1)];
+      }
+    } else {
+      const float* xr = x + (b * N) * Lr + min(max(pos, 0), Lr - 1);
+#pragma unroll
+      for (int c = 0; c < 16; ++c) { raw[c] = xr[(int64_t)min(nb * 16 + c, N - 1) * Lr]; okc[c] = true; }   // unconditional (clamped) loads, then select
+    }
     bf16x8 h0, h1, l0, l1;
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
-      float v = (inside && nb * 16 + c < N) ? raw[c] : 0.f;
+      float v = (inside && okc[c] && nb * 16 + c < N) ? raw[c] : 0.f;
       v = lrelu_f(v, slope);
       const bf16 hv = (bf16)v;
       const bf16 lv = (bf16)(v - (float)hv);
@@ -232,6 +250,14 @@ __device__ __forceinline__ float merged_phase_weight(const float* __restrict__ w
   return (t >= 0 && kk < Kmem) ? w[((int64_t)n * Cin + ci) * Kmem + kk] : 0.f;
 }
 
+// the merged-phase FORWARD weight of output row m, virtual input channel n = (ci, r), virtual tap k: w[m][ci][S (k - vpad) + r + rpad]
+__device__ __forceinline__ float merged_fwd_weight(const float* __restrict__ w, int m, int n, int k, int Cin, int Kmem, int S,
+                                                   int rpad, int vpad) {
+  const int ci = n / S, r = n - ci * S;
+  const int kk = S * (k - vpad) + r + rpad;
+  return (kk >= 0 && kk < Kmem) ? w[((int64_t)m * Cin + ci) * Kmem + kk] : 0.f;
+}
+
 __global__ __launch_bounds__(256) void conv_weight_split_kernel(const float* __restrict__ w, bf16* __restrict__ a_hi,
                                                                 bf16* __restrict__ a_lo, int M, int N, int Mpad, int nblk,
                                                                 int K, int Kmem, int transposed, int tap_off, int tap_stride, int AP,
@@ -247,6 +273,7 @@ __global__ __launch_bounds__(256) void conv_weight_split_kernel(const float* __r
     if (k < K && m < M && n < N) {
       // forward: A[m][k][n] = w[m][n][k];  data gradient: A[m][k][n] = w[n][m][tap_off + tap_stride * (K - 1 - k)]
       if (rowS > 0) v = merged_phase_weight(w, m, n, k, M / rowS, Kmem, rowS, rpad, vpad);
+      else if (rowS < 0) v = merged_fwd_weight(w, m, n, k, N / -rowS, Kmem, -rowS, rpad, vpad);
       else v = transposed ? w[((int64_t)n * M + m) * Kmem + tap_off + tap_stride * (K - 1 - k)] : w[((int64_t)m * N + n) * Kmem + k];
     }
     const bf16 h = (bf16)v;
@@ -288,6 +315,7 @@ __global__ __launch_bounds__(256) void conv_weight_split_batched_kernel(const Ws
     float v = 0.f;
     if (k < d.K && m < d.M && n < d.N) {
       if (d.rowS > 0) v = merged_phase_weight(d.w, m, n, k, d.M / d.rowS, d.Kmem, d.rowS, d.rpad, d.vpad);
+      else if (d.rowS < 0) v = merged_fwd_weight(d.w, m, n, k, d.N / -d.rowS, d.Kmem, -d.rowS, d.rpad, d.vpad);
       else v = d.transposed ? d.w[((int64_t)n * d.M + m) * d.Kmem + d.tap_off + d.tap_stride * (d.K - 1 - k)]
                             : d.w[((int64_t)m * d.N + n) * d.Kmem + k];
     }
@@ -947,7 +975,7 @@ static DmaGeom conv_dma_geom(const ConvMfmaParams& p, int CW) {
   for (int cand = 4; cand >= 2; cand >>= 1)
     if (cand * g.nxc <= xcmax && cand * g.nwc <= 4 * V2_WC && cand <= nblk && 2 * cand * stage1 <= lds_cap) { g.nbs = cand; break; }
   g.smem = 2 * g.nbs * stage1;
-  g.ok = g.nxc <= xcmax && g.nwc <= 4 * V2_WC && g.smem <= 150 * 1024 && p.M > 32 && p.N >= 16;
+  g.ok = g.nxc <= xcmax && g.nwc <= 4 * V2_WC && g.smem <= 150 * 1024 && (p.M > 32 || (p.rowS < 0 && p.M >= 16)) && p.N >= 16;
   return g;
 }
 // the 64 x 256 tile when it still yields >= 2 workgroups per CU (flag 131072: never, flag 262144: whenever it fits)
@@ -962,7 +990,7 @@ static int conv1d_bf16x3_dma_launch(ConvMfmaParams p, const ConvCtx& cx, hipStre
   // of a 64-position segment), lay the whole batch end to end as one virtual row with zero gaps wide enough for the taps
   // (flag 134217728: keep the segment folding)
   int cat_w = 0, cat_b = 0, cat_l = 0;
-  if (!p.x_hi && p.B > 1 && p.SEG <= 128 && p.out_stride == 1 && p.out_off == 0 && p.LoutTotal == p.Lout && !(cx.flags & 134217728)) {
+  if (!p.x_hi && p.B > 1 && p.SEG <= 128 && p.out_stride == 1 && p.out_off == 0 && p.LoutTotal == p.Lout && p.rowS == 0 && !(cx.flags & 134217728)) {
     const int S = p.stride;
     const int reach = std::max(std::max(p.pad, S * (p.Lout - 1) - p.pad + (p.K - 1) * p.dil - (p.Lin - 1)), 0);
     const int Lg = std::max(p.Lout, (int)cdiv(p.Lin + reach, S));
@@ -999,7 +1027,7 @@ static int conv1d_bf16x3_dma_launch(ConvMfmaParams p, const ConvCtx& cx, hipStre
                                                                                                p.transposed, p.tap_off, p.tap_stride, AP, p.rowS, p.rpad, p.pad);
   if (!p.x_hi) {   // (polyphase data gradients share one split of dy across their phase launches)
     conv_input_split_kernel<<<(int)std::min<int64_t>(cdiv(xel / 16, 256), 8192), 256, 0, stream>>>(p.x, xhi, xlo, p.B, p.N, p.Lin, nblk, p.in_slope,
-                                                                                                   p.Lp, p.PADL, cat_w, cat_b, cat_l);
+                                                                                                   p.Lp, p.PADL, cat_w, cat_b, cat_l, p.rowS < 0 ? -p.rowS : 0, p.Lreal);
     p.x_hi = xhi; p.x_lo = xlo;
   }
   dim3 grid((unsigned)cdiv(p.Lout, SEG == LT ? LT : SEG), (unsigned)cdiv(p.M, MT), (unsigned)cdiv(p.B, LT / SEG));
@@ -1029,11 +1057,12 @@ static int conv1d_bf16x3_launch_t(ConvMfmaParams p, const ConvCtx& cx, hipStream
   // pre-split + DMA kernel when the input is re-read by >= 3 output-channel tiles (measured: a full extra pass over x costs
   // more than on-the-fly splitting for the 16..64-channel long-row layers, and wins from 192 channels up); flag 32768:
   // from one tile, flag 65536: never (tools/conv_bench.py)
-  if (WCO == 2 && !(cx.flags & 65536) && (p.x_hi != nullptr || cdiv(p.M, MT) >= ((cx.flags & 32768) ? 1 : 3))) {
+  if (WCO == 2 && !(cx.flags & 65536) && (p.x_hi != nullptr || p.rowS < 0 || cdiv(p.M, MT) >= ((cx.flags & 32768) ? 1 : 3))) {
     int rc = conv1d_bf16x3_dma_launch(p, cx, stream, handled, conv_dma_pick(p, cx));
     if (rc || *handled) return rc;
     if (p.x_hi) return fail(TTTS_EUNSUPPORTED, "conv1d: shared input split without the DMA kernel");
   }
+  if (p.rowS < 0) return TTTS_OK;          // (the de-interleaved input only exists as the DMA kernel's pre-split copy)
   const int K = p.K, SEG = p.SEG > LT ? LT : p.SEG;
   p.SEG = SEG;
   const int lin_t = (LT / SEG) * ((SEG - 1) * p.stride + (K - 1) * p.dil + 1);
@@ -1074,6 +1103,7 @@ static int conv1d_mfma_launch(ConvMfmaParams p, const ConvCtx& cx, hipStream_t s
   // batch folding for short rows (see SEG); requested segment length, clipped to the tile by the launcher
   p.SEG = conv_seg_request(p.Lout, p.B);
   if (cx.ws && p.N >= 16 && !(cx.flags & 4096)) {
+    if (p.rowS < 0) return conv1d_bf16x3_launch_t<2>(p, cx, stream, handled);
     int rc = p.M <= 32 ? conv1d_bf16x3_launch_t<1>(p, cx, stream, handled) : conv1d_bf16x3_launch_t<2>(p, cx, stream, handled);
     if (rc || *handled) return rc;
     if (p.M <= 32) {   // the 32 x 256 tile's input strip did not fit LDS (large stride): 64 x 128, half of its rows idle
@@ -1081,7 +1111,7 @@ static int conv1d_mfma_launch(ConvMfmaParams p, const ConvCtx& cx, hipStream_t s
       if (rc || *handled) return rc;
     }
   }
-  if (p.rowS > 0) return TTTS_OK;        // (the phase-merged form exists in the split-bf16 kernels only: the caller falls back)
+  if (p.rowS != 0) return TTTS_OK;       // (the phase-merged forms exist in the split-bf16 kernels only: the caller falls back)
   // tile choice: always the largest tile.  Measured (tools/conv_bench.py, B = 32): the smaller tiles <2,2>, <1,2>, <1,1> --
   // meant to put more workgroups on a CU for the 192-channel x 256-frame layers -- are 2-2.5x SLOWER there (WN in_layer
   // dgrad 346 -> 738 us): the kernel is bound by the global -> LDS staging work per MFMA, so less reuse per staged slab
@@ -1109,6 +1139,24 @@ int conv1d_mfma_try(const float* x, const float* w, const float* bias, const flo
   *handled = false;
   if (N < 8 || K > 16) return TTTS_OK;       // thin inputs / long taps stay on the direct kernels (M = 1 heads are fine:
                                              // a 32-row tile with one live row beats looping 1024 channels on the vector ALUs)
+  // Phase-merged strided forward (round 4; see ConvMfmaParams::rowS < 0): the k16 stride-8 / stride-10 resampling layers staged a
+  // 2576-position input strip per 256 outputs and ran at 5-25 TF/s; as a stride-1 convolution over Cin x stride de-interleaved
+  // channels they take the DMA kernel: 668 -> 322 us (16 -> 32 k16 s10), 772 -> 150 us (256 -> 512 k16 s10); at stride 2 the plain
+  // strided staging is still faster (32.6 vs 41.7 us), hence stride >= 4.  Flag 4194304: off (A/B switch, shared with the merged
+  // data gradient).
+  if (stride >= 4 && dil == 1 && !transposed && K >= stride && cx.ws && N >= 2 && (int64_t)N * stride >= 16 && (int64_t)N * stride <= 8192 &&
+      !(cx.flags & (4096 | 4194304 | 65536))) {
+    const int tmin = pad > 0 ? -(int)cdiv(pad, stride) : 0;              // floor((0 - pad) / stride)
+    const int tmax = (K - 1 - pad) >= 0 ? (K - 1 - pad) / stride : -(int)cdiv(pad - (K - 1), stride);
+    const int Kv = tmax - tmin + 1;
+    ConvMfmaParams q{x, w, bias, bbias, resid, omask, gate, y, B, M, N * stride, (int)cdiv(Lin, stride), Lout, Kv, 1, -tmin, 1, 0, 0,
+                     K, 0, 1, 1, 0, Lout, 0, in_slope, gate_slope, out_act, out_slope, out_scale, accumulate, nullptr, nullptr, 0, nullptr, nullptr};
+    q.rowS = -stride; q.rpad = pad; q.Lreal = Lin;
+    bool h = false;
+    int rc = conv1d_mfma_launch(q, cx, stream, &h);
+    if (rc) return rc;
+    if (h) { *handled = true; return TTTS_OK; }
+  }
   ConvMfmaParams p{x, w, bias, bbias, resid, omask, gate, y, B, M, N, Lin, Lout, K, stride, pad, dil, transposed, 0,
                    K, 0, 1, 1, 0, Lout, 0, in_slope, gate_slope, out_act, out_slope, out_scale, accumulate, nullptr, nullptr, 0, nullptr, nullptr};
   return conv1d_mfma_launch(p, cx, stream, handled);
