@@ -215,7 +215,10 @@ def test_resblock1_vs_oracle_at_path_shape():
 
 
 @pytest.mark.parametrize("case", [(16, 64, 41, 4, 20, 4, 600), (64, 256, 41, 4, 20, 16, 300), (512, 512, 41, 4, 20, 128, 90),
-                                  (1, 16, 15, 1, 7, 1, 500), (96, 64, 5, 3, 2, 1, 200)])
+                                  (1, 16, 15, 1, 7, 1, 500), (96, 64, 5, 3, 2, 1, 200),
+                                  # the 256-group / 64-group layers at their own row lengths (round 4: the cig = 4 quad kernels pick the
+                                  # position tile by row length: 80 outputs -> 16, 320 -> 64; a chunk boundary in the weight gradient)
+                                  (1024, 1024, 41, 4, 20, 256, 320), (256, 1024, 41, 4, 20, 64, 1280), (64, 256, 41, 4, 20, 16, 1100)])
 def test_grouped_conv_with_lrelu_output_vs_torch(case):
     """DiscriminatorS / DiscriminatorP layers: (grouped) conv followed by leaky-relu(0.1) on the OUTPUT."""
     from ttts_amd.vqvae.modules import _Conv1dFn

@@ -274,6 +274,123 @@ __global__ __launch_bounds__(256) void grouped_slab_sum_kernel(const float* __re
 }
 
 // ---- dispatch (conv.hip) -------------------------------------------------------------------------------------------------------
+// ---- direct kernels for 4 input channels per group (round 4) ----------------------------------------------------------------------
+// All four grouped DiscriminatorS layers have cig = 4.  The MFMA forms above spend their time on padding there: the 256-group
+// layer (cog = 4, 80 output positions) fills a quarter of its 16 x 16 weight blocks and 80 of a workgroup's 256 positions -- 364 us
+// for 0.9 GFLOP and 52 MB.  Here a thread owns a quad of output channels at one position: per (tap, input channel) one LDS read of
+// x (phase-de-interleaved strip, consecutive lanes = consecutive positions), one 16-byte broadcast read of the quad's four weights
+// and four fmaf.  QW = 256 / LT quads x LT positions per workgroup, LT chosen so that the row length wastes the least.
+struct G4Params {
+  const float* x; const float* w; const float* bias; float* y;
+  int B, G, cog, Lin, Lout, K, S, pad;
+  float in_slope; int out_act; float out_slope, out_scale;
+};
+template <int LT>
+__global__ __launch_bounds__(256) void conv1d_g4_fwd_kernel(G4Params p) {
+  constexpr int QW = 256 / LT;
+  extern __shared__ __attribute__((aligned(16))) float g4_smem[];
+  const int S = p.S, K = p.K, IP = LT + (K - 1) / S + 1;
+  float* xs = g4_smem;                                      // [QW][4 ci][S][IP]
+  float* ws = xs + (size_t)QW * 4 * S * IP;                 // [QW][K][4 ci][4 co]
+  const int tid = threadIdx.x, q = tid / LT, l = tid % LT;
+  const int l0 = blockIdx.x * LT, b = blockIdx.z, nquad = p.G * p.cog / 4;
+  const int qg0 = blockIdx.y * QW;
+  const int in0 = l0 * S - p.pad, strip = S * IP;
+  // x strips, one per quad (quads of one group stage the same rows again: at most 16 x 4 x S x IP floats)
+  for (int i = tid; i < QW * 4 * strip; i += 256) {
+    const int u = i % strip, c = (i / strip) & 3, qq = i / (4 * strip);
+    const int qg = min(qg0 + qq, nquad - 1), grp = (qg * 4) / p.cog, gpos = in0 + u;
+    const float v = p.x[((int64_t)b * p.G * 4 + grp * 4 + c) * p.Lin + min(max(gpos, 0), p.Lin - 1)];
+    xs[((qq * 4 + c) * S + u % S) * IP + u / S] = (gpos >= 0 && gpos < p.Lin) ? g_lrelu(v, p.in_slope) : 0.f;
+  }
+  for (int i = tid; i < QW * K * 16; i += 256) {
+    const int j = i & 3, c = (i >> 2) & 3, k = (i >> 4) % K, qq = i / (16 * K);
+    const int qg = min(qg0 + qq, nquad - 1);
+    ws[i] = p.w[((int64_t)(qg * 4 + j) * 4 + c) * K + k];
+  }
+  __syncthreads();
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const float* xq = xs + (size_t)q * 4 * strip + l;
+  const float* wq = ws + (size_t)q * K * 16;
+  for (int ph = 0; ph < S; ++ph) {
+    for (int k = ph, d = 0; k < K; k += S, ++d) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float xv = xq[(c * S + ph) * IP + d];
+        const float4 w4 = *reinterpret_cast<const float4*>(wq + (k * 4 + c) * 4);
+        acc[0] = fmaf(w4.x, xv, acc[0]); acc[1] = fmaf(w4.y, xv, acc[1]);
+        acc[2] = fmaf(w4.z, xv, acc[2]); acc[3] = fmaf(w4.w, xv, acc[3]);
+      }
+    }
+  }
+  const int qg = qg0 + q, lo = l0 + l;
+  if (qg >= nquad || lo >= p.Lout) return;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int co = qg * 4 + j;
+    float v = acc[j] + (p.bias ? p.bias[co] : 0.f);
+    if (p.out_act == 1) v = tanhf(v);
+    else if (p.out_act == 2) v = g_lrelu(v, p.out_slope);
+    p.y[((int64_t)b * p.G * p.cog + co) * p.Lout + lo] = v * p.out_scale;
+  }
+}
+
+// weight gradient, cig = 4: one workgroup = one quad of output channels x one (batch element, 256-position chunk) slice range; thread
+// = (co of the quad, ci, tap) for 16 K <= 768 combinations, looping over the positions of its slices with dy and the x strip in LDS.
+// Partial sums per slice range go to a slab [range][Cout][4][K]; g4_slab_sum_kernel adds them in range order (deterministic).
+constexpr int G4W_LC = 256;
+__global__ __launch_bounds__(256) void conv1d_g4_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                              float* __restrict__ slab, int B, int G, int cog, int Lin, int Lout,
+                                                              int K, int S, int pad, float dy_slope, float x_slope, int cpb) {
+  extern __shared__ __attribute__((aligned(16))) float g4_smem[];
+  const int XW = (G4W_LC - 1) * S + K;                      // input positions a chunk of outputs touches
+  float* ds = g4_smem;                                      // [4 co][G4W_LC]
+  float* xs = ds + 4 * G4W_LC;                              // [4 ci][XW]
+  const int tid = threadIdx.x, qg = blockIdx.x, rng = blockIdx.y;
+  const int grp = (qg * 4) / cog, nlc = (Lout + G4W_LC - 1) / G4W_LC, nchunks = B * nlc;
+  const int ncomb = 16 * K;
+  float acc[3] = {0.f, 0.f, 0.f};                           // combos tid, tid + 256, tid + 512 (K <= 48)
+  for (int ch = rng * cpb; ch < min(nchunks, (rng + 1) * cpb); ++ch) {
+    const int b = ch / nlc, l0 = (ch - b * nlc) * G4W_LC, nl = min(G4W_LC, Lout - l0), in0 = l0 * S - pad;
+    __syncthreads();
+    for (int i = tid; i < 4 * G4W_LC; i += 256) {
+      const int j = i / G4W_LC, ll = i % G4W_LC;
+      ds[i] = ll < nl ? g_lrelu(dy[((int64_t)b * G * cog + qg * 4 + j) * Lout + l0 + ll], dy_slope) : 0.f;
+    }
+    for (int i = tid; i < 4 * XW; i += 256) {
+      const int c = i / XW, u = i % XW, gpos = in0 + u;
+      const float v = x[((int64_t)b * G * 4 + grp * 4 + c) * Lin + min(max(gpos, 0), Lin - 1)];
+      xs[i] = (gpos >= 0 && gpos < Lin) ? g_lrelu(v, x_slope) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int cb = tid + 256 * r;
+      if (cb >= ncomb) break;
+      const int k = cb % K, c = (cb / K) & 3, j = cb / (4 * K);
+      const float* dr = ds + j * G4W_LC;
+      const float* xr = xs + c * XW + k;
+      float a = acc[r];
+      for (int ll = 0; ll < nl; ++ll) a = fmaf(dr[ll], xr[ll * S], a);
+      acc[r] = a;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int cb = tid + 256 * r;
+    if (cb >= ncomb) break;
+    const int k = cb % K, c = (cb / K) & 3, j = cb / (4 * K);
+    slab[((int64_t)rng * G * cog + qg * 4 + j) * 4 * K + c * K + k] = acc[r];
+  }
+}
+__global__ __launch_bounds__(256) void g4_slab_sum_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nrng, int64_t per) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (int64_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int r = 0; r < nrng; ++r) s += slab[r * per + i];
+    dw[i] += s;
+  }
+}
+
 static int gp_attr(const void* fn, bool& done) {
   if (done) return TTTS_OK;
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -288,6 +405,27 @@ int conv1d_grouped_fwd_mfma_try(const float* x, const float* w, const float* bia
                                 float out_slope, float out_scale, int accumulate, hipStream_t stream, bool* handled) {
   *handled = false;
   const int cig = Cin / groups, cog = Cout / groups;
+  // (measured, B = 32: the 256-group layer 364 -> 120 us; with 16 output channels per group the MFMA kernel below stays ahead --
+  // 105 vs 221 us on the 64-group layer -- so the quad kernel takes cog == 4 only)
+  if (dil == 1 && cig == 4 && cog == 4 && K <= 64 && !bbias && !resid && !gate && !omask && !accumulate) {
+    // direct quad kernel; position tile = the one of {16, 32, 64} that wastes the least of the row (ties: the larger)
+    int LT = 64;
+    for (int cand : {32, 16})
+      if (cdiv(Lout, cand) * cand < cdiv(Lout, LT) * LT) LT = cand;
+    const int QW = 256 / LT, IP = LT + (K - 1) / stride + 1;
+    const size_t smem = ((size_t)QW * 4 * stride * IP + (size_t)QW * K * 16) * sizeof(float);
+    if (smem <= 150 * 1024) {
+      G4Params q{x, w, bias, y, B, groups, cog, Lin, Lout, K, stride, pad, in_slope, out_act, out_slope, out_scale};
+      dim3 grid((unsigned)cdiv(Lout, LT), (unsigned)cdiv(Cout / 4, QW), (unsigned)B);
+      int rc = TTTS_OK;
+      if (LT == 64) { static bool a = false; rc = gp_attr(reinterpret_cast<const void*>(conv1d_g4_fwd_kernel<64>), a); if (!rc) conv1d_g4_fwd_kernel<64><<<grid, 256, smem, stream>>>(q); }
+      else if (LT == 32) { static bool a = false; rc = gp_attr(reinterpret_cast<const void*>(conv1d_g4_fwd_kernel<32>), a); if (!rc) conv1d_g4_fwd_kernel<32><<<grid, 256, smem, stream>>>(q); }
+      else { static bool a = false; rc = gp_attr(reinterpret_cast<const void*>(conv1d_g4_fwd_kernel<16>), a); if (!rc) conv1d_g4_fwd_kernel<16><<<grid, 256, smem, stream>>>(q); }
+      if (rc) return rc;
+      *handled = true;
+      return check_launch("conv1d_g4_fwd");
+    }
+  }
   if (dil != 1 || cog > 16 || 16 % cog != 0 || cig * (16 / cog) > 16 || Cout % 16 != 0) return TTTS_OK;
   const int nci = cig * (16 / cog), R4 = (nci * K + 3) & ~3, IP = GP_NPT + (K - 1) / stride + 1;
   const size_t smem = ((size_t)nci * stride * IP + (size_t)R4 * 16 + R4) * sizeof(float);
@@ -328,6 +466,24 @@ int conv1d_grouped_wgrad_mfma_try(const float* dy, const float* x, float* dw, in
                                   hipStream_t stream, bool* handled) {
   *handled = false;
   const int cig = Cin / groups, cog = Cout / groups;
+  if (dil == 1 && cig == 4 && cog == 4 && K <= 48 && cx.ws) {       // (256-group layer, B = 64: 670 -> 171 us; cog = 16: MFMA kernel)
+    const int nchunks = B * (int)cdiv(Lout, G4W_LC), nquad = Cout / 4;
+    const int ranges = (int)std::max<int64_t>(1, std::min<int64_t>(nchunks, cdiv(2048, nquad)));
+    const int cpb = (int)cdiv(nchunks, ranges), nrng = (int)cdiv(nchunks, cpb);
+    const int64_t per = (int64_t)Cout * 4 * K;
+    const size_t smem = ((size_t)4 * G4W_LC + (size_t)4 * ((G4W_LC - 1) * stride + K)) * sizeof(float);
+    if ((int64_t)nrng * per * (int64_t)sizeof(float) <= cx.ws_bytes && smem <= 150 * 1024) {
+      static bool a = false;
+      int rc = gp_attr(reinterpret_cast<const void*>(conv1d_g4_wgrad_kernel), a);
+      if (rc) return rc;
+      float* slab = static_cast<float*>(cx.ws);
+      conv1d_g4_wgrad_kernel<<<dim3((unsigned)nquad, (unsigned)nrng), 256, smem, stream>>>(dy, x, slab, B, groups, cog, Lin, Lout, K, stride,
+                                                                                        pad, dy_slope, x_slope, cpb);
+      g4_slab_sum_kernel<<<(unsigned)std::min<int64_t>(cdiv(per, 256), 4096), 256, 0, stream>>>(slab, dw, nrng, per);
+      *handled = true;
+      return check_launch("conv1d_g4_wgrad");
+    }
+  }
   if (dil != 1 || cog > 16 || 16 % cog != 0 || cig * (16 / cog) > 16 || Cout % 16 != 0 || !cx.ws) return TTTS_OK;
   const int nci = cig * (16 / cog), NT = (int)cdiv(nci * K, 16);
   if (NT != 11 && NT != 41) return TTTS_OK;

@@ -1057,7 +1057,9 @@ static int conv1d_bf16x3_launch_t(ConvMfmaParams p, const ConvCtx& cx, hipStream
   // pre-split + DMA kernel when the input is re-read by >= 3 output-channel tiles (measured: a full extra pass over x costs
   // more than on-the-fly splitting for the 16..64-channel long-row layers, and wins from 192 channels up); flag 32768:
   // from one tile, flag 65536: never (tools/conv_bench.py)
-  if (WCO == 2 && !(cx.flags & 65536) && (p.x_hi != nullptr || p.rowS < 0 || cdiv(p.M, MT) >= ((cx.flags & 32768) ? 1 : 3))) {
+  // (flag 512, experiment: 1 x 1 convolutions of up to 256 output channels on the on-the-fly kernel -- one launch instead of pre-pass + DMA kernel)
+  const bool k1_direct = (cx.flags & 512) && p.K == 1 && p.M <= 256 && p.x_hi == nullptr && p.rowS == 0;
+  if (WCO == 2 && !(cx.flags & 65536) && !k1_direct && (p.x_hi != nullptr || p.rowS < 0 || cdiv(p.M, MT) >= ((cx.flags & 32768) ? 1 : 3))) {
     int rc = conv1d_bf16x3_dma_launch(p, cx, stream, handled, conv_dma_pick(p, cx));
     if (rc || *handled) return rc;
     if (p.x_hi) return fail(TTTS_EUNSUPPORTED, "conv1d: shared input split without the DMA kernel");
