@@ -1966,6 +1966,9 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, f
                                    const ConvCtx& cx, hipStream_t stream, bool* handled) {
   *handled = false;
   if (!cx.ws || (cx.flags & 4096)) return TTTS_OK;
+  // (flag 1, experiment: small 1 x 1 weight gradients -- the WN res/skip layers, 192 x 192 over 8192 positions -- on the exact-f32
+  // kernel: one launch instead of pre-pass + split-bf16 kernel)
+  if ((cx.flags & 1) && K == 1 && (int64_t)Cin * Cout <= 256 * 256 && (int64_t)B * Lout <= 32768) return TTTS_OK;
   // workgroups a launch aims for when it splits the reduction: 512 = two per CU; flag 536870912: one per CU (half the slab
   // traffic, less latency hiding -- tools/gpu_ab_vq.sh)
   const int wg_target = (cx.flags & 536870912) ? 256 : (cx.flags & 1073741824) ? 1024 : 512;   // (flag 1073741824: four per CU)
