@@ -55,7 +55,7 @@ struct ConvMfmaParams {
                        // rowS < 0: PHASE-MERGED strided FORWARD with S = -rowS: input channel n of the GEMM is (channel n / S, phase
                        // n % S) of x, x'[(ci, r)][j] = x[ci][S j + r] (the pre-split pass de-interleaves), y[co][l] = sum w[co][ci][S t
                        // + r + rpad] x'[(ci, r)][l + t]: a stride-1 convolution over Cin x S channels with ~K / S + 1 taps (DMA kernel only)
-  int Lreal;           // rowS < 0: row length of the real input x
+  int Lreal;           // rowS < 0: row length of the real input x;  rowS > 0: bytes of dynamic LDS of the launch (DMA kernel epilogue)
 };
 
 
@@ -803,6 +803,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
       }
     }
   }
+  if (p.rowS > 0 && !(p.accumulate | (p.gate != nullptr) | (p.resid != nullptr) | (p.omask != nullptr)) &&
+      (size_t)MT * (LT + 1) * sizeof(float) <= (size_t)p.Lreal) {       // (rowS > 0: Lreal = bytes of dynamic LDS the launch got)
+    // Phase-merged data gradient: the rows of one channel are its `rowS` phases, so a direct store writes 4-byte elements rowS
+    // apart (3x-10x the L2 write requests of a coalesced row).  The tile goes through LDS instead (the stage buffers are free now)
+    // and is written back in dx order: consecutive lanes = consecutive dx positions S j + r of one channel.
+    __syncthreads();                                         // every wave is done with the last stage
+    float* tile = reinterpret_cast<float*>(smem);            // [MT][LT + 1]
+    constexpr int LTP = LT + 1;
+#pragma unroll
+    for (int i = 0; i < CW; ++i)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          tile[((wco * CW + i) * 32 + acc_row(r, hh)) * LTP + wl * 64 + t * 32 + col] = acc[i][t][r];
+    __syncthreads();
+    const int S = p.rowS, nch = p.M / S;
+    const int c_first = m0 / S, c_last = min((m0 + MT - 1) / S, nch - 1), span = S * LT;
+    for (int c = c_first; c <= c_last; ++c) {
+      for (int e = tid; e < span; e += 256) {
+        const int jl = e / S, r = e - jl * S, ml = c * S + r - m0;
+        if (ml < 0 || ml >= MT) continue;                    // (this channel's other phases belong to the neighbouring row tile)
+        const int b = b0 + jl / SEG, jt = j0 + jl % SEG, jj = jt * S + r;
+        if (b >= p.B || jt >= p.Lout || jj >= p.LoutTotal) continue;
+        const float v = (tile[ml * LTP + jl] + (p.bias ? p.bias[c] : 0.f)) * p.out_scale;
+        p.y[((int64_t)b * nch + c) * p.LoutTotal + jj] = v;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < CW; ++i)
     conv_tile_epilogue<1>(p, acc[i][0], acc[i][1], wl, 0, col, hh, j0, m0 + (wco * CW + i) * 32, b0, SEG);
@@ -1007,7 +1037,11 @@ static int conv1d_bf16x3_dma_launch(ConvMfmaParams p, const ConvCtx& cx, hipStre
   p.SEG = SEG;
   if (!g.ok) return TTTS_OK;
   p.NBS = (cx.flags & 268435456) ? 1 : g.nbs;     // (flag 268435456: one channel block per stage, for comparison)
-  const size_t dma_smem = (size_t)2 * p.NBS * 2 * (g.nxc + g.nwc) * 512 * sizeof(bf16);
+  size_t dma_smem = (size_t)2 * p.NBS * 2 * (g.nxc + g.nwc) * 512 * sizeof(bf16);
+  if (p.rowS > 0) {      // the phase-merged epilogue transposes the 64 x LT tile through LDS (room for it, two workgroups per CU still fit)
+    dma_smem = std::max(dma_smem, (size_t)MT * (LT + 1) * sizeof(float));
+    p.Lreal = (int)dma_smem;
+  }
   const int nblk = (p.N + 15) / 16, AP = K * 16 + 8;
   p.Mpad = (int)(cdiv(p.M, MT) * MT);
   if (!p.x_hi) { p.PADL = g.padl; p.Lp = (int)cdiv(g.padl + p.Lin + g.padr, 8) * 8; }
@@ -1041,7 +1075,7 @@ static int conv1d_bf16x3_dma_launch(ConvMfmaParams p, const ConvCtx& cx, hipStre
   }
 #define TTTS_DMA_K(CW_)                                                                                          \
   switch ((cx.flags & 33554432) ? 0 : K) {   /* flag 33554432: runtime tap loop everywhere */                    \
-    case 1: TTTS_DMA(CW_, 1) break; case 3: TTTS_DMA(CW_, 3) break; case 5: TTTS_DMA(CW_, 5) break;              \
+    case 1: TTTS_DMA(CW_, 1) break; case 2: TTTS_DMA(CW_, 2) break; case 3: TTTS_DMA(CW_, 3) break; case 5: TTTS_DMA(CW_, 5) break; \
     case 7: TTTS_DMA(CW_, 7) break; case 11: TTTS_DMA(CW_, 11) break; default: TTTS_DMA(CW_, 0) break;           \
   }
   if (CW == 1) TTTS_DMA_K(1) else TTTS_DMA_K(2)
@@ -1092,7 +1126,7 @@ static int conv1d_bf16x3_launch_t(ConvMfmaParams p, const ConvCtx& cx, hipStream
     conv1d_bf16x3_kernel<WCO, KT_><<<grid, 256, smem, stream>>>(p);                                  \
   }
   switch ((cx.flags & 33554432) ? 0 : K) {
-    case 1: TTTS_V1(1) break; case 3: TTTS_V1(3) break; case 5: TTTS_V1(5) break;
+    case 1: TTTS_V1(1) break; case 2: TTTS_V1(2) break; case 3: TTTS_V1(3) break; case 5: TTTS_V1(5) break;   // (2: the phase-merged strided layers)
     case 7: TTTS_V1(7) break; case 11: TTTS_V1(11) break; default: TTTS_V1(0) break;
   }
 #undef TTTS_V1
@@ -1146,7 +1180,7 @@ int conv1d_mfma_try(const float* x, const float* w, const float* bias, const flo
   // channels they take the DMA kernel: 668 -> 322 us (16 -> 32 k16 s10), 772 -> 150 us (256 -> 512 k16 s10); at stride 2 the plain
   // strided staging is still faster (32.6 vs 41.7 us), hence stride >= 4.  Flag 4194304: off (A/B switch, shared with the merged
   // data gradient).
-  if (stride >= 4 && dil == 1 && !transposed && K >= stride && cx.ws && N >= 2 && (int64_t)N * stride >= 16 && (int64_t)N * stride <= 8192 &&
+  if ((stride >= 4 || (stride == 3 && (cx.flags & 2))) && dil == 1 && !transposed && K >= stride && cx.ws && N >= 2 && (int64_t)N * stride >= 16 && (int64_t)N * stride <= 8192 &&
       !(cx.flags & (4096 | 4194304 | 65536))) {
     const int tmin = pad > 0 ? -(int)cdiv(pad, stride) : 0;              // floor((0 - pad) / stride)
     const int tmax = (K - 1 - pad) >= 0 ? (K - 1 - pad) / stride : -(int)cdiv(pad - (K - 1), stride);
