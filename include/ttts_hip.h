@@ -34,7 +34,7 @@ extern "C" {
 #define TTTS_EHIP (-2)         /* a HIP runtime call or kernel launch failed */
 #define TTTS_EUNSUPPORTED (-3) /* valid request this build has no kernel for */
 
-#define TTTS_ABI_VERSION 8
+#define TTTS_ABI_VERSION 9
 
 /* ---- library ------------------------------------------------------------------------------------ */
 int ttts_abi_version(void);
@@ -505,6 +505,13 @@ int ttts_conv1d_fwd_f32(const float* x, const float* w, const float* bias, const
                         int32_t K, int32_t stride, int32_t pad, int32_t dil, int32_t groups, float in_slope,
                         float gate_slope, int32_t out_act, float out_slope, float out_scale, int32_t accumulate,
                         const ttts_conv_ctx* ctx, void* stream);
+/* Dual-destination forward (ABI v9; stride 1, groups 1): ONE convolution whose first Cout1 output channels go to y [B, Cout1, Lout]
+ * (y = (conv + bias + resid) * omask) and whose remaining channels go to y2 [B, Cout - Cout1, Lout] (y2 [+]= (conv + bias) * omask,
+ * accumulate2).  WaveNet's res/skip 1 x 1 convolution (`res_skip_acts[:, :H]` / `[:, H:]`, ttts/vqvae/modules.py:96-104) is two
+ * destinations of one GEMM over the same input; results are those of the two ttts_conv1d_fwd_f32 calls it replaces. */
+int ttts_conv1d_fwd_dual_f32(const float* x, const float* w, const float* bias, const float* resid, const float* omask, float* y,
+                             float* y2, int32_t B, int32_t Cin, int32_t Lin, int32_t Cout, int32_t Cout1, int32_t Lout, int32_t K,
+                             int32_t pad, int32_t dil, float in_slope, int32_t accumulate2, const ttts_conv_ctx* ctx, void* stream);
 int ttts_conv1d_dgrad_f32(const float* dy, const float* w, const float* bias, const float* resid,
                           const float* gate, const float* omask, float* dx, int32_t B, int32_t Cin, int32_t Lin, int32_t Cout,
                           int32_t Lout, int32_t K, int32_t stride, int32_t pad, int32_t dil, int32_t groups,

@@ -750,6 +750,29 @@ def test_split_bf16_conv_accuracy(case):
 
 
 @pytest.mark.bf16x3
+@pytest.mark.parametrize("mode", ["split_bf16", "exact"])
+def test_dual_destination_conv_equals_the_two_launches(mode):
+    """ttts_conv1d_fwd_dual_f32 (the WN res | skip convolution as ONE launch with two destinations) against the two
+    ttts_conv1d_fwd_f32 calls it replaces: bit-identical in both precision modes (exact mode runs the two launches inside)."""
+    from ttts_amd import ops
+    ops.set_conv_precision(mode)
+    g = torch.Generator().manual_seed(5)
+    B, H, T = 4, 192, 256
+    acts = torch.randn(B, H, T, generator=g).to(_dev()); w = (torch.randn(2 * H, H, 1, generator=g) * 0.07).to(_dev())
+    bias = torch.randn(2 * H, generator=g).to(_dev()); xi = torch.randn(B, H, T, generator=g).to(_dev())
+    mask = (torch.rand(B, T, generator=g) > 0.2).float().to(_dev())
+    out0 = torch.randn(B, H, T, generator=g).to(_dev())
+    for acc in (False, True):
+        x_ref = ops.conv1d_fwd(acts, w[:H], bias[:H], xi, omask=mask)
+        o_ref = out0.clone()
+        ops.conv1d_fwd(acts, w[H:], bias[H:], omask=mask, out=o_ref, accumulate=acc)
+        x_new = torch.full_like(xi, float("nan")); o_new = out0.clone()
+        ops.conv1d_fwd_dual(acts, w, bias, xi, mask, x_new, o_new, H, accumulate2=acc)
+        assert torch.equal(x_new, x_ref) and torch.equal(o_new, o_ref), (mode, acc)
+    ops.set_conv_precision("split_bf16")
+
+
+@pytest.mark.bf16x3
 def test_codes_through_model_split_bf16_near_tie_audit(golden_dir):
     """The benchmarked (split-bf16) convolution path carries the code-index claim: the indices of the assembled model equal the
     reference's on every WELL-SEPARATED row.  A row may differ only if the quantizer-input perturbation delta this path

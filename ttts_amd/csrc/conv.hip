@@ -31,6 +31,10 @@ int conv1d_dgrad_strided_mfma_try(const float* dy, const float* w, const float* 
                                   int Lout, int K, int stride, int pad, float in_slope, float gate_slope, float out_scale,
                                   int accumulate, const ConvCtx& cx, hipStream_t stream, bool* handled);
 
+int conv1d_mfma_dual_try(const float* x, const float* w, const float* bias, const float* resid, const float* omask, float* y, float* y2,
+                         int B, int M, int M1, int N, int Lin, int Lout, int K, int pad, int dil, float in_slope, int accumulate2,
+                         const ConvCtx& cx, hipStream_t stream, bool* handled);
+
 // conv_thin.hip: streaming kernels for one input channel / one output channel
 int conv1d_thin_fwd_try(const float* x, const float* w, const float* bias, const float* bbias, const float* resid,
                         const float* gate, const float* omask, float* y, int B, int Cin, int Lin, int Cout, int Lout, int K,
@@ -703,6 +707,30 @@ extern "C" int ttts_conv1d_fwd_f32(const float* x, const float* w, const float* 
   dim3 grid((unsigned)cdiv(Lout, CV_LT), (unsigned)cdiv(Cout / groups, CV_CT), (unsigned)(B * groups));
   conv1d_fwd_kernel<<<grid, 256, smem, as_stream(stream)>>>(p);
   return check_launch("conv1d_fwd");
+}
+
+extern "C" int ttts_conv1d_fwd_dual_f32(const float* x, const float* w, const float* bias, const float* resid, const float* omask,
+                                        float* y, float* y2, int32_t B, int32_t Cin, int32_t Lin, int32_t Cout, int32_t Cout1, int32_t Lout,
+                                        int32_t K, int32_t pad, int32_t dil, float in_slope, int32_t accumulate2,
+                                        const ttts_conv_ctx* ctx, void* stream) {
+  TTTS_REQUIRE(x && w && y && y2, "conv1d_fwd_dual: null pointer");
+  TTTS_REQUIRE(Cout1 > 0 && Cout1 < Cout, "conv1d_fwd_dual: need 0 < Cout1 < Cout");
+  TTTS_REQUIRE(!ctx || !ctx->workspace || aligned16(ctx->workspace), "conv1d_fwd_dual: ctx workspace must be 16-byte aligned");
+  const ConvCtx cx = conv_ctx_of(ctx);
+  int rc = conv_check(B, Cin, Lin, Cout, Lout, K, 1, pad, dil, 1);
+  if (rc) return rc;
+  if (!(cx.flags & 256)) {
+    bool handled = false;
+    rc = conv1d_mfma_dual_try(x, w, bias, resid, omask, y, y2, B, Cout, Cout1, Cin, Lin, Lout, K, pad, dil, in_slope, accumulate2, cx,
+                              as_stream(stream), &handled);
+    if (rc || handled) return rc;
+  }
+  // the two single-destination launches it stands for (exact-fp32 mode, shapes the split-bf16 kernels do not take)
+  rc = ttts_conv1d_fwd_f32(x, w, bias, nullptr, resid, nullptr, omask, y, B, Cin, Lin, Cout1, Lout, K, 1, pad, dil, 1, in_slope, 1.f, 0, 1.f,
+                           1.f, 0, ctx, stream);
+  if (rc) return rc;
+  return ttts_conv1d_fwd_f32(x, w + (int64_t)Cout1 * Cin * K, bias ? bias + Cout1 : nullptr, nullptr, nullptr, nullptr, omask, y2, B, Cin, Lin,
+                             Cout - Cout1, Lout, K, 1, pad, dil, 1, in_slope, 1.f, 0, 1.f, 1.f, accumulate2, ctx, stream);
 }
 
 extern "C" int ttts_conv1d_dgrad_f32(const float* dy, const float* w, const float* bias, const float* resid,

@@ -56,6 +56,9 @@ struct ConvMfmaParams {
                        // n % S) of x, x'[(ci, r)][j] = x[ci][S j + r] (the pre-split pass de-interleaves), y[co][l] = sum w[co][ci][S t
                        // + r + rpad] x'[(ci, r)][l + t]: a stride-1 convolution over Cin x S channels with ~K / S + 1 taps (DMA kernel only)
   int Lreal;           // rowS < 0: row length of the real input x;  rowS > 0: bytes of dynamic LDS of the launch (DMA kernel epilogue)
+  float* y2; int M1, acc2;   // y2 != NULL: DUAL-destination forward (round 4).  Output rows m < M1 go to y as usual (bias, resid, mask);
+                       // rows m >= M1 go to y2[b][m - M1][j] = [y2 +] (acc + bias[m]) * mask * out_scale (acc2: accumulate).  The WN
+                       // res/skip 1 x 1 convolution is ONE launch that way instead of two over the same input
 };
 
 
@@ -433,15 +436,21 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvMfmaParams& p, cons
     for (int r = 0; r < 16; ++r) {
       const int m = m0 + wco * 32 + acc_row(r, hh);
       if (m >= p.M) continue;
-      const int64_t o = ((int64_t)b * p.M + m) * p.LoutTotal + j;
       float v = (t == 0 ? acc0[r] : acc1[r]) + (p.bias ? p.bias[m] : 0.f);
+      // (dual destination, p.y2: rows >= M1 go to y2 with their own accumulate flag and without the residual -- selected, not
+      // branched: a second store path here sent the 64 x 64 wave tile's accumulators through scratch)
+      const bool second = p.y2 != nullptr && m >= p.M1;
+      const int Mo = p.y2 ? (second ? p.M - p.M1 : p.M1) : p.M, mm = second ? m - p.M1 : m;
+      float* dst = second ? p.y2 : p.y;
+      const int accf = second ? p.acc2 : p.accumulate;
+      const int64_t o = ((int64_t)b * Mo + mm) * p.LoutTotal + j;
       if (p.bbias) v += p.bbias[(int64_t)b * p.M + m];
       if (p.gate) v *= (p.gate[o] > 0.f ? 1.f : p.gate_slope);
-      if (p.resid) v += p.resid[o];
+      if (p.resid && !second) v += p.resid[o];
       if (p.out_act == 1) v = tanhf(v);
       else if (p.out_act == 2) v = lrelu_f(v, p.out_slope);
       v *= om * p.out_scale;
-      p.y[o] = p.accumulate ? p.y[o] + v : v;
+      dst[o] = accf ? dst[o] + v : v;
     }
   }
 }
@@ -1147,7 +1156,7 @@ static int conv1d_mfma_launch(ConvMfmaParams p, const ConvCtx& cx, hipStream_t s
       if (rc || *handled) return rc;
     }
   }
-  if (p.rowS != 0) return TTTS_OK;       // (the phase-merged forms exist in the split-bf16 kernels only: the caller falls back)
+  if (p.rowS != 0 || p.y2) return TTTS_OK;   // (the phase-merged / dual-destination forms exist in the split-bf16 kernels only: the caller falls back)
   // tile choice: always the largest tile.  Measured (tools/conv_bench.py, B = 32): the smaller tiles <2,2>, <1,2>, <1,1> --
   // meant to put more workgroups on a CU for the 192-channel x 256-frame layers -- are 2-2.5x SLOWER there (WN in_layer
   // dgrad 346 -> 738 us): the kernel is bound by the global -> LDS staging work per MFMA, so less reuse per staged slab
@@ -1168,6 +1177,18 @@ static int conv1d_mfma_launch(ConvMfmaParams p, const ConvCtx& cx, hipStream_t s
 }
 
 // Returns TTTS_OK and sets *handled when the MFMA path took the launch.
+// dual-destination forward (stride 1): see ConvMfmaParams::y2
+int conv1d_mfma_dual_try(const float* x, const float* w, const float* bias, const float* resid, const float* omask, float* y, float* y2,
+                         int B, int M, int M1, int N, int Lin, int Lout, int K, int pad, int dil, float in_slope, int accumulate2,
+                         const ConvCtx& cx, hipStream_t stream, bool* handled) {
+  *handled = false;
+  if (N < 16 || K > 16 || !cx.ws || (cx.flags & 4096)) return TTTS_OK;
+  ConvMfmaParams p{x, w, bias, nullptr, resid, omask, nullptr, y, B, M, N, Lin, Lout, K, 1, pad, dil, 0, 0,
+                   K, 0, 1, 1, 0, Lout, 0, in_slope, 1.f, 0, 1.f, 1.f, 0, nullptr, nullptr, 0, nullptr, nullptr};
+  p.y2 = y2; p.M1 = M1; p.acc2 = accumulate2;
+  return conv1d_mfma_launch(p, cx, stream, handled);
+}
+
 int conv1d_mfma_try(const float* x, const float* w, const float* bias, const float* bbias, const float* resid,
                     const float* gate, const float* omask, float* y, int B, int M, int N, int Lin, int Lout, int K,
                     int stride, int pad, int dil, int transposed, float in_slope, float gate_slope, int out_act,

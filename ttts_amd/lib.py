@@ -67,7 +67,7 @@ _c = ctypes
 _P, _I32, _I64, _U64, _F = _c.c_void_p, _c.c_int32, _c.c_int64, _c.c_uint64, _c.c_float
 
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class ConvCtx(ctypes.Structure):
@@ -207,6 +207,7 @@ SIGNATURES = {
     "ttts_weight_norm_bwd_f32": (_I32, [_P, _P, _P, _P, _P, _P, _I32, _I32, _P]),
     "ttts_weight_norm_fwd_batched_f32": (_I32, [_P, _I32, _I32, _P]),
     "ttts_weight_norm_bwd_batched_f32": (_I32, [_P, _I32, _I32, _P]),
+    "ttts_conv1d_fwd_dual_f32": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _F, _I32, _P, _P]),
     "ttts_conv_wsplit_cache_create": (_I32, [_P, _I64, _P, _I64, _I32, ctypes.POINTER(ctypes.c_void_p)]),
     "ttts_conv_wsplit_cache_refresh": (_I32, [_P, _P]),
     "ttts_conv_wsplit_cache_disarm": (_I32, [_P]),

@@ -919,6 +919,23 @@ def conv1d_fwd(x, w, bias=None, resid=None, stride=1, pad=0, dil=1, in_slope=1.0
     return y
 
 
+def conv1d_fwd_dual(x, w, bias, resid, omask, y, y2, cout1, pad=0, dil=1, in_slope=1.0, accumulate2=False):
+    """One stride-1 convolution with two destinations (include/ttts_hip.h: ttts_conv1d_fwd_dual_f32): output channels [0, cout1) ->
+    y = (conv + bias + resid) * omask, channels [cout1, Cout) -> y2 [+]= (conv + bias) * omask.  Returns (y, y2)."""
+    for t, n in ((x, "x"), (w, "w"), (bias, "bias"), (resid, "resid"), (omask, "omask"), (y, "y"), (y2, "y2")):
+        _req(t, torch.float32, n)
+    x = x.contiguous(); w = w.contiguous()
+    B, Cin, Lin = x.shape
+    Cout, _, K = w.shape
+    Lout = conv_out_len(Lin, K, 1, pad, dil)
+    if not (y.is_contiguous() and y2.is_contiguous() and tuple(y.shape) == (B, cout1, Lout) and tuple(y2.shape) == (B, Cout - cout1, Lout)):
+        raise TttsError("conv1d_fwd_dual: y / y2 must be contiguous (B, cout1, Lout) / (B, Cout - cout1, Lout)")
+    c = lambda t: t.contiguous() if t is not None else None
+    check(_l.get().ttts_conv1d_fwd_dual_f32(_p(x), _p(w), _p(c(bias)), _p(c(resid)), _p(c(omask)), _p(y), _p(y2), B, Cin, Lin, Cout, cout1,
+                                            Lout, K, pad, dil, in_slope, int(accumulate2), _conv_ctx(x.device), _stream()), "conv1d_fwd_dual")
+    return y, y2
+
+
 def conv1d_dgrad(dy, w, lin, stride=1, pad=0, dil=1, gate=None, gate_slope=1.0, bias=None, in_slope=1.0, resid=None,
                  out_scale=1.0, out=None, accumulate=False, groups=1, omask=None):
     """dx (B,Cin,lin) of a conv with weight w (Cout,Cin/groups,K) -- or the ConvTranspose1d forward with w = its weight

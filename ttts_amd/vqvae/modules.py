@@ -647,6 +647,9 @@ class Activation1d(nn.Module):
 
 
 # ---- WaveNet stack (modules.WN, ttts/vqvae/modules.py:136-221) as ONE autograd node ------------------------------------
+_WN_DUAL = os.environ.get("TTTS_WN_DUAL", "1") == "1"      # (A/B switch: 0 = the two launches the dual convolution replaces)
+
+
 class _WNFn(torch.autograd.Function):
     """params = [in_v, in_g, in_b, rs_v, rs_g, rs_b] * n_layers (old-style weight norm tensors).
     Per layer: x_in = conv_k(x) + g_l ; acts = tanh*sigmoid ; (res | skip) = 1x1(acts) ; x = (x + res) * mask ;
@@ -679,8 +682,12 @@ class _WNFn(torch.autograd.Function):
             x_in = ops.conv1d_fwd(xi, w_in, in_b, None, 1, pad, dil, bbias=bb)
             acts = ops.gate_fwd(x_in, ops.GATE_TANH_SIGMOID)
             if i < n_layers - 1:
-                x_next = ops.conv1d_fwd(acts, w_rs[:H], rs_b[:H], xi, omask=m2)
-                ops.conv1d_fwd(acts, w_rs[H:], rs_b[H:], omask=m2, out=out, accumulate=i > 0)
+                if _WN_DUAL:          # res | skip: one launch, two destinations (x_next = (x + res) * mask, out += skip * mask)
+                    x_next = torch.empty_like(xi)
+                    ops.conv1d_fwd_dual(acts, w_rs, rs_b, xi, m2, x_next, out, H, accumulate2=i > 0)
+                else:
+                    x_next = ops.conv1d_fwd(acts, w_rs[:H], rs_b[:H], xi, omask=m2)
+                    ops.conv1d_fwd(acts, w_rs[H:], rs_b[H:], omask=m2, out=out, accumulate=i > 0)
             else:
                 x_next = None
                 ops.conv1d_fwd(acts, w_rs, rs_b, omask=m2, out=out, accumulate=i > 0)
