@@ -639,3 +639,47 @@ def test_attention_dropout_product_scheme_statistics():
             assert abs(corr(x.ravel(), y.ravel())) < 5e-3
             binom = np.sqrt(0.09 / S)
             assert 0.8 * binom < d.mean(1).std() < 1.25 * binom and 0.8 * binom < d.mean(0).std() < 1.25 * binom
+
+
+def test_phase_merged_strided_convolution_identities():
+    """The index algebra behind ConvMfmaParams::rowS (csrc/conv_mfma.hip: merged_phase_weight / merged_fwd_weight), restated with
+    torch on the CPU: a strided convolution's data gradient equals ONE stride-1 convolution whose rows are (channel, phase) pairs,
+    and its forward equals a stride-1 convolution over the phase-de-interleaved input -- for the step's k16 stride-10 / stride-8
+    layers, a row length that is not a multiple of the stride, K = stride and K < 2 stride."""
+    import torch
+    import torch.nn.functional as F
+    torch.manual_seed(0)
+    for cin, cout, k, s, pad, L in [(4, 6, 16, 10, 7, 300), (3, 5, 16, 8, 4, 203), (5, 4, 5, 3, 2, 101), (2, 3, 4, 4, 0, 43), (3, 2, 7, 2, 3, 57)]:
+        x = torch.randn(2, cin, L, dtype=torch.float64); w = torch.randn(cout, cin, k, dtype=torch.float64)
+        y = F.conv1d(x, w, stride=s, padding=pad)
+        dy = torch.randn_like(y)
+        # ---- data gradient: rows m = (ci, r), dx[ci][s j + r] = sum_{co, e} A[m][co][e] dy[co][j + e - vpad]
+        emax = (s - 1 + pad) // s
+        emin = min((r + pad) // s - (k - 1 - (r + pad) % s) // s for r in range(s))
+        kv, vpad, T = emax - emin + 1, -emin, -(-L // s)
+        A = torch.zeros(cin * s, cout, kv, dtype=torch.float64)
+        for m in range(cin * s):
+            ci, r = divmod(m, s)
+            for e in range(kv):
+                t = (r + pad) // s - (e - vpad)
+                kk = (r + pad) % s + s * t
+                if t >= 0 and kk < k:
+                    A[m, :, e] = w[:, ci, kk]
+        out = F.conv1d(F.pad(dy, (vpad, T + kv)), A)[:, :, :T]
+        dx = out.view(2, cin, s, T).permute(0, 1, 3, 2).reshape(2, cin, T * s)[:, :, :L]
+        ref = torch.nn.grad.conv1d_input(x.shape, w, dy, stride=s, padding=pad)
+        assert (dx - ref).abs().max() < 1e-10
+        # ---- forward: x'[(ci, r)][j] = x[ci][s j + r], y[co][l] = sum W[co][(ci, r)][t'] x'[(ci, r)][l + t' - vp]
+        tmin = -(-pad // s) * -1 if pad > 0 else 0
+        tmax = (k - 1 - pad) // s
+        kf, vp, Lv = tmax - tmin + 1, -tmin, -(-L // s)
+        xp = F.pad(x, (0, Lv * s - L)).view(2, cin, Lv, s).permute(0, 1, 3, 2).reshape(2, cin * s, Lv)
+        W = torch.zeros(cout, cin * s, kf, dtype=torch.float64)
+        for n in range(cin * s):
+            ci, r = divmod(n, s)
+            for t in range(kf):
+                kk = s * (t - vp) + r + pad
+                if 0 <= kk < k:
+                    W[:, n, t] = w[:, ci, kk]
+        yv = F.conv1d(F.pad(xp, (vp, y.shape[2] + kf)), W)[:, :, :y.shape[2]]
+        assert (yv - y).abs().max() < 1e-10
