@@ -1901,16 +1901,14 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_batched_kernel(const Sl
   }
 }
 
-struct SlabKey {
-  const float* dw; const float* db; int nsplit, K, Cout, Cin;
-  bool operator==(const SlabKey& o) const {
-    return dw == o.dw && db == o.db && nsplit == o.nsplit && K == o.K && Cout == o.Cout && Cin == o.Cin;
-  }
+struct SlabKey {              // (the split count is NOT part of the key: it follows the batch's row lengths, the slot is per layer)
+  const float* dw; const float* db; int K, Cout, Cin;
+  bool operator==(const SlabKey& o) const { return dw == o.dw && db == o.db && K == o.K && Cout == o.Cout && Cin == o.Cin; }
 };
 struct SlabKeyHash {
   size_t operator()(const SlabKey& k) const {
     uint64_t h = reinterpret_cast<uint64_t>(k.dw) * 0x9E3779B97F4A7C15ull ^ reinterpret_cast<uint64_t>(k.db);
-    for (int v : {k.nsplit, k.K, k.Cout, k.Cin}) h = (h ^ (uint64_t)(uint32_t)v) * 0x100000001B3ull;
+    for (int v : {k.K, k.Cout, k.Cin}) h = (h ^ (uint64_t)(uint32_t)v) * 0x100000001B3ull;
     return (size_t)h;
   }
 };
@@ -1920,6 +1918,7 @@ struct SlabArena {
   int max_entries;
   bool armed = false;
   std::vector<SlabDesc> host;
+  std::vector<int> cap;                     // splits a slot has room for (a later batch with longer rows gets a new, larger slot)
   std::vector<uint8_t> touched;
   int n_touched = 0;
   std::unordered_map<SlabKey, int, SlabKeyHash> index;
@@ -1947,38 +1946,48 @@ static float* slab_defer(float* dw, float* db, bool want_bslab, int nsplit, int 
   for (SlabArena* c : g_slab) {
     if (wp < c->dw_lo || wp >= c->dw_hi) continue;
     if (!c->armed) return nullptr;
-    const SlabKey key{dw, want_bslab ? db : nullptr, nsplit, K, Cout, Cin};
+    const SlabKey key{dw, want_bslab ? db : nullptr, K, Cout, Cin};
+    const int64_t per = (int64_t)K * Cout * Cin;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
     auto it = c->index.find(key);
-    int idx;
-    if (it != c->index.end()) {
-      idx = it->second;
-      if (c->touched[idx]) { ++c->fallbacks; return nullptr; }     // a second gradient into the same dw in this phase
-    } else {
-      const int64_t per = (int64_t)K * Cout * Cin;
-      const int64_t need = (((int64_t)nsplit * (per + (want_bslab ? Cout : 0)) * (int64_t)sizeof(float) + 255) / 256) * 256;
-      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-      if ((int)c->host.size() >= c->max_entries || c->used + need > c->bytes ||
-          hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+    int idx = it != c->index.end() ? it->second : -1;
+    if (idx >= 0 && c->touched[idx]) { ++c->fallbacks; return nullptr; }      // a second gradient into the same dw in this phase
+    if (idx >= 0 && nsplit <= c->cap[idx]) {
+      if (c->host[idx].nsplit != nsplit) {                  // other row lengths than last time: the table entry follows (4 bytes)
+        if (capturing) { ++c->fallbacks; return nullptr; }
+        c->host[idx].nsplit = nsplit;
+        if (hipMemcpyAsync(c->storage + (int64_t)idx * sizeof(SlabDesc), &c->host[idx], sizeof(SlabDesc), hipMemcpyHostToDevice,
+                           stream) != hipSuccess) { ++c->fallbacks; return nullptr; }
+      }
+    } else {                                                // first sighting, or the slot is too small for this split count
+      const int capn = idx >= 0 ? std::max(nsplit, 2 * c->cap[idx]) : nsplit;
+      const int64_t need = (((int64_t)capn * (per + (want_bslab ? Cout : 0)) * (int64_t)sizeof(float) + 255) / 256) * 256;
+      if (capturing || (idx < 0 && (int)c->host.size() >= c->max_entries) || c->used + need > c->bytes) {
         ++c->fallbacks;
         return nullptr;
       }
       SlabDesc d;
       float* slab = reinterpret_cast<float*>(c->storage + c->used);
-      d.slab = slab; d.dw = dw; d.bslab = want_bslab ? slab + (int64_t)nsplit * per : nullptr; d.db = want_bslab ? db : nullptr;
+      d.slab = slab; d.dw = dw; d.bslab = want_bslab ? slab + (int64_t)capn * per : nullptr; d.db = want_bslab ? db : nullptr;
       d.nsplit = nsplit; d.K = K; d.Cout = Cout; d.Cin = Cin; d.pad_ = 0;
-      d.block_begin = (int)c->blocks;
-      idx = (int)c->host.size();
-      c->host.push_back(d);
+      const bool fresh = idx < 0;
+      d.block_begin = fresh ? (int)c->blocks : c->host[idx].block_begin;
+      if (fresh) { idx = (int)c->host.size(); c->host.push_back(d); } else c->host[idx] = d;
       if (hipMemcpyAsync(c->storage + (int64_t)idx * sizeof(SlabDesc), &c->host[idx], sizeof(SlabDesc), hipMemcpyHostToDevice,
                          stream) != hipSuccess) {
-        c->host.pop_back();
+        if (fresh) c->host.pop_back();
         ++c->fallbacks;
         return nullptr;
       }
-      c->touched.push_back(0);
-      c->blocks += slab_desc_blocks(d);
+      if (fresh) {
+        c->touched.push_back(0); c->cap.push_back(capn);
+        c->blocks += slab_desc_blocks(d);
+        c->index.emplace(key, idx);
+      } else {
+        c->cap[idx] = capn;
+      }
       c->used += need;
-      c->index.emplace(key, idx);
     }
     c->touched[idx] = 1;
     ++c->n_touched;
@@ -2311,7 +2320,7 @@ int ttts_conv_wgrad_arena_create(const void* dw_base, int64_t dw_bytes, void* st
   c->dw_lo = static_cast<const char*>(dw_base); c->dw_hi = c->dw_lo + dw_bytes;
   c->storage = static_cast<char*>(storage); c->bytes = storage_bytes; c->used = table;
   c->max_entries = max_entries;
-  c->host.reserve(max_entries); c->touched.reserve(max_entries);
+  c->host.reserve(max_entries); c->touched.reserve(max_entries); c->cap.reserve(max_entries);
   std::lock_guard<std::mutex> g(g_slab_mu);
   for (SlabArena* o : g_slab)
     if (c->dw_lo < o->dw_hi && o->dw_lo < c->dw_hi) { delete c; return fail(TTTS_EINVAL, "wgrad arena: gradient range overlaps a registered one"); }
