@@ -3,7 +3,9 @@
 batch 8 per GPU, 1024 audio tokens + 128 text tokens, bf16, full ttts/gpt/config.json model).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either under python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ..., or
+     plainly as above: with no RANK in the environment the script re-executes itself under torch.distributed.run with
+     one rank per GPU on 127.0.0.1 and a free port, and rank 0's JSON line is the only thing on stdout)
 
 A "step" is one pass of the hot path over one synthetic batch per rank: token plumbing, forward, backward, gradient
 all-reduce (N > 1, RCCL), grad-norm + clip, AdamW, LR schedule -- everything ttts/gpt/train.py:96-121 does per
@@ -137,7 +139,7 @@ def vqvae_leg(dev, steps, warmup, cpu_leg=True):
     saved, recs = {}, []
 
     def wrap(name, flops_fn):
-        fn = getattr(ops, name); saved[name] = fn
+        fn = saved[name]
 
         def w(*a, **kw):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -146,18 +148,41 @@ def vqvae_leg(dev, steps, warmup, cpu_leg=True):
             return r
         setattr(ops, name, w)
     # algorithmic FLOPs = 2 x (output elements) x (reduction length C_in / groups x taps)
-    wrap("conv1d_fwd", lambda y, x, w_, *a: 2.0 * y.numel() * w_.shape[1] * w_.shape[2])
-    wrap("conv1d_dgrad", lambda dx, dy, w_, *a: 2.0 * dy.numel() * w_.shape[1] * w_.shape[2])
-    wrap("conv1d_wgrad", lambda dw, dy, x, *a: 2.0 * dy.shape[0] * dy.shape[2] * dw.numel())
+    def fl_fwd(y, x, w_, *a): return 2.0 * y.numel() * w_.shape[1] * w_.shape[2]
+    def fl_dgrad(dx, dy, w_, *a): return 2.0 * dy.numel() * w_.shape[1] * w_.shape[2]
+    def fl_wgrad(dw, dy, x, *a): return 2.0 * dy.shape[0] * dy.shape[2] * dw.numel()
+    for name in ("conv1d_fwd", "conv1d_dgrad", "conv1d_wgrad"):
+        saved[name] = getattr(ops, name)
+    env_prev = {k: os.environ.get(k) for k in ("TTTS_BRANCH_STREAMS", "TTTS_D_STREAMS")}
+    timing_note, dt_one, host_issue_s, park_s = None, None, None, None
     try:
         # (one stream for this pass: with the branches on side streams, overlapping launches would share the chip and every
         # event pair would read longer than the kernel alone)
-        env_prev = {k: os.environ.get(k) for k in ("TTTS_BRANCH_STREAMS", "TTTS_D_STREAMS")}
         os.environ.update({"TTTS_BRANCH_STREAMS": "0", "TTTS_D_STREAMS": "0"})
-        if hasattr(torch.cuda, "_sleep"):
-            torch.cuda._sleep(int(8e7))         # park the device so the host runs ahead: event pairs then measure device time
-        tr.train_step(data)
-        torch.cuda.synchronize()
+        # An event pair measures DEVICE time only while the host runs ahead of the device: the device is parked (a spin kernel)
+        # for longer than the host needs to issue the whole step.  How long that is depends on the box, so it is measured: the
+        # un-instrumented one-stream step first (its wall time bounds the host's issue time from above), then instrumented pass 1
+        # (parked 2 x that; absorbs first-use allocations; its host time is read off the clock), then pass 2 parked 1.3 x pass 1's
+        # host time -- pass 2 is the one that counts.
+        for k, v in saved.items():
+            setattr(ops, k, v)                      # un-instrumented for the plain one-stream step
+        tr.train_step(data); torch.cuda.synchronize()
+        t0 = time.perf_counter(); tr.train_step(data); torch.cuda.synchronize(); dt_one = time.perf_counter() - t0
+        spin = int(1e7)                             # calibrate the spin kernel: cycles -> seconds
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(spin); torch.cuda.synchronize()
+        e0.record(); torch.cuda._sleep(spin); e1.record(); torch.cuda.synchronize()
+        cyc_per_s = spin / max(e0.elapsed_time(e1) * 1e-3, 1e-6)
+        for name in list(saved):
+            wrap(name, {"conv1d_fwd": fl_fwd, "conv1d_dgrad": fl_dgrad, "conv1d_wgrad": fl_wgrad}[name])
+        park_s = 2.0 * dt_one
+        for attempt in range(2):
+            recs.clear()
+            torch.cuda._sleep(int(park_s * cyc_per_s))
+            t0 = time.perf_counter(); tr.train_step(data); host_issue_s = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            if attempt == 0:
+                park_s = 1.3 * host_issue_s
     finally:
         for k, v in saved.items():
             setattr(ops, k, v)
@@ -171,6 +196,9 @@ def vqvae_leg(dev, steps, warmup, cpu_leg=True):
     tot_s, tot_f, tot_n = sum(f[1] for f in fam.values()), sum(f[2] for f in fam.values()), sum(f[0] for f in fam.values())
     ach = tot_f / tot_s / 1e12
     peak = PEAK_BF16_TFLOPS / 3.0               # an fp32 product costs three bf16 MFMA products (hi*hi + hi*lo + lo*hi)
+    # the convolution launches are a SUBSET of the one-stream step: their summed device time cannot exceed that step's wall time.
+    # If it does, the event pairs measured host gaps (the host fell behind the device) and no fraction is reported.
+    timing_invalid = bool(dt_one is None or tot_s > 1.02 * dt_one)
     try:
         conv_traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["vqvae_conv_family"]["bytes_per_step"]
     except Exception:
@@ -187,11 +215,18 @@ def vqvae_leg(dev, steps, warmup, cpu_leg=True):
            "algorithmic_tflops_note": "1.97 GFLOP per frame = the REFERENCE step, which also computes (and discards) the discriminator's "
                                       "parameter gradients in the generator phase; this build skips them, so executed FLOPs are lower",
            "roofline": {"bound": "mfma", "kernel": "conv1d_{fwd,dgrad,wgrad} (split-bf16 implicit GEMM; %d launches per step)" % tot_n,
-                        "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                        "achieved": None if timing_invalid else round(ach, 1), "peak": round(peak, 1), "unit": "TFLOP/s",
+                        "frac": None if timing_invalid else round(ach / peak, 4), "timing_invalid": timing_invalid,
+                        "family_gflop_per_step": round(tot_f / 1e9, 1),
+                        "one_stream_step_ms": None if dt_one is None else round(dt_one * 1e3, 2),
+                        "host_issue_ms": None if host_issue_s is None else round(host_issue_s * 1e3, 2),
+                        "park_ms": None if park_s is None else round(park_s * 1e3, 2),
                         "traffic": conv_traffic, "traffic_note": "HBM-side bytes of the whole family per STEP (incl. operand pre-passes "
                         "and slab reductions) from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE), "
                         "not measured in this run",
-                        "ms_per_step": round(tot_s * 1e3, 2), "timing": "HIP events around every launch of one eager step",
+                        "ms_per_step": round(tot_s * 1e3, 2), "timing": "HIP events around every convolution launch of one eager ONE-STREAM step, device parked 1.3 x the "
+                        "measured host issue time so the host stays ahead; second instrumented pass (the first absorbs allocations); "
+                        "timing_invalid when the family's summed time exceeds the un-instrumented one-stream step",
                         "families_ms": {k: round(v[1] * 1e3, 2) for k, v in fam.items()}},
            "losses": {k: round(v, 4) for k, v in vals.items()}, "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
     if cpu_leg:
@@ -460,6 +495,23 @@ def cpu_baseline(seconds_budget=24.0):
     return out
 
 
+def _respawn_under_torchrun(n):
+    """`python bench.py --gpus N` with no torchrun environment: start N ranks (one per GPU) of this very command line under
+    torch.distributed.run on the loopback address and a free port, pass their stdout / stderr through, return the exit code.
+    (ttts/gpt/train.py is launched by `accelerate launch`, which does the same: one process per GPU.)"""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL's cross-process buffers need it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -480,6 +532,8 @@ def main():
     ap.add_argument("--grad-dtype", default="f32", choices=["f32", "bf16"],
                     help="N > 1: element type of the gradient all-reduce (bf16 halves the bytes on the xGMI links; replicas stay bit-identical)")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(_respawn_under_torchrun(args.gpus))
 
     from ttts_amd import ops
     from ttts_amd.gpt import GptEngine, prepare_tokens

@@ -387,6 +387,24 @@ def test_bench_two_ranks_sharing_the_gpu(tmp_path):
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16 and out["value"] > 0 and out["scaling"] == "weak"
 
 
+def test_bench_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` WITHOUT torchrun (the driver's verb): with no RANK in the environment the script re-executes itself
+    under torch.distributed.run, one rank per GPU, and rank 0's JSON line is the only line on stdout that starts with '{'."""
+    import subprocess
+    import sys
+    env = dict(os.environ, TTTS_SHARE_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--profile-steps", "1"], capture_output=True, text=True, env=env, timeout=240)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["world_size"] == 2 and out["config"]["ranks_seen_by_backend"] == 2
+    assert out["config"]["global_batch"] == 16 and out["value"] > 0
+
+
 def test_ranged_gradient_exchange_two_ranks_sharing_the_gpu():
     """The overlapped exchange (backward in two graph sections, finished gradient ranges all-reduced in between) is
     bit-identical to one whole-arena all-reduce and keeps the replicas identical (tools/dp_consistency.py, gloo, 2 ranks)."""

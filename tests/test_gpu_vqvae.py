@@ -719,6 +719,29 @@ def test_vqvae_two_ranks_sharing_the_gpu(tmp_path):
     assert "rank0-ok" in r.stdout and "rank1-ok" in r.stdout
 
 
+def test_vqvae_main_spawns_one_rank_per_gpu(tmp_path):
+    """ttts.vqvae.train.main() with no launcher environment starts the ranks itself (ttts/vqvae/train.py:44-60 spawns
+    torch.cuda.device_count() processes): here two ranks sharing the one GPU over gloo (TTTS_SPAWN_RANKS / TTTS_SHARE_GPU), one
+    epoch of two steps on short synthetic clips, rank 0 writes the G_/D_ checkpoint pair."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = json.load(open(os.path.join(root, "ttts_amd", "vqvae", "config.json")))
+    cfg["train"].update({"epochs": 1, "batch_size": 1, "exp_dir": str(tmp_path / "exp"), "log_interval": 1})
+    cfg["dataset"].update({"synthetic_samples": 32000, "synthetic_text_len": 12})
+    (tmp_path / "cfg.json").write_text(json.dumps(cfg))
+    env = dict(os.environ, TTTS_SHARE_GPU="1", TTTS_SPAWN_RANKS="2", PYTHONPATH=root)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    code = "from ttts.vqvae.train import main; main([%r], steps_per_epoch=2)" % str(tmp_path / "cfg.json")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=400, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert r.stdout.count("Train Epoch: 1") == 2, r.stdout           # rank 0 only logs, once per step
+    saved = sorted(os.listdir(tmp_path / "exp"))
+    assert saved == ["D_2.pth", "G_2.pth"], saved
+
+
 def _rel_l2(a, b):
     a = a.detach().cpu().double(); b = b.detach().cpu().double()
     return ((a - b).norm() / b.norm().clamp_min(1e-300)).item()

@@ -683,3 +683,29 @@ def test_phase_merged_strided_convolution_identities():
                     W[:, n, t] = w[:, ci, kk]
         yv = F.conv1d(F.pad(xp, (vp, y.shape[2] + kf)), W)[:, :, :y.shape[2]]
         assert (yv - y).abs().max() < 1e-10
+
+
+def test_bench_respawn_command_line(monkeypatch):
+    """bench.py --gpus N without a torchrun environment re-executes itself as `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` (the driver's verb is
+    `python bench.py --gpus N`); inside a torchrun environment (RANK set) it does not."""
+    import importlib
+    import subprocess
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2"])
+    monkeypatch.delenv("RANK", raising=False)
+    with pytest.raises(SystemExit) as ex:
+        bench.main()
+    assert ex.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    assert cmd[-7].endswith("bench.py") and cmd[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

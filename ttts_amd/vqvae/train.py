@@ -484,7 +484,8 @@ def run(rank, n_gpus, hps, train_loader=None, steps_per_epoch=100):
         if getattr(hps.dataset, "path", "synthetic") != "synthetic":
             raise NotImplementedError("ttts.vqvae.train ships the synthetic data source; pass train_loader= for real data "
                                       "(ttts_amd.vqvae.dataset.DistributedBucketSampler gives the reference's batching)")
-        src = iter(SyntheticVqvaeBatches(hps.train.batch_size, seed=hps.train.seed + r, device=device))
+        src = iter(SyntheticVqvaeBatches(hps.train.batch_size, n_samples=int(getattr(hps.dataset, "synthetic_samples", 163840)),
+                                         text_len=int(getattr(hps.dataset, "synthetic_text_len", 64)), seed=hps.train.seed + r, device=device))
         train_loader = _EpochLoader(src, steps_per_epoch)
     try:
         _, _, _, epoch_str = load_checkpoint(latest_checkpoint_path(hps.train.exp_dir, "D_*.pth"), net_d, optim_d)
@@ -506,12 +507,37 @@ def run(rank, n_gpus, hps, train_loader=None, steps_per_epoch=100):
         scheduler_g.step(); scheduler_d.step()
 
 
-def main():
-    """ttts/vqvae/train.py:44-60.  The reference spawns one process per visible GPU itself; here the launcher does
-    (`torchrun --nproc-per-node N -m ttts.vqvae.train`), so main() is the per-process body."""
-    hps = get_hparams(*sys.argv[1:2])
-    n_gpus = int(os.environ.get("WORLD_SIZE", "1"))
-    run(int(os.environ.get("RANK", "0")), n_gpus, hps)
+def _spawned(local_rank, n_gpus, config_args, run_kwargs):
+    """Body of one spawned rank (module-level so that the `spawn` start method can import it): the torchrun environment is
+    written here, the process group itself comes up inside run() -> init_distributed()."""
+    os.environ.update({"RANK": str(local_rank), "LOCAL_RANK": str(local_rank), "WORLD_SIZE": str(n_gpus)})
+    run(local_rank, n_gpus, get_hparams(*config_args), **run_kwargs)
+
+
+def main(argv=None, **run_kwargs):
+    """ttts/vqvae/train.py:44-60: one process per visible GPU, started from here.  Under a launcher (WORLD_SIZE in the
+    environment: `torchrun --nproc-per-node N -m ttts.vqvae.train`) this process IS one rank and runs the body; otherwise --
+    the reference's `python ttts/vqvae/train.py` -- `torch.cuda.device_count()` ranks are spawned on the loopback address and a
+    free port (the reference draws a random port on "localhost"; the container's host name may not resolve), each running
+    run(rank, n_gpus, hps).  One visible GPU: no process group, no spawn.  TTTS_SPAWN_RANKS overrides the rank count (tests:
+    with TTTS_SHARE_GPU=1 the ranks share cuda:0 over gloo)."""
+    argv = list(sys.argv[1:2] if argv is None else argv)
+    if "WORLD_SIZE" in os.environ:
+        return run(int(os.environ.get("RANK", "0")), int(os.environ["WORLD_SIZE"]), get_hparams(*argv), **run_kwargs)
+    if not torch.cuda.is_available():
+        raise ops.TttsError("ttts.vqvae.train needs a GPU (no CPU fallback)")
+    n_gpus = int(os.environ.get("TTTS_SPAWN_RANKS", "0")) or torch.cuda.device_count()
+    if n_gpus <= 1:
+        return run(0, 1, get_hparams(*argv), **run_kwargs)
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    mp.spawn(_spawned, nprocs=n_gpus, args=(n_gpus, argv, run_kwargs))
 
 
 if __name__ == "__main__":
