@@ -34,7 +34,7 @@ extern "C" {
 #define TTTS_EHIP (-2)         /* a HIP runtime call or kernel launch failed */
 #define TTTS_EUNSUPPORTED (-3) /* valid request this build has no kernel for */
 
-#define TTTS_ABI_VERSION 9
+#define TTTS_ABI_VERSION 10
 
 /* ---- library ------------------------------------------------------------------------------------ */
 int ttts_abi_version(void);
@@ -481,6 +481,8 @@ int ttts_peak_scale_f32(float* x, const void* peak_bits, int32_t B, int32_t T, f
  *             split-bf16 matrix-core kernels (fp32 operands carried as hi + lo bf16, x*w accumulated in fp32 as
  *             hi*hi + hi*lo + lo*hi, relative error ~2^-16) and stage their pre-split operands / partial sums there;
  *             convolutions sharing one workspace must be ordered on one stream.  NULL (or ctx == NULL): exact kernels.
+ *  handles:   see the struct; the caches / arenas are caller-owned objects too, so that all state a call can depend on is
+ *             reachable from its arguments (no global state in the library except immutable kernel tables).
  *  flags:     TTTS_CONV_EXACT_F32 keeps the exact-fp32 MFMA kernels (bit-for-bit fmaf chains) even with a workspace;
  *             the remaining bits override tile / kernel heuristics for experiments (tools/conv_bench.py) and are 0 in
  *             normal operation. */
@@ -488,7 +490,10 @@ typedef struct ttts_conv_ctx {
   void* workspace;
   int64_t workspace_bytes;
   int32_t flags;
-  int32_t reserved;
+  int32_t n_handles;        /* ABI v10 (was `reserved`): entries of `handles` */
+  void* const* handles;     /* ABI v10: the weight-split caches (ttts_conv_wsplit_cache_create) and weight-gradient arenas
+                             * (ttts_conv_wgrad_arena_create) this call may use, in any order; NULL / 0: none.  The library keeps
+                             * NO registry of them: a convolution call sees exactly the objects its context names. */
 } ttts_conv_ctx;
 #define TTTS_CONV_EXACT_F32 4096
 #define TTTS_CONV_DIRECT_ONLY 256        /* experiments: every convolution on the direct (non-MFMA) kernels */
@@ -551,9 +556,10 @@ int ttts_weight_norm_bwd_batched_f32(const ttts_wn_desc* desc_dev, int32_t n_des
  * convolution call with a given (weight pointer, layout) records a descriptor and splits into a persistent slot; later calls
  * launch nothing, and ttts_conv_wsplit_cache_refresh -- to be called after every change of the weights, before they are next
  * used -- rewrites all recorded splits in ONE launch and arms the cache.  Disarmed (initially, and after _disarm: call it when
- * the step ends, since the arrays may then change without a refresh), when storage or max_entries run out, or on a first
- * sighting during stream capture, calls split per launch into the workspace as before: the cache changes launch counts,
- * never results.  No reference counterpart (cudnn picks its own weight layouts inside F.conv1d, ttts/vqvae/vq2.py:364-403). */
+ * the step ends, since the arrays may then change without a refresh), when storage or max_entries run out, on a first
+ * sighting during stream capture, or -- between an entry's first split and the next refresh -- on any stream other than the one
+ * that issued that split (only that stream is ordered behind it), calls split per launch into the workspace as before: the
+ * cache changes launch counts, never results.  The handle goes into ttts_conv_ctx::handles of the calls that may use it (v10).  No reference counterpart (cudnn picks its own weight layouts inside F.conv1d, ttts/vqvae/vq2.py:364-403). */
 int ttts_conv_wsplit_cache_create(const void* w_base, int64_t w_bytes, void* storage, int64_t storage_bytes, int32_t max_entries,
                                   void** cache_out);
 int ttts_conv_wsplit_cache_refresh(void* cache, void* stream);
@@ -566,13 +572,19 @@ int ttts_conv_wsplit_cache_destroy(void* cache);
  * its slabs to a persistent slot in caller-owned `storage` (256-byte aligned) and launches no reduce; _reduce adds every slab
  * set written since _begin into its dw / db in ONE launch and disarms.  Call _reduce before anything reads the gradients.  A
  * second gradient into the same dw within a phase, exhausted storage, a first sighting during stream capture, or a bias gradient
- * outside every registered range reduce immediately as before. */
+ * outside every arena of the call's context reduce immediately as before.  The handle goes into ttts_conv_ctx::handles (v10). */
 int ttts_conv_wgrad_arena_create(const void* dw_base, int64_t dw_bytes, void* storage, int64_t storage_bytes, int32_t max_entries,
                                  void** arena_out);
 int ttts_conv_wgrad_arena_begin(void* arena);
 int ttts_conv_wgrad_arena_reduce(void* arena, void* stream);
 int ttts_conv_wgrad_arena_disarm(void* arena);      /* abandon the phase: nothing is added, later calls reduce immediately */
-int ttts_conv_wgrad_arena_stats(void* arena, int64_t* out5 /* entries, storage bytes used, deferred, fallbacks, partial reduces */);
+/* ABI v10.  An entry handed out DURING A STREAM CAPTURE belongs to the recorded graph (its weight-gradient launch holds the slab
+ * pointer and split count, the reduce launch reads both from the device-side table at replay), so it is frozen: later calls that
+ * would need another split count or a larger slot reduce immediately (a fallback, counted) instead of rewriting it.  The caller
+ * declares "no graph recorded over this arena will be replayed any more" with _release_graphs (e.g. before it re-records its step
+ * for a new batch shape); `generation` (stats[5]) counts every change of the table, for callers that prefer to check. */
+int ttts_conv_wgrad_arena_release_graphs(void* arena);
+int ttts_conv_wgrad_arena_stats(void* arena, int64_t* out6 /* entries, storage bytes used, deferred, fallbacks, partial reduces, generation */);
 int ttts_conv_wgrad_arena_destroy(void* arena);
 int ttts_tanh_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, void* stream);
 int ttts_lrelu_bwd_f32(const float* dy, const float* y, float* dx, float slope, int64_t n, void* stream);

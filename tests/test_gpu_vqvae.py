@@ -1023,3 +1023,112 @@ def test_fused_cross_attention_forward_backward(B, H, dk, Tq, Tk, fill, use_q):
         oo, ogs = grads(lambda: _AttnCoreFn.apply(q, k, v, None, None, qm if qm is not None else torch.ones(B, Tq, device=dev), km, H, 0,
                                                   scale, fill, 0.0, 0))
         assert rel(o, oo) < 2e-6 and all(rel(a, b_) < 3e-6 for a, b_ in zip(gs, ogs))
+
+
+# ---- round 5: the advisor's four state / ordering findings ------------------------------------------------------------------
+@pytest.mark.bf16x3
+def test_recorded_wgrad_entries_are_frozen_until_released():
+    """A weight-gradient slab entry handed out during a stream capture belongs to the recorded graph: a later eager call with other
+    row lengths (another split count) must NOT rewrite it (it reduces immediately instead, a counted fallback), so replaying the
+    graph afterwards still gives the gradient it recorded; after release_graphs() the entry follows the new shape again."""
+    from ttts_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    cin, cout, k = 64, 64, 11
+    grads = torch.zeros(cout * cin * k + 64, device=dev)
+    dw = grads[:cout * cin * k].view(cout, cin, k)
+    arena = ops.WgradSlabArena(grads, 256 << 20)
+
+    def wgrad(x, dy):
+        arena.begin()
+        ops.conv1d_wgrad(dy, x, k, 1, 5, 1, out=dw)
+        arena.reduce()
+    xa, dya = torch.randn(4, cin, 2048, generator=g).to(dev), torch.randn(4, cout, 2048, generator=g).to(dev)
+    xb, dyb = torch.randn(4, cin, 9000, generator=g).to(dev), torch.randn(4, cout, 9000, generator=g).to(dev)
+    dw.zero_(); wgrad(xa, dya); ref_a = dw.clone()            # first sighting (eager): records the entry
+    assert arena.stats()["deferred"] == 1
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        wgrad(xa, dya)
+    torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+    with torch.cuda.graph(graph):
+        wgrad(xa, dya)
+    gen0, fb0 = arena.stats()["generation"], arena.stats()["fallbacks"]
+    dw.zero_(); wgrad(xb, dyb); torch.cuda.synchronize(); ref_b = dw.clone()          # other row lengths, eagerly
+    st = arena.stats()
+    if st["fallbacks"] > fb0:                                   # (only when the split count really differs between the shapes)
+        assert st["generation"] == gen0, "a recorded entry was rewritten"
+    dw.zero_(); graph.replay(); torch.cuda.synchronize()
+    assert torch.equal(dw, ref_a), "the recorded graph no longer reproduces its gradient"
+    arena.release_graphs()
+    dw.zero_(); wgrad(xb, dyb); torch.cuda.synchronize()
+    assert torch.equal(dw, ref_b)
+    arena.close()
+
+
+@pytest.mark.bf16x3
+def test_weight_split_first_sighting_is_private_to_its_stream():
+    """Between an entry's first split (issued on the registering call's stream) and the next refresh(), a convolution with the same
+    weights on ANOTHER stream must not read the persistent slot (nothing orders it behind that split): it is answered 'not cached'
+    (a miss) and splits into its own stream's scratch.  Results equal the uncached ones on both streams."""
+    from ttts_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(9)
+    w = (torch.randn(128, 128, 5, generator=g) * 0.05).to(dev)
+    x = torch.randn(4, 128, 1024, generator=g).to(dev)
+    ref = ops.conv1d_fwd(x, w, None, None, 1, 2, 1)
+    cache = ops.WeightSplitCache(w)
+    cache.refresh()                                             # arms the (still empty) cache
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    cur = torch.cuda.current_stream()
+    s1.wait_stream(cur); s2.wait_stream(cur)
+    with torch.cuda.stream(s1):
+        y1 = ops.conv1d_fwd(x, w, None, None, 1, 2, 1)          # first sighting: registers, splits on s1
+    st1 = cache.stats()
+    with torch.cuda.stream(s2):
+        y2 = ops.conv1d_fwd(x, w, None, None, 1, 2, 1)          # same key, other stream, before any refresh
+    st2 = cache.stats()
+    cur.wait_stream(s1); cur.wait_stream(s2); torch.cuda.synchronize()
+    assert st1["entries"] == 1 and st2["entries"] == 1
+    assert st2["hits"] == st1["hits"] and st2["misses"] == st1["misses"] + 1, (st1, st2)
+    assert torch.equal(y1, ref) and torch.equal(y2, ref)
+    cache.refresh()
+    with torch.cuda.stream(s2):
+        s2.wait_stream(cur)
+        y3 = ops.conv1d_fwd(x, w, None, None, 1, 2, 1)          # after the refresh every stream forked behind it may hit
+    cur.wait_stream(s2); torch.cuda.synchronize()
+    assert cache.stats()["hits"] == st2["hits"] + 1 and torch.equal(y3, ref)
+    cache.close()
+    y4 = ops.conv1d_fwd(x, w, None, None, 1, 2, 1)              # the closed cache is out of every context
+    assert torch.equal(y4, ref)
+
+
+@pytest.mark.bf16x3
+def test_backward_through_branch_streams_joins_by_itself():
+    """A plain user loop -- forward, backward, read the gradients, no join_side_streams() -- through modules that fan out over side
+    streams (MultiPeriodDiscriminator, a Generator's MRF stages): the engine callback queued by the fan-out's autograd node makes
+    the caller's stream wait for the side streams, so the gradients read right after backward() equal the one-stream ones."""
+    from ttts_amd.vqvae import modules
+    from ttts_amd.vqvae.vq2 import MultiPeriodDiscriminator
+    dev = _dev()
+    torch.manual_seed(4)
+    net = MultiPeriodDiscriminator().to(dev)
+    y = torch.randn(2, 1, 8192, device=dev); y_hat = torch.randn(2, 1, 8192, device=dev)
+
+    def grads(streams):
+        os.environ["TTTS_D_STREAMS"] = streams
+        for p_ in net.parameters():
+            p_.grad = torch.zeros_like(p_)           # existing slots: the backward kernels accumulate straight into them (_grad_slot)
+        r, g_, _, _ = net(y, y_hat.detach())
+        loss = sum(((1 - a) ** 2).mean() + (b ** 2).mean() for a, b in zip(r, g_))
+        loss.backward()
+        return torch.cat([p_.grad.flatten().clone() for p_ in net.parameters()])       # read on the caller's stream, no explicit join
+    try:
+        one = grads("0")
+        for _ in range(3):
+            many = grads("3")
+            assert torch.equal(one, many) or float((one - many).abs().max()) <= 1e-6 * float(one.abs().max())
+    finally:
+        os.environ.pop("TTTS_D_STREAMS", None)

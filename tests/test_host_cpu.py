@@ -32,7 +32,7 @@ def test_header_symbols_exported_and_bound(lib):
     for name in declared:
         assert hasattr(handle, name), "header declares %s but libttts_hip.so does not export it" % name
     assert declared == set(lib.SIGNATURES), declared ^ set(lib.SIGNATURES)
-    assert lib.get().ttts_abi_version() == lib.ABI_VERSION == 9
+    assert lib.get().ttts_abi_version() == lib.ABI_VERSION == 10
 
 
 def test_gemm_nt_dispatch_table(lib):

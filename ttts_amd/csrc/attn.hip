@@ -793,7 +793,7 @@ extern "C" int ttts_attn_causal_fwd_bf16(const void* q, const void* k, const voi
     {                                                                                                                    \
       using C2 = AttnCfg<DH>;                                                                                            \
       const size_t smem = (size_t)128 * (C2::KSTR + C2::VSTR) * sizeof(bf16) + 128 * sizeof(uint32_t);                    \
-      static bool attr_set = false;                                                                                      \
+      static OnceFlag attr_set;                                                                                      \
       if (!attr_set) {                                                                                                   \
         hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kv2_kernel<DH, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
         hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kv2_kernel<DH, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \

@@ -5,6 +5,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+
 #include "../../include/ttts_hip.h"
 
 namespace ttts {
@@ -18,6 +20,21 @@ inline int fail(int code, const char* fmt, ...) {
   va_end(ap);
   return code;
 }
+// "done on the CURRENT device": the dynamic-LDS opt-in of hipFuncSetAttribute is a per-device attribute, so a once-flag next to a
+// launch site must be per device as well (one process may drive several devices).  Drop-in for a `static bool`.
+struct OnceFlag {
+  std::atomic<uint64_t> mask{0};
+  static int dev() { int d = 0; (void)hipGetDevice(&d); return d & 63; }
+  operator bool() const { return (mask.load(std::memory_order_acquire) >> dev()) & 1; }
+  OnceFlag& operator=(bool v) { if (v) mask.fetch_or(1ull << dev(), std::memory_order_release); return *this; }
+};
+inline hipError_t lds_opt_in(OnceFlag& f, const void* fn, int bytes = 160 * 1024) {
+  if (f) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) f = true;
+  return e;
+}
+
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(TTTS_EHIP, "%s: %s", what, hipGetErrorString(e));
@@ -37,13 +54,18 @@ struct ConvCtx {
   void* ws = nullptr;      // scratch for split-bf16 operand copies / weight-gradient slabs; NULL: exact-fp32 kernels only
   int64_t ws_bytes = 0;
   int flags = 0;           // TTTS_CONV_EXACT_F32 | heuristic overrides (tests, tools/conv_bench.py)
+  void* const* handles = nullptr;   // the caller's weight-split caches / weight-gradient arenas this call may use (ABI v10)
+  int n_handles = 0;
 };
+// Every object handed out through ttts_conv_ctx::handles starts with this tag (the two kinds share one list).
+enum : uint32_t { TTTS_HANDLE_WSPLIT = 0x4c505357u /* "WSPL" */, TTTS_HANDLE_SLAB = 0x42414c53u /* "SLAB" */ };
 inline ConvCtx conv_ctx_of(const ttts_conv_ctx* c) {
   ConvCtx cx;
   if (c) {
     cx.ws = c->workspace;
     cx.ws_bytes = c->workspace ? c->workspace_bytes : 0;
     cx.flags = c->flags;
+    if (c->handles && c->n_handles > 0) { cx.handles = c->handles; cx.n_handles = c->n_handles; }
   }
   return cx;
 }

@@ -634,7 +634,7 @@ __global__ __launch_bounds__(256) void add4_scale_tail_kernel(const float* __res
   if (i < n) y[i] = scale * (((a[i] + (b ? b[i] : 0.f)) + (c ? c[i] : 0.f)) + (d ? d[i] : 0.f));
 }
 
-static int set_smem_attr(const void* fn, bool& done) {
+static int set_smem_attr(const void* fn, OnceFlag& done) {
   if (done) return TTTS_OK;
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return fail(TTTS_EHIP, "conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -688,7 +688,7 @@ extern "C" int ttts_conv1d_fwd_f32(const float* x, const float* w, const float* 
     const int nci = (cog >= CV_CT ? 1 : CV_CT / cog) * cig;
     const size_t gsmem = ((size_t)nci * lin_t + (size_t)CV_CT * cig * K) * sizeof(float);
     if (cog % 4 == 0 && (CV_CT % cog == 0 || cog % CV_CT == 0) && nci <= 32 && gsmem <= 150 * 1024) {
-      static bool gattr = false;
+      static OnceFlag gattr;
       rc = set_smem_attr(reinterpret_cast<const void*>(conv1d_fwd_grouped_kernel), gattr);
       if (rc) return rc;
       ConvParams p{x, w, bias, bbias, resid, omask, gate, y, B, cig, Lin, cog, Lout, K, stride, pad, dil, groups,
@@ -699,7 +699,7 @@ extern "C" int ttts_conv1d_fwd_f32(const float* x, const float* w, const float* 
   }
   const size_t smem = ((size_t)CV_CI * lin_t + (size_t)CV_CT * CV_CI * K) * sizeof(float);
   TTTS_REQUIRE(smem <= 160 * 1024, "conv1d_fwd: tile does not fit LDS (K=%d stride=%d dil=%d)", K, stride, dil);
-  static bool attr = false;
+  static OnceFlag attr;
   rc = set_smem_attr(reinterpret_cast<const void*>(conv1d_fwd_kernel), attr);
   if (rc) return rc;
   ConvParams p{x, w, bias, bbias, resid, omask, gate, y, B, Cin / groups, Lin, Cout / groups, Lout, K, stride, pad, dil, groups,
@@ -776,7 +776,7 @@ extern "C" int ttts_conv1d_dgrad_f32(const float* dy, const float* w, const floa
     const int nco = cig <= CV_CT && cig % 4 == 0 && CV_CT % cig == 0 ? (CV_CT / cig) * cog : 0;
     const size_t gsmem = ((size_t)nco * lt + (size_t)nco * cig * K) * sizeof(float);
     if (nco > 0 && gsmem <= 150 * 1024) {
-      static bool gattr = false;
+      static OnceFlag gattr;
       int rc = set_smem_attr(reinterpret_cast<const void*>(conv1d_dgrad_grouped_kernel), gattr);
       if (rc) return rc;
       ConvParams p{dy, w, bias, nullptr, resid, omask, gate, dx, B, cig, Lin, cog, Lout, K, stride, pad, dil, groups,
@@ -787,7 +787,7 @@ extern "C" int ttts_conv1d_dgrad_f32(const float* dy, const float* w, const floa
   }
   const size_t smem = ((size_t)CV_CI * lt + (size_t)CV_CI * CV_CT * K) * sizeof(float);
   TTTS_REQUIRE(smem <= 160 * 1024, "conv1d_dgrad: tile does not fit LDS");
-  static bool attr = false;
+  static OnceFlag attr;
   int rc = set_smem_attr(reinterpret_cast<const void*>(conv1d_dgrad_kernel), attr);
   if (rc) return rc;
   ConvParams p{dy, w, bias, nullptr, resid, omask, gate, dx, B, Cin / groups, Lin, Cout / groups, Lout, K, stride, pad, dil, groups,
@@ -829,7 +829,7 @@ static int conv1d_wgrad_impl(const float* dy, const float* x, float* dw, float* 
     const int lin_g = (WG_L - 1) * stride + (K - 1) * dil + 1;
     const size_t gsmem = ((size_t)16 * (WG_L + 1) + (size_t)nci * lin_g) * sizeof(float);
     if (cig * K <= 16 * WGG_ACC && (16 % cog == 0 || cog % 16 == 0) && gsmem <= 150 * 1024) {
-      static bool gattr = false;
+      static OnceFlag gattr;
       int rc = set_smem_attr(reinterpret_cast<const void*>(conv1d_wgrad_grouped_kernel), gattr);
       if (rc) return rc;
       const int chunks = B * (int)cdiv(Lout, WG_L);
@@ -846,7 +846,7 @@ static int conv1d_wgrad_impl(const float* dy, const float* x, float* dw, float* 
   TTTS_REQUIRE(K > 0, "conv1d_wgrad: bad K");
   const int lin_t = (WG_L - 1) * stride + (K - 1) * dil + 1;
   const size_t smem = ((size_t)WG_T * (WG_L + 1) + (size_t)WG_T * lin_t) * sizeof(float);
-  static bool attr = false;
+  static OnceFlag attr;
   int rc = set_smem_attr(reinterpret_cast<const void*>(conv1d_wgrad_kernel), attr);
   if (rc) return rc;
   const int tiles = (int)(cdiv(Cout, WG_T) * cdiv(Cin, WG_T)) * groups;

@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void g4_slab_sum_kernel(const float* __restric
   }
 }
 
-static int gp_attr(const void* fn, bool& done) {
+static int gp_attr(const void* fn, OnceFlag& done) {
   if (done) return TTTS_OK;
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return fail(TTTS_EHIP, "conv_grouped: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -418,9 +418,9 @@ int conv1d_grouped_fwd_mfma_try(const float* x, const float* w, const float* bia
       G4Params q{x, w, bias, y, B, groups, cog, Lin, Lout, K, stride, pad, in_slope, out_act, out_slope, out_scale};
       dim3 grid((unsigned)cdiv(Lout, LT), (unsigned)cdiv(Cout / 4, QW), (unsigned)B);
       int rc = TTTS_OK;
-      if (LT == 64) { static bool a = false; rc = gp_attr(reinterpret_cast<const void*>(conv1d_g4_fwd_kernel<64>), a); if (!rc) conv1d_g4_fwd_kernel<64><<<grid, 256, smem, stream>>>(q); }
-      else if (LT == 32) { static bool a = false; rc = gp_attr(reinterpret_cast<const void*>(conv1d_g4_fwd_kernel<32>), a); if (!rc) conv1d_g4_fwd_kernel<32><<<grid, 256, smem, stream>>>(q); }
-      else { static bool a = false; rc = gp_attr(reinterpret_cast<const void*>(conv1d_g4_fwd_kernel<16>), a); if (!rc) conv1d_g4_fwd_kernel<16><<<grid, 256, smem, stream>>>(q); }
+      if (LT == 64) { static OnceFlag a; rc = gp_attr(reinterpret_cast<const void*>(conv1d_g4_fwd_kernel<64>), a); if (!rc) conv1d_g4_fwd_kernel<64><<<grid, 256, smem, stream>>>(q); }
+      else if (LT == 32) { static OnceFlag a; rc = gp_attr(reinterpret_cast<const void*>(conv1d_g4_fwd_kernel<32>), a); if (!rc) conv1d_g4_fwd_kernel<32><<<grid, 256, smem, stream>>>(q); }
+      else { static OnceFlag a; rc = gp_attr(reinterpret_cast<const void*>(conv1d_g4_fwd_kernel<16>), a); if (!rc) conv1d_g4_fwd_kernel<16><<<grid, 256, smem, stream>>>(q); }
       if (rc) return rc;
       *handled = true;
       return check_launch("conv1d_g4_fwd");
@@ -430,7 +430,7 @@ int conv1d_grouped_fwd_mfma_try(const float* x, const float* w, const float* bia
   const int nci = cig * (16 / cog), R4 = (nci * K + 3) & ~3, IP = GP_NPT + (K - 1) / stride + 1;
   const size_t smem = ((size_t)nci * stride * IP + (size_t)R4 * 16 + R4) * sizeof(float);
   if (smem > 150 * 1024) return TTTS_OK;
-  static bool attr = false;
+  static OnceFlag attr;
   int rc = gp_attr(reinterpret_cast<const void*>(conv1d_grouped_fwd_mfma_kernel), attr);
   if (rc) return rc;
   GroupedParams p{x, w, bias, bbias, resid, omask, gate, y, B, cig, Lin, cog, Lout, K, stride, pad, groups,
@@ -450,7 +450,7 @@ int conv1d_grouped_dgrad_mfma_try(const float* dy, const float* w, const float* 
   const int Q = (K + stride - 1) / stride, R4 = (Q * cog + 3) & ~3, TPp = (GP_NPT + Q - 1) | 1;
   const size_t smem = ((size_t)cog * TPp + (size_t)R4 * 16 + R4) * sizeof(float);
   if (smem > 150 * 1024) return TTTS_OK;
-  static bool attr = false;
+  static OnceFlag attr;
   int rc = gp_attr(reinterpret_cast<const void*>(conv1d_grouped_dgrad_mfma_kernel), attr);
   if (rc) return rc;
   GroupedParams p{dy, w, bias, nullptr, resid, omask, gate, dx, B, cig, Lin, cog, Lout, K, stride, pad, groups,
@@ -473,7 +473,7 @@ int conv1d_grouped_wgrad_mfma_try(const float* dy, const float* x, float* dw, in
     const int64_t per = (int64_t)Cout * 4 * K;
     const size_t smem = ((size_t)4 * G4W_LC + (size_t)4 * ((G4W_LC - 1) * stride + K)) * sizeof(float);
     if ((int64_t)nrng * per * (int64_t)sizeof(float) <= cx.ws_bytes && smem <= 150 * 1024) {
-      static bool a = false;
+      static OnceFlag a;
       int rc = gp_attr(reinterpret_cast<const void*>(conv1d_g4_wgrad_kernel), a);
       if (rc) return rc;
       float* slab = static_cast<float*>(cx.ws);
@@ -499,12 +499,12 @@ int conv1d_grouped_wgrad_mfma_try(const float* dy, const float* x, float* dw, in
   float* slab = static_cast<float*>(cx.ws);
   dim3 grid((unsigned)sgs, (unsigned)nsplit);
   if (NT == 11) {
-    static bool a = false;
+    static OnceFlag a;
     int rc = gp_attr(reinterpret_cast<const void*>(conv1d_grouped_wgrad_mfma_kernel<11>), a);
     if (rc) return rc;
     conv1d_grouped_wgrad_mfma_kernel<11><<<grid, 256, smem, stream>>>(dy, x, slab, B, cig, Lin, cog, Lout, K, stride, pad, groups, dy_slope, x_slope, cpb);
   } else {
-    static bool a = false;
+    static OnceFlag a;
     int rc = gp_attr(reinterpret_cast<const void*>(conv1d_grouped_wgrad_mfma_kernel<41>), a);
     if (rc) return rc;
     conv1d_grouped_wgrad_mfma_kernel<41><<<grid, 256, smem, stream>>>(dy, x, slab, B, cig, Lin, cog, Lout, K, stride, pad, groups, dy_slope, x_slope, cpb);

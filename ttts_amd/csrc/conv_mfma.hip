@@ -346,29 +346,38 @@ struct WsplitKeyHash {
   }
 };
 struct WsplitCache {
+  uint32_t magic = TTTS_HANDLE_WSPLIT;      // (first member: how a ttts_conv_ctx::handles entry is told apart)
+  std::mutex mu;
   const char* w_lo; const char* w_hi;
   char* storage; int64_t bytes, used;       // [descriptor table: max_entries][256-byte aligned split arrays ...]
   int max_entries;
   bool armed = false;
   std::vector<WsplitDesc> host;
+  // the stream that wrote an entry's FIRST split (by its own launch, since the last refresh), else null: until the next refresh
+  // rewrites the entry, only that stream is ordered behind the split -- a lookup from any other stream is answered "not cached"
+  std::vector<hipStream_t> first_writer;
   std::unordered_map<WsplitKey, int, WsplitKeyHash> index;
   int64_t blocks = 0, hits = 0, misses = 0, launches_saved = 0;
 };
-static std::mutex g_wsplit_mu;
-static std::vector<WsplitCache*> g_wsplit;
+
+// A descriptor goes to its slot of the device-side table as a KERNEL ARGUMENT (by value): no host memory has to outlive the call.
+template <typename Desc>
+__global__ void desc_store_kernel(Desc* dst, Desc d) { *dst = d; }
 
 // (hi, lo) of the persistent split of this call's weights, or false: split into scratch as before.  *need_split: the caller
 // launches the split itself (a descriptor recorded by this very call; the next refresh covers it).
-static bool wsplit_lookup(const ConvMfmaParams& p, int nblk, int AP, int64_t elems_alloc, hipStream_t stream, bf16** hi,
-                          bf16** lo, bool* need_split) {
-  std::lock_guard<std::mutex> g(g_wsplit_mu);
+static bool wsplit_lookup(const ConvMfmaParams& p, const ConvCtx& cx, int nblk, int AP, int64_t elems_alloc, hipStream_t stream,
+                          bf16** hi, bf16** lo, bool* need_split) {
   const char* wp = reinterpret_cast<const char*>(p.w);
-  for (WsplitCache* c : g_wsplit) {
-    if (wp < c->w_lo || wp >= c->w_hi) continue;
+  for (int hidx = 0; hidx < cx.n_handles; ++hidx) {
+    WsplitCache* c = static_cast<WsplitCache*>(cx.handles[hidx]);
+    if (!c || c->magic != TTTS_HANDLE_WSPLIT || wp < c->w_lo || wp >= c->w_hi) continue;
+    std::lock_guard<std::mutex> g(c->mu);
     if (!c->armed) return false;
     const WsplitKey key{p.w, p.M, p.N, p.Mpad, p.K, p.Kmem, p.transposed, p.tap_off, p.tap_stride, AP, p.rowS, p.rpad, p.pad};
     auto it = c->index.find(key);
     if (it != c->index.end()) {
+      if (c->first_writer[it->second] != nullptr && c->first_writer[it->second] != stream) { ++c->misses; return false; }
       const WsplitDesc& d = c->host[it->second];
       *hi = d.hi; *lo = d.lo; *need_split = false;
       ++c->hits;
@@ -385,12 +394,10 @@ static bool wsplit_lookup(const ConvMfmaParams& p, int nblk, int AP, int64_t ele
     d.tap_off = p.tap_off; d.tap_stride = p.tap_stride; d.AP = AP; d.rowS = p.rowS; d.rpad = p.rpad; d.vpad = p.pad;
     d.block_begin = (int)c->blocks;
     const int idx = (int)c->host.size();
-    c->host.push_back(d);                     // (reserved to max_entries: the element never moves under the copy below)
-    if (hipMemcpyAsync(c->storage + (int64_t)idx * sizeof(WsplitDesc), &c->host[idx], sizeof(WsplitDesc), hipMemcpyHostToDevice,
-                       stream) != hipSuccess) {
-      c->host.pop_back();
-      return false;
-    }
+    desc_store_kernel<WsplitDesc><<<1, 1, 0, stream>>>(reinterpret_cast<WsplitDesc*>(c->storage) + idx, d);
+    if (hipGetLastError() != hipSuccess) return false;
+    c->host.push_back(d);
+    c->first_writer.push_back(stream);
     c->blocks += cdiv((int64_t)nblk * p.Mpad * AP, WSPLIT_EPB);
     c->used += need;
     c->index.emplace(key, idx);
@@ -950,7 +957,7 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_mfma_kernel(WgradMfmaParams 
 }
 
 
-static int set_attr_once(const void* fn, bool& done) {
+static int set_attr_once(const void* fn, OnceFlag& done) {
   if (done) return TTTS_OK;
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return fail(TTTS_EHIP, "conv_mfma: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -976,7 +983,7 @@ static int conv1d_mfma_launch_t(ConvMfmaParams p, const ConvCtx& cx, hipStream_t
   if (smem > 96 * 1024) return TTTS_OK;
   p.NT = NT;
   dim3 grid((unsigned)cdiv(p.Lout, SEG == LT ? LT : SEG), (unsigned)cdiv(p.M, MT), (unsigned)cdiv(p.B, LT / SEG));
-  static bool attr = false;
+  static OnceFlag attr;
   int rc = set_attr_once(reinterpret_cast<const void*>(conv1d_mfma_kernel<WCO, NW>), attr);
   if (rc) return rc;
   conv1d_mfma_kernel<WCO, NW><<<grid, 64 * NW, smem, stream>>>(p);
@@ -1063,7 +1070,7 @@ static int conv1d_bf16x3_dma_launch(ConvMfmaParams p, const ConvCtx& cx, hipStre
   bf16* hi = xlo + xel;
   bf16* lo = hi + welems;
   bool need_split = true;
-  wsplit_lookup(p, nblk, AP, welems, stream, &hi, &lo, &need_split);      // (persistent copies when the weights are cached)
+  wsplit_lookup(p, cx, nblk, AP, welems, stream, &hi, &lo, &need_split);      // (persistent copies when the weights are cached)
   p.a_hi = hi; p.a_lo = lo;
   if (need_split)
     conv_weight_split_kernel<<<(int)std::min<int64_t>(cdiv(welems, 256), 2048), 256, 0, stream>>>(p.w, hi, lo, p.M, p.N, p.Mpad, nblk, K, p.Kmem,
@@ -1077,7 +1084,7 @@ static int conv1d_bf16x3_dma_launch(ConvMfmaParams p, const ConvCtx& cx, hipStre
   int rc = TTTS_OK;
 #define TTTS_DMA(CW_, KT_)                                                                                       \
   {                                                                                                               \
-    static bool attr_ = false;                                                                                    \
+    static OnceFlag attr_;                                                                                    \
     rc = set_attr_once(reinterpret_cast<const void*>(conv1d_bf16x3_dma_kernel<CW_, KT_>), attr_);                 \
     if (rc) return rc;                                                                                            \
     conv1d_bf16x3_dma_kernel<CW_, KT_><<<grid, 256, dma_smem, stream>>>(p);                                        \
@@ -1120,7 +1127,7 @@ static int conv1d_bf16x3_launch_t(ConvMfmaParams p, const ConvCtx& cx, hipStream
   bf16* hi = static_cast<bf16*>(cx.ws);
   bf16* lo = hi + elems;
   bool need_split = true;
-  wsplit_lookup(p, nblk, K * 16, elems, stream, &hi, &lo, &need_split);
+  wsplit_lookup(p, cx, nblk, K * 16, elems, stream, &hi, &lo, &need_split);
   p.a_hi = hi; p.a_lo = lo;
   if (need_split)
     conv_weight_split_kernel<<<(int)std::min<int64_t>(cdiv(elems, 256), 2048), 256, 0, stream>>>(p.w, hi, lo, p.M, p.N, p.Mpad, nblk, K, p.Kmem,
@@ -1129,7 +1136,7 @@ static int conv1d_bf16x3_launch_t(ConvMfmaParams p, const ConvCtx& cx, hipStream
   int rc = TTTS_OK;
 #define TTTS_V1(KT_)                                                                                 \
   {                                                                                                   \
-    static bool attr_ = false;                                                                        \
+    static OnceFlag attr_;                                                                        \
     rc = set_attr_once(reinterpret_cast<const void*>(conv1d_bf16x3_kernel<WCO, KT_>), attr_);         \
     if (rc) return rc;                                                                                \
     conv1d_bf16x3_kernel<WCO, KT_><<<grid, 256, smem, stream>>>(p);                                  \
@@ -1913,6 +1920,8 @@ struct SlabKeyHash {
   }
 };
 struct SlabArena {
+  uint32_t magic = TTTS_HANDLE_SLAB;
+  std::mutex mu;
   const char* dw_lo; const char* dw_hi;
   char* storage; int64_t bytes, used;       // [descriptor table: max_entries][slabs ...]
   int max_entries;
@@ -1920,12 +1929,14 @@ struct SlabArena {
   std::vector<SlabDesc> host;
   std::vector<int> cap;                     // splits a slot has room for (a later batch with longer rows gets a new, larger slot)
   std::vector<uint8_t> touched;
+  // an entry that was handed out during a stream capture is part of a recorded graph (the weight-gradient launch holds its slab
+  // pointer and split count, the reduce launch reads them from the table at replay): it stays as it is -- calls that would need
+  // another split count or a larger slot reduce immediately instead -- until ttts_conv_wgrad_arena_release_graphs
+  std::vector<uint8_t> in_graph;
   int n_touched = 0;
   std::unordered_map<SlabKey, int, SlabKeyHash> index;
-  int64_t blocks = 0, deferred = 0, fallbacks = 0, partial_reduces = 0;
+  int64_t blocks = 0, deferred = 0, fallbacks = 0, partial_reduces = 0, generation = 0;
 };
-static std::mutex g_slab_mu;
-static std::vector<SlabArena*> g_slab;
 
 static int slab_desc_blocks(const SlabDesc& d) {
   return (int)(cdiv((int64_t)d.K * d.Cout * d.Cin, SLABB_EPB) + (d.bslab ? cdiv(d.Cout, SLABB_EPB) : 0));
@@ -1933,18 +1944,22 @@ static int slab_desc_blocks(const SlabDesc& d) {
 
 // The persistent slab of this weight-gradient call when its reduce can be deferred (then *bslab_out is the matching bias slab,
 // or NULL without `db`), else NULL: slabs in scratch and an immediate reduce, as before.
-static float* slab_defer(float* dw, float* db, bool want_bslab, int nsplit, int K, int Cout, int Cin, hipStream_t stream,
-                         float** bslab_out) {
-  std::lock_guard<std::mutex> g(g_slab_mu);
+static float* slab_defer(const ConvCtx& cx, float* dw, float* db, bool want_bslab, int nsplit, int K, int Cout, int Cin,
+                         hipStream_t stream, float** bslab_out) {
   const char* wp = reinterpret_cast<const char*>(dw);
   if (want_bslab) {          // the bias gradient is summed later too: only into a persistent (registered) gradient array
     const char* bp = reinterpret_cast<const char*>(db);
     bool ok = false;
-    for (SlabArena* c : g_slab) ok = ok || (bp >= c->dw_lo && bp < c->dw_hi);
+    for (int h = 0; h < cx.n_handles; ++h) {
+      const SlabArena* c = static_cast<const SlabArena*>(cx.handles[h]);
+      ok = ok || (c && c->magic == TTTS_HANDLE_SLAB && bp >= c->dw_lo && bp < c->dw_hi);
+    }
     if (!ok) return nullptr;
   }
-  for (SlabArena* c : g_slab) {
-    if (wp < c->dw_lo || wp >= c->dw_hi) continue;
+  for (int h = 0; h < cx.n_handles; ++h) {
+    SlabArena* c = static_cast<SlabArena*>(cx.handles[h]);
+    if (!c || c->magic != TTTS_HANDLE_SLAB || wp < c->dw_lo || wp >= c->dw_hi) continue;
+    std::lock_guard<std::mutex> g(c->mu);
     if (!c->armed) return nullptr;
     const SlabKey key{dw, want_bslab ? db : nullptr, K, Cout, Cin};
     const int64_t per = (int64_t)K * Cout * Cin;
@@ -1954,16 +1969,20 @@ static float* slab_defer(float* dw, float* db, bool want_bslab, int nsplit, int 
     int idx = it != c->index.end() ? it->second : -1;
     if (idx >= 0 && c->touched[idx]) { ++c->fallbacks; return nullptr; }      // a second gradient into the same dw in this phase
     if (idx >= 0 && nsplit <= c->cap[idx]) {
-      if (c->host[idx].nsplit != nsplit) {                  // other row lengths than last time: the table entry follows (4 bytes)
-        if (capturing) { ++c->fallbacks; return nullptr; }
-        c->host[idx].nsplit = nsplit;
-        if (hipMemcpyAsync(c->storage + (int64_t)idx * sizeof(SlabDesc), &c->host[idx], sizeof(SlabDesc), hipMemcpyHostToDevice,
-                           stream) != hipSuccess) { ++c->fallbacks; return nullptr; }
+      if (c->host[idx].nsplit != nsplit) {                  // other row lengths than last time: the table entry follows
+        if (capturing || c->in_graph[idx]) { ++c->fallbacks; return nullptr; }
+        SlabDesc d = c->host[idx];
+        d.nsplit = nsplit;
+        desc_store_kernel<SlabDesc><<<1, 1, 0, stream>>>(reinterpret_cast<SlabDesc*>(c->storage) + idx, d);
+        if (hipGetLastError() != hipSuccess) { ++c->fallbacks; return nullptr; }
+        c->host[idx] = d;
+        ++c->generation;
       }
     } else {                                                // first sighting, or the slot is too small for this split count
       const int capn = idx >= 0 ? std::max(nsplit, 2 * c->cap[idx]) : nsplit;
       const int64_t need = (((int64_t)capn * (per + (want_bslab ? Cout : 0)) * (int64_t)sizeof(float) + 255) / 256) * 256;
-      if (capturing || (idx < 0 && (int)c->host.size() >= c->max_entries) || c->used + need > c->bytes) {
+      if (capturing || (idx >= 0 && c->in_graph[idx]) || (idx < 0 && (int)c->host.size() >= c->max_entries) ||
+          c->used + need > c->bytes) {
         ++c->fallbacks;
         return nullptr;
       }
@@ -1973,23 +1992,24 @@ static float* slab_defer(float* dw, float* db, bool want_bslab, int nsplit, int 
       d.nsplit = nsplit; d.K = K; d.Cout = Cout; d.Cin = Cin; d.pad_ = 0;
       const bool fresh = idx < 0;
       d.block_begin = fresh ? (int)c->blocks : c->host[idx].block_begin;
-      if (fresh) { idx = (int)c->host.size(); c->host.push_back(d); } else c->host[idx] = d;
-      if (hipMemcpyAsync(c->storage + (int64_t)idx * sizeof(SlabDesc), &c->host[idx], sizeof(SlabDesc), hipMemcpyHostToDevice,
-                         stream) != hipSuccess) {
-        if (fresh) c->host.pop_back();
-        ++c->fallbacks;
-        return nullptr;
-      }
+      const int slot = fresh ? (int)c->host.size() : idx;
+      desc_store_kernel<SlabDesc><<<1, 1, 0, stream>>>(reinterpret_cast<SlabDesc*>(c->storage) + slot, d);
+      if (hipGetLastError() != hipSuccess) { ++c->fallbacks; return nullptr; }
       if (fresh) {
-        c->touched.push_back(0); c->cap.push_back(capn);
+        idx = slot;
+        c->host.push_back(d);
+        c->touched.push_back(0); c->in_graph.push_back(0); c->cap.push_back(capn);
         c->blocks += slab_desc_blocks(d);
         c->index.emplace(key, idx);
       } else {
+        c->host[idx] = d;
         c->cap[idx] = capn;
       }
       c->used += need;
+      ++c->generation;
     }
     c->touched[idx] = 1;
+    if (capturing) c->in_graph[idx] = 1;
     ++c->n_touched;
     ++c->deferred;
     *bslab_out = const_cast<float*>(c->host[idx].bslab);
@@ -2006,7 +2026,7 @@ static void launch_wgrad_taps_one(const WgradB3Params& p, dim3 grid, hipStream_t
   constexpr int STAGE_EL = 2 * (AC + BC) * 512;
   constexpr size_t smem = (size_t)2 * STAGE_EL * sizeof(bf16);
   static_assert(smem <= 160 * 1024, "taps stage too large");
-  static bool attr = false;
+  static OnceFlag attr;
   if (set_attr_once(reinterpret_cast<const void*>(conv1d_wgrad_bf16x3_taps_kernel<K, DIL, K0, KN, TILE, S, PO>), attr)) return;
   conv1d_wgrad_bf16x3_taps_kernel<K, DIL, K0, KN, TILE, S, PO><<<grid, 256, smem, stream>>>(p);
 }
@@ -2056,7 +2076,7 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, f
       float* slab = static_cast<float*>(cx.ws);
       float* bslab = db ? slab + (int64_t)nsplit * K * Cout * Cin : nullptr;
       float* pb = nullptr;
-      float* ps = slab_defer(dw, db, db != nullptr, nsplit, K, Cout, Cin, stream, &pb);     // (persistent slabs: reduce deferred)
+      float* ps = slab_defer(cx, dw, db, db != nullptr, nsplit, K, Cout, Cin, stream, &pb);     // (persistent slabs: reduce deferred)
       if (ps) { slab = ps; bslab = pb; }
       WgradMfmaParams p{dy, x, dw, B, Cin, Lin, Cout, Lout, K, 1, pad, dil, dy_slope, x_slope, cpb, slab, 64, bslab};
       dim3 grid((unsigned)cdiv(Cin, 32), (unsigned)cdiv(Cout, 32), (unsigned)nsplit);
@@ -2104,7 +2124,7 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, f
       const int nlc = nlc0, nchunks = nchunks0, cpb = cpb0;
       float* slab = reinterpret_cast<float*>(reinterpret_cast<char*>(xl + 2 * x_par) + ((16 - (reinterpret_cast<uintptr_t>(xl + 2 * x_par) & 15)) & 15));
       float* pb = nullptr;
-      float* ps = slab_defer(dw, nullptr, false, nsplit, K, Cout, Cin, stream, &pb);
+      float* ps = slab_defer(cx, dw, nullptr, false, nsplit, K, Cout, Cin, stream, &pb);
       if (ps) slab = ps;
       WgradB3Params p{dyh, dyl, xh, xl, dw, Bk, Cin, Cout, K, 1, dil, Lq, Li, 0, x_par, cpb, nchunks, nlc, slab};
       dim3 grid((unsigned)cdiv(Cin, 64), (unsigned)cdiv(Cout, 64), (unsigned)nsplit);
@@ -2148,7 +2168,7 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, f
       char* end = reinterpret_cast<char*>(xl + (x_el + 7) / 8 * 8);
       float* slab = reinterpret_cast<float*>(end + ((16 - (reinterpret_cast<uintptr_t>(end) & 15)) & 15));
       float* pb = nullptr;
-      float* ps = slab_defer(dw, nullptr, false, nsplit, K, Cout, Cin, stream, &pb);
+      float* ps = slab_defer(cx, dw, nullptr, false, nsplit, K, Cout, Cin, stream, &pb);
       if (ps) slab = ps;
       WgradB3Params p{dyh, dyl, xh, xl, dw, Bk, Cin, Cout, K, S, dil, Lq, Li, PO, x_el, cpb, nchunks, nlc, slab};
       dim3 grid((unsigned)cdiv(Cin, 64), (unsigned)cdiv(Cout, 64), (unsigned)nsplit);
@@ -2191,7 +2211,7 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, f
     if (!small && nsp > 1 && (end - static_cast<char*>(cx.ws)) + slab_bytes <= cx.ws_bytes) slab = reinterpret_cast<float*>(end);
   }
   float* pb = nullptr;
-  float* ps = slab ? slab_defer(dw, nullptr, false, nsp, K, Cout, Cin, stream, &pb) : nullptr;
+  float* ps = slab ? slab_defer(cx, dw, nullptr, false, nsp, K, Cout, Cin, stream, &pb) : nullptr;
   if (ps) slab = ps;
   WgradB3Params p{dyh, dyl, xh, xl, dw, B, Cin, Cout, K, stride, dil, Lq, Li, PL - pad, x_par, cpb, nchunks, nlc, slab};
   dim3 grid((unsigned)cdiv(Cin, TILE), (unsigned)cdiv(Cout, TILE), (unsigned)(K * nsp));
@@ -2229,7 +2249,7 @@ int conv1d_wgrad_mfma_try(const float* dy, const float* x, float* dw, float* db,
   const int64_t per = (int64_t)Cout * Cin * K;
   if (cx.ws && nz > 1 && (int64_t)nz * per * (int64_t)sizeof(float) <= cx.ws_bytes) slab = static_cast<float*>(cx.ws);
   WgradMfmaParams p{dy, x, dw, B, Cin, Lin, Cout, Lout, K, stride, pad, dil, dy_slope, x_slope, cpb, slab, SEGW};
-  static bool a = false;
+  static OnceFlag a;
   int rc = set_attr_once(reinterpret_cast<const void*>(conv1d_wgrad_mfma_kernel), a);
   if (rc) return rc;
   dim3 grid((unsigned)cdiv(Cin * K, 64), (unsigned)cdiv(Cout, 64), (unsigned)nz);
@@ -2241,7 +2261,8 @@ int conv1d_wgrad_mfma_try(const float* dy, const float* x, float* dw, float* db,
 
 }  // namespace ttts
 
-// C entry points of the weight-split cache (include/ttts_hip.h)
+// C entry points of the weight-split cache and the weight-gradient arena (include/ttts_hip.h).  Both are caller-owned objects:
+// the library keeps no list of them -- a convolution call sees the ones named in its ttts_conv_ctx::handles.
 extern "C" {
 
 int ttts_conv_wsplit_cache_create(const void* w_base, int64_t w_bytes, void* storage, int64_t storage_bytes, int32_t max_entries,
@@ -2255,25 +2276,31 @@ int ttts_conv_wsplit_cache_create(const void* w_base, int64_t w_bytes, void* sto
   c->w_lo = static_cast<const char*>(w_base); c->w_hi = c->w_lo + w_bytes;
   c->storage = static_cast<char*>(storage); c->bytes = storage_bytes; c->used = table;
   c->max_entries = max_entries;
-  c->host.reserve(max_entries);
-  std::lock_guard<std::mutex> g(g_wsplit_mu);
-  for (WsplitCache* o : g_wsplit)
-    if (c->w_lo < o->w_hi && o->w_lo < c->w_hi) { delete c; return fail(TTTS_EINVAL, "wsplit cache: weight range overlaps a registered one"); }
-  g_wsplit.push_back(c);
+  c->host.reserve(max_entries); c->first_writer.reserve(max_entries);
   *cache_out = c;
   return TTTS_OK;
 }
 
+static ttts::WsplitCache* as_wsplit(void* h) {
+  ttts::WsplitCache* c = static_cast<ttts::WsplitCache*>(h);
+  return c && c->magic == ttts::TTTS_HANDLE_WSPLIT ? c : nullptr;
+}
+static ttts::SlabArena* as_slab(void* h) {
+  ttts::SlabArena* c = static_cast<ttts::SlabArena*>(h);
+  return c && c->magic == ttts::TTTS_HANDLE_SLAB ? c : nullptr;
+}
+
 int ttts_conv_wsplit_cache_refresh(void* cache, void* stream) {
   using namespace ttts;
-  WsplitCache* c = static_cast<WsplitCache*>(cache);
-  if (!c) return fail(TTTS_EINVAL, "wsplit cache: null handle");
+  WsplitCache* c = as_wsplit(cache);
+  if (!c) return fail(TTTS_EINVAL, "wsplit cache: not a cache handle");
   int n; int64_t blocks;
   {
-    std::lock_guard<std::mutex> g(g_wsplit_mu);
+    std::lock_guard<std::mutex> g(c->mu);
     c->armed = true;
     n = (int)c->host.size(); blocks = c->blocks;
     c->launches_saved += n;
+    std::fill(c->first_writer.begin(), c->first_writer.end(), nullptr);     // rewritten below: every stream forked after this call may read
   }
   if (n == 0) return TTTS_OK;
   conv_weight_split_batched_kernel<<<(unsigned)blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(
@@ -2283,28 +2310,28 @@ int ttts_conv_wsplit_cache_refresh(void* cache, void* stream) {
 
 int ttts_conv_wsplit_cache_disarm(void* cache) {
   using namespace ttts;
-  WsplitCache* c = static_cast<WsplitCache*>(cache);
-  if (!c) return fail(TTTS_EINVAL, "wsplit cache: null handle");
-  std::lock_guard<std::mutex> g(g_wsplit_mu);
+  WsplitCache* c = as_wsplit(cache);
+  if (!c) return fail(TTTS_EINVAL, "wsplit cache: not a cache handle");
+  std::lock_guard<std::mutex> g(c->mu);
   c->armed = false;
   return TTTS_OK;
 }
 
 int ttts_conv_wsplit_cache_stats(void* cache, int64_t* out4) {
   using namespace ttts;
-  WsplitCache* c = static_cast<WsplitCache*>(cache);
+  WsplitCache* c = as_wsplit(cache);
   if (!c || !out4) return fail(TTTS_EINVAL, "wsplit cache: null argument");
-  std::lock_guard<std::mutex> g(g_wsplit_mu);
+  std::lock_guard<std::mutex> g(c->mu);
   out4[0] = (int64_t)c->host.size(); out4[1] = c->used; out4[2] = c->hits; out4[3] = c->misses;
   return TTTS_OK;
 }
 
 int ttts_conv_wsplit_cache_destroy(void* cache) {
   using namespace ttts;
-  WsplitCache* c = static_cast<WsplitCache*>(cache);
-  if (!c) return TTTS_OK;
-  std::lock_guard<std::mutex> g(g_wsplit_mu);
-  g_wsplit.erase(std::remove(g_wsplit.begin(), g_wsplit.end(), c), g_wsplit.end());
+  if (!cache) return TTTS_OK;
+  WsplitCache* c = as_wsplit(cache);
+  if (!c) return fail(TTTS_EINVAL, "wsplit cache: not a cache handle");
+  c->magic = 0;                       // (a context that still lists the handle skips it; the caller removes it from its contexts first)
   delete c;
   return TTTS_OK;
 }
@@ -2320,20 +2347,16 @@ int ttts_conv_wgrad_arena_create(const void* dw_base, int64_t dw_bytes, void* st
   c->dw_lo = static_cast<const char*>(dw_base); c->dw_hi = c->dw_lo + dw_bytes;
   c->storage = static_cast<char*>(storage); c->bytes = storage_bytes; c->used = table;
   c->max_entries = max_entries;
-  c->host.reserve(max_entries); c->touched.reserve(max_entries); c->cap.reserve(max_entries);
-  std::lock_guard<std::mutex> g(g_slab_mu);
-  for (SlabArena* o : g_slab)
-    if (c->dw_lo < o->dw_hi && o->dw_lo < c->dw_hi) { delete c; return fail(TTTS_EINVAL, "wgrad arena: gradient range overlaps a registered one"); }
-  g_slab.push_back(c);
+  c->host.reserve(max_entries); c->touched.reserve(max_entries); c->in_graph.reserve(max_entries); c->cap.reserve(max_entries);
   *arena_out = c;
   return TTTS_OK;
 }
 
 int ttts_conv_wgrad_arena_begin(void* arena) {
   using namespace ttts;
-  SlabArena* c = static_cast<SlabArena*>(arena);
-  if (!c) return fail(TTTS_EINVAL, "wgrad arena: null handle");
-  std::lock_guard<std::mutex> g(g_slab_mu);
+  SlabArena* c = as_slab(arena);
+  if (!c) return fail(TTTS_EINVAL, "wgrad arena: not an arena handle");
+  std::lock_guard<std::mutex> g(c->mu);
   std::fill(c->touched.begin(), c->touched.end(), 0);
   c->n_touched = 0;
   c->armed = true;
@@ -2342,10 +2365,10 @@ int ttts_conv_wgrad_arena_begin(void* arena) {
 
 int ttts_conv_wgrad_arena_reduce(void* arena, void* stream_) {
   using namespace ttts;
-  SlabArena* c = static_cast<SlabArena*>(arena);
-  if (!c) return fail(TTTS_EINVAL, "wgrad arena: null handle");
+  SlabArena* c = as_slab(arena);
+  if (!c) return fail(TTTS_EINVAL, "wgrad arena: not an arena handle");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  std::lock_guard<std::mutex> g(g_slab_mu);
+  std::lock_guard<std::mutex> g(c->mu);
   const bool was_armed = c->armed;
   c->armed = false;
   if (!was_armed || c->n_touched == 0) return TTTS_OK;
@@ -2367,30 +2390,40 @@ int ttts_conv_wgrad_arena_reduce(void* arena, void* stream_) {
 
 int ttts_conv_wgrad_arena_disarm(void* arena) {
   using namespace ttts;
-  SlabArena* c = static_cast<SlabArena*>(arena);
-  if (!c) return fail(TTTS_EINVAL, "wgrad arena: null handle");
-  std::lock_guard<std::mutex> g(g_slab_mu);
+  SlabArena* c = as_slab(arena);
+  if (!c) return fail(TTTS_EINVAL, "wgrad arena: not an arena handle");
+  std::lock_guard<std::mutex> g(c->mu);
   c->armed = false;
   std::fill(c->touched.begin(), c->touched.end(), 0);
   c->n_touched = 0;
   return TTTS_OK;
 }
 
-int ttts_conv_wgrad_arena_stats(void* arena, int64_t* out5) {
+int ttts_conv_wgrad_arena_release_graphs(void* arena) {
   using namespace ttts;
-  SlabArena* c = static_cast<SlabArena*>(arena);
-  if (!c || !out5) return fail(TTTS_EINVAL, "wgrad arena: null argument");
-  std::lock_guard<std::mutex> g(g_slab_mu);
-  out5[0] = (int64_t)c->host.size(); out5[1] = c->used; out5[2] = c->deferred; out5[3] = c->fallbacks; out5[4] = c->partial_reduces;
+  SlabArena* c = as_slab(arena);
+  if (!c) return fail(TTTS_EINVAL, "wgrad arena: not an arena handle");
+  std::lock_guard<std::mutex> g(c->mu);
+  std::fill(c->in_graph.begin(), c->in_graph.end(), 0);
+  return TTTS_OK;
+}
+
+int ttts_conv_wgrad_arena_stats(void* arena, int64_t* out6) {
+  using namespace ttts;
+  SlabArena* c = as_slab(arena);
+  if (!c || !out6) return fail(TTTS_EINVAL, "wgrad arena: null argument");
+  std::lock_guard<std::mutex> g(c->mu);
+  out6[0] = (int64_t)c->host.size(); out6[1] = c->used; out6[2] = c->deferred; out6[3] = c->fallbacks; out6[4] = c->partial_reduces;
+  out6[5] = c->generation;
   return TTTS_OK;
 }
 
 int ttts_conv_wgrad_arena_destroy(void* arena) {
   using namespace ttts;
-  SlabArena* c = static_cast<SlabArena*>(arena);
-  if (!c) return TTTS_OK;
-  std::lock_guard<std::mutex> g(g_slab_mu);
-  g_slab.erase(std::remove(g_slab.begin(), g_slab.end(), c), g_slab.end());
+  if (!arena) return TTTS_OK;
+  SlabArena* c = as_slab(arena);
+  if (!c) return fail(TTTS_EINVAL, "wgrad arena: not an arena handle");
+  c->magic = 0;
   delete c;
   return TTTS_OK;
 }

@@ -571,7 +571,7 @@ extern "C" int ttts_linear_decode_bf16(const void* x, int64_t ldx, int32_t x_is_
   p.W = static_cast<const bf16*>(W); p.ldw = ldw; p.bias = bias; p.out = out; p.ldc = ldc; p.resid = resid;
   p.M = M; p.N = N; p.K = K; p.epi = epilogue; p.eps = 1e-5f;
   const size_t smem = (size_t)16 * (K + 8) * sizeof(bf16) + (size_t)LW * 16 * 16 * sizeof(float);
-  static bool attr_set = false;
+  static OnceFlag attr_set;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return fail(TTTS_EHIP, "linear_decode: hipFuncSetAttribute: %s", hipGetErrorString(e));

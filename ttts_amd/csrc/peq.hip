@@ -264,7 +264,7 @@ extern "C" int ttts_stft_filter_frames_f32(const float* wav, const float* window
   const int frames = 1 + T / hop;
   const int L = n_fft / 2;
   const size_t smem = (size_t)(PEQ_FR * 2 + 1) * L * sizeof(float2);
-  static bool attr_set = false;
+  static OnceFlag attr_set;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(peq_frames_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return fail(TTTS_EHIP, "stft_filter_frames: hipFuncSetAttribute: %s", hipGetErrorString(e));

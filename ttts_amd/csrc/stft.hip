@@ -605,8 +605,8 @@ extern "C" int ttts_stft_mag_fwd_f32(const float* wav, const float* window, cons
   const bool r4 = L >= 256 && L <= 2048;                 // 64-byte output runs, but 110 KB of LDS = one workgroup per CU: 120 us vs 91); short transforms keep radix-2
   if (L == 1024) {                                        // n_fft 2048 (the training configuration): per-thread tables, LDS swizzle
     const size_t smemp = (size_t)2 * NF * L * sizeof(float2) + (size_t)(L + 1) * (FR4 + 1) * sizeof(float);
-    static const hipError_t attrp = hipFuncSetAttribute(reinterpret_cast<const void*>(stft_mag_r4p_kernel<NF, FR4, 10>),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static OnceFlag attrp_once;
+    const hipError_t attrp = lds_opt_in(attrp_once, reinterpret_cast<const void*>(stft_mag_r4p_kernel<NF, FR4, 10>), 160 * 1024);
     if (attrp != hipSuccess) return fail(TTTS_EHIP, "stft: hipFuncSetAttribute: %s", hipGetErrorString(attrp));
     stft_mag_r4p_kernel<NF, FR4, 10><<<B * (int)cdiv(frames, FR4), 256, smemp, as_stream(stream)>>>(
         wav, window, reinterpret_cast<const float2*>(twiddle), spec, T, hop, frames);
@@ -615,8 +615,8 @@ extern "C" int ttts_stft_mag_fwd_f32(const float* wav, const float* window, cons
   if (r4) {
     const size_t smem4 = (size_t)2 * NF * L * sizeof(float2) + ((size_t)(L + 1) * (FR4 + 1) + (((L + 1) * (FR4 + 1)) & 1)) * sizeof(float) +
                          (size_t)L * sizeof(float2);
-    static const hipError_t attr4 = hipFuncSetAttribute(reinterpret_cast<const void*>(stft_mag_r4_kernel<NF, FR4>),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static OnceFlag attr4_once;
+    const hipError_t attr4 = lds_opt_in(attr4_once, reinterpret_cast<const void*>(stft_mag_r4_kernel<NF, FR4>), 160 * 1024);
     if (attr4 != hipSuccess) return fail(TTTS_EHIP, "stft: hipFuncSetAttribute: %s", hipGetErrorString(attr4));
     stft_mag_r4_kernel<NF, FR4><<<B * (int)cdiv(frames, FR4), 256, smem4, as_stream(stream)>>>(
         wav, window, reinterpret_cast<const float2*>(twiddle), spec, T, n_fft, hop, frames, log2L);
@@ -626,8 +626,8 @@ extern "C" int ttts_stft_mag_fwd_f32(const float* wav, const float* window, cons
   const size_t span_bytes = ((size_t)(STFT_FR - 1) * hop + n_fft) * sizeof(float);
   const int span_lds = smem + span_bytes <= 80 * 1024;   // only where it does not cost the second workgroup per CU
   if (span_lds) smem += span_bytes;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(stft_mag_kernel),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  static OnceFlag attr_once;
+    const hipError_t attr = lds_opt_in(attr_once, reinterpret_cast<const void*>(stft_mag_kernel), 160 * 1024);
   if (attr != hipSuccess) return fail(TTTS_EHIP, "stft: hipFuncSetAttribute: %s", hipGetErrorString(attr));
   const int grid = B * (int)cdiv(frames, STFT_FR);
   stft_mag_kernel<<<grid, 256, smem, as_stream(stream)>>>(wav, window, reinterpret_cast<const float2*>(twiddle), spec, T,
@@ -662,7 +662,7 @@ extern "C" int ttts_stft_mag_bwd_f32(const float* wav, const float* window, cons
   int log2L = 0;
   while ((1 << log2L) < n_fft / 2) ++log2L;
   const size_t smem = (size_t)2 * n_fft * sizeof(float2);
-  static bool attr_set = false;
+  static OnceFlag attr_set;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stft_mag_bwd_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -623,11 +623,9 @@ extern "C" int ttts_vq_nearest_f32(const float* x, const float* codebook, int64_
   TTTS_REQUIRE(N > 0 && K > 0 && D > 0 && D % 2 == 0 && D <= 256, "vq_nearest: need even D <= 256 (D=%d)", D);
   hipStream_t s = as_stream(stream);
   const size_t smem = ((size_t)(VQ_ROWS + VQ_CODES) * (D + 1) + 8 * VQ_ROWS) * sizeof(float);
-  static const hipError_t attr = [] {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(vq_nearest_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    return e != hipSuccess ? e : hipFuncSetAttribute(reinterpret_cast<const void*>(vq_nearest_slice_kernel),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  }();
+  static OnceFlag once_generic, once_slice;
+  hipError_t attr = lds_opt_in(once_generic, reinterpret_cast<const void*>(vq_nearest_kernel));
+  if (attr == hipSuccess) attr = lds_opt_in(once_slice, reinterpret_cast<const void*>(vq_nearest_slice_kernel));
   if (attr != hipSuccess) return fail(TTTS_EHIP, "vq_nearest: hipFuncSetAttribute: %s", hipGetErrorString(attr));
   if ((D == 64 || D == 128 || D == 192) && aligned16(x) && aligned16(codebook) && (!xq || aligned16(xq))) {
     const int SL = (int)cdiv(K, VQ3_SLICE);
@@ -637,9 +635,8 @@ extern "C" int ttts_vq_nearest_f32(const float* x, const float* codebook, int64_
     hipError_t e = hipSuccess;
 #define VQ3_LAUNCH(D4_)                                                                                                          \
     do {                                                                                                                          \
-      static const hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void*>(vq_nearest_tile_kernel<D4_>),                 \
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 32 * 4 * D4_ * 4);         \
-      e = a;                                                                                                                      \
+      static OnceFlag once_tile;                                                                                                  \
+      e = lds_opt_in(once_tile, reinterpret_cast<const void*>(vq_nearest_tile_kernel<D4_>), 6 * 32 * 4 * D4_ * 4);                \
       if (e == hipSuccess) vq_nearest_tile_kernel<D4_><<<grid, 256, lds, s>>>(x, codebook, part, N, K, SL);                      \
     } while (0)
     if (D == 64) VQ3_LAUNCH(16); else if (D == 128) VQ3_LAUNCH(32); else VQ3_LAUNCH(48);   // (D = 256: six images would need 192 KB of LDS)

@@ -67,12 +67,13 @@ _c = ctypes
 _P, _I32, _I64, _U64, _F = _c.c_void_p, _c.c_int32, _c.c_int64, _c.c_uint64, _c.c_float
 
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class ConvCtx(ctypes.Structure):
     """include/ttts_hip.h: ttts_conv_ctx (caller-owned; the library keeps no copy)."""
-    _fields_ = [("workspace", _P), ("workspace_bytes", _I64), ("flags", _I32), ("reserved", _I32)]
+    _fields_ = [("workspace", _P), ("workspace_bytes", _I64), ("flags", _I32), ("n_handles", _I32),
+                ("handles", ctypes.POINTER(ctypes.c_void_p))]
 
 
 class LnFinalizeDesc(ctypes.Structure):
@@ -218,6 +219,7 @@ SIGNATURES = {
     "ttts_conv_wgrad_arena_reduce": (_I32, [_P, _P]),
     "ttts_conv_wgrad_arena_disarm": (_I32, [_P]),
     "ttts_conv_wgrad_arena_stats": (_I32, [_P, ctypes.POINTER(ctypes.c_int64)]),
+    "ttts_conv_wgrad_arena_release_graphs": (_I32, [_P]),
     "ttts_conv_wgrad_arena_destroy": (_I32, [_P]),
     "ttts_tanh_bwd_f32": (_I32, [_P, _P, _P, _I64, _P]),
     "ttts_add4_scale_f32": (_I32, [_P, _P, _P, _P, _F, _P, _I64, _P]),

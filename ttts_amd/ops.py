@@ -357,6 +357,40 @@ class WeightNormPlan:
         check(_l.get().ttts_weight_norm_bwd_batched_f32(_p(self.table), self.n, self.rows, _stream()), "weight_norm_bwd_batched")
 
 
+# The weight-split caches and weight-gradient arenas alive on each device.  The C library keeps no list of them (ABI v10): every
+# convolution context (one per stream, _conv_ctx) carries the device's handles in `ttts_conv_ctx::handles`; this host-side table is
+# where those arrays are rebuilt when an object is created or closed.
+_conv_handles = {}            # device key -> {"objs": [owner objects], "array": ctypes array | None}
+
+
+def _register_conv_handle(obj, device):
+    ent = _conv_handles.setdefault(_device_key(device), {"objs": [], "array": None})
+    ent["objs"].append(obj)
+    _rebuild_conv_handles(_device_key(device))
+
+
+def _unregister_conv_handle(obj, device):
+    ent = _conv_handles.get(_device_key(device))
+    if ent is not None and obj in ent["objs"]:
+        ent["objs"].remove(obj)
+        _rebuild_conv_handles(_device_key(device))
+
+
+def _rebuild_conv_handles(dkey):
+    ent = _conv_handles[dkey]
+    hs = [o._h.value for o in ent["objs"] if o._h is not None and o._h.value]
+    ent["array"] = (ctypes.c_void_p * len(hs))(*hs) if hs else None
+    for (ck, _stream_h), (ctx, _buf) in _conv_ctxs.items():
+        if ck == dkey:
+            _set_ctx_handles(ctx, ent)
+
+
+def _set_ctx_handles(ctx, ent):
+    arr = ent["array"] if ent is not None else None
+    ctx.n_handles = len(arr) if arr is not None else 0
+    ctx.handles = ctypes.cast(arr, ctypes.POINTER(ctypes.c_void_p)) if arr is not None else ctypes.POINTER(ctypes.c_void_p)()
+
+
 class WeightSplitCache:
     """Persistent bf16 hi/lo splits of every convolution weight living in `weights` (a flat fp32 tensor: an optimizer's parameter
     arena or a WeightNormBank's effective weights), rewritten by ONE launch per `refresh()` instead of one split launch in front
@@ -373,6 +407,7 @@ class WeightSplitCache:
         check(_l.get().ttts_conv_wsplit_cache_create(_p(weights), weights.numel() * 4, _p(self.storage), self.storage.numel(),
                                                      max_entries, ctypes.byref(h)), "wsplit_cache_create")
         self._h = h
+        _register_conv_handle(self, weights.device)
 
     def refresh(self):
         check(_l.get().ttts_conv_wsplit_cache_refresh(self._h, _stream()), "wsplit_cache_refresh")
@@ -387,8 +422,9 @@ class WeightSplitCache:
 
     def close(self):
         if self._h is not None and self._h.value:
-            _l.get().ttts_conv_wsplit_cache_destroy(self._h)
-            self._h = None
+            h, self._h = self._h, None
+            _unregister_conv_handle(self, self.weights.device)      # (out of every context before the object goes away)
+            _l.get().ttts_conv_wsplit_cache_destroy(h)
 
     def __del__(self):
         try:
@@ -413,6 +449,7 @@ class WgradSlabArena:
         check(_l.get().ttts_conv_wgrad_arena_create(_p(grads), grads.numel() * 4, _p(self.storage), self.storage.numel(),
                                                     max_entries, ctypes.byref(h)), "wgrad_arena_create")
         self._h = h
+        _register_conv_handle(self, grads.device)
 
     def begin(self):
         check(_l.get().ttts_conv_wgrad_arena_begin(self._h), "wgrad_arena_begin")
@@ -424,14 +461,21 @@ class WgradSlabArena:
         check(_l.get().ttts_conv_wgrad_arena_disarm(self._h), "wgrad_arena_disarm")
 
     def stats(self):
-        out = (ctypes.c_int64 * 5)()
+        out = (ctypes.c_int64 * 6)()
         check(_l.get().ttts_conv_wgrad_arena_stats(self._h, out), "wgrad_arena_stats")
-        return {"entries": out[0], "bytes_used": out[1], "deferred": out[2], "fallbacks": out[3], "partial_reduces": out[4]}
+        return {"entries": out[0], "bytes_used": out[1], "deferred": out[2], "fallbacks": out[3], "partial_reduces": out[4],
+                "generation": out[5]}
+
+    def release_graphs(self):
+        """No hipGraph recorded over this arena will be replayed any more (the caller dropped it): entries frozen by a capture may
+        follow new batch shapes again."""
+        check(_l.get().ttts_conv_wgrad_arena_release_graphs(self._h), "wgrad_arena_release_graphs")
 
     def close(self):
         if self._h is not None and self._h.value:
-            _l.get().ttts_conv_wgrad_arena_destroy(self._h)
-            self._h = None
+            h, self._h = self._h, None
+            _unregister_conv_handle(self, self.grads.device)
+            _l.get().ttts_conv_wgrad_arena_destroy(h)
 
     def __del__(self):
         try:
@@ -888,12 +932,13 @@ def _conv_ctx(device):
     every conv entry point receives the struct by pointer.  TTTS_CONV_FP32=1 creates it without scratch (exact kernels)."""
     # one scratch per (device, stream): convolutions issued on different streams (the sub-discriminators run concurrently,
     # vq2.MultiPeriodDiscriminator) must not share operand-split buffers
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+    key = (_device_key(device), torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
     if key not in _conv_ctxs:
         buf = None
         if os.environ.get("TTTS_CONV_FP32", "0") != "1":
             buf = torch.empty(int(os.environ.get("TTTS_CONV_SCRATCH_MB", "1536")) << 20, dtype=torch.uint8, device=device)
-        ctx = _l.ConvCtx(_p(buf), buf.numel() if buf is not None else 0, 0, 0)
+        ctx = _l.ConvCtx(_p(buf), buf.numel() if buf is not None else 0, 0, 0, ctypes.POINTER(ctypes.c_void_p)())
+        _set_ctx_handles(ctx, _conv_handles.get(key[0]))
         _conv_ctxs[key] = (ctx, buf)
         _apply_flags()
     return ctypes.byref(_conv_ctxs[key][0])

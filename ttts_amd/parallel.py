@@ -58,7 +58,7 @@ class FlatDataParallel:
         if grad_dtype is None and os.environ.get("TTTS_DP_GRAD_DTYPE", "") in ("bf16", "bfloat16"):
             grad_dtype = torch.bfloat16
         self.grad_dtype = grad_dtype
-        self._stage = None
+        self._stages = {}                    # one bf16 staging buffer per arena (keyed by its data pointer): D and G alternate
         self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         self.world = dist.get_world_size(group) if self.enabled else 1
         self.rank = dist.get_rank(group) if self.enabled else 0
@@ -89,9 +89,11 @@ class FlatDataParallel:
         if not self.enabled or hi <= lo:
             return None
         if self.grad_dtype is not None and flat_grads.dtype != self.grad_dtype:
-            if self._stage is None or self._stage.numel() != flat_grads.numel() or self._stage.device != flat_grads.device:
-                self._stage = torch.empty(flat_grads.numel(), dtype=self.grad_dtype, device=flat_grads.device)
-            st = self._stage[lo:hi]
+            key = (flat_grads.data_ptr(), flat_grads.numel(), str(flat_grads.device))
+            stage = self._stages.get(key)
+            if stage is None:
+                stage = self._stages[key] = torch.empty(flat_grads.numel(), dtype=self.grad_dtype, device=flat_grads.device)
+            st = stage[lo:hi]
             st.copy_(flat_grads[lo:hi])                      # (on the collective's input stream order: torch.distributed syncs with it)
             work = dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             return _WidenOnWait(work, st, flat_grads[lo:hi])

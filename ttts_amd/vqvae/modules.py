@@ -76,6 +76,57 @@ def join_side_streams(device):
         main.wait_stream(_dirty_streams.pop())
 
 
+class _JoinAfterBackward(torch.autograd.Function):
+    """Identity on the outputs of a fan-out.  Its backward node runs BEFORE the branches' nodes (it sits downstream of them) and
+    queues an engine callback: when the whole backward pass is over, the stream backward() was called on waits for the side
+    streams the branches ran on.  This makes the join part of every backward through run_branches / MultiPeriodDiscriminator --
+    user loops, tests, torch.autograd.grad -- instead of a rule the caller has to know (VqvaeStep still calls
+    join_side_streams() itself: waiting twice is free)."""
+
+    @staticmethod
+    def forward(ctx, holder, *xs):
+        ctx.holder = holder
+        return xs
+
+    @staticmethod
+    def backward(ctx, *gs):
+        device, streams = ctx.holder
+
+        def join():
+            main = torch.cuda.current_stream(device)
+            for st in streams:
+                main.wait_stream(st)
+        torch.autograd.Variable._execution_engine.queue_callback(join)
+        return (None,) + gs
+
+
+def join_after_backward(outs, device, streams):
+    """`outs` (tensor or nested tuples / lists of tensors) with every gradient-carrying tensor routed through _JoinAfterBackward."""
+    if not streams or not torch.is_grad_enabled():
+        return outs
+    flat = []
+
+    def collect(o):
+        if torch.is_tensor(o):
+            if o.requires_grad:
+                flat.append(o)
+        elif isinstance(o, (tuple, list)):
+            for e in o:
+                collect(e)
+    collect(outs)
+    if not flat:
+        return outs
+    new = iter(_JoinAfterBackward.apply((device, list(streams)), *flat))
+
+    def rebuild(o):
+        if torch.is_tensor(o):
+            return next(new) if o.requires_grad else o
+        if isinstance(o, (tuple, list)):
+            return type(o)(rebuild(e) for e in o)
+        return o
+    return rebuild(outs)
+
+
 _wgrad_rr = [0]
 
 
@@ -114,7 +165,7 @@ def run_branches(fns, device, pool="mrf"):
             used.append(st)
     for st in used:
         main.wait_stream(st)
-    return outs
+    return join_after_backward(outs, device, used)
 
 
 def _grad_slot(p):

@@ -293,6 +293,11 @@ class VqvaeTrainer:
         key = tuple((k, tuple(v.shape)) for k, v in sorted(data.items()))
         st = getattr(self, "_graph_state", None)
         if st is None or st["key"] != key:
+            # the old recording is dropped here: its frozen weight-gradient slab entries may follow the new batch shape again
+            # (include/ttts_hip.h: ttts_conv_wgrad_arena_release_graphs) -- before the warm-up steps that re-shape them
+            self._graph_state = None
+            for a in self.step_fn.slabs_g + self.step_fn.slabs_d:
+                a.release_graphs()
             st = self._capture(data, key)
             self._graph_state = st
         if st["graph"] is None:
@@ -318,13 +323,24 @@ class VqvaeTrainer:
         prev = EuclideanCodebook.sync_free
         EuclideanCodebook.sync_free = True                   # no host read-backs inside the step (see expire_codes_)
         try:
-            side = torch.cuda.Stream(device=self.device)
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):                    # warm-up on a side stream, as torch's capture recipe asks
-                for _ in range(2):
-                    self.train_step(inputs)
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
+            # ONE warm-up stream per trainer, reused by every re-capture (a fresh torch.cuda.Stream per capture would make the
+            # convolution contexts -- keyed by stream, 1.5 GB of operand scratch each -- grow with every new batch shape)
+            side = getattr(self, "_warm_stream", None)
+            if side is None:
+                side = self._warm_stream = torch.cuda.Stream(device=self.device)
+            warm_ok, warm_err = 1, None
+            try:
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):                # warm-up on a side stream, as torch's capture recipe asks
+                    for _ in range(2):
+                        self.train_step(inputs)
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+            except Exception as e:                           # noqa: BLE001
+                warm_ok, warm_err = 0, e
+            # every rank votes on every exit path: a rank that left here alone would skip the collectives its peers still issue
+            if not (self.dp.all_ranks_ok(warm_ok) if self.dp.enabled else warm_ok):
+                raise RuntimeError("warm-up failed on %s" % ("this rank: %s" % warm_err if warm_err is not None else "another rank"))
             if self.dp.enabled:
                 # World size > 1: the collectives cannot be recorded, so the step is recorded as THREE graphs that share one
                 # memory pool (tensors and the autograd graph of an earlier segment stay valid in the later ones) with the two

@@ -118,6 +118,7 @@ class MultiPeriodDiscriminator(nn.Module):
             both = torch.cat([y, y_hat], 0)
             outs = [on(i, lambda d=d: d(both)) for i, d in enumerate(self.discriminators)]
             join()
+            outs = modules.join_after_backward(outs, y.device, pool)
             for out, fmap in outs:
                 y_d_r, y_d_g = out.chunk(2, 0)
                 y_d_rs.append(y_d_r)
@@ -133,6 +134,7 @@ class MultiPeriodDiscriminator(nn.Module):
         for i, d in enumerate(self.discriminators):
             outs.append((on(i + 1, lambda d=d: real(d)), on(i, lambda d=d: d(y_hat))))
         join()
+        outs = modules.join_after_backward(outs, y.device, pool)
         for (y_d_r, fmap_r), (y_d_g, fmap_g) in outs:
             y_d_rs.append(y_d_r)
             y_d_gs.append(y_d_g)
