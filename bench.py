@@ -306,6 +306,28 @@ def diffusion_leg(dev, steps, warmup, cpu_leg=True):
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
     loss = float(out["loss"])
     assert loss == loss, "non-finite diffusion loss"
+    # the same step with every 1 x 1 convolution / linear layer on the fp8 (e4m3) matrix cores -- BASELINE config #5's GEMM arithmetic
+    # (csrc/fp8_gemm.hip; activations between the layers stay fp32, the k = 3 convolutions and the attention GEMMs as above)
+    from ttts_amd.diffusion import aa_model as _aa
+    fp8 = None
+    prev_mode = _aa.set_precision("fp8")
+    try:
+        for _ in range(warmup):
+            out8 = tr.train_step(mel, ref, lat)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(steps):
+            out8 = tr.train_step(mel, ref, lat)
+        torch.cuda.synchronize(); dt8 = (time.perf_counter() - t0) / steps
+        loss8 = float(out8["loss"])
+        assert loss8 == loss8, "non-finite diffusion loss in fp8 mode"
+        fp8 = {"ms_per_step": round(dt8 * 1e3, 2), "value": round(B * T / dt8, 1), "unit": "frames/s", "loss": round(loss8, 4),
+               "dtype": "f32 activations; the 1 x 1 convolutions / linear layers (qkv, proj_out, ResBlock input conv, integrating conv, "
+                        "timestep MLP: forward, data gradient and weight gradient) as e4m3 x e4m3 on v_mfma_f32_32x32x16_fp8_fp8 with "
+                        "per-tensor current scaling and fp32 accumulation; k = 3 convolutions split-bf16, attention GEMMs exact f32",
+               "parity": "tests/test_gpu_fp8.py: kernels within 2e-6 of the oracle's quantised arithmetic; step vs the reference "
+                         "fixture: loss within 5 %, model output within 20 % relative L2, gradient cosines >= 0.9"}
+    finally:
+        _aa.set_precision(prev_mode)
 
     def attn(t):      # qkv + proj 1x1 convs, QK^T and PV
         return 2 * t * C * 3 * C + 2 * t * C * C + 4 * t * t * C
@@ -325,7 +347,7 @@ def diffusion_leg(dev, steps, warmup, cpu_leg=True):
                         "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                         "note": "algorithmic FLOPs = 3 x forward (%.1f GFLOP per sample) / step time; peak = bf16 MFMA / 3 (an fp32 product "
                                 "costs three bf16 products)" % (fwd / 1e9)},
-           "loss": round(loss, 4), "grad_norm": round(float(out["grad_norm"]), 4)}
+           "loss": round(loss, 4), "grad_norm": round(float(out["grad_norm"]), 4), "fp8_gemms": fp8}
     if cpu_leg:
         res["cpu_baseline"] = diffusion_cpu_baseline()
     return res

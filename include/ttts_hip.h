@@ -689,6 +689,28 @@ int ttts_kl_loss_bwd_f32(const float* z_p, const float* logs_q, const float* m_p
  * out_tr i32 [64 lanes][8]: the uint16 LDS element indices two ds_read_b64_tr_b16 return for the kernels' address map. */
 int ttts_probe_mfma_layout(float* out_c, int32_t* out_tr, void* stream);
 
+/* ---- FP8 (OCP e4m3) matrix-core GEMMs (ABI v10; csrc/fp8_gemm.hip) ------------------------------------------------------------
+ * The 1 x 1 convolutions / linear layers of the diffusion mel-denoiser step in BASELINE config #5's arithmetic ("bf16 + fp8 MFMA
+ * GEMMs"): nn.Conv1d(k = 1) of AttentionBlock.qkv / .proj_out (ttts/utils/utils.py:172-215), ResBlock.in_layers[2]
+ * (ttts/diffusion/aa_model.py:70-131) and AA_diffusion.integrating_conv (:228), forward + data gradient + weight gradient.
+ * Per-TENSOR current scaling: amax = max |x| of the tensor being quantised (ttts_fp8_amax_f32, a device scalar), q = e4m3(x * 448 /
+ * amax) (round to nearest even, clamped to +-448; amax == 0: scale 1), products on v_mfma_f32_32x32x16_fp8_fp8, fp32 accumulation,
+ * result scaled by amax_a amax_b / 448^2 (read from device memory by the GEMM: no host round trip, capturable).
+ *  _quant:            q [rows][cols_pad] from x [rows][cols] (reduction axis already contiguous; zero padded)
+ *  _quant_transpose:  q [B][T][Cp] from x [B][C][T] (the reduction axis of a (B, C, T) activation made contiguous; zero padded)
+ *  _gemm_nt:          Y[go][m][n] (+)= alpha sum_{gi} sum_k A[go][gi][m][k] B[go][gi][n][k] (+ bias[m]) (+ resid[go][m][n]);
+ *                     K a multiple of 64, operands / pitches / group strides 16-byte aligned (strides in bytes = elements),
+ *                     Y / resid strides in elements: Y[go * y_stride_outer + m * y_stride_m + n * y_stride_n].
+ * Oracle: oracle/fp8_ref.py (same scales and rounding, fp32 matmul): results differ by summation order only. */
+int ttts_fp8_amax_f32(const float* x, int64_t n, float* amax_out, void* stream);
+int ttts_fp8_quant_f32(const float* x, void* q, const float* amax, int64_t rows, int32_t cols, int32_t cols_pad, void* stream);
+int ttts_fp8_quant_transpose_f32(const float* x, void* q, const float* amax, int32_t B, int32_t C, int32_t T, int32_t Cp, void* stream);
+int ttts_fp8_gemm_nt(const void* a, const void* b, float* y, const float* bias, const float* resid, const float* amax_a,
+                     const float* amax_b, int32_t M, int32_t N, int32_t K, int32_t groups_outer, int32_t groups_inner,
+                     int64_t lda, int64_t ldb, int64_t a_stride_outer, int64_t a_stride_inner, int64_t b_stride_outer,
+                     int64_t b_stride_inner, int64_t y_stride_outer, int64_t y_stride_m, int64_t y_stride_n,
+                     int32_t accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

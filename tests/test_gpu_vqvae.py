@@ -1063,8 +1063,14 @@ def test_recorded_wgrad_entries_are_frozen_until_released():
     dw.zero_(); graph.replay(); torch.cuda.synchronize()
     assert torch.equal(dw, ref_a), "the recorded graph no longer reproduces its gradient"
     arena.release_graphs()
+    fb1 = arena.stats()["fallbacks"]
     dw.zero_(); wgrad(xb, dyb); torch.cuda.synchronize()
-    assert torch.equal(dw, ref_b)
+    st2 = arena.stats()
+    assert st2["fallbacks"] == fb1, "after release_graphs() the entry must follow the new shape (no immediate reduce)"
+    if st["fallbacks"] > fb0:
+        assert st2["generation"] > gen0
+    # (the deferred and the immediate reduce add the split-K slabs in different orders: equal to rounding, not bit for bit)
+    assert float((dw - ref_b).abs().max()) <= 1e-5 * float(ref_b.abs().max())
     arena.close()
 
 

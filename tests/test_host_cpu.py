@@ -709,3 +709,31 @@ def test_bench_respawn_command_line(monkeypatch):
     assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
     assert cmd[-7].endswith("bench.py") and cmd[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_fp8_entry_points_validate_without_gpu_and_oracle_properties(lib):
+    """ttts_fp8_* argument validation runs before anything touches the device; the fp8 oracle's quantiser is the OCP e4m3 cast
+    (idempotent, saturating at 448, round-to-nearest-even, zero tensors), and its 1 x 1 convolution sits within e4m3's error of fp32."""
+    from oracle import fp8_ref as F8
+    l = lib.get()
+    buf = (ctypes.c_char * 4096)()
+    p = (ctypes.addressof(buf) + 15) // 16 * 16
+    assert l.ttts_fp8_gemm_nt(p, p, p, None, None, p, p, 64, 64, 96, 1, 1, 96, 96, 0, 0, 0, 0, 0, 64, 1, 0, None) == -1      # K % 64 != 0
+    assert b"multiple of 64" in l.ttts_last_error()
+    assert l.ttts_fp8_gemm_nt(None, p, p, None, None, p, p, 64, 64, 64, 1, 1, 64, 64, 0, 0, 0, 0, 0, 64, 1, 0, None) == -1
+    assert b"null pointer" in l.ttts_last_error()
+    assert l.ttts_fp8_gemm_nt(p, p, p, None, None, p, p, 64, 64, 64, 1, 1, 60, 64, 0, 0, 0, 0, 0, 64, 1, 0, None) == -1    # pitch not 16-aligned
+    assert l.ttts_fp8_quant_f32(p, p, p, 4, 30, 30, None) == -1 and b"multiple of 4" in l.ttts_last_error()
+    assert l.ttts_fp8_quant_transpose_f32(p, p, p, 1, 30, 8, 24, None) == -1
+    assert l.ttts_fp8_amax_f32(None, 8, p, None) == -1
+    x = torch.tensor([0.0, 1.0, -448.0, 17.0, 18.0, 19.0, 1e-9, 300.0])
+    q, a = F8.quant(x)
+    assert float(a) == 448.0 and torch.equal(q, F8.quant(q)[0])                      # idempotent on representable values
+    assert q.tolist()[:3] == [0.0, 1.0, -448.0] and q[3].item() == 16.0 and q[4].item() == 18.0 and q[5].item() == 20.0   # ties to even (step 2 at 16..32)
+    assert F8.quant(torch.zeros(5))[0].abs().sum() == 0 and F8.alpha(torch.tensor(0.0), torch.tensor(0.0)) == 1.0
+    g = torch.Generator().manual_seed(0)
+    xx, w = torch.randn(2, 256, 40, generator=g), torch.randn(96, 256, generator=g) / 16
+    ref = torch.einsum("oc,bct->bot", w, xx)
+    assert float((F8.conv1x1_fwd(xx, w) - ref).norm() / ref.norm()) < 6e-2
+    assert float((F8.conv1x1_dgrad(ref, w) - torch.einsum("oc,bot->bct", w, ref)).norm() / torch.einsum("oc,bot->bct", w, ref).norm()) < 6e-2
+    assert float((F8.conv1x1_wgrad(ref, xx) - torch.einsum("bot,bct->oc", ref, xx)).norm() / torch.einsum("bot,bct->oc", ref, xx).norm()) < 6e-2

@@ -11,6 +11,7 @@ The two random choices of the reference forward (`unconditioned_percentage` mask
 reference (`torch.rand` / `random.random`) and can be injected (`uncond=`, `drop_layers=`) for parity tests.
 """
 import math
+import os
 import random
 
 import torch
@@ -96,6 +97,110 @@ def normalization(channels):
     return GroupNorm32(groups, channels)
 
 
+# ---- precision of the 1 x 1 convolutions / linear layers ---------------------------------------------------------------------------
+# "f32" (default): fp32 on split-bf16 matrix-core products, as everywhere else on the path.  "fp8": BASELINE config #5's "fp8 MFMA
+# GEMMs" -- operands quantised per tensor to OCP e4m3 (current scaling), v_mfma_f32_32x32x16_fp8_fp8 with fp32 accumulation, for the
+# forward, the data gradient and the weight gradient (csrc/fp8_gemm.hip; oracle/fp8_ref.py).  Activations between the layers stay
+# fp32 (wider than the config's bf16).  Switch: set_precision() or TTTS_DIFFUSION_PRECISION.
+_PRECISION = {"mode": os.environ.get("TTTS_DIFFUSION_PRECISION", "f32")}
+
+
+def set_precision(mode):
+    if mode not in ("f32", "fp8"):
+        raise ValueError("diffusion precision must be 'f32' or 'fp8'")
+    prev = _PRECISION["mode"]
+    _PRECISION["mode"] = mode
+    return prev
+
+
+class _Conv1x1Fp8Fn(torch.autograd.Function):
+    """y = W x (+ bias) (+ resid) on the fp8 matrix cores; x (B, Cin, T), w (Cout, Cin, 1)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, resid):
+        x = x.contiguous()
+        y, ax = ops.conv1x1_fp8_fwd(x, w, bias, resid.contiguous() if resid is not None else None)
+        ctx.save_for_backward(x, w, ax)
+        ctx.refs = (w, bias)
+        ctx.has = (bias is not None, resid is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, ax = ctx.saved_tensors
+        dy = dy.contiguous()
+        need = ctx.needs_input_grad
+        dx = dw = db = None
+        ady = None
+        if need[0]:
+            dx, ady = ops.conv1x1_fp8_dgrad(dy, w)
+        if need[1]:
+            slot = _grad_slot(ctx.refs[0])
+            out = slot if slot is not None else torch.zeros_like(w)
+            ops.conv1x1_fp8_wgrad(dy, x, out, ady, ax)
+            dw = None if slot is not None else out
+        if ctx.has[0] and need[2]:
+            bslot = _grad_slot(ctx.refs[1])
+            db = ops.conv1d_bias_grad(dy, out=bslot)
+            if bslot is not None:
+                db = None
+        return dx, dw, db, (dy if ctx.has[1] and need[3] else None)
+
+
+class _LinearFp8Fn(torch.autograd.Function):
+    """y = x W^T + bias on the fp8 matrix cores; x (R, Cin), w (Cout, Cin)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        x = x.contiguous()
+        R, Cin = x.shape
+        Cout = w.shape[0]
+        ax, aw = ops.fp8_amax(x), ops.fp8_amax(w)
+        xq, wq = ops.fp8_quant(x, ax), ops.fp8_quant(w, aw)
+        y = torch.empty(R, Cout, dtype=torch.float32, device=x.device)
+        ops.fp8_gemm_nt(wq, xq, y, aw, ax, Cout, R, xq.shape[1], bias=bias, y_strides=(0, 1, Cout))
+        ctx.save_for_backward(x, w, ax, aw)
+        ctx.refs = (w, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, ax, aw = ctx.saved_tensors
+        dy = dy.contiguous()
+        R, Cin = x.shape
+        Cout = w.shape[0]
+        need = ctx.needs_input_grad
+        dx = dw = db = None
+        ady = ops.fp8_amax(dy)
+        if need[0]:
+            wtq = ops.fp8_quant_transpose(w.view(1, Cout, Cin), aw)[0]          # (Cin, Coutp)
+            dyq = ops.fp8_quant(dy, ady)                                        # (R, Coutp)
+            dx = torch.empty(R, Cin, dtype=torch.float32, device=x.device)
+            ops.fp8_gemm_nt(wtq, dyq, dx, aw, ady, Cin, R, dyq.shape[1], y_strides=(0, 1, Cin))
+        if need[1]:
+            slot = _grad_slot(ctx.refs[0])
+            out = slot if slot is not None else torch.zeros_like(w)
+            dytq = ops.fp8_quant_transpose(dy.view(1, R, Cout), ady)[0]         # (Cout, Rp)
+            xtq = ops.fp8_quant_transpose(x.view(1, R, Cin), ax)[0]             # (Cin, Rp)
+            ops.fp8_gemm_nt(dytq, xtq, out, ady, ax, Cout, Cin, dytq.shape[1], y_strides=(0, Cin, 1), accumulate=True)
+            dw = None if slot is not None else out
+        if need[2]:
+            bslot = _grad_slot(ctx.refs[1])
+            db = ops.conv1d_bias_grad(dy.t().contiguous().view(1, Cout, R), out=bslot)
+            if bslot is not None:
+                db = None
+        return dx, dw, db
+
+
+class Conv1x1(Conv1d):
+    """A Conv1d of kernel size 1 that follows the diffusion precision switch (same parameters / state-dict keys as Conv1d)."""
+
+    def forward(self, x, resid=None, **kw):
+        if _PRECISION["mode"] == "fp8" and self.kernel_size == 1 and not kw:
+            return _Conv1x1Fp8Fn.apply(x, self.weight, self.bias, resid)
+        return super().forward(x, resid=resid, **kw)
+
+
 class Linear(nn.Module):
     """nn.Linear (2-D weight, default init) evaluated as a 1x1 convolution over a length-1 signal."""
 
@@ -107,6 +212,8 @@ class Linear(nn.Module):
 
     def forward(self, x):
         from ..vqvae.modules import _Conv1dFn
+        if _PRECISION["mode"] == "fp8":
+            return _LinearFp8Fn.apply(x.reshape(-1, self.in_features), self.weight, self.bias).reshape(*x.shape[:-1], self.out_features)
         y = _Conv1dFn.apply(x.reshape(-1, self.in_features, 1), self.weight.unsqueeze(-1), self.bias, None, None, 1, 0, 1, 1.0, None)
         return y.reshape(*x.shape[:-1], self.out_features)
 
@@ -188,8 +295,8 @@ class AttentionBlock(nn.Module):
         self.channels = channels
         self.num_heads = num_heads if num_head_channels == -1 else channels // num_head_channels
         self.norm = normalization(channels)
-        self.qkv = Conv1d(channels, channels * 3, 1)
-        self.proj_out = Conv1d(channels, channels, 1)
+        self.qkv = Conv1x1(channels, channels * 3, 1)
+        self.proj_out = Conv1x1(channels, channels, 1)
         with torch.no_grad():                                           # zero_module (utils.py:104-110)
             self.proj_out.weight.zero_(); self.proj_out.bias.zero_()
         self.relative_pos_embeddings = RelativePositionBias(scale=(channels // self.num_heads) ** .5, causal=False, heads=num_heads,
@@ -292,12 +399,12 @@ class ResBlock(TimestepBlock):
         padding = {1: 0, 3: 1, 5: 2}[kernel_size]
         eff_kernel, eff_padding = (1, 0) if efficient_config else (3, 1)
         self.in_layers = _Seq(**{"0": normalization(channels), "1": SiLU(),
-                                 "2": Conv1d(channels, self.out_channels, eff_kernel, padding=eff_padding)})
+                                 "2": (Conv1x1 if eff_kernel == 1 else Conv1d)(channels, self.out_channels, eff_kernel, padding=eff_padding)})
         self.emb_layers = _Seq(**{"0": SiLU(), "1": Linear(emb_channels, 2 * self.out_channels if use_scale_shift_norm else self.out_channels)})
         self.out_layers = _Seq(**{"0": normalization(self.out_channels), "1": SiLU(), "2": nn.Identity(),
                                   "3": Conv1d(self.out_channels, self.out_channels, kernel_size, padding=padding)})
-        self.skip_connection = nn.Identity() if self.out_channels == channels else Conv1d(channels, self.out_channels, eff_kernel,
-                                                                                         padding=eff_padding)
+        self.skip_connection = nn.Identity() if self.out_channels == channels else (Conv1x1 if eff_kernel == 1 else Conv1d)(
+            channels, self.out_channels, eff_kernel, padding=eff_padding)
 
     def forward(self, x, emb):
         h = self.in_layers[2](self.in_layers[0](x, silu=True))
@@ -403,7 +510,7 @@ class AA_diffusion(nn.Module):
         self.unconditioned_embedding = nn.Parameter(torch.randn(1, C, 1))
         self.conditioning_timestep_integrator = _Seq(**{str(i): DiffusionLayer(C, dropout, H) for i in range(3)})
         self.refer_enc = _Seq(**{"0": Conv1d(in_channels, C, 3, padding=1), "1": ab(), "2": ab(), "3": ab(), "4": RefEncoder(C, C)})
-        self.integrating_conv = Conv1d(C * 2, C, kernel_size=1)
+        self.integrating_conv = Conv1x1(C * 2, C, kernel_size=1)
         self.layers = nn.ModuleList([DiffusionLayer(C, dropout, H) for _ in range(num_layers)] +
                                     [ResBlock(C, C, dropout, dims=1, use_scale_shift_norm=True) for _ in range(3)])
         self.out = _Seq(**{"0": normalization(C), "1": SiLU(), "2": Conv1d(C, out_channels, 3, padding=1)})

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(CSRC, "build")
 SO_PATH = os.environ.get("TTTS_LIB") or os.path.join(HERE, "libttts_hip.so")   # TTTS_LIB: an alternate build of the same ABI (same-box A/B runs: tools/gpu_ab_lib.sh)
-SOURCES = ["lib.hip", "elementwise.hip", "gemm.hip", "attn.hip", "attn_dh64.hip", "vq.hip", "stft.hip", "conv.hip", "conv_mfma.hip", "conv_thin.hip", "conv_grouped.hip", "losses.hip", "vqvae_ops.hip", "attn_f32.hip", "attn_cross.hip", "peq.hip", "decode.hip", "diffusion_ops.hip"]
+SOURCES = ["lib.hip", "elementwise.hip", "gemm.hip", "attn.hip", "attn_dh64.hip", "vq.hip", "stft.hip", "conv.hip", "conv_mfma.hip", "conv_thin.hip", "conv_grouped.hip", "losses.hip", "vqvae_ops.hip", "attn_f32.hip", "attn_cross.hip", "peq.hip", "decode.hip", "diffusion_ops.hip", "fp8_gemm.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-Wall", "-Wno-unused-variable"]
 
@@ -252,6 +252,11 @@ SIGNATURES = {
     "ttts_kl_loss_fwd_f32": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P]),
     "ttts_kl_loss_bwd_f32": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
     "ttts_probe_mfma_layout": (_I32, [_P, _P, _P]),
+    "ttts_fp8_amax_f32": (_I32, [_P, _I64, _P, _P]),
+    "ttts_fp8_quant_f32": (_I32, [_P, _P, _P, _I64, _I32, _I32, _P]),
+    "ttts_fp8_quant_transpose_f32": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "ttts_fp8_gemm_nt": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _I64, _I64, _I64,
+                                _I64, _I64, _I32, _P]),
 }
 
 _lib = None

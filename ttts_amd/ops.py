@@ -1362,3 +1362,96 @@ def probe_layout(device):
     tr = torch.empty(64, 8, dtype=torch.int32, device=device)
     check(_l.get().ttts_probe_mfma_layout(_p(c), _p(tr), _stream()), "probe")
     return c, tr
+
+
+# ---- FP8 (e4m3) matrix-core GEMMs: the 1 x 1 convolutions of the diffusion step in config #5's arithmetic (csrc/fp8_gemm.hip) ----
+def _pad_to(n, m):
+    return (n + m - 1) // m * m
+
+
+def fp8_amax(x, out=None):
+    """max |x| of the whole tensor as a device scalar (no host read-back)."""
+    _req(x, torch.float32, "x")
+    out = torch.empty(1, dtype=torch.float32, device=x.device) if out is None else out
+    check(_l.get().ttts_fp8_amax_f32(_p(x), x.numel(), _p(out), _stream()), "fp8_amax")
+    return out
+
+
+def fp8_quant(x2d, amax, cols_pad=None):
+    """x (rows, cols) fp32, reduction axis contiguous -> uint8 (rows, cols_pad) of e4m3 codes, zero padded to a multiple of 64."""
+    _req(x2d, torch.float32, "x")
+    rows, cols = x2d.shape
+    cols_pad = _pad_to(cols, 64) if cols_pad is None else cols_pad
+    q = torch.empty(rows, cols_pad, dtype=torch.uint8, device=x2d.device)
+    check(_l.get().ttts_fp8_quant_f32(_p(x2d), _p(q), _p(amax), rows, cols, cols_pad, _stream()), "fp8_quant")
+    return q
+
+
+def fp8_quant_transpose(x, amax):
+    """x (B, C, T) fp32 -> uint8 (B, T, Cp): the channel (reduction) axis made contiguous, zero padded to a multiple of 64."""
+    _req(x, torch.float32, "x")
+    B, C, T = x.shape
+    Cp = _pad_to(C, 64)
+    q = torch.empty(B, T, Cp, dtype=torch.uint8, device=x.device)
+    check(_l.get().ttts_fp8_quant_transpose_f32(_p(x), _p(q), _p(amax), B, C, T, Cp, _stream()), "fp8_quant_transpose")
+    return q
+
+
+def fp8_gemm_nt(a, b, y, amax_a, amax_b, M, N, K, bias=None, resid=None, groups_outer=1, groups_inner=1, lda=None, ldb=None,
+                a_strides=(0, 0), b_strides=(0, 0), y_strides=(0, None, 1), accumulate=False):
+    """Y[go][m][n] (+)= alpha sum_gi sum_k A[go][gi][m][k] B[go][gi][n][k] (+ bias[m]) (+ resid) on the fp8 matrix cores
+    (include/ttts_hip.h: ttts_fp8_gemm_nt); a / b uint8 e4m3 codes, y fp32."""
+    _req(y, torch.float32, "y")
+    ysm = N if y_strides[1] is None else y_strides[1]
+    check(_l.get().ttts_fp8_gemm_nt(_p(a), _p(b), _p(y), _p(bias), _p(resid), _p(amax_a), _p(amax_b), M, N, K, groups_outer,
+                                    groups_inner, K if lda is None else lda, K if ldb is None else ldb, a_strides[0], a_strides[1],
+                                    b_strides[0], b_strides[1], y_strides[0], ysm, y_strides[2], int(accumulate), _stream()),
+          "fp8_gemm_nt")
+    return y
+
+
+def conv1x1_fp8_fwd(x, w, bias=None, resid=None, wq=None):
+    """y[b] = W x[b] (+ bias) (+ resid) with both operands in e4m3 (per-tensor current scaling).  x (B, Cin, T), w (Cout, Cin[, 1]).
+    Returns (y, amax_x): the activation's amax is reused by the backward's weight gradient."""
+    B, Cin, T = x.shape
+    Cout = w.shape[0]
+    w2 = w.reshape(Cout, Cin)
+    ax = fp8_amax(x)
+    xq = fp8_quant_transpose(x, ax)                              # (B, T, Kp)
+    if wq is None:
+        aw = fp8_amax(w2)
+        wq = (fp8_quant(w2, aw), aw)
+    Kp = xq.shape[2]
+    y = torch.empty(B, Cout, T, dtype=torch.float32, device=x.device)
+    fp8_gemm_nt(wq[0], xq, y, wq[1], ax, Cout, T, Kp, bias=bias, resid=resid, groups_outer=B, b_strides=(T * Kp, 0),
+                y_strides=(Cout * T, T, 1))
+    return y, ax
+
+
+def conv1x1_fp8_dgrad(dy, w):
+    """dx[b] = W^T dy[b] in e4m3; dy (B, Cout, T), w (Cout, Cin[, 1]).  Returns (dx, amax_dy)."""
+    B, Cout, T = dy.shape
+    Cin = w.shape[1]
+    w3 = w.reshape(1, Cout, Cin)
+    ady = fp8_amax(dy)
+    dyq = fp8_quant_transpose(dy, ady)                           # (B, T, Coutp)
+    aw = fp8_amax(w3)
+    wtq = fp8_quant_transpose(w3, aw)[0]                         # (Cin, Coutp)
+    Kp = dyq.shape[2]
+    dx = torch.empty(B, Cin, T, dtype=torch.float32, device=dy.device)
+    fp8_gemm_nt(wtq, dyq, dx, aw, ady, Cin, T, Kp, groups_outer=B, b_strides=(T * Kp, 0), y_strides=(Cin * T, T, 1))
+    return dx, ady
+
+
+def conv1x1_fp8_wgrad(dy, x, out, amax_dy=None, amax_x=None):
+    """out (Cout, Cin[, 1]) += sum_b dy[b] x[b]^T in e4m3 (the time axis is the reduction axis: no transpose needed)."""
+    B, Cout, T = dy.shape
+    Cin = x.shape[1]
+    ady = fp8_amax(dy) if amax_dy is None else amax_dy
+    ax = fp8_amax(x) if amax_x is None else amax_x
+    dyq = fp8_quant(dy.reshape(B * Cout, T), ady)                # (B Cout, Tp)
+    xq = fp8_quant(x.reshape(B * Cin, T), ax)                    # (B Cin, Tp)
+    Tp = dyq.shape[1]
+    fp8_gemm_nt(dyq, xq, out, ady, ax, Cout, Cin, Tp, groups_inner=B, a_strides=(0, Cout * Tp), b_strides=(0, Cin * Tp),
+                y_strides=(0, Cin, 1), accumulate=True)
+    return out
