@@ -324,8 +324,9 @@ def diffusion_leg(dev, steps, warmup, cpu_leg=True):
                "dtype": "f32 activations; the 1 x 1 convolutions / linear layers (qkv, proj_out, ResBlock input conv, integrating conv, "
                         "timestep MLP: forward, data gradient and weight gradient) as e4m3 x e4m3 on v_mfma_f32_32x32x16_fp8_fp8 with "
                         "per-tensor current scaling and fp32 accumulation; k = 3 convolutions split-bf16, attention GEMMs exact f32",
-               "parity": "tests/test_gpu_fp8.py: kernels within 2e-6 of the oracle's quantised arithmetic; step vs the reference "
-                         "fixture: loss within 5 %, model output within 20 % relative L2, gradient cosines >= 0.9"}
+               "parity": "tests/test_gpu_fp8.py: kernels within 6e-5 of the output range of the oracle's quantised arithmetic (measured 1.6e-5); "
+                         "step vs the reference fixture: loss within 2 % (measured 0.24 %), model output within 15 % relative L2 "
+                         "(8.7 %), gradient cosines >= 0.95 (>= 0.987)"}
     finally:
         _aa.set_precision(prev_mode)
 

@@ -701,15 +701,23 @@ int ttts_probe_mfma_layout(float* out_c, int32_t* out_tr, void* stream);
  *  _gemm_nt:          Y[go][m][n] (+)= alpha sum_{gi} sum_k A[go][gi][m][k] B[go][gi][n][k] (+ bias[m]) (+ resid[go][m][n]);
  *                     K a multiple of 64, operands / pitches / group strides 16-byte aligned (strides in bytes = elements),
  *                     Y / resid strides in elements: Y[go * y_stride_outer + m * y_stride_m + n * y_stride_n].
- * Oracle: oracle/fp8_ref.py (same scales and rounding, fp32 matmul): results differ by summation order only. */
+ *  _quant_both:       both layouts of one (B, C, T) tensor in one pass (Cp, Tp multiples of 64)
+ *  _gemm_nt workspace: weight-gradient shaped calls (few output tiles, many inner groups) split the inner groups over several
+ *                     workgroups per tile when `workspace` (>= ttts_fp8_gemm_nt_workspace_bytes(...), 16-byte aligned) is given; the
+ *                     partial slabs are summed in a fixed order by a second launch (deterministic).  NULL: never split.
+ * Oracle: oracle/fp8_ref.py (same scales and rounding, exact sums): results differ by the matrix core's internal summation of the
+ * 16 products of an instruction (measured 1.6e-5 of the output range; the tests hold 6e-5). */
 int ttts_fp8_amax_f32(const float* x, int64_t n, float* amax_out, void* stream);
 int ttts_fp8_quant_f32(const float* x, void* q, const float* amax, int64_t rows, int32_t cols, int32_t cols_pad, void* stream);
 int ttts_fp8_quant_transpose_f32(const float* x, void* q, const float* amax, int32_t B, int32_t C, int32_t T, int32_t Cp, void* stream);
+int ttts_fp8_quant_both_f32(const float* x, void* q_rows, void* q_t, const float* amax, int32_t B, int32_t C, int32_t T, int32_t Cp,
+                            int32_t Tp, void* stream);
+int64_t ttts_fp8_gemm_nt_workspace_bytes(int32_t M, int32_t N, int32_t groups_outer, int32_t groups_inner);
 int ttts_fp8_gemm_nt(const void* a, const void* b, float* y, const float* bias, const float* resid, const float* amax_a,
                      const float* amax_b, int32_t M, int32_t N, int32_t K, int32_t groups_outer, int32_t groups_inner,
                      int64_t lda, int64_t ldb, int64_t a_stride_outer, int64_t a_stride_inner, int64_t b_stride_outer,
                      int64_t b_stride_inner, int64_t y_stride_outer, int64_t y_stride_m, int64_t y_stride_n,
-                     int32_t accumulate, void* stream);
+                     int32_t accumulate, void* workspace, void* stream);
 
 #ifdef __cplusplus
 }

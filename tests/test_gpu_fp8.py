@@ -53,32 +53,37 @@ def test_amax_and_quantisers_match_the_oracle(shape):
 
 
 @pytest.mark.parametrize("case", [(2, 64, 64, 37), (3, 512, 1536, 432), (16, 1024, 512, 400), (1, 192, 100, 1), (2, 100, 200, 129),
-                                  (5, 512, 512, 128)])
+                                  (5, 512, 512, 128), (16, 512, 512, 432)])
 def test_conv1x1_fp8_forward_and_gradients_match_the_oracle(case):
-    """forward, data gradient, weight gradient of a 1 x 1 convolution on the fp8 matrix cores: within 2e-6 of the output range of
-    the oracle (identical quantised operands, exact products: only the fp32 summation order differs), and within e4m3's own error
-    of the fp32 convolution (relative L2 <= 6e-2: 3 mantissa bits on both operands)."""
+    """forward, data gradient, weight gradient of a 1 x 1 convolution on the fp8 matrix cores: within 6e-5 of the output range of
+    the oracle (identical quantised operands and exact products; the matrix core sums the 16 products of an instruction in its own
+    internal format rather than as an fp32 chain: measured 1.6e-5), and within e4m3's own error of the fp32 convolution (relative
+    L2 <= 6e-2: 3 mantissa bits on both operands).  Covers both tile shapes, ragged M / N edges, padded reduction axes and the
+    split (slab + ordered reduce) weight gradient."""
     from ttts_amd import ops
     B, Cin, Cout, T = case
     g = torch.Generator().manual_seed(Cin + T)
     x = torch.randn(B, Cin, T, generator=g); w = torch.randn(Cout, Cin, 1, generator=g) / Cin ** 0.5
     bias = torch.randn(Cout, generator=g); resid = torch.randn(B, Cout, T, generator=g); dy = torch.randn(B, Cout, T, generator=g)
     dev = _dev()
-    y, ax = ops.conv1x1_fp8_fwd(x.to(dev), w.to(dev), bias.to(dev), resid.to(dev))
+    y, xq, wq = ops.conv1x1_fp8_fwd(x.to(dev), w.to(dev), bias.to(dev), resid.to(dev))
     want = F8.conv1x1_fwd(x, w, bias, resid)
-    assert float((y.cpu() - want).abs().max()) <= 2e-6 * float(want.abs().max()) + 1e-6
+    assert float((y.cpu() - want).abs().max()) <= 6e-5 * float(want.abs().max()) + 1e-6
     full = torch.einsum("oc,bct->bot", w[:, :, 0].double(), x.double()).float() + bias.view(1, -1, 1) + resid
     assert _rel(y, full) <= 6e-2
-    dx, ady = ops.conv1x1_fp8_dgrad(dy.to(dev), w.to(dev))
-    want = F8.conv1x1_dgrad(dy, w)
-    assert float((dx.cpu() - want).abs().max()) <= 2e-6 * float(want.abs().max()) + 1e-6
-    assert _rel(dx, torch.einsum("oc,bot->bct", w[:, :, 0].double(), dy.double())) <= 6e-2
     acc0 = torch.randn(Cout, Cin, 1, generator=g)
     dw = acc0.clone().to(dev)
-    ops.conv1x1_fp8_wgrad(dy.to(dev), x.to(dev), dw, ady, ax)                  # accumulates
+    dx = ops.conv1x1_fp8_bwd(dy.to(dev), xq, wq, Cin, need_dx=True, dw_out=dw)                      # dw accumulates
+    want = F8.conv1x1_dgrad(dy, w)
+    assert float((dx.cpu() - want).abs().max()) <= 6e-5 * float(want.abs().max()) + 1e-6
+    assert _rel(dx, torch.einsum("oc,bot->bct", w[:, :, 0].double(), dy.double())) <= 6e-2
     want = F8.conv1x1_wgrad(dy, x)
-    assert float((dw.cpu()[:, :, 0] - acc0[:, :, 0] - want).abs().max()) <= 4e-6 * float(want.abs().max()) + 1e-5
+    assert float((dw.cpu()[:, :, 0] - acc0[:, :, 0] - want).abs().max()) <= 1e-4 * float(want.abs().max()) + 1e-5
     assert _rel(dw.cpu()[:, :, 0] - acc0[:, :, 0], torch.einsum("bot,bct->oc", dy.double(), x.double())) <= 6e-2
+    # the weight gradient is bitwise reproducible (ordered slab reduction, no atomics)
+    dw2 = acc0.clone().to(dev)
+    ops.conv1x1_fp8_bwd(dy.to(dev), xq, wq, Cin, need_dx=False, dw_out=dw2)
+    assert torch.equal(dw, dw2)
 
 
 def test_fp8_modules_autograd_matches_the_oracle():
@@ -97,12 +102,12 @@ def test_fp8_modules_autograd_matches_the_oracle():
         y.backward(gy)
         w = conv.weight.detach().cpu(); b = conv.bias.detach().cpu()
         wy = F8.conv1x1_fwd(x.detach().cpu(), w, b, r.detach().cpu())
-        assert float((y.detach().cpu() - wy).abs().max()) <= 2e-6 * float(wy.abs().max()) + 1e-6
+        assert float((y.detach().cpu() - wy).abs().max()) <= 6e-5 * float(wy.abs().max()) + 1e-6
         assert torch.equal(r.grad, gy)
         wdx = F8.conv1x1_dgrad(gy.cpu(), w)
-        assert float((x.grad.cpu() - wdx).abs().max()) <= 2e-6 * float(wdx.abs().max()) + 1e-6
+        assert float((x.grad.cpu() - wdx).abs().max()) <= 6e-5 * float(wdx.abs().max()) + 1e-6
         wdw = F8.conv1x1_wgrad(gy.cpu(), x.detach().cpu())
-        assert float((conv.weight.grad.cpu()[:, :, 0] - wdw).abs().max()) <= 4e-6 * float(wdw.abs().max()) + 1e-5
+        assert float((conv.weight.grad.cpu()[:, :, 0] - wdw).abs().max()) <= 1e-4 * float(wdw.abs().max()) + 1e-5
         assert _rel(conv.bias.grad, gy.sum((0, 2))) <= 1e-5
         lin = A.Linear(64, 96).to(dev)
         xl = torch.randn(16, 64, generator=g).to(dev).requires_grad_(True); gl = torch.randn(16, 96, generator=g).to(dev)
@@ -110,7 +115,7 @@ def test_fp8_modules_autograd_matches_the_oracle():
         yl.backward(gl)
         wl = lin.weight.detach().cpu()
         ref = F8.conv1x1_fwd(xl.detach().cpu().t().unsqueeze(0), wl, lin.bias.detach().cpu())[0].t()
-        assert float((yl.detach().cpu() - ref).abs().max()) <= 2e-6 * float(ref.abs().max()) + 1e-6
+        assert float((yl.detach().cpu() - ref).abs().max()) <= 6e-5 * float(ref.abs().max()) + 1e-6
         assert _rel(xl.grad, gl.cpu().double() @ wl.double()) <= 6e-2
         assert _rel(lin.weight.grad, gl.cpu().double().t() @ xl.detach().cpu().double()) <= 6e-2
         assert _rel(lin.bias.grad, gl.sum(0)) <= 1e-5
@@ -121,10 +126,10 @@ def test_fp8_modules_autograd_matches_the_oracle():
 def test_diffusion_step_in_fp8_mode_against_the_reference_fixture():
     """The diffusion train step with every 1 x 1 convolution / linear layer on the fp8 matrix cores (BASELINE config #5's GEMM
     arithmetic) against the reference-generated fixture (fp32 reference).  Stated tolerance, e4m3 on both GEMM operands (2^-4
-    relative per element, independent errors): loss within 5 %, model output within 20 % relative L2 (the fixture's
-    deterministic fills give activations with a wide spread, i.e. the worst case for per-tensor scaling), sampled parameter
-    gradients at cosine >= 0.9 with the reference's; three optimizer steps stay finite and the loss sequence follows the
-    reference's within 10 %."""
+    relative per element, independent errors): loss within 2 % (measured 0.24 %), model output within 15 % relative L2 (measured
+    8.7 %: the fixture's deterministic fills give activations with a wide spread, the worst case for per-tensor scaling), sampled
+    parameter gradients at cosine >= 0.95 with the reference's (measured >= 0.987); the loss sequence of three optimizer steps
+    follows the reference's within 2 % (measured 0.25 %)."""
     from ttts_amd.diffusion import AA_diffusion, SpacedDiffusion, get_named_beta_schedule, space_timesteps
     from ttts_amd.diffusion import aa_model as A
     from ttts_amd.diffusion.train import DiffusionTrainer
@@ -153,8 +158,8 @@ def test_diffusion_step_in_fp8_mode_against_the_reference_fixture():
             a, b = ps[k].grad.detach().cpu().double().flatten(), T(gold["grad:" + k]).double().flatten()
             cos[k] = float(a @ b / (a.norm() * b.norm()).clamp_min(1e-300))
         print("fp8 diffusion: loss rel %.3e, model_out rel L2 %.3e, grad cosines %s" % (rel_loss, rel_out, {k: round(v, 4) for k, v in cos.items()}))
-        assert rel_loss <= 5e-2 and rel_out <= 0.2, (rel_loss, rel_out)
-        assert min(cos.values()) >= 0.9, cos
+        assert rel_loss <= 2e-2 and rel_out <= 0.15, (rel_loss, rel_out)
+        assert min(cos.values()) >= 0.95, cos
         tr = DiffusionTrainer({"train": {"lr": 1e-4, "timesteps": 1000}, "aa_diffusion": cfg}, device=dev)
         with torch.no_grad():
             for k, p in tr.diffusion.named_parameters():
@@ -165,6 +170,6 @@ def test_diffusion_step_in_fp8_mode_against_the_reference_fixture():
             o = tr.train_step(D("x_start"), D("refer"), D("latent"), t=D("t"), noise=D("noise"), normalized=True)
             losses.append(float(o["loss"]))
         print("fp8 diffusion: step losses", losses, "reference", gold["step_losses"].tolist())
-        np.testing.assert_allclose(losses, gold["step_losses"], rtol=1e-1)
+        np.testing.assert_allclose(losses, gold["step_losses"], rtol=2e-2)
     finally:
         A.set_precision(prev)

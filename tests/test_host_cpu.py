@@ -718,14 +718,17 @@ def test_fp8_entry_points_validate_without_gpu_and_oracle_properties(lib):
     l = lib.get()
     buf = (ctypes.c_char * 4096)()
     p = (ctypes.addressof(buf) + 15) // 16 * 16
-    assert l.ttts_fp8_gemm_nt(p, p, p, None, None, p, p, 64, 64, 96, 1, 1, 96, 96, 0, 0, 0, 0, 0, 64, 1, 0, None) == -1      # K % 64 != 0
+    assert l.ttts_fp8_gemm_nt(p, p, p, None, None, p, p, 64, 64, 96, 1, 1, 96, 96, 0, 0, 0, 0, 0, 64, 1, 0, None, None) == -1      # K % 64 != 0
     assert b"multiple of 64" in l.ttts_last_error()
-    assert l.ttts_fp8_gemm_nt(None, p, p, None, None, p, p, 64, 64, 64, 1, 1, 64, 64, 0, 0, 0, 0, 0, 64, 1, 0, None) == -1
+    assert l.ttts_fp8_gemm_nt(None, p, p, None, None, p, p, 64, 64, 64, 1, 1, 64, 64, 0, 0, 0, 0, 0, 64, 1, 0, None, None) == -1
     assert b"null pointer" in l.ttts_last_error()
-    assert l.ttts_fp8_gemm_nt(p, p, p, None, None, p, p, 64, 64, 64, 1, 1, 60, 64, 0, 0, 0, 0, 0, 64, 1, 0, None) == -1    # pitch not 16-aligned
+    assert l.ttts_fp8_gemm_nt(p, p, p, None, None, p, p, 64, 64, 64, 1, 1, 60, 64, 0, 0, 0, 0, 0, 64, 1, 0, None, None) == -1    # pitch not 16-aligned
     assert l.ttts_fp8_quant_f32(p, p, p, 4, 30, 30, None) == -1 and b"multiple of 4" in l.ttts_last_error()
     assert l.ttts_fp8_quant_transpose_f32(p, p, p, 1, 30, 8, 24, None) == -1
     assert l.ttts_fp8_amax_f32(None, 8, p, None) == -1
+    assert l.ttts_fp8_quant_both_f32(p, p, p, p, 1, 30, 8, 60, 64, None) == -1 and b"multiples of 64" in l.ttts_last_error()
+    # weight-gradient shapes split their inner groups (slabs + ordered reduce); output-rich shapes never do
+    assert l.ttts_fp8_gemm_nt_workspace_bytes(512, 512, 1, 16) == 16 * 512 * 512 * 4 and l.ttts_fp8_gemm_nt_workspace_bytes(1536, 432, 16, 1) == 0
     x = torch.tensor([0.0, 1.0, -448.0, 17.0, 18.0, 19.0, 1e-9, 300.0])
     q, a = F8.quant(x)
     assert float(a) == 448.0 and torch.equal(q, F8.quant(q)[0])                      # idempotent on representable values

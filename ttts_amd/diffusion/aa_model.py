@@ -114,31 +114,32 @@ def set_precision(mode):
 
 
 class _Conv1x1Fp8Fn(torch.autograd.Function):
-    """y = W x (+ bias) (+ resid) on the fp8 matrix cores; x (B, Cin, T), w (Cout, Cin, 1)."""
+    """y = W x (+ bias) (+ resid) on the fp8 matrix cores; x (B, Cin, T), w (Cout, Cin, 1).  The backward works from the forward's
+    e4m3 codes (the activation row-wise, the weight in both layouts): nothing is measured or quantised twice."""
 
     @staticmethod
     def forward(ctx, x, w, bias, resid):
         x = x.contiguous()
-        y, ax = ops.conv1x1_fp8_fwd(x, w, bias, resid.contiguous() if resid is not None else None)
-        ctx.save_for_backward(x, w, ax)
+        y, xq, wq = ops.conv1x1_fp8_fwd(x, w, bias, resid.contiguous() if resid is not None else None)
+        ctx.saved = (xq, wq)
+        ctx.cin = x.shape[1]
         ctx.refs = (w, bias)
         ctx.has = (bias is not None, resid is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, ax = ctx.saved_tensors
+        xq, wq = ctx.saved
+        ctx.saved = None
         dy = dy.contiguous()
         need = ctx.needs_input_grad
-        dx = dw = db = None
-        ady = None
-        if need[0]:
-            dx, ady = ops.conv1x1_fp8_dgrad(dy, w)
+        dw = db = None
+        out = None
         if need[1]:
             slot = _grad_slot(ctx.refs[0])
-            out = slot if slot is not None else torch.zeros_like(w)
-            ops.conv1x1_fp8_wgrad(dy, x, out, ady, ax)
+            out = slot if slot is not None else torch.zeros_like(ctx.refs[0])
             dw = None if slot is not None else out
+        dx = ops.conv1x1_fp8_bwd(dy, xq, wq, ctx.cin, need_dx=need[0], dw_out=out)
         if ctx.has[0] and need[2]:
             bslot = _grad_slot(ctx.refs[1])
             db = ops.conv1d_bias_grad(dy, out=bslot)

@@ -255,8 +255,10 @@ SIGNATURES = {
     "ttts_fp8_amax_f32": (_I32, [_P, _I64, _P, _P]),
     "ttts_fp8_quant_f32": (_I32, [_P, _P, _P, _I64, _I32, _I32, _P]),
     "ttts_fp8_quant_transpose_f32": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "ttts_fp8_quant_both_f32": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
+    "ttts_fp8_gemm_nt_workspace_bytes": (_I64, [_I32, _I32, _I32, _I32]),
     "ttts_fp8_gemm_nt": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _I64, _I64, _I64,
-                                _I64, _I64, _I32, _P]),
+                                _I64, _I64, _I32, _P, _P]),
 }
 
 _lib = None

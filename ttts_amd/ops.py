@@ -1397,61 +1397,72 @@ def fp8_quant_transpose(x, amax):
     return q
 
 
+def fp8_quant_both(x, amax):
+    """x (B, C, T) fp32 -> (rows uint8 (B, C, Tp), transposed uint8 (B, T, Cp)) in one pass; Cp, Tp multiples of 64."""
+    _req(x, torch.float32, "x")
+    B, C, T = x.shape
+    Cp, Tp = _pad_to(C, 64), _pad_to(T, 64)
+    qr = torch.empty(B, C, Tp, dtype=torch.uint8, device=x.device)
+    qt = torch.empty(B, T, Cp, dtype=torch.uint8, device=x.device)
+    check(_l.get().ttts_fp8_quant_both_f32(_p(x), _p(qr), _p(qt), _p(amax), B, C, T, Cp, Tp, _stream()), "fp8_quant_both")
+    return qr, qt
+
+
 def fp8_gemm_nt(a, b, y, amax_a, amax_b, M, N, K, bias=None, resid=None, groups_outer=1, groups_inner=1, lda=None, ldb=None,
                 a_strides=(0, 0), b_strides=(0, 0), y_strides=(0, None, 1), accumulate=False):
     """Y[go][m][n] (+)= alpha sum_gi sum_k A[go][gi][m][k] B[go][gi][n][k] (+ bias[m]) (+ resid) on the fp8 matrix cores
     (include/ttts_hip.h: ttts_fp8_gemm_nt); a / b uint8 e4m3 codes, y fp32."""
     _req(y, torch.float32, "y")
     ysm = N if y_strides[1] is None else y_strides[1]
+    wsb = _l.get().ttts_fp8_gemm_nt_workspace_bytes(M, N, groups_outer, groups_inner)
+    ws = torch.empty(wsb // 4, dtype=torch.float32, device=y.device) if wsb > 0 else None
     check(_l.get().ttts_fp8_gemm_nt(_p(a), _p(b), _p(y), _p(bias), _p(resid), _p(amax_a), _p(amax_b), M, N, K, groups_outer,
                                     groups_inner, K if lda is None else lda, K if ldb is None else ldb, a_strides[0], a_strides[1],
-                                    b_strides[0], b_strides[1], y_strides[0], ysm, y_strides[2], int(accumulate), _stream()),
+                                    b_strides[0], b_strides[1], y_strides[0], ysm, y_strides[2], int(accumulate), _p(ws), _stream()),
           "fp8_gemm_nt")
     return y
 
 
+class Fp8Weight:
+    """Both e4m3 layouts of a 1 x 1 convolution weight (Cout, Cin[, 1]) under ONE amax: `q` (Cout, Cinp) for the forward,
+    `qt` (Cin, Coutp) for the data gradient."""
+
+    def __init__(self, w):
+        Cout, Cin = w.shape[0], w.shape[1]
+        self.amax = fp8_amax(w)
+        self.q, qt = fp8_quant_both(w.reshape(1, Cout, Cin), self.amax)
+        self.q, self.qt = self.q[0], qt[0]
+
+
 def conv1x1_fp8_fwd(x, w, bias=None, resid=None, wq=None):
     """y[b] = W x[b] (+ bias) (+ resid) with both operands in e4m3 (per-tensor current scaling).  x (B, Cin, T), w (Cout, Cin[, 1]).
-    Returns (y, amax_x): the activation's amax is reused by the backward's weight gradient."""
+    Returns (y, (x rows-layout codes, amax_x), Fp8Weight): what the backward needs -- 1 byte per activation element instead of 4."""
     B, Cin, T = x.shape
     Cout = w.shape[0]
-    w2 = w.reshape(Cout, Cin)
     ax = fp8_amax(x)
-    xq = fp8_quant_transpose(x, ax)                              # (B, T, Kp)
-    if wq is None:
-        aw = fp8_amax(w2)
-        wq = (fp8_quant(w2, aw), aw)
-    Kp = xq.shape[2]
+    xr, xt = fp8_quant_both(x, ax)                               # (B, Cin, Tp), (B, T, Kp)
+    wq = Fp8Weight(w) if wq is None else wq
+    Kp = xt.shape[2]
     y = torch.empty(B, Cout, T, dtype=torch.float32, device=x.device)
-    fp8_gemm_nt(wq[0], xq, y, wq[1], ax, Cout, T, Kp, bias=bias, resid=resid, groups_outer=B, b_strides=(T * Kp, 0),
+    fp8_gemm_nt(wq.q, xt, y, wq.amax, ax, Cout, T, Kp, bias=bias, resid=resid, groups_outer=B, b_strides=(T * Kp, 0),
                 y_strides=(Cout * T, T, 1))
-    return y, ax
+    return y, (xr, ax), wq
 
 
-def conv1x1_fp8_dgrad(dy, w):
-    """dx[b] = W^T dy[b] in e4m3; dy (B, Cout, T), w (Cout, Cin[, 1]).  Returns (dx, amax_dy)."""
+def conv1x1_fp8_bwd(dy, xq, wq, Cin, need_dx=True, dw_out=None):
+    """Backward of conv1x1_fp8_fwd from its saved codes: dy (B, Cout, T) is measured and quantised ONCE (both layouts);
+    dx[b] = W^T dy[b]; dw_out (Cout, Cin[, 1]) += sum_b dy[b] x[b]^T.  Returns dx (or None)."""
     B, Cout, T = dy.shape
-    Cin = w.shape[1]
-    w3 = w.reshape(1, Cout, Cin)
     ady = fp8_amax(dy)
-    dyq = fp8_quant_transpose(dy, ady)                           # (B, T, Coutp)
-    aw = fp8_amax(w3)
-    wtq = fp8_quant_transpose(w3, aw)[0]                         # (Cin, Coutp)
-    Kp = dyq.shape[2]
-    dx = torch.empty(B, Cin, T, dtype=torch.float32, device=dy.device)
-    fp8_gemm_nt(wtq, dyq, dx, aw, ady, Cin, T, Kp, groups_outer=B, b_strides=(T * Kp, 0), y_strides=(Cin * T, T, 1))
-    return dx, ady
-
-
-def conv1x1_fp8_wgrad(dy, x, out, amax_dy=None, amax_x=None):
-    """out (Cout, Cin[, 1]) += sum_b dy[b] x[b]^T in e4m3 (the time axis is the reduction axis: no transpose needed)."""
-    B, Cout, T = dy.shape
-    Cin = x.shape[1]
-    ady = fp8_amax(dy) if amax_dy is None else amax_dy
-    ax = fp8_amax(x) if amax_x is None else amax_x
-    dyq = fp8_quant(dy.reshape(B * Cout, T), ady)                # (B Cout, Tp)
-    xq = fp8_quant(x.reshape(B * Cin, T), ax)                    # (B Cin, Tp)
-    Tp = dyq.shape[1]
-    fp8_gemm_nt(dyq, xq, out, ady, ax, Cout, Cin, Tp, groups_inner=B, a_strides=(0, Cout * Tp), b_strides=(0, Cin * Tp),
-                y_strides=(0, Cin, 1), accumulate=True)
-    return out
+    dyr, dyt = fp8_quant_both(dy, ady)                           # (B, Cout, Tp), (B, T, Coutp)
+    dx = None
+    if need_dx:
+        Kp = dyt.shape[2]
+        dx = torch.empty(B, Cin, T, dtype=torch.float32, device=dy.device)
+        fp8_gemm_nt(wq.qt, dyt, dx, wq.amax, ady, Cin, T, Kp, groups_outer=B, b_strides=(T * Kp, 0), y_strides=(Cin * T, T, 1))
+    if dw_out is not None:
+        xr, ax = xq
+        Tp = dyr.shape[2]
+        fp8_gemm_nt(dyr, xr, dw_out, ady, ax, Cout, Cin, Tp, groups_inner=B, a_strides=(0, Cout * Tp), b_strides=(0, Cin * Tp),
+                    y_strides=(0, Cin, 1), accumulate=True)
+    return dx
