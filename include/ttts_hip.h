@@ -707,7 +707,8 @@ int ttts_probe_mfma_layout(float* out_c, int32_t* out_tr, void* stream);
  *                     partial slabs are summed in a fixed order by a second launch (deterministic).  NULL: never split.
  * Oracle: oracle/fp8_ref.py (same scales and rounding, exact sums): results differ by the matrix core's internal summation of the
  * 16 products of an instruction (measured 1.6e-5 of the output range; the tests hold 6e-5). */
-int ttts_fp8_amax_f32(const float* x, int64_t n, float* amax_out, void* stream);
+/* out_is_zero != 0: *amax_out is known to be zero (e.g. a fresh word of a pool the caller cleared in bulk): no clearing launch */
+int ttts_fp8_amax_f32(const float* x, int64_t n, float* amax_out, int32_t out_is_zero, void* stream);
 int ttts_fp8_quant_f32(const float* x, void* q, const float* amax, int64_t rows, int32_t cols, int32_t cols_pad, void* stream);
 int ttts_fp8_quant_transpose_f32(const float* x, void* q, const float* amax, int32_t B, int32_t C, int32_t T, int32_t Cp, void* stream);
 int ttts_fp8_quant_both_f32(const float* x, void* q_rows, void* q_t, const float* amax, int32_t B, int32_t C, int32_t T, int32_t Cp,

@@ -725,7 +725,7 @@ def test_fp8_entry_points_validate_without_gpu_and_oracle_properties(lib):
     assert l.ttts_fp8_gemm_nt(p, p, p, None, None, p, p, 64, 64, 64, 1, 1, 60, 64, 0, 0, 0, 0, 0, 64, 1, 0, None, None) == -1    # pitch not 16-aligned
     assert l.ttts_fp8_quant_f32(p, p, p, 4, 30, 30, None) == -1 and b"multiple of 4" in l.ttts_last_error()
     assert l.ttts_fp8_quant_transpose_f32(p, p, p, 1, 30, 8, 24, None) == -1
-    assert l.ttts_fp8_amax_f32(None, 8, p, None) == -1
+    assert l.ttts_fp8_amax_f32(None, 8, p, 0, None) == -1
     assert l.ttts_fp8_quant_both_f32(p, p, p, p, 1, 30, 8, 60, 64, None) == -1 and b"multiples of 64" in l.ttts_last_error()
     # weight-gradient shapes split their inner groups (slabs + ordered reduce); output-rich shapes never do
     assert l.ttts_fp8_gemm_nt_workspace_bytes(512, 512, 1, 16) == 16 * 512 * 512 * 4 and l.ttts_fp8_gemm_nt_workspace_bytes(1536, 432, 16, 1) == 0

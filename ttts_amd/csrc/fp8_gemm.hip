@@ -308,12 +308,14 @@ __global__ __launch_bounds__(256) void fp8_slab_reduce_kernel(Fp8GemmParams p, i
 
 using namespace ttts;
 
-extern "C" int ttts_fp8_amax_f32(const float* x, int64_t n, float* amax_out, void* stream) {
+extern "C" int ttts_fp8_amax_f32(const float* x, int64_t n, float* amax_out, int32_t out_is_zero, void* stream) {
   TTTS_REQUIRE(x && amax_out && n > 0, "fp8_amax: null pointer / empty tensor");
   TTTS_REQUIRE(aligned16(x), "fp8_amax: 16-byte alignment required");
   hipStream_t s = as_stream(stream);
-  if (hipMemsetAsync(amax_out, 0, sizeof(float), s) != hipSuccess) return fail(TTTS_EHIP, "fp8_amax: memset failed");
-  const int grid = (int)std::min<int64_t>(cdiv(n, 256 * 4 * 4), 2048);
+  // out_is_zero: the caller hands a word it knows to be zero (a fresh slot of a pre-cleared pool): no memset launch
+  if (!out_is_zero && hipMemsetAsync(amax_out, 0, sizeof(float), s) != hipSuccess) return fail(TTTS_EHIP, "fp8_amax: memset failed");
+  // at most 256 workgroups: each ends in one atomicMax on the same word (2048 of them took longer than the 14 MB read)
+  const int grid = (int)std::min<int64_t>(cdiv(n, 256 * 4 * 4), 256);
   fp8_amax_kernel<<<grid, 256, 0, s>>>(x, n, reinterpret_cast<uint32_t*>(amax_out));
   return check_launch("fp8_amax");
 }

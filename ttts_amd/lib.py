@@ -252,7 +252,7 @@ SIGNATURES = {
     "ttts_kl_loss_fwd_f32": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P]),
     "ttts_kl_loss_bwd_f32": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
     "ttts_probe_mfma_layout": (_I32, [_P, _P, _P]),
-    "ttts_fp8_amax_f32": (_I32, [_P, _I64, _P, _P]),
+    "ttts_fp8_amax_f32": (_I32, [_P, _I64, _P, _I32, _P]),
     "ttts_fp8_quant_f32": (_I32, [_P, _P, _P, _I64, _I32, _I32, _P]),
     "ttts_fp8_quant_transpose_f32": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "ttts_fp8_quant_both_f32": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),

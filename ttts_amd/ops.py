@@ -1369,11 +1369,28 @@ def _pad_to(n, m):
     return (n + m - 1) // m * m
 
 
+_amax_pools = {}        # device key -> [zeroed float32 pool, next free slot]
+
+
 def fp8_amax(x, out=None):
-    """max |x| of the whole tensor as a device scalar (no host read-back)."""
+    """max |x| of the whole tensor as a device scalar (no host read-back).  Without `out` the result lands in a fresh word of a
+    pool that was cleared in bulk (one fill launch per 4096 results instead of one per result); every word is handed out once, so
+    saved results stay valid for as long as they are referenced.  Under stream capture the word is cleared by the call itself (a
+    replay must not start from the previous replay's maximum)."""
     _req(x, torch.float32, "x")
-    out = torch.empty(1, dtype=torch.float32, device=x.device) if out is None else out
-    check(_l.get().ttts_fp8_amax_f32(_p(x), x.numel(), _p(out), _stream()), "fp8_amax")
+    zero = 0
+    if out is None:
+        if x.is_cuda and torch.cuda.is_current_stream_capturing():
+            out = torch.empty(1, dtype=torch.float32, device=x.device)
+        else:
+            key = (_device_key(x.device), torch.cuda.current_stream(x.device).cuda_stream if x.is_cuda else 0)
+            pool = _amax_pools.get(key)
+            if pool is None or pool[1] >= pool[0].numel():
+                pool = _amax_pools[key] = [torch.zeros(4096, dtype=torch.float32, device=x.device), 0]
+            out = pool[0][pool[1]:pool[1] + 1]
+            pool[1] += 1
+            zero = 1
+    check(_l.get().ttts_fp8_amax_f32(_p(x), x.numel(), _p(out), zero, _stream()), "fp8_amax")
     return out
 
 
