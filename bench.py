@@ -728,7 +728,12 @@ def main():
                           "dist_backend": (torch.distributed.get_backend() if world > 1 else None), "world_size": world,
                           "ranks_seen_by_backend": (torch.distributed.get_world_size() if world > 1 else 1),
                           "grad_exchange_dtype": (args.grad_dtype if world > 1 else None),
-                          "capture_note": getattr(eng, "_capture_error", None)},
+                          "capture_note": getattr(eng, "_capture_error", None),
+                          # the multi-GPU communication budget of DESIGN section 6 rests on an ASSUMED RCCL bus bandwidth (250 GB/s
+                          # on the 7-link xGMI mesh): this line's allreduce_arena_ms is the first measurement of it
+                          "exchange_budget_note": ("DESIGN section 6 budgets the exchange with an assumed 250 GB/s RCCL bus bandwidth; "
+                                                   "allreduce_arena_ms / allreduce_arena_mb in this line are the measured figures"
+                                                   if world > 1 else None)},
                "final_loss_mel": round(lm, 4), "per_rank_ms_per_step": per_rank_ms,
                "allreduce_arena_ms": (None if allreduce_ms is None else round(allreduce_ms, 3)),
                "allreduce_arena_mb": (None if allreduce_ms is None else round(eng.grads.numel() * 4 / 2 ** 20, 1)), "roofline": roof}
