@@ -494,6 +494,9 @@ typedef struct ttts_conv_ctx {
   void* const* handles;     /* ABI v10: the weight-split caches (ttts_conv_wsplit_cache_create) and weight-gradient arenas
                              * (ttts_conv_wgrad_arena_create) this call may use, in any order; NULL / 0: none.  The library keeps
                              * NO registry of them: a convolution call sees exactly the objects its context names. */
+  int32_t device;           /* ABI v10: ordinal of the device the call runs on (the one `stream` belongs to), or -1: the library asks
+                             * the runtime where it has to (per-device kernel attributes) -- a hint that saves an API call per launch */
+  int32_t reserved;
 } ttts_conv_ctx;
 #define TTTS_CONV_EXACT_F32 4096
 #define TTTS_CONV_DIRECT_ONLY 256        /* experiments: every convolution on the direct (non-MFMA) kernels */

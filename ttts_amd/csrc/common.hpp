@@ -22,9 +22,20 @@ inline int fail(int code, const char* fmt, ...) {
 }
 // "done on the CURRENT device": the dynamic-LDS opt-in of hipFuncSetAttribute is a per-device attribute, so a once-flag next to a
 // launch site must be per device as well (one process may drive several devices).  Drop-in for a `static bool`.
+// Device ordinal the CURRENT C-ABI call runs on, when the caller told us (ttts_conv_ctx::device: the convolution family launches
+// thousands of kernels per step and hipGetDevice is an API call), else -1: ask the runtime.  Set for the duration of an entry point.
+inline int& device_hint() { static thread_local int d = -1; return d; }
+struct DeviceHint {
+  explicit DeviceHint(int d) { device_hint() = d; }
+  ~DeviceHint() { device_hint() = -1; }
+};
 struct OnceFlag {
   std::atomic<uint64_t> mask{0};
-  static int dev() { int d = 0; (void)hipGetDevice(&d); return d & 63; }
+  static int dev() {
+    int d = device_hint();
+    if (d < 0) (void)hipGetDevice(&d);
+    return d & 63;
+  }
   operator bool() const { return (mask.load(std::memory_order_acquire) >> dev()) & 1; }
   OnceFlag& operator=(bool v) { if (v) mask.fetch_or(1ull << dev(), std::memory_order_release); return *this; }
 };
@@ -56,6 +67,7 @@ struct ConvCtx {
   int flags = 0;           // TTTS_CONV_EXACT_F32 | heuristic overrides (tests, tools/conv_bench.py)
   void* const* handles = nullptr;   // the caller's weight-split caches / weight-gradient arenas this call may use (ABI v10)
   int n_handles = 0;
+  int device = -1;                  // device ordinal of the call (ABI v10), -1: unknown
 };
 // Every object handed out through ttts_conv_ctx::handles starts with this tag (the two kinds share one list).
 enum : uint32_t { TTTS_HANDLE_WSPLIT = 0x4c505357u /* "WSPL" */, TTTS_HANDLE_SLAB = 0x42414c53u /* "SLAB" */ };
@@ -66,6 +78,7 @@ inline ConvCtx conv_ctx_of(const ttts_conv_ctx* c) {
     cx.ws_bytes = c->workspace ? c->workspace_bytes : 0;
     cx.flags = c->flags;
     if (c->handles && c->n_handles > 0) { cx.handles = c->handles; cx.n_handles = c->n_handles; }
+    cx.device = c->device;
   }
   return cx;
 }

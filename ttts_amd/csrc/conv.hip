@@ -661,6 +661,7 @@ extern "C" int ttts_conv1d_fwd_f32(const float* x, const float* w, const float* 
   TTTS_REQUIRE(x && w && y, "conv1d_fwd: null pointer");
   TTTS_REQUIRE(!ctx || !ctx->workspace || aligned16(ctx->workspace), "conv1d_fwd: ctx workspace must be 16-byte aligned");
   const ConvCtx cx = conv_ctx_of(ctx);
+  const DeviceHint device_hint_scope(cx.device);
   TTTS_REQUIRE(out_act >= 0 && out_act <= 2, "conv1d_fwd: out_act must be 0 (none), 1 (tanh) or 2 (leaky-relu)");
   int rc = conv_check(B, Cin, Lin, Cout, Lout, K, stride, pad, dil, groups);
   if (rc) return rc;
@@ -717,6 +718,7 @@ extern "C" int ttts_conv1d_fwd_dual_f32(const float* x, const float* w, const fl
   TTTS_REQUIRE(Cout1 > 0 && Cout1 < Cout, "conv1d_fwd_dual: need 0 < Cout1 < Cout");
   TTTS_REQUIRE(!ctx || !ctx->workspace || aligned16(ctx->workspace), "conv1d_fwd_dual: ctx workspace must be 16-byte aligned");
   const ConvCtx cx = conv_ctx_of(ctx);
+  const DeviceHint device_hint_scope(cx.device);
   int rc = conv_check(B, Cin, Lin, Cout, Lout, K, 1, pad, dil, 1);
   if (rc) return rc;
   if (!(cx.flags & 256)) {
@@ -741,6 +743,7 @@ extern "C" int ttts_conv1d_dgrad_f32(const float* dy, const float* w, const floa
   TTTS_REQUIRE(dy && w && dx, "conv1d_dgrad: null pointer");
   TTTS_REQUIRE(!ctx || !ctx->workspace || aligned16(ctx->workspace), "conv1d_dgrad: ctx workspace must be 16-byte aligned");
   const ConvCtx cx = conv_ctx_of(ctx);
+  const DeviceHint device_hint_scope(cx.device);
   TTTS_REQUIRE(groups > 0 && Cin % groups == 0 && Cout % groups == 0, "conv1d_dgrad: channels not divisible by groups");
   TTTS_REQUIRE(B > 0 && Cin > 0 && Lin > 0 && Cout > 0 && Lout > 0 && K > 0 && stride > 0 && dil > 0 && pad >= 0, "conv1d_dgrad: bad shape");
   TTTS_REQUIRE(stride == 1 || dil == 1, "conv1d_dgrad: stride > 1 requires dilation 1");
@@ -805,6 +808,7 @@ static int conv1d_wgrad_impl(const float* dy, const float* x, float* dw, float* 
   TTTS_REQUIRE(dy && x && dw, "conv1d_wgrad: null pointer");
   TTTS_REQUIRE(!ctx || !ctx->workspace || aligned16(ctx->workspace), "conv1d_wgrad: ctx workspace must be 16-byte aligned");
   const ConvCtx cx = conv_ctx_of(ctx);
+  const DeviceHint device_hint_scope(cx.device);
   TTTS_REQUIRE(groups > 0 && Cin % groups == 0 && Cout % groups == 0, "conv1d_wgrad: channels not divisible by groups");
   if (groups == 1 && !(cx.flags & (256 | 8388608))) {
     bool handled = false;

@@ -73,7 +73,7 @@ ABI_VERSION = 10
 class ConvCtx(ctypes.Structure):
     """include/ttts_hip.h: ttts_conv_ctx (caller-owned; the library keeps no copy)."""
     _fields_ = [("workspace", _P), ("workspace_bytes", _I64), ("flags", _I32), ("n_handles", _I32),
-                ("handles", ctypes.POINTER(ctypes.c_void_p))]
+                ("handles", ctypes.POINTER(ctypes.c_void_p)), ("device", _I32), ("reserved", _I32)]
 
 
 class LnFinalizeDesc(ctypes.Structure):

@@ -17,8 +17,15 @@ __all__ = ["gemm_nt", "gemm_tn_accum", "colsum_accum", "attn_fwd", "attn_bwd", "
            "vq_commit", "vq_ema_update", "stft_mag", "mel_log", "CastPlan", "TransposePlan", "ColsumPlan", "LnFinalizePlan", "TnPlan", "probe_layout", "device_info"]
 
 
+def _raw_stream(index=None):
+    """Handle of torch's current HIP stream on device `index` (default: the current device) as an int.  torch.cuda.current_stream()
+    builds a Stream object through three Python layers (~5 us); this is called for every launch -- 5 800 times per VQ-VAE-GAN step,
+    whose eager multi-stream form is host-sensitive -- so the raw accessor the runtime itself uses is taken instead."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice() if index is None else index)
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(_raw_stream())
 
 
 def _p(t):
@@ -360,20 +367,25 @@ class WeightNormPlan:
 # The weight-split caches and weight-gradient arenas alive on each device.  The C library keeps no list of them (ABI v10): every
 # convolution context (one per stream, _conv_ctx) carries the device's handles in `ttts_conv_ctx::handles`; this host-side table is
 # where those arrays are rebuilt when an object is created or closed.
-_conv_handles = {}            # device key -> {"objs": [owner objects], "array": ctypes array | None}
+_conv_handles = {}            # device ordinal -> {"objs": [owner objects], "array": ctypes array | None}
+
+
+def _ordinal(device):
+    d = torch.device(device)
+    return d.index if d.index is not None else torch.cuda.current_device()
 
 
 def _register_conv_handle(obj, device):
-    ent = _conv_handles.setdefault(_device_key(device), {"objs": [], "array": None})
+    ent = _conv_handles.setdefault(_ordinal(device), {"objs": [], "array": None})
     ent["objs"].append(obj)
-    _rebuild_conv_handles(_device_key(device))
+    _rebuild_conv_handles(_ordinal(device))
 
 
 def _unregister_conv_handle(obj, device):
-    ent = _conv_handles.get(_device_key(device))
+    ent = _conv_handles.get(_ordinal(device))
     if ent is not None and obj in ent["objs"]:
         ent["objs"].remove(obj)
-        _rebuild_conv_handles(_device_key(device))
+        _rebuild_conv_handles(_ordinal(device))
 
 
 def _rebuild_conv_handles(dkey):
@@ -932,13 +944,17 @@ def _conv_ctx(device):
     every conv entry point receives the struct by pointer.  TTTS_CONV_FP32=1 creates it without scratch (exact kernels)."""
     # one scratch per (device, stream): convolutions issued on different streams (the sub-discriminators run concurrently,
     # vq2.MultiPeriodDiscriminator) must not share operand-split buffers
-    key = (_device_key(device), torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+    # (keyed by the device ORDINAL and the stream handle: this runs once per convolution call, ~1700 times a step -- no string work here)
+    if device.type != "cuda":
+        raise TttsError("the convolution family runs on a GPU only (got %s)" % device)
+    idx = device.index if device.index is not None else torch._C._cuda_getDevice()
+    key = (idx, _raw_stream(idx))
     if key not in _conv_ctxs:
         buf = None
         if os.environ.get("TTTS_CONV_FP32", "0") != "1":
             buf = torch.empty(int(os.environ.get("TTTS_CONV_SCRATCH_MB", "1536")) << 20, dtype=torch.uint8, device=device)
-        ctx = _l.ConvCtx(_p(buf), buf.numel() if buf is not None else 0, 0, 0, ctypes.POINTER(ctypes.c_void_p)())
-        _set_ctx_handles(ctx, _conv_handles.get(key[0]))
+        ctx = _l.ConvCtx(_p(buf), buf.numel() if buf is not None else 0, 0, 0, ctypes.POINTER(ctypes.c_void_p)(), idx, 0)
+        _set_ctx_handles(ctx, _conv_handles.get(idx))
         _conv_ctxs[key] = (ctx, buf)
         _apply_flags()
     return ctypes.byref(_conv_ctxs[key][0])
@@ -1383,7 +1399,7 @@ def fp8_amax(x, out=None):
         if x.is_cuda and torch.cuda.is_current_stream_capturing():
             out = torch.empty(1, dtype=torch.float32, device=x.device)
         else:
-            key = (_device_key(x.device), torch.cuda.current_stream(x.device).cuda_stream if x.is_cuda else 0)
+            key = (x.device.index, _raw_stream(x.device.index))
             pool = _amax_pools.get(key)
             if pool is None or pool[1] >= pool[0].numel():
                 pool = _amax_pools[key] = [torch.zeros(4096, dtype=torch.float32, device=x.device), 0]

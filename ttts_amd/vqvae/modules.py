@@ -38,6 +38,26 @@ def _take_dw_buffer(w):
 
 _branch_pools = {}
 _dirty_streams = []
+_env_cache = {}
+
+
+def _env_int(name, default):
+    """int(os.environ[name]) for switches read on hot paths: os.environ.get costs ~1.5 us (key encode, lookup, value decode); the raw
+    value is compared with the one parsed last time instead of being parsed again."""
+    try:
+        raw = os.environ._data.get(_env_keys.get(name) or _env_keys.setdefault(name, os.environ.encodekey(name)))
+    except AttributeError:                               # (an os.environ without CPython's internals: the plain, slower way)
+        v = os.environ.get(name)
+        return default if v in (None, "") else int(v)
+    hit = _env_cache.get(name)
+    if hit is not None and hit[0] is raw:
+        return hit[1]
+    val = default if raw is None else int(os.environ.decodevalue(raw) or default)
+    _env_cache[name] = (raw, val)
+    return val
+
+
+_env_keys = {}
 
 
 def side_streams(pool, device, n=None):
@@ -76,51 +96,54 @@ def join_side_streams(device):
         main.wait_stream(_dirty_streams.pop())
 
 
-class _JoinAfterBackward(torch.autograd.Function):
-    """Identity on the outputs of a fan-out.  Its backward node runs BEFORE the branches' nodes (it sits downstream of them) and
-    queues an engine callback: when the whole backward pass is over, the stream backward() was called on waits for the side
-    streams the branches ran on.  This makes the join part of every backward through run_branches / MultiPeriodDiscriminator --
-    user loops, tests, torch.autograd.grad -- instead of a rule the caller has to know (VqvaeStep still calls
-    join_side_streams() itself: waiting twice is free)."""
+_join_pending = {}          # device -> {stream handle: stream}: side streams the running backward pass has touched
 
-    @staticmethod
-    def forward(ctx, holder, *xs):
-        ctx.holder = holder
-        return xs
 
-    @staticmethod
-    def backward(ctx, *gs):
-        device, streams = ctx.holder
-
-        def join():
+def _join_pending_streams():
+    """Engine callback (end of a backward pass, on the thread and stream backward() was called from)."""
+    for device, streams in list(_join_pending.items()):
+        if streams:
             main = torch.cuda.current_stream(device)
-            for st in streams:
+            for st in streams.values():
                 main.wait_stream(st)
-        torch.autograd.Variable._execution_engine.queue_callback(join)
-        return (None,) + gs
+            streams.clear()
+
+
+class _JoinAfterBackward(torch.autograd.Function):
+    """Identity on ONE output tensor of a fan-out branch.  Its backward node sits downstream of the branch, so it runs before the
+    branch's nodes; it notes the branch's stream and queues an engine callback: when the whole backward pass is over, the stream
+    backward() was called on waits for every side stream noted.  This makes the join part of every backward through run_branches /
+    MultiPeriodDiscriminator -- user loops, tests, torch.autograd.grad -- instead of a rule the caller has to know (VqvaeStep still
+    calls join_side_streams() itself: waiting twice is free).  One node PER TENSOR, deliberately: a single node over all outputs
+    of a fan-out is a barrier -- it runs only when every one of its gradients has arrived, so no branch's backward could start
+    before the slowest loss term was differentiated (measured: + 2.7 ms on the 132 ms VQ-VAE-GAN step, HISTORY 18.3)."""
+
+    @staticmethod
+    def forward(ctx, holder, x):
+        ctx.holder = holder
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        device, streams = ctx.holder
+        pend = _join_pending.setdefault(device, {})
+        for st in streams:
+            pend[st.cuda_stream] = st
+        # (queued every time: a backward pass that raised never ran its callbacks, so "already queued" cannot be remembered)
+        torch.autograd.Variable._execution_engine.queue_callback(_join_pending_streams)
+        return None, g
 
 
 def join_after_backward(outs, device, streams):
-    """`outs` (tensor or nested tuples / lists of tensors) with every gradient-carrying tensor routed through _JoinAfterBackward."""
-    if not streams or not torch.is_grad_enabled():
+    """`outs` (tensor or nested tuples / lists of tensors) with every gradient-carrying tensor routed through its own
+    _JoinAfterBackward node."""
+    if not streams or not torch.is_grad_enabled() or _env_int("TTTS_AUTOJOIN", 1) != 1:
         return outs
-    flat = []
-
-    def collect(o):
-        if torch.is_tensor(o):
-            if o.requires_grad:
-                flat.append(o)
-        elif isinstance(o, (tuple, list)):
-            for e in o:
-                collect(e)
-    collect(outs)
-    if not flat:
-        return outs
-    new = iter(_JoinAfterBackward.apply((device, list(streams)), *flat))
+    holder = (device, list(streams))
 
     def rebuild(o):
         if torch.is_tensor(o):
-            return next(new) if o.requires_grad else o
+            return _JoinAfterBackward.apply(holder, o) if o.requires_grad else o
         if isinstance(o, (tuple, list)):
             return type(o)(rebuild(e) for e in o)
         return o
@@ -135,7 +158,10 @@ def wgrad_side_stream(device):
     backward node, or None: TTTS_WGRAD_STREAMS streams, taken in turn.  Default 0 (off): measured 146.6 ms against 136-139 ms per step with 2 streams
     (profiles/r04_ab_wgrad_streams.txt) -- with the branch streams already filling the chip the extra fork per convolution costs more
     than the overlap returns."""
-    streams = side_streams("wgrad", device, int(os.environ.get("TTTS_WGRAD_STREAMS", "0")))
+    n = _env_int("TTTS_WGRAD_STREAMS", 0)          # (once per convolution backward: ~1 100 times a step)
+    if n <= 0:
+        return None
+    streams = side_streams("wgrad", device, n)
     if not streams:
         return None
     _wgrad_rr[0] = (_wgrad_rr[0] + 1) % len(streams)

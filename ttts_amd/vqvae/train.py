@@ -160,9 +160,19 @@ class VqvaeStep:
         else:
             wav_aug = augment(wav, self.aug, self.hps)                        # train.py:337-338 (PEQ part)
         spec_aug = spec if wav_aug is wav else spectrogram_torch(wav_aug, h.filter_length, h.hop_length, h.win_length, center=False)
+        # No host read-back inside the step: the dead-code replacement of the quantizer (core_vq.py:152-168) asks the host whether any
+        # code expired -- a device -> host sync in the middle of the generator forward that stalls the launch stream for ~16 ms of a
+        # 132 ms step (the host waits for the encoders, then the device waits for the host to catch up).  What it would write never
+        # survives the step, in the reference either (quantize.expire_codes_ has the line-by-line argument), so the trainer's step
+        # skips it, as the recorded (hipGraph) step always had to.  TTTS_VQ_EXPIRE_SYNC=1 restores the read-back.
+        from .quantize import EuclideanCodebook
+        prev_sync_free = EuclideanCodebook.sync_free
+        if os.environ.get("TTTS_VQ_EXPIRE_SYNC", "0") != "1":
+            EuclideanCodebook.sync_free = True
         try:
             return self._phases(wav, wav_aug, wav_lengths, spec, spec_aug, spec_lengths, text, text_lengths, y, inject, cut)
         finally:
+            EuclideanCodebook.sync_free = prev_sync_free
             for bank in (self.bank_g, self.bank_d):
                 if bank is not None:
                     bank.release()
