@@ -1314,23 +1314,46 @@ int conv1d_dgrad_strided_mfma_try(const float* dy, const float* w, const float* 
 //              (PL = roundup_stride(pad)); the odd copy lets every row segment start on a 4-byte boundary
 // (2-D grids: blockIdx.y walks rows, a thread converts two adjacent elements -- the flat-index form spent most of its time in
 // 64-bit divisions)
+// (round 5: EIGHT adjacent elements per thread and 16-byte stores -- two per thread made 20 000 workgroups of 2 KB each for one
+// layer's dy: 26 us for 31 MB, dispatch-bound; rows shorter than 256 x 8 elements are walked several at a time by one workgroup)
+__device__ __forceinline__ void wgrad_split_store8(const float (&v)[8], bf16* __restrict__ hi, bf16* __restrict__ lo) {
+  bf16x8 h, w;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    h[e] = (bf16)v[e];
+    w[e] = (bf16)(v[e] - (float)h[e]);
+  }
+  *reinterpret_cast<bf16x8*>(hi) = h;
+  *reinterpret_cast<bf16x8*>(lo) = w;
+}
+// rows-per-workgroup geometry shared by the launcher and the bodies: items = 16-byte groups per row
+__host__ __device__ __forceinline__ int wgrad_split_rpb(int items) { return items >= 256 ? 1 : 256 / items; }
+
 __device__ __forceinline__ void wgrad_split_dy_body(const float* __restrict__ dy, bf16* __restrict__ hi,
                                                     bf16* __restrict__ lo, int64_t rows, int Lout, int Lq, float slope,
                                                     float* __restrict__ db, int Cout, int bx, int by, int gy, float* sh) {
   // db != NULL (slope == 1): the layer's bias gradient, db[row % Cout] += sum of the row -- this pass reads all of dy anyway.
-  // gy is a multiple of Cout then, so every row a workgroup walks belongs to the same channel.
-  const int l = (bx * 256 + threadIdx.x) * 2;
+  // gy is a multiple of Cout then, so every row a workgroup walks (by, by + gy, by + 2 gy, ...) belongs to the same channel.
+  const int items = Lq >> 3, rpb = wgrad_split_rpb(items);
+  const int sr = rpb == 1 ? 0 : (int)threadIdx.x / items;
+  const int it = rpb == 1 ? bx * 256 + (int)threadIdx.x : (int)threadIdx.x - sr * items;
   float bs = 0.f;
-  if (l < Lq) {
-    for (int64_t r = by; r < rows; r += gy) {
-      const float* src = dy + r * Lout;
-      const float v0 = l < Lout ? lrelu_f(src[l], slope) : 0.f, v1 = l + 1 < Lout ? lrelu_f(src[l + 1], slope) : 0.f;
-      bs += v0 + v1;
-      bf16x2 h, w;
-      h[0] = (bf16)v0; h[1] = (bf16)v1;
-      w[0] = (bf16)(v0 - (float)h[0]); w[1] = (bf16)(v1 - (float)h[1]);
-      *reinterpret_cast<bf16x2*>(hi + r * Lq + l) = h;
-      *reinterpret_cast<bf16x2*>(lo + r * Lq + l) = w;
+  if (it < items && sr < rpb) {
+    const int l = it * 8;
+    for (int64_t r = by + (int64_t)sr * gy; r < rows; r += (int64_t)gy * rpb) {
+      const float* src = dy + r * Lout + l;
+      float v[8];
+      if (l + 8 <= Lout && (reinterpret_cast<uintptr_t>(src) & 15u) == 0) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src), c = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = c[e]; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = l + e < Lout ? src[e] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[e] = lrelu_f(v[e], slope); bs += v[e]; }
+      wgrad_split_store8(v, hi + r * Lq + l, lo + r * Lq + l);
     }
   }
   if (db) {
@@ -1344,21 +1367,24 @@ __device__ __forceinline__ void wgrad_split_dy_body(const float* __restrict__ dy
 __device__ __forceinline__ void wgrad_split_x_body(const float* __restrict__ x, bf16* __restrict__ hi,
                                                    bf16* __restrict__ lo, int64_t rows, int Lin, int stride, int Li,
                                                    int PL, float slope, int bx, int by, int bz, int gy) {
-  const int ii = (bx * 256 + threadIdx.x) * 2;
-  if (ii >= Li) return;
+  const int items = Li >> 3, rpb = wgrad_split_rpb(items);
+  const int sr = rpb == 1 ? 0 : (int)threadIdx.x / items;
+  const int it = rpb == 1 ? bx * 256 + (int)threadIdx.x : (int)threadIdx.x - sr * items;
+  if (it >= items || sr >= rpb) return;
+  const int ii = it * 8;
   const int par = bz / stride, r = bz % stride;
   const int64_t per = rows * stride * Li;
-  const int64_t q0 = (int64_t)(ii + par) * stride + r - PL, q1 = q0 + stride;
-  for (int64_t row = by; row < rows; row += gy) {
+  const int64_t q0 = (int64_t)(ii + par) * stride + r - PL;
+  for (int64_t row = by + (int64_t)sr * gy; row < rows; row += (int64_t)gy * rpb) {
     const float* src = x + row * Lin;
-    const float v0 = (q0 >= 0 && q0 < Lin) ? lrelu_f(src[q0], slope) : 0.f;
-    const float v1 = (q1 >= 0 && q1 < Lin) ? lrelu_f(src[q1], slope) : 0.f;
-    bf16x2 h, w;
-    h[0] = (bf16)v0; h[1] = (bf16)v1;
-    w[0] = (bf16)(v0 - (float)h[0]); w[1] = (bf16)(v1 - (float)h[1]);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int64_t q = q0 + (int64_t)e * stride;
+      v[e] = (q >= 0 && q < Lin) ? lrelu_f(src[q], slope) : 0.f;
+    }
     const int64_t o = par * per + (row * stride + r) * Li + ii;
-    *reinterpret_cast<bf16x2*>(hi + o) = h;
-    *reinterpret_cast<bf16x2*>(lo + o) = w;
+    wgrad_split_store8(v, hi + o, lo + o);
   }
 }
 // Both operand splits of a weight gradient in ONE launch (they were two ~5 us launches per layer): workgroups [0, nb_dy) split
@@ -1387,24 +1413,23 @@ __global__ __launch_bounds__(256) void wgrad_split_pair_kernel(WgradSplitPair p)
 __device__ __forceinline__ void wgrad_split_cat_body(const float* __restrict__ src, bf16* __restrict__ hi, bf16* __restrict__ lo,
                                                      int B, int C, int L, int Lg, int shift, int Lrow, float slope,
                                                      float* __restrict__ db, int S, int bx, int by, float* sh) {
-  // by = channel * S + phase; element v of the virtual row: b = v / Lg, j = v % Lg, source position j*S + phase - shift
-  const int c = by / S, ph = by % S, v0 = (bx * 256 + threadIdx.x) * 2;
+  // by = channel * S + phase; element v of the virtual row: b = v / Lg, j = v % Lg, source position j*S + phase - shift.
+  // Eight adjacent elements per thread, 16-byte stores (Lrow is a multiple of 8), as in wgrad_split_dy_body.
+  const int c = by / S, ph = by % S, v0 = (bx * 256 + threadIdx.x) * 8;
   float bs = 0.f;
   if (v0 < Lrow) {
-    float val[2];
+    float val[8];
+    int b = v0 / Lg, jj = v0 - b * Lg;                       // (one division per thread; the batch element advances by carry)
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int v = v0 + e, b = v / Lg, j = (v - b * Lg) * S + ph - shift;
+    for (int e = 0; e < 8; ++e) {
+      const int j = jj * S + ph - shift;
       const bool ok = b < B && j >= 0 && j < L;
       const float t = src[((int64_t)min(b, B - 1) * C + c) * L + min(max(j, 0), L - 1)];
       val[e] = ok ? lrelu_f(t, slope) : 0.f;
+      bs += val[e];
+      if (++jj == Lg) { jj = 0; ++b; }
     }
-    bs = val[0] + val[1];
-    bf16x2 h, w;
-    h[0] = (bf16)val[0]; h[1] = (bf16)val[1];
-    w[0] = (bf16)(val[0] - (float)h[0]); w[1] = (bf16)(val[1] - (float)h[1]);
-    *reinterpret_cast<bf16x2*>(hi + (int64_t)by * Lrow + v0) = h;
-    *reinterpret_cast<bf16x2*>(lo + (int64_t)by * Lrow + v0) = w;
+    wgrad_split_store8(val, hi + (int64_t)by * Lrow + v0, lo + (int64_t)by * Lrow + v0);
   }
   if (db) {
     bs = wave_sum(bs);
@@ -1424,9 +1449,9 @@ __global__ __launch_bounds__(256) void wgrad_split_cat_pair_kernel(WgradCatSide 
 static void launch_wgrad_cat_pair(const float* dy, bf16* dyh, bf16* dyl, int Cout, int Lout, int Lq, float dy_slope, float* db,
                                   const float* x, bf16* xh, bf16* xl, int Cin, int Lin, int shift, int Li, float x_slope, int S, int B,
                                   int Lg, hipStream_t stream) {
-  WgradCatSide a{dy, dyh, dyl, Cout, Lout, 0, Lq, dy_slope, db, 1, (int)cdiv(Lq / 2, 256), 0};
+  WgradCatSide a{dy, dyh, dyl, Cout, Lout, 0, Lq, dy_slope, db, 1, (int)cdiv(Lq / 8, 256), 0};
   a.nb = a.nbx * Cout;
-  WgradCatSide b{x, xh, xl, Cin, Lin, shift, Li, x_slope, nullptr, S, (int)cdiv(Li / 2, 256), 0};
+  WgradCatSide b{x, xh, xl, Cin, Lin, shift, Li, x_slope, nullptr, S, (int)cdiv(Li / 8, 256), 0};
   b.nb = b.nbx * Cin * S;
   wgrad_split_cat_pair_kernel<<<(unsigned)(a.nb + b.nb), 256, 0, stream>>>(a, b, B, Lg);
 }
@@ -1434,13 +1459,15 @@ static void launch_wgrad_cat_pair(const float* dy, bf16* dyh, bf16* dyl, int Cou
 static void launch_wgrad_splits(const float* dy, const float* x, bf16* dyh, bf16* dyl, bf16* xh, bf16* xl, int64_t rows_dy, int Lout,
                                 int Lq, float dy_slope, int64_t rows_x, int Lin, int stride, int Li, int PL, float x_slope, int npar,
                                 float* db, int Cout, hipStream_t stream) {
-  int64_t gy = std::min<int64_t>(rows_dy, 32768);
-  if (db && gy < rows_dy) gy = std::max<int64_t>(Cout, gy / Cout * Cout);       // rows r, r + gy, ... share a channel
+  // grid.y walks rows; a workgroup takes rpb rows per trip (short rows), so cdiv(rows, rpb) workgroups cover a pass over the rows
+  const int rpb_dy = wgrad_split_rpb(Lq / 8), rpb_x = wgrad_split_rpb(Li / 8);
+  int64_t gy = std::min<int64_t>(cdiv(rows_dy, rpb_dy), 32768);
+  if (db) gy = std::min<int64_t>(rows_dy, std::max<int64_t>(Cout, cdiv(gy, Cout) * Cout));   // rows r, r + gy, ... share a channel
   WgradSplitPair p;
   p.dy = dy; p.dyh = dyh; p.dyl = dyl; p.rows_dy = rows_dy; p.Lout = Lout; p.Lq = Lq; p.dy_slope = dy_slope; p.db = db; p.Cout = Cout;
-  p.nbx_dy = (int)cdiv(Lq / 2, 256); p.gy_dy = (int)gy; p.nb_dy = p.nbx_dy * p.gy_dy;
+  p.nbx_dy = (int)cdiv(Lq / 8, 256); p.gy_dy = (int)gy; p.nb_dy = p.nbx_dy * p.gy_dy;
   p.x = x; p.xh = xh; p.xl = xl; p.rows_x = rows_x; p.Lin = Lin; p.stride = stride; p.Li = Li; p.PL = PL; p.x_slope = x_slope;
-  p.nbx_x = (int)cdiv(Li / 2, 256); p.gy_x = (int)std::min<int64_t>(rows_x, 32768);
+  p.nbx_x = (int)cdiv(Li / 8, 256); p.gy_x = (int)std::min<int64_t>(cdiv(rows_x, rpb_x), 32768);
   const int64_t nb = (int64_t)p.nb_dy + (int64_t)p.nbx_x * p.gy_x * npar * stride;
   wgrad_split_pair_kernel<<<(unsigned)nb, 256, 0, stream>>>(p);
 }
@@ -1867,7 +1894,9 @@ struct SlabDesc {
   int nsplit, K, Cout, Cin;
   int block_begin, pad_;
 };
-constexpr int SLABB_EPB = 64;        // elements per workgroup: wave g sums splits g, g + 4, ... of 64 consecutive elements
+constexpr int SLABB_EPB = 256;       // elements per workgroup: wave g sums splits g, g + 4, ... of 256 consecutive elements, FOUR per lane
+                                     // (round 5: it was 64 with one element per lane -- 82 000 workgroups of a few hundred bytes for one
+                                     // 1024 x 1024 x 5 gradient: dispatch-bound at 1.8 TB/s; per-element summation order unchanged)
 
 __global__ __launch_bounds__(256) void wgrad_slab_reduce_batched_kernel(const SlabDesc* __restrict__ table, int n_desc, int block_base) {
   __shared__ float part[4][SLABB_EPB];
@@ -1881,29 +1910,57 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_batched_kernel(const Sl
   const int64_t per = (int64_t)d.K * d.Cout * d.Cin;
   const int nblk_w = (int)((per + SLABB_EPB - 1) / SLABB_EPB);
   const int lb = gb - d.block_begin;
-  const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int e4 = (threadIdx.x & 63) * 4, g = threadIdx.x >> 6;
   const bool bias_blk = lb >= nblk_w;          // trailing workgroups of a layer: its bias gradient [split][Cout] -> db
   const float* src = bias_blk ? d.bslab : d.slab;
   const int64_t len = bias_blk ? d.Cout : per;
-  const int64_t i = (int64_t)(bias_blk ? lb - nblk_w : lb) * SLABB_EPB + e;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  if (i < len) {
+  const int64_t i0 = (int64_t)(bias_blk ? lb - nblk_w : lb) * SLABB_EPB + e4;
+  float acc[4][4];                             // [independent chain][element]: four loads in flight per element, as before
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[c][j] = 0.f;
+  const bool vec = (len & 3) == 0 && i0 + 3 < len && (reinterpret_cast<uintptr_t>(src) & 15u) == 0;
+  auto load4 = [&](int sp, float (&v)[4]) {
+    const float* q = src + sp * len + i0;
+    if (vec) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(q);
+      v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = i0 + j < len ? q[j] : 0.f;
+    }
+  };
+  if (i0 < len) {
     int sp = g;
     for (; sp + 12 < d.nsplit; sp += 16) {
-      const float v0 = src[sp * len + i], v1 = src[(sp + 4) * len + i], v2 = src[(sp + 8) * len + i], v3 = src[(sp + 12) * len + i];
-      a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+      float v0[4], v1[4], v2[4], v3[4];
+      load4(sp, v0); load4(sp + 4, v1); load4(sp + 8, v2); load4(sp + 12, v3);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { acc[0][j] += v0[j]; acc[1][j] += v1[j]; acc[2][j] += v2[j]; acc[3][j] += v3[j]; }
     }
-    for (; sp < d.nsplit; sp += 4) a0 += src[sp * len + i];
+    for (; sp < d.nsplit; sp += 4) {
+      float v0[4];
+      load4(sp, v0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[0][j] += v0[j];
+    }
   }
-  part[g][e] = (a0 + a1) + (a2 + a3);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) part[g][e4 + j] = (acc[0][j] + acc[1][j]) + (acc[2][j] + acc[3][j]);
   __syncthreads();
-  if (g == 0 && i < len) {
-    const float sum = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
-    if (bias_blk) {
-      d.db[i] += sum;
-    } else {
-      const int ci = (int)(i % d.Cin), co = (int)((i / d.Cin) % d.Cout), k = (int)(i / d.Cin / d.Cout);
-      d.dw[((int64_t)co * d.Cin + ci) * d.K + k] += sum;
+  if (g == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t i = i0 + j;
+      if (i >= len) continue;
+      const float sum = (part[0][e4 + j] + part[1][e4 + j]) + (part[2][e4 + j] + part[3][e4 + j]);
+      if (bias_blk) {
+        d.db[i] += sum;
+      } else {
+        const int ci = (int)(i % d.Cin), co = (int)((i / d.Cin) % d.Cout), k = (int)(i / d.Cin / d.Cout);
+        d.dw[((int64_t)co * d.Cin + ci) * d.K + k] += sum;
+      }
     }
   }
 }

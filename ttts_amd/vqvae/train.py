@@ -506,6 +506,10 @@ def run(rank, n_gpus, hps, train_loader=None, steps_per_epoch=100):
         raise ops.TttsError("ttts.vqvae.train needs a GPU (no CPU fallback)")
     torch.cuda.set_device(device)
     net_g, net_d, optim_g, optim_d, aug, dp = build_parts(hps, device)
+    # everything built so far lives as long as the run: keep it out of the cyclic collector's passes (an eager step creates ~10^5
+    # short-lived objects, and a full collection inside a step is a millisecond-scale gap in the launch stream)
+    import gc
+    gc.collect(); gc.freeze()
     if train_loader is None:
         if getattr(hps.dataset, "path", "synthetic") != "synthetic":
             raise NotImplementedError("ttts.vqvae.train ships the synthetic data source; pass train_loader= for real data "
