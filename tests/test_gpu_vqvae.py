@@ -1109,6 +1109,10 @@ def test_weight_split_first_sighting_is_private_to_its_stream():
     cache.close()
     y4 = ops.conv1d_fwd(x, w, None, None, 1, 2, 1)              # the closed cache is out of every context
     assert torch.equal(y4, ref)
+    # per-stream contexts (1.5 GB of scratch each) can be retired: the side streams' go, the current stream's stays and still works
+    n_before = len(ops._conv_ctxs)
+    assert ops.release_conv_ctxs(_dev()) >= 2 and len(ops._conv_ctxs) <= n_before - 2
+    assert torch.equal(ops.conv1d_fwd(x, w, None, None, 1, 2, 1), ref)
 
 
 @pytest.mark.bf16x3

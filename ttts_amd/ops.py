@@ -961,6 +961,27 @@ def _conv_ctx(device):
 
 
 
+def release_conv_ctxs(device=None, keep_current=True):
+    """Drop the per-stream convolution contexts (and their 1.5 GB scratch buffers each) of `device` -- all devices when None -- after a
+    device synchronisation; with keep_current the context of torch's current stream stays.  Contexts are otherwise kept for the life of
+    the process (one per stream that ever ran a convolution: ~12 for the VQ-VAE-GAN step with its branch streams); call this when a
+    set of side streams is retired, e.g. between a training run and an evaluation that uses none.  Returns the number dropped."""
+    if not _conv_ctxs:
+        return 0
+    torch.cuda.synchronize()
+    want = None if device is None else _ordinal(device)
+    dropped = 0
+    for key in list(_conv_ctxs):
+        idx, stream = key
+        if want is not None and idx != want:
+            continue
+        if keep_current and stream == _raw_stream(idx):
+            continue
+        del _conv_ctxs[key]
+        dropped += 1
+    return dropped
+
+
 def conv1d_fwd(x, w, bias=None, resid=None, stride=1, pad=0, dil=1, in_slope=1.0, out_act=None, out_scale=1.0,
                out=None, accumulate=False, bbias=None, gate=None, gate_slope=1.0, groups=1, out_slope=1.0, omask=None):
     """y = [y +] out_scale * act(lrelu'(gate) * (bias + bbias + conv1d(lrelu(x, in_slope), w)) + resid);
