@@ -1413,23 +1413,24 @@ __global__ __launch_bounds__(256) void wgrad_split_pair_kernel(WgradSplitPair p)
 __device__ __forceinline__ void wgrad_split_cat_body(const float* __restrict__ src, bf16* __restrict__ hi, bf16* __restrict__ lo,
                                                      int B, int C, int L, int Lg, int shift, int Lrow, float slope,
                                                      float* __restrict__ db, int S, int bx, int by, float* sh) {
-  // by = channel * S + phase; element v of the virtual row: b = v / Lg, j = v % Lg, source position j*S + phase - shift.
-  // Eight adjacent elements per thread, 16-byte stores (Lrow is a multiple of 8), as in wgrad_split_dy_body.
-  const int c = by / S, ph = by % S, v0 = (bx * 256 + threadIdx.x) * 8;
+  // by = channel * S + phase; element v of the virtual row: b = v / Lg, j = v % Lg, source position j*S + phase - shift
+  const int c = by / S, ph = by % S, v0 = (bx * 256 + threadIdx.x) * 2;
   float bs = 0.f;
   if (v0 < Lrow) {
-    float val[8];
-    int b = v0 / Lg, jj = v0 - b * Lg;                       // (one division per thread; the batch element advances by carry)
+    float val[2];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int j = jj * S + ph - shift;
+    for (int e = 0; e < 2; ++e) {
+      const int v = v0 + e, b = v / Lg, j = (v - b * Lg) * S + ph - shift;
       const bool ok = b < B && j >= 0 && j < L;
       const float t = src[((int64_t)min(b, B - 1) * C + c) * L + min(max(j, 0), L - 1)];
       val[e] = ok ? lrelu_f(t, slope) : 0.f;
-      bs += val[e];
-      if (++jj == Lg) { jj = 0; ++b; }
     }
-    wgrad_split_store8(val, hi + (int64_t)by * Lrow + v0, lo + (int64_t)by * Lrow + v0);
+    bs = val[0] + val[1];
+    bf16x2 h, w;
+    h[0] = (bf16)val[0]; h[1] = (bf16)val[1];
+    w[0] = (bf16)(val[0] - (float)h[0]); w[1] = (bf16)(val[1] - (float)h[1]);
+    *reinterpret_cast<bf16x2*>(hi + (int64_t)by * Lrow + v0) = h;
+    *reinterpret_cast<bf16x2*>(lo + (int64_t)by * Lrow + v0) = w;
   }
   if (db) {
     bs = wave_sum(bs);
@@ -1449,9 +1450,9 @@ __global__ __launch_bounds__(256) void wgrad_split_cat_pair_kernel(WgradCatSide 
 static void launch_wgrad_cat_pair(const float* dy, bf16* dyh, bf16* dyl, int Cout, int Lout, int Lq, float dy_slope, float* db,
                                   const float* x, bf16* xh, bf16* xl, int Cin, int Lin, int shift, int Li, float x_slope, int S, int B,
                                   int Lg, hipStream_t stream) {
-  WgradCatSide a{dy, dyh, dyl, Cout, Lout, 0, Lq, dy_slope, db, 1, (int)cdiv(Lq / 8, 256), 0};
+  WgradCatSide a{dy, dyh, dyl, Cout, Lout, 0, Lq, dy_slope, db, 1, (int)cdiv(Lq / 2, 256), 0};
   a.nb = a.nbx * Cout;
-  WgradCatSide b{x, xh, xl, Cin, Lin, shift, Li, x_slope, nullptr, S, (int)cdiv(Li / 8, 256), 0};
+  WgradCatSide b{x, xh, xl, Cin, Lin, shift, Li, x_slope, nullptr, S, (int)cdiv(Li / 2, 256), 0};
   b.nb = b.nbx * Cin * S;
   wgrad_split_cat_pair_kernel<<<(unsigned)(a.nb + b.nb), 256, 0, stream>>>(a, b, B, Lg);
 }
