@@ -581,11 +581,11 @@ def main():
     # (same box, same code: the VQ-VAE-GAN leg reads 123.7 ms alone and 128.8 ms after the GPT leg, while its hipGraph replay reads
     # the same 129 ms either way: HISTORY 18.4).  The GPT leg is a graph replay and does not care what ran before it.
     pre = {}
+    if world == 1 and not args.no_diffusion:           # (all-eager: ahead of the VQ-VAE-GAN leg, which ends with a graph recording)
+        pre["diffusion"] = diffusion_leg(dev, args.diffusion_steps, 3, cpu_leg=not args.no_cpu_baseline)
+        torch.cuda.empty_cache()
     if world == 1 and not args.no_vqvae:
         pre["vqvae"] = vqvae_leg(dev, args.vqvae_steps, 2, cpu_leg=not args.no_cpu_baseline)
-        torch.cuda.empty_cache()
-    if world == 1 and not args.no_diffusion:
-        pre["diffusion"] = diffusion_leg(dev, args.diffusion_steps, 3, cpu_leg=not args.no_cpu_baseline)
     if pre:
         ops.release_conv_ctxs(keep_current=False)          # the legs' per-stream convolution scratch (1.5 GB each)
         gc.collect()
