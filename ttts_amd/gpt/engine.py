@@ -126,6 +126,7 @@ class GptEngine:
         self.seed = int(seed)
         self.step_count = 0                 # optimizer steps taken (host mirror)
         self.dw_split_overlap = os.environ.get("TTTS_DW_SPLIT_OVERLAP", "0") == "1"   # grouped dW of the upper half under the lower half's chain
+        self.tail_overlap = os.environ.get("TTTS_TAIL_OVERLAP", "0") == "1"   # small end-of-backward launches beside the grouped dW (see _run_dw)
         self.overlap_dw = os.environ.get("TTTS_OVERLAP_DW", "0") == "1"   # dW GEMMs on a side stream (see backward);
         # off by default: measured +0.7 % only, and concurrent kernels blur per-kernel profiles
         # Deferred, grouped weight gradients (see _dw_plan): every layer keeps its four dY buffers and ALL dW GEMMs of a
@@ -367,15 +368,32 @@ class GptEngine:
         self._dw_plans[key] = (plans, single, ln_plan, cs_plans)
         return self._dw_plans[key]
 
-    def _run_dw(self, lo, hi, heads):
+    def _run_dw(self, lo, hi, heads, tail=None):
+        """The section's weight gradients (grouped launches), LayerNorm parameter gradients and bias column sums.  `tail`: a callable
+        with more small independent work of the section (the embedding backward).  With tail_overlap the small launches -- each a
+        few dozen workgroups, 30 + 39 + 24 us run one after the other -- go to the side stream and run beside the grouped
+        weight-gradient launch and beside each other (all four write disjoint gradient rows and only read the section's buffers)."""
         plans, single, ln_plan, cs_plans = self._dw_plan(lo, hi, heads)
+
+        def small():
+            ln_plan.run()
+            for plan in cs_plans:
+                plan.run()
+            if tail is not None:
+                tail()
+        if self.tail_overlap:
+            main, side = torch.cuda.current_stream(), self._side_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                small()
         for plan in plans:
             plan.run()
         for at, bt, g in single:
             ops.gemm_tn_accum(at, bt, g, workspace=self.b["tn_ws"])
-        ln_plan.run()
-        for plan in cs_plans:
-            plan.run()
+        if self.tail_overlap:
+            main.wait_stream(side)
+        else:
+            small()
 
     def _padded(self, t):
         """The zero-row-padded [Mp, c] buffer behind an [M, c] activation view (weight-gradient GEMM operand)."""
@@ -532,12 +550,15 @@ class GptEngine:
         ev_fc = ev_qkv = None            # side-stream reads of d_fc / dqkv by the previous layer
         for i in reversed(range(lo_layer, hi_layer)):
             ev_fc, ev_qkv = self._backward_layer(i, side, fork, done, wait, ev_fc, ev_qkv)
-        if self.grouped_dw and (hi_layer > lo_layer or part in (None, 0)):
-            self._run_dw(lo_layer, hi_layer, part in (None, 0))   # the head / final-norm gradients belong to the section that ran _backward_head
-        if part in (None, 1):
+        def embed_tail():
             ops.embed_bwd(b["text_inp"], b["mel_inp"], b["dres"], G("text_embedding.weight"),
                           G("text_pos_embedding.emb.weight"), G("mel_embedding.weight"), G("mel_pos_embedding.emb.weight"),
                           p, self._seed(1), counter=self.seed_ctr)
+        ran_dw = self.grouped_dw and (hi_layer > lo_layer or part in (None, 0))
+        if ran_dw:      # (the head / final-norm gradients belong to the section that ran _backward_head)
+            self._run_dw(lo_layer, hi_layer, part in (None, 0), tail=embed_tail if part in (None, 1) else None)
+        if part in (None, 1) and not ran_dw:
+            embed_tail()
         if side is not main:
             main.wait_stream(side)       # join: the optimizer / all-reduce needs every dW
 
