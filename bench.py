@@ -349,13 +349,19 @@ def diffusion_leg(dev, steps, warmup, cpu_leg=True):
         + 3 * (resb(T) + attn(T)) + 2 * T * 100 * C * 3 + 2 * T * 2 * C * C + 6 * (resb(T) + attn(T)) + 3 * resb(T) + 2 * T * C * 200 * 3
     ach = 3.0 * fwd * B / dt / 1e12
     peak = PEAK_BF16_TFLOPS / 3.0
+    try:
+        diff_traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["diffusion_step"]["bytes_per_step"]
+    except Exception:
+        diff_traffic = None
     res = {"metric": "diffusion_train_mel_frames_per_sec", "value": round(B * T / dt, 1), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 2),
            "steps": steps, "warmup": warmup,
            "dtype": "f32 (conv / linear products as split-bf16 x3 on the bf16 MFMA, attention GEMMs on the exact f32 MFMA) -- wider than config #5's bf16 + fp8",
            "config": {"workload": "AA_diffusion train step (q_sample, model, mse + learned-range VB, backward, clip 1.0, AdamW), batch 16 x "
                                   "(100 x 400 mel, 512 x 100 latent, 100 x 200 reference), 43.2 M parameters, eager launches"},
            "roofline": {"bound": "mfma", "kernel": "whole step (convolution family + attention GEMMs)", "achieved": round(ach, 2),
-                        "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                        "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": diff_traffic,
+                        "traffic_note": "HBM-side bytes of ALL kernels of one step from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json: "
+                                        "FETCH_SIZE x 2 + WRITE_SIZE), not measured in this run; the step materialises its (B, H, T, T) attention scores",
                         "note": "algorithmic FLOPs = 3 x forward (%.1f GFLOP per sample) / step time; peak = bf16 MFMA / 3 (an fp32 product "
                                 "costs three bf16 products)" % (fwd / 1e9)},
            "loss": round(loss, 4), "grad_norm": round(float(out["grad_norm"]), 4), "fp8_gemms": fp8}
