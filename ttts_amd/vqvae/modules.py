@@ -549,6 +549,60 @@ def _wn_conv_new(channels, k, d):
     return Conv1d(channels, channels, k, 1, dilation=d, padding=get_padding(k, d)).apply_weight_norm("new")
 
 
+def _wgrad_into_slots(dy, x, w_ref, b_ref, k, pad, dil, x_slope, need_w, need_b):
+    """Weight (+ bias) gradient of one stride-1 convolution the way _Conv1dFn.backward routes it: straight into the parameters'
+    persistent .grad slots where they exist (then None is returned for autograd), else into the weight-norm buffer / a fresh tensor."""
+    dw = db = None
+    want_b = b_ref is not None and need_b
+    bslot = _grad_slot(b_ref) if want_b else None
+    if need_w:
+        slot = _grad_slot(w_ref)
+        slot_w = None if slot is not None else _take_dw_buffer(w_ref)
+        if want_b:
+            db = bslot if bslot is not None else torch.zeros(dy.shape[1], dtype=torch.float32, device=dy.device)
+        dw = ops.conv1d_wgrad(dy, x, k, 1, pad, dil, x_slope=x_slope, out=slot if slot is not None else slot_w, db=db if want_b else None)
+        if slot is not None:
+            dw = None
+    elif want_b:
+        db = ops.conv1d_bias_grad(dy, out=bslot)
+    if bslot is not None:
+        db = None
+    return dw, db
+
+
+class _ResPairFn(torch.autograd.Function):
+    """y = x + c2(lrelu(c1(lrelu(x)))) -- one (dilated, plain) pair of ResBlock1 -- as ONE autograd node.  As two nodes, x has two
+    consumers (c1's input and c2's fused residual), so the engine finished every pair's backward with `grad_x = dgrad(c1) + dy`: an
+    elementwise launch over the activation (135 of them per VQ-VAE-GAN step, ~11 GB of traffic at config #3).  Here dy rides into
+    c1's data gradient as its `resid` epilogue operand: the same two fp32 numbers are added, in the kernel -- bit-identical."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, pad1, dil1, pad2, slope):
+        x = x.contiguous()
+        xt = ops.conv1d_fwd(x, w1, b1, None, 1, pad1, dil1, slope)
+        y = ops.conv1d_fwd(xt, w2, b2, x, 1, pad2, 1, slope)
+        ctx.save_for_backward(x, xt, w1, w2)
+        ctx.cfg = (pad1, dil1, pad2, slope)
+        ctx.refs = (w1, b1, w2, b2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, xt, w1, w2 = ctx.saved_tensors
+        pad1, dil1, pad2, slope = ctx.cfg
+        r1, rb1, r2, rb2 = ctx.refs
+        need = ctx.needs_input_grad
+        dy = dy.contiguous()
+        gate_t = xt if slope != 1.0 else None
+        d_xt = ops.conv1d_dgrad(dy, w2, xt.shape[2], 1, pad2, 1, gate=gate_t, gate_slope=slope)
+        dw2, db2 = _wgrad_into_slots(dy, xt, r2, rb2, w2.shape[2], pad2, 1, slope, need[3], need[4])
+        dx = None
+        if need[0]:
+            dx = ops.conv1d_dgrad(d_xt, w1, x.shape[2], 1, pad1, dil1, gate=x if slope != 1.0 else None, gate_slope=slope, resid=dy)
+        dw1, db1 = _wgrad_into_slots(d_xt, x, r1, rb1, w1.shape[2], pad1, dil1, slope, need[1], need[2])
+        return dx, dw1, db1, dw2, db2, None, None, None, None
+
+
 class ResBlock1(nn.Module):
     """ttts/vqvae/modules.py:224-318: x <- x + c2(lrelu(c1(lrelu(x)))) for three (dilated, plain) conv pairs.  The two
     leaky-relus and the residual add are fused into the convolutions."""
@@ -561,9 +615,14 @@ class ResBlock1(nn.Module):
     def forward(self, x, x_mask=None):
         if x_mask is not None:
             raise NotImplementedError("ResBlock1 with x_mask is not on the training path (vq2.py never passes one)")
+        fused = _env_int("TTTS_RESPAIR", 0) == 1          # opt-in: measured level with the two-node form (HISTORY 18.4)
         for c1, c2 in zip(self.convs1, self.convs2):
-            xt = c1(x, in_slope=LRELU_SLOPE)
-            x = c2(xt, in_slope=LRELU_SLOPE, resid=x)
+            if fused:          # one autograd node per pair: the residual's gradient is added in c1's data-gradient epilogue
+                x = _ResPairFn.apply(x, c1.effective_weight(), c1.bias, c2.effective_weight(), c2.bias, c1.padding, c1.dilation,
+                                     c2.padding, LRELU_SLOPE)
+            else:
+                xt = c1(x, in_slope=LRELU_SLOPE)
+                x = c2(xt, in_slope=LRELU_SLOPE, resid=x)
         return x
 
 
