@@ -499,6 +499,13 @@ typedef struct ttts_conv_ctx {
   int32_t reserved;
 } ttts_conv_ctx;
 #define TTTS_CONV_EXACT_F32 4096
+#define TTTS_CONV_F16X1 1024             /* ABI v10: single-pass "TF32-class" arithmetic for the matrix-core convolutions: operands
+                                          * rounded to fp16 (11 significant bits, what the reference's TF32 cuDNN convolutions carry,
+                                          * ttts/vqvae/train.py:34-36; saturating at +-65504), ONE fp16 MFMA product per pair with fp32
+                                          * accumulation instead of the three bf16 products of the split form.  Forward and data
+                                          * gradient; weight gradients keep the split form (wider, 14 % of the family's time).  The
+                                          * data gradient's input needs the caller's loss scaling to stay inside fp16's range
+                                          * (ttts_amd.vqvae.train applies 2^10).  Ignored with TTTS_CONV_EXACT_F32. */
 #define TTTS_CONV_DIRECT_ONLY 256        /* experiments: every convolution on the direct (non-MFMA) kernels */
 #define TTTS_CONV_SMALL_TILES 2048       /* experiments: allow the small MFMA tile shapes */
 #define TTTS_CONV_FORCE_SPLIT_WGRAD 8192 /* tests: split-bf16 weight gradient for every shape */

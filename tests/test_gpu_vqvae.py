@@ -1142,3 +1142,37 @@ def test_backward_through_branch_streams_joins_by_itself():
             assert torch.equal(one, many) or float((one - many).abs().max()) <= 1e-6 * float(one.abs().max())
     finally:
         os.environ.pop("TTTS_D_STREAMS", None)
+
+
+# ---- round 5: the single-pass "TF32-class" convolution mode (TTTS_CONV_F16X1) ----------------------------------------------------------
+@pytest.mark.bf16x3
+@pytest.mark.parametrize("case", [(64, 64, 11, 1, 25, 5, 2048), (192, 384, 5, 1, 2, 1, 256), (512, 1024, 5, 3, 2, 1, 253),
+                                  (1024, 1024, 5, 1, 2, 1, 23), (32, 16, 16, 1, 7, 1, 400), (256, 320, 5, 1, 2, 1, 37),
+                                  (192, 192, 1, 1, 0, 1, 256), (16, 32, 16, 10, 7, 1, 3000), (128, 256, 16, 8, 4, 1, 333),
+                                  (40, 24, 7, 2, 3, 1, 501)])
+def test_tf32class_conv_accuracy(case):
+    """The single-pass mode: operands rounded to fp16 (11 significant bits = TF32's), one MFMA product, fp32 accumulation.
+    Stated tolerance: 1.5e-3 of the output range for the forward, the data gradient and the weight gradient (TF32's own class:
+    2^-11 per operand; measured ~3e-4), against the fp64 convolution -- and NOT equal to the split-bf16 result, i.e. the mode is
+    really on.  Covers the on-the-fly kernel, the DMA kernel, phase-merged strided forms, 1 x 1 and folded short rows."""
+    from ttts_amd import ops
+    cin, cout, k, s, pad, dil, L = case
+    g = torch.Generator().manual_seed(cin + k)
+    x = torch.randn(3, cin, L, generator=g); w = torch.randn(cout, cin, k, generator=g) / (cin * k) ** 0.5
+    yr = F.conv1d(F.leaky_relu(x.double(), 0.1), w.double(), stride=s, padding=pad, dilation=dil)
+    dy = torch.randn(yr.shape, generator=g)
+    dxr = torch.nn.grad.conv1d_input(x.shape, w.double(), dy.double(), stride=s, padding=pad, dilation=dil)
+    dwr = torch.nn.grad.conv1d_weight(F.leaky_relu(x.double(), 0.1), w.shape, dy.double(), stride=s, padding=pad, dilation=dil)
+    y0 = ops.conv1d_fwd(x.to(_dev()), w.to(_dev()), None, None, s, pad, dil, in_slope=0.1)
+    prev = ops.set_conv_precision("tf32class")
+    try:
+        y = ops.conv1d_fwd(x.to(_dev()), w.to(_dev()), None, None, s, pad, dil, in_slope=0.1)
+        dx = ops.conv1d_dgrad(dy.to(_dev()), w.to(_dev()), L, s, pad, dil)
+        dw = ops.conv1d_wgrad(dy.to(_dev()), x.to(_dev()), k, s, pad, dil, x_slope=0.1)
+    finally:
+        ops.set_conv_precision(prev)
+    _close(y, yr, 1.5e-3, 0, "y")
+    _close(dx, dxr, 1.5e-3, 0, "dx")
+    _close(dw, dwr, 1.5e-3, 0, "dw")
+    if cin >= 16:          # (narrower layers never take the matrix-core path: both modes run the same direct kernel)
+        assert not torch.equal(y, y0)

@@ -151,6 +151,17 @@ __device__ __forceinline__ float4 ln_row_apply(const float4& v, float mean, floa
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+// v_mfma_f32_32x32x16_f16 on operands that are STORED in bf16-typed arrays (same 2 bytes per element, same fragment layout): the
+// single-pass "TF32-class" convolution mode (fp16 has the 11 significant bits TF32 has; fp32 accumulation).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma32_f16(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// fp32 -> fp16 (round to nearest even, saturating at +-65504 instead of overflowing to inf), returned in a bf16-typed slot
+__device__ __forceinline__ bf16 f16_slot(float v) {
+  v = fminf(fmaxf(v, -65504.f), 65504.f);
+  return __builtin_bit_cast(bf16, (_Float16)v);
+}
 // row index inside a 32x32 accumulator tile held by (reg r, lane-half h = lane >> 5)
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 

@@ -193,7 +193,8 @@ __global__ __launch_bounds__(64 * NW) void conv1d_mfma_kernel(ConvMfmaParams p) 
 // above MFMA time)
 __global__ __launch_bounds__(256) void conv_input_split_kernel(const float* __restrict__ x, bf16* __restrict__ hi,
                                                                bf16* __restrict__ lo, int B, int N, int L, int nblk, float slope,
-                                                               int Lp, int PADL, int catW, int catB, int catL, int inS = 0, int Lreal = 0) {
+                                                               int Lp, int PADL, int catW, int catB, int catL, int inS = 0, int Lreal = 0,
+                                                               int f16 = 0) {
   // one thread per (batch element, 16-channel block, padded position): 16 coalesced row reads, four 16-byte stores.
   // catW > 0: ONE destination row (B == 1) holding the catB source rows of length catL end to end, catW positions apart
   const int64_t total = (int64_t)B * nblk * Lp;
@@ -232,15 +233,17 @@ __global__ __launch_bounds__(256) void conv_input_split_kernel(const float* __re
     for (int c = 0; c < 16; ++c) {
       float v = (inside && okc[c] && nb * 16 + c < N) ? raw[c] : 0.f;
       v = lrelu_f(v, slope);
-      const bf16 hv = (bf16)v;
+      const bf16 hv = f16 ? f16_slot(v) : (bf16)v;       // (f16: the single-pass mode's fp16 copy; the lo array is not written)
       const bf16 lv = (bf16)(v - (float)hv);
       if (c < 8) { h0[c] = hv; l0[c] = lv; } else { h1[c - 8] = hv; l1[c - 8] = lv; }
     }
     const int64_t o = ((((i / Lp / nblk) * nblk + nb) * 2) * Lp + pp) * 8;        // half 0; half 1 is Lp * 8 elements further
     *reinterpret_cast<bf16x8*>(hi + o) = h0;
     *reinterpret_cast<bf16x8*>(hi + o + (int64_t)Lp * 8) = h1;
-    *reinterpret_cast<bf16x8*>(lo + o) = l0;
-    *reinterpret_cast<bf16x8*>(lo + o + (int64_t)Lp * 8) = l1;
+    if (!f16) {
+      *reinterpret_cast<bf16x8*>(lo + o) = l0;
+      *reinterpret_cast<bf16x8*>(lo + o + (int64_t)Lp * 8) = l1;
+    }
   }
 }
 
@@ -264,7 +267,7 @@ __device__ __forceinline__ float merged_fwd_weight(const float* __restrict__ w, 
 __global__ __launch_bounds__(256) void conv_weight_split_kernel(const float* __restrict__ w, bf16* __restrict__ a_hi,
                                                                 bf16* __restrict__ a_lo, int M, int N, int Mpad, int nblk,
                                                                 int K, int Kmem, int transposed, int tap_off, int tap_stride, int AP,
-                                                                int rowS = 0, int rpad = 0, int vpad = 0) {
+                                                                int rowS = 0, int rpad = 0, int vpad = 0, int f16 = 0) {
   // rows of AP >= K*16 elements ([tap][16 channels], zero tail): AP = K*16 + 8 is the LDS row pitch of the DMA-fed kernel,
   // whose stages are verbatim copies of [MT rows][AP] runs of these arrays
   const int64_t total = (int64_t)nblk * Mpad * AP;
@@ -279,9 +282,9 @@ __global__ __launch_bounds__(256) void conv_weight_split_kernel(const float* __r
       else if (rowS < 0) v = merged_fwd_weight(w, m, n, k, N / -rowS, Kmem, -rowS, rpad, vpad);
       else v = transposed ? w[((int64_t)n * M + m) * Kmem + tap_off + tap_stride * (K - 1 - k)] : w[((int64_t)m * N + n) * Kmem + k];
     }
-    const bf16 h = (bf16)v;
+    const bf16 h = f16 ? f16_slot(v) : (bf16)v;
     a_hi[i] = h;
-    a_lo[i] = (bf16)(v - (float)h);
+    if (!f16) a_lo[i] = (bf16)(v - (float)h);
   }
 }
 
@@ -296,6 +299,7 @@ struct WsplitDesc {
   const float* w; bf16* hi; bf16* lo;
   int M, N, Mpad, nblk, K, Kmem, transposed, tap_off, tap_stride, AP;
   int block_begin, rowS, rpad, vpad;
+  int f16, pad2_;                     // f16: single-pass mode (fp16 copy in `hi`, `lo` unused)
 };
 constexpr int WSPLIT_EPB = 2048;      // elements per workgroup of the batched launch (8 per thread)
 
@@ -322,25 +326,26 @@ __global__ __launch_bounds__(256) void conv_weight_split_batched_kernel(const Ws
       else v = d.transposed ? d.w[((int64_t)n * d.M + m) * d.Kmem + d.tap_off + d.tap_stride * (d.K - 1 - k)]
                             : d.w[((int64_t)m * d.N + n) * d.Kmem + k];
     }
-    const bf16 hv = (bf16)v;
+    const bf16 hv = d.f16 ? f16_slot(v) : (bf16)v;
     h[c] = hv;
     l[c] = (bf16)(v - (float)hv);
   }
   *reinterpret_cast<bf16x8*>(d.hi + i) = h;
-  *reinterpret_cast<bf16x8*>(d.lo + i) = l;
+  if (!d.f16) *reinterpret_cast<bf16x8*>(d.lo + i) = l;
 }
 
 struct WsplitKey {
-  const float* w; int M, N, Mpad, K, Kmem, transposed, tap_off, tap_stride, AP, rowS, rpad, vpad;
+  const float* w; int M, N, Mpad, K, Kmem, transposed, tap_off, tap_stride, AP, rowS, rpad, vpad, f16;
   bool operator==(const WsplitKey& o) const {
     return w == o.w && M == o.M && N == o.N && Mpad == o.Mpad && K == o.K && Kmem == o.Kmem && transposed == o.transposed &&
-           tap_off == o.tap_off && tap_stride == o.tap_stride && AP == o.AP && rowS == o.rowS && rpad == o.rpad && vpad == o.vpad;
+           tap_off == o.tap_off && tap_stride == o.tap_stride && AP == o.AP && rowS == o.rowS && rpad == o.rpad && vpad == o.vpad &&
+           f16 == o.f16;
   }
 };
 struct WsplitKeyHash {
   size_t operator()(const WsplitKey& k) const {
     uint64_t h = reinterpret_cast<uint64_t>(k.w) * 0x9E3779B97F4A7C15ull;
-    for (int v : {k.M, k.N, k.Mpad, k.K, k.Kmem, k.transposed, k.tap_off, k.tap_stride, k.AP, k.rowS, k.rpad, k.vpad})
+    for (int v : {k.M, k.N, k.Mpad, k.K, k.Kmem, k.transposed, k.tap_off, k.tap_stride, k.AP, k.rowS, k.rpad, k.vpad, k.f16})
       h = (h ^ (uint64_t)(uint32_t)v) * 0x100000001B3ull;
     return (size_t)h;
   }
@@ -374,7 +379,8 @@ static bool wsplit_lookup(const ConvMfmaParams& p, const ConvCtx& cx, int nblk, 
     if (!c || c->magic != TTTS_HANDLE_WSPLIT || wp < c->w_lo || wp >= c->w_hi) continue;
     std::lock_guard<std::mutex> g(c->mu);
     if (!c->armed) return false;
-    const WsplitKey key{p.w, p.M, p.N, p.Mpad, p.K, p.Kmem, p.transposed, p.tap_off, p.tap_stride, AP, p.rowS, p.rpad, p.pad};
+    const int f16 = (cx.flags & TTTS_CONV_F16X1) ? 1 : 0;
+    const WsplitKey key{p.w, p.M, p.N, p.Mpad, p.K, p.Kmem, p.transposed, p.tap_off, p.tap_stride, AP, p.rowS, p.rpad, p.pad, f16};
     auto it = c->index.find(key);
     if (it != c->index.end()) {
       if (c->first_writer[it->second] != nullptr && c->first_writer[it->second] != stream) { ++c->misses; return false; }
@@ -392,6 +398,7 @@ static bool wsplit_lookup(const ConvMfmaParams& p, const ConvCtx& cx, int nblk, 
     d.w = p.w; d.hi = reinterpret_cast<bf16*>(c->storage + c->used); d.lo = d.hi + elems_alloc;
     d.M = p.M; d.N = p.N; d.Mpad = p.Mpad; d.nblk = nblk; d.K = p.K; d.Kmem = p.Kmem; d.transposed = p.transposed;
     d.tap_off = p.tap_off; d.tap_stride = p.tap_stride; d.AP = AP; d.rowS = p.rowS; d.rpad = p.rpad; d.vpad = p.pad;
+    d.f16 = f16; d.pad2_ = 0;
     d.block_begin = (int)c->blocks;
     const int idx = (int)c->host.size();
     desc_store_kernel<WsplitDesc><<<1, 1, 0, stream>>>(reinterpret_cast<WsplitDesc*>(c->storage) + idx, d);
@@ -464,24 +471,33 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvMfmaParams& p, cons
 
 // ---- inner loop shared by the split-bf16 kernels: CW 32-row blocks of output channels x two 32-position blocks per wave,
 // fragments, then 6 CW MFMAs per tap
+// F16 (last template argument of everything below, default false): the single-pass mode (TTTS_CONV_F16X1) -- the `hi` arrays hold
+// fp16 values, the `lo` arrays are neither read nor multiplied, one MFMA group per tap instead of three.
 template <int CW>
 struct B3Frag { bf16x8 ah[CW], al[CW], bh[2], bl[2]; };
-template <int CW>
+template <int CW, bool F16 = false>
 __device__ __forceinline__ void b3_load(B3Frag<CW>& f, const bf16* xh, const bf16* xl, const bf16* ah, const bf16* al,
                                         const int (&arow)[CW], int bpos0, int bpos1, int k, int dil8) {
 #pragma unroll
   for (int i = 0; i < CW; ++i) {
     f.ah[i] = *reinterpret_cast<const bf16x8*>(ah + arow[i] + k * 16);
-    f.al[i] = *reinterpret_cast<const bf16x8*>(al + arow[i] + k * 16);
+    if (!F16) f.al[i] = *reinterpret_cast<const bf16x8*>(al + arow[i] + k * 16);
   }
   const int ko = k * dil8;
   f.bh[0] = *reinterpret_cast<const bf16x8*>(xh + bpos0 + ko);
-  f.bl[0] = *reinterpret_cast<const bf16x8*>(xl + bpos0 + ko);
+  if (!F16) f.bl[0] = *reinterpret_cast<const bf16x8*>(xl + bpos0 + ko);
   f.bh[1] = *reinterpret_cast<const bf16x8*>(xh + bpos1 + ko);
-  f.bl[1] = *reinterpret_cast<const bf16x8*>(xl + bpos1 + ko);
+  if (!F16) f.bl[1] = *reinterpret_cast<const bf16x8*>(xl + bpos1 + ko);
 }
-template <int CW>
+template <int CW, bool F16 = false>
 __device__ __forceinline__ void b3_mma(const B3Frag<CW>& f, f32x16 (&acc)[CW][2]) {
+  if constexpr (F16) {
+#pragma unroll
+    for (int i = 0; i < CW; ++i)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc[i][t] = mfma32_f16(f.ah[i], f.bh[t], acc[i][t]);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < CW; ++i)
 #pragma unroll
@@ -503,38 +519,48 @@ __device__ __forceinline__ void b3_mma(const B3Frag<CW>& f, f32x16 (&acc)[CW][2]
 // issues the NEXT stage's global_load_lds there, one or two at a time in the shadow of the running MFMAs, instead of a burst
 // of ~26 in front of the stage during which the wave feeds nothing to the matrix cores.  Same MFMA order as b3_mma: results
 // are bit-identical.
-template <int CW, int KT, typename Piece>
+template <int CW, int KT, bool F16 = false, typename Piece>
 __device__ __forceinline__ void b3_stage_pipe(const bf16* xh, const bf16* xl, const bf16* ah, const bf16* al, const int (&arow)[CW],
                                               int bpos0, int bpos1, int dil8, f32x16 (&acc)[CW][2], Piece&& piece) {
   B3Frag<CW> f[2];
-  b3_load<CW>(f[0], xh, xl, ah, al, arow, bpos0, bpos1, 0, dil8);
+  b3_load<CW, F16>(f[0], xh, xl, ah, al, arow, bpos0, bpos1, 0, dil8);
   __builtin_amdgcn_sched_barrier(0);       // (tap 0's reads stay ahead of tap 1's: the first wait is then counted too)
 #pragma unroll
   for (int k = 0; k < KT; ++k) {
     const B3Frag<CW>& c = f[k & 1];
-    if (k + 1 < KT) b3_load<CW>(f[(k + 1) & 1], xh, xl, ah, al, arow, bpos0, bpos1, k + 1, dil8);
+    if (k + 1 < KT) b3_load<CW, F16>(f[(k + 1) & 1], xh, xl, ah, al, arow, bpos0, bpos1, k + 1, dil8);
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (F16) {                   // one MFMA group per tap; the tap's three DMA slots follow it
 #pragma unroll
-    for (int i = 0; i < CW; ++i)
+      for (int i = 0; i < CW; ++i)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) acc[i][t] = mfma32(c.al[i], c.bh[t], acc[i][t]);
-    __builtin_amdgcn_sched_barrier(0);
-    piece(3 * k);
-    __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < 2; ++t) acc[i][t] = mfma32_f16(c.ah[i], c.bh[t], acc[i][t]);
+      __builtin_amdgcn_sched_barrier(0);
+      piece(3 * k); piece(3 * k + 1); piece(3 * k + 2);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
 #pragma unroll
-    for (int i = 0; i < CW; ++i)
+      for (int i = 0; i < CW; ++i)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) acc[i][t] = mfma32(c.ah[i], c.bl[t], acc[i][t]);
-    __builtin_amdgcn_sched_barrier(0);
-    piece(3 * k + 1);
-    __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < 2; ++t) acc[i][t] = mfma32(c.al[i], c.bh[t], acc[i][t]);
+      __builtin_amdgcn_sched_barrier(0);
+      piece(3 * k);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < CW; ++i)
+      for (int i = 0; i < CW; ++i)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) acc[i][t] = mfma32(c.ah[i], c.bh[t], acc[i][t]);
-    __builtin_amdgcn_sched_barrier(0);
-    piece(3 * k + 2);
-    __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < 2; ++t) acc[i][t] = mfma32(c.ah[i], c.bl[t], acc[i][t]);
+      __builtin_amdgcn_sched_barrier(0);
+      piece(3 * k + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < CW; ++i)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[i][t] = mfma32(c.ah[i], c.bh[t], acc[i][t]);
+      __builtin_amdgcn_sched_barrier(0);
+      piece(3 * k + 2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 }
 struct B3NoPiece { __device__ __forceinline__ void operator()(int) const {} };
@@ -551,28 +577,28 @@ __host__ __device__ constexpr bool b3_pipe() {
 
 // KT = compile-time tap count (0: runtime K).  With the taps unrolled the scheduler hoists the LDS fragment reads of later
 // taps above the MFMAs of earlier ones; the runtime loop waits for its six reads before every group of six MFMAs.
-template <int CW, int KT>
+template <int CW, int KT, bool F16 = false>
 __device__ __forceinline__ void b3_stage(const bf16* xh, const bf16* xl, const bf16* ah, const bf16* al, const int (&arow)[CW],
                                          int bpos0, int bpos1, int K, int dil8, f32x16 (&acc)[CW][2]) {
   // (an explicit two-deep fragment prefetch across taps with runtime K measured 10-14 % SLOWER than the plain loop: +44 VGPRs
   // and branchy control)
   if (KT > 0) {
     if constexpr (b3_pipe<CW, KT>()) {
-      b3_stage_pipe<CW, KT>(xh, xl, ah, al, arow, bpos0, bpos1, dil8, acc, B3NoPiece());
+      b3_stage_pipe<CW, KT, F16>(xh, xl, ah, al, arow, bpos0, bpos1, dil8, acc, B3NoPiece());
     } else {
 #pragma unroll
       for (int k = 0; k < KT; ++k) {
         B3Frag<CW> f;
-        b3_load<CW>(f, xh, xl, ah, al, arow, bpos0, bpos1, k, dil8);
-        b3_mma<CW>(f, acc);
+        b3_load<CW, F16>(f, xh, xl, ah, al, arow, bpos0, bpos1, k, dil8);
+        b3_mma<CW, F16>(f, acc);
       }
     }
   } else {
 #pragma unroll 2
     for (int k = 0; k < K; ++k) {
       B3Frag<CW> f;
-      b3_load<CW>(f, xh, xl, ah, al, arow, bpos0, bpos1, k, dil8);
-      b3_mma<CW>(f, acc);
+      b3_load<CW, F16>(f, xh, xl, ah, al, arow, bpos0, bpos1, k, dil8);
+      b3_mma<CW, F16>(f, acc);
     }
   }
 }
@@ -580,7 +606,7 @@ __device__ __forceinline__ void b3_stage(const bf16* xh, const bf16* xl, const b
 // Variant 1: the input is split ON THE FLY while it is staged (few output-channel tiles re-read it: the 16..128-channel
 // long-row layers, where a separate split pass would cost more HBM traffic than it saves).  Single LDS stage; overlap comes
 // from several workgroups per CU.
-template <int WCO, int KT>
+template <int WCO, int KT, bool F16 = false>
 __global__ __launch_bounds__(256) void conv1d_bf16x3_kernel(ConvMfmaParams p) {
   constexpr int MT = 32 * WCO, WL = 4 / WCO, LT = 64 * WL;
   extern __shared__ __attribute__((aligned(16))) float cm_smem[];
@@ -640,14 +666,16 @@ __global__ __launch_bounds__(256) void conv1d_bf16x3_kernel(ConvMfmaParams p) {
       for (int c = 0; c < 16; ++c) {
         float v = (ok && nb * 16 + c < p.N) ? raw[c] : 0.f;
         v = lrelu_f(v, p.in_slope);
-        const bf16 hv = (bf16)v;
+        const bf16 hv = F16 ? f16_slot(v) : (bf16)v;
         const bf16 lv = (bf16)(v - (float)hv);
         if (c < 8) { h0[c] = hv; l0[c] = lv; } else { h1[c - 8] = hv; l1[c - 8] = lv; }
       }
       *reinterpret_cast<bf16x8*>(xh + pp * 8) = h0;
       *reinterpret_cast<bf16x8*>(xh + xhalf + pp * 8) = h1;
-      *reinterpret_cast<bf16x8*>(xl + pp * 8) = l0;
-      *reinterpret_cast<bf16x8*>(xl + xhalf + pp * 8) = l1;
+      if (!F16) {
+        *reinterpret_cast<bf16x8*>(xl + pp * 8) = l0;
+        *reinterpret_cast<bf16x8*>(xl + xhalf + pp * 8) = l1;
+      }
     }
     // weights: the stage's [MT][K][16] slab is contiguous in the split arrays; 16-byte chunks, LDS slots precomputed (wlds)
     {
@@ -663,7 +691,8 @@ __global__ __launch_bounds__(256) void conv1d_bf16x3_kernel(ConvMfmaParams p) {
           const int i = g + j;
           if (i < WCH && i < nw) {
             const int ii = max(min(i, wlast), 0) * 2048;
-            vh[j] = *reinterpret_cast<const bf16x8*>(gh + ii); vl[j] = *reinterpret_cast<const bf16x8*>(gl + ii);
+            vh[j] = *reinterpret_cast<const bf16x8*>(gh + ii);
+            if (!F16) vl[j] = *reinterpret_cast<const bf16x8*>(gl + ii);
           }
         }
 #pragma unroll
@@ -671,13 +700,13 @@ __global__ __launch_bounds__(256) void conv1d_bf16x3_kernel(ConvMfmaParams p) {
           const int i = g + j;
           if (i < WCH && i < nw) {
             *reinterpret_cast<bf16x8*>(ah + wlds[i]) = vh[j];
-            *reinterpret_cast<bf16x8*>(ah + (wlds[i] == 2 * MT * apitch ? 2 * MT * apitch + 8 : wlds[i] + MT * apitch)) = vl[j];
+            if (!F16) *reinterpret_cast<bf16x8*>(ah + (wlds[i] == 2 * MT * apitch ? 2 * MT * apitch + 8 : wlds[i] + MT * apitch)) = vl[j];
           }
         }
       }
     }
     __syncthreads();
-    b3_stage<1, KT>(xh, xl, ah, al, arow, bpos0, bpos1, K, p.dil * 8, acc);
+    b3_stage<1, KT, F16>(xh, xl, ah, al, arow, bpos0, bpos1, K, p.dil * 8, acc);
   }
   conv_tile_epilogue<WCO>(p, acc[0][0], acc[0][1], wl, wco, col, hh, j0, m0, b0, SEG);
 }
@@ -693,7 +722,7 @@ __global__ __launch_bounds__(256) void conv1d_bf16x3_kernel(ConvMfmaParams p) {
 // CW = 2: waves 1 x 4, wave tile 64 x 64, workgroup tile 64 x 256: 8 fragment reads feed 12 MFMAs (6 : 6 above) and a weight
 //         stage is amortised over twice the positions -- for launches that still fill the chip with the larger tile.
 constexpr int V2_WC = 6;   // most 64-slot DMA chunks of one weight array a wave issues per stage (K <= 11)
-template <int CW, int KT>
+template <int CW, int KT, bool F16 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv1d_bf16x3_dma_kernel(ConvMfmaParams p) {
   constexpr int MT = 64, LT = 128 * CW, WCO = 2 / CW;
   constexpr int XC = CW == 1 ? 4 : 7;                       // most DMA chunks of one input array per wave and stage
@@ -757,14 +786,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
       if (nb0 + __builtin_amdgcn_readfirstlane(xblk[j]) < nblk) {      // wave-uniform: a scalar branch
         const bf16* g = xsrc[j] + nb0 * xstep;
         lds_dma16_untracked(g, st + (uint32_t)xdst[j] * 2u);
-        lds_dma16_untracked(g + xlo_d, st + (uint32_t)(xdst[j] + XS) * 2u);
+        if (!F16) lds_dma16_untracked(g + xlo_d, st + (uint32_t)(xdst[j] + XS) * 2u);     // (F16: the lo arrays are never read)
       }
     } else {
       const int j = i >= XC ? i - XC : 0;
       if (nb0 + __builtin_amdgcn_readfirstlane(wblk[j]) < nblk) {
         const bf16* g = wsrc[j] + nb0 * wstep;
         lds_dma16_untracked(g, st + (uint32_t)wdst[j] * 2u);
-        lds_dma16_untracked(g + wlo_d, st + (uint32_t)(wdst[j] + WS) * 2u);
+        if (!F16) lds_dma16_untracked(g + wlo_d, st + (uint32_t)(wdst[j] + WS) * 2u);
       }
     }
   };
@@ -798,7 +827,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
       // the next stage's DMA is issued piecewise between the MFMA groups of this stage's first block (3 KT slots)
       const bool more = si + 1 < nstage;
       constexpr int NSLOT = 3 * (KT > 0 ? KT : 1), NPIECE = XC + V2_WC;
-      b3_stage_pipe<CW, (KT > 0 ? KT : 1)>(sb, sb + XS, sb + 2 * XS, sb + 2 * XS + WS, arow, bpos0, bpos1, p.dil * 8, acc, [&](int slot) {
+      b3_stage_pipe<CW, (KT > 0 ? KT : 1), F16>(sb, sb + XS, sb + 2 * XS, sb + 2 * XS + WS, arow, bpos0, bpos1, p.dil * 8, acc, [&](int slot) {
         if (more) {
 #pragma unroll
           for (int i = 0; i < NPIECE; ++i)
@@ -808,14 +837,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
       for (int blk = 1; blk < NBS; ++blk) {
         if (si * NBS + blk >= nblk) break;
         const bf16* xh = sb + blk * STAGE1;
-        b3_stage<CW, KT>(xh, xh + XS, xh + 2 * XS, xh + 2 * XS + WS, arow, bpos0, bpos1, K, p.dil * 8, acc);
+        b3_stage<CW, KT, F16>(xh, xh + XS, xh + 2 * XS, xh + 2 * XS + WS, arow, bpos0, bpos1, K, p.dil * 8, acc);
       }
     } else {
       if (si + 1 < nstage) issue(si + 1, (si + 1) & 1);
       for (int blk = 0; blk < NBS; ++blk) {
         if (si * NBS + blk >= nblk) break;
         const bf16* xh = sb + blk * STAGE1;
-        b3_stage<CW, KT>(xh, xh + XS, xh + 2 * XS, xh + 2 * XS + WS, arow, bpos0, bpos1, K, p.dil * 8, acc);
+        b3_stage<CW, KT, F16>(xh, xh + XS, xh + 2 * XS, xh + 2 * XS + WS, arow, bpos0, bpos1, K, p.dil * 8, acc);
       }
     }
   }
@@ -1072,23 +1101,25 @@ static int conv1d_bf16x3_dma_launch(ConvMfmaParams p, const ConvCtx& cx, hipStre
   bool need_split = true;
   wsplit_lookup(p, cx, nblk, AP, welems, stream, &hi, &lo, &need_split);      // (persistent copies when the weights are cached)
   p.a_hi = hi; p.a_lo = lo;
+  const int f16 = (cx.flags & TTTS_CONV_F16X1) ? 1 : 0;
   if (need_split)
     conv_weight_split_kernel<<<(int)std::min<int64_t>(cdiv(welems, 256), 2048), 256, 0, stream>>>(p.w, hi, lo, p.M, p.N, p.Mpad, nblk, K, p.Kmem,
-                                                                                               p.transposed, p.tap_off, p.tap_stride, AP, p.rowS, p.rpad, p.pad);
+                                                                                               p.transposed, p.tap_off, p.tap_stride, AP, p.rowS, p.rpad, p.pad, f16);
   if (!p.x_hi) {   // (polyphase data gradients share one split of dy across their phase launches)
     conv_input_split_kernel<<<(int)std::min<int64_t>(cdiv(xel / 16, 256), 8192), 256, 0, stream>>>(p.x, xhi, xlo, p.B, p.N, p.Lin, nblk, p.in_slope,
-                                                                                                   p.Lp, p.PADL, cat_w, cat_b, cat_l, p.rowS < 0 ? -p.rowS : 0, p.Lreal);
+                                                                                                   p.Lp, p.PADL, cat_w, cat_b, cat_l, p.rowS < 0 ? -p.rowS : 0, p.Lreal, f16);
     p.x_hi = xhi; p.x_lo = xlo;
   }
   dim3 grid((unsigned)cdiv(p.Lout, SEG == LT ? LT : SEG), (unsigned)cdiv(p.M, MT), (unsigned)cdiv(p.B, LT / SEG));
   int rc = TTTS_OK;
-#define TTTS_DMA(CW_, KT_)                                                                                       \
+#define TTTS_DMA1(CW_, KT_, F_)                                                                                  \
   {                                                                                                               \
     static OnceFlag attr_;                                                                                    \
-    rc = set_attr_once(reinterpret_cast<const void*>(conv1d_bf16x3_dma_kernel<CW_, KT_>), attr_);                 \
+    rc = set_attr_once(reinterpret_cast<const void*>(conv1d_bf16x3_dma_kernel<CW_, KT_, F_>), attr_);             \
     if (rc) return rc;                                                                                            \
-    conv1d_bf16x3_dma_kernel<CW_, KT_><<<grid, 256, dma_smem, stream>>>(p);                                        \
+    conv1d_bf16x3_dma_kernel<CW_, KT_, F_><<<grid, 256, dma_smem, stream>>>(p);                                    \
   }
+#define TTTS_DMA(CW_, KT_) if (f16) TTTS_DMA1(CW_, KT_, true) else TTTS_DMA1(CW_, KT_, false)
 #define TTTS_DMA_K(CW_)                                                                                          \
   switch ((cx.flags & 33554432) ? 0 : K) {   /* flag 33554432: runtime tap loop everywhere */                    \
     case 1: TTTS_DMA(CW_, 1) break; case 2: TTTS_DMA(CW_, 2) break; case 3: TTTS_DMA(CW_, 3) break; case 5: TTTS_DMA(CW_, 5) break; \
@@ -1097,6 +1128,7 @@ static int conv1d_bf16x3_dma_launch(ConvMfmaParams p, const ConvCtx& cx, hipStre
   if (CW == 1) TTTS_DMA_K(1) else TTTS_DMA_K(2)
 #undef TTTS_DMA_K
 #undef TTTS_DMA
+#undef TTTS_DMA1
   *handled = true;
   return check_launch("conv1d_bf16x3_dma");
 }
@@ -1129,23 +1161,26 @@ static int conv1d_bf16x3_launch_t(ConvMfmaParams p, const ConvCtx& cx, hipStream
   bool need_split = true;
   wsplit_lookup(p, cx, nblk, K * 16, elems, stream, &hi, &lo, &need_split);
   p.a_hi = hi; p.a_lo = lo;
+  const int f16 = (cx.flags & TTTS_CONV_F16X1) ? 1 : 0;
   if (need_split)
     conv_weight_split_kernel<<<(int)std::min<int64_t>(cdiv(elems, 256), 2048), 256, 0, stream>>>(p.w, hi, lo, p.M, p.N, p.Mpad, nblk, K, p.Kmem,
-                                                                                              p.transposed, p.tap_off, p.tap_stride, K * 16, p.rowS, p.rpad, p.pad);
+                                                                                              p.transposed, p.tap_off, p.tap_stride, K * 16, p.rowS, p.rpad, p.pad, f16);
   dim3 grid((unsigned)cdiv(p.Lout, SEG == LT ? LT : SEG), (unsigned)cdiv(p.M, MT), (unsigned)cdiv(p.B, LT / SEG));
   int rc = TTTS_OK;
-#define TTTS_V1(KT_)                                                                                 \
+#define TTTS_V1F(KT_, F_)                                                                            \
   {                                                                                                   \
     static OnceFlag attr_;                                                                        \
-    rc = set_attr_once(reinterpret_cast<const void*>(conv1d_bf16x3_kernel<WCO, KT_>), attr_);         \
+    rc = set_attr_once(reinterpret_cast<const void*>(conv1d_bf16x3_kernel<WCO, KT_, F_>), attr_);     \
     if (rc) return rc;                                                                                \
-    conv1d_bf16x3_kernel<WCO, KT_><<<grid, 256, smem, stream>>>(p);                                  \
+    conv1d_bf16x3_kernel<WCO, KT_, F_><<<grid, 256, smem, stream>>>(p);                              \
   }
+#define TTTS_V1(KT_) if (f16) TTTS_V1F(KT_, true) else TTTS_V1F(KT_, false)
   switch ((cx.flags & 33554432) ? 0 : K) {
     case 1: TTTS_V1(1) break; case 2: TTTS_V1(2) break; case 3: TTTS_V1(3) break; case 5: TTTS_V1(5) break;   // (2: the phase-merged strided layers)
     case 7: TTTS_V1(7) break; case 11: TTTS_V1(11) break; default: TTTS_V1(0) break;
   }
 #undef TTTS_V1
+#undef TTTS_V1F
   *handled = true;
   return check_launch("conv1d_bf16x3");
 }
@@ -1283,7 +1318,8 @@ int conv1d_dgrad_strided_mfma_try(const float* dy, const float* w, const float* 
     const int64_t xel = (int64_t)B * nblk * 2 * Lp * 8;
     if (all_ok && 2 * xel * (int64_t)sizeof(bf16) + (32 << 20) <= cx.ws_bytes) {
       bf16* xh = static_cast<bf16*>(cx.ws);
-      conv_input_split_kernel<<<(int)std::min<int64_t>(cdiv(xel / 16, 256), 8192), 256, 0, stream>>>(dy, xh, xh + xel, B, Cout, Lout, nblk, in_slope, Lp, padl, 0, 0, 0);
+      conv_input_split_kernel<<<(int)std::min<int64_t>(cdiv(xel / 16, 256), 8192), 256, 0, stream>>>(dy, xh, xh + xel, B, Cout, Lout, nblk, in_slope, Lp, padl, 0, 0, 0, 0, 0,
+                                                                                                     (cx.flags & TTTS_CONV_F16X1) ? 1 : 0);
       xs_hi = xh; xs_lo = xh + xel; sh_Lp = Lp; sh_padl = padl;
     }
   }

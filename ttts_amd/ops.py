@@ -912,14 +912,21 @@ _conv_ctxs = {}
 
 
 def set_conv_precision(mode):
-    """'split_bf16' (default: fp32 products as hi*hi + hi*lo + lo*hi on the bf16 matrix cores, fp32 accumulation) or 'exact'
-    (fp32-input MFMA, bit-for-bit an fmaf chain).  Returns the previous mode."""
-    if mode not in ("split_bf16", "exact"):
-        raise ValueError("conv precision must be 'split_bf16' or 'exact'")
+    """'split_bf16' (default: fp32 products as hi*hi + hi*lo + lo*hi on the bf16 matrix cores, fp32 accumulation), 'exact'
+    (fp32-input MFMA, bit-for-bit an fmaf chain) or 'tf32class' (forward and data gradient: operands rounded to fp16 -- the 11 significant
+    bits of the TF32 the reference's cuDNN convolutions run with, ttts/vqvae/train.py:34-36 -- ONE fp16 MFMA product per pair, fp32
+    accumulation; weight gradients keep the split form; the data gradient's input needs loss scaling to stay in fp16's range:
+    VqvaeStep applies it).  Returns the previous mode."""
+    if mode not in ("split_bf16", "exact", "tf32class"):
+        raise ValueError("conv precision must be 'split_bf16', 'exact' or 'tf32class'")
     prev = _state["conv_precision"]
     _state["conv_precision"] = mode
     _apply_flags()
     return prev
+
+
+def conv_precision():
+    return _state["conv_precision"]
 
 
 def set_variant_flags(flags):
@@ -930,12 +937,12 @@ def set_variant_flags(flags):
     return prev
 
 
-_state = {"conv_precision": "split_bf16", "variant": int(os.environ.get("TTTS_DEBUG_FLAGS", "0") or 0)}
+_state = {"conv_precision": os.environ.get("TTTS_CONV_PRECISION", "split_bf16"), "variant": int(os.environ.get("TTTS_DEBUG_FLAGS", "0") or 0)}
 
 
 def _apply_flags():
     for ctx, _buf in _conv_ctxs.values():
-        ctx.flags = _state["variant"] | (4096 if _state["conv_precision"] == "exact" else 0)
+        ctx.flags = _state["variant"] | {"exact": 4096, "tf32class": 1024}.get(_state["conv_precision"], 0)
 
 
 def _conv_ctx(device):

@@ -195,6 +195,10 @@ class VqvaeStep:
                                           h.win_length, h.mel_fmin, h.mel_fmax)
         y = slice_segments(y.unsqueeze(1), ids_slice * h.hop_length, tr.segment_size)
         scale = self.dp.loss_scale()
+        # 'tf32class' convolutions round the data gradient's input to fp16: a fixed power-of-two loss scale keeps the GAN's small
+        # gradients (1e-7 .. 1e-2 per element) inside fp16's normal range; it is divided out of the flat gradient arenas before the
+        # exchange / the optimizer (exact: a power of two), so the reported gradient norms and the updates are the unscaled ones
+        ls = float(os.environ.get("TTTS_LOSS_SCALE", "1024")) if ops.conv_precision() == "tf32class" else 1.0
         # ---- discriminator phase
         if self.bank_d is not None:
             self.bank_d.refresh()
@@ -205,12 +209,14 @@ class VqvaeStep:
         y_d_hat_r, y_d_hat_g, _, _ = self.net_d(y, y_hat.detach())
         loss_disc, losses_disc_r, losses_disc_g = L.discriminator_loss(y_d_hat_r, y_d_hat_g)
         self.optim_d.zero_grad()
-        (loss_disc * scale).backward()
+        (loss_disc * (scale * ls)).backward()
         join_side_streams(y.device)
         for a in self.slabs_d:
             a.reduce()
         if self.bank_d is not None:
             self.bank_d.finish()
+        if ls != 1.0:
+            self.optim_d.flat_g.mul_(1.0 / ls)
         self._exchange(1, cut)
         self.optim_d.step()
         # ---- generator phase.  The reference lets this backward fill net_d's parameter gradients too and throws them away at
@@ -231,12 +237,14 @@ class VqvaeStep:
             loss_gen, losses_gen = L.generator_loss(y_d_hat_g)
             loss_gen_all = loss_gen + loss_fm + loss_mel + kl_ssl * 1 + loss_kl
             self.optim_g.zero_grad()
-            (loss_gen_all * scale).backward()
+            (loss_gen_all * (scale * ls)).backward()
             join_side_streams(y.device)
             for a in self.slabs_g:
                 a.reduce()
             if self.bank_g is not None:
                 self.bank_g.finish()
+            if ls != 1.0:
+                self.optim_g.flat_g.mul_(1.0 / ls)
         finally:
             for prm in self._d_params:
                 prm.requires_grad_(True)
