@@ -144,6 +144,27 @@ def vqvae_leg(dev, steps, warmup, cpu_leg=True):
         dt, mode = dt_eager, "eager launches, independent branches on side streams"
     vals = {k: float(v) for k, v in out.items()}
     assert all(v == v for v in vals.values()), vals
+    # the same step with the forward / data-gradient convolutions in the reference's own GPU arithmetic class (TF32: 11 significant
+    # bits; here fp16 x fp16 single-pass MFMA products with fp32 accumulation, weight gradients still split-bf16, loss scale 2^10):
+    # reported BESIDE the fp32-equivalent default, never as `value`
+    tf32 = None
+    prev_prec = ops.set_conv_precision("tf32class")
+    try:
+        dt_t, out_t = timed(tr.train_step)
+        vt = {k: float(v) for k, v in out_t.items()}
+        assert all(v == v for v in vt.values()), vt
+        tf32 = {"ms_per_step": round(dt_t * 1e3, 2), "value": round(B * 256 / dt_t, 1), "unit": "frames/s",
+                "dtype": "forward / data-gradient convolution products as ONE fp16 x fp16 MFMA (11 significant bits = TF32's, the reference's "
+                         "cuDNN arithmetic, ttts/vqvae/train.py:34-36; operands saturate at 65504), fp32 accumulation; weight gradients "
+                         "split-bf16 x3; loss scale 2^10 divided out of the gradient arenas; everything else as the default",
+                "parity": "tests/test_gpu_vqvae.py::test_tf32class_conv_accuracy (1.5e-3 of the output range per convolution) and "
+                          "::test_full_step_in_tf32class_mode_against_the_reference_fixture (losses within 1e-3 of the reference fixture, "
+                          "gradient norms 2e-3, quantizer input 3e-3 of its range; code flips only on audited near ties: 1 of 50 rows)",
+                "roof_note": "one product per pair: this mode's matrix-core roof is the full 2500 TFLOP/s, not 2500 / 3",
+                "algorithmic_tflops": round(1.97e9 * B * 256 / dt_t / 1e12, 1),
+                "losses": {k: round(v, 4) for k, v in vt.items()}}
+    finally:
+        ops.set_conv_precision(prev_prec)
     # dominant kernel family: the convolutions (implicit GEMM on the matrix cores), timed eagerly with HIP events
     fam = {"conv1d_fwd": [0, 0.0, 0.0], "conv1d_dgrad": [0, 0.0, 0.0], "conv1d_wgrad": [0, 0.0, 0.0]}
     saved, recs = {}, []
@@ -238,7 +259,8 @@ def vqvae_leg(dev, steps, warmup, cpu_leg=True):
                         "measured host issue time so the host stays ahead; second instrumented pass (the first absorbs allocations); "
                         "timing_invalid when the family's summed time exceeds the un-instrumented one-stream step",
                         "families_ms": {k: round(v[1] * 1e3, 2) for k, v in fam.items()}},
-           "losses": {k: round(v, 4) for k, v in vals.items()}, "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+           "losses": {k: round(v, 4) for k, v in vals.items()}, "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+           "tf32class": tf32}
     if cpu_leg:
         res["cpu_baseline"] = vqvae_cpu_baseline()
     return res

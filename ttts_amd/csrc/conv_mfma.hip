@@ -390,12 +390,12 @@ static bool wsplit_lookup(const ConvMfmaParams& p, const ConvCtx& cx, int nblk, 
       return true;
     }
     ++c->misses;
-    const int64_t need = ((2 * elems_alloc * (int64_t)sizeof(bf16) + 255) / 256) * 256;
+    const int64_t need = (((f16 ? 1 : 2) * elems_alloc * (int64_t)sizeof(bf16) + 255) / 256) * 256;    // (single-pass mode: no lo array)
     if ((int)c->host.size() >= c->max_entries || c->used + need > c->bytes) return false;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
     WsplitDesc d;
-    d.w = p.w; d.hi = reinterpret_cast<bf16*>(c->storage + c->used); d.lo = d.hi + elems_alloc;
+    d.w = p.w; d.hi = reinterpret_cast<bf16*>(c->storage + c->used); d.lo = f16 ? d.hi : d.hi + elems_alloc;
     d.M = p.M; d.N = p.N; d.Mpad = p.Mpad; d.nblk = nblk; d.K = p.K; d.Kmem = p.Kmem; d.transposed = p.transposed;
     d.tap_off = p.tap_off; d.tap_stride = p.tap_stride; d.AP = AP; d.rowS = p.rowS; d.rpad = p.rpad; d.vpad = p.pad;
     d.f16 = f16; d.pad2_ = 0;

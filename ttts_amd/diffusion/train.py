@@ -80,9 +80,14 @@ class DiffusionTrainer:
             self.optimizer.zero_grad()
             for a in self._slabs:
                 a.begin()
-            (loss * self.dp.loss_scale()).backward()
+            # ('tf32class' convolutions round the data gradient's input to fp16: a power-of-two loss scale keeps it in range, see
+            # ttts_amd/vqvae/train.py; divided out of the arena below)
+            ls = float(os.environ.get("TTTS_LOSS_SCALE", "1024")) if ops.conv_precision() == "tf32class" else 1.0
+            (loss * (self.dp.loss_scale() * ls)).backward()
             for a in self._slabs:
                 a.reduce()
+            if ls != 1.0:
+                self.optimizer.flat_g.mul_(1.0 / ls)
         finally:
             for c in self._wsplit + self._slabs:
                 c.disarm()
