@@ -672,11 +672,11 @@ def main():
         toks = None
         if args.mode != "eager":
             # N > 1: the gradient all-reduce of the upper layers + heads overlaps the backward of the lower layers
-            if world > 1 and args.exchange == "whole":
+            if dp.enabled and args.exchange == "whole":
                 eng.train_step(toks, w_text, w_mel, capture=True, lr=tr["lr"], exchange=lambda: dp.allreduce_grads_(eng.grads))
             else:
                 eng.train_step(toks, w_text, w_mel, capture=True, lr=tr["lr"],
-                               exchange_range=(lambda lo, hi: dp.allreduce_range_(eng.grads, lo, hi)) if world > 1 else None)
+                               exchange_range=(lambda lo, hi: dp.allreduce_range_(eng.grads, lo, hi)) if dp.enabled else None)
             return
         eng.forward()
         eng.backward(w_text, w_mel)
@@ -709,7 +709,7 @@ def main():
     # exchange by itself: one SUM all-reduce of the whole fp32 gradient arena, HIP events on the current stream, 5 repetitions
     per_rank_ms = [round(my_elapsed / args.steps * 1e3, 3)]
     allreduce_ms = None
-    if world > 1:
+    if dp.enabled:
         import torch.distributed as dist
         gathered = [None] * world
         dist.all_gather_object(gathered, per_rank_ms[0])
@@ -781,7 +781,7 @@ def main():
     args.mode = saved_mode
     eng.overlap_dw = saved_overlap
     torch.cuda.synchronize()
-    if world > 1:
+    if dp.enabled:
         dp.barrier()
 
     if rank == 0:
@@ -793,20 +793,20 @@ def main():
                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": "VALL-E GPT train step (ttts/gpt/config.json model: 6 layers, d512, 8 heads, 21.46 M "
                                       "params), batch 8 per GPU x (128 text + 1024 audio tokens) = S 1156, fwd+bwd+clip+AdamW, "
-                                      "dropout %.1f, %s" % (dropout, "eager launches" if not graphed else ("hipGraph replay" if world == 1 else
+                                      "dropout %.1f, %s" % (dropout, "eager launches" if not graphed else ("hipGraph replay" if not dp.enabled else
                                                                        "hipGraph replay, RCCL all-reduce of the upper layers overlapped with the lower layers' backward")),
                           "global_batch": world * B_PER_GPU, "seq_len": TEXT_LEN + 2 + MEL_LEN + 2, "parallelism": "dp%d" % world,
                           "mode": args.mode, "graph_replay": bool(graphed),
-                          "exchange": (args.exchange if world > 1 else None),
-                          "dist_backend": (torch.distributed.get_backend() if world > 1 else None), "world_size": world,
-                          "ranks_seen_by_backend": (torch.distributed.get_world_size() if world > 1 else 1),
-                          "grad_exchange_dtype": (args.grad_dtype if world > 1 else None),
+                          "exchange": (args.exchange if dp.enabled else None),
+                          "dist_backend": (torch.distributed.get_backend() if dp.enabled else None), "world_size": world,
+                          "ranks_seen_by_backend": (torch.distributed.get_world_size() if dp.enabled else 1),
+                          "grad_exchange_dtype": (args.grad_dtype if dp.enabled else None),
                           "capture_note": getattr(eng, "_capture_error", None),
                           # the multi-GPU communication budget of DESIGN section 6 rests on an ASSUMED RCCL bus bandwidth (250 GB/s
                           # on the 7-link xGMI mesh): this line's allreduce_arena_ms is the first measurement of it
                           "exchange_budget_note": ("DESIGN section 6 budgets the exchange with an assumed 250 GB/s RCCL bus bandwidth; "
                                                    "allreduce_arena_ms / allreduce_arena_mb in this line are the measured figures"
-                                                   if world > 1 else None)},
+                                                   if dp.enabled else None)},
                "final_loss_mel": round(lm, 4), "per_rank_ms_per_step": per_rank_ms,
                "allreduce_arena_ms": (None if allreduce_ms is None else round(allreduce_ms, 3)),
                "allreduce_arena_mb": (None if allreduce_ms is None else round(eng.grads.numel() * 4 / 2 ** 20, 1)), "roofline": roof}

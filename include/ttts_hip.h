@@ -34,7 +34,7 @@ extern "C" {
 #define TTTS_EHIP (-2)         /* a HIP runtime call or kernel launch failed */
 #define TTTS_EUNSUPPORTED (-3) /* valid request this build has no kernel for */
 
-#define TTTS_ABI_VERSION 10
+#define TTTS_ABI_VERSION 11
 
 /* ---- library ------------------------------------------------------------------------------------ */
 int ttts_abi_version(void);
@@ -286,7 +286,10 @@ int ttts_ce_bwd_bf16(const void* logits, int64_t ldl, const int64_t* targets, co
  * Replaces: get_grad_norm (ttts/gpt/train.py:22-31, 84 .item() syncs), accelerator.clip_grad_norm_(1.0)
  * (:115), torch.optim.AdamW (:56,118), LambdaLR(warmup) (:36-40,57,120) -- on ONE flat fp32 arena.
  *
- * state: f32[8] device buffer {step, lr, bias_corr1, bias_corr2_sqrt, grad_norm, clip_coef, -, -}.
+ * state: f32[8] device buffer {step, lr, bias_corr1, bias_corr2_sqrt, grad_norm, clip_coef, skip, -}.
+ * skip (ABI v11): non-zero makes THIS optimizer step a no-op -- ttts_adamw_schedule does not advance, ttts_adamw_f32 leaves the
+ *   parameters, moments and shadow alone and only consumes (zeroes) the gradient: `GradScaler.step`'s behaviour on an overflowed
+ *   step (ttts/vqvae/train.py:262,356-372 with fp16_run), decided on the device by ttts_loss_scale_check.  Zero: as before.
  * ttts_adamw_schedule: step += 1 (step counts optimizer steps taken, starts at 0), lr = base_lr *
  *   (warmup_steps > 0 ? min(1, (step-1)/warmup_steps) : 1)  [LambdaLR value used by THIS step],
  *   bias corrections in double precision.  Device-side so the whole step stays graph-capturable. */
@@ -596,6 +599,23 @@ int ttts_conv_wgrad_arena_disarm(void* arena);      /* abandon the phase: nothin
 int ttts_conv_wgrad_arena_release_graphs(void* arena);
 int ttts_conv_wgrad_arena_stats(void* arena, int64_t* out6 /* entries, storage bytes used, deferred, fallbacks, partial reduces, generation */);
 int ttts_conv_wgrad_arena_destroy(void* arena);
+/* ABI v11: range bookkeeping of TTTS_CONV_F16X1 and the dynamic loss scale built on it.  Replaces: torch.cuda.amp.GradScaler
+ * (ttts/vqvae/train.py:262 `GradScaler(enabled=hps.train.fp16_run)`, :356-372 scale / unscale_ / step / update) for the
+ * single-pass fp16 convolution mode, whose data gradients are loss-scaled into fp16's range.
+ * Every fp32 -> fp16 operand conversion of that mode counts, per device, the threads (8-16 neighbouring elements each) that saw
+ *   [0] a value above 65504 (saturated; +-inf included; NaN stays NaN and is not counted), [1] a non-zero value that became zero
+ *   (|v| <= 2^-25), [2] a non-zero value below fp16's smallest normal 2^-14 (fewer than 11 significant bits kept).
+ * ttts_conv_f16_events: events3[i] += counter[i] on `stream` (device memory, int32[3]); reset != 0 clears the counters.  The
+ *   counters belong to the device `stream` runs on.  Graph-capturable; no host sync.
+ * ttts_loss_scale_check: one per backward, after ttts_conv_f16_events (and after an all-reduce of events3 under data parallelism):
+ *   events3[0] != 0 -> *skip = 1 (pass &optimizer_state[6], see ttts_adamw_schedule) and "overflow seen" in ls8; totals += events;
+ *   events3 is cleared.  ls8 = f32[8] {scale, 1 / scale, clean steps in a row, overflow since the last update, saturation total,
+ *   flush total, skipped optimizer steps, subnormal total}; the caller initialises {scale, 1 / scale, 0...}.
+ * ttts_loss_scale_update: one per step: overflow -> scale *= backoff (not below 1), else after growth_interval clean steps in a
+ *   row scale *= growth (not above 2^24); 1 / scale follows.  GradScaler's defaults: backoff 0.5, growth 2, interval 2000. */
+int ttts_conv_f16_events(int32_t* events3, int32_t reset, void* stream);
+int ttts_loss_scale_check(float* ls8, int32_t* events3, float* skip, void* stream);
+int ttts_loss_scale_update(float* ls8, int32_t growth_interval, float backoff, float growth, void* stream);
 int ttts_tanh_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, void* stream);
 int ttts_lrelu_bwd_f32(const float* dy, const float* y, float* dx, float slope, int64_t n, void* stream);
 /* y = scale * (a + b + c + d), b/c/d optional (NULL): `xs / num_kernels` of Generator.forward (vq2.py:396-403) and its

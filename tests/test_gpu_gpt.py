@@ -455,6 +455,53 @@ def test_ranged_gradient_exchange_two_ranks_nccl():
     assert "rank0-consistent" in r.stdout and "rank1-consistent" in r.stdout
 
 
+def _world1_nccl(argv, timeout=400):
+    """One rank, backend nccl (= RCCL), TTTS_DP_FORCE=1: the data-parallel path executed for real on a 1-GPU box."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, TTTS_DP_FORCE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0",
+               WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("TTTS_SHARE_GPU", None)
+    env.pop("TTTS_DIST_BACKEND", None)
+    return subprocess.run([sys.executable] + argv, capture_output=True, text=True, env=env, timeout=timeout)
+
+
+def test_rccl_world1_gpt_ranged_exchange_is_bit_identical_to_the_plain_step():
+    """RCCL executes: a one-rank `nccl` process group, three captured GPT steps whose backward is cut into hipGraph sections
+    around range all-reduces (and, second variant, one whole-arena all-reduce) issued on the live communicator -- parameters
+    and losses bit-identical to the same steps without any collective (tools/dp_world1_nccl.py gpt)."""
+    r = _world1_nccl([os.path.join(ROOT, "tools", "dp_world1_nccl.py"), "gpt"])
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "gpt-ok backend=nccl" in r.stdout, r.stdout
+
+
+def test_rccl_world1_vqvae_trainer_collectives():
+    """The VQ-VAE-GAN trainer on a one-rank `nccl` group: parameter broadcast, codebook-buffer broadcast in front of every
+    step, the discriminator and generator arena all-reduces -- eagerly and with the step recorded as three hipGraph segments
+    around the two all-reduces -- bit-identical to the non-distributed trainer (tools/dp_world1_nccl.py vqvae)."""
+    r = _world1_nccl([os.path.join(ROOT, "tools", "dp_world1_nccl.py"), "vqvae"], timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "vqvae-ok backend=nccl" in r.stdout, r.stdout
+
+
+def test_bench_world1_on_rccl_reports_the_backend():
+    """`TTTS_DP_FORCE=1 python bench.py --gpus 1`: the bench's N > 1 code path (ranged exchange beside the step graphs, barrier,
+    max-over-ranks, the arena all-reduce timing) on a one-rank RCCL communicator; the line says which backend ran."""
+    r = _world1_nccl([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline",
+                      "--no-vqvae", "--no-diffusion", "--profile-steps", "1"])
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["config"]["dist_backend"] == "nccl" and out["config"]["ranks_seen_by_backend"] == 1 and out["n_gpus"] == 1
+    assert out["config"]["exchange"] == "ranged" and out["config"]["graph_replay"] is True
+    assert out["allreduce_arena_ms"] is not None and out["allreduce_arena_ms"] > 0 and out["value"] > 0
+
+
 def test_engine_keeps_buffers_plans_and_graphs_of_recent_shapes(gpt):
     """Real batches change (B, Tt, Tm) every step: a shape that comes back must find its buffers, descriptor tables and captured
     step again (GptEngine._ensure_buffers' shape cache) and give the same losses as before."""

@@ -1227,3 +1227,109 @@ def test_full_step_in_tf32class_mode_against_the_reference_fixture(golden_dir):
         np.testing.assert_allclose([out["grad_norm_d"].item(), out["grad_norm_g"].item()], g["grad_norms"], rtol=2e-3)
     finally:
         _ops.set_conv_precision("split_bf16")
+
+
+@pytest.mark.bf16x3
+def test_tf32class_and_fp8_keep_nan_and_count_range_events():
+    """The reduced-precision modes must not turn a diverged tensor into ordinary numbers: a NaN input reaches the output of a
+    tf32class convolution (forward, data gradient) and of an fp8 GEMM as NaN (the saturating clamps used to map it to -65504 / -448
+    and amax dropped it).  And the fp16 conversions keep books: operands above 65504 / at or below 2^-25 / below 2^-14 show up in
+    ops.conv_f16_events as saturated / flushed / subnormal, nothing is counted for in-range operands."""
+    from ttts_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 64, 300, generator=g).to(_dev()); w = (torch.randn(96, 64, 5, generator=g) / 18).to(_dev())
+    ev = torch.zeros(4, dtype=torch.int32, device=_dev())
+    prev = ops.set_conv_precision("tf32class")
+    try:
+        ops.conv_f16_events(ev, reset=True); ev.zero_()
+        y = ops.conv1d_fwd(x, w, None, None, 1, 2, 1)
+        assert bool(torch.isfinite(y).all())
+        assert ops.conv_f16_events(ev).tolist()[:2] == [0, 0]            # in range: nothing saturated, nothing flushed
+        ev.zero_()
+        xn = x.clone(); xn[1, 7, 100] = float("nan")
+        yn = ops.conv1d_fwd(xn, w, None, None, 1, 2, 1)
+        assert bool(torch.isnan(yn[1, :, 98:103]).all()) and bool(torch.isfinite(yn[0]).all())
+        dy = torch.randn(y.shape, generator=g).to(_dev()); dy[0, 3, 50] = float("nan")
+        dx = ops.conv1d_dgrad(dy, w, 300, 1, 2, 1)
+        assert bool(torch.isnan(dx[0, :, 48:53]).all()) and bool(torch.isfinite(dx[1]).all())
+        assert ops.conv_f16_events(ev).tolist()[0] == 0                  # NaN is carried, not counted as saturation
+        ev.zero_()
+        xb = x.clone(); xb[0, 1, 10] = 2.0 ** 17; xb[0, 2, 11] = -float("inf"); xb[1, 3, 12] = 1e-9; xb[1, 4, 13] = 3e-5
+        yb = ops.conv1d_fwd(xb, w, None, None, 1, 2, 1)
+        sat, flushed, sub = ops.conv_f16_events(ev).tolist()[:3]
+        assert sat >= 2 and flushed >= 1 and sub >= 2, (sat, flushed, sub)
+        assert bool(torch.isfinite(yb).all())                             # saturated (+-65504), not inf
+        ev.zero_()
+        assert ops.conv_f16_events(ev).tolist()[:3] == [0, 0, 0]         # the fetch above reset the device counters
+    finally:
+        ops.set_conv_precision(prev)
+    # fp8: NaN element -> NaN amax -> NaN scale and alpha -> NaN output (every element: the tensor's scale is gone)
+    a = torch.randn(1, 128, 64, generator=g).to(_dev()); wq = torch.randn(256, 128, 1, generator=g).to(_dev())
+    assert float(ops.fp8_amax(a)) == float(a.abs().max())
+    a[0, 5, 9] = float("nan")
+    am = ops.fp8_amax(a)
+    assert bool(torch.isnan(am))
+    yq, _, _ = ops.conv1x1_fp8_fwd(a, wq, None)
+    assert bool(torch.isnan(yq).all())
+
+
+@pytest.mark.bf16x3
+def test_dynamic_loss_scale_skips_on_overflow_and_grows_after_clean_steps(golden_dir, monkeypatch):
+    """GradScaler's rule on device words (ops.DynamicLossScale; ttts/vqvae/train.py:262,356-372): with an initial scale of 2^40 the
+    scaled data gradients leave fp16's range -> the fp16 conversions count saturation, BOTH optimizer steps of that step are
+    skipped (parameters and Adam moments bit-identical, schedule not advanced), the scale halves; with a sane scale and a growth
+    interval of 2 the scale doubles after two clean steps and the updates happen.  No host sync inside the step."""
+    from ttts_amd import ops as _ops
+    monkeypatch.setenv("TTTS_LOSS_SCALE", str(2.0 ** 40))
+    monkeypatch.setenv("TTTS_LOSS_SCALE_INTERVAL", "2")
+    g, tr, data, inject = _step_setup(golden_dir)
+    _ops.set_conv_precision("tf32class")
+    try:
+        pg, pd_ = tr.optim_g.flat_p.clone(), tr.optim_d.flat_p.clone()
+        out = tr.train_step(data, dict(inject))
+        torch.cuda.synchronize()
+        rep = tr.step_fn._lsc.report()
+        print("overflow step:", rep, {k: float(out[k]) for k in ("loss_scale", "f16_saturated", "skipped_steps")})
+        assert float(out["loss_scale"]) == 2.0 ** 40 and rep["scale"] == 2.0 ** 39 and rep["saturated"] > 0 and rep["skipped"] == 2
+        assert torch.equal(tr.optim_g.flat_p, pg) and torch.equal(tr.optim_d.flat_p, pd_)
+        assert float(tr.optim_g.opt_state[0]) == 0.0 and float(tr.optim_d.opt_state[0]) == 0.0
+        assert not tr.optim_g.exp_avg.any() and not tr.optim_g.flat_g.any()
+        # a sane scale: clean steps update the parameters, and after two of them the scale doubles
+        lsc = tr.step_fn._lsc
+        lsc.state[0] = 1024.0; lsc.state[1] = 1.0 / 1024.0; lsc.state[2] = 0.0
+        sat0 = lsc.report()["saturated"]
+        o1 = tr.train_step(data, dict(inject)); s1 = float(o1["loss_scale"])
+        o2 = tr.train_step(data, dict(inject)); s2 = float(o2["loss_scale"])
+        o3 = tr.train_step(data, dict(inject)); s3 = float(o3["loss_scale"])
+        rep = lsc.report()
+        print("clean steps:", s1, s2, s3, rep)
+        assert (s1, s2, s3) == (1024.0, 1024.0, 2048.0) and rep["saturated"] == sat0 and rep["skipped"] == 2
+        assert not torch.equal(tr.optim_g.flat_p, pg) and float(tr.optim_g.opt_state[0]) == 3.0
+        # the first clean step is the fixture's step: same losses as the static-scale path measured before (1e-3)
+        got = np.array([o1[k].item() for k in ("loss_disc", "loss_gen", "loss_fm", "loss_mel", "kl_ssl", "loss_kl")])
+        np.testing.assert_allclose(got, g["losses"], rtol=1e-3)
+        np.testing.assert_allclose([o1["grad_norm_d"].item(), o1["grad_norm_g"].item()], g["grad_norms"], rtol=2e-3)
+    finally:
+        _ops.set_conv_precision("split_bf16")
+
+
+@pytest.mark.bf16x3
+def test_second_cache_or_arena_over_the_same_array_is_refused():
+    """Overlapping weight-split caches / weight-gradient arenas are refused before their storage is allocated (TttsError): the
+    trainers' `except TttsError` paths -- a second VqvaeStep over the same networks runs without its own cache -- depend on it."""
+    from ttts_amd import ops
+    w = torch.zeros(4096, device=_dev()); gr = torch.zeros(4096, device=_dev())
+    c = ops.WeightSplitCache(w); a = ops.WgradSlabArena(gr, 1 << 20)
+    try:
+        before = torch.cuda.memory_allocated()
+        with pytest.raises(ops.TttsError):
+            ops.WeightSplitCache(w[1024:2048])
+        with pytest.raises(ops.TttsError):
+            ops.WgradSlabArena(gr, 1 << 20)
+        assert torch.cuda.memory_allocated() == before
+        other = ops.WeightSplitCache(torch.zeros(64, device=_dev()))      # a disjoint array is fine
+        other.close()
+    finally:
+        c.close(); a.close()
+    c2 = ops.WeightSplitCache(w)                                          # after close() the range is free again
+    c2.close()

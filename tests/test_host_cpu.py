@@ -32,7 +32,7 @@ def test_header_symbols_exported_and_bound(lib):
     for name in declared:
         assert hasattr(handle, name), "header declares %s but libttts_hip.so does not export it" % name
     assert declared == set(lib.SIGNATURES), declared ^ set(lib.SIGNATURES)
-    assert lib.get().ttts_abi_version() == lib.ABI_VERSION == 10
+    assert lib.get().ttts_abi_version() == lib.ABI_VERSION == 11
 
 
 def test_gemm_nt_dispatch_table(lib):
@@ -421,6 +421,51 @@ def test_flat_data_parallel_gloo_world2(tmp_path):
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "rank0-ok" in r.stdout and "rank1-ok" in r.stdout
+
+
+def test_precision_environment_typos_are_refused():
+    """TTTS_CONV_PRECISION / TTTS_DIFFUSION_PRECISION are validated at import: 'tf32' (for 'tf32class') used to select the default
+    kernels silently while conv_precision() reported the bogus string."""
+    for var, mod in (("TTTS_CONV_PRECISION", "ttts_amd.ops"), ("TTTS_DIFFUSION_PRECISION", "ttts_amd.diffusion.aa_model")):
+        r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import %s" % (ROOT, mod)],
+                           capture_output=True, text=True, env=dict(os.environ, **{var: "tf32"}), timeout=120)
+        assert r.returncode != 0 and var in r.stderr, r.stderr[-500:]
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); from ttts_amd import ops; "
+                        "assert ops.conv_precision() == 'tf32class'" % ROOT],
+                       capture_output=True, text=True, env=dict(os.environ, TTTS_CONV_PRECISION="tf32class"), timeout=120)
+    assert r.returncode == 0, r.stderr[-500:]
+
+
+def test_forced_world1_group_runs_the_collectives(tmp_path):
+    """TTTS_DP_FORCE=1 at world size 1 (gloo here; `nccl` in the -m gpu tests): the group is created with no launcher
+    environment, FlatDataParallel is enabled and its collectives are the identity."""
+    script = tmp_path / "w1.py"
+    script.write_text("import sys, torch\nsys.path.insert(0, %r)\n" % ROOT + """
+import torch.distributed as dist
+from ttts_amd.parallel import FlatDataParallel, init_distributed
+rank, world, _ = init_distributed("gloo")
+assert (rank, world) == (0, 1) and dist.is_initialized() and dist.get_world_size() == 1
+dp = FlatDataParallel()
+assert dp.enabled and dp.world == 1 and dp.loss_scale() == 1.0
+g = torch.arange(100, dtype=torch.float32); want = g.clone()
+dp.allreduce_grads_(g)
+h = dp.allreduce_range_(g, 10, 60); h.wait()
+dp.broadcast_(g)
+assert torch.equal(g, want) and dp.all_ranks_ok(True) and not dp.all_ranks_ok(False) and dp.max_over_ranks(2.5) == 2.5
+dp.barrier()
+print("w1-ok")
+""")
+    env = dict(os.environ, TTTS_DP_FORCE="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0 and "w1-ok" in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]
+    env.pop("TTTS_DP_FORCE")
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r)\nfrom ttts_amd.parallel import FlatDataParallel, "
+                        "init_distributed\ninit_distributed('gloo')\nimport torch.distributed as d\n"
+                        "assert not d.is_initialized() and not FlatDataParallel().enabled" % ROOT],
+                       capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
 
 
 WORKER_N = r"""

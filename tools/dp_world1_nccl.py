@@ -1,0 +1,163 @@
+"""World-size-1 run of the data-parallel path on backend "nccl" (= RCCL): `TTTS_DP_FORCE=1 python tools/dp_world1_nccl.py <part>`.
+
+A 1-GPU box cannot run two RCCL ranks (RCCL refuses duplicate devices), but a ONE-rank communicator is a real communicator:
+`ncclCommInitRank`, `ncclAllReduce` / `ncclBroadcast` on RCCL's stream, hipGraph capture and replay beside it.  With the flag
+every collective of the N > 1 path is issued (a sum over one rank is the identity), so each part below must end with exactly the
+bits of the same steps run without a process group -- which the script also runs, in the same process, for the comparison.
+
+parts:  gpt    three captured GPT steps, ranged exchange (three hipGraphs around four range all-reduces) and whole-arena exchange
+        vqvae  the VQ-VAE-GAN trainer: parameter + codebook broadcast, the D / G arena all-reduces, eagerly and as three
+               hipGraph segments
+Prints `<part>-ok ...` on success.  (ttts/gpt/train.py:58,112,117; ttts/vqvae/train.py:127-132,207-208.)"""
+import hashlib
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from ttts_amd.parallel import FlatDataParallel, dp_forced, init_distributed  # noqa: E402
+
+part = sys.argv[1] if len(sys.argv) > 1 else "gpt"
+assert dp_forced(), "run with TTTS_DP_FORCE=1"
+rank, world, local = init_distributed()
+assert world == 1 and dist.is_initialized() and dist.get_backend() == "nccl", (world, dist.is_initialized())
+dev = torch.device("cuda", local)
+torch.cuda.set_device(dev)
+dp = FlatDataParallel()
+assert dp.enabled and dp.world == 1
+calls = {"all_reduce": 0, "broadcast": 0}
+_ar, _bc = dist.all_reduce, dist.broadcast
+
+
+def _count_ar(*a, **k):
+    calls["all_reduce"] += 1
+    return _ar(*a, **k)
+
+
+def _count_bc(*a, **k):
+    calls["broadcast"] += 1
+    return _bc(*a, **k)
+
+
+dist.all_reduce, dist.broadcast = _count_ar, _count_bc
+
+
+def digest(*tensors):
+    h = hashlib.sha256()
+    for t in tensors:
+        h.update(t.detach().float().cpu().numpy().tobytes())
+    return h.hexdigest()[:16]
+
+
+class _Off:
+    """A FlatDataParallel that is switched off (the non-distributed step) while the process group stays alive."""
+    enabled, world, rank = False, 1, 0
+    loss_scale = staticmethod(lambda: 1.0)
+    broadcast_ = staticmethod(lambda *a, **k: None)
+    allreduce_grads_ = staticmethod(lambda *a, **k: None)
+    allreduce_range_ = staticmethod(lambda *a, **k: None)
+    all_ranks_ok = staticmethod(bool)
+    barrier = staticmethod(lambda: None)
+
+
+if part == "gpt":
+    from ttts_amd.gpt import GptEngine, prepare_tokens
+    cfg = dict(layers=4, model_dim=128, heads=4, max_text_tokens=40, max_mel_tokens=100, number_text_tokens=256,
+               start_text_token=255, number_mel_codes=1026, start_mel_token=1024, stop_mel_token=1025, mel_length_compression=1024)
+    g = torch.Generator().manual_seed(10)
+    text = torch.randint(1, 255, (2, 24), generator=g); mel = torch.randint(0, 1024, (2, 60), generator=g)
+    tl = torch.full((2,), 24); wl = torch.full((2,), 60 * 1024)
+
+    def run(mode):
+        eng = GptEngine(cfg, dev, dropout_p=0.1, seed=0)
+        eng.seed_ctr.zero_()
+        torch.manual_seed(0)
+        with torch.no_grad():
+            for k, shp in eng.spec:
+                p = eng.view(eng.params, k)
+                p.fill_(1.0 if k.endswith("weight") else 0.0) if len(shp) == 1 else p.normal_(0.0, 0.05)
+        if mode != "none":
+            dp.broadcast_(eng.params)
+        eng.refresh_shadows()
+        toks = prepare_tokens(eng.c, text.to(dev), tl, mel.to(dev), wl)
+        for _ in range(3):
+            if mode == "range":
+                eng.train_step(toks, 0.01, 1.0, capture=True, lr=1e-3,
+                               exchange_range=lambda lo, hi: dp.allreduce_range_(eng.grads, lo, hi))
+            elif mode == "whole":
+                eng.train_step(toks, 0.01, 1.0, capture=True, lr=1e-3, exchange=lambda: dp.allreduce_grads_(eng.grads))
+            else:
+                eng.train_step(toks, 0.01, 1.0, capture=True, lr=1e-3)
+        torch.cuda.synchronize()
+        graphs = eng._graph
+        assert graphs is not None and graphs[0] is not None, getattr(eng, "_capture_error", None)
+        return eng.params.clone(), eng.losses()
+
+    n0 = calls["all_reduce"]
+    pr, lr_ = run("range")
+    n_range = calls["all_reduce"] - n0
+    pw, lw = run("whole")
+    n_whole = calls["all_reduce"] - n0 - n_range
+    pn, ln = run("none")
+    assert calls["all_reduce"] - n0 - n_range - n_whole == 0
+    assert n_range >= 3 * 2 and n_whole == 3, (n_range, n_whole)       # >= two ranges per step; one arena per step
+    assert torch.equal(pr, pn) and torch.equal(pw, pn), "RCCL world-1 exchange changed the step: %g / %g" % (
+        (pr - pn).abs().max().item(), (pw - pn).abs().max().item())
+    assert lr_ == ln and lw == ln
+    print("gpt-ok backend=%s all_reduce calls: ranged %d, whole %d; params %s loss_mel %.4f"
+          % (dist.get_backend(), n_range, n_whole, digest(pn), ln[1]), flush=True)
+
+elif part == "vqvae":
+    from ttts_amd.vqvae.train import SyntheticVqvaeBatches, VqvaeTrainer, get_hparams
+
+    def run(forced):
+        hps = get_hparams()
+        hps.vqvae.p_dropout = 0.0
+        tr = VqvaeTrainer(hps)
+        if not forced:
+            tr.dp = tr.step_fn.dp = _Off()
+        else:
+            assert tr.dp.enabled
+        cb = tr.net_g.quantizer.vq.layers[0]._codebook
+        gen = torch.Generator(device="cpu").manual_seed(3)
+        with torch.no_grad():
+            cb.inited.fill_(1)
+            cb.embed.copy_(torch.randn(cb.embed.shape, generator=gen) * 0.3)
+            cb.embed_avg.copy_(cb.embed * 4); cb.cluster_size.fill_(4.0)
+        torch.manual_seed(77)                                 # slice starts / posterior noise of the steps below
+        loader = iter(SyntheticVqvaeBatches(1, n_samples=32000, text_len=12, seed=100, device=tr.device))
+        for _ in range(2):
+            out = tr.train_step(next(loader))
+        torch.cuda.synchronize()
+        eager = (tr.optim_g.flat_p.clone(), tr.optim_d.flat_p.clone(), cb.embed.clone())
+        for _ in range(3):
+            out = tr.train_step_graphed(next(loader))
+        torch.cuda.synchronize()
+        st = tr._graph_state
+        assert st["graph"] is not None, "capture refused"
+        if forced:
+            assert len(st["segments"]) == 3 and len(st["between"]) == 2, st.get("segments")
+        vals = {k: float(v) for k, v in out.items()}
+        assert all(v == v and abs(v) < 1e9 for v in vals.values()), vals
+        return eager, (tr.optim_g.flat_p.clone(), tr.optim_d.flat_p.clone(), cb.embed.clone()), vals
+
+    ef, gf, vf = run(True)
+    n_ar, n_bc = calls["all_reduce"], calls["broadcast"]
+    en, gn, vn = run(False)
+    assert (calls["all_reduce"], calls["broadcast"]) == (n_ar, n_bc)
+    # 2 eager + 2 warm-up + 1 recorded + 3 replayed steps, two arena all-reduces each (+ the capture votes); parameter broadcast
+    # at construction, codebook buffers in front of every step
+    assert n_ar >= 2 * 8 and n_bc >= 2 + 8, (n_ar, n_bc)
+    worst = lambda a, b: max(float((x - y).abs().max()) for x, y in zip(a, b))   # noqa: E731
+    same_eager = all(torch.equal(x, y) for x, y in zip(ef, en))
+    same_graph = all(torch.equal(x, y) for x, y in zip(gf, gn))
+    print("vqvae-ok backend=%s all_reduce %d broadcast %d bit_identical_eager=%s bit_identical_graphed=%s worst %.3g / %.3g params %s"
+          % (dist.get_backend(), n_ar, n_bc, same_eager, same_graph, worst(ef, en), worst(gf, gn), digest(*gf)), flush=True)
+    assert same_eager, "eager steps differ from the non-distributed run by %g" % worst(ef, en)
+    assert same_graph, "graphed steps differ from the non-distributed run by %g" % worst(gf, gn)
+else:
+    raise SystemExit("unknown part " + part)
+dist.barrier()
+dist.destroy_process_group()

@@ -157,10 +157,19 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x16 mfma32_f16(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
-// fp32 -> fp16 (round to nearest even, saturating at +-65504 instead of overflowing to inf), returned in a bf16-typed slot
+// fp32 -> fp16 (round to nearest even, saturating at +-65504 instead of overflowing to inf), returned in a bf16-typed slot.
+// NaN stays NaN (fmaxf(NaN, x) == x would turn a diverged tensor into -65504 and hide the divergence from every finite-loss check).
 __device__ __forceinline__ bf16 f16_slot(float v) {
-  v = fminf(fmaxf(v, -65504.f), 65504.f);
-  return __builtin_bit_cast(bf16, (_Float16)v);
+  const float c = fminf(fmaxf(v, -65504.f), 65504.f);
+  return __builtin_bit_cast(bf16, (_Float16)(v != v ? v : c));
+}
+// the same with range bookkeeping: bit 0 of `ev` = |v| above fp16's largest finite value (saturated, +-inf included), bit 1 = a
+// non-zero v that rounds to fp16 zero (|v| <= 2^-25), bit 2 = non-zero below fp16's smallest normal 2^-14 (fewer than 11
+// significant bits survive).  The split kernels OR these per thread and add to the per-device counters once, at the thread's end.
+__device__ __forceinline__ bf16 f16_slot_ev(float v, unsigned& ev) {
+  const float a = fabsf(v);
+  ev |= (a > 65504.f ? 1u : 0u) | ((a > 0.f && a <= 2.98023224e-8f) ? 2u : 0u) | ((a > 0.f && a < 6.10351562e-5f) ? 4u : 0u);
+  return f16_slot(v);
 }
 // row index inside a 32x32 accumulator tile held by (reg r, lane-half h = lane >> 5)
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }

@@ -64,6 +64,53 @@ struct ConvMfmaParams {
 
 __device__ __forceinline__ float lrelu_f(float v, float s) { return v > 0.f ? v : v * s; }
 
+// ---- range bookkeeping of the single-pass fp16 ("TF32-class") mode (ABI v11) --------------------------------------------------
+// fp16 has TF32's 11 significant bits but 5 exponent bits instead of 8: an operand above 65504 saturates, one at or below 2^-25
+// becomes zero, one below 2^-14 keeps fewer bits.  Every fp32 -> fp16 conversion of the mode (operand pre-passes, on-the-fly
+// staging, weight splits) ORs what it saw into a per-thread word and adds it here once -- a module global, i.e. one copy per
+// device -- so that a trainer can see, without a host sync inside the step, that its loss scale left the range
+// (ttts_conv_f16_events; ttts_loss_scale_update turns it into GradScaler's halve / skip / grow rule).
+// Counts are THREADS that saw the event (a thread converts 8..16 neighbouring elements), not elements.
+__device__ unsigned int g_f16_events[4];      // {saturated, flushed to zero, subnormal, -}
+__device__ __forceinline__ void f16_events_commit(unsigned ev) {
+  if (ev) {                                   // (rare: the common case costs one compare per thread)
+    if (ev & 1u) atomicAdd(&g_f16_events[0], 1u);
+    if (ev & 2u) atomicAdd(&g_f16_events[1], 1u);
+    if (ev & 4u) atomicAdd(&g_f16_events[2], 1u);
+  }
+}
+__global__ void f16_events_fetch_kernel(int32_t* __restrict__ out, int reset) {
+  const int i = threadIdx.x;
+  if (i < 3) {
+    out[i] += (int32_t)min(g_f16_events[i], 0x3fffffffu);
+    if (reset) g_f16_events[i] = 0u;
+  }
+}
+// GradScaler's rule on device words.  ls = {scale, 1 / scale, clean steps in a row, overflow seen since the last update,
+// total saturation events, total flush events, skipped steps, total subnormal events}.
+//   check  (one per backward): events[0] != 0 -> *skip = 1 (the optimizer step that follows leaves parameters and moments alone) and
+//          ls[3] = 1; totals accumulate; events are cleared for the next backward.
+//   update (one per step): overflow -> scale *= backoff (not below 1), streak = 0; else streak += 1 and after `interval` clean steps
+//          scale *= growth (not above 2^24).  1 / scale follows (both exact: powers of two for the default factors).
+__global__ void loss_scale_check_kernel(float* __restrict__ ls, int32_t* __restrict__ events, float* __restrict__ skip) {
+  if (threadIdx.x != 0) return;
+  const bool over = events[0] != 0;
+  if (skip) *skip = over ? 1.f : 0.f;
+  if (over) { ls[3] = 1.f; ls[6] += 1.f; }
+  ls[4] += (float)events[0]; ls[5] += (float)events[1]; ls[7] += (float)events[2];
+  events[0] = 0; events[1] = 0; events[2] = 0;
+}
+__global__ void loss_scale_update_kernel(float* __restrict__ ls, int interval, float backoff, float growth) {
+  if (threadIdx.x != 0) return;
+  float scale = ls[0], streak = ls[2];
+  if (ls[3] != 0.f) { scale = fmaxf(scale * backoff, 1.f); streak = 0.f; }
+  else {
+    streak += 1.f;
+    if (interval > 0 && streak >= (float)interval) { scale = fminf(scale * growth, 16777216.f); streak = 0.f; }
+  }
+  ls[0] = scale; ls[1] = 1.f / scale; ls[2] = streak; ls[3] = 0.f;
+}
+
 // WCO = waves along the output-channel axis (1 or 2), NW = waves per workgroup (1, 2 or 4); the NW / WCO remaining waves tile
 // positions.  Tile shapes (channels x positions): <2,4> 64x128, <1,4> 32x256, <2,2> 64x64, <1,2> 32x128, <1,1> 32x64 -- the
 // small ones exist so that short / narrow layers (192 channels x 256 frames x batch 32 = 192 big tiles on 256 CUs) still put
@@ -198,6 +245,7 @@ __global__ __launch_bounds__(256) void conv_input_split_kernel(const float* __re
   // one thread per (batch element, 16-channel block, padded position): 16 coalesced row reads, four 16-byte stores.
   // catW > 0: ONE destination row (B == 1) holding the catB source rows of length catL end to end, catW positions apart
   const int64_t total = (int64_t)B * nblk * Lp;
+  unsigned ev = 0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int pp = (int)(i % Lp), nb = (int)((i / Lp) % nblk);
     int pos = pp - PADL;
@@ -233,7 +281,7 @@ __global__ __launch_bounds__(256) void conv_input_split_kernel(const float* __re
     for (int c = 0; c < 16; ++c) {
       float v = (inside && okc[c] && nb * 16 + c < N) ? raw[c] : 0.f;
       v = lrelu_f(v, slope);
-      const bf16 hv = f16 ? f16_slot(v) : (bf16)v;       // (f16: the single-pass mode's fp16 copy; the lo array is not written)
+      const bf16 hv = f16 ? f16_slot_ev(v, ev) : (bf16)v;   // (f16: the single-pass mode's fp16 copy; the lo array is not written)
       const bf16 lv = (bf16)(v - (float)hv);
       if (c < 8) { h0[c] = hv; l0[c] = lv; } else { h1[c - 8] = hv; l1[c - 8] = lv; }
     }
@@ -245,6 +293,7 @@ __global__ __launch_bounds__(256) void conv_input_split_kernel(const float* __re
       *reinterpret_cast<bf16x8*>(lo + o + (int64_t)Lp * 8) = l1;
     }
   }
+  f16_events_commit(ev);
 }
 
 // the merged-phase weight of row m, virtual tap k: w[n][ci][kk] with ci = m / S, r = m % S, t = (r + rpad) / S - (k - vpad),
@@ -271,6 +320,7 @@ __global__ __launch_bounds__(256) void conv_weight_split_kernel(const float* __r
   // rows of AP >= K*16 elements ([tap][16 channels], zero tail): AP = K*16 + 8 is the LDS row pitch of the DMA-fed kernel,
   // whose stages are verbatim copies of [MT rows][AP] runs of these arrays
   const int64_t total = (int64_t)nblk * Mpad * AP;
+  unsigned ev = 0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int e = (int)(i % AP), m = (int)(i / AP % Mpad), nb = (int)(i / AP / Mpad);
     const int c = e & 15, k = e >> 4;
@@ -282,10 +332,11 @@ __global__ __launch_bounds__(256) void conv_weight_split_kernel(const float* __r
       else if (rowS < 0) v = merged_fwd_weight(w, m, n, k, N / -rowS, Kmem, -rowS, rpad, vpad);
       else v = transposed ? w[((int64_t)n * M + m) * Kmem + tap_off + tap_stride * (K - 1 - k)] : w[((int64_t)m * N + n) * Kmem + k];
     }
-    const bf16 h = f16 ? f16_slot(v) : (bf16)v;
+    const bf16 h = f16 ? f16_slot_ev(v, ev) : (bf16)v;
     a_hi[i] = h;
     if (!f16) a_lo[i] = (bf16)(v - (float)h);
   }
+  f16_events_commit(ev);
 }
 
 // ---- weight-split cache (ABI v8) -----------------------------------------------------------------------------------------
@@ -316,6 +367,7 @@ __global__ __launch_bounds__(256) void conv_weight_split_batched_kernel(const Ws
   const int e = (int)(i % d.AP), m = (int)(i / d.AP % d.Mpad), nb = (int)(i / d.AP / d.Mpad);
   const int c0 = e & 15, k = e >> 4;
   bf16x8 h, l;
+  unsigned ev = 0;
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     const int n = nb * 16 + c0 + c;
@@ -326,12 +378,13 @@ __global__ __launch_bounds__(256) void conv_weight_split_batched_kernel(const Ws
       else v = d.transposed ? d.w[((int64_t)n * d.M + m) * d.Kmem + d.tap_off + d.tap_stride * (d.K - 1 - k)]
                             : d.w[((int64_t)m * d.N + n) * d.Kmem + k];
     }
-    const bf16 hv = d.f16 ? f16_slot(v) : (bf16)v;
+    const bf16 hv = d.f16 ? f16_slot_ev(v, ev) : (bf16)v;
     h[c] = hv;
     l[c] = (bf16)(v - (float)hv);
   }
   *reinterpret_cast<bf16x8*>(d.hi + i) = h;
   if (!d.f16) *reinterpret_cast<bf16x8*>(d.lo + i) = l;
+  f16_events_commit(ev);
 }
 
 struct WsplitKey {
@@ -378,7 +431,7 @@ static bool wsplit_lookup(const ConvMfmaParams& p, const ConvCtx& cx, int nblk, 
     WsplitCache* c = static_cast<WsplitCache*>(cx.handles[hidx]);
     if (!c || c->magic != TTTS_HANDLE_WSPLIT || wp < c->w_lo || wp >= c->w_hi) continue;
     std::lock_guard<std::mutex> g(c->mu);
-    if (!c->armed) return false;
+    if (!c->armed) continue;            // (a later handle over the same range may be the armed one)
     const int f16 = (cx.flags & TTTS_CONV_F16X1) ? 1 : 0;
     const WsplitKey key{p.w, p.M, p.N, p.Mpad, p.K, p.Kmem, p.transposed, p.tap_off, p.tap_stride, AP, p.rowS, p.rpad, p.pad, f16};
     auto it = c->index.find(key);
@@ -654,6 +707,7 @@ __global__ __launch_bounds__(256) void conv1d_bf16x3_kernel(ConvMfmaParams p) {
     // during the MFMAs was measured and lost: +40 VGPRs cost a resident wave, RB1(64) k7 54 -> 69 us, RB1(32) k11 44 -> 51.)
     // (loads are unconditional from clamped addresses, then selected: a guarded load is an exec-masked branch with its own
     // wait -- sixteen of them per position serialised the staging of every 16-channel block)
+    unsigned ev = 0;
     for (int pp = tid; pp < lin_t; pp += 256) {
       const int sg = nseg == 1 ? 0 : pp / lin_s, pos = pp - sg * lin_s, gi = in0 + pos;
       const bool ok = b0 + sg < p.B && gi >= 0 && gi < p.Lin;
@@ -666,7 +720,7 @@ __global__ __launch_bounds__(256) void conv1d_bf16x3_kernel(ConvMfmaParams p) {
       for (int c = 0; c < 16; ++c) {
         float v = (ok && nb * 16 + c < p.N) ? raw[c] : 0.f;
         v = lrelu_f(v, p.in_slope);
-        const bf16 hv = F16 ? f16_slot(v) : (bf16)v;
+        const bf16 hv = F16 ? f16_slot_ev(v, ev) : (bf16)v;
         const bf16 lv = (bf16)(v - (float)hv);
         if (c < 8) { h0[c] = hv; l0[c] = lv; } else { h1[c - 8] = hv; l1[c - 8] = lv; }
       }
@@ -677,6 +731,7 @@ __global__ __launch_bounds__(256) void conv1d_bf16x3_kernel(ConvMfmaParams p) {
         *reinterpret_cast<bf16x8*>(xl + xhalf + pp * 8) = l1;
       }
     }
+    if (F16) f16_events_commit(ev);
     // weights: the stage's [MT][K][16] slab is contiguous in the split arrays; 16-byte chunks, LDS slots precomputed (wlds)
     {
       const bf16* gh = p.a_hi + nb * slab + (int64_t)m0 * K * 16 + tid * 8;
@@ -2054,7 +2109,7 @@ static float* slab_defer(const ConvCtx& cx, float* dw, float* db, bool want_bsla
     SlabArena* c = static_cast<SlabArena*>(cx.handles[h]);
     if (!c || c->magic != TTTS_HANDLE_SLAB || wp < c->dw_lo || wp >= c->dw_hi) continue;
     std::lock_guard<std::mutex> g(c->mu);
-    if (!c->armed) return nullptr;
+    if (!c->armed) continue;            // (a later handle over the same range may be the armed one)
     const SlabKey key{dw, want_bslab ? db : nullptr, K, Cout, Cin};
     const int64_t per = (int64_t)K * Cout * Cin;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -2520,6 +2575,29 @@ int ttts_conv_wgrad_arena_destroy(void* arena) {
   c->magic = 0;
   delete c;
   return TTTS_OK;
+}
+
+// ---- ABI v11: range events of the fp16 conversions + the dynamic loss scale built on them ---------------------------------------
+int ttts_conv_f16_events(int32_t* events3, int32_t reset, void* stream) {
+  using namespace ttts;
+  if (!events3) return fail(TTTS_EINVAL, "f16 events: null destination");
+  f16_events_fetch_kernel<<<1, 64, 0, static_cast<hipStream_t>(stream)>>>(events3, reset);
+  return check_launch("f16_events_fetch");
+}
+
+int ttts_loss_scale_check(float* ls8, int32_t* events3, float* skip, void* stream) {
+  using namespace ttts;
+  if (!ls8 || !events3) return fail(TTTS_EINVAL, "loss scale check: null argument");
+  loss_scale_check_kernel<<<1, 64, 0, static_cast<hipStream_t>(stream)>>>(ls8, events3, skip);
+  return check_launch("loss_scale_check");
+}
+
+int ttts_loss_scale_update(float* ls8, int32_t growth_interval, float backoff, float growth, void* stream) {
+  using namespace ttts;
+  if (!ls8) return fail(TTTS_EINVAL, "loss scale update: null state");
+  if (!(backoff > 0.f && backoff <= 1.f) || !(growth >= 1.f)) return fail(TTTS_EINVAL, "loss scale update: backoff in (0, 1], growth >= 1");
+  loss_scale_update_kernel<<<1, 64, 0, static_cast<hipStream_t>(stream)>>>(ls8, growth_interval, backoff, growth);
+  return check_launch("loss_scale_update");
 }
 
 }  // extern "C"

@@ -552,6 +552,7 @@ __global__ __launch_bounds__(256) void transpose_bf16_batched_kernel(const ttts_
 // ======================================================================================================
 __global__ void adamw_schedule_kernel(float* state, float base_lr, float beta1, float beta2, int warmup_steps) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (state[6] != 0.f) return;                 // skipped step (ABI v11: set by ttts_loss_scale_check): the schedule does not advance
   const double step = (double)state[0] + 1.0;  // exact in fp32 up to 2^24 steps
   double factor = 1.0;
   if (warmup_steps > 0) {
@@ -605,6 +606,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
   const float lr = state[1], bc1 = state[2], bc2s = state[3], coef = state[5];
   const float decay = 1.0f - lr * wd;
   const float step_size = lr / bc1;
+  if (state[6] != 0.f) {                       // skipped step: parameters, moments and shadow stay; the gradient is still consumed
+    if (zero_grad)
+      for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
+        reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     float4 pv = reinterpret_cast<float4*>(p)[i];
     float4 gv = reinterpret_cast<float4*>(g)[i];

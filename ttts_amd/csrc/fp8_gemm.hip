@@ -30,13 +30,24 @@ namespace ttts {
 
 constexpr float FP8_MAX = 448.0f;
 
+// NaN is carried, not clamped away (fmaxf(NaN, x) == x): a NaN element stays NaN through the clamp and the e4m3 conversion, a NaN
+// anywhere in a tensor makes its amax NaN (fp8_amax_kernel), and a NaN amax makes both the quantisation scale and the GEMM's alpha
+// NaN -- a diverged tensor reaches the loss as NaN, as it does in the fp32 / split-bf16 paths.
 __device__ __forceinline__ float fp8_scale_of(const float* amax) {
   const float a = *amax;
-  return a > 0.f ? FP8_MAX / a : 1.0f;
+  return a != a ? a : (a > 0.f ? FP8_MAX / a : 1.0f);
+}
+__device__ __forceinline__ float fp8_alpha_of(const float* amax_a, const float* amax_b) {
+  const float a = *amax_a, b = *amax_b;
+  if (a != a || b != b) return a + b;
+  return ((a > 0.f ? a : FP8_MAX) / FP8_MAX) * ((b > 0.f ? b : FP8_MAX) / FP8_MAX);
+}
+__device__ __forceinline__ float fp8_clamp(float v) {
+  const float c = fminf(fmaxf(v, -FP8_MAX), FP8_MAX);
+  return v != v ? v : c;
 }
 __device__ __forceinline__ uint32_t fp8_pack4(float a, float b, float c, float d) {
-  a = fminf(fmaxf(a, -FP8_MAX), FP8_MAX); b = fminf(fmaxf(b, -FP8_MAX), FP8_MAX);
-  c = fminf(fmaxf(c, -FP8_MAX), FP8_MAX); d = fminf(fmaxf(d, -FP8_MAX), FP8_MAX);
+  a = fp8_clamp(a); b = fp8_clamp(b); c = fp8_clamp(c); d = fp8_clamp(d);
   int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
   w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
   return (uint32_t)w;
@@ -45,24 +56,26 @@ __device__ __forceinline__ uint32_t fp8_pack4(float a, float b, float c, float d
 // ---- amax --------------------------------------------------------------------------------------------------------------------
 // |x| as an unsigned integer orders like the float: one atomicMax per workgroup into a word the launcher cleared.
 __global__ __launch_bounds__(256) void fp8_amax_kernel(const float* __restrict__ x, int64_t n, uint32_t* __restrict__ out) {
-  float m = 0.f;
+  // the maximum is taken on the BIT PATTERNS of |x| (unsigned integers order like non-negative floats, and every NaN pattern is
+  // above +inf's): a NaN element wins the maximum and the result word is a NaN
+  uint32_t m = 0u;
   const int64_t stride = (int64_t)gridDim.x * 256 * 4;
   for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
     if (i + 3 < n) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
-      m = fmaxf(fmaxf(m, fabsf(v[0])), fmaxf(fmaxf(fabsf(v[1]), fabsf(v[2])), fabsf(v[3])));
+      m = max(max(m, __float_as_uint(fabsf(v[0]))), max(max(__float_as_uint(fabsf(v[1])), __float_as_uint(fabsf(v[2]))), __float_as_uint(fabsf(v[3]))));
     } else {
-      for (int64_t j = i; j < n; ++j) m = fmaxf(m, fabsf(x[j]));
+      for (int64_t j = i; j < n; ++j) m = max(m, __float_as_uint(fabsf(x[j])));
     }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  __shared__ float part[4];
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+  __shared__ uint32_t part[4];
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) {
-    m = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
-    atomicMax(out, __float_as_uint(m));
+    m = max(max(part[0], part[1]), max(part[2], part[3]));
+    atomicMax(out, m);
   }
 }
 
@@ -264,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void fp8_gemm_nt_kernel(Fp8GemmParams p) {
       }
     return;
   }
-  const float alpha = ((*p.amax_a > 0.f ? *p.amax_a : FP8_MAX) / FP8_MAX) * ((*p.amax_b > 0.f ? *p.amax_b : FP8_MAX) / FP8_MAX);
+  const float alpha = fp8_alpha_of(p.amax_a, p.amax_b);
   float* Y = p.Y + go * p.y_so;
   const float* R = p.resid ? p.resid + go * p.y_so : nullptr;
 #pragma unroll
@@ -289,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void fp8_gemm_nt_kernel(Fp8GemmParams p) {
 // sum of the `ksplit` partial slabs of every outer group, in slab order (deterministic), scaled and stored like the direct epilogue
 __global__ __launch_bounds__(256) void fp8_slab_reduce_kernel(Fp8GemmParams p, int groups_outer) {
   const int64_t per = (int64_t)p.M * p.N, total = per * groups_outer;
-  const float alpha = ((*p.amax_a > 0.f ? *p.amax_a : FP8_MAX) / FP8_MAX) * ((*p.amax_b > 0.f ? *p.amax_b : FP8_MAX) / FP8_MAX);
+  const float alpha = fp8_alpha_of(p.amax_a, p.amax_b);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int go = (int)(i / per);
     const int64_t e = i - go * per;

@@ -103,6 +103,8 @@ def normalization(channels):
 # forward, the data gradient and the weight gradient (csrc/fp8_gemm.hip; oracle/fp8_ref.py).  Activations between the layers stay
 # fp32 (wider than the config's bf16).  Switch: set_precision() or TTTS_DIFFUSION_PRECISION.
 _PRECISION = {"mode": os.environ.get("TTTS_DIFFUSION_PRECISION", "f32")}
+if _PRECISION["mode"] not in ("f32", "fp8"):          # a typo must not silently select the default arithmetic
+    raise ValueError("TTTS_DIFFUSION_PRECISION must be 'f32' or 'fp8' (got %r)" % _PRECISION["mode"])
 
 
 def set_precision(mode):

@@ -82,20 +82,39 @@ class DiffusionTrainer:
                 a.begin()
             # ('tf32class' convolutions round the data gradient's input to fp16: a power-of-two loss scale keeps it in range, see
             # ttts_amd/vqvae/train.py; divided out of the arena below)
-            ls = float(os.environ.get("TTTS_LOSS_SCALE", "1024")) if ops.conv_precision() == "tf32class" else 1.0
-            (loss * (self.dp.loss_scale() * ls)).backward()
+            # the scale is dynamic: ops.DynamicLossScale, GradScaler's halve / skip / grow rule on device words)
+            lsc = None
+            if ops.conv_precision() == "tf32class":
+                if getattr(self, "_lsc", None) is None:
+                    self._lsc = ops.DynamicLossScale.from_env(self.device)
+                lsc = self._lsc
+            if lsc is None:
+                (loss * self.dp.loss_scale()).backward()
+            else:
+                ((loss * self.dp.loss_scale()) * lsc.scale).backward()
             for a in self._slabs:
                 a.reduce()
-            if ls != 1.0:
-                self.optimizer.flat_g.mul_(1.0 / ls)
+            if lsc is not None:
+                lsc.fetch()
         finally:
             for c in self._wsplit + self._slabs:
                 c.disarm()
+        if lsc is not None and self.dp.enabled:
+            torch.distributed.all_reduce(lsc.events, group=self.dp.group)
         self.dp.allreduce_grads_(self.optimizer.flat_g)
+        res = {"loss": loss.detach(), "terms": out}
+        if lsc is not None:
+            lsc.decide(self.optimizer.opt_state)
+            self.optimizer.flat_g.mul_(lsc.inv_scale)
+            res.update({"loss_scale": lsc.scale.clone(), "f16_saturated": lsc.saturated, "f16_flushed": lsc.flushed,
+                        "f16_subnormal": lsc.subnormal, "skipped_steps": lsc.skipped})
         lr = self.base_lr * warmup(self.step)                             # LambdaLR: the factor of the step being taken
         self.optimizer.step(lr=lr, max_norm=1.0)
+        if lsc is not None:
+            lsc.update()
         self.step += 1
-        return {"loss": loss.detach(), "grad_norm": self.optimizer.grad_norm(), "terms": out}
+        res["grad_norm"] = self.optimizer.grad_norm()
+        return res
 
     def save(self, path):
         if self.rank == 0:

@@ -766,7 +766,8 @@ class GptEngine:
         mode.  A refused capture is reported once on stderr and the engine keeps running launch by launch -- slower on the
         host, identical on the device."""
         torch.cuda.synchronize()
-        cmode = "global" if mode == "none" else "thread_local"
+        alive = torch.distributed.is_available() and torch.distributed.is_initialized()
+        cmode = "global" if (mode == "none" and not alive) else "thread_local"
 
         def record(fn):
             g = torch.cuda.CUDAGraph()

@@ -67,7 +67,7 @@ _c = ctypes
 _P, _I32, _I64, _U64, _F = _c.c_void_p, _c.c_int32, _c.c_int64, _c.c_uint64, _c.c_float
 
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class ConvCtx(ctypes.Structure):
@@ -221,6 +221,9 @@ SIGNATURES = {
     "ttts_conv_wgrad_arena_stats": (_I32, [_P, ctypes.POINTER(ctypes.c_int64)]),
     "ttts_conv_wgrad_arena_release_graphs": (_I32, [_P]),
     "ttts_conv_wgrad_arena_destroy": (_I32, [_P]),
+    "ttts_conv_f16_events": (_I32, [_P, _I32, _P]),
+    "ttts_loss_scale_check": (_I32, [_P, _P, _P, _P]),
+    "ttts_loss_scale_update": (_I32, [_P, _I32, _F, _F, _P]),
     "ttts_tanh_bwd_f32": (_I32, [_P, _P, _P, _I64, _P]),
     "ttts_add4_scale_f32": (_I32, [_P, _P, _P, _P, _F, _P, _I64, _P]),
     "ttts_gate_fwd_f32": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _P]),

@@ -375,6 +375,21 @@ def _ordinal(device):
     return d.index if d.index is not None else torch.cuda.current_device()
 
 
+def _check_no_overlap(kind, tensor):
+    """A second cache / arena over (part of) the same array is refused BEFORE its storage is allocated: the library (ABI v10) keeps
+    no registry, so the check lives with the list the contexts are built from.  Callers that share networks (a second VqvaeStep
+    over the same nets) catch the TttsError and run without their own cache, served by the first object's."""
+    ent = _conv_handles.get(_ordinal(tensor.device))
+    lo, hi = tensor.data_ptr(), tensor.data_ptr() + tensor.numel() * tensor.element_size()
+    for o in (ent["objs"] if ent is not None else []):
+        if type(o).__name__ != kind or o._h is None:
+            continue
+        t = o.weights if kind == "WeightSplitCache" else o.grads
+        olo, ohi = t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()
+        if lo < ohi and olo < hi:
+            raise TttsError("%s: the range overlaps one that already has a %s (close() that one first)" % (kind, kind))
+
+
 def _register_conv_handle(obj, device):
     ent = _conv_handles.setdefault(_ordinal(device), {"objs": [], "array": None})
     ent["objs"].append(obj)
@@ -413,6 +428,7 @@ class WeightSplitCache:
         _req(weights, torch.float32, "weights")
         if not weights.is_contiguous():
             raise TttsError("WeightSplitCache: weights must be contiguous")
+        _check_no_overlap("WeightSplitCache", weights)
         self.weights = weights
         self.storage = torch.empty(weights.numel() * bytes_per_elem + slack + max_entries * 96, dtype=torch.uint8, device=weights.device)
         h = ctypes.c_void_p()
@@ -455,6 +471,7 @@ class WgradSlabArena:
         _req(grads, torch.float32, "grads")
         if not grads.is_contiguous():
             raise TttsError("WgradSlabArena: grads must be contiguous")
+        _check_no_overlap("WgradSlabArena", grads)
         self.grads = grads
         self.storage = torch.empty(int(storage_bytes) + max_entries * 64 + 4096, dtype=torch.uint8, device=grads.device)
         h = ctypes.c_void_p()
@@ -938,6 +955,83 @@ def set_variant_flags(flags):
 
 
 _state = {"conv_precision": os.environ.get("TTTS_CONV_PRECISION", "split_bf16"), "variant": int(os.environ.get("TTTS_DEBUG_FLAGS", "0") or 0)}
+if _state["conv_precision"] not in ("split_bf16", "exact", "tf32class"):     # a typo must not silently select the default kernels
+    raise ValueError("TTTS_CONV_PRECISION must be 'split_bf16', 'exact' or 'tf32class' (got %r)" % _state["conv_precision"])
+
+
+def conv_f16_events(events, reset=True):
+    """events (int32[3], device) += the device's {saturated, flushed-to-zero, subnormal} counts of the fp32 -> fp16 operand
+    conversions of the 'tf32class' convolution mode since the last reset (include/ttts_hip.h: ttts_conv_f16_events).  No sync."""
+    _req(events, torch.int32, "events")
+    if events.numel() < 3:
+        raise TttsError("conv_f16_events: events must hold three int32 words")
+    check(_l.get().ttts_conv_f16_events(_p(events), 1 if reset else 0, _stream()), "conv_f16_events")
+    return events
+
+
+class DynamicLossScale:
+    """`torch.cuda.amp.GradScaler`'s rule (ttts/vqvae/train.py:262,356-372) for the 'tf32class' convolutions, entirely on the device
+    -- no `.item()`, so the step stays one stream of launches and can be recorded as a hipGraph:
+
+        loss * s.scale                   (device scalar)                                   scaler.scale(loss)
+        s.check(optimizer[, reduce])     after the backward: range events -> skip flag     scaler.unscale_ / found_inf
+        arena.mul_(s.inv_scale)          exact for powers of two                           scaler.unscale_
+        optimizer.step()                 a no-op when the check set its skip flag          scaler.step
+        s.update()                       halve on overflow, double after `interval` clean  scaler.update
+
+    What counts as overflow: an operand of an fp16 conversion above 65504 (the conversions saturate instead of producing inf, so
+    the usual "gradient is inf / nan" test would never fire -- the device counters of ops.conv_f16_events are the test).  State,
+    as device scalars: .scale, .inv_scale, .saturated, .flushed, .subnormal, .skipped (totals since construction)."""
+
+    def __init__(self, device, init_scale=1024.0, growth_interval=2000, backoff=0.5, growth=2.0, dynamic=True):
+        self.state = torch.zeros(8, dtype=torch.float32, device=device)
+        self.state[0] = float(init_scale)
+        self.state[1] = 1.0 / float(init_scale)
+        self.events = torch.zeros(4, dtype=torch.int32, device=device)
+        self.interval, self.backoff, self.growth, self.dynamic = int(growth_interval), float(backoff), float(growth), bool(dynamic)
+
+    @classmethod
+    def from_env(cls, device):
+        """TTTS_LOSS_SCALE = initial scale (default 2^10), TTTS_LOSS_SCALE_DYNAMIC=0 pins it, TTTS_LOSS_SCALE_INTERVAL = clean
+        steps in a row before it doubles (default 2000, GradScaler's)."""
+        return cls(device, float(os.environ.get("TTTS_LOSS_SCALE", "1024")), int(os.environ.get("TTTS_LOSS_SCALE_INTERVAL", "2000")),
+                   dynamic=os.environ.get("TTTS_LOSS_SCALE_DYNAMIC", "1") != "0")
+
+    scale = property(lambda self: self.state[0])
+    inv_scale = property(lambda self: self.state[1])
+    saturated = property(lambda self: self.state[4])
+    flushed = property(lambda self: self.state[5])
+    skipped = property(lambda self: self.state[6])
+    subnormal = property(lambda self: self.state[7])
+
+    def fetch(self):
+        """Move the device's range-event counters of the backward that just ran into .events (and clear them)."""
+        conv_f16_events(self.events, reset=True)
+        return self.events
+
+    def decide(self, optimizer_state=None):
+        """An overflow in .events sets optimizer_state[6] (FlatAdamW / GptEngine `opt_state`), which turns the following optimizer
+        step into a no-op; totals accumulate; .events is cleared.  A static scale (dynamic=False) counts but never skips."""
+        skip = optimizer_state[6:7] if (optimizer_state is not None and self.dynamic) else None
+        check(_l.get().ttts_loss_scale_check(_p(self.state), _p(self.events), _p(skip), _stream()), "loss_scale_check")
+
+    def check(self, optimizer_state=None, reduce=None):
+        """fetch + decide; `reduce(events)` in between (data parallel: a SUM all-reduce) makes the decision the same on every rank."""
+        self.fetch()
+        if reduce is not None:
+            reduce(self.events)
+        self.decide(optimizer_state)
+
+    def update(self):
+        if self.dynamic:
+            check(_l.get().ttts_loss_scale_update(_p(self.state), self.interval, self.backoff, self.growth, _stream()), "loss_scale_update")
+        else:
+            self.state[3].zero_()
+
+    def report(self):
+        """Host copy (one sync): {'scale', 'saturated', 'flushed', 'subnormal', 'skipped'}."""
+        v = self.state.tolist()
+        return {"scale": v[0], "saturated": int(v[4]), "flushed": int(v[5]), "subnormal": int(v[7]), "skipped": int(v[6])}
 
 
 def _apply_flags():

@@ -18,17 +18,31 @@ def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
+def dp_forced():
+    """TTTS_DP_FORCE=1: run the data-parallel exchange (process group, collectives, the graphs captured beside the live
+    communicator) even at world size 1.  A sum over one rank is the identity, so results are bit-identical to the
+    non-distributed step -- what the flag buys is that RCCL (backend "nccl") really executes on a 1-GPU box."""
+    return os.environ.get("TTTS_DP_FORCE", "0") not in ("", "0")
+
+
 def init_distributed(backend=None):
     """Initialise the default process group from the torchrun environment (RANK / WORLD_SIZE / MASTER_*)."""
     rank, world, local = env_rank_world()
     if os.environ.get("TTTS_SHARE_GPU"):   # test hook: several ranks on ONE GPU (RCCL refuses duplicate GPUs -> gloo)
         local = 0
         backend = backend or "gloo"
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or dp_forced()) and not dist.is_initialized():
         if backend is None:
             backend = os.environ.get("TTTS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        if "MASTER_PORT" not in os.environ:
+            if world == 1:                      # forced single rank with no launcher: any free loopback port
+                import socket
+                with socket.socket() as s:
+                    s.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+            else:
+                os.environ["MASTER_PORT"] = "29500"
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend, rank=rank, world_size=world)
@@ -59,7 +73,8 @@ class FlatDataParallel:
             grad_dtype = torch.bfloat16
         self.grad_dtype = grad_dtype
         self._stages = {}                    # one bf16 staging buffer per arena (keyed by its data pointer): D and G alternate
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.enabled = (dist.is_available() and dist.is_initialized()
+                        and (dist.get_world_size(group) > 1 or dp_forced()))
         self.world = dist.get_world_size(group) if self.enabled else 1
         self.rank = dist.get_rank(group) if self.enabled else 0
 

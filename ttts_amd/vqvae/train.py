@@ -137,11 +137,27 @@ class VqvaeStep:
         given, is how a caller that records the step as hipGraph segments takes the collective OUT of the recording: it ends
         the current segment, runs fn, starts the next one (VqvaeTrainer._capture)."""
         arena = self.optim_d.flat_g if which == 1 else self.optim_g.flat_g
-        fn = lambda: self.dp.allreduce_grads_(arena)   # noqa: E731
+        lsc = self._loss_scaler()
+
+        def fn():
+            if lsc is not None and self.dp.enabled:      # the overflow decision must be the same on every rank: SUM of the event counts
+                torch.distributed.all_reduce(lsc.events, group=self.dp.group)
+            self.dp.allreduce_grads_(arena)
         if cut is None:
             fn()
         else:
             cut(fn)
+
+    def _loss_scaler(self):
+        """The dynamic loss scale of the 'tf32class' convolution mode (ops.DynamicLossScale: GradScaler's rule on device words;
+        the reference builds `GradScaler(enabled=hps.train.fp16_run)`, vqvae/train.py:262), or None in the fp32-equivalent modes.
+        TTTS_LOSS_SCALE = initial scale (default 2^10), TTTS_LOSS_SCALE_DYNAMIC=0 pins it, TTTS_LOSS_SCALE_INTERVAL = clean steps
+        before it doubles (2000)."""
+        if ops.conv_precision() != "tf32class":
+            return None
+        if getattr(self, "_lsc", None) is None:
+            self._lsc = ops.DynamicLossScale.from_env(self.optim_g.flat_g.device)
+        return self._lsc
 
     def __call__(self, data, inject=None, cut=None, sync_buffers=True):
         """data: dict(wav (B, T) f32, wav_lengths, text, text_lengths) on the device.  Returns a dict of device scalars."""
@@ -195,10 +211,12 @@ class VqvaeStep:
                                           h.win_length, h.mel_fmin, h.mel_fmax)
         y = slice_segments(y.unsqueeze(1), ids_slice * h.hop_length, tr.segment_size)
         scale = self.dp.loss_scale()
-        # 'tf32class' convolutions round the data gradient's input to fp16: a fixed power-of-two loss scale keeps the GAN's small
+        # 'tf32class' convolutions round the data gradient's input to fp16: a power-of-two loss scale keeps the GAN's small
         # gradients (1e-7 .. 1e-2 per element) inside fp16's normal range; it is divided out of the flat gradient arenas before the
-        # exchange / the optimizer (exact: a power of two), so the reported gradient norms and the updates are the unscaled ones
-        ls = float(os.environ.get("TTTS_LOSS_SCALE", "1024")) if ops.conv_precision() == "tf32class" else 1.0
+        # optimizer (exact: a power of two), so the reported gradient norms and the updates are the unscaled ones.  The scale is
+        # DYNAMIC (GradScaler's rule, device-side): a saturated conversion in a backward skips that optimizer step and halves the scale
+        lsc = self._loss_scaler()
+        ls = lsc.scale if lsc is not None else 1.0
         # ---- discriminator phase
         if self.bank_d is not None:
             self.bank_d.refresh()
@@ -209,15 +227,18 @@ class VqvaeStep:
         y_d_hat_r, y_d_hat_g, _, _ = self.net_d(y, y_hat.detach())
         loss_disc, losses_disc_r, losses_disc_g = L.discriminator_loss(y_d_hat_r, y_d_hat_g)
         self.optim_d.zero_grad()
-        (loss_disc * (scale * ls)).backward()
+        (loss_disc * scale if lsc is None else (loss_disc * scale) * ls).backward()
         join_side_streams(y.device)
         for a in self.slabs_d:
             a.reduce()
         if self.bank_d is not None:
             self.bank_d.finish()
-        if ls != 1.0:
-            self.optim_d.flat_g.mul_(1.0 / ls)
+        if lsc is not None:
+            lsc.fetch()
         self._exchange(1, cut)
+        if lsc is not None:
+            lsc.decide(self.optim_d.opt_state)
+            self.optim_d.flat_g.mul_(lsc.inv_scale)
         self.optim_d.step()
         # ---- generator phase.  The reference lets this backward fill net_d's parameter gradients too and throws them away at
         # the next `optim_d.zero_grad()` (vqvae/train.py:354-372 there): here the discriminator's parameters are frozen for the
@@ -237,24 +258,33 @@ class VqvaeStep:
             loss_gen, losses_gen = L.generator_loss(y_d_hat_g)
             loss_gen_all = loss_gen + loss_fm + loss_mel + kl_ssl * 1 + loss_kl
             self.optim_g.zero_grad()
-            (loss_gen_all * (scale * ls)).backward()
+            (loss_gen_all * scale if lsc is None else (loss_gen_all * scale) * ls).backward()
             join_side_streams(y.device)
             for a in self.slabs_g:
                 a.reduce()
             if self.bank_g is not None:
                 self.bank_g.finish()
-            if ls != 1.0:
-                self.optim_g.flat_g.mul_(1.0 / ls)
+            if lsc is not None:
+                lsc.fetch()
         finally:
             for prm in self._d_params:
                 prm.requires_grad_(True)
         self.optim_d.zero_grad()
         self._exchange(2, cut)
+        if lsc is not None:
+            lsc.decide(self.optim_g.opt_state)
+            self.optim_g.flat_g.mul_(lsc.inv_scale)
         self.optim_g.step()
-        return {"loss_disc": loss_disc.detach(), "loss_gen": loss_gen.detach(), "loss_fm": loss_fm.detach(),
-                "loss_mel": loss_mel.detach(), "kl_ssl": kl_ssl.detach(), "loss_kl": loss_kl.detach(),
-                "grad_norm_d": self.optim_d.grad_norm(), "grad_norm_g": self.optim_g.grad_norm(),
-                "loss_gen_all": loss_gen_all.detach()}
+        out = {"loss_disc": loss_disc.detach(), "loss_gen": loss_gen.detach(), "loss_fm": loss_fm.detach(),
+               "loss_mel": loss_mel.detach(), "kl_ssl": kl_ssl.detach(), "loss_kl": loss_kl.detach(),
+               "grad_norm_d": self.optim_d.grad_norm(), "grad_norm_g": self.optim_g.grad_norm(),
+               "loss_gen_all": loss_gen_all.detach()}
+        if lsc is not None:
+            # the scale this step ran with and the running totals of the fp16 range events (device scalars; see ops.DynamicLossScale)
+            out.update({"loss_scale": lsc.scale.clone(), "f16_saturated": lsc.saturated, "f16_flushed": lsc.flushed,
+                        "f16_subnormal": lsc.subnormal, "skipped_steps": lsc.skipped})
+            lsc.update()
+        return out
 
 
 def build_parts(hps, device, seed=None, use_augment=None):
@@ -271,7 +301,7 @@ def build_parts(hps, device, seed=None, use_augment=None):
     optim_d = FlatAdamW(net_d.parameters(), tr.learning_rate, betas=tr.betas, eps=tr.eps)
     dp = FlatDataParallel()
     dp.broadcast_(optim_g.flat_p, optim_d.flat_p)
-    if dp.enabled:      # dropout / sampling streams must differ across ranks (DDP leaves per-process RNG independent)
+    if dp.enabled and dp.world > 1:   # dropout / sampling streams must differ across ranks (DDP leaves per-process RNG independent)
         from .attentions import _SeedSource
         _SeedSource.reseed(hps.train.seed if seed is None else seed, dp.rank)
         torch.manual_seed((hps.train.seed if seed is None else seed) + 7919 * dp.rank)
@@ -308,7 +338,8 @@ class VqvaeTrainer:
         gradient all-reduces (see _capture).  The first call with a new
         shape runs two eager warm-up steps and records; if capture is refused the trainer says so ONCE and keeps running
         launch by launch."""
-        key = tuple((k, tuple(v.shape)) for k, v in sorted(data.items()))
+        # (the convolution precision is baked into a recording -- kernel selection, the loss-scale launches -- so it is part of the key)
+        key = tuple((k, tuple(v.shape)) for k, v in sorted(data.items())) + (ops.conv_precision(),)
         st = getattr(self, "_graph_state", None)
         if st is None or st["key"] != key:
             # the old recording is dropped here: its frozen weight-gradient slab entries may follow the new batch shape again
@@ -365,15 +396,17 @@ class VqvaeTrainer:
                 # flat gradient all-reduces between them -- and the codebook broadcast in front -- issued eagerly at replay.
                 # (Their overlap with compute is limited by the step itself: the generator phase's discriminator forward
                 # needs the UPDATED discriminator, i.e. the first all-reduce, and nothing follows the second one.)
+                # (thread-local capture mode: the process group's watchdog thread polls its work events while we record, which
+                # the default global mode turns into hipErrorStreamCaptureUnsupported -- seen on the first RCCL run, world size 1)
                 segs, between = [torch.cuda.CUDAGraph()], []
-                ctx = [torch.cuda.graph(segs[0])]
+                ctx = [torch.cuda.graph(segs[0], capture_error_mode="thread_local")]
 
                 def cut(fn):
                     ctx[0].__exit__(None, None, None)
                     between.append(fn)
                     fn()                                     # (keeps the ranks' collective sequences aligned during recording)
                     segs.append(torch.cuda.CUDAGraph())
-                    ctx[0] = torch.cuda.graph(segs[-1], pool=segs[0].pool())
+                    ctx[0] = torch.cuda.graph(segs[-1], pool=segs[0].pool(), capture_error_mode="thread_local")
                     ctx[0].__enter__()
                 self.step_fn._sync_buffers()
                 ok, err = 1, None
@@ -397,7 +430,8 @@ class VqvaeTrainer:
                     raise RuntimeError("capture refused on %s" % ("this rank: %s" % err if err is not None else "another rank"))
                 return {"key": key, "graph": segs[0], "segments": segs, "between": between, "inputs": inputs, "out": out}
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            alive = torch.distributed.is_available() and torch.distributed.is_initialized()
+            with torch.cuda.graph(g, capture_error_mode="thread_local" if alive else "global"):
                 out = self.train_step(inputs)
             return {"key": key, "graph": g, "inputs": inputs, "out": out}
         except Exception as err:                             # noqa: BLE001 -- any refusal: report once, run eagerly
