@@ -385,6 +385,24 @@ int ttts_relpos_bias_bwd_f32(const float* dS, const int32_t* bucket, float* dtab
                              int32_t Tq, int32_t Tk, int32_t bucket_offset, int32_t num_buckets, float scale,
                              int32_t accumulate, void* stream);
 int ttts_softmax_bias_fwd_f32(float* scores, const float* bias, int32_t B, int32_t H, int32_t Tq, int32_t Tk, void* stream);
+/* ABI v11: the attention of AttentionBlock as ONE forward and THREE backward launches (csrc/attn_relpos.hip): no (B, H, T, T) tensor.
+ * Replaces: QKVAttentionLegacy.forward (ttts/utils/utils.py:136-169) + RelativePositionBias.forward (xtransformers.py:146-185)
+ *   w = softmax(q^T k / sqrt(ch) + table[bucket(j - i)][h] * bias_scale),  out = v w^T
+ * qkv f32 (B, H, 3, ch, T) (the qkv convolution's output viewed per head), ch == 32; table f32 (num_buckets, H); bucket int32
+ * [2 bucket_off + 1] with the bucket of d = j - i at index d + bucket_off (bucket_off >= T - 1); out f32 (B, H, ch, T);
+ * lse f32 (B, H, T): log2-domain log-sum-exp of the scores, the backward's only saved statistic.
+ * products: 3 = split-bf16 operands (hi*hi + hi*lo + lo*hi, fp32-equivalent), 1 = plain bf16 operands (autocast arithmetic);
+ * fp32 accumulation and softmax either way.  T <= ttts_attn_relpos_max_t(products) (all keys of a head live in LDS): 448 / 896.
+ * bwd: dqkv f32 (B, H, 3, ch, T) written; dtable (num_buckets, H) written or (accumulate_dtable) added to, NULL: not computed --
+ * summed in a fixed order (deterministic).  workspace: ttts_attn_relpos_workspace_bytes(B, H, T). */
+int32_t ttts_attn_relpos_max_t(int32_t products);
+int64_t ttts_attn_relpos_workspace_bytes(int32_t B, int32_t H, int32_t T);
+int ttts_attn_relpos_fwd_f32(const float* qkv, const float* table, const int32_t* bucket, int32_t bucket_off, float* out, float* lse,
+                             int32_t B, int32_t H, int32_t T, int32_t ch, float bias_scale, int32_t products, void* stream);
+int ttts_attn_relpos_bwd_f32(const float* qkv, const float* table, const int32_t* bucket, int32_t bucket_off, const float* out,
+                             const float* dout, const float* lse, float* dqkv, float* dtable, int32_t accumulate_dtable,
+                             void* workspace, int32_t B, int32_t H, int32_t T, int32_t ch, int32_t num_buckets, float bias_scale,
+                             int32_t products, void* stream);
 int ttts_interp_nearest_fwd_f32(const float* x, float* y, int64_t rows, int32_t Tin, int32_t Tout, void* stream);
 int ttts_interp_nearest_bwd_f32(const float* dy, float* dx, int64_t rows, int32_t Tin, int32_t Tout, void* stream);
 int ttts_timestep_embedding_f32(const int64_t* t, const float* freqs, float* emb, int32_t N, int32_t dim, void* stream);

@@ -142,6 +142,79 @@ def test_diffusion_loss_vs_oracle():
     _close(dmo[:, :C], mo.grad[:, :C], 1e-5, 1e-9, "d eps"); _close(dmo[:, C:], mo.grad[:, C:], 5e-5, 1e-9, "d var")
 
 
+def _attn_relpos_reference(qkv, table, bucket, H, scale):
+    """QKVAttentionLegacy + RelativePositionBias in fp64 (ttts/utils/utils.py:136-169, xtransformers.py:176-185)."""
+    B, W, Tn = qkv.shape
+    ch = W // (3 * H)
+    q, k, v = qkv.double().reshape(B * H, 3 * ch, Tn).split(ch, dim=1)
+    sc = 1.0 / np.sqrt(np.sqrt(ch))
+    w = torch.einsum("bct,bcs->bts", q * sc, k * sc)
+    off = (bucket.numel() - 1) // 2
+    idx = (torch.arange(Tn)[None, :] - torch.arange(Tn)[:, None]) + off                  # d = key - query
+    bias = table.double()[bucket.long()[idx]].permute(2, 0, 1) * scale                   # (H, Tq, Tk)
+    w = (w.reshape(B, H, Tn, Tn) + bias[None]).reshape(B * H, Tn, Tn)
+    w = torch.softmax(w, dim=-1)
+    return torch.einsum("bts,bcs->bct", w, v).reshape(B, H * ch, Tn)
+
+
+@pytest.mark.parametrize("B,H,Tn", [(2, 16, 400), (1, 16, 232), (3, 4, 100), (2, 3, 77), (1, 2, 33), (2, 16, 200), (1, 1, 448)])
+@pytest.mark.parametrize("products", [3, 1])
+def test_fused_relpos_attention_vs_fp64(B, H, Tn, products):
+    """csrc/attn_relpos.hip (one forward, three backward launches; no (B, H, T, T) tensor) against the fp64 formula of the
+    reference's attention: output, dqkv and the bias table's gradient.  Stated tolerances, relative to each tensor's range:
+    split-bf16 operands (products = 3, the default path) 3e-5 -- fp32-equivalent; plain bf16 operands (products = 1, the fp8 mode's
+    autocast arithmetic) 2e-2.  Also: equal to the materialised-scores path it replaces within the same bound, and the bias
+    gradient is bit-reproducible (fixed summation order)."""
+    from ttts_amd import ops
+    from ttts_amd.diffusion.aa_model import _bucket_table
+    g = torch.Generator().manual_seed(Tn + H)
+    ch = 32
+    qkv = torch.randn(B, 3 * H * ch, Tn, generator=g) * 1.2
+    table = torch.randn(32, H, generator=g) * 0.5
+    scale = float(ch) ** 0.5
+    bucket = _bucket_table(Tn, 32, 64, torch.device("cpu"))
+    q64 = qkv.double().requires_grad_(True); t64 = table.double().requires_grad_(True)
+    ref = _attn_relpos_reference(q64, t64, bucket, H, scale)
+    dout = torch.randn(ref.shape, generator=g)
+    ref.backward(dout.double())
+    qd, td, bd, dd = qkv.to(_dev()), table.to(_dev()), bucket.to(_dev()), dout.to(_dev())
+    out, lse = ops.attn_relpos_fwd(qd, td, bd, H, scale, products)
+    dqkv, dtable = ops.attn_relpos_bwd(qd, td, bd, out, dd, lse, H, scale, products)
+    dqkv2, dtable2 = ops.attn_relpos_bwd(qd, td, bd, out, dd, lse, H, scale, products)
+    tol = 3e-5 if products == 3 else 2e-2
+    _close(out, ref, tol, msg="out")
+    _close(dqkv, q64.grad, tol, msg="dqkv")
+    _close(dtable, t64.grad, tol, msg="dtable")
+    assert torch.equal(dtable, dtable2) and torch.equal(dqkv, dqkv2)
+    slot = torch.full_like(td, 2.0)                                   # accumulate into a gradient-arena slot
+    ops.attn_relpos_bwd(qd, td, bd, out, dd, lse, H, scale, products, dtable=slot)
+    assert torch.equal(slot, dtable + 2.0)
+    none_q, none_t = ops.attn_relpos_bwd(qd, td, bd, out, dd, lse, H, scale, products, need_dtable=False)
+    assert none_t is None and torch.equal(none_q, dqkv)
+
+
+def test_attention_block_fused_equals_materialised_path(monkeypatch):
+    """AttentionBlock through the fused kernels == through the batched-GEMM / softmax path it replaces (both fp32-equivalent):
+    output and every gradient within 3e-5 of range."""
+    from ttts_amd.diffusion import aa_model as M
+    torch.manual_seed(3)
+    blk = M.AttentionBlock(512, 16, relative_pos_embeddings=True).to(_dev())
+    with torch.no_grad():
+        blk.proj_out.weight.normal_(0, 0.05); blk.proj_out.bias.normal_(0, 0.05)
+    x = torch.randn(2, 512, 232, device=_dev())
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(M, "_FUSED_ATTN", fused)
+        xi = x.clone().requires_grad_(True)
+        for prm in blk.parameters():
+            prm.grad = None
+        y = blk(xi)
+        (y * torch.cos(y.detach())).sum().backward()
+        res[fused] = [y.detach(), xi.grad] + [prm.grad.clone() for prm in blk.parameters()]
+    for a, b in zip(res[True], res[False]):
+        _close(a, b, 3e-5, msg="fused vs materialised")
+
+
 def test_attention_block_and_res_block_match_fixture(gold):
     from ttts_amd.diffusion.aa_model import AttentionBlock, ResBlock
     dev = _dev()

@@ -311,11 +311,45 @@ class AttentionBlock(nn.Module):
         T = x.shape[-1]
         qkv = self.qkv(self.norm(x))
         if self.relative_pos_embeddings is not None:
-            h = _AttnWithBias.apply(qkv, self.relative_pos_embeddings.relative_attention_bias.weight,
-                                    _bucket_table(T, 32, 64, x.device), self.num_heads, float(self.relative_pos_embeddings.scale))
+            products = 1 if _PRECISION["mode"] == "fp8" else 3
+            fused = (_FUSED_ATTN and self.channels // self.num_heads == 32 and T <= ops.attn_relpos_max_t(products))
+            h = (_AttnRelPosFused if fused else _AttnWithBias).apply(
+                qkv, self.relative_pos_embeddings.relative_attention_bias.weight, _bucket_table(T, 32, 64, x.device),
+                self.num_heads, float(self.relative_pos_embeddings.scale))
         else:
             raise NotImplementedError("every AttentionBlock on the diffusion path uses relative position embeddings")
         return self.proj_out(h, resid=x)
+
+
+_FUSED_ATTN = os.environ.get("TTTS_DIFFUSION_FUSED_ATTN", "1") == "1"    # (A/B switch: 0 = the materialised-scores path below)
+
+
+class _AttnRelPosFused(torch.autograd.Function):
+    """AttentionBlock's attention as one forward and three backward launches (csrc/attn_relpos.hip): scores, probabilities and the
+    (H, T, T) bias never exist in memory; saved for the backward: qkv, the output and one log-sum-exp per (b, h, query).
+    Operand arithmetic follows the step's precision mode: split-bf16 (fp32-equivalent) by default, plain bf16 -- the reference's
+    autocast attention (ttts/diffusion/train.py:171) -- in the "fp8" mode."""
+
+    @staticmethod
+    def forward(ctx, qkv, table, bucket, H, scale):
+        qkv = qkv.contiguous()
+        products = 1 if _PRECISION["mode"] == "fp8" else 3
+        tab = table.contiguous()
+        out, lse = ops.attn_relpos_fwd(qkv, tab, bucket, H, scale, products)
+        ctx.save_for_backward(qkv, tab, bucket, out, lse)
+        ctx.cfg = (H, scale, products)
+        ctx.ref = table
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, tab, bucket, out, lse = ctx.saved_tensors
+        H, scale, products = ctx.cfg
+        need = ctx.needs_input_grad[1]
+        slot = _grad_slot(ctx.ref) if need else None
+        dqkv, dtable = ops.attn_relpos_bwd(qkv, tab, bucket, out, dout.contiguous(), lse, H, scale, products, dtable=slot,
+                                           need_dtable=need)
+        return dqkv, (None if (slot is not None or not need) else dtable), None, None, None
 
 
 class _AttnWithBias(torch.autograd.Function):

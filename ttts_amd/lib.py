@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(CSRC, "build")
 SO_PATH = os.environ.get("TTTS_LIB") or os.path.join(HERE, "libttts_hip.so")   # TTTS_LIB: an alternate build of the same ABI (same-box A/B runs: tools/gpu_ab_lib.sh)
-SOURCES = ["lib.hip", "elementwise.hip", "gemm.hip", "attn.hip", "attn_dh64.hip", "vq.hip", "stft.hip", "conv.hip", "conv_mfma.hip", "conv_thin.hip", "conv_grouped.hip", "losses.hip", "vqvae_ops.hip", "attn_f32.hip", "attn_cross.hip", "peq.hip", "decode.hip", "diffusion_ops.hip", "fp8_gemm.hip"]
+SOURCES = ["lib.hip", "elementwise.hip", "gemm.hip", "attn.hip", "attn_dh64.hip", "vq.hip", "stft.hip", "conv.hip", "conv_mfma.hip", "conv_thin.hip", "conv_grouped.hip", "losses.hip", "vqvae_ops.hip", "attn_f32.hip", "attn_cross.hip", "peq.hip", "decode.hip", "diffusion_ops.hip", "fp8_gemm.hip", "attn_relpos.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-Wall", "-Wno-unused-variable"]
 
@@ -175,6 +175,10 @@ SIGNATURES = {
     "ttts_relpos_bias_bwd_workspace_bytes": (_I64, [_I32, _I32, _I32, _I32]),
     "ttts_relpos_bias_bwd_f32": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _F, _I32, _P]),
     "ttts_softmax_bias_fwd_f32": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _P]),
+    "ttts_attn_relpos_max_t": (_I32, [_I32]),
+    "ttts_attn_relpos_workspace_bytes": (_I64, [_I32, _I32, _I32]),
+    "ttts_attn_relpos_fwd_f32": (_I32, [_P, _P, _P, _I32, _P, _P, _I32, _I32, _I32, _I32, _F, _I32, _P]),
+    "ttts_attn_relpos_bwd_f32": (_I32, [_P, _P, _P, _I32, _P, _P, _P, _P, _P, _I32, _P, _I32, _I32, _I32, _I32, _I32, _F, _I32, _P]),
     "ttts_interp_nearest_fwd_f32": (_I32, [_P, _P, _I64, _I32, _I32, _P]),
     "ttts_interp_nearest_bwd_f32": (_I32, [_P, _P, _I64, _I32, _I32, _P]),
     "ttts_timestep_embedding_f32": (_I32, [_P, _P, _P, _I32, _I32, _P]),

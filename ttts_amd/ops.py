@@ -691,6 +691,39 @@ def relpos_bias_bwd(dS, bucket, num_buckets, scale, out=None):
     return out
 
 
+def attn_relpos_max_t(products):
+    return int(_l.get().ttts_attn_relpos_max_t(int(products)))
+
+
+def attn_relpos_fwd(qkv, table, bucket, H, scale, products=3):
+    """Fused non-causal attention with the bucketed relative-position bias (include/ttts_hip.h: ttts_attn_relpos_fwd_f32).
+    qkv (B, 3 H ch, T) fp32 contiguous, per head (q | k | v) x ch channels; returns (out (B, H ch, T), lse (B, H, T))."""
+    _req(qkv, torch.float32, "qkv"); _req(table, torch.float32, "table"); _req(bucket, torch.int32, "bucket")
+    B, W, T = qkv.shape
+    ch = W // (3 * H)
+    out = torch.empty(B, H * ch, T, dtype=torch.float32, device=qkv.device)
+    lse = torch.empty(B, H, T, dtype=torch.float32, device=qkv.device)
+    check(_l.get().ttts_attn_relpos_fwd_f32(_p(qkv), _p(table), _p(bucket), (bucket.numel() - 1) // 2, _p(out), _p(lse), B, H, T, ch,
+                                            float(scale), int(products), _stream()), "attn_relpos_fwd")
+    return out, lse
+
+
+def attn_relpos_bwd(qkv, table, bucket, out, dout, lse, H, scale, products=3, dtable=None, need_dtable=True):
+    """dqkv (and the bias table's gradient: added into `dtable` when given -- a gradient-arena slot -- else returned) of
+    attn_relpos_fwd.  Returns (dqkv, dtable or None)."""
+    B, W, T = qkv.shape
+    ch = W // (3 * H)
+    dqkv = torch.empty_like(qkv)
+    acc = dtable is not None
+    if need_dtable and dtable is None:
+        dtable = torch.empty_like(table)
+    ws = torch.empty(_l.get().ttts_attn_relpos_workspace_bytes(B, H, T) // 4, dtype=torch.float32, device=qkv.device)
+    check(_l.get().ttts_attn_relpos_bwd_f32(_p(qkv), _p(table), _p(bucket), (bucket.numel() - 1) // 2, _p(out), _p(dout), _p(lse),
+                                            _p(dqkv), _p(dtable) if need_dtable else None, 1 if acc else 0, _p(ws), B, H, T, ch,
+                                            table.shape[0], float(scale), int(products), _stream()), "attn_relpos_bwd")
+    return dqkv, (dtable if need_dtable else None)
+
+
 def softmax_bias_fwd(S, bias):
     B, H, Tq, Tk = S.shape
     check(_l.get().ttts_softmax_bias_fwd_f32(_p(S), _p(bias), B, H, Tq, Tk, _stream()), "softmax_bias_fwd")
