@@ -394,7 +394,8 @@ int ttts_softmax_bias_fwd_f32(float* scores, const float* bias, int32_t B, int32
  * products: 3 = split-bf16 operands (hi*hi + hi*lo + lo*hi, fp32-equivalent), 1 = plain bf16 operands (autocast arithmetic);
  * fp32 accumulation and softmax either way.  T <= ttts_attn_relpos_max_t(products) (all keys of a head live in LDS): 448 / 896.
  * bwd: dqkv f32 (B, H, 3, ch, T) written; dtable (num_buckets, H) written or (accumulate_dtable) added to, NULL: not computed --
- * summed in a fixed order (deterministic).  workspace: ttts_attn_relpos_workspace_bytes(B, H, T). */
+ * (per-workgroup diagonal sums by LDS atomics, then a fixed-order reduction: reproducible to fp32 summation noise; dqkv bit for bit).
+ * workspace: ttts_attn_relpos_workspace_bytes(B, H, T). */
 int32_t ttts_attn_relpos_max_t(int32_t products);
 int64_t ttts_attn_relpos_workspace_bytes(int32_t B, int32_t H, int32_t T);
 int ttts_attn_relpos_fwd_f32(const float* qkv, const float* table, const int32_t* bucket, int32_t bucket_off, float* out, float* lse,

@@ -163,8 +163,7 @@ def test_fused_relpos_attention_vs_fp64(B, H, Tn, products):
     """csrc/attn_relpos.hip (one forward, three backward launches; no (B, H, T, T) tensor) against the fp64 formula of the
     reference's attention: output, dqkv and the bias table's gradient.  Stated tolerances, relative to each tensor's range:
     split-bf16 operands (products = 3, the default path) 3e-5 -- fp32-equivalent; plain bf16 operands (products = 1, the fp8 mode's
-    autocast arithmetic) 2e-2.  Also: equal to the materialised-scores path it replaces within the same bound, and the bias
-    gradient is bit-reproducible (fixed summation order)."""
+    autocast arithmetic) 2e-2.  dqkv is bit-reproducible, the bias gradient to fp32 summation noise."""
     from ttts_amd import ops
     from ttts_amd.diffusion.aa_model import _bucket_table
     g = torch.Generator().manual_seed(Tn + H)
@@ -185,10 +184,13 @@ def test_fused_relpos_attention_vs_fp64(B, H, Tn, products):
     _close(out, ref, tol, msg="out")
     _close(dqkv, q64.grad, tol, msg="dqkv")
     _close(dtable, t64.grad, tol, msg="dtable")
-    assert torch.equal(dtable, dtable2) and torch.equal(dqkv, dqkv2)
+    # dqkv is bit-reproducible; the bias gradient's per-workgroup diagonal sums are LDS float atomics (order not fixed), the rest
+    # of its reduction is ordered: run-to-run differences stay at fp32 summation noise
+    assert torch.equal(dqkv, dqkv2)
+    _close(dtable, dtable2, 2e-6, msg="dtable run to run")
     slot = torch.full_like(td, 2.0)                                   # accumulate into a gradient-arena slot
     ops.attn_relpos_bwd(qd, td, bd, out, dd, lse, H, scale, products, dtable=slot)
-    assert torch.equal(slot, dtable + 2.0)
+    _close(slot, dtable + 2.0, 2e-6, msg="accumulated dtable")
     none_q, none_t = ops.attn_relpos_bwd(qd, td, bd, out, dd, lse, H, scale, products, need_dtable=False)
     assert none_t is None and torch.equal(none_q, dqkv)
 

@@ -17,7 +17,8 @@
 // of the next MFMA; V^T / K^T come out of the same row-major tiles through ds_read_b64_tr_b16.  The bias is a per-head table
 // rel[d = key - query] in LDS (2 T floats), added to the score registers.  The backward is two kernels in the same style:
 // dQ (+ delta, + the bias gradient: dS summed per diagonal with LDS atomics, one partial row per workgroup, reduced in a fixed
-// order by a finishing kernel) and dK / dV ("S form": one key per lane, Q / dO of the head staged in LDS).
+// order by a finishing kernel; the in-workgroup atomics' order is not fixed, so the bias gradient reproduces to fp32 summation
+// noise, everything else bit for bit) and dK / dV ("S form": one key per lane, Q / dO of the head staged in LDS).
 #include <algorithm>
 
 #include "attn_common.hpp"
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(256) void relattn_bwd_dq_kernel(RelAttnParams p) {
 }
 
 // bias-gradient finish: one workgroup per head.  tot[d] = sum over the head's workgroups (fixed order), then one thread per bucket
-// walks d in order: dtable[bucket][h] (+)= scale * sum_{d in bucket} tot[d].  Deterministic.
+// walks d in order: dtable[bucket][h] (+)= scale * sum_{d in bucket} tot[d].  (This part is order-fixed.)
 __global__ __launch_bounds__(256) void relattn_dbias_finish_kernel(RelAttnParams p, float* __restrict__ dtable, int num_buckets,
                                                                    int accumulate) {
   extern __shared__ __attribute__((aligned(16))) char ra_smem[];
