@@ -2,8 +2,10 @@
 
 A 1-GPU box cannot run two RCCL ranks (RCCL refuses duplicate devices), but a ONE-rank communicator is a real communicator:
 `ncclCommInitRank`, `ncclAllReduce` / `ncclBroadcast` on RCCL's stream, hipGraph capture and replay beside it.  With the flag
-every collective of the N > 1 path is issued (a sum over one rank is the identity), so each part below must end with exactly the
-bits of the same steps run without a process group -- which the script also runs, in the same process, for the comparison.
+every collective of the N > 1 path is issued (a sum over one rank is the identity), so each part below must end where the same
+steps end without a process group -- which the script also runs, in the same process, for the comparison: bit for bit for the
+GPT step (deterministic kernels), within the step's own run-to-run noise for the VQ-VAE-GAN step (a few float-atomic kernels; two
+plain runs are compared as well).
 
 parts:  gpt    three captured GPT steps, ranged exchange (three hipGraphs around four range all-reduces) and whole-arena exchange
         vqvae  the VQ-VAE-GAN trainer: parameter + codebook broadcast, the D / G arena all-reduces, eagerly and as three
@@ -148,16 +150,24 @@ elif part == "vqvae":
     en, gn, vn = run(False)
     # (the plain trainer's constructor still broadcasts its two parameter arenas -- the group is alive -- then runs collective-free)
     assert calls["all_reduce"] == n_ar and calls["broadcast"] == n_bc + 2, (calls, n_ar, n_bc)
+    en2, gn2, vn2 = run(False)                               # the step's own run-to-run noise (float atomics in a few kernels)
     # 2 eager + 2 warm-up + 1 recorded + 3 replayed steps, two arena all-reduces each (+ the capture votes); parameter broadcast
     # at construction, codebook buffers in front of every step
     assert n_ar >= 2 * 8 and n_bc >= 2 + 8, (n_ar, n_bc)
     worst = lambda a, b: max(float((x - y).abs().max()) for x, y in zip(a, b))   # noqa: E731
     same_eager = all(torch.equal(x, y) for x, y in zip(ef, en))
     same_graph = all(torch.equal(x, y) for x, y in zip(gf, gn))
-    print("vqvae-ok backend=%s all_reduce %d broadcast %d bit_identical_eager=%s bit_identical_graphed=%s worst %.3g / %.3g params %s"
-          % (dist.get_backend(), n_ar, n_bc, same_eager, same_graph, worst(ef, en), worst(gf, gn), digest(*gf)), flush=True)
-    assert same_eager, "eager steps differ from the non-distributed run by %g" % worst(ef, en)
-    assert same_graph, "graphed steps differ from the non-distributed run by %g" % worst(gf, gn)
+    noise_e, noise_g = worst(en, en2), worst(gn, gn2)
+    dloss = max(abs(vf[k] - vn[k]) / max(abs(vn[k]), 1e-6) for k in vn)
+    nloss = max(abs(vn2[k] - vn[k]) / max(abs(vn[k]), 1e-6) for k in vn)
+    print("vqvae-ok backend=%s all_reduce %d broadcast %d bit_identical eager=%s graphed=%s; worst |param diff| vs the plain trainer "
+          "%.3g / %.3g (plain vs plain: %.3g / %.3g); losses after 5 steps: rel diff %.3g (plain vs plain %.3g) params %s"
+          % (dist.get_backend(), n_ar, n_bc, same_eager, same_graph, worst(ef, en), worst(gf, gn), noise_e, noise_g, dloss, nloss,
+             digest(*gf)), flush=True)
+    # a sum over one rank is the identity: the forced run may differ from the plain one only by what two plain runs differ by
+    assert worst(ef, en) <= 4.0 * noise_e + 1e-7, "eager steps differ from the non-distributed run beyond run-to-run noise"
+    assert worst(gf, gn) <= 4.0 * noise_g + 1e-7, "graphed steps differ from the non-distributed run beyond run-to-run noise"
+    assert dloss <= 4.0 * nloss + 1e-6
 else:
     raise SystemExit("unknown part " + part)
 dist.barrier()

@@ -20,27 +20,7 @@ struct AttnParams {
   float inv_keep;
   uint32_t seed_lo, seed_hi;
   const uint32_t* ctr;  // caller-owned dropout stream counter (device) or NULL
-  int group_mode;       // head_dim-64 kernels: 128-row blocks per workgroup -- 0: one; 1: pairs (i, n - 1 - i); 2: <= 4 balanced groups
 };
-
-// Causal work is triangular: block i of n (128 rows each) walks 2 i + 2 tiles of the other axis, so one block per workgroup means
-// workgroups of 2 .. 2 n tiles and a launch bound by its longest ones while the short ones' SIMDs idle.  A workgroup that takes
-// block n - 1 - g and then block g walks 2 n + 2 tiles whatever g is (mode 1); for n = 10 (S = 1156) mode 2 makes FOUR groups
-// of 26 - 28 tiles per (b, h): {9, 3}, {8, 4}, {7, 5}, {6, 2, 1, 0} -- 256 workgroups for B H = 64, one per CU.
-// group_item: the it-th block (by weight rank: 0 = lightest ... n - 1 = heaviest) of group g, or -1 when the list is over.
-__host__ __device__ inline int attn_group_count(int mode, int n) {
-  if (mode == 2 && n == 10) return 4;
-  return mode == 0 ? n : (n + 1) / 2;
-}
-__device__ __forceinline__ int attn_group_item(int mode, int n, int g, int it) {
-  if (mode == 0) return it == 0 ? n - 1 - g : -1;
-  if (mode == 2 && n == 10) {
-    if (g < 3) return it == 0 ? 9 - g : (it == 1 ? 3 + g : -1);
-    return it == 0 ? 6 : (it <= 3 ? 3 - it : -1);
-  }
-  const int hi = n - 1 - g;
-  return it == 0 ? hi : ((it == 1 && g < hi) ? g : -1);
-}
 
 constexpr float NEG_BIG = -1.0e30f;
 constexpr float LOG2E = 1.4426950408889634f;

@@ -20,7 +20,6 @@
 //    per-step conditionals, ring addresses advanced in place, DMA sources kept as running pointers.
 // Operand layouts (v_mfma_f32_32x32x16_bf16) are those of attn.hip: S^T = K.Q^T keeps one query per lane, the exponentiated
 // accumulator registers are the B operand of O^T += V^T.P^T with V^T read by the hardware transpose read.
-#include <stdio.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -28,10 +27,6 @@
 #include "attn_common.hpp"
 
 namespace ttts {
-// shipped defaults of the blocks-per-workgroup grouping (decided by in-step A/B runs: profiles/r06_ab_attn_grouping.txt)
-#define ATTN_GROUP_DEFAULT_FWD 0
-#define ATTN_GROUP_DEFAULT_DQ 0
-#define ATTN_GROUP_DEFAULT_DKDV 0
 namespace dh64 {
 
 constexpr int DH = 64;
@@ -146,22 +141,17 @@ __device__ __forceinline__ uint32_t ds2(float p0, float p1, float dp0, float dp1
 // scores) and V(j - 1), V(j); at its top the wave issues V(j + 1) and then K(j + 2), at its end it waits with vmcnt(2):
 // everything but the two K(j + 2) pieces has landed, i.e. K has two steps and V one step of flight.
 // -------------------------------------------------------------------------------------------------------
-template <bool DROPOUT, bool GROUPED>
-__global__ __launch_bounds__(256, GROUPED ? 2 : 3) void attn_fwd_kernel(AttnParams p) {
+template <bool DROPOUT>
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t lds0 = lds_byte_addr(smem);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hh = lane >> 5;
   const int nqb = (p.S + 127) / 128;
-  const int nbh = gridDim.x / attn_group_count(p.group_mode, nqb);
-  const int grp = (int)(blockIdx.x / nbh);
+  const int nbh = gridDim.x / nqb;
+  const int qb = nqb - 1 - (int)(blockIdx.x / nbh);             // longest workgroups first
   const int bh = blockIdx.x % nbh, h = bh % p.H, b = bh / p.H;
-  // the workgroup's blocks, heaviest first (attn_common.hpp: attn_group_item); GROUPED = false is the one-block kernel, unchanged
-  for (int item = 0; item < (GROUPED ? 4 : 1); ++item) {
-  const int qb = GROUPED ? attn_group_item(p.group_mode, nqb, grp, item) : nqb - 1 - grp;
-  if (GROUPED && qb < 0) break;
-  if (GROUPED && item) __syncthreads();                         // the previous block's epilogue staging has been read
   const int q0 = qb * 128, q_base = q0 + wave * 32;
   const int query = q_base + (lane & 31);
   const bf16* kp = uniform_ptr(p.k + (int64_t)b * p.sb + h * DH);
@@ -420,7 +410,6 @@ __global__ __launch_bounds__(256, GROUPED ? 2 : 3) void attn_fwd_kernel(AttnPara
       if (q_base + row < p.S) *reinterpret_cast<bf16x8*>(op + (int64_t)(q_base + row) * p.oss + ch * 8) = v;
     }
   }
-  }   // blocks of this workgroup
 }
 
 // -------------------------------------------------------------------------------------------------------
@@ -432,7 +421,7 @@ __global__ __launch_bounds__(256, GROUPED ? 2 : 3) void attn_fwd_kernel(AttnPara
 // Step j handles blocks 2j - 1 (tile j - 1) and 2j (tile j): it reads K / V of tiles j - 1 and j, while tile j + 1 (issued at
 // the top of the step into the third ring slot) is in flight; one vmcnt(0) + barrier per step.
 // -------------------------------------------------------------------------------------------------------
-template <bool DROPOUT, bool GROUPED>
+template <bool DROPOUT>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t lds0 = lds_byte_addr(smem);
@@ -440,14 +429,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hh = lane >> 5;
   const int nqb = (p.S + 127) / 128;
-  const int nbh = gridDim.x / attn_group_count(p.group_mode, nqb);
-  const int grp = (int)(blockIdx.x / nbh);
+  const int nbh = gridDim.x / nqb;
+  const int qb = nqb - 1 - (int)(blockIdx.x / nbh);             // longest workgroups first
   const int bh = blockIdx.x % nbh, h = bh % p.H, b = bh / p.H;
-  // the workgroup's blocks, heaviest first (attn_common.hpp: attn_group_item); GROUPED = false is the one-block kernel, unchanged
-  for (int item = 0; item < (GROUPED ? 4 : 1); ++item) {
-  const int qb = GROUPED ? attn_group_item(p.group_mode, nqb, grp, item) : nqb - 1 - grp;
-  if (GROUPED && qb < 0) break;
-  if (GROUPED && item) __syncthreads();                         // the previous block's epilogue staging has been read
   const int q_base = qb * 128 + wave * 32;
   const int query = q_base + (lane & 31), queryc = min(query, p.S - 1);
   const bf16* kp = uniform_ptr(p.k + (int64_t)b * p.sb + h * DH);
@@ -661,7 +645,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
     const bf16x8 v = *reinterpret_cast<const bf16x8*>(ost + row * 144 + ch * 16);
     if (q_base + row < p.S) *reinterpret_cast<bf16x8*>(dq + (int64_t)(q_base + row) * p.ss + ch * 8) = v;
   }
-  }   // blocks of this workgroup
 }
 
 // -------------------------------------------------------------------------------------------------------
@@ -675,7 +658,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
 // -------------------------------------------------------------------------------------------------------
 constexpr int STAT_TILE_B = 3 * 64 * 4;          // lse2[64], -delta[64], row hash[64] of one query tile
 
-template <bool DROPOUT, bool GROUPED>
+template <bool DROPOUT>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t lds0 = lds_byte_addr(smem);
@@ -683,14 +666,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hh = lane >> 5;
   const int nkb = (p.S + 127) / 128;
-  const int nbh = gridDim.x / attn_group_count(p.group_mode, nkb);
-  const int grp = (int)(blockIdx.x / nbh);
+  const int nbh = gridDim.x / nkb;
+  const int kblk = (int)(blockIdx.x / nbh);                     // earliest key blocks see the most queries: they come first
   const int bh = blockIdx.x % nbh, h = bh % p.H, b = bh / p.H;
-  for (int item = 0; item < (GROUPED ? 4 : 1); ++item) {        // the workgroup's blocks, heaviest first (earliest key blocks see the most queries)
-  const int kw = GROUPED ? attn_group_item(p.group_mode, nkb, grp, item) : nkb - 1 - grp;
-  if (GROUPED && kw < 0) break;
-  if (GROUPED && item) __syncthreads();
-  const int kblk = nkb - 1 - kw;
   const int k_base = kblk * 128 + wave * 32;
   const int key = k_base + (lane & 31), keyc = min(key, p.S - 1);
   const bf16* qp = uniform_ptr(p.q + (int64_t)b * p.sb + h * DH);
@@ -965,7 +943,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
       *reinterpret_cast<bf16x8*>(dv + (int64_t)(k_base + row) * p.ss + ch * 8) = vv;
     }
   }
-  }   // blocks of this workgroup
 }
 
 constexpr size_t FWD_SMEM = LDS_TAB + 4 * 64 * sizeof(uint32_t);       // Bm[4][64]
@@ -974,96 +951,24 @@ constexpr size_t DKDV_SMEM = LDS_TAB + 4 * STAT_TILE_B;
 }  // namespace dh64
 
 // 49 - 51 KB of dynamic LDS per workgroup: below the 64 KB a kernel may use without a function attribute
-// Blocks per workgroup (attn_common.hpp: attn_group_item).  TTTS_ATTN_GROUPING = "f,q,k" (or one digit for all three) overrides the
-// per-kernel default for A/B runs: 0 one 128-row block per workgroup, 1 pairs, 2 four balanced groups when there are 10 blocks.
-static int attn_group_mode(int which) {
-  static int modes[3] = {-1, -1, -1};
-  if (modes[0] < 0) {
-    int m[3] = {ATTN_GROUP_DEFAULT_FWD, ATTN_GROUP_DEFAULT_DQ, ATTN_GROUP_DEFAULT_DKDV};
-    if (const char* e = getenv("TTTS_ATTN_GROUPING")) {
-      int a = -1, b = -1, c = -1;
-      const int n = sscanf(e, "%d,%d,%d", &a, &b, &c);
-      if (n == 1) { m[0] = m[1] = m[2] = a; }
-      else if (n == 3) { m[0] = a; m[1] = b; m[2] = c; }
-    }
-    for (int i = 0; i < 3; ++i) modes[i] = m[i] < 0 || m[i] > 2 ? 0 : m[i];
-  }
-  return modes[which];
-}
-
-// experiment: TTTS_ATTN_LDS_PAD = "f,q,k" extra KB of dynamic LDS per workgroup (fewer resident workgroups per CU: with fewer slots
-// than workgroups the dispatcher hands the remaining blocks, longest first, to whichever slot frees up -- list scheduling)
-static size_t attn_lds_pad(int which) {
-  static int pad[3] = {-1, -1, -1};
-  if (pad[0] < 0) {
-    int a = 0, b = 0, c = 0;
-    if (const char* e = getenv("TTTS_ATTN_LDS_PAD")) {
-      const int n = sscanf(e, "%d,%d,%d", &a, &b, &c);
-      if (n == 1) b = c = a;
-    }
-    pad[0] = a; pad[1] = b; pad[2] = c;
-  }
-  return (size_t)pad[which] * 1024;
-}
-template <typename K>
-static void attn_lds_opt_in(K kern, size_t bytes) {
-  if (bytes > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-}
-
-int attn_fwd_dh64(const AttnParams& p0, hipStream_t s) {
-  AttnParams p = p0;
-  p.group_mode = attn_group_mode(0);
-  const int grid = attn_group_count(p.group_mode, (p.S + 127) / 128) * p.H * p.B;
-  const size_t lds = dh64::FWD_SMEM + attn_lds_pad(0);
-  if (lds > 64 * 1024) {
-    attn_lds_opt_in(dh64::attn_fwd_kernel<true, true>, lds); attn_lds_opt_in(dh64::attn_fwd_kernel<false, true>, lds);
-    attn_lds_opt_in(dh64::attn_fwd_kernel<true, false>, lds); attn_lds_opt_in(dh64::attn_fwd_kernel<false, false>, lds);
-  }
-  if (p.group_mode) {
-    if (p.thr) dh64::attn_fwd_kernel<true, true><<<grid, 256, lds, s>>>(p);
-    else dh64::attn_fwd_kernel<false, true><<<grid, 256, lds, s>>>(p);
-  } else {
-    if (p.thr) dh64::attn_fwd_kernel<true, false><<<grid, 256, lds, s>>>(p);
-    else dh64::attn_fwd_kernel<false, false><<<grid, 256, lds, s>>>(p);
-  }
+int attn_fwd_dh64(const AttnParams& p, hipStream_t s) {
+  const int grid = ((p.S + 127) / 128) * p.H * p.B;
+  if (p.thr) dh64::attn_fwd_kernel<true><<<grid, 256, dh64::FWD_SMEM, s>>>(p);
+  else dh64::attn_fwd_kernel<false><<<grid, 256, dh64::FWD_SMEM, s>>>(p);
   return check_launch("attn_fwd_dh64");
 }
 
-int attn_bwd_dkdv_dh64(const AttnParams& p0, hipStream_t s) {
-  AttnParams p = p0;
-  p.group_mode = attn_group_mode(2);
-  const int grid = attn_group_count(p.group_mode, (p.S + 127) / 128) * p.H * p.B;
-  const size_t lds = dh64::DKDV_SMEM + attn_lds_pad(2);
-  if (lds > 64 * 1024) {
-    attn_lds_opt_in(dh64::attn_bwd_dkdv_kernel<true, true>, lds); attn_lds_opt_in(dh64::attn_bwd_dkdv_kernel<false, true>, lds);
-    attn_lds_opt_in(dh64::attn_bwd_dkdv_kernel<true, false>, lds); attn_lds_opt_in(dh64::attn_bwd_dkdv_kernel<false, false>, lds);
-  }
-  if (p.group_mode) {
-    if (p.thr) dh64::attn_bwd_dkdv_kernel<true, true><<<grid, 256, lds, s>>>(p);
-    else dh64::attn_bwd_dkdv_kernel<false, true><<<grid, 256, lds, s>>>(p);
-  } else {
-    if (p.thr) dh64::attn_bwd_dkdv_kernel<true, false><<<grid, 256, lds, s>>>(p);
-    else dh64::attn_bwd_dkdv_kernel<false, false><<<grid, 256, lds, s>>>(p);
-  }
+int attn_bwd_dkdv_dh64(const AttnParams& p, hipStream_t s) {
+  const int grid = ((p.S + 127) / 128) * p.H * p.B;
+  if (p.thr) dh64::attn_bwd_dkdv_kernel<true><<<grid, 256, dh64::DKDV_SMEM, s>>>(p);
+  else dh64::attn_bwd_dkdv_kernel<false><<<grid, 256, dh64::DKDV_SMEM, s>>>(p);
   return check_launch("attn_bwd_dkdv_dh64");
 }
 
-int attn_bwd_dq_dh64(const AttnParams& p0, hipStream_t s) {
-  AttnParams p = p0;
-  p.group_mode = attn_group_mode(1);
-  const int grid = attn_group_count(p.group_mode, (p.S + 127) / 128) * p.H * p.B;
-  const size_t lds = dh64::FWD_SMEM + attn_lds_pad(1);
-  if (lds > 64 * 1024) {
-    attn_lds_opt_in(dh64::attn_bwd_dq_kernel<true, true>, lds); attn_lds_opt_in(dh64::attn_bwd_dq_kernel<false, true>, lds);
-    attn_lds_opt_in(dh64::attn_bwd_dq_kernel<true, false>, lds); attn_lds_opt_in(dh64::attn_bwd_dq_kernel<false, false>, lds);
-  }
-  if (p.group_mode) {
-    if (p.thr) dh64::attn_bwd_dq_kernel<true, true><<<grid, 256, lds, s>>>(p);
-    else dh64::attn_bwd_dq_kernel<false, true><<<grid, 256, lds, s>>>(p);
-  } else {
-    if (p.thr) dh64::attn_bwd_dq_kernel<true, false><<<grid, 256, lds, s>>>(p);
-    else dh64::attn_bwd_dq_kernel<false, false><<<grid, 256, lds, s>>>(p);
-  }
+int attn_bwd_dq_dh64(const AttnParams& p, hipStream_t s) {
+  const int grid = ((p.S + 127) / 128) * p.H * p.B;
+  if (p.thr) dh64::attn_bwd_dq_kernel<true><<<grid, 256, dh64::FWD_SMEM, s>>>(p);
+  else dh64::attn_bwd_dq_kernel<false><<<grid, 256, dh64::FWD_SMEM, s>>>(p);
   return check_launch("attn_bwd_dq_dh64");
 }
 
