@@ -305,3 +305,37 @@ def test_trainer_three_steps_match_fixture(gold):
     big = ref > 1e-3 * ref.max()
     assert np.abs(delta[big] - ref[big]).max() <= 3e-2 * ref.max()
     assert np.median(np.abs(delta[big] / ref[big] - 1)) < 1e-2
+
+
+def test_graphed_diffusion_step_follows_the_eager_step():
+    """DiffusionTrainer.train_step_graphed (one hipGraph per layer-drop pattern, shared pool, device-side warm-up factor) against
+    the launch-by-launch step: same seeds -> the same layer-drop draws, timesteps and noise -> losses and gradient norms of six
+    steps equal to 2e-5 relative (the learning rate's warm-up factor is rounded on the device instead of the host), parameters after
+    the six steps to 1e-6 of their range; at least two different recordings were replayed."""
+    import random
+    from ttts_amd.diffusion.train import DiffusionTrainer
+    cfg = {"train": {"lr": 1e-4, "timesteps": 1000},
+           "aa_diffusion": dict(in_channels=100, out_channels=200, model_channels=512, num_heads=16, num_layers=4, in_latent_channels=512,
+                                dropout=0, layer_drop=0.35, unconditioned_percentage=0.0)}
+    g = torch.Generator().manual_seed(1)
+    mel = (torch.randn(2, 100, 120, generator=g) * 2 - 4).to(_dev()); ref = (torch.randn(2, 100, 80, generator=g) * 2 - 4).to(_dev())
+    lat = torch.randn(2, 512, 30, generator=g).to(_dev())
+    res = {}
+    for graphed in (False, True):
+        random.seed(11); torch.manual_seed(11)
+        tr = DiffusionTrainer(cfg, device=_dev(), seed=3)
+        with torch.no_grad():
+            for k, p in tr.diffusion.named_parameters():
+                if k.endswith("proj_out.weight"):
+                    p.normal_(0, 0.02)
+        vals = []
+        for i in range(8):
+            fn = tr.train_step_graphed if (graphed and i >= 2) else tr.train_step
+            out = fn(mel, ref, lat)
+            vals.append((float(out["loss"]), float(out["grad_norm"])))
+        res[graphed] = (vals, tr.optimizer.flat_p.clone(), tr)
+    st = res[True][2]._gstate
+    assert not st["failed"] and len(st["graphs"]) >= 2, (st["failed"], list(st["graphs"]))
+    np.testing.assert_allclose(np.array(res[True][0]), np.array(res[False][0]), rtol=2e-5)
+    _close(res[True][1], res[False][1], 1e-6, msg="parameters after 8 steps")
+    assert res[True][2].step == res[False][2].step == 8 and float(res[True][2].optimizer.opt_state[0]) == 8.0

@@ -15,6 +15,7 @@ from .. import ops
 
 from ..optim import FlatAdamW
 from ..parallel import FlatDataParallel, init_distributed
+from . import aa_model as _aa
 from .aa_model import AA_diffusion, normalize_tacotron_mel
 from .gaussian import SpacedDiffusion, get_named_beta_schedule, space_timesteps
 
@@ -61,9 +62,70 @@ class DiffusionTrainer:
         except ops.TttsError:           # (a second trainer over the same arrays: it runs without them)
             pass
 
+    # ---- the step as hipGraph replays ------------------------------------------------------------------------------------------
+    def train_step_graphed(self, mel, mel_refer, latent, normalized=False, max_graphs=24):
+        """The same step replayed from a recorded hipGraph (the eager step is ~2 700 launches issued from Python: with the fused
+        attention kernels its device time is well below the host's issue time).  The forward's one HOST-side random choice --
+        which layers `layer_drop` skips (aa_model.py:268-277: random.random() per layer) -- is drawn here, exactly as the eager
+        forward draws it, and selects WHICH recording is replayed: one graph per drop pattern that has occurred (no drop and the
+        seven single drops cover 85 % of the steps at layer_drop 0.1), all sharing one memory pool; rarer patterns beyond
+        `max_graphs` run launch by launch.  t and the noise are drawn into static buffers in front of the replay (the trainer's own
+        generator); the unconditioned mask is drawn inside the graph (torch's capture-aware default generator); the warm-up
+        factor of the learning rate is applied on the device from the optimizer's step counter.  Needs two eager steps first
+        (lazy initialisation of caches and arenas).  The returned scalars are the graph's static outputs: read them before the
+        next call."""
+        import random
+        model = self.diffusion
+        n = len(model.layers)
+        drop = tuple(i for i in range(n)
+                     if model.training and model.layer_drop > 0 and i != 0 and i != n - 1 and random.random() < model.layer_drop)
+        if self.step < 2 or self.dp.enabled:
+            return self.train_step(mel, mel_refer, latent, inject={"drop_layers": drop}, normalized=normalized)
+        key = (tuple(mel.shape), tuple(mel_refer.shape), tuple(latent.shape), bool(normalized), ops.conv_precision(),
+               _aa._PRECISION["mode"])
+        st = getattr(self, "_gstate", None)
+        if st is None or st["key"] != key:
+            for a in self._slabs:
+                a.release_graphs()
+            st = self._gstate = {"key": key, "graphs": {}, "pool": None, "failed": False,
+                                 "mel": mel.clone(), "ref": mel_refer.clone(), "lat": latent.clone(),
+                                 "t": torch.zeros(mel.shape[0], dtype=torch.long, device=self.device),
+                                 "noise": torch.zeros_like(mel)}
+        st["mel"].copy_(mel); st["ref"].copy_(mel_refer); st["lat"].copy_(latent)
+        st["t"].copy_(torch.randint(0, self.desired_diffusion_steps, (mel.shape[0],), device=self.device, generator=self.gen))
+        st["noise"].copy_(torch.randn(mel.shape, device=self.device, dtype=mel.dtype, generator=self.gen))
+        ent = st["graphs"].get(drop)
+        if ent is None and not st["failed"] and len(st["graphs"]) < max_graphs:
+            try:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                alive = torch.distributed.is_available() and torch.distributed.is_initialized()
+                with torch.cuda.graph(g, pool=st["pool"], capture_error_mode="thread_local" if alive else "global"):
+                    out = self._step_body(st["mel"], st["ref"], st["lat"], st["t"], st["noise"], {"drop_layers": drop}, normalized,
+                                          device_warmup=True)
+                if st["pool"] is None:
+                    st["pool"] = g.pool()
+                ent = st["graphs"][drop] = (g, out)
+                # (capture only records: the step itself still has to run, and does below)
+            except Exception as err:                         # noqa: BLE001 -- refused: say so once, run launch by launch from now on
+                import sys
+                print("ttts_amd: hipGraph capture of the diffusion step failed (%s); running it launch by launch"
+                      % str(err).splitlines()[0][:200], file=sys.stderr, flush=True)
+                st["failed"] = True
+                torch.cuda.synchronize()
+        if ent is None:
+            return self._step_body(st["mel"], st["ref"], st["lat"], st["t"], st["noise"], {"drop_layers": drop}, normalized,
+                                   device_warmup=False)
+        ent[0].replay()
+        self.step += 1
+        return ent[1]
+
     def train_step(self, mel, mel_refer, latent, t=None, noise=None, inject=None, normalized=False):
         """mel (B, 100, T) / mel_refer (B, 100, Tr) raw log-mels (`normalized=True`: already through normalize_tacotron_mel),
         latent (B, 512, T / 4) GPT latents (already transposed, train.py:161-165).  Returns {"loss", "grad_norm"} device scalars."""
+        return self._step_body(mel, mel_refer, latent, t, noise, inject, normalized, device_warmup=False)
+
+    def _step_body(self, mel, mel_refer, latent, t, noise, inject, normalized, device_warmup):
         x_start = mel if normalized else normalize_tacotron_mel(mel)
         refer = mel_refer if normalized else normalize_tacotron_mel(mel_refer)
         if t is None:
@@ -108,11 +170,15 @@ class DiffusionTrainer:
             self.optimizer.flat_g.mul_(lsc.inv_scale)
             res.update({"loss_scale": lsc.scale.clone(), "f16_saturated": lsc.saturated, "f16_flushed": lsc.flushed,
                         "f16_subnormal": lsc.subnormal, "skipped_steps": lsc.skipped})
-        lr = self.base_lr * warmup(self.step)                             # LambdaLR: the factor of the step being taken
-        self.optimizer.step(lr=lr, max_norm=1.0)
+        if device_warmup:       # recorded step: the factor comes from the optimizer's device-side step counter (same formula)
+            self.optimizer.step(lr=self.base_lr, max_norm=1.0, warmup_steps=1000)
+        else:
+            lr = self.base_lr * warmup(self.step)                         # LambdaLR: the factor of the step being taken
+            self.optimizer.step(lr=lr, max_norm=1.0)
         if lsc is not None:
             lsc.update()
-        self.step += 1
+        if not (device_warmup and torch.cuda.is_current_stream_capturing()):
+            self.step += 1
         res["grad_norm"] = self.optimizer.grad_norm()
         return res
 

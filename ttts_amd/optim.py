@@ -64,14 +64,16 @@ class FlatAdamW(torch.optim.Optimizer):
             if p.grad is None or p.grad.data_ptr() != self.flat_g[o:].data_ptr():
                 p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
 
-    def step(self, closure=None, lr=None, max_norm=0.0):
+    def step(self, closure=None, lr=None, max_norm=0.0, warmup_steps=0):
         """One AdamW step at learning rate `lr` (default: param_groups[0]["lr"]); also measures ||g||_2 (opt_state[4])
-        and leaves the gradient arena zeroed."""
+        and leaves the gradient arena zeroed.  warmup_steps > 0: `lr` is the BASE rate and the LambdaLR warm-up factor
+        min(1, step / warmup_steps) is applied on the device from the optimizer's own step counter -- a recorded (hipGraph) step
+        cannot take a new host-side rate every replay."""
         if closure is not None:
             raise NotImplementedError("FlatAdamW.step: closures are not part of the path")
         self.attach_grads()
         b1, b2 = self.betas
-        ops.adamw_schedule(self.opt_state, self.lr if lr is None else lr, b1, b2, 0)
+        ops.adamw_schedule(self.opt_state, self.lr if lr is None else lr, b1, b2, int(warmup_steps))
         ops.gradnorm(self.flat_g, max_norm, self.opt_state, self._ws)
         ops.adamw(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, None, self.opt_state, b1, b2, self.eps,
                   self.weight_decay, zero_grad=True)
