@@ -1333,3 +1333,51 @@ def test_second_cache_or_arena_over_the_same_array_is_refused():
         c.close(); a.close()
     c2 = ops.WeightSplitCache(w)                                          # after close() the range is free again
     c2.close()
+
+
+@pytest.mark.bf16x3
+@pytest.mark.parametrize("case", [(32, 192, 384, 256), (16, 512, 1536, 400), (4, 1025, 192, 256), (3, 100, 512, 77), (2, 192, 192, 50),
+                                  (1, 40, 72, 333), (5, 384, 192, 1000)])
+@pytest.mark.parametrize("mode", ["split_bf16", "tf32class"])
+def test_conv1x1_kernel_equals_the_general_path(case, mode):
+    """conv1x1_b3_kernel (round 6: 1 x 1 convolutions as a GEMM over channels -- fp32 input split on the way into LDS, weight
+    fragments straight from the pre-split arrays, 64 x 64 tiles, no operand pre-pass) against the pre-pass + DMA-kernel path it
+    replaces (variant flag 512 switches it off): BIT-identical -- same products in the same order -- for the forward with every
+    epilogue option (bias, per-sample bias, leaky-relu on the input, gate, residual, tanh, mask, scale, accumulate), the dual
+    destination form and the data gradient; and within the mode's stated tolerance of the fp64 convolution."""
+    from ttts_amd import ops
+    B, cin, cout, L = case
+    g = torch.Generator().manual_seed(cin + L)
+    x = torch.randn(B, cin, L, generator=g).to(_dev()); w = (torch.randn(cout, cin, 1, generator=g) / cin ** 0.5).to(_dev())
+    bias = torch.randn(cout, generator=g).to(_dev()); bb = torch.randn(B, cout, generator=g).to(_dev())
+    resid = torch.randn(B, cout, L, generator=g).to(_dev()); gate = torch.randn(B, cout, L, generator=g).to(_dev())
+    mask = (torch.rand(B, L, generator=g) > 0.2).float().to(_dev())
+    dy = torch.randn(B, cout, L, generator=g).to(_dev())
+    prev = ops.set_conv_precision(mode)
+    try:
+        def run():
+            y0 = ops.conv1d_fwd(x, w)
+            y1 = ops.conv1d_fwd(x, w, bias, resid, in_slope=0.1, out_act="tanh", out_scale=0.5, bbias=bb, gate=gate, gate_slope=0.2, omask=mask)
+            acc = resid.clone(); ops.conv1d_fwd(x, w, bias, out=acc, accumulate=True)
+            dx = ops.conv1d_dgrad(dy, w, L)
+            duo = None
+            if cout % 2 == 0:
+                h = cout // 2
+                ya, yb = torch.empty(B, h, L, device=_dev()), torch.full((B, cout - h, L), 0.25, device=_dev())
+                ops.conv1d_fwd_dual(x, w, bias, resid[:, :h].contiguous(), mask, ya, yb, h, accumulate2=True)
+                duo = torch.cat([ya, yb], 1)
+            return [y0, y1, acc, dx] + ([duo] if duo is not None else [])
+        new = run()
+        ops.set_variant_flags(512)
+        try:
+            old = run()
+        finally:
+            ops.set_variant_flags(0)
+    finally:
+        ops.set_conv_precision(prev)
+    for i, (a, b) in enumerate(zip(new, old)):
+        assert torch.equal(a, b), "output %d differs from the general path: max %g" % (i, (a - b).abs().max().item())
+    yr = F.conv1d(x.double().cpu(), w.double().cpu())
+    _close(new[0], yr, 2e-5 if mode == "split_bf16" else 1.5e-3, 0, "y vs fp64")
+    dxr = torch.nn.grad.conv1d_input(x.shape, w.double().cpu(), dy.double().cpu())
+    _close(new[3], dxr, 2e-5 if mode == "split_bf16" else 1.5e-3, 0, "dx vs fp64")

@@ -11,7 +11,7 @@
 // default path uses; NP = 1: plain bf16 operands, the reference's autocast arithmetic (ttts/diffusion/train.py:171), used by the
 // "fp8" mode of the step.  Softmax statistics, the bias, dS and all accumulators are fp32.
 //
-// Shape of the kernels (the S^T form of attn.hip): a workgroup owns (b, h, 128 queries), a wave 32 of them; ALL T keys of the
+// Shape of the kernels (the S^T form of attn.hip): a workgroup (8 waves) owns (b, h, 256 queries), a wave 32 of them; ALL T keys of the
 // head are staged once in LDS as bf16 [key][32 ch] rows (T <= 448 with NP = 3); S^T = K Q^T puts one query per lane, so the row
 // maximum / sum are in-register reductions plus one lane <-> lane + 32 exchange and the exponentiated registers ARE the B operand
 // of the next MFMA; V^T / K^T come out of the same row-major tiles through ds_read_b64_tr_b16.  The bias is a per-head table
@@ -64,28 +64,40 @@ __device__ __forceinline__ f32x16 mma_split(bf16x8 ah, bf16x8 al, bf16x8 bh, bf1
   return mfma32(ah, bh, acc);
 }
 
-// stage src (32 channels x T fp32, time contiguous) as bf16 rows [s][RSTR] (hi and, NP = 3, lo); rows T <= s < Tp are zero
+// stage src (32 channels x T fp32, time contiguous) as bf16 rows [s][RSTR] (hi and, NP = 3, lo); rows T <= s < Tp are zero.
+// All of a thread's loads are issued before the first conversion (a load-convert-store loop ran one ~1 us memory round trip per
+// iteration: 13 of them per operand, 25 us of a workgroup's 30): MAXIT x 8 independent loads in flight per thread.
+constexpr int WG_THREADS = 512;                    // 8 waves: 256 queries (keys) per workgroup
 template <int NP>
 __device__ __forceinline__ void stage_rows(const float* __restrict__ src, int T, int Tp, bf16* hi, bf16* lo, int tid) {
-  for (int i = tid; i < 4 * Tp; i += 256) {
+  constexpr int MAXIT = ((NP == 3 ? 448 : 896) * 4 + WG_THREADS - 1) / WG_THREADS;                 // items (8 channels x 1 position) per thread
+  float v[MAXIT][8];
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int i = min(tid + it * WG_THREADS, 4 * Tp - 1);
     const int cb = i / Tp, s = i - cb * Tp;
-    float v[8];
     const float* sp = src + (int64_t)(cb * 8) * T + min(s, T - 1);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = sp[(int64_t)e * T];
-    if (s >= T) {
+    for (int e = 0; e < 8; ++e) v[it][e] = sp[(int64_t)e * T];
+  }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+  for (int it = 0; it < MAXIT; ++it) {
+    const int i = tid + it * WG_THREADS;
+    if (i < 4 * Tp) {
+      const int cb = i / Tp, s = i - cb * Tp;
+      float w[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) w[e] = s < T ? v[it][e] : 0.f;
+      bf16x8 h, l;
+      split8<NP>(w, h, l);
+      *reinterpret_cast<bf16x8*>(hi + s * RSTR + cb * 8) = h;
+      if (NP == 3) *reinterpret_cast<bf16x8*>(lo + s * RSTR + cb * 8) = l;
     }
-    bf16x8 h, l;
-    split8<NP>(v, h, l);
-    *reinterpret_cast<bf16x8*>(hi + s * RSTR + cb * 8) = h;
-    if (NP == 3) *reinterpret_cast<bf16x8*>(lo + s * RSTR + cb * 8) = l;
   }
 }
 // the per-head bias row in the exp2 domain: rel[d + Tp] = table[bucket(d)][h] * scale * log2(e), d = key - query
 __device__ __forceinline__ void stage_rel(const RelAttnParams& p, int h, float* rel, int tid) {
-  for (int i = tid; i < 2 * p.Tp; i += 256) {
+  for (int i = tid; i < 2 * p.Tp; i += WG_THREADS) {
     const int idx = min(max(i - p.Tp + p.boff, 0), 2 * p.boff);
     rel[i] = p.table[(int64_t)p.bucket[idx] * p.H + h] * p.bscale * LOG2E;
   }
@@ -107,7 +119,7 @@ __device__ __forceinline__ void load_col_frags(const float* __restrict__ src, in
 // forward
 // -------------------------------------------------------------------------------------------------------------------------------
 template <int NP>
-__global__ __launch_bounds__(256) void relattn_fwd_kernel(RelAttnParams p) {
+__global__ __launch_bounds__(WG_THREADS) void relattn_fwd_kernel(RelAttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char ra_smem[];
   const int Tp = p.Tp, T = p.T;
   bf16* Kh = reinterpret_cast<bf16*>(ra_smem);
@@ -121,12 +133,12 @@ __global__ __launch_bounds__(256) void relattn_fwd_kernel(RelAttnParams p) {
   stage_rows<NP>(qb + (int64_t)32 * T, T, Tp, Kh, Kl, tid);
   stage_rows<NP>(qb + (int64_t)64 * T, T, Tp, Vh, Vl, tid);
   stage_rel(p, h, rel, tid);
-  const int query = qt * 128 + wave * 32 + col, qq = min(query, T - 1);
+  const int query = qt * 256 + wave * 32 + col, qq = min(query, T - 1);
   const bool valid = query < T;
   bf16x8 qh[2], ql[2];
   load_col_frags<NP>(qb, T, qq, hh, p.c, valid, qh, ql);
   __syncthreads();
-  if (qt * 128 + wave * 32 >= T) return;       // (wave-uniform; no barrier follows)
+  if (qt * 256 + wave * 32 >= T) return;       // (wave-uniform; no barrier follows)
 
   f32x16 ot;
 #pragma unroll
@@ -200,7 +212,7 @@ __global__ __launch_bounds__(256) void relattn_fwd_kernel(RelAttnParams p) {
 // backward, dQ (one query per lane) + delta + bias-gradient partials
 // -------------------------------------------------------------------------------------------------------------------------------
 template <int NP>
-__global__ __launch_bounds__(256) void relattn_bwd_dq_kernel(RelAttnParams p) {
+__global__ __launch_bounds__(WG_THREADS) void relattn_bwd_dq_kernel(RelAttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char ra_smem[];
   const int Tp = p.Tp, T = p.T;
   bf16* Kh = reinterpret_cast<bf16*>(ra_smem);
@@ -208,15 +220,16 @@ __global__ __launch_bounds__(256) void relattn_bwd_dq_kernel(RelAttnParams p) {
   bf16* Kl = Vh + Tp * RSTR;
   bf16* Vl = Kl + Tp * RSTR;
   float* rel = reinterpret_cast<float*>(ra_smem + (size_t)(NP == 3 ? 4 : 2) * Tp * RSTR * sizeof(bf16));
-  float* dsum = rel + 2 * Tp;                  // [2 Tp]: sum of dS over this workgroup's (query, key) pairs with key - query = d
+  float* dsum = rel + 2 * Tp;                  // [2][2 Tp]: sum of dS over this workgroup's (query, key) pairs with key - query = d, one
+                                               // copy per lane half (lanes (t, 0) and (t + 4, 1) of one instruction hit the same diagonal)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, col = lane & 31, g = lane >> 4, ip = lane & 15;
   const int bh = blockIdx.x / p.nqt, qt = blockIdx.x - bh * p.nqt, h = bh % p.H;
   const float* qb = p.qkv + (int64_t)bh * 96 * T;
   stage_rows<NP>(qb + (int64_t)32 * T, T, Tp, Kh, Kl, tid);
   stage_rows<NP>(qb + (int64_t)64 * T, T, Tp, Vh, Vl, tid);
   stage_rel(p, h, rel, tid);
-  for (int i = tid; i < 2 * Tp; i += 256) dsum[i] = 0.f;
-  const int query = qt * 128 + wave * 32 + col, qq = min(query, T - 1);
+  for (int i = tid; i < 4 * Tp; i += WG_THREADS) dsum[i] = 0.f;
+  const int query = qt * 256 + wave * 32 + col, qq = min(query, T - 1);
   const bool valid = query < T;
   bf16x8 qh[2], ql[2], gh[2], gl[2];
   load_col_frags<NP>(qb, T, qq, hh, p.c, valid, qh, ql);
@@ -239,7 +252,7 @@ __global__ __launch_bounds__(256) void relattn_bwd_dq_kernel(RelAttnParams p) {
   const float lse = valid ? p.lse[(int64_t)bh * T + qq] : POS_BIG;     // invalid lanes: P = exp2(.. - BIG) = 0
   if (valid && hh == 0) p.delta[(int64_t)bh * T + query] = dl;
   __syncthreads();
-  const bool active = qt * 128 + wave * 32 < T;                        // wave-uniform
+  const bool active = qt * 256 + wave * 32 < T;                        // wave-uniform
   if (active) {
     f32x16 dq;
 #pragma unroll
@@ -248,7 +261,7 @@ __global__ __launch_bounds__(256) void relattn_bwd_dq_kernel(RelAttnParams p) {
     const int k_nat = col * RSTR + hh * 8;
     const int k_tr = (4 * hh + (ip >> 2)) * RSTR + 16 * (g & 1) + 4 * (ip & 3);
     const float* relq = rel + Tp - qq;
-    float* dsq = dsum + Tp - qq;
+    float* dsq = dsum + hh * 2 * Tp + Tp - qq;
     for (int kb = 0; kb < nkb; ++kb) {
       f32x16 s, dp;
 #pragma unroll
@@ -274,8 +287,8 @@ __global__ __launch_bounds__(256) void relattn_bwd_dq_kernel(RelAttnParams p) {
         if (ragged && key >= T) sv = NEG_BIG;
         const float pr = __builtin_amdgcn_exp2f(sv - lse);
         ds[r] = pr * (dp[r] - dl);
-        if (p.want_dbias) atomicAdd(&dsq[key], ds[r]);         // ds_add_f32 (lanes of one instruction hit distinct diagonals, the
-      }                                                        // two lane halves may collide: the LDS serialises those)
+        if (p.want_dbias) atomicAdd(&dsq[key], ds[r]);         // ds_add_f32: the 32 lanes of a half hit 32 consecutive diagonals
+      }
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
         float de[8];
@@ -302,33 +315,51 @@ __global__ __launch_bounds__(256) void relattn_bwd_dq_kernel(RelAttnParams p) {
   if (p.want_dbias) {
     __syncthreads();
     float* pp = p.part + (int64_t)blockIdx.x * 2 * Tp;
-    for (int i = tid; i < 2 * Tp; i += 256) pp[i] = dsum[i];
+    for (int i = tid; i < 2 * Tp; i += WG_THREADS) pp[i] = dsum[i] + dsum[2 * Tp + i];
   }
 }
 
-// bias-gradient finish: one workgroup per head.  tot[d] = sum over the head's workgroups (fixed order), then one thread per bucket
-// walks d in order: dtable[bucket][h] (+)= scale * sum_{d in bucket} tot[d].  (This part is order-fixed.)
+// bias-gradient finish: one workgroup per head.  tot[d] = sum over the head's workgroups (fixed order, eight loads in flight), then
+// eight threads per bucket walk d in strides of eight and are combined by a fixed shuffle tree:
+// dtable[bucket][h] (+)= scale * sum_{d in bucket} tot[d].  (This part is order-fixed.)
 __global__ __launch_bounds__(256) void relattn_dbias_finish_kernel(RelAttnParams p, float* __restrict__ dtable, int num_buckets,
                                                                    int accumulate) {
   extern __shared__ __attribute__((aligned(16))) char ra_smem[];
   float* tot = reinterpret_cast<float*>(ra_smem);     // [2 Tp]
   const int h = blockIdx.x, Tp = p.Tp, tid = threadIdx.x;
+  const int rows = p.B * p.nqt;
   for (int i = tid; i < 2 * Tp; i += 256) {
     float s = 0.f;
-    for (int b = 0; b < p.B; ++b)
-      for (int qt = 0; qt < p.nqt; ++qt) s += p.part[((int64_t)(b * p.H + h) * p.nqt + qt) * 2 * Tp + i];
+    int r = 0;
+    for (; r + 8 <= rows; r += 8) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int rr = r + e, b = rr / p.nqt, qt = rr - b * p.nqt;
+        v[e] = p.part[((int64_t)(b * p.H + h) * p.nqt + qt) * 2 * Tp + i];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[e];
+    }
+    for (; r < rows; ++r) {
+      const int b = r / p.nqt, qt = r - b * p.nqt;
+      s += p.part[((int64_t)(b * p.H + h) * p.nqt + qt) * 2 * Tp + i];
+    }
     tot[i] = s;
   }
   __syncthreads();
-  if (tid < num_buckets) {
+  for (int b0 = 0; b0 < num_buckets; b0 += 32) {       // 32 buckets x 8 threads per pass
+    const int bk = b0 + (tid >> 3), sub = tid & 7;
     float s = 0.f;
-    for (int i = 0; i < 2 * Tp; ++i) {
+    for (int i = sub; i < 2 * Tp; i += 8) {
       const int d = i - Tp;
-      if (d <= -p.T || d >= p.T) continue;
-      if (p.bucket[d + p.boff] == tid) s += tot[i];
+      if (d > -p.T && d < p.T && p.bucket[d + p.boff] == bk) s += tot[i];
     }
-    float* dst = dtable + (int64_t)tid * p.H + h;
-    *dst = (accumulate ? *dst : 0.f) + s * p.bscale;
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+    if (sub == 0 && bk < num_buckets) {
+      float* dst = dtable + (int64_t)bk * p.H + h;
+      *dst = (accumulate ? *dst : 0.f) + s * p.bscale;
+    }
   }
 }
 
@@ -336,7 +367,7 @@ __global__ __launch_bounds__(256) void relattn_dbias_finish_kernel(RelAttnParams
 // backward, dK / dV (one key per lane; Q and dO of the head staged in LDS)
 // -------------------------------------------------------------------------------------------------------------------------------
 template <int NP>
-__global__ __launch_bounds__(256) void relattn_bwd_dkdv_kernel(RelAttnParams p) {
+__global__ __launch_bounds__(WG_THREADS) void relattn_bwd_dkdv_kernel(RelAttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char ra_smem[];
   const int Tp = p.Tp, T = p.T;
   bf16* Qh = reinterpret_cast<bf16*>(ra_smem);
@@ -352,17 +383,17 @@ __global__ __launch_bounds__(256) void relattn_bwd_dkdv_kernel(RelAttnParams p) 
   stage_rows<NP>(qb, T, Tp, Qh, Ql, tid);
   stage_rows<NP>(p.d_o + (int64_t)bh * 32 * T, T, Tp, Gh, Gl, tid);
   stage_rel(p, h, rel, tid);
-  for (int i = tid; i < Tp; i += 256) {
+  for (int i = tid; i < Tp; i += WG_THREADS) {
     lse_s[i] = i < T ? p.lse[(int64_t)bh * T + i] : POS_BIG;          // queries beyond T: P = 0
     del_s[i] = i < T ? p.delta[(int64_t)bh * T + i] : 0.f;
   }
-  const int key = kt * 128 + wave * 32 + col, kk = min(key, T - 1);
+  const int key = kt * 256 + wave * 32 + col, kk = min(key, T - 1);
   const bool valid = key < T;
   bf16x8 kh[2], kl[2], vh[2], vl[2];
   load_col_frags<NP>(qb + (int64_t)32 * T, T, kk, hh, p.c, valid, kh, kl);       // K carries log2(e) / sqrt(ch)
   load_col_frags<NP>(qb + (int64_t)64 * T, T, kk, hh, 1.0f, valid, vh, vl);
   __syncthreads();
-  if (kt * 128 + wave * 32 >= T) return;
+  if (kt * 256 + wave * 32 >= T) return;
   f32x16 dk, dv;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
@@ -440,7 +471,7 @@ extern "C" int32_t ttts_attn_relpos_max_t(int32_t products) { return products ==
 
 extern "C" int64_t ttts_attn_relpos_workspace_bytes(int32_t B, int32_t H, int32_t T) {
   if (B <= 0 || H <= 0 || T <= 0) return 0;
-  const int64_t Tp = (T + 31) / 32 * 32, nqt = (T + 127) / 128;
+  const int64_t Tp = (T + 31) / 32 * 32, nqt = (T + 255) / 256;
   return ((int64_t)B * H * T + (int64_t)B * H * nqt * 2 * Tp) * (int64_t)sizeof(float);     // delta + bias-gradient partials
 }
 
@@ -453,7 +484,7 @@ static int relattn_fill(RelAttnParams& p, const float* qkv, const float* table, 
                ttts_attn_relpos_max_t(products));
   TTTS_REQUIRE(bucket_off >= T - 1, "attn_relpos: bucket table covers |d| <= %d, T = %d", bucket_off, T);
   p = RelAttnParams{};
-  p.qkv = qkv; p.table = table; p.bucket = bucket; p.B = B; p.H = H; p.T = T; p.Tp = (T + 31) / 32 * 32; p.nqt = (T + 127) / 128;
+  p.qkv = qkv; p.table = table; p.bucket = bucket; p.B = B; p.H = H; p.T = T; p.Tp = (T + 31) / 32 * 32; p.nqt = (T + 255) / 256;
   p.boff = bucket_off; p.a = 1.0f / sqrtf((float)ch); p.c = p.a * LOG2E; p.bscale = bias_scale;
   return TTTS_OK;
 }
@@ -477,10 +508,10 @@ extern "C" int ttts_attn_relpos_fwd_f32(const float* qkv, const float* table, co
   const dim3 grid((unsigned)(B * H * p.nqt));
   if (products == 3) {
     if (int rc = relattn_opt_in(f3, relattn_fwd_kernel<3>, lds)) return rc;
-    relattn_fwd_kernel<3><<<grid, 256, lds, as_stream(stream)>>>(p);
+    relattn_fwd_kernel<3><<<grid, WG_THREADS, lds, as_stream(stream)>>>(p);
   } else {
     if (int rc = relattn_opt_in(f1, relattn_fwd_kernel<1>, lds)) return rc;
-    relattn_fwd_kernel<1><<<grid, 256, lds, as_stream(stream)>>>(p);
+    relattn_fwd_kernel<1><<<grid, WG_THREADS, lds, as_stream(stream)>>>(p);
   }
   return check_launch("attn_relpos_fwd");
 }
@@ -498,22 +529,22 @@ extern "C" int ttts_attn_relpos_bwd_f32(const float* qkv, const float* table, co
   p.want_dbias = dtable != nullptr;
   hipStream_t s = as_stream(stream);
   const dim3 grid((unsigned)(B * H * p.nqt));
-  const int lds_q = relattn_lds_bytes(products, p.Tp, 2 * p.Tp), lds_k = relattn_lds_bytes(products, p.Tp, 2 * p.Tp);
+  const int lds_q = relattn_lds_bytes(products, p.Tp, 4 * p.Tp), lds_k = relattn_lds_bytes(products, p.Tp, 2 * p.Tp);
   static OnceFlag fq1, fq3, fk1, fk3;
   if (products == 3) {
     if (int rc = relattn_opt_in(fq3, relattn_bwd_dq_kernel<3>, lds_q)) return rc;
-    relattn_bwd_dq_kernel<3><<<grid, 256, lds_q, s>>>(p);
+    relattn_bwd_dq_kernel<3><<<grid, WG_THREADS, lds_q, s>>>(p);
   } else {
     if (int rc = relattn_opt_in(fq1, relattn_bwd_dq_kernel<1>, lds_q)) return rc;
-    relattn_bwd_dq_kernel<1><<<grid, 256, lds_q, s>>>(p);
+    relattn_bwd_dq_kernel<1><<<grid, WG_THREADS, lds_q, s>>>(p);
   }
   if (int rc = check_launch("attn_relpos_bwd_dq")) return rc;
   if (products == 3) {
     if (int rc = relattn_opt_in(fk3, relattn_bwd_dkdv_kernel<3>, lds_k)) return rc;
-    relattn_bwd_dkdv_kernel<3><<<grid, 256, lds_k, s>>>(p);
+    relattn_bwd_dkdv_kernel<3><<<grid, WG_THREADS, lds_k, s>>>(p);
   } else {
     if (int rc = relattn_opt_in(fk1, relattn_bwd_dkdv_kernel<1>, lds_k)) return rc;
-    relattn_bwd_dkdv_kernel<1><<<grid, 256, lds_k, s>>>(p);
+    relattn_bwd_dkdv_kernel<1><<<grid, WG_THREADS, lds_k, s>>>(p);
   }
   if (int rc = check_launch("attn_relpos_bwd_dkdv")) return rc;
   if (dtable) {

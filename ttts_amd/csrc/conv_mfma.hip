@@ -1041,6 +1041,143 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_mfma_kernel(WgradMfmaParams 
 }
 
 
+// ---- 1 x 1 convolutions without the operand pre-pass (round 6) ------------------------------------------------------------------
+// The 192-channel 1 x 1 layers of the WaveNet stacks, the attention projections and the diffusion model's 512-channel linear layers
+// took the general path: conv_input_split_kernel (a full pass over x: ~10 us) + the 64 x 256-tile DMA kernel (23-37 us for 1-4 GFLOP:
+// six MFMAs per wave and 16-channel stage, all DMA latency).  ~350 such calls per VQ-VAE-GAN step, ~125 per diffusion step.
+// Here a 1 x 1 convolution is what it is -- Y[b] = W X[b], a GEMM whose reduction is the channel axis:
+//   * tile 64 output channels x 64 positions, four waves of 32 x 32, so a 192 x 256-frame x 32 layer launches 768 / 384 workgroups
+//     of ~48 KB (3 per CU) instead of 96 / 192 large ones;
+//   * x is read as fp32 straight from the tensor (coalesced 256-byte row pieces), leaky-relu'd and split into bf16 hi / lo ON THE WAY
+//     into LDS, 128 channels per chunk, the next chunk's loads in flight under the current chunk's MFMAs -- no scratch copy;
+//   * the weights' A fragments come straight from the pre-split [channel block][row][16] arrays (weight-split cache layout of the
+//     on-the-fly kernel): the 32 rows x 32 bytes a wave needs per k-step are ONE contiguous 1-KB piece, i.e. a fully coalesced
+//     global_load_dwordx4 per fragment -- no LDS for the weights at all.
+// Same products in the same order as b3_mma (lo*hi, hi*lo, hi*hi per 16-channel block, blocks ascending): bit-identical to the
+// path it replaces.  Epilogue: the non-phase-merged branch of conv_tile_epilogue (bias, per-sample bias, gate, residual, tanh /
+// leaky-relu, mask, scale, accumulate, dual destination).  Flag 512: off (A/B switch).
+template <bool F16>
+__global__ __launch_bounds__(256, 3) void conv1x1_b3_kernel(ConvMfmaParams p) {
+  constexpr int KC = 128, NTL = 64;
+  __shared__ __attribute__((aligned(16))) bf16 xs[2][KC / 8][NTL][8];          // [hi | lo][8-channel group][position][8]: 32 KB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, col = lane & 31;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int j0 = blockIdx.x * NTL, m0 = blockIdx.y * 64, b = blockIdx.z;
+  const int nblk = (p.N + 15) / 16, nchunk = (p.N + KC - 1) / KC;
+  const float* xb = p.x + (int64_t)b * p.N * p.Lin;
+  const int sn = tid & 63, sk = tid >> 6;                                       // staging: position, first 8-channel group (+4 per round)
+  const int spos = min(j0 + sn, p.Lin - 1);
+  const bool sok = j0 + sn < p.Lin;
+  float raw[4][8];
+  auto load_chunk = [&](int c0) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int ch0 = c0 + (it * 4 + sk) * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) raw[it][e] = xb[(int64_t)min(ch0 + e, p.N - 1) * p.Lin + spos];   // clamped loads, selected below
+    }
+  };
+  unsigned ev = 0;
+  auto store_chunk = [&](int c0) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int k8 = it * 4 + sk, ch0 = c0 + k8 * 8;
+      bf16x8 h, l;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = (sok && ch0 + e < p.N) ? raw[it][e] : 0.f;
+        v = lrelu_f(v, p.in_slope);
+        const bf16 hv = F16 ? f16_slot_ev(v, ev) : (bf16)v;
+        h[e] = hv;
+        l[e] = (bf16)(v - (float)hv);
+      }
+      *reinterpret_cast<bf16x8*>(&xs[0][k8][sn][0]) = h;
+      if (!F16) *reinterpret_cast<bf16x8*>(&xs[1][k8][sn][0]) = l;
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const bf16* ahp = p.a_hi + ((int64_t)(m0 + wm * 32 + col)) * 16 + hh * 8;     // + kb * Mpad * 16 per 16-channel block
+  const bf16* alp = p.a_lo + ((int64_t)(m0 + wm * 32 + col)) * 16 + hh * 8;
+  const int64_t astep = (int64_t)p.Mpad * 16;
+  load_chunk(0);
+  for (int c = 0; c < nchunk; ++c) {
+    bf16x8 ah[KC / 16], al[KC / 16];
+#pragma unroll
+    for (int ks = 0; ks < KC / 16; ++ks) {
+      const int kb = min(c * (KC / 16) + ks, nblk - 1);                         // (blocks past the end: loaded clamped, never multiplied)
+      ah[ks] = *reinterpret_cast<const bf16x8*>(ahp + kb * astep);
+      if (!F16) al[ks] = *reinterpret_cast<const bf16x8*>(alp + kb * astep);
+    }
+    if (c) __syncthreads();                                                     // the previous chunk's fragments have been read
+    store_chunk(c * KC);
+    __syncthreads();
+    if (c + 1 < nchunk) load_chunk((c + 1) * KC);
+#pragma unroll
+    for (int ks = 0; ks < KC / 16; ++ks) {
+      if (c * (KC / 16) + ks < nblk) {                                          // workgroup-uniform
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&xs[0][2 * ks + hh][wn * 32 + col][0]);
+        if constexpr (F16) {
+          acc = mfma32_f16(ah[ks], bh, acc);
+        } else {
+          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&xs[1][2 * ks + hh][wn * 32 + col][0]);
+          acc = mfma32(al[ks], bh, acc);
+          acc = mfma32(ah[ks], bl, acc);
+          acc = mfma32(ah[ks], bh, acc);
+        }
+      }
+    }
+  }
+  if (F16) f16_events_commit(ev);
+  const int j = j0 + wn * 32 + col;
+  if (j >= p.Lout) return;
+  const float om = p.omask ? p.omask[(int64_t)b * p.LoutTotal + j] : 1.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm * 32 + acc_row(r, hh);
+    if (m >= p.M) continue;
+    float v = acc[r] + (p.bias ? p.bias[m] : 0.f);
+    const bool second = p.y2 != nullptr && m >= p.M1;
+    const int Mo = p.y2 ? (second ? p.M - p.M1 : p.M1) : p.M, mm = second ? m - p.M1 : m;
+    float* dst = second ? p.y2 : p.y;
+    const int accf = second ? p.acc2 : p.accumulate;
+    const int64_t o = ((int64_t)b * Mo + mm) * p.LoutTotal + j;
+    if (p.bbias) v += p.bbias[(int64_t)b * p.M + m];
+    if (p.gate) v *= (p.gate[o] > 0.f ? 1.f : p.gate_slope);
+    if (p.resid && !second) v += p.resid[o];
+    if (p.out_act == 1) v = tanhf(v);
+    else if (p.out_act == 2) v = lrelu_f(v, p.out_slope);
+    v *= om * p.out_scale;
+    dst[o] = accf ? dst[o] + v : v;
+  }
+}
+
+static bool conv1x1_b3_fits(const ConvMfmaParams& p, const ConvCtx& cx) {
+  return p.K == 1 && p.stride == 1 && p.dil == 1 && p.pad == 0 && p.rowS == 0 && p.catLg == 0 && !p.x_hi && p.out_stride == 1 &&
+         p.out_off == 0 && p.Lout == p.Lin && p.LoutTotal == p.Lout && p.Lout >= 48 && p.N >= 32 && !(cx.flags & 512);
+}
+static int conv1x1_b3_launch(ConvMfmaParams p, const ConvCtx& cx, hipStream_t stream, bool* handled) {
+  const int nblk = (p.N + 15) / 16;
+  p.Mpad = (int)(cdiv(p.M, 64) * 64);
+  const int64_t elems = (int64_t)nblk * p.Mpad * 16;
+  if (2 * elems * (int64_t)sizeof(bf16) > cx.ws_bytes) return TTTS_OK;
+  bf16* hi = static_cast<bf16*>(cx.ws);
+  bf16* lo = hi + elems;
+  bool need_split = true;
+  wsplit_lookup(p, cx, nblk, 16, elems, stream, &hi, &lo, &need_split);       // (the on-the-fly kernel's K * 16 layout: entries are shared)
+  p.a_hi = hi; p.a_lo = lo;
+  const int f16 = (cx.flags & TTTS_CONV_F16X1) ? 1 : 0;
+  if (need_split)
+    conv_weight_split_kernel<<<(int)std::min<int64_t>(cdiv(elems, 256), 2048), 256, 0, stream>>>(p.w, hi, lo, p.M, p.N, p.Mpad, nblk, 1, p.Kmem,
+                                                                                              p.transposed, p.tap_off, p.tap_stride, 16, 0, 0, 0, f16);
+  const dim3 grid((unsigned)cdiv(p.Lout, 64), (unsigned)(p.Mpad / 64), (unsigned)p.B);
+  if (f16) conv1x1_b3_kernel<true><<<grid, 256, 0, stream>>>(p);
+  else conv1x1_b3_kernel<false><<<grid, 256, 0, stream>>>(p);
+  *handled = true;
+  return check_launch("conv1x1_b3");
+}
+
 static int set_attr_once(const void* fn, OnceFlag& done) {
   if (done) return TTTS_OK;
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1195,7 +1332,7 @@ static int conv1d_bf16x3_launch_t(ConvMfmaParams p, const ConvCtx& cx, hipStream
   // more than on-the-fly splitting for the 16..64-channel long-row layers, and wins from 192 channels up); flag 32768:
   // from one tile, flag 65536: never (tools/conv_bench.py)
   // (flag 512, experiment: 1 x 1 convolutions of up to 256 output channels on the on-the-fly kernel -- one launch instead of pre-pass + DMA kernel)
-  const bool k1_direct = (cx.flags & 512) && p.K == 1 && p.M <= 256 && p.x_hi == nullptr && p.rowS == 0;
+  const bool k1_direct = false;   // (round 4's flag-512 experiment -- 1 x 1 layers on the on-the-fly kernel -- lost; the flag now switches conv1x1_b3_kernel off)
   if (WCO == 2 && !(cx.flags & 65536) && !k1_direct && (p.x_hi != nullptr || p.rowS < 0 || cdiv(p.M, MT) >= ((cx.flags & 32768) ? 1 : 3))) {
     int rc = conv1d_bf16x3_dma_launch(p, cx, stream, handled, conv_dma_pick(p, cx));
     if (rc || *handled) return rc;
@@ -1245,6 +1382,10 @@ static int conv1d_mfma_launch(ConvMfmaParams p, const ConvCtx& cx, hipStream_t s
   // batch folding for short rows (see SEG); requested segment length, clipped to the tile by the launcher
   p.SEG = conv_seg_request(p.Lout, p.B);
   if (cx.ws && p.N >= 16 && !(cx.flags & 4096)) {
+    if (conv1x1_b3_fits(p, cx)) {
+      int rc = conv1x1_b3_launch(p, cx, stream, handled);
+      if (rc || *handled) return rc;
+    }
     if (p.rowS < 0) return conv1d_bf16x3_launch_t<2>(p, cx, stream, handled);
     int rc = p.M <= 32 ? conv1d_bf16x3_launch_t<1>(p, cx, stream, handled) : conv1d_bf16x3_launch_t<2>(p, cx, stream, handled);
     if (rc || *handled) return rc;
