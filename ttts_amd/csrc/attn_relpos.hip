@@ -16,9 +16,9 @@
 // maximum / sum are in-register reductions plus one lane <-> lane + 32 exchange and the exponentiated registers ARE the B operand
 // of the next MFMA; V^T / K^T come out of the same row-major tiles through ds_read_b64_tr_b16.  The bias is a per-head table
 // rel[d = key - query] in LDS (2 T floats), added to the score registers.  The backward is two kernels in the same style:
-// dQ (+ delta, + the bias gradient: dS summed per diagonal with LDS atomics, one partial row per workgroup, reduced in a fixed
-// order by a finishing kernel; the in-workgroup atomics' order is not fixed, so the bias gradient reproduces to fp32 summation
-// noise, everything else bit for bit) and dK / dV ("S form": one key per lane, Q / dO of the head staged in LDS).
+// dQ (+ delta, + the bias gradient: dS summed per diagonal -- the 32 x 32 blocks skewed in registers, one LDS atomic per lane and
+// block --, one partial row per workgroup, reduced in a fixed order by a finishing kernel; the in-workgroup atomics' order is not
+// fixed, so the bias gradient reproduces to fp32 summation noise, everything else bit for bit) and dK / dV ("S form": one key per lane, Q / dO of the head staged in LDS).
 #include <algorithm>
 
 #include "attn_common.hpp"
@@ -220,15 +220,14 @@ __global__ __launch_bounds__(WG_THREADS) void relattn_bwd_dq_kernel(RelAttnParam
   bf16* Kl = Vh + Tp * RSTR;
   bf16* Vl = Kl + Tp * RSTR;
   float* rel = reinterpret_cast<float*>(ra_smem + (size_t)(NP == 3 ? 4 : 2) * Tp * RSTR * sizeof(bf16));
-  float* dsum = rel + 2 * Tp;                  // [2][2 Tp]: sum of dS over this workgroup's (query, key) pairs with key - query = d, one
-                                               // copy per lane half (lanes (t, 0) and (t + 4, 1) of one instruction hit the same diagonal)
+  float* dsum = rel + 2 * Tp;                  // [2 Tp]: sum of dS over this workgroup's (query, key) pairs with key - query = d
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, col = lane & 31, g = lane >> 4, ip = lane & 15;
   const int bh = blockIdx.x / p.nqt, qt = blockIdx.x - bh * p.nqt, h = bh % p.H;
   const float* qb = p.qkv + (int64_t)bh * 96 * T;
   stage_rows<NP>(qb + (int64_t)32 * T, T, Tp, Kh, Kl, tid);
   stage_rows<NP>(qb + (int64_t)64 * T, T, Tp, Vh, Vl, tid);
   stage_rel(p, h, rel, tid);
-  for (int i = tid; i < 4 * Tp; i += WG_THREADS) dsum[i] = 0.f;
+  for (int i = tid; i < 2 * Tp; i += WG_THREADS) dsum[i] = 0.f;
   const int query = qt * 256 + wave * 32 + col, qq = min(query, T - 1);
   const bool valid = query < T;
   bf16x8 qh[2], ql[2], gh[2], gl[2];
@@ -261,7 +260,22 @@ __global__ __launch_bounds__(WG_THREADS) void relattn_bwd_dq_kernel(RelAttnParam
     const int k_nat = col * RSTR + hh * 8;
     const int k_tr = (4 * hh + (ip >> 2)) * RSTR + 16 * (g & 1) + 4 * (ip & 3);
     const float* relq = rel + Tp - qq;
-    float* dsq = dsum + hh * 2 * Tp + Tp - qq;
+    // Bias gradient: dsum[d] += dS over the diagonals d = key - query.  One LDS atomic per score (16 per lane and block) made this
+    // kernel 2.5x slower than dK / dV; instead the 32 x 32 block is SKEWED in registers: for score register r the lanes of a half
+    // hold 32 consecutive diagonals (k_r - t), so pulling from lane (k_r - lambda) mod 32 (ds_bpermute) puts diagonal
+    // d_local = lambda (k_r >= lambda) or lambda - 32 (k_r < lambda) into lane lambda for EVERY r -- two running sums per lane.  The
+    // negative half of block kb and the positive half of block kb - 1 are the same absolute diagonals, so one value per lane and
+    // block goes to LDS (32 consecutive addresses from lane half 0: no conflicts), 13 atomics per wave instead of 208.
+    int pull[16];
+    uint32_t posmask = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kr = acc_row(r, hh);
+      pull[r] = ((((kr - col) & 31) | (hh << 5)) << 2);
+      posmask |= (kr >= col ? 1u : 0u) << r;
+    }
+    float carry = 0.f;
+    float* dsw = dsum + Tp - (qt * 256 + wave * 32) + col;      // + 32 kb: diagonal (32 kb + lambda) - (wave's first query)
     for (int kb = 0; kb < nkb; ++kb) {
       f32x16 s, dp;
 #pragma unroll
@@ -287,7 +301,20 @@ __global__ __launch_bounds__(WG_THREADS) void relattn_bwd_dq_kernel(RelAttnParam
         if (ragged && key >= T) sv = NEG_BIG;
         const float pr = __builtin_amdgcn_exp2f(sv - lse);
         ds[r] = pr * (dp[r] - dl);
-        if (p.want_dbias) atomicAdd(&dsq[key], ds[r]);         // ds_add_f32: the 32 lanes of a half hit 32 consecutive diagonals
+      }
+      if (p.want_dbias) {
+        float pos = 0.f, neg = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(pull[r], __builtin_bit_cast(int, ds[r])));
+          const bool isp = (posmask >> r) & 1u;
+          pos += isp ? v : 0.f;
+          neg += isp ? 0.f : v;
+        }
+        pos += __shfl_xor(pos, 32, 64);
+        neg += __shfl_xor(neg, 32, 64);
+        if (hh == 0) atomicAdd(&dsw[32 * (kb - 1)], carry + neg);   // diagonals 32 (kb - 1) + lambda - q0: complete now
+        carry = pos;
       }
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
@@ -306,6 +333,7 @@ __global__ __launch_bounds__(WG_THREADS) void relattn_bwd_dq_kernel(RelAttnParam
         dq = mma_split<NP>(kth, ktl, dh_, dl_, dq);           // dQ^T += K^T dS^T
       }
     }
+    if (p.want_dbias && hh == 0) atomicAdd(&dsw[32 * (nkb - 1)], carry);
     if (valid) {
       float* dqp = p.dqkv + (int64_t)bh * 96 * T + query;
 #pragma unroll
@@ -315,7 +343,7 @@ __global__ __launch_bounds__(WG_THREADS) void relattn_bwd_dq_kernel(RelAttnParam
   if (p.want_dbias) {
     __syncthreads();
     float* pp = p.part + (int64_t)blockIdx.x * 2 * Tp;
-    for (int i = tid; i < 2 * Tp; i += WG_THREADS) pp[i] = dsum[i] + dsum[2 * Tp + i];
+    for (int i = tid; i < 2 * Tp; i += WG_THREADS) pp[i] = dsum[i];
   }
 }
 
@@ -529,7 +557,7 @@ extern "C" int ttts_attn_relpos_bwd_f32(const float* qkv, const float* table, co
   p.want_dbias = dtable != nullptr;
   hipStream_t s = as_stream(stream);
   const dim3 grid((unsigned)(B * H * p.nqt));
-  const int lds_q = relattn_lds_bytes(products, p.Tp, 4 * p.Tp), lds_k = relattn_lds_bytes(products, p.Tp, 2 * p.Tp);
+  const int lds_q = relattn_lds_bytes(products, p.Tp, 2 * p.Tp), lds_k = relattn_lds_bytes(products, p.Tp, 2 * p.Tp);
   static OnceFlag fq1, fq3, fk1, fk3;
   if (products == 3) {
     if (int rc = relattn_opt_in(fq3, relattn_bwd_dq_kernel<3>, lds_q)) return rc;

@@ -164,7 +164,10 @@ class DiffusionTrainer:
         if lsc is not None and self.dp.enabled:
             torch.distributed.all_reduce(lsc.events, group=self.dp.group)
         self.dp.allreduce_grads_(self.optimizer.flat_g)
-        res = {"loss": loss.detach(), "terms": out}
+        # (detached: a returned tensor that still carries its grad_fn keeps this step's autograd graph -- and with it the parameters'
+        # AccumulateGrad nodes, bound to the stream they were created on -- alive in the caller's hands; a later hipGraph capture
+        # then inherits nodes of the default stream and hipStreamEndCapture crashes)
+        res = {"loss": loss.detach(), "terms": {k: v.detach() for k, v in out.items()}}
         if lsc is not None:
             lsc.decide(self.optimizer.opt_state)
             self.optimizer.flat_g.mul_(lsc.inv_scale)
