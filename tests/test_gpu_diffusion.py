@@ -335,7 +335,7 @@ def test_graphed_diffusion_step_follows_the_eager_step():
             vals.append((float(out["loss"]), float(out["grad_norm"])))
         res[graphed] = (vals, tr.optimizer.flat_p.clone(), tr)
     st = res[True][2]._gstate
-    assert not st["failed"] and len(st["graphs"]) >= 2, (st["failed"], list(st["graphs"]))
+    assert not st["failed"] and len(st["graphs"]) >= 6, (st["failed"], list(st["graphs"]))   # () and the five single drops
     np.testing.assert_allclose(np.array(res[True][0]), np.array(res[False][0]), rtol=2e-5)
     _close(res[True][1], res[False][1], 1e-6, msg="parameters after 8 steps")
     assert res[True][2].step == res[False][2].step == 8 and float(res[True][2].optimizer.opt_state[0]) == 8.0

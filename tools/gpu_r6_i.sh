@@ -1,0 +1,14 @@
+#!/bin/bash
+# round 6: full GPU test suite + the default bench line
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+O=gpurun_out/r6i; mkdir -p $O
+timeout 3000 python -m pytest tests -m gpu -q -p no:cacheprovider -x 2>&1 | grep -v "^$" | tail -8
+timeout 1500 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc $?"; tail -3 $O/bench.err | cut -c1-300
+python - <<'PY'
+import json
+d = json.loads(open("gpurun_out/r6i/bench.json").read().strip().splitlines()[-1])
+print({k: d[k] for k in d if k.startswith(("vqvae_", "diffusion_", "gpt_"))})
+print("gpt", d["ms_per_step"], d["value"], "roofline frac", d["roofline"]["frac"], d["roofline"]["step_frac"])
+v = d["vqvae"]; print("vqvae", v["ms_per_step"], v["ms_per_step_eager_streams"], v["ms_per_step_graph_replay"], v["roofline"]["frac"], v["roofline"]["families_ms"], v["tf32class"]["ms_per_step"], v["tf32class"]["loss_scale"], v["tf32class"]["f16_saturated"])
+f = d["diffusion"]; print("diffusion", f["ms_per_step"], f["ms_per_step_eager"], f["ms_per_step_graph_replay"], f["graphs_recorded"], f["roofline"]["frac"], "fp8", f["fp8_gemms"]["ms_per_step"], f["fp8_gemms"]["ms_per_step_eager"], f["fp8_gemms"]["ms_per_step_graph_replay"], f["fp8_gemms"]["with_tf32class_convs"]["ms_per_step"])
+PY

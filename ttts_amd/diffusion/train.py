@@ -63,13 +63,14 @@ class DiffusionTrainer:
             pass
 
     # ---- the step as hipGraph replays ------------------------------------------------------------------------------------------
-    def train_step_graphed(self, mel, mel_refer, latent, normalized=False, max_graphs=24):
+    def train_step_graphed(self, mel, mel_refer, latent, normalized=False, max_graphs=24, max_dropped=1):
         """The same step replayed from a recorded hipGraph (the eager step is ~2 700 launches issued from Python: with the fused
         attention kernels its device time is well below the host's issue time).  The forward's one HOST-side random choice --
         which layers `layer_drop` skips (aa_model.py:268-277: random.random() per layer) -- is drawn here, exactly as the eager
         forward draws it, and selects WHICH recording is replayed: one graph per drop pattern that has occurred (no drop and the
-        seven single drops cover 85 % of the steps at layer_drop 0.1), all sharing one memory pool; rarer patterns beyond
-        `max_graphs` run launch by launch.  t and the noise are drawn into static buffers in front of the replay (the trainer's own
+        seven single drops cover 85 % of the steps at layer_drop 0.1), all sharing one memory pool.  Patterns with at most
+        `max_dropped` skipped layers are recorded up front, on the first call with a new shape (recording does not run the step);
+        rarer patterns run launch by launch -- a recording costs several eager steps and would be replayed once in a hundred.  t and the noise are drawn into static buffers in front of the replay (the trainer's own
         generator); the unconditioned mask is drawn inside the graph (torch's capture-aware default generator); the warm-up
         factor of the learning rate is applied on the device from the optimizer's step counter.  Needs two eager steps first
         (lazy initialisation of caches and arenas).  The returned scalars are the graph's static outputs: read them before the
@@ -94,25 +95,34 @@ class DiffusionTrainer:
         st["mel"].copy_(mel); st["ref"].copy_(mel_refer); st["lat"].copy_(latent)
         st["t"].copy_(torch.randint(0, self.desired_diffusion_steps, (mel.shape[0],), device=self.device, generator=self.gen))
         st["noise"].copy_(torch.randn(mel.shape, device=self.device, dtype=mel.dtype, generator=self.gen))
-        ent = st["graphs"].get(drop)
-        if ent is None and not st["failed"] and len(st["graphs"]) < max_graphs:
+        def record(pattern):
             try:
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 alive = torch.distributed.is_available() and torch.distributed.is_initialized()
                 with torch.cuda.graph(g, pool=st["pool"], capture_error_mode="thread_local" if alive else "global"):
-                    out = self._step_body(st["mel"], st["ref"], st["lat"], st["t"], st["noise"], {"drop_layers": drop}, normalized,
+                    out = self._step_body(st["mel"], st["ref"], st["lat"], st["t"], st["noise"], {"drop_layers": pattern}, normalized,
                                           device_warmup=True)
                 if st["pool"] is None:
                     st["pool"] = g.pool()
-                ent = st["graphs"][drop] = (g, out)
-                # (capture only records: the step itself still has to run, and does below)
+                st["graphs"][pattern] = (g, out)              # (capture only records: the step itself still has to run)
             except Exception as err:                         # noqa: BLE001 -- refused: say so once, run launch by launch from now on
                 import sys
                 print("ttts_amd: hipGraph capture of the diffusion step failed (%s); running it launch by launch"
                       % str(err).splitlines()[0][:200], file=sys.stderr, flush=True)
                 st["failed"] = True
                 torch.cuda.synchronize()
+        if not st["graphs"] and not st["failed"]:            # first call with this shape: the frequent patterns, up front
+            import itertools
+            droppable = [i for i in range(1, n - 1)] if (model.training and model.layer_drop > 0) else []
+            for k in range(0, max_dropped + 1):
+                for pattern in itertools.combinations(droppable, k):
+                    if len(st["graphs"]) < max_graphs and not st["failed"]:
+                        record(tuple(pattern))
+        ent = st["graphs"].get(drop)
+        if ent is None and not st["failed"] and len(drop) <= max_dropped and len(st["graphs"]) < max_graphs:
+            record(drop)
+            ent = st["graphs"].get(drop)
         if ent is None:
             return self._step_body(st["mel"], st["ref"], st["lat"], st["t"], st["noise"], {"drop_layers": drop}, normalized,
                                    device_warmup=False)
