@@ -239,8 +239,8 @@ def vqvae_leg(dev, steps, warmup, cpu_leg=True):
         assert all(v == v for v in vt.values()), vt
         tf32 = {"ms_per_step": round(dt_t * 1e3, 2), "value": round(B * 256 / dt_t, 1), "unit": "frames/s",
                 "dtype": "forward / data-gradient convolution products as ONE fp16 x fp16 MFMA (11 significant bits = TF32's, the reference's "
-                         "cuDNN arithmetic, ttts/vqvae/train.py:34-36; 5 exponent bits: operands saturate at 65504 and lose bits below 6.1e-5 -- "
-                         "counted on the device), fp32 accumulation; weight gradients split-bf16 x3; dynamic loss scale (GradScaler's rule, "
+                         "cuDNN arithmetic, ttts/vqvae/train.py:34-36; 5 exponent bits: operands saturate at 65504, flush to zero at 3e-8 -- both "
+                         "counted on the device -- and keep fewer bits below 6.1e-5), fp32 accumulation; weight gradients split-bf16 x3; dynamic loss scale (GradScaler's rule, "
                          "initial 2^10) divided out of the gradient arenas; everything else as the default",
                 "parity": "tests/test_gpu_vqvae.py::test_tf32class_conv_accuracy (1.5e-3 of the output range per convolution), "
                           "::test_full_step_in_tf32class_mode_against_the_reference_fixture (losses within 1e-3 of the reference fixture, "
@@ -251,7 +251,7 @@ def vqvae_leg(dev, steps, warmup, cpu_leg=True):
                 "losses_after_steps": steps + warmup,
                 "losses": {k: round(v, 4) for k, v in vt.items() if k.startswith(("loss", "kl", "grad"))},
                 "loss_scale": vt.get("loss_scale"), "f16_saturated": vt.get("f16_saturated"), "f16_flushed": vt.get("f16_flushed"),
-                "f16_subnormal": vt.get("f16_subnormal"), "skipped_steps": vt.get("skipped_steps")}
+                "skipped_steps": vt.get("skipped_steps")}
         max_mem = max(max_mem, torch.cuda.max_memory_allocated())
         tr2 = None
     finally:
@@ -336,139 +336,160 @@ def vqvae_cpu_baseline():
                       "%.2f s/step" % (n, frames, frames * 640, threads, dt)}
 
 
-def diffusion_leg(dev, steps, warmup, cpu_leg=True):
+class DiffusionLeg:
     """BASELINE config #5: the diffusion mel-denoiser train step (AA_diffusion, ttts/diffusion/train.py:156-203) at batch 16,
     x_start (16,100,400), latent (16,512,100), refer (16,100,200).  Arithmetic as built: fp32 with split-bf16 matrix-core
-    convolutions and attention -- WIDER than the config's "bf16 + fp8" (stated in `dtype`)."""
-    from ttts_amd.diffusion.train import DiffusionTrainer
-    B, C, T, Tl, Tr = 16, 512, 400, 100, 200
-    cfg = {"train": {"lr": 1e-4, "timesteps": 1000},
-           "aa_diffusion": dict(in_channels=100, out_channels=200, model_channels=C, num_heads=16, num_layers=6, in_latent_channels=512,
-                                dropout=0, layer_drop=0.1)}
-    tr = DiffusionTrainer(cfg, device=dev)
-    with torch.no_grad():      # the reference zero-initialises every attention output projection: give them signal
-        for k, p in tr.diffusion.named_parameters():
-            if k.endswith("proj_out.weight"):
-                p.normal_(0, 0.02)
-    g = torch.Generator().manual_seed(0)
-    mel = (torch.randn(B, 100, T, generator=g) * 2 - 4).to(dev); ref = (torch.randn(B, 100, Tr, generator=g) * 2 - 4).to(dev)
-    lat = torch.randn(B, 512, Tl, generator=g).to(dev)                     # inputs resident in HBM before the timed region
-    def timed(fn, n_warm):
-        for _ in range(n_warm):
-            o = fn(mel, ref, lat)
-        torch.cuda.synchronize(); t0_ = time.perf_counter()
-        for _ in range(steps):
-            o = fn(mel, ref, lat)
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0_) / steps, o
+    convolutions and attention -- WIDER than the config's "bf16 + fp8" (stated in `dtype`) -- and, beside it, the
+    reduced-precision modes (fp8 GEMMs + bf16 attention; the same with TF32-class k = 3 convolutions).
+    Two phases, because order matters for eager timings (HISTORY 18.4: a process that has recorded hipGraphs issues eager launches
+    more slowly): eager() times every mode launch by launch BEFORE anything in the process has recorded a graph; graphs(), called
+    after the VQ-VAE-GAN leg's eager timing, replays the same steps from recorded hipGraphs."""
+    MODES = ("default", "fp8", "fp8_tf32class")
 
-    def both(tag):
-        """(eager s/step, graph-replay s/step or None, last outputs): the same step issued launch by launch (~2 700 launches from
-        Python) and replayed from recorded hipGraphs (one per layer-drop pattern with at most one skipped layer -- 85 % of the steps --
-        recorded by the first call, ahead of the clock; rarer patterns run launch by launch inside the timed region)."""
-        dt_e, o = timed(tr.train_step, warmup)
-        dt_g = None
-        try:
-            dt_g, o_g = timed(tr.train_step_graphed, 3)
-            if tr._gstate.get("failed") or not tr._gstate["graphs"]:
-                dt_g = None
-            else:
-                o = o_g if dt_g < dt_e else o
-        except Exception as err:                  # noqa: BLE001 -- report, keep the eager number
-            print("bench: graphed diffusion step (%s) failed: %s" % (tag, str(err).splitlines()[0][:160]), file=sys.stderr, flush=True)
-            dt_g = None
-        lv = float(o["loss"])
-        assert lv == lv, "non-finite diffusion loss (%s)" % tag
-        return dt_e, dt_g, o, lv
+    def __init__(self, dev, steps, warmup):
+        from ttts_amd.diffusion.train import DiffusionTrainer
+        self.B, self.C, self.T, self.Tl, self.Tr = 16, 512, 400, 100, 200
+        self.steps, self.warmup = steps, warmup
+        cfg = {"train": {"lr": 1e-4, "timesteps": 1000},
+               "aa_diffusion": dict(in_channels=100, out_channels=200, model_channels=self.C, num_heads=16, num_layers=6, in_latent_channels=512,
+                                    dropout=0, layer_drop=0.1)}
+        self.tr = DiffusionTrainer(cfg, device=dev)
+        with torch.no_grad():      # the reference zero-initialises every attention output projection: give them signal
+            for k, p in self.tr.diffusion.named_parameters():
+                if k.endswith("proj_out.weight"):
+                    p.normal_(0, 0.02)
+        g = torch.Generator().manual_seed(0)
+        B, T, Tr, Tl = self.B, self.T, self.Tr, self.Tl
+        self.mel = (torch.randn(B, 100, T, generator=g) * 2 - 4).to(dev); self.ref = (torch.randn(B, 100, Tr, generator=g) * 2 - 4).to(dev)
+        self.lat = torch.randn(B, 512, Tl, generator=g).to(dev)                # inputs resident in HBM before the timed region
+        self.dt_e, self.dt_g, self.out, self.loss = {}, {}, {}, {}
 
-    def pick(dt_e, dt_g):
-        return dt_e if dt_g is None else min(dt_e, dt_g)
-    dt_e, dt_g, out, loss = both("default")
-    dt = pick(dt_e, dt_g)
-    # the same step with every 1 x 1 convolution / linear layer on the fp8 (e4m3) matrix cores -- BASELINE config #5's GEMM arithmetic
-    # (csrc/fp8_gemm.hip; activations between the layers stay fp32, the k = 3 convolutions as above) and the attention core on plain
-    # bf16 operands (the reference's autocast attention)
-    from ttts_amd.diffusion import aa_model as _aa
-    fp8 = None
-    prev_mode = _aa.set_precision("fp8")
-    try:
-        dt8_e, dt8_g, out8, loss8 = both("fp8")
-        dt8 = pick(dt8_e, dt8_g)
-        fp8 = {"ms_per_step": round(dt8 * 1e3, 2), "ms_per_step_eager": round(dt8_e * 1e3, 2),
-               "ms_per_step_graph_replay": None if dt8_g is None else round(dt8_g * 1e3, 2),
-               "value": round(B * T / dt8, 1), "unit": "frames/s", "loss": round(loss8, 4),
-               "dtype": "f32 activations; the 1 x 1 convolutions / linear layers (qkv, proj_out, ResBlock input conv, integrating conv, "
-                        "timestep MLP: forward, data gradient and weight gradient) as e4m3 x e4m3 on v_mfma_f32_32x32x16_fp8_fp8 with "
-                        "per-tensor current scaling and fp32 accumulation; attention core (fused, csrc/attn_relpos.hip) on plain bf16 "
-                        "operands with fp32 softmax / accumulation; k = 3 convolutions split-bf16",
-               "parity": "tests/test_gpu_fp8.py: kernels within 6e-5 of the output range of the oracle's quantised arithmetic (measured 1.6e-5); "
-                         "step vs the reference fixture: loss within 2 %, model output within 15 % relative L2, gradient cosines >= 0.95; "
-                         "tests/test_gpu_diffusion.py::test_fused_relpos_attention_vs_fp64 (bf16 operands: 2e-2 of range)"}
-        # ... and with the remaining (k = 3) convolutions' forward / data gradient in the single-pass TF32-class arithmetic as well
-        # (fp16 x fp16 products, fp32 accumulation, dynamic loss scale in the trainer): every GEMM-shaped op of the step below fp32
-        # width -- the closest this build comes to config #5's "bf16 + fp8"
+    def _mode(self, mode):
+        """context: the precision switches of a mode"""
+        import contextlib
         from ttts_amd import ops as _ops
-        prev_conv = _ops.set_conv_precision("tf32class")
-        try:
-            dt9_e, dt9_g, out9, loss9 = both("fp8 + tf32class")
-            dt9 = pick(dt9_e, dt9_g)
-            fp8["with_tf32class_convs"] = {"ms_per_step": round(dt9 * 1e3, 2), "ms_per_step_eager": round(dt9_e * 1e3, 2),
-                                           "ms_per_step_graph_replay": None if dt9_g is None else round(dt9_g * 1e3, 2),
-                                           "value": round(B * T / dt9, 1), "loss": round(loss9, 4),
-                                           "loss_scale": float(out9["loss_scale"]) if "loss_scale" in out9 else None,
-                                           "f16_saturated": int(out9["f16_saturated"]) if "f16_saturated" in out9 else None,
-                                           "skipped_steps": int(out9["skipped_steps"]) if "skipped_steps" in out9 else None,
-                                           "dtype": "as above, and the k = 3 convolutions' forward / data gradient as ONE fp16 x fp16 MFMA product "
-                                                    "(11 significant bits, fp32 accumulation; weight gradients split-bf16), dynamic loss scale "
-                                                    "(GradScaler's rule on device counters of the fp16 conversions' range events)",
-                                           "parity": "tools/exp/tf32_diffusion_check.py (config #5 shapes, same inputs): loss equal to 7 digits, "
-                                                     "gradient arena 6.9e-4 relative L2 of the split-bf16 default's, worst tensor 1.8e-3"}
-        finally:
-            _ops.set_conv_precision(prev_conv)
-    finally:
-        _aa.set_precision(prev_mode)
+        from ttts_amd.diffusion import aa_model as _aa
 
-    def attn(t):      # qkv + proj 1x1 convs, QK^T and PV
-        return 2 * t * C * 3 * C + 2 * t * C * C + 4 * t * t * C
+        @contextlib.contextmanager
+        def cm():
+            prev_mode = _aa.set_precision("fp8" if mode != "default" else "f32")
+            prev_conv = _ops.set_conv_precision("tf32class" if mode == "fp8_tf32class" else "split_bf16")
+            try:
+                yield
+            finally:
+                _ops.set_conv_precision(prev_conv)
+                _aa.set_precision(prev_mode)
+        return cm()
 
-    def resb(t):
-        return 2 * t * C * C + 2 * t * C * C * 3
-    fwd = (2 * Tl * 512 * C * 3 + 3 * attn(Tl)) + (2 * Tr * 100 * C * 3 + 3 * attn(Tr) + 2 * (Tr + 32) * C * C * 3 + 4 * attn(Tr + 32)) \
-        + 3 * (resb(T) + attn(T)) + 2 * T * 100 * C * 3 + 2 * T * 2 * C * C + 6 * (resb(T) + attn(T)) + 3 * resb(T) + 2 * T * C * 200 * 3
-    ach = 3.0 * fwd * B / dt / 1e12
-    peak = PEAK_BF16_TFLOPS / 3.0
-    if fp8 is not None:
+    def _timed(self, fn, n_warm):
+        for _ in range(n_warm):
+            o = fn(self.mel, self.ref, self.lat)
+        torch.cuda.synchronize(); t0_ = time.perf_counter()
+        for _ in range(self.steps):
+            o = fn(self.mel, self.ref, self.lat)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0_) / self.steps, o
+
+    def eager(self):
+        for mode in self.MODES:
+            with self._mode(mode):
+                self.dt_e[mode], o = self._timed(self.tr.train_step, self.warmup)
+                self.out[mode] = {k: (float(v) if torch.is_tensor(v) and v.numel() == 1 else None) for k, v in o.items() if k != "terms"}
+                self.loss[mode] = self.out[mode]["loss"]
+                assert self.loss[mode] == self.loss[mode], "non-finite diffusion loss (%s)" % mode
+        return self
+
+    def graphs(self):
+        """The same steps replayed from recorded hipGraphs: one per layer-drop pattern with at most one skipped layer (85 % of the
+        steps), recorded by the first call, ahead of the clock; rarer patterns run launch by launch inside the timed region."""
+        for mode in self.MODES:
+            with self._mode(mode):
+                try:
+                    dt_g, o = self._timed(self.tr.train_step_graphed, 3)
+                    ok = not self.tr._gstate.get("failed") and len(self.tr._gstate["graphs"]) > 0
+                    lv = float(o["loss"])
+                    assert lv == lv, "non-finite diffusion loss in graph replay (%s)" % mode
+                    self.dt_g[mode] = dt_g if ok else None
+                    self.n_graphs = len(self.tr._gstate["graphs"])
+                except Exception as err:                  # noqa: BLE001 -- report, keep the eager number
+                    print("bench: graphed diffusion step (%s) failed: %s" % (mode, str(err).splitlines()[0][:160]), file=sys.stderr, flush=True)
+                    self.dt_g[mode] = None
+        return self
+
+    def _pick(self, mode):
+        e, g = self.dt_e[mode], self.dt_g.get(mode)
+        return e if g is None else min(e, g)
+
+    def _times(self, mode):
+        g = self.dt_g.get(mode)
+        return {"ms_per_step": round(self._pick(mode) * 1e3, 2), "ms_per_step_eager": round(self.dt_e[mode] * 1e3, 2),
+                "ms_per_step_graph_replay": None if g is None else round(g * 1e3, 2)}
+
+    def result(self, cpu_leg=True):
+        B, C, T, Tl, Tr = self.B, self.C, self.T, self.Tl, self.Tr
+        dt = self._pick("default")
+        fp8 = dict(self._times("fp8"))
+        fp8.update({"value": round(B * T / self._pick("fp8"), 1), "unit": "frames/s", "loss": round(self.loss["fp8"], 4),
+                    "dtype": "f32 activations; the 1 x 1 convolutions / linear layers (qkv, proj_out, ResBlock input conv, integrating conv, "
+                             "timestep MLP: forward, data gradient and weight gradient) as e4m3 x e4m3 on v_mfma_f32_32x32x16_fp8_fp8 with "
+                             "per-tensor current scaling and fp32 accumulation; attention core (fused, csrc/attn_relpos.hip) on plain bf16 "
+                             "operands with fp32 softmax / accumulation; k = 3 convolutions split-bf16",
+                    "parity": "tests/test_gpu_fp8.py: kernels within 6e-5 of the output range of the oracle's quantised arithmetic (measured 1.6e-5); "
+                              "step vs the reference fixture: loss within 2 %, model output within 15 % relative L2, gradient cosines >= 0.95; "
+                              "tests/test_gpu_diffusion.py::test_fused_relpos_attention_vs_fp64 (bf16 operands: 2e-2 of range)"})
+        o9 = self.out["fp8_tf32class"]
+        sub = dict(self._times("fp8_tf32class"))
+        sub.update({"value": round(B * T / self._pick("fp8_tf32class"), 1), "loss": round(self.loss["fp8_tf32class"], 4),
+                    "loss_scale": o9.get("loss_scale"), "f16_saturated": o9.get("f16_saturated"), "f16_flushed": o9.get("f16_flushed"),
+                    "skipped_steps": o9.get("skipped_steps"),
+                    "dtype": "as above, and the k = 3 convolutions' forward / data gradient as ONE fp16 x fp16 MFMA product "
+                             "(11 significant bits, fp32 accumulation; weight gradients split-bf16), dynamic loss scale "
+                             "(GradScaler's rule on device counters of the fp16 conversions' range events)",
+                    "parity": "tools/exp/tf32_diffusion_check.py (config #5 shapes, same inputs): loss equal to 7 digits, "
+                              "gradient arena 6.9e-4 relative L2 of the split-bf16 default's, worst tensor 1.8e-3"})
+        fp8["with_tf32class_convs"] = sub
+
+        def attn(t):      # qkv + proj 1x1 convs, QK^T and PV
+            return 2 * t * C * 3 * C + 2 * t * C * C + 4 * t * t * C
+
+        def resb(t):
+            return 2 * t * C * C + 2 * t * C * C * 3
+        fwd = (2 * Tl * 512 * C * 3 + 3 * attn(Tl)) + (2 * Tr * 100 * C * 3 + 3 * attn(Tr) + 2 * (Tr + 32) * C * C * 3 + 4 * attn(Tr + 32)) \
+            + 3 * (resb(T) + attn(T)) + 2 * T * 100 * C * 3 + 2 * T * 2 * C * C + 6 * (resb(T) + attn(T)) + 3 * resb(T) + 2 * T * C * 200 * 3
+        ach = 3.0 * fwd * B / dt / 1e12
+        peak = PEAK_BF16_TFLOPS / 3.0
         # the reduced-precision leg's own roof: its GEMMs are ONE product per pair on v_mfma_f32_32x32x16_fp8_fp8 -- the NON-scaled fp8
         # form, which issues at the bf16 rate (MI355X_MICROARCH.md: only the MX-scaled K = 64 / 128 instructions reach ~5 PF) -- and its
         # attention one bf16 product; the k = 3 convolutions stay three bf16 products (one in the tf32class sub-leg)
-        a8 = 3.0 * fwd * B / (fp8["ms_per_step"] * 1e-3) / 1e12
+        a8 = 3.0 * fwd * B / self._pick("fp8") / 1e12
         fp8["roofline"] = {"bound": "mfma", "kernel": "whole step (fp8 1 x 1 GEMMs + bf16 attention + split-bf16 k = 3 convolutions)",
                            "achieved": round(a8, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(a8 / PEAK_BF16_TFLOPS, 4),
                            "traffic": None,
                            "note": "peak = the dense bf16 rate: the instruction used, v_mfma_f32_32x32x16_fp8_fp8 (non-scaled), issues at "
                                    "the bf16 rate; the ~5 PF fp8 roof needs v_mfma_scale_f32_32x32x64_f8f6f4, which this build does not use"}
-    try:
-        diff_traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["diffusion_step"]["bytes_per_step"]
-    except Exception:
-        diff_traffic = None
-    res = {"metric": "diffusion_train_mel_frames_per_sec", "value": round(B * T / dt, 1), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 2),
-           "ms_per_step_eager": round(dt_e * 1e3, 2), "ms_per_step_graph_replay": None if dt_g is None else round(dt_g * 1e3, 2),
-           "graphs_recorded": len(tr._gstate["graphs"]) if getattr(tr, "_gstate", None) else 0,
-           "steps": steps, "warmup": warmup,
-           "dtype": "f32 (conv / linear / attention products as split-bf16 x3 on the bf16 MFMA, fp32 accumulation and softmax) -- wider than config #5's bf16 + fp8",
-           "config": {"workload": "AA_diffusion train step (q_sample, model, mse + learned-range VB, backward, clip 1.0, AdamW), batch 16 x "
-                                  "(100 x 400 mel, 512 x 100 latent, 100 x 200 reference), 43.2 M parameters, %s"
-                                  % ("hipGraph replay (one recording per layer-drop pattern)" if (dt_g is not None and dt_g <= dt_e) else "eager launches")},
-           "roofline": {"bound": "mfma", "kernel": "whole step (convolution family + attention GEMMs)", "achieved": round(ach, 2),
-                        "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": diff_traffic,
-                        "traffic_note": "HBM-side bytes of ALL kernels of one step from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json: "
-                                        "FETCH_SIZE x 2 + WRITE_SIZE), not measured in this run",
-                        "note": "algorithmic FLOPs = 3 x forward (%.1f GFLOP per sample) / step time; peak = bf16 MFMA / 3 (an fp32 product "
-                                "costs three bf16 products)" % (fwd / 1e9)},
-           "loss": round(loss, 4), "grad_norm": round(float(out["grad_norm"]), 4), "fp8_gemms": fp8}
-    if cpu_leg:
-        res["cpu_baseline"] = diffusion_cpu_baseline()
-    return res
+        try:
+            diff_traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["diffusion_step"]["bytes_per_step"]
+        except Exception:
+            diff_traffic = None
+        g = self.dt_g.get("default")
+        res = {"metric": "diffusion_train_mel_frames_per_sec", "value": round(B * T / dt, 1), "unit": "frames/s"}
+        res.update(self._times("default"))
+        res.update({"graphs_recorded": getattr(self, "n_graphs", 0), "steps": self.steps, "warmup": self.warmup,
+                    "dtype": "f32 (conv / linear / attention products as split-bf16 x3 on the bf16 MFMA, fp32 accumulation and softmax) -- wider than config #5's bf16 + fp8",
+                    "config": {"workload": "AA_diffusion train step (q_sample, model, mse + learned-range VB, backward, clip 1.0, AdamW), batch 16 x "
+                                           "(100 x 400 mel, 512 x 100 latent, 100 x 200 reference), 43.2 M parameters, %s"
+                                           % ("hipGraph replay (one recording per layer-drop pattern)" if (g is not None and g <= self.dt_e["default"]) else "eager launches")},
+                    "roofline": {"bound": "mfma", "kernel": "whole step (convolution family + fused attention)", "achieved": round(ach, 2),
+                                 "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": diff_traffic,
+                                 "traffic_note": "HBM-side bytes of ALL kernels of one step from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json: "
+                                                 "FETCH_SIZE x 2 + WRITE_SIZE), not measured in this run",
+                                 "note": "algorithmic FLOPs = 3 x forward (%.1f GFLOP per sample) / step time; peak = bf16 MFMA / 3 (an fp32 product "
+                                         "costs three bf16 products)" % (fwd / 1e9)},
+                    "loss": round(self.loss["default"], 4), "grad_norm": round(self.out["default"]["grad_norm"], 4), "fp8_gemms": fp8})
+        if cpu_leg:
+            res["cpu_baseline"] = diffusion_cpu_baseline()
+        self.tr = None
+        return res
 
 
 def diffusion_cpu_baseline():
@@ -688,11 +709,15 @@ def main():
     # (same box, same code: the VQ-VAE-GAN leg reads 123.7 ms alone and 128.8 ms after the GPT leg, while its hipGraph replay reads
     # the same 129 ms either way: HISTORY 18.4).  The GPT leg is a graph replay and does not care what ran before it.
     pre = {}
-    if world == 1 and not args.no_diffusion:           # (all-eager: ahead of the VQ-VAE-GAN leg, which ends with a graph recording)
-        pre["diffusion"] = diffusion_leg(dev, args.diffusion_steps, 3, cpu_leg=not args.no_cpu_baseline)
-        torch.cuda.empty_cache()
-    if world == 1 and not args.no_vqvae:
+    dleg = None
+    if world == 1 and not args.no_diffusion:           # (eager timings first: nothing in the process has recorded a graph yet)
+        dleg = DiffusionLeg(dev, args.diffusion_steps, 3).eager()
+    if world == 1 and not args.no_vqvae:               # (eager timing, then its own graph recording)
         pre["vqvae"] = vqvae_leg(dev, args.vqvae_steps, 2, cpu_leg=not args.no_cpu_baseline)
+    if dleg is not None:
+        pre["diffusion"] = dleg.graphs().result(cpu_leg=not args.no_cpu_baseline)
+        dleg = None
+        torch.cuda.empty_cache()
     if pre:
         ops.release_conv_ctxs(keep_current=False)          # the legs' per-stream convolution scratch (1.5 GB each)
         gc.collect()

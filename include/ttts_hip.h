@@ -623,13 +623,15 @@ int ttts_conv_wgrad_arena_destroy(void* arena);
  * single-pass fp16 convolution mode, whose data gradients are loss-scaled into fp16's range.
  * Every fp32 -> fp16 operand conversion of that mode counts, per device, the threads (8-16 neighbouring elements each) that saw
  *   [0] a value above 65504 (saturated; +-inf included; NaN stays NaN and is not counted), [1] a non-zero value that became zero
- *   (|v| <= 2^-25), [2] a non-zero value below fp16's smallest normal 2^-14 (fewer than 11 significant bits kept).
+ *   (|v| <= 2^-25), [2] reserved, always 0 (values below fp16's smallest normal 2^-14 keep fewer than 11 significant bits; they
+ *   are common -- millions per step -- and are deliberately not counted: the mode's stated accuracy, 1.5e-3 of a convolution's
+ *   output range, is measured WITH them, tests/test_gpu_vqvae.py::test_tf32class_conv_accuracy).
  * ttts_conv_f16_events: events3[i] += counter[i] on `stream` (device memory, int32[3]); reset != 0 clears the counters.  The
  *   counters belong to the device `stream` runs on.  Graph-capturable; no host sync.
  * ttts_loss_scale_check: one per backward, after ttts_conv_f16_events (and after an all-reduce of events3 under data parallelism):
  *   events3[0] != 0 -> *skip = 1 (pass &optimizer_state[6], see ttts_adamw_schedule) and "overflow seen" in ls8; totals += events;
  *   events3 is cleared.  ls8 = f32[8] {scale, 1 / scale, clean steps in a row, overflow since the last update, saturation total,
- *   flush total, skipped optimizer steps, subnormal total}; the caller initialises {scale, 1 / scale, 0...}.
+ *   flush total, skipped optimizer steps, reserved}; the caller initialises {scale, 1 / scale, 0...}.
  * ttts_loss_scale_update: one per step: overflow -> scale *= backoff (not below 1), else after growth_interval clean steps in a
  *   row scale *= growth (not above 2^24); 1 / scale follows.  GradScaler's defaults: backoff 0.5, growth 2, interval 2000. */
 int ttts_conv_f16_events(int32_t* events3, int32_t reset, void* stream);

@@ -1234,7 +1234,7 @@ def test_tf32class_and_fp8_keep_nan_and_count_range_events():
     """The reduced-precision modes must not turn a diverged tensor into ordinary numbers: a NaN input reaches the output of a
     tf32class convolution (forward, data gradient) and of an fp8 GEMM as NaN (the saturating clamps used to map it to -65504 / -448
     and amax dropped it).  And the fp16 conversions keep books: operands above 65504 / at or below 2^-25 / below 2^-14 show up in
-    ops.conv_f16_events as saturated / flushed / subnormal, nothing is counted for in-range operands."""
+    ops.conv_f16_events as saturated / flushed (values that are merely subnormal in fp16 are not counted), nothing for in-range operands."""
     from ttts_amd import ops
     g = torch.Generator().manual_seed(5)
     x = torch.randn(2, 64, 300, generator=g).to(_dev()); w = (torch.randn(96, 64, 5, generator=g) / 18).to(_dev())
@@ -1256,8 +1256,8 @@ def test_tf32class_and_fp8_keep_nan_and_count_range_events():
         ev.zero_()
         xb = x.clone(); xb[0, 1, 10] = 2.0 ** 17; xb[0, 2, 11] = -float("inf"); xb[1, 3, 12] = 1e-9; xb[1, 4, 13] = 3e-5
         yb = ops.conv1d_fwd(xb, w, None, None, 1, 2, 1)
-        sat, flushed, sub = ops.conv_f16_events(ev).tolist()[:3]
-        assert sat >= 2 and flushed >= 1 and sub >= 2, (sat, flushed, sub)
+        sat, flushed, reserved = ops.conv_f16_events(ev).tolist()[:3]
+        assert sat >= 2 and flushed >= 1 and reserved == 0, (sat, flushed, reserved)
         assert bool(torch.isfinite(yb).all())                             # saturated (+-65504), not inf
         ev.zero_()
         assert ops.conv_f16_events(ev).tolist()[:3] == [0, 0, 0]         # the fetch above reset the device counters

@@ -66,17 +66,16 @@ __device__ __forceinline__ float lrelu_f(float v, float s) { return v > 0.f ? v 
 
 // ---- range bookkeeping of the single-pass fp16 ("TF32-class") mode (ABI v11) --------------------------------------------------
 // fp16 has TF32's 11 significant bits but 5 exponent bits instead of 8: an operand above 65504 saturates, one at or below 2^-25
-// becomes zero, one below 2^-14 keeps fewer bits.  Every fp32 -> fp16 conversion of the mode (operand pre-passes, on-the-fly
+// becomes zero (one below 2^-14 keeps fewer bits: not counted, see common.hpp).  Every fp32 -> fp16 conversion of the mode (operand pre-passes, on-the-fly
 // staging, weight splits) ORs what it saw into a per-thread word and adds it here once -- a module global, i.e. one copy per
 // device -- so that a trainer can see, without a host sync inside the step, that its loss scale left the range
 // (ttts_conv_f16_events; ttts_loss_scale_update turns it into GradScaler's halve / skip / grow rule).
 // Counts are THREADS that saw the event (a thread converts 8..16 neighbouring elements), not elements.
-__device__ unsigned int g_f16_events[4];      // {saturated, flushed to zero, subnormal, -}
+__device__ unsigned int g_f16_events[4];      // {saturated, flushed to zero, reserved (0), -}
 __device__ __forceinline__ void f16_events_commit(unsigned ev) {
   if (ev) {                                   // (rare: the common case costs one compare per thread)
     if (ev & 1u) atomicAdd(&g_f16_events[0], 1u);
     if (ev & 2u) atomicAdd(&g_f16_events[1], 1u);
-    if (ev & 4u) atomicAdd(&g_f16_events[2], 1u);
   }
 }
 __global__ void f16_events_fetch_kernel(int32_t* __restrict__ out, int reset) {
@@ -87,7 +86,7 @@ __global__ void f16_events_fetch_kernel(int32_t* __restrict__ out, int reset) {
   }
 }
 // GradScaler's rule on device words.  ls = {scale, 1 / scale, clean steps in a row, overflow seen since the last update,
-// total saturation events, total flush events, skipped steps, total subnormal events}.
+// total saturation events, total flush events, skipped steps, reserved}.
 //   check  (one per backward): events[0] != 0 -> *skip = 1 (the optimizer step that follows leaves parameters and moments alone) and
 //          ls[3] = 1; totals accumulate; events are cleared for the next backward.
 //   update (one per step): overflow -> scale *= backoff (not below 1), streak = 0; else streak += 1 and after `interval` clean steps

@@ -182,7 +182,7 @@ class DiffusionTrainer:
             lsc.decide(self.optimizer.opt_state)
             self.optimizer.flat_g.mul_(lsc.inv_scale)
             res.update({"loss_scale": lsc.scale.clone(), "f16_saturated": lsc.saturated, "f16_flushed": lsc.flushed,
-                        "f16_subnormal": lsc.subnormal, "skipped_steps": lsc.skipped})
+                        "skipped_steps": lsc.skipped})
         if device_warmup:       # recorded step: the factor comes from the optimizer's device-side step counter (same formula)
             self.optimizer.step(lr=self.base_lr, max_norm=1.0, warmup_steps=1000)
         else:

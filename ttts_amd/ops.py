@@ -993,7 +993,7 @@ if _state["conv_precision"] not in ("split_bf16", "exact", "tf32class"):     # a
 
 
 def conv_f16_events(events, reset=True):
-    """events (int32[3], device) += the device's {saturated, flushed-to-zero, subnormal} counts of the fp32 -> fp16 operand
+    """events (int32[3], device) += the device's {saturated, flushed-to-zero, reserved = 0} counts of the fp32 -> fp16 operand
     conversions of the 'tf32class' convolution mode since the last reset (include/ttts_hip.h: ttts_conv_f16_events).  No sync."""
     _req(events, torch.int32, "events")
     if events.numel() < 3:
@@ -1014,7 +1014,7 @@ class DynamicLossScale:
 
     What counts as overflow: an operand of an fp16 conversion above 65504 (the conversions saturate instead of producing inf, so
     the usual "gradient is inf / nan" test would never fire -- the device counters of ops.conv_f16_events are the test).  State,
-    as device scalars: .scale, .inv_scale, .saturated, .flushed, .subnormal, .skipped (totals since construction)."""
+    as device scalars: .scale, .inv_scale, .saturated, .flushed, .skipped (totals since construction)."""
 
     def __init__(self, device, init_scale=1024.0, growth_interval=2000, backoff=0.5, growth=2.0, dynamic=True):
         self.state = torch.zeros(8, dtype=torch.float32, device=device)
@@ -1035,7 +1035,6 @@ class DynamicLossScale:
     saturated = property(lambda self: self.state[4])
     flushed = property(lambda self: self.state[5])
     skipped = property(lambda self: self.state[6])
-    subnormal = property(lambda self: self.state[7])
 
     def fetch(self):
         """Move the device's range-event counters of the backward that just ran into .events (and clear them)."""
@@ -1062,9 +1061,9 @@ class DynamicLossScale:
             self.state[3].zero_()
 
     def report(self):
-        """Host copy (one sync): {'scale', 'saturated', 'flushed', 'subnormal', 'skipped'}."""
+        """Host copy (one sync): {'scale', 'saturated', 'flushed', 'skipped'}."""
         v = self.state.tolist()
-        return {"scale": v[0], "saturated": int(v[4]), "flushed": int(v[5]), "subnormal": int(v[7]), "skipped": int(v[6])}
+        return {"scale": v[0], "saturated": int(v[4]), "flushed": int(v[5]), "skipped": int(v[6])}
 
 
 def _apply_flags():

@@ -282,7 +282,7 @@ class VqvaeStep:
         if lsc is not None:
             # the scale this step ran with and the running totals of the fp16 range events (device scalars; see ops.DynamicLossScale)
             out.update({"loss_scale": lsc.scale.clone(), "f16_saturated": lsc.saturated, "f16_flushed": lsc.flushed,
-                        "f16_subnormal": lsc.subnormal, "skipped_steps": lsc.skipped})
+                        "skipped_steps": lsc.skipped})
             lsc.update()
         return out
 
