@@ -73,9 +73,14 @@ __device__ __forceinline__ float lrelu_f(float v, float s) { return v > 0.f ? v 
 // Counts are THREADS that saw the event (a thread converts 8..16 neighbouring elements), not elements.
 __device__ unsigned int g_f16_events[4];      // {saturated, flushed to zero, reserved (0), -}
 __device__ __forceinline__ void f16_events_commit(unsigned ev) {
-  if (ev) {                                   // (rare: the common case costs one compare per thread)
-    if (ev & 1u) atomicAdd(&g_f16_events[0], 1u);
-    if (ev & 2u) atomicAdd(&g_f16_events[1], 1u);
+  // one atomic per WAVE and event kind (flushes are not rare: ~3 M threads per VQ-VAE-GAN step see one), counts stay per thread
+  const uint64_t m1 = __builtin_amdgcn_ballot_w64((ev & 1u) != 0), m2 = __builtin_amdgcn_ballot_w64((ev & 2u) != 0);
+  if ((m1 | m2) != 0) {
+    const uint64_t act = __builtin_amdgcn_ballot_w64(true);
+    if ((int)(threadIdx.x & 63) == __builtin_ctzll(act)) {      // first active lane of the wave
+      if (m1) atomicAdd(&g_f16_events[0], (unsigned)__builtin_popcountll(m1));
+      if (m2) atomicAdd(&g_f16_events[1], (unsigned)__builtin_popcountll(m2));
+    }
   }
 }
 __global__ void f16_events_fetch_kernel(int32_t* __restrict__ out, int reset) {

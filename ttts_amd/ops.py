@@ -1551,7 +1551,10 @@ def fp8_amax(x, out=None):
     zero = 0
     if out is None:
         if x.is_cuda and torch.cuda.is_current_stream_capturing():
-            out = torch.empty(1, dtype=torch.float32, device=x.device)
+            # (a fill KERNEL, not the library's hipMemsetAsync: the recorded 4-byte memset node left the word uncleared at replay --
+            # the diffusion step's fp8 mode replayed from a hipGraph produced NaN losses, eager launches did not)
+            out = torch.zeros(1, dtype=torch.float32, device=x.device)
+            zero = 1
         else:
             key = (x.device.index, _raw_stream(x.device.index))
             pool = _amax_pools.get(key)
