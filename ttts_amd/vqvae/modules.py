@@ -38,6 +38,7 @@ def _take_dw_buffer(w):
 
 _branch_pools = {}
 _dirty_streams = []
+_fork_depth = [0]            # > 0 while run_branches is issuing a branch on a side stream (host-side nesting level)
 _env_cache = {}
 
 
@@ -60,14 +61,28 @@ def _env_int(name, default):
 _env_keys = {}
 
 
+def _eager_pools():
+    """Fan-out levels in use outside a capture (TTTS_EAGER_POOLS, default all: disc, synth, mrf, wgrad)."""
+    raw = os.environ.get("TTTS_EAGER_POOLS")
+    return ("disc", "synth", "mrf", "wgrad") if raw is None else raw.split(",")
+
+
 def side_streams(pool, device, n=None):
     """The named set of side streams of `device` (created on first use); [] when disabled (TTTS_BRANCH_STREAMS=0) or not a GPU."""
     n = int(os.environ.get("TTTS_BRANCH_STREAMS", "3")) if n is None else n
     if n <= 0 or device.type != "cuda":
         return []
-    if pool not in os.environ.get("TTTS_CAPTURE_POOLS", "disc,synth").split(",") and torch.cuda.is_current_stream_capturing():
-        # hipStreamEndCapture crashes (SIGSEGV, ROCm 7.2) on a capture that holds NESTED fan-outs (synth -> mrf); each level alone
-        # records fine (tools/exp/capture_debug.sh): recorded steps keep the outer levels (TTTS_CAPTURE_POOLS)
+    if torch.cuda.is_current_stream_capturing():
+        # hipStreamEndCapture crashes (SIGSEGV, ROCm 7.2) on a capture that holds NESTED fan-outs (a fork made on a forked stream:
+        # synth -> mrf; tools/exp/capture_debug.sh).  The step's fan-outs are siblings since round 6 (run_branches(inline=...): the
+        # branch that fans out again stays on the caller's stream), so every level CAN be recorded; a branch that does sit on a side
+        # stream (_fork_depth > 0: the prior path) runs its own inner fan-out sequentially while recording.  Which levels pay under
+        # replay was measured (HISTORY 19.8, tools/gpu_r6_n.sh; B = 32): none 136.4 ms, disc 136.8, synth 120.6, disc + synth 114.5,
+        # disc + mrf 127.6, synth + mrf 128.4, all three 122.4 -- the three-way ResBlock fan-out that helps eager launches costs a
+        # replay 8 ms (every fork / join is a cross-stream dependency the graph executor resolves with barrier packets)
+        if _fork_depth[0] > 0 or pool not in os.environ.get("TTTS_CAPTURE_POOLS", "disc,synth").split(","):
+            return []
+    elif pool not in _eager_pools():
         return []
     key = (pool, device.index if device.index is not None else torch.cuda.current_device(), n)
     streams = _branch_pools.get(key)
@@ -170,23 +185,33 @@ def wgrad_side_stream(device):
     return st
 
 
-def run_branches(fns, device, pool="mrf"):
+def run_branches(fns, device, pool="mrf", inline=None):
     """Independent sub-graphs (callables) on side streams, results in order.  Most convolution launches of the VQ-VAE-GAN step
     either under-fill the 256 CUs or end in a nearly empty last round of workgroups; issued on separate streams, one branch's
     tail overlaps another branch's next launch (and autograd replays every node on its forward stream, so the backward overlaps
     the same way -- call join_side_streams() after it).  Every side stream first waits for the caller's stream and the caller's
     stream waits for all of them before returning, so the call is ordered like a plain sequential one.  `pool` names a set of
-    TTTS_BRANCH_STREAMS (default 3; 0: run sequentially on the caller's stream) streams; nested fan-outs use different pools."""
+    TTTS_BRANCH_STREAMS (default 3; 0: run sequentially on the caller's stream) streams; nested fan-outs use different pools.
+    `inline` = index of a branch that runs on the CALLER's stream (after the earlier branches were issued to their side streams):
+    a branch that fans out again then forks from the caller's stream, i.e. the fan-outs are siblings instead of nested -- which is
+    what lets a stream capture keep both levels (hipStreamEndCapture crashes on a fork made from a forked stream, ROCm 7.2)."""
     streams = side_streams(pool, device) if len(fns) >= 2 else []
     if not streams:
         return [f() for f in fns]
     main = torch.cuda.current_stream(device)
     outs, used = [], []
     for i, f in enumerate(fns):
-        st = streams[i % len(streams)]
-        fork_to(st, main)
-        with torch.cuda.stream(st):
+        if i == inline:                  # this branch stays on the caller's stream: whatever it forks is forked from there
             outs.append(f())
+            continue
+        st = streams[(i if inline is None or i < inline else i - 1) % len(streams)]
+        fork_to(st, main)
+        _fork_depth[0] += 1
+        try:
+            with torch.cuda.stream(st):
+                outs.append(f())
+        finally:
+            _fork_depth[0] -= 1
         if st not in used:
             used.append(st)
     for st in used:

@@ -19,6 +19,12 @@ from .style_encoder import MelStyleEncoder  # noqa: F401
 from .modules import LRELU_SLOPE, Conv1d, Conv2dK1, Generator, get_padding  # noqa: F401
 
 
+# SynthesizerTrn's two branches: the posterior / flow / decoder branch (index 1) runs on the caller's stream, only the prior branch on
+# a side stream -- the decoder's own three-way fan-out then forks from the caller's stream too (siblings, not nested: see
+# modules.run_branches).  TTTS_SYNTH_INLINE=-1 restores both branches on side streams (the nested form a capture cannot hold).
+_SYNTH_INLINE = (lambda v: None if v < 0 else v)(int(os.environ.get("TTTS_SYNTH_INLINE", "1")))
+
+
 def _no_spectral_norm(flag):
     if flag:
         raise NotImplementedError("use_spectral_norm=True is not on the training path (vqvae/config.json: false)")
@@ -361,7 +367,7 @@ class SynthesizerTrn(nn.Module):
             return z, m_q, logs_q, z_p, ids, self.dec(z_slice, g=ge)
 
         (quantized, commit_loss, m_p, logs_p), (z, m_q, logs_q, z_p, ids_slice, o) = modules.run_branches(
-            [prior, posterior], y.device, pool="synth")
+            [prior, posterior], y.device, pool="synth", inline=_SYNTH_INLINE)   # (the decoder's own fan-out forks from this stream)
         return o, commit_loss, ids_slice, y_mask, (z, z_p, m_p, logs_p, m_q, logs_q), quantized
 
     @torch.no_grad()
