@@ -472,58 +472,109 @@ static bool wsplit_lookup(const ConvMfmaParams& p, const ConvCtx& cx, int nblk, 
 }
 
 // fused epilogue of the split-bf16 kernels: two 32 x 32 accumulators of a wave (positions wl*64 + {0, 32} + col)
-template <int WCO>
-__device__ __forceinline__ void conv_tile_epilogue(const ConvMfmaParams& p, const f32x16& acc0, const f32x16& acc1, int wl,
-                                                   int wco, int col, int hh, int j0, int m0, int b0, int SEG) {
+// One lane's 16 accumulator rows (row of register r: mb + (r & 3) + 8 (r >> 2)) of ONE output column (b, j).
+// Round 6: as a per-element loop `v += resid[o]; ...; y[o] = v` each element's operand read sat behind the previous element's
+// store (y may alias resid / gate for all the compiler knows), i.e. 16-32 DEPENDENT memory round trips per lane: a workgroup of the
+// ResBlock convolutions lived ~25 us around ~2 us of MFMAs (PMC: 21 VALU instructions per MFMA, 45 % of the wave cycles in
+// s_waitcnt; profiles/r06_pmc_conv_onthefly.txt).  The launches of the training steps read at most ONE such operand (the lrelu gate
+// of a data gradient, the residual of a ResBlock's second convolution, the output itself when accumulating, a per-sample bias):
+// that case requests it for all 16 rows BEFORE the first store.  Same operations on the same values in the same order per element:
+// bit-identical.  Everything else (dual destination, several operands) keeps the per-element loop.
+__device__ __forceinline__ void conv_store_col16(const ConvMfmaParams& p, const f32x16& acc, int mb, int b, int j, float om) {
+  // (row / column indices made opaque here: everything below depends only on kernel arguments and the thread index, and the compiler
+  // computed all of it -- 16 rows x two code paths of addresses and selects -- in the kernel's PROLOGUE, live across the main loop:
+  // 55 spilled VGPRs in the DMA kernel)
+  asm volatile("" : "+v"(mb), "+v"(j));
+  const int nops = (p.gate ? 1 : 0) + (p.resid ? 1 : 0) + (p.accumulate ? 1 : 0) + (p.bbias ? 1 : 0);
+  if (p.y2 == nullptr && nops <= 1) {
+    const int mode = p.gate ? 1 : p.resid ? 2 : p.accumulate ? 3 : p.bbias ? 4 : 0;      // (uniform)
+    const float* ap = p.gate ? p.gate : p.resid ? p.resid : p.y;
+    const int64_t rs = p.LoutTotal, o0 = (int64_t)b * p.M * rs + j;
+    const float sc = om * p.out_scale;
+    float bia[16], aux[16];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int ct = wl * 64 + t * 32 + col;
-    int b = b0 + ct / SEG, jt = j0 + ct % SEG;
-    if (jt >= p.Lout || b >= p.B) continue;
-    if (p.catLg) {                                         // virtual row -> (batch element, position)
-      b = jt / p.catLg; jt -= b * p.catLg;
-      if (jt >= p.catLout) continue;
-    }
-    const int j = p.out_off + jt * p.out_stride;
-    const float om = p.omask ? p.omask[(int64_t)b * p.LoutTotal + j] : 1.f;
-    if (p.rowS > 0) {                                      // phase-merged data gradient: row (ci, r) -> dx[b][ci][rowS jt + r]
-      const int nch = p.M / p.rowS;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wco * 32 + acc_row(r, hh);
-        if (m >= p.M) continue;
-        const int ci = m / p.rowS, jj = jt * p.rowS + (m - ci * p.rowS);
-        if (jj >= p.LoutTotal) continue;
-        const int64_t o = ((int64_t)b * nch + ci) * p.LoutTotal + jj;
-        float v = (t == 0 ? acc0[r] : acc1[r]) + (p.bias ? p.bias[ci] : 0.f);
-        if (p.gate) v *= (p.gate[o] > 0.f ? 1.f : p.gate_slope);
-        if (p.resid) v += p.resid[o];
-        v *= (p.omask ? p.omask[(int64_t)b * p.LoutTotal + jj] : 1.f) * p.out_scale;
-        p.y[o] = p.accumulate ? p.y[o] + v : v;
-      }
-      continue;
+    for (int r = 0; r < 16; ++r) {
+      const int m = min(mb + (r & 3) + 8 * (r >> 2), p.M - 1);          // (clamped: reads of rows past M are in range and unused)
+      bia[r] = p.bias ? p.bias[m] : 0.f;
+      aux[r] = mode == 0 ? 0.f : mode == 4 ? p.bbias[(int64_t)b * p.M + m] : ap[o0 + m * rs];
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wco * 32 + acc_row(r, hh);
+      const int m = mb + (r & 3) + 8 * (r >> 2);
       if (m >= p.M) continue;
-      float v = (t == 0 ? acc0[r] : acc1[r]) + (p.bias ? p.bias[m] : 0.f);
-      // (dual destination, p.y2: rows >= M1 go to y2 with their own accumulate flag and without the residual -- selected, not
-      // branched: a second store path here sent the 64 x 64 wave tile's accumulators through scratch)
-      const bool second = p.y2 != nullptr && m >= p.M1;
-      const int Mo = p.y2 ? (second ? p.M - p.M1 : p.M1) : p.M, mm = second ? m - p.M1 : m;
-      float* dst = second ? p.y2 : p.y;
-      const int accf = second ? p.acc2 : p.accumulate;
-      const int64_t o = ((int64_t)b * Mo + mm) * p.LoutTotal + j;
-      if (p.bbias) v += p.bbias[(int64_t)b * p.M + m];
-      if (p.gate) v *= (p.gate[o] > 0.f ? 1.f : p.gate_slope);
-      if (p.resid && !second) v += p.resid[o];
+      float v = acc[r] + bia[r];
+      if (mode == 4) v += aux[r];
+      if (mode == 1) v *= (aux[r] > 0.f ? 1.f : p.gate_slope);
+      if (mode == 2) v += aux[r];
       if (p.out_act == 1) v = tanhf(v);
       else if (p.out_act == 2) v = lrelu_f(v, p.out_slope);
-      v *= om * p.out_scale;
-      dst[o] = accf ? dst[o] + v : v;
+      v *= sc;
+      p.y[o0 + m * rs] = mode == 3 ? aux[r] + v : v;
     }
+    return;
   }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = mb + (r & 3) + 8 * (r >> 2);
+    if (m >= p.M) continue;
+    float v = acc[r] + (p.bias ? p.bias[m] : 0.f);
+    // (dual destination, p.y2: rows >= M1 go to y2 with their own accumulate flag and without the residual -- selected, not
+    // branched: a second store path here sent the 64 x 64 wave tile's accumulators through scratch)
+    const bool second = p.y2 != nullptr && m >= p.M1;
+    const int Mo = p.y2 ? (second ? p.M - p.M1 : p.M1) : p.M, mm = second ? m - p.M1 : m;
+    float* dst = second ? p.y2 : p.y;
+    const int accf = second ? p.acc2 : p.accumulate;
+    const int64_t o = ((int64_t)b * Mo + mm) * p.LoutTotal + j;
+    if (p.bbias) v += p.bbias[(int64_t)b * p.M + m];
+    if (p.gate) v *= (p.gate[o] > 0.f ? 1.f : p.gate_slope);
+    if (p.resid && !second) v += p.resid[o];
+    if (p.out_act == 1) v = tanhf(v);
+    else if (p.out_act == 2) v = lrelu_f(v, p.out_slope);
+    v *= om * p.out_scale;
+    dst[o] = accf ? dst[o] + v : v;
+  }
+}
+
+// one 32-position block (t = 0 / 1) of a wave's accumulator pair.  (`acc` is the block's own accumulator, never a reference picked by
+// `t == 0 ? acc0 : acc1`: that select became a pointer select in the DMA kernel and sent its accumulators to scratch -- 320 bytes
+// per lane, DiscriminatorP's 1024-channel layers 307 -> 1665 us)
+template <int WCO>
+__device__ __forceinline__ void conv_tile_col(const ConvMfmaParams& p, const f32x16& acc, int t, int wl, int wco, int col, int hh,
+                                              int j0, int m0, int b0, int SEG) {
+  const int ct = wl * 64 + t * 32 + col;
+  int b = b0 + ct / SEG, jt = j0 + ct % SEG;
+  if (jt >= p.Lout || b >= p.B) return;
+  if (p.catLg) {                                         // virtual row -> (batch element, position)
+    b = jt / p.catLg; jt -= b * p.catLg;
+    if (jt >= p.catLout) return;
+  }
+  const int j = p.out_off + jt * p.out_stride;
+  const float om = p.omask ? p.omask[(int64_t)b * p.LoutTotal + j] : 1.f;
+  if (p.rowS <= 0) {
+    conv_store_col16(p, acc, m0 + wco * 32 + 4 * hh, b, j, om);
+    return;
+  }
+  // phase-merged data gradient: row (ci, r) -> dx[b][ci][rowS jt + r]
+  const int nch = p.M / p.rowS;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wco * 32 + acc_row(r, hh);
+    if (m >= p.M) continue;
+    const int ci = m / p.rowS, jj = jt * p.rowS + (m - ci * p.rowS);
+    if (jj >= p.LoutTotal) continue;
+    const int64_t o = ((int64_t)b * nch + ci) * p.LoutTotal + jj;
+    float v = acc[r] + (p.bias ? p.bias[ci] : 0.f);
+    if (p.gate) v *= (p.gate[o] > 0.f ? 1.f : p.gate_slope);
+    if (p.resid) v += p.resid[o];
+    v *= (p.omask ? p.omask[(int64_t)b * p.LoutTotal + jj] : 1.f) * p.out_scale;
+    p.y[o] = p.accumulate ? p.y[o] + v : v;
+  }
+}
+template <int WCO>
+__device__ __forceinline__ void conv_tile_epilogue(const ConvMfmaParams& p, const f32x16& acc0, const f32x16& acc1, int wl,
+                                                   int wco, int col, int hh, int j0, int m0, int b0, int SEG) {
+  conv_tile_col<WCO>(p, acc0, 0, wl, wco, col, hh, j0, m0, b0, SEG);
+  conv_tile_col<WCO>(p, acc1, 1, wl, wco, col, hh, j0, m0, b0, SEG);
 }
 
 // ---- inner loop shared by the split-bf16 kernels: CW 32-row blocks of output channels x two 32-position blocks per wave,
@@ -663,8 +714,13 @@ __device__ __forceinline__ void b3_stage(const bf16* xh, const bf16* xl, const b
 // Variant 1: the input is split ON THE FLY while it is staged (few output-channel tiles re-read it: the 16..128-channel
 // long-row layers, where a separate split pass would cost more HBM traffic than it saves).  Single LDS stage; overlap comes
 // from several workgroups per CU.
+// waves per SIMD the register allocation has to leave room for: what the LDS footprint allows anyway (the round-6 staging keeps
+// more loads in flight; without the bound <2, 7> and <2, 3> each lost a resident wave to it)
+__host__ __device__ constexpr int b3_min_waves(int WCO, int KT) {
+  return KT == 0 ? 3 : KT <= 3 ? (WCO == 2 && KT == 3 ? 3 : 4) : 3;
+}
 template <int WCO, int KT, bool F16 = false>
-__global__ __launch_bounds__(256) void conv1d_bf16x3_kernel(ConvMfmaParams p) {
+__global__ __launch_bounds__(256, b3_min_waves(WCO, KT)) void conv1d_bf16x3_kernel(ConvMfmaParams p) {
   constexpr int MT = 32 * WCO, WL = 4 / WCO, LT = 64 * WL;
   extern __shared__ __attribute__((aligned(16))) float cm_smem[];
   const int K = p.K, SEG = p.SEG, nseg = LT / SEG;
@@ -711,21 +767,45 @@ __global__ __launch_bounds__(256) void conv1d_bf16x3_kernel(ConvMfmaParams p) {
     // during the MFMAs was measured and lost: +40 VGPRs cost a resident wave, RB1(64) k7 54 -> 69 us, RB1(32) k11 44 -> 51.)
     // (loads are unconditional from clamped addresses, then selected: a guarded load is an exec-masked branch with its own
     // wait -- sixteen of them per position serialised the staging of every 16-channel block)
+    // Round 6: ONE memory round trip per stage.  The strip is 256 positions + the halo ((K - 1) dil <= 50 more): as a loop
+    // `pp = tid; pp < lin_t; pp += 256` the halo was a second full round trip that only wave 0 made -- with the other three waves
+    // parked at the barrier -- and the weight chunks a third one behind it (a workgroup lived ~25 us around ~2 us of MFMAs,
+    // tools/trace_overlap.py: these launches run alone on the chip for 22 ms of a 115 ms step).  Now every thread requests its
+    // first weight chunks, its main position and a QUARTER (4 channels) of one halo position back to back, and converts / stores
+    // afterwards; halos beyond 64 positions (several short rows per tile) keep the loop form for the rest.
     unsigned ev = 0;
-    for (int pp = tid; pp < lin_t; pp += 256) {
-      const int sg = nseg == 1 ? 0 : pp / lin_s, pos = pp - sg * lin_s, gi = in0 + pos;
-      const bool ok = b0 + sg < p.B && gi >= 0 && gi < p.Lin;
-      const float* xr = p.x + ((int64_t)min(b0 + sg, p.B - 1) * p.N) * p.Lin + min(max(gi, 0), p.Lin - 1);
-      float raw[16];
+    const bf16* gh = p.a_hi + nb * slab + (int64_t)m0 * K * 16 + tid * 8;
+    const bf16* gl = p.a_lo + nb * slab + (int64_t)m0 * K * 16 + tid * 8;
+    // weight chunks requested with the strip: all of them where the LDS footprint already limits a CU to two or three workgroups
+    // (64-row tiles: <2, 11> stages 47 KB of weights), three otherwise (16 VGPRs per chunk in flight: see below)
+    // (none for the instantiations whose register budget at their resident-wave count has no room: they spilled 8-16 VGPRs)
+    // (and none for the 64-row tiles: measured slower with them in flight -- RB1(128) k11 172 vs 148 us -- and their strip is one trip anyway)
+    constexpr int WG0 = KT == 0 || WCO == 2 ? 0 : WCH < 3 ? WCH : 3;
+    bf16x8 wh0[WG0 > 0 ? WG0 : 1], wl0[WG0 > 0 ? WG0 : 1];
 #pragma unroll
-      for (int c = 0; c < 16; ++c) raw[c] = xr[(int64_t)min(nb * 16 + c, p.N - 1) * p.Lin];
+    for (int j = 0; j < WG0; ++j) {
+      if (j < nw) {
+        const int ii = max(min(j, wlast), 0) * 2048;
+        wh0[j] = *reinterpret_cast<const bf16x8*>(gh + ii);
+        if (!F16) wl0[j] = *reinterpret_cast<const bf16x8*>(gl + ii);
+      }
+    }
+    auto strip_src = [&](int pp, bool& ok) {
+      const int sg = nseg == 1 ? 0 : pp / lin_s, pos = pp - sg * lin_s, gi = in0 + pos;
+      ok = b0 + sg < p.B && gi >= 0 && gi < p.Lin;
+      return p.x + ((int64_t)min(b0 + sg, p.B - 1) * p.N) * p.Lin + min(max(gi, 0), p.Lin - 1);
+    };
+    auto split1 = [&](float v, bf16& hv, bf16& lv) {
+      v = lrelu_f(v, p.in_slope);
+      hv = F16 ? f16_slot_ev(v, ev) : (bf16)v;
+      lv = (bf16)(v - (float)hv);
+    };
+    auto put16 = [&](int pp, const float (&raw)[16], bool ok) {
       bf16x8 h0, h1, l0, l1;
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
-        float v = (ok && nb * 16 + c < p.N) ? raw[c] : 0.f;
-        v = lrelu_f(v, p.in_slope);
-        const bf16 hv = F16 ? f16_slot_ev(v, ev) : (bf16)v;
-        const bf16 lv = (bf16)(v - (float)hv);
+        bf16 hv, lv;
+        split1((ok && nb * 16 + c < p.N) ? raw[c] : 0.f, hv, lv);
         if (c < 8) { h0[c] = hv; l0[c] = lv; } else { h1[c - 8] = hv; l1[c - 8] = lv; }
       }
       *reinterpret_cast<bf16x8*>(xh + pp * 8) = h0;
@@ -734,16 +814,64 @@ __global__ __launch_bounds__(256) void conv1d_bf16x3_kernel(ConvMfmaParams p) {
         *reinterpret_cast<bf16x8*>(xl + pp * 8) = l0;
         *reinterpret_cast<bf16x8*>(xl + xhalf + pp * 8) = l1;
       }
+    };
+    if constexpr (WCO == 2) {
+      // (128-position tiles: the strip is shorter than the workgroup unless several short rows share the tile)
+      for (int pp = tid; pp < lin_t; pp += 256) {
+        bool ok;
+        const float* xr = strip_src(pp, ok);
+        float raw[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) raw[c] = xr[(int64_t)min(nb * 16 + c, p.N - 1) * p.Lin];
+        put16(pp, raw, ok);
+      }
+    } else {
+      // main position (tid) and halo quarter (position 256 + tid / 4, channels 4 (tid % 4) ..): requests first
+      bool ok_m, ok_q;
+      const int pm = min(tid, lin_t - 1), pq = min(256 + (tid >> 2), lin_t - 1), cq = (tid & 3) * 4;
+      const float* xm = strip_src(pm, ok_m);
+      const float* xq = strip_src(pq, ok_q);
+      float raw[16], rq[4];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) raw[c] = xm[(int64_t)min(nb * 16 + c, p.N - 1) * p.Lin];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) rq[c] = xq[(int64_t)min(nb * 16 + cq + c, p.N - 1) * p.Lin];
+      if (tid < lin_t) put16(tid, raw, ok_m);
+      if (256 + (tid >> 2) < lin_t) {
+        bf16x4 hq, lq;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          bf16 hv, lv;
+          split1((ok_q && nb * 16 + cq + c < p.N) ? rq[c] : 0.f, hv, lv);
+          hq[c] = hv; lq[c] = lv;
+        }
+        const int o = (cq >> 3) * xhalf + pq * 8 + (cq & 7);
+        *reinterpret_cast<bf16x4*>(xh + o) = hq;
+        if (!F16) *reinterpret_cast<bf16x4*>(xl + o) = lq;
+      }
+    }
+    for (int pp = (WCO == 2 ? lin_t : 320) + tid; pp < lin_t; pp += 256) {   // (beyond that: several short rows in one tile)
+      bool ok;
+      const float* xr = strip_src(pp, ok);
+      float raw[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) raw[c] = xr[(int64_t)min(nb * 16 + c, p.N - 1) * p.Lin];
+      put16(pp, raw, ok);
     }
     if (F16) f16_events_commit(ev);
     // weights: the stage's [MT][K][16] slab is contiguous in the split arrays; 16-byte chunks, LDS slots precomputed (wlds)
     {
-      const bf16* gh = p.a_hi + nb * slab + (int64_t)m0 * K * 16 + tid * 8;
-      const bf16* gl = p.a_lo + nb * slab + (int64_t)m0 * K * 16 + tid * 8;
+#pragma unroll
+      for (int j = 0; j < WG0; ++j) {
+        if (j < nw) {
+          *reinterpret_cast<bf16x8*>(ah + wlds[j]) = wh0[j];
+          if (!F16) *reinterpret_cast<bf16x8*>(ah + (wlds[j] == 2 * MT * apitch ? 2 * MT * apitch + 8 : wlds[j] + MT * apitch)) = wl0[j];
+        }
+      }
       // groups of three chunks in flight (all of them at once costs 16 VGPRs per chunk: <2, 7> went from four waves per SIMD
       // to three and lost 15 %)
 #pragma unroll
-      for (int g = 0; g < WCH; g += 3) {
+      for (int g = WG0; g < WCH; g += 3) {
         bf16x8 vh[3], vl[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -937,9 +1065,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     }
     return;
   }
-#pragma unroll
-  for (int i = 0; i < CW; ++i)
-    conv_tile_epilogue<1>(p, acc[i][0], acc[i][1], wl, 0, col, hh, j0, m0 + (wco * CW + i) * 32, b0, SEG);
+  // (written out, not a loop over i: with the larger round-6 epilogue body the loop was no longer unrolled before the accumulator
+  // array was scalarised -- `acc[i]` with a run-time i put all four accumulators into scratch)
+  conv_tile_epilogue<1>(p, acc[0][0], acc[0][1], wl, 0, col, hh, j0, m0 + (wco * CW) * 32, b0, SEG);
+  if constexpr (CW == 2) conv_tile_epilogue<1>(p, acc[CW - 1][0], acc[CW - 1][1], wl, 0, col, hh, j0, m0 + (wco * CW + 1) * 32, b0, SEG);
 }
 
 // dw[i] += sum_split slab[split][i];  blockIdx.y sums a group of SLAB_G splits and adds its partial with one atomic (a single
@@ -1137,24 +1266,7 @@ __global__ __launch_bounds__(256, 3) void conv1x1_b3_kernel(ConvMfmaParams p) {
   const int j = j0 + wn * 32 + col;
   if (j >= p.Lout) return;
   const float om = p.omask ? p.omask[(int64_t)b * p.LoutTotal + j] : 1.f;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = m0 + wm * 32 + acc_row(r, hh);
-    if (m >= p.M) continue;
-    float v = acc[r] + (p.bias ? p.bias[m] : 0.f);
-    const bool second = p.y2 != nullptr && m >= p.M1;
-    const int Mo = p.y2 ? (second ? p.M - p.M1 : p.M1) : p.M, mm = second ? m - p.M1 : m;
-    float* dst = second ? p.y2 : p.y;
-    const int accf = second ? p.acc2 : p.accumulate;
-    const int64_t o = ((int64_t)b * Mo + mm) * p.LoutTotal + j;
-    if (p.bbias) v += p.bbias[(int64_t)b * p.M + m];
-    if (p.gate) v *= (p.gate[o] > 0.f ? 1.f : p.gate_slope);
-    if (p.resid && !second) v += p.resid[o];
-    if (p.out_act == 1) v = tanhf(v);
-    else if (p.out_act == 2) v = lrelu_f(v, p.out_slope);
-    v *= om * p.out_scale;
-    dst[o] = accf ? dst[o] + v : v;
-  }
+  conv_store_col16(p, acc, m0 + wm * 32 + 4 * hh, b, j, om);
 }
 
 static bool conv1x1_b3_fits(const ConvMfmaParams& p, const ConvCtx& cx) {
