@@ -717,7 +717,8 @@ __device__ __forceinline__ void b3_stage(const bf16* xh, const bf16* xl, const b
 // waves per SIMD the register allocation has to leave room for: what the LDS footprint allows anyway (the round-6 staging keeps
 // more loads in flight; without the bound <2, 7> and <2, 3> each lost a resident wave to it)
 __host__ __device__ constexpr int b3_min_waves(int WCO, int KT) {
-  return KT == 0 ? 3 : KT <= 3 ? (WCO == 2 && KT == 3 ? 3 : 4) : 3;
+  if (WCO == 2) return KT == 11 ? 2 : 3;    // (<2, 11> stages 58 KB: two workgroups per CU whatever the registers allow)
+  return KT == 0 ? 3 : KT <= 3 ? 4 : 3;
 }
 template <int WCO, int KT, bool F16 = false>
 __global__ __launch_bounds__(256, b3_min_waves(WCO, KT)) void conv1d_bf16x3_kernel(ConvMfmaParams p) {
@@ -761,25 +762,69 @@ __global__ __launch_bounds__(256, b3_min_waves(WCO, KT)) void conv1d_bf16x3_kern
     wlds[i] = ch < wchunks ? m * apitch + r * 8 : 2 * MT * apitch;            // dump slots: 2 x 8 elements behind `al`
   }
   const int wlast = (wchunks - 1 - tid) >> 8;          // last in-range chunk index of this thread (may be -1 -> clamp to 0)
+  // One thread per strip position, 16 channels each (coalesced row segments); loads are unconditional from clamped addresses, then
+  // selected (a guarded load is an exec-masked branch with its own wait -- sixteen of them per position serialised the staging of
+  // every 16-channel block).  Round 6, two changes to the staging:
+  //  * the strip of 256-position tiles is 256 positions + a halo ((K - 1) dil <= 50 more): as a loop `pp = tid; pp < lin_t; pp += 256`
+  //    the halo was a second full memory round trip that only wave 0 made, with the other three waves parked at the barrier.  Every
+  //    thread now also requests a QUARTER (4 channels) of one halo position together with its main position;
+  //  * the NEXT stage's strip is requested right behind the barrier that publishes the current one and stays in flight under the
+  //    current stage's MFMAs (16-20 VGPRs).  A stage was: barrier, request, ~2.5 k cycles of HBM latency, convert, weights
+  //    (another round trip), barrier, ~2 k cycles of MFMAs -- a wave fed the matrix cores for 14 % of its life
+  //    (profiles/r06_pmc_conv_onthefly.txt).  (Round 2 measured a prefetch that cost a resident wave and lost; the resident-wave
+  //    count is pinned by b3_min_waves now.)
+  unsigned ev = 0;
+  bool ok_m, ok_q = false;
+  const int cq = (tid & 3) * 4;
+  auto strip_src = [&](int pp, bool& ok) {
+    const int sg = nseg == 1 ? 0 : pp / lin_s, pos = pp - sg * lin_s, gi = in0 + pos;
+    ok = b0 + sg < p.B && gi >= 0 && gi < p.Lin;
+    return p.x + ((int64_t)min(b0 + sg, p.B - 1) * p.N) * p.Lin + min(max(gi, 0), p.Lin - 1);
+  };
+  const float* xm = strip_src(min(tid, lin_t - 1), ok_m);
+  const float* xq = xm;
+  if constexpr (WCO == 1) xq = strip_src(min(256 + (tid >> 2), lin_t - 1), ok_q);
+  float raw[16], rq[WCO == 1 ? 4 : 1];
+  auto request = [&](int nb) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) raw[c] = xm[(int64_t)min(nb * 16 + c, p.N - 1) * p.Lin];
+    if constexpr (WCO == 1) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) rq[c] = xq[(int64_t)min(nb * 16 + cq + c, p.N - 1) * p.Lin];
+    }
+  };
+  auto split1 = [&](float v, bf16& hv, bf16& lv) {
+    v = lrelu_f(v, p.in_slope);
+    hv = F16 ? f16_slot_ev(v, ev) : (bf16)v;
+    lv = (bf16)(v - (float)hv);
+  };
+  auto put16 = [&](int nb, int pp, const float (&rw)[16], bool ok) {
+    bf16x8 h0, h1, l0, l1;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      bf16 hv, lv;
+      split1((ok && nb * 16 + c < p.N) ? rw[c] : 0.f, hv, lv);
+      if (c < 8) { h0[c] = hv; l0[c] = lv; } else { h1[c - 8] = hv; l1[c - 8] = lv; }
+    }
+    *reinterpret_cast<bf16x8*>(xh + pp * 8) = h0;
+    *reinterpret_cast<bf16x8*>(xh + xhalf + pp * 8) = h1;
+    if (!F16) {
+      *reinterpret_cast<bf16x8*>(xl + pp * 8) = l0;
+      *reinterpret_cast<bf16x8*>(xl + xhalf + pp * 8) = l1;
+    }
+  };
+  // (the 256-position tiles of the 16 / 32-channel layers keep the synchronous form: with the strip held across the MFMAs they ran
+  // 10 % SLOWER -- RB1(32) k11 46 -> 51 us, k7 d3 57 -> 64 us: one resident wave less at K <= 3, spills at K = 11 -- while the
+  // 64-row tiles gained: RB1(128) k11 166 -> 150 us, RB1(64) k7 62.5 -> 57.5 us; tools/gpu_r6_x.sh)
+  constexpr bool PF = WCO == 2;
+  if (PF) request(0);
   for (int nb = 0; nb < nblk; ++nb) {
     __syncthreads();
-    // one thread per position, 16 channels each (coalesced row segments).  (Prefetching the next block's strip into registers
-    // during the MFMAs was measured and lost: +40 VGPRs cost a resident wave, RB1(64) k7 54 -> 69 us, RB1(32) k11 44 -> 51.)
-    // (loads are unconditional from clamped addresses, then selected: a guarded load is an exec-masked branch with its own
-    // wait -- sixteen of them per position serialised the staging of every 16-channel block)
-    // Round 6: ONE memory round trip per stage.  The strip is 256 positions + the halo ((K - 1) dil <= 50 more): as a loop
-    // `pp = tid; pp < lin_t; pp += 256` the halo was a second full round trip that only wave 0 made -- with the other three waves
-    // parked at the barrier -- and the weight chunks a third one behind it (a workgroup lived ~25 us around ~2 us of MFMAs,
-    // tools/trace_overlap.py: these launches run alone on the chip for 22 ms of a 115 ms step).  Now every thread requests its
-    // first weight chunks, its main position and a QUARTER (4 channels) of one halo position back to back, and converts / stores
-    // afterwards; halos beyond 64 positions (several short rows per tile) keep the loop form for the rest.
-    unsigned ev = 0;
+    if (!PF) request(nb);
     const bf16* gh = p.a_hi + nb * slab + (int64_t)m0 * K * 16 + tid * 8;
     const bf16* gl = p.a_lo + nb * slab + (int64_t)m0 * K * 16 + tid * 8;
-    // weight chunks requested with the strip: all of them where the LDS footprint already limits a CU to two or three workgroups
-    // (64-row tiles: <2, 11> stages 47 KB of weights), three otherwise (16 VGPRs per chunk in flight: see below)
-    // (none for the instantiations whose register budget at their resident-wave count has no room: they spilled 8-16 VGPRs)
-    // (and none for the 64-row tiles: measured slower with them in flight -- RB1(128) k11 172 vs 148 us -- and their strip is one trip anyway)
+    // weight chunks requested in front of the strip's conversion (16 VGPRs per chunk in flight; none for the instantiations whose
+    // register budget at their resident-wave count has no room, and none for the 64-row tiles: measured slower with them in flight)
     constexpr int WG0 = KT == 0 || WCO == 2 ? 0 : WCH < 3 ? WCH : 3;
     bf16x8 wh0[WG0 > 0 ? WG0 : 1], wl0[WG0 > 0 ? WG0 : 1];
 #pragma unroll
@@ -790,54 +835,11 @@ __global__ __launch_bounds__(256, b3_min_waves(WCO, KT)) void conv1d_bf16x3_kern
         if (!F16) wl0[j] = *reinterpret_cast<const bf16x8*>(gl + ii);
       }
     }
-    auto strip_src = [&](int pp, bool& ok) {
-      const int sg = nseg == 1 ? 0 : pp / lin_s, pos = pp - sg * lin_s, gi = in0 + pos;
-      ok = b0 + sg < p.B && gi >= 0 && gi < p.Lin;
-      return p.x + ((int64_t)min(b0 + sg, p.B - 1) * p.N) * p.Lin + min(max(gi, 0), p.Lin - 1);
-    };
-    auto split1 = [&](float v, bf16& hv, bf16& lv) {
-      v = lrelu_f(v, p.in_slope);
-      hv = F16 ? f16_slot_ev(v, ev) : (bf16)v;
-      lv = (bf16)(v - (float)hv);
-    };
-    auto put16 = [&](int pp, const float (&raw)[16], bool ok) {
-      bf16x8 h0, h1, l0, l1;
-#pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        bf16 hv, lv;
-        split1((ok && nb * 16 + c < p.N) ? raw[c] : 0.f, hv, lv);
-        if (c < 8) { h0[c] = hv; l0[c] = lv; } else { h1[c - 8] = hv; l1[c - 8] = lv; }
-      }
-      *reinterpret_cast<bf16x8*>(xh + pp * 8) = h0;
-      *reinterpret_cast<bf16x8*>(xh + xhalf + pp * 8) = h1;
-      if (!F16) {
-        *reinterpret_cast<bf16x8*>(xl + pp * 8) = l0;
-        *reinterpret_cast<bf16x8*>(xl + xhalf + pp * 8) = l1;
-      }
-    };
-    if constexpr (WCO == 2) {
-      // (128-position tiles: the strip is shorter than the workgroup unless several short rows share the tile)
-      for (int pp = tid; pp < lin_t; pp += 256) {
-        bool ok;
-        const float* xr = strip_src(pp, ok);
-        float raw[16];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) raw[c] = xr[(int64_t)min(nb * 16 + c, p.N - 1) * p.Lin];
-        put16(pp, raw, ok);
-      }
-    } else {
-      // main position (tid) and halo quarter (position 256 + tid / 4, channels 4 (tid % 4) ..): requests first
-      bool ok_m, ok_q;
-      const int pm = min(tid, lin_t - 1), pq = min(256 + (tid >> 2), lin_t - 1), cq = (tid & 3) * 4;
-      const float* xm = strip_src(pm, ok_m);
-      const float* xq = strip_src(pq, ok_q);
-      float raw[16], rq[4];
-#pragma unroll
-      for (int c = 0; c < 16; ++c) raw[c] = xm[(int64_t)min(nb * 16 + c, p.N - 1) * p.Lin];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) rq[c] = xq[(int64_t)min(nb * 16 + cq + c, p.N - 1) * p.Lin];
-      if (tid < lin_t) put16(tid, raw, ok_m);
-      if (256 + (tid >> 2) < lin_t) {
+    // this stage's strip: requested one stage ago
+    if (tid < lin_t) put16(nb, tid, raw, ok_m);
+    if constexpr (WCO == 1) {
+      const int pq = 256 + (tid >> 2);
+      if (pq < lin_t) {
         bf16x4 hq, lq;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -850,15 +852,14 @@ __global__ __launch_bounds__(256, b3_min_waves(WCO, KT)) void conv1d_bf16x3_kern
         if (!F16) *reinterpret_cast<bf16x4*>(xl + o) = lq;
       }
     }
-    for (int pp = (WCO == 2 ? lin_t : 320) + tid; pp < lin_t; pp += 256) {   // (beyond that: several short rows in one tile)
+    for (int pp = (WCO == 2 ? 256 : 320) + tid; pp < lin_t; pp += 256) {   // (beyond that: several short rows in one tile)
       bool ok;
       const float* xr = strip_src(pp, ok);
-      float raw[16];
+      float rw[16];
 #pragma unroll
-      for (int c = 0; c < 16; ++c) raw[c] = xr[(int64_t)min(nb * 16 + c, p.N - 1) * p.Lin];
-      put16(pp, raw, ok);
+      for (int c = 0; c < 16; ++c) rw[c] = xr[(int64_t)min(nb * 16 + c, p.N - 1) * p.Lin];
+      put16(nb, pp, rw, ok);
     }
-    if (F16) f16_events_commit(ev);
     // weights: the stage's [MT][K][16] slab is contiguous in the split arrays; 16-byte chunks, LDS slots precomputed (wlds)
     {
 #pragma unroll
@@ -870,11 +871,12 @@ __global__ __launch_bounds__(256, b3_min_waves(WCO, KT)) void conv1d_bf16x3_kern
       }
       // groups of three chunks in flight (all of them at once costs 16 VGPRs per chunk: <2, 7> went from four waves per SIMD
       // to three and lost 15 %)
+      constexpr int GS = (WCO == 2 && KT == 7) ? 2 : 3;     // (<2, 7> with the prefetched strip: three chunks in flight spilled 3 VGPRs)
 #pragma unroll
-      for (int g = WG0; g < WCH; g += 3) {
-        bf16x8 vh[3], vl[3];
+      for (int g = WG0; g < WCH; g += GS) {
+        bf16x8 vh[GS], vl[GS];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
+        for (int j = 0; j < GS; ++j) {
           const int i = g + j;
           if (i < WCH && i < nw) {
             const int ii = max(min(i, wlast), 0) * 2048;
@@ -883,7 +885,7 @@ __global__ __launch_bounds__(256, b3_min_waves(WCO, KT)) void conv1d_bf16x3_kern
           }
         }
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
+        for (int j = 0; j < GS; ++j) {
           const int i = g + j;
           if (i < WCH && i < nw) {
             *reinterpret_cast<bf16x8*>(ah + wlds[i]) = vh[j];
@@ -893,8 +895,10 @@ __global__ __launch_bounds__(256, b3_min_waves(WCO, KT)) void conv1d_bf16x3_kern
       }
     }
     __syncthreads();
+    if (PF && nb + 1 < nblk) request(nb + 1);              // in flight under this stage's MFMAs
     b3_stage<1, KT, F16>(xh, xl, ah, al, arow, bpos0, bpos1, K, p.dil * 8, acc);
   }
+  if (F16) f16_events_commit(ev);
   conv_tile_epilogue<WCO>(p, acc[0][0], acc[0][1], wl, wco, col, hh, j0, m0, b0, SEG);
 }
 
@@ -2115,6 +2119,10 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad_fused_taps_kernel(WgradMf
   // s_waitcnt, which serialised the 48 loads of a chunk -- 11 us per chunk)
   auto load_regs = [&](int chunk) {
     const int b = chunk / nlc, l0 = (chunk % nlc) * CH;
+    // (<11, 1, 128> and <11, 5, 64> spill 8 / 9 VGPRs: the per-thread row / offset tables of the 17 request pairs are computed once
+    // and held across the chunk loop.  Round 6 measured the alternative -- the thread index made opaque per chunk, so the tables are
+    // recomputed (a division by the odd window pitch per pair): no spill, 238 VGPRs, and 157 us (all pairs) / 206 us (x window only)
+    // against 147 us for the RB1(128) k11 weight gradient.  The spills are the cheaper form.)
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int q = tid + 256 * i, row = q / (CH / 2), l = l0 + (q % (CH / 2)) * 2;
