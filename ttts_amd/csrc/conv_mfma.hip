@@ -486,6 +486,32 @@ __device__ __forceinline__ void conv_store_col16(const ConvMfmaParams& p, const 
   // 55 spilled VGPRs in the DMA kernel)
   asm volatile("" : "+v"(mb), "+v"(j));
   const int nops = (p.gate ? 1 : 0) + (p.resid ? 1 : 0) + (p.accumulate ? 1 : 0) + (p.bbias ? 1 : 0);
+  if (p.y2 == nullptr && nops == 2 && p.gate && p.resid) {
+    // gate AND residual: the first convolution's data gradient of a ResBlock pair that runs as one autograd node (TTTS_RESPAIR)
+    const int64_t rs = p.LoutTotal, o0 = (int64_t)b * p.M * rs + j;
+    const float sc = om * p.out_scale;
+    float bia[16], gv[16], rv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = min(mb + (r & 3) + 8 * (r >> 2), p.M - 1);
+      bia[r] = p.bias ? p.bias[m] : 0.f;
+      gv[r] = p.gate[o0 + m * rs];
+      rv[r] = p.resid[o0 + m * rs];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = mb + (r & 3) + 8 * (r >> 2);
+      if (m >= p.M) continue;
+      float v = acc[r] + bia[r];
+      v *= (gv[r] > 0.f ? 1.f : p.gate_slope);
+      v += rv[r];
+      if (p.out_act == 1) v = tanhf(v);
+      else if (p.out_act == 2) v = lrelu_f(v, p.out_slope);
+      v *= sc;
+      p.y[o0 + m * rs] = v;
+    }
+    return;
+  }
   if (p.y2 == nullptr && nops <= 1) {
     const int mode = p.gate ? 1 : p.resid ? 2 : p.accumulate ? 3 : p.bbias ? 4 : 0;      // (uniform)
     const float* ap = p.gate ? p.gate : p.resid ? p.resid : p.y;

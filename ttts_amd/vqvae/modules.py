@@ -640,7 +640,11 @@ class ResBlock1(nn.Module):
     def forward(self, x, x_mask=None):
         if x_mask is not None:
             raise NotImplementedError("ResBlock1 with x_mask is not on the training path (vq2.py never passes one)")
-        fused = _env_int("TTTS_RESPAIR", 0) == 1          # opt-in: measured level with the two-node form (HISTORY 18.4)
+        # one autograd node per pair (default since round 6; TTTS_RESPAIR=0: two nodes).  Round 5 measured it level with the two-node
+        # form: the residual's gradient rode into c1's data gradient through the per-element epilogue loop (a chain of dependent
+        # round trips).  With the batched gate + residual epilogue (csrc/conv_mfma.hip: conv_store_col16) the 135 engine-side adds it
+        # removes show: 104.8 / 105.7 -> 103.2 / 103.1 ms replayed, 107.3 -> 105.2 ms eager (tools/gpu_r6_o.sh)
+        fused = _env_int("TTTS_RESPAIR", 1) == 1
         for c1, c2 in zip(self.convs1, self.convs2):
             if fused:          # one autograd node per pair: the residual's gradient is added in c1's data-gradient epilogue
                 x = _ResPairFn.apply(x, c1.effective_weight(), c1.bias, c2.effective_weight(), c2.bias, c1.padding, c1.dilation,
