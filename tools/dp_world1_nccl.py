@@ -171,7 +171,7 @@ elif part == "vqvae":
     tol_e, tol_g = max(4.0 * noise_e, 3e-2), max(4.0 * noise_g, 3e-2)
     assert worst(ef, en) <= tol_e, "eager steps differ from the non-distributed run beyond run-to-run noise"
     assert worst(gf, gn) <= tol_g, "graphed steps differ from the non-distributed run beyond run-to-run noise"
-    assert dloss <= max(4.0 * nloss, 5e-2), "losses differ from the non-distributed run beyond run-to-run noise"
+    # (the losses are printed, not asserted: two plain runs of this GAN step differ by 4-17 % in a loss after five steps)
     assert dloss <= 4.0 * nloss + 1e-6
 else:
     raise SystemExit("unknown part " + part)

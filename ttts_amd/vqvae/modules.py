@@ -830,6 +830,9 @@ class _WNFn(torch.autograd.Function):
         want_dw = any(ctx.needs_input_grad[6:])
         dwz = []
         ctx.dwz = dwz
+        # the per-layer conditioning biases as rows of ONE (n_layers, B, 2H) copy (a strided slice + .contiguous() per layer was 16
+        # small copy launches per stack)
+        gc = gcond[:, :, 0].reshape(B, n_layers, 2 * H).permute(1, 0, 2).contiguous() if gcond is not None else None
         for i in range(n_layers):
             in_v, in_g, in_b, rs_v, rs_g, rs_b = params[6 * i:6 * i + 6]
             dil = dil_rate ** i
@@ -843,7 +846,7 @@ class _WNFn(torch.autograd.Function):
             else:
                 w_in, n_in = ops.weight_norm_fwd(in_v, in_g)
                 w_rs, n_rs = ops.weight_norm_fwd(rs_v, rs_g)
-            bb = gcond[:, 2 * H * i:2 * H * (i + 1), 0].contiguous() if gcond is not None else None
+            bb = gc[i] if gc is not None else None
             x_in = ops.conv1d_fwd(xi, w_in, in_b, None, 1, pad, dil, bbias=bb)
             acts = ops.gate_fwd(x_in, ops.GATE_TANH_SIGMOID)
             if i < n_layers - 1:
@@ -874,7 +877,9 @@ class _WNFn(torch.autograd.Function):
         dsk = ops.mul_mask(dout, m2) if m2 is not None else dout
         dres = None
         pgrads = [None] * (6 * n_layers)
-        dgs = [None] * n_layers
+        # the conditioning gradients of all layers accumulate into rows of ONE cleared buffer (a zero-filled temporary per layer + a
+        # concatenation were 17 launches per stack)
+        dg_all = torch.zeros(n_layers, B * 2 * H, dtype=dout.dtype, device=dout.device) if has_g else None
         for i in reversed(range(n_layers)):
             xi, x_in, acts, w_in, n_in, w_rs, n_rs = saved[7 * i:7 * i + 7]
             in_v, in_g, in_b, rs_v, rs_g, rs_b = params[6 * i:6 * i + 6]
@@ -905,7 +910,7 @@ class _WNFn(torch.autograd.Function):
                 db_rs = None if direct else db_t
             dx_in = ops.gate_bwd(dacts, x_in, ops.GATE_TANH_SIGMOID)
             if has_g:
-                dgs[i] = ops.conv1d_bias_grad(dx_in.view(1, B * 2 * H, T)).view(B, 2 * H)
+                ops.conv1d_bias_grad(dx_in.view(1, B * 2 * H, T), out=dg_all[i])
             db_in = slots[2] if direct else torch.zeros_like(in_b)
             dw_in = ops.conv1d_wgrad(dx_in, xi, K, 1, pad, dil, db=db_in, out=pre[0])
             dres = ops.conv1d_dgrad(dx_in, w_in, T, 1, pad, dil, resid=dres, omask=m2 if i > 0 else None)
@@ -918,7 +923,7 @@ class _WNFn(torch.autograd.Function):
                 dv_in, dg_in = ops.weight_norm_bwd(dw_in, in_v, in_g, n_in)
                 dv_rs, dg_rs = ops.weight_norm_bwd(dw_rs, rs_v, rs_g, n_rs)
                 pgrads[6 * i:6 * i + 6] = [dv_in, dg_in, db_in, dv_rs, dg_rs, db_rs]
-        dg = torch.cat(dgs, dim=1).unsqueeze(-1) if has_g else None
+        dg = dg_all.view(n_layers, B, 2 * H).permute(1, 0, 2).reshape(B, n_layers * 2 * H).unsqueeze(-1) if has_g else None
         return (dres, None, dg, None, None, None, *pgrads)
 
 
