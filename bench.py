@@ -139,8 +139,8 @@ def vqvae_leg(dev, steps, warmup, cpu_leg=True):
             gc.unfreeze()
         return dt_, o
     # two ways to issue the same step: eager launches with the independent branches (sub-discriminators, prior / posterior paths,
-    # the three ResBlocks of every MRF stage) on side streams, and one hipGraph replay (the generator's nested fan-out cannot be
-    # recorded, modules.side_streams).  `value` is the faster one; both are reported.
+    # the three ResBlocks of every MRF stage) on side streams, and one hipGraph replay (which keeps the sub-discriminator and
+    # prior / posterior fan-outs: modules.side_streams, TTTS_CAPTURE_POOLS).  `value` is the faster one; both are reported.
     dt_eager, out = timed(tr.train_step)
     vals = {k: float(v) for k, v in out.items()}          # after warmup + steps eager steps: the count the TF32-class column is taken at
     assert all(v == v for v in vals.values()), vals
