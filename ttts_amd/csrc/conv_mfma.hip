@@ -743,6 +743,9 @@ __device__ __forceinline__ void b3_stage(const bf16* xh, const bf16* xl, const b
 // waves per SIMD the register allocation has to leave room for: what the LDS footprint allows anyway (the round-6 staging keeps
 // more loads in flight; without the bound <2, 7> and <2, 3> each lost a resident wave to it)
 __host__ __device__ constexpr int b3_min_waves(int WCO, int KT) {
+#ifdef TTTS_B3_WPF_ALL
+  if (WCO == 2) return (KT == 11 || KT == 7 || KT == 5) ? 2 : 3;
+#endif
   if (WCO == 2) return KT == 11 ? 2 : 3;    // (<2, 11> stages 58 KB: two workgroups per CU whatever the registers allow)
   return KT == 0 ? 3 : KT <= 3 ? 4 : 3;
 }
@@ -843,16 +846,20 @@ __global__ __launch_bounds__(256, b3_min_waves(WCO, KT)) void conv1d_bf16x3_kern
   // 10 % SLOWER -- RB1(32) k11 46 -> 51 us, k7 d3 57 -> 64 us: one resident wave less at K <= 3, spills at K = 11 -- while the
   // 64-row tiles gained: RB1(128) k11 166 -> 150 us, RB1(64) k7 62.5 -> 57.5 us; tools/gpu_r6_x.sh)
   constexpr bool PF = WCO == 2;
-  if (PF) request(0);
-  for (int nb = 0; nb < nblk; ++nb) {
-    __syncthreads();
-    if (!PF) request(nb);
+  // weight chunks requested ahead of the strip's conversion (16 VGPRs per chunk in flight).  256-position tiles: the first three, in
+  // front of the conversion.  64-row tiles: ALL of a stage's chunks, one stage ahead with the strip (TTTS_B3_WPF chunks; the weights
+  // are re-read by every workgroup -- 45 KB per stage at K = 11, 460 MB of L2 -> LDS traffic per RB1(128) launch against 42 MB of
+  // input -- and were two more synchronous round trips per stage)
+  // (K = 5 / 7 at 64 rows: no register room at three resident waves -- -DTTTS_B3_WPF_ALL gives them the prefetch at two waves)
+#ifdef TTTS_B3_WPF_ALL
+  constexpr int WG0 = KT == 0 ? 0 : WCO == 2 ? WCH : WCH < 3 ? WCH : 3;
+#else
+  constexpr int WG0 = KT == 0 ? 0 : WCO == 2 ? ((KT == 11 || KT <= 3) ? WCH : 0) : WCH < 3 ? WCH : 3;
+#endif
+  bf16x8 wh0[WG0 > 0 ? WG0 : 1], wl0[WG0 > 0 ? WG0 : 1];
+  auto request_w = [&](int nb) {
     const bf16* gh = p.a_hi + nb * slab + (int64_t)m0 * K * 16 + tid * 8;
     const bf16* gl = p.a_lo + nb * slab + (int64_t)m0 * K * 16 + tid * 8;
-    // weight chunks requested in front of the strip's conversion (16 VGPRs per chunk in flight; none for the instantiations whose
-    // register budget at their resident-wave count has no room, and none for the 64-row tiles: measured slower with them in flight)
-    constexpr int WG0 = KT == 0 || WCO == 2 ? 0 : WCH < 3 ? WCH : 3;
-    bf16x8 wh0[WG0 > 0 ? WG0 : 1], wl0[WG0 > 0 ? WG0 : 1];
 #pragma unroll
     for (int j = 0; j < WG0; ++j) {
       if (j < nw) {
@@ -861,6 +868,13 @@ __global__ __launch_bounds__(256, b3_min_waves(WCO, KT)) void conv1d_bf16x3_kern
         if (!F16) wl0[j] = *reinterpret_cast<const bf16x8*>(gl + ii);
       }
     }
+  };
+  if (PF) { request(0); request_w(0); }
+  for (int nb = 0; nb < nblk; ++nb) {
+    __syncthreads();
+    if (!PF) { request(nb); request_w(nb); }
+    const bf16* gh = p.a_hi + nb * slab + (int64_t)m0 * K * 16 + tid * 8;
+    const bf16* gl = p.a_lo + nb * slab + (int64_t)m0 * K * 16 + tid * 8;
     // this stage's strip: requested one stage ago
     if (tid < lin_t) put16(nb, tid, raw, ok_m);
     if constexpr (WCO == 1) {
@@ -921,7 +935,7 @@ __global__ __launch_bounds__(256, b3_min_waves(WCO, KT)) void conv1d_bf16x3_kern
       }
     }
     __syncthreads();
-    if (PF && nb + 1 < nblk) request(nb + 1);              // in flight under this stage's MFMAs
+    if (PF && nb + 1 < nblk) { request(nb + 1); request_w(nb + 1); }   // in flight under this stage's MFMAs
     b3_stage<1, KT, F16>(xh, xl, ah, al, arow, bpos0, bpos1, K, p.dil * 8, acc);
   }
   if (F16) f16_events_commit(ev);
