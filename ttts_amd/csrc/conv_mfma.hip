@@ -1233,13 +1233,17 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_mfma_kernel(WgradMfmaParams 
 // Same products in the same order as b3_mma (lo*hi, hi*lo, hi*hi per 16-channel block, blocks ascending): bit-identical to the
 // path it replaces.  Epilogue: the non-phase-merged branch of conv_tile_epilogue (bias, per-sample bias, gate, residual, tanh /
 // leaky-relu, mask, scale, accumulate, dual destination).  Flag 512: off (A/B switch).
-template <bool F16>
+// TALL (round 6, wide layers: M % 128 == 0, M >= 512 -- the diffusion model's 512 / 1024 / 1536-row projections): 128 x 64 tiles, the
+// four waves stacked along M, each 32 rows x BOTH 32-position blocks.  Every output-channel tile re-splits the x tile it shares with the
+// other M / tile-rows workgroups (VALU : MFMA cycles ~1.7 : 1 at 64 rows, whatever M is): twice the rows halve that, and a weight
+// fragment feeds two MFMA triples instead of one.  Same products in the same order per output element: bit-identical to the 64-row form.
+template <bool F16, bool TALL = false>
 __global__ __launch_bounds__(256, 3) void conv1x1_b3_kernel(ConvMfmaParams p) {
-  constexpr int KC = 128, NTL = 64;
+  constexpr int KC = 128, NTL = 64, NCB = TALL ? 2 : 1;
   __shared__ __attribute__((aligned(16))) bf16 xs[2][KC / 8][NTL][8];          // [hi | lo][8-channel group][position][8]: 32 KB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, col = lane & 31;
-  const int wm = wave & 1, wn = wave >> 1;
-  const int j0 = blockIdx.x * NTL, m0 = blockIdx.y * 64, b = blockIdx.z;
+  const int wm = TALL ? wave : (wave & 1), wn = TALL ? 0 : (wave >> 1);
+  const int j0 = blockIdx.x * NTL, m0 = blockIdx.y * (TALL ? 128 : 64), b = blockIdx.z;
   const int nblk = (p.N + 15) / 16, nchunk = (p.N + KC - 1) / KC;
   const float* xb = p.x + (int64_t)b * p.N * p.Lin;
   const int sn = tid & 63, sk = tid >> 6;                                       // staging: position, first 8-channel group (+4 per round)
@@ -1272,9 +1276,11 @@ __global__ __launch_bounds__(256, 3) void conv1x1_b3_kernel(ConvMfmaParams p) {
       if (!F16) *reinterpret_cast<bf16x8*>(&xs[1][k8][sn][0]) = l;
     }
   };
-  f32x16 acc;
+  f32x16 acc[NCB];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
   const bf16* ahp = p.a_hi + ((int64_t)(m0 + wm * 32 + col)) * 16 + hh * 8;     // + kb * Mpad * 16 per 16-channel block
   const bf16* alp = p.a_lo + ((int64_t)(m0 + wm * 32 + col)) * 16 + hh * 8;
   const int64_t astep = (int64_t)p.Mpad * 16;
@@ -1294,23 +1300,31 @@ __global__ __launch_bounds__(256, 3) void conv1x1_b3_kernel(ConvMfmaParams p) {
 #pragma unroll
     for (int ks = 0; ks < KC / 16; ++ks) {
       if (c * (KC / 16) + ks < nblk) {                                          // workgroup-uniform
-        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&xs[0][2 * ks + hh][wn * 32 + col][0]);
-        if constexpr (F16) {
-          acc = mfma32_f16(ah[ks], bh, acc);
-        } else {
-          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&xs[1][2 * ks + hh][wn * 32 + col][0]);
-          acc = mfma32(al[ks], bh, acc);
-          acc = mfma32(ah[ks], bl, acc);
-          acc = mfma32(ah[ks], bh, acc);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+          const int pc = (TALL ? cb : wn) * 32 + col;
+          const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&xs[0][2 * ks + hh][pc][0]);
+          if constexpr (F16) {
+            acc[cb] = mfma32_f16(ah[ks], bh, acc[cb]);
+          } else {
+            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&xs[1][2 * ks + hh][pc][0]);
+            acc[cb] = mfma32(al[ks], bh, acc[cb]);
+            acc[cb] = mfma32(ah[ks], bl, acc[cb]);
+            acc[cb] = mfma32(ah[ks], bh, acc[cb]);
+          }
         }
       }
     }
   }
   if (F16) f16_events_commit(ev);
-  const int j = j0 + wn * 32 + col;
-  if (j >= p.Lout) return;
-  const float om = p.omask ? p.omask[(int64_t)b * p.LoutTotal + j] : 1.f;
-  conv_store_col16(p, acc, m0 + wm * 32 + 4 * hh, b, j, om);
+  {
+    const int j = j0 + wn * 32 + col;
+    if (j < p.Lout) conv_store_col16(p, acc[0], m0 + wm * 32 + 4 * hh, b, j, p.omask ? p.omask[(int64_t)b * p.LoutTotal + j] : 1.f);
+  }
+  if constexpr (TALL) {
+    const int j = j0 + 32 + col;
+    if (j < p.Lout) conv_store_col16(p, acc[NCB - 1], m0 + wm * 32 + 4 * hh, b, j, p.omask ? p.omask[(int64_t)b * p.LoutTotal + j] : 1.f);
+  }
 }
 
 static bool conv1x1_b3_fits(const ConvMfmaParams& p, const ConvCtx& cx) {
@@ -1331,8 +1345,13 @@ static int conv1x1_b3_launch(ConvMfmaParams p, const ConvCtx& cx, hipStream_t st
   if (need_split)
     conv_weight_split_kernel<<<(int)std::min<int64_t>(cdiv(elems, 256), 2048), 256, 0, stream>>>(p.w, hi, lo, p.M, p.N, p.Mpad, nblk, 1, p.Kmem,
                                                                                               p.transposed, p.tap_off, p.tap_stride, 16, 0, 0, 0, f16);
-  const dim3 grid((unsigned)cdiv(p.Lout, 64), (unsigned)(p.Mpad / 64), (unsigned)p.B);
-  if (f16) conv1x1_b3_kernel<true><<<grid, 256, 0, stream>>>(p);
+  // 128-row tiles for the wide layers (flag 1024: off); the 192 / 384-row WaveNet layers keep 64 rows -- they need the workgroups
+  const bool tall = p.M % 128 == 0 && p.M >= 512 && !(cx.flags & 1024);
+  const dim3 grid((unsigned)cdiv(p.Lout, 64), (unsigned)(p.Mpad / (tall ? 128 : 64)), (unsigned)p.B);
+  if (tall) {
+    if (f16) conv1x1_b3_kernel<true, true><<<grid, 256, 0, stream>>>(p);
+    else conv1x1_b3_kernel<false, true><<<grid, 256, 0, stream>>>(p);
+  } else if (f16) conv1x1_b3_kernel<true><<<grid, 256, 0, stream>>>(p);
   else conv1x1_b3_kernel<false><<<grid, 256, 0, stream>>>(p);
   *handled = true;
   return check_launch("conv1x1_b3");
