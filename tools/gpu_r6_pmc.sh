@@ -8,9 +8,9 @@ R=$PWD
 export TMPDIR=/tmp
 O=$R/gpurun_out/r6p
 mkdir -p $O
-bash tools/gpt_pmc.sh r06_pmc_gpt_sq SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE > /dev/null
-bash tools/gpt_pmc.sh r06_pmc_gpt_fetch FETCH_SIZE > /dev/null
-bash tools/gpt_pmc.sh r06_pmc_gpt_write WRITE_SIZE > /dev/null
+[ -n "$SKIP_GPT_PMC" ] || bash tools/gpt_pmc.sh r06_pmc_gpt_sq SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE > /dev/null
+[ -n "$SKIP_GPT_PMC" ] || bash tools/gpt_pmc.sh r06_pmc_gpt_fetch FETCH_SIZE > /dev/null
+[ -n "$SKIP_GPT_PMC" ] || bash tools/gpt_pmc.sh r06_pmc_gpt_write WRITE_SIZE > /dev/null
 cp gpurun_out/pmc/r06_pmc_gpt_*.txt $O/
 grep -A9 "dh64" $O/r06_pmc_gpt_sq.txt | head -50
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/gprof -o gpt -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-vqvae --no-diffusion > $O/prof_bench.json 2> $O/prof.err); echo "GPT PROF rc=$?"
