@@ -370,6 +370,179 @@ __global__ __launch_bounds__(256) void stft_mag_r4p_kernel(const float* __restri
   }
 }
 
+// (round 6) n_fft = 2048 with ONE WAVE PER FRAME and ONE LDS transpose.  The radix-4 kernel above sends every frame through five
+// barrier-separated LDS passes (write + read of the whole 8-KB frame with stride-Ns addressing each): 50 us for 32 clips = 13.6 % of
+// the HBM roof, neither HBM (6.8 us) nor VALU (6.4 us) bound but LDS-pass / barrier bound.  Here the packed 1024-point complex
+// transform is factored 32 x 32 (n = 32 n1 + n2, k = k1 + 32 k2):
+//     Z[k1 + 32 k2] = sum_n2 W_1024^(n2 k1) W_32^(n2 k2) [ sum_n1 z[32 n1 + n2] W_32^(n1 k1) ]
+// and BOTH 32-point transforms run in registers: lane (c = lane & 31, h = lane >> 5) holds the 16 points n1 = h + 2 m of column c,
+// does a radix-16 (two radix-4 stages) on them, and the two halves of a column combine through one cross-half exchange
+// (F[j + 16 s] = G_0[j] + (-1)^s W_32^j G_1[j]).  Between the two transforms the 32 x 32 matrix is transposed through a
+// WAVE-PRIVATE 8-KB LDS buffer (pitch 33: conflict-free both ways) -- no workgroup barrier anywhere in a frame; the real-spectrum
+// unpacking fetches Z[L - k] through the same buffer.  Per frame: 2 x (8 KB written + 8 KB read) of LDS instead of 5 x, zero
+// barriers instead of 7.  Magnitudes are parked in a [bin][16 frames] tile and leave as 64-byte runs along the frame axis.
+// Twiddles: the host table (exp(-2 pi i t / 2048), t < 1024) staged in LDS; W_16 / W_32 powers are literals.
+namespace w32 {
+#ifndef TTTS_STFT_W32_FR
+#define TTTS_STFT_W32_FR 16
+#define TTTS_STFT_W32_WAVES 8
+#endif
+// FR frames per workgroup (the output leaves in FR x 4-byte runs), WAVES waves, FR / WAVES frames per wave.  Default 16 x 8 with the
+// twiddle / window tables in LDS: 153 KB, one workgroup per CU, 64-byte runs.  -DTTTS_STFT_W32_FR=8 -DTTTS_STFT_W32_WAVES=4 reads the
+// tables from global memory (L2 / L1-resident, 8 KB each) and fits TWO workgroups per CU (70.7 KB): measured level, 41.3 vs 40.7 us
+// (tools/gpu_r6_af.sh) -- the kernel is bound by its ~1 500 VALU instructions per frame, not by the overlap of its phases
+constexpr int FR = TTTS_STFT_W32_FR, WAVES = TTTS_STFT_W32_WAVES, L = 1024, PITCH = 33;
+constexpr bool TABLES_IN_LDS = FR >= 16;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 t) { return make_float2(a.x * t.x - a.y * t.y, a.x * t.y + a.y * t.x); }
+// forward 4-point DFT in place: (a, b, c, d) -> (y0, y1, y2, y3)
+__device__ __forceinline__ void fft4(float2& a, float2& b, float2& c, float2& d) {
+  const float2 s0 = cadd(a, c), s1 = csub(a, c), s2 = cadd(b, d), s3 = csub(b, d);
+  a = cadd(s0, s2); c = csub(s0, s2);
+  b = make_float2(s1.x + s3.y, s1.y - s3.x);          // s1 - i s3
+  d = make_float2(s1.x - s3.y, s1.y + s3.x);          // s1 + i s3
+}
+// forward 16-point DFT in place; X[k] ends up in x[(k >> 2) + 4 (k & 3)]
+__device__ __forceinline__ void fft16(float2 (&x)[16]) {
+  constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R = 0.70710678118654752f;
+#pragma unroll
+  for (int n1 = 0; n1 < 4; ++n1) fft4(x[n1], x[n1 + 4], x[n1 + 8], x[n1 + 12]);     // x[n1 + 4 k2] = A[n1][k2]
+  // A[n1][k2] *= W_16^(n1 k2)
+  x[1 + 4] = cmul(x[1 + 4], make_float2(C1, -S1));   x[1 + 8] = cmul(x[1 + 8], make_float2(R, -R));    x[1 + 12] = cmul(x[1 + 12], make_float2(S1, -C1));
+  x[2 + 4] = cmul(x[2 + 4], make_float2(R, -R));     x[2 + 8] = make_float2(x[2 + 8].y, -x[2 + 8].x);  x[2 + 12] = cmul(x[2 + 12], make_float2(-R, -R));
+  x[3 + 4] = cmul(x[3 + 4], make_float2(S1, -C1));   x[3 + 8] = cmul(x[3 + 8], make_float2(-R, -R));   x[3 + 12] = cmul(x[3 + 12], make_float2(-C1, S1));
+#pragma unroll
+  for (int k2 = 0; k2 < 4; ++k2) fft4(x[4 * k2], x[4 * k2 + 1], x[4 * k2 + 2], x[4 * k2 + 3]);       // x[k1 + 4 k2] = X[4 k1 + k2]
+}
+// The 32-point transform of a column held by a lane pair: in x[m] = column point h + 2 m; out y[j] = F[j + 16 h] (natural order).
+__device__ __forceinline__ void fft32_pair(float2 (&x)[16], float2 (&y)[16], int h) {
+  // W_32^j = exp(-2 pi i j / 32), j < 16
+  constexpr float C32[16] = {1.f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654752f,
+                             0.55557023301960218f, 0.38268343236508977f, 0.19509032201612825f, 0.f, -0.19509032201612825f,
+                             -0.38268343236508977f, -0.55557023301960218f, -0.70710678118654752f, -0.83146961230254524f,
+                             -0.92387953251128674f, -0.98078528040323043f};
+  constexpr float S32[16] = {0.f, 0.19509032201612825f, 0.38268343236508977f, 0.55557023301960218f, 0.70710678118654752f,
+                             0.83146961230254524f, 0.92387953251128674f, 0.98078528040323043f, 1.f, 0.98078528040323043f,
+                             0.92387953251128674f, 0.83146961230254524f, 0.70710678118654752f, 0.55557023301960218f,
+                             0.38268343236508977f, 0.19509032201612825f};
+  fft16(x);
+  const float sgn = h ? -1.f : 1.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    // the odd half carries W_32^j (a per-lane twiddle (1, 0) on the even half: no divergent multiply, no select of products)
+    const float2 g = cmul(x[(j >> 2) + 4 * (j & 3)], make_float2(h ? C32[j] : 1.f, h ? -S32[j] : 0.f));
+    // the other half's value: one v_permlane32_swap per component (swap(v, v) = ([lo, lo], [hi, hi])) instead of a ds_bpermute round trip
+    const u32x2 sx = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, g.x), __builtin_bit_cast(uint32_t, g.x), false, false);
+    const u32x2 sy = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, g.y), __builtin_bit_cast(uint32_t, g.y), false, false);
+    const uint32_t sxl = sx[0], sxh = sx[1], syl = sy[0], syh = sy[1];
+    const float ox = __builtin_bit_cast(float, h ? sxl : sxh), oy = __builtin_bit_cast(float, h ? syl : syh);
+    y[j] = make_float2(fmaf(sgn, g.x, ox), fmaf(sgn, g.y, oy));   // F[j] = G0 + W G1 (even half) ;  F[j + 16] = G0 - W G1 (odd half)
+  }
+}
+}  // namespace w32
+
+__global__ __launch_bounds__(64 * w32::WAVES, 2) void stft_mag_w32_kernel(const float* __restrict__ wav, const float* __restrict__ window,
+                                                           const float2* __restrict__ tw, float* __restrict__ spec, int T, int hop,
+                                                           int frames) {
+  using namespace w32;
+  constexpr int n_fft = 2 * L;
+  extern __shared__ __attribute__((aligned(16))) float stft_smem[];
+  constexpr int NT = 64 * WAVES;
+  float2* tws_l = reinterpret_cast<float2*>(stft_smem);           // [L] exp(-2 pi i t / n_fft)        } only when TABLES_IN_LDS
+  float2* wins_l = tws_l + L;                                     // [L] (w[2 n], w[2 n + 1])          }
+  float2* bufs = TABLES_IN_LDS ? wins_l + L : tws_l;              // [WAVES][32 * PITCH]
+  float* outs = reinterpret_cast<float*>(bufs + WAVES * 32 * PITCH);   // [L + 1][FR + 1]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, h = lane >> 5;
+  if (TABLES_IN_LDS) {
+    for (int i = tid; i < L; i += NT) {
+      tws_l[i] = tw[i];
+      wins_l[i] = make_float2(window[2 * i], window[2 * i + 1]);
+    }
+    __syncthreads();
+  }
+  const float2* tws = TABLES_IN_LDS ? tws_l : tw;
+  const float2* wins = TABLES_IN_LDS ? wins_l : reinterpret_cast<const float2*>(window);
+  const int fblocks = (frames + FR - 1) / FR;
+  const int b = blockIdx.x / fblocks, f0 = (blockIdx.x % fblocks) * FR;
+  const int pad = (n_fft - hop) / 2;
+  const float* w = wav + (int64_t)b * T;
+  float2* buf = bufs + wave * 32 * PITCH;
+  auto W2048 = [&](int t) {                                       // exp(-2 pi i t / 2048), any t >= 0
+    t &= n_fft - 1;
+    const float2 v = tws[t & (L - 1)];
+    return t >= L ? make_float2(-v.x, -v.y) : v;
+  };
+  // per-lane twiddles, the same for every frame: between the transforms W_1024^(c k1), k1 = j + 16 h; unpacking: w_k, k = c + 32 (j + 16 h)
+  float2 twa[16], twu[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    twa[j] = W2048(2 * c * (j + 16 * h));
+    twu[j] = tws[c + 32 * (j + 16 * h)];
+  }
+  auto load_frame = [&](int f, float2 (&x)[16]) {
+    const int frame = min(f, frames - 1);
+    // (an interior-frame fast path without the reflection folding -- ~190 VALU instructions per frame -- doubled the load code and
+    // spilled 35 VGPRs at the 256-register budget: 48.8 us; removed)
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const int n = 64 * m + lane;                                // packed point 32 (h + 2 m) + c
+      int i0 = frame * hop + 2 * n - pad, i1 = i0 + 1;
+      i0 = i0 < 0 ? -i0 : i0; i1 = i1 < 0 ? -i1 : i1;
+      i0 = i0 >= T ? 2 * (T - 1) - i0 : i0; i1 = i1 >= T ? 2 * (T - 1) - i1 : i1;
+      x[m] = make_float2(w[i0], w[i1]);
+    }
+  };
+  constexpr int FPW = FR / WAVES;                                 // frames per wave
+  float2 x[16], y[16], nx[16];
+  load_frame(f0 + wave * FPW, nx);
+#pragma unroll
+  for (int q = 0; q < FPW; ++q) {
+    const int fi = wave * FPW + q;                                // frame slot of the tile
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const float2 wn = wins[64 * m + lane];
+      x[m] = make_float2(nx[m].x * wn.x, nx[m].y * wn.y);
+    }
+    if (q + 1 < FPW) load_frame(f0 + fi + 1, nx);                 // in flight under this frame's arithmetic
+    fft32_pair(x, y, h);                                          // y[j] = F[k1 = j + 16 h] of column n2 = c
+    __builtin_amdgcn_wave_barrier();                              // (the previous frame's reads of the buffer are done: same wave, in order)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) buf[(j + 16 * h) * PITCH + c] = cmul(y[j], twa[j]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int m = 0; m < 16; ++m) x[m] = buf[c * PITCH + h + 2 * m];   // row k1 = c, points n2 = h + 2 m
+    fft32_pair(x, y, h);                                          // y[j] = Z[c + 32 (j + 16 h)]
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) buf[c + 32 * (j + 16 * h)] = y[j];   // natural order for the Z[L - k] fetch
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int k = c + 32 * (j + 16 * h);
+      const float2 zk = y[j], zc = buf[(L - k) & (L - 1)];
+      float re, im;
+      if (k == 0) {
+        re = zk.x + zk.y; im = 0.f;
+        outs[L * (FR + 1) + fi] = sqrtf((zk.x - zk.y) * (zk.x - zk.y) + 1e-6f);   // bin L
+      } else {
+        const float er = 0.5f * (zk.x + zc.x), ei = 0.5f * (zk.y - zc.y);
+        const float orr = 0.5f * (zk.y + zc.y), oi = -0.5f * (zk.x - zc.x);
+        re = er + (orr * twu[j].x - oi * twu[j].y);
+        im = ei + (orr * twu[j].y + oi * twu[j].x);
+      }
+      outs[k * (FR + 1) + fi] = __builtin_amdgcn_sqrtf(re * re + im * im + 1e-6f);
+    }
+  }
+  __syncthreads();
+  const int nf = min(FR, frames - f0);
+  for (int i = tid; i < (L + 1) * FR; i += NT) {
+    const int k = i / FR, ff = i % FR;
+    if (ff < nf) spec[((int64_t)b * (L + 1) + k) * frames + f0 + ff] = outs[k * (FR + 1) + ff];
+  }
+}
+
 // mel[b][m][f] = log(max(sum_k basis[m][k] spec[b][k][f], 1e-5)).
 // (round 2) A mel filterbank row is a narrow band (Slaney triangles: ~2 x 1025 non-zeros in 128 x 1025), so the dense
 // 32 x 64 x 32 tiled product of round 1 (166 us for 32 clips: 2.9 % of the HBM roof, all of it multiplying zeros) is replaced
@@ -603,7 +776,18 @@ extern "C" int ttts_stft_mag_fwd_f32(const float* wav, const float* window, cons
   while ((1 << log2L) < L) ++log2L;
   constexpr int NF = 2, FR4 = 8;                         // radix-4 kernel: frames per pass, frames per workgroup (16 frames =
   const bool r4 = L >= 256 && L <= 2048;                 // 64-byte output runs, but 110 KB of LDS = one workgroup per CU: 120 us vs 91); short transforms keep radix-2
-  if (L == 1024) {                                        // n_fft 2048 (the training configuration): per-thread tables, LDS swizzle
+  static const bool r4_forced = getenv("TTTS_STFT_R4") != nullptr;   // (A/B switch: the round-3 radix-4 kernel)
+  if (L == 1024 && !r4_forced) {             // n_fft 2048 (the training configuration): one wave per frame, 32 x 32 in registers
+    const size_t smemw = (w32::TABLES_IN_LDS ? (size_t)2 * L * sizeof(float2) : 0) + (size_t)w32::WAVES * 32 * w32::PITCH * sizeof(float2) +
+                         (size_t)(L + 1) * (w32::FR + 1) * sizeof(float);
+    static OnceFlag attrw_once;
+    const hipError_t attrw = lds_opt_in(attrw_once, reinterpret_cast<const void*>(stft_mag_w32_kernel), 160 * 1024);
+    if (attrw != hipSuccess) return fail(TTTS_EHIP, "stft: hipFuncSetAttribute: %s", hipGetErrorString(attrw));
+    stft_mag_w32_kernel<<<B * (int)cdiv(frames, w32::FR), 64 * w32::WAVES, smemw, as_stream(stream)>>>(
+        wav, window, reinterpret_cast<const float2*>(twiddle), spec, T, hop, frames);
+    return check_launch("stft_mag_fwd");
+  }
+  if (L == 1024) {                                        // (TTTS_STFT_R4=1: the round-3 radix-4 kernel) per-thread tables, LDS swizzle
     const size_t smemp = (size_t)2 * NF * L * sizeof(float2) + (size_t)(L + 1) * (FR4 + 1) * sizeof(float);
     static OnceFlag attrp_once;
     const hipError_t attrp = lds_opt_in(attrp_once, reinterpret_cast<const void*>(stft_mag_r4p_kernel<NF, FR4, 10>), 160 * 1024);
