@@ -106,6 +106,140 @@ __global__ __launch_bounds__(256) void groupnorm_bwd_kernel(const float* __restr
   }
 }
 
+// (round 6) Register-resident forms for groups of up to 256 x 4 x GN_V elements (the diffusion model's 16 channels x <= 448 frames:
+// 6 400).  The kernels above walk a group three times with 4-byte loads (sum, squared deviations, output) and wait for memory in each
+// pass: 18 / 31 us forward / backward for 13 MB tensors whose one-pass traffic is 3.3 / 5 us.  Here a workgroup reads its group ONCE
+// as float4s into registers, reduces twice (mean, then squared deviations of the held values -- the same two-pass arithmetic) and
+// writes from registers.  Needs T % 4 == 0 (rows stay 16-byte aligned) and n / 4 <= 256 GN_V.
+constexpr int GN_V = 8;
+__global__ __launch_bounds__(256) void groupnorm_fwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, const float* __restrict__ ss,
+                                                                float* __restrict__ y, float* __restrict__ mean_out,
+                                                                float* __restrict__ rstd_out, int C, int T, int G, float eps, int act) {
+  __shared__ float sh[4];
+  const int b = blockIdx.x / G, g = blockIdx.x % G;
+  const int Cg = C / G, n = Cg * T, n4 = n >> 2, T4 = T >> 2;
+  const int64_t base = ((int64_t)b * C + g * Cg) * T;
+  const float4* x4 = reinterpret_cast<const float4*>(x + base);
+  float4 v[GN_V];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < GN_V; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    v[k] = i < n4 ? x4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+  }
+  const float mean = block_sum(s, sh) / (float)n;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < GN_V; ++k) {
+    if (threadIdx.x + 256 * k < n4) {
+      const float d0 = v[k].x - mean, d1 = v[k].y - mean, d2 = v[k].z - mean, d3 = v[k].w - mean;
+      q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(block_sum(q, sh) / (float)n + eps);
+  if (threadIdx.x == 0) { mean_out[blockIdx.x] = mean; rstd_out[blockIdx.x] = rstd; }
+  float4* y4 = reinterpret_cast<float4*>(y + base);
+#pragma unroll
+  for (int k = 0; k < GN_V; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    if (i >= n4) continue;
+    const int c = g * Cg + i / T4;
+    const float gmc = gamma[c], bt = beta[c];
+    const float sc = ss ? 1.f + ss[(int64_t)b * 2 * C + c] : 1.f, sf = ss ? ss[(int64_t)b * 2 * C + C + c] : 0.f;
+    float o[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float u = (o[e] - mean) * rstd * gmc + bt;
+      if (ss) u = u * sc + sf;
+      if (act) u = u * dsigmoid(u);
+      o[e] = u;
+    }
+    y4[i] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// backward: x and dy held in registers (one channel per wave at a time, as above: the per-channel sums are wave reductions), dx
+// written from them after the two group sums are known
+constexpr int GN_BW = 7;       // elements per lane and channel held (T <= 64 * GN_BW = 448)
+constexpr int GN_BC = 4;       // channels per wave held (Cg <= 4 * GN_BC = 16)
+__global__ __launch_bounds__(256) void groupnorm_bwd_reg_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                const float* __restrict__ ss, const float* __restrict__ mean_in,
+                                                                const float* __restrict__ rstd_in, float* __restrict__ dx,
+                                                                float* __restrict__ pg, float* __restrict__ pb,
+                                                                float* __restrict__ dss, int C, int T, int G, int act) {
+  __shared__ float sh[4];
+  const int b = blockIdx.x / G, g = blockIdx.x % G;
+  const int Cg = C / G, n = Cg * T;
+  const int64_t base = ((int64_t)b * C + g * Cg) * T;
+  const float mean = mean_in[blockIdx.x], rstd = rstd_in[blockIdx.x];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float zr[GN_BC][GN_BW], dzr[GN_BC][GN_BW];      // z and dz of this lane's elements
+  float sum_dz = 0.f, sum_dzz = 0.f;
+#pragma unroll
+  for (int q = 0; q < GN_BC; ++q) {
+    const int cl = wave + 4 * q;
+    const bool cok = cl < Cg;
+    const int c = g * Cg + min(cl, Cg - 1);
+    const float gm = gamma[c], bt = beta[c];
+    const float sc = ss ? ss[(int64_t)b * 2 * C + c] : 0.f, sf = ss ? ss[(int64_t)b * 2 * C + C + c] : 0.f;
+    float xv[GN_BW], dv[GN_BW];
+#pragma unroll
+    for (int e = 0; e < GN_BW; ++e) {             // requests first (clamped addresses, selected below)
+      const int64_t o = base + (int64_t)min(cl, Cg - 1) * T + min(lane + 64 * e, T - 1);
+      xv[e] = x[o]; dv[e] = dy[o];
+    }
+    float s_da = 0.f, s_daz = 0.f, s_dua = 0.f, s_du = 0.f;
+#pragma unroll
+    for (int e = 0; e < GN_BW; ++e) {
+      const bool ok = cok && lane + 64 * e < T;
+      const float z = (xv[e] - mean) * rstd;
+      const float a = z * gm + bt;
+      const float u = a * (1.f + sc) + sf;
+      float du = ok ? dv[e] : 0.f;
+      if (act) { const float sg = dsigmoid(u); du *= sg * (1.f + u * (1.f - sg)); }
+      const float da = du * (1.f + sc);
+      s_da += da; s_daz += da * z; s_dua += du * a; s_du += du;
+      const float dz = da * gm;
+      sum_dz += dz; sum_dzz += dz * z;
+      zr[q][e] = z; dzr[q][e] = dz;
+    }
+    s_da = wave_sum(s_da); s_daz = wave_sum(s_daz);
+    if (ss) { s_dua = wave_sum(s_dua); s_du = wave_sum(s_du); }
+    if (lane == 0 && cok) {
+      pg[(int64_t)b * C + c] = s_daz;
+      pb[(int64_t)b * C + c] = s_da;
+      if (ss) { dss[(int64_t)b * 2 * C + c] = s_dua; dss[(int64_t)b * 2 * C + C + c] = s_du; }
+    }
+  }
+  const float m1 = block_sum(sum_dz, sh) / (float)n, m2 = block_sum(sum_dzz, sh) / (float)n;
+#pragma unroll
+  for (int q = 0; q < GN_BC; ++q) {
+    const int cl = wave + 4 * q;
+    if (cl >= Cg) continue;
+#pragma unroll
+    for (int e = 0; e < GN_BW; ++e) {
+      const int t = lane + 64 * e;
+      if (t < T) dx[base + (int64_t)cl * T + t] = rstd * (dzr[q][e] - m1 - zr[q][e] * m2);
+    }
+  }
+}
+
+// out[c] (+)= sum_r in[r][c] for TWO arrays in one launch (the d gamma / d beta partials of a GroupNorm backward)
+__global__ __launch_bounds__(256) void reduce_rows2_kernel(const float* __restrict__ in0, float* __restrict__ out0,
+                                                           const float* __restrict__ in1, float* __restrict__ out1, int R, int C,
+                                                           int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float* in = blockIdx.y ? in1 : in0;
+  float* out = blockIdx.y ? out1 : out0;
+  float s = 0.f;
+  for (int r = 0; r < R; ++r) s += in[(int64_t)r * C + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
 // out[c] (+)= sum_r in[r][c]   (fixed order)
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C,
                                                           int accumulate) {
@@ -378,7 +512,11 @@ extern "C" int ttts_groupnorm_fwd_f32(const float* x, const float* gamma, const 
                                       int32_t silu, void* stream) {
   TTTS_REQUIRE(x && gamma && beta && y && mean && rstd && B > 0 && C > 0 && T > 0, "groupnorm_fwd: bad arguments");
   TTTS_REQUIRE(groups > 0 && C % groups == 0, "groupnorm_fwd: C %% groups != 0");
-  groupnorm_fwd_kernel<<<B * groups, 256, 0, as_stream(stream)>>>(x, gamma, beta, scale_shift, y, mean, rstd, C, T, groups, eps, silu);
+  const int n = C / groups * T;
+  if (T % 4 == 0 && n / 4 <= 256 * GN_V && (reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (reinterpret_cast<uintptr_t>(y) & 15u) == 0)
+    groupnorm_fwd_reg_kernel<<<B * groups, 256, 0, as_stream(stream)>>>(x, gamma, beta, scale_shift, y, mean, rstd, C, T, groups, eps, silu);
+  else
+    groupnorm_fwd_kernel<<<B * groups, 256, 0, as_stream(stream)>>>(x, gamma, beta, scale_shift, y, mean, rstd, C, T, groups, eps, silu);
   return check_launch("groupnorm_fwd");
 }
 
@@ -391,10 +529,13 @@ extern "C" int ttts_groupnorm_bwd_f32(const float* dy, const float* x, const flo
   TTTS_REQUIRE(!scale_shift || d_scale_shift, "groupnorm_bwd: d_scale_shift missing");
   float* pg = workspace;                 // [B][C]
   float* pb = workspace + (int64_t)B * C;
-  groupnorm_bwd_kernel<<<B * groups, 256, 0, as_stream(stream)>>>(dy, x, gamma, beta, scale_shift, mean, rstd, dx, pg, pb, d_scale_shift,
-                                                                 C, T, groups, silu);
-  reduce_rows_kernel<<<(int)cdiv(C, 256), 256, 0, as_stream(stream)>>>(pg, dgamma, B, C, accumulate);
-  reduce_rows_kernel<<<(int)cdiv(C, 256), 256, 0, as_stream(stream)>>>(pb, dbeta, B, C, accumulate);
+  if (T <= 64 * GN_BW && C / groups <= 4 * GN_BC)
+    groupnorm_bwd_reg_kernel<<<B * groups, 256, 0, as_stream(stream)>>>(dy, x, gamma, beta, scale_shift, mean, rstd, dx, pg, pb,
+                                                                       d_scale_shift, C, T, groups, silu);
+  else
+    groupnorm_bwd_kernel<<<B * groups, 256, 0, as_stream(stream)>>>(dy, x, gamma, beta, scale_shift, mean, rstd, dx, pg, pb, d_scale_shift,
+                                                                   C, T, groups, silu);
+  reduce_rows2_kernel<<<dim3((unsigned)cdiv(C, 256), 2), 256, 0, as_stream(stream)>>>(pg, dgamma, pb, dbeta, B, C, accumulate);
   return check_launch("groupnorm_bwd");
 }
 
