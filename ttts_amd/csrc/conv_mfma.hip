@@ -2268,6 +2268,107 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad_fused_taps_kernel(WgradMf
   }
 }
 
+// ---- 1 x 1 weight gradients of wide layers in ONE pass (round 6) ------------------------------------------------------------------
+// dw[co][ci] = sum_{b, t} dy[b][co][t] x[b][ci][t]: a GEMM whose reduction runs along the rows' contiguous axis.  Wide layers (more than
+// 128 x 128 channels: the WaveNet res / skip layers, the attention projections, the diffusion model's 512 / 1536-row linear layers;
+// ~170 calls per VQ-VAE-GAN step, ~65 per diffusion step) took wgrad_split_pair_kernel (a full pass over both operands: fp32 read,
+// bf16 hi / lo write) + the pre-split all-taps kernel with one tap (hi / lo read): 13 + 10 us at the WN shape, 18 + 26 us for the
+// diffusion qkv layer.  Here a workgroup owns a 64 x 64 tile of dw, reads the fp32 rows of both operands once per 128-position chunk
+// (float4 requests, the next chunk in flight under the current one's MFMAs), applies the fused leaky-relus, splits into bf16 hi / lo on
+// the way into LDS and accumulates lo.hi + hi.lo + hi.hi per 16-position k-step (2 x 2 waves of 32 x 32).  Split-K over chunks with
+// per-split slabs exactly like the other weight-gradient kernels (deferred, ordered reduce); the bias gradient rides along as row
+// sums of dy.  Needs Lout % 4 == 0 (16-byte row pieces).
+constexpr int W1_CH = 128, W1_PITCH = W1_CH + 8;
+__global__ __launch_bounds__(256, 2) void conv1x1_wgrad_fused_kernel(WgradMfmaParams p) {
+  __shared__ __attribute__((aligned(16))) bf16 sm[4 * 64 * W1_PITCH];
+  bf16* ah = sm; bf16* al = sm + 64 * W1_PITCH; bf16* bh = sm + 2 * 64 * W1_PITCH; bf16* bl = sm + 3 * 64 * W1_PITCH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, col = lane & 31;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64, split = blockIdx.z;
+  const int L = p.Lout, nlc = (L + W1_CH - 1) / W1_CH, nchunks = p.B * nlc;
+  // staging map: 8 requests per operand and thread; request i covers row (tid >> 5) + 8 i, positions 4 (tid & 31) .. + 3 of the chunk
+  const int srow = tid >> 5, st = (tid & 31) * 4;
+  float4 ra[8], rb[8];
+  float bsum[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) bsum[i] = 0.f;
+  auto request = [&](int chunk) {
+    const int b = chunk / nlc, l = (chunk - b * nlc) * W1_CH + st;
+    const int lc = min(l, L - 4);                                   // (clamped: a piece past the row end is requested in range, zeroed below)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = srow + 8 * i;
+      ra[i] = *reinterpret_cast<const float4*>(p.dy + ((int64_t)b * p.Cout + min(co0 + r, p.Cout - 1)) * L + lc);
+      rb[i] = *reinterpret_cast<const float4*>(p.x + ((int64_t)b * p.Cin + min(ci0 + r, p.Cin - 1)) * L + lc);
+    }
+  };
+  auto split4 = [](const float4 v, float slope, bf16* hi, bf16* lo) {
+    const float e0 = lrelu_f(v.x, slope), e1 = lrelu_f(v.y, slope), e2 = lrelu_f(v.z, slope), e3 = lrelu_f(v.w, slope);
+    bf16x4 h, w;
+    h[0] = (bf16)e0; h[1] = (bf16)e1; h[2] = (bf16)e2; h[3] = (bf16)e3;
+    w[0] = (bf16)(e0 - (float)h[0]); w[1] = (bf16)(e1 - (float)h[1]); w[2] = (bf16)(e2 - (float)h[2]); w[3] = (bf16)(e3 - (float)h[3]);
+    *reinterpret_cast<bf16x4*>(hi) = h;
+    *reinterpret_cast<bf16x4*>(lo) = w;
+  };
+  auto deposit = [&](int chunk) {
+    const int b = chunk / nlc, l = (chunk - b * nlc) * W1_CH + st;
+    const bool tok = l < L;                                          // (L % 4 == 0: a piece is inside the row or past its end)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = srow + 8 * i;
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 a = (tok && co0 + r < p.Cout) ? ra[i] : z, bq = (tok && ci0 + r < p.Cin) ? rb[i] : z;
+      bsum[i] += (a.x + a.y) + (a.z + a.w);
+      split4(a, p.dy_slope, ah + r * W1_PITCH + st, al + r * W1_PITCH + st);
+      split4(bq, p.x_slope, bh + r * W1_PITCH + st, bl + r * W1_PITCH + st);
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int chunk0 = split * p.chunks_per_block;
+  const int nmine = max(0, min(p.chunks_per_block, nchunks - chunk0));
+  const bf16* arow_h = ah + (wm * 32 + col) * W1_PITCH + hh * 8;
+  const bf16* arow_l = al + (wm * 32 + col) * W1_PITCH + hh * 8;
+  const bf16* brow_h = bh + (wn * 32 + col) * W1_PITCH + hh * 8;
+  const bf16* brow_l = bl + (wn * 32 + col) * W1_PITCH + hh * 8;
+  if (nmine > 0) request(chunk0);
+  for (int cc = 0; cc < nmine; ++cc) {
+    __syncthreads();                                       // everyone is done reading the previous chunk
+    deposit(chunk0 + cc);
+    __syncthreads();
+    if (cc + 1 < nmine) request(chunk0 + cc + 1);          // in flight while the matrix cores run
+#pragma unroll
+    for (int ks = 0; ks < W1_CH / 16; ++ks) {
+      const bf16x8 a_h = *reinterpret_cast<const bf16x8*>(arow_h + ks * 16), a_l = *reinterpret_cast<const bf16x8*>(arow_l + ks * 16);
+      const bf16x8 b_h = *reinterpret_cast<const bf16x8*>(brow_h + ks * 16), b_l = *reinterpret_cast<const bf16x8*>(brow_l + ks * 16);
+      acc = mfma32(a_l, b_h, acc);
+      acc = mfma32(a_h, b_l, acc);
+      acc = mfma32(a_h, b_h, acc);
+    }
+  }
+  if (p.bslab && blockIdx.x == 0) {
+    // bias gradient: row sums of dy seen by this split (a row's 32 staging lanes are one half-wave)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float v = bsum[i];
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      const int r = srow + 8 * i;
+      if ((lane & 31) == 0 && co0 + r < p.Cout) p.bslab[(int64_t)split * p.Cout + co0 + r] = v;
+    }
+  }
+  const int ci = ci0 + wn * 32 + col;
+  if (ci < p.Cin) {
+    float* sl = p.slab + (int64_t)split * p.Cout * p.Cin;          // [split][co][ci], summed by the slab reduce
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int co = co0 + wm * 32 + acc_row(i, hh);
+      if (co < p.Cout) sl[(int64_t)co * p.Cin + ci] = acc[i];
+    }
+  }
+}
+
 // dw[co][ci][k] += sum_split slab[split][k][co][ci]
 __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsplit,
                                                                 int K, int Cout, int Cin, const float* __restrict__ bslab,
@@ -2565,6 +2666,32 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, f
       if (db) *db_done = true;
       *handled = true;
       return check_launch("conv1d_wgrad_fused_taps");
+    }
+  }
+  if (K == 1 && stride == 1 && pad == 0 && wide_c && Lout == Lin && Lout % 4 == 0 && Lout >= 48 && !(cx.flags & (16384 | 2048)) &&
+      cdiv(Cin, 64) * cdiv(Cout, 64) <= 56 &&
+      (reinterpret_cast<uintptr_t>(dy) & 15u) == 0 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0) {
+    // one pass over the fp32 operands (conv1x1_wgrad_fused_kernel; flag 2048: the pre-pass + pre-split kernel instead).  Up to 56
+    // tiles: the WaveNet / attention-projection / 1025 -> 192 layers (WN res|skip 34.0 -> 24.8 us, 1025 -> 192 62.6 -> 46.9 us); the
+    // diffusion model's 512 .. 1536-row layers (64 .. 192 tiles, each operand row re-read by 8 .. 24 tiles) measured level with the
+    // pre-split path, whose LDS-DMA kernel re-reads half-size copies: 16.1 vs 15.9 ms per step, left there
+    const int nlc = (int)cdiv(Lout, W1_CH), nchunks = B * nlc;
+    const int tiles = (int)(cdiv(Cin, 64) * cdiv(Cout, 64));
+    const int splits = (int)std::max<int64_t>(1, std::min<int64_t>(nchunks, cdiv(wg_target, tiles)));
+    const int cpb = (int)cdiv(nchunks, splits), nsplit = (int)cdiv(nchunks, cpb);
+    const int64_t slab_bytes = (int64_t)nsplit * ((int64_t)Cout * Cin + Cout) * (int64_t)sizeof(float);
+    if (slab_bytes <= cx.ws_bytes) {
+      float* slab = static_cast<float*>(cx.ws);
+      float* bslab = db ? slab + (int64_t)nsplit * Cout * Cin : nullptr;
+      float* pb = nullptr;
+      float* ps = slab_defer(cx, dw, db, db != nullptr, nsplit, 1, Cout, Cin, stream, &pb);     // (persistent slabs: reduce deferred)
+      if (ps) { slab = ps; bslab = pb; }
+      WgradMfmaParams p{dy, x, dw, B, Cin, Lin, Cout, Lout, 1, 1, 0, 1, dy_slope, x_slope, cpb, slab, 64, bslab};
+      conv1x1_wgrad_fused_kernel<<<dim3((unsigned)cdiv(Cin, 64), (unsigned)cdiv(Cout, 64), (unsigned)nsplit), 256, 0, stream>>>(p);
+      if (!ps) wgrad_slab_reduce_kernel<<<dim3((unsigned)std::min<int64_t>(cdiv((int64_t)Cout * Cin, 256), 4096), (unsigned)cdiv(nsplit, SLAB_G)), 256, 0, stream>>>(slab, dw, nsplit, 1, Cout, Cin, bslab, db);
+      if (db) *db_done = true;
+      *handled = true;
+      return check_launch("conv1x1_wgrad_fused");
     }
   }
   if (taps) {
