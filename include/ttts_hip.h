@@ -663,6 +663,10 @@ int ttts_add4_scale_f32(const float* a, const float* b, const float* c, const fl
 int ttts_gate_fwd_f32(const float* x, float* y, int32_t B, int32_t H, int32_t T, int32_t kind, void* stream);
 int ttts_gate_bwd_f32(const float* dy, const float* x, float* dx, int32_t B, int32_t H, int32_t T, int32_t kind,
                       void* stream);
+/* (v11 addition) gate_bwd that also writes rowsum f32 [B, 2H] = sum_t dx[b][c][t]: the conditioning gradient of a WaveNet layer
+ * (ttts/vqvae/modules.py:194-201: g_l is added to x_in before the gate, so d g_l = sum over t of d x_in) without a second pass. */
+int ttts_gate_bwd_rowsum_f32(const float* dy, const float* x, float* dx, float* rowsum, int32_t B, int32_t H, int32_t T,
+                             int32_t kind, void* stream);
 int ttts_mul_mask_f32(const float* x, const float* mask, float* y, int32_t B, int32_t C, int32_t T, void* stream);
 int ttts_gauss_sample_fwd_f32(const float* stats, const float* eps, const float* mask, float* z, int32_t B, int32_t C,
                               int32_t T, void* stream);

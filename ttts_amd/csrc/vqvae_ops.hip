@@ -44,6 +44,41 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
   }
 }
 
+// gate_bwd + the per-(sample, channel) sums of dx over t (round 6: the WaveNet layers' conditioning gradient d g[b][c] = sum_t
+// d x_in[b][c][t] was a separate pass over dx -- 12 288 one-row workgroups, 16 us -- behind every gate_bwd of a conditioned stack).
+// One wave per (b, r): its a-row and g-row of dy / x, the two row sums by wave reduction -> rowsum[b][2H] (plain stores, fixed order).
+__global__ __launch_bounds__(256) void gate_bwd_rowsum_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                              float* __restrict__ dx, float* __restrict__ rowsum, int B, int H,
+                                                              int T, int kind) {
+  const int lane = threadIdx.x & 63;
+  const int64_t pair = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pair >= (int64_t)B * H) return;                      // (whole waves)
+  const int64_t b = pair / H, r = pair % H;
+  const float* xa = x + (b * 2 * H + r) * T;
+  const float* xg = xa + (int64_t)H * T;
+  const float* d = dy + (b * H + r) * T;
+  float* da = dx + (b * 2 * H + r) * T;
+  float* dg = da + (int64_t)H * T;
+  float sa = 0.f, sg = 0.f;
+  for (int t = lane; t < T; t += 64) {
+    const float a = xa[t], g = xg[t], dv = d[t];
+    const float s = sigmoidf_(g);
+    float va, vg;
+    if (kind == 0) {
+      const float th = tanhf(a);
+      va = dv * s * (1.f - th * th);
+      vg = dv * th * s * (1.f - s);
+    } else {
+      va = dv * s;
+      vg = dv * a * s * (1.f - s);
+    }
+    da[t] = va; dg[t] = vg;
+    sa += va; sg += vg;
+  }
+  sa = wave_sum(sa); sg = wave_sum(sg);
+  if (lane == 0) { rowsum[b * 2 * H + r] = sa; rowsum[b * 2 * H + H + r] = sg; }
+}
+
 // y[b][c][t] = x[b][c][t] * m[b][t]
 __global__ __launch_bounds__(256) void mul_mask_kernel(const float* __restrict__ x, const float* __restrict__ m,
                                                        float* __restrict__ y, int B, int C, int T) {
@@ -457,6 +492,12 @@ extern "C" int ttts_gate_bwd_f32(const float* dy, const float* x, float* dx, int
   TTTS_REQUIRE(dy && x && dx && B > 0 && H > 0 && T > 0 && (kind == 0 || kind == 1), "gate_bwd: bad arguments");
   gate_bwd_kernel<<<grid_for((int64_t)B * H * T), 256, 0, as_stream(stream)>>>(dy, x, dx, B, H, T, kind);
   return check_launch("gate_bwd");
+}
+extern "C" int ttts_gate_bwd_rowsum_f32(const float* dy, const float* x, float* dx, float* rowsum, int32_t B, int32_t H, int32_t T,
+                                        int32_t kind, void* stream) {
+  TTTS_REQUIRE(dy && x && dx && rowsum && B > 0 && H > 0 && T > 0 && (kind == 0 || kind == 1), "gate_bwd_rowsum: bad arguments");
+  gate_bwd_rowsum_kernel<<<(unsigned)cdiv((int64_t)B * H, 4), 256, 0, as_stream(stream)>>>(dy, x, dx, rowsum, B, H, T, kind);
+  return check_launch("gate_bwd_rowsum");
 }
 extern "C" int ttts_mul_mask_f32(const float* x, const float* mask, float* y, int32_t B, int32_t C, int32_t T, void* stream) {
   TTTS_REQUIRE(x && mask && y && B > 0 && C > 0 && T > 0, "mul_mask: bad arguments");

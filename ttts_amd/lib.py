@@ -232,6 +232,7 @@ SIGNATURES = {
     "ttts_add4_scale_f32": (_I32, [_P, _P, _P, _P, _F, _P, _I64, _P]),
     "ttts_gate_fwd_f32": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _P]),
     "ttts_gate_bwd_f32": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "ttts_gate_bwd_rowsum_f32": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "ttts_mul_mask_f32": (_I32, [_P, _P, _P, _I32, _I32, _I32, _P]),
     "ttts_gauss_sample_fwd_f32": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _P]),
     "ttts_gauss_sample_bwd_f32": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),

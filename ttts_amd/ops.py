@@ -1254,10 +1254,15 @@ def gate_fwd(x, kind=GATE_TANH_SIGMOID):
     return y
 
 
-def gate_bwd(dy, x, kind=GATE_TANH_SIGMOID):
+def gate_bwd(dy, x, kind=GATE_TANH_SIGMOID, rowsum=None):
+    """rowsum (f32, B * 2H elements, contiguous): also receives sum_t dx[b][c][t] (written, not accumulated)."""
     dy = _f32c(dy, "dy"); x = _f32c(x, "x")
     B, C2, T = x.shape
     dx = torch.empty_like(x)
+    if rowsum is not None:
+        assert rowsum.is_contiguous() and rowsum.numel() == B * C2 and rowsum.dtype == torch.float32
+        check(_l.get().ttts_gate_bwd_rowsum_f32(_p(dy), _p(x), _p(dx), _p(rowsum), B, C2 // 2, T, kind, _stream()), "gate_bwd_rowsum")
+        return dx
     check(_l.get().ttts_gate_bwd_f32(_p(dy), _p(x), _p(dx), B, C2 // 2, T, kind, _stream()), "gate_bwd")
     return dx
 

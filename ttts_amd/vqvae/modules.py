@@ -877,9 +877,9 @@ class _WNFn(torch.autograd.Function):
         dsk = ops.mul_mask(dout, m2) if m2 is not None else dout
         dres = None
         pgrads = [None] * (6 * n_layers)
-        # the conditioning gradients of all layers accumulate into rows of ONE cleared buffer (a zero-filled temporary per layer + a
-        # concatenation were 17 launches per stack)
-        dg_all = torch.zeros(n_layers, B * 2 * H, dtype=dout.dtype, device=dout.device) if has_g else None
+        # the conditioning gradients of all layers land in rows of ONE buffer (a zero-filled temporary + a bias-gradient launch per
+        # layer and a concatenation were 33 launches per stack)
+        dg_all = torch.empty(n_layers, B * 2 * H, dtype=dout.dtype, device=dout.device) if has_g else None
         for i in reversed(range(n_layers)):
             xi, x_in, acts, w_in, n_in, w_rs, n_rs = saved[7 * i:7 * i + 7]
             in_v, in_g, in_b, rs_v, rs_g, rs_b = params[6 * i:6 * i + 6]
@@ -908,9 +908,8 @@ class _WNFn(torch.autograd.Function):
                 db_t = slots[5] if direct else torch.zeros_like(rs_b)
                 ops.conv1d_wgrad(dsk, acts, 1, out=dw_rs, db=db_t)
                 db_rs = None if direct else db_t
-            dx_in = ops.gate_bwd(dacts, x_in, ops.GATE_TANH_SIGMOID)
-            if has_g:
-                ops.conv1d_bias_grad(dx_in.view(1, B * 2 * H, T), out=dg_all[i])
+            # (the conditioning gradient d g_l[b][c] = sum_t d x_in rides on the gate's backward: one launch)
+            dx_in = ops.gate_bwd(dacts, x_in, ops.GATE_TANH_SIGMOID, rowsum=dg_all[i] if has_g else None)
             db_in = slots[2] if direct else torch.zeros_like(in_b)
             dw_in = ops.conv1d_wgrad(dx_in, xi, K, 1, pad, dil, db=db_in, out=pre[0])
             dres = ops.conv1d_dgrad(dx_in, w_in, T, 1, pad, dil, resid=dres, omask=m2 if i > 0 else None)
