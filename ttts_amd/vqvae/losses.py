@@ -56,13 +56,38 @@ def l1_loss(target, pred):
     return _mean_term(t, p, ops.RED_ABSDIFF)
 
 
+class _SumOfTerms(torch.autograd.Function):
+    """sum_i scale_i * sum term(a_i, b_i) accumulated into ONE device scalar (`reduce_loss(..., accumulate=True)`), gradient to every
+    b_i.  The feature loss is 36 such terms: as 36 autograd nodes it also cost 36 scalar `add` launches, 36 AddBackward nodes and a
+    final `* 2`; here the factor is folded into the scales.  inputs = (a_0, b_0, a_1, b_1, ...)."""
+
+    @staticmethod
+    def forward(ctx, scales, *ab):
+        ctx.scales = scales
+        ctx.save_for_backward(*ab)
+        out = torch.zeros(1, dtype=torch.float32, device=ab[0].device)
+        for i, sc in enumerate(scales):
+            ops.reduce_loss(ab[2 * i], ab[2 * i + 1], ops.RED_ABSDIFF, sc, out=out, accumulate=True)
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        ab = ctx.saved_tensors
+        g = gout.contiguous().view(1).float()
+        grads = [None]
+        for i, sc in enumerate(ctx.scales):
+            grads += [None, ops.reduce_loss_bwd(ab[2 * i], ab[2 * i + 1], ops.RED_ABSDIFF, sc, g)]
+        return tuple(grads)
+
+
 def feature_loss(fmap_r, fmap_g):
-    loss = 0
+    terms, scales = [], []
     for dr, dg in zip(fmap_r, fmap_g):
         for rl, gl in zip(dr, dg):
             r, g = _pair_dense(rl.float().detach(), gl.float())
-            loss = loss + _mean_term(r, g, ops.RED_ABSDIFF)
-    return loss * 2
+            terms += [_aligned(r), _aligned(g)]
+            scales.append(2.0 / r.numel())
+    return _SumOfTerms.apply(tuple(scales), *terms)
 
 
 def discriminator_loss(disc_real_outputs, disc_generated_outputs):
