@@ -1246,31 +1246,48 @@ __global__ __launch_bounds__(256, 3) void conv1x1_b3_kernel(ConvMfmaParams p) {
   const int j0 = blockIdx.x * NTL, m0 = blockIdx.y * (TALL ? 128 : 64), b = blockIdx.z;
   const int nblk = (p.N + 15) / 16, nchunk = (p.N + KC - 1) / KC;
   const float* xb = p.x + (int64_t)b * p.N * p.Lin;
-  const int sn = tid & 63, sk = tid >> 6;                                       // staging: position, first 8-channel group (+4 per round)
+  // staging: position sn, first 8-channel group sk (+4 per round).  sk is the WAVE index, made scalar: a row's base address
+  // (channel x Lin) is then SALU arithmetic and the 32 requests of a chunk share ONE vector offset (the position).  PMC at the
+  // diffusion qkv shape before (r6aj): 2 782 VALU instructions per wave around 192 MFMAs -- 14.5 per MFMA, a SIMD's VALU + MFMA issue
+  // time 93 % of the waves' life -- most of them per-request 64-bit address arithmetic, clamps and selects of the staging below.
+  const int sn = tid & 63, sk = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int spos = min(j0 + sn, p.Lin - 1);
   const bool sok = j0 + sn < p.Lin;
+  const bool tile_in = j0 + NTL <= p.Lin;                                       // workgroup-uniform: every position of the tile exists
+  const bool plain_in = p.in_slope == 1.f;                                      // uniform: no leaky-relu on the input
   float raw[4][8];
   auto load_chunk = [&](int c0) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-      const int ch0 = c0 + (it * 4 + sk) * 8;
+      const int ch0 = c0 + (it * 4 + sk) * 8;                                   // scalar
 #pragma unroll
-      for (int e = 0; e < 8; ++e) raw[it][e] = xb[(int64_t)min(ch0 + e, p.N - 1) * p.Lin + spos];   // clamped loads, selected below
+      for (int e = 0; e < 8; ++e)                                               // clamped (scalar) row, selected below
+        raw[it][e] = (xb + (int64_t)min(ch0 + e, p.N - 1) * p.Lin)[spos];
     }
   };
   unsigned ev = 0;
   auto store_chunk = [&](int c0) {
+    const bool all_in = tile_in && c0 + KC <= p.N;                              // (uniform) nothing to select
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int k8 = it * 4 + sk, ch0 = c0 + k8 * 8;
       bf16x8 h, l;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = raw[it][e];
+      if (!all_in) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (sok && ch0 + e < p.N) ? v[e] : 0.f;
+      }
+      if (!plain_in) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = lrelu_f(v[e], p.in_slope);
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float v = (sok && ch0 + e < p.N) ? raw[it][e] : 0.f;
-        v = lrelu_f(v, p.in_slope);
-        const bf16 hv = F16 ? f16_slot_ev(v, ev) : (bf16)v;
+        const bf16 hv = F16 ? f16_slot_ev(v[e], ev) : (bf16)v[e];
         h[e] = hv;
-        l[e] = (bf16)(v - (float)hv);
+        l[e] = (bf16)(v[e] - (float)hv);
       }
       *reinterpret_cast<bf16x8*>(&xs[0][k8][sn][0]) = h;
       if (!F16) *reinterpret_cast<bf16x8*>(&xs[1][k8][sn][0]) = l;
