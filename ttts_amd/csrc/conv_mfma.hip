@@ -1237,7 +1237,8 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_mfma_kernel(WgradMfmaParams 
 // four waves stacked along M, each 32 rows x BOTH 32-position blocks.  Every output-channel tile re-splits the x tile it shares with the
 // other M / tile-rows workgroups (VALU : MFMA cycles ~1.7 : 1 at 64 rows, whatever M is): twice the rows halve that, and a weight
 // fragment feeds two MFMA triples instead of one.  Same products in the same order per output element: bit-identical to the 64-row form.
-template <bool F16, bool TALL = false>
+// FULLK: N % 128 == 0 (every chunk has all eight k-steps): the k-steps of a chunk are ONE straight-line block.
+template <bool F16, bool TALL = false, bool FULLK = false>
 __global__ __launch_bounds__(256, 3) void conv1x1_b3_kernel(ConvMfmaParams p) {
   constexpr int KC = 128, NTL = 64, NCB = TALL ? 2 : 1;
   __shared__ __attribute__((aligned(16))) bf16 xs[2][KC / 8][NTL][8];          // [hi | lo][8-channel group][position][8]: 32 KB
@@ -1310,13 +1311,32 @@ __global__ __launch_bounds__(256, 3) void conv1x1_b3_kernel(ConvMfmaParams p) {
       ah[ks] = *reinterpret_cast<const bf16x8*>(ahp + kb * astep);
       if (!F16) al[ks] = *reinterpret_cast<const bf16x8*>(alp + kb * astep);
     }
+    // (pinned here: the compiler sank these 16 requests to the front of the MFMA loop -- vmcnt(14), (12), ... (0) in front of every
+    // k-step, i.e. the whole L2 round trip exposed once per chunk instead of flying under the conversion and the two barriers)
+    __builtin_amdgcn_sched_barrier(0);
     if (c) __syncthreads();                                                     // the previous chunk's fragments have been read
     store_chunk(c * KC);
     __syncthreads();
-    if (c + 1 < nchunk) load_chunk((c + 1) * KC);
-#pragma unroll
-    for (int ks = 0; ks < KC / 16; ++ks) {
-      if (c * (KC / 16) + ks < nblk) {                                          // workgroup-uniform
+    // UNCONDITIONAL (the last chunk re-requests itself, unused): behind `if (c + 1 < nchunk)` the two paths met in front of the MFMAs
+    // and the compiler's wait-count merge took the stricter one -- s_waitcnt vmcnt(14) for the first weight fragment, which drains
+    // the 32 requests just issued for the next chunk: nothing flew under the MFMAs (ISA read, round 6)
+    load_chunk(min(c + 1, nchunk - 1) * KC);
+    __builtin_amdgcn_sched_barrier(0);      // (and they stay in front of the MFMAs: in the 128-row form they had been sunk behind them)
+    auto kstep = [&](int ks) {
+      if constexpr (TALL && !F16) {
+        // the two position blocks' products interleaved (consecutive MFMAs on different accumulators, each accumulator's own order
+        // unchanged -- as b3_mma does)
+        const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(&xs[0][2 * ks + hh][col][0]);
+        const bf16x8 bh1 = *reinterpret_cast<const bf16x8*>(&xs[0][2 * ks + hh][32 + col][0]);
+        const bf16x8 bl0 = *reinterpret_cast<const bf16x8*>(&xs[1][2 * ks + hh][col][0]);
+        const bf16x8 bl1 = *reinterpret_cast<const bf16x8*>(&xs[1][2 * ks + hh][32 + col][0]);
+        acc[0] = mfma32(al[ks], bh0, acc[0]);
+        acc[NCB - 1] = mfma32(al[ks], bh1, acc[NCB - 1]);
+        acc[0] = mfma32(ah[ks], bl0, acc[0]);
+        acc[NCB - 1] = mfma32(ah[ks], bl1, acc[NCB - 1]);
+        acc[0] = mfma32(ah[ks], bh0, acc[0]);
+        acc[NCB - 1] = mfma32(ah[ks], bh1, acc[NCB - 1]);
+      } else {
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
           const int pc = (TALL ? cb : wn) * 32 + col;
@@ -1331,6 +1351,18 @@ __global__ __launch_bounds__(256, 3) void conv1x1_b3_kernel(ConvMfmaParams p) {
           }
         }
       }
+    };
+    // A whole chunk runs as ONE straight-line block.  With a (workgroup-uniform) `if (block < nblk)` around every k-step each k-step
+    // was its own basic block and the compiler's wait-count bookkeeping merged conservatively at every block entry: s_waitcnt
+    // vmcnt(14) in front of the first MFMA of a chunk -- i.e. "all but 14 requests done", which drains the NEXT chunk's 32 input
+    // requests that had just been issued to fly under these MFMAs (ISA read, round 6).
+    if constexpr (FULLK) {
+#pragma unroll
+      for (int ks = 0; ks < KC / 16; ++ks) kstep(ks);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < KC / 16; ++ks)
+        if (c * (KC / 16) + ks < nblk) kstep(ks);                                // workgroup-uniform
     }
   }
   if (F16) f16_events_commit(ev);
@@ -1365,10 +1397,13 @@ static int conv1x1_b3_launch(ConvMfmaParams p, const ConvCtx& cx, hipStream_t st
   // 128-row tiles for the wide layers (flag 1024: off); the 192 / 384-row WaveNet layers keep 64 rows -- they need the workgroups
   const bool tall = p.M % 128 == 0 && p.M >= 512 && !(cx.flags & 1024);
   const dim3 grid((unsigned)cdiv(p.Lout, 64), (unsigned)(p.Mpad / (tall ? 128 : 64)), (unsigned)p.B);
+  const bool fullk = p.N % 128 == 0;
   if (tall) {
     if (f16) conv1x1_b3_kernel<true, true><<<grid, 256, 0, stream>>>(p);
+    else if (fullk) conv1x1_b3_kernel<false, true, true><<<grid, 256, 0, stream>>>(p);
     else conv1x1_b3_kernel<false, true><<<grid, 256, 0, stream>>>(p);
   } else if (f16) conv1x1_b3_kernel<true><<<grid, 256, 0, stream>>>(p);
+  else if (fullk) conv1x1_b3_kernel<false, false, true><<<grid, 256, 0, stream>>>(p);
   else conv1x1_b3_kernel<false><<<grid, 256, 0, stream>>>(p);
   *handled = true;
   return check_launch("conv1x1_b3");
