@@ -359,6 +359,18 @@ __global__ __launch_bounds__(256) void relattn_dbias_finish_kernel(RelAttnParams
   for (int i = tid; i < 2 * Tp; i += 256) {
     float s = 0.f;
     int r = 0;
+    // (32 requests in flight, then 8: with 16 workgroups on the chip the kernel is a chain of dependent round trips -- 14 per column
+    // group at 8 in flight, 23 us for a 0.7-MB reduction; the sums are formed in the same order)
+    for (; r + 32 <= rows; r += 32) {
+      float v[32];
+#pragma unroll
+      for (int e = 0; e < 32; ++e) {
+        const int rr = r + e, b = rr / p.nqt, qt = rr - b * p.nqt;
+        v[e] = p.part[((int64_t)(b * p.H + h) * p.nqt + qt) * 2 * Tp + i];
+      }
+#pragma unroll
+      for (int e = 0; e < 32; ++e) s += v[e];
+    }
     for (; r + 8 <= rows; r += 8) {
       float v[8];
 #pragma unroll
