@@ -2228,6 +2228,10 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad_fused_taps_kernel(WgradMf
   for (int i = 0; i < NA; ++i) bsum[i] = 0.f;
   // (unconditional loads from clamped addresses + a select: a guarded load compiles to an exec-masked branch with its own
   // s_waitcnt, which serialised the 48 loads of a chunk -- 11 us per chunk)
+  // Requests only: the values are masked when they are deposited (mask_regs, one chunk later).  Round 6, ISA read (tools/isa_scan.py):
+  // with the select `(rok && l < Lout) ? v0 : 0` right behind each request pair the compiler waited for every PAIR before issuing
+  // the next in six instantiations (<7, 1, 128>, <7, 3, 128>, <3, *, 64>, <11, 1, 64>): 17 dependent round trips per chunk where one
+  // was meant to fly under the MFMAs -- the RB1(128) k7 weight gradient spent ~50 of its 62 us in them.
   auto load_regs = [&](int chunk) {
     const int b = chunk / nlc, l0 = (chunk % nlc) * CH;
     // (<11, 1, 128> and <11, 5, 64> spill 8 / 9 VGPRs: the per-thread row / offset tables of the 17 request pairs are computed once
@@ -2238,19 +2242,32 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad_fused_taps_kernel(WgradMf
     for (int i = 0; i < NA; ++i) {
       const int q = tid + 256 * i, row = q / (CH / 2), l = l0 + (q % (CH / 2)) * 2;
       const float* src = p.dy + ((int64_t)b * p.Cout + min(co0 + row, p.Cout - 1)) * p.Lout;
-      const bool rok = co0 + row < p.Cout;
-      const float v0 = src[min(l, p.Lout - 1)], v1 = src[min(l + 1, p.Lout - 1)];
-      ra[i][0] = (rok && l < p.Lout) ? v0 : 0.f;
-      ra[i][1] = (rok && l + 1 < p.Lout) ? v1 : 0.f;
+      ra[i][0] = src[min(l, p.Lout - 1)];
+      ra[i][1] = src[min(l + 1, p.Lout - 1)];
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int q = tid + 256 * i, row = q / WPR, g = l0 - p.pad + (q - row * WPR) * 2;
       const float* src = p.x + ((int64_t)b * p.Cin + min(ci0 + min(row, 31), p.Cin - 1)) * p.Lin;
+      rb[i][0] = src[min(max(g, 0), p.Lin - 1)];
+      rb[i][1] = src[min(max(g + 1, 0), p.Lin - 1)];
+    }
+  };
+  auto mask_regs = [&](int chunk) {                           // the selects of the chunk whose requests load_regs issued
+    const int l0 = (chunk % nlc) * CH;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int q = tid + 256 * i, row = q / (CH / 2), l = l0 + (q % (CH / 2)) * 2;
+      const bool rok = co0 + row < p.Cout;
+      ra[i][0] = (rok && l < p.Lout) ? ra[i][0] : 0.f;
+      ra[i][1] = (rok && l + 1 < p.Lout) ? ra[i][1] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int q = tid + 256 * i, row = q / WPR, g = l0 - p.pad + (q - row * WPR) * 2;
       const bool rok = row < 32 && ci0 + row < p.Cin;
-      const float v0 = src[min(max(g, 0), p.Lin - 1)], v1 = src[min(max(g + 1, 0), p.Lin - 1)];
-      rb[i][0] = (rok && g >= 0 && g < p.Lin) ? v0 : 0.f;
-      rb[i][1] = (rok && g + 1 >= 0 && g + 1 < p.Lin) ? v1 : 0.f;
+      rb[i][0] = (rok && g >= 0 && g < p.Lin) ? rb[i][0] : 0.f;
+      rb[i][1] = (rok && g + 1 >= 0 && g + 1 < p.Lin) ? rb[i][1] : 0.f;
     }
   };
   auto split2 = [](float v0, float v1, bf16x2& h, bf16x2& l) {
@@ -2284,9 +2301,11 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad_fused_taps_kernel(WgradMf
   if (nmine > 0) load_regs(chunk0);
   for (int cc = 0; cc < nmine; ++cc) {
     __syncthreads();                                       // everyone is done reading the previous chunk
+    mask_regs(chunk0 + cc);
     store_lds(chunk0 + cc);
     __syncthreads();
     if (cc + 1 < nmine) load_regs(chunk0 + cc + 1);        // in flight while the matrix cores run
+    __builtin_amdgcn_sched_barrier(0);                     // (the requests stay in front of the MFMAs)
     if (wv == 0) fused_taps_compute<K, DIL, 0, CH>(ah, al, bh, bl, col, hh, acc);
     else if (wv == 1) fused_taps_compute<K, DIL, 1, CH>(ah, al, bh, bl, col, hh, acc);
     else if (wv == 2) fused_taps_compute<K, DIL, 2, CH>(ah, al, bh, bl, col, hh, acc);
