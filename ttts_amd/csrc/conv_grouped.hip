@@ -48,11 +48,19 @@ __global__ __launch_bounds__(256) void conv1d_grouped_fwd_mfma_kernel(GroupedPar
   const int ci0 = (co0 / cog) * cig;
   const int in0 = l0 * S - p.pad;
   const float* xb = p.x + ((int64_t)b * CinT + ci0) * p.Lin;
+  // (requests of a batch first, selects and LDS stores after: see the weight-gradient kernel below)
   for (int c = wave; c < nci; c += 4) {
     const float* xr = xb + (int64_t)c * p.Lin;
-    for (int u = lane; u < S * IP; u += 64) {
-      const int g = in0 + u;
-      xs[(c * S + u % S) * IP + u / S] = (g >= 0 && g < p.Lin) ? g_lrelu(xr[min(max(g, 0), p.Lin - 1)], p.in_slope) : 0.f;
+    const int nu = S * IP;
+    for (int u0 = lane; u0 < nu; u0 += 64 * 8) {
+      float t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] = xr[min(max(in0 + u0 + 64 * j, 0), p.Lin - 1)];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int u = u0 + 64 * j, g = in0 + u;
+        if (u < nu) xs[(c * S + u % S) * IP + u / S] = (g >= 0 && g < p.Lin) ? g_lrelu(t[j], p.in_slope) : 0.f;
+      }
     }
   }
   for (int i = tid; i < R4 * 16; i += 256) {
@@ -115,9 +123,15 @@ __global__ __launch_bounds__(256) void conv1d_grouped_dgrad_mfma_kernel(GroupedP
   const float* dyb = p.x + ((int64_t)b * CoutT + grp * cog) * p.Lout;
   for (int c = wave; c < cog; c += 4) {
     const float* dr = dyb + (int64_t)c * p.Lout;
-    for (int v = lane; v < TP; v += 64) {
-      const int l = lbase + v;
-      ds[c * TPp + v] = (l >= 0 && l < p.Lout) ? g_lrelu(dr[min(max(l, 0), p.Lout - 1)], p.in_slope) : 0.f;
+    for (int v0 = lane; v0 < TP; v0 += 64 * 8) {
+      float t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] = dr[min(max(lbase + v0 + 64 * j, 0), p.Lout - 1)];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int v = v0 + 64 * j, l = lbase + v;
+        if (v < TP) ds[c * TPp + v] = (l >= 0 && l < p.Lout) ? g_lrelu(t[j], p.in_slope) : 0.f;
+      }
     }
   }
   for (int i = tid; i < R4 * 16; i += 256) {
@@ -192,19 +206,33 @@ __global__ __launch_bounds__(256) void conv1d_grouped_wgrad_mfma_kernel(const fl
     if (chunk >= nchunks) break;
     const int b = chunk / nlc, l0 = (chunk % nlc) * GW_LC, in0 = l0 * S - pad;
     __syncthreads();
+    // staging: the requests of a batch first (unconditional, clamped), selects and LDS stores after.  Round 6 (tools/isa_scan.py): as
+    // `lds[..] = ok ? lrelu(row[..]) : 0` per element the compiler waited for every single request before the next -- a wave's ~70
+    // row pieces per chunk were 70 dependent round trips (333 us for the k41 layer).  Same values: bit-identical.
     for (int c = wave; c < 16; c += 4) {
       const bool cok = co0 + c < CoutT;
       const float* dr = dy + ((int64_t)b * CoutT + min(co0 + c, CoutT - 1)) * Lout;
-      for (int v = lane; v < GW_LC; v += 64) {
-        const int l = l0 + v;
-        dys[c * DP + v] = (cok && l < Lout) ? g_lrelu(dr[min(l, Lout - 1)], dy_slope) : 0.f;
+      float t[GW_LC / 64];
+#pragma unroll
+      for (int j = 0; j < GW_LC / 64; ++j) t[j] = dr[min(l0 + lane + 64 * j, Lout - 1)];
+#pragma unroll
+      for (int j = 0; j < GW_LC / 64; ++j) {
+        const int v = lane + 64 * j, l = l0 + v;
+        dys[c * DP + v] = (cok && l < Lout) ? g_lrelu(t[j], dy_slope) : 0.f;
       }
     }
     for (int c = wave; c < nci; c += 4) {
       const float* xr = x + ((int64_t)b * CinT + ci0 + c) * Lin;
-      for (int u = lane; u < S * IP0; u += 64) {
-        const int g = in0 + u;
-        xs[(c * S + u % S) * IP + u / S] = (g >= 0 && g < Lin) ? g_lrelu(xr[min(max(g, 0), Lin - 1)], x_slope) : 0.f;
+      const int nu = S * IP0;
+      for (int u0 = lane; u0 < nu; u0 += 64 * 8) {
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = xr[min(max(in0 + u0 + 64 * j, 0), Lin - 1)];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int u = u0 + 64 * j, g = in0 + u;
+          if (u < nu) xs[(c * S + u % S) * IP + u / S] = (g >= 0 && g < Lin) ? g_lrelu(t[j], x_slope) : 0.f;
+        }
       }
     }
     __syncthreads();

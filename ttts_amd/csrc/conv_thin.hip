@@ -160,8 +160,31 @@ __global__ __launch_bounds__(256) void conv1d_cout1_fwd_kernel(const float* __re
   }
   float acc = 0.f;
   const float* xb = x + (int64_t)b * Cin * Lin;
-#pragma unroll 4
-  for (int ci = cg; ci < Cin; ci += 16) {
+  // Requests of FOUR channels (4 K taps + 4 K weights) first, arithmetic after.  Round 6 (tools/isa_scan.py): as `v = xr[gi[k]];
+  // acc = fmaf(w, ok ? lrelu(v) : 0, acc)` the compiler waited for every pair of requests before issuing the next -- a thread's 64
+  // channels x K taps were 100+ dependent round trips (62 us for a 66-MB read).  Same fmaf chain in the same order: bit-identical.
+  constexpr int CU = 4;
+  int ci = cg;
+  for (; ci + 16 * (CU - 1) < Cin; ci += 16 * CU) {
+    float xv[CU][TO_KMAX], wv[CU][TO_KMAX];
+#pragma unroll
+    for (int u = 0; u < CU; ++u) {
+      const float* xr = xb + (int64_t)(ci + 16 * u) * Lin;
+      const float* wr = w + (int64_t)(ci + 16 * u) * K;
+#pragma unroll
+      for (int k = 0; k < TO_KMAX; ++k) {
+        if (k < K) { xv[u][k] = xr[gi[k]]; wv[u][k] = wr[k]; }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < CU; ++u) {
+#pragma unroll
+      for (int k = 0; k < TO_KMAX; ++k) {
+        if (k < K) acc = fmaf(wv[u][k], gok[k] ? thin_lrelu(xv[u][k], in_slope) : 0.f, acc);
+      }
+    }
+  }
+  for (; ci < Cin; ci += 16) {
     const float* xr = xb + (int64_t)ci * Lin;
     const float* wr = w + (int64_t)ci * K;
 #pragma unroll
