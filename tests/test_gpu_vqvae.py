@@ -1336,6 +1336,52 @@ def test_second_cache_or_arena_over_the_same_array_is_refused():
 
 
 @pytest.mark.bf16x3
+@pytest.mark.parametrize("case", [(32, 192, 384, 256), (4, 1025, 192, 256), (3, 200, 130, 100), (2, 192, 192, 52), (5, 384, 192, 1000),
+                                  (2, 512, 512, 400)])
+def test_conv1x1_weight_gradient_one_pass_vs_presplit_path(case):
+    """conv1x1_wgrad_fused_kernel (round 6: 1 x 1 weight gradients of wide layers with up to 56 output tiles in ONE pass over the fp32
+    operands) against the pre-pass + pre-split kernel it replaces (variant flag 2048) and against the fp64 product: ragged channel
+    counts, row lengths that are not multiples of the 128-position chunk, fused leaky-relus, the bias gradient, accumulation into an
+    existing dw.  The last case has 64 tiles: it stays on the pre-split path either way (both runs equal)."""
+    from ttts_amd import ops
+    B, cin, cout, L = case
+    g = torch.Generator().manual_seed(cin * 3 + L)
+    x = torch.randn(B, cin, L, generator=g).to(_dev()); dy = torch.randn(B, cout, L, generator=g).to(_dev())
+    dw0 = torch.randn(cout, cin, 1, generator=g).to(_dev())
+
+    def run():
+        a = ops.conv1d_wgrad(dy, x, 1)
+        db = torch.zeros(cout, device=_dev())
+        b = ops.conv1d_wgrad(dy, x, 1, x_slope=0.1, out=dw0.clone(), db=db)
+        return a, b, db
+    new = run()
+    ops.set_variant_flags(2048)
+    try:
+        old = run()
+    finally:
+        ops.set_variant_flags(0)
+    ref = torch.einsum("bot,bit->oi", dy.double().cpu(), x.double().cpu()).unsqueeze(-1)
+    ref2 = dw0.double().cpu() + torch.einsum("bot,bit->oi", dy.double().cpu(), F.leaky_relu(x.double().cpu(), 0.1)).unsqueeze(-1)
+    for got, tag in ((new, "one pass"), (old, "pre-split")):
+        _close(got[0], ref, 2e-5, 0, tag + " dw")
+        _close(got[1], ref2, 2e-5, 0, tag + " dw (x_slope, accumulate)")
+        _close(got[2], dy.double().cpu().sum((0, 2)), 1e-5, 1e-4, tag + " db")
+
+
+def test_gate_bwd_with_row_sums_equals_gate_bwd_plus_reduction():
+    """ttts_gate_bwd_rowsum_f32 (round 6): the same dx as ttts_gate_bwd_f32, bit for bit, and rowsum[b][c] = sum_t dx[b][c][t]."""
+    from ttts_amd import ops
+    g = torch.Generator().manual_seed(77)
+    for B, H, T, kind in ((3, 20, 77, ops.GATE_TANH_SIGMOID), (2, 192, 256, ops.GATE_TANH_SIGMOID), (2, 7, 130, ops.GATE_GLU)):
+        x = torch.randn(B, 2 * H, T, generator=g).to(_dev()); dy = torch.randn(B, H, T, generator=g).to(_dev())
+        rs = torch.full((B * 2 * H,), 7.0, device=_dev())
+        a = ops.gate_bwd(dy, x, kind)
+        b = ops.gate_bwd(dy, x, kind, rowsum=rs)
+        assert torch.equal(a, b)
+        _close(rs.view(B, 2 * H), a.double().sum(-1), 1e-6, 1e-5, "row sums")
+
+
+@pytest.mark.bf16x3
 @pytest.mark.parametrize("case", [(32, 192, 384, 256), (16, 512, 1536, 400), (4, 1025, 192, 256), (3, 100, 512, 77), (2, 192, 192, 50),
                                   (1, 40, 72, 333), (5, 384, 192, 1000)])
 @pytest.mark.parametrize("mode", ["split_bf16", "tf32class"])
