@@ -851,11 +851,17 @@ __global__ __launch_bounds__(256, b3_min_waves(WCO, KT)) void conv1d_bf16x3_kern
   // are re-read by every workgroup -- 45 KB per stage at K = 11, 460 MB of L2 -> LDS traffic per RB1(128) launch against 42 MB of
   // input -- and were two more synchronous round trips per stage)
   // (K = 5 / 7 at 64 rows: no register room at three resident waves -- -DTTTS_B3_WPF_ALL gives them the prefetch at two waves)
+  // K = 5 at 64 rows (no register room to hold chunks across the MFMAs at three resident waves): its first chunks are requested at
+  // the TOP of the stage, in front of the barrier -- they fly under the barrier wait and the strip's conversion, when the fragment
+  // registers are dead (W_TOP)
 #ifdef TTTS_B3_WPF_ALL
   constexpr int WG0 = KT == 0 ? 0 : WCO == 2 ? WCH : WCH < 3 ? WCH : 3;
+  constexpr bool W_AHEAD = true;
 #else
-  constexpr int WG0 = KT == 0 ? 0 : WCO == 2 ? ((KT == 11 || KT <= 3) ? WCH : 0) : WCH < 3 ? WCH : 3;
+  constexpr bool W_AHEAD = WCO == 2 && (KT == 11 || KT <= 3);
+  constexpr int WG0 = KT == 0 ? 0 : WCO == 2 ? (W_AHEAD ? WCH : KT == 5 ? 3 : 0) : WCH < 3 ? WCH : 3;
 #endif
+  constexpr bool W_TOP = PF && !W_AHEAD && KT == 5;   // (K = 7: 13 spilled registers with the requests above the barrier)
   bf16x8 wh0[WG0 > 0 ? WG0 : 1], wl0[WG0 > 0 ? WG0 : 1];
   auto request_w = [&](int nb) {
     const bf16* gh = p.a_hi + nb * slab + (int64_t)m0 * K * 16 + tid * 8;
@@ -869,10 +875,12 @@ __global__ __launch_bounds__(256, b3_min_waves(WCO, KT)) void conv1d_bf16x3_kern
       }
     }
   };
-  if (PF) { request(0); request_w(0); }
+  if (PF) { request(0); if (W_AHEAD) request_w(0); }
   for (int nb = 0; nb < nblk; ++nb) {
+    if (W_TOP) request_w(nb);
     __syncthreads();
-    if (!PF) { request(nb); request_w(nb); }
+    if (!PF) request(nb);
+    if (!W_AHEAD && !W_TOP) request_w(nb);
     const bf16* gh = p.a_hi + nb * slab + (int64_t)m0 * K * 16 + tid * 8;
     const bf16* gl = p.a_lo + nb * slab + (int64_t)m0 * K * 16 + tid * 8;
     // this stage's strip: requested one stage ago
@@ -935,7 +943,7 @@ __global__ __launch_bounds__(256, b3_min_waves(WCO, KT)) void conv1d_bf16x3_kern
       }
     }
     __syncthreads();
-    if (PF && nb + 1 < nblk) { request(nb + 1); request_w(nb + 1); }   // in flight under this stage's MFMAs
+    if (PF && nb + 1 < nblk) { request(nb + 1); if (W_AHEAD) request_w(nb + 1); }   // in flight under this stage's MFMAs
     b3_stage<1, KT, F16>(xh, xl, ah, al, arow, bpos0, bpos1, K, p.dil * 8, acc);
   }
   if (F16) f16_events_commit(ev);
