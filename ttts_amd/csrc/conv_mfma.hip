@@ -656,6 +656,11 @@ __device__ __forceinline__ void b3_mma(const B3Frag<CW>& f, f32x16 (&acc)[CW][2]
 template <int CW, int KT, bool F16 = false, typename Piece>
 __device__ __forceinline__ void b3_stage_pipe(const bf16* xh, const bf16* xl, const bf16* ah, const bf16* al, const int (&arow)[CW],
                                               int bpos0, int bpos1, int dil8, f32x16 (&acc)[CW][2], Piece&& piece) {
+#ifdef TTTS_EXP_NO_MFMA                                     // (what-bounds-it build: the stage's DMA slots without its arithmetic)
+#pragma unroll
+  for (int s = 0; s < 3 * KT; ++s) piece(s);
+  return;
+#endif
   B3Frag<CW> f[2];
   b3_load<CW, F16>(f[0], xh, xl, ah, al, arow, bpos0, bpos1, 0, dil8);
   __builtin_amdgcn_sched_barrier(0);       // (tap 0's reads stay ahead of tap 1's: the first wait is then counted too)
@@ -1018,6 +1023,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
   // group instead of counting, which defeats the fragment pipeline; the protocol is the stage-top vmcnt(0) + barrier below.
   const uint32_t lds0 = lds_byte_addr(smem);
   auto issue_piece = [&](int st_i, int buf, int i) {
+#ifdef TTTS_EXP_NO_DMA                                      // (what-bounds-it build: only stage 0 is ever filled; results are wrong)
+    if (st_i > 0) return;
+#endif
     const uint32_t st = lds0 + (uint32_t)(buf * STAGE) * (uint32_t)sizeof(bf16);
     const int nb0 = st_i * NBS;
     if (i < XC) {
@@ -1059,6 +1067,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
   for (int si = 0; si < nstage; ++si) {
     // stage si has landed (every wave drains its own DMA before the barrier) and nobody still reads the other buffer
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef TTTS_EXP_NO_BARRIER
+    if (si == 0)
+#endif
     __syncthreads();
     const bf16* sb = smem + (si & 1) * STAGE;
     constexpr bool PIPE = b3_pipe<CW, KT>();
@@ -1070,7 +1081,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         if (more) {
 #pragma unroll
           for (int i = 0; i < NPIECE; ++i)
+#ifdef TTTS_EXP_FRONT
+            if (i / TTTS_EXP_FRONT == slot) issue_piece(si + 1, (si + 1) & 1, i);
+#else
             if (i % NSLOT == slot) issue_piece(si + 1, (si + 1) & 1, i);
+#endif
         }
       });
       for (int blk = 1; blk < NBS; ++blk) {
