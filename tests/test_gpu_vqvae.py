@@ -1368,6 +1368,38 @@ def test_conv1x1_weight_gradient_one_pass_vs_presplit_path(case):
         _close(got[2], dy.double().cpu().sum((0, 2)), 1e-5, 1e-4, tag + " db")
 
 
+@pytest.mark.parametrize("case", [(24, 512, 256, 253, 5, 3, 2), (40, 256, 128, 111, 5, 3, 2), (56, 192, 64, 69, 5, 3, 2),
+                                  (12, 128, 96, 153, 7, 3, 3), (3, 256, 64, 1000, 5, 3, 2)])
+def test_strided_data_gradient_short_rows_as_one_virtual_row(case):
+    """Phase-merged stride-3 data gradients with short rows (DiscriminatorP: 23 .. 127 positions per phase): the batch laid end to end
+    as one virtual row (round 6; it used to fold power-of-two segments: 85 of 128 positions used at period 3) against the segment
+    form (variant flag 524288) -- the same taps in the same order, so bit for bit -- and against the fp64 transposed convolution;
+    with a leaky-relu gate and accumulation into dx as well (the epilogue that does not go through LDS).  The last case has long rows:
+    no folding either way."""
+    from ttts_amd import ops
+    B, cin, cout, L, K, S, pad = case
+    g = torch.Generator().manual_seed(cin + L)
+    lout = ops.conv_out_len(L, K, S, pad, 1)
+    dy = torch.randn(B, cout, lout, generator=g).to(_dev())
+    w = (torch.randn(cout, cin, K, generator=g) * 0.05).to(_dev())
+    xg = torch.randn(B, cin, L, generator=g).to(_dev())
+
+    def run():
+        return ops.conv1d_dgrad(dy, w, L, S, pad, 1), ops.conv1d_dgrad(dy, w, L, S, pad, 1, gate=xg, gate_slope=0.1)
+    new = run()
+    ops.set_variant_flags(524288)
+    try:
+        old = run()
+    finally:
+        ops.set_variant_flags(0)
+    assert torch.equal(new[0], old[0]), float((new[0] - old[0]).abs().max())
+    assert torch.equal(new[1], old[1]), float((new[1] - old[1]).abs().max())
+    ref = F.conv_transpose1d(dy.double().cpu(), w.double().cpu(), stride=S, padding=pad,
+                             output_padding=L - ((lout - 1) * S - 2 * pad + K))
+    _close(new[0], ref, 2e-5, 0, "dx")
+    _close(new[1], ref * torch.where(xg.double().cpu() > 0, 1.0, 0.1), 2e-5, 0, "dx (gate)")
+
+
 def test_gate_bwd_with_row_sums_equals_gate_bwd_plus_reduction():
     """ttts_gate_bwd_rowsum_f32 (round 6): the same dx as ttts_gate_bwd_f32, bit for bit, and rowsum[b][c] = sum_t dx[b][c][t]."""
     from ttts_amd import ops

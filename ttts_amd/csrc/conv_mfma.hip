@@ -1124,8 +1124,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
       for (int e = tid; e < span; e += 256) {
         const int jl = e / S, r = e - jl * S, ml = c * S + r - m0;
         if (ml < 0 || ml >= MT) continue;                    // (this channel's other phases belong to the neighbouring row tile)
-        const int b = b0 + jl / SEG, jt = j0 + jl % SEG, jj = jt * S + r;
-        if (b >= p.B || jt >= p.Lout || jj >= p.LoutTotal) continue;
+        int b = b0 + jl / SEG, jt = j0 + jl % SEG;
+        if (b >= p.B || jt >= p.Lout) continue;
+        if (p.catLg) {                                       // virtual row -> (batch element, position)
+          b = jt / p.catLg; jt -= b * p.catLg;
+          if (jt >= p.catLout) continue;
+        }
+        const int jj = jt * S + r;
+        if (jj >= p.LoutTotal) continue;
         const float v = (tile[ml * LTP + jl] + (p.bias ? p.bias[c] : 0.f)) * p.out_scale;
         p.y[((int64_t)b * nch + c) * p.LoutTotal + jj] = v;
       }
@@ -1511,7 +1517,10 @@ static int conv1d_bf16x3_dma_launch(ConvMfmaParams p, const ConvCtx& cx, hipStre
   // of a 64-position segment), lay the whole batch end to end as one virtual row with zero gaps wide enough for the taps
   // (flag 134217728: keep the segment folding)
   int cat_w = 0, cat_b = 0, cat_l = 0;
-  if (!p.x_hi && p.B > 1 && p.SEG <= 128 && p.out_stride == 1 && p.out_off == 0 && p.LoutTotal == p.Lout && p.rowS == 0 && !(cx.flags & 134217728)) {
+  // (round 6: the phase-merged strided data gradients too -- their rows are the ceil(L / stride) positions of a phase, 85 of a
+  // 128-position segment for DiscriminatorP's period 3; flag 524288: segments for them as before)
+  const bool cat_rows = p.rowS == 0 ? p.LoutTotal == p.Lout : (p.rowS > 0 && p.stride == 1 && !(cx.flags & 524288));
+  if (!p.x_hi && p.B > 1 && p.SEG <= 128 && p.out_stride == 1 && p.out_off == 0 && cat_rows && !(cx.flags & 134217728)) {
     const int S = p.stride;
     const int reach = std::max(std::max(p.pad, S * (p.Lout - 1) - p.pad + (p.K - 1) * p.dil - (p.Lin - 1)), 0);
     const int Lg = std::max(p.Lout, (int)cdiv(p.Lin + reach, S));
