@@ -541,7 +541,8 @@ typedef struct ttts_conv_ctx {
  * target of 256 / 1024 workgroups instead of 512, 1 small 1 x 1 weight gradients on the exact kernel, 2 phase-merged forward at
  * stride 3 too -- every one of them measured and left off (HISTORY.md 17.3); round 6: 512 switches conv1x1_b3_kernel (1 x 1
  * convolutions without the operand pre-pass: ON by default) off, 1024 its 128-row tiles for wide layers (M % 128 == 0, M >= 512),
- * 2048 the one-pass 1 x 1 weight gradient (conv1x1_wgrad_fused_kernel) */
+ * 2048 the one-pass 1 x 1 weight gradient (conv1x1_wgrad_fused_kernel), 524288 power-of-two segments instead of one virtual row
+ * for the short rows of phase-merged strided data gradients */
 int ttts_conv1d_fwd_f32(const float* x, const float* w, const float* bias, const float* bbias, const float* resid,
                         const float* gate, const float* omask, float* y, int32_t B, int32_t Cin, int32_t Lin, int32_t Cout, int32_t Lout,
                         int32_t K, int32_t stride, int32_t pad, int32_t dil, int32_t groups, float in_slope,
