@@ -102,6 +102,14 @@ __device__ __forceinline__ int xcd_order(int bid, int nblk) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
+// logical (x, y, z) of this workgroup of a 3-D grid, x fastest, through xcd_order: an XCD's L2 then sees a contiguous run of tiles
+// instead of every eighth one (operands shared by neighbouring tiles are fetched from the fabric once, not once per XCD)
+__device__ __forceinline__ void xcd_tile(int& x, int& y, int& z) {
+  const int gx = gridDim.x, gy = gridDim.y;
+  const int lin = xcd_order(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), gx * gy * gridDim.z);
+  x = lin % gx; y = (lin / gx) % gy; z = lin / (gx * gy);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

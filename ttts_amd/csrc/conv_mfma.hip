@@ -773,7 +773,14 @@ __global__ __launch_bounds__(256, b3_min_waves(WCO, KT)) void conv1d_bf16x3_kern
   bf16* al = ah + MT * apitch;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, col = lane & 31;
   const int wco = wave % WCO, wl = wave / WCO;
+  // (output-channel tile fastest, XCD-contiguous: the one or two workgroups over the same input strip share an L2, and so do
+  // neighbouring strips' halos)
+#ifdef TTTS_EXP_NO_XCD_OTF
   const int j0 = blockIdx.x * LT, m0 = blockIdx.y * MT, b0 = blockIdx.z * nseg;
+#else
+  const int lin_b = xcd_order(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);
+  const int j0 = ((lin_b / gridDim.y) % gridDim.x) * LT, m0 = (lin_b % gridDim.y) * MT, b0 = (lin_b / (gridDim.y * gridDim.x)) * nseg;
+#endif
   const int in0 = j0 * p.stride - p.pad;
   f32x16 acc[1][2];
 #pragma unroll
@@ -1182,7 +1189,9 @@ constexpr int WM_L = 64;
 __global__ __launch_bounds__(256) void conv1d_wgrad_mfma_kernel(WgradMfmaParams p) {
   extern __shared__ __attribute__((aligned(16))) float cm_smem[];
   const int NK = p.Cin * p.K;
-  const int n0 = blockIdx.x * 64, co0 = blockIdx.y * 64;
+  int bx_, by_, bz_;
+  xcd_tile(bx_, by_, bz_);
+  const int n0 = bx_ * 64, co0 = by_ * 64;
   const int ci_first = n0 / p.K, ci_last = min(p.Cin - 1, (n0 + 63) / p.K), nch = ci_last - ci_first + 1;
   const int SEGW = p.SEGW, nsg = WM_L / SEGW;
   const int lin_s = (SEGW - 1) * p.stride + (p.K - 1) * p.dil + 1;      // input strip of one segment
@@ -1202,7 +1211,7 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_mfma_kernel(WgradMfmaParams 
   const int nsl = (p.Lout + SEGW - 1) / SEGW;          // segments per batch element
   const int nsegs = p.B * nsl;                          // segments in all
   for (int cc = 0; cc < p.chunks_per_block; ++cc) {
-    const int chunk = blockIdx.z * p.chunks_per_block + cc;
+    const int chunk = bz_ * p.chunks_per_block + cc;
     if (chunk * nsg >= nsegs) break;
     __syncthreads();
     {
@@ -1234,7 +1243,7 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_mfma_kernel(WgradMfmaParams 
     }
   }
   if (ncol_ok) {
-    float* sl = p.slab ? p.slab + (int64_t)blockIdx.z * p.Cout * NK : nullptr;
+    float* sl = p.slab ? p.slab + (int64_t)bz_ * p.Cout * NK : nullptr;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + wco * 32 + acc_row(r, hh);
@@ -1273,7 +1282,12 @@ __global__ __launch_bounds__(256, 3) void conv1x1_b3_kernel(ConvMfmaParams p) {
   __shared__ __attribute__((aligned(16))) bf16 xs[2][KC / 8][NTL][8];          // [hi | lo][8-channel group][position][8]: 32 KB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, col = lane & 31;
   const int wm = TALL ? wave : (wave & 1), wn = TALL ? 0 : (wave >> 1);
-  const int j0 = blockIdx.x * NTL, m0 = blockIdx.y * (TALL ? 128 : 64), b = blockIdx.z;
+  // tile order: output-channel tile fastest, dealt to the XCDs in contiguous runs (xcd_order) -- the M / 64 (128) workgroups that read
+  // one input tile then share an L2.  (Round-robin order: every XCD fetched every input tile -- the diffusion step's 208 launches
+  // read 18.6 GB from the fabric for ~3 GB of operands, profiles/r06_diffusion_pmc_traffic.json)
+  const int lin_b = xcd_order(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x * gridDim.y * gridDim.z);
+  const int by_ = lin_b % gridDim.y, bx_ = (lin_b / gridDim.y) % gridDim.x, bz_ = lin_b / (gridDim.y * gridDim.x);
+  const int j0 = bx_ * NTL, m0 = by_ * (TALL ? 128 : 64), b = bz_;
   const int nblk = (p.N + 15) / 16, nchunk = (p.N + KC - 1) / KC;
   const float* xb = p.x + (int64_t)b * p.N * p.Lin;
   // staging: position sn, first 8-channel group sk (+4 per round).  sk is the WAVE index, made scalar: a row's base address
@@ -2086,7 +2100,9 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad_bf16x3_taps_kernel(WgradB
   extern __shared__ __attribute__((aligned(16))) float cm_smem[];
   bf16* sm = reinterpret_cast<bf16*>(cm_smem);             // 2 stages
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, col = lane & 31;
-  const int ci0 = blockIdx.x * TILE, co0 = blockIdx.y * TILE, split = blockIdx.z;
+  int bx_, by_, bz_;
+  xcd_tile(bx_, by_, bz_);      // (the tiles of one split read the same positions of dy and x: one XCD walks them)
+  const int ci0 = bx_ * TILE, co0 = by_ * TILE, split = bz_;
   const int wco = TILE == 64 ? (wave & 1) : 0, wci = TILE == 64 ? (wave >> 1) : 0;
   f32x16 acc[KN];
 #pragma unroll
@@ -2248,7 +2264,9 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad_fused_taps_kernel(WgradMf
   __shared__ __attribute__((aligned(16))) bf16 sm[2 * 32 * PITCH + 2 * 32 * WP];
   bf16* ah = sm; bf16* al = sm + 32 * PITCH; bf16* bh = sm + 2 * 32 * PITCH; bf16* bl = bh + 32 * WP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, col = lane & 31;
-  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32, split = blockIdx.z;
+  int bx_, by_, bz_;
+  xcd_tile(bx_, by_, bz_);
+  const int ci0 = bx_ * 32, co0 = by_ * 32, split = bz_;
   const int nlc = (p.Lout + CH - 1) / CH, nchunks = p.B * nlc;
   f32x16 acc[3];
 #pragma unroll
@@ -2343,7 +2361,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad_fused_taps_kernel(WgradMf
     else if (wv == 2) fused_taps_compute<K, DIL, 2, CH>(ah, al, bh, bl, col, hh, acc);
     else fused_taps_compute<K, DIL, 3, CH>(ah, al, bh, bl, col, hh, acc);
   }
-  if (p.bslab && blockIdx.x == 0) {
+  if (p.bslab && bx_ == 0) {
     // bias gradient: row sums of dy seen by this split (a row of the tile belongs to one wave, or half-wave at CH = 64)
     constexpr int RL = CH == 128 ? 64 : 32;                // lanes per row
 #pragma unroll
@@ -2387,7 +2405,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_wgrad_fused_kernel(WgradMfmaPa
   bf16* ah = sm; bf16* al = sm + 64 * W1_PITCH; bf16* bh = sm + 2 * 64 * W1_PITCH; bf16* bl = sm + 3 * 64 * W1_PITCH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, col = lane & 31;
   const int wm = wave & 1, wn = wave >> 1;
-  const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64, split = blockIdx.z;
+  int bx_, by_, bz_;
+  xcd_tile(bx_, by_, bz_);
+  const int ci0 = bx_ * 64, co0 = by_ * 64, split = bz_;
   const int L = p.Lout, nlc = (L + W1_CH - 1) / W1_CH, nchunks = p.B * nlc;
   // staging map: 8 requests per operand and thread; request i covers row (tid >> 5) + 8 i, positions 4 (tid & 31) .. + 3 of the chunk
   const int srow = tid >> 5, st = (tid & 31) * 4;
@@ -2450,7 +2470,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_wgrad_fused_kernel(WgradMfmaPa
       acc = mfma32(a_h, b_h, acc);
     }
   }
-  if (p.bslab && blockIdx.x == 0) {
+  if (p.bslab && bx_ == 0) {
     // bias gradient: row sums of dy seen by this split (a row's 32 staging lanes are one half-wave)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
