@@ -186,8 +186,10 @@ __global__ __launch_bounds__(256, 2) void fp8_gemm_nt_kernel(Fp8GemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, hh = lane >> 5;
-  const int go = blockIdx.z / p.ksplit, part = blockIdx.z - go * p.ksplit;
-  const int mt0 = blockIdx.y * TM, nt0 = blockIdx.x * TN;
+  int bx_, by_, bz_;
+  xcd_tile(bx_, by_, bz_);            // (an XCD walks a contiguous run of tiles: the A panel of a row of tiles is fetched into ONE L2)
+  const int go = bz_ / p.ksplit, part = bz_ - go * p.ksplit;
+  const int mt0 = by_ * TM, nt0 = bx_ * TN;
   const int gi_per = (p.GI + p.ksplit - 1) / p.ksplit;
   const int gi0 = part * gi_per, gi1 = min(p.GI, gi0 + gi_per);
   const uint8_t* Ag = p.A + go * p.a_so;
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void fp8_gemm_nt_kernel(Fp8GemmParams p) {
 
   const int m0 = mt0 + wm * 32 * BM, n0 = nt0 + wn * 64;
   if (p.ksplit > 1) {                 // partial sums, unscaled, plain [M][N] layout
-    float* S = p.slab + (int64_t)blockIdx.z * p.M * p.N;
+    float* S = p.slab + (int64_t)bz_ * p.M * p.N;
 #pragma unroll
     for (int bm = 0; bm < BM; ++bm)
 #pragma unroll
