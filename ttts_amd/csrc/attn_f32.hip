@@ -30,11 +30,13 @@ constexpr int BG_T = 64, BG_K = 16;
 __global__ __launch_bounds__(256) void bgemm_kernel(BgemmParams p) {
   __shared__ float As[BG_K][BG_T + 4];
   __shared__ float Bs[BG_K][BG_T + 4];
-  const int z = blockIdx.z, zo = z / p.inner, zi = z % p.inner;
+  int bx_, by_, bz_;
+  xcd_tile(bx_, by_, bz_);            // (the tiles of one batch element share its A / B panels: an XCD walks a contiguous run of them)
+  const int z = bz_, zo = z / p.inner, zi = z % p.inner;
   const float* A = p.A + zo * p.a_so + zi * p.a_si;
   const float* B = p.B + zo * p.b_so + zi * p.b_si;
   float* C = p.C + zo * p.c_so + zi * p.c_si;
-  const int m0 = blockIdx.y * BG_T, n0 = blockIdx.x * BG_T;
+  const int m0 = by_ * BG_T, n0 = bx_ * BG_T;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, hh = lane >> 5, col = lane & 31;
   f32x16 acc;
 #pragma unroll
