@@ -2742,6 +2742,10 @@ static void launch_wgrad_taps(const WgradB3Params& p, dim3 grid, int tile, hipSt
   launch_wgrad_taps_t<K, DIL, 64>(p, grid, stream);
 }
 
+#ifndef TTTS_W1_TILES
+#define TTTS_W1_TILES 56      // most (ci, co) tiles for the one-pass 1 x 1 weight gradient (A/B builds: -DTTTS_W1_TILES=n)
+#endif
+
 static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, float* db, bool* db_done, int B, int Cin, int Lin,
                                    int Cout, int Lout, int K, int stride, int pad, int dil, float dy_slope, float x_slope,
                                    const ConvCtx& cx, hipStream_t stream, bool* handled) {
@@ -2792,12 +2796,13 @@ static int conv1d_wgrad_bf16x3_try(const float* dy, const float* x, float* dw, f
     }
   }
   if (K == 1 && stride == 1 && pad == 0 && wide_c && Lout == Lin && Lout % 4 == 0 && Lout >= 48 && !(cx.flags & (16384 | 2048)) &&
-      cdiv(Cin, 64) * cdiv(Cout, 64) <= 56 &&
+      cdiv(Cin, 64) * cdiv(Cout, 64) <= TTTS_W1_TILES &&
       (reinterpret_cast<uintptr_t>(dy) & 15u) == 0 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0) {
     // one pass over the fp32 operands (conv1x1_wgrad_fused_kernel; flag 2048: the pre-pass + pre-split kernel instead).  Up to 56
     // tiles: the WaveNet / attention-projection / 1025 -> 192 layers (WN res|skip 34.0 -> 24.8 us, 1025 -> 192 62.6 -> 46.9 us); the
     // diffusion model's 512 .. 1536-row layers (64 .. 192 tiles, each operand row re-read by 8 .. 24 tiles) measured level with the
-    // pre-split path, whose LDS-DMA kernel re-reads half-size copies: 16.1 vs 15.9 ms per step, left there
+    // pre-split path, whose LDS-DMA kernel re-reads half-size copies: 16.1 vs 15.9 ms per step, left there (re-measured after the
+    // XCD-contiguous tile order, tools/gpu_r6_au.sh: <= 64 tiles 15.08 vs 15.14 ms, all layers 15.45 ms)
     const int nlc = (int)cdiv(Lout, W1_CH), nchunks = B * nlc;
     const int tiles = (int)(cdiv(Cin, 64) * cdiv(Cout, 64));
     const int splits = (int)std::max<int64_t>(1, std::min<int64_t>(nchunks, cdiv(wg_target, tiles)));
